@@ -1,0 +1,58 @@
+// common.hpp -- shared host-side plumbing of libgamut_hip (error strings, streams).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include "../../include/gamut_hip.h"
+
+namespace gamut {
+
+// Thread-local message, same convention as Image._error in the reference
+// (image.d:1563-1570): a zero-terminated C string, never thrown.
+char* last_error_buf();
+int   set_error(int status, const char* fmt, ...);
+inline void clear_error() { last_error_buf()[0] = 0; }
+
+// per-thread default stream (created lazily, non-blocking w.r.t. the null stream)
+hipStream_t thread_stream();
+inline hipStream_t pick_stream(void* s) { return s ? reinterpret_cast<hipStream_t>(s) : thread_stream(); }
+
+#define GAMUT_HIP_CHECK(expr)                                                                 \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess)                                                                \
+            return ::gamut::set_error(GAMUT_HIP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e__)); \
+    } while (0)
+
+inline int launch_status(const char* what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(GAMUT_HIP_ERR_HIP, "%s launch failed: %s", what, hipGetErrorString(e));
+    return GAMUT_HIP_OK;
+}
+
+// PixelType tables (types.d:62-86, internals/types.d:44-96)
+constexpr int kPixelSize[GAMUT_PIXEL_COUNT]     = { 1,2,4, 2,4,8, 2,4,8, 3,6,12, 4,8,16, 4,8,16 };
+constexpr int kPixelChannels[GAMUT_PIXEL_COUNT] = { 1,1,1, 2,2,2, 2,2,2, 3,3,3, 4,4,4, 4,4,4 };
+inline bool valid_type(int t) { return t >= 0 && t < GAMUT_PIXEL_COUNT; }
+
+// kernel launchers implemented in the .hip files
+int convert_device(int srcType, const void* src, int64_t srcPitch, int64_t srcLayerOffset,
+                   int dstType, void* dst, int64_t dstPitch, int64_t dstLayerOffset,
+                   int width, int height, int layers, hipStream_t stream);
+
+int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
+                            const uint8_t* max_zag, int64_t zag_stride,
+                            uint8_t* out, int64_t out_pitch, int64_t out_stride,
+                            int width, int height, int scan_type, int out_comps,
+                            int count, hipStream_t stream);
+
+int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len,
+                        uint8_t* out, int64_t out_stride,
+                        uint32_t x, uint32_t y, int img_n, int out_n, int depth, int color,
+                        int count, hipStream_t stream);
+
+} // namespace gamut

@@ -1,0 +1,418 @@
+// convert.hip -- K8/K9: the PixelType -> PixelType scanline conversion matrix on gfx950.
+//
+// Replaces the row kernels of source/gamut/scanline.d (:139-803) and the
+// drivers scanlinesCopy (:37-55) / scanlinesConvert (:70-121).  The reference
+// converts through an intermediate scanline (rgba8 when both ends are plain
+// 8-bit, else rgbaf32, scanline.d:25-31); here the intermediate pixel lives in
+// registers, so each pixel is read once and written once: the kernel is a pure
+// HBM stream (algorithmic bytes = size(src)+size(dst) per pixel).
+//
+// Arithmetic contract (DESIGN.md "f32 parity"): every binary32 operation is
+// rounded on its own -- built with -ffp-contract=off and written with
+// __fadd_rn/__fmul_rn/__fdiv_rn so no FMA can form; division is the IEEE
+// correctly rounded one (v_div_scale/v_div_fmas/v_div_fixup), never a
+// reciprocal multiply; float->int is x86 cvttss2si (truncate; NaN / out of
+// int32 range -> 0x80000000) followed by taking the low 8/16 bits, which is
+// what `cast(ubyte)(float)` compiles to in the reference's x86-64 build.
+//
+// Work decomposition: one thread converts a "unit" of G pixels, G chosen per
+// type pair so both sides of the unit are whole dwords and the wider side is
+// >= 16 B (one dwordx4 per lane, lane-contiguous => fully coalesced 1 KiB per
+// wave instruction).  Units are distributed grid-stride over <= 8 blocks/CU.
+#include "common.hpp"
+#include <utility>
+
+namespace gamut {
+namespace {
+
+typedef uint32_t u32;
+
+template <int T> struct PT {
+    static constexpr int ch     = kPixelChannels[T];
+    static constexpr int bits   = (T % 3 == 0) ? 8 : (T % 3 == 1) ? 16 : 32;
+    static constexpr int size   = kPixelSize[T];
+    static constexpr bool premul = (T >= GAMUT_PIXEL_lap8 && T <= GAMUT_PIXEL_lapf32) || (T >= GAMUT_PIXEL_rgbap8);
+    // internals/types.d:99-111: only l8, la8, rgb8, rgba8 are "8-bit" for the intermediate choice
+    static constexpr bool plain8 = (T == GAMUT_PIXEL_l8 || T == GAMUT_PIXEL_la8 || T == GAMUT_PIXEL_rgb8 || T == GAMUT_PIXEL_rgba8);
+};
+
+constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
+constexpr int clcm(int a, int b) { return a / cgcd(a, b) * b; }
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int unit_pixels(int s, int d)
+{
+    int g = clcm(4 / cgcd(s, 4), 4 / cgcd(d, 4));
+    while (cmax(g * s, g * d) < 16) g *= 2;
+    return g;
+}
+constexpr int vec_bytes(int unit_bytes) { return unit_bytes % 16 == 0 ? 16 : unit_bytes % 8 == 0 ? 8 : 4; }
+
+// ---- unit load / store -----------------------------------------------------
+template <int BYTES>
+__device__ __forceinline__ void load_unit(const uint8_t* p, u32 (&w)[BYTES / 4])
+{
+    constexpr int V = vec_bytes(BYTES);
+    if constexpr (V == 16) {
+        #pragma unroll
+        for (int i = 0; i < BYTES / 16; ++i) {
+            const uint4 v = reinterpret_cast<const uint4*>(p)[i];
+            w[4*i] = v.x; w[4*i+1] = v.y; w[4*i+2] = v.z; w[4*i+3] = v.w;
+        }
+    } else if constexpr (V == 8) {
+        #pragma unroll
+        for (int i = 0; i < BYTES / 8; ++i) {
+            const uint2 v = reinterpret_cast<const uint2*>(p)[i];
+            w[2*i] = v.x; w[2*i+1] = v.y;
+        }
+    } else {
+        #pragma unroll
+        for (int i = 0; i < BYTES / 4; ++i) w[i] = reinterpret_cast<const u32*>(p)[i];
+    }
+}
+template <int BYTES>
+__device__ __forceinline__ void store_unit(uint8_t* p, const u32 (&w)[BYTES / 4])
+{
+    constexpr int V = vec_bytes(BYTES);
+    if constexpr (V == 16) {
+        #pragma unroll
+        for (int i = 0; i < BYTES / 16; ++i)
+            reinterpret_cast<uint4*>(p)[i] = make_uint4(w[4*i], w[4*i+1], w[4*i+2], w[4*i+3]);
+    } else if constexpr (V == 8) {
+        #pragma unroll
+        for (int i = 0; i < BYTES / 8; ++i) reinterpret_cast<uint2*>(p)[i] = make_uint2(w[2*i], w[2*i+1]);
+    } else {
+        #pragma unroll
+        for (int i = 0; i < BYTES / 4; ++i) reinterpret_cast<u32*>(p)[i] = w[i];
+    }
+}
+
+// ---- component access inside a unit (all indices fold at compile time) ------
+template <int BITS> __device__ __forceinline__ u32 get_comp(const u32* w, int idx)
+{
+    if constexpr (BITS == 8)  return (w[idx >> 2] >> ((idx & 3) * 8)) & 0xFFu;
+    if constexpr (BITS == 16) return (w[idx >> 1] >> ((idx & 1) * 16)) & 0xFFFFu;
+    return w[idx];
+}
+template <int BITS> __device__ __forceinline__ void put_comp(u32* w, int idx, u32 v)
+{
+    if constexpr (BITS == 8)       w[idx >> 2] |= (v & 0xFFu) << ((idx & 3) * 8);
+    else if constexpr (BITS == 16) w[idx >> 1] |= (v & 0xFFFFu) << ((idx & 1) * 16);
+    else                           w[idx] = v;
+}
+
+// x86 cvttss2si
+__device__ __forceinline__ int cvtt(float x)
+{
+    const bool in_range = (x >= -2147483648.0f) && (x < 2147483648.0f);
+    return in_range ? (int)x : (int)0x80000000;
+}
+
+struct RGBAf { float r, g, b, a; };
+struct RGBA8 { u32 r, g, b, a; };
+
+// scanline.d:240-529 ("xxx_to_rgbaf32")
+template <int T> __device__ __forceinline__ RGBAf decode_f32(const u32* w, int p)
+{
+    constexpr int CH = PT<T>::ch, BITS = PT<T>::bits;
+    float c[4];
+    #pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        const u32 raw = get_comp<BITS>(w, p * CH + k);
+        if constexpr (BITS == 8)       c[k] = __fdiv_rn((float)(int)raw, 255.0f);
+        else if constexpr (BITS == 16) c[k] = __fdiv_rn((float)(int)raw, 65535.0f);
+        else                           c[k] = __uint_as_float(raw);
+    }
+    RGBAf o;
+    if constexpr (CH == 1)      { o.r = o.g = o.b = c[0]; o.a = 1.0f; }
+    else if constexpr (CH == 2) { o.r = c[0]; o.a = c[1]; if constexpr (PT<T>::premul) { if (o.a != 0.0f) o.r = __fdiv_rn(o.r, o.a); } o.g = o.b = o.r; }
+    else if constexpr (CH == 3) { o.r = c[0]; o.g = c[1]; o.b = c[2]; o.a = 1.0f; }
+    else {
+        o.r = c[0]; o.g = c[1]; o.b = c[2]; o.a = c[3];
+        if constexpr (PT<T>::premul) { if (o.a != 0.0f) { o.r = __fdiv_rn(o.r, o.a); o.g = __fdiv_rn(o.g, o.a); o.b = __fdiv_rn(o.b, o.a); } }
+    }
+    return o;
+}
+
+// scanline.d:539-803 ("rgbaf32_to_xxx"); evaluation order as written there
+template <int BITS> __device__ __forceinline__ u32 quant(float v)   // cast(T)(0.5f + v)
+{
+    const int i = cvtt(__fadd_rn(0.5f, v));
+    return BITS == 8 ? ((u32)i & 0xFFu) : ((u32)i & 0xFFFFu);
+}
+template <int T> __device__ __forceinline__ void encode_f32(u32* w, int p, const RGBAf& v)
+{
+    constexpr int CH = PT<T>::ch, BITS = PT<T>::bits;
+    constexpr float M = BITS == 8 ? 255.0f : 65535.0f;
+    constexpr bool PRE = PT<T>::premul;
+    if constexpr (CH <= 2) {
+        float s = __fadd_rn(__fadd_rn(v.r, v.g), v.b);            // (r + g + b)
+        if constexpr (PRE) s = __fmul_rn(s, v.a);                 // * a
+        if constexpr (BITS == 32) {
+            put_comp<32>(w, p * CH, __float_as_uint(__fdiv_rn(s, 3.0f)));
+            if constexpr (CH == 2) put_comp<32>(w, p * CH + 1, __float_as_uint(v.a));
+        } else {
+            put_comp<BITS>(w, p * CH, quant<BITS>(__fdiv_rn(__fmul_rn(s, M), 3.0f)));
+            if constexpr (CH == 2) put_comp<BITS>(w, p * CH + 1, quant<BITS>(__fmul_rn(v.a, M)));
+        }
+    } else {
+        float c[4] = { v.r, v.g, v.b, v.a };
+        #pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            float x = c[k];
+            if constexpr (PRE) { if (k < 3) x = __fmul_rn(x, v.a); }
+            if constexpr (BITS == 32) put_comp<32>(w, p * CH + k, __float_as_uint(x));
+            else                      put_comp<BITS>(w, p * CH + k, quant<BITS>(__fmul_rn(x, M)));
+        }
+    }
+}
+
+// scanline.d:160-194 / :201-234 (plain 8-bit types through rgba8; l8 <- R only)
+template <int T> __device__ __forceinline__ RGBA8 decode_u8(const u32* w, int p)
+{
+    constexpr int CH = PT<T>::ch;
+    RGBA8 o;
+    if constexpr (CH == 1)      { o.r = o.g = o.b = get_comp<8>(w, p); o.a = 255; }
+    else if constexpr (CH == 2) { o.r = o.g = o.b = get_comp<8>(w, 2*p); o.a = get_comp<8>(w, 2*p + 1); }
+    else if constexpr (CH == 3) { o.r = get_comp<8>(w, 3*p); o.g = get_comp<8>(w, 3*p+1); o.b = get_comp<8>(w, 3*p+2); o.a = 255; }
+    else                        { o.r = get_comp<8>(w, 4*p); o.g = get_comp<8>(w, 4*p+1); o.b = get_comp<8>(w, 4*p+2); o.a = get_comp<8>(w, 4*p+3); }
+    return o;
+}
+template <int T> __device__ __forceinline__ void encode_u8(u32* w, int p, const RGBA8& v)
+{
+    constexpr int CH = PT<T>::ch;
+    if constexpr (CH == 1)      { put_comp<8>(w, p, v.r); }
+    else if constexpr (CH == 2) { put_comp<8>(w, 2*p, v.r); put_comp<8>(w, 2*p+1, v.a); }
+    else if constexpr (CH == 3) { put_comp<8>(w, 3*p, v.r); put_comp<8>(w, 3*p+1, v.g); put_comp<8>(w, 3*p+2, v.b); }
+    else                        { put_comp<8>(w, 4*p, v.r); put_comp<8>(w, 4*p+1, v.g); put_comp<8>(w, 4*p+2, v.b); put_comp<8>(w, 4*p+3, v.a); }
+}
+
+template <int S, int D, int G>
+__device__ __forceinline__ void convert_unit(const u32* in, u32* out)
+{
+    constexpr int DW = G * PT<D>::size / 4;
+    #pragma unroll
+    for (int i = 0; i < DW; ++i) out[i] = 0;
+    #pragma unroll
+    for (int p = 0; p < G; ++p) {
+        if constexpr (PT<S>::plain8 && PT<D>::plain8) encode_u8<D>(out, p, decode_u8<S>(in, p));
+        else                                            encode_f32<D>(out, p, decode_f32<S>(in, p));
+    }
+}
+
+struct ConvArgs {
+    const uint8_t* src; uint8_t* dst;
+    int64_t srcPitch, srcLayer, dstPitch, dstLayer;
+    int64_t total;          // rows * upr
+    u32 upr;                // units per row incl. the tail unit
+    u32 full_units;         // width / G
+    u32 tail_px;            // width % G
+    u32 height;
+    u32 rows;
+};
+
+// byte-granular single-pixel path (row tails, and everything when alignment forbids vectors)
+template <int S, int D>
+__device__ __forceinline__ void convert_pixel_bytes(const uint8_t* s, uint8_t* d)
+{
+    constexpr int SS = PT<S>::size, DS = PT<D>::size;
+    u32 in[(SS + 3) / 4] = {}, out[(DS + 3) / 4] = {};
+    #pragma unroll
+    for (int i = 0; i < SS; ++i) in[i >> 2] |= (u32)s[i] << ((i & 3) * 8);
+    if constexpr (PT<S>::plain8 && PT<D>::plain8) encode_u8<D>(out, 0, decode_u8<S>(in, 0));
+    else                                            encode_f32<D>(out, 0, decode_f32<S>(in, 0));
+    #pragma unroll
+    for (int i = 0; i < DS; ++i) d[i] = (uint8_t)(out[i >> 2] >> ((i & 3) * 8));
+}
+
+constexpr int kThreads = 256;
+constexpr int kUnroll  = 4;
+
+template <int S, int D>
+__global__ __launch_bounds__(kThreads) void k_convert_vec(ConvArgs a)
+{
+    constexpr int G  = unit_pixels(PT<S>::size, PT<D>::size);
+    constexpr int SB = G * PT<S>::size, DB = G * PT<D>::size;
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t base = (int64_t)blockIdx.x * kThreads + threadIdx.x; base < a.total; base += stride * kUnroll) {
+        u32 in[kUnroll][SB / 4];
+        const uint8_t* sp[kUnroll]; uint8_t* dp[kUnroll];
+        u32 uidx[kUnroll]; bool live[kUnroll];
+        #pragma unroll
+        for (int j = 0; j < kUnroll; ++j) {
+            const int64_t idx = base + j * stride;
+            live[j] = idx < a.total;
+            u32 row = 0, u = (u32)idx;
+            if (a.rows > 1) {
+                row = (a.total <= 0xFFFFFFFFLL) ? (u32)idx / a.upr : (u32)(idx / a.upr);
+                u = (u32)(idx - (int64_t)row * a.upr);
+            }
+            u32 layer = 0, y = row;
+            if (row >= a.height) { layer = row / a.height; y = row - layer * a.height; }
+            sp[j] = a.src + layer * a.srcLayer + (int64_t)y * a.srcPitch + (int64_t)u * SB;
+            dp[j] = a.dst + layer * a.dstLayer + (int64_t)y * a.dstPitch + (int64_t)u * DB;
+            uidx[j] = u;
+            if (live[j] && u < a.full_units) load_unit<SB>(sp[j], in[j]);
+        }
+        #pragma unroll
+        for (int j = 0; j < kUnroll; ++j) {
+            if (!live[j]) continue;
+            if (uidx[j] < a.full_units) {
+                u32 out[DB / 4];
+                convert_unit<S, D, G>(in[j], out);
+                store_unit<DB>(dp[j], out);
+            } else {
+                for (u32 p = 0; p < a.tail_px; ++p)
+                    convert_pixel_bytes<S, D>(sp[j] + p * PT<S>::size, dp[j] + p * PT<D>::size);
+            }
+        }
+    }
+}
+
+// alignment-free fallback: one pixel per thread, byte accesses
+template <int S, int D>
+__global__ __launch_bounds__(kThreads) void k_convert_bytes(ConvArgs a, u32 width)
+{
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    const int64_t total = (int64_t)a.rows * width;
+    for (int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += stride) {
+        const u32 row = (u32)(idx / width), x = (u32)(idx - (int64_t)row * width);
+        const u32 layer = row / a.height, y = row - layer * a.height;
+        convert_pixel_bytes<S, D>(a.src + layer * a.srcLayer + (int64_t)y * a.srcPitch + (int64_t)x * PT<S>::size,
+                                  a.dst + layer * a.dstLayer + (int64_t)y * a.dstPitch + (int64_t)x * PT<D>::size);
+    }
+}
+
+// K9 scanlinesCopy: same type, re-layout only (pitch / v-flip / border)
+__global__ __launch_bounds__(kThreads) void k_copy_rows(ConvArgs a, u32 row_bytes, int vec)
+{
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    const u32 upr = (row_bytes + vec - 1) / vec;
+    const int64_t total = (int64_t)a.rows * upr;
+    for (int64_t idx = (int64_t)blockIdx.x * kThreads + threadIdx.x; idx < total; idx += stride) {
+        const u32 row = (u32)(idx / upr), u = (u32)(idx - (int64_t)row * upr);
+        const u32 layer = row / a.height, y = row - layer * a.height;
+        const uint8_t* s = a.src + layer * a.srcLayer + (int64_t)y * a.srcPitch + (int64_t)u * vec;
+        uint8_t* d = a.dst + layer * a.dstLayer + (int64_t)y * a.dstPitch + (int64_t)u * vec;
+        if (vec == 16 && (u + 1) * 16u <= row_bytes) *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(s);
+        else {
+            const u32 n = min((u32)vec, row_bytes - u * vec);
+            for (u32 i = 0; i < n; ++i) d[i] = s[i];
+        }
+    }
+}
+
+inline int grid_for(int64_t work_items, int device_cus)
+{
+    int64_t blocks = (work_items + kThreads - 1) / kThreads;
+    const int64_t cap = (int64_t)device_cus * 8;     // 8 x 256-thread blocks per CU = 32 waves/CU
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+int device_cus()
+{
+    static thread_local int cus = 0;
+    if (!cus) {
+        int dev = 0; hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+inline bool aligned(const void* p, int64_t pitch, int64_t layer, int rows, int layers, int a)
+{
+    if (((uintptr_t)p) % a) return false;
+    if (rows > 1 && (pitch % a)) return false;
+    if (layers > 1 && (layer % a)) return false;
+    return true;
+}
+
+template <int S, int D>
+int launch_pair(ConvArgs a, int width, int height, int layers, hipStream_t stream)
+{
+    constexpr int G  = unit_pixels(PT<S>::size, PT<D>::size);
+    constexpr int SB = G * PT<S>::size, DB = G * PT<D>::size;
+    // collapse gapless top-down storage into one long row (the common case: decoder outputs,
+    // LAYOUT_GAPLESS images) so only the base pointers need alignment
+    int64_t w = width; int rows = height * layers; int h = height;
+    const bool gapless = a.srcPitch == (int64_t)width * PT<S>::size && a.dstPitch == (int64_t)width * PT<D>::size &&
+                         (layers == 1 || (a.srcLayer == a.srcPitch * height && a.dstLayer == a.dstPitch * height));
+    if (gapless && (int64_t)width * rows / G < 0xFFFFFFF0LL) { w = (int64_t)width * rows; rows = 1; h = 1; }
+    a.rows = (u32)rows; a.height = (u32)h;
+    const bool vec_ok = aligned(a.src, a.srcPitch, a.srcLayer, rows, rows > h ? 2 : 1, vec_bytes(SB)) &&
+                        aligned(a.dst, a.dstPitch, a.dstLayer, rows, rows > h ? 2 : 1, vec_bytes(DB));
+    if (vec_ok) {
+        a.full_units = (u32)(w / G); a.tail_px = (u32)(w % G);
+        a.upr = a.full_units + (a.tail_px ? 1 : 0);
+        a.total = (int64_t)rows * a.upr;
+        if (a.total == 0) return GAMUT_HIP_OK;
+        const int grid = grid_for((a.total + kUnroll - 1) / kUnroll, device_cus());
+        hipLaunchKernelGGL((k_convert_vec<S, D>), dim3(grid), dim3(kThreads), 0, stream, a);
+    } else {
+        const int64_t total = (int64_t)rows * w;
+        if (total == 0) return GAMUT_HIP_OK;
+        hipLaunchKernelGGL((k_convert_bytes<S, D>), dim3(grid_for(total, device_cus())), dim3(kThreads), 0, stream, a, (u32)w);
+    }
+    return launch_status("scanlines_convert");
+}
+
+template <int S, int Dd>
+bool try_pair(int dstType, const ConvArgs& a, int w, int h, int l, hipStream_t st, int& rc)
+{
+    if constexpr (S != Dd) {          // same-type pairs take the copy path and never reach here
+        if (dstType == Dd) { rc = launch_pair<S, Dd>(a, w, h, l, st); return true; }
+    }
+    return false;
+}
+template <int S, int... Ds>
+int dispatch_dst(int dstType, std::integer_sequence<int, Ds...>, const ConvArgs& a, int w, int h, int l, hipStream_t st)
+{
+    int rc = GAMUT_HIP_ERR_INVALID_ARG;
+    (void)(try_pair<S, Ds>(dstType, a, w, h, l, st, rc) || ...);
+    return rc;
+}
+template <int... Ss>
+int dispatch_src(int srcType, int dstType, std::integer_sequence<int, Ss...>, const ConvArgs& a, int w, int h, int l, hipStream_t st)
+{
+    int rc = GAMUT_HIP_ERR_INVALID_ARG;
+    (void)((srcType == Ss ? (rc = dispatch_dst<Ss>(dstType, std::make_integer_sequence<int, GAMUT_PIXEL_COUNT>{}, a, w, h, l, st), true) : false) || ...);
+    return rc;
+}
+
+} // namespace
+
+int convert_device(int srcType, const void* src, int64_t srcPitch, int64_t srcLayerOffset,
+                   int dstType, void* dst, int64_t dstPitch, int64_t dstLayerOffset,
+                   int width, int height, int layers, hipStream_t stream)
+{
+    if (!valid_type(srcType) || !valid_type(dstType))
+        return set_error(GAMUT_HIP_ERR_INVALID_ARG, "scanlines_convert: invalid PixelType %d -> %d", srcType, dstType);
+    if (width < 0 || height < 0 || layers < 0)
+        return set_error(GAMUT_HIP_ERR_INVALID_ARG, "scanlines_convert: negative dimension");
+    if (width == 0 || height == 0 || layers == 0) return GAMUT_HIP_OK;
+    if (!src || !dst) return set_error(GAMUT_HIP_ERR_INVALID_ARG, "scanlines_convert: null pointer");
+
+    ConvArgs a{};
+    a.src = static_cast<const uint8_t*>(src); a.dst = static_cast<uint8_t*>(dst);
+    a.srcPitch = srcPitch; a.srcLayer = srcLayerOffset; a.dstPitch = dstPitch; a.dstLayer = dstLayerOffset;
+
+    if (srcType == dstType) {                                  // scanlinesCopy, scanline.d:75-78
+        const u32 row_bytes = (u32)width * kPixelSize[srcType];
+        int64_t rows = (int64_t)height * layers; u32 h = (u32)height; u32 rb = row_bytes;
+        const bool gapless = srcPitch == row_bytes && dstPitch == row_bytes &&
+                             (layers == 1 || (srcLayerOffset == srcPitch * height && dstLayerOffset == dstPitch * height));
+        if (gapless && (int64_t)row_bytes * rows < 0xFFFFFFF0LL) { rb = (u32)(row_bytes * rows); rows = 1; h = 1; }
+        a.rows = (u32)rows; a.height = h;
+        const int layers_eff = rows > h ? 2 : 1;
+        const int vec = (aligned(src, srcPitch, srcLayerOffset, (int)rows, layers_eff, 16) &&
+                         aligned(dst, dstPitch, dstLayerOffset, (int)rows, layers_eff, 16)) ? 16 : 1;
+        const int64_t total = rows * ((rb + vec - 1) / vec);
+        hipLaunchKernelGGL(k_copy_rows, dim3(grid_for(total, device_cus())), dim3(kThreads), 0, stream, a, rb, vec);
+        return launch_status("scanlines_copy");
+    }
+    return dispatch_src(srcType, dstType, std::make_integer_sequence<int, GAMUT_PIXEL_COUNT>{}, a, width, height, layers, stream);
+}
+
+} // namespace gamut

@@ -1,0 +1,370 @@
+// jpeg.hip -- K1-K4: JPEG block reconstruction on gfx950.
+//
+// Replaces, for every MCU of every image of a batch, the reference's
+//   transform_mcu / transform_mcu_expand   jpegload.d:2120-2255  (IDCT, H2V2 chroma upsample)
+//   expanded_convert / H?V?Convert / gray  jpegload.d:2528-2823  (YCbCr -> RGBA)
+//   output packing                         jpegload.d:3761-3801  (rgba8 / rgb8 / l8)
+// Input: dense de-quantised int16 coefficients (what decode_next_row leaves in
+// m_pMCU_coefficients, :2432/:2474), 128 B per block, blocks in MCU order.
+//
+// Two kernels:
+//   k_jpeg_h2v2_rgba8  -- the tuned path for the headline case (4:2:0 -> rgba8).
+//       One 256-thread workgroup reconstructs a strip of 8 MCUs (128x16 px).
+//       HBM traffic is exactly the algorithmic one: 768 B of coefficients in
+//       (dwordx4 per lane, lane-contiguous) and 1024 B of pixels out (each wave
+//       store instruction writes two full 128-B lines).  The 8x8 transposes
+//       between the row and the column pass, and the hand-off between the
+//       upsample stages, go through LDS (padded to be bank-conflict free); the
+//       VALU does only arithmetic.
+//   k_jpeg_generic     -- every sampling mode (grey, H1V1, H2V1, H1V2, H2V2) and
+//       every output format (l8 / rgb8 / rgba8): one thread per coefficient block
+//       into an LDS sample buffer, then one thread per pixel.  Correct, untuned.
+#include "common.hpp"
+#include "jpeg_math.hpp"
+
+namespace gamut {
+namespace {
+
+using namespace jpg;
+
+constexpr int TILE_MCUS = 8;      // MCUs per workgroup
+
+struct JpegArgs {
+    const int16_t* coeffs; int64_t coeff_stride;     // int16 elements between images
+    const uint8_t* max_zag; int64_t zag_stride;      // bytes between images (NULL = dense)
+    uint8_t* out; int64_t out_pitch; int64_t out_stride;
+    int width, height;
+    int mcus_per_row, mcus_per_col;
+    int scan_type, out_comps;
+};
+
+// =============================================================================
+// tuned H2V2 -> rgba8
+// =============================================================================
+// LDS layout (ints).  Every 8x8 int tile is stored with a 72-int block stride and
+// 8-int row stride: a column read (8 lanes x consecutive c, 4 blocks per 32-lane
+// group) then touches 32 distinct banks.
+constexpr int BLK_STRIDE = 72;
+constexpr int T1_INTS = 32 * BLK_STRIDE;           // 32 Y blocks: pass-1 results
+constexpr int H_INTS  = 16 * BLK_STRIDE;           // 16 chroma blocks: horizontal upsample stage H[k][m]
+constexpr int V_INTS  = 16 * BLK_STRIDE;           // vertical stage V[n][m]
+// T2 (32 (mcu,quadrant) tiles: rows 0-3 = Cb pass-1 rows, 4-7 = Cr) reuses T1's storage: T1 is last read in
+// phase P2, T2 is first written in P3, and a workgroup barrier separates the two.
+constexpr int LDS_INTS = T1_INTS + H_INTS + V_INTS;
+
+__global__ __launch_bounds__(256) void k_jpeg_h2v2_rgba8(JpegArgs a)
+{
+    __shared__ __attribute__((aligned(16))) i32 lds[LDS_INTS];
+    i32* const T1 = lds;
+    i32* const Hs = T1 + T1_INTS;
+    i32* const Vs = Hs + H_INTS;
+    i32* const T2 = T1;
+
+    const int t = threadIdx.x;
+    const int img = blockIdx.z, mcu_y = blockIdx.y, mcu_x0 = blockIdx.x * TILE_MCUS;
+    const int16_t* cbase = a.coeffs + (int64_t)img * a.coeff_stride + ((int64_t)mcu_y * a.mcus_per_row + mcu_x0) * (6 * 64);
+    const int mcus_here = min(TILE_MCUS, a.mcus_per_row - mcu_x0);
+
+    // ---- mapping A: thread = (Y block b = (mcu m, quadrant q), row/column index r) ----
+    const int b = t >> 3, r = t & 7, m = b >> 2, q = b & 3;
+    const bool mcu_live = m < mcus_here;
+
+    // ---- mapping B: thread = (chroma block cb = (mcu, comp), row k, half) ----
+    const int cbk = t >> 4, k = (t >> 1) & 7, half = t & 1;
+    const bool cmcu_live = (cbk >> 1) < mcus_here;
+
+    // P0: loads (issued together; 16 B per lane, lane-contiguous inside each MCU)
+    uint4 yrow = make_uint4(0, 0, 0, 0), crow = make_uint4(0, 0, 0, 0);
+    if (mcu_live)  yrow = *reinterpret_cast<const uint4*>(cbase + m * 384 + q * 64 + r * 8);
+    if (cmcu_live) crow = *reinterpret_cast<const uint4*>(cbase + (cbk >> 1) * 384 + 256 + (cbk & 1) * 64 + k * 8);
+    bool y_col1 = false;     // Col!(1) shortcut of the reference applies (max_zag <= 2)
+    if (a.max_zag && mcu_live) {
+        const uint8_t* zb = a.max_zag + (int64_t)img * a.zag_stride + ((int64_t)mcu_y * a.mcus_per_row + mcu_x0 + m) * 6;
+        y_col1 = zb[q] <= 2;
+    }
+
+    // P1a: luma pass 1 (row r of block b) -> T1[b][r][0..7]
+    {
+        i32 x[8], tv[8];
+        unpack_row(yrow, x);
+        row_pass<8>(x, tv);
+        i32* dst = T1 + b * BLK_STRIDE + r * 8;
+        *reinterpret_cast<int4*>(dst)     = make_int4(tv[0], tv[1], tv[2], tv[3]);
+        *reinterpret_cast<int4*>(dst + 4) = make_int4(tv[4], tv[5], tv[6], tv[7]);
+    }
+    // P1b: chroma horizontal stage: row k of chroma block cbk -> H[k][half*4 .. half*4+3]
+    {
+        i32 u[8], hv[4];
+        unpack_row(crow, u);
+        if (half == 0) map_E(u, hv); else map_O(u, hv);
+        *reinterpret_cast<int4*>(Hs + cbk * BLK_STRIDE + k * 8 + half * 4) = make_int4(hv[0], hv[1], hv[2], hv[3]);
+    }
+    __syncthreads();
+
+    // P2a: luma pass 2 (column r of block b) -> 8 samples in registers
+    i32 ys[8];
+    {
+        i32 tv[8];
+        const i32* src = T1 + b * BLK_STRIDE + r;
+        #pragma unroll
+        for (int i = 0; i < 8; ++i) tv[i] = src[i * 8];
+        col_pass<8>(tv, ys);
+        if (y_col1) {
+            const i32 v = col1_sample(tv[0]);
+            #pragma unroll
+            for (int i = 0; i < 8; ++i) ys[i] = v;
+        }
+    }
+    // P2b: chroma vertical stage: column mcol of H -> V[half*4 .. +3][mcol]   (k doubles as the column index here)
+    {
+        i32 u[8], vv[4];
+        const i32* src = Hs + cbk * BLK_STRIDE + k;
+        #pragma unroll
+        for (int i = 0; i < 8; ++i) u[i] = src[i * 8];
+        if (half == 0) map_E(u, vv); else map_O(u, vv);
+        i32* dst = Vs + cbk * BLK_STRIDE + (half * 4) * 8 + k;
+        #pragma unroll
+        for (int i = 0; i < 4; ++i) dst[i * 8] = vv[i];
+    }
+    __syncthreads();
+
+    // P3: per (mcu, comp, quadrant, row j): the 4 coefficients blk_q[j][0..3] and idct_4x4's pass 1 on them.
+    //     blk0 = (V00+V10)+(V01+V11), blk1 = (V00+V10)-(V01+V11), blk2 = (V00-V10)+(V01-V11), blk3 = (V00-V10)-(V01-V11)
+    //     with V00 = V[j][i], V10 = V[4+j][i], V01 = V[j][4+i], V11 = V[4+j][4+i]   (jpegload.d:2230-2251, :886-902)
+    {
+        const int mm = t >> 5, comp = (t >> 4) & 1, qq = (t >> 2) & 3, j = t & 3;
+        const i32* vb = Vs + (mm * 2 + comp) * BLK_STRIDE;
+        const int4 a0 = *reinterpret_cast<const int4*>(vb + j * 8), a1 = *reinterpret_cast<const int4*>(vb + j * 8 + 4);
+        const int4 b0 = *reinterpret_cast<const int4*>(vb + (4 + j) * 8), b1 = *reinterpret_cast<const int4*>(vb + (4 + j) * 8 + 4);
+        const i32 v00[4] = { a0.x, a0.y, a0.z, a0.w }, v01[4] = { a1.x, a1.y, a1.z, a1.w };
+        const i32 v10[4] = { b0.x, b0.y, b0.z, b0.w }, v11[4] = { b1.x, b1.y, b1.z, b1.w };
+        i32 x[8], tv[8];
+        #pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const i32 p = (qq & 2) ? wsub(v00[i], v10[i]) : wadd(v00[i], v10[i]);     // a = P+Q (top) / b = P-Q (bottom)
+            const i32 s = (qq & 2) ? wsub(v01[i], v11[i]) : wadd(v01[i], v11[i]);     // c = R+S        / d = R-S
+            x[i] = (i32)(short)((qq & 1) ? wsub(p, s) : wadd(p, s));                  // cast(jpgd_block_t)
+        }
+        x[4] = x[5] = x[6] = x[7] = 0;
+        row_pass<4>(x, tv);
+        i32* dst = T2 + (mm * 4 + qq) * BLK_STRIDE + (comp * 4 + j) * 8;
+        *reinterpret_cast<int4*>(dst)     = make_int4(tv[0], tv[1], tv[2], tv[3]);
+        *reinterpret_cast<int4*>(dst + 4) = make_int4(tv[4], tv[5], tv[6], tv[7]);
+    }
+    __syncthreads();
+
+    // P4: chroma pass 2 (Col!4 on column r of the quadrant's Cb and Cr), colour, store
+    {
+        i32 tc[8], cbs[8], crs[8];
+        const i32* src = T2 + b * BLK_STRIDE + r;
+        #pragma unroll
+        for (int i = 0; i < 4; ++i) tc[i] = src[i * 8];
+        tc[4] = tc[5] = tc[6] = tc[7] = 0;
+        col_pass<4>(tc, cbs);
+        #pragma unroll
+        for (int i = 0; i < 4; ++i) tc[i] = src[(4 + i) * 8];
+        col_pass<4>(tc, crs);
+
+        const int px = (mcu_x0 + m) * 16 + (q & 1) * 8 + r;
+        const int py0 = mcu_y * 16 + (q >> 1) * 8;
+        if (mcu_live && px < a.width) {
+            uint8_t* o = a.out + (int64_t)img * a.out_stride + (int64_t)py0 * a.out_pitch + (int64_t)px * 4;
+            #pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (py0 + i < a.height)
+                    *reinterpret_cast<u32*>(o + (int64_t)i * a.out_pitch) = ycc_to_rgba(ys[i], cbs[i], crs[i]);
+        }
+    }
+}
+
+// =============================================================================
+// generic: all sampling modes, all output formats
+// =============================================================================
+// full dense IDCT of one block held by one thread (jpegload.d:308-376 without the sparse dispatch)
+__device__ void idct_block(const int16_t* __restrict__ src, uint8_t* __restrict__ dst, bool col1)
+{
+    i32 tmp[64];
+    #pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        i32 x[8], tv[8];
+        unpack_row(*reinterpret_cast<const uint4*>(src + r * 8), x);
+        row_pass<8>(x, tv);
+        #pragma unroll
+        for (int c = 0; c < 8; ++c) tmp[r * 8 + c] = tv[c];
+    }
+    #pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        i32 tv[8], s[8];
+        #pragma unroll
+        for (int r = 0; r < 8; ++r) tv[r] = tmp[r * 8 + c];
+        col_pass<8>(tv, s);
+        if (col1) { const i32 v = col1_sample(tv[0]); for (int r = 0; r < 8; ++r) s[r] = v; }
+        #pragma unroll
+        for (int r = 0; r < 8; ++r) dst[r * 8 + c] = (uint8_t)s[r];
+    }
+}
+
+// one chroma block -> four expanded sample blocks (transform_mcu_expand :2152-2254)
+__device__ void upsample_block(const int16_t* __restrict__ src, uint8_t* __restrict__ dst4)
+{
+    i32 H[8][8];      // H[k][m]: m<4 = E map, m>=4 = O map of source row k
+    #pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        i32 u[8], e[4], o[4];
+        unpack_row(*reinterpret_cast<const uint4*>(src + kk * 8), u);
+        map_E(u, e); map_O(u, o);
+        #pragma unroll
+        for (int i = 0; i < 4; ++i) { H[kk][i] = e[i]; H[kk][4 + i] = o[i]; }
+    }
+    i32 V[8][8];      // V[n][m]
+    #pragma unroll
+    for (int mm = 0; mm < 8; ++mm) {
+        i32 u[8], e[4], o[4];
+        #pragma unroll
+        for (int kk = 0; kk < 8; ++kk) u[kk] = H[kk][mm];
+        map_E(u, e); map_O(u, o);
+        #pragma unroll
+        for (int i = 0; i < 4; ++i) { V[i][mm] = e[i]; V[4 + i][mm] = o[i]; }
+    }
+    for (int qq = 0; qq < 4; ++qq) {
+        i32 tmp[4][8];
+        #pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            i32 x[8], tv[8];
+            #pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const i32 p = (qq & 2) ? wsub(V[j][i], V[4 + j][i]) : wadd(V[j][i], V[4 + j][i]);
+                const i32 s = (qq & 2) ? wsub(V[j][4 + i], V[4 + j][4 + i]) : wadd(V[j][4 + i], V[4 + j][4 + i]);
+                x[i] = (i32)(short)((qq & 1) ? wsub(p, s) : wadd(p, s));
+            }
+            x[4] = x[5] = x[6] = x[7] = 0;
+            row_pass<4>(x, tv);
+            #pragma unroll
+            for (int c = 0; c < 8; ++c) tmp[j][c] = tv[c];
+        }
+        #pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            i32 tv[8] = { tmp[0][c], tmp[1][c], tmp[2][c], tmp[3][c], 0, 0, 0, 0 }, s[8];
+            col_pass<4>(tv, s);
+            #pragma unroll
+            for (int rr = 0; rr < 8; ++rr) dst4[qq * 64 + rr * 8 + c] = (uint8_t)s[rr];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_jpeg_generic(JpegArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t samples[TILE_MCUS * 12 * 64];
+    const int t = threadIdx.x;
+    const int img = blockIdx.z, mcu_y = blockIdx.y, mcu_x0 = blockIdx.x * TILE_MCUS;
+    const int st = a.scan_type;
+    const int nb = st == GAMUT_JPGD_GRAYSCALE ? 1 : st == GAMUT_JPGD_YH1V1 ? 3 : st == GAMUT_JPGD_YH2V2 ? 6 : 4;
+    const int sb = st == GAMUT_JPGD_YH2V2 ? 12 : nb;                     // sample blocks per MCU (m_expanded_blocks_per_mcu)
+    const int mcu_w = (st == GAMUT_JPGD_YH2V1 || st == GAMUT_JPGD_YH2V2) ? 16 : 8;
+    const int mcu_h = (st == GAMUT_JPGD_YH1V2 || st == GAMUT_JPGD_YH2V2) ? 16 : 8;
+    const int mcus_here = min(TILE_MCUS, a.mcus_per_row - mcu_x0);
+    const int64_t blk0 = ((int64_t)mcu_y * a.mcus_per_row + mcu_x0) * nb;
+    const int16_t* cbase = a.coeffs + (int64_t)img * a.coeff_stride + blk0 * 64;
+    const uint8_t* zbase = a.max_zag ? a.max_zag + (int64_t)img * a.zag_stride + blk0 : nullptr;
+
+    // phase 1: one thread per coefficient block
+    if (t < mcus_here * nb) {
+        const int m = t / nb, bi = t - m * nb;
+        const int16_t* src = cbase + (int64_t)t * 64;
+        uint8_t* dst = samples + m * sb * 64;
+        if (st == GAMUT_JPGD_YH2V2 && bi >= 4) upsample_block(src, dst + (4 + (bi - 4) * 4) * 64);
+        else idct_block(src, dst + bi * 64, zbase && zbase[t] <= 2);
+    }
+    __syncthreads();
+
+    // phase 2: one thread per pixel of the strip (row-major inside the strip)
+    const int strip_w = mcus_here * mcu_w;
+    const int npx = strip_w * mcu_h;
+    uint8_t* obase = a.out + (int64_t)img * a.out_stride;
+    for (int p = t; p < npx; p += 256) {
+        const int ly = p / strip_w, lx = p - ly * strip_w;
+        const int m = lx / mcu_w, xin = lx - m * mcu_w;
+        const int gx = mcu_x0 * mcu_w + lx, gy = mcu_y * mcu_h + ly;
+        if (gx >= a.width || gy >= a.height) continue;
+        const uint8_t* s = samples + m * sb * 64;
+        u32 rgba;
+        i32 yv;
+        if (st == GAMUT_JPGD_GRAYSCALE) {                                   // gray_convert :2715-2728
+            yv = s[ly * 8 + xin]; rgba = 0;
+        } else if (st == GAMUT_JPGD_YH1V1) {                                // H1V1Convert :2528-2555
+            const int o = ly * 8 + xin;
+            yv = s[o]; rgba = ycc_to_rgba(yv, s[64 + o], s[128 + o]);
+        } else if (st == GAMUT_JPGD_YH2V1) {                                // H2V1Convert :2558-2600
+            yv = s[(xin >> 3) * 64 + ly * 8 + (xin & 7)];
+            const int co = 2 * 64 + ly * 8 + (xin >> 1);
+            rgba = ycc_to_rgba(yv, s[co], s[co + 64]);
+        } else if (st == GAMUT_JPGD_YH1V2) {                                // H1V2Convert :2603-2647
+            yv = s[(ly >> 3) * 64 + (ly & 7) * 8 + xin];
+            const int co = 2 * 64 + (ly >> 1) * 8 + xin;
+            rgba = ycc_to_rgba(yv, s[co], s[co + 64]);
+        } else {                                                            // expanded_convert :2731-2823
+            const int o = ((ly >> 3) * 2 + (xin >> 3)) * 64 + (ly & 7) * 8 + (xin & 7);
+            yv = s[o]; rgba = ycc_to_rgba(yv, s[4 * 64 + o], s[8 * 64 + o]);
+        }
+        // output packing :3761-3801
+        uint8_t* o = obase + (int64_t)gy * a.out_pitch + (int64_t)gx * a.out_comps;
+        if (st == GAMUT_JPGD_GRAYSCALE) {
+            o[0] = (uint8_t)yv;
+            if (a.out_comps >= 3) { o[1] = o[2] = (uint8_t)yv; if (a.out_comps == 4) o[3] = 255; }
+        } else if (a.out_comps == 4) {
+            o[0] = (uint8_t)rgba; o[1] = (uint8_t)(rgba >> 8); o[2] = (uint8_t)(rgba >> 16); o[3] = 255;
+        } else if (a.out_comps == 3) {
+            o[0] = (uint8_t)rgba; o[1] = (uint8_t)(rgba >> 8); o[2] = (uint8_t)(rgba >> 16);
+        } else {
+            o[0] = (uint8_t)rgb_to_luma(rgba);
+        }
+    }
+}
+
+} // namespace
+
+int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
+                            const uint8_t* max_zag, int64_t zag_stride,
+                            uint8_t* out, int64_t out_pitch, int64_t out_stride,
+                            int width, int height, int scan_type, int out_comps,
+                            int count, hipStream_t stream)
+{
+    // limits of the reference decoder: jpegload.d:101-102, 1355-1381, 3134-3195
+    if (width < 1 || height < 1 || width > 16384 || height > 16384)
+        return set_error(GAMUT_HIP_ERR_INVALID_ARG, "jpeg_reconstruct: bad image size %dx%d", width, height);
+    if (scan_type < GAMUT_JPGD_GRAYSCALE || scan_type > GAMUT_JPGD_YH2V2)
+        return set_error(GAMUT_HIP_ERR_INVALID_ARG, "jpeg_reconstruct: bad scan type %d", scan_type);
+    if (out_comps != 1 && out_comps != 3 && out_comps != 4)
+        return set_error(GAMUT_HIP_ERR_INVALID_ARG, "jpeg_reconstruct: out_comps must be 1, 3 or 4");
+    if (count < 0) return set_error(GAMUT_HIP_ERR_INVALID_ARG, "jpeg_reconstruct: negative count");
+    if (count == 0) return GAMUT_HIP_OK;
+    if (!coeffs || !out) return set_error(GAMUT_HIP_ERR_INVALID_ARG, "jpeg_reconstruct: null pointer");
+    if (((uintptr_t)coeffs & 15) || (count > 1 && (coeff_stride & 7)))
+        return set_error(GAMUT_HIP_ERR_INVALID_ARG, "jpeg_reconstruct: coefficient buffers must be 16-byte aligned");
+
+    JpegArgs a{};
+    a.coeffs = coeffs; a.coeff_stride = coeff_stride; a.max_zag = max_zag; a.zag_stride = zag_stride;
+    a.out = out; a.out_pitch = out_pitch; a.out_stride = out_stride;
+    a.width = width; a.height = height; a.scan_type = scan_type; a.out_comps = out_comps;
+    const int mcu_w = (scan_type == GAMUT_JPGD_YH2V1 || scan_type == GAMUT_JPGD_YH2V2) ? 16 : 8;
+    const int mcu_h = (scan_type == GAMUT_JPGD_YH1V2 || scan_type == GAMUT_JPGD_YH2V2) ? 16 : 8;
+    a.mcus_per_row = (width + mcu_w - 1) / mcu_w;          // jpegload.d:3197-3198
+    a.mcus_per_col = (height + mcu_h - 1) / mcu_h;
+    const int tiles = (a.mcus_per_row + TILE_MCUS - 1) / TILE_MCUS;
+
+    for (int i0 = 0; i0 < count; i0 += 65535) {             // gridDim.z limit
+        const int n = count - i0 < 65535 ? count - i0 : 65535;
+        JpegArgs c = a;
+        c.coeffs += (int64_t)i0 * coeff_stride; c.out += (int64_t)i0 * out_stride;
+        if (c.max_zag) c.max_zag += (int64_t)i0 * zag_stride;
+        const dim3 grid(tiles, a.mcus_per_col, n);
+        const bool tuned = scan_type == GAMUT_JPGD_YH2V2 && out_comps == 4 && ((uintptr_t)out & 3) == 0 &&
+                           (out_pitch & 3) == 0 && (out_stride & 3) == 0;
+        if (tuned) hipLaunchKernelGGL(k_jpeg_h2v2_rgba8, grid, dim3(256), 0, stream, c);
+        else       hipLaunchKernelGGL(k_jpeg_generic, grid, dim3(256), 0, stream, c);
+        if (int rc = launch_status("jpeg_reconstruct")) return rc;
+    }
+    return GAMUT_HIP_OK;
+}
+
+} // namespace gamut

@@ -1,0 +1,184 @@
+// runtime.hip -- C-ABI runtime entry points of libgamut_hip (init, errors, memory, streams)
+// and the host-pointer drop-in for scanlinesConvert / scanlinesCopy.
+#include "common.hpp"
+
+namespace gamut {
+
+char* last_error_buf()
+{
+    static thread_local char buf[512] = { 0 };
+    return buf;
+}
+
+int set_error(int status, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(last_error_buf(), 512, fmt, ap);
+    va_end(ap);
+    return status;
+}
+
+hipStream_t thread_stream()
+{
+    static thread_local hipStream_t s = nullptr;
+    if (!s) {
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;   // falls back to the null stream
+    }
+    return s;
+}
+
+namespace {
+
+// RAII device buffer for the synchronous host entry points
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n)
+    {
+        if (hipMalloc(&p, n ? n : 1) != hipSuccess) { p = nullptr; return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed", n); }
+        return GAMUT_HIP_OK;
+    }
+};
+
+int require_device()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return set_error(GAMUT_HIP_ERR_NO_DEVICE, "no HIP device available (libgamut_hip has no CPU fallback)");
+    return GAMUT_HIP_OK;
+}
+
+// Host drop-in shared by convert and copy: stage the rectangle through tight HBM buffers.
+int host_convert(int srcType, const uint8_t* src, int srcPitch, int dstType, uint8_t* dst, int dstPitch, int width, int height)
+{
+    if (!valid_type(srcType) || !valid_type(dstType))
+        return set_error(GAMUT_HIP_ERR_INVALID_ARG, "scanlinesConvert: invalid PixelType %d -> %d", srcType, dstType);
+    if (width < 0 || height < 0) return set_error(GAMUT_HIP_ERR_INVALID_ARG, "scanlinesConvert: negative size");
+    if (width == 0 || height == 0) return GAMUT_HIP_OK;
+    if (!src || !dst) return set_error(GAMUT_HIP_ERR_INVALID_ARG, "scanlinesConvert: null pointer");
+    if (int rc = require_device()) return rc;
+
+    const size_t srow = (size_t)width * kPixelSize[srcType], drow = (size_t)width * kPixelSize[dstType];
+    const size_t sabs = (size_t)(srcPitch < 0 ? -(int64_t)srcPitch : srcPitch), dabs = (size_t)(dstPitch < 0 ? -(int64_t)dstPitch : dstPitch);
+    if (height > 1 && (sabs < srow || dabs < drow))
+        return set_error(GAMUT_HIP_ERR_INVALID_ARG, "scanlinesConvert: pitch smaller than a scanline");
+    // lowest-address row of each rectangle (pitch < 0 => stored bottom-up)
+    const uint8_t* s0 = srcPitch < 0 ? src + (int64_t)(height - 1) * srcPitch : src;
+    uint8_t*       d0 = dstPitch < 0 ? dst + (int64_t)(height - 1) * dstPitch : dst;
+
+    DevBuf ds, dd;
+    if (int rc = ds.alloc(srow * height)) return rc;
+    if (int rc = dd.alloc(drow * height)) return rc;
+    hipStream_t st = thread_stream();
+    GAMUT_HIP_CHECK(hipMemcpy2DAsync(ds.p, srow, s0, height > 1 ? sabs : srow, srow, height, hipMemcpyHostToDevice, st));
+    // device rectangles keep the memory order of the host ones, so flipped stays flipped
+    const uint8_t* dsrc = static_cast<const uint8_t*>(ds.p) + (srcPitch < 0 ? (int64_t)(height - 1) * srow : 0);
+    uint8_t*       ddst = static_cast<uint8_t*>(dd.p) + (dstPitch < 0 ? (int64_t)(height - 1) * drow : 0);
+    if (int rc = convert_device(srcType, dsrc, srcPitch < 0 ? -(int64_t)srow : (int64_t)srow, 0,
+                                dstType, ddst, dstPitch < 0 ? -(int64_t)drow : (int64_t)drow, 0, width, height, 1, st))
+        return rc;
+    GAMUT_HIP_CHECK(hipMemcpy2DAsync(d0, height > 1 ? dabs : drow, dd.p, drow, drow, height, hipMemcpyDeviceToHost, st));
+    GAMUT_HIP_CHECK(hipStreamSynchronize(st));
+    return GAMUT_HIP_OK;
+}
+
+} // namespace
+} // namespace gamut
+
+using namespace gamut;
+
+extern "C" {
+
+const char* gamut_hip_version(void) { return "gamut-hip 0.1 (gfx950)"; }
+
+int gamut_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int gamut_hip_init(int device)
+{
+    clear_error();
+    if (int rc = require_device()) return rc;
+    if (device >= 0) GAMUT_HIP_CHECK(hipSetDevice(device));
+    GAMUT_HIP_CHECK(hipFree(nullptr));      // force context creation
+    return GAMUT_HIP_OK;
+}
+
+void gamut_hip_shutdown(void) { (void)hipDeviceSynchronize(); }
+
+const char* gamut_hip_last_error(void) { return last_error_buf(); }
+
+void* gamut_hip_device_malloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "hipMalloc(%zu) failed", bytes); return nullptr; }
+    return p;
+}
+void gamut_hip_device_free(void* p) { if (p) (void)hipFree(p); }
+
+void* gamut_hip_host_malloc_pinned(size_t bytes)
+{
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "hipHostMalloc(%zu) failed", bytes); return nullptr; }
+    return p;
+}
+void gamut_hip_host_free_pinned(void* p) { if (p) (void)hipHostFree(p); }
+
+int gamut_hip_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream)
+{
+    GAMUT_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, pick_stream(stream)));
+    return GAMUT_HIP_OK;
+}
+int gamut_hip_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream)
+{
+    GAMUT_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, pick_stream(stream)));
+    return GAMUT_HIP_OK;
+}
+void* gamut_hip_stream_create(void)
+{
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { set_error(GAMUT_HIP_ERR_HIP, "hipStreamCreate failed"); return nullptr; }
+    return s;
+}
+void gamut_hip_stream_destroy(void* stream) { if (stream) (void)hipStreamDestroy(reinterpret_cast<hipStream_t>(stream)); }
+int gamut_hip_stream_synchronize(void* stream)
+{
+    GAMUT_HIP_CHECK(hipStreamSynchronize(pick_stream(stream)));
+    return GAMUT_HIP_OK;
+}
+
+int gamut_hip_pixel_type_size(int type) { return valid_type(type) ? kPixelSize[type] : 0; }
+
+int gamut_hip_scanlines_inter_type(int srcType, int dstType)
+{
+    auto plain8 = [](int t) { return t == GAMUT_PIXEL_l8 || t == GAMUT_PIXEL_la8 || t == GAMUT_PIXEL_rgb8 || t == GAMUT_PIXEL_rgba8; };
+    return (plain8(srcType) && plain8(dstType)) ? GAMUT_PIXEL_rgba8 : GAMUT_PIXEL_rgbaf32;
+}
+
+int gamut_hip_scanlines_convert(int srcType, const uint8_t* src, int srcPitch,
+                                int dstType, uint8_t* dst, int dstPitch, int width, int height)
+{
+    clear_error();
+    return host_convert(srcType, src, srcPitch, dstType, dst, dstPitch, width, height);
+}
+
+int gamut_hip_scanlines_copy(int type, const uint8_t* src, int srcPitch, uint8_t* dst, int dstPitch, int width, int height)
+{
+    clear_error();
+    return host_convert(type, src, srcPitch, type, dst, dstPitch, width, height);
+}
+
+int gamut_hip_scanlines_convert_device(int srcType, const void* src, int64_t srcPitch, int64_t srcLayerOffset,
+                                       int dstType, void* dst, int64_t dstPitch, int64_t dstLayerOffset,
+                                       int width, int height, int layers, void* stream)
+{
+    clear_error();
+    return convert_device(srcType, src, srcPitch, srcLayerOffset, dstType, dst, dstPitch, dstLayerOffset,
+                          width, height, layers, pick_stream(stream));
+}
+
+} // extern "C"

@@ -1,0 +1,193 @@
+/*
+ * gamut_hip.h -- C ABI of the MI355X (gfx950) batched image-decode /
+ * pixel-convert path for Gamut (AuburnSounds/gamut).
+ *
+ * This header is the drop-in boundary: plain C, pointers and sizes only, no
+ * C++/torch types.  A D program binds it with `extern(C) nothrow @nogc`
+ * prototypes (INTEGRATION.md shows the binding file).  Each entry point names
+ * the reference interface it replaces (paths relative to the reference repo,
+ * source/gamut/...).
+ *
+ * Conventions (mirroring the reference):
+ *   - no exceptions, no aborts: functions return an int status (0 = ok) or a
+ *     NULL pointer; gamut_hip_last_error() gives a static/thread-local C string
+ *   - PixelType ordinals are exactly types.d:32-59 (l8 = 0 ... rgbapf32 = 17,
+ *     unknown = -1); pitches are signed bytes (negative = stored bottom-up)
+ *   - "host" entry points take host pointers, are synchronous, and return
+ *     malloc()-compatible memory where the reference does (free() it)
+ *   - "device" entry points take HBM pointers, enqueue on the given hipStream_t
+ *     (passed as void*, NULL = the library's per-thread default stream) and do
+ *     not synchronise; results stay resident in HBM
+ *   - thread-safe: no mutable global state besides lazily created per-thread
+ *     streams; concurrent calls on different images are safe
+ */
+#ifndef GAMUT_HIP_H
+#define GAMUT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes -------------------------------------------------------- */
+enum {
+    GAMUT_HIP_OK              = 0,
+    GAMUT_HIP_ERR_INVALID_ARG = 1,
+    GAMUT_HIP_ERR_UNSUPPORTED = 2,   /* e.g. planar/compressed PixelType: scanline.d:82-85 */
+    GAMUT_HIP_ERR_OUT_OF_MEMORY = 3,
+    GAMUT_HIP_ERR_HIP         = 4,   /* a HIP runtime call failed; see last_error */
+    GAMUT_HIP_ERR_DECODE      = 5,   /* corrupt / unsupported stream */
+    GAMUT_HIP_ERR_NO_DEVICE   = 6
+};
+
+/* ---- PixelType (types.d:32-59) ------------------------------------------- */
+enum {
+    GAMUT_PIXEL_unknown = -1,
+    GAMUT_PIXEL_l8 = 0, GAMUT_PIXEL_l16, GAMUT_PIXEL_lf32,
+    GAMUT_PIXEL_la8, GAMUT_PIXEL_la16, GAMUT_PIXEL_laf32,
+    GAMUT_PIXEL_lap8, GAMUT_PIXEL_lap16, GAMUT_PIXEL_lapf32,
+    GAMUT_PIXEL_rgb8, GAMUT_PIXEL_rgb16, GAMUT_PIXEL_rgbf32,
+    GAMUT_PIXEL_rgba8, GAMUT_PIXEL_rgba16, GAMUT_PIXEL_rgbaf32,
+    GAMUT_PIXEL_rgbap8, GAMUT_PIXEL_rgbap16, GAMUT_PIXEL_rgbapf32,
+    GAMUT_PIXEL_COUNT
+};
+
+/* JPEG sampling modes (jpegload.d:117-118, JPEG_SUBSAMPLING) */
+enum { GAMUT_JPGD_GRAYSCALE = 0, GAMUT_JPGD_YH1V1, GAMUT_JPGD_YH2V1, GAMUT_JPGD_YH1V2, GAMUT_JPGD_YH2V2 };
+
+/* ---- runtime ------------------------------------------------------------- */
+const char* gamut_hip_version(void);
+/* number of visible GPUs (0 if none / no driver) */
+int  gamut_hip_device_count(void);
+/* bind the calling thread to `device` (-1 = keep current). Returns status. */
+int  gamut_hip_init(int device);
+void gamut_hip_shutdown(void);
+/* message for the last non-zero status on this thread ("" if none) */
+const char* gamut_hip_last_error(void);
+
+/* device memory / stream helpers so a non-HIP host (D, C) can drive the batched API */
+void* gamut_hip_device_malloc(size_t bytes);
+void  gamut_hip_device_free(void* p);
+void* gamut_hip_host_malloc_pinned(size_t bytes);
+void  gamut_hip_host_free_pinned(void* p);
+int   gamut_hip_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);
+int   gamut_hip_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
+void* gamut_hip_stream_create(void);
+void  gamut_hip_stream_destroy(void* stream);
+int   gamut_hip_stream_synchronize(void* stream);
+
+/* ---- K8/K9: scanline conversion matrix ------------------------------------
+ * replaces scanlinesConvert (scanline.d:70-121) / scanlinesCopy (:37-55).
+ * Same argument meaning; the interType/interBuf scratch arguments disappear
+ * (the intermediate lives in registers).  Returns GAMUT_HIP_OK where the
+ * reference returns true. */
+int gamut_hip_pixel_type_size(int type);                       /* types.d:62-86 */
+int gamut_hip_scanlines_inter_type(int srcType, int dstType);  /* scanline.d:25-31 */
+
+/* host pointers; synchronous (H2D, kernel, D2H inside) */
+int gamut_hip_scanlines_convert(int srcType, const uint8_t* src, int srcPitch,
+                                int dstType, uint8_t* dst, int dstPitch,
+                                int width, int height);
+int gamut_hip_scanlines_copy(int type, const uint8_t* src, int srcPitch,
+                             uint8_t* dst, int dstPitch, int width, int height);
+
+/* HBM pointers; layered like Image.convertTo's layer loop (image.d:1273-1311):
+ * layer L's first scanline is src + L*srcLayerOffset.  Asynchronous. */
+int gamut_hip_scanlines_convert_device(int srcType, const void* src, int64_t srcPitch, int64_t srcLayerOffset,
+                                       int dstType, void* dst, int64_t dstPitch, int64_t dstLayerOffset,
+                                       int width, int height, int layers, void* stream);
+
+/* ---- K1-K4: JPEG block reconstruction --------------------------------------
+ * replaces transform_mcu / transform_mcu_expand (jpegload.d:2120-2255), the
+ * *Convert row functions (:2528-2823) and the output packing of
+ * decompress_jpeg_image_from_stream (:3753-3802).
+ *
+ * Input per image = what decode_next_row (:2405-2525) hands to transform_mcu:
+ * de-quantised int16 coefficients in natural order, 64 per block, blocks in
+ * MCU order (calc_mcu_block_order :3076-3088: Y.. Cb Cr), MCUs row-major,
+ * mcus_per_row = ceil(width / mcu_w), mcus_per_col = ceil(height / mcu_h).
+ * max_zag (optional, may be NULL) is m_mcu_block_max_zag per block (:2512);
+ * NULL means "dense": identical results for every block whose pass-1 outputs
+ * stay below 2^18 in magnitude, which holds for all 8-bit sample data
+ * ("sparse IDCT paths").
+ * Output: rows of width*out_comps bytes (out_comps 1, 3 or 4: l8 / rgb8 / rgba8,
+ * :3761-3801), out_pitch bytes apart. */
+typedef struct gamut_hip_jpeg_desc {
+    const int16_t* coeffs;      /* HBM */
+    const uint8_t* max_zag;     /* HBM or NULL */
+    uint8_t*       out;         /* HBM */
+    int64_t        out_pitch;   /* bytes */
+    int32_t        width, height;
+    int32_t        scan_type;   /* GAMUT_JPGD_* */
+    int32_t        out_comps;   /* 1, 3, 4 */
+} gamut_hip_jpeg_desc;
+
+/* `count` independent images, arbitrary sizes. descs is a HOST array. Async. */
+int gamut_hip_jpeg_reconstruct_device(const gamut_hip_jpeg_desc* descs, int count, void* stream);
+
+/* uniform batch: image i uses coeffs + i*coeff_stride (int16 elements),
+ * max_zag + i*zag_stride (bytes, ignored if max_zag NULL), out + i*out_stride
+ * (bytes).  One launch for the whole batch.  Async. */
+int gamut_hip_jpeg_reconstruct_batch_device(const int16_t* coeffs, int64_t coeff_stride,
+                                            const uint8_t* max_zag, int64_t zag_stride,
+                                            uint8_t* out, int64_t out_pitch, int64_t out_stride,
+                                            int width, int height, int scan_type, int out_comps,
+                                            int count, void* stream);
+
+/* host-side feeder: baseline (SOF0/SOF1) entropy decode of one file into the
+ * dense form above (jpegload.d:1160-1848 markers, :2405-2525 decode).
+ * The frame's buffers are malloc'd; release with gamut_hip_jpeg_frame_free. */
+typedef struct gamut_hip_jpeg_frame {
+    int32_t  width, height, comps, scan_type;
+    int32_t  mcus_per_row, mcus_per_col, blocks_per_mcu;
+    int16_t* coeffs;            /* host */
+    uint8_t* max_zag;           /* host */
+    float    pixel_aspect_ratio, dpi_y;   /* -1 when unknown */
+} gamut_hip_jpeg_frame;
+int  gamut_hip_jpeg_decode_coeffs(const uint8_t* data, size_t len, gamut_hip_jpeg_frame* out);
+void gamut_hip_jpeg_frame_free(gamut_hip_jpeg_frame* f);
+
+/* drop-in for decompress_jpeg_image_from_stream (jpegload.d:3720-3723) on a
+ * memory buffer: host entropy decode, GPU reconstruction, malloc'd
+ * width*req_comps*height result (NULL on failure).  req_comps -1/1/3/4. */
+uint8_t* gamut_hip_decompress_jpeg_image_from_memory(const uint8_t* data, size_t len,
+        int* width, int* height, int* actual_comps,
+        float* pixelAspectRatio, float* dotsPerInchY, int req_comps);
+
+/* ---- K5-K7: PNG de-filter / expand -----------------------------------------
+ * replaces stbi__create_png_image_raw (stbdec.d:1406-1635).  raw = inflated
+ * stream of one non-interlaced image (or one Adam7 pass): per row one filter
+ * byte + ceil(img_n*x*depth/8) bytes.  out = x*y*out_n*(depth==16?2:1) bytes,
+ * tightly packed, out_n == img_n or img_n+1 (alpha = 255 inserted), 1/2/4-bit
+ * samples expanded (grey scaled when color==0), 16-bit samples native-endian. */
+typedef struct gamut_hip_png_desc {
+    const uint8_t* raw;         /* HBM */
+    uint8_t*       out;         /* HBM */
+    uint32_t       raw_len;
+    uint32_t       x, y;
+    int32_t        img_n, out_n, depth, color;
+} gamut_hip_png_desc;
+int gamut_hip_png_defilter_device(const gamut_hip_png_desc* descs, int count, void* stream);
+
+/* uniform batch: image i uses raw + i*raw_stride, out + i*out_stride (bytes). */
+int gamut_hip_png_defilter_batch_device(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len,
+                                        uint8_t* out, int64_t out_stride,
+                                        uint32_t x, uint32_t y, int img_n, int out_n, int depth, int color,
+                                        int count, void* stream);
+
+/* drop-ins for stbi_load_from_callbacks / stbi_load_16_from_callbacks
+ * (stbdec.d:713-735) on a memory buffer: host chunk parse + inflate, GPU
+ * de-filter/expand/post passes, malloc'd result (NULL on failure). */
+uint8_t*  gamut_hip_stbi_load_from_memory(const uint8_t* data, size_t len, int* x, int* y, int* comp, int req_comp,
+                                          float* ppmX, float* ppmY, float* pixelRatio);
+uint16_t* gamut_hip_stbi_load_16_from_memory(const uint8_t* data, size_t len, int* x, int* y, int* comp, int req_comp,
+                                             float* ppmX, float* ppmY, float* pixelRatio);
+/* stbi__png_is16 (stbdec.d:2091-2109) */
+int gamut_hip_png_is16(const uint8_t* data, size_t len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAMUT_HIP_H */

@@ -1,0 +1,158 @@
+"""GPU parity: the HIP scanline conversion matrix (through the C ABI) vs the CPU oracle.
+
+Bar: bit-exact for every PixelType pair -- integer outputs byte-for-byte, f32
+outputs compared as raw 32-bit patterns (0 ulp vs IEEE per-operation binary32;
+the stated tolerance against "whatever D compiler built the reference" is 1 ulp,
+see DESIGN.md).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import gen
+import oracle_lib as O
+from oracle_lib import PIXEL_TYPES, PT, PT_SIZE
+
+pytestmark = pytest.mark.gpu
+
+
+class DevBuf:
+    def __init__(self, L, host):
+        self.L, self.n = L, host.size
+        self.p = L.gamut_hip_device_malloc(max(1, host.size))
+        assert self.p
+        from gamut_amd import _capi
+        _capi.check(L.gamut_hip_memcpy_h2d(self.p, host.ctypes.data, host.size, None))
+        _capi.check(L.gamut_hip_stream_synchronize(None))
+
+    def get(self):
+        from gamut_amd import _capi
+        out = np.empty(self.n, np.uint8)
+        _capi.check(self.L.gamut_hip_stream_synchronize(None))
+        _capi.check(self.L.gamut_hip_memcpy_d2h(out.ctypes.data, self.p, self.n, None))
+        _capi.check(self.L.gamut_hip_stream_synchronize(None))
+        return out
+
+    def free(self):
+        self.L.gamut_hip_device_free(self.p)
+
+
+def _run_device(L, st, dt, sbuf, soff, spitch, dbuf_size, doff, dpitch, w, h, layers=1, slayer=0, dlayer=0):
+    from gamut_amd import _capi
+    ds = DevBuf(L, sbuf)
+    dd = DevBuf(L, np.full(dbuf_size, 0xA5, np.uint8))
+    _capi.check(L.gamut_hip_scanlines_convert_device(st, ds.p + soff, spitch, slayer, dt, dd.p + doff, dpitch, dlayer,
+                                                     w, h, layers, None))
+    out = dd.get()
+    ds.free(); dd.free()
+    return out
+
+
+@pytest.mark.parametrize("src", PIXEL_TYPES)
+def test_all_pairs_device_bit_exact(hip, src):
+    """every destination type from `src`, three layouts: gapless/aligned, padded unaligned pitch, flipped."""
+    rng = np.random.default_rng(1234 + PT[src])
+    st = PT[src]
+    for dst in PIXEL_TYPES:
+        dt = PT[dst]
+        for (w, h, spad, dpad, flip) in [(67, 9, 0, 0, False), (33, 5, 3, 5, False), (21, 4, 16, 32, True), (256, 2, 0, 0, False)]:
+            px = gen.make_pixels(src, w * h, rng)
+            spitch, dpitch = w * PT_SIZE[st] + spad, w * PT_SIZE[dt] + dpad
+            sbuf, soff, sp = gen.pack_rows(px, w, h, spitch, flipped=flip)
+            # expected (oracle) into a 0xA5-filled buffer of the same geometry
+            exp = np.full(dpitch * h + 32, 0xA5, np.uint8)
+            doff, dp = ((h - 1) * dpitch, -dpitch) if flip else (0, dpitch)
+            inter = O.lib().orc_scanlines_inter_type(st, dt)
+            ibuf = np.zeros(w * 16 + 16, np.uint8)
+            assert O.lib().orc_scanlines_convert(st, sbuf.ctypes.data + soff, sp, dt, exp.ctypes.data + doff, dp, w, h,
+                                                 inter, ibuf.ctypes.data)
+            got = _run_device(hip, st, dt, sbuf, soff, sp, exp.size, doff, dp, w, h)
+            if not np.array_equal(got, exp):
+                bad = np.flatnonzero(got != exp)
+                raise AssertionError(f"{src}->{dst} w={w} h={h} flip={flip}: {bad.size} bytes differ, first at {bad[:8]}; "
+                                     f"got {got[bad[:8]]} exp {exp[bad[:8]]}")
+
+
+def test_layers_and_gapless_flatten(hip):
+    """layered buffers (Image.convertTo's layer loop, image.d:1273-1311), contiguous and with a gap between layers."""
+    rng = np.random.default_rng(7)
+    w, h, layers = 50, 7, 3
+    for src, dst in [("rgba16", "rgbaf32"), ("rgbaf32", "rgba8"), ("rgba8", "rgba16"), ("rgb8", "l16"), ("la8", "rgb8")]:
+        st, dt = PT[src], PT[dst]
+        for gap in (0, 64):
+            sl, dl = w * h * PT_SIZE[st] + gap, w * h * PT_SIZE[dt] + gap
+            px = gen.make_pixels(src, w * h * layers, rng).reshape(layers, h * w, -1)
+            sbuf = np.full(sl * layers + 16, 0xA5, np.uint8)
+            exp = np.full(dl * layers + 16, 0xA5, np.uint8)
+            for l in range(layers):
+                row = px[l].view(np.uint8).reshape(-1)
+                sbuf[l * sl: l * sl + row.size] = row
+                e = O.scanlines_convert(st, row, dt, w, h)
+                exp[l * dl: l * dl + e.size] = e
+            got = _run_device(hip, st, dt, sbuf, 0, w * PT_SIZE[st], exp.size, 0, w * PT_SIZE[dt], w, h, layers, sl, dl)
+            assert np.array_equal(got, exp), f"{src}->{dst} gap={gap}"
+
+
+def test_exhaustive_integer_tables(hip):
+    """all 256 / 65536 codes for the u8/u16 <-> f32 and u8 <-> u16 composites (SURVEY.md 8a note)."""
+    u8 = np.arange(256, dtype=np.uint8).repeat(4).reshape(-1, 4)
+    u16 = np.arange(65536, dtype=np.uint16).repeat(4).reshape(-1, 4)
+    for src, arr, dsts in [("rgba8", u8, ["rgbaf32", "rgba16", "rgbap16", "l16"]),
+                           ("rgba16", u16, ["rgbaf32", "rgba8", "rgbap8", "la8"])]:
+        st = PT[src]
+        n = arr.shape[0]
+        for dst in dsts:
+            dt = PT[dst]
+            exp = O.scanlines_convert(st, arr, dt, n, 1)
+            got = _run_device(hip, st, dt, arr.view(np.uint8).reshape(-1).copy(), 0, n * PT_SIZE[st], exp.size, 0,
+                              n * PT_SIZE[dt], n, 1)
+            assert np.array_equal(got, exp), f"{src}->{dst}"
+    # the composites the reference ends up computing (verified in SURVEY.md): v*257 and (v*255+32767)//65535
+    got = _run_device(hip, PT["rgba8"], PT["rgba16"], u8.reshape(-1).copy(), 0, 1024, 2048, 0, 2048, 256, 1).view(np.uint16)
+    assert np.array_equal(got, (u8.reshape(-1).astype(np.uint32) * 257).astype(np.uint16))
+    got = _run_device(hip, PT["rgba16"], PT["rgba8"], u16.view(np.uint8).reshape(-1).copy(), 0, 65536 * 8, 65536 * 4, 0,
+                      65536 * 4, 65536, 1)
+    assert np.array_equal(got, ((u16.reshape(-1).astype(np.uint64) * 255 + 32767) // 65535).astype(np.uint8))
+
+
+def test_f32_boundaries(hip):
+    """f32 -> u8/u16 at every half-integer boundary +-1 ulp, out-of-range and non-finite-free extremes."""
+    e = gen.f32_edge_values()
+    n = (e.size // 4) * 4
+    px = e[:n].reshape(-1, 4).copy()
+    st = PT["rgbaf32"]
+    for dst in ["rgba8", "rgba16", "rgb8", "rgb16", "l8", "l16", "la8", "la16", "lap8", "lap16", "rgbap8", "rgbap16",
+                "lf32", "laf32", "lapf32", "rgbf32", "rgbapf32"]:
+        dt = PT[dst]
+        w = px.shape[0]
+        exp = O.scanlines_convert(st, px, dt, w, 1)
+        got = _run_device(hip, st, dt, px.view(np.uint8).reshape(-1).copy(), 0, w * 16, exp.size, 0, w * PT_SIZE[dt], w, 1)
+        assert np.array_equal(got, exp), dst
+
+
+def test_host_dropin_matches_scanlinesConvert(hip):
+    """gamut_hip_scanlines_convert: host pointers, signed pitches, gap bytes untouched (scanline.d:70-121)."""
+    from gamut_amd import _capi
+    rng = np.random.default_rng(99)
+    for src, dst, flip_s, flip_d in [("rgb8", "rgbaf32", False, True), ("rgbaf32", "rgba8", True, False),
+                                     ("l8", "rgba8", False, False), ("rgba16", "rgba16", True, False),
+                                     ("rgbap16", "la8", False, False)]:
+        st, dt = PT[src], PT[dst]
+        w, h = 45, 6
+        px = gen.make_pixels(src, w * h, rng)
+        spitch, dpitch = w * PT_SIZE[st] + 7, w * PT_SIZE[dt] + 9
+        sbuf, soff, sp = gen.pack_rows(px, w, h, spitch, flipped=flip_s)
+        exp = np.full(dpitch * h + 32, 0xA5, np.uint8)
+        got = exp.copy()
+        doff, dp = ((h - 1) * dpitch, -dpitch) if flip_d else (0, dpitch)
+        inter = O.lib().orc_scanlines_inter_type(st, dt)
+        ibuf = np.zeros(w * 16 + 16, np.uint8)
+        assert O.lib().orc_scanlines_convert(st, sbuf.ctypes.data + soff, sp, dt, exp.ctypes.data + doff, dp, w, h, inter,
+                                             ibuf.ctypes.data)
+        _capi.check(hip.gamut_hip_scanlines_convert(st, sbuf.ctypes.data + soff, sp, dt, got.ctypes.data + doff, dp, w, h))
+        assert np.array_equal(got, exp), f"{src}->{dst}"
+    # zero-size and invalid arguments follow the reference's conventions
+    assert hip.gamut_hip_scanlines_convert(12, None, 0, 14, None, 0, 0, 0) == 0
+    assert hip.gamut_hip_scanlines_convert(-1, sbuf.ctypes.data, 4, 14, got.ctypes.data, 16, 1, 1) == _capi.ERR_INVALID_ARG
+    assert b"PixelType" in hip.gamut_hip_last_error()

@@ -1,0 +1,199 @@
+"""GPU parity: JPEG block reconstruction (IDCT + 4:2:0 frequency-domain upsample + YCbCr->RGB)
+through the C ABI vs the CPU oracle.  Bar: bit-exact, every sampling mode, every output format."""
+import ctypes as C
+import glob
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from gamut_amd import _capi
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = json.load(open(os.path.join(HERE, "golden", "golden.json")))
+JPEGS = sorted(glob.glob(os.path.join(HERE, "golden", "jpeg", "*.jpg"))) + [os.path.join(HERE, "golden", "ref_images", "issue35.jpg")]
+NB = {0: 1, 1: 3, 2: 4, 3: 4, 4: 6}
+MCU = {0: (8, 8), 1: (8, 8), 2: (16, 8), 3: (8, 16), 4: (16, 16)}
+ZAG = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42,
+       49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def dev_upload(L, arr):
+    arr = np.ascontiguousarray(arr)
+    p = L.gamut_hip_device_malloc(max(16, arr.nbytes))
+    assert p
+    _capi.check(L.gamut_hip_memcpy_h2d(p, arr.ctypes.data, arr.nbytes, None))
+    _capi.check(L.gamut_hip_stream_synchronize(None))
+    return p
+
+
+def gpu_reconstruct(L, width, height, scan_type, coeffs, max_zag, out_comps, count=1, pad=0):
+    """coeffs: (count, nblk, 64) int16.  Returns (count, height, width*out_comps) uint8."""
+    coeffs = np.ascontiguousarray(coeffs, np.int16).reshape(count, -1)
+    dco = dev_upload(L, coeffs)
+    dzz = dev_upload(L, np.ascontiguousarray(max_zag, np.uint8).reshape(count, -1)) if max_zag is not None else None
+    pitch = width * out_comps + pad
+    istride = pitch * height + 64
+    host = np.full(count * istride, 0xA5, np.uint8)
+    dout = dev_upload(L, host)
+    nblk = coeffs.shape[1] // 64
+    _capi.check(L.gamut_hip_jpeg_reconstruct_batch_device(dco, coeffs.shape[1], dzz, nblk, dout, pitch, istride,
+                                                           width, height, scan_type, out_comps, count, None))
+    _capi.check(L.gamut_hip_stream_synchronize(None))
+    _capi.check(L.gamut_hip_memcpy_d2h(host.ctypes.data, dout, host.nbytes, None))
+    _capi.check(L.gamut_hip_stream_synchronize(None))
+    for p in (dco, dzz, dout):
+        if p:
+            L.gamut_hip_device_free(p)
+    out = np.empty((count, height, width * out_comps), np.uint8)
+    for i in range(count):
+        img = host[i * istride:(i + 1) * istride]
+        rows = img[:pitch * height].reshape(height, pitch)
+        out[i] = rows[:, :width * out_comps]
+        assert (rows[:, width * out_comps:] == 0xA5).all(), "wrote into the row gap"
+        assert (img[pitch * height:] == 0xA5).all(), "wrote past the image"
+    return out
+
+
+def random_coeffs(rng, nblk, kind):
+    if kind == "natural":           # DCT-like: decaying magnitudes, mostly zero high frequencies
+        scale = 600.0 / (1.0 + np.add.outer(np.arange(8), np.arange(8)) ** 2)
+        c = rng.normal(0, 1, (nblk, 8, 8)) * scale
+        c[:, 0, 0] = rng.integers(-1000, 1000, nblk)
+        c = np.where(rng.random((nblk, 8, 8)) < 0.5, 0, c)
+        return np.round(c).astype(np.int16).reshape(nblk, 64)
+    if kind == "dense":
+        return rng.integers(-256, 257, (nblk, 64)).astype(np.int16)
+    return rng.integers(-32768, 32768, (nblk, 64)).astype(np.int16)        # "wild": every int16, wrap-around arithmetic
+
+
+@pytest.mark.parametrize("path", JPEGS, ids=[os.path.basename(p) for p in JPEGS])
+def test_fixture_files(hip, path):
+    """product feeder -> GPU kernels == oracle == frozen golden hashes, for out_comps 1, 3, 4."""
+    data = open(path, "rb").read()
+    name = os.path.basename(path)[:-4]
+    buf = np.frombuffer(data, np.uint8)
+    fr = _capi.JpegFrame()
+    _capi.check(hip.gamut_hip_jpeg_decode_coeffs(buf.ctypes.data, buf.size, C.byref(fr)))
+    nblk = fr.mcus_per_row * fr.mcus_per_col * fr.blocks_per_mcu
+    co = np.ctypeslib.as_array(fr.coeffs, (nblk, 64)).copy()
+    mz = np.ctypeslib.as_array(fr.max_zag, (nblk,)).copy()
+    w, h, comps, st = fr.width, fr.height, fr.comps, fr.scan_type
+    hip.gamut_hip_jpeg_frame_free(C.byref(fr))
+    for rc in (1, 3, 4):
+        exp = O.jpeg_reconstruct(w, h, comps, st, co, mz, rc)
+        got = gpu_reconstruct(hip, w, h, st, co[None], mz[None], rc)[0]
+        assert np.array_equal(got, exp), f"{name} comps{rc}: {np.count_nonzero(got != exp)} bytes differ"
+        assert sha(got) == GOLDEN["frozen"][f"{name}:comps{rc}"]
+        got_dense = gpu_reconstruct(hip, w, h, st, co[None], None, rc, pad=5)[0]      # max_zag = NULL: identical on real data
+        assert np.array_equal(got_dense, exp)
+
+
+@pytest.mark.parametrize("scan_type", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("kind", ["natural", "dense", "wild"])
+def test_random_coefficients(hip, scan_type, kind):
+    rng = np.random.default_rng(100 * scan_type + len(kind))
+    mw, mh = MCU[scan_type]
+    for (w, h) in [(1, 1), (17, 9), (130, 33), (16 * 9 + 3, 16 * 2), (257, 65)]:
+        nblk = ((w + mw - 1) // mw) * ((h + mh - 1) // mh) * NB[scan_type]
+        co = random_coeffs(rng, nblk, kind)
+        comps = 1 if scan_type == 0 else 3
+        for rc in (4, 3, 1):
+            exp = O.jpeg_reconstruct(w, h, comps, scan_type, co, None, rc)
+            got = gpu_reconstruct(hip, w, h, scan_type, co[None], None, rc, pad=(3 if rc != 4 else 8))[0]
+            assert np.array_equal(got, exp), f"st={scan_type} {kind} {w}x{h} comps{rc}: {np.count_nonzero(got != exp)} differ"
+
+
+@pytest.mark.parametrize("scan_type", [0, 1, 4])
+def test_sparse_paths_with_max_zag(hip, scan_type):
+    """m_mcu_block_max_zag drives the reference's sparse IDCT variants (jpegload.d:295-376); with full-range int16
+    coefficients the Col!(1) shortcut (max_zag <= 2) differs from the dense form by 32-bit wrap-around and must be matched."""
+    rng = np.random.default_rng(5 + scan_type)
+    mw, mh = MCU[scan_type]
+    w, h = 16 * 11 + 5, 16 * 3 + 1
+    nblk = ((w + mw - 1) // mw) * ((h + mh - 1) // mh) * NB[scan_type]
+    co = random_coeffs(rng, nblk, "wild")
+    mz = rng.choice([1, 2, 2, 2, 3, 4, 6, 10, 20, 36, 64], nblk).astype(np.uint8)
+    zag = np.array(ZAG)
+    for i in range(nblk):
+        co[i, zag[mz[i]:]] = 0
+    comps = 1 if scan_type == 0 else 3
+    exp = O.jpeg_reconstruct(w, h, comps, scan_type, co, mz, 4 if comps == 3 else 1)
+    dense = O.jpeg_reconstruct(w, h, comps, scan_type, co, None, 4 if comps == 3 else 1)
+    assert not np.array_equal(exp, dense), "test vector does not exercise the Col!1 overflow case"
+    got = gpu_reconstruct(hip, w, h, scan_type, co[None], mz[None], 4 if comps == 3 else 1)[0]
+    assert np.array_equal(got, exp)
+
+
+def test_batch_strides_and_1080p(hip):
+    """uniform batch launch: per-image strides honoured; one full-size 1920x1080 4:2:0 frame (BASELINE.json config 2 geometry)."""
+    rng = np.random.default_rng(42)
+    w, h, st = 1920, 1080, 4
+    nblk = 120 * 68 * 6
+    co = np.stack([random_coeffs(rng, nblk, "natural") for _ in range(3)])
+    got = gpu_reconstruct(hip, w, h, st, co, None, 4, count=3)
+    for i in range(3):
+        exp = O.jpeg_reconstruct(w, h, 3, st, co[i], None, 4)
+        assert np.array_equal(got[i], exp), f"image {i}"
+
+
+def test_descriptor_api_mixed_sizes(hip):
+    rng = np.random.default_rng(8)
+    jobs = [(100, 60, 4, 4), (33, 17, 1, 3), (64, 64, 0, 1), (250, 40, 2, 4)]
+    descs = (_capi.JpegDesc * len(jobs))()
+    keep, exps, outs = [], [], []
+    for i, (w, h, st, rc) in enumerate(jobs):
+        mw, mh = MCU[st]
+        nblk = ((w + mw - 1) // mw) * ((h + mh - 1) // mh) * NB[st]
+        co = random_coeffs(rng, nblk, "natural")
+        exps.append(O.jpeg_reconstruct(w, h, 1 if st == 0 else 3, st, co, None, rc))
+        dco = dev_upload(hip, co)
+        dout = dev_upload(hip, np.zeros(w * h * rc, np.uint8))
+        keep += [dco, dout]; outs.append((dout, w * h * rc))
+        descs[i].coeffs, descs[i].max_zag, descs[i].out, descs[i].out_pitch = dco, None, dout, w * rc
+        descs[i].width, descs[i].height, descs[i].scan_type, descs[i].out_comps = w, h, st, rc
+    _capi.check(hip.gamut_hip_jpeg_reconstruct_device(descs, len(jobs), None))
+    _capi.check(hip.gamut_hip_stream_synchronize(None))
+    for (dout, n), exp in zip(outs, exps):
+        got = np.empty(n, np.uint8)
+        _capi.check(hip.gamut_hip_memcpy_d2h(got.ctypes.data, dout, n, None))
+        _capi.check(hip.gamut_hip_stream_synchronize(None))
+        assert np.array_equal(got, exp.reshape(-1))
+    for p in keep:
+        hip.gamut_hip_device_free(p)
+
+
+@pytest.mark.parametrize("path", JPEGS, ids=[os.path.basename(p) for p in JPEGS])
+def test_host_dropin_decompress(hip, path):
+    """gamut_hip_decompress_jpeg_image_from_memory == decompress_jpeg_image_from_stream (jpegload.d:3720-3808)."""
+    data = open(path, "rb").read()
+    buf = np.frombuffer(data, np.uint8)
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    for rc in (-1, 1, 3, 4):
+        exp = O.decompress_jpeg(data, rc)
+        w, h, ac = C.c_int(), C.c_int(), C.c_int()
+        par, dpi = C.c_float(), C.c_float()
+        p = hip.gamut_hip_decompress_jpeg_image_from_memory(buf.ctypes.data, buf.size, C.byref(w), C.byref(h), C.byref(ac),
+                                                            C.byref(par), C.byref(dpi), rc)
+        assert p, hip.gamut_hip_last_error()
+        comps = ac.value if rc < 0 else rc
+        got = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (h.value, w.value * comps)).copy()
+        libc.free(p)
+        assert np.array_equal(got, exp[0])
+        assert (ac.value, par.value, dpi.value) == exp[1:]
+    # error convention: NULL + message, no exception (jpegload.d:3726-3733)
+    assert not hip.gamut_hip_decompress_jpeg_image_from_memory(buf.ctypes.data, buf.size, C.byref(w), C.byref(h), C.byref(ac),
+                                                                C.byref(par), C.byref(dpi), 2)
+    assert not hip.gamut_hip_decompress_jpeg_image_from_memory(buf.ctypes.data, 0, C.byref(w), C.byref(h), C.byref(ac),
+                                                                C.byref(par), C.byref(dpi), 4)
+    assert hip.gamut_hip_last_error() != b""

@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X Gamut hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): a batch of 1024 synthetic 1920x1080 baseline 4:2:0
+JPEGs per GPU, already entropy-decoded to dense de-quantised coefficients resident in HBM;
+one "step" = one pass of the hot path (8x8 IDCT + frequency-domain 4:2:0 chroma upsample +
+YCbCr->RGBA8) over the whole batch through the C ABI (gamut_hip_jpeg_reconstruct_batch_device).
+Images are independent, so ranks shard by image index with no data-path collective
+("scaling": "weak": every rank owns a full 1024-image batch).
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the launch
+stream; `cpu_baseline` is the CPU oracle (a scalar C restatement of the reference's loops,
+oracle/) timed on this box's host cores over a bounded sample of the same coefficients.
+Other kernels of the path: --workload convert:<src>:<dst> | png  (same JSON shape).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="images per GPU per step")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--workload", default="jpeg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def traffic_from_profiles(kernel_substr):
+    """HBM bytes per launch from the committed rocprofv3 --pmc summary (profiles/*traffic*.json), or None."""
+    import glob
+    best = None
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
+        try:
+            for row in json.load(open(p)).get("kernels", []):
+                if kernel_substr in row.get("kernel", ""):
+                    best = row.get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+    return best
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from gamut_amd import _capi, synth
+    L = _capi.lib()
+    _capi.check(L.gamut_hip_init(local_rank))
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # ------------------------------------------------------------------ workload
+    w, h, B = args.width, args.height, args.batch
+    wl = args.workload
+    check = None
+    if wl == "jpeg":
+        coeffs = synth.jpeg_coeff_batch(B, w, h, dev, seed=1 + rank)
+        nblk = coeffs.shape[1]
+        out = torch.empty((B, h, w * 4), dtype=torch.uint8, device=dev)
+        px_per_step = B * w * h
+        bytes_per_step = B * (nblk * 128 + w * h * 4)            # 6 266 880 + 8 294 400 per 1080p image
+        kernel_name = "k_jpeg_h2v2_rgba8"
+        workload = f"batch {B} x {w}x{h} baseline JPEG 4:2:0, IDCT + freq-domain chroma upsample + YCbCr->RGBA8"
+
+        def step():
+            _capi.check(L.gamut_hip_jpeg_reconstruct_batch_device(coeffs.data_ptr(), nblk * 64, None, 0, out.data_ptr(), w * 4,
+                                                                   h * w * 4, w, h, 4, 4, B, stream))
+
+        def check():
+            import oracle_lib as O
+            step()
+            torch.cuda.synchronize()
+            for i in sorted({0, B - 1}):
+                exp = O.jpeg_reconstruct(w, h, 3, O.JPGD_YH2V2, coeffs[i].cpu().numpy(), None, 4)
+                if not np.array_equal(out[i].cpu().numpy(), exp):
+                    raise SystemExit(f"PARITY FAILURE on image {i}")
+
+        def cpu_leg(seconds):
+            import oracle_lib as O
+            host = [coeffs[i].cpu().numpy() for i in range(min(B, 64))]
+            O.jpeg_reconstruct(w, h, 3, O.JPGD_YH2V2, host[0], None, 4)           # warm
+            n, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < seconds:
+                O.jpeg_reconstruct(w, h, 3, O.JPGD_YH2V2, host[n % len(host)], None, 4)
+                n += 1
+            dt = time.perf_counter() - t0
+            return n * w * h / dt / 1e6, f"{n} of the batch's {w}x{h} coefficient frames, coefficients -> rgba8, single thread, {dt:.1f} s"
+        dtype = "int32"
+    elif wl.startswith("convert:"):
+        import oracle_lib as O
+        _, s, d = wl.split(":")
+        st, dt_ = O.PT[s], O.PT[d]
+        B = args.batch if args.batch != 1024 else 8
+        w = h = 8192 if (args.width, args.height) == (1920, 1080) else args.width
+        npx = w * h
+        g = torch.Generator(device=dev); g.manual_seed(7 + rank)
+        sdt = O.PT_DTYPE[st]
+        if sdt == np.float32:
+            src = torch.rand((B, npx * O.PT_CHANNELS[st]), device=dev, generator=g, dtype=torch.float32)
+        elif sdt == np.uint16:
+            src = torch.randint(0, 65536, (B, npx * O.PT_CHANNELS[st]), device=dev, generator=g, dtype=torch.int32).to(torch.uint16)
+        else:
+            src = torch.randint(0, 256, (B, npx * O.PT_CHANNELS[st]), device=dev, generator=g, dtype=torch.int32).to(torch.uint8)
+        out = torch.empty((B, npx * O.PT_SIZE[dt_]), dtype=torch.uint8, device=dev)
+        px_per_step = B * npx
+        bytes_per_step = px_per_step * (O.PT_SIZE[st] + O.PT_SIZE[dt_])
+        kernel_name = "k_convert_vec"
+        workload = f"convertTo {s}->{d}, {B} layers of {w}x{h}, gapless"
+        sp, dp = w * O.PT_SIZE[st], w * O.PT_SIZE[dt_]
+
+        def step():
+            _capi.check(L.gamut_hip_scanlines_convert_device(st, src.data_ptr(), sp, sp * h, dt_, out.data_ptr(), dp, dp * h,
+                                                              w, h, B, stream))
+
+        def check():
+            step()
+            torch.cuda.synchronize()
+            rows = 4
+            a = src[B - 1].view(torch.uint8)[:rows * sp].cpu().numpy()
+            exp = O.scanlines_convert(st, a, dt_, w, rows)
+            if not np.array_equal(out[B - 1][:rows * dp].cpu().numpy(), exp):
+                raise SystemExit("PARITY FAILURE")
+
+        def cpu_leg(seconds):
+            rows = 256
+            a = src[0].view(torch.uint8)[:rows * sp].cpu().numpy()
+            n, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < seconds:
+                O.scanlines_convert(st, a, dt_, w, rows)
+                n += 1
+            dt = time.perf_counter() - t0
+            return n * rows * w / dt / 1e6, f"{n} x {rows} rows of {w} px, scanlinesConvert, single thread, {dt:.1f} s"
+        dtype = "f32"
+    else:
+        raise SystemExit(f"unknown workload {wl}")
+
+    if check is not None and rank == 0:
+        check()
+
+    # ------------------------------------------------------------------ timing
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record()
+        step()
+        b.record()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms = [a.elapsed_time(b) for a, b in evs]
+
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        avg_kernel_s = float(np.mean(kern_ms)) * 1e-3
+        achieved = bytes_per_step / avg_kernel_s / 1e9
+        res = {
+            "metric": "Mpixels/sec decoded (batched 1080p JPEG 4:2:0)" if wl == "jpeg" else f"Mpixels/sec ({wl})",
+            "value": round(world * px_per_step * args.steps / elapsed / 1e6, 1),
+            "unit": "Mpx/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": dtype, "data": "synthetic",
+            "config": {"workload": workload, "images_per_gpu_per_step": B, "sharding": "image-index, no collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic_from_profiles(kernel_name),
+                         "kernel": kernel_name, "algorithmic_bytes_per_launch": bytes_per_step,
+                         "kernel_ms_avg": round(avg_kernel_s * 1e3, 4), "kernel_ms_min": round(min(kern_ms), 4)},
+        }
+        if world == 1 and not args.no_cpu:
+            v, sample = cpu_leg(args.cpu_seconds)
+            res["cpu_baseline"] = {"value": round(v, 2), "unit": "Mpx/s", "cores": 1, "kind": "port", "sample": sample}
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -16,9 +16,11 @@ char* last_error_buf();
 int   set_error(int status, const char* fmt, ...);
 inline void clear_error() { last_error_buf()[0] = 0; }
 
-// per-thread default stream (created lazily, non-blocking w.r.t. the null stream)
+// per-thread private stream used by the synchronous host drop-ins (created lazily)
 hipStream_t thread_stream();
-inline hipStream_t pick_stream(void* s) { return s ? reinterpret_cast<hipStream_t>(s) : thread_stream(); }
+// device entry points: the caller's hipStream_t; NULL is HIP's null (legacy default) stream, so work
+// enqueued by a caller that never touches streams is ordered with everything else it does
+inline hipStream_t pick_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 #define GAMUT_HIP_CHECK(expr)                                                                 \
     do {                                                                                      \

@@ -1,0 +1,78 @@
+"""Synthetic, seeded workloads for bench.py / smoke(), built on the GPU with torch.
+
+torch is plumbing here (device memory + fast input synthesis); nothing in this file is
+on the measured path.  The JPEG batch is produced the way an encoder would: smooth-plus-
+noise RGB -> YCbCr -> 4:2:0 -> forward DCT -> quantise with the Annex-K tables at q=90
+-> de-quantise -> int16, laid out in MCU order, i.e. exactly the dense coefficient form
+decode_next_row (jpegload.d:2405-2525) hands to transform_mcu_expand.
+"""
+import math
+
+import torch
+
+# ITU T.81 Annex K.1 / K.2 (natural order)
+_LUMA_Q = [16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+           18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99]
+_CHROMA_Q = [17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99,
+             99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99]
+
+
+def _qtable(base, quality, device):
+    scale = 5000 // quality if quality < 50 else 200 - 2 * quality      # libjpeg jpeg_quality_scaling
+    q = (torch.tensor(base, dtype=torch.float32, device=device) * scale + 50).div(100, rounding_mode="floor").clamp(1, 255)
+    return q.reshape(8, 8)
+
+
+def _dct_matrix(device):
+    k = torch.arange(8, dtype=torch.float64, device=device)
+    c = torch.cos((2 * k[None, :] + 1) * k[:, None] * math.pi / 16) * 0.5
+    c[0, :] *= 1 / math.sqrt(2)
+    return c.to(torch.float32)
+
+
+def synth_rgb_batch(n, width, height, device, seed):
+    """(n, 3, height, width) float32 in [0,255]: 3 low-frequency sinusoids per channel (amplitude <= 100 in total) + noise +-4."""
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    yy = torch.arange(height, dtype=torch.float32, device=device)[None, None, :, None]
+    xx = torch.arange(width, dtype=torch.float32, device=device)[None, None, None, :]
+    img = torch.full((n, 3, height, width), 128.0, device=device)
+    for _ in range(3):
+        fx = (torch.rand((n, 3, 1, 1), device=device, generator=g) * 5.5 + 0.5) * (2 * math.pi / max(width, height))
+        fy = (torch.rand((n, 3, 1, 1), device=device, generator=g) * 5.5 + 0.5) * (2 * math.pi / max(width, height))
+        ph = torch.rand((n, 3, 1, 1), device=device, generator=g) * (2 * math.pi)
+        amp = torch.rand((n, 3, 1, 1), device=device, generator=g) * 23.3 + 10.0
+        img += amp * torch.sin(xx * fx + yy * fy + ph)
+    img += torch.randint(-4, 5, img.shape, device=device, generator=g).to(torch.float32)
+    return img.clamp_(0, 255).floor_()
+
+
+def jpeg_coeff_batch(n, width, height, device, seed=0, quality=90, chunk=16):
+    """Dense de-quantised coefficients of n synthetic 4:2:0 images: int16 tensor (n, MY*MX*6, 64)."""
+    my, mx = (height + 15) // 16, (width + 15) // 16
+    hp, wp = my * 16, mx * 16
+    d = _dct_matrix(device)
+    ql, qc = _qtable(_LUMA_Q, quality, device), _qtable(_CHROMA_Q, quality, device)
+    out = torch.empty((n, my * mx * 6, 64), dtype=torch.int16, device=device)
+    for i0 in range(0, n, chunk):
+        c = min(chunk, n - i0)
+        rgb = synth_rgb_batch(c, width, height, device, seed * 1000003 + i0)
+        rgb = torch.nn.functional.pad(rgb, (0, wp - width, 0, hp - height), mode="replicate")
+        r, g, b = rgb[:, 0], rgb[:, 1], rgb[:, 2]
+        y = 0.299 * r + 0.587 * g + 0.114 * b - 128.0
+        cb = -0.168736 * r - 0.331264 * g + 0.5 * b
+        cr = 0.5 * r - 0.418688 * g - 0.081312 * b
+        cb = torch.nn.functional.avg_pool2d(cb[:, None], 2)[:, 0]
+        cr = torch.nn.functional.avg_pool2d(cr[:, None], 2)[:, 0]
+
+        def fdct_quant(p, q):
+            cc, h, w = p.shape
+            blk = p.reshape(cc, h // 8, 8, w // 8, 8).permute(0, 1, 3, 2, 4)            # (c, by, bx, 8, 8)
+            f = d @ blk @ d.T
+            return (torch.round(f / q) * q).clamp_(-32768, 32767).to(torch.int16)
+
+        yb = fdct_quant(y, ql).reshape(c, my, 2, mx, 2, 64).permute(0, 1, 3, 2, 4, 5).reshape(c, my, mx, 4, 64)
+        cbb = fdct_quant(cb, qc).reshape(c, my, mx, 1, 64)
+        crb = fdct_quant(cr, qc).reshape(c, my, mx, 1, 64)
+        out[i0:i0 + c] = torch.cat([yb, cbb, crb], dim=3).reshape(c, my * mx * 6, 64)
+    return out

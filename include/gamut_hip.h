@@ -16,8 +16,8 @@
  *   - "host" entry points take host pointers, are synchronous, and return
  *     malloc()-compatible memory where the reference does (free() it)
  *   - "device" entry points take HBM pointers, enqueue on the given hipStream_t
- *     (passed as void*, NULL = the library's per-thread default stream) and do
- *     not synchronise; results stay resident in HBM
+ *     (passed as void*, NULL = HIP's null stream) and do not synchronise;
+ *     results stay resident in HBM
  *   - thread-safe: no mutable global state besides lazily created per-thread
  *     streams; concurrent calls on different images are safe
  */

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output directories into small files fit for profiles/:
+   <out>/kernel_stats.csv      copy of the --stats per-kernel summary
+   <out>/traffic.json          per-kernel HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes
+FETCH_SIZE / WRITE_SIZE are reported in KiB-like units of 1024 B? -- no: rocprofv3 reports them in KB
+(derived: TCC_EA0_RDREQ*64 B /1024 ...).  Per /opt/skills/guides/MI355X_MICROARCH.md (HBM section) on
+gfx950 FETCH_SIZE reads exactly half of a wide (16 B/lane) coalesced read stream, so the corrected
+read bytes are 2 * FETCH_SIZE * 1024; WRITE_SIZE is taken as reported (uncalibrated there)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+
+def find(d, pat):
+    return sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))
+
+
+def counter_avg(d, counter):
+    acc = defaultdict(lambda: [0.0, 0])
+    for f in find(d, "*counter_collection.csv"):
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") != counter:
+                continue
+            k = row["Kernel_Name"]
+            acc[k][0] += float(row["Counter_Value"])
+            acc[k][1] += 1
+    return {k: (v[0] / v[1], v[1]) for k, v in acc.items()}
+
+
+def main():
+    base, out = sys.argv[1], sys.argv[2]
+    os.makedirs(out, exist_ok=True)
+    for f in find(os.path.join(base, "trace"), "*kernel_stats.csv"):
+        shutil.copy(f, os.path.join(out, "kernel_stats.csv"))
+    fetch = counter_avg(os.path.join(base, "pmc_fetch"), "FETCH_SIZE")
+    write = counter_avg(os.path.join(base, "pmc_write"), "WRITE_SIZE")
+    kernels = []
+    for k in sorted(set(fetch) | set(write)):
+        f, nf = fetch.get(k, (None, 0))
+        w, nw = write.get(k, (None, 0))
+        row = {"kernel": k, "dispatches_fetch_pass": nf, "dispatches_write_pass": nw,
+               "FETCH_SIZE_raw_avg": f, "WRITE_SIZE_raw_avg": w}
+        if f is not None and w is not None:
+            row["read_bytes_corrected"] = 2 * f * 1024
+            row["write_bytes"] = w * 1024
+            row["hbm_bytes_per_launch"] = 2 * f * 1024 + w * 1024
+        kernels.append(row)
+    json.dump({"note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); units KB->B",
+               "kernels": kernels}, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+    print(json.dumps(kernels, indent=1)[:3000])
+
+
+if __name__ == "__main__":
+    main()

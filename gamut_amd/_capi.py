@@ -64,8 +64,8 @@ SIGNATURES = {
     "gamut_hip_jpeg_decode_coeffs": (_i, [_vp, _sz, C.POINTER(JpegFrame)]),
     "gamut_hip_jpeg_frame_free": (None, [C.POINTER(JpegFrame)]),
     "gamut_hip_decompress_jpeg_image_from_memory": (_vp, [_vp, _sz, _pi, _pi, _pi, _pf, _pf, _i]),
-    "gamut_hip_png_defilter_device": (_i, [C.POINTER(PngDesc), _i, _vp]),
-    "gamut_hip_png_defilter_batch_device": (_i, [_vp, _i64, _u32, _vp, _i64, _u32, _u32, _i, _i, _i, _i, _i, _vp]),
+    "gamut_hip_png_defilter_device": (_i, [C.POINTER(PngDesc), _i, _vp, _vp]),
+    "gamut_hip_png_defilter_batch_device": (_i, [_vp, _i64, _u32, _vp, _i64, _u32, _u32, _i, _i, _i, _i, _i, _vp, _vp]),
     "gamut_hip_stbi_load_from_memory": (_vp, [_vp, _sz, _pi, _pi, _pi, _i, _pf, _pf, _pf]),
     "gamut_hip_stbi_load_16_from_memory": (_vp, [_vp, _sz, _pi, _pi, _pi, _i, _pf, _pf, _pf]),
     "gamut_hip_png_is16": (_i, [_vp, _sz]),

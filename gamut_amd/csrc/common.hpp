@@ -55,6 +55,12 @@ int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
 int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len,
                         uint8_t* out, int64_t out_stride,
                         uint32_t x, uint32_t y, int img_n, int out_n, int depth, int color,
-                        int count, hipStream_t stream);
+                        int count, uint32_t* status, hipStream_t stream);
+
+int png_transparency_launch(void* img, int64_t npx, int out_n, int depth16, const uint16_t tc[3], hipStream_t st);
+int png_palette_launch(const uint8_t* idx, uint8_t* out, int64_t npx, int pal_n, const uint8_t* palette_dev, hipStream_t st);
+int png_convert_format_launch(const void* src, void* dst, int64_t npx, int img_n, int req, int depth16, hipStream_t st);
+int png_depth_convert_launch(const void* src, void* dst, int64_t n, int to16, hipStream_t st);
+int png_adam7_scatter_launch(const uint8_t* pass, uint8_t* final_, uint32_t px, uint32_t py, uint32_t img_x, int out_bytes, int p, hipStream_t st);
 
 } // namespace gamut

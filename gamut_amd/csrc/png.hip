@@ -1,0 +1,395 @@
+// png.hip -- K5-K7: PNG row de-filter (None/Sub/Up/Avg/Paeth) + bit-depth / alpha / endian expand.
+//
+// Replaces stbi__create_png_image_raw (stbdec.d:1406-1635) and the post passes
+// stbi__compute_transparency(16) :1682-1730, stbi__expand_png_palette :1732-1765,
+// stbi__convert_format(16) :916-1199, stbi__convert_16_to_8 / _8_to_16 :635-666.
+//
+// De-filter is the only non-trivially-parallel loop of the whole path: byte (x,y) depends on
+// its left, upper and upper-left neighbours (Paeth), so the dependency graph is a 2-D
+// wavefront.  Mapping used here:
+//   * one workgroup of W waves per image; wave w owns the 64-row bands w, w+W, w+2W, ...
+//   * inside a band lane = row; lane j runs one "iteration" (4 filter units = 4*FB bytes)
+//     behind lane j-1, so the upper neighbours arrive from lane j-1 with one DPP row shift
+//     of the FB dwords it produced in the previous iteration; the left neighbours are the
+//     lane's own previous outputs (registers)
+//   * lane 0 of band b needs the last row of band b-1, produced by another wave of the same
+//     workgroup: it is read back from the output rows in HBM/L2 (full-row capacity, so no
+//     back-pressure is needed), gated by a monotonic per-wave progress counter in LDS with a
+//     workgroup-scope release (producer) / acquire (consumer) pair.  Consecutive bands run
+//     ~64 iterations apart, so all W waves are busy at once.
+//   * the per-row filter type is data: None/Sub/Up/Avg are one masked form
+//     ((a & ma) + (b & mb)) >> sh; the Paeth predictor is evaluated only while some row of
+//     the wave's band uses it (wave-uniform branch).
+// With zero neighbours outside the image the PNG formulas reproduce stb's first-row /
+// first-pixel special cases exactly (stbdec.d:1381-1388, :1453-1465).
+#include "common.hpp"
+
+namespace gamut {
+namespace {
+
+typedef uint32_t u32;
+
+constexpr int PNG_WAVES = 16;          // waves per workgroup (= bands in flight per image)
+constexpr int PUB = 8;                 // publish / check progress every PUB iterations (32 filter units)
+
+struct DefilterArgs {
+    const uint8_t* raw; int64_t raw_stride;      // inflated stream(s): per row 1 filter byte + wb bytes
+    uint8_t* D; int64_t d_stride; int64_t d_pitch;   // de-filtered rows (pitch % 4 == 0)
+    u32* status;                                 // per image, |= 1 on an invalid filter byte (stbdec.d:1438)
+    u32 rows, wb;                                // rows, bytes per row
+    u32 store_tail_masked;                       // 1: D rows are tight (fused output) -> never write past wb
+};
+
+__device__ __forceinline__ u32 byte_of(const u32* g, int idx) { return (g[idx >> 2] >> ((idx & 3) * 8)) & 0xFFu; }
+
+// stbi__paeth, stbdec.d:1390-1401
+__device__ __forceinline__ u32 paeth(u32 a, u32 b, u32 c)
+{
+    const int pa = abs((int)b - (int)c), pb = abs((int)a - (int)c), pc = abs((int)a + (int)b - 2 * (int)c);
+    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+// shift a dword one lane up the wave (lane j receives lane j-1's value; lane 0 keeps `fill`):
+// one DPP move, wave_shr:1 (gfx9 DPP control 0x138), bound_ctrl off so lane 0 retains `old`
+__device__ __forceinline__ u32 from_lane_below(u32 v, u32 fill)
+{
+    return (u32)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xF, 0xF, false);
+}
+
+template <int FB>
+__global__ __launch_bounds__(PNG_WAVES * 64) void k_png_defilter(DefilterArgs a)
+{
+    __shared__ u32 prog[PNG_WAVES];               // cumulative iterations finished (and visible) by each wave's lane 63
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int img = blockIdx.x;
+    const uint8_t* raw = a.raw + (int64_t)img * a.raw_stride;
+    uint8_t* D = a.D + (int64_t)img * a.d_stride;
+    const u32 npix = a.wb / FB;                   // filter units per row
+    const u32 niter = (npix + 3) / 4;
+    const u32 nbands = (a.rows + 63) / 64;
+    if (threadIdx.x < PNG_WAVES) prog[threadIdx.x] = 0;
+    __syncthreads();
+
+    for (u32 band = wave; band < nbands; band += PNG_WAVES) {
+        const u32 seq = band / PNG_WAVES;
+        const u32 row = band * 64 + lane;
+        const bool row_live = row < a.rows;
+        const uint8_t* rp = raw + (int64_t)(row_live ? row : 0) * (a.wb + 1);
+        u32 f = row_live ? rp[0] : 0;
+        if (f > 4) { if (a.status) atomicOr(a.status + img, 1u); f = 0; }
+        const u32 ma = (f == 1 || f == 3 || f == 4) ? 0xFFu : 0u;
+        const u32 mb = (f == 2 || f == 3 || f == 4) ? 0xFFu : 0u;
+        const u32 sh = (f == 3) ? 1u : 0u;
+        const bool is_paeth = f == 4;
+        const bool any_paeth = __any(is_paeth && row_live);
+
+        // aligned view of this lane's filtered bytes
+        const uintptr_t rstart = (uintptr_t)(rp + 1);
+        const u32* rword = (const u32*)(rstart & ~(uintptr_t)3);
+        const u32 rshift = (u32)(rstart & 3);
+        const u32* rlast = (const u32*)(((uintptr_t)raw + (uint64_t)a.rows * (a.wb + 1) - 1) & ~(uintptr_t)3);   // last dword holding a valid byte
+        uint8_t* drow = D + (int64_t)(row_live ? row : 0) * a.d_pitch;
+        const uint8_t* dprev = D + (int64_t)(band * 64 - 1) * a.d_pitch;        // row above lane 0 (band > 0 only)
+        const int prod_wave = (wave + PNG_WAVES - 1) % PNG_WAVES;
+        const u32 prod_base = (band > 0 ? (band - 1) / PNG_WAVES : 0) * niter;
+
+        u32 outp[FB], bp[FB];                     // previous iteration: own outputs, upper-row values
+        #pragma unroll
+        for (int i = 0; i < FB; ++i) { outp[i] = 0; bp[i] = 0; }
+        u32 carry = 0;                            // last aligned raw dword of the previous iteration
+        if (row_live) carry = *(rword < rlast ? rword : rlast);
+
+        const u32 T_end = niter + 63;
+        for (u32 T = 0; T < T_end; ++T) {
+            const int it = (int)T - lane;
+            const bool live = row_live && it >= 0 && it < (int)niter;
+
+            // consumer side of the band hand-off (wave-uniform)
+            if (band > 0 && T < niter && (T % PUB) == 0) {
+                const u32 need = prod_base + min(niter, T + PUB);
+                while (__hip_atomic_load(&prog[prod_wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
+                    __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+
+            // raw bytes of this iteration: FB dwords starting rshift bytes into the aligned stream
+            u32 rg[FB];
+            {
+                const u32* p = rword + (int64_t)(it < 0 ? 0 : it) * FB + 1;
+                u32 prev = carry;
+                #pragma unroll
+                for (int i = 0; i < FB; ++i) {
+                    u32 w = 0;
+                    if (live) w = *((p + i) < rlast ? (p + i) : rlast);
+                    rg[i] = __builtin_amdgcn_alignbyte(w, prev, rshift);
+                    prev = w;
+                }
+                if (live) carry = prev;
+            }
+            // upper row: lane j-1's outputs of its previous loop trip; lane 0 reads the band above from memory
+            u32 bg[FB];
+            #pragma unroll
+            for (int i = 0; i < FB; ++i) {
+                u32 fill = 0;
+                if (lane == 0 && band > 0 && live) fill = ((const u32*)dprev)[(int64_t)it * FB + i];
+                bg[i] = from_lane_below(outp[i], fill);
+            }
+
+            u32 og[FB];
+            #pragma unroll
+            for (int i = 0; i < FB; ++i) og[i] = 0;
+            #pragma unroll
+            for (int k = 0; k < 4 * FB; ++k) {        // byte k of the group; its left / upper-left neighbours are FB bytes back
+                const u32 x  = byte_of(rg, k);
+                const u32 bb = byte_of(bg, k);
+                const u32 aa = k >= FB ? byte_of(og, k - FB) : byte_of(outp, 3 * FB + k);
+                const u32 cc = k >= FB ? byte_of(bg, k - FB) : byte_of(bp, 3 * FB + k);
+                u32 pred = ((aa & ma) + (bb & mb)) >> sh;
+                if (any_paeth) { const u32 pp = paeth(aa, bb, cc); pred = is_paeth ? pp : pred; }
+                og[k >> 2] |= ((x + pred) & 0xFFu) << ((k & 3) * 8);
+            }
+
+            if (live) {
+                #pragma unroll
+                for (int i = 0; i < FB; ++i) { outp[i] = og[i]; bp[i] = bg[i]; }
+                uint8_t* dst = drow + (int64_t)it * (4 * FB);
+                const u32 valid = min(4u * FB, a.wb - (u32)it * (4 * FB));     // bytes of this group inside the row
+                if (valid == 4 * FB || !a.store_tail_masked) {
+                    if constexpr (FB == 4) *reinterpret_cast<uint4*>(dst) = make_uint4(og[0], og[1], og[2], og[3]);
+                    else if constexpr (FB == 2 || FB == 6) {
+                        #pragma unroll
+                        for (int i = 0; i < FB; i += 2) *reinterpret_cast<uint2*>(dst + 4 * i) = make_uint2(og[i], og[i + 1]);
+                    } else if constexpr (FB == 8) {
+                        *reinterpret_cast<uint4*>(dst) = make_uint4(og[0], og[1], og[2], og[3]);
+                        *reinterpret_cast<uint4*>(dst + 16) = make_uint4(og[4], og[5], og[6], og[7]);
+                    } else {
+                        #pragma unroll
+                        for (int i = 0; i < FB; ++i) reinterpret_cast<u32*>(dst)[i] = og[i];
+                    }
+                } else {
+                    for (u32 i = 0; i < valid; ++i) dst[i] = (uint8_t)(og[i >> 2] >> ((i & 3) * 8));
+                }
+            }
+
+            // producer side: lane 63 finished iteration T-63
+            const int it63 = (int)T - 63;
+            if (it63 >= 0 && (((it63 + 1) % PUB) == 0 || it63 == (int)niter - 1)) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 63)
+                    __hip_atomic_store(&prog[wave], seq * niter + (u32)it63 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+}
+
+// ---- stage B: expand de-filtered rows into the output image (stbdec.d:1467-1480, 1504-1546, 1552-1632) ----
+struct ExpandArgs {
+    const uint8_t* D; int64_t d_stride; int64_t d_pitch;
+    uint8_t* out; int64_t out_stride;
+    u32 x, y; int img_n, out_n, depth, color;
+};
+__global__ __launch_bounds__(256) void k_png_expand(ExpandArgs a)
+{
+    const int img = blockIdx.y;
+    const uint8_t* D = a.D + (int64_t)img * a.d_stride;
+    uint8_t* out = a.out + (int64_t)img * a.out_stride;
+    const int64_t npx = (int64_t)a.x * a.y;
+    const int bytes = a.depth == 16 ? 2 : 1;
+    const u32 scale = (a.color == 0) ? (a.depth == 1 ? 0xFFu : a.depth == 2 ? 0x55u : a.depth == 4 ? 0x11u : 1u) : 1u;   // stbi__depth_scale_table :1403
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npx; p += (int64_t)gridDim.x * 256) {
+        const u32 row = (u32)(p / a.x), col = (u32)(p - (int64_t)row * a.x);
+        const uint8_t* d = D + (int64_t)row * a.d_pitch;
+        uint8_t* o = out + p * (a.out_n * bytes);
+        for (int ch = 0; ch < a.out_n; ++ch) {
+            if (ch < a.img_n) {
+                const u32 s = col * a.img_n + ch;                 // sample index in the row
+                if (a.depth == 8) o[ch] = d[s];
+                else if (a.depth == 16) { o[2 * ch] = d[2 * s + 1]; o[2 * ch + 1] = d[2 * s]; }      // (hi << 8) | lo, little-endian store
+                else {
+                    const u32 per = 8 / a.depth, byte = d[s / per];
+                    const u32 v = (byte >> (8 - a.depth - (s % per) * a.depth)) & ((1u << a.depth) - 1);
+                    o[ch] = (uint8_t)(scale * v);
+                }
+            } else {                                              // inserted alpha = 255 / 65535
+                if (bytes == 2) { o[2 * ch] = 255; o[2 * ch + 1] = 255; } else o[ch] = 255;
+            }
+        }
+    }
+}
+
+
+// ---- post passes (one thread per pixel) --------------------------------------------------------
+// stbi__compute_transparency / 16 (stbdec.d:1682-1730): colour-key -> alpha
+template <typename T>
+__global__ __launch_bounds__(256) void k_png_transparency(T* p, int64_t npx, int out_n, T t0, T t1, T t2, T maxv)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npx; i += (int64_t)gridDim.x * 256) {
+        T* q = p + i * out_n;
+        if (out_n == 2) q[1] = (q[0] == t0) ? 0 : maxv;
+        else if (q[0] == t0 && q[1] == t1 && q[2] == t2) q[3] = 0;
+    }
+}
+// stbi__expand_png_palette (:1732-1765); palette = 256 x RGBA in HBM
+__global__ __launch_bounds__(256) void k_png_palette(const uint8_t* idx, uint8_t* out, int64_t npx, int pal_n, const uint8_t* palette)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npx; i += (int64_t)gridDim.x * 256) {
+        const uint8_t* e = palette + (int)idx[i] * 4;
+        uint8_t* o = out + i * pal_n;
+        o[0] = e[0]; o[1] = e[1]; o[2] = e[2];
+        if (pal_n == 4) o[3] = e[3];
+    }
+}
+// stbi__convert_format / 16 (:916-1199); luma = (77 r + 150 g + 29 b) >> 8 (:911-914)
+template <typename T>
+__global__ __launch_bounds__(256) void k_png_convert_format(const T* src, T* dst, int64_t npx, int img_n, int req, T maxv)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npx; i += (int64_t)gridDim.x * 256) {
+        const T* s = src + i * img_n; T* d = dst + i * req;
+        const T y = img_n >= 3 ? (T)(((int)s[0] * 77 + (int)s[1] * 150 + 29 * (int)s[2]) >> 8) : s[0];
+        switch (img_n * 8 + req) {
+        case 1*8+2: d[0] = s[0]; d[1] = maxv; break;
+        case 1*8+3: d[0] = d[1] = d[2] = s[0]; break;
+        case 1*8+4: d[0] = d[1] = d[2] = s[0]; d[3] = maxv; break;
+        case 2*8+1: d[0] = s[0]; break;
+        case 2*8+3: d[0] = d[1] = d[2] = s[0]; break;
+        case 2*8+4: d[0] = d[1] = d[2] = s[0]; d[3] = s[1]; break;
+        case 3*8+4: d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = maxv; break;
+        case 3*8+1: d[0] = y; break;
+        case 3*8+2: d[0] = y; d[1] = maxv; break;
+        case 4*8+1: d[0] = y; break;
+        case 4*8+2: d[0] = y; d[1] = s[3]; break;
+        case 4*8+3: d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; break;
+        default: break;
+        }
+    }
+}
+// stbi__convert_16_to_8 (:635-649, >> 8) and stbi__convert_8_to_16 (:651-666, * 257)
+__global__ __launch_bounds__(256) void k_png_16_to_8(const uint16_t* src, uint8_t* dst, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = (uint8_t)((src[i] >> 8) & 0xFF);
+}
+__global__ __launch_bounds__(256) void k_png_8_to_16(const uint8_t* src, uint16_t* dst, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = (uint16_t)((src[i] << 8) + src[i]);
+}
+// Adam7 scatter of one pass into the final image (stbi__create_png_image :1664-1671)
+__global__ __launch_bounds__(256) void k_png_adam7_scatter(const uint8_t* pass, uint8_t* final_, u32 px, u32 py, u32 img_x, int out_bytes,
+                                                           int xorig, int yorig, int xspc, int yspc)
+{
+    const int64_t n = (int64_t)px * py;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const u32 j = (u32)(i / px), ii = (u32)(i - (int64_t)j * px);
+        const uint8_t* s = pass + i * out_bytes;
+        uint8_t* d = final_ + ((int64_t)(j * yspc + yorig) * img_x + (ii * xspc + xorig)) * out_bytes;
+        for (int b = 0; b < out_bytes; ++b) d[b] = s[b];
+    }
+}
+
+inline int blocks_for(int64_t n) { int64_t b = (n + 255) / 256; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
+
+struct Scratch {      // per-thread scratch for de-filtered rows of formats that need stage B
+    void* p = nullptr; size_t cap = 0;       // intentionally not freed at thread exit (the HIP runtime may already be gone)
+    void* get(size_t n)
+    {
+        if (n > cap) {
+            if (p) { (void)hipDeviceSynchronize(); (void)hipFree(p); p = nullptr; cap = 0; }
+            if (hipMalloc(&p, n) != hipSuccess) { p = nullptr; return nullptr; }
+            cap = n;
+        }
+        return p;
+    }
+};
+
+} // namespace
+
+int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len,
+                         uint8_t* out, int64_t out_stride,
+                         uint32_t x, uint32_t y, int img_n, int out_n, int depth, int color,
+                         int count, uint32_t* status, hipStream_t stream)
+{
+    // validation as in stbi__create_png_image_raw (stbdec.d:1419-1430, 1441-1442) and parse_png_file (:1890-1906)
+    if (depth != 1 && depth != 2 && depth != 4 && depth != 8 && depth != 16)
+        return set_error(GAMUT_HIP_ERR_INVALID_ARG, "png_defilter: depth must be 1/2/4/8/16");
+    if (img_n < 1 || img_n > 4 || !(out_n == img_n || out_n == img_n + 1) || out_n > 4)
+        return set_error(GAMUT_HIP_ERR_INVALID_ARG, "png_defilter: bad channel counts %d -> %d", img_n, out_n);
+    if (x == 0 || y == 0 || x > (1u << 24) || y > (1u << 24) || (1u << 30) / x / (uint32_t)img_n < y)
+        return set_error(GAMUT_HIP_ERR_INVALID_ARG, "png_defilter: bad image size");
+    if (count < 0) return set_error(GAMUT_HIP_ERR_INVALID_ARG, "png_defilter: negative count");
+    if (count == 0) return GAMUT_HIP_OK;
+    if (!raw || !out) return set_error(GAMUT_HIP_ERR_INVALID_ARG, "png_defilter: null pointer");
+    const uint32_t wb = ((uint32_t)img_n * x * (uint32_t)depth + 7) >> 3;
+    if ((uint64_t)raw_len < ((uint64_t)wb + 1) * y)
+        return set_error(GAMUT_HIP_ERR_DECODE, "png_defilter: not enough pixels (raw_len %u < %llu)", raw_len, (unsigned long long)((uint64_t)wb + 1) * y);
+    if (depth < 8 && wb > x) return set_error(GAMUT_HIP_ERR_DECODE, "png_defilter: invalid width");
+
+    const int bytes = depth == 16 ? 2 : 1;
+    const int FB = depth < 8 ? 1 : img_n * bytes;
+    const bool fused = depth == 8 && out_n == img_n && (wb % 4) == 0 && ((uintptr_t)out % 4) == 0 && (count == 1 || out_stride % 4 == 0);
+
+    DefilterArgs a{};
+    a.raw = raw; a.raw_stride = raw_stride; a.rows = y; a.wb = wb; a.status = status;
+    static thread_local Scratch scratch;
+    if (fused) { a.D = out; a.d_stride = out_stride; a.d_pitch = wb; a.store_tail_masked = 1; }
+    else {
+        const int64_t group = 4 * FB;
+        a.d_pitch = ((int64_t)wb + group - 1) / group * group;
+        a.d_pitch = (a.d_pitch + 15) / 16 * 16;
+        a.d_stride = a.d_pitch * y;
+        a.D = (uint8_t*)scratch.get((size_t)a.d_stride * count + 64);
+        if (!a.D) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png_defilter: scratch allocation failed");
+        a.store_tail_masked = 0;
+    }
+    const dim3 grid(count), block(PNG_WAVES * 64);
+    switch (FB) {
+    case 1: hipLaunchKernelGGL(k_png_defilter<1>, grid, block, 0, stream, a); break;
+    case 2: hipLaunchKernelGGL(k_png_defilter<2>, grid, block, 0, stream, a); break;
+    case 3: hipLaunchKernelGGL(k_png_defilter<3>, grid, block, 0, stream, a); break;
+    case 4: hipLaunchKernelGGL(k_png_defilter<4>, grid, block, 0, stream, a); break;
+    case 6: hipLaunchKernelGGL(k_png_defilter<6>, grid, block, 0, stream, a); break;
+    case 8: hipLaunchKernelGGL(k_png_defilter<8>, grid, block, 0, stream, a); break;
+    default: return set_error(GAMUT_HIP_ERR_INVALID_ARG, "png_defilter: unsupported filter unit %d", FB);
+    }
+    if (int rc = launch_status("png_defilter")) return rc;
+    if (!fused) {
+        ExpandArgs e{};
+        e.D = a.D; e.d_stride = a.d_stride; e.d_pitch = a.d_pitch; e.out = out; e.out_stride = out_stride;
+        e.x = x; e.y = y; e.img_n = img_n; e.out_n = out_n; e.depth = depth; e.color = color;
+        hipLaunchKernelGGL(k_png_expand, dim3(blocks_for((int64_t)x * y), count), dim3(256), 0, stream, e);
+        if (int rc = launch_status("png_expand")) return rc;
+    }
+    return GAMUT_HIP_OK;
+}
+
+
+int png_transparency_launch(void* img, int64_t npx, int out_n, int depth16, const uint16_t tc[3], hipStream_t st)
+{
+    if (depth16) hipLaunchKernelGGL(k_png_transparency<uint16_t>, dim3(blocks_for(npx)), dim3(256), 0, st, (uint16_t*)img, npx, out_n, tc[0], tc[1], tc[2], (uint16_t)65535);
+    else hipLaunchKernelGGL(k_png_transparency<uint8_t>, dim3(blocks_for(npx)), dim3(256), 0, st, (uint8_t*)img, npx, out_n, (uint8_t)tc[0], (uint8_t)tc[1], (uint8_t)tc[2], (uint8_t)255);
+    return launch_status("png_transparency");
+}
+int png_palette_launch(const uint8_t* idx, uint8_t* out, int64_t npx, int pal_n, const uint8_t* palette_dev, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_png_palette, dim3(blocks_for(npx)), dim3(256), 0, st, idx, out, npx, pal_n, palette_dev);
+    return launch_status("png_palette");
+}
+int png_convert_format_launch(const void* src, void* dst, int64_t npx, int img_n, int req, int depth16, hipStream_t st)
+{
+    if (depth16) hipLaunchKernelGGL(k_png_convert_format<uint16_t>, dim3(blocks_for(npx)), dim3(256), 0, st, (const uint16_t*)src, (uint16_t*)dst, npx, img_n, req, (uint16_t)0xffff);
+    else hipLaunchKernelGGL(k_png_convert_format<uint8_t>, dim3(blocks_for(npx)), dim3(256), 0, st, (const uint8_t*)src, (uint8_t*)dst, npx, img_n, req, (uint8_t)255);
+    return launch_status("png_convert_format");
+}
+int png_depth_convert_launch(const void* src, void* dst, int64_t n, int to16, hipStream_t st)
+{
+    if (to16) hipLaunchKernelGGL(k_png_8_to_16, dim3(blocks_for(n)), dim3(256), 0, st, (const uint8_t*)src, (uint16_t*)dst, n);
+    else hipLaunchKernelGGL(k_png_16_to_8, dim3(blocks_for(n)), dim3(256), 0, st, (const uint16_t*)src, (uint8_t*)dst, n);
+    return launch_status("png_depth_convert");
+}
+int png_adam7_scatter_launch(const uint8_t* pass, uint8_t* final_, uint32_t px, uint32_t py, uint32_t img_x, int out_bytes, int p, hipStream_t st)
+{
+    static const int xorig[7] = { 0,4,0,2,0,1,0 }, yorig[7] = { 0,0,4,0,2,0,1 }, xspc[7] = { 8,8,4,4,2,2,1 }, yspc[7] = { 8,8,8,4,4,2,2 };
+    hipLaunchKernelGGL(k_png_adam7_scatter, dim3(blocks_for((int64_t)px * py)), dim3(256), 0, st, pass, final_, px, py, img_x, out_bytes,
+                       xorig[p], yorig[p], xspc[p], yspc[p]);
+    return launch_status("png_adam7_scatter");
+}
+
+} // namespace gamut

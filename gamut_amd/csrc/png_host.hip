@@ -1,0 +1,326 @@
+// png_host.hip -- host side of the PNG path and its C-ABI entry points.
+//
+// Host feeder = what stays on the CPU in the reference too:
+// the chunk walk of stbi__parse_png_file (stbdec.d:1777-2023: IHDR/PLTE/tRNS/pHYs/CgBI/IDAT,
+// missing-IEND tolerance :2008-2012) and the inflate of finalize_decode (:1808-1819; the
+// reference calls the third-party `miniz`, here the system zlib in raw mode with the adler32
+// unchecked like the reference's trusted_input=true).  Everything after the inflate runs on
+// the GPU: de-filter / expand (png.hip), Adam7 scatter, tRNS, palette, channel and depth
+// conversion, in the order of finalize_decode (:1821-1857) and stbi__do_png (:2025-2055).
+#include "common.hpp"
+#include <zlib.h>
+
+namespace gamut {
+namespace {
+
+struct Reader {                       // stb's memory reader: reads past the end yield 0 (stbi__get8)
+    const uint8_t* p; const uint8_t* end;
+    int      get8()    { return p < end ? *p++ : 0; }
+    uint32_t get16be() { uint32_t z = (uint32_t)get8(); return (z << 8) + (uint32_t)get8(); }
+    uint32_t get32be() { uint32_t z = get16be(); return (z << 16) + get16be(); }
+    bool     eof() const { return p >= end; }
+    void     skip(uint32_t n) { if ((size_t)(end - p) < n) p = end; else p += n; }
+};
+
+struct PngHeader {
+    uint32_t x = 0, y = 0; int depth = 0, color = 0, interlace = 0, img_n = 0, pal_img_n = 0;
+    bool has_trans = false, is_iphone = false;
+    uint8_t palette[1024]; uint32_t pal_len = 0;
+    uint16_t tc[3] = { 0, 0, 0 };      // tRNS key: 8-bit values already scaled (stbdec.d:1945), 16-bit as-is (:1941)
+    float ppmX = -1, ppmY = -1, aspect = -1;
+    uint8_t* idata = nullptr; uint32_t ioff = 0;
+    ~PngHeader() { free(idata); }
+};
+
+const uint8_t kDepthScale[9] = { 0, 0xff, 0x55, 0, 0x11, 0, 0, 0, 0x01 };
+constexpr uint32_t fourcc(char a, char b, char c, char d) { return ((uint32_t)(uint8_t)a << 24) | ((uint32_t)(uint8_t)b << 16) | ((uint32_t)(uint8_t)c << 8) | (uint8_t)d; }
+
+// header_only: stop as stbi__png_info_raw does (SCAN_header), enough for stbi__png_is16
+int parse(const uint8_t* data, size_t len, PngHeader& h, bool header_only)
+{
+    static const uint8_t sig[8] = { 137, 80, 78, 71, 13, 10, 26, 10 };
+    Reader s{ data, data + len };
+    for (int i = 0; i < 8; ++i) if (s.get8() != sig[i]) return set_error(GAMUT_HIP_ERR_DECODE, "png: bad signature");
+    bool first = true; uint32_t cap = 0;
+    for (;;) {
+        const uint32_t clen = s.get32be(), type = s.get32be();
+        switch (type) {
+        case fourcc('C','g','B','I'): h.is_iphone = true; s.skip(clen); break;
+        case fourcc('p','H','Y','s'):
+            h.ppmX = (float)s.get32be(); h.ppmY = (float)s.get32be(); h.aspect = h.ppmX / h.ppmY;
+            if (s.get8() != 1) { h.ppmX = -1; h.ppmY = -1; }
+            break;
+        case fourcc('I','H','D','R'): {
+            if (!first || clen != 13) return set_error(GAMUT_HIP_ERR_DECODE, "png: bad IHDR");
+            first = false;
+            h.x = s.get32be(); h.y = s.get32be();
+            if (h.y > (1u << 24) || h.x > (1u << 24)) return set_error(GAMUT_HIP_ERR_DECODE, "png: too large");
+            h.depth = s.get8();
+            if (h.depth != 1 && h.depth != 2 && h.depth != 4 && h.depth != 8 && h.depth != 16) return set_error(GAMUT_HIP_ERR_DECODE, "png: 1/2/4/8/16-bit only");
+            h.color = s.get8();
+            if (h.color > 6 || (h.color == 3 && h.depth == 16)) return set_error(GAMUT_HIP_ERR_DECODE, "png: bad ctype");
+            if (h.color == 3) h.pal_img_n = 3; else if (h.color & 1) return set_error(GAMUT_HIP_ERR_DECODE, "png: bad ctype");
+            if (s.get8()) return set_error(GAMUT_HIP_ERR_DECODE, "png: bad comp method");
+            if (s.get8()) return set_error(GAMUT_HIP_ERR_DECODE, "png: bad filter method");
+            h.interlace = s.get8(); if (h.interlace > 1) return set_error(GAMUT_HIP_ERR_DECODE, "png: bad interlace method");
+            if (!h.x || !h.y) return set_error(GAMUT_HIP_ERR_DECODE, "png: 0-pixel image");
+            if (!h.pal_img_n) {
+                h.img_n = (h.color & 2 ? 3 : 1) + (h.color & 4 ? 1 : 0);
+                if ((1u << 30) / h.x / (uint32_t)h.img_n < h.y) return set_error(GAMUT_HIP_ERR_DECODE, "png: too large");
+                if (header_only) return GAMUT_HIP_OK;
+            } else {
+                h.img_n = 1;
+                if ((1u << 30) / h.x / 4 < h.y) return set_error(GAMUT_HIP_ERR_DECODE, "png: too large");
+            }
+        } break;
+        case fourcc('P','L','T','E'):
+            if (first || clen > 256 * 3) return set_error(GAMUT_HIP_ERR_DECODE, "png: invalid PLTE");
+            h.pal_len = clen / 3;
+            if (h.pal_len * 3 != clen) return set_error(GAMUT_HIP_ERR_DECODE, "png: invalid PLTE");
+            for (uint32_t i = 0; i < h.pal_len; ++i) {
+                h.palette[i*4] = (uint8_t)s.get8(); h.palette[i*4+1] = (uint8_t)s.get8(); h.palette[i*4+2] = (uint8_t)s.get8(); h.palette[i*4+3] = 255;
+            }
+            break;
+        case fourcc('t','R','N','S'):
+            if (first) return set_error(GAMUT_HIP_ERR_DECODE, "png: first not IHDR");
+            if (h.idata) return set_error(GAMUT_HIP_ERR_DECODE, "png: tRNS after IDAT");
+            if (h.pal_img_n) {
+                if (header_only) { h.img_n = 4; return GAMUT_HIP_OK; }
+                if (h.pal_len == 0 || clen > h.pal_len) return set_error(GAMUT_HIP_ERR_DECODE, "png: bad tRNS");
+                h.pal_img_n = 4;
+                for (uint32_t i = 0; i < clen; ++i) h.palette[i*4+3] = (uint8_t)s.get8();
+            } else {
+                if (!(h.img_n & 1) || clen != (uint32_t)h.img_n * 2) return set_error(GAMUT_HIP_ERR_DECODE, "png: bad tRNS");
+                h.has_trans = true;
+                for (int k = 0; k < h.img_n; ++k) {
+                    const uint32_t v = s.get16be();
+                    h.tc[k] = h.depth == 16 ? (uint16_t)v : (uint16_t)(uint8_t)((uint8_t)(v & 255) * kDepthScale[h.depth]);
+                }
+            }
+            break;
+        case fourcc('I','D','A','T'): {
+            if (first) return set_error(GAMUT_HIP_ERR_DECODE, "png: first not IHDR");
+            if (h.pal_img_n && !h.pal_len) return set_error(GAMUT_HIP_ERR_DECODE, "png: no PLTE");
+            if (header_only) { h.img_n = h.pal_img_n ? h.pal_img_n : h.img_n; return GAMUT_HIP_OK; }
+            if ((int32_t)(h.ioff + clen) < (int32_t)h.ioff) return set_error(GAMUT_HIP_ERR_DECODE, "png: IDAT overflow");
+            if (h.ioff + clen > cap) {
+                uint32_t ncap = cap ? cap : (clen > 4096 ? clen : 4096);
+                while (h.ioff + clen > ncap) ncap *= 2;
+                uint8_t* n = (uint8_t*)realloc(h.idata, ncap);
+                if (!n) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png: out of memory");
+                h.idata = n; cap = ncap;
+            }
+            if ((size_t)(s.end - s.p) < clen) return set_error(GAMUT_HIP_ERR_DECODE, "png: out of data");
+            memcpy(h.idata + h.ioff, s.p, clen); s.p += clen; h.ioff += clen;
+        } break;
+        case fourcc('I','E','N','D'):
+            if (first) return set_error(GAMUT_HIP_ERR_DECODE, "png: first not IHDR");
+            return GAMUT_HIP_OK;
+        default:
+            if (first) return set_error(GAMUT_HIP_ERR_DECODE, "png: first not IHDR");
+            if (type == 0 && s.eof()) return GAMUT_HIP_OK;                 // Gamut issue #92: no IEND
+            if ((type & (1u << 29)) == 0) return set_error(GAMUT_HIP_ERR_DECODE, "png: unknown critical chunk");
+            s.skip(clen);
+            break;
+        }
+        s.get32be();      // CRC, not checked
+    }
+}
+
+// stbi_zlib_decode_malloc_guesssize_headerflag (stbdec.d:1267-1321)
+uint8_t* inflate_idat(const uint8_t* buf, uint32_t len, size_t guess, uint32_t* outlen, bool parse_header)
+{
+    if (parse_header) {
+        if (len < 2 || ((buf[0] * 256 + buf[1]) % 31) != 0 || (buf[1] & 32) || (buf[0] & 15) != 8) { set_error(GAMUT_HIP_ERR_DECODE, "png: bad zlib header"); return nullptr; }
+        buf += 2; len -= 2;
+    }
+    size_t cap = guess ? guess : 1;
+    uint8_t* out = (uint8_t*)malloc(cap);
+    z_stream z; memset(&z, 0, sizeof(z));
+    if (!out || inflateInit2(&z, -15) != Z_OK) { free(out); set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png: inflate init failed"); return nullptr; }
+    z.next_in = const_cast<Bytef*>(buf); z.avail_in = len; z.next_out = out; z.avail_out = (uInt)cap;
+    for (;;) {
+        const int r = inflate(&z, Z_NO_FLUSH);
+        if (r == Z_STREAM_END) break;
+        if ((r == Z_OK || r == Z_BUF_ERROR) && z.avail_out == 0 && cap <= 536870912u) {
+            size_t ncap = cap * 2; if (ncap < 32 * 1024) ncap = 32 * 1024;
+            uint8_t* n = (uint8_t*)realloc(out, ncap);
+            if (!n) { inflateEnd(&z); free(out); set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png: out of memory"); return nullptr; }
+            out = n; z.next_out = out + cap; z.avail_out = (uInt)(ncap - cap); cap = ncap;
+            continue;
+        }
+        if (r == Z_OK && z.avail_in != 0) continue;
+        inflateEnd(&z); free(out); set_error(GAMUT_HIP_ERR_DECODE, "png: corrupt zlib stream"); return nullptr;
+    }
+    *outlen = (uint32_t)z.total_out;
+    inflateEnd(&z);
+    return out;
+}
+
+struct Dev {
+    void* p = nullptr;
+    ~Dev() { if (p) (void)hipFree(p); }
+    bool alloc(size_t n) { if (hipMalloc(&p, n ? n : 1) != hipSuccess) { p = nullptr; set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png: hipMalloc(%zu) failed", n); return false; } return true; }
+    void swap(Dev& o) { void* t = p; p = o.p; o.p = t; }
+};
+
+// whole stbi__do_png on the GPU after the host inflate.  Returns malloc'd host pixels (8 or 16 bit as decoded).
+uint8_t* png_load(const uint8_t* data, size_t len, int* px, int* py, int* pn, int req_comp, int* bits_out,
+                  float* ppmX, float* ppmY, float* aspect)
+{
+    if (req_comp < 0 || req_comp > 4) { set_error(GAMUT_HIP_ERR_INVALID_ARG, "png: bad req_comp"); return nullptr; }
+    PngHeader h;
+    if (parse(data, len, h, false)) return nullptr;
+    if (ppmX) *ppmX = h.ppmX;
+    if (ppmY) *ppmY = h.ppmY;
+    if (aspect) *aspect = h.aspect;
+    if (!h.idata) { set_error(GAMUT_HIP_ERR_DECODE, "png: no IDAT"); return nullptr; }
+    const uint32_t bpl = (h.x * (uint32_t)h.depth + 7) / 8;
+    uint32_t raw_len = 0;
+    uint8_t* raw = inflate_idat(h.idata, h.ioff, (size_t)bpl * h.y * h.img_n + h.y, &raw_len, !h.is_iphone);
+    if (!raw) return nullptr;
+    struct FreeRaw { uint8_t* p; ~FreeRaw() { free(p); } } fr{ raw };
+
+    int img_n = h.img_n, out_n;
+    if ((req_comp == img_n + 1 && req_comp != 3 && !h.pal_img_n) || h.has_trans) out_n = img_n + 1; else out_n = img_n;   // :1821-1824
+    const int bytes = h.depth == 16 ? 2 : 1;
+    const int64_t npx = (int64_t)h.x * h.y;
+    hipStream_t st = thread_stream();
+    int dev_count = 0;
+    if (hipGetDeviceCount(&dev_count) != hipSuccess || dev_count <= 0) { set_error(GAMUT_HIP_ERR_NO_DEVICE, "no HIP device available (libgamut_hip has no CPU fallback)"); return nullptr; }
+
+    Dev draw, dimg, dstatus;
+    if (!draw.alloc((size_t)raw_len + 16) || !dimg.alloc((size_t)npx * out_n * bytes + 16) || !dstatus.alloc(4)) return nullptr;
+    if (hipMemcpyAsync(draw.p, raw, raw_len, hipMemcpyHostToDevice, st) != hipSuccess || hipMemsetAsync(dstatus.p, 0, 4, st) != hipSuccess) {
+        set_error(GAMUT_HIP_ERR_HIP, "png: upload failed"); return nullptr;
+    }
+    if (!h.interlace) {
+        if (png_defilter_launch((const uint8_t*)draw.p, 0, raw_len, (uint8_t*)dimg.p, 0, h.x, h.y, img_n, out_n, h.depth, h.color, 1, (uint32_t*)dstatus.p, st)) return nullptr;
+    } else {                                                              // stbi__create_png_image :1646-1679
+        static const int xorig[7] = { 0,4,0,2,0,1,0 }, yorig[7] = { 0,0,4,0,2,0,1 }, xspc[7] = { 8,8,4,4,2,2,1 }, yspc[7] = { 8,8,8,4,4,2,2 };
+        Dev dpass;
+        if (!dpass.alloc((size_t)npx * out_n * bytes + 16)) return nullptr;
+        const uint8_t* rp = (const uint8_t*)draw.p; uint32_t left = raw_len;
+        for (int p = 0; p < 7; ++p) {
+            const uint32_t x = (h.x - xorig[p] + xspc[p] - 1) / xspc[p], y = (h.y - yorig[p] + yspc[p] - 1) / yspc[p];
+            if (!x || !y) continue;
+            const uint32_t img_len = ((((uint32_t)img_n * x * h.depth) + 7) >> 3) * y + y;
+            if (png_defilter_launch(rp, 0, left, (uint8_t*)dpass.p, 0, x, y, img_n, out_n, h.depth, h.color, 1, (uint32_t*)dstatus.p, st)) return nullptr;
+            if (png_adam7_scatter_launch((const uint8_t*)dpass.p, (uint8_t*)dimg.p, x, y, h.x, out_n * bytes, p, st)) return nullptr;
+            rp += img_len; left -= img_len;
+        }
+    }
+    if (h.has_trans && png_transparency_launch(dimg.p, npx, out_n, h.depth == 16, h.tc, st)) return nullptr;      // :1829-1841
+    if (h.pal_img_n) {                                                      // :1843-1851
+        img_n = h.pal_img_n; out_n = h.pal_img_n;
+        if (req_comp >= 3) out_n = req_comp;
+        Dev dpal, dexp;
+        if (!dpal.alloc(1024) || !dexp.alloc((size_t)npx * out_n + 16)) return nullptr;
+        if (hipMemcpyAsync(dpal.p, h.palette, 1024, hipMemcpyHostToDevice, st) != hipSuccess) { set_error(GAMUT_HIP_ERR_HIP, "png: upload failed"); return nullptr; }
+        if (png_palette_launch((const uint8_t*)dimg.p, (uint8_t*)dexp.p, npx, out_n, (const uint8_t*)dpal.p, st)) return nullptr;
+        if (hipStreamSynchronize(st) != hipSuccess) { set_error(GAMUT_HIP_ERR_HIP, "png: sync failed"); return nullptr; }   // dpal lifetime
+        dimg.swap(dexp);
+    } else if (h.has_trans) ++img_n;                                        // :1852-1855
+    if (req_comp && req_comp != out_n) {                                    // stbi__do_png :2038-2045
+        Dev dconv;
+        if (!dconv.alloc((size_t)npx * req_comp * bytes + 16)) return nullptr;
+        if (png_convert_format_launch(dimg.p, dconv.p, npx, out_n, req_comp, bytes == 2, st)) return nullptr;
+        if (hipStreamSynchronize(st) != hipSuccess) { set_error(GAMUT_HIP_ERR_HIP, "png: sync failed"); return nullptr; }
+        dimg.swap(dconv);
+        out_n = req_comp;
+    }
+    const size_t out_bytes = (size_t)npx * out_n * bytes;
+    uint8_t* result = (uint8_t*)malloc(out_bytes ? out_bytes : 1);
+    uint32_t status = 0;
+    if (!result) { set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png: out of memory"); return nullptr; }
+    if (hipMemcpyAsync(result, dimg.p, out_bytes, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(&status, dstatus.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        free(result); set_error(GAMUT_HIP_ERR_HIP, "png: download failed: %s", hipGetErrorString(hipGetLastError())); return nullptr;
+    }
+    if (status) { free(result); set_error(GAMUT_HIP_ERR_DECODE, "png: invalid filter"); return nullptr; }
+    *px = (int)h.x; *py = (int)h.y; if (pn) *pn = img_n;
+    *bits_out = h.depth <= 8 ? 8 : 16;
+    return result;
+}
+
+// 16 <-> 8 of stbi__load_and_postprocess_* (stbdec.d:669-707) on the GPU
+uint8_t* depth_convert_host(uint8_t* src, size_t count, bool to16)
+{
+    Dev a, b;
+    hipStream_t st = thread_stream();
+    const size_t sb = count * (to16 ? 1 : 2), db = count * (to16 ? 2 : 1);
+    uint8_t* out = (uint8_t*)malloc(db ? db : 1);
+    bool ok = out && a.alloc(sb) && b.alloc(db) &&
+              hipMemcpyAsync(a.p, src, sb, hipMemcpyHostToDevice, st) == hipSuccess &&
+              png_depth_convert_launch(a.p, b.p, (int64_t)count, to16, st) == GAMUT_HIP_OK &&
+              hipMemcpyAsync(out, b.p, db, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    free(src);
+    if (!ok) { free(out); if (!last_error_buf()[0]) set_error(GAMUT_HIP_ERR_HIP, "png: depth conversion failed"); return nullptr; }
+    return out;
+}
+
+} // namespace
+} // namespace gamut
+
+using namespace gamut;
+
+extern "C" {
+
+int gamut_hip_png_defilter_batch_device(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len,
+                                        uint8_t* out, int64_t out_stride,
+                                        uint32_t x, uint32_t y, int img_n, int out_n, int depth, int color,
+                                        int count, uint32_t* status, void* stream)
+{
+    clear_error();
+    return png_defilter_launch(raw, raw_stride, raw_len, out, out_stride, x, y, img_n, out_n, depth, color, count, status, pick_stream(stream));
+}
+
+int gamut_hip_png_defilter_device(const gamut_hip_png_desc* descs, int count, uint32_t* status, void* stream)
+{
+    clear_error();
+    if (count < 0 || (count > 0 && !descs)) return set_error(GAMUT_HIP_ERR_INVALID_ARG, "png_defilter: bad descriptor array");
+    for (int i = 0; i < count; ++i) {
+        const gamut_hip_png_desc& d = descs[i];
+        if (int rc = png_defilter_launch(d.raw, 0, d.raw_len, d.out, 0, d.x, d.y, d.img_n, d.out_n, d.depth, d.color, 1,
+                                         status ? status + i : nullptr, pick_stream(stream)))
+            return rc;
+    }
+    return GAMUT_HIP_OK;
+}
+
+uint8_t* gamut_hip_stbi_load_from_memory(const uint8_t* data, size_t len, int* x, int* y, int* comp, int req_comp,
+                                         float* ppmX, float* ppmY, float* pixelRatio)
+{
+    clear_error();
+    int bits = 8, n = 0, w = 0, h = 0;
+    uint8_t* r = png_load(data, len, &w, &h, &n, req_comp, &bits, ppmX, ppmY, pixelRatio);
+    if (!r) return nullptr;
+    if (x) *x = w;
+    if (y) *y = h;
+    if (comp) *comp = n;
+    if (bits != 8) r = depth_convert_host(r, (size_t)w * h * (req_comp == 0 ? n : req_comp), false);      // stbi__convert_16_to_8
+    return r;
+}
+
+uint16_t* gamut_hip_stbi_load_16_from_memory(const uint8_t* data, size_t len, int* x, int* y, int* comp, int req_comp,
+                                             float* ppmX, float* ppmY, float* pixelRatio)
+{
+    clear_error();
+    int bits = 8, n = 0, w = 0, h = 0;
+    uint8_t* r = png_load(data, len, &w, &h, &n, req_comp, &bits, ppmX, ppmY, pixelRatio);
+    if (!r) return nullptr;
+    if (x) *x = w;
+    if (y) *y = h;
+    if (comp) *comp = n;
+    if (bits != 16) r = depth_convert_host(r, (size_t)w * h * (req_comp == 0 ? n : req_comp), true);       // stbi__convert_8_to_16
+    return reinterpret_cast<uint16_t*>(r);
+}
+
+int gamut_hip_png_is16(const uint8_t* data, size_t len)
+{
+    PngHeader h;
+    if (parse(data, len, h, true)) { clear_error(); return 0; }
+    return h.depth == 16 ? 1 : 0;
+}
+
+} // extern "C"

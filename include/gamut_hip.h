@@ -169,13 +169,15 @@ typedef struct gamut_hip_png_desc {
     uint32_t       x, y;
     int32_t        img_n, out_n, depth, color;
 } gamut_hip_png_desc;
-int gamut_hip_png_defilter_device(const gamut_hip_png_desc* descs, int count, void* stream);
+/* status (HBM, may be NULL): one uint32 per image, bit 0 is set when a row carries an invalid
+ * filter type (> 4, "Corrupt PNG" stbdec.d:1438); zero it before the call. */
+int gamut_hip_png_defilter_device(const gamut_hip_png_desc* descs, int count, uint32_t* status, void* stream);
 
 /* uniform batch: image i uses raw + i*raw_stride, out + i*out_stride (bytes). */
 int gamut_hip_png_defilter_batch_device(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len,
                                         uint8_t* out, int64_t out_stride,
                                         uint32_t x, uint32_t y, int img_n, int out_n, int depth, int color,
-                                        int count, void* stream);
+                                        int count, uint32_t* status, void* stream);
 
 /* drop-ins for stbi_load_from_callbacks / stbi_load_16_from_callbacks
  * (stbdec.d:713-735) on a memory buffer: host chunk parse + inflate, GPU

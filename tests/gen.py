@@ -91,3 +91,112 @@ def synth_rgb(width, height, index=0, alpha=False):
     if alpha:
         chans.append(np.clip(255.0 * (xx + yy) / max(1, width + height - 2), 0, 255))
     return np.stack(chans, -1).astype(np.uint8)
+
+
+# ---------------------------------------------------------------- PNG stream builders (tests + bench)
+def png_forward_filter(rows, fb, filters):
+    """rows: (h, wb) uint8 packed sample bytes; fb: filter unit in bytes; filters: (h,) values 0..4.
+    Returns the inflated-stream layout the de-filter kernels consume: per row 1 filter byte + wb bytes."""
+    rows = np.ascontiguousarray(rows, np.uint8)
+    h, wb = rows.shape
+    cur = rows.astype(np.int16)
+    a = np.zeros_like(cur); a[:, fb:] = cur[:, :-fb] if wb > fb else 0
+    b = np.zeros_like(cur); b[1:] = cur[:-1]
+    c = np.zeros_like(cur); c[1:, fb:] = cur[:-1, :-fb] if wb > fb else 0
+    p = a + b - c
+    pa, pb, pc = np.abs(p - a), np.abs(p - b), np.abs(p - c)
+    paeth = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, b, c))
+    preds = [np.zeros_like(cur), a, b, (a + b) >> 1, paeth]
+    f = np.asarray(filters, np.uint8).reshape(h)
+    out = np.empty((h, wb + 1), np.uint8)
+    out[:, 0] = f
+    for t in range(5):
+        m = f == t
+        if m.any():
+            out[m, 1:] = ((cur[m] - preds[t][m]) & 255).astype(np.uint8)
+    return out.reshape(-1)
+
+
+def png_heuristic_filters(rows, fb):
+    """stb_image_write's choice (stb_image_write.d:387-406): per row the filter with the smallest sum of |signed residual|."""
+    rows = np.ascontiguousarray(rows, np.uint8)
+    h, wb = rows.shape
+    best = np.zeros(h, np.uint8)
+    best_cost = np.full(h, np.iinfo(np.int64).max, np.int64)
+    for t in range(5):
+        res = png_forward_filter(rows, fb, np.full(h, t, np.uint8)).reshape(h, wb + 1)[:, 1:].view(np.int8)
+        cost = np.abs(res.astype(np.int64)).sum(axis=1)
+        upd = cost < best_cost
+        best[upd] = t
+        best_cost[upd] = cost[upd]
+    return best
+
+
+def pack_samples(samples, depth):
+    """samples: (h, n) integer sample values (n = width*channels) -> (h, ceil(n*depth/8)) packed bytes, PNG bit order / big-endian."""
+    samples = np.asarray(samples)
+    h, n = samples.shape
+    if depth == 8:
+        return samples.astype(np.uint8)
+    if depth == 16:
+        s = samples.astype(np.uint16)
+        return np.stack([(s >> 8).astype(np.uint8), (s & 255).astype(np.uint8)], -1).reshape(h, n * 2)
+    per = 8 // depth
+    pad = (-n) % per
+    s = np.concatenate([samples.astype(np.uint8), np.zeros((h, pad), np.uint8)], 1).reshape(h, -1, per)
+    out = np.zeros(s.shape[:2], np.uint8)
+    for k in range(per):
+        out |= (s[:, :, k] & ((1 << depth) - 1)) << (8 - depth * (k + 1))
+    return out
+
+
+def write_png(samples, width, height, color, depth, filters=None, interlace=0, palette=None, trns=None, iphone=False,
+              idat_split=3, extra_chunks=(), no_iend=False):
+    """Minimal PNG writer for tests: samples (height, width*channels) ints; returns file bytes."""
+    import struct
+    import zlib
+    ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[color]
+    fb = 1 if depth < 8 else ch * (2 if depth == 16 else 1)
+    rng = np.random.default_rng(width * 7919 + height)
+
+    def stream(smp, w, h):
+        rows = pack_samples(smp.reshape(h, w * ch), depth)
+        f = filters if filters is not None and np.ndim(filters) == 0 else None
+        ff = np.full(h, f, np.uint8) if f is not None else (rng.integers(0, 5, h).astype(np.uint8) if filters is None else np.asarray(filters)[:h])
+        return png_forward_filter(rows, fb, ff).tobytes()
+
+    smp = np.asarray(samples).reshape(height, width, ch)
+    if not interlace:
+        raw = stream(smp, width, height)
+    else:
+        xo, yo, xs, ys = [0, 4, 0, 2, 0, 1, 0], [0, 0, 4, 0, 2, 0, 1], [8, 8, 4, 4, 2, 2, 1], [8, 8, 8, 4, 4, 2, 2]
+        raw = b""
+        for p in range(7):
+            sub = smp[yo[p]::ys[p], xo[p]::xs[p]]
+            if sub.shape[0] and sub.shape[1]:
+                raw += stream(sub, sub.shape[1], sub.shape[0])
+    if iphone:
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        z = co.compress(raw) + co.flush()
+    else:
+        z = zlib.compress(raw, 6)
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+
+    out = b"\x89PNG\r\n\x1a\n"
+    if iphone:
+        out += chunk(b"CgBI", b"\x50\x00\x20\x02")
+    out += chunk(b"IHDR", struct.pack(">IIBBBBB", width, height, depth, color, 0, 0, interlace))
+    for t, d in extra_chunks:
+        out += chunk(t, d)
+    if palette is not None:
+        out += chunk(b"PLTE", np.asarray(palette, np.uint8).tobytes())
+    if trns is not None:
+        out += chunk(b"tRNS", bytes(trns))
+    n = max(1, len(z) // idat_split)
+    for i in range(0, len(z), n):
+        out += chunk(b"IDAT", z[i:i + n])
+    if not no_iend:
+        out += chunk(b"IEND", b"")
+    return out

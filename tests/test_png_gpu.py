@@ -1,0 +1,192 @@
+"""GPU parity: PNG de-filter / expand and the whole stb load path through the C ABI vs the CPU oracle
+(and vs the pixels the streams were built from: PNG is lossless).  Bar: bit-exact."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import gen
+import oracle_lib as O
+from gamut_amd import _capi
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def up(L, arr):
+    arr = np.ascontiguousarray(arr)
+    p = L.gamut_hip_device_malloc(max(16, arr.nbytes))
+    assert p
+    _capi.check(L.gamut_hip_memcpy_h2d(p, arr.ctypes.data, arr.nbytes, None))
+    _capi.check(L.gamut_hip_stream_synchronize(None))
+    return p
+
+
+def down(L, p, n):
+    out = np.empty(n, np.uint8)
+    _capi.check(L.gamut_hip_stream_synchronize(None))
+    _capi.check(L.gamut_hip_memcpy_d2h(out.ctypes.data, p, n, None))
+    _capi.check(L.gamut_hip_stream_synchronize(None))
+    return out
+
+
+def gpu_defilter(L, raw, x, y, img_n, out_n, depth, color, count=1, raw_stride=0, expect_status=0):
+    raw = np.ascontiguousarray(raw, np.uint8)
+    nbytes = x * y * out_n * (2 if depth == 16 else 1)
+    ostride = nbytes + 64
+    draw = up(L, raw)
+    dout = up(L, np.full(count * ostride, 0xA5, np.uint8))
+    dst = up(L, np.zeros(count, np.uint32))
+    raw_len = raw.size if count == 1 else raw_stride
+    _capi.check(L.gamut_hip_png_defilter_batch_device(draw, raw_stride, raw_len, dout, ostride, x, y, img_n, out_n, depth, color,
+                                                       count, dst, None))
+    host = down(L, dout, count * ostride)
+    status = down(L, dst, count * 4).view(np.uint32)
+    for p in (draw, dout, dst):
+        L.gamut_hip_device_free(p)
+    outs = []
+    for i in range(count):
+        img = host[i * ostride:(i + 1) * ostride]
+        assert (img[nbytes:] == 0xA5).all(), "wrote past the image"
+        outs.append(img[:nbytes].copy())
+    assert (status != 0).astype(int).tolist() == ([expect_status] * count if np.isscalar(expect_status) else list(expect_status))
+    return outs
+
+
+FORMATS = [(1, 1, 0), (1, 2, 0), (1, 4, 0), (1, 8, 0), (1, 16, 0), (2, 8, 4), (2, 16, 4), (3, 8, 2), (3, 16, 2), (4, 8, 6), (4, 16, 6),
+           (1, 1, 3), (1, 2, 3), (1, 4, 3), (1, 8, 3)]
+
+
+@pytest.mark.parametrize("img_n,depth,color", FORMATS)
+def test_defilter_formats_filters_sizes(hip, img_n, depth, color):
+    rng = np.random.default_rng(depth * 10 + img_n)
+    fb = 1 if depth < 8 else img_n * (2 if depth == 16 else 1)
+    for (x, y) in [(1, 1), (2, 3), (5, 2), (37, 70), (130, 129), (33, 1100)]:
+        smooth = rng.integers(0, 1 << depth, (y, x * img_n))
+        smooth = (np.cumsum(rng.integers(-2, 3, (y, x * img_n)), axis=1) + smooth[:, :1]) % (1 << depth) if x > 8 else smooth
+        rows = gen.pack_samples(smooth, depth)
+        fsets = [np.full(y, t, np.uint8) for t in range(5)] + [rng.integers(0, 5, y).astype(np.uint8), gen.png_heuristic_filters(rows, fb)]
+        if (x, y) in ((33, 1100),):
+            fsets = fsets[4:]
+        for filt in fsets:
+            raw = gen.png_forward_filter(rows, fb, filt)
+            for out_n in ([img_n] + ([img_n + 1] if img_n in (1, 3) and color != 3 else [])):
+                exp = O.png_create_image_raw(raw, img_n, out_n, x, y, depth, color)
+                assert exp is not None
+                got = gpu_defilter(hip, raw, x, y, img_n, out_n, depth, color)[0]
+                assert np.array_equal(got, exp), f"n={img_n} d={depth} {x}x{y} out_n={out_n} filters={np.unique(filt)}: {np.count_nonzero(got != exp)} bytes differ"
+
+
+def test_config3_geometry_roundtrip(hip):
+    """3840x2160 RGBA8 (BASELINE.json config 3): forward-filter -> GPU de-filter gives the pixels back; both filter policies."""
+    w, h = 3840, 2160
+    img = gen.synth_rgb(w, h, 77, alpha=True).reshape(h, w * 4)
+    for name, filt in [("heuristic", gen.png_heuristic_filters(img, 4)), ("random", np.random.default_rng(3).integers(0, 5, h).astype(np.uint8)),
+                       ("paeth", np.full(h, 4, np.uint8))]:
+        raw = gen.png_forward_filter(img, 4, filt)
+        got = gpu_defilter(hip, raw, w, h, 4, 4, 8, 6)[0]
+        assert np.array_equal(got, img.reshape(-1)), name
+    exp = O.png_create_image_raw(raw, 4, 4, w, h, 8, 6)
+    assert np.array_equal(exp, img.reshape(-1))
+
+
+def test_batch_and_corrupt_filter(hip):
+    rng = np.random.default_rng(12)
+    x, y, n = 61, 150, 4
+    stride = (x * 4 + 1) * y + 13
+    raws = np.zeros(n * stride, np.uint8)
+    exps = []
+    for i in range(n):
+        img = rng.integers(0, 256, (y, x * 4), dtype=np.uint8)
+        raw = gen.png_forward_filter(img, 4, rng.integers(0, 5, y))
+        if i == 2:
+            raw[(x * 4 + 1) * 70] = 9          # invalid filter type: "Corrupt PNG" (stbdec.d:1438)
+        raws[i * stride:i * stride + raw.size] = raw
+        exps.append(img.reshape(-1))
+    got = gpu_defilter(hip, raws, x, y, 4, 4, 8, 6, count=n, raw_stride=stride, expect_status=[0, 0, 1, 0])
+    for i in (0, 1, 3):
+        assert np.array_equal(got[i], exps[i])
+    assert O.png_create_image_raw(raws[2 * stride:3 * stride], 4, 4, x, y, 8, 6) is None
+    # not enough pixels (stbdec.d:1430)
+    d = up(hip, raws)
+    assert hip.gamut_hip_png_defilter_batch_device(d, 0, 100, d, 0, x, y, 4, 4, 8, 6, 1, None, None) == _capi.ERR_DECODE
+    hip.gamut_hip_device_free(d)
+
+
+def _load(hip, data, req, sixteen):
+    buf = np.frombuffer(data, np.uint8)
+    x, y, n = C.c_int(), C.c_int(), C.c_int()
+    fx, fy, fr = C.c_float(), C.c_float(), C.c_float()
+    fn = hip.gamut_hip_stbi_load_16_from_memory if sixteen else hip.gamut_hip_stbi_load_from_memory
+    p = fn(buf.ctypes.data, buf.size, C.byref(x), C.byref(y), C.byref(n), req, C.byref(fx), C.byref(fy), C.byref(fr))
+    if not p:
+        return None
+    comps = n.value if req == 0 else req
+    ct = C.c_uint16 if sixteen else C.c_uint8
+    out = np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), (y.value, x.value, comps)).copy()
+    libc = C.CDLL(None); libc.free.argtypes = [C.c_void_p]; libc.free(p)
+    return out, n.value, (fx.value, fy.value, fr.value)
+
+
+def _check_file(hip, data, label):
+    for sixteen in (False, True):
+        for req in (0, 1, 2, 3, 4):
+            exp = O.stbi_load(data, req, sixteen)
+            got = _load(hip, data, req, sixteen)
+            if exp is None:
+                assert got is None, label
+                continue
+            assert got is not None, f"{label} req={req} 16={sixteen}: {hip.gamut_hip_last_error()}"
+            assert got[1] == exp[1] and np.array_equal(got[0], exp[0]), f"{label} req={req} 16={sixteen}"
+
+
+@pytest.mark.parametrize("name", ["issue65.png", "vst3-compatible.png", "issue76.png", "issue51cgbi.png", "issue51cgbi2.png"])
+def test_reference_fixture_files(hip, name):
+    _check_file(hip, open(os.path.join(HERE, "golden", "ref_images", name), "rb").read(), name)
+
+
+def test_truncated_reference_files_load(hip):
+    """Gamut issue #92 (missing IEND / truncated CRC): must still decode (stbdec.d:2008-2012)."""
+    for name in ["issue92-no-IEND.png", "issue92-truncated-in-CRC.png"]:
+        data = open(os.path.join(HERE, "golden", "ref_images", name), "rb").read()
+        exp = O.stbi_load(data, 4, False)
+        got = _load(hip, data, 4, False)
+        assert got is not None and np.array_equal(got[0], exp[0]), name
+
+
+def test_generated_png_files(hip):
+    """every colour type x depth, tRNS, palettes, Adam7, CgBI, pHYs, split IDATs"""
+    rng = np.random.default_rng(21)
+    w, h = 23, 19
+    cases = []
+    for color, depths in [(0, (1, 2, 4, 8, 16)), (2, (8, 16)), (4, (8, 16)), (6, (8, 16)), (3, (1, 2, 4, 8))]:
+        ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[color]
+        for depth in depths:
+            smp = rng.integers(0, 1 << depth, (h, w * ch))
+            pal = rng.integers(0, 256, (1 << min(depth, 8), 3)) if color == 3 else None
+            for interlace in (0, 1):
+                cases.append((f"c{color}d{depth}i{interlace}", gen.write_png(smp, w, h, color, depth, interlace=interlace, palette=pal)))
+            if color == 0:
+                key = int(smp[0, 0])
+                cases.append((f"c0d{depth}trns", gen.write_png(smp, w, h, 0, depth, trns=[key >> 8, key & 255])))
+            if color == 2:
+                k = [int(v) for v in smp[0, :3]]
+                cases.append((f"c2d{depth}trns", gen.write_png(smp, w, h, 2, depth, trns=sum(([v >> 8, v & 255] for v in k), []))))
+            if color == 3:
+                cases.append((f"c3d{depth}trns", gen.write_png(smp, w, h, 3, depth, palette=pal, trns=list(rng.integers(0, 256, min(len(pal), 5))))))
+    smp = rng.integers(0, 256, (h, w * 4))
+    cases.append(("cgbi", gen.write_png(smp, w, h, 6, 8, iphone=True)))
+    cases.append(("phys", gen.write_png(smp, w, h, 6, 8, extra_chunks=[(b"pHYs", (3780).to_bytes(4, "big") + (7560).to_bytes(4, "big") + b"\x01")])))
+    cases.append(("noiend", gen.write_png(smp, w, h, 6, 8, no_iend=True)))
+    cases.append(("1x1", gen.write_png(smp[:1, :4], 1, 1, 6, 8)))
+    cases.append(("adam7_small", gen.write_png(smp[:3, :8], 2, 3, 6, 8, interlace=1)))
+    for label, data in cases:
+        _check_file(hip, data, label)
+    got = _load(hip, dict(cases)["phys"], 0, False)
+    exp_info = O.png_parse(dict(cases)["phys"])
+    assert got[2] == (exp_info["ppmX"], exp_info["ppmY"], exp_info["pixelAspectRatio"]) == (3780.0, 7560.0, 0.5)
+    # garbage in: NULL + message out
+    assert _load(hip, b"not a png at all", 0, False) is None and hip.gamut_hip_last_error() != b""
+    assert _load(hip, dict(cases)["1x1"][:40], 0, False) is None

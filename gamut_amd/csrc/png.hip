@@ -31,6 +31,7 @@ typedef uint32_t u32;
 
 constexpr int PNG_WAVES = 16;          // waves per workgroup (= bands in flight per image)
 constexpr int PUB = 8;                 // publish / check progress every PUB iterations (32 filter units)
+constexpr int PF = 4;                  // loop trips of row data kept in flight per lane
 
 struct DefilterArgs {
     const uint8_t* raw; int64_t raw_stride;      // inflated stream(s): per row 1 filter byte + wb bytes
@@ -99,84 +100,100 @@ __global__ __launch_bounds__(PNG_WAVES * 64) void k_png_defilter(DefilterArgs a)
         u32 carry = 0;                            // last aligned raw dword of the previous iteration
         if (row_live) carry = *(rword < rlast ? rword : rlast);
 
-        const u32 T_end = niter + 63;
-        for (u32 T = 0; T < T_end; ++T) {
-            const int it = (int)T - lane;
-            const bool live = row_live && it >= 0 && it < (int)niter;
-
-            // consumer side of the band hand-off (wave-uniform)
-            if (band > 0 && T < niter && (T % PUB) == 0) {
-                const u32 need = prod_base + min(niter, T + PUB);
-                while (__hip_atomic_load(&prog[prod_wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
-                    __builtin_amdgcn_s_sleep(2);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            }
-
-            // raw bytes of this iteration: FB dwords starting rshift bytes into the aligned stream
-            u32 rg[FB];
-            {
-                const u32* p = rword + (int64_t)(it < 0 ? 0 : it) * FB + 1;
-                u32 prev = carry;
-                #pragma unroll
-                for (int i = 0; i < FB; ++i) {
-                    u32 w = 0;
-                    if (live) w = *((p + i) < rlast ? (p + i) : rlast);
-                    rg[i] = __builtin_amdgcn_alignbyte(w, prev, rshift);
-                    prev = w;
-                }
-                if (live) carry = prev;
-            }
-            // upper row: lane j-1's outputs of its previous loop trip; lane 0 reads the band above from memory
-            u32 bg[FB];
+        // Software prefetch: the loads of loop trip T+PF are issued at trip T into register set T % PF (static after
+        // unrolling by PF), so a lane always has PF iterations (PF*4*FB bytes) of its row in flight.
+        u32 rset[PF][FB], dset[PF][FB];
+        auto issue_loads = [&](u32 Tn, u32 (&rs)[FB], u32 (&ds)[FB]) {
+            const int itn = (int)Tn - lane;
+            const bool ln = row_live && itn >= 0 && itn < (int)niter;
+            const u32* pn = rword + (int64_t)(itn < 0 ? 0 : itn) * FB + 1;
             #pragma unroll
             for (int i = 0; i < FB; ++i) {
-                u32 fill = 0;
-                if (lane == 0 && band > 0 && live) fill = ((const u32*)dprev)[(int64_t)it * FB + i];
-                bg[i] = from_lane_below(outp[i], fill);
+                rs[i] = 0; ds[i] = 0;
+                if (ln) rs[i] = *((pn + i) < rlast ? (pn + i) : rlast);
+                if (ln && lane == 0 && band > 0) ds[i] = ((const u32*)dprev)[(int64_t)itn * FB + i];
             }
+        };
+        auto wait_for_band_above = [&](u32 upto) {      // wave-uniform: rows of the band above are visible up to iteration `upto`
+            const u32 need = prod_base + min(niter, upto);
+            while (__hip_atomic_load(&prog[prod_wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
+                __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        };
+        if (band > 0) wait_for_band_above(PUB + PF);
+        #pragma unroll
+        for (int u = 0; u < PF; ++u) issue_loads((u32)u, rset[u], dset[u]);
 
-            u32 og[FB];
+        const u32 T_end = niter + 63;
+        for (u32 T0 = 0; T0 < T_end; T0 += PF) {
             #pragma unroll
-            for (int i = 0; i < FB; ++i) og[i] = 0;
-            #pragma unroll
-            for (int k = 0; k < 4 * FB; ++k) {        // byte k of the group; its left / upper-left neighbours are FB bytes back
-                const u32 x  = byte_of(rg, k);
-                const u32 bb = byte_of(bg, k);
-                const u32 aa = k >= FB ? byte_of(og, k - FB) : byte_of(outp, 3 * FB + k);
-                const u32 cc = k >= FB ? byte_of(bg, k - FB) : byte_of(bp, 3 * FB + k);
-                u32 pred = ((aa & ma) + (bb & mb)) >> sh;
-                if (any_paeth) { const u32 pp = paeth(aa, bb, cc); pred = is_paeth ? pp : pred; }
-                og[k >> 2] |= ((x + pred) & 0xFFu) << ((k & 3) * 8);
-            }
+            for (int u = 0; u < PF; ++u) {
+                const u32 T = T0 + u;
+                const int it = (int)T - lane;
+                const bool live = row_live && it >= 0 && it < (int)niter;
 
-            if (live) {
-                #pragma unroll
-                for (int i = 0; i < FB; ++i) { outp[i] = og[i]; bp[i] = bg[i]; }
-                uint8_t* dst = drow + (int64_t)it * (4 * FB);
-                const u32 valid = min(4u * FB, a.wb - (u32)it * (4 * FB));     // bytes of this group inside the row
-                if (valid == 4 * FB || !a.store_tail_masked) {
-                    if constexpr (FB == 4) *reinterpret_cast<uint4*>(dst) = make_uint4(og[0], og[1], og[2], og[3]);
-                    else if constexpr (FB == 2 || FB == 6) {
-                        #pragma unroll
-                        for (int i = 0; i < FB; i += 2) *reinterpret_cast<uint2*>(dst + 4 * i) = make_uint2(og[i], og[i + 1]);
-                    } else if constexpr (FB == 8) {
-                        *reinterpret_cast<uint4*>(dst) = make_uint4(og[0], og[1], og[2], og[3]);
-                        *reinterpret_cast<uint4*>(dst + 16) = make_uint4(og[4], og[5], og[6], og[7]);
-                    } else {
-                        #pragma unroll
-                        for (int i = 0; i < FB; ++i) reinterpret_cast<u32*>(dst)[i] = og[i];
+                // raw bytes of this iteration: FB dwords starting rshift bytes into the aligned stream
+                u32 rg[FB], bg[FB];
+                {
+                    u32 prev = carry;
+                    #pragma unroll
+                    for (int i = 0; i < FB; ++i) {
+                        rg[i] = __builtin_amdgcn_alignbyte(rset[u][i], prev, rshift);
+                        prev = rset[u][i];
                     }
-                } else {
-                    for (u32 i = 0; i < valid; ++i) dst[i] = (uint8_t)(og[i >> 2] >> ((i & 3) * 8));
+                    if (live) carry = prev;
                 }
-            }
+                // upper row: lane j-1's outputs of its previous loop trip; lane 0 takes the band above (prefetched)
+                #pragma unroll
+                for (int i = 0; i < FB; ++i) bg[i] = from_lane_below(outp[i], dset[u][i]);
 
-            // producer side: lane 63 finished iteration T-63
-            const int it63 = (int)T - 63;
-            if (it63 >= 0 && (((it63 + 1) % PUB) == 0 || it63 == (int)niter - 1)) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 63)
-                    __hip_atomic_store(&prog[wave], seq * niter + (u32)it63 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // consumer side of the band hand-off, then refill this register set for trip T+PF
+                if (band > 0 && T + PF < niter && ((T + PF) % PUB) == 0) wait_for_band_above(T + PF + PUB);
+                issue_loads(T + PF, rset[u], dset[u]);
+
+                u32 og[FB];
+                #pragma unroll
+                for (int i = 0; i < FB; ++i) og[i] = 0;
+                #pragma unroll
+                for (int k = 0; k < 4 * FB; ++k) {        // byte k of the group; its left / upper-left neighbours are FB bytes back
+                    const u32 x  = byte_of(rg, k);
+                    const u32 bb = byte_of(bg, k);
+                    const u32 aa = k >= FB ? byte_of(og, k - FB) : byte_of(outp, 3 * FB + k);
+                    const u32 cc = k >= FB ? byte_of(bg, k - FB) : byte_of(bp, 3 * FB + k);
+                    u32 pred = ((aa & ma) + (bb & mb)) >> sh;
+                    if (any_paeth) { const u32 pp = paeth(aa, bb, cc); pred = is_paeth ? pp : pred; }
+                    og[k >> 2] |= ((x + pred) & 0xFFu) << ((k & 3) * 8);
+                }
+
+                if (live) {
+                    #pragma unroll
+                    for (int i = 0; i < FB; ++i) { outp[i] = og[i]; bp[i] = bg[i]; }
+                    uint8_t* dst = drow + (int64_t)it * (4 * FB);
+                    const u32 valid = min(4u * FB, a.wb - (u32)it * (4 * FB));     // bytes of this group inside the row
+                    if (valid == 4 * FB || !a.store_tail_masked) {
+                        if constexpr (FB == 4) *reinterpret_cast<uint4*>(dst) = make_uint4(og[0], og[1], og[2], og[3]);
+                        else if constexpr (FB == 2 || FB == 6) {
+                            #pragma unroll
+                            for (int i = 0; i < FB; i += 2) *reinterpret_cast<uint2*>(dst + 4 * i) = make_uint2(og[i], og[i + 1]);
+                        } else if constexpr (FB == 8) {
+                            *reinterpret_cast<uint4*>(dst) = make_uint4(og[0], og[1], og[2], og[3]);
+                            *reinterpret_cast<uint4*>(dst + 16) = make_uint4(og[4], og[5], og[6], og[7]);
+                        } else {
+                            #pragma unroll
+                            for (int i = 0; i < FB; ++i) reinterpret_cast<u32*>(dst)[i] = og[i];
+                        }
+                    } else {
+                        for (u32 i = 0; i < valid; ++i) dst[i] = (uint8_t)(og[i >> 2] >> ((i & 3) * 8));
+                    }
+                }
+
+                // producer side: lane 63 finished iteration T-63
+                const int it63 = (int)T - 63;
+                if (it63 >= 0 && it63 < (int)niter && (((it63 + 1) % PUB) == 0 || it63 == (int)niter - 1)) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 63)
+                        __hip_atomic_store(&prog[wave], seq * niter + (u32)it63 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
         }
     }

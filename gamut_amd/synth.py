@@ -76,3 +76,45 @@ def jpeg_coeff_batch(n, width, height, device, seed=0, quality=90, chunk=16):
         crb = fdct_quant(cr, qc).reshape(c, my, mx, 1, 64)
         out[i0:i0 + c] = torch.cat([yb, cbb, crb], dim=3).reshape(c, my * mx * 6, 64)
     return out
+
+
+def png_raw_batch(n, width, height, device, seed=0, policy="heuristic", chunk=4):
+    """Inflated (post-zlib) filtered streams of n synthetic RGBA8 images: uint8 tensor (n, height*(width*4+1)).
+    Pixels: the smooth-plus-noise generator + a smooth alpha ramp.  Per-row filter type:
+    "heuristic" = stb_image_write's min sum |residual| choice (stb_image_write.d:387-406), "random" = uniform 0..4,
+    or an int 0..4 for a single filter type.  Also returns the original pixels' checksums for a round-trip check."""
+    wb = width * 4
+    out = torch.empty((n, height, wb + 1), dtype=torch.uint8, device=device)
+    sums = torch.empty((n,), dtype=torch.int64, device=device)
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed) + 17)
+    yy = torch.arange(height, dtype=torch.float32, device=device)[None, :, None]
+    xx = torch.arange(width, dtype=torch.float32, device=device)[None, None, :]
+    alpha = (255.0 * (xx + yy) / max(1, width + height - 2)).clamp(0, 255).floor()
+    for i0 in range(0, n, chunk):
+        c = min(chunk, n - i0)
+        rgb = synth_rgb_batch(c, width, height, device, seed * 1000003 + i0)            # (c,3,h,w)
+        px = torch.cat([rgb, alpha.expand(c, height, width)[:, None]], 1).permute(0, 2, 3, 1).reshape(c, height, wb).to(torch.int16)
+        sums[i0:i0 + c] = px.to(torch.int64).sum(dim=(1, 2))
+        a = torch.zeros_like(px); a[:, :, 4:] = px[:, :, :-4]
+        b = torch.zeros_like(px); b[:, 1:] = px[:, :-1]
+        cc = torch.zeros_like(px); cc[:, 1:, 4:] = px[:, :-1, :-4]
+        p = a + b - cc
+        pa, pb, pc = (p - a).abs(), (p - b).abs(), (p - cc).abs()
+        paeth = torch.where((pa <= pb) & (pa <= pc), a, torch.where(pb <= pc, b, cc))
+        del p, pa, pb, pc
+        preds = [torch.zeros_like(px), a, b, (a + b) >> 1, paeth]
+        res = [((px - q) & 255).to(torch.uint8) for q in preds]
+        del preds, a, b, cc, paeth
+        if policy == "heuristic":
+            cost = torch.stack([r.view(torch.int8).to(torch.int32).abs().sum(dim=2) for r in res], 0)     # (5,c,h)
+            f = cost.argmin(dim=0)
+        elif policy == "random":
+            f = torch.randint(0, 5, (c, height), device=device, generator=g)
+        else:
+            f = torch.full((c, height), int(policy), device=device, dtype=torch.int64)
+        sel = torch.stack(res, 0).gather(0, f[None, :, :, None].expand(1, c, height, wb))[0]
+        out[i0:i0 + c, :, 0] = f.to(torch.uint8)
+        out[i0:i0 + c, :, 1:] = sel
+        del res, sel
+    return out.reshape(n, height * (wb + 1)), sums

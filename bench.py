@@ -47,14 +47,14 @@ def parse():
 
 
 def traffic_from_profiles(kernel_substr):
-    """HBM bytes per launch from the committed rocprofv3 --pmc summary (profiles/*traffic*.json), or None."""
+    """HBM bytes per image from the committed rocprofv3 --pmc summary (profiles/*traffic*.json), or None."""
     import glob
     best = None
     for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
         try:
             for row in json.load(open(p)).get("kernels", []):
-                if kernel_substr in row.get("kernel", ""):
-                    best = row.get("hbm_bytes_per_launch")
+                if kernel_substr in row.get("kernel", "") and row.get("hbm_bytes_per_image"):
+                    best = row["hbm_bytes_per_image"]
         except Exception:
             pass
     return best
@@ -248,7 +248,7 @@ def main():
             "dtype": dtype, "data": "synthetic",
             "config": {"workload": workload, "images_per_gpu_per_step": B, "sharding": "image-index, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic_from_profiles(kernel_name),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": (lambda t: None if t is None else round(t * B))(traffic_from_profiles(kernel_name)),
                          "kernel": kernel_name, "algorithmic_bytes_per_launch": bytes_per_step,
                          "kernel_ms_avg": round(avg_kernel_s * 1e3, 4), "kernel_ms_min": round(min(kern_ms), 4)},
         }

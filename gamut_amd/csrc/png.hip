@@ -29,9 +29,10 @@ namespace {
 
 typedef uint32_t u32;
 
-constexpr int PNG_WAVES = 16;          // waves per workgroup (= bands in flight per image)
+constexpr int PNG_WAVES = 8;           // waves per workgroup (= bands in flight per image); two workgroups fit a CU
 constexpr int PUB = 8;                 // publish / check progress every PUB iterations (32 filter units)
 constexpr int PF = 4;                  // loop trips of row data kept in flight per lane
+constexpr int PUBLAG = 4;              // progress is published PUBLAG trips after the store it covers (see defilter_band)
 
 struct DefilterArgs {
     const uint8_t* raw; int64_t raw_stride;      // inflated stream(s): per row 1 filter byte + wb bytes
@@ -40,6 +41,8 @@ struct DefilterArgs {
     u32 rows, wb;                                // rows, bytes per row
     u32 store_tail_masked;                       // 1: D rows are tight (fused output) -> never write past wb
 };
+
+struct __attribute__((packed)) PackedU32 { u32 v; };      // a dword at any byte alignment
 
 __device__ __forceinline__ u32 byte_of(const u32* g, int idx) { return (g[idx >> 2] >> ((idx & 3) * 8)) & 0xFFu; }
 
@@ -57,10 +60,142 @@ __device__ __forceinline__ u32 from_lane_below(u32 v, u32 fill)
     return (u32)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xF, 0xF, false);
 }
 
-template <int FB>
-__global__ __launch_bounds__(PNG_WAVES * 64) void k_png_defilter(DefilterArgs a)
+// One 64-row band.  PAETH = some row of the band uses the Paeth filter (wave-uniform, hoisted out of the byte loop).
+template <int FB, int W, bool PAETH>
+__device__ __forceinline__ void defilter_band(const DefilterArgs& a, const uint8_t* raw, uint8_t* D, u32* prog, u32 band,
+                                              int wave, int lane, u32 niter, u32 f, bool row_live)
 {
-    __shared__ u32 prog[PNG_WAVES];               // cumulative iterations finished (and visible) by each wave's lane 63
+    const u32 seq = band / W;
+    const u32 row = band * 64 + lane;
+    const u32 ma = (f == 1 || f == 3 || f == 4) ? 0xFFu : 0u;
+    const u32 mb = (f == 2 || f == 3 || f == 4) ? 0xFFu : 0u;
+    const u32 sh = (f == 3) ? 1u : 0u;
+    const bool is_paeth = f == 4;
+
+    const uint8_t* rbytes = raw + (int64_t)(row_live ? row : 0) * (a.wb + 1) + 1;
+    uint8_t* drow = D + (int64_t)(row_live ? row : 0) * a.d_pitch;
+    const uint8_t* dprev = band > 0 ? D + (int64_t)(band * 64 - 1) * a.d_pitch : D;     // row above lane 0; band 0: anything valid, masked to 0
+    const u32 dmask = band > 0 ? 0xFFFFFFFFu : 0u;
+    const int prod_wave = (wave + W - 1) % W;
+    const u32 prod_base = (band > 0 ? (band - 1) / W : 0) * niter;
+    const u32 full_iters = a.wb / (4 * FB);                              // iterations whose 4*FB bytes all lie inside the row
+
+    u32 outp[FB], bp[FB];                     // previous iteration: own outputs, upper-row values
+    #pragma unroll
+    for (int i = 0; i < FB; ++i) { outp[i] = 0; bp[i] = 0; }
+
+    // Software prefetch: the loads of loop trip T+PF are issued at trip T into register set T % PF (static after
+    // unrolling by PF), so a lane always has PF iterations of its row in flight.  The loads are unconditional
+    // (addresses clamped into the row, results of dead lanes unused): a branch around a load makes the compiler drain
+    // the memory queue (s_waitcnt vmcnt(0)) on every trip.  gfx950 handles the byte-unaligned dword / dwordx4
+    // accesses natively (tools/unaligned_probe.hip).
+    u32 rset[PF][FB], dset[PF][FB];
+    auto issue_loads = [&](u32 Tn, u32 (&rs)[FB], u32 (&ds)[FB]) {
+        int itn = (int)Tn - lane;
+        itn = itn < 0 ? 0 : itn;
+        const u32 itc = min((u32)itn, full_iters > 0 ? full_iters - 1 : 0u);       // always a fully readable group
+        const uint8_t* pn = full_iters ? rbytes + (int64_t)itc * (4 * FB) : raw;   // rows shorter than one group use the tail path only
+        const uint8_t* dn = dprev + (int64_t)min(Tn, niter - 1) * (4 * FB);        // lane 0's iteration is Tn: wave-uniform address
+        #pragma unroll
+        for (int i = 0; i < FB; ++i) {
+            rs[i] = reinterpret_cast<const PackedU32*>(pn)[i].v;
+            ds[i] = reinterpret_cast<const u32*>(dn)[i] & dmask;
+        }
+    };
+    auto wait_for_band_above = [&](u32 upto) {      // wave-uniform: rows of the band above are visible up to iteration `upto`
+        const u32 need = prod_base + min(niter, upto);
+        while (__hip_atomic_load(&prog[prod_wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
+            __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    if (band > 0) wait_for_band_above(PUB + PF);
+    #pragma unroll
+    for (int u = 0; u < PF; ++u) issue_loads((u32)u, rset[u], dset[u]);
+
+    const u32 T_end = niter + 63 + PUBLAG;
+    for (u32 T0 = 0; T0 < T_end; T0 += PF) {
+        #pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const u32 T = T0 + u;
+            const int it = (int)T - lane;
+            const bool live = row_live && it >= 0 && it < (int)niter;
+
+            u32 rg[FB], bg[FB];
+            #pragma unroll
+            for (int i = 0; i < FB; ++i) rg[i] = rset[u][i];
+            if (live && it >= (int)full_iters) {          // ragged last group of a row: bytewise, zero-padded (never reads past the row)
+                const uint8_t* pt = rbytes + (int64_t)it * (4 * FB);
+                const u32 nb = a.wb - (u32)it * (4 * FB);
+                #pragma unroll
+                for (int i = 0; i < FB; ++i) rg[i] = 0;
+                #pragma unroll
+                for (int i = 0; i < 4 * FB; ++i) if ((u32)i < nb) rg[i >> 2] |= (u32)pt[i] << ((i & 3) * 8);
+            }
+            // upper row: lane j-1's outputs of its previous loop trip; lane 0 takes the band above (prefetched)
+            #pragma unroll
+            for (int i = 0; i < FB; ++i) bg[i] = from_lane_below(outp[i], dset[u][i]);
+
+            // consumer side of the band hand-off, then refill this register set for trip T+PF
+            if (band > 0 && T + PF < niter && ((T + PF) % PUB) == 0) wait_for_band_above(T + PF + PUB);
+            issue_loads(T + PF, rset[u], dset[u]);
+
+            u32 og[FB];
+            #pragma unroll
+            for (int i = 0; i < FB; ++i) og[i] = 0;
+            #pragma unroll
+            for (int k = 0; k < 4 * FB; ++k) {        // byte k of the group; its left / upper-left neighbours are FB bytes back
+                const u32 x  = byte_of(rg, k);
+                const u32 bb = byte_of(bg, k);
+                const u32 aa = k >= FB ? byte_of(og, k - FB) : byte_of(outp, 3 * FB + k);
+                u32 pred = ((aa & ma) + (bb & mb)) >> sh;
+                if constexpr (PAETH) {
+                    const u32 cc = k >= FB ? byte_of(bg, k - FB) : byte_of(bp, 3 * FB + k);
+                    const u32 pp = paeth(aa, bb, cc);
+                    pred = is_paeth ? pp : pred;
+                }
+                og[k >> 2] |= ((x + pred) & 0xFFu) << ((k & 3) * 8);
+            }
+
+            if (live) {
+                #pragma unroll
+                for (int i = 0; i < FB; ++i) { outp[i] = og[i]; bp[i] = bg[i]; }
+                uint8_t* dst = drow + (int64_t)it * (4 * FB);
+                const u32 valid = min(4u * FB, a.wb - (u32)it * (4 * FB));     // bytes of this group inside the row
+                if (valid == 4 * FB || !a.store_tail_masked) {
+                    if constexpr (FB == 4) *reinterpret_cast<uint4*>(dst) = make_uint4(og[0], og[1], og[2], og[3]);
+                    else if constexpr (FB == 2 || FB == 6) {
+                        #pragma unroll
+                        for (int i = 0; i < FB; i += 2) *reinterpret_cast<uint2*>(dst + 4 * i) = make_uint2(og[i], og[i + 1]);
+                    } else if constexpr (FB == 8) {
+                        *reinterpret_cast<uint4*>(dst) = make_uint4(og[0], og[1], og[2], og[3]);
+                        *reinterpret_cast<uint4*>(dst + 16) = make_uint4(og[4], og[5], og[6], og[7]);
+                    } else {
+                        #pragma unroll
+                        for (int i = 0; i < FB; ++i) reinterpret_cast<u32*>(dst)[i] = og[i];
+                    }
+                } else {
+                    for (u32 i = 0; i < valid; ++i) dst[i] = (uint8_t)(og[i >> 2] >> ((i & 3) * 8));
+                }
+            }
+
+            // producer side.  Lane 63 stored iteration T-63 in this trip; what is published is the iteration it stored
+            // PUBLAG trips ago: every trip issues at least two loads after its store, and the vector-memory counter
+            // retires in order, so once at most 2*PUBLAG operations are outstanding that older store has been
+            // acknowledged by the L2 -- without draining the prefetches that are in flight behind it.
+            const int itp = (int)T - 63 - PUBLAG;
+            if (itp >= 0 && itp < (int)niter && (((itp + 1) % PUB) == 0 || itp == (int)niter - 1)) {
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PUBLAG) : "memory");
+                if (lane == 63)
+                    __hip_atomic_store(&prog[wave], seq * niter + (u32)itp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+}
+
+template <int FB, int W>
+__global__ __launch_bounds__(W * 64) void k_png_defilter(DefilterArgs a)
+{
+    __shared__ u32 prog[W];                       // cumulative iterations finished (and visible) by each wave's lane 63
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int img = blockIdx.x;
     const uint8_t* raw = a.raw + (int64_t)img * a.raw_stride;
@@ -68,134 +203,198 @@ __global__ __launch_bounds__(PNG_WAVES * 64) void k_png_defilter(DefilterArgs a)
     const u32 npix = a.wb / FB;                   // filter units per row
     const u32 niter = (npix + 3) / 4;
     const u32 nbands = (a.rows + 63) / 64;
-    if (threadIdx.x < PNG_WAVES) prog[threadIdx.x] = 0;
+    if (threadIdx.x < W) prog[threadIdx.x] = 0;
     __syncthreads();
 
-    for (u32 band = wave; band < nbands; band += PNG_WAVES) {
-        const u32 seq = band / PNG_WAVES;
+    for (u32 band = wave; band < nbands; band += W) {
         const u32 row = band * 64 + lane;
         const bool row_live = row < a.rows;
-        const uint8_t* rp = raw + (int64_t)(row_live ? row : 0) * (a.wb + 1);
-        u32 f = row_live ? rp[0] : 0;
+        u32 f = row_live ? raw[(int64_t)row * (a.wb + 1)] : 0;
         if (f > 4) { if (a.status) atomicOr(a.status + img, 1u); f = 0; }
-        const u32 ma = (f == 1 || f == 3 || f == 4) ? 0xFFu : 0u;
-        const u32 mb = (f == 2 || f == 3 || f == 4) ? 0xFFu : 0u;
-        const u32 sh = (f == 3) ? 1u : 0u;
-        const bool is_paeth = f == 4;
-        const bool any_paeth = __any(is_paeth && row_live);
+        if (__any(f == 4)) defilter_band<FB, W, true >(a, raw, D, prog, band, wave, lane, niter, f, row_live);
+        else               defilter_band<FB, W, false>(a, raw, D, prog, band, wave, lane, niter, f, row_live);
+    }
+}
 
-        // aligned view of this lane's filtered bytes
-        const uintptr_t rstart = (uintptr_t)(rp + 1);
-        const u32* rword = (const u32*)(rstart & ~(uintptr_t)3);
-        const u32 rshift = (u32)(rstart & 3);
-        const u32* rlast = (const u32*)(((uintptr_t)raw + (uint64_t)a.rows * (a.wb + 1) - 1) & ~(uintptr_t)3);   // last dword holding a valid byte
-        uint8_t* drow = D + (int64_t)(row_live ? row : 0) * a.d_pitch;
-        const uint8_t* dprev = D + (int64_t)(band * 64 - 1) * a.d_pitch;        // row above lane 0 (band > 0 only)
-        const int prod_wave = (wave + PNG_WAVES - 1) % PNG_WAVES;
-        const u32 prod_base = (band > 0 ? (band - 1) / PNG_WAVES : 0) * niter;
+// =====================================================================================================
+// FB == 4 (8-bit RGBA, 16-bit grey+alpha): LDS-staged, coalesced I/O.
+//
+// With lane = row, a plain per-lane load/store touches 64 different cache lines per wave instruction and the
+// vector-memory address path serialises them (measured: 1.2 TB/s regardless of the filter mix, VALU idle).
+// Here a wave moves its band in tiles of TT loop trips: the 16-byte piece lane j needs in trip T is iteration
+// T - j of row j, so a tile is a parallelogram in (row, byte) space; it is fetched and written back by
+// cooperative instructions in which 8 consecutive lanes cover 128 contiguous bytes of one row.  Pieces live in
+// LDS at tile[row][T % TT]; a lane reads its raw piece, and overwrites the same slot with the de-filtered one.
+// The next tile's pieces are prefetched into registers while the current tile is processed.
+constexpr int TT = 8;
+constexpr int TILE_PITCH = TT * 16 + 16;          // bytes per row in LDS: 9 x 16 B => conflict-free ds_read_b128 across lanes
 
-        u32 outp[FB], bp[FB];                     // previous iteration: own outputs, upper-row values
+template <int W, bool PAETH>
+__device__ __forceinline__ void defilter_band4(const DefilterArgs& a, const uint8_t* raw, uint8_t* D, u32* prog, uint8_t* tile, u32 band,
+                                               int wave, int lane, u32 niter, u32 f, bool row_live)
+{
+    constexpr int FB = 4;
+    const u32 seq = band / W;
+    const u32 row = band * 64 + lane;
+    const u32 ma = (f == 1 || f == 3 || f == 4) ? 0xFFu : 0u;
+    const u32 mb = (f == 2 || f == 3 || f == 4) ? 0xFFu : 0u;
+    const u32 sh = (f == 3) ? 1u : 0u;
+    const bool is_paeth = f == 4;
+
+    const uint8_t* rbytes = raw + (int64_t)(row_live ? row : 0) * (a.wb + 1) + 1;
+    uint8_t* drow = D + (int64_t)(row_live ? row : 0) * a.d_pitch;
+    const uint8_t* dprev = band > 0 ? D + (int64_t)(band * 64 - 1) * a.d_pitch : D;
+    const u32 dmask = band > 0 ? 0xFFFFFFFFu : 0u;
+    const int prod_wave = (wave + W - 1) % W;
+    const u32 prod_base = (band > 0 ? (band - 1) / W : 0) * niter;
+    const u32 full_iters = a.wb / 16;
+
+    // cooperative mapping: in transfer k (0..7) this lane handles row 8k + crow, slot cslot
+    const int crow = lane >> 3, cslot = lane & 7;
+    const u32 rows_left = a.rows - band * 64;                           // live rows in this band (may exceed 64)
+    const uint8_t* craw = raw + (int64_t)(band * 64 + crow) * (a.wb + 1) + 1;
+    uint8_t* cdst = D + (int64_t)(band * 64 + crow) * a.d_pitch;
+    uint8_t* my_tile = tile + lane * TILE_PITCH;                        // this lane's row of pieces
+    uint8_t* co_tile = tile + crow * TILE_PITCH + cslot * 16;           // + k * 8 * TILE_PITCH
+
+    u32 outp[FB], bp[FB];
+    #pragma unroll
+    for (int i = 0; i < FB; ++i) { outp[i] = 0; bp[i] = 0; }
+
+    auto wait_for_band_above = [&](u32 upto) {
+        const u32 need = prod_base + min(niter, upto);
+        while (__hip_atomic_load(&prog[prod_wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
+            __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    // iteration handled by (row 8k+crow, slot cslot) in the tile starting at trip T0; clamped to a readable full piece
+    auto coop_iter = [&](u32 T0, int k) { return (int)T0 + cslot - (8 * k + crow); };
+
+    uint4 pre[TT];                                  // next tile's raw pieces (cooperative layout)
+    auto prefetch_tile = [&](u32 T0) {
         #pragma unroll
-        for (int i = 0; i < FB; ++i) { outp[i] = 0; bp[i] = 0; }
-        u32 carry = 0;                            // last aligned raw dword of the previous iteration
-        if (row_live) carry = *(rword < rlast ? rword : rlast);
+        for (int k = 0; k < 8; ++k) {
+            int it = coop_iter(T0, k);
+            const u32 r = (u32)(8 * k + crow) < rows_left ? (u32)(8 * k) : 0u;             // dead rows re-read a live one (unused)
+            it = it < 0 ? 0 : it;
+            const u32 itc = min((u32)it, full_iters > 0 ? full_iters - 1 : 0u);
+            const uint8_t* pn = full_iters ? craw + (int64_t)r * (a.wb + 1) + (int64_t)itc * 16 : raw;
+            const PackedU32* q = reinterpret_cast<const PackedU32*>(pn);
+            pre[k] = make_uint4(q[0].v, q[1].v, q[2].v, q[3].v);
+        }
+    };
+    u32 dset[PF][FB];
+    auto issue_dprev = [&](u32 Tn, u32 (&ds)[FB]) {
+        const uint8_t* dn = dprev + (int64_t)min(Tn, niter - 1) * 16;                      // lane 0's iteration is Tn: wave-uniform address
+        #pragma unroll
+        for (int i = 0; i < FB; ++i) ds[i] = reinterpret_cast<const u32*>(dn)[i] & dmask;
+    };
 
-        // Software prefetch: the loads of loop trip T+PF are issued at trip T into register set T % PF (static after
-        // unrolling by PF), so a lane always has PF iterations (PF*4*FB bytes) of its row in flight.
-        u32 rset[PF][FB], dset[PF][FB];
-        auto issue_loads = [&](u32 Tn, u32 (&rs)[FB], u32 (&ds)[FB]) {
-            const int itn = (int)Tn - lane;
-            const bool ln = row_live && itn >= 0 && itn < (int)niter;
-            const u32* pn = rword + (int64_t)(itn < 0 ? 0 : itn) * FB + 1;
-            #pragma unroll
-            for (int i = 0; i < FB; ++i) {
-                rs[i] = 0; ds[i] = 0;
-                if (ln) rs[i] = *((pn + i) < rlast ? (pn + i) : rlast);
-                if (ln && lane == 0 && band > 0) ds[i] = ((const u32*)dprev)[(int64_t)itn * FB + i];
+    if (band > 0) wait_for_band_above(PUB + PF);
+    prefetch_tile(0);
+    #pragma unroll
+    for (int u = 0; u < PF; ++u) issue_dprev((u32)u, dset[u]);
+
+    const u32 T_end = niter + 63;
+    for (u32 T0 = 0; T0 < T_end; T0 += TT) {
+        // stage this tile's raw pieces (prefetched) in LDS, then start fetching the next tile
+        #pragma unroll
+        for (int k = 0; k < 8; ++k) *reinterpret_cast<uint4*>(co_tile + k * 8 * TILE_PITCH) = pre[k];
+        prefetch_tile(T0 + TT);
+
+        #pragma unroll
+        for (int u = 0; u < TT; ++u) {
+            const u32 T = T0 + u;
+            const int it = (int)T - lane;
+            const bool live = row_live && it >= 0 && it < (int)niter;
+            const bool ragged = live && it >= (int)full_iters;
+
+            const uint4 rv = *reinterpret_cast<const uint4*>(my_tile + u * 16);
+            u32 rg[FB] = { rv.x, rv.y, rv.z, rv.w }, bg[FB];
+            if (ragged) {                                   // last, partial piece of a row: bytewise, zero-padded
+                const uint8_t* pt = rbytes + (int64_t)it * 16;
+                const u32 nb = a.wb - (u32)it * 16;
+                #pragma unroll
+                for (int i = 0; i < FB; ++i) rg[i] = 0;
+                #pragma unroll
+                for (int i = 0; i < 16; ++i) if ((u32)i < nb) rg[i >> 2] |= (u32)pt[i] << ((i & 3) * 8);
             }
-        };
-        auto wait_for_band_above = [&](u32 upto) {      // wave-uniform: rows of the band above are visible up to iteration `upto`
-            const u32 need = prod_base + min(niter, upto);
-            while (__hip_atomic_load(&prog[prod_wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
-                __builtin_amdgcn_s_sleep(2);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        };
-        if (band > 0) wait_for_band_above(PUB + PF);
-        #pragma unroll
-        for (int u = 0; u < PF; ++u) issue_loads((u32)u, rset[u], dset[u]);
-
-        const u32 T_end = niter + 63;
-        for (u32 T0 = 0; T0 < T_end; T0 += PF) {
             #pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                const u32 T = T0 + u;
-                const int it = (int)T - lane;
-                const bool live = row_live && it >= 0 && it < (int)niter;
+            for (int i = 0; i < FB; ++i) bg[i] = from_lane_below(outp[i], dset[u % PF][i]);
+            if (band > 0 && T + PF < niter && ((T + PF) % PUB) == 0) wait_for_band_above(T + PF + PUB);
+            issue_dprev(T + PF, dset[u % PF]);
 
-                // raw bytes of this iteration: FB dwords starting rshift bytes into the aligned stream
-                u32 rg[FB], bg[FB];
-                {
-                    u32 prev = carry;
-                    #pragma unroll
-                    for (int i = 0; i < FB; ++i) {
-                        rg[i] = __builtin_amdgcn_alignbyte(rset[u][i], prev, rshift);
-                        prev = rset[u][i];
-                    }
-                    if (live) carry = prev;
-                }
-                // upper row: lane j-1's outputs of its previous loop trip; lane 0 takes the band above (prefetched)
-                #pragma unroll
-                for (int i = 0; i < FB; ++i) bg[i] = from_lane_below(outp[i], dset[u][i]);
-
-                // consumer side of the band hand-off, then refill this register set for trip T+PF
-                if (band > 0 && T + PF < niter && ((T + PF) % PUB) == 0) wait_for_band_above(T + PF + PUB);
-                issue_loads(T + PF, rset[u], dset[u]);
-
-                u32 og[FB];
-                #pragma unroll
-                for (int i = 0; i < FB; ++i) og[i] = 0;
-                #pragma unroll
-                for (int k = 0; k < 4 * FB; ++k) {        // byte k of the group; its left / upper-left neighbours are FB bytes back
-                    const u32 x  = byte_of(rg, k);
-                    const u32 bb = byte_of(bg, k);
-                    const u32 aa = k >= FB ? byte_of(og, k - FB) : byte_of(outp, 3 * FB + k);
+            u32 og[FB] = { 0, 0, 0, 0 };
+            #pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const u32 x  = byte_of(rg, k);
+                const u32 bb = byte_of(bg, k);
+                const u32 aa = k >= FB ? byte_of(og, k - FB) : byte_of(outp, 3 * FB + k);
+                u32 pred = ((aa & ma) + (bb & mb)) >> sh;
+                if constexpr (PAETH) {
                     const u32 cc = k >= FB ? byte_of(bg, k - FB) : byte_of(bp, 3 * FB + k);
-                    u32 pred = ((aa & ma) + (bb & mb)) >> sh;
-                    if (any_paeth) { const u32 pp = paeth(aa, bb, cc); pred = is_paeth ? pp : pred; }
-                    og[k >> 2] |= ((x + pred) & 0xFFu) << ((k & 3) * 8);
+                    const u32 pp = paeth(aa, bb, cc);
+                    pred = is_paeth ? pp : pred;
                 }
-
-                if (live) {
-                    #pragma unroll
-                    for (int i = 0; i < FB; ++i) { outp[i] = og[i]; bp[i] = bg[i]; }
-                    uint8_t* dst = drow + (int64_t)it * (4 * FB);
-                    const u32 valid = min(4u * FB, a.wb - (u32)it * (4 * FB));     // bytes of this group inside the row
-                    if (valid == 4 * FB || !a.store_tail_masked) {
-                        if constexpr (FB == 4) *reinterpret_cast<uint4*>(dst) = make_uint4(og[0], og[1], og[2], og[3]);
-                        else if constexpr (FB == 2 || FB == 6) {
-                            #pragma unroll
-                            for (int i = 0; i < FB; i += 2) *reinterpret_cast<uint2*>(dst + 4 * i) = make_uint2(og[i], og[i + 1]);
-                        } else if constexpr (FB == 8) {
-                            *reinterpret_cast<uint4*>(dst) = make_uint4(og[0], og[1], og[2], og[3]);
-                            *reinterpret_cast<uint4*>(dst + 16) = make_uint4(og[4], og[5], og[6], og[7]);
-                        } else {
-                            #pragma unroll
-                            for (int i = 0; i < FB; ++i) reinterpret_cast<u32*>(dst)[i] = og[i];
-                        }
-                    } else {
-                        for (u32 i = 0; i < valid; ++i) dst[i] = (uint8_t)(og[i >> 2] >> ((i & 3) * 8));
-                    }
-                }
-
-                // producer side: lane 63 finished iteration T-63
-                const int it63 = (int)T - 63;
-                if (it63 >= 0 && it63 < (int)niter && (((it63 + 1) % PUB) == 0 || it63 == (int)niter - 1)) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    if (lane == 63)
-                        __hip_atomic_store(&prog[wave], seq * niter + (u32)it63 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
+                og[k >> 2] |= ((x + pred) & 0xFFu) << ((k & 3) * 8);
+            }
+            if (live) {
+                #pragma unroll
+                for (int i = 0; i < FB; ++i) { outp[i] = og[i]; bp[i] = bg[i]; }
+            }
+            *reinterpret_cast<uint4*>(my_tile + u * 16) = make_uint4(og[0], og[1], og[2], og[3]);
+            if (ragged) {
+                uint8_t* dst = drow + (int64_t)it * 16;
+                const u32 nb = a.wb - (u32)it * 16;
+                if (!a.store_tail_masked) *reinterpret_cast<uint4*>(dst) = make_uint4(og[0], og[1], og[2], og[3]);
+                else for (u32 i = 0; i < nb; ++i) dst[i] = (uint8_t)(og[i >> 2] >> ((i & 3) * 8));
             }
         }
+
+        // write the tile's de-filtered pieces back, 128 contiguous bytes per row
+        #pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int it = coop_iter(T0, k);
+            const uint4 v = *reinterpret_cast<const uint4*>(co_tile + k * 8 * TILE_PITCH);
+            if ((u32)(8 * k + crow) < rows_left && it >= 0 && it < (int)full_iters)
+                *reinterpret_cast<uint4*>(cdst + (int64_t)(8 * k) * a.d_pitch + (int64_t)it * 16) = v;
+        }
+        // publish what lane 63 stored in the PREVIOUS tile: since then this tile issued 8 prefetch loads and 8
+        // row-above loads, so "at most 16 vector-memory operations outstanding" implies those older stores have been
+        // acknowledged (the counter retires in order) -- the prefetches in flight are not drained.
+        const int done = (int)T0 - 63;                        // iterations of lane 63 written back before this tile
+        if (done > 0) {
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            if (lane == 63)
+                __hip_atomic_store(&prog[wave], seq * niter + min((u32)done, niter), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    // band finished: everything is on its way; drain and publish the whole band
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 63)
+        __hip_atomic_store(&prog[wave], seq * niter + niter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int W>
+__global__ __launch_bounds__(W * 64, 4) void k_png_defilter4_tiled(DefilterArgs a)
+{
+    __shared__ u32 prog[W];
+    __shared__ __attribute__((aligned(16))) uint8_t tiles[W][64 * TILE_PITCH];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int img = blockIdx.x;
+    const uint8_t* raw = a.raw + (int64_t)img * a.raw_stride;
+    uint8_t* D = a.D + (int64_t)img * a.d_stride;
+    const u32 niter = (a.wb / 4 + 3) / 4;
+    const u32 nbands = (a.rows + 63) / 64;
+    if (threadIdx.x < W) prog[threadIdx.x] = 0;
+    __syncthreads();
+    for (u32 band = wave; band < nbands; band += W) {
+        const u32 row = band * 64 + lane;
+        const bool row_live = row < a.rows;
+        u32 f = row_live ? raw[(int64_t)row * (a.wb + 1)] : 0;
+        if (f > 4) { if (a.status) atomicOr(a.status + img, 1u); f = 0; }
+        if (__any(f == 4)) defilter_band4<W, true >(a, raw, D, prog, tiles[wave], band, wave, lane, niter, f, row_live);
+        else               defilter_band4<W, false>(a, raw, D, prog, tiles[wave], band, wave, lane, niter, f, row_live);
     }
 }
 
@@ -358,12 +557,12 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
     }
     const dim3 grid(count), block(PNG_WAVES * 64);
     switch (FB) {
-    case 1: hipLaunchKernelGGL(k_png_defilter<1>, grid, block, 0, stream, a); break;
-    case 2: hipLaunchKernelGGL(k_png_defilter<2>, grid, block, 0, stream, a); break;
-    case 3: hipLaunchKernelGGL(k_png_defilter<3>, grid, block, 0, stream, a); break;
-    case 4: hipLaunchKernelGGL(k_png_defilter<4>, grid, block, 0, stream, a); break;
-    case 6: hipLaunchKernelGGL(k_png_defilter<6>, grid, block, 0, stream, a); break;
-    case 8: hipLaunchKernelGGL(k_png_defilter<8>, grid, block, 0, stream, a); break;
+    case 1: hipLaunchKernelGGL((k_png_defilter<1, PNG_WAVES>), grid, block, 0, stream, a); break;
+    case 2: hipLaunchKernelGGL((k_png_defilter<2, PNG_WAVES>), grid, block, 0, stream, a); break;
+    case 3: hipLaunchKernelGGL((k_png_defilter<3, PNG_WAVES>), grid, block, 0, stream, a); break;
+    case 4: hipLaunchKernelGGL((k_png_defilter4_tiled<PNG_WAVES>), grid, block, 0, stream, a); break;
+    case 6: hipLaunchKernelGGL((k_png_defilter<6, PNG_WAVES>), grid, block, 0, stream, a); break;
+    case 8: hipLaunchKernelGGL((k_png_defilter<8, PNG_WAVES>), grid, block, 0, stream, a); break;
     default: return set_error(GAMUT_HIP_ERR_INVALID_ARG, "png_defilter: unsupported filter unit %d", FB);
     }
     if (int rc = launch_status("png_defilter")) return rc;

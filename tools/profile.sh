@@ -1,0 +1,19 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): rocprofv3 kernel trace + FETCH_SIZE / WRITE_SIZE passes for one bench workload.
+#   bash tools/profile.sh <tag> <pmc-batch> -- <bench.py args...>
+# Condensed summaries land in gpurun_out/summary_<tag>/ (copy what you want judged into profiles/).
+set -u
+TAG=$1; PB=$2; shift 3
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+python $REPO/bench.py "$@" > $OUT/bench.json 2> $OUT/bench.err
+tail -1 $OUT/bench.json
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o t -- python $REPO/bench.py "$@" --no-cpu > $OUT/trace.log 2>&1
+rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o t -- python $REPO/bench.py "$@" --steps 3 --warmup 1 --no-cpu --batch $PB > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o t -- python $REPO/bench.py "$@" --steps 3 --warmup 1 --no-cpu --batch $PB > $OUT/pmc_write.log 2>&1
+python $REPO/tools/summarize_prof.py $OUT $REPO/gpurun_out/summary_$TAG $PB | grep -A12 gamut | head -40
+cp $OUT/bench.json $REPO/gpurun_out/summary_$TAG/bench.json
+rm -rf $OUT
+grep gamut $REPO/gpurun_out/summary_$TAG/kernel_stats.csv | cut -c1-200

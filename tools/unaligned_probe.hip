@@ -6,7 +6,8 @@
 __global__ void k(const unsigned char* src, unsigned char* dst, int off)
 {
     const int t = threadIdx.x;
-    uint4 v; unsigned w;
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    v4u v; unsigned w;
     asm volatile("global_load_dwordx4 %0, %1, off\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(src + off + t * 16) : "memory");
     asm volatile("global_load_dword %0, %1, off\n s_waitcnt vmcnt(0)" : "=v"(w) : "v"(src + off + t * 4) : "memory");
     asm volatile("global_store_dwordx4 %0, %1, off\n s_waitcnt vmcnt(0)" :: "v"(dst + off + t * 16), "v"(v) : "memory");

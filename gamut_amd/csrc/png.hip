@@ -277,9 +277,9 @@ __device__ __forceinline__ void defilter_band4(const DefilterArgs& a, const uint
             int it = coop_iter(T0, k);
             const u32 r = (u32)(8 * k + crow) < rows_left ? (u32)(8 * k) : 0u;             // dead rows re-read a live one (unused)
             it = it < 0 ? 0 : it;
-            const u32 itc = min((u32)it, full_iters > 0 ? full_iters - 1 : 0u);
-            const uint8_t* pn = full_iters ? craw + (int64_t)r * (a.wb + 1) + (int64_t)itc * 16 : raw;
-            const PackedU32* q = reinterpret_cast<const PackedU32*>(pn);
+            // full pieces by index; the ragged last piece (and anything past it, unused) = the last 16 bytes of the row
+            const int64_t off = (u32)it < full_iters ? (int64_t)it * 16 : (int64_t)a.wb - 16;
+            const PackedU32* q = reinterpret_cast<const PackedU32*>(craw + (int64_t)r * (a.wb + 1) + off);
             pre[k] = make_uint4(q[0].v, q[1].v, q[2].v, q[3].v);
         }
     };
@@ -311,13 +311,15 @@ __device__ __forceinline__ void defilter_band4(const DefilterArgs& a, const uint
 
             const uint4 rv = *reinterpret_cast<const uint4*>(my_tile + u * 16);
             u32 rg[FB] = { rv.x, rv.y, rv.z, rv.w }, bg[FB];
-            if (ragged) {                                   // last, partial piece of a row: bytewise, zero-padded
-                const uint8_t* pt = rbytes + (int64_t)it * 16;
-                const u32 nb = a.wb - (u32)it * 16;
-                #pragma unroll
-                for (int i = 0; i < FB; ++i) rg[i] = 0;
-                #pragma unroll
-                for (int i = 0; i < 16; ++i) if ((u32)i < nb) rg[i >> 2] |= (u32)pt[i] << ((i & 3) * 8);
+            if (__any(ragged)) {        // last, partial piece of a row: the staged piece is the row's LAST 16 bytes (see prefetch_tile);
+                if (ragged) {           // keep its top nb bytes, moved down.  wb % 4 == 0, so the shift is whole dwords.  No memory op here.
+                    const u32 nb = a.wb - (u32)it * 16;
+                    const u32 v1 = rg[1], v2 = rg[2], v3 = rg[3];
+                    rg[0] = nb == 12 ? v1 : nb == 8 ? v2 : v3;
+                    rg[1] = nb == 12 ? v2 : nb == 8 ? v3 : 0u;
+                    rg[2] = nb == 12 ? v3 : 0u;
+                    rg[3] = 0u;
+                }
             }
             #pragma unroll
             for (int i = 0; i < FB; ++i) bg[i] = from_lane_below(outp[i], dset[u % PF][i]);
@@ -343,11 +345,12 @@ __device__ __forceinline__ void defilter_band4(const DefilterArgs& a, const uint
                 for (int i = 0; i < FB; ++i) { outp[i] = og[i]; bp[i] = bg[i]; }
             }
             *reinterpret_cast<uint4*>(my_tile + u * 16) = make_uint4(og[0], og[1], og[2], og[3]);
-            if (ragged) {
-                uint8_t* dst = drow + (int64_t)it * 16;
-                const u32 nb = a.wb - (u32)it * 16;
-                if (!a.store_tail_masked) *reinterpret_cast<uint4*>(dst) = make_uint4(og[0], og[1], og[2], og[3]);
-                else for (u32 i = 0; i < nb; ++i) dst[i] = (uint8_t)(og[i >> 2] >> ((i & 3) * 8));
+            if (__any(ragged)) {        // partial piece: up to three dword stores straight to the row (not part of the cooperative write-back)
+                u32* dst = reinterpret_cast<u32*>(drow + (int64_t)(ragged ? it : 0) * 16);
+                const u32 nb = ragged ? a.wb - (u32)it * 16 : 0u;
+                if (nb >= 4) dst[0] = og[0];
+                if (nb >= 8) dst[1] = og[1];
+                if (nb >= 12) dst[2] = og[2];
             }
         }
 
@@ -375,8 +378,8 @@ __device__ __forceinline__ void defilter_band4(const DefilterArgs& a, const uint
         __hip_atomic_store(&prog[wave], seq * niter + niter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int W>
-__global__ __launch_bounds__(W * 64, 4) void k_png_defilter4_tiled(DefilterArgs a)
+template <int W, int MINW>
+__global__ __launch_bounds__(W * 64, MINW) void k_png_defilter4_tiled(DefilterArgs a)
 {
     __shared__ u32 prog[W];
     __shared__ __attribute__((aligned(16))) uint8_t tiles[W][64 * TILE_PITCH];
@@ -560,7 +563,12 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
     case 1: hipLaunchKernelGGL((k_png_defilter<1, PNG_WAVES>), grid, block, 0, stream, a); break;
     case 2: hipLaunchKernelGGL((k_png_defilter<2, PNG_WAVES>), grid, block, 0, stream, a); break;
     case 3: hipLaunchKernelGGL((k_png_defilter<3, PNG_WAVES>), grid, block, 0, stream, a); break;
-    case 4: hipLaunchKernelGGL((k_png_defilter4_tiled<PNG_WAVES>), grid, block, 0, stream, a); break;
+    case 4:
+        // tiled kernel: 8 waves per workgroup, register budget left unconstrained (160+ VGPRs, no spills): measured faster
+        // than 128-VGPR variants that spill (tools notes in DESIGN.md)
+        if (wb < 16) hipLaunchKernelGGL((k_png_defilter<4, PNG_WAVES>), grid, block, 0, stream, a);
+        else         hipLaunchKernelGGL((k_png_defilter4_tiled<PNG_WAVES, 2>), grid, block, 0, stream, a);
+        break;
     case 6: hipLaunchKernelGGL((k_png_defilter<6, PNG_WAVES>), grid, block, 0, stream, a); break;
     case 8: hipLaunchKernelGGL((k_png_defilter<8, PNG_WAVES>), grid, block, 0, stream, a); break;
     default: return set_error(GAMUT_HIP_ERR_INVALID_ARG, "png_defilter: unsupported filter unit %d", FB);

@@ -1,0 +1,125 @@
+"""CPU tests of the product side: the C-ABI library loads without a GPU and exports every symbol include/gamut_hip.h
+declares; host-side logic (JPEG entropy feeder, PNG header scan, argument validation, error conventions) agrees with
+the oracle.  No compute entry point is exercised here (there is no CPU fallback to exercise)."""
+import ctypes as C
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from gamut_amd import _capi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+G = os.path.join(HERE, "golden")
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "gamut_hip.h")).read()
+    declared = set(re.findall(r"\b(gamut_hip_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 25
+    raw = C.CDLL(_capi.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(raw, name), f"libgamut_hip.so does not export {name}"
+    assert declared == set(_capi.SIGNATURES), "python binding table and header disagree"
+    L = _capi.lib()
+    assert b"gfx950" in L.gamut_hip_version()
+
+
+def test_enums_mirror_the_reference():
+    header = open(os.path.join(ROOT, "include", "gamut_hip.h")).read()
+    names = re.search(r"GAMUT_PIXEL_l8 = 0,(.*?)GAMUT_PIXEL_COUNT", header, re.S).group(1)
+    order = ["l8"] + re.findall(r"GAMUT_PIXEL_([a-z0-9]+)", names)
+    assert order == O.PIXEL_TYPES                                  # types.d:32-59 ordinals
+    L = _capi.lib()
+    for i, n in enumerate(O.PIXEL_TYPES):
+        assert L.gamut_hip_pixel_type_size(i) == O.PT_SIZE[i] == O.lib().orc_pixel_type_size(i)
+        for j in range(len(O.PIXEL_TYPES)):
+            assert L.gamut_hip_scanlines_inter_type(i, j) == O.lib().orc_scanlines_inter_type(i, j)
+    assert L.gamut_hip_pixel_type_size(-1) == 0 and L.gamut_hip_pixel_type_size(18) == 0
+
+
+JPEGS = sorted(glob.glob(os.path.join(G, "jpeg", "*.jpg"))) + [os.path.join(G, "ref_images", "issue35.jpg")]
+
+
+@pytest.mark.parametrize("path", JPEGS, ids=[os.path.basename(p) for p in JPEGS])
+def test_jpeg_feeder_matches_oracle(path):
+    """product host feeder (jpeg_host.hip) == oracle feeder: coefficients, max_zag, geometry, JFIF metadata"""
+    L = _capi.lib()
+    data = open(path, "rb").read()
+    buf = np.frombuffer(data, np.uint8)
+    fr = _capi.JpegFrame()
+    _capi.check(L.gamut_hip_jpeg_decode_coeffs(buf.ctypes.data, buf.size, C.byref(fr)))
+    d = O.DecodedJpeg(data)
+    n = fr.mcus_per_row * fr.mcus_per_col * fr.blocks_per_mcu
+    assert (fr.width, fr.height, fr.comps, fr.scan_type, fr.mcus_per_row, fr.mcus_per_col, fr.blocks_per_mcu) == \
+           (d.width, d.height, d.comps, d.scan_type, d.mcus_per_row, d.mcus_per_col, d.blocks_per_mcu)
+    assert np.array_equal(np.ctypeslib.as_array(fr.coeffs, (n, 64)), d.coeffs)
+    assert np.array_equal(np.ctypeslib.as_array(fr.max_zag, (n,)), d.max_zag)
+    assert (fr.pixel_aspect_ratio, fr.dpi_y) == (d.pixel_aspect_ratio, d.dpi_y)
+    L.gamut_hip_jpeg_frame_free(C.byref(fr))
+    L.gamut_hip_jpeg_frame_free(C.byref(fr))           # idempotent
+
+
+def test_jpeg_feeder_rejects_bad_streams():
+    L = _capi.lib()
+    fr = _capi.JpegFrame()
+    good = open(os.path.join(G, "ref_images", "issue35.jpg"), "rb").read()
+    cases = [b"", b"\xff\xd8", b"\x89PNG\r\n\x1a\n" + b"0" * 64, good[:200], good[:4000],
+             good.replace(b"\xff\xc0", b"\xff\xc2", 1)]                                  # progressive SOF: not supported by the GPU feeder
+    for data in cases:
+        buf = np.frombuffer(data, np.uint8) if data else np.zeros(1, np.uint8)
+        rc = L.gamut_hip_jpeg_decode_coeffs(buf.ctypes.data, len(data), C.byref(fr))
+        assert rc == _capi.ERR_DECODE and L.gamut_hip_last_error() != b"", data[:8]
+        assert not fr.coeffs and not fr.max_zag
+    assert L.gamut_hip_jpeg_decode_coeffs(None, 0, None) == _capi.ERR_INVALID_ARG
+
+
+def test_png_is16():
+    L = _capi.lib()
+    for name, exp in [("issue76.png", 1), ("issue65.png", 0), ("vst3-compatible.png", 0), ("issue35.jpg", 0)]:
+        buf = np.frombuffer(open(os.path.join(G, "ref_images", name), "rb").read(), np.uint8)
+        assert L.gamut_hip_png_is16(buf.ctypes.data, buf.size) == exp
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    """on a box without a GPU every compute entry point reports an error; nothing is computed on the CPU"""
+    L = _capi.lib()
+    if L.gamut_hip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    a = np.zeros(16, np.uint8); b = np.full(64, 0xA5, np.uint8)
+    rc = L.gamut_hip_scanlines_convert(O.PT["rgba8"], a.ctypes.data, 16, O.PT["rgbaf32"], b.ctypes.data, 64, 4, 1)
+    assert rc == _capi.ERR_NO_DEVICE and b"no HIP device" in L.gamut_hip_last_error()
+    assert (b == 0xA5).all()
+    assert L.gamut_hip_init(0) == _capi.ERR_NO_DEVICE
+    with pytest.raises(_capi.GamutHipError):
+        _capi.check(rc)
+    buf = np.frombuffer(open(os.path.join(G, "ref_images", "issue35.jpg"), "rb").read(), np.uint8)
+    w, h, ac = C.c_int(), C.c_int(), C.c_int()
+    par, dpi = C.c_float(), C.c_float()
+    assert not L.gamut_hip_decompress_jpeg_image_from_memory(buf.ctypes.data, buf.size, C.byref(w), C.byref(h), C.byref(ac), C.byref(par), C.byref(dpi), 4)
+    png = np.frombuffer(open(os.path.join(G, "ref_images", "issue76.png"), "rb").read(), np.uint8)
+    f = C.c_float()
+    assert not L.gamut_hip_stbi_load_from_memory(png.ctypes.data, png.size, C.byref(w), C.byref(h), C.byref(ac), 0, C.byref(f), C.byref(f), C.byref(f))
+    assert b"no HIP device" in L.gamut_hip_last_error()
+
+
+def test_argument_validation_needs_no_device():
+    L = _capi.lib()
+    d = np.zeros(64, np.uint8)
+    p = d.ctypes.data
+    assert L.gamut_hip_scanlines_convert_device(-1, p, 4, 0, 12, p, 4, 0, 1, 1, 1, None) == _capi.ERR_INVALID_ARG
+    assert L.gamut_hip_scanlines_convert_device(12, p, 4, 0, 18, p, 4, 0, 1, 1, 1, None) == _capi.ERR_INVALID_ARG
+    assert L.gamut_hip_scanlines_convert_device(12, p, 4, 0, 14, p, 16, 0, 0, 5, 1, None) == _capi.OK          # zero-size: nothing to do (image.d:1217-1224)
+    assert L.gamut_hip_jpeg_reconstruct_batch_device(p, 0, None, 0, p, 4, 0, 0, 8, 4, 4, 1, None) == _capi.ERR_INVALID_ARG
+    assert L.gamut_hip_jpeg_reconstruct_batch_device(p, 0, None, 0, p, 4, 0, 20000, 8, 4, 4, 1, None) == _capi.ERR_INVALID_ARG    # > 16384 (jpegload.d:102)
+    assert L.gamut_hip_jpeg_reconstruct_batch_device(p, 0, None, 0, p, 4, 0, 8, 8, 7, 4, 1, None) == _capi.ERR_INVALID_ARG
+    assert L.gamut_hip_jpeg_reconstruct_batch_device(p, 0, None, 0, p, 4, 0, 8, 8, 4, 2, 1, None) == _capi.ERR_INVALID_ARG        # 2 comps never produced by the codec (jpeg.d:55-56)
+    assert L.gamut_hip_png_defilter_batch_device(p, 0, 64, p, 0, 4, 4, 4, 4, 3, 6, 1, None, None) == _capi.ERR_INVALID_ARG       # depth 3
+    assert L.gamut_hip_png_defilter_batch_device(p, 0, 64, p, 0, 4, 4, 4, 2, 8, 6, 1, None, None) == _capi.ERR_INVALID_ARG       # out_n < img_n
+    assert L.gamut_hip_png_defilter_batch_device(p, 0, 10, p, 0, 4, 4, 4, 4, 8, 6, 1, None, None) == _capi.ERR_DECODE            # not enough pixels (stbdec.d:1430)
+    assert L.gamut_hip_png_defilter_batch_device(p, 0, 64, p, 0, 0, 4, 4, 4, 8, 6, 1, None, None) == _capi.ERR_INVALID_ARG       # 0-pixel image (stbdec.d:1897)
+    assert b"png_defilter" in L.gamut_hip_last_error()

@@ -133,7 +133,7 @@ def main():
         out = torch.empty((B, npx * O.PT_SIZE[dt_]), dtype=torch.uint8, device=dev)
         px_per_step = B * npx
         bytes_per_step = px_per_step * (O.PT_SIZE[st] + O.PT_SIZE[dt_])
-        kernel_name = "k_convert_vec"
+        kernel_name = f"k_convert_vec<{st}, {dt_}>"
         workload = f"convertTo {s}->{d}, {B} layers of {w}x{h}, gapless"
         sp, dp = w * O.PT_SIZE[st], w * O.PT_SIZE[dt_]
 

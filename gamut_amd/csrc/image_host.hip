@@ -1,0 +1,409 @@
+// image_host.hip -- host-side mirror of Gamut's `struct Image` (source/gamut/image.d) for the GPU path,
+// exported through include/gamut_image.h.  Written in C++ because the image has no D compiler; member
+// names, state and error strings follow the reference so a test written against image.d reads the same.
+//
+//   fields                       image.d:1573-1620
+//   error state                  image.d:1563-1570, internals/errors.d:14-35
+//   allocatePixelStorage         internals/types.d:355-540      (border / trailing / multiplicity / alignment / v-flip / bonus bytes)
+//   layout constraint helpers    internals/types.d:166-289
+//   load flags                   internals/types.d:563-661, types.d:351-602
+//   loadFromMemory               image.d:886-901, 1751-1772 ; loadJPEG plugins/jpeg.d:42-104 ; loadPNG plugins/png.d:44-163
+//   convertTo                    image.d:1180-1332 ; getAdHocLayoutConstraints :1809-1905
+//
+// Pixel storage is host malloc memory, as in the reference.  Every pixel operation goes to the GPU through
+// the C ABI of gamut_hip.h (host drop-ins); nothing is computed on the CPU here.
+#include "common.hpp"
+#include "../../include/gamut_image.h"
+#include <new>
+
+namespace {
+
+using namespace gamut;
+
+const char* const kStrImageHasNoType           = "Image has no type";
+const char* const kStrImageDecodingFailed      = "Image decoding failed";
+const char* const kStrImageFormatUnidentified  = "Unidentified image format";
+const char* const kStrImageNotInitialized      = "Uninitialized image";
+const char* const kStrImageTooLarge            = "Can't have an image that exceeds Gamut size limitations";
+const char* const kStrImageWrongComponents     = "Invalid number of component for image";
+const char* const kStrInvalidFlags             = "Invalid image decoding flags";
+const char* const kStrIllegalNegativeDimension = "Illegal negative dimension";
+const char* const kStrIllegalLayoutConstraints = "Cannot satisfy illegal layout constraints";
+const char* const kStrOutOfMemory              = "Out of memory";
+const char* const kStrUnsupportedTypeConversion= "Unsupported image pixel type conversion";
+const char* const kStrUnsupportedVFlip         = "Can't flip image vertically";
+const char* const kStrOverlappingScanlines     = "Scanlines are overlapping";
+
+constexpr int  MAX_W = 16777216, MAX_H = 16777216, MAX_LAYERS = 4194303;          // types.d:103-110
+constexpr long long MAX_BYTES = 34359738368LL;                                     // types.d:117
+constexpr int  BORDER_MASK = 384;
+
+// ---- layout constraint helpers (internals/types.d:166-289) ----
+int layoutMultiplicity(int c)      { return 1 << (c & 3); }
+int layoutTrailingPixels(int c)    { return (1 << ((c & 0x0C) >> 2)) - 1; }
+int layoutScanlineAlignment(int c) { return 1 << ((c >> 4) & 0x0f); }
+int layoutBorderWidth(int c)       { return (c >> 7) & 3; }
+bool layoutGapless(int c)          { return (c & GAMUT_LAYOUT_GAPLESS) != 0; }
+
+bool layoutConstraintsValid(int c)
+{
+    if ((c & GAMUT_LAYOUT_VERT_FLIPPED) && (c & GAMUT_LAYOUT_VERT_STRAIGHT)) return false;
+    if (layoutGapless(c)) {
+        if (layoutMultiplicity(c) > 1 || layoutTrailingPixels(c) > 0 || layoutScanlineAlignment(c) > 1 || layoutBorderWidth(c) > 0) return false;
+    }
+    return true;
+}
+bool layoutConstraintsCompatible(int newer, int older)
+{
+    if ((newer & GAMUT_LAYOUT_GAPLESS) && !(older & GAMUT_LAYOUT_GAPLESS)) return false;
+    if ((newer & GAMUT_LAYOUT_VERT_FLIPPED) && !(older & GAMUT_LAYOUT_VERT_FLIPPED)) return false;
+    if ((newer & GAMUT_LAYOUT_VERT_STRAIGHT) && !(older & GAMUT_LAYOUT_VERT_STRAIGHT)) return false;
+    if (layoutMultiplicity(newer) > layoutMultiplicity(older)) return false;
+    if (layoutTrailingPixels(newer) > layoutTrailingPixels(older)) return false;
+    if (layoutScanlineAlignment(newer) > layoutScanlineAlignment(older)) return false;
+    if (layoutBorderWidth(newer) > layoutBorderWidth(older)) return false;
+    return true;
+}
+int pointerAlignment(size_t p)      // getPointerAlignment, internals/types.d:202-213
+{
+    for (int k = 7; k >= 1; --k) if ((p & ((size_t(1) << k) - 1)) == 0) return k << 4;
+    return 0;
+}
+bool imageIsValidSize(int layers, int w, int h)
+{
+    return !(layers < 0 || w < 0 || h < 0 || layers > MAX_LAYERS || w > MAX_W || h > MAX_H);
+}
+
+// ---- PixelType algebra (types.d:351-602): type = family*3 + depth, family l, la, lap, rgb, rgba, rgbap ----
+int convertPixelType(int t, int op)
+{
+    if (!valid_type(t)) return GAMUT_PIXEL_unknown;
+    int fam = t / 3, depth = t % 3;
+    switch (op) {
+    case GAMUT_TO_GREYSCALE:  if (fam >= 3) fam -= 3; break;
+    case GAMUT_TO_RGB:        if (fam < 3) fam += 3; break;
+    case GAMUT_TO_ADD_ALPHA:  if (fam == 0 || fam == 3) fam += 1; break;
+    case GAMUT_TO_DROP_ALPHA: if (fam == 1 || fam == 2) fam = 0; else if (fam >= 4) fam = 3; break;
+    case GAMUT_TO_PREMUL:     if (fam == 1 || fam == 4) fam += 1; break;
+    case GAMUT_TO_NO_PREMUL:  if (fam == 2 || fam == 5) fam -= 1; break;
+    case GAMUT_TO_8BIT:  depth = 0; break;
+    case GAMUT_TO_16BIT: depth = 1; break;
+    case GAMUT_TO_FP32:  depth = 2; break;
+    default: return GAMUT_PIXEL_unknown;
+    }
+    return fam * 3 + depth;
+}
+bool validLoadFlags(int f)          // internals/types.d:563-578
+{
+    if ((f & GAMUT_LOAD_GREYSCALE) && (f & GAMUT_LOAD_RGB)) return false;
+    if ((f & GAMUT_LOAD_ALPHA) && (f & GAMUT_LOAD_NO_ALPHA)) return false;
+    if ((f & GAMUT_LOAD_PREMUL) && (f & GAMUT_LOAD_NO_PREMUL)) return false;
+    int bits = 0;
+    if (f & GAMUT_LOAD_8BIT) ++bits;
+    if (f & GAMUT_LOAD_16BIT) ++bits;
+    if (f & GAMUT_LOAD_FP32) ++bits;
+    return bits <= 1;
+}
+int computeRequestedImageComponents(int f)      // internals/types.d:587-609
+{
+    int req = -1;
+    if (!validLoadFlags(f)) return 0;
+    if (f & GAMUT_LOAD_GREYSCALE) { if (f & GAMUT_LOAD_ALPHA) req = 2; else if (f & GAMUT_LOAD_NO_ALPHA) req = 1; }
+    else if (f & GAMUT_LOAD_RGB)  { if (f & GAMUT_LOAD_ALPHA) req = 4; else if (f & GAMUT_LOAD_NO_ALPHA) req = 3; }
+    return req;
+}
+int applyLoadFlags(int type, int f)             // internals/types.d:627-661
+{
+    if (!validLoadFlags(f)) return GAMUT_PIXEL_unknown;
+    static const int order[][2] = { { GAMUT_LOAD_GREYSCALE, GAMUT_TO_GREYSCALE }, { GAMUT_LOAD_RGB, GAMUT_TO_RGB },
+        { GAMUT_LOAD_ALPHA, GAMUT_TO_ADD_ALPHA }, { GAMUT_LOAD_NO_ALPHA, GAMUT_TO_DROP_ALPHA }, { GAMUT_LOAD_8BIT, GAMUT_TO_8BIT },
+        { GAMUT_LOAD_16BIT, GAMUT_TO_16BIT }, { GAMUT_LOAD_FP32, GAMUT_TO_FP32 }, { GAMUT_LOAD_PREMUL, GAMUT_TO_PREMUL },
+        { GAMUT_LOAD_NO_PREMUL, GAMUT_TO_NO_PREMUL } };
+    for (auto& o : order) if (f & o[0]) type = convertPixelType(type, o[1]);
+    return type;
+}
+
+// ---- allocatePixelStorage (internals/types.d:355-540) ----
+struct Storage { uint8_t* data = nullptr; uint8_t* alloc = nullptr; int pitch = 0; int layerOffset = 0; };
+bool allocatePixelStorage(uint8_t* existing, int type, int layers, int width, int height, int constraints, int bonusBytes,
+                          bool clearWithZeroes, Storage& out)
+{
+    if (!imageIsValidSize(layers, width, height)) return false;
+    const int border = layoutBorderWidth(constraints), rowAlignment = layoutScanlineAlignment(constraints);
+    const int trailingPixels = layoutTrailingPixels(constraints), xMultiplicity = layoutMultiplicity(constraints);
+    auto nextMultipleOf = [](size_t base, size_t multiple) { return multiple * ((base + multiple - 1) / multiple); };
+    const int rightPadding = (int)nextMultipleOf((size_t)(width + border), (size_t)xMultiplicity) - (width + border);
+    int borderRight = border + rightPadding;
+    if (borderRight < trailingPixels) borderRight = trailingPixels;
+    const int actualWidthInPixels = border + width + borderRight;
+    const long long actualHeightOfOneLayer = (long long)border + height + border;
+    const long long actualHeightInPixels = actualHeightOfOneLayer * layers;
+    const int pixelSize = kPixelSize[type];
+    int bytePitch = pixelSize * actualWidthInPixels;
+    bytePitch = (int)nextMultipleOf((size_t)bytePitch, (size_t)rowAlignment);
+    long long sizeNeeded = (long long)bytePitch * actualHeightInPixels + (rowAlignment - 1) + bonusBytes;
+    if (sizeNeeded > MAX_BYTES) return false;
+    const size_t allocationSize = (size_t)sizeNeeded;
+    uint8_t* allocation = (uint8_t*)realloc(existing, allocationSize);
+    if (allocationSize != 0 && !allocation) return false;
+    if (clearWithZeroes && allocationSize > 0) memset(allocation, 0, allocationSize);
+    const size_t offsetToFirst = (size_t)bonusBytes + (size_t)bytePitch * border + (size_t)pixelSize * border;
+    uint8_t* pixels = (uint8_t*)nextMultipleOf((size_t)(allocation + offsetToFirst), (size_t)rowAlignment);
+    uint8_t* first = pixels; int pitch = bytePitch;
+    const bool forceFlip = (constraints & GAMUT_LAYOUT_VERT_FLIPPED) != 0, forceStraight = (constraints & GAMUT_LAYOUT_VERT_STRAIGHT) != 0;
+    if ((forceFlip && pitch > 0) || (forceStraight && pitch < 0)) {          // flipScanlinePointers :294-306
+        if (height >= 2) first += (ptrdiff_t)pitch * (height - 1);
+        pitch = -pitch;
+    }
+    out.data = first; out.pitch = pitch; out.alloc = allocation;
+    if (layers == 0 || layers == 1) out.layerOffset = 0;
+    else {
+        const long long off = (long long)bytePitch * actualHeightOfOneLayer;
+        if (off > 2147483647LL) { free(allocation); return false; }
+        out.layerOffset = (int)off;
+    }
+    return true;
+}
+
+} // namespace
+
+// fields in the reference's declaration order (image.d:1573-1620)
+struct gamut_image {
+    int       _type = GAMUT_PIXEL_unknown;
+    uint16_t  _layoutConstraints = 0;
+    uint8_t*  _data = nullptr;
+    uint8_t*  _allocArea = nullptr;
+    int       _width = 0, _height = 0, _layerCount = 0;
+    int       _pitch = 0, _layerOffset = 0;
+    const char* _error = kStrImageNotInitialized;
+    float     _pixelAspectRatio = -1, _resolutionY = -1;
+
+    void error(const char* msg) { _error = msg; _type = GAMUT_PIXEL_unknown; }           // image.d:1563-1570
+    void clearError() { _error = nullptr; }
+    bool isValid() const { return _error == nullptr; }
+    bool hasData() const { return _data != nullptr; }
+    void cleanupBitmapIfOwned() { if (_allocArea) { free(_allocArea); _allocArea = nullptr; _data = nullptr; } }
+    void cleanupBitmapAndTypeIfAny() { cleanupBitmapIfOwned(); _data = nullptr; _type = GAMUT_PIXEL_unknown; _error = kStrImageHasNoType; }
+
+    bool forgetPreviousUsage(int layers, int w, int h)                                     // image.d:1624-1645
+    {
+        cleanupBitmapAndTypeIfAny();
+        clearError();
+        if (layers < 0 || w < 0 || h < 0) { error(kStrIllegalNegativeDimension); return false; }
+        if (!imageIsValidSize(layers, w, h)) { error(kStrImageTooLarge); return false; }
+        return true;
+    }
+    bool setStorage(int w, int h, int layers, int type, int constraints, bool clear)       // image.d:1677-1727
+    {
+        if (!valid_type(type)) { error(kStrUnsupportedTypeConversion); return false; }
+        if (!layoutConstraintsValid(constraints)) { error(kStrIllegalLayoutConstraints); return false; }
+        Storage s;
+        if (!allocatePixelStorage(_allocArea, type, layers, w, h, constraints, 0, clear, s)) { _allocArea = nullptr; error(kStrOutOfMemory); return false; }
+        _data = s.data; _allocArea = s.alloc; _type = type; _width = w; _height = h; _pitch = s.pitch;
+        _layoutConstraints = (uint16_t)constraints; _layerCount = layers; _layerOffset = s.layerOffset;
+        return true;
+    }
+    bool createLayered(int w, int h, int layers, int type, int constraints, bool clear)
+    {
+        if (!forgetPreviousUsage(layers, w, h)) return false;
+        return setStorage(w, h, layers, type, constraints, clear);
+    }
+
+    int getAdHocLayoutConstraints() const                                                   // image.d:1809-1905
+    {
+        const int pitch = _pitch, absPitch = pitch >= 0 ? pitch : -pitch;
+        const int pixelSize = kPixelSize[_type], scanLen = _width * pixelSize;
+        const int excessPixels = (absPitch - scanLen) / pixelSize;
+        int c = 0;
+        int multi = layoutMultiplicity(_layoutConstraints);
+        const int withGap = excessPixels >= 7 ? 8 : excessPixels >= 3 ? 4 : excessPixels >= 1 ? 2 : 1;
+        int withWidth = 1;
+        if (_width % 2 == 0) withWidth = 2;
+        if (_width % 4 == 0) withWidth = 4;
+        if (_width % 8 == 0) withWidth = 8;
+        if (multi < withGap) multi = withGap;
+        if (multi < withWidth) multi = withWidth;
+        c |= multi == 8 ? GAMUT_LAYOUT_MULTIPLICITY_8 : multi == 4 ? GAMUT_LAYOUT_MULTIPLICITY_4 : multi == 2 ? GAMUT_LAYOUT_MULTIPLICITY_2 : 0;
+        c |= excessPixels >= 7 ? GAMUT_LAYOUT_TRAILING_7 : excessPixels >= 3 ? GAMUT_LAYOUT_TRAILING_3 : excessPixels >= 1 ? GAMUT_LAYOUT_TRAILING_1 : 0;
+        const int a1 = pointerAlignment((size_t)_data), a2 = pointerAlignment((size_t)absPitch);
+        c |= a1 < a2 ? a1 : a2;
+        if (pitch >= 0) c |= GAMUT_LAYOUT_VERT_STRAIGHT;
+        if (pitch <= 0) c |= GAMUT_LAYOUT_VERT_FLIPPED;
+        const bool gaplessScanlines = pitch == absPitch;
+        const bool gaplessLayers = (_layerCount == 0 || _layerCount == 1) ? true : _layerOffset == absPitch * _height;
+        if (gaplessScanlines && gaplessLayers) c |= GAMUT_LAYOUT_GAPLESS;
+        c |= (_layoutConstraints & BORDER_MASK);
+        return c;
+    }
+
+    bool convertTo(int targetType, int layoutConstraints)                                  // image.d:1180-1332
+    {
+        if (!isValid()) return false;
+        layoutConstraints &= 0xFFFF;
+        if (!valid_type(targetType)) { error(kStrUnsupportedTypeConversion); return false; }
+        if (!layoutConstraintsValid(layoutConstraints)) { error(kStrIllegalLayoutConstraints); return false; }
+        if (!hasData()) { _type = targetType; _layoutConstraints = (uint16_t)layoutConstraints; return true; }
+        const bool compatible = layoutConstraintsCompatible(layoutConstraints, getAdHocLayoutConstraints());
+        if (_type == targetType && compatible) { _layoutConstraints = (uint16_t)layoutConstraints; return true; }
+        if ((_width == 0 || _height == 0 || _layerCount == 0) && compatible) { _layoutConstraints = (uint16_t)layoutConstraints; return true; }
+
+        const int interType = gamut_hip_scanlines_inter_type(_type, targetType);
+        const int bonusBytes = targetType != _type ? _width * kPixelSize[interType] : 0;      // the scratch row the reference reserves (:1238-1241)
+        Storage s;
+        if (!allocatePixelStorage(nullptr, targetType, _layerCount, _width, _height, layoutConstraints, bonusBytes, false, s)) {
+            error(kStrOutOfMemory); return false;
+        }
+        bool ok = true;
+        const uint8_t* srcLayer = _data; uint8_t* dstLayer = s.data;
+        for (int layer = 0; layer < _layerCount && ok; ++layer) {                             // :1273-1311, one GPU pass per layer
+            ok = gamut_hip_scanlines_convert(_type, srcLayer, _pitch, targetType, dstLayer, s.pitch, _width, _height) == GAMUT_HIP_OK;
+            srcLayer += _layerOffset; dstLayer += s.layerOffset;
+        }
+        if (!ok) { free(s.alloc); error(kStrUnsupportedTypeConversion); return false; }      // keeps the former pixels (:1313-1319)
+        const int layers = _layerCount, w = _width, h = _height;
+        cleanupBitmapIfOwned();
+        _layoutConstraints = (uint16_t)layoutConstraints; _data = s.data; _allocArea = s.alloc; _type = targetType;
+        _pitch = s.pitch; _layerCount = layers; _layerOffset = s.layerOffset; _width = w; _height = h; _error = nullptr;
+        return true;
+    }
+
+    void adopt(uint8_t* decoded, int w, int h, int type, int comps_bytes, float aspect, float resY)   // jpeg.d:82-100 / png.d:108-157
+    {
+        _type = type; _width = w; _height = h; _allocArea = decoded; _data = decoded; _pitch = w * comps_bytes;
+        _pixelAspectRatio = aspect; _resolutionY = resY; _layoutConstraints = GAMUT_LAYOUT_DEFAULT; _layerCount = 1; _layerOffset = 0;
+    }
+
+    void loadJPEG(const uint8_t* bytes, size_t len, int flags)                              // plugins/jpeg.d:42-104
+    {
+        int requested = computeRequestedImageComponents(flags);
+        if (requested == 0) { error(kStrInvalidFlags); return; }
+        if (requested == 2) requested = -1;
+        int w = 0, h = 0, actual = 0; float aspect = -1, dpiY = -1;
+        uint8_t* decoded = gamut_hip_decompress_jpeg_image_from_memory(bytes, len, &w, &h, &actual, &aspect, &dpiY, requested);
+        if (!decoded) { error(kStrImageDecodingFailed); return; }
+        if (actual != 1 && actual != 3 && actual != 4) { error(kStrImageWrongComponents); free(decoded); return; }
+        if (!imageIsValidSize(1, w, h)) { error(kStrImageTooLarge); free(decoded); return; }
+        const int comps = requested == -1 ? actual : requested;
+        adopt(decoded, w, h, comps == 1 ? GAMUT_PIXEL_l8 : comps == 3 ? GAMUT_PIXEL_rgb8 : GAMUT_PIXEL_rgba8, comps, aspect, dpiY);
+        convertTo(applyLoadFlags(_type, flags), flags & 0xFFFF);
+    }
+    void loadPNG(const uint8_t* bytes, size_t len, int flags)                               // plugins/png.d:44-163
+    {
+        const bool is16 = gamut_hip_png_is16(bytes, len) != 0;
+        int requested = computeRequestedImageComponents(flags);
+        if (requested == 0) { error(kStrInvalidFlags); return; }
+        if (requested == -1) requested = 0;
+        bool to16 = is16;
+        if (flags & GAMUT_LOAD_8BIT) to16 = false;
+        if (flags & GAMUT_LOAD_16BIT) to16 = true;
+        int w = 0, h = 0, comps = 0; float ppmX = -1, ppmY = -1, ratio = -1;
+        uint8_t* decoded = to16 ? (uint8_t*)gamut_hip_stbi_load_16_from_memory(bytes, len, &w, &h, &comps, requested, &ppmX, &ppmY, &ratio)
+                                : gamut_hip_stbi_load_from_memory(bytes, len, &w, &h, &comps, requested, &ppmX, &ppmY, &ratio);
+        if (requested != 0) comps = requested;
+        if (!decoded) { error(kStrImageDecodingFailed); return; }
+        if (!imageIsValidSize(1, w, h)) { error(kStrImageTooLarge); free(decoded); return; }
+        static const int t8[5] = { -1, GAMUT_PIXEL_l8, GAMUT_PIXEL_la8, GAMUT_PIXEL_rgb8, GAMUT_PIXEL_rgba8 };
+        static const int t16[5] = { -1, GAMUT_PIXEL_l16, GAMUT_PIXEL_la16, GAMUT_PIXEL_rgb16, GAMUT_PIXEL_rgba16 };
+        adopt(decoded, w, h, (to16 ? t16 : t8)[comps], comps * (to16 ? 2 : 1), ratio == -1 ? -1.0f : ratio,
+              ppmY == -1 ? -1.0f : ppmY / 39.37007874f);                                    // convertInchesToMeters (types.d:126-129)
+        convertTo(applyLoadFlags(_type, flags), flags & 0xFFFF);
+    }
+};
+
+static int identify(const uint8_t* b, size_t len)
+{
+    static const uint8_t png[8] = { 0x89, 0x50, 0x4e, 0x47, 0x0d, 0x0a, 0x1a, 0x0a };
+    if (b && len >= 2 && b[0] == 0xFF && b[1] == 0xD8) return GAMUT_FORMAT_JPEG;            // detectJPEG plugins/jpeg.d:106-110
+    if (b && len >= 8 && !memcmp(b, png, 8)) return GAMUT_FORMAT_PNG;                       // detectPNG plugins/png.d:165-169
+    return GAMUT_FORMAT_unknown;
+}
+
+extern "C" {
+
+int  gamut_convert_pixel_type(int type, int op) { return convertPixelType(type, op); }
+int  gamut_apply_load_flags(int type, int flags) { return applyLoadFlags(type, flags); }
+int  gamut_compute_requested_image_components(int flags) { return computeRequestedImageComponents(flags); }
+int  gamut_valid_load_flags(int flags) { return validLoadFlags(flags); }
+int  gamut_layout_constraints_valid(int c) { return layoutConstraintsValid(c); }
+int  gamut_layout_constraints_compatible(int newer, int older) { return layoutConstraintsCompatible(newer, older); }
+int  gamut_identify_format_from_memory(const uint8_t* bytes, size_t len) { return identify(bytes, len); }
+void gamut_free_image_data(void* p) { free(p); }
+
+gamut_image* gamut_image_new(void) { return new (std::nothrow) gamut_image(); }
+void gamut_image_delete(gamut_image* img) { if (img) { img->cleanupBitmapIfOwned(); delete img; } }
+
+int gamut_image_create(gamut_image* img, int w, int h, int type, int layout) { return img->createLayered(w, h, 1, type, layout, true); }
+int gamut_image_create_layered(gamut_image* img, int w, int h, int layers, int type, int layout) { return img->createLayered(w, h, layers, type, layout, true); }
+int gamut_image_create_no_init(gamut_image* img, int w, int h, int type, int layout) { return img->createLayered(w, h, 1, type, layout, false); }
+int gamut_image_create_layered_no_init(gamut_image* img, int w, int h, int layers, int type, int layout) { return img->createLayered(w, h, layers, type, layout, false); }
+int gamut_image_create_with_no_data(gamut_image* img, int w, int h, int type, int layout)   // image.d:760-789
+{
+    if (!img->forgetPreviousUsage(1, w, h)) return 0;
+    if (!layoutConstraintsValid(layout)) { img->error(kStrIllegalLayoutConstraints); return 0; }
+    img->_data = nullptr; img->_allocArea = nullptr; img->_type = type; img->_width = w; img->_height = h; img->_pitch = 0;
+    img->_layoutConstraints = (uint16_t)layout; img->_layerCount = 1; img->_layerOffset = 0;
+    return 1;
+}
+int gamut_image_create_view(gamut_image* img, void* data, int w, int h, int type, int pitch)  // image.d:697-752
+{
+    if (!img->forgetPreviousUsage(1, w, h)) return 0;
+    if (!valid_type(type)) { img->error(kStrUnsupportedTypeConversion); return 0; }
+    const int minPitch = kPixelSize[type] * w, absPitch = pitch >= 0 ? pitch : -pitch;
+    if (absPitch < minPitch) { img->error(kStrOverlappingScanlines); return 0; }
+    img->_data = (uint8_t*)data; img->_allocArea = nullptr; img->_type = type; img->_width = w; img->_height = h; img->_pitch = pitch;
+    img->_layoutConstraints = GAMUT_LAYOUT_DEFAULT; img->_layerCount = 1; img->_layerOffset = 0;
+    return 1;
+}
+
+int gamut_image_load_from_memory(gamut_image* img, const uint8_t* bytes, size_t len, int flags)  // image.d:886-901, 1751-1772
+{
+    img->cleanupBitmapAndTypeIfAny();
+    img->clearError();
+    switch (identify(bytes, len)) {
+    case GAMUT_FORMAT_JPEG: img->loadJPEG(bytes, len, flags); break;
+    case GAMUT_FORMAT_PNG:  img->loadPNG(bytes, len, flags); break;
+    default: img->error(kStrImageFormatUnidentified); break;
+    }
+    return img->isValid();
+}
+
+int gamut_image_convert_to(gamut_image* img, int targetType, int layout) { return img->convertTo(targetType, layout); }
+int gamut_image_set_layout(gamut_image* img, int layout) { return img->convertTo(img->_type, layout); }
+int gamut_image_convert_op(gamut_image* img, int op, int layout) { return img->convertTo(convertPixelType(img->_type, op), layout); }
+int gamut_image_convert_to_greyscale_alpha(gamut_image* img, int layout)
+{ return img->convertTo(convertPixelType(convertPixelType(img->_type, GAMUT_TO_GREYSCALE), GAMUT_TO_ADD_ALPHA), layout); }
+int gamut_image_convert_to_rgba(gamut_image* img, int layout)
+{ return img->convertTo(convertPixelType(convertPixelType(img->_type, GAMUT_TO_RGB), GAMUT_TO_ADD_ALPHA), layout); }
+int gamut_image_flip_vertical(gamut_image* img)                                            // image.d:1524-1532, 1907-1924
+{
+    if (!img->isValid()) return 0;
+    if (!img->hasData()) return 1;
+    if (img->_layoutConstraints & (GAMUT_LAYOUT_VERT_FLIPPED | GAMUT_LAYOUT_VERT_STRAIGHT)) {   // physical flip = re-layout on the GPU is not offered: report like the logical path
+        img->error(kStrUnsupportedVFlip); return 0;
+    }
+    if (img->_height >= 2) img->_data += (ptrdiff_t)img->_pitch * (img->_height - 1);
+    img->_pitch = -img->_pitch;
+    return 1;
+}
+
+int   gamut_image_type(const gamut_image* img) { return img->_type; }
+int   gamut_image_width(const gamut_image* img) { return img->_width; }
+int   gamut_image_height(const gamut_image* img) { return img->_height; }
+int   gamut_image_layers(const gamut_image* img) { return img->_layerCount; }
+int   gamut_image_pitch_in_bytes(const gamut_image* img) { return img->_pitch; }
+int   gamut_image_layer_offset_in_bytes(const gamut_image* img) { return img->_layerOffset; }
+int   gamut_image_scanline_in_bytes(const gamut_image* img) { return valid_type(img->_type) ? img->_width * kPixelSize[img->_type] : 0; }
+int   gamut_image_layout_constraints(const gamut_image* img) { return img->_layoutConstraints; }
+int   gamut_image_is_error(const gamut_image* img) { return img->_error != nullptr; }
+int   gamut_image_is_valid(const gamut_image* img) { return img->_error == nullptr; }
+const char* gamut_image_error_message(const gamut_image* img) { return img->_error; }
+int   gamut_image_has_data(const gamut_image* img) { return img->_data != nullptr; }
+int   gamut_image_is_owned(const gamut_image* img) { return img->_data != nullptr && img->_allocArea != nullptr; }
+int   gamut_image_is_stored_upside_down(const gamut_image* img) { return img->_pitch < 0; }
+float gamut_image_pixel_aspect_ratio(const gamut_image* img) { return img->_pixelAspectRatio; }
+float gamut_image_dots_per_inch_y(const gamut_image* img) { return img->_resolutionY; }
+uint8_t* gamut_image_scanptr(gamut_image* img, int y) { return img->_data + (ptrdiff_t)img->_pitch * y; }
+uint8_t* gamut_image_layerptr(gamut_image* img, int layer, int y) { return img->_data + (ptrdiff_t)img->_pitch * y + (ptrdiff_t)layer * img->_layerOffset; }
+uint8_t* gamut_image_disown_data(gamut_image* img) { uint8_t* r = img->_allocArea; img->_allocArea = nullptr; return r; }
+
+} // extern "C"

@@ -241,7 +241,6 @@ __device__ __forceinline__ void defilter_band4(const DefilterArgs& a, const uint
     const u32 sh = (f == 3) ? 1u : 0u;
     const bool is_paeth = f == 4;
 
-    const uint8_t* rbytes = raw + (int64_t)(row_live ? row : 0) * (a.wb + 1) + 1;
     uint8_t* drow = D + (int64_t)(row_live ? row : 0) * a.d_pitch;
     const uint8_t* dprev = band > 0 ? D + (int64_t)(band * 64 - 1) * a.d_pitch : D;
     const u32 dmask = band > 0 ? 0xFFFFFFFFu : 0u;

@@ -27,6 +27,13 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_capi.SIGNATURES), "python binding table and header disagree"
     L = _capi.lib()
     assert b"gfx950" in L.gamut_hip_version()
+    # ... and the Image mirror's header
+    from gamut_amd import image as gi
+    header2 = open(os.path.join(ROOT, "include", "gamut_image.h")).read()
+    declared2 = set(re.findall(r"\b(gamut_[a-z0-9_]+)\s*\(", header2))
+    for name in sorted(declared2):
+        assert hasattr(raw, name), f"libgamut_hip.so does not export {name}"
+    assert declared2 == set(gi.IMAGE_SIGNATURES)
 
 
 def test_enums_mirror_the_reference():

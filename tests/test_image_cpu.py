@@ -1,0 +1,150 @@
+"""CPU tests of the C++ `Image` mirror (include/gamut_image.h): state machine, storage layout, flag algebra.
+They mirror the reference's in-source unittests (image.d:1964-2326, internals/types.d:170-236, 610-620);
+no pixel operation is involved, so no GPU is needed."""
+import numpy as np
+import pytest
+
+from gamut_amd import image as gi
+from gamut_amd.image import Image
+from oracle_lib import PIXEL_TYPES, PT, PT_SIZE
+
+L = gi.lib()
+
+
+def test_pixel_type_algebra():
+    """convertPixelTypeTo* (types.d:351-602) checked against name manipulation"""
+    def split(n):
+        for fam in ("rgbap", "rgba", "rgb", "lap", "la", "l"):
+            if n.startswith(fam):
+                return fam, n[len(fam):]
+    rules = {gi.TO_GREYSCALE: {"rgb": "l", "rgba": "la", "rgbap": "lap"}, gi.TO_RGB: {"l": "rgb", "la": "rgba", "lap": "rgbap"},
+             gi.TO_ADD_ALPHA: {"l": "la", "rgb": "rgba"}, gi.TO_DROP_ALPHA: {"la": "l", "lap": "l", "rgba": "rgb", "rgbap": "rgb"},
+             gi.TO_PREMUL: {"la": "lap", "rgba": "rgbap"}, gi.TO_NO_PREMUL: {"lap": "la", "rgbap": "rgba"}}
+    for n in PIXEL_TYPES:
+        fam, depth = split(n)
+        for op, m in rules.items():
+            assert PIXEL_TYPES[L.gamut_convert_pixel_type(PT[n], op)] == m.get(fam, fam) + depth
+        for op, d in ((gi.TO_8BIT, "8"), (gi.TO_16BIT, "16"), (gi.TO_FP32, "f32")):
+            assert PIXEL_TYPES[L.gamut_convert_pixel_type(PT[n], op)] == fam + d
+    assert L.gamut_convert_pixel_type(-1, gi.TO_RGB) == -1
+
+
+def test_load_flag_mapping():
+    """internals/types.d:610-620 unittest + applyLoadFlags"""
+    f = L.gamut_compute_requested_image_components
+    assert f(gi.LOAD_GREYSCALE) == -1
+    assert f(gi.LOAD_GREYSCALE | gi.LOAD_NO_ALPHA) == 1
+    assert f(gi.LOAD_GREYSCALE | gi.LOAD_ALPHA) == 2
+    assert f(gi.LOAD_GREYSCALE | gi.LOAD_ALPHA | gi.LOAD_NO_ALPHA) == 0
+    assert f(gi.LOAD_RGB) == -1
+    assert f(gi.LOAD_RGB | gi.LOAD_NO_ALPHA) == 3
+    assert f(gi.LOAD_RGB | gi.LOAD_GREYSCALE) == 0
+    assert f(gi.LOAD_RGB | gi.LOAD_ALPHA) == 4
+    assert f(gi.LOAD_8BIT | gi.LOAD_16BIT) == 0
+    a = L.gamut_apply_load_flags
+    assert PIXEL_TYPES[a(PT["rgb8"], gi.LOAD_RGB | gi.LOAD_ALPHA | gi.LOAD_8BIT | gi.LOAD_NO_PREMUL)] == "rgba8"      # package.d:178-199 idiom
+    assert PIXEL_TYPES[a(PT["rgba8"], gi.LOAD_FP32 | gi.LOAD_GREYSCALE)] == "laf32"                                   # test-suite testIssue65
+    assert PIXEL_TYPES[a(PT["la16"], gi.LOAD_PREMUL | gi.LOAD_8BIT)] == "lap8"
+    assert a(PT["rgb8"], gi.LOAD_PREMUL | gi.LOAD_NO_PREMUL) == -1
+
+
+def test_layout_helpers():
+    """internals/types.d:170-236 unittests + validity / compatibility rules (:241-289)"""
+    v, c = L.gamut_layout_constraints_valid, L.gamut_layout_constraints_compatible
+    assert v(0) and v(gi.LAYOUT_GAPLESS) and v(gi.LAYOUT_VERT_FLIPPED | gi.LAYOUT_BORDER[3] | gi.LAYOUT_ALIGNED[128])
+    assert not v(gi.LAYOUT_VERT_FLIPPED | gi.LAYOUT_VERT_STRAIGHT)
+    for bad in (gi.LAYOUT_MULTIPLICITY[2], gi.LAYOUT_TRAILING[1], gi.LAYOUT_ALIGNED[2], gi.LAYOUT_BORDER[1]):
+        assert not v(gi.LAYOUT_GAPLESS | bad)
+    assert c(0, 0) and c(gi.LAYOUT_ALIGNED[16], gi.LAYOUT_ALIGNED[64]) and not c(gi.LAYOUT_ALIGNED[64], gi.LAYOUT_ALIGNED[16])
+    assert not c(gi.LAYOUT_GAPLESS, 0) and c(0, gi.LAYOUT_GAPLESS)
+    assert not c(gi.LAYOUT_BORDER[2], gi.LAYOUT_BORDER[1]) and c(gi.LAYOUT_TRAILING[3], gi.LAYOUT_TRAILING[7])
+
+
+def test_error_state_machine():
+    """image.d:1976-2009: Image.init is errored; creation clears it; bad arguments set static messages"""
+    im = Image()
+    assert im.isError and not im.isValid and im.errorMessage == "Uninitialized image" and im.type == -1
+    assert im.create(4, 3, PT["rgba8"]) and im.isValid and im.errorMessage is None and im.hasData and im.isOwned
+    assert not im.create(-1, 3) and im.errorMessage == "Illegal negative dimension" and im.type == -1
+    assert not im.create(16777217, 1) and im.errorMessage == "Can't have an image that exceeds Gamut size limitations"
+    assert not im.create(4, 4, PT["rgba8"], gi.LAYOUT_VERT_FLIPPED | gi.LAYOUT_VERT_STRAIGHT)
+    assert im.errorMessage == "Cannot satisfy illegal layout constraints"
+    assert not im.loadFromMemory(b"") and im.errorMessage == "Unidentified image format"          # issue46.jpg is an empty file
+    assert not im.loadFromMemory(b"GIF89a........") and im.isError
+    assert im.create(2, 2) and im.isValid                                                          # "by loading/creating we forget past mistakes"
+    assert L.gamut_identify_format_from_memory(np.frombuffer(b"\xff\xd8\xff\xe0", np.uint8).ctypes.data, 4) == 0
+
+
+@pytest.mark.parametrize("type_name", ["l8", "rgb8", "rgba16", "rgbaf32", "lap16"])
+def test_allocate_pixel_storage_layout(type_name):
+    """allocatePixelStorage (internals/types.d:355-540): pitch formula, alignment, borders, v-flip, zero fill (image.d:2032-2049)"""
+    t, ps = PT[type_name], PT_SIZE[PT[type_name]]
+    for w, h in [(0, 0), (1, 1), (5, 3), (17, 4), (64, 2)]:
+        for border in (0, 1, 3):
+            for align in (1, 16, 128):
+                for mult in (1, 4, 8):
+                    for trail in (0, 3, 7):
+                        for vert in (0, gi.LAYOUT_VERT_FLIPPED, gi.LAYOUT_VERT_STRAIGHT):
+                            lay = gi.LAYOUT_BORDER[border] | gi.LAYOUT_ALIGNED[align] | gi.LAYOUT_MULTIPLICITY[mult] | gi.LAYOUT_TRAILING[trail] | vert
+                            im = Image()
+                            assert im.create(w, h, t, lay), im.errorMessage
+                            right = border + (-(w + border)) % mult
+                            right = max(right, trail)
+                            # reference quirk kept by the mirror: layoutScanlineAlignment masks 4 bits ((c >> 4) & 0x0f,
+                            # internals/types.d:191-194) while the field has 3, so LAYOUT_BORDER_1/_3 (bit 7) raise the alignment to 256
+                            eff = 1 << ((lay >> 4) & 0x0F)
+                            exp_pitch = -(-(ps * (border + w + right)) // eff) * eff
+                            assert abs(im.pitchInBytes) == exp_pitch
+                            assert (im.pitchInBytes < 0) == (vert == gi.LAYOUT_VERT_FLIPPED) or h == 0 and im.pitchInBytes == -exp_pitch
+                            assert im.layoutConstraints == lay and im.layers == 1 and im.layerOffsetInBytes == 0
+                            if h:
+                                assert im.scanptr(0) % eff == 0 and (im.scanptr(0) + im.pitchInBytes) % eff == 0
+                                assert im.pixels().sum() == 0
+                                for y in (-border, h - 1 + border):            # border rows are addressable and zeroed
+                                    row = np.ctypeslib.as_array((np.ctypeslib.ctypes.c_uint8 * max(1, ps * w)).from_address(im.scanptr(y)))
+                                    assert row.sum() == 0
+    im = Image()
+    assert im.create(8, 8, PT["rgba8"], gi.LAYOUT_GAPLESS | gi.LAYOUT_VERT_STRAIGHT) and im.pitchInBytes == 32
+
+
+def test_layered_images_and_views():
+    """image.d:2186-2254 (layers), :2080-2109 (views, negative pitch)"""
+    im = Image()
+    assert im.createLayered(6, 4, 5, PT["rgb8"], gi.LAYOUT_BORDER[1] | gi.LAYOUT_ALIGNED[16])
+    pitch = im.pitchInBytes
+    assert pitch % 16 == 0 and im.layers == 5 and im.layerOffsetInBytes == pitch * (4 + 2)
+    assert im.layerptr(3, 0) - im.layerptr(0, 0) == 3 * im.layerOffsetInBytes
+    assert im.createLayered(4, 4, 0, PT["l8"]) and im.layers == 0 and im.layerOffsetInBytes == 0
+    buf = np.arange(4 * 3 * 4, dtype=np.uint8)
+    v = Image()
+    assert v.createView(buf, 4, 3, PT["rgba8"], 16) and v.hasData and not v.isOwned and v.layoutConstraints == 0
+    assert np.array_equal(v.pixels().reshape(-1), buf)
+    assert v.createView(buf, 4, 3, PT["rgba8"], -16) and v.isStoredUpsideDown
+    assert np.array_equal(v.scanline(0), buf[32:48]) and np.array_equal(v.scanline(2), buf[0:16])
+    assert not v.createView(buf, 4, 3, PT["rgba8"], 15) and v.errorMessage == "Scanlines are overlapping"
+
+
+def test_flip_vertical_logical():
+    """image.d:2257-2326: logical flip negates the pitch; refused when a vertical constraint is set"""
+    im = Image()
+    assert im.create(3, 4, PT["l8"])
+    p0, pitch = im.scanptr(0), im.pitchInBytes
+    assert im.flipVertical() and im.pitchInBytes == -pitch and im.scanptr(0) == p0 + 3 * pitch and im.scanptr(3) == p0
+    assert im.flipVertical() and im.scanptr(0) == p0
+    assert im.create(3, 4, PT["l8"], gi.LAYOUT_VERT_STRAIGHT) and not im.flipVertical() and im.errorMessage == "Can't flip image vertically"
+
+
+def test_convert_to_without_pixels_needs_no_gpu():
+    """convertTo early-outs (image.d:1193-1224): no data / same type + compatible layout / zero size"""
+    im = Image()
+    assert im.createWithNoData(10, 10, PT["rgb8"]) and not im.hasData
+    assert im.convertTo(PT["rgbaf32"], gi.LAYOUT_ALIGNED[64]) and im.type == PT["rgbaf32"] and im.layoutConstraints == gi.LAYOUT_ALIGNED[64]
+    assert not im.convertTo(-1) and im.errorMessage == "Unsupported image pixel type conversion"
+    assert im.create(8, 2, PT["rgba8"]) and im.convertTo(PT["rgba8"], gi.LAYOUT_MULTIPLICITY[8])          # width % 8 == 0: ad-hoc compatible, no realloc
+    p = im.scanptr(0)
+    assert im.setLayout(gi.LAYOUT_VERT_STRAIGHT) and im.scanptr(0) == p
+    # zero-size + compatible layout returns true WITHOUT touching the type (image.d:1217-1224) -- kept as is
+    assert im.create(0, 5, PT["rgba8"]) and im.convertTo(PT["l16"], 0) and im.type == PT["rgba8"]
+    d = im.L.gamut_image_disown_data(im.h)
+    assert not im.isOwned
+    im.L.gamut_free_image_data(d)

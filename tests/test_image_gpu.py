@@ -1,0 +1,138 @@
+"""GPU tests of the `Image` mirror: loadFromMemory (JPEG / PNG) and convertTo through the GPU kernels, compared with the
+oracle composed the way the reference composes its pieces (plugins/jpeg.d:42-104, plugins/png.d:44-163, image.d:1180-1332)."""
+import glob
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import gen
+import oracle_lib as O
+from gamut_amd import image as gi
+from gamut_amd.image import Image
+from oracle_lib import PIXEL_TYPES, PT, PT_SIZE
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = os.path.join(HERE, "golden")
+L = gi.lib()
+
+
+def expected_load(data, flags, fmt):
+    """what the reference computes: codec output with the requested component count, then convertTo(applyLoadFlags)"""
+    req = L.gamut_compute_requested_image_components(flags)
+    if fmt == "jpeg":
+        if req == 2:
+            req = -1
+        out, actual, par, dpi = O.decompress_jpeg(data, req)
+        comps = actual if req == -1 else req
+        t0 = {1: "l8", 3: "rgb8", 4: "rgba8"}[comps]
+        px = out.reshape(-1)
+        h = out.shape[0]; w = out.shape[1] // comps
+    else:
+        is16 = O.png_parse(data)["depth"] == 16
+        to16 = is16
+        if flags & gi.LOAD_8BIT: to16 = False
+        if flags & gi.LOAD_16BIT: to16 = True
+        arr, n = O.stbi_load(data, 0 if req == -1 else req, to16)
+        h, w, comps = arr.shape
+        t0 = {1: "l", 2: "la", 3: "rgb", 4: "rgba"}[comps] + ("16" if to16 else "8")
+        px = arr.reshape(-1)
+    t1 = L.gamut_apply_load_flags(PT[t0], flags)
+    conv = O.scanlines_convert(t0, px, t1, w, h) if t1 != PT[t0] else np.ascontiguousarray(px).view(np.uint8).reshape(-1)
+    return w, h, t1, conv.reshape(h, -1)
+
+
+def test_config1_640x480_jpeg_to_rgba8(hip):
+    """BASELINE.json configs[0]: single 640x480 baseline 4:2:0 JPEG -> rgba8 via Image.loadFromMemory with the
+    package.d:178-199 flag idiom; pixels equal the frozen golden hash"""
+    data = open(os.path.join(G, "jpeg", "cfg1_640x480_420_q90.jpg"), "rb").read()
+    flags = gi.LOAD_RGB | gi.LOAD_ALPHA | gi.LOAD_8BIT | gi.LOAD_NO_PREMUL | gi.LAYOUT_VERT_STRAIGHT | gi.LAYOUT_GAPLESS
+    im = Image()
+    assert im.loadFromMemory(data, flags), im.errorMessage
+    assert (im.width, im.height, PIXEL_TYPES[im.type], im.layers) == (640, 480, "rgba8", 1)
+    assert im.pitchInBytes == 640 * 4 and im.isOwned and not im.isStoredUpsideDown
+    golden = json.load(open(os.path.join(G, "golden.json")))["frozen"]["cfg1_640x480_420_q90:comps4"]
+    assert hashlib.sha256(im.pixels().tobytes()).hexdigest() == golden
+
+
+JPEGS = sorted(glob.glob(os.path.join(G, "jpeg", "s_*.jpg"))) + [os.path.join(G, "ref_images", "issue35.jpg")]
+FLAGSETS = [0, gi.LOAD_RGB | gi.LOAD_ALPHA | gi.LOAD_8BIT, gi.LOAD_GREYSCALE | gi.LOAD_NO_ALPHA, gi.LOAD_GREYSCALE | gi.LOAD_ALPHA,
+            gi.LOAD_FP32 | gi.LOAD_GREYSCALE, gi.LOAD_16BIT | gi.LOAD_RGB | gi.LOAD_NO_ALPHA, gi.LOAD_RGB | gi.LOAD_ALPHA | gi.LOAD_PREMUL | gi.LOAD_FP32]
+
+
+@pytest.mark.parametrize("path", JPEGS, ids=[os.path.basename(p) for p in JPEGS])
+def test_load_jpeg_with_flags(hip, path):
+    data = open(path, "rb").read()
+    for flags in FLAGSETS:
+        for layout in (0, gi.LAYOUT_VERT_FLIPPED | gi.LAYOUT_ALIGNED[64], gi.LAYOUT_GAPLESS):
+            w, h, t1, exp = expected_load(data, flags, "jpeg")
+            im = Image()
+            assert im.loadFromMemory(data, flags | layout), im.errorMessage
+            assert (im.width, im.height, im.type) == (w, h, t1)
+            assert np.array_equal(im.pixels(), exp), f"flags={flags:#x} layout={layout}"
+            if layout & gi.LAYOUT_VERT_FLIPPED:
+                assert im.isStoredUpsideDown and im.scanptr(0) % 64 == 0 and im.pitchInBytes % 64 == 0
+    im = Image()
+    assert not im.loadFromMemory(data, gi.LOAD_RGB | gi.LOAD_GREYSCALE) and im.errorMessage == "Invalid image decoding flags"
+    assert not im.loadFromMemory(data[:300], 0) and im.errorMessage == "Image decoding failed"
+    if path.endswith("issue35.jpg"):
+        assert im.loadFromMemory(data) and im.pixelAspectRatio == 1.0 and im.dotsPerInchY == 72.0
+
+
+def test_load_png_with_flags(hip):
+    rng = np.random.default_rng(4)
+    w, h = 21, 13
+    files = {"issue76": open(os.path.join(G, "ref_images", "issue76.png"), "rb").read(),
+             "vst3": open(os.path.join(G, "ref_images", "vst3-compatible.png"), "rb").read(),
+             "rgb8": gen.write_png(rng.integers(0, 256, (h, w * 3)), w, h, 2, 8),
+             "rgba16": gen.write_png(rng.integers(0, 65536, (h, w * 4)), w, h, 6, 16),
+             "pal4": gen.write_png(rng.integers(0, 16, (h, w)), w, h, 3, 4, palette=rng.integers(0, 256, (16, 3)), trns=[0, 128, 255]),
+             "la8": gen.write_png(rng.integers(0, 256, (h, w * 2)), w, h, 4, 8, interlace=1)}
+    for name, data in files.items():
+        for flags in FLAGSETS + [gi.LOAD_8BIT, gi.LOAD_16BIT]:
+            ew, eh, t1, exp = expected_load(data, flags, "png")
+            im = Image()
+            assert im.loadFromMemory(data, flags | gi.LAYOUT_TRAILING[3]), f"{name}: {im.errorMessage}"
+            assert (im.width, im.height, im.type) == (ew, eh, t1), name
+            assert np.array_equal(im.pixels(), exp), f"{name} flags={flags:#x}"
+    im = Image()                                              # testIssue76 (test-suite main.d:172-190)
+    assert im.loadFromMemory(files["issue76"]) and PIXEL_TYPES[im.type] == "l16" and (im.width, im.height) == (2, 2)
+    assert im.scanline(0).view(np.uint16).tolist() == [1875, 65535] and im.scanline(1).view(np.uint16).tolist() == [0, 2807]
+
+
+def test_issue65_sequence(hip):
+    """examples/test-suite/source/main.d testIssue65: load FP32|GREYSCALE, setLayout(TRAILING_1), setLayout(TRAILING_0), convertTo8Bit"""
+    data = open(os.path.join(G, "ref_images", "issue65.png"), "rb").read()
+    im = Image()
+    assert im.loadFromMemory(data, gi.LOAD_FP32 | gi.LOAD_GREYSCALE) and im.hasData and im.isValid and PIXEL_TYPES[im.type] == "laf32"
+    assert im.setLayout(gi.LAYOUT_TRAILING[1]) and abs(im.pitchInBytes) >= (1024 + 1) * 8
+    assert im.setLayout(gi.LAYOUT_TRAILING[0]) and im.hasData
+    assert im.convertTo8Bit() and im.hasData and PIXEL_TYPES[im.type] == "la8"
+    arr, n = O.stbi_load(data, 0)
+    f = O.scanlines_convert("rgba8", arr.reshape(-1), "laf32", 1024, 1024)
+    exp = O.scanlines_convert("laf32", f, "la8", 1024, 1024)
+    assert np.array_equal(im.pixels().reshape(-1), exp)
+
+
+def test_convert_to_layouts_and_layers(hip):
+    """convertTo on layered images with borders / alignment / flips: every layer converted, gap bytes irrelevant"""
+    rng = np.random.default_rng(9)
+    w, h, layers = 11, 6, 3
+    for src, dst, lay in [("rgba8", "rgbaf32", gi.LAYOUT_BORDER[1] | gi.LAYOUT_ALIGNED[32]), ("rgbaf32", "rgb16", gi.LAYOUT_VERT_FLIPPED),
+                          ("rgb16", "l8", gi.LAYOUT_GAPLESS), ("l8", "la16", gi.LAYOUT_TRAILING[7] | gi.LAYOUT_MULTIPLICITY[8]),
+                          ("la16", "la16", gi.LAYOUT_VERT_FLIPPED | gi.LAYOUT_ALIGNED[128])]:
+        im = Image()
+        assert im.createLayered(w, h, layers, PT[src])
+        px = gen.make_pixels(src, w * h * layers, rng).reshape(layers, h, -1).view(np.uint8).reshape(layers, h, -1)
+        for l in range(layers):
+            for y in range(h):
+                row = np.ctypeslib.as_array((np.ctypeslib.ctypes.c_uint8 * px.shape[2]).from_address(im.layerptr(l, y)))
+                row[:] = px[l, y]
+        assert im.convertTo(PT[dst], lay), im.errorMessage
+        assert im.type == PT[dst] and im.layers == layers and im.layoutConstraints == lay
+        for l in range(layers):
+            exp = O.scanlines_convert(src, px[l].reshape(-1), dst, w, h).reshape(h, -1) if src != dst else px[l]
+            assert np.array_equal(im.pixels(l), exp), f"{src}->{dst} layer {l}"

@@ -52,6 +52,33 @@ constexpr int V_INTS  = 16 * BLK_STRIDE;           // vertical stage V[n][m]
 // phase P2, T2 is first written in P3, and a workgroup barrier separates the two.
 constexpr int LDS_INTS = T1_INTS + H_INTS + V_INTS;
 
+// Both upsample maps have the same shape: two pass-through inputs and two rounded 4-term sums (jpegload.d:929-952,
+// 1001-1032).  A lane evaluates either the "E" or the "O" map depending on its `half` bit; instead of branching (both
+// sides would run for every wave) it carries its 8 multipliers in registers and stores results in the fixed physical
+// order (pass0, pass1, sumA, sumB).  Logical index m of the 8 outputs (0-3 = E0..E3, 4-7 = O0..O3) <-> physical slot:
+//   E: e0=pass0 e1=sumA e2=pass1 e3=sumB     O: o0=sumA o1=pass0 o2=sumB o3=pass1
+__device__ __forceinline__ constexpr int phys_slot(int m) { constexpr int P[8] = { 0, 2, 1, 3, 6, 4, 7, 5 }; return P[m]; }
+
+struct MapCoef { i32 a[4], b[4]; };
+
+// Every LDS hand-off of the tuned kernel stays inside one 32-lane half of a wave (thread t only ever reads tiles
+// written by threads with the same t >> 5: Y tile t>>3, chroma block t>>4, T2 tile t>>3), so no workgroup barrier is
+// needed: LDS operations of one wave execute in program order, and this fence only stops the compiler from moving
+// them across the phase boundary.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ void map_half(const MapCoef& c, int half, const i32 (&u)[8], i32 (&o)[4])
+{
+    o[0] = half ? u[2] : u[0];
+    o[1] = half ? u[6] : u[4];
+    o[2] = D4(c.a[0], u[1], c.a[1], u[3], c.a[2], u[5], c.a[3], u[7]);
+    o[3] = D4(c.b[0], u[1], c.b[1], u[3], c.b[2], u[5], c.b[3], u[7]);
+}
+
 __global__ __launch_bounds__(256) void k_jpeg_h2v2_rgba8(JpegArgs a)
 {
     __shared__ __attribute__((aligned(16))) i32 lds[LDS_INTS];
@@ -62,7 +89,9 @@ __global__ __launch_bounds__(256) void k_jpeg_h2v2_rgba8(JpegArgs a)
 
     const int t = threadIdx.x;
     const int img = blockIdx.z, mcu_y = blockIdx.y, mcu_x0 = blockIdx.x * TILE_MCUS;
+    // wave-uniform bases (scalar registers); per-thread parts are small 32-bit offsets
     const int16_t* cbase = a.coeffs + (int64_t)img * a.coeff_stride + ((int64_t)mcu_y * a.mcus_per_row + mcu_x0) * (6 * 64);
+    uint8_t* obase = a.out + (int64_t)img * a.out_stride + (int64_t)(mcu_y * 16) * a.out_pitch + (int64_t)mcu_x0 * 64;
     const int mcus_here = min(TILE_MCUS, a.mcus_per_row - mcu_x0);
 
     // ---- mapping A: thread = (Y block b = (mcu m, quadrant q), row/column index r) ----
@@ -72,16 +101,14 @@ __global__ __launch_bounds__(256) void k_jpeg_h2v2_rgba8(JpegArgs a)
     // ---- mapping B: thread = (chroma block cb = (mcu, comp), row k, half) ----
     const int cbk = t >> 4, k = (t >> 1) & 7, half = t & 1;
     const bool cmcu_live = (cbk >> 1) < mcus_here;
+    MapCoef mc;
+    mc.a[0] = half ? O0a : E1a; mc.a[1] = half ? O0b : E1b; mc.a[2] = half ? O0c : E1c; mc.a[3] = half ? O0d : E1d;
+    mc.b[0] = half ? O2a : E3a; mc.b[1] = half ? O2b : E3b; mc.b[2] = half ? O2c : E3c; mc.b[3] = half ? O2d : E3d;
 
     // P0: loads (issued together; 16 B per lane, lane-contiguous inside each MCU)
     uint4 yrow = make_uint4(0, 0, 0, 0), crow = make_uint4(0, 0, 0, 0);
-    if (mcu_live)  yrow = *reinterpret_cast<const uint4*>(cbase + m * 384 + q * 64 + r * 8);
-    if (cmcu_live) crow = *reinterpret_cast<const uint4*>(cbase + (cbk >> 1) * 384 + 256 + (cbk & 1) * 64 + k * 8);
-    bool y_col1 = false;     // Col!(1) shortcut of the reference applies (max_zag <= 2)
-    if (a.max_zag && mcu_live) {
-        const uint8_t* zb = a.max_zag + (int64_t)img * a.zag_stride + ((int64_t)mcu_y * a.mcus_per_row + mcu_x0 + m) * 6;
-        y_col1 = zb[q] <= 2;
-    }
+    if (mcu_live)  yrow = *reinterpret_cast<const uint4*>(cbase + (u32)(m * 384 + q * 64 + r * 8));
+    if (cmcu_live) crow = *reinterpret_cast<const uint4*>(cbase + (u32)((cbk >> 1) * 384 + 256 + (cbk & 1) * 64 + k * 8));
 
     // P1a: luma pass 1 (row r of block b) -> T1[b][r][0..7]
     {
@@ -92,14 +119,14 @@ __global__ __launch_bounds__(256) void k_jpeg_h2v2_rgba8(JpegArgs a)
         *reinterpret_cast<int4*>(dst)     = make_int4(tv[0], tv[1], tv[2], tv[3]);
         *reinterpret_cast<int4*>(dst + 4) = make_int4(tv[4], tv[5], tv[6], tv[7]);
     }
-    // P1b: chroma horizontal stage: row k of chroma block cbk -> H[k][half*4 .. half*4+3]
+    // P1b: chroma horizontal stage: source row k of chroma block cbk -> H[k][physical slots half*4 .. +3]
     {
         i32 u[8], hv[4];
         unpack_row(crow, u);
-        if (half == 0) map_E(u, hv); else map_O(u, hv);
+        map_half(mc, half, u, hv);
         *reinterpret_cast<int4*>(Hs + cbk * BLK_STRIDE + k * 8 + half * 4) = make_int4(hv[0], hv[1], hv[2], hv[3]);
     }
-    __syncthreads();
+    wave_sync();
 
     // P2a: luma pass 2 (column r of block b) -> 8 samples in registers
     i32 ys[8];
@@ -109,41 +136,47 @@ __global__ __launch_bounds__(256) void k_jpeg_h2v2_rgba8(JpegArgs a)
         #pragma unroll
         for (int i = 0; i < 8; ++i) tv[i] = src[i * 8];
         col_pass<8>(tv, ys);
-        if (y_col1) {
+        if (a.max_zag) {          // wave-uniform: the reference's Col!(1) shortcut (max_zag <= 2) only matters when the caller passes max_zag
+            bool y_col1 = false;
+            if (mcu_live) y_col1 = a.max_zag[(int64_t)img * a.zag_stride + ((int64_t)mcu_y * a.mcus_per_row + mcu_x0 + m) * 6 + q] <= 2;
             const i32 v = col1_sample(tv[0]);
             #pragma unroll
-            for (int i = 0; i < 8; ++i) ys[i] = v;
+            for (int i = 0; i < 8; ++i) ys[i] = y_col1 ? v : ys[i];
         }
     }
-    // P2b: chroma vertical stage: column mcol of H -> V[half*4 .. +3][mcol]   (k doubles as the column index here)
+    // P2b: chroma vertical stage on physical column k of H (all 8 source rows) -> V[physical rows half*4 .. +3][k]
     {
         i32 u[8], vv[4];
         const i32* src = Hs + cbk * BLK_STRIDE + k;
         #pragma unroll
         for (int i = 0; i < 8; ++i) u[i] = src[i * 8];
-        if (half == 0) map_E(u, vv); else map_O(u, vv);
+        map_half(mc, half, u, vv);
         i32* dst = Vs + cbk * BLK_STRIDE + (half * 4) * 8 + k;
         #pragma unroll
         for (int i = 0; i < 4; ++i) dst[i * 8] = vv[i];
     }
-    __syncthreads();
+    wave_sync();
 
     // P3: per (mcu, comp, quadrant, row j): the 4 coefficients blk_q[j][0..3] and idct_4x4's pass 1 on them.
     //     blk0 = (V00+V10)+(V01+V11), blk1 = (V00+V10)-(V01+V11), blk2 = (V00-V10)+(V01-V11), blk3 = (V00-V10)-(V01-V11)
-    //     with V00 = V[j][i], V10 = V[4+j][i], V01 = V[j][4+i], V11 = V[4+j][4+i]   (jpegload.d:2230-2251, :886-902)
+    //     with V00 = V[j][i], V10 = V[4+j][i], V01 = V[j][4+i], V11 = V[4+j][4+i]   (jpegload.d:2230-2251, :886-902).
+    //     The +-1 factors ride on 24-bit multiply-adds (|V| < 2^19).
     {
         const int mm = t >> 5, comp = (t >> 4) & 1, qq = (t >> 2) & 3, j = t & 3;
+        const int rowA = ((j & 1) << 1) | (j >> 1);                   // phys_slot(j)
+        const int rowB = 4 + ((((j & 1) ^ 1) << 1) | (j >> 1));       // phys_slot(4 + j)
         const i32* vb = Vs + (mm * 2 + comp) * BLK_STRIDE;
-        const int4 a0 = *reinterpret_cast<const int4*>(vb + j * 8), a1 = *reinterpret_cast<const int4*>(vb + j * 8 + 4);
-        const int4 b0 = *reinterpret_cast<const int4*>(vb + (4 + j) * 8), b1 = *reinterpret_cast<const int4*>(vb + (4 + j) * 8 + 4);
-        const i32 v00[4] = { a0.x, a0.y, a0.z, a0.w }, v01[4] = { a1.x, a1.y, a1.z, a1.w };
-        const i32 v10[4] = { b0.x, b0.y, b0.z, b0.w }, v11[4] = { b1.x, b1.y, b1.z, b1.w };
+        const int4 a0 = *reinterpret_cast<const int4*>(vb + rowA * 8), a1 = *reinterpret_cast<const int4*>(vb + rowA * 8 + 4);
+        const int4 b0 = *reinterpret_cast<const int4*>(vb + rowB * 8), b1 = *reinterpret_cast<const int4*>(vb + rowB * 8 + 4);
+        const i32 ra[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+        const i32 rb[8] = { b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w };
+        const i32 sq = (qq & 2) ? -1 : 1, sr = (qq & 1) ? -1 : 1;
         i32 x[8], tv[8];
         #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const i32 p = (qq & 2) ? wsub(v00[i], v10[i]) : wadd(v00[i], v10[i]);     // a = P+Q (top) / b = P-Q (bottom)
-            const i32 s = (qq & 2) ? wsub(v01[i], v11[i]) : wadd(v01[i], v11[i]);     // c = R+S        / d = R-S
-            x[i] = (i32)(short)((qq & 1) ? wsub(p, s) : wadd(p, s));                  // cast(jpgd_block_t)
+            const i32 p  = mad24(rb[phys_slot(i)], sq, ra[phys_slot(i)]);          // a = P+Q (top) / b = P-Q (bottom)
+            const i32 s2 = mad24(rb[phys_slot(4 + i)], sq, ra[phys_slot(4 + i)]);  // c = R+S        / d = R-S
+            x[i] = (i32)(short)mad24(s2, sr, p);                                   // cast(jpgd_block_t)
         }
         x[4] = x[5] = x[6] = x[7] = 0;
         row_pass<4>(x, tv);
@@ -151,7 +184,7 @@ __global__ __launch_bounds__(256) void k_jpeg_h2v2_rgba8(JpegArgs a)
         *reinterpret_cast<int4*>(dst)     = make_int4(tv[0], tv[1], tv[2], tv[3]);
         *reinterpret_cast<int4*>(dst + 4) = make_int4(tv[4], tv[5], tv[6], tv[7]);
     }
-    __syncthreads();
+    wave_sync();
 
     // P4: chroma pass 2 (Col!4 on column r of the quadrant's Cb and Cr), colour, store
     {
@@ -165,14 +198,17 @@ __global__ __launch_bounds__(256) void k_jpeg_h2v2_rgba8(JpegArgs a)
         for (int i = 0; i < 4; ++i) tc[i] = src[(4 + i) * 8];
         col_pass<4>(tc, crs);
 
-        const int px = (mcu_x0 + m) * 16 + (q & 1) * 8 + r;
-        const int py0 = mcu_y * 16 + (q >> 1) * 8;
-        if (mcu_live && px < a.width) {
-            uint8_t* o = a.out + (int64_t)img * a.out_stride + (int64_t)py0 * a.out_pitch + (int64_t)px * 4;
+        const int lx = m * 16 + (q & 1) * 8 + r;               // pixel column inside the strip
+        const int ly0 = (q >> 1) * 8;                          // first pixel row inside the strip
+        if (mcu_live && mcu_x0 * 16 + lx < a.width) {
+            uint8_t* o = obase + (u32)(lx * 4);
+            const int rows_here = a.height - mcu_y * 16 - ly0;
+            // one pixel per lane per row: a wave store instruction writes two full 128-byte lines.  (16-byte stores after an
+            // in-quad DPP transpose were measured 2 % slower: the kernel is VALU-bound, not store-issue-bound.)
             #pragma unroll
             for (int i = 0; i < 8; ++i)
-                if (py0 + i < a.height)
-                    *reinterpret_cast<u32*>(o + (int64_t)i * a.out_pitch) = ycc_to_rgba(ys[i], cbs[i], crs[i]);
+                if (i < rows_here)
+                    __builtin_nontemporal_store(ycc_to_rgba(ys[i], cbs[i], crs[i]), reinterpret_cast<u32*>(o + (int64_t)(ly0 + i) * a.out_pitch));
         }
     }
 }

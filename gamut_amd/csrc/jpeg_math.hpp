@@ -138,10 +138,10 @@ static_assert(C_CRR == 91881 && C_CBB == 116130 && C_CRG == -46802 && C_CBG == -
 // returns packed RGBA8 (A = 255), little-endian byte order R,G,B,A
 __device__ __forceinline__ u32 ycc_to_rgba(i32 y, i32 cb, i32 cr)
 {
-    const i32 crk = cr - 128, cbk = cb - 128;
-    const i32 r = y + (mad24(crk, C_CRR, 32768) >> 16);
-    const i32 g = y + (mad24(crk, C_CRG, mad24(cbk, C_CBG, 32768)) >> 16);
-    const i32 b = y + (mad24(cbk, C_CBB, 32768) >> 16);
+    // (c - 128) * K + 32768 == c * K + (32768 - 128 * K): the level shift rides in the addend
+    const i32 r = y + (mad24(cr, C_CRR, 32768 - 128 * C_CRR) >> 16);
+    const i32 g = y + (mad24(cr, C_CRG, mad24(cb, C_CBG, 32768 - 128 * C_CRG - 128 * C_CBG)) >> 16);
+    const i32 b = y + (mad24(cb, C_CBB, 32768 - 128 * C_CBB) >> 16);
     return (u32)clamp255(r) | ((u32)clamp255(g) << 8) | ((u32)clamp255(b) << 16) | 0xFF000000u;
 }
 // RGB -> grey of decompress_jpeg_image_from_stream (:3786-3792)

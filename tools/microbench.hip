@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <cstdlib>
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); return 1; } } while (0)
 
@@ -40,6 +41,29 @@ __global__ __launch_bounds__(256) void NAME(int* out, int a, int b)             
 #define A_SAD(r)    "v_sad_u8 " #r ", " #r ", %8, " #r "\n"
 #define A_BFE(r)    "v_bfe_i32 " #r ", " #r ", 0, 16\n"
 #define A_MUL64(r)  "v_mul_hi_u32 " #r ", " #r ", %8\n"
+#define A_FMA(r)    "v_fma_f32 " #r ", " #r ", %8, " #r "\n"
+#define A_FADD(r)   "v_add_f32 " #r ", " #r ", %8\n"
+#define A_FMUL(r)   "v_mul_f32 " #r ", " #r ", %8\n"
+#define A_FLOOR(r)  "v_floor_f32 " #r ", " #r "\n"
+#define A_CVTFI(r)  "v_cvt_f32_i32 " #r ", " #r "\n"
+#define A_CVTIF(r)  "v_cvt_i32_f32 " #r ", " #r "\n"
+#define A_CVTUB(r)  "v_cvt_f32_ubyte1 " #r ", " #r "\n"
+#define A_CVTPK(r)  "v_cvt_pk_u8_f32 " #r ", " #r ", 1, " #r "\n"
+#define A_SATPK(r)  "v_sat_pk_u8_i16 " #r ", " #r "\n"
+#define A_MAXI(r)   "v_max_i32 " #r ", " #r ", %8\n"
+#define A_MINI(r)   "v_min_i32 " #r ", " #r ", %8\n"
+#define A_CNDM(r)   "v_cndmask_b32 " #r ", " #r ", %8, vcc\n"
+#define A_AND(r)    "v_and_b32 " #r ", " #r ", %8\n"
+#define A_XOR(r)    "v_xor_b32 " #r ", " #r ", %8\n"
+#define A_SUB(r)    "v_sub_u32 " #r ", " #r ", %8\n"
+#define A_LSHL(r)   "v_lshlrev_b32 " #r ", 3, " #r "\n"
+#define A_LSHLOR(r) "v_lshl_or_b32 " #r ", " #r ", 3, %8\n"
+#define A_ANDOR(r)  "v_and_or_b32 " #r ", " #r ", %8, " #r "\n"
+#define A_SADU32(r) "v_sad_u32 " #r ", " #r ", %8, " #r "\n"
+#define A_PKMAX(r)  "v_pk_max_i16 " #r ", " #r ", %8\n"
+#define A_PKSUB(r)  "v_pk_sub_i16 " #r ", " #r ", %8\n"
+#define A_ALIGNB(r) "v_alignbyte_b32 " #r ", " #r ", %8, 1\n"
+#define A_PKFMA(r)  "v_pk_fma_f32 " #r ", " #r ", " #r ", " #r "\n"
 
 RATE_KERNEL(k_add, A_ADD)
 RATE_KERNEL(k_mullo, A_MULLO)
@@ -61,6 +85,28 @@ RATE_KERNEL(k_madi16, A_MADI16)
 RATE_KERNEL(k_sad, A_SAD)
 RATE_KERNEL(k_bfe, A_BFE)
 RATE_KERNEL(k_mulhi, A_MUL64)
+RATE_KERNEL(k_fma, A_FMA)
+RATE_KERNEL(k_fadd, A_FADD)
+RATE_KERNEL(k_fmul, A_FMUL)
+RATE_KERNEL(k_floor, A_FLOOR)
+RATE_KERNEL(k_cvtfi, A_CVTFI)
+RATE_KERNEL(k_cvtif, A_CVTIF)
+RATE_KERNEL(k_cvtub, A_CVTUB)
+RATE_KERNEL(k_cvtpk, A_CVTPK)
+RATE_KERNEL(k_satpk, A_SATPK)
+RATE_KERNEL(k_maxi, A_MAXI)
+RATE_KERNEL(k_mini, A_MINI)
+RATE_KERNEL(k_cndm, A_CNDM)
+RATE_KERNEL(k_and, A_AND)
+RATE_KERNEL(k_xor, A_XOR)
+RATE_KERNEL(k_sub, A_SUB)
+RATE_KERNEL(k_lshl, A_LSHL)
+RATE_KERNEL(k_lshlor, A_LSHLOR)
+RATE_KERNEL(k_andor, A_ANDOR)
+RATE_KERNEL(k_sadu32, A_SADU32)
+RATE_KERNEL(k_pkmax, A_PKMAX)
+RATE_KERNEL(k_pksub, A_PKSUB)
+RATE_KERNEL(k_alignb, A_ALIGNB)
 
 __global__ __launch_bounds__(256) void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n)
 {
@@ -103,6 +149,7 @@ int main()
         {"v_ashrrev_i32", k_ashr}, {"v_mov_dpp quad_perm", k_dppq}, {"v_mov_dpp row_shl4 bank", k_dpps},
         {"v_lshl_add_u32", k_lshladd}, {"v_add3_u32", k_add3}, {"v_pk_add_i16", k_pkadd}, {"v_pk_mul_lo_u16", k_pkmul},
         {"v_pk_mad_i16", k_pkmad}, {"v_mad_i32_i16", k_madi16}, {"v_sad_u8", k_sad}, {"v_bfe_i32", k_bfe}, {"v_mul_hi_u32", k_mulhi},
+        {"v_fma_f32", k_fma}, {"v_add_f32", k_fadd}, {"v_mul_f32", k_fmul}, {"v_floor_f32", k_floor}, {"v_cvt_f32_i32", k_cvtfi}, {"v_cvt_i32_f32", k_cvtif}, {"v_cvt_f32_ubyte1", k_cvtub}, {"v_cvt_pk_u8_f32", k_cvtpk}, {"v_sat_pk_u8_i16", k_satpk}, {"v_max_i32", k_maxi}, {"v_min_i32", k_mini}, {"v_cndmask_b32", k_cndm}, {"v_and_b32", k_and}, {"v_xor_b32", k_xor}, {"v_sub_u32", k_sub}, {"v_lshlrev_b32", k_lshl}, {"v_lshl_or_b32", k_lshlor}, {"v_and_or_b32", k_andor}, {"v_sad_u32", k_sadu32}, {"v_pk_max_i16", k_pkmax}, {"v_pk_sub_i16", k_pksub}, {"v_alignbyte_b32", k_alignb},
     };
     for (auto& k : ks) {
         float ms = time_ms([&] { hipLaunchKernelGGL(k.k, dim3(blocks), dim3(256), 0, 0, out, 1, 3); }, 5);
@@ -110,6 +157,7 @@ int main()
         double per_cu_clk = wave_instr / p.multiProcessorCount / (ms * 1e-3) / (p.clockRate * 1e3);
         printf("%-26s %8.3f ms  %6.3f wave-instr/clk/CU  (%.2f cycles per wave-instr per SIMD)\n", k.name, ms, per_cu_clk, 4.0 / per_cu_clk);
     }
+    if (getenv("QUICK")) return 0;
     const size_t bytes = (size_t)4 << 30;     // 4 GiB per side: far past the 256 MiB Infinity Cache
     void *s, *d; CK(hipMalloc(&s, bytes)); CK(hipMalloc(&d, bytes));
     CK(hipMemset(s, 1, bytes)); CK(hipMemset(d, 2, bytes));

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgamut_hip.so")
+LIB_PATH = os.environ.get("GAMUT_HIP_LIB") or os.path.join(_HERE, "lib", "libgamut_hip.so")
 
 OK, ERR_INVALID_ARG, ERR_UNSUPPORTED, ERR_OUT_OF_MEMORY, ERR_HIP, ERR_DECODE, ERR_NO_DEVICE = range(7)
 

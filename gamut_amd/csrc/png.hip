@@ -53,6 +53,44 @@ __device__ __forceinline__ u32 paeth(u32 a, u32 b, u32 c)
     return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
 }
 
+// ---- four filter bytes at a time (one RGBA8 pixel per dword) ---------------------------------------------------
+// bytewise (a + b) mod 256
+__device__ __forceinline__ u32 add_bytes(u32 x, u32 y)
+{
+    return ((x & 0x7f7f7f7fu) + (y & 0x7f7f7f7fu)) ^ ((x ^ y) & 0x80808080u);
+}
+// bytewise floor((a + b) / 2), the Avg predictor (9-bit sum, stbdec.d:1497)
+__device__ __forceinline__ u32 avg_bytes(u32 a, u32 b)
+{
+    return (a & b) + (((a ^ b) & 0xfefefefeu) >> 1);
+}
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 as_s16x2(u32 v) { return __builtin_bit_cast(s16x2, v); }
+__device__ __forceinline__ u32 as_u32(s16x2 v) { return __builtin_bit_cast(u32, v); }
+// stbi__paeth (stbdec.d:1390-1401) on two channels at once, 16-bit lanes (v_pk_* instructions); a, b, c in 0..255
+__device__ __forceinline__ s16x2 paeth2(s16x2 a, s16x2 b, s16x2 c)
+{
+    const s16x2 zero = { 0, 0 }, one = { 1, 1 };
+    const s16x2 t1 = b - c, t2 = a - c, n1 = zero - t1;
+    const s16x2 pa = __builtin_elementwise_max(t1, n1);                       // |p - a| = |b - c|
+    const s16x2 pb = __builtin_elementwise_max(t2, zero - t2);                // |p - b| = |a - c|
+    const s16x2 t3 = t1 + t2;
+    const s16x2 pc = __builtin_elementwise_max(t3, zero - t3);                // |p - c| = |a + b - 2c|
+    const s16x2 m  = __builtin_elementwise_min(pb, pc);
+    const s16x2 k  = __builtin_elementwise_min(__builtin_elementwise_max(pa - m, zero), one);     // 1: not a   (pa > min(pb, pc))
+    const s16x2 k2 = __builtin_elementwise_min(__builtin_elementwise_max(pb - pc, zero), one);    // 1: c over b (pb > pc)
+    const s16x2 bc = k2 * n1 + b;                                             // b or c        (c - b = -t1)
+    return k * (bc - a) + a;                                                  // a, b or c
+}
+// the same for one whole pixel packed in a dword
+__device__ __forceinline__ u32 paeth_bytes(u32 a, u32 b, u32 c)
+{
+    const u32 LO = 0x0c010c00u, HI = 0x0c030c02u;                             // v_perm_b32: bytes (0,1) / (2,3) -> 16-bit lanes
+    const s16x2 plo = paeth2(as_s16x2(__builtin_amdgcn_perm(0, a, LO)), as_s16x2(__builtin_amdgcn_perm(0, b, LO)), as_s16x2(__builtin_amdgcn_perm(0, c, LO)));
+    const s16x2 phi = paeth2(as_s16x2(__builtin_amdgcn_perm(0, a, HI)), as_s16x2(__builtin_amdgcn_perm(0, b, HI)), as_s16x2(__builtin_amdgcn_perm(0, c, HI)));
+    return __builtin_amdgcn_perm(as_u32(phi), as_u32(plo), 0x06040200u);      // low bytes of the four lanes
+}
+
 // shift a dword one lane up the wave (lane j receives lane j-1's value; lane 0 keeps `fill`):
 // one DPP move, wave_shr:1 (gfx9 DPP control 0x138), bound_ctrl off so lane 0 retains `old`
 __device__ __forceinline__ u32 from_lane_below(u32 v, u32 fill)
@@ -221,24 +259,32 @@ __global__ __launch_bounds__(W * 64) void k_png_defilter(DefilterArgs a)
 //
 // With lane = row, a plain per-lane load/store touches 64 different cache lines per wave instruction and the
 // vector-memory address path serialises them (measured: 1.2 TB/s regardless of the filter mix, VALU idle).
-// Here a wave moves its band in tiles of TT loop trips: the 16-byte piece lane j needs in trip T is iteration
-// T - j of row j, so a tile is a parallelogram in (row, byte) space; it is fetched and written back by
-// cooperative instructions in which 8 consecutive lanes cover 128 contiguous bytes of one row.  Pieces live in
-// LDS at tile[row][T % TT]; a lane reads its raw piece, and overwrites the same slot with the de-filtered one.
-// The next tile's pieces are prefetched into registers while the current tile is processed.
+// Here each row of the band owns a ring of RING 16-byte pieces in LDS, piece `it` of a row living in slot it % RING.
+// A wave works in tiles of TT loop trips (lane j handles iteration T - j in trip T):
+//   * the raw pieces of the next tile -- a parallelogram in (row, byte) space -- are fetched into registers by
+//     cooperative loads in which 8 consecutive lanes cover 128 contiguous bytes of one row, and dropped into the
+//     rings at the start of the tile;
+//   * in a trip a lane reads its raw piece from its ring and overwrites the slot with the de-filtered piece;
+//   * at the end of the tile every row has finished exactly one more 128-BYTE-ALIGNED group of 8 pieces (iterations
+//     8g .. 8g+7, computed during this tile and the one before); those groups are written back, 8 lanes per row.
+// Writing whole aligned 128-byte lines matters: the same bytes stored as tile-shaped (16-byte-granular, unaligned)
+// 128-byte runs ran at 2.0 TB/s store-only against 3.7 TB/s aligned (tools/png_abl.sh experiments).
 constexpr int TT = 8;
-constexpr int TILE_PITCH = TT * 16 + 16;          // bytes per row in LDS: 9 x 16 B => conflict-free ds_read_b128 across lanes
+constexpr int RING = 16;                          // pieces per row: a finished-but-unwritten group (<= 7 pieces) + the tile in flight (8)
+constexpr int ROW_PITCH = RING * 16;              // 256 B: lane j's slot (T - j) % 16 => ds_read_b128 conflict-free across 8 consecutive lanes
+#ifndef PNG_NT_STORES
+#define PNG_NT_STORES 1
+#endif
 
 template <int W, bool PAETH>
-__device__ __forceinline__ void defilter_band4(const DefilterArgs& a, const uint8_t* raw, uint8_t* D, u32* prog, uint8_t* tile, u32 band,
+__device__ __forceinline__ void defilter_band4(const DefilterArgs& a, const uint8_t* raw, uint8_t* D, u32* prog, uint8_t* ring, u32 band,
                                                int wave, int lane, u32 niter, u32 f, bool row_live)
 {
     constexpr int FB = 4;
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
     const u32 seq = band / W;
     const u32 row = band * 64 + lane;
-    const u32 ma = (f == 1 || f == 3 || f == 4) ? 0xFFu : 0u;
-    const u32 mb = (f == 2 || f == 3 || f == 4) ? 0xFFu : 0u;
-    const u32 sh = (f == 3) ? 1u : 0u;
+    const u32 mA = f == 1 ? 0xFFFFFFFFu : 0u, mB = f == 2 ? 0xFFFFFFFFu : 0u, mAvg = f == 3 ? 0xFFFFFFFFu : 0u;     // None/Sub/Up/Avg as one masked form
     const bool is_paeth = f == 4;
 
     uint8_t* drow = D + (int64_t)(row_live ? row : 0) * a.d_pitch;
@@ -248,13 +294,13 @@ __device__ __forceinline__ void defilter_band4(const DefilterArgs& a, const uint
     const u32 prod_base = (band > 0 ? (band - 1) / W : 0) * niter;
     const u32 full_iters = a.wb / 16;
 
-    // cooperative mapping: in transfer k (0..7) this lane handles row 8k + crow, slot cslot
+    // cooperative mapping: in transfer k (0..7) this lane handles row 8k + crow, piece cslot of that row's 8
     const int crow = lane >> 3, cslot = lane & 7;
     const u32 rows_left = a.rows - band * 64;                           // live rows in this band (may exceed 64)
     const uint8_t* craw = raw + (int64_t)(band * 64 + crow) * (a.wb + 1) + 1;
     uint8_t* cdst = D + (int64_t)(band * 64 + crow) * a.d_pitch;
-    uint8_t* my_tile = tile + lane * TILE_PITCH;                        // this lane's row of pieces
-    uint8_t* co_tile = tile + crow * TILE_PITCH + cslot * 16;           // + k * 8 * TILE_PITCH
+    uint8_t* my_ring = ring + lane * ROW_PITCH;
+    uint8_t* co_ring = ring + crow * ROW_PITCH;                         // + k * 8 * ROW_PITCH + slot * 16
 
     u32 outp[FB], bp[FB];
     #pragma unroll
@@ -266,14 +312,12 @@ __device__ __forceinline__ void defilter_band4(const DefilterArgs& a, const uint
             __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
-    // iteration handled by (row 8k+crow, slot cslot) in the tile starting at trip T0; clamped to a readable full piece
-    auto coop_iter = [&](u32 T0, int k) { return (int)T0 + cslot - (8 * k + crow); };
 
     uint4 pre[TT];                                  // next tile's raw pieces (cooperative layout)
     auto prefetch_tile = [&](u32 T0) {
         #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            int it = coop_iter(T0, k);
+            int it = (int)T0 + cslot - (8 * k + crow);                                     // piece of row 8k+crow used in trip T0 + cslot
             const u32 r = (u32)(8 * k + crow) < rows_left ? (u32)(8 * k) : 0u;             // dead rows re-read a live one (unused)
             it = it < 0 ? 0 : it;
             // full pieces by index; the ragged last piece (and anything past it, unused) = the last 16 bytes of the row
@@ -282,11 +326,10 @@ __device__ __forceinline__ void defilter_band4(const DefilterArgs& a, const uint
             pre[k] = make_uint4(q[0].v, q[1].v, q[2].v, q[3].v);
         }
     };
-    u32 dset[PF][FB];
-    auto issue_dprev = [&](u32 Tn, u32 (&ds)[FB]) {
+    u32x4 dset[PF];
+    auto issue_dprev = [&](u32 Tn, u32x4& ds) {
         const uint8_t* dn = dprev + (int64_t)min(Tn, niter - 1) * 16;                      // lane 0's iteration is Tn: wave-uniform address
-        #pragma unroll
-        for (int i = 0; i < FB; ++i) ds[i] = reinterpret_cast<const u32*>(dn)[i] & dmask;
+        ds = *reinterpret_cast<const u32x4*>(dn);
     };
 
     if (band > 0) wait_for_band_above(PUB + PF);
@@ -294,11 +337,16 @@ __device__ __forceinline__ void defilter_band4(const DefilterArgs& a, const uint
     #pragma unroll
     for (int u = 0; u < PF; ++u) issue_dprev((u32)u, dset[u]);
 
-    const u32 T_end = niter + 63;
+    // trips must reach iteration niter-1 of lane 63; write-back must reach row 63's last group (tile T0 = 8 g_last + 64)
+    const u32 T_end = max(niter + 63, 8 * ((full_iters - 1) >> 3) + 65);
+    u32 my_slot = (u32)(-lane) & (RING - 1);                                               // slot of iteration T - lane, kept incrementally
     for (u32 T0 = 0; T0 < T_end; T0 += TT) {
-        // stage this tile's raw pieces (prefetched) in LDS, then start fetching the next tile
+        // drop this tile's raw pieces (prefetched) into the rings, then start fetching the next tile
         #pragma unroll
-        for (int k = 0; k < 8; ++k) *reinterpret_cast<uint4*>(co_tile + k * 8 * TILE_PITCH) = pre[k];
+        for (int k = 0; k < 8; ++k) {
+            const u32 slot = (T0 + (u32)cslot - (u32)(8 * k + crow)) & (RING - 1);
+            *reinterpret_cast<uint4*>(co_ring + k * 8 * ROW_PITCH + slot * 16) = pre[k];
+        }
         prefetch_tile(T0 + TT);
 
         #pragma unroll
@@ -308,7 +356,9 @@ __device__ __forceinline__ void defilter_band4(const DefilterArgs& a, const uint
             const bool live = row_live && it >= 0 && it < (int)niter;
             const bool ragged = live && it >= (int)full_iters;
 
-            const uint4 rv = *reinterpret_cast<const uint4*>(my_tile + u * 16);
+            uint4* piece = reinterpret_cast<uint4*>(my_ring + my_slot * 16);
+            my_slot = (my_slot + 1) & (RING - 1);
+            const uint4 rv = *piece;
             u32 rg[FB] = { rv.x, rv.y, rv.z, rv.w }, bg[FB];
             if (__any(ragged)) {        // last, partial piece of a row: the staged piece is the row's LAST 16 bytes (see prefetch_tile);
                 if (ragged) {           // keep its top nb bytes, moved down.  wb % 4 == 0, so the shift is whole dwords.  No memory op here.
@@ -321,29 +371,26 @@ __device__ __forceinline__ void defilter_band4(const DefilterArgs& a, const uint
                 }
             }
             #pragma unroll
-            for (int i = 0; i < FB; ++i) bg[i] = from_lane_below(outp[i], dset[u % PF][i]);
+            for (int i = 0; i < FB; ++i) bg[i] = from_lane_below(outp[i], dset[u % PF][i] & dmask);
             if (band > 0 && T + PF < niter && ((T + PF) % PUB) == 0) wait_for_band_above(T + PF + PUB);
             issue_dprev(T + PF, dset[u % PF]);
 
-            u32 og[FB] = { 0, 0, 0, 0 };
+            u32 og[FB];
             #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const u32 x  = byte_of(rg, k);
-                const u32 bb = byte_of(bg, k);
-                const u32 aa = k >= FB ? byte_of(og, k - FB) : byte_of(outp, 3 * FB + k);
-                u32 pred = ((aa & ma) + (bb & mb)) >> sh;
+            for (int p = 0; p < 4; ++p) {             // one pixel (dword) at a time; left / upper-left neighbours are the previous pixel
+                const u32 aa = p ? og[p - 1] : outp[3];
+                u32 pred = (aa & mA) | (bg[p] & mB) | (avg_bytes(aa, bg[p]) & mAvg);
                 if constexpr (PAETH) {
-                    const u32 cc = k >= FB ? byte_of(bg, k - FB) : byte_of(bp, 3 * FB + k);
-                    const u32 pp = paeth(aa, bb, cc);
+                    const u32 pp = paeth_bytes(aa, bg[p], p ? bg[p - 1] : bp[3]);
                     pred = is_paeth ? pp : pred;
                 }
-                og[k >> 2] |= ((x + pred) & 0xFFu) << ((k & 3) * 8);
+                og[p] = add_bytes(rg[p], pred);
             }
             if (live) {
                 #pragma unroll
                 for (int i = 0; i < FB; ++i) { outp[i] = og[i]; bp[i] = bg[i]; }
             }
-            *reinterpret_cast<uint4*>(my_tile + u * 16) = make_uint4(og[0], og[1], og[2], og[3]);
+            *piece = make_uint4(og[0], og[1], og[2], og[3]);
             if (__any(ragged)) {        // partial piece: up to three dword stores straight to the row (not part of the cooperative write-back)
                 u32* dst = reinterpret_cast<u32*>(drow + (int64_t)(ragged ? it : 0) * 16);
                 const u32 nb = ragged ? a.wb - (u32)it * 16 : 0u;
@@ -353,22 +400,25 @@ __device__ __forceinline__ void defilter_band4(const DefilterArgs& a, const uint
             }
         }
 
-        // write the tile's de-filtered pieces back, 128 contiguous bytes per row
+        // write back the group of 8 pieces each row completed with this tile: one aligned 128-byte run per row
         #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int it = coop_iter(T0, k);
-            const uint4 v = *reinterpret_cast<const uint4*>(co_tile + k * 8 * TILE_PITCH);
-            if ((u32)(8 * k + crow) < rows_left && it >= 0 && it < (int)full_iters)
-                *reinterpret_cast<uint4*>(cdst + (int64_t)(8 * k) * a.d_pitch + (int64_t)it * 16) = v;
+            const int it = (((int)T0 - (8 * k + crow)) & ~7) + cslot;                      // piece 8g + cslot, g = floor((T0 - row) / 8)
+            const uint4 v = *reinterpret_cast<const uint4*>(co_ring + k * 8 * ROW_PITCH + ((u32)it & (RING - 1)) * 16);
+            if ((u32)(8 * k + crow) < rows_left && it >= 0 && it < (int)full_iters) {
+                u32x4* dst = reinterpret_cast<u32x4*>(cdst + (int64_t)(8 * k) * a.d_pitch + (int64_t)it * 16);
+                if (PNG_NT_STORES) __builtin_nontemporal_store(u32x4{ v.x, v.y, v.z, v.w }, dst);
+                else               *dst = u32x4{ v.x, v.y, v.z, v.w };
+            }
         }
-        // publish what lane 63 stored in the PREVIOUS tile: since then this tile issued 8 prefetch loads and 8
-        // row-above loads, so "at most 16 vector-memory operations outstanding" implies those older stores have been
-        // acknowledged (the counter retires in order) -- the prefetches in flight are not drained.
-        const int done = (int)T0 - 63;                        // iterations of lane 63 written back before this tile
+        // publish what lane 63 had written back BEFORE this tile (groups below floor((T0 - 63) / 8)): since then this
+        // tile issued 8 prefetch loads and 8 row-above loads, so "at most 16 vector-memory operations outstanding" implies
+        // those older stores have been acknowledged (the counter retires in order) -- the prefetches in flight are not drained.
+        const int done = ((int)T0 - 63) & ~7;
         if (done > 0) {
             asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             if (lane == 63)
-                __hip_atomic_store(&prog[wave], seq * niter + min((u32)done, niter), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&prog[wave], seq * niter + min((u32)done, full_iters), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     // band finished: everything is on its way; drain and publish the whole band
@@ -381,8 +431,8 @@ template <int W, int MINW>
 __global__ __launch_bounds__(W * 64, MINW) void k_png_defilter4_tiled(DefilterArgs a)
 {
     __shared__ u32 prog[W];
-    __shared__ __attribute__((aligned(16))) uint8_t tiles[W][64 * TILE_PITCH];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ __attribute__((aligned(16))) uint8_t tiles[W][64 * ROW_PITCH];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int img = blockIdx.x;
     const uint8_t* raw = a.raw + (int64_t)img * a.raw_stride;
     uint8_t* D = a.D + (int64_t)img * a.d_stride;

@@ -64,31 +64,43 @@ __device__ __forceinline__ u32 avg_bytes(u32 a, u32 b)
 {
     return (a & b) + (((a ^ b) & 0xfefefefeu) >> 1);
 }
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ s16x2 as_s16x2(u32 v) { return __builtin_bit_cast(s16x2, v); }
-__device__ __forceinline__ u32 as_u32(s16x2 v) { return __builtin_bit_cast(u32, v); }
-// stbi__paeth (stbdec.d:1390-1401) on two channels at once, 16-bit lanes (v_pk_* instructions); a, b, c in 0..255
-__device__ __forceinline__ s16x2 paeth2(s16x2 a, s16x2 b, s16x2 c)
-{
-    const s16x2 zero = { 0, 0 }, one = { 1, 1 };
-    const s16x2 t1 = b - c, t2 = a - c, n1 = zero - t1;
-    const s16x2 pa = __builtin_elementwise_max(t1, n1);                       // |p - a| = |b - c|
-    const s16x2 pb = __builtin_elementwise_max(t2, zero - t2);                // |p - b| = |a - c|
-    const s16x2 t3 = t1 + t2;
-    const s16x2 pc = __builtin_elementwise_max(t3, zero - t3);                // |p - c| = |a + b - 2c|
-    const s16x2 m  = __builtin_elementwise_min(pb, pc);
-    const s16x2 k  = __builtin_elementwise_min(__builtin_elementwise_max(pa - m, zero), one);     // 1: not a   (pa > min(pb, pc))
-    const s16x2 k2 = __builtin_elementwise_min(__builtin_elementwise_max(pb - pc, zero), one);    // 1: c over b (pb > pc)
-    const s16x2 bc = k2 * n1 + b;                                             // b or c        (c - b = -t1)
-    return k * (bc - a) + a;                                                  // a, b or c
-}
-// the same for one whole pixel packed in a dword
+// ---- stbi__paeth (stbdec.d:1390-1401) on two channels at once, in packed FP16 ---------------------------------
+// A byte n is carried as the half-precision number 1024 + n, whose bit pattern is simply 0x6400 | n (ulp = 1 in
+// [1024, 2048)), so bytes <-> halves are single v_perm_b32 byte shuffles.  All differences (|.| <= 510), the 0/1
+// selectors and the selected value are small integers, exact in FP16; the bias cancels in every difference.
+// FP16 buys free negation (VOP3P neg modifiers: |t| = max(t, -t) is one instruction) and a free 0/1 step
+// (the clamp modifier on an integer-valued difference), 12 packed instructions per channel pair.  Written as inline
+// asm: the optimizer otherwise rewrites the 0/1 arithmetic into per-channel compares and selects (3x the count).
+#define PKF2(name, text) __device__ __forceinline__ u32 name(u32 x, u32 y) { u32 r; asm(text : "=v"(r) : "v"(x), "v"(y)); return r; }
+PKF2(pkf_add,       "v_pk_add_f16 %0, %1, %2")
+PKF2(pkf_sub,       "v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]")
+PKF2(pkf_step,      "v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1] clamp")          // x > y ? 1 : 0  (integers)
+PKF2(pkf_min,       "v_pk_min_f16 %0, %1, %2")
+#undef PKF2
+__device__ __forceinline__ u32 pkf_abs(u32 t) { u32 r; asm("v_pk_max_f16 %0, %1, %1 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(t)); return r; }
+__device__ __forceinline__ u32 pkf_fma(u32 x, u32 y, u32 z) { u32 r; asm("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z)); return r; }
+__device__ __forceinline__ u32 pkf_fnma(u32 x, u32 y, u32 z) { u32 r; asm("v_pk_fma_f16 %0, %1, %2, %3 neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(r) : "v"(x), "v"(y), "v"(z)); return r; }
+// one whole pixel packed in a dword; the two channel pairs (L: bytes 0,1  H: bytes 2,3) are written interleaved so that
+// no packed instruction consumes the result of the one just before it (gfx950 needs a wait state there).
 __device__ __forceinline__ u32 paeth_bytes(u32 a, u32 b, u32 c)
 {
-    const u32 LO = 0x0c010c00u, HI = 0x0c030c02u;                             // v_perm_b32: bytes (0,1) / (2,3) -> 16-bit lanes
-    const s16x2 plo = paeth2(as_s16x2(__builtin_amdgcn_perm(0, a, LO)), as_s16x2(__builtin_amdgcn_perm(0, b, LO)), as_s16x2(__builtin_amdgcn_perm(0, c, LO)));
-    const s16x2 phi = paeth2(as_s16x2(__builtin_amdgcn_perm(0, a, HI)), as_s16x2(__builtin_amdgcn_perm(0, b, HI)), as_s16x2(__builtin_amdgcn_perm(0, c, HI)));
-    return __builtin_amdgcn_perm(as_u32(phi), as_u32(plo), 0x06040200u);      // low bytes of the four lanes
+    const u32 BIAS = 0x64646464u, LO = 0x04010400u, HI = 0x04030402u;                   // bytes -> halves 0x64nn
+    const u32 aL = __builtin_amdgcn_perm(BIAS, a, LO), aH = __builtin_amdgcn_perm(BIAS, a, HI);
+    const u32 bL = __builtin_amdgcn_perm(BIAS, b, LO), bH = __builtin_amdgcn_perm(BIAS, b, HI);
+    const u32 cL = __builtin_amdgcn_perm(BIAS, c, LO), cH = __builtin_amdgcn_perm(BIAS, c, HI);
+    const u32 t1L = pkf_sub(bL, cL),        t1H = pkf_sub(bH, cH);
+    const u32 t2L = pkf_sub(aL, cL),        t2H = pkf_sub(aH, cH);
+    const u32 paL = pkf_abs(t1L),           paH = pkf_abs(t1H);                         // |p - a|   (p = a + b - c)
+    const u32 t3L = pkf_add(t1L, t2L),      t3H = pkf_add(t1H, t2H);
+    const u32 pbL = pkf_abs(t2L),           pbH = pkf_abs(t2H);                         // |p - b|
+    const u32 pcL = pkf_abs(t3L),           pcH = pkf_abs(t3H);                         // |p - c|
+    const u32 mL  = pkf_min(pbL, pcL),      mH  = pkf_min(pbH, pcH);
+    const u32 k2L = pkf_step(pbL, pcL),     k2H = pkf_step(pbH, pcH);                   // 1: c over b (pb > pc)
+    const u32 kL  = pkf_step(paL, mL),      kH  = pkf_step(paH, mH);                    // 1: not a   (pa > min(pb, pc))
+    const u32 bcL = pkf_fnma(k2L, t1L, bL), bcH = pkf_fnma(k2H, t1H, bH);               // b + k2 * (c - b)
+    const u32 sL  = pkf_sub(bcL, aL),       sH  = pkf_sub(bcH, aH);
+    const u32 pL  = pkf_fma(kL, sL, aL),    pH  = pkf_fma(kH, sH, aH);                  // a + k * (bc - a)
+    return __builtin_amdgcn_perm(pH, pL, 0x06040200u);                                  // low bytes of the four halves
 }
 
 // shift a dword one lane up the wave (lane j receives lane j-1's value; lane 0 keeps `fill`):
@@ -302,9 +314,9 @@ __device__ __forceinline__ void defilter_band4(const DefilterArgs& a, const uint
     uint8_t* my_ring = ring + lane * ROW_PITCH;
     uint8_t* co_ring = ring + crow * ROW_PITCH;                         // + k * 8 * ROW_PITCH + slot * 16
 
-    u32 outp[FB], bp[FB];
+    u32 outp[FB], bp3 = 0;                        // this lane's previous piece; last dword of the previous piece of the row above
     #pragma unroll
-    for (int i = 0; i < FB; ++i) { outp[i] = 0; bp[i] = 0; }
+    for (int i = 0; i < FB; ++i) outp[i] = 0;
 
     auto wait_for_band_above = [&](u32 upto) {
         const u32 need = prod_base + min(niter, upto);
@@ -348,19 +360,20 @@ __device__ __forceinline__ void defilter_band4(const DefilterArgs& a, const uint
             *reinterpret_cast<uint4*>(co_ring + k * 8 * ROW_PITCH + slot * 16) = pre[k];
         }
         prefetch_tile(T0 + TT);
+        // some lane meets the partial last piece of its row (iteration full_iters, trip full_iters + lane) in this tile
+        const bool rag_tile = (a.wb & 15) != 0 && T0 + TT > full_iters && T0 <= full_iters + 63;
 
         #pragma unroll
         for (int u = 0; u < TT; ++u) {
             const u32 T = T0 + u;
             const int it = (int)T - lane;
-            const bool live = row_live && it >= 0 && it < (int)niter;
-            const bool ragged = live && it >= (int)full_iters;
+            const bool ragged = rag_tile && row_live && it == (int)full_iters;
 
             uint4* piece = reinterpret_cast<uint4*>(my_ring + my_slot * 16);
             my_slot = (my_slot + 1) & (RING - 1);
             const uint4 rv = *piece;
             u32 rg[FB] = { rv.x, rv.y, rv.z, rv.w }, bg[FB];
-            if (__any(ragged)) {        // last, partial piece of a row: the staged piece is the row's LAST 16 bytes (see prefetch_tile);
+            if (rag_tile) {             // last, partial piece of a row: the staged piece is the row's LAST 16 bytes (see prefetch_tile);
                 if (ragged) {           // keep its top nb bytes, moved down.  wb % 4 == 0, so the shift is whole dwords.  No memory op here.
                     const u32 nb = a.wb - (u32)it * 16;
                     const u32 v1 = rg[1], v2 = rg[2], v3 = rg[3];
@@ -381,17 +394,19 @@ __device__ __forceinline__ void defilter_band4(const DefilterArgs& a, const uint
                 const u32 aa = p ? og[p - 1] : outp[3];
                 u32 pred = (aa & mA) | (bg[p] & mB) | (avg_bytes(aa, bg[p]) & mAvg);
                 if constexpr (PAETH) {
-                    const u32 pp = paeth_bytes(aa, bg[p], p ? bg[p - 1] : bp[3]);
+                    const u32 pp = paeth_bytes(aa, bg[p], p ? bg[p - 1] : bp3);
                     pred = is_paeth ? pp : pred;
                 }
                 og[p] = add_bytes(rg[p], pred);
             }
-            if (live) {
-                #pragma unroll
-                for (int i = 0; i < FB; ++i) { outp[i] = og[i]; bp[i] = bg[i]; }
-            }
+            // a lane that has not reached its row yet (it < 0) must keep presenting zeros to the lane below and to its own
+            // first pixel; past the end of the row (it >= niter) whatever it computes is only seen by lanes that are past
+            // the end of theirs as well, and is never written back
+            #pragma unroll
+            for (int i = 0; i < FB; ++i) outp[i] = it >= 0 ? og[i] : 0u;
+            bp3 = bg[3];
             *piece = make_uint4(og[0], og[1], og[2], og[3]);
-            if (__any(ragged)) {        // partial piece: up to three dword stores straight to the row (not part of the cooperative write-back)
+            if (rag_tile) {             // partial piece: up to three dword stores straight to the row (not part of the cooperative write-back)
                 u32* dst = reinterpret_cast<u32*>(drow + (int64_t)(ragged ? it : 0) * 16);
                 const u32 nb = ragged ? a.wb - (u32)it * 16 : 0u;
                 if (nb >= 4) dst[0] = og[0];

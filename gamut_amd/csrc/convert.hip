@@ -107,6 +107,18 @@ __device__ __forceinline__ int cvtt(float x)
     return in_range ? (int)x : (int)0x80000000;
 }
 
+// x / M, correctly rounded (== the IEEE division scanline.d performs), for integer x in [0, M], M = 255 or 65535:
+// q = RN(x * RN(1/M)), one FMA residual, one FMA correction (Markstein).  Exhaustively checked against exact
+// rational arithmetic for all 256 / 65536 inputs (tests/test_oracle_pinning.py::test_division_by_max_identity) and
+// against the oracle on the GPU for every 16-bit value; 3 instructions instead of the ~10 of a generic division.
+template <int M> __device__ __forceinline__ float div_by_max(float x)
+{
+    constexpr float y = 1.0f / (float)M;
+    const float q = __fmul_rn(x, y);
+    const float r = __fmaf_rn(-q, (float)M, x);
+    return __fmaf_rn(r, y, q);
+}
+
 struct RGBAf { float r, g, b, a; };
 struct RGBA8 { u32 r, g, b, a; };
 
@@ -118,8 +130,8 @@ template <int T> __device__ __forceinline__ RGBAf decode_f32(const u32* w, int p
     #pragma unroll
     for (int k = 0; k < CH; ++k) {
         const u32 raw = get_comp<BITS>(w, p * CH + k);
-        if constexpr (BITS == 8)       c[k] = __fdiv_rn((float)(int)raw, 255.0f);
-        else if constexpr (BITS == 16) c[k] = __fdiv_rn((float)(int)raw, 65535.0f);
+        if constexpr (BITS == 8)       c[k] = div_by_max<255>((float)(int)raw);
+        else if constexpr (BITS == 16) c[k] = div_by_max<65535>((float)(int)raw);
         else                           c[k] = __uint_as_float(raw);
     }
     RGBAf o;

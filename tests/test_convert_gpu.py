@@ -156,3 +156,13 @@ def test_host_dropin_matches_scanlinesConvert(hip):
     assert hip.gamut_hip_scanlines_convert(12, None, 0, 14, None, 0, 0, 0) == 0
     assert hip.gamut_hip_scanlines_convert(-1, sbuf.ctypes.data, 4, 14, got.ctypes.data, 16, 1, 1) == _capi.ERR_INVALID_ARG
     assert b"PixelType" in hip.gamut_hip_last_error()
+
+
+def test_every_16bit_and_8bit_value_decodes_exactly(hip):
+    """the kernel divides by 255 / 65535 with an FMA sequence instead of a division: every input value, bit for bit."""
+    for src, n, dt in (("l16", 65536, np.uint16), ("l8", 256, np.uint8)):
+        px = np.arange(n, dtype=dt).view(np.uint8)
+        for dst in ("rgbaf32", "lf32", "rgba16", "rgba8"):
+            exp = O.scanlines_convert(PT[src], px, PT[dst], n, 1)
+            got = _run_device(hip, PT[src], PT[dst], px, 0, px.size, exp.size, 0, exp.size, n, 1)
+            assert np.array_equal(got, exp), (src, dst)

@@ -323,3 +323,36 @@ def test_convert_pitches_and_flip():
     assert np.array_equal(dst, tight)
     assert O.lib().orc_scanlines_inter_type(PT["la8"], PT["rgb8"]) == PT["rgba8"]
     assert O.lib().orc_scanlines_inter_type(PT["lap8"], PT["rgb8"]) == PT["rgbaf32"]          # premultiplied 8-bit is not "8-bit" (internals/types.d:99-111)
+
+
+def test_division_by_max_identity():
+    """x / 255.0f and x / 65535.0f (scanline.d:240-529) == RN(q + RN(x - M q) * y), q = RN(x * y), y = RN(1 / M), for every
+    integer input: the form the HIP kernels use (gamut_amd/csrc/convert.hip div_by_max).  Checked in exact arithmetic."""
+    from fractions import Fraction
+
+    def rn32(fr):                                   # Fraction -> nearest-even binary32, as a Fraction
+        if fr == 0:
+            return Fraction(0)
+        sgn = -1 if fr < 0 else 1
+        fr = abs(fr)
+        e = fr.numerator.bit_length() - fr.denominator.bit_length()
+        while Fraction(2) ** e > fr:
+            e -= 1
+        while Fraction(2) ** (e + 1) <= fr:
+            e += 1
+        ulp = Fraction(2) ** (max(e, -126) - 23)
+        q = fr / ulp
+        n = q.numerator // q.denominator
+        rem = q - n
+        if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and n % 2 == 1):
+            n += 1
+        return sgn * n * ulp
+
+    for M, step in ((255, 1), (65535, 1)):
+        y = rn32(Fraction(1, M))
+        assert float(y) == float(np.float32(1.0) / np.float32(M))
+        for x in range(0, M + 1, step):
+            q = rn32(x * y)
+            r = rn32(x - M * q)
+            assert r == x - M * q                    # the residual FMA is exact
+            assert float(rn32(q + r * y)) == float(np.float32(x) / np.float32(M)), (M, x)

@@ -63,7 +63,7 @@ FORMATS = [(1, 1, 0), (1, 2, 0), (1, 4, 0), (1, 8, 0), (1, 16, 0), (2, 8, 4), (2
 def test_defilter_formats_filters_sizes(hip, img_n, depth, color):
     rng = np.random.default_rng(depth * 10 + img_n)
     fb = 1 if depth < 8 else img_n * (2 if depth == 16 else 1)
-    for (x, y) in [(1, 1), (2, 3), (5, 2), (37, 70), (130, 129), (33, 1100)]:
+    for (x, y) in [(1, 1), (2, 3), (5, 2), (7, 5), (37, 70), (64, 65), (130, 129), (259, 67), (33, 1100)]:
         smooth = rng.integers(0, 1 << depth, (y, x * img_n))
         smooth = (np.cumsum(rng.integers(-2, 3, (y, x * img_n)), axis=1) + smooth[:, :1]) % (1 << depth) if x > 8 else smooth
         rows = gen.pack_samples(smooth, depth)

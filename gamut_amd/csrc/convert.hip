@@ -18,7 +18,7 @@
 // Work decomposition: one thread converts a "unit" of G pixels, G chosen per
 // type pair so both sides of the unit are whole dwords and the wider side is
 // >= 16 B (one dwordx4 per lane, lane-contiguous => fully coalesced 1 KiB per
-// wave instruction).  Units are distributed grid-stride over <= 8 blocks/CU.
+// wave instruction).  Units are distributed grid-stride over <= 6 blocks/CU.
 #include "common.hpp"
 #include <utility>
 
@@ -316,7 +316,8 @@ __global__ __launch_bounds__(kThreads) void k_copy_rows(ConvArgs a, u32 row_byte
 inline int grid_for(int64_t work_items, int device_cus)
 {
     int64_t blocks = (work_items + kThreads - 1) / kThreads;
-    const int64_t cap = (int64_t)device_cus * 8;     // 8 x 256-thread blocks per CU = 32 waves/CU
+    static const int per_cu = getenv("GAMUT_CONVERT_BLOCKS_PER_CU") ? atoi(getenv("GAMUT_CONVERT_BLOCKS_PER_CU")) : 6;
+    const int64_t cap = (int64_t)device_cus * per_cu;     // 6 x 256-thread blocks per CU (swept 2..12 on MI355X: flat within noise above 4; tuning knob)
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (int)blocks;

@@ -71,12 +71,13 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ __forceinline__ void map_half(const MapCoef& c, int half, const i32 (&u)[8], i32 (&o)[4])
+// pass0 / pass1: the lane's two pass-through inputs (u0,u4 for "E", u2,u6 for "O"), already selected by the caller
+__device__ __forceinline__ void map_half(const MapCoef& c, i32 pass0, i32 pass1, i32 u1, i32 u3, i32 u5, i32 u7, i32 (&o)[4])
 {
-    o[0] = half ? u[2] : u[0];
-    o[1] = half ? u[6] : u[4];
-    o[2] = D4(c.a[0], u[1], c.a[1], u[3], c.a[2], u[5], c.a[3], u[7]);
-    o[3] = D4(c.b[0], u[1], c.b[1], u[3], c.b[2], u[5], c.b[3], u[7]);
+    o[0] = pass0;
+    o[1] = pass1;
+    o[2] = D4(c.a[0], u1, c.a[1], u3, c.a[2], u5, c.a[3], u7);
+    o[3] = D4(c.b[0], u1, c.b[1], u3, c.b[2], u5, c.b[3], u7);
 }
 
 __global__ __launch_bounds__(256) void k_jpeg_h2v2_rgba8(JpegArgs a)
@@ -121,9 +122,10 @@ __global__ __launch_bounds__(256) void k_jpeg_h2v2_rgba8(JpegArgs a)
     }
     // P1b: chroma horizontal stage: source row k of chroma block cbk -> H[k][physical slots half*4 .. +3]
     {
-        i32 u[8], hv[4];
-        unpack_row(crow, u);
-        map_half(mc, half, u, hv);
+        i32 hv[4];
+        const u32 w0 = half ? crow.y : crow.x, w1 = half ? crow.w : crow.z;        // (u2 | u3) : (u0 | u1),  (u6 | u7) : (u4 | u5)
+        map_half(mc, (i32)(short)(w0 & 0xFFFF), (i32)(short)(w1 & 0xFFFF),
+                 (i32)crow.x >> 16, (i32)crow.y >> 16, (i32)crow.z >> 16, (i32)crow.w >> 16, hv);
         *reinterpret_cast<int4*>(Hs + cbk * BLK_STRIDE + k * 8 + half * 4) = make_int4(hv[0], hv[1], hv[2], hv[3]);
     }
     wave_sync();
@@ -146,11 +148,10 @@ __global__ __launch_bounds__(256) void k_jpeg_h2v2_rgba8(JpegArgs a)
     }
     // P2b: chroma vertical stage on physical column k of H (all 8 source rows) -> V[physical rows half*4 .. +3][k]
     {
-        i32 u[8], vv[4];
+        i32 vv[4];
         const i32* src = Hs + cbk * BLK_STRIDE + k;
-        #pragma unroll
-        for (int i = 0; i < 8; ++i) u[i] = src[i * 8];
-        map_half(mc, half, u, vv);
+        const i32* psrc = src + half * 16;                   // rows 0,4 ("E") or 2,6 ("O"): the pass-through rows, picked by address
+        map_half(mc, psrc[0], psrc[32], src[8], src[24], src[40], src[56], vv);
         i32* dst = Vs + cbk * BLK_STRIDE + (half * 4) * 8 + k;
         #pragma unroll
         for (int i = 0; i < 4; ++i) dst[i * 8] = vv[i];
@@ -201,14 +202,22 @@ __global__ __launch_bounds__(256) void k_jpeg_h2v2_rgba8(JpegArgs a)
         const int lx = m * 16 + (q & 1) * 8 + r;               // pixel column inside the strip
         const int ly0 = (q >> 1) * 8;                          // first pixel row inside the strip
         if (mcu_live && mcu_x0 * 16 + lx < a.width) {
-            uint8_t* o = obase + (u32)(lx * 4);
-            const int rows_here = a.height - mcu_y * 16 - ly0;
             // one pixel per lane per row: a wave store instruction writes two full 128-byte lines.  (16-byte stores after an
             // in-quad DPP transpose were measured 2 % slower: the kernel is VALU-bound, not store-issue-bound.)
-            #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (i < rows_here)
-                    __builtin_nontemporal_store(ycc_to_rgba(ys[i], cbs[i], crs[i]), reinterpret_cast<u32*>(o + (int64_t)(ly0 + i) * a.out_pitch));
+            // Addresses = uniform strip base + 32-bit lane offset (the launcher checks 16 * out_pitch < 2^31).
+            const u32 pitch = (u32)a.out_pitch;
+            u32 voff = (u32)(lx * 4) + (u32)ly0 * pitch;
+            if (a.height - mcu_y * 16 >= 16) {                 // wave-uniform: all 16 rows of the strip exist
+                #pragma unroll
+                for (int i = 0; i < 8; ++i, voff += pitch)
+                    __builtin_nontemporal_store(ycc_to_rgba(ys[i], cbs[i], crs[i]), reinterpret_cast<u32*>(obase + voff));
+            } else {
+                const int rows_here = a.height - mcu_y * 16 - ly0;
+                #pragma unroll
+                for (int i = 0; i < 8; ++i, voff += pitch)
+                    if (i < rows_here)
+                        __builtin_nontemporal_store(ycc_to_rgba(ys[i], cbs[i], crs[i]), reinterpret_cast<u32*>(obase + voff));
+            }
         }
     }
 }
@@ -395,7 +404,7 @@ int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
         if (c.max_zag) c.max_zag += (int64_t)i0 * zag_stride;
         const dim3 grid(tiles, a.mcus_per_col, n);
         const bool tuned = scan_type == GAMUT_JPGD_YH2V2 && out_comps == 4 && ((uintptr_t)out & 3) == 0 &&
-                           (out_pitch & 3) == 0 && (out_stride & 3) == 0;
+                           (out_pitch & 3) == 0 && (out_stride & 3) == 0 && out_pitch > 0 && out_pitch < (1 << 27);
         if (tuned) hipLaunchKernelGGL(k_jpeg_h2v2_rgba8, grid, dim3(256), 0, stream, c);
         else       hipLaunchKernelGGL(k_jpeg_generic, grid, dim3(256), 0, stream, c);
         if (int rc = launch_status("jpeg_reconstruct")) return rc;

@@ -142,7 +142,13 @@ __device__ __forceinline__ u32 ycc_to_rgba(i32 y, i32 cb, i32 cr)
     const i32 r = y + (mad24(cr, C_CRR, 32768 - 128 * C_CRR) >> 16);
     const i32 g = y + (mad24(cr, C_CRG, mad24(cb, C_CBG, 32768 - 128 * C_CRG - 128 * C_CBG)) >> 16);
     const i32 b = y + (mad24(cb, C_CBB, 32768 - 128 * C_CBB) >> 16);
-    return (u32)clamp255(r) | ((u32)clamp255(g) << 8) | ((u32)clamp255(b) << 16) | 0xFF000000u;
+    // clamp + pack: r, g, b are within +-2^10, so they can be saturated as 16-bit lanes (v_sat_pk_u8_i16 does two at once)
+    // and gathered with byte permutes: 4 instructions instead of 3 clamps + 3 shift/ors
+    const u32 rg = __builtin_amdgcn_perm((u32)g, (u32)r, 0x05040100u);     // r.lo16 | g.lo16 << 16
+    u32 rg8, b8;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(rg8) : "v"(rg));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(b8) : "v"(b));                     // byte 0 = sat(b); byte 1 unused
+    return __builtin_amdgcn_perm(b8, rg8, 0x0d040100u);                    // R, G, B, 0xFF
 }
 // RGB -> grey of decompress_jpeg_image_from_stream (:3786-3792)
 __device__ __forceinline__ u32 rgb_to_luma(u32 rgba)

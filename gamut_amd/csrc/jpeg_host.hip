@@ -6,10 +6,15 @@
 // order through g_ZAG, track m_mcu_block_max_zag), for a whole image at once, after the
 // marker pass of :1160-1848 (DQT tables kept in zig-zag order as int16, :1313-1329; DHT;
 // SOF0/SOF1 8-bit; DRI; SOS).  It stays on the host: bit-serial work.
-// Not supported here (the call fails like the reference fails on a stream it rejects):
-// progressive / arithmetic / lossless frames, multi-scan baseline files.
+// Progressive frames (SOF2, jpegload.d:3296-3664) accumulate their scans into per-component coefficient planes on the
+// host and come out in the same dense form, so the kernels do not know the difference.
+// Not supported (the call fails like the reference fails on a stream it rejects): arithmetic / lossless /
+// hierarchical frames, 12-bit precision, CMYK, multi-scan *baseline* files.
 #include "common.hpp"
+#include <atomic>
 #include <new>
+#include <thread>
+#include <vector>
 
 namespace gamut {
 namespace {
@@ -92,11 +97,20 @@ struct BitReader {
 
 inline int be16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
 
+// One SOS header (read_sos_marker :1466-1540)
+struct Scan {
+    int ncomp = 0, comp[3] = {};                // frame component indices, in scan order
+    int ss = 0, se = 63, ah = 0, al = 0;        // spectral selection, successive approximation (progressive only)
+};
+
 struct Parser {
+    const uint8_t* data = nullptr; size_t len = 0, pos = 0;
     int16_t   quant[4][64]; bool quant_def[4] = { false, false, false, false };
     HuffTable huff[8];                 // 0-3 DC, 4-7 AC (index mapping of read_dht_marker :1247)
     int comp_id[3] = {}, hs[3] = {}, vs[3] = {}, tq[3] = {}, td[3] = {}, ta[3] = {};
     int restart_interval = 0;
+    bool have_sof = false, progressive = false;
+    Scan scan;
 };
 
 int fail(gamut_hip_jpeg_frame* f, const char* why)
@@ -105,34 +119,28 @@ int fail(gamut_hip_jpeg_frame* f, const char* why)
     return set_error(GAMUT_HIP_ERR_DECODE, "jpeg: %s", why);
 }
 
-int decode_coeffs(const uint8_t* data, size_t len, gamut_hip_jpeg_frame* f)
+// Walks the marker segments from P.pos (process_markers :1578-1848) until an SOS has been read (returns 0xDA, P.pos at
+// the first entropy-coded byte, P.scan filled) or the stream ends (0xD9).  Tables may be (re)defined between scans.
+// On a malformed segment returns -1 after fail().
+int next_scan(Parser& P, gamut_hip_jpeg_frame* f)
 {
-    memset(f, 0, sizeof(*f));
-    f->pixel_aspect_ratio = -1; f->dpi_y = -1;
-    if (!data || len < 4 || data[0] != 0xFF || data[1] != 0xD8) return fail(f, "not a JPEG (no SOI)");
-
-    Parser* ps = new (std::nothrow) Parser();
-    if (!ps) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: out of memory");
-    struct Guard { Parser* p; ~Guard() { delete p; } } guard{ ps };
-    Parser& P = *ps;
-
-    size_t pos = 2; bool have_sof = false; const uint8_t* scan = nullptr;
-    while (!scan) {
+    const uint8_t* data = P.data; const size_t len = P.len; size_t& pos = P.pos;
+    for (;;) {
         while (pos < len && data[pos] != 0xFF) ++pos;          // next_marker :1544-1572
         while (pos < len && data[pos] == 0xFF) ++pos;
-        if (pos >= len) return fail(f, "no SOS marker");
+        if (pos >= len) return 0xD9;
         const int m = data[pos++];
         if (m == 0x00 || m == 0x01 || m == 0xD8 || (m >= 0xD0 && m <= 0xD7)) continue;
-        if (m == 0xD9) return fail(f, "EOI before SOS");
-        if (pos + 2 > len) return fail(f, "truncated marker");
+        if (m == 0xD9) return 0xD9;
+        if (pos + 2 > len) { fail(f, "truncated marker"); return -1; }
         const int seg = be16(data + pos);
-        if (seg < 2 || pos + (size_t)seg > len) return fail(f, "bad marker length");
+        if (seg < 2 || pos + (size_t)seg > len) { fail(f, "bad marker length"); return -1; }
         const uint8_t* s = data + pos + 2; int n = seg - 2;
         switch (m) {
         case 0xDB:                                             // DQT :1274-1346
             while (n > 0) {
                 const int prec = s[0] >> 4, id = s[0] & 15; ++s; --n;
-                if (id >= 4 || n < (prec ? 128 : 64)) return fail(f, "bad DQT");
+                if (id >= 4 || n < (prec ? 128 : 64)) { fail(f, "bad DQT"); return -1; }
                 for (int i = 0; i < 64; ++i) {
                     uint32_t v = *s++; if (prec) v = (v << 8) + *s++;
                     P.quant[id][i] = (int16_t)v;               // stored as `short`, zig-zag order
@@ -142,55 +150,56 @@ int decode_coeffs(const uint8_t* data, size_t len, gamut_hip_jpeg_frame* f)
             break;
         case 0xC4:                                             // DHT :1173-1270
             while (n > 0) {
-                if (n < 17) return fail(f, "bad DHT");
+                if (n < 17) { fail(f, "bad DHT"); return -1; }
                 const int idx = (s[0] & 0x0F) + ((s[0] & 0x10) >> 4) * 4;
-                if (idx >= 8) return fail(f, "bad DHT index");
+                if (idx >= 8) { fail(f, "bad DHT index"); return -1; }
                 HuffTable& h = P.huff[idx];
                 int cnt = 0; h.bits[0] = 0;
                 for (int i = 1; i <= 16; ++i) { h.bits[i] = s[i]; cnt += s[i]; }
                 s += 17; n -= 17;
-                if (cnt > 255 || n < cnt) return fail(f, "bad DHT counts");
+                if (cnt > 255 || n < cnt) { fail(f, "bad DHT counts"); return -1; }
                 memset(h.vals, 0, sizeof(h.vals)); memcpy(h.vals, s, (size_t)cnt);
                 s += cnt; n -= cnt; h.defined = true; h.build();
             }
             break;
-        case 0xC0: case 0xC1: {                                // SOF0 / SOF1 :1349-1417
-            if (n < 6) return fail(f, "bad SOF");
-            if (s[0] != 8) return fail(f, "only 8-bit precision is supported");
+        case 0xC0: case 0xC1: case 0xC2: {                     // SOF0 / SOF1 / SOF2 :1349-1417, :1596-1607
+            if (P.have_sof) { fail(f, "more than one frame header"); return -1; }
+            if (n < 6) { fail(f, "bad SOF"); return -1; }
+            if (s[0] != 8) { fail(f, "only 8-bit precision is supported"); return -1; }
             f->height = be16(s + 1); f->width = be16(s + 3); f->comps = s[5];
-            if (f->height < 1 || f->height > 16384) return fail(f, "bad height");
-            if (f->width < 1 || f->width > 16384) return fail(f, "bad width");
-            if (f->comps != 1 && f->comps != 3) return fail(f, "unsupported colorspace");       // init_frame :3191-3195
-            if (n != f->comps * 3 + 6) return fail(f, "bad SOF length");
+            if (f->height < 1 || f->height > 16384) { fail(f, "bad height"); return -1; }
+            if (f->width < 1 || f->width > 16384) { fail(f, "bad width"); return -1; }
+            if (f->comps != 1 && f->comps != 3) { fail(f, "unsupported colorspace"); return -1; }       // init_frame :3191-3195
+            if (n != f->comps * 3 + 6) { fail(f, "bad SOF length"); return -1; }
             for (int i = 0; i < f->comps; ++i) {
                 P.comp_id[i] = s[6 + 3 * i]; P.hs[i] = s[7 + 3 * i] >> 4; P.vs[i] = s[7 + 3 * i] & 15; P.tq[i] = s[8 + 3 * i];
-                if (P.tq[i] >= 4) return fail(f, "bad quant table selector");
+                if (P.tq[i] >= 4) { fail(f, "bad quant table selector"); return -1; }
             }
             // init_frame :3134-3190
             if (f->comps == 1) {
-                if (P.hs[0] != 1 || P.vs[0] != 1) return fail(f, "unsupported sampling factors");
+                if (P.hs[0] != 1 || P.vs[0] != 1) { fail(f, "unsupported sampling factors"); return -1; }
                 f->scan_type = GAMUT_JPGD_GRAYSCALE; f->blocks_per_mcu = 1;
             } else {
-                if (P.hs[1] != 1 || P.vs[1] != 1 || P.hs[2] != 1 || P.vs[2] != 1) return fail(f, "unsupported sampling factors");
+                if (P.hs[1] != 1 || P.vs[1] != 1 || P.hs[2] != 1 || P.vs[2] != 1) { fail(f, "unsupported sampling factors"); return -1; }
                 if      (P.hs[0] == 1 && P.vs[0] == 1) { f->scan_type = GAMUT_JPGD_YH1V1; f->blocks_per_mcu = 3; }
                 else if (P.hs[0] == 2 && P.vs[0] == 1) { f->scan_type = GAMUT_JPGD_YH2V1; f->blocks_per_mcu = 4; }
                 else if (P.hs[0] == 1 && P.vs[0] == 2) { f->scan_type = GAMUT_JPGD_YH1V2; f->blocks_per_mcu = 4; }
                 else if (P.hs[0] == 2 && P.vs[0] == 2) { f->scan_type = GAMUT_JPGD_YH2V2; f->blocks_per_mcu = 6; }
-                else return fail(f, "unsupported sampling factors");
+                else { fail(f, "unsupported sampling factors"); return -1; }
             }
             const int mw = 8 * (f->comps == 3 ? P.hs[0] : 1), mh = 8 * (f->comps == 3 ? P.vs[0] : 1);
             f->mcus_per_row = (f->width + mw - 1) / mw; f->mcus_per_col = (f->height + mh - 1) / mh;
-            have_sof = true;
+            P.have_sof = true; P.progressive = (m == 0xC2);
         } break;
-        case 0xC2: case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB: case 0xCD: case 0xCE: case 0xCF:
-            return fail(f, "progressive / lossless / arithmetic frames are not supported by the GPU feeder");
-        case 0xCC: return fail(f, "arithmetic coding is not supported");
+        case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB: case 0xCD: case 0xCE: case 0xCF:
+            fail(f, "lossless / hierarchical / arithmetic frames are not supported"); return -1;       // :1608-1628
+        case 0xCC: fail(f, "arithmetic coding is not supported"); return -1;
         case 0xDD:                                             // DRI :1445-1462
-            if (seg != 4) return fail(f, "bad DRI length");
+            if (seg != 4) { fail(f, "bad DRI length"); return -1; }
             P.restart_interval = be16(s);
             break;
         case 0xE0:                                             // APP0 / JFIF density :1632-1690
-            if (n >= 12 && !memcmp(s, "JFIF\0", 5)) {
+            if (n >= 14 && !memcmp(s, "JFIF\0", 5)) {
                 const int units = s[7], xd = be16(s + 8), yd = be16(s + 10);
                 f->pixel_aspect_ratio = (float)(xd / (double)yd);
                 if (units == 0) f->dpi_y = -1;
@@ -199,47 +208,57 @@ int decode_coeffs(const uint8_t* data, size_t len, gamut_hip_jpeg_frame* f)
             }
             break;
         case 0xDA: {                                           // SOS :1466-1540
-            if (!have_sof) return fail(f, "SOS before SOF");
-            if (n < 1 || s[0] != f->comps || n != f->comps * 2 + 4) return fail(f, "only single-scan baseline files are supported");
-            for (int i = 0; i < f->comps; ++i) {
+            if (!P.have_sof) { fail(f, "SOS before SOF"); return -1; }
+            Scan& sc = P.scan;
+            if (n < 1 || s[0] < 1 || s[0] > f->comps || n != s[0] * 2 + 4) { fail(f, "bad SOS length"); return -1; }
+            sc.ncomp = s[0];
+            for (int i = 0; i < sc.ncomp; ++i) {
                 int ci = 0; while (ci < f->comps && P.comp_id[ci] != s[1 + 2 * i]) ++ci;
-                if (ci >= f->comps) return fail(f, "bad SOS component id");
+                if (ci >= f->comps) { fail(f, "bad SOS component id"); return -1; }
+                sc.comp[i] = ci;
                 P.td[ci] = (s[2 + 2 * i] >> 4) & 15; P.ta[ci] = (s[2 + 2 * i] & 15) + 4;
-                if (P.td[ci] >= 4 || P.ta[ci] >= 8) return fail(f, "bad Huffman table selector");
+                if (P.td[ci] >= 4 || P.ta[ci] >= 8) { fail(f, "bad Huffman table selector"); return -1; }
             }
-            scan = data + pos + seg;
-        } break;
+            const uint8_t* t = s + 1 + 2 * sc.ncomp;
+            sc.ss = t[0]; sc.se = t[1]; sc.ah = t[2] >> 4; sc.al = t[2] & 15;
+            if (!P.progressive) { sc.ss = 0; sc.se = 63; }
+            pos += (size_t)seg;
+            return 0xDA;
+        }
         default: break;                                        // APPn / COM / unknown: skipped (:1826-1846)
         }
         pos += (size_t)seg;
     }
+}
 
+// process_restart :2335-2402: the entropy reader stopped at the marker; step over the expected RSTn
+bool resync(BitReader& br, int& expect_rst)
+{
+    const uint8_t* q = br.p;
+    while (q + 1 < br.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) ++q;
+    if (q + 1 >= br.end || q[1] != 0xD0 + expect_rst) return false;
+    br.restart(q + 2);
+    expect_rst = (expect_rst + 1) & 7;
+    return true;
+}
+
+// ---- sequential frames: one interleaved scan (decode_next_row :2405-2525) --------------------------------------
+int decode_baseline(Parser& P, gamut_hip_jpeg_frame* f, const int* order, int nb, size_t nmcu)
+{
+    if (P.scan.ncomp != f->comps) return fail(f, "only single-scan baseline files are supported");
     for (int c = 0; c < f->comps; ++c) {                       // check_quant_tables / check_huff_tables :2990-3034
         if (!P.quant_def[P.tq[c]]) return fail(f, "undefined quant table");
         if (!P.huff[P.td[c]].defined || !P.huff[P.ta[c]].defined) return fail(f, "undefined Huffman table");
     }
-
-    int order[6], nb = 0;                                      // calc_mcu_block_order :3076-3088
-    if (f->comps == 1) order[nb++] = 0;
-    else for (int c = 0; c < 3; ++c) for (int i = 0; i < P.hs[c] * P.vs[c]; ++i) order[nb++] = c;
-
-    const size_t nmcu = (size_t)f->mcus_per_row * f->mcus_per_col, nblk = nmcu * nb;
-    f->coeffs  = (int16_t*)calloc(nblk * 64, sizeof(int16_t));
-    f->max_zag = (uint8_t*)malloc(nblk ? nblk : 1);
-    if (!f->coeffs || !f->max_zag) { fail(f, "out of memory"); return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: out of memory"); }
-
-    BitReader br(scan, data + len);
+    BitReader br(P.data + P.pos, P.data + P.len);
     uint32_t pred[3] = { 0, 0, 0 };
     int until_restart = P.restart_interval, expect_rst = 0;
     int16_t* blk = f->coeffs; uint8_t* mz = f->max_zag;
     for (size_t mcu = 0; mcu < nmcu; ++mcu) {
-        if (P.restart_interval && until_restart == 0) {        // process_restart :2335-2402
-            const uint8_t* q = br.p;
-            while (q + 1 < br.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) ++q;
-            if (q + 1 >= br.end || q[1] != 0xD0 + expect_rst) return fail(f, "bad restart marker");
-            br.restart(q + 2);
+        if (P.restart_interval && until_restart == 0) {
+            if (!resync(br, expect_rst)) return fail(f, "bad restart marker");
             pred[0] = pred[1] = pred[2] = 0;
-            until_restart = P.restart_interval; expect_rst = (expect_rst + 1) & 7;
+            until_restart = P.restart_interval;
         }
         for (int b = 0; b < nb; ++b, blk += 64, ++mz) {
             const int c = order[b];
@@ -271,6 +290,221 @@ int decode_coeffs(const uint8_t* data, size_t len, gamut_hip_jpeg_frame* f)
     return GAMUT_HIP_OK;
 }
 
+// ---- progressive frames (init_progressive :3585-3664) ---------------------------------------------------------
+// Every component owns a plane of 64-coefficient blocks (natural order, not yet de-quantised) covering the padded
+// MCU grid; DC and AC share a block (the reference's separate 1x1 DC buffer is merged back in load_next_row
+// :2280-2284, and AC scans never touch coefficient 0).  Scans accumulate into the planes; afterwards the planes are
+// gathered into the same MCU-ordered dense form the baseline path produces.
+struct Plane { int16_t* blk = nullptr; int bw = 0, bh = 0; int16_t* at(int bx, int by) const { return blk + ((size_t)by * bw + bx) * 64; } };
+
+struct Progressive {
+    Parser& P; gamut_hip_jpeg_frame* f;
+    Plane plane[3];
+    BitReader br; uint32_t pred[3] = { 0, 0, 0 }; int eobrun = 0;
+    Progressive(Parser& p, gamut_hip_jpeg_frame* fr) : P(p), f(fr), br(nullptr, nullptr) {}
+    ~Progressive() { for (Plane& pl : plane) free(pl.blk); }
+
+    inline int bit() { if (br.nbits < 1) br.refill(); const int v = (int)br.peek(1); br.drop(1); return v; }
+    inline int bits(int n) { if (!n) return 0; if (br.nbits < n) br.refill(); const int v = (int)br.peek(n); br.drop(n); return v; }
+
+    bool dc_first(int c, int16_t* b)                     // decode_block_dc_first :3298-3319
+    {
+        const int s = br.decode(P.huff[P.td[c]]);
+        if (s < 0) return false;
+        const int v = br.receive_extend(s & 15) + (int)pred[c];
+        pred[c] = (uint32_t)v;
+        b[0] = (int16_t)((uint32_t)v << P.scan.al);
+        return true;
+    }
+    bool dc_refine(int, int16_t* b)                      // decode_block_dc_refine :3321-3333
+    {
+        if (bit()) b[0] = (int16_t)(b[0] | (1 << P.scan.al));
+        return true;
+    }
+    bool ac_first(int c, int16_t* b)                     // decode_block_ac_first :3335-3398
+    {
+        if (eobrun) { --eobrun; return true; }
+        const HuffTable& ac = P.huff[P.ta[c]];
+        for (int k = P.scan.ss; k <= P.scan.se; ++k) {
+            const int rs = br.decode(ac);
+            if (rs < 0) return false;
+            const int run = rs >> 4, size = rs & 15;
+            if (size) {
+                if ((k += run) > 63) return false;
+                b[kZag[k]] = (int16_t)((uint32_t)br.receive_extend(size) << P.scan.al);
+            } else if (run == 15) {
+                if ((k += 15) > 63) return false;
+            } else {                                     // EOBn: this block and the next eobrun blocks end here
+                eobrun = (1 << run) + bits(run) - 1;
+                break;
+            }
+        }
+        return true;
+    }
+    inline void correct(int16_t& coef, int plus, int minus)      // one correction bit for a coefficient with history
+    {
+        if (bit() && (coef & plus) == 0) coef = (int16_t)(coef + (coef >= 0 ? plus : minus));
+    }
+    bool ac_refine(int c, int16_t* b)                    // decode_block_ac_refine :3400-3518
+    {
+        const int plus = 1 << P.scan.al, minus = (int)(0xFFFFFFFFu << P.scan.al);
+        const HuffTable& ac = P.huff[P.ta[c]];
+        int k = P.scan.ss;
+        if (eobrun == 0) {
+            while (k <= P.scan.se) {
+                const int rs = br.decode(ac);
+                if (rs < 0) return false;
+                int run = rs >> 4; const int size = rs & 15;
+                int fresh = 0;                           // value of the newly non-zero coefficient, if any
+                if (size) {
+                    if (size != 1) return false;
+                    fresh = bit() ? plus : minus;
+                } else if (run != 15) {
+                    eobrun = (1 << run) + bits(run);
+                    break;
+                }
+                // skip `run` coefficients that are still zero, correcting every non-zero one passed on the way
+                for (; k <= P.scan.se; ++k) {
+                    int16_t& coef = b[kZag[k]];
+                    if (coef) correct(coef, plus, minus);
+                    else { if (run == 0) break; --run; }
+                }
+                if (fresh && k < 64) b[kZag[k]] = (int16_t)fresh;
+                ++k;
+            }
+        }
+        if (eobrun > 0) {
+            for (; k <= P.scan.se; ++k) { int16_t& coef = b[kZag[k]]; if (coef) correct(coef, plus, minus); }
+            --eobrun;
+        }
+        return true;
+    }
+
+    // decode_scan :3521-3582.  Interleaved scans walk the frame's MCU grid; a single-component scan walks that
+    // component's own blocks (ceil of its sampled size, calc_mcu_block_order :3052-3066), row by row.
+    template <class Fn> bool run_scan(Fn fn)
+    {
+        const Scan& sc = P.scan;
+        int until_restart = P.restart_interval, expect_rst = 0;
+        auto boundary = [&]() -> bool {
+            if (P.restart_interval && until_restart == 0) {
+                if (!resync(br, expect_rst)) return false;
+                pred[0] = pred[1] = pred[2] = 0; eobrun = 0;
+                until_restart = P.restart_interval;
+            }
+            return true;
+        };
+        if (sc.ncomp == 1) {
+            const int c = sc.comp[0];
+            int max_h = 1, max_v = 1;
+            for (int i = 0; i < f->comps; ++i) { if (P.hs[i] > max_h) max_h = P.hs[i]; if (P.vs[i] > max_v) max_v = P.vs[i]; }
+            const int nbx = ((f->width  * P.hs[c] + max_h - 1) / max_h + 7) / 8;
+            const int nby = ((f->height * P.vs[c] + max_v - 1) / max_v + 7) / 8;
+            if (nbx > plane[c].bw || nby > plane[c].bh) return false;
+            for (int by = 0; by < nby; ++by)
+                for (int bx = 0; bx < nbx; ++bx) {
+                    if (!boundary()) return false;
+                    if (!fn(c, plane[c].at(bx, by))) return false;
+                    --until_restart;
+                }
+        } else {
+            for (int my = 0; my < f->mcus_per_col; ++my)
+                for (int mx = 0; mx < f->mcus_per_row; ++mx) {
+                    if (!boundary()) return false;
+                    for (int i = 0; i < sc.ncomp; ++i) {
+                        const int c = sc.comp[i];
+                        for (int v = 0; v < P.vs[c]; ++v)
+                            for (int h = 0; h < P.hs[c]; ++h)
+                                if (!fn(c, plane[c].at(mx * P.hs[c] + h, my * P.vs[c] + v))) return false;
+                    }
+                    --until_restart;
+                }
+        }
+        return true;
+    }
+
+    int run(const int* order, int nb)
+    {
+        for (int c = 0; c < f->comps; ++c) {
+            plane[c].bw = f->mcus_per_row * P.hs[c]; plane[c].bh = f->mcus_per_col * P.vs[c];
+            plane[c].blk = (int16_t*)calloc((size_t)plane[c].bw * plane[c].bh * 64, sizeof(int16_t));
+            if (!plane[c].blk) { fail(f, "out of memory"); return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: out of memory"); }
+        }
+        for (int marker = 0xDA; marker == 0xDA; ) {
+            const Scan& sc = P.scan;
+            const bool dc_scan = sc.ss == 0, refine = sc.ah != 0;
+            if (sc.ss > sc.se || sc.se > 63 || (dc_scan && sc.se != 0)) return fail(f, "bad SOS spectral selection");
+            if (!dc_scan && sc.ncomp != 1) return fail(f, "AC scans can only contain one component");
+            if (refine && sc.al != sc.ah - 1) return fail(f, "bad SOS successive approximation");
+            for (int i = 0; i < sc.ncomp; ++i) {
+                const int c = sc.comp[i];
+                if (!P.quant_def[P.tq[c]]) return fail(f, "undefined quant table");
+                if (dc_scan ? (!refine && !P.huff[P.td[c]].defined) : !P.huff[P.ta[c]].defined) return fail(f, "undefined Huffman table");
+            }
+            br = BitReader(P.data + P.pos, P.data + P.len);
+            pred[0] = pred[1] = pred[2] = 0; eobrun = 0;
+            bool ok;
+            if (dc_scan) ok = refine ? run_scan([&](int c, int16_t* b) { return dc_refine(c, b); }) : run_scan([&](int c, int16_t* b) { return dc_first(c, b); });
+            else         ok = refine ? run_scan([&](int c, int16_t* b) { return ac_refine(c, b); }) : run_scan([&](int c, int16_t* b) { return ac_first(c, b); });
+            if (!ok) return fail(f, "decode error in a progressive scan");
+            P.pos = (size_t)(br.p - P.data);                   // the reader never steps over a marker
+            marker = next_scan(P, f);
+            if (marker < 0) return GAMUT_HIP_ERR_DECODE;
+        }
+        // load_next_row :2259-2333: per block, last non-zero coefficient in zig-zag order + 1, then de-quantise
+        int16_t* dst = f->coeffs; uint8_t* mz = f->max_zag;
+        for (int my = 0; my < f->mcus_per_col; ++my)
+            for (int mx = 0; mx < f->mcus_per_row; ++mx)
+                for (int b = 0, within = 0; b < nb; ++b, dst += 64, ++mz) {
+                    const int c = order[b];
+                    within = (b > 0 && order[b - 1] == c) ? within + 1 : 0;
+                    const int16_t* src = plane[c].at(mx * P.hs[c] + within % P.hs[c], my * P.vs[c] + within / P.hs[c]);
+                    const int16_t* q = P.quant[P.tq[c]];
+                    int last = 63;
+                    while (last > 0 && src[kZag[last]] == 0) --last;
+                    *mz = (uint8_t)(last + 1);
+                    for (int k = 0; k <= last; ++k) {
+                        const int16_t v = src[kZag[k]];
+                        if (v) dst[kZag[k]] = (int16_t)((uint32_t)(int32_t)v * (uint32_t)(int32_t)q[k]);
+                    }
+                }
+        return GAMUT_HIP_OK;
+    }
+};
+
+int decode_coeffs(const uint8_t* data, size_t len, gamut_hip_jpeg_frame* f)
+{
+    memset(f, 0, sizeof(*f));
+    f->pixel_aspect_ratio = -1; f->dpi_y = -1;
+    if (!data || len < 4 || data[0] != 0xFF || data[1] != 0xD8) return fail(f, "not a JPEG (no SOI)");
+
+    Parser* ps = new (std::nothrow) Parser();
+    if (!ps) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: out of memory");
+    struct Guard { Parser* p; ~Guard() { delete p; } } guard{ ps };
+    Parser& P = *ps;
+    P.data = data; P.len = len; P.pos = 2;
+
+    const int first = next_scan(P, f);
+    if (first < 0) return GAMUT_HIP_ERR_DECODE;
+    if (first != 0xDA) return fail(f, "no SOS marker");
+
+    int order[6], nb = 0;                                      // calc_mcu_block_order :3076-3088 (frame-interleaved)
+    if (f->comps == 1) order[nb++] = 0;
+    else for (int c = 0; c < 3; ++c) for (int i = 0; i < P.hs[c] * P.vs[c]; ++i) order[nb++] = c;
+
+    const size_t nmcu = (size_t)f->mcus_per_row * f->mcus_per_col, nblk = nmcu * nb;
+    f->coeffs  = (int16_t*)calloc(nblk * 64, sizeof(int16_t));
+    f->max_zag = (uint8_t*)malloc(nblk ? nblk : 1);
+    if (!f->coeffs || !f->max_zag) { fail(f, "out of memory"); return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: out of memory"); }
+
+    if (!P.progressive) return decode_baseline(P, f, order, nb, nmcu);
+    Progressive* pg = new (std::nothrow) Progressive(P, f);
+    if (!pg) { fail(f, "out of memory"); return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: out of memory"); }
+    const int rc = pg->run(order, nb);
+    delete pg;
+    return rc;
+}
+
 } // namespace
 } // namespace gamut
 
@@ -283,6 +517,43 @@ int gamut_hip_jpeg_decode_coeffs(const uint8_t* data, size_t len, gamut_hip_jpeg
     clear_error();
     if (!out) return set_error(GAMUT_HIP_ERR_INVALID_ARG, "jpeg_decode_coeffs: null frame");
     return decode_coeffs(data, len, out);
+}
+
+int gamut_hip_jpeg_decode_coeffs_batch(const uint8_t* const* data, const size_t* len, int count,
+                                       gamut_hip_jpeg_frame* out, int* status, int threads)
+{
+    clear_error();
+    if (count < 0 || (count > 0 && (!data || !len || !out)))
+        return set_error(GAMUT_HIP_ERR_INVALID_ARG, "jpeg_decode_coeffs_batch: bad arguments");
+    if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+    if (threads < 1) threads = 1;
+    if (threads > count) threads = count;
+    // images are independent: workers pull the next index; every worker keeps the message of its lowest failing image
+    std::atomic<int> next{ 0 };
+    struct Failure { int index = INT32_MAX, code = GAMUT_HIP_OK; char msg[256] = { 0 }; };
+    std::vector<Failure> fails((size_t)(threads > 0 ? threads : 1));
+    auto work = [&](int tid) {
+        for (int i; (i = next.fetch_add(1, std::memory_order_relaxed)) < count; ) {
+            const int rc = decode_coeffs(data[i], len[i], &out[i]);
+            if (status) status[i] = rc;
+            if (rc != GAMUT_HIP_OK && i < fails[tid].index) {
+                fails[tid].index = i; fails[tid].code = rc;
+                snprintf(fails[tid].msg, sizeof(fails[tid].msg), "%s", last_error_buf());       // this worker thread's message
+            }
+        }
+    };
+    if (threads <= 1) { if (count > 0) work(0); }
+    else {
+        std::vector<std::thread> pool;
+        pool.reserve((size_t)threads - 1);
+        for (int t = 1; t < threads; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (std::thread& th : pool) th.join();
+    }
+    const Failure* first = nullptr;
+    for (const Failure& fl : fails) if (fl.code != GAMUT_HIP_OK && (!first || fl.index < first->index)) first = &fl;
+    if (!first) { clear_error(); return GAMUT_HIP_OK; }
+    return set_error(first->code, "image %d: %s", first->index, first->msg);
 }
 
 void gamut_hip_jpeg_frame_free(gamut_hip_jpeg_frame* f)

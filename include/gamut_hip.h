@@ -136,8 +136,9 @@ int gamut_hip_jpeg_reconstruct_batch_device(const int16_t* coeffs, int64_t coeff
                                             int width, int height, int scan_type, int out_comps,
                                             int count, void* stream);
 
-/* host-side feeder: baseline (SOF0/SOF1) entropy decode of one file into the
- * dense form above (jpegload.d:1160-1848 markers, :2405-2525 decode).
+/* host-side feeder: entropy decode of one file into the dense form above --
+ * baseline SOF0/SOF1 (jpegload.d:1160-1848 markers, :2405-2525 decode_next_row) and
+ * progressive SOF2 (:3296-3664 scans into coefficient planes, :2259-2333 hand-over).
  * The frame's buffers are malloc'd; release with gamut_hip_jpeg_frame_free. */
 typedef struct gamut_hip_jpeg_frame {
     int32_t  width, height, comps, scan_type;
@@ -148,6 +149,12 @@ typedef struct gamut_hip_jpeg_frame {
 } gamut_hip_jpeg_frame;
 int  gamut_hip_jpeg_decode_coeffs(const uint8_t* data, size_t len, gamut_hip_jpeg_frame* out);
 void gamut_hip_jpeg_frame_free(gamut_hip_jpeg_frame* f);
+/* the same for `count` independent files on up to `threads` host threads (<= 0: one per hardware thread).  The reference
+ * decodes one image at a time (the serial Huffman stage is what bounds a batch once the GPU stages
+ * run at HBM speed).  status[i] (may be NULL) receives image i's status and out[i] its frame (zeroed on failure);
+ * returns GAMUT_HIP_OK when every image decoded, otherwise the status of the lowest-numbered failing image. */
+int  gamut_hip_jpeg_decode_coeffs_batch(const uint8_t* const* data, const size_t* len, int count,
+                                        gamut_hip_jpeg_frame* out, int* status, int threads);
 
 /* drop-in for decompress_jpeg_image_from_stream (jpegload.d:3720-3723) on a
  * memory buffer: host entropy decode, GPU reconstruction, malloc'd

@@ -271,7 +271,7 @@ static int frame_geometry(orc_jpeg_frame* f, const int h_samp[3], const int v_sa
     return 0;
 }
 
-/* ---- baseline entropy decoder (feeder) ----------------------------------- */
+/* ---- entropy decoder (feeder): baseline and progressive ------------------- */
 typedef struct {
     int      present;
     uint8_t  num[17];
@@ -350,75 +350,77 @@ static inline int huff_extend(int x, int s) { return (s && x < (1 << (s - 1))) ?
 
 static inline int rd16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
 
-int orc_jpeg_decode_coeffs(const uint8_t* data, size_t len, orc_jpeg_frame* f)
+/* decoder state across markers and scans (the members of jpeg_decoder the feeder needs, :401-520) */
+typedef struct {
+    const uint8_t* data; size_t len, pos;
+    int16_t  quant[4][64]; int quant_present[4];
+    hufftab* huff;                                       /* 0-3 DC, 4-7 AC (:1247) */
+    int comp_id[3], h_samp[3], v_samp[3], comp_quant[3], comp_dc[3], comp_ac[3];
+    int restart_interval, have_sof, progressive;
+    int comps_in_scan, comp_list[3], spectral_start, spectral_end, successive_low, successive_high;   /* read_sos_marker */
+} jstate;
+
+/* process_markers (:1578-1848) up to and including the next SOS (read_sos_marker :1466-1540).
+   Returns 0xDA with S->pos at the first entropy-coded byte, 0xD9 at EOI / end of data, -1 on error. */
+static int scan_header(jstate* S, orc_jpeg_frame* f)
 {
-    memset(f, 0, sizeof(*f));
-    f->pixel_aspect_ratio = -1; f->dpi_y = -1;
-    if (len < 4 || data[0] != 0xFF || data[1] != 0xD8) return -1;
-
-    int16_t quant[4][64]; int quant_present[4] = {0,0,0,0};
-    hufftab* huff = (hufftab*)calloc(8, sizeof(hufftab));   /* 0-3 DC, 4-7 AC (:1247) */
-    int comp_id[3] = {0,0,0}, h_samp[3] = {0,0,0}, v_samp[3] = {0,0,0}, comp_quant[3] = {0,0,0};
-    int comp_dc[3] = {0,0,0}, comp_ac[3] = {0,0,0};
-    int restart_interval = 0, have_sof = 0, rc = -1;
-    size_t pos = 2;
-    if (!huff) return -1;
-
+    const uint8_t* data = S->data; const size_t len = S->len;
     for (;;) {
         /* next_marker :1544-1572 */
-        while (pos < len && data[pos] != 0xFF) pos++;
-        while (pos < len && data[pos] == 0xFF) pos++;
-        if (pos >= len) goto done;
-        const int m = data[pos++];
+        while (S->pos < len && data[S->pos] != 0xFF) S->pos++;
+        while (S->pos < len && data[S->pos] == 0xFF) S->pos++;
+        if (S->pos >= len) return 0xD9;
+        const int m = data[S->pos++];
         if (m == 0) continue;
         if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
-        if (m == 0xD9) goto done;
-        if (pos + 2 > len) goto done;
-        const int seglen = rd16(data + pos);
-        if (seglen < 2 || pos + (size_t)seglen > len) goto done;
-        const uint8_t* s = data + pos + 2; int n = seglen - 2;
+        if (m == 0xD9) return 0xD9;
+        if (S->pos + 2 > len) return -1;
+        const int seglen = rd16(data + S->pos);
+        if (seglen < 2 || S->pos + (size_t)seglen > len) return -1;
+        const uint8_t* s = data + S->pos + 2; int n = seglen - 2;
         if (m == 0xDB) {                                 /* DQT :1274-1346 */
             while (n > 0) {
                 const int pq = s[0] >> 4, tq = s[0] & 15; s++; n--;
-                if (tq >= 4 || n < (pq ? 128 : 64)) goto done;
+                if (tq >= 4 || n < (pq ? 128 : 64)) return -1;
                 for (int i = 0; i < 64; ++i) {
                     u32 t = *s++;
                     if (pq) t = (t << 8) + *s++;
-                    quant[tq][i] = (int16_t)t;            /* jpgd_quant_t = short :409,1328 */
+                    S->quant[tq][i] = (int16_t)t;         /* jpgd_quant_t = short :409,1328 */
                 }
-                n -= pq ? 128 : 64; quant_present[tq] = 1;
+                n -= pq ? 128 : 64; S->quant_present[tq] = 1;
             }
         } else if (m == 0xC4) {                          /* DHT :1173-1270 */
             while (n > 0) {
                 int index = s[0]; s++; n--;
-                if (n < 16) goto done;
+                if (n < 16) return -1;
                 index = (index & 0x0F) + ((index & 0x10) >> 4) * 4;
-                if (index >= 8) goto done;
-                hufftab* h = &huff[index];
+                if (index >= 8) return -1;
+                hufftab* h = &S->huff[index];
                 int count = 0; h->num[0] = 0;
                 for (int i = 1; i <= 16; ++i) { h->num[i] = s[i - 1]; count += s[i - 1]; }
                 s += 16; n -= 16;
-                if (count > 255 || n < count) goto done;
+                if (count > 255 || n < count) return -1;
                 memset(h->val, 0, 256); memcpy(h->val, s, (size_t)count);
                 s += count; n -= count;
                 h->present = 1; huff_build(h);
             }
-        } else if (m == 0xC0 || m == 0xC1) {             /* SOF0/SOF1 :1349-1417 */
-            if (n < 6 || s[0] != 8) goto done;
+        } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) { /* SOF0/SOF1/SOF2 :1349-1417, :1596-1607 */
+            if (S->have_sof) return -1;
+            if (n < 6 || s[0] != 8) return -1;
             f->height = rd16(s + 1); f->width = rd16(s + 3); f->comps = s[5];
-            if (f->height < 1 || f->height > 16384 || f->width < 1 || f->width > 16384) goto done;
-            if ((f->comps != 1 && f->comps != 3) || n != f->comps * 3 + 6) goto done;
+            if (f->height < 1 || f->height > 16384 || f->width < 1 || f->width > 16384) return -1;
+            if ((f->comps != 1 && f->comps != 3) || n != f->comps * 3 + 6) return -1;
             for (int i = 0; i < f->comps; ++i) {
-                comp_id[i] = s[6 + 3*i]; h_samp[i] = s[7 + 3*i] >> 4; v_samp[i] = s[7 + 3*i] & 15; comp_quant[i] = s[8 + 3*i];
-                if (comp_quant[i] >= 4) goto done;
+                S->comp_id[i] = s[6 + 3*i]; S->h_samp[i] = s[7 + 3*i] >> 4; S->v_samp[i] = s[7 + 3*i] & 15; S->comp_quant[i] = s[8 + 3*i];
+                if (S->comp_quant[i] >= 4) return -1;
             }
-            if (frame_geometry(f, h_samp, v_samp)) goto done;
-            have_sof = 1;
-        } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
-            goto done;                                   /* progressive / lossless / arithmetic: not in this feeder */
+            if (frame_geometry(f, S->h_samp, S->v_samp)) return -1;
+            S->have_sof = 1; S->progressive = (m == 0xC2);
+        } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8) {
+            return -1;                                   /* lossless / hierarchical / arithmetic: rejected like :1608-1628 */
         } else if (m == 0xDD) {                          /* DRI :1445-1462 */
-            if (seglen != 4) goto done;
-            restart_interval = rd16(s);
+            if (seglen != 4) return -1;
+            S->restart_interval = rd16(s);
         } else if (m == 0xE0) {                          /* APP0 JFIF density */
             if (n >= 14 && !memcmp(s, "JFIF\0", 5)) {
                 /* :1636-1672 */
@@ -429,55 +431,215 @@ int orc_jpeg_decode_coeffs(const uint8_t* data, size_t len, orc_jpeg_frame* f)
                 else if (unit == 2) f->dpi_y = (yd * 100.0f) / 39.37007874f;
             }
         } else if (m == 0xDA) {                          /* SOS :1466-1540 */
-            if (!have_sof || n < 1) goto done;
+            if (!S->have_sof || n < 1) return -1;
             const int ns = s[0];
-            if (ns != f->comps || n != ns * 2 + 4) goto done;   /* interleaved single scan only */
+            if (ns < 1 || ns > f->comps || n != ns * 2 + 4) return -1;
             for (int i = 0; i < ns; ++i) {
-                int ci; for (ci = 0; ci < f->comps; ++ci) if (s[1 + 2*i] == comp_id[ci]) break;
-                if (ci >= f->comps) goto done;
-                comp_dc[ci] = (s[2 + 2*i] >> 4) & 15; comp_ac[ci] = (s[2 + 2*i] & 15) + 4;
-                if (comp_dc[ci] >= 4 || comp_ac[ci] >= 8) goto done;
+                int ci; for (ci = 0; ci < f->comps; ++ci) if (s[1 + 2*i] == S->comp_id[ci]) break;
+                if (ci >= f->comps) return -1;
+                S->comp_list[i] = ci;
+                S->comp_dc[ci] = (s[2 + 2*i] >> 4) & 15; S->comp_ac[ci] = (s[2 + 2*i] & 15) + 4;
+                if (S->comp_dc[ci] >= 4 || S->comp_ac[ci] >= 8) return -1;
             }
-            pos += (size_t)seglen;
+            S->comps_in_scan = ns;
+            S->spectral_start = s[1 + 2*ns]; S->spectral_end = s[2 + 2*ns];
+            S->successive_high = s[3 + 2*ns] >> 4; S->successive_low = s[3 + 2*ns] & 15;
+            if (!S->progressive) { S->spectral_start = 0; S->spectral_end = 63; }
+            S->pos += (size_t)seglen;
+            return 0xDA;
+        }
+        S->pos += (size_t)seglen;
+    }
+}
+
+/* process_restart :2335-2402: resynchronise on the expected RSTn */
+static int restart(bitreader* br, int* next_restart)
+{
+    const uint8_t* q = br->p;
+    while (q + 1 < br->end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) q++;
+    if (q + 1 >= br->end || q[1] != 0xD0 + *next_restart) return -1;
+    br->p = q + 2; br->bitbuf = 0; br->bits = 0; br->hit_marker = 0;
+    *next_restart = (*next_restart + 1) & 7;
+    return 0;
+}
+
+/* ---- progressive frames (:3296-3683) ------------------------------------------------------------------------
+   One 64-coefficient block per (component, block_x, block_y) in natural order: the reference keeps DC in a 1x1
+   coeff_buf and AC in an 8x8 one and merges them in load_next_row (:2280-2284); AC scans never touch index 0
+   (spectral_start >= 1, :3633-3646), so a single block holds both. */
+typedef struct { int16_t* blk; int bw, bh; } cplane;        /* coeff_buf :3274-3294, block dims = max_mcus * samp (:3601-3604) */
+
+typedef struct { jstate* S; bitreader br; cplane pl[3]; u32 last_dc[3]; int eob_run; } pstate;
+
+static int dc_first(pstate* P, int c, int16_t* p)            /* decode_block_dc_first :3298-3319 */
+{
+    int s = huff_decode(&P->br, &P->S->huff[P->S->comp_dc[c]]);
+    if (s < 0) return -1;
+    if (s != 0) { const int r = (int)br_get(&P->br, s & 15); s = huff_extend(r, s & 15); }
+    P->last_dc[c] = (u32)(s += (int)P->last_dc[c]);
+    p[0] = (int16_t)wshl(s, P->S->successive_low);
+    return 0;
+}
+static int dc_refine(pstate* P, int c, int16_t* p)           /* decode_block_dc_refine :3321-3333 */
+{
+    (void)c;
+    if (br_get(&P->br, 1)) p[0] = (int16_t)(p[0] | (1 << P->S->successive_low));
+    return 0;
+}
+static int ac_first(pstate* P, int c, int16_t* p)            /* decode_block_ac_first :3335-3398 */
+{
+    if (P->eob_run) { P->eob_run--; return 0; }
+    for (int k = P->S->spectral_start; k <= P->S->spectral_end; k++) {
+        int s = huff_decode(&P->br, &P->S->huff[P->S->comp_ac[c]]);
+        if (s < 0) return -1;
+        int r = s >> 4; s &= 15;
+        if (s) {
+            if ((k += r) > 63) return -1;
+            r = (int)br_get(&P->br, s);
+            s = huff_extend(r, s);
+            p[g_ZAG[k]] = (int16_t)wshl(s, P->S->successive_low);
+        } else if (r == 15) {
+            if ((k += 15) > 63) return -1;
+        } else {
+            P->eob_run = 1 << r;
+            if (r) P->eob_run += (int)br_get(&P->br, r);
+            P->eob_run--;
             break;
         }
-        pos += (size_t)seglen;
     }
+    return 0;
+}
+static void refine_nonzero(pstate* P, int16_t* coef, int p1, int m1)   /* the correction-bit step shared by :3457-3472 and :3498-3511 */
+{
+    if (br_get(&P->br, 1)) {
+        if ((*coef & p1) == 0) *coef = (int16_t)(*coef >= 0 ? *coef + p1 : *coef + m1);
+    }
+}
+static int ac_refine(pstate* P, int c, int16_t* p)           /* decode_block_ac_refine :3400-3518 */
+{
+    const int p1 = 1 << P->S->successive_low, m1 = (int)(((u32)-1) << P->S->successive_low);
+    int k = P->S->spectral_start;
+    if (P->eob_run == 0) {
+        for (; k <= P->S->spectral_end; k++) {
+            int s = huff_decode(&P->br, &P->S->huff[P->S->comp_ac[c]]);
+            if (s < 0) return -1;
+            int r = s >> 4; s &= 15;
+            if (s) {
+                if (s != 1) return -1;
+                s = br_get(&P->br, 1) ? p1 : m1;
+            } else if (r != 15) {
+                P->eob_run = 1 << r;
+                if (r) P->eob_run += (int)br_get(&P->br, r);
+                break;
+            }
+            do {
+                int16_t* coef = p + g_ZAG[k & 63];
+                if (*coef != 0) refine_nonzero(P, coef, p1, m1);
+                else if (--r < 0) break;
+                k++;
+            } while (k <= P->S->spectral_end);
+            if (s && k < 64) p[g_ZAG[k]] = (int16_t)s;
+        }
+    }
+    if (P->eob_run > 0) {
+        for (; k <= P->S->spectral_end; k++) {
+            int16_t* coef = p + g_ZAG[k & 63];
+            if (*coef != 0) refine_nonzero(P, coef, p1, m1);
+        }
+        P->eob_run--;
+    }
+    return 0;
+}
 
-    {
-        /* check tables :2990-3034 */
-        int mcu_org[6], nb = 0;
-        if (f->comps == 1) mcu_org[nb++] = 0;
-        else for (int c = 0; c < 3; ++c) for (int k = 0; k < h_samp[c] * v_samp[c]; ++k) mcu_org[nb++] = c;  /* :3076-3088 */
-        for (int c = 0; c < f->comps; ++c)
-            if (!quant_present[comp_quant[c]] || !huff[comp_dc[c]].present || !huff[comp_ac[c]].present) goto done;
+/* decode_scan :3521-3582 with calc_mcu_block_order's scan geometry (:3038-3090) */
+static int progressive_scan(pstate* P, const orc_jpeg_frame* f, int (*fn)(pstate*, int, int16_t*))
+{
+    const jstate* S = P->S;
+    int max_h = 0, max_v = 0, mcu_org[6], nb = 0, mcus_per_row, mcus_per_col;
+    for (int c = 0; c < f->comps; ++c) { if (S->h_samp[c] > max_h) max_h = S->h_samp[c]; if (S->v_samp[c] > max_v) max_v = S->v_samp[c]; }
+    if (S->comps_in_scan == 1) {
+        const int c = S->comp_list[0];
+        mcus_per_row = (((f->width  * S->h_samp[c]) + (max_h - 1)) / max_h + 7) / 8;    /* m_comp_h_blocks :3054 */
+        mcus_per_col = (((f->height * S->v_samp[c]) + (max_v - 1)) / max_v + 7) / 8;
+        mcu_org[nb++] = c;
+    } else {
+        mcus_per_row = (((f->width  + 7) / 8) + (max_h - 1)) / max_h;
+        mcus_per_col = (((f->height + 7) / 8) + (max_v - 1)) / max_v;
+        for (int i = 0; i < S->comps_in_scan; ++i) { const int c = S->comp_list[i]; for (int k = 0; k < S->h_samp[c] * S->v_samp[c]; ++k) mcu_org[nb++] = c; }
+    }
+    int restarts_left = S->restart_interval, next_restart = 0;
+    int block_y_mcu[3] = {0, 0, 0};
+    for (int mcu_col = 0; mcu_col < mcus_per_col; ++mcu_col) {
+        int block_x_mcu[3] = {0, 0, 0};
+        for (int mcu_row = 0; mcu_row < mcus_per_row; ++mcu_row) {
+            int xo = 0, yo = 0;
+            if (S->restart_interval && restarts_left == 0) {
+                if (restart(&P->br, &next_restart)) return -1;
+                P->last_dc[0] = P->last_dc[1] = P->last_dc[2] = 0; P->eob_run = 0;
+                restarts_left = S->restart_interval;
+            }
+            for (int b = 0; b < nb; ++b) {
+                const int c = mcu_org[b];
+                const int bx = block_x_mcu[c] + xo, by = block_y_mcu[c] + yo;
+                if (bx >= P->pl[c].bw || by >= P->pl[c].bh) return -1;       /* coeff_buf_getp asserts :3293 */
+                if (fn(P, c, P->pl[c].blk + ((size_t)by * P->pl[c].bw + bx) * 64)) return -1;
+                if (S->comps_in_scan == 1) block_x_mcu[c]++;
+                else if (++xo == S->h_samp[c]) { xo = 0; if (++yo == S->v_samp[c]) { yo = 0; block_x_mcu[c] += S->h_samp[c]; } }
+            }
+            restarts_left--;
+        }
+        if (S->comps_in_scan == 1) block_y_mcu[S->comp_list[0]]++;
+        else for (int i = 0; i < S->comps_in_scan; ++i) block_y_mcu[S->comp_list[i]] += S->v_samp[S->comp_list[i]];
+    }
+    return 0;
+}
 
-        const size_t nmcu = (size_t)f->mcus_per_row * f->mcus_per_col;
-        const size_t nblocks = nmcu * (size_t)nb;
-        f->coeffs  = (int16_t*)calloc(nblocks * 64, sizeof(int16_t));
-        f->max_zag = (uint8_t*)malloc(nblocks ? nblocks : 1);
-        if (!f->coeffs || !f->max_zag) goto done;
+int orc_jpeg_decode_coeffs(const uint8_t* data, size_t len, orc_jpeg_frame* f)
+{
+    memset(f, 0, sizeof(*f));
+    f->pixel_aspect_ratio = -1; f->dpi_y = -1;
+    if (len < 4 || data[0] != 0xFF || data[1] != 0xD8) return -1;
 
-        bitreader br = { data + pos, data + len, 0, 0, 0 };
+    jstate* S = (jstate*)calloc(1, sizeof(jstate));
+    if (!S) return -1;
+    S->huff = (hufftab*)calloc(8, sizeof(hufftab));
+    S->data = data; S->len = len; S->pos = 2;
+    int rc = -1;
+    pstate* P = NULL;
+    if (!S->huff) goto done;
+
+    if (scan_header(S, f) != 0xDA) goto done;
+
+    int mcu_org[6], nb = 0;                                        /* frame-interleaved block order :3076-3088 */
+    if (f->comps == 1) mcu_org[nb++] = 0;
+    else for (int c = 0; c < 3; ++c) for (int k = 0; k < S->h_samp[c] * S->v_samp[c]; ++k) mcu_org[nb++] = c;
+    const size_t nmcu = (size_t)f->mcus_per_row * f->mcus_per_col;
+    const size_t nblocks = nmcu * (size_t)nb;
+    f->coeffs  = (int16_t*)calloc(nblocks * 64, sizeof(int16_t));
+    f->max_zag = (uint8_t*)malloc(nblocks ? nblocks : 1);
+    if (!f->coeffs || !f->max_zag) goto done;
+
+    if (!S->progressive) {
+        /* init_sequential :3666-3677: one interleaved scan carrying every component */
+        if (S->comps_in_scan != f->comps) goto done;
+        for (int c = 0; c < f->comps; ++c)                          /* check tables :2990-3034 */
+            if (!S->quant_present[S->comp_quant[c]] || !S->huff[S->comp_dc[c]].present || !S->huff[S->comp_ac[c]].present) goto done;
+
+        bitreader br = { data + S->pos, data + len, 0, 0, 0 };
         u32 last_dc[3] = {0,0,0};
-        int restarts_left = restart_interval, next_restart = 0;
+        int restarts_left = S->restart_interval, next_restart = 0;
         int16_t* p = f->coeffs; uint8_t* mz = f->max_zag;
 
         for (size_t mcu = 0; mcu < nmcu; ++mcu) {
-            if (restart_interval && restarts_left == 0) {       /* process_restart :2335-2402 */
-                const uint8_t* q = br.p;
-                /* the bit reader may have stopped right at the marker; find FF Dn */
-                while (q + 1 < br.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) q++;
-                if (q + 1 >= br.end || q[1] != 0xD0 + next_restart) goto done;
-                br.p = q + 2; br.bitbuf = 0; br.bits = 0; br.hit_marker = 0;
+            if (S->restart_interval && restarts_left == 0) {       /* process_restart :2335-2402 */
+                if (restart(&br, &next_restart)) goto done;
                 last_dc[0] = last_dc[1] = last_dc[2] = 0;
-                restarts_left = restart_interval;
-                next_restart = (next_restart + 1) & 7;
+                restarts_left = S->restart_interval;
             }
             for (int b = 0; b < nb; ++b, p += 64, ++mz) {       /* decode_next_row :2419-2515 (dense store: no stale data to clear) */
                 const int c = mcu_org[b];
-                const int16_t* q = quant[comp_quant[c]];
-                int s = huff_decode(&br, &huff[comp_dc[c]]);
+                const int16_t* q = S->quant[S->comp_quant[c]];
+                int s = huff_decode(&br, &S->huff[S->comp_dc[c]]);
                 if (s < 0) goto done;
                 int r = (int)br_get(&br, s & 15);
                 s = huff_extend(r, s & 15);
@@ -485,7 +647,7 @@ int orc_jpeg_decode_coeffs(const uint8_t* data, size_t len, orc_jpeg_frame* f)
                 p[0] = (int16_t)wmul(s, q[0]);
                 int k;
                 for (k = 1; k < 64; ++k) {
-                    s = huff_decode(&br, &huff[comp_ac[c]]);
+                    s = huff_decode(&br, &S->huff[S->comp_ac[c]]);
                     if (s < 0) goto done;
                     r = s >> 4; s &= 15;
                     if (s) {
@@ -503,9 +665,57 @@ int orc_jpeg_decode_coeffs(const uint8_t* data, size_t len, orc_jpeg_frame* f)
             restarts_left--;
         }
         rc = 0;
+    } else {
+        /* init_progressive :3585-3664: every scan into the coefficient planes, then load_next_row's hand-over */
+        P = (pstate*)calloc(1, sizeof(pstate));
+        if (!P) goto done;
+        P->S = S;
+        for (int c = 0; c < f->comps; ++c) {
+            P->pl[c].bw = f->mcus_per_row * S->h_samp[c]; P->pl[c].bh = f->mcus_per_col * S->v_samp[c];
+            P->pl[c].blk = (int16_t*)calloc((size_t)P->pl[c].bw * P->pl[c].bh * 64, sizeof(int16_t));
+            if (!P->pl[c].blk) goto done;
+        }
+        for (int marker = 0xDA; marker == 0xDA; ) {
+            const int dc_only = S->spectral_start == 0, refinement = S->successive_high != 0;
+            if (S->spectral_start > S->spectral_end || S->spectral_end > 63) goto done;
+            if (dc_only) { if (S->spectral_end) goto done; }
+            else if (S->comps_in_scan != 1) goto done;             /* AC scans carry one component :3642-3646 */
+            if (refinement && S->successive_low != S->successive_high - 1) goto done;
+            for (int i = 0; i < S->comps_in_scan; ++i) {           /* check_huff_tables :3013-3034 (by scan kind), check_quant_tables */
+                const int c = S->comp_list[i];
+                if (!S->quant_present[S->comp_quant[c]]) goto done;
+                if (dc_only ? (!refinement && !S->huff[S->comp_dc[c]].present) : !S->huff[S->comp_ac[c]].present) goto done;   /* DC refinement reads raw bits only */
+            }
+            P->br.p = data + S->pos; P->br.end = data + len; P->br.bitbuf = 0; P->br.bits = 0; P->br.hit_marker = 0;
+            P->last_dc[0] = P->last_dc[1] = P->last_dc[2] = 0; P->eob_run = 0;                 /* init_scan :3108-3110 */
+            if (progressive_scan(P, f, dc_only ? (refinement ? dc_refine : dc_first) : (refinement ? ac_refine : ac_first))) goto done;
+            S->pos = (size_t)(P->br.p - data);                     /* the reader never steps over a marker */
+            marker = scan_header(S, f);
+            if (marker < 0) goto done;
+        }
+        /* load_next_row :2259-2333 for every MCU row: merge, find the last non-zero coefficient, de-quantise */
+        int16_t* p = f->coeffs; uint8_t* mz = f->max_zag;
+        for (int my = 0; my < f->mcus_per_col; ++my)
+            for (int mx = 0; mx < f->mcus_per_row; ++mx) {
+                int xo = 0, yo = 0, cprev = -1;
+                for (int b = 0; b < nb; ++b, p += 64, ++mz) {
+                    const int c = mcu_org[b];
+                    if (c != cprev) { xo = yo = 0; cprev = c; }
+                    const int bx = mx * S->h_samp[c] + xo, by = my * S->v_samp[c] + yo;
+                    if (++xo == S->h_samp[c]) { xo = 0; ++yo; }
+                    memcpy(p, P->pl[c].blk + ((size_t)by * P->pl[c].bw + bx) * 64, 128);
+                    const int16_t* q = S->quant[S->comp_quant[c]];
+                    int i;
+                    for (i = 63; i > 0; i--) if (p[g_ZAG[i]]) break;
+                    *mz = (uint8_t)(i + 1);
+                    for (; i >= 0; i--) if (p[g_ZAG[i]]) p[g_ZAG[i]] = (int16_t)wmul(p[g_ZAG[i]], q[i]);
+                }
+            }
+        rc = 0;
     }
 done:
-    free(huff);
+    if (P) { for (int c = 0; c < 3; ++c) free(P->pl[c].blk); free(P); }
+    free(S->huff); free(S);
     if (rc) orc_jpeg_frame_free(f);
     return rc;
 }

@@ -71,12 +71,41 @@ def test_jpeg_feeder_matches_oracle(path):
     L.gamut_hip_jpeg_frame_free(C.byref(fr))           # idempotent
 
 
+def test_jpeg_batch_feeder_threads():
+    """gamut_hip_jpeg_decode_coeffs_batch: N independent files on a thread pool == one at a time; a bad file fails alone."""
+    import time
+    L = _capi.lib()
+    blobs = [open(p, "rb").read() for p in JPEGS] * 6 + [b"\xff\xd8garbage"]
+    bufs = [np.frombuffer(b, np.uint8) for b in blobs]
+    n = len(blobs)
+    ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+    lens = (C.c_size_t * n)(*[b.size for b in bufs])
+    for threads in (1, 4, 0):
+        frames = (_capi.JpegFrame * n)()
+        status = (C.c_int * n)()
+        rc = L.gamut_hip_jpeg_decode_coeffs_batch(ptrs, lens, n, frames, status, threads)
+        assert rc == _capi.ERR_DECODE and L.gamut_hip_last_error().startswith(b"image %d:" % (n - 1))
+        assert list(status[:n - 1]) == [0] * (n - 1) and status[n - 1] == _capi.ERR_DECODE and not frames[n - 1].coeffs
+        for i in range(n - 1):
+            d = O.DecodedJpeg(blobs[i])
+            k = frames[i].mcus_per_row * frames[i].mcus_per_col * frames[i].blocks_per_mcu
+            assert np.array_equal(np.ctypeslib.as_array(frames[i].coeffs, (k, 64)), d.coeffs)
+            assert np.array_equal(np.ctypeslib.as_array(frames[i].max_zag, (k,)), d.max_zag)
+            L.gamut_hip_jpeg_frame_free(C.byref(frames[i]))
+    frames = (_capi.JpegFrame * n)()
+    assert L.gamut_hip_jpeg_decode_coeffs_batch(ptrs, lens, n - 1, frames, None, 3) == 0          # all good, no status array
+    for i in range(n - 1):
+        L.gamut_hip_jpeg_frame_free(C.byref(frames[i]))
+    assert L.gamut_hip_jpeg_decode_coeffs_batch(None, None, 0, None, None, 2) == 0
+    assert L.gamut_hip_jpeg_decode_coeffs_batch(None, None, 3, None, None, 2) == _capi.ERR_INVALID_ARG
+
+
 def test_jpeg_feeder_rejects_bad_streams():
     L = _capi.lib()
     fr = _capi.JpegFrame()
     good = open(os.path.join(G, "ref_images", "issue35.jpg"), "rb").read()
     cases = [b"", b"\xff\xd8", b"\x89PNG\r\n\x1a\n" + b"0" * 64, good[:200], good[:4000],
-             good.replace(b"\xff\xc0", b"\xff\xc2", 1)]                                  # progressive SOF: not supported by the GPU feeder
+             good.replace(b"\xff\xc0", b"\xff\xc2", 1)]                                  # baseline scan under a progressive SOF: bad spectral selection
     for data in cases:
         buf = np.frombuffer(data, np.uint8) if data else np.zeros(1, np.uint8)
         rc = L.gamut_hip_jpeg_decode_coeffs(buf.ctypes.data, len(data), C.byref(fr))

@@ -131,6 +131,27 @@ def test_jpeg_golden(path):
         assert np.array_equal(full[0], out)
 
 
+def test_jpeg_progressive_equals_baseline_twin():
+    """SOF2 files (jpegload.d:3296-3664) written from the same pixels and quantisation as a baseline file must decode to
+    the very same de-quantised coefficients (only the entropy coding differs), and to the same pixels; max_zag follows
+    load_next_row's rule (:2286-2290: last non-zero coefficient in zig-zag order, + 1)."""
+    zag = np.array([0,1,8,16,9,2,3,10,17,24,32,25,18,11,4,5,12,19,26,33,40,48,41,34,27,20,13,6,7,14,21,28,35,42,49,56,
+                    57,50,43,36,29,22,15,23,30,37,44,51,58,59,52,45,38,31,39,46,53,60,61,54,47,55,62,63])
+    twins = [(n, m["baseline_twin"]) for n, m in GOLDEN["meta"].items() if "baseline_twin" in m]
+    assert len(twins) >= 6
+    for prog, base in twins:
+        dp = open(os.path.join(G, "jpeg", prog + ".jpg"), "rb").read()
+        db = open(os.path.join(G, "jpeg", base + ".jpg"), "rb").read()
+        assert b"\xff\xc2" in dp and b"\xff\xc2" not in db
+        p, b = O.DecodedJpeg(dp), O.DecodedJpeg(db)
+        assert (p.width, p.height, p.comps, p.scan_type) == (b.width, b.height, b.comps, b.scan_type)
+        assert np.array_equal(p.coeffs, b.coeffs), prog
+        nz = p.coeffs[:, zag] != 0
+        assert np.array_equal(p.max_zag, np.where(nz[:, 1:].any(axis=1), 64 - np.argmax(nz[:, ::-1], axis=1), 1)), prog
+        for rc in (1, 3, 4):
+            assert np.array_equal(O.decompress_jpeg(dp, rc)[0], O.decompress_jpeg(db, rc)[0]), (prog, rc)
+
+
 def test_jpeg_rowfirst_differs_from_libjpeg_order():
     """the reference (jpgd) runs rows first (jpegload.d:335-375); that is NOT libjpeg's result (4967 samples differ on issue35)"""
     d = O.DecodedJpeg(open(os.path.join(G, "ref_images", "issue35.jpg"), "rb").read())

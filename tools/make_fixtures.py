@@ -54,6 +54,15 @@ def main():
         ("s_97x131_gray", 97, 131, dict(quality=85), 7),
         ("s_16x16_420", 16, 16, dict(quality=95, subsampling=2), 8),
         ("s_1x1_444", 1, 1, dict(quality=95, subsampling=0), 9),
+        # progressive twins (SOF2; libjpeg's default script: DC first, AC first, AC refine, DC refine scans) of the files
+        # above: same source pixels and quantisation => the SAME quantised coefficients, only the entropy coding differs
+        ("p_131x97_444", 131, 97, dict(quality=90, subsampling=0, progressive=True), 1),
+        ("p_131x97_422", 131, 97, dict(quality=85, subsampling=1, progressive=True), 2),
+        ("p_131x97_420", 131, 97, dict(quality=75, subsampling=2, progressive=True), 3),
+        ("p_131x97_420_rst", 131, 97, dict(quality=92, subsampling=2, restart_marker_blocks=3, progressive=True), 4),
+        ("p_97x131_gray", 97, 131, dict(quality=85, progressive=True), 7),
+        ("p_16x16_420", 16, 16, dict(quality=95, subsampling=2, progressive=True), 8),
+        ("p_1x1_444", 1, 1, dict(quality=95, subsampling=0, progressive=True), 9),
     ]
     for name, w, h, kw, idx in specs:
         img = gen.synth_rgb(w, h, idx)
@@ -76,6 +85,11 @@ def main():
         d = O.DecodedJpeg(data)
         golden["meta"][name] = dict(width=d.width, height=d.height, comps=d.comps, scan_type=d.scan_type,
                                     bytes=len(data), coeff_sha=sha(d.coeffs), max_zag_sha=sha(d.max_zag))
+        if name.startswith("p_"):
+            assert b"\xff\xc2" in data
+            twin = "s_" + name[2:]
+            assert golden["meta"][twin]["coeff_sha"] == golden["meta"][name]["coeff_sha"], name
+            golden["meta"][name]["baseline_twin"] = twin
         pil = np.array(Image.open(io.BytesIO(data))) if "patched" not in name else None
         if d.scan_type in (O.JPGD_GRAYSCALE, O.JPGD_YH1V1):
             rc = 1 if d.comps == 1 else 3

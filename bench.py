@@ -162,23 +162,25 @@ def main():
         dtype = "f32"
     elif wl == "png" or wl.startswith("png:"):
         import oracle_lib as O
-        policy = wl.split(":")[1] if ":" in wl else "heuristic"
+        parts = wl.split(":")                                  # png[:policy[:channels]]
+        policy = parts[1] if len(parts) > 1 else "heuristic"
+        ch = int(parts[2]) if len(parts) > 2 else 4
         if policy.isdigit():
             policy = int(policy)
         if (args.width, args.height) == (1920, 1080):
             w, h = 3840, 2160
         B = args.batch if args.batch != 1024 else 512
-        raw, sums = synth.png_raw_batch(B, w, h, dev, seed=3 + rank, policy=policy)
+        raw, sums = synth.png_raw_batch(B, w, h, dev, seed=3 + rank, policy=policy, channels=ch)
         raw_len = raw.shape[1]
-        out = torch.empty((B, h * w * 4), dtype=torch.uint8, device=dev)
+        out = torch.empty((B, h * w * ch), dtype=torch.uint8, device=dev)
         status = torch.zeros((B,), dtype=torch.int32, device=dev)
         px_per_step = B * w * h
-        bytes_per_step = B * (raw_len + w * h * 4)             # 33 179 760 + 33 177 600 per 3840x2160 image
+        bytes_per_step = B * (raw_len + w * h * ch)            # 33 179 760 + 33 177 600 per 3840x2160 RGBA8 image
         kernel_name = "k_png_defilter"
-        workload = f"batch {B} x {w}x{h} PNG 8-bit RGBA, post-inflate de-filter ({policy} row filters)"
+        workload = f"batch {B} x {w}x{h} PNG 8-bit {['', 'grey', 'grey+alpha', 'RGB', 'RGBA'][ch]}, post-inflate de-filter ({policy} row filters)"
 
         def step():
-            _capi.check(L.gamut_hip_png_defilter_batch_device(raw.data_ptr(), raw_len, raw_len, out.data_ptr(), w * h * 4, w, h, 4, 4, 8, 6,
+            _capi.check(L.gamut_hip_png_defilter_batch_device(raw.data_ptr(), raw_len, raw_len, out.data_ptr(), w * h * ch, w, h, ch, ch, 8, {1: 0, 2: 4, 3: 2, 4: 6}[ch],
                                                                B, status.data_ptr(), stream))
 
         def check():
@@ -188,7 +190,7 @@ def main():
             got = out.view(B, -1).to(torch.int64).sum(dim=1) if B <= 64 else torch.stack([out[i].to(torch.int64).sum() for i in range(B)])
             if not torch.equal(got, sums):
                 raise SystemExit("PARITY FAILURE: checksum of de-filtered pixels != checksum of the source pixels")
-            exp = O.png_create_image_raw(raw[B - 1].cpu().numpy(), 4, 4, w, h, 8, 6)
+            exp = O.png_create_image_raw(raw[B - 1].cpu().numpy(), ch, ch, w, h, 8, {1: 0, 2: 4, 3: 2, 4: 6}[ch])
             if not np.array_equal(out[B - 1].cpu().numpy(), exp):
                 raise SystemExit("PARITY FAILURE vs oracle")
 
@@ -196,7 +198,7 @@ def main():
             host = [raw[i].cpu().numpy() for i in range(min(B, 8))]
             n, t0 = 0, time.perf_counter()
             while time.perf_counter() - t0 < seconds:
-                O.png_create_image_raw(host[n % len(host)], 4, 4, w, h, 8, 6)
+                O.png_create_image_raw(host[n % len(host)], ch, ch, w, h, 8, {1: 0, 2: 4, 3: 2, 4: 6}[ch])
                 n += 1
             dt = time.perf_counter() - t0
             return n * w * h / dt / 1e6, f"{n} of the batch's {w}x{h} filtered streams, stbi__create_png_image_raw, single thread, {dt:.1f} s"

@@ -103,6 +103,95 @@ __device__ __forceinline__ u32 paeth_bytes(u32 a, u32 b, u32 c)
     return __builtin_amdgcn_perm(pH, pL, 0x06040200u);                                  // low bytes of the four halves
 }
 
+// 4 bytes of the 16-byte piece v[0..3] starting at byte offset O (bytes past the piece read as zero)
+template <int O> __device__ __forceinline__ u32 bytes_at(const u32 (&v)[4])
+{
+    constexpr int k = O >> 2, sh = O & 3;
+    if constexpr (sh == 0) return v[k];
+    else if constexpr (k == 3) return v[3] >> (8 * sh);
+    else return __builtin_amdgcn_alignbyte(v[k + 1], v[k], sh);
+}
+// 4 bytes of the byte stream  prev[0..3] ++ cur[0..3]  starting at byte offset 16 + O, O in [-16, 12]
+template <int O> __device__ __forceinline__ u32 stream_at(const u32 (&prev)[4], const u32 (&cur)[4])
+{
+    constexpr int P = 16 + O, k = P >> 2, sh = P & 3;
+    const u32 lo = k < 4 ? prev[k] : cur[k - 4];
+    if constexpr (sh == 0) return lo;
+    else { const u32 hi = (k + 1) < 4 ? prev[k + 1] : cur[k + 1 - 4]; return __builtin_amdgcn_alignbyte(hi, lo, sh); }
+}
+
+struct RowFilter { u32 mA, mB, mAvg; bool paeth; };     // None/Sub/Up/Avg as one masked form + "this row is Paeth"
+
+template <bool PAETH>
+__device__ __forceinline__ u32 defilter4(const RowFilter& f, u32 x, u32 a, u32 b, u32 c)      // four bytes at once
+{
+    u32 pred = (a & f.mA) | (b & f.mB) | (avg_bytes(a, b) & f.mAvg);
+    if constexpr (PAETH) { const u32 pp = paeth_bytes(a, b, c); pred = f.paeth ? pp : pred; }
+    return add_bytes(x, pred);
+}
+
+// De-filter one 16-byte piece of a row (stbdec.d:1484-1503, any filter unit FB = bytes per pixel): rg = raw bytes,
+// bg = the piece above, po / pb = the previous piece of this row (already de-filtered) / of the row above.
+// Byte i depends on bytes i-FB, so any FB (<= 4) consecutive bytes can be computed together as one dword, whatever the
+// pixel alignment of the piece: FB >= 4 walks the piece dword by dword and fetches "left" / "upper-left" at byte
+// distance FB from the stream; FB < 4 walks it in steps of FB bytes (FB = 3: offsets 0,3,6,9,12 and 13 -- the last step
+// recomputes two bytes, identically).  Lanes of a dword beyond the step's FB bytes compute garbage that is dropped.
+template <int FB, bool PAETH>
+__device__ __forceinline__ void filter_piece(const RowFilter& f, const u32 (&rg)[4], const u32 (&bg)[4],
+                                             const u32 (&po)[4], const u32 (&pb)[4], u32 (&og)[4])
+{
+    if constexpr (FB == 4 || FB == 8) {
+        constexpr int D = FB / 4;                      // dwords back
+        #pragma unroll
+        for (int p = 0; p < 4; ++p)
+            og[p] = defilter4<PAETH>(f, rg[p], p >= D ? og[p - D] : po[4 + p - D], bg[p], p >= D ? bg[p - D] : pb[4 + p - D]);
+    } else if constexpr (FB == 6) {
+        u32 a, c;
+        a = stream_at<0 - 6>(po, og);  c = stream_at<0 - 6>(pb, bg);  og[0] = defilter4<PAETH>(f, rg[0], a, bg[0], c);
+        a = stream_at<4 - 6>(po, og);  c = stream_at<4 - 6>(pb, bg);  og[1] = defilter4<PAETH>(f, rg[1], a, bg[1], c);
+        a = stream_at<8 - 6>(po, og);  c = stream_at<8 - 6>(pb, bg);  og[2] = defilter4<PAETH>(f, rg[2], a, bg[2], c);
+        a = stream_at<12 - 6>(po, og); c = stream_at<12 - 6>(pb, bg); og[3] = defilter4<PAETH>(f, rg[3], a, bg[3], c);
+    } else if constexpr (FB == 3) {
+        const u32 b0 = bytes_at<0>(bg), b1 = bytes_at<3>(bg), b2 = bytes_at<6>(bg), b3 = bytes_at<9>(bg), b4 = bytes_at<12>(bg), b5 = bytes_at<13>(bg);
+        const u32 s0 = defilter4<PAETH>(f, bytes_at<0>(rg),  po[3] >> 8, b0, pb[3] >> 8);
+        const u32 s1 = defilter4<PAETH>(f, bytes_at<3>(rg),  s0, b1, b0);
+        const u32 s2 = defilter4<PAETH>(f, bytes_at<6>(rg),  s1, b2, b1);
+        const u32 s3 = defilter4<PAETH>(f, bytes_at<9>(rg),  s2, b3, b2);
+        const u32 s4 = defilter4<PAETH>(f, bytes_at<12>(rg), s3, b4, b3);
+        const u32 a5 = __builtin_amdgcn_perm(s4, s3, 0x0c040201u);                 // stream bytes 10, 11 (s3) and 12 (s4)
+        const u32 s5 = defilter4<PAETH>(f, bytes_at<13>(rg), a5, b5, bytes_at<10>(bg));
+        og[0] = __builtin_amdgcn_perm(s1, s0, 0x04020100u);                        // bytes 0,1,2 | 3
+        og[1] = __builtin_amdgcn_perm(s2, s1, 0x05040201u);                        // 4,5 | 6,7
+        og[2] = __builtin_amdgcn_perm(s3, s2, 0x06050402u);                        // 8 | 9,10,11
+        og[3] = __builtin_amdgcn_perm(s5, s4, 0x06050400u);                        // 12 | 13,14,15
+    } else if constexpr (FB == 2) {
+        u32 s[8], bprev = pb[3] >> 16, sprev = po[3] >> 16;
+        #pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const u32 x = (u & 1) ? rg[u >> 1] >> 16 : rg[u >> 1], b = (u & 1) ? bg[u >> 1] >> 16 : bg[u >> 1];
+            s[u] = defilter4<PAETH>(f, x, sprev, b, bprev);
+            sprev = s[u]; bprev = b;
+        }
+        #pragma unroll
+        for (int k = 0; k < 4; ++k) og[k] = __builtin_amdgcn_perm(s[2 * k + 1], s[2 * k], 0x05040100u);
+    } else {                                           // FB == 1: every byte hangs on the one before it
+        static_assert(FB == 1, "filter unit");
+        u32 s[16], bprev = pb[3] >> 24, sprev = po[3] >> 24;
+        #pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int sh = 8 * (u & 3);
+            const u32 x = sh ? rg[u >> 2] >> sh : rg[u >> 2], b = sh ? bg[u >> 2] >> sh : bg[u >> 2];
+            s[u] = defilter4<PAETH>(f, x, sprev, b, bprev);
+            sprev = s[u]; bprev = b;
+        }
+        #pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const u32 lo = __builtin_amdgcn_perm(s[4 * k + 1], s[4 * k], 0x0c0c0400u), hi = __builtin_amdgcn_perm(s[4 * k + 3], s[4 * k + 2], 0x0c0c0400u);
+            og[k] = lo | (hi << 16);
+        }
+    }
+}
+
 // shift a dword one lane up the wave (lane j receives lane j-1's value; lane 0 keeps `fill`):
 // one DPP move, wave_shr:1 (gfx9 DPP control 0x138), bound_ctrl off so lane 0 retains `old`
 __device__ __forceinline__ u32 from_lane_below(u32 v, u32 fill)
@@ -288,16 +377,15 @@ constexpr int ROW_PITCH = RING * 16;              // 256 B: lane j's slot (T - j
 #define PNG_NT_STORES 1
 #endif
 
-template <int W, bool PAETH>
-__device__ __forceinline__ void defilter_band4(const DefilterArgs& a, const uint8_t* raw, uint8_t* D, u32* prog, uint8_t* ring, u32 band,
+template <int FB, int W, bool PAETH>
+__device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const uint8_t* raw, uint8_t* D, u32* prog, uint8_t* ring, u32 band,
                                                int wave, int lane, u32 niter, u32 f, bool row_live)
 {
-    constexpr int FB = 4;
+    constexpr int PW = 4;                         // dwords per piece
     typedef u32 u32x4 __attribute__((ext_vector_type(4)));
     const u32 seq = band / W;
     const u32 row = band * 64 + lane;
-    const u32 mA = f == 1 ? 0xFFFFFFFFu : 0u, mB = f == 2 ? 0xFFFFFFFFu : 0u, mAvg = f == 3 ? 0xFFFFFFFFu : 0u;     // None/Sub/Up/Avg as one masked form
-    const bool is_paeth = f == 4;
+    const RowFilter rf = { f == 1 ? 0xFFFFFFFFu : 0u, f == 2 ? 0xFFFFFFFFu : 0u, f == 3 ? 0xFFFFFFFFu : 0u, f == 4 };
 
     uint8_t* drow = D + (int64_t)(row_live ? row : 0) * a.d_pitch;
     const uint8_t* dprev = band > 0 ? D + (int64_t)(band * 64 - 1) * a.d_pitch : D;
@@ -305,6 +393,8 @@ __device__ __forceinline__ void defilter_band4(const DefilterArgs& a, const uint
     const int prod_wave = (wave + W - 1) % W;
     const u32 prod_base = (band > 0 ? (band - 1) / W : 0) * niter;
     const u32 full_iters = a.wb / 16;
+    // pieces written back cooperatively: a partial last piece goes along when the destination rows are padded (scratch)
+    const u32 wb_iters = a.store_tail_masked ? full_iters : niter;
 
     // cooperative mapping: in transfer k (0..7) this lane handles row 8k + crow, piece cslot of that row's 8
     const int crow = lane >> 3, cslot = lane & 7;
@@ -314,9 +404,9 @@ __device__ __forceinline__ void defilter_band4(const DefilterArgs& a, const uint
     uint8_t* my_ring = ring + lane * ROW_PITCH;
     uint8_t* co_ring = ring + crow * ROW_PITCH;                         // + k * 8 * ROW_PITCH + slot * 16
 
-    u32 outp[FB], bp3 = 0;                        // this lane's previous piece; last dword of the previous piece of the row above
+    u32 outp[PW], bprev[PW];                      // previous piece of this lane's row (de-filtered) and of the row above it
     #pragma unroll
-    for (int i = 0; i < FB; ++i) outp[i] = 0;
+    for (int i = 0; i < PW; ++i) { outp[i] = 0; bprev[i] = 0; }
 
     auto wait_for_band_above = [&](u32 upto) {
         const u32 need = prod_base + min(niter, upto);
@@ -350,7 +440,7 @@ __device__ __forceinline__ void defilter_band4(const DefilterArgs& a, const uint
     for (int u = 0; u < PF; ++u) issue_dprev((u32)u, dset[u]);
 
     // trips must reach iteration niter-1 of lane 63; write-back must reach row 63's last group (tile T0 = 8 g_last + 64)
-    const u32 T_end = max(niter + 63, 8 * ((full_iters - 1) >> 3) + 65);
+    const u32 T_end = max(niter + 63, 8 * ((wb_iters - 1) >> 3) + 65);
     u32 my_slot = (u32)(-lane) & (RING - 1);                                               // slot of iteration T - lane, kept incrementally
     for (u32 T0 = 0; T0 < T_end; T0 += TT) {
         // drop this tile's raw pieces (prefetched) into the rings, then start fetching the next tile
@@ -372,42 +462,35 @@ __device__ __forceinline__ void defilter_band4(const DefilterArgs& a, const uint
             uint4* piece = reinterpret_cast<uint4*>(my_ring + my_slot * 16);
             my_slot = (my_slot + 1) & (RING - 1);
             const uint4 rv = *piece;
-            u32 rg[FB] = { rv.x, rv.y, rv.z, rv.w }, bg[FB];
+            u32 rg[PW] = { rv.x, rv.y, rv.z, rv.w }, bg[PW];
             if (rag_tile) {             // last, partial piece of a row: the staged piece is the row's LAST 16 bytes (see prefetch_tile);
-                if (ragged) {           // keep its top nb bytes, moved down.  wb % 4 == 0, so the shift is whole dwords.  No memory op here.
-                    const u32 nb = a.wb - (u32)it * 16;
-                    const u32 v1 = rg[1], v2 = rg[2], v3 = rg[3];
-                    rg[0] = nb == 12 ? v1 : nb == 8 ? v2 : v3;
-                    rg[1] = nb == 12 ? v2 : nb == 8 ? v3 : 0u;
-                    rg[2] = nb == 12 ? v3 : 0u;
-                    rg[3] = 0u;
+                if (ragged) {           // keep its top nb bytes, moved down by 16 - nb bytes (zeros come in behind).  No memory op here.
+                    const u32 sh = 16 - (a.wb - (u32)it * 16), ds = sh >> 2, bs = sh & 3;
+                    u32 w[5];
+                    #pragma unroll
+                    for (int i = 0; i < 5; ++i) {
+                        const u32 v0 = i < 4 ? rg[i] : 0u, v1 = i + 1 < 4 ? rg[i + 1] : 0u, v2 = i + 2 < 4 ? rg[i + 2] : 0u, v3 = i + 3 < 4 ? rg[i + 3] : 0u;
+                        w[i] = ds == 0 ? v0 : ds == 1 ? v1 : ds == 2 ? v2 : v3;
+                    }
+                    #pragma unroll
+                    for (int i = 0; i < 4; ++i) rg[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], bs);
                 }
             }
             #pragma unroll
-            for (int i = 0; i < FB; ++i) bg[i] = from_lane_below(outp[i], dset[u % PF][i] & dmask);
+            for (int i = 0; i < PW; ++i) bg[i] = from_lane_below(outp[i], dset[u % PF][i] & dmask);
             if (band > 0 && T + PF < niter && ((T + PF) % PUB) == 0) wait_for_band_above(T + PF + PUB);
             issue_dprev(T + PF, dset[u % PF]);
 
-            u32 og[FB];
-            #pragma unroll
-            for (int p = 0; p < 4; ++p) {             // one pixel (dword) at a time; left / upper-left neighbours are the previous pixel
-                const u32 aa = p ? og[p - 1] : outp[3];
-                u32 pred = (aa & mA) | (bg[p] & mB) | (avg_bytes(aa, bg[p]) & mAvg);
-                if constexpr (PAETH) {
-                    const u32 pp = paeth_bytes(aa, bg[p], p ? bg[p - 1] : bp3);
-                    pred = is_paeth ? pp : pred;
-                }
-                og[p] = add_bytes(rg[p], pred);
-            }
+            u32 og[PW];
+            filter_piece<FB, PAETH>(rf, rg, bg, outp, bprev, og);
             // a lane that has not reached its row yet (it < 0) must keep presenting zeros to the lane below and to its own
             // first pixel; past the end of the row (it >= niter) whatever it computes is only seen by lanes that are past
             // the end of theirs as well, and is never written back
             #pragma unroll
-            for (int i = 0; i < FB; ++i) outp[i] = it >= 0 ? og[i] : 0u;
-            bp3 = bg[3];
+            for (int i = 0; i < PW; ++i) { outp[i] = it >= 0 ? og[i] : 0u; bprev[i] = bg[i]; }
             *piece = make_uint4(og[0], og[1], og[2], og[3]);
-            if (rag_tile) {             // partial piece: up to three dword stores straight to the row (not part of the cooperative write-back)
-                u32* dst = reinterpret_cast<u32*>(drow + (int64_t)(ragged ? it : 0) * 16);
+            if (rag_tile && a.store_tail_masked) {   // partial piece of an exact-size destination row (wb % 4 == 0 there): up to three
+                u32* dst = reinterpret_cast<u32*>(drow + (int64_t)(ragged ? it : 0) * 16);      // dword stores straight to the row
                 const u32 nb = ragged ? a.wb - (u32)it * 16 : 0u;
                 if (nb >= 4) dst[0] = og[0];
                 if (nb >= 8) dst[1] = og[1];
@@ -420,7 +503,7 @@ __device__ __forceinline__ void defilter_band4(const DefilterArgs& a, const uint
         for (int k = 0; k < 8; ++k) {
             const int it = (((int)T0 - (8 * k + crow)) & ~7) + cslot;                      // piece 8g + cslot, g = floor((T0 - row) / 8)
             const uint4 v = *reinterpret_cast<const uint4*>(co_ring + k * 8 * ROW_PITCH + ((u32)it & (RING - 1)) * 16);
-            if ((u32)(8 * k + crow) < rows_left && it >= 0 && it < (int)full_iters) {
+            if ((u32)(8 * k + crow) < rows_left && it >= 0 && it < (int)wb_iters) {
                 u32x4* dst = reinterpret_cast<u32x4*>(cdst + (int64_t)(8 * k) * a.d_pitch + (int64_t)it * 16);
                 if (PNG_NT_STORES) __builtin_nontemporal_store(u32x4{ v.x, v.y, v.z, v.w }, dst);
                 else               *dst = u32x4{ v.x, v.y, v.z, v.w };
@@ -433,7 +516,7 @@ __device__ __forceinline__ void defilter_band4(const DefilterArgs& a, const uint
         if (done > 0) {
             asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             if (lane == 63)
-                __hip_atomic_store(&prog[wave], seq * niter + min((u32)done, full_iters), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&prog[wave], seq * niter + min((u32)done, wb_iters), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     // band finished: everything is on its way; drain and publish the whole band
@@ -442,8 +525,8 @@ __device__ __forceinline__ void defilter_band4(const DefilterArgs& a, const uint
         __hip_atomic_store(&prog[wave], seq * niter + niter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int W, int MINW>
-__global__ __launch_bounds__(W * 64, MINW) void k_png_defilter4_tiled(DefilterArgs a)
+template <int FB, int W, int MINW>
+__global__ __launch_bounds__(W * 64, MINW) void k_png_defilter_ring(DefilterArgs a)
 {
     __shared__ u32 prog[W];
     __shared__ __attribute__((aligned(16))) uint8_t tiles[W][64 * ROW_PITCH];
@@ -451,7 +534,7 @@ __global__ __launch_bounds__(W * 64, MINW) void k_png_defilter4_tiled(DefilterAr
     const int img = blockIdx.x;
     const uint8_t* raw = a.raw + (int64_t)img * a.raw_stride;
     uint8_t* D = a.D + (int64_t)img * a.d_stride;
-    const u32 niter = (a.wb / 4 + 3) / 4;
+    const u32 niter = (a.wb + 15) / 16;
     const u32 nbands = (a.rows + 63) / 64;
     if (threadIdx.x < W) prog[threadIdx.x] = 0;
     __syncthreads();
@@ -460,8 +543,8 @@ __global__ __launch_bounds__(W * 64, MINW) void k_png_defilter4_tiled(DefilterAr
         const bool row_live = row < a.rows;
         u32 f = row_live ? raw[(int64_t)row * (a.wb + 1)] : 0;
         if (f > 4) { if (a.status) atomicOr(a.status + img, 1u); f = 0; }
-        if (__any(f == 4)) defilter_band4<W, true >(a, raw, D, prog, tiles[wave], band, wave, lane, niter, f, row_live);
-        else               defilter_band4<W, false>(a, raw, D, prog, tiles[wave], band, wave, lane, niter, f, row_live);
+        if (__any(f == 4)) defilter_band_ring<FB, W, true >(a, raw, D, prog, tiles[wave], band, wave, lane, niter, f, row_live);
+        else               defilter_band_ring<FB, W, false>(a, raw, D, prog, tiles[wave], band, wave, lane, niter, f, row_live);
     }
 }
 
@@ -623,18 +706,15 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
         a.store_tail_masked = 0;
     }
     const dim3 grid(count), block(PNG_WAVES * 64);
+    // rows of at least one 16-byte piece: the LDS-ring kernel (coalesced, aligned I/O); 8 waves per workgroup, register
+    // budget left unconstrained (no spills: measured faster than 128-VGPR variants that spill).  Narrower rows: the
+    // per-lane kernel.
+    const bool ring = wb >= 16;
     switch (FB) {
-    case 1: hipLaunchKernelGGL((k_png_defilter<1, PNG_WAVES>), grid, block, 0, stream, a); break;
-    case 2: hipLaunchKernelGGL((k_png_defilter<2, PNG_WAVES>), grid, block, 0, stream, a); break;
-    case 3: hipLaunchKernelGGL((k_png_defilter<3, PNG_WAVES>), grid, block, 0, stream, a); break;
-    case 4:
-        // tiled kernel: 8 waves per workgroup, register budget left unconstrained (160+ VGPRs, no spills): measured faster
-        // than 128-VGPR variants that spill (tools notes in DESIGN.md)
-        if (wb < 16) hipLaunchKernelGGL((k_png_defilter<4, PNG_WAVES>), grid, block, 0, stream, a);
-        else         hipLaunchKernelGGL((k_png_defilter4_tiled<PNG_WAVES, 2>), grid, block, 0, stream, a);
-        break;
-    case 6: hipLaunchKernelGGL((k_png_defilter<6, PNG_WAVES>), grid, block, 0, stream, a); break;
-    case 8: hipLaunchKernelGGL((k_png_defilter<8, PNG_WAVES>), grid, block, 0, stream, a); break;
+#define GAMUT_PNG_CASE(N) case N: if (ring) hipLaunchKernelGGL((k_png_defilter_ring<N, PNG_WAVES, 2>), grid, block, 0, stream, a); \
+                                  else      hipLaunchKernelGGL((k_png_defilter<N, PNG_WAVES>), grid, block, 0, stream, a); break;
+    GAMUT_PNG_CASE(1) GAMUT_PNG_CASE(2) GAMUT_PNG_CASE(3) GAMUT_PNG_CASE(4) GAMUT_PNG_CASE(6) GAMUT_PNG_CASE(8)
+#undef GAMUT_PNG_CASE
     default: return set_error(GAMUT_HIP_ERR_INVALID_ARG, "png_defilter: unsupported filter unit %d", FB);
     }
     if (int rc = launch_status("png_defilter")) return rc;

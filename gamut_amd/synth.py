@@ -78,12 +78,14 @@ def jpeg_coeff_batch(n, width, height, device, seed=0, quality=90, chunk=16):
     return out
 
 
-def png_raw_batch(n, width, height, device, seed=0, policy="heuristic", chunk=4):
-    """Inflated (post-zlib) filtered streams of n synthetic RGBA8 images: uint8 tensor (n, height*(width*4+1)).
+def png_raw_batch(n, width, height, device, seed=0, policy="heuristic", chunk=4, channels=4):
+    """Inflated (post-zlib) filtered streams of n synthetic 8-bit images (channels: 4 RGBA, 3 RGB, 2 grey+alpha, 1 grey):
+    uint8 tensor (n, height*(width*channels+1)).
     Pixels: the smooth-plus-noise generator + a smooth alpha ramp.  Per-row filter type:
     "heuristic" = stb_image_write's min sum |residual| choice (stb_image_write.d:387-406), "random" = uniform 0..4,
     or an int 0..4 for a single filter type.  Also returns the original pixels' checksums for a round-trip check."""
-    wb = width * 4
+    ch = int(channels)
+    wb = width * ch
     out = torch.empty((n, height, wb + 1), dtype=torch.uint8, device=device)
     sums = torch.empty((n,), dtype=torch.int64, device=device)
     g = torch.Generator(device=device)
@@ -94,11 +96,13 @@ def png_raw_batch(n, width, height, device, seed=0, policy="heuristic", chunk=4)
     for i0 in range(0, n, chunk):
         c = min(chunk, n - i0)
         rgb = synth_rgb_batch(c, width, height, device, seed * 1000003 + i0)            # (c,3,h,w)
-        px = torch.cat([rgb, alpha.expand(c, height, width)[:, None]], 1).permute(0, 2, 3, 1).reshape(c, height, wb).to(torch.int16)
+        planes = torch.cat([rgb, alpha.expand(c, height, width)[:, None]], 1)                        # (c,4,h,w)
+        planes = planes[:, {4: [0, 1, 2, 3], 3: [0, 1, 2], 2: [1, 3], 1: [1]}[ch]]
+        px = planes.permute(0, 2, 3, 1).reshape(c, height, wb).to(torch.int16)
         sums[i0:i0 + c] = px.to(torch.int64).sum(dim=(1, 2))
-        a = torch.zeros_like(px); a[:, :, 4:] = px[:, :, :-4]
+        a = torch.zeros_like(px); a[:, :, ch:] = px[:, :, :-ch]
         b = torch.zeros_like(px); b[:, 1:] = px[:, :-1]
-        cc = torch.zeros_like(px); cc[:, 1:, 4:] = px[:, :-1, :-4]
+        cc = torch.zeros_like(px); cc[:, 1:, ch:] = px[:, :-1, :-ch]
         p = a + b - cc
         pa, pb, pc = (p - a).abs(), (p - b).abs(), (p - cc).abs()
         paeth = torch.where((pa <= pb) & (pa <= pc), a, torch.where(pb <= pc, b, cc))

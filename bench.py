@@ -165,6 +165,7 @@ def main():
         parts = wl.split(":")                                  # png[:policy[:channels]]
         policy = parts[1] if len(parts) > 1 else "heuristic"
         ch = int(parts[2]) if len(parts) > 2 else 4
+        on = int(parts[3]) if len(parts) > 3 else ch           # out_n: ch or ch + 1 (alpha inserted, stbdec.d:1467-1480)
         if policy.isdigit():
             policy = int(policy)
         if (args.width, args.height) == (1920, 1080):
@@ -172,15 +173,15 @@ def main():
         B = args.batch if args.batch != 1024 else 512
         raw, sums = synth.png_raw_batch(B, w, h, dev, seed=3 + rank, policy=policy, channels=ch)
         raw_len = raw.shape[1]
-        out = torch.empty((B, h * w * ch), dtype=torch.uint8, device=dev)
+        out = torch.empty((B, h * w * on), dtype=torch.uint8, device=dev)
         status = torch.zeros((B,), dtype=torch.int32, device=dev)
         px_per_step = B * w * h
-        bytes_per_step = B * (raw_len + w * h * ch)            # 33 179 760 + 33 177 600 per 3840x2160 RGBA8 image
+        bytes_per_step = B * (raw_len + w * h * on)            # 33 179 760 + 33 177 600 per 3840x2160 RGBA8 image
         kernel_name = "k_png_defilter"
-        workload = f"batch {B} x {w}x{h} PNG 8-bit {['', 'grey', 'grey+alpha', 'RGB', 'RGBA'][ch]}, post-inflate de-filter ({policy} row filters)"
+        workload = f"batch {B} x {w}x{h} PNG 8-bit {['', 'grey', 'grey+alpha', 'RGB', 'RGBA'][ch]}, post-inflate de-filter{' + alpha insert' if on != ch else ''} ({policy} row filters)"
 
         def step():
-            _capi.check(L.gamut_hip_png_defilter_batch_device(raw.data_ptr(), raw_len, raw_len, out.data_ptr(), w * h * ch, w, h, ch, ch, 8, {1: 0, 2: 4, 3: 2, 4: 6}[ch],
+            _capi.check(L.gamut_hip_png_defilter_batch_device(raw.data_ptr(), raw_len, raw_len, out.data_ptr(), w * h * on, w, h, ch, on, 8, {1: 0, 2: 4, 3: 2, 4: 6}[ch],
                                                                B, status.data_ptr(), stream))
 
         def check():
@@ -188,9 +189,9 @@ def main():
             torch.cuda.synchronize()
             assert int(status.abs().sum()) == 0
             got = out.view(B, -1).to(torch.int64).sum(dim=1) if B <= 64 else torch.stack([out[i].to(torch.int64).sum() for i in range(B)])
-            if not torch.equal(got, sums):
+            if not torch.equal(got, sums + (on - ch) * 255 * w * h):           # inserted alpha = 255
                 raise SystemExit("PARITY FAILURE: checksum of de-filtered pixels != checksum of the source pixels")
-            exp = O.png_create_image_raw(raw[B - 1].cpu().numpy(), ch, ch, w, h, 8, {1: 0, 2: 4, 3: 2, 4: 6}[ch])
+            exp = O.png_create_image_raw(raw[B - 1].cpu().numpy(), ch, on, w, h, 8, {1: 0, 2: 4, 3: 2, 4: 6}[ch])
             if not np.array_equal(out[B - 1].cpu().numpy(), exp):
                 raise SystemExit("PARITY FAILURE vs oracle")
 
@@ -198,7 +199,7 @@ def main():
             host = [raw[i].cpu().numpy() for i in range(min(B, 8))]
             n, t0 = 0, time.perf_counter()
             while time.perf_counter() - t0 < seconds:
-                O.png_create_image_raw(host[n % len(host)], ch, ch, w, h, 8, {1: 0, 2: 4, 3: 2, 4: 6}[ch])
+                O.png_create_image_raw(host[n % len(host)], ch, on, w, h, 8, {1: 0, 2: 4, 3: 2, 4: 6}[ch])
                 n += 1
             dt = time.perf_counter() - t0
             return n * w * h / dt / 1e6, f"{n} of the batch's {w}x{h} filtered streams, stbi__create_png_image_raw, single thread, {dt:.1f} s"

@@ -668,6 +668,47 @@ struct Scratch {      // per-thread scratch for de-filtered rows of formats that
 
 } // namespace
 
+// Vector form of stage B for whole-byte samples: a thread expands 4 pixels (whole dwords on both sides for every channel
+// count), i.e. inserts alpha = 255 / 65535 (stbdec.d:1467-1480, :1504-1546) and swaps 16-bit samples to host order
+// (:1617-1632).  De-filtered rows are 16-byte aligned (scratch pitch); the tight output rows may start anywhere, which
+// gfx950's unaligned dword stores absorb.
+template <int IN_N, int OUT_N, int BYTES>
+__global__ __launch_bounds__(256) void k_png_expand_vec(ExpandArgs a)
+{
+    constexpr int IB = 4 * IN_N * BYTES, OB = 4 * OUT_N * BYTES;
+    const u32 g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= (a.x + 3) / 4) return;
+    const uint8_t* D = a.D + (int64_t)blockIdx.z * a.d_stride + (int64_t)g * IB;
+    uint8_t* out = a.out + (int64_t)blockIdx.z * a.out_stride + (int64_t)g * OB;
+    const u32 npx = min(4u, a.x - 4 * g);
+    for (u32 row = blockIdx.y; row < a.y; row += gridDim.y) {
+        const u32* src = reinterpret_cast<const u32*>(D + (int64_t)row * a.d_pitch);
+        u32 in[IB / 4], ow[OB / 4];
+        #pragma unroll
+        for (int i = 0; i < IB / 4; ++i) in[i] = src[i];
+        #pragma unroll
+        for (int i = 0; i < OB / 4; ++i) ow[i] = 0;
+        #pragma unroll
+        for (int px = 0; px < 4; ++px)
+            #pragma unroll
+            for (int ch = 0; ch < OUT_N; ++ch)
+                #pragma unroll
+                for (int b = 0; b < BYTES; ++b) {
+                    const int ob = (px * OUT_N + ch) * BYTES + b;
+                    u32 v = 0xFFu;                                          // inserted alpha
+                    if (ch < IN_N) { const int ib = (px * IN_N + ch) * BYTES + (BYTES == 2 ? 1 - b : b); v = (in[ib >> 2] >> ((ib & 3) * 8)) & 0xFFu; }
+                    ow[ob >> 2] |= v << ((ob & 3) * 8);
+                }
+        uint8_t* dst = out + (int64_t)row * a.x * (OUT_N * BYTES);
+        if (npx == 4) {
+            #pragma unroll
+            for (int i = 0; i < OB / 4; ++i) reinterpret_cast<PackedU32*>(dst)[i].v = ow[i];
+        } else {
+            for (u32 i = 0; i < npx * OUT_N * BYTES; ++i) dst[i] = (uint8_t)(ow[i >> 2] >> ((i & 3) * 8));
+        }
+    }
+}
+
 int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len,
                          uint8_t* out, int64_t out_stride,
                          uint32_t x, uint32_t y, int img_n, int out_n, int depth, int color,
@@ -722,7 +763,17 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
         ExpandArgs e{};
         e.D = a.D; e.d_stride = a.d_stride; e.d_pitch = a.d_pitch; e.out = out; e.out_stride = out_stride;
         e.x = x; e.y = y; e.img_n = img_n; e.out_n = out_n; e.depth = depth; e.color = color;
-        hipLaunchKernelGGL(k_png_expand, dim3(blocks_for((int64_t)x * y), count), dim3(256), 0, stream, e);
+        const dim3 vgrid(((x + 3) / 4 + 255) / 256, y < 65535u ? y : 65535u, count);
+        bool vec = depth >= 8 && count <= 65535;
+        if (vec) {
+#define GAMUT_PNG_EXPAND(I, O) if (img_n == I && out_n == O) { \
+                if (depth == 8) hipLaunchKernelGGL((k_png_expand_vec<I, O, 1>), vgrid, dim3(256), 0, stream, e); \
+                else            hipLaunchKernelGGL((k_png_expand_vec<I, O, 2>), vgrid, dim3(256), 0, stream, e); } else
+            GAMUT_PNG_EXPAND(1, 1) GAMUT_PNG_EXPAND(1, 2) GAMUT_PNG_EXPAND(2, 2) GAMUT_PNG_EXPAND(3, 3) GAMUT_PNG_EXPAND(3, 4) GAMUT_PNG_EXPAND(4, 4)
+            vec = false;
+#undef GAMUT_PNG_EXPAND
+        }
+        if (!vec) hipLaunchKernelGGL(k_png_expand, dim3(blocks_for((int64_t)x * y), count), dim3(256), 0, stream, e);
         if (int rc = launch_status("png_expand")) return rc;
     }
     return GAMUT_HIP_OK;

@@ -82,38 +82,39 @@ def main():
     w, h, B = args.width, args.height, args.batch
     wl = args.workload
     check = None
-    if wl == "jpeg":
+    if wl == "jpeg" or wl.startswith("jpeg:"):
+        oc = int(wl.split(":")[1]) if ":" in wl else 4          # jpeg[:out_comps]  (4 = rgba8 headline, 3 = rgb8, 1 = l8)
         coeffs = synth.jpeg_coeff_batch(B, w, h, dev, seed=1 + rank)
         nblk = coeffs.shape[1]
-        out = torch.empty((B, h, w * 4), dtype=torch.uint8, device=dev)
+        out = torch.empty((B, h, w * oc), dtype=torch.uint8, device=dev)
         px_per_step = B * w * h
-        bytes_per_step = B * (nblk * 128 + w * h * 4)            # 6 266 880 + 8 294 400 per 1080p image
-        kernel_name = "k_jpeg_h2v2_rgba8"
-        workload = f"batch {B} x {w}x{h} baseline JPEG 4:2:0, IDCT + freq-domain chroma upsample + YCbCr->RGBA8"
+        bytes_per_step = B * (nblk * 128 + w * h * oc)           # 6 266 880 + 8 294 400 per 1080p image (rgba8)
+        kernel_name = "k_jpeg_h2v2"
+        workload = f"batch {B} x {w}x{h} baseline JPEG 4:2:0, IDCT + freq-domain chroma upsample + YCbCr->{ {4: 'RGBA8', 3: 'RGB8', 1: 'L8'}[oc] }"
 
         def step():
-            _capi.check(L.gamut_hip_jpeg_reconstruct_batch_device(coeffs.data_ptr(), nblk * 64, None, 0, out.data_ptr(), w * 4,
-                                                                   h * w * 4, w, h, 4, 4, B, stream))
+            _capi.check(L.gamut_hip_jpeg_reconstruct_batch_device(coeffs.data_ptr(), nblk * 64, None, 0, out.data_ptr(), w * oc,
+                                                                   h * w * oc, w, h, 4, oc, B, stream))
 
         def check():
             import oracle_lib as O
             step()
             torch.cuda.synchronize()
             for i in sorted({0, B - 1}):
-                exp = O.jpeg_reconstruct(w, h, 3, O.JPGD_YH2V2, coeffs[i].cpu().numpy(), None, 4)
+                exp = O.jpeg_reconstruct(w, h, 3, O.JPGD_YH2V2, coeffs[i].cpu().numpy(), None, oc)
                 if not np.array_equal(out[i].cpu().numpy(), exp):
                     raise SystemExit(f"PARITY FAILURE on image {i}")
 
         def cpu_leg(seconds):
             import oracle_lib as O
             host = [coeffs[i].cpu().numpy() for i in range(min(B, 64))]
-            O.jpeg_reconstruct(w, h, 3, O.JPGD_YH2V2, host[0], None, 4)           # warm
+            O.jpeg_reconstruct(w, h, 3, O.JPGD_YH2V2, host[0], None, oc)          # warm
             n, t0 = 0, time.perf_counter()
             while time.perf_counter() - t0 < seconds:
-                O.jpeg_reconstruct(w, h, 3, O.JPGD_YH2V2, host[n % len(host)], None, 4)
+                O.jpeg_reconstruct(w, h, 3, O.JPGD_YH2V2, host[n % len(host)], None, oc)
                 n += 1
             dt = time.perf_counter() - t0
-            return n * w * h / dt / 1e6, f"{n} of the batch's {w}x{h} coefficient frames, coefficients -> rgba8, single thread, {dt:.1f} s"
+            return n * w * h / dt / 1e6, f"{n} of the batch's {w}x{h} coefficient frames, coefficients -> pixels, single thread, {dt:.1f} s"
         dtype = "int32"
     elif wl.startswith("convert:"):
         import oracle_lib as O

@@ -8,7 +8,8 @@
 // m_pMCU_coefficients, :2432/:2474), 128 B per block, blocks in MCU order.
 //
 // Two kernels:
-//   k_jpeg_h2v2_rgba8  -- the tuned path for the headline case (4:2:0 -> rgba8).
+//   k_jpeg_h2v2<OC>    -- the tuned path for 4:2:0 (the headline case -> rgba8; also rgb8, what loadJPEG produces by
+//       default, plugins/jpeg.d:48-86, and l8).
 //       One 256-thread workgroup reconstructs a strip of 8 MCUs (128x16 px).
 //       HBM traffic is exactly the algorithmic one: 768 B of coefficients in
 //       (dwordx4 per lane, lane-contiguous) and 1024 B of pixels out (each wave
@@ -80,7 +81,8 @@ __device__ __forceinline__ void map_half(const MapCoef& c, i32 pass0, i32 pass1,
     o[3] = D4(c.b[0], u1, c.b[1], u3, c.b[2], u5, c.b[3], u7);
 }
 
-__global__ __launch_bounds__(256) void k_jpeg_h2v2_rgba8(JpegArgs a)
+template <int OC>                // output components: 4 = rgba8, 3 = rgb8, 1 = l8 (grey of the RGB result, jpegload.d:3786-3792)
+__global__ __launch_bounds__(256) void k_jpeg_h2v2(JpegArgs a)
 {
     __shared__ __attribute__((aligned(16))) i32 lds[LDS_INTS];
     i32* const T1 = lds;
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256) void k_jpeg_h2v2_rgba8(JpegArgs a)
     const int img = blockIdx.z, mcu_y = blockIdx.y, mcu_x0 = blockIdx.x * TILE_MCUS;
     // wave-uniform bases (scalar registers); per-thread parts are small 32-bit offsets
     const int16_t* cbase = a.coeffs + (int64_t)img * a.coeff_stride + ((int64_t)mcu_y * a.mcus_per_row + mcu_x0) * (6 * 64);
-    uint8_t* obase = a.out + (int64_t)img * a.out_stride + (int64_t)(mcu_y * 16) * a.out_pitch + (int64_t)mcu_x0 * 64;
+    uint8_t* obase = a.out + (int64_t)img * a.out_stride + (int64_t)(mcu_y * 16) * a.out_pitch + (int64_t)mcu_x0 * (16 * OC);
     const int mcus_here = min(TILE_MCUS, a.mcus_per_row - mcu_x0);
 
     // ---- mapping A: thread = (Y block b = (mcu m, quadrant q), row/column index r) ----
@@ -201,22 +203,63 @@ __global__ __launch_bounds__(256) void k_jpeg_h2v2_rgba8(JpegArgs a)
 
         const int lx = m * 16 + (q & 1) * 8 + r;               // pixel column inside the strip
         const int ly0 = (q >> 1) * 8;                          // first pixel row inside the strip
-        if (mcu_live && mcu_x0 * 16 + lx < a.width) {
+        const bool px_live = mcu_live && mcu_x0 * 16 + lx < a.width;
+        const bool all_rows = a.height - mcu_y * 16 >= 16;     // wave-uniform: all 16 rows of the strip exist
+        const int rows_here = a.height - mcu_y * 16 - ly0;
+        const u32 pitch = (u32)a.out_pitch;                    // the launcher checks 16 * out_pitch < 2^31
+        // Addresses = uniform strip base + 32-bit lane offset.  Pixel rows are written with nontemporal stores.
+        if constexpr (OC == 4) {
             // one pixel per lane per row: a wave store instruction writes two full 128-byte lines.  (16-byte stores after an
             // in-quad DPP transpose were measured 2 % slower: the kernel is VALU-bound, not store-issue-bound.)
-            // Addresses = uniform strip base + 32-bit lane offset (the launcher checks 16 * out_pitch < 2^31).
-            const u32 pitch = (u32)a.out_pitch;
-            u32 voff = (u32)(lx * 4) + (u32)ly0 * pitch;
-            if (a.height - mcu_y * 16 >= 16) {                 // wave-uniform: all 16 rows of the strip exist
-                #pragma unroll
-                for (int i = 0; i < 8; ++i, voff += pitch)
-                    __builtin_nontemporal_store(ycc_to_rgba(ys[i], cbs[i], crs[i]), reinterpret_cast<u32*>(obase + voff));
-            } else {
-                const int rows_here = a.height - mcu_y * 16 - ly0;
-                #pragma unroll
-                for (int i = 0; i < 8; ++i, voff += pitch)
-                    if (i < rows_here)
+            if (px_live) {
+                u32 voff = (u32)(lx * 4) + (u32)ly0 * pitch;
+                if (all_rows) {
+                    #pragma unroll
+                    for (int i = 0; i < 8; ++i, voff += pitch)
                         __builtin_nontemporal_store(ycc_to_rgba(ys[i], cbs[i], crs[i]), reinterpret_cast<u32*>(obase + voff));
+                } else {
+                    #pragma unroll
+                    for (int i = 0; i < 8; ++i, voff += pitch)
+                        if (i < rows_here)
+                            __builtin_nontemporal_store(ycc_to_rgba(ys[i], cbs[i], crs[i]), reinterpret_cast<u32*>(obase + voff));
+                }
+            }
+        } else if constexpr (OC == 3) {
+            // rgb8: the four pixels of a lane quad are 12 bytes = 3 dwords; lane j < 3 of the quad builds dword j from its own
+            // pixel and its right neighbour's (one DPP quad shuffle + one byte permute) and stores it.  A quad cut by the
+            // right image edge falls back to byte stores (rows are tightly packed: nothing may spill into the next row).
+            const int j = lx & 3;
+            const u32 sel = j == 0 ? 0x04020100u : j == 1 ? 0x05040201u : 0x06050402u;
+            const bool quad_inside = mcu_live && mcu_x0 * 16 + (lx | 3) < a.width;
+            u32 voff = (u32)(lx * 3 + j) + (u32)ly0 * pitch;   // dword j of the quad: (lx - j) * 3 + 4 j
+            u32 boff = (u32)(lx * 3) + (u32)ly0 * pitch;
+            #pragma unroll
+            for (int i = 0; i < 8; ++i, voff += pitch, boff += pitch) {
+                const u32 px = ycc_to_rgba(ys[i], cbs[i], crs[i]);
+                const u32 nx = (u32)__builtin_amdgcn_mov_dpp((int)px, 0xF9, 0xF, 0xF, true);      // quad_perm [1,2,3,3]: right neighbour
+                const u32 dw = __builtin_amdgcn_perm(nx, px, sel);
+                if (all_rows || i < rows_here) {
+                    if (quad_inside) { if (j < 3) __builtin_nontemporal_store(dw, reinterpret_cast<u32*>(obase + voff)); }
+                    else if (px_live) { uint8_t* o = obase + boff; o[0] = (uint8_t)px; o[1] = (uint8_t)(px >> 8); o[2] = (uint8_t)(px >> 16); }
+                }
+            }
+        } else {
+            // l8: four lanes' grey bytes make one dword, gathered with two in-quad OR steps; lane 0 of the quad stores
+            static_assert(OC == 1, "output components");
+            const int j = lx & 3;
+            const bool quad_inside = mcu_live && mcu_x0 * 16 + (lx | 3) < a.width;
+            u32 voff = (u32)(lx - j) + (u32)ly0 * pitch;
+            u32 boff = (u32)lx + (u32)ly0 * pitch;
+            #pragma unroll
+            for (int i = 0; i < 8; ++i, voff += pitch, boff += pitch) {
+                const u32 g = rgb_to_luma(ycc_to_rgba(ys[i], cbs[i], crs[i]));
+                u32 v = g << (8 * j);
+                v |= (u32)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);                   // quad_perm [1,0,3,2]
+                v |= (u32)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);                   // quad_perm [2,3,0,1]
+                if (all_rows || i < rows_here) {
+                    if (quad_inside) { if (j == 0) __builtin_nontemporal_store(v, reinterpret_cast<u32*>(obase + voff)); }
+                    else if (px_live) obase[boff] = (uint8_t)g;
+                }
             }
         }
     }
@@ -403,10 +446,13 @@ int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
         c.coeffs += (int64_t)i0 * coeff_stride; c.out += (int64_t)i0 * out_stride;
         if (c.max_zag) c.max_zag += (int64_t)i0 * zag_stride;
         const dim3 grid(tiles, a.mcus_per_col, n);
-        const bool tuned = scan_type == GAMUT_JPGD_YH2V2 && out_comps == 4 && ((uintptr_t)out & 3) == 0 &&
-                           (out_pitch & 3) == 0 && (out_stride & 3) == 0 && out_pitch > 0 && out_pitch < (1 << 27);
-        if (tuned) hipLaunchKernelGGL(k_jpeg_h2v2_rgba8, grid, dim3(256), 0, stream, c);
-        else       hipLaunchKernelGGL(k_jpeg_generic, grid, dim3(256), 0, stream, c);
+        // tuned 4:2:0 kernel: rgba8 needs dword-aligned rows; rgb8 / l8 rows may start anywhere (unaligned dword stores)
+        const bool tuned = scan_type == GAMUT_JPGD_YH2V2 && out_pitch > 0 && out_pitch < (1 << 27) &&
+                           (out_comps != 4 || (((uintptr_t)out & 3) == 0 && (out_pitch & 3) == 0 && (out_stride & 3) == 0));
+        if (!tuned)              hipLaunchKernelGGL(k_jpeg_generic, grid, dim3(256), 0, stream, c);
+        else if (out_comps == 4) hipLaunchKernelGGL(k_jpeg_h2v2<4>, grid, dim3(256), 0, stream, c);
+        else if (out_comps == 3) hipLaunchKernelGGL(k_jpeg_h2v2<3>, grid, dim3(256), 0, stream, c);
+        else                     hipLaunchKernelGGL(k_jpeg_h2v2<1>, grid, dim3(256), 0, stream, c);
         if (int rc = launch_status("jpeg_reconstruct")) return rc;
     }
     return GAMUT_HIP_OK;

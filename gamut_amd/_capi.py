@@ -62,6 +62,9 @@ SIGNATURES = {
     "gamut_hip_jpeg_reconstruct_device": (_i, [C.POINTER(JpegDesc), _i, _vp]),
     "gamut_hip_jpeg_reconstruct_batch_device": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp]),
     "gamut_hip_jpeg_decode_coeffs": (_i, [_vp, _sz, C.POINTER(JpegFrame)]),
+    "gamut_hip_jpeg_read_header": (_i, [_vp, _sz, C.POINTER(JpegFrame)]),
+    "gamut_hip_jpeg_entropy_decode_device": (_i, [C.POINTER(_vp), C.POINTER(_sz), _i, C.POINTER(_i64), C.POINTER(_i64), _vp, _vp, _vp,
+                                              C.POINTER(JpegFrame), C.POINTER(_i), _vp]),
     "gamut_hip_jpeg_decode_coeffs_batch": (_i, [C.POINTER(_vp), C.POINTER(_sz), _i, C.POINTER(JpegFrame), C.POINTER(_i), _i]),
     "gamut_hip_jpeg_frame_free": (None, [C.POINTER(JpegFrame)]),
     "gamut_hip_decompress_jpeg_image_from_memory": (_vp, [_vp, _sz, _pi, _pi, _pi, _pf, _pf, _i]),

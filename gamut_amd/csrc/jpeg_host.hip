@@ -12,6 +12,7 @@
 // hierarchical frames, 12-bit precision, CMYK, multi-scan *baseline* files.
 #include "common.hpp"
 #include <atomic>
+#include <chrono>
 #include <new>
 #include <thread>
 #include <vector>
@@ -505,6 +506,337 @@ int decode_coeffs(const uint8_t* data, size_t len, gamut_hip_jpeg_frame* f)
     return rc;
 }
 
+
+// =====================================================================================================================
+// Entropy decode ON THE GPU: baseline scans only.
+//
+// Huffman decoding is serial inside a stream, but a batch holds many independent streams: every image, and inside an
+// image every restart interval (process_restart :2335-2402 resets the DC predictors and byte-aligns the stream), can be
+// decoded by its own lane.  The host only walks the markers (tables, geometry) and locates the RSTn boundaries; the
+// compressed bytes go to the device as they are (230 kB instead of 6.3 MB of coefficients per 1080p image over PCIe) and
+// k_jpeg_entropy writes the same dense de-quantised coefficient form decode_next_row (:2405-2525) produces, straight
+// into HBM, ready for k_jpeg_h2v2 / k_jpeg_generic.  Same arithmetic as decode_baseline() above, which is its oracle.
+struct DevHuff {                       // one Huffman table (shared by every image that uses the same table)
+    uint16_t fast[512];                // 9-bit lookahead -> (length << 8) | symbol, 0 = longer code
+    int32_t  maxcode[18];
+    int32_t  delta[17];
+    uint8_t  vals[256];
+    uint8_t  pad[4];
+};
+struct DevImage {
+    int64_t coeff_off, zag_off;        // int16 elements / bytes from the start of the caller's buffers
+    int32_t nb, ny;                    // blocks per MCU, of which luma (component of block b: b < ny ? 0 : b - ny + 1)
+    int32_t quant[3], dc[3], ac[3];    // table indices per component
+    int32_t pad;
+};
+struct DevItem { int32_t image, first_mcu, n_mcus, pad; uint64_t begin, end; };    // one restart interval (or whole scan)
+
+__constant__ uint8_t kZagDev[64] = { 0,1,8,16,9,2,3,10,17,24,32,25,18,11,4,5,12,19,26,33,40,48,41,34,27,20,13,6,7,14,21,28,35,42,49,56,57,50,43,36,29,22,15,23,30,37,44,51,58,59,52,45,38,31,39,46,53,60,61,54,47,55,62,63 };
+
+struct DevBits {                       // MSB-first reader, same conventions as BitReader above
+    const uint8_t* p;                  // next byte not yet in `acc`; when pre_ok, `pre` already holds bytes p .. p+3
+    const uint8_t* end; uint64_t acc; int nbits; bool at_marker; uint32_t pre; bool pre_ok;
+    // The next four bytes are requested one refill ahead, so their global-memory latency overlaps the symbols decoded
+    // in between (a lane is a serial chain of dependent operations: latency, not bandwidth, is what it pays for).
+    __device__ __forceinline__ void prime() { pre_ok = !at_marker && p + 4 <= end; if (pre_ok) __builtin_memcpy(&pre, p, 4); }
+    __device__ __forceinline__ void refill()
+    {
+        if (nbits > 32) return;
+        if (pre_ok) {                                          // four ordinary bytes at once (any alignment)
+            const uint32_t w = pre, t = ~w;
+            if (((t - 0x01010101u) & ~t & 0x80808080u) == 0) { // no 0xFF among them
+                acc = (acc << 32) | __builtin_bswap32(w); nbits += 32; p += 4;
+                prime();
+                return;
+            }
+        }
+        while (nbits <= 56) {                                  // byte-wise: FF00 stuffing, stop at a marker and feed 1-bits
+            uint32_t c = 0xFF;
+            if (!at_marker && p < end) {
+                c = *p;
+                if (c == 0xFF) { if (p + 1 < end && p[1] == 0) p += 2; else at_marker = true; }
+                else ++p;
+            }
+            acc = (acc << 8) | c; nbits += 8;
+            if (nbits > 32) break;
+        }
+        prime();
+    }
+    __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)(acc >> (nbits - n)) & ((1u << n) - 1); }
+    __device__ __forceinline__ int decode(const DevHuff* h)
+    {
+        refill();
+        const uint32_t e = h->fast[peek(9)];
+        if (e) { nbits -= (int)(e >> 8); return (int)(e & 0xFF); }
+        int32_t code = (int32_t)peek(9); int len = 9;
+        while (len < 17 && code > h->maxcode[len]) { ++len; code = (int32_t)peek(len); }
+        if (len > 16) return -1;
+        nbits -= len;
+        return h->vals[(code + h->delta[len]) & 0xFF];
+    }
+    __device__ __forceinline__ int receive_extend(int s)       // JPGD_HUFF_EXTEND :816-822
+    {
+        if (!s) return 0;
+        refill();
+        const int v = (int)peek(s); nbits -= s;
+        return v < (1 << (s - 1)) ? v + (int)(0xFFFFFFFFu << s) + 1 : v;
+    }
+};
+
+constexpr int kEntropyThreads = 64;                          // one wave per workgroup: lanes spread over CUs, each with its own L1
+constexpr int kLdsHuff = 16, kLdsQuant = 16;                   // tables a workgroup keeps in LDS (23 KB + 2 KB)
+
+// IN_LDS: the batch uses few distinct tables (the usual case: encoders write the Annex K tables or one optimised set per
+// quality), so every workgroup copies them all into LDS and a symbol costs LDS latencies instead of L2 ones -- the
+// table look-up sits on the lane's critical path twice per symbol.
+template <bool IN_LDS>
+__global__ __launch_bounds__(kEntropyThreads) void k_jpeg_entropy(const DevItem* items, int n_items, const DevImage* images,
+                                                                  const DevHuff* huff_g, int n_huff, const int16_t* quant_g /* [t][64], zig-zag order */,
+                                                                  int n_quant, const uint8_t* blob, int16_t* coeffs, uint8_t* max_zag, uint32_t* status)
+{
+    __shared__ DevHuff sh_huff[IN_LDS ? kLdsHuff : 1];
+    __shared__ int16_t sh_quant[IN_LDS ? kLdsQuant * 64 : 1];
+    __shared__ uint8_t sh_zag[64];
+    // The block being decoded lives in LDS (one 128-byte row per lane, 144-byte pitch): the sparse coefficient writes are
+    // LDS writes, and a finished block leaves as eight 16-byte stores -- a whole line, zeros included, so the destination
+    // needs no clearing and the lane's bit-stream loads never queue behind a trail of 2-byte global stores.
+    __shared__ __attribute__((aligned(16))) uint8_t sh_blk[kEntropyThreads * 144];
+    if (threadIdx.x < 64) sh_zag[threadIdx.x] = kZagDev[threadIdx.x];
+    {
+        uint4* z = reinterpret_cast<uint4*>(sh_blk + threadIdx.x * 144);
+        #pragma unroll
+        for (int k = 0; k < 8; ++k) z[k] = make_uint4(0, 0, 0, 0);
+    }
+    if constexpr (IN_LDS) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(huff_g); uint32_t* dst = reinterpret_cast<uint32_t*>(sh_huff);
+        for (int k = threadIdx.x; k < n_huff * (int)(sizeof(DevHuff) / 4); k += kEntropyThreads) dst[k] = src[k];
+        for (int k = threadIdx.x; k < n_quant * 64; k += kEntropyThreads) sh_quant[k] = quant_g[k];
+    }
+    __syncthreads();
+    const DevHuff* huff = IN_LDS ? sh_huff : huff_g;
+    const int16_t* quant = IN_LDS ? sh_quant : quant_g;
+
+    const int i = blockIdx.x * kEntropyThreads + threadIdx.x;
+    if (i >= n_items) return;
+    const DevItem it = items[i];
+    const DevImage im = images[it.image];
+    DevBits br{ blob + it.begin, blob + it.end, 0, 0, false, 0, false };
+    br.prime();
+    int pred0 = 0, pred1 = 0, pred2 = 0;
+    int16_t* out = coeffs + im.coeff_off + (int64_t)it.first_mcu * im.nb * 64;
+    uint8_t* mz = max_zag + im.zag_off + (int64_t)it.first_mcu * im.nb;
+    int16_t* blk = reinterpret_cast<int16_t*>(sh_blk + threadIdx.x * 144);
+    for (int mcu = 0; mcu < it.n_mcus; ++mcu) {
+        for (int b = 0; b < im.nb; ++b, out += 64, ++mz) {
+            const int c = b < im.ny ? 0 : b - im.ny + 1;
+            const int16_t* q = quant + (c == 0 ? im.quant[0] : c == 1 ? im.quant[1] : im.quant[2]) * 64;
+            const DevHuff* dc = huff + (c == 0 ? im.dc[0] : c == 1 ? im.dc[1] : im.dc[2]);
+            const DevHuff* ac = huff + (c == 0 ? im.ac[0] : c == 1 ? im.ac[1] : im.ac[2]);
+            const int s = br.decode(dc);
+            if (s < 0) { atomicOr(status + it.image, 1u); return; }
+            const int pred = c == 0 ? pred0 : c == 1 ? pred1 : pred2;
+            const int v = br.receive_extend(s & 15) + pred;
+            if (c == 0) pred0 = v; else if (c == 1) pred1 = v; else pred2 = v;
+            blk[0] = (int16_t)((uint32_t)v * (uint32_t)(int32_t)q[0]);
+            int kk = 1;
+            for (; kk < 64; ++kk) {
+                const int rs = br.decode(ac);
+                if (rs < 0) { atomicOr(status + it.image, 1u); return; }
+                const int run = rs >> 4, size = rs & 15;
+                if (size) {
+                    if (run) { if (kk + run > 63) { atomicOr(status + it.image, 2u); return; } kk += run; }
+                    const int e = br.receive_extend(size);
+                    blk[sh_zag[kk]] = (int16_t)((uint32_t)e * (uint32_t)(int32_t)q[kk]);
+                } else if (run == 15) {
+                    if (kk + 16 > 64) { atomicOr(status + it.image, 2u); return; }
+                    kk += 15;
+                } else break;
+            }
+            *mz = (uint8_t)kk;                                   // m_mcu_block_max_zag :2512
+            uint4* src = reinterpret_cast<uint4*>(blk);
+            uint4* dst = reinterpret_cast<uint4*>(out);          // 128-byte blocks at 128-byte-aligned offsets (checked by the host)
+            #pragma unroll
+            for (int k = 0; k < 8; ++k) { dst[k] = src[k]; src[k] = make_uint4(0, 0, 0, 0); }
+        }
+    }
+}
+
+// Host side: header walk per file, table de-duplication, restart-interval index, one upload, one launch.
+struct EntropyScratch {                // per-thread device staging, grown on demand, never shrunk
+    void* dev = nullptr; size_t cap = 0;
+    void* get(size_t n)
+    {
+        if (n > cap) {
+            if (dev) { (void)hipDeviceSynchronize(); (void)hipFree(dev); dev = nullptr; cap = 0; }
+            if (hipMalloc(&dev, n + n / 4 + 4096) != hipSuccess) { dev = nullptr; return nullptr; }
+            cap = n + n / 4 + 4096;
+        }
+        return dev;
+    }
+};
+
+// geometry + the position of the single baseline scan; shared by read_header and the device decoder
+int parse_baseline(Parser& P, const uint8_t* data, size_t len, gamut_hip_jpeg_frame* f, bool want_scan)
+{
+    memset(f, 0, sizeof(*f));
+    f->pixel_aspect_ratio = -1; f->dpi_y = -1;
+    if (!data || len < 4 || data[0] != 0xFF || data[1] != 0xD8) return fail(f, "not a JPEG (no SOI)");
+    P.data = data; P.len = len; P.pos = 2;
+    const int first = next_scan(P, f);
+    if (first < 0) return GAMUT_HIP_ERR_DECODE;
+    if (first != 0xDA) return fail(f, "no SOS marker");
+    if (!want_scan) return GAMUT_HIP_OK;
+    if (P.progressive) return set_error(GAMUT_HIP_ERR_UNSUPPORTED, "jpeg: progressive frames are decoded by the host feeder (gamut_hip_jpeg_decode_coeffs)");
+    if (P.scan.ncomp != f->comps) return fail(f, "only single-scan baseline files are supported");
+    for (int c = 0; c < f->comps; ++c) {
+        if (!P.quant_def[P.tq[c]]) return fail(f, "undefined quant table");
+        if (!P.huff[P.td[c]].defined || !P.huff[P.ta[c]].defined) return fail(f, "undefined Huffman table");
+    }
+    return GAMUT_HIP_OK;
+}
+
+template <class T> int intern(std::vector<T>& pool, const T& t)      // index of a bit-identical table, appended if new
+{
+    for (size_t i = 0; i < pool.size(); ++i) if (!memcmp(&pool[i], &t, sizeof(T))) return (int)i;
+    pool.push_back(t);
+    return (int)pool.size() - 1;
+}
+struct QuantTab { int16_t q[64]; };
+
+int entropy_decode_device(const uint8_t* const* data, const size_t* len, int count,
+                          const int64_t* coeff_offset, const int64_t* zag_offset,
+                          int16_t* d_coeffs, uint8_t* d_max_zag, uint32_t* d_status,
+                          gamut_hip_jpeg_frame* info, int* host_status, hipStream_t stream)
+{
+    const bool trace = getenv("GAMUT_HIP_TRACE") != nullptr;           // stage timings on stderr (tools/e2e_bench.py)
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    double ms_parse = 0, ms_upload = 0;
+    std::vector<DevImage> images((size_t)count);
+    std::vector<int> hst((size_t)count, GAMUT_HIP_OK);              // per-file header status
+    std::vector<DevItem> items;
+    std::vector<DevHuff> huffs;
+    std::vector<QuantTab> quants;
+    std::vector<uint8_t> blob;
+    int first_failure = GAMUT_HIP_OK; char first_msg[256] = { 0 };
+    Parser* ps = new (std::nothrow) Parser();
+    if (!ps) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: out of memory");
+    struct Guard { Parser* p; ~Guard() { delete p; } } guard{ ps };
+
+    for (int i = 0; i < count; ++i) {
+        *ps = Parser();
+        Parser& P = *ps;
+        gamut_hip_jpeg_frame& f = info[i];
+        const int rc = parse_baseline(P, data[i], len[i], &f, true);
+        hst[(size_t)i] = rc;
+        memset(&images[(size_t)i], 0, sizeof(DevImage));
+        if (rc != GAMUT_HIP_OK) {
+            if (first_failure == GAMUT_HIP_OK) { first_failure = rc; snprintf(first_msg, sizeof(first_msg), "image %d: %s", i, last_error_buf()); }
+            continue;
+        }
+        DevImage& im = images[(size_t)i];
+        im.coeff_off = coeff_offset[i]; im.zag_off = zag_offset[i];
+        if ((coeff_offset[i] & 7) != 0 || ((uintptr_t)d_coeffs & 15) != 0)
+            return set_error(GAMUT_HIP_ERR_INVALID_ARG, "jpeg_entropy_decode_device: coefficient buffers must be 16-byte aligned (offset %d)", i);
+        im.nb = f.blocks_per_mcu; im.ny = f.comps == 1 ? 1 : P.hs[0] * P.vs[0];
+        for (int c = 0; c < f.comps; ++c) {
+            QuantTab qt; memcpy(qt.q, P.quant[P.tq[c]], sizeof(qt.q));
+            im.quant[c] = intern(quants, qt);
+            for (int k = 0; k < 2; ++k) {
+                const HuffTable& h = P.huff[k ? P.ta[c] : P.td[c]];
+                DevHuff d; memset(&d, 0, sizeof(d));
+                for (int w = 0; w < 512; ++w) { const uint16_t e = h.fast[w << 1]; d.fast[w] = (e >> 8) <= 9 ? e : 0; }   // 10-bit table -> 9-bit
+                memcpy(d.maxcode, h.maxcode, sizeof(d.maxcode)); memcpy(d.delta, h.delta, sizeof(d.delta)); memcpy(d.vals, h.vals, sizeof(d.vals));
+                (k ? im.ac[c] : im.dc[c]) = intern(huffs, d);
+            }
+        }
+        // the entropy-coded segment: from the SOS payload end to the next marker that is not RSTn / FF00
+        const uint8_t* base = data[i]; const size_t n = len[i];
+        size_t q = P.pos, seg_begin = P.pos;
+        const int total_mcus = f.mcus_per_row * f.mcus_per_col;
+        int next_mcu = 0, expect = 0;
+        auto push = [&](size_t b, size_t e, int nm) {
+            DevItem it{}; it.image = i; it.first_mcu = next_mcu; it.n_mcus = nm; it.begin = blob.size() + (b - P.pos); it.end = blob.size() + (e - P.pos);
+            items.push_back(it); next_mcu += nm;
+        };
+        bool bad = false;
+        while (true) {
+            const uint8_t* hit = q < n ? (const uint8_t*)memchr(base + q, 0xFF, n - q) : nullptr;
+            if (!hit || hit + 1 >= base + n) { q = n; break; }
+            const uint8_t m = hit[1];
+            q = (size_t)(hit - base);
+            if (m == 0x00 || m == 0xFF) { q += (m == 0xFF) ? 1 : 2; continue; }
+            if (m >= 0xD0 && m <= 0xD7 && P.restart_interval && next_mcu + P.restart_interval < total_mcus) {
+                if (m != 0xD0 + expect) { bad = true; break; }
+                push(seg_begin, q, P.restart_interval);
+                expect = (expect + 1) & 7; q += 2; seg_begin = q;
+                continue;
+            }
+            break;                                             // EOI or any other marker ends the scan
+        }
+        if (!bad && next_mcu < total_mcus) {
+            if (P.restart_interval && total_mcus - next_mcu > P.restart_interval) bad = true;      // a restart marker is missing
+            else push(seg_begin, q, total_mcus - next_mcu);
+        }
+        if (bad) {
+            while (!items.empty() && items.back().image == i) items.pop_back();
+            fail(&f, "bad restart marker");
+            hst[(size_t)i] = GAMUT_HIP_ERR_DECODE;
+            if (first_failure == GAMUT_HIP_OK) { first_failure = GAMUT_HIP_ERR_DECODE; snprintf(first_msg, sizeof(first_msg), "image %d: bad restart marker", i); }
+            continue;
+        }
+        blob.insert(blob.end(), base + P.pos, base + q);
+        blob.insert(blob.end(), 8, (uint8_t)0xFF);             // slack so a 4-byte fetch at the end of a segment stays inside the blob
+    }
+
+    ms_parse = ms_since(t_begin);
+    if (!items.empty()) {
+        const auto t_up = std::chrono::steady_clock::now();
+        // one device staging allocation: [items][images][huff][quant][blob]; the tables go up as one small copy, the
+        // compressed bytes as another
+        auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        const size_t o_items = 0, o_img = align(o_items + items.size() * sizeof(DevItem)), o_huff = align(o_img + images.size() * sizeof(DevImage)),
+                     o_quant = align(o_huff + huffs.size() * sizeof(DevHuff)), o_blob = align(o_quant + quants.size() * sizeof(QuantTab)),
+                     total = o_blob + blob.size();
+        static thread_local EntropyScratch scratch;
+        uint8_t* d = (uint8_t*)scratch.get(total);
+        if (!d) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: device staging allocation of %zu bytes failed", total);
+        std::vector<uint8_t> meta(o_blob);
+        memcpy(meta.data() + o_items, items.data(), items.size() * sizeof(DevItem));
+        memcpy(meta.data() + o_img, images.data(), images.size() * sizeof(DevImage));
+        memcpy(meta.data() + o_huff, huffs.data(), huffs.size() * sizeof(DevHuff));
+        memcpy(meta.data() + o_quant, quants.data(), quants.size() * sizeof(QuantTab));
+        GAMUT_HIP_CHECK(hipMemcpyAsync(d, meta.data(), o_blob, hipMemcpyHostToDevice, stream));
+        GAMUT_HIP_CHECK(hipMemcpyAsync(d + o_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, stream));
+        if (d_status) GAMUT_HIP_CHECK(hipMemsetAsync(d_status, 0, (size_t)count * sizeof(uint32_t), stream));
+        uint32_t* st = d_status;
+        if (!st) {                                             // the kernel wants somewhere to flag errors
+            static thread_local EntropyScratch sink;
+            st = (uint32_t*)sink.get((size_t)count * sizeof(uint32_t));
+            if (!st) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: status allocation failed");
+        }
+        if (trace) { (void)hipStreamSynchronize(stream); ms_upload = ms_since(t_up); }
+        const auto t_k = std::chrono::steady_clock::now();
+        const int n_items = (int)items.size(), n_huff = (int)huffs.size(), n_quant = (int)quants.size();
+        const dim3 grid((n_items + kEntropyThreads - 1) / kEntropyThreads), block(kEntropyThreads);
+        if (n_huff <= kLdsHuff && n_quant <= kLdsQuant)
+            hipLaunchKernelGGL(k_jpeg_entropy<true>, grid, block, 0, stream,
+                               (const DevItem*)(d + o_items), n_items, (const DevImage*)(d + o_img), (const DevHuff*)(d + o_huff), n_huff,
+                               (const int16_t*)(d + o_quant), n_quant, (const uint8_t*)(d + o_blob), d_coeffs, d_max_zag, st);
+        else
+            hipLaunchKernelGGL(k_jpeg_entropy<false>, grid, block, 0, stream,
+                               (const DevItem*)(d + o_items), n_items, (const DevImage*)(d + o_img), (const DevHuff*)(d + o_huff), n_huff,
+                               (const int16_t*)(d + o_quant), n_quant, (const uint8_t*)(d + o_blob), d_coeffs, d_max_zag, st);
+        if (int rc = launch_status("jpeg_entropy")) return rc;
+        GAMUT_HIP_CHECK(hipStreamSynchronize(stream));         // the pageable staging vector dies with this call
+        if (trace) fprintf(stderr, "[gamut_hip] jpeg_entropy_decode_device: %d files, %d lanes, %d+%d tables, %.1f MB compressed: parse %.1f ms, upload %.1f ms, kernel %.1f ms\n",
+                           count, n_items, n_huff, n_quant, blob.size() / 1e6, ms_parse, ms_upload, ms_since(t_k));
+    }
+    if (host_status) memcpy(host_status, hst.data(), (size_t)count * sizeof(int));
+    if (first_failure != GAMUT_HIP_OK) return set_error(first_failure, "%s", first_msg);
+    return GAMUT_HIP_OK;
+}
+
 } // namespace
 } // namespace gamut
 
@@ -554,6 +886,32 @@ int gamut_hip_jpeg_decode_coeffs_batch(const uint8_t* const* data, const size_t*
     for (const Failure& fl : fails) if (fl.code != GAMUT_HIP_OK && (!first || fl.index < first->index)) first = &fl;
     if (!first) { clear_error(); return GAMUT_HIP_OK; }
     return set_error(first->code, "image %d: %s", first->index, first->msg);
+}
+
+int gamut_hip_jpeg_read_header(const uint8_t* data, size_t len, gamut_hip_jpeg_frame* out)
+{
+    clear_error();
+    if (!out) return set_error(GAMUT_HIP_ERR_INVALID_ARG, "jpeg_read_header: null frame");
+    Parser* ps = new (std::nothrow) Parser();
+    if (!ps) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: out of memory");
+    const int rc = parse_baseline(*ps, data, len, out, false);
+    delete ps;
+    return rc;
+}
+
+int gamut_hip_jpeg_entropy_decode_device(const uint8_t* const* data, const size_t* len, int count,
+                                         const int64_t* coeff_offset, const int64_t* zag_offset,
+                                         int16_t* coeffs, uint8_t* max_zag, uint32_t* status_dev,
+                                         gamut_hip_jpeg_frame* info, int* status_host, void* stream)
+{
+    clear_error();
+    if (count < 0 || (count > 0 && (!data || !len || !coeff_offset || !zag_offset || !coeffs || !max_zag || !info)))
+        return set_error(GAMUT_HIP_ERR_INVALID_ARG, "jpeg_entropy_decode_device: bad arguments");
+    if (count == 0) return GAMUT_HIP_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return set_error(GAMUT_HIP_ERR_NO_DEVICE, "no HIP device available (libgamut_hip has no CPU fallback)");
+    return entropy_decode_device(data, len, count, coeff_offset, zag_offset, coeffs, max_zag, status_dev, info, status_host, pick_stream(stream));
 }
 
 void gamut_hip_jpeg_frame_free(gamut_hip_jpeg_frame* f)

@@ -149,6 +149,21 @@ typedef struct gamut_hip_jpeg_frame {
 } gamut_hip_jpeg_frame;
 int  gamut_hip_jpeg_decode_coeffs(const uint8_t* data, size_t len, gamut_hip_jpeg_frame* out);
 void gamut_hip_jpeg_frame_free(gamut_hip_jpeg_frame* f);
+/* header walk only (markers up to the first SOS): geometry and JFIF density; coeffs / max_zag stay NULL.  Lets a caller
+ * size and lay out device buffers: an image needs mcus_per_row * mcus_per_col * blocks_per_mcu blocks of 64 int16. */
+int  gamut_hip_jpeg_read_header(const uint8_t* data, size_t len, gamut_hip_jpeg_frame* out);
+/* Entropy decode ON THE DEVICE of `count` baseline files given in host memory: the compressed
+ * scans are uploaded as they are and one lane per image -- per restart interval where the file has them -- writes the
+ * dense de-quantised coefficient form (what decode_next_row, jpegload.d:2405-2525, leaves per MCU row) into
+ * coeffs[coeff_offset[i] ..] (int16 elements) and max_zag[zag_offset[i] ..] (device pointers, caller-sized from
+ * gamut_hip_jpeg_read_header).  info[i] receives the geometry (host), status_host[i] (may be NULL) the per-file header
+ * status -- GAMUT_HIP_ERR_UNSUPPORTED for progressive files, which stay with the host feeder -- and status_dev[i] (device,
+ * may be NULL) becomes non-zero if file i's entropy stream is corrupt.  Returns when the decode has finished on `stream`;
+ * the status of the lowest-numbered failing file, GAMUT_HIP_OK if none. */
+int  gamut_hip_jpeg_entropy_decode_device(const uint8_t* const* data, const size_t* len, int count,
+                                          const int64_t* coeff_offset, const int64_t* zag_offset,
+                                          int16_t* coeffs, uint8_t* max_zag, uint32_t* status_dev,
+                                          gamut_hip_jpeg_frame* info, int* status_host, void* stream);
 /* the same for `count` independent files on up to `threads` host threads (<= 0: one per hardware thread).  The reference
  * decodes one image at a time (the serial Huffman stage is what bounds a batch once the GPU stages
  * run at HBM speed).  status[i] (may be NULL) receives image i's status and out[i] its frame (zeroed on failure);

@@ -197,3 +197,96 @@ def test_host_dropin_decompress(hip, path):
     assert not hip.gamut_hip_decompress_jpeg_image_from_memory(buf.ctypes.data, 0, C.byref(w), C.byref(h), C.byref(ac),
                                                                 C.byref(par), C.byref(dpi), 4)
     assert hip.gamut_hip_last_error() != b""
+
+
+# ------------------------------------------------------------------ entropy decode on the device
+def _entropy_decode_device(L, blobs):
+    """-> (rc, host_status, dev_status, [(coeffs, max_zag) or None per file])"""
+    n = len(blobs)
+    bufs = [np.frombuffer(b, np.uint8) if len(b) else np.zeros(1, np.uint8) for b in blobs]
+    ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+    lens = (C.c_size_t * n)(*[len(b) for b in blobs])
+    hdr = (_capi.JpegFrame * n)()
+    nblk = []
+    for i in range(n):
+        rc = L.gamut_hip_jpeg_read_header(ptrs[i], lens[i], C.byref(hdr[i]))
+        nblk.append(hdr[i].mcus_per_row * hdr[i].mcus_per_col * hdr[i].blocks_per_mcu if rc == 0 else 0)
+        assert not hdr[i].coeffs and not hdr[i].max_zag
+    co_off = np.concatenate([[0], np.cumsum(nblk)[:-1]]).astype(np.int64) * 64
+    zz_off = np.concatenate([[0], np.cumsum(nblk)[:-1]]).astype(np.int64)
+    total = max(1, sum(nblk))
+    dco = dev_upload(L, np.full(total * 64, 0x5A5A, np.uint16))          # poisoned: the call must clear what it owns
+    dzz = dev_upload(L, np.full(total, 0xEE, np.uint8))
+    dst = dev_upload(L, np.full(n, 0xFFFFFFFF, np.uint32))
+    info = (_capi.JpegFrame * n)()
+    hst = (C.c_int * n)()
+    rc = L.gamut_hip_jpeg_entropy_decode_device(ptrs, lens, n, co_off.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                zz_off.ctypes.data_as(C.POINTER(C.c_int64)), dco, dzz, dst, info, hst, None)
+    co = np.empty(total * 64, np.int16); zz = np.empty(total, np.uint8); st = np.empty(n, np.uint32)
+    _capi.check(L.gamut_hip_memcpy_d2h(co.ctypes.data, dco, co.nbytes, None))
+    _capi.check(L.gamut_hip_memcpy_d2h(zz.ctypes.data, dzz, zz.nbytes, None))
+    _capi.check(L.gamut_hip_memcpy_d2h(st.ctypes.data, dst, st.nbytes, None))
+    _capi.check(L.gamut_hip_stream_synchronize(None))
+    for p in (dco, dzz, dst):
+        L.gamut_hip_device_free(p)
+    res = []
+    for i in range(n):
+        if hst[i] != 0:
+            res.append(None)
+        else:
+            res.append((co[co_off[i]:co_off[i] + nblk[i] * 64].reshape(-1, 64), zz[zz_off[i]:zz_off[i] + nblk[i]], info[i]))
+    return rc, list(hst), st, res
+
+
+def test_device_entropy_decode_matches_host_feeder(hip):
+    """every baseline fixture (all sampling modes, optimised tables, restart intervals) in ONE mixed batch: the coefficients
+    and max_zag the GPU lanes write == the oracle's feeder, bit for bit; progressive files are reported, not decoded."""
+    blobs = [open(p, "rb").read() for p in JPEGS]
+    rc, hst, st, res = _entropy_decode_device(hip, blobs)
+    n_prog = 0
+    for path, data, h, s, r in zip(JPEGS, blobs, hst, st, res):
+        if b"\xff\xc2" in data[:2000] and os.path.basename(path).startswith("p_"):
+            assert h == _capi.ERR_UNSUPPORTED and r is None
+            n_prog += 1
+            continue
+        assert h == 0 and s == 0, path
+        d = O.DecodedJpeg(data)
+        co, zz, info = r
+        assert (info.width, info.height, info.comps, info.scan_type) == (d.width, d.height, d.comps, d.scan_type)
+        assert np.array_equal(co, d.coeffs), path
+        assert np.array_equal(zz, d.max_zag), path
+    assert n_prog >= 6 and rc == _capi.ERR_UNSUPPORTED
+
+
+def test_device_entropy_decode_large_and_restart_parallel(hip):
+    """a 1080p file, and the same pixels with a restart marker every 2 MCU rows (one lane per interval)"""
+    import io
+    from PIL import Image
+    import gen
+    img = Image.fromarray(gen.synth_rgb(1920, 1080, 11))
+    blobs = []
+    for kw in (dict(quality=90, subsampling=2), dict(quality=90, subsampling=2, restart_marker_rows=2),
+               dict(quality=50, subsampling=0, optimize=True), dict(quality=95, subsampling=1, restart_marker_blocks=7)):
+        bio = io.BytesIO(); img.save(bio, "JPEG", **kw); blobs.append(bio.getvalue())
+    rc, hst, st, res = _entropy_decode_device(hip, blobs)
+    assert rc == 0 and hst == [0] * 4 and not st.any()
+    for data, (co, zz, info) in zip(blobs, res):
+        d = O.DecodedJpeg(data)
+        assert np.array_equal(co, d.coeffs) and np.array_equal(zz, d.max_zag)
+
+
+def test_device_entropy_decode_corrupt_streams(hip):
+    """damaged entropy data must neither hang nor write outside the image's buffers; header damage is a host-side status"""
+    good = open(os.path.join(HERE, "golden", "jpeg", "s_131x97_420.jpg"), "rb").read()
+    sos = good.index(b"\xff\xda")
+    rng = np.random.default_rng(3)
+    noisy = bytearray(good)
+    for k in rng.integers(sos + 20, len(good) - 2, 40):
+        noisy[k] = int(rng.integers(0, 255))
+    blobs = [good, good[:sos + 40], bytes(noisy), good[:100], b"", good]
+    rc, hst, st, res = _entropy_decode_device(hip, blobs)
+    assert hst[0] == 0 and hst[5] == 0 and st[0] == 0 and st[5] == 0
+    assert hst[3] == _capi.ERR_DECODE and hst[4] == _capi.ERR_DECODE and rc == _capi.ERR_DECODE
+    d = O.DecodedJpeg(good)
+    for i in (0, 5):                                   # neighbours of the damaged files are intact
+        assert np.array_equal(res[i][0], d.coeffs) and np.array_equal(res[i][1], d.max_zag)

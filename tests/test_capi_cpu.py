@@ -100,6 +100,23 @@ def test_jpeg_batch_feeder_threads():
     assert L.gamut_hip_jpeg_decode_coeffs_batch(None, None, 3, None, None, 2) == _capi.ERR_INVALID_ARG
 
 
+def test_jpeg_read_header_needs_no_device():
+    """gamut_hip_jpeg_read_header: geometry without entropy decoding (what a caller sizes its device buffers from)"""
+    L = _capi.lib()
+    for path in JPEGS:
+        data = open(path, "rb").read()
+        buf = np.frombuffer(data, np.uint8)
+        fr = _capi.JpegFrame()
+        _capi.check(L.gamut_hip_jpeg_read_header(buf.ctypes.data, buf.size, C.byref(fr)))
+        d = O.DecodedJpeg(data)
+        assert (fr.width, fr.height, fr.comps, fr.scan_type, fr.mcus_per_row, fr.mcus_per_col, fr.blocks_per_mcu) == \
+               (d.width, d.height, d.comps, d.scan_type, d.mcus_per_row, d.mcus_per_col, d.blocks_per_mcu)
+        assert not fr.coeffs and not fr.max_zag and (fr.pixel_aspect_ratio, fr.dpi_y) == (d.pixel_aspect_ratio, d.dpi_y)
+    fr = _capi.JpegFrame()
+    assert L.gamut_hip_jpeg_read_header(None, 0, C.byref(fr)) == _capi.ERR_DECODE
+    assert L.gamut_hip_jpeg_read_header(None, 0, None) == _capi.ERR_INVALID_ARG
+
+
 def test_jpeg_feeder_rejects_bad_streams():
     L = _capi.lib()
     fr = _capi.JpegFrame()
@@ -141,6 +158,9 @@ def test_no_gpu_means_loud_failure_not_fallback():
     f = C.c_float()
     assert not L.gamut_hip_stbi_load_from_memory(png.ctypes.data, png.size, C.byref(w), C.byref(h), C.byref(ac), 0, C.byref(f), C.byref(f), C.byref(f))
     assert b"no HIP device" in L.gamut_hip_last_error()
+    ptrs = (C.c_void_p * 1)(buf.ctypes.data); lens = (C.c_size_t * 1)(buf.size); off = (C.c_int64 * 1)(0)
+    info = (_capi.JpegFrame * 1)()
+    assert L.gamut_hip_jpeg_entropy_decode_device(ptrs, lens, 1, off, off, 0x1000, 0x1000, None, info, None, None) == _capi.ERR_NO_DEVICE
 
 
 def test_argument_validation_needs_no_device():

@@ -83,35 +83,39 @@ def main():
     wl = args.workload
     check = None
     if wl == "jpeg" or wl.startswith("jpeg:"):
-        oc = int(wl.split(":")[1]) if ":" in wl else 4          # jpeg[:out_comps]  (4 = rgba8 headline, 3 = rgb8, 1 = l8)
-        coeffs = synth.jpeg_coeff_batch(B, w, h, dev, seed=1 + rank)
+        jp = wl.split(":")                                       # jpeg[:out_comps[:scan_type]]
+        oc = int(jp[1]) if len(jp) > 1 else 4                    # 4 = rgba8 (headline), 3 = rgb8, 1 = l8
+        st = int(jp[2]) if len(jp) > 2 else 4                    # jpgd scan type: 4 = 4:2:0 (headline), 2 = 4:2:2, 1 = 4:4:4, 0 = grey
+        comps_in = 1 if st == 0 else 3
+        coeffs = synth.jpeg_coeff_batch(B, w, h, dev, seed=1 + rank, scan_type=st)
         nblk = coeffs.shape[1]
         out = torch.empty((B, h, w * oc), dtype=torch.uint8, device=dev)
         px_per_step = B * w * h
         bytes_per_step = B * (nblk * 128 + w * h * oc)           # 6 266 880 + 8 294 400 per 1080p image (rgba8)
-        kernel_name = "k_jpeg_h2v2"
-        workload = f"batch {B} x {w}x{h} baseline JPEG 4:2:0, IDCT + freq-domain chroma upsample + YCbCr->{ {4: 'RGBA8', 3: 'RGB8', 1: 'L8'}[oc] }"
+        kernel_name = "k_jpeg_h2v2" if st == 4 else "k_jpeg_"
+        workload = (f"batch {B} x {w}x{h} baseline JPEG { {4: '4:2:0', 2: '4:2:2', 1: '4:4:4', 0: 'grey'}[st] }, IDCT"
+                    f"{' + freq-domain chroma upsample' if st == 4 else ''} + YCbCr->{ {4: 'RGBA8', 3: 'RGB8', 1: 'L8'}[oc] }")
 
         def step():
             _capi.check(L.gamut_hip_jpeg_reconstruct_batch_device(coeffs.data_ptr(), nblk * 64, None, 0, out.data_ptr(), w * oc,
-                                                                   h * w * oc, w, h, 4, oc, B, stream))
+                                                                   h * w * oc, w, h, st, oc, B, stream))
 
         def check():
             import oracle_lib as O
             step()
             torch.cuda.synchronize()
             for i in sorted({0, B - 1}):
-                exp = O.jpeg_reconstruct(w, h, 3, O.JPGD_YH2V2, coeffs[i].cpu().numpy(), None, oc)
+                exp = O.jpeg_reconstruct(w, h, comps_in, st, coeffs[i].cpu().numpy(), None, oc)
                 if not np.array_equal(out[i].cpu().numpy(), exp):
                     raise SystemExit(f"PARITY FAILURE on image {i}")
 
         def cpu_leg(seconds):
             import oracle_lib as O
             host = [coeffs[i].cpu().numpy() for i in range(min(B, 64))]
-            O.jpeg_reconstruct(w, h, 3, O.JPGD_YH2V2, host[0], None, oc)          # warm
+            O.jpeg_reconstruct(w, h, comps_in, st, host[0], None, oc)             # warm
             n, t0 = 0, time.perf_counter()
             while time.perf_counter() - t0 < seconds:
-                O.jpeg_reconstruct(w, h, 3, O.JPGD_YH2V2, host[n % len(host)], None, oc)
+                O.jpeg_reconstruct(w, h, comps_in, st, host[n % len(host)], None, oc)
                 n += 1
             dt = time.perf_counter() - t0
             return n * w * h / dt / 1e6, f"{n} of the batch's {w}x{h} coefficient frames, coefficients -> pixels, single thread, {dt:.1f} s"

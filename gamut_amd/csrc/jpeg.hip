@@ -17,6 +17,7 @@
 //       between the row and the column pass, and the hand-off between the
 //       upsample stages, go through LDS (padded to be bank-conflict free); the
 //       VALU does only arithmetic.
+//   k_jpeg_plain<ST,OC> -- tuned grey / 4:4:4 / 4:2:2 (two-pass IDCT as above, four pixels per thread in the colour stage).
 //   k_jpeg_generic     -- every sampling mode (grey, H1V1, H2V1, H1V2, H2V2) and
 //       every output format (l8 / rgb8 / rgba8): one thread per coefficient block
 //       into an LDS sample buffer, then one thread per pixel.  Correct, untuned.
@@ -266,6 +267,114 @@ __global__ __launch_bounds__(256) void k_jpeg_h2v2(JpegArgs a)
 }
 
 // =============================================================================
+// tuned grey / 4:4:4 / 4:2:2 (no frequency-domain upsample: H1V1Convert :2528-2555, H2V1Convert :2558-2600,
+// gray_convert :2715-2728 replicate chroma samples)
+// =============================================================================
+// A workgroup reconstructs a strip of 8 MCUs (32 for grey): the same two-pass IDCT as above (thread = block x row, then
+// block x column, 8x8 transposes through LDS), samples dropped into an LDS byte buffer [block][row][col], then one thread
+// per group of four horizontally adjacent pixels: whole-dword sample reads, four pixels packed into 16 / 12 / 4 bytes and
+// stored with lane-contiguous addresses (16 lanes cover one row of the strip).
+struct __attribute__((packed, aligned(4))) Dwords4 { u32 v[4]; };
+struct __attribute__((packed, aligned(1))) Dwords3 { u32 v[3]; };
+struct __attribute__((packed, aligned(1))) Dword1 { u32 v; };
+
+template <int ST, int OC>
+__global__ __launch_bounds__(256) void k_jpeg_plain(JpegArgs a)
+{
+    static_assert(ST == GAMUT_JPGD_GRAYSCALE || ST == GAMUT_JPGD_YH1V1 || ST == GAMUT_JPGD_YH2V1, "sampling mode");
+    constexpr int BPM  = ST == GAMUT_JPGD_GRAYSCALE ? 1 : ST == GAMUT_JPGD_YH1V1 ? 3 : 4;
+    constexpr int MCUS = ST == GAMUT_JPGD_GRAYSCALE ? 32 : 8;
+    constexpr int NBLK = MCUS * BPM;                              // 32 / 24 / 32 blocks = NBLK * 8 working threads
+    constexpr int MW   = ST == GAMUT_JPGD_YH2V1 ? 16 : 8;
+    constexpr int SW   = MCUS * MW;                               // strip width in pixels: 256 / 64 / 128
+    __shared__ __attribute__((aligned(16))) i32 T1[NBLK * BLK_STRIDE];
+    __shared__ __attribute__((aligned(16))) uint8_t S[NBLK * 64];
+
+    const int t = threadIdx.x;
+    const int img = blockIdx.z, mcu_y = blockIdx.y, mcu_x0 = blockIdx.x * MCUS;
+    const int64_t blk0 = ((int64_t)mcu_y * a.mcus_per_row + mcu_x0) * BPM;
+    const int16_t* cbase = a.coeffs + (int64_t)img * a.coeff_stride + blk0 * 64;
+    const int mcus_here = min(MCUS, a.mcus_per_row - mcu_x0);
+    const int b = t >> 3, r = t & 7;
+    const bool blk_live = b < mcus_here * BPM;
+
+    if (t < NBLK * 8) {
+        uint4 row = make_uint4(0, 0, 0, 0);
+        if (blk_live) row = *reinterpret_cast<const uint4*>(cbase + (u32)(t * 8));       // block b, row r: lane-contiguous
+        i32 x[8], tv[8];
+        unpack_row(row, x);
+        row_pass<8>(x, tv);
+        i32* dst = T1 + b * BLK_STRIDE + r * 8;
+        *reinterpret_cast<int4*>(dst)     = make_int4(tv[0], tv[1], tv[2], tv[3]);
+        *reinterpret_cast<int4*>(dst + 4) = make_int4(tv[4], tv[5], tv[6], tv[7]);
+    }
+    wave_sync();                                                  // a block's 8 threads sit in one wave
+    if (t < NBLK * 8) {
+        i32 tv[8], sm[8];
+        const i32* src = T1 + b * BLK_STRIDE + r;
+        #pragma unroll
+        for (int i = 0; i < 8; ++i) tv[i] = src[i * 8];
+        col_pass<8>(tv, sm);
+        if (a.max_zag) {                                          // wave-uniform: Col!(1) shortcut, see the 4:2:0 kernel
+            bool col1 = false;
+            if (blk_live) col1 = a.max_zag[(int64_t)img * a.zag_stride + blk0 + b] <= 2;
+            const i32 v = col1_sample(tv[0]);
+            #pragma unroll
+            for (int i = 0; i < 8; ++i) sm[i] = col1 ? v : sm[i];
+        }
+        #pragma unroll
+        for (int i = 0; i < 8; ++i) S[b * 64 + i * 8 + r] = (uint8_t)sm[i];
+    }
+    __syncthreads();
+
+    uint8_t* obase = a.out + (int64_t)img * a.out_stride + (int64_t)(mcu_y * 8) * a.out_pitch + (int64_t)mcu_x0 * (MW * OC);
+    const int rows_here = min(8, a.height - mcu_y * 8);
+    const int px_here = min(mcus_here * MW, a.width - mcu_x0 * MW);             // live pixels of a strip row
+    constexpr int GPR = SW / 4;                                   // groups of 4 pixels per strip row
+    for (int g = t; g < GPR * 8; g += 256) {
+        const int y = g / GPR, x0 = (g - y * GPR) * 4;
+        if (y >= rows_here || x0 >= px_here) continue;
+        const int m = x0 / MW, xin = x0 - m * MW;
+        u32 ys, px[4];
+        if constexpr (ST == GAMUT_JPGD_GRAYSCALE) {
+            ys = *reinterpret_cast<const u32*>(S + m * 64 + y * 8 + xin);
+        } else if constexpr (ST == GAMUT_JPGD_YH1V1) {
+            const uint8_t* sp = S + m * 192 + y * 8 + xin;
+            ys = *reinterpret_cast<const u32*>(sp);
+            const u32 cbs = *reinterpret_cast<const u32*>(sp + 64), crs = *reinterpret_cast<const u32*>(sp + 128);
+            #pragma unroll
+            for (int j = 0; j < 4; ++j) px[j] = ycc_to_rgba((ys >> (8 * j)) & 255, (cbs >> (8 * j)) & 255, (crs >> (8 * j)) & 255);
+        } else {
+            const uint8_t* mp = S + m * 256;
+            ys = *reinterpret_cast<const u32*>(mp + (xin >> 3) * 64 + y * 8 + (xin & 7));
+            const u32 cbs = *reinterpret_cast<const uint16_t*>(mp + 128 + y * 8 + (xin >> 1));
+            const u32 crs = *reinterpret_cast<const uint16_t*>(mp + 192 + y * 8 + (xin >> 1));
+            #pragma unroll
+            for (int j = 0; j < 4; ++j) px[j] = ycc_to_rgba((ys >> (8 * j)) & 255, (cbs >> (8 * (j >> 1))) & 255, (crs >> (8 * (j >> 1))) & 255);
+        }
+        uint8_t* o = obase + (int64_t)y * a.out_pitch + (int64_t)x0 * OC;
+        const int npx = min(4, px_here - x0);
+        u32 w[4];                                                 // the group's OC * 4 output bytes
+        if constexpr (ST == GAMUT_JPGD_GRAYSCALE) {               // grey replicated, alpha 255 (:3761-3801)
+            if constexpr (OC == 1) w[0] = ys;
+            else if constexpr (OC == 3) { w[0] = __builtin_amdgcn_perm(ys, ys, 0x01000000u); w[1] = __builtin_amdgcn_perm(ys, ys, 0x02020101u); w[2] = __builtin_amdgcn_perm(ys, ys, 0x03030302u); }
+            else { w[0] = __builtin_amdgcn_perm(ys, ys, 0x0d000000u); w[1] = __builtin_amdgcn_perm(ys, ys, 0x0d010101u); w[2] = __builtin_amdgcn_perm(ys, ys, 0x0d020202u); w[3] = __builtin_amdgcn_perm(ys, ys, 0x0d030303u); }
+        } else {
+            if constexpr (OC == 4) { w[0] = px[0]; w[1] = px[1]; w[2] = px[2]; w[3] = px[3]; }
+            else if constexpr (OC == 3) { w[0] = __builtin_amdgcn_perm(px[1], px[0], 0x04020100u); w[1] = __builtin_amdgcn_perm(px[2], px[1], 0x05040201u); w[2] = __builtin_amdgcn_perm(px[3], px[2], 0x06050402u); }
+            else w[0] = rgb_to_luma(px[0]) | (rgb_to_luma(px[1]) << 8) | (rgb_to_luma(px[2]) << 16) | (rgb_to_luma(px[3]) << 24);
+        }
+        if (npx == 4) {
+            if constexpr (OC == 4)      { Dwords4 d; d.v[0] = w[0]; d.v[1] = w[1]; d.v[2] = w[2]; d.v[3] = w[3]; *reinterpret_cast<Dwords4*>(o) = d; }
+            else if constexpr (OC == 3) { Dwords3 d; d.v[0] = w[0]; d.v[1] = w[1]; d.v[2] = w[2]; *reinterpret_cast<Dwords3*>(o) = d; }
+            else                        { Dword1 d; d.v = w[0]; *reinterpret_cast<Dword1*>(o) = d; }
+        } else {
+            for (int k = 0; k < npx * OC; ++k) o[k] = (uint8_t)(w[k >> 2] >> ((k & 3) * 8));
+        }
+    }
+}
+
+// =============================================================================
 // generic: all sampling modes, all output formats
 // =============================================================================
 // full dense IDCT of one block held by one thread (jpegload.d:308-376 without the sparse dispatch)
@@ -446,13 +555,22 @@ int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
         c.coeffs += (int64_t)i0 * coeff_stride; c.out += (int64_t)i0 * out_stride;
         if (c.max_zag) c.max_zag += (int64_t)i0 * zag_stride;
         const dim3 grid(tiles, a.mcus_per_col, n);
-        // tuned 4:2:0 kernel: rgba8 needs dword-aligned rows; rgb8 / l8 rows may start anywhere (unaligned dword stores)
-        const bool tuned = scan_type == GAMUT_JPGD_YH2V2 && out_pitch > 0 && out_pitch < (1 << 27) &&
+        // tuned kernels: rgba8 needs dword-aligned rows; rgb8 / l8 rows may start anywhere (unaligned dword stores)
+        const bool tuned = out_pitch > 0 && out_pitch < (1 << 27) && scan_type != GAMUT_JPGD_YH1V2 &&
                            (out_comps != 4 || (((uintptr_t)out & 3) == 0 && (out_pitch & 3) == 0 && (out_stride & 3) == 0));
-        if (!tuned)              hipLaunchKernelGGL(k_jpeg_generic, grid, dim3(256), 0, stream, c);
+        const dim3 grid32((a.mcus_per_row + 31) / 32, a.mcus_per_col, n);           // grey: 32 MCUs per workgroup
+#define GAMUT_JPEG_PLAIN(ST, G) do { \
+            if (out_comps == 4)      hipLaunchKernelGGL((k_jpeg_plain<ST, 4>), G, dim3(256), 0, stream, c); \
+            else if (out_comps == 3) hipLaunchKernelGGL((k_jpeg_plain<ST, 3>), G, dim3(256), 0, stream, c); \
+            else                     hipLaunchKernelGGL((k_jpeg_plain<ST, 1>), G, dim3(256), 0, stream, c); } while (0)
+        if (!tuned)                                   hipLaunchKernelGGL(k_jpeg_generic, grid, dim3(256), 0, stream, c);
+        else if (scan_type == GAMUT_JPGD_GRAYSCALE)   GAMUT_JPEG_PLAIN(GAMUT_JPGD_GRAYSCALE, grid32);
+        else if (scan_type == GAMUT_JPGD_YH1V1)       GAMUT_JPEG_PLAIN(GAMUT_JPGD_YH1V1, grid);
+        else if (scan_type == GAMUT_JPGD_YH2V1)       GAMUT_JPEG_PLAIN(GAMUT_JPGD_YH2V1, grid);
         else if (out_comps == 4) hipLaunchKernelGGL(k_jpeg_h2v2<4>, grid, dim3(256), 0, stream, c);
         else if (out_comps == 3) hipLaunchKernelGGL(k_jpeg_h2v2<3>, grid, dim3(256), 0, stream, c);
         else                     hipLaunchKernelGGL(k_jpeg_h2v2<1>, grid, dim3(256), 0, stream, c);
+#undef GAMUT_JPEG_PLAIN
         if (int rc = launch_status("jpeg_reconstruct")) return rc;
     }
     return GAMUT_HIP_OK;

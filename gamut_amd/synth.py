@@ -47,13 +47,16 @@ def synth_rgb_batch(n, width, height, device, seed):
     return img.clamp_(0, 255).floor_()
 
 
-def jpeg_coeff_batch(n, width, height, device, seed=0, quality=90, chunk=16):
-    """Dense de-quantised coefficients of n synthetic 4:2:0 images: int16 tensor (n, MY*MX*6, 64)."""
-    my, mx = (height + 15) // 16, (width + 15) // 16
-    hp, wp = my * 16, mx * 16
+def jpeg_coeff_batch(n, width, height, device, seed=0, quality=90, chunk=16, scan_type=4):
+    """Dense de-quantised coefficients of n synthetic images: int16 tensor (n, MY*MX*blocks_per_mcu, 64), blocks in MCU
+    order.  scan_type (jpgd's): 4 = 4:2:0 (default), 2 = 4:2:2 (H2V1), 1 = 4:4:4 (H1V1), 0 = grey."""
+    hs, vs = {0: (1, 1), 1: (1, 1), 2: (2, 1), 4: (2, 2)}[scan_type]
+    my, mx = (height + 8 * vs - 1) // (8 * vs), (width + 8 * hs - 1) // (8 * hs)
+    hp, wp = my * 8 * vs, mx * 8 * hs
+    nb = hs * vs + (2 if scan_type else 0)
     d = _dct_matrix(device)
     ql, qc = _qtable(_LUMA_Q, quality, device), _qtable(_CHROMA_Q, quality, device)
-    out = torch.empty((n, my * mx * 6, 64), dtype=torch.int16, device=device)
+    out = torch.empty((n, my * mx * nb, 64), dtype=torch.int16, device=device)
     for i0 in range(0, n, chunk):
         c = min(chunk, n - i0)
         rgb = synth_rgb_batch(c, width, height, device, seed * 1000003 + i0)
@@ -62,8 +65,9 @@ def jpeg_coeff_batch(n, width, height, device, seed=0, quality=90, chunk=16):
         y = 0.299 * r + 0.587 * g + 0.114 * b - 128.0
         cb = -0.168736 * r - 0.331264 * g + 0.5 * b
         cr = 0.5 * r - 0.418688 * g - 0.081312 * b
-        cb = torch.nn.functional.avg_pool2d(cb[:, None], 2)[:, 0]
-        cr = torch.nn.functional.avg_pool2d(cr[:, None], 2)[:, 0]
+        if hs * vs > 1:
+            cb = torch.nn.functional.avg_pool2d(cb[:, None], (vs, hs))[:, 0]
+            cr = torch.nn.functional.avg_pool2d(cr[:, None], (vs, hs))[:, 0]
 
         def fdct_quant(p, q):
             cc, h, w = p.shape
@@ -71,10 +75,11 @@ def jpeg_coeff_batch(n, width, height, device, seed=0, quality=90, chunk=16):
             f = d @ blk @ d.T
             return (torch.round(f / q) * q).clamp_(-32768, 32767).to(torch.int16)
 
-        yb = fdct_quant(y, ql).reshape(c, my, 2, mx, 2, 64).permute(0, 1, 3, 2, 4, 5).reshape(c, my, mx, 4, 64)
-        cbb = fdct_quant(cb, qc).reshape(c, my, mx, 1, 64)
-        crb = fdct_quant(cr, qc).reshape(c, my, mx, 1, 64)
-        out[i0:i0 + c] = torch.cat([yb, cbb, crb], dim=3).reshape(c, my * mx * 6, 64)
+        yb = fdct_quant(y, ql).reshape(c, my, vs, mx, hs, 64).permute(0, 1, 3, 2, 4, 5).reshape(c, my, mx, hs * vs, 64)
+        parts = [yb]
+        if scan_type:
+            parts += [fdct_quant(cb, qc).reshape(c, my, mx, 1, 64), fdct_quant(cr, qc).reshape(c, my, mx, 1, 64)]
+        out[i0:i0 + c] = torch.cat(parts, dim=3).reshape(c, my * mx * nb, 64)
     return out
 
 

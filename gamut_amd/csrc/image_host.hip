@@ -7,7 +7,8 @@
 //   allocatePixelStorage         internals/types.d:355-540      (border / trailing / multiplicity / alignment / v-flip / bonus bytes)
 //   layout constraint helpers    internals/types.d:166-289
 //   load flags                   internals/types.d:563-661, types.d:351-602
-//   loadFromMemory               image.d:886-901, 1751-1772 ; loadJPEG plugins/jpeg.d:42-104 ; loadPNG plugins/png.d:44-163
+//   loadFromMemory               image.d:886-901, 1751-1772 ; loadJPEG plugins/jpeg.d:42-104 ; loadPNG plugins/png.d:44-163 ;
+//                                loadQOI plugins/qoi.d:47-141
 //   convertTo                    image.d:1180-1332 ; getAdHocLayoutConstraints :1809-1905
 //
 // Pixel storage is host malloc memory, as in the reference.  Every pixel operation goes to the GPU through
@@ -308,6 +309,22 @@ struct gamut_image {
               ppmY == -1 ? -1.0f : ppmY / 39.37007874f);                                    // convertInchesToMeters (types.d:126-129)
         convertTo(applyLoadFlags(_type, flags), flags & 0xFFFF);
     }
+    void loadQOI(const uint8_t* bytes, size_t len, int flags)                               // plugins/qoi.d:47-141
+    {
+        int requested = computeRequestedImageComponents(flags);
+        if (requested == 0) { error(kStrInvalidFlags); return; }
+        if (requested == -1 || requested == 1 || requested == 2) requested = 0;             // the QOI decoder only makes RGB / RGBA (:81-83)
+        gamut_hip_qoi_desc desc;
+        uint8_t* decoded = (uint8_t*)gamut_hip_qoi_decode(bytes, (int)len, &desc, requested);
+        if (!decoded) { error(kStrImageDecodingFailed); return; }
+        if (!imageIsValidSize(1, (int)desc.width, (int)desc.height)) { error(kStrImageTooLarge); free(decoded); return; }
+        const int comps = requested == 0 ? desc.channels : requested;
+        // _pitch = desc.channels * desc.width (:133): the FILE's channel count, also when another count was requested --
+        // kept as the reference has it
+        adopt(decoded, (int)desc.width, (int)desc.height, comps == 3 ? GAMUT_PIXEL_rgb8 : GAMUT_PIXEL_rgba8, desc.channels, -1.0f, -1.0f);
+        _layoutConstraints = 0;
+        convertTo(applyLoadFlags(_type, flags), flags & 0xFFFF);
+    }
 };
 
 static int identify(const uint8_t* b, size_t len)
@@ -315,6 +332,7 @@ static int identify(const uint8_t* b, size_t len)
     static const uint8_t png[8] = { 0x89, 0x50, 0x4e, 0x47, 0x0d, 0x0a, 0x1a, 0x0a };
     if (b && len >= 2 && b[0] == 0xFF && b[1] == 0xD8) return GAMUT_FORMAT_JPEG;            // detectJPEG plugins/jpeg.d:106-110
     if (b && len >= 8 && !memcmp(b, png, 8)) return GAMUT_FORMAT_PNG;                       // detectPNG plugins/png.d:165-169
+    if (b && len >= 4 && !memcmp(b, "qoif", 4)) return GAMUT_FORMAT_QOI;                    // detectQOI plugins/qoi.d:144-148
     return GAMUT_FORMAT_unknown;
 }
 
@@ -362,6 +380,7 @@ int gamut_image_load_from_memory(gamut_image* img, const uint8_t* bytes, size_t 
     switch (identify(bytes, len)) {
     case GAMUT_FORMAT_JPEG: img->loadJPEG(bytes, len, flags); break;
     case GAMUT_FORMAT_PNG:  img->loadPNG(bytes, len, flags); break;
+    case GAMUT_FORMAT_QOI:  img->loadQOI(bytes, len, flags); break;
     default: img->error(kStrImageFormatUnidentified); break;
     }
     return img->isValid();

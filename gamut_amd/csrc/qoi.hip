@@ -1,0 +1,165 @@
+// qoi.hip -- QOI decode (needed for the mixed JPEG/PNG/QOI batch of BASELINE.json config 5).
+//
+// Replaces qoi_decode (source/gamut/codecs/qoi.d:448-550).  The format is a byte-serial state machine (previous pixel,
+// 64-entry colour hash, run counter): nothing to parallelise inside a stream, so the parallelism is the batch -- one
+// lane per image.  The lane's hash table lives in LDS (lane-interleaved, so the 64 lanes of a wave hit 64 different
+// banks x 2), the stream is read byte-wise through L1, pixels are written as they come.  The host only validates the
+// 14-byte header (same checks as :472-480) and uploads the streams as they are.
+#include "common.hpp"
+#include <vector>
+
+namespace gamut {
+namespace {
+
+constexpr uint32_t kQoiMagic = 0x716F6966u, kQoiPixelsMax = 400000000u;      // qoi.d:244, :251
+constexpr int kQoiHeader = 14, kQoiPadding = 8;                                // :245, :268
+
+struct QoiItem { uint64_t begin; int64_t out_off; uint32_t size, npx; int32_t channels, pad; };
+
+__global__ __launch_bounds__(64) void k_qoi_decode(const QoiItem* items, int n, const uint8_t* blob, uint8_t* out)
+{
+    __shared__ uint32_t index[64 * 64];                       // [hash][lane]
+    const int lane = threadIdx.x;
+    #pragma unroll 8
+    for (int k = 0; k < 64; ++k) index[k * 64 + lane] = 0;    // memset(index, 0) :491  (a lane only touches its own column)
+    const int i = blockIdx.x * 64 + lane;
+    if (i >= n) return;
+    const QoiItem it = items[i];
+    const uint8_t* bytes = blob + it.begin;
+    uint8_t* pixels = out + it.out_off;
+    uint32_t r = 0, g = 0, b = 0, a = 255;                    // :492-495
+    int p = kQoiHeader, run = 0;
+    const int chunks_len = (int)it.size - kQoiPadding;
+    for (uint32_t px = 0; px < it.npx; ++px) {
+        if (run > 0) --run;
+        else if (p < chunks_len) {
+            const uint32_t b1 = bytes[p++];
+            if (b1 == 0xFE)      { r = bytes[p++]; g = bytes[p++]; b = bytes[p++]; }                        // QOI_OP_RGB
+            else if (b1 == 0xFF) { r = bytes[p++]; g = bytes[p++]; b = bytes[p++]; a = bytes[p++]; }        // QOI_OP_RGBA
+            else if ((b1 & 0xC0) == 0x00) { const uint32_t v = index[b1 * 64 + lane]; r = v & 255; g = (v >> 8) & 255; b = (v >> 16) & 255; a = v >> 24; }
+            else if ((b1 & 0xC0) == 0x40) { r = (r + ((b1 >> 4) & 3) - 2) & 255; g = (g + ((b1 >> 2) & 3) - 2) & 255; b = (b + (b1 & 3) - 2) & 255; }
+            else if ((b1 & 0xC0) == 0x80) {
+                const uint32_t b2 = bytes[p++]; const int vg = (int)(b1 & 0x3f) - 32;
+                r = (r + vg - 8 + ((b2 >> 4) & 0x0f)) & 255; g = (g + vg) & 255; b = (b + vg - 8 + (b2 & 0x0f)) & 255;
+            } else run = (int)(b1 & 0x3f);                                                                 // QOI_OP_RUN
+            index[((r * 3 + g * 5 + b * 7 + a * 11) & 63) * 64 + lane] = r | g << 8 | b << 16 | a << 24;    // QOI_COLOR_HASH :239-242
+        }
+        if (it.channels == 4) { uint32_t v = r | g << 8 | b << 16 | a << 24; __builtin_memcpy(pixels + (size_t)px * 4, &v, 4); }
+        else { uint8_t* o = pixels + (size_t)px * 3; o[0] = (uint8_t)r; o[1] = (uint8_t)g; o[2] = (uint8_t)b; }
+    }
+}
+
+inline uint32_t be32(const uint8_t* p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
+
+// header checks of qoi_decode :458-480; 0 = ok
+int read_header(const uint8_t* data, int size, gamut_hip_qoi_desc* d, int channels)
+{
+    memset(d, 0, sizeof(*d));
+    if ((channels != 0 && channels != 3 && channels != 4) || !data || size < kQoiHeader + kQoiPadding)
+        return set_error(GAMUT_HIP_ERR_DECODE, "qoi: invalid arguments or truncated file");
+    const uint32_t magic = be32(data);
+    d->width = be32(data + 4); d->height = be32(data + 8); d->channels = data[12]; d->colorspace = data[13];
+    if (d->width == 0 || d->height == 0 || d->channels < 3 || d->channels > 4 || d->colorspace > 1 || magic != kQoiMagic ||
+        d->height >= kQoiPixelsMax / d->width)
+        return set_error(GAMUT_HIP_ERR_DECODE, "qoi: bad header");
+    return GAMUT_HIP_OK;
+}
+
+struct Staging {                      // per-thread device staging, grown on demand
+    void* dev = nullptr; size_t cap = 0;
+    void* get(size_t n)
+    {
+        if (n > cap) {
+            if (dev) { (void)hipDeviceSynchronize(); (void)hipFree(dev); dev = nullptr; cap = 0; }
+            if (hipMalloc(&dev, n + n / 4 + 4096) != hipSuccess) { dev = nullptr; return nullptr; }
+            cap = n + n / 4 + 4096;
+        }
+        return dev;
+    }
+};
+
+int decode_batch(const uint8_t* const* data, const int* size, int count, int channels, const int64_t* out_offset, uint8_t* d_out,
+                 gamut_hip_qoi_desc* descs, int* status_host, hipStream_t stream)
+{
+    std::vector<QoiItem> items; std::vector<uint8_t> blob;
+    int first = GAMUT_HIP_OK, first_idx = -1;
+    for (int i = 0; i < count; ++i) {
+        const int rc = read_header(data[i], size[i], &descs[i], channels);
+        if (status_host) status_host[i] = rc;
+        if (rc != GAMUT_HIP_OK) { if (first == GAMUT_HIP_OK) { first = rc; first_idx = i; } continue; }
+        QoiItem it{}; it.begin = blob.size(); it.out_off = out_offset[i]; it.size = (uint32_t)size[i];
+        it.npx = descs[i].width * descs[i].height; it.channels = channels ? channels : descs[i].channels;
+        items.push_back(it);
+        blob.insert(blob.end(), data[i], data[i] + size[i]);
+    }
+    if (!items.empty()) {
+        const size_t o_blob = (items.size() * sizeof(QoiItem) + 255) & ~(size_t)255, total = o_blob + blob.size();
+        static thread_local Staging staging;
+        uint8_t* d = (uint8_t*)staging.get(total);
+        if (!d) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "qoi: device staging allocation of %zu bytes failed", total);
+        GAMUT_HIP_CHECK(hipMemcpyAsync(d, items.data(), items.size() * sizeof(QoiItem), hipMemcpyHostToDevice, stream));
+        GAMUT_HIP_CHECK(hipMemcpyAsync(d + o_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, stream));
+        const int n = (int)items.size();
+        hipLaunchKernelGGL(k_qoi_decode, dim3((n + 63) / 64), dim3(64), 0, stream, (const QoiItem*)d, n, (const uint8_t*)(d + o_blob), d_out);
+        if (int rc = launch_status("qoi_decode")) return rc;
+        GAMUT_HIP_CHECK(hipStreamSynchronize(stream));         // the pageable staging vectors die with this call
+    }
+    if (first != GAMUT_HIP_OK) return set_error(first, "image %d: qoi: bad header or arguments", first_idx);
+    return GAMUT_HIP_OK;
+}
+
+} // namespace
+} // namespace gamut
+
+using namespace gamut;
+
+extern "C" {
+
+int gamut_hip_qoi_read_header(const void* data, int size, gamut_hip_qoi_desc* desc)
+{
+    clear_error();
+    if (!desc) return set_error(GAMUT_HIP_ERR_INVALID_ARG, "qoi_read_header: null desc");
+    return read_header((const uint8_t*)data, size, desc, 0);
+}
+
+int gamut_hip_qoi_decode_batch_device(const uint8_t* const* data, const int* size, int count, int channels,
+                                      const int64_t* out_offset, uint8_t* out, gamut_hip_qoi_desc* descs, int* status_host, void* stream)
+{
+    clear_error();
+    if (count < 0 || (count > 0 && (!data || !size || !out_offset || !out || !descs)))
+        return set_error(GAMUT_HIP_ERR_INVALID_ARG, "qoi_decode_batch_device: bad arguments");
+    if (count == 0) return GAMUT_HIP_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return set_error(GAMUT_HIP_ERR_NO_DEVICE, "no HIP device available (libgamut_hip has no CPU fallback)");
+    return decode_batch(data, size, count, channels, out_offset, out, descs, status_host, pick_stream(stream));
+}
+
+// drop-in for qoi_decode (qoi.d:448): malloc'd pixels or NULL
+void* gamut_hip_qoi_decode(const void* data, int size, gamut_hip_qoi_desc* desc, int channels)
+{
+    clear_error();
+    gamut_hip_qoi_desc local;
+    if (!desc) desc = &local;
+    if (read_header((const uint8_t*)data, size, desc, channels) != GAMUT_HIP_OK) return nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_error(GAMUT_HIP_ERR_NO_DEVICE, "no HIP device available (libgamut_hip has no CPU fallback)"); return nullptr; }
+    const int ch = channels ? channels : desc->channels;
+    const size_t bytes = (size_t)desc->width * desc->height * ch;
+    uint8_t* result = (uint8_t*)malloc(bytes ? bytes : 1);
+    void* dout = nullptr;
+    if (!result) { set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "qoi: out of memory"); return nullptr; }
+    bool ok = hipMalloc(&dout, bytes ? bytes : 1) == hipSuccess;
+    if (!ok) set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "qoi: hipMalloc(%zu) failed", bytes);
+    const uint8_t* ptr = (const uint8_t*)data; const int64_t off = 0;
+    hipStream_t st = thread_stream();
+    ok = ok && decode_batch(&ptr, &size, 1, channels, &off, (uint8_t*)dout, desc, nullptr, st) == GAMUT_HIP_OK;
+    if (ok && (hipMemcpyAsync(result, dout, bytes, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) {
+        set_error(GAMUT_HIP_ERR_HIP, "qoi: copy back failed"); ok = false;
+    }
+    if (dout) (void)hipFree(dout);
+    if (!ok) { free(result); return nullptr; }
+    return result;
+}
+
+} // extern "C"

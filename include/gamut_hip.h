@@ -211,6 +211,18 @@ uint16_t* gamut_hip_stbi_load_16_from_memory(const uint8_t* data, size_t len, in
 /* stbi__png_is16 (stbdec.d:2091-2109) */
 int gamut_hip_png_is16(const uint8_t* data, size_t len);
 
+/* ---- QOI (codecs/qoi.d) -- SURVEY.md 8f row N4 ---------------------------------------------------------------- */
+typedef struct gamut_hip_qoi_desc { uint32_t width, height; uint8_t channels, colorspace; } gamut_hip_qoi_desc;   /* qoi_desc, decode fields */
+/* drop-in for qoi_decode (qoi.d:448-550): channels = 0 (as in the file), 3 or 4; malloc'd width*height*channels bytes, or
+ * NULL with the same header checks (:458-480).  Decoded on the GPU (one lane per stream). */
+void* gamut_hip_qoi_decode(const void* data, int size, gamut_hip_qoi_desc* desc, int channels);
+/* header only (host) */
+int   gamut_hip_qoi_read_header(const void* data, int size, gamut_hip_qoi_desc* desc);
+/* batch: `count` streams in host memory -> pixels at out + out_offset[i] (device), one lane per image.  descs[i] (host)
+ * receives the headers, status_host[i] (may be NULL) the per-file header status.  Returns when the decode has finished. */
+int   gamut_hip_qoi_decode_batch_device(const uint8_t* const* data, const int* size, int count, int channels,
+                                        const int64_t* out_offset, uint8_t* out, gamut_hip_qoi_desc* descs, int* status_host, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

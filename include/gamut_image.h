@@ -21,7 +21,7 @@ extern "C" {
 #endif
 
 /* ImageFormat (types.d:14-28) */
-enum { GAMUT_FORMAT_unknown = -1, GAMUT_FORMAT_JPEG = 0, GAMUT_FORMAT_PNG = 1 };
+enum { GAMUT_FORMAT_unknown = -1, GAMUT_FORMAT_JPEG = 0, GAMUT_FORMAT_PNG = 1, GAMUT_FORMAT_QOI = 2 };   /* ImageFormat, types.d:14-21 */
 
 /* LoadFlags (types.d:139-197) */
 enum {
@@ -53,7 +53,7 @@ int  gamut_compute_requested_image_components(int flags);              /* intern
 int  gamut_valid_load_flags(int flags);                                /* internals/types.d:563-578 */
 int  gamut_layout_constraints_valid(int constraints);                  /* internals/types.d:267-289 */
 int  gamut_layout_constraints_compatible(int newer, int older);        /* internals/types.d:241-264 */
-int  gamut_identify_format_from_memory(const uint8_t* bytes, size_t len);   /* image.d:1038-1061 (JPEG, PNG) */
+int  gamut_identify_format_from_memory(const uint8_t* bytes, size_t len);   /* image.d:1038-1061 (JPEG, PNG, QOI) */
 void gamut_free_image_data(void* mallocArea);                          /* freeImageData, image.d:27-30 */
 
 /* lifetime: a new image is Image.init = errored with "Uninitialized image" (image.d:1609-1613) */

@@ -134,6 +134,11 @@ uint16_t* orc_stbi_load_16_from_memory(const uint8_t* data, size_t len, int* x, 
 void orc_png_convert_format8(const uint8_t* src, int img_n, int req_comp, uint32_t x, uint32_t y, uint8_t* dst);
 void orc_png_convert_format16(const uint16_t* src, int img_n, int req_comp, uint32_t x, uint32_t y, uint16_t* dst);
 
+/* ---- QOI (codecs/qoi.d:448-550) -------------------------------------------------------------------------------- */
+typedef struct { uint32_t width, height; uint8_t channels, colorspace; } orc_qoi_desc;
+/* qoi_decode: channels = 0 (as in the file), 3 or 4; returns malloc'd width*height*channels bytes or NULL */
+uint8_t*  orc_qoi_decode(const uint8_t* data, int size, orc_qoi_desc* desc, int channels);
+
 #ifdef __cplusplus
 }
 #endif

@@ -200,3 +200,44 @@ def write_png(samples, width, height, color, depth, filters=None, interlace=0, p
     if not no_iend:
         out += chunk(b"IEND", b"")
     return out
+
+
+def qoi_encode(px, colorspace=0, force_ops=True):
+    """QOI encoder written from the public format specification (qoiformat.org: 14-byte header, QOI_OP_RGB / RGBA / INDEX /
+    DIFF / LUMA / RUN, 8-byte end marker) -- an independent producer of test streams, NOT taken from the reference.
+    px: (h, w, 3|4) uint8."""
+    h, w, ch = px.shape
+    out = bytearray(b"qoif" + int(w).to_bytes(4, "big") + int(h).to_bytes(4, "big") + bytes([ch, colorspace]))
+    index = [(0, 0, 0, 0)] * 64
+    prev = (0, 0, 0, 255)
+    run = 0
+    flat = px.reshape(-1, ch).tolist()
+    n = len(flat)
+    for i, v in enumerate(flat):
+        cur = (v[0], v[1], v[2], v[3] if ch == 4 else 255)
+        if cur == prev:
+            run += 1
+            if run == 62 or i == n - 1:
+                out.append(0xC0 | (run - 1)); run = 0
+            continue
+        if run:
+            out.append(0xC0 | (run - 1)); run = 0
+        hp = (cur[0] * 3 + cur[1] * 5 + cur[2] * 7 + cur[3] * 11) % 64
+        if index[hp] == cur:
+            out.append(hp)
+        else:
+            index[hp] = cur
+            if cur[3] == prev[3]:
+                dr, dg, db = ((cur[0] - prev[0] + 128) & 255) - 128, ((cur[1] - prev[1] + 128) & 255) - 128, ((cur[2] - prev[2] + 128) & 255) - 128
+                dgr, dgb = dr - dg, db - dg
+                if -2 <= dr <= 1 and -2 <= dg <= 1 and -2 <= db <= 1:
+                    out.append(0x40 | (dr + 2) << 4 | (dg + 2) << 2 | (db + 2))
+                elif -8 <= dgr <= 7 and -32 <= dg <= 31 and -8 <= dgb <= 7:
+                    out += bytes([0x80 | (dg + 32), (dgr + 8) << 4 | (dgb + 8)])
+                else:
+                    out += bytes([0xFE, cur[0], cur[1], cur[2]])
+            else:
+                out += bytes([0xFF, cur[0], cur[1], cur[2], cur[3]])
+        prev = cur
+    out += bytes([0, 0, 0, 0, 0, 0, 0, 1])
+    return bytes(out)

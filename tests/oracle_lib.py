@@ -200,6 +200,26 @@ def decompress_jpeg(data, req_comps=-1):
     return out, ac.value, par.value, dpi.value
 
 
+# ---------------------------------------------------------------- qoi
+class QoiDesc(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("channels", C.c_uint8), ("colorspace", C.c_uint8)]
+
+
+def qoi_decode(data, channels=0):
+    """-> (pixels (h, w*channels) uint8, file_channels, colorspace) or None"""
+    buf = np.frombuffer(bytes(data), np.uint8) if len(data) else np.zeros(1, np.uint8)
+    d = QoiDesc()
+    fn = lib().orc_qoi_decode
+    fn.restype, fn.argtypes = C.c_void_p, [C.c_void_p, C.c_int, C.POINTER(QoiDesc), C.c_int]
+    p = fn(buf.ctypes.data, len(data), C.byref(d), channels)
+    if not p:
+        return None
+    ch = channels or d.channels
+    out = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (d.height * d.width * ch,)).copy().reshape(d.height, d.width * ch)
+    _libc.free(p)
+    return out, d.channels, d.colorspace
+
+
 # ---------------------------------------------------------------- png
 def png_create_image_raw(raw, img_n, out_n, x, y, depth, color=None):
     raw = np.ascontiguousarray(raw, np.uint8)

@@ -9,6 +9,7 @@ import re
 import numpy as np
 import pytest
 
+import gen
 import oracle_lib as O
 from gamut_amd import _capi
 
@@ -117,6 +118,19 @@ def test_jpeg_read_header_needs_no_device():
     assert L.gamut_hip_jpeg_read_header(None, 0, None) == _capi.ERR_INVALID_ARG
 
 
+def test_qoi_header_needs_no_device():
+    L = _capi.lib()
+    a = gen.synth_rgb(37, 11, 2)
+    data = np.frombuffer(gen.qoi_encode(np.dstack([a, a[:, :, 0]]), colorspace=1), np.uint8)
+    d = _capi.QoiDesc()
+    _capi.check(L.gamut_hip_qoi_read_header(data.ctypes.data, data.size, C.byref(d)))
+    assert (d.width, d.height, d.channels, d.colorspace) == (37, 11, 4, 1)
+    bad = data.copy(); bad[0] = 0x78
+    assert L.gamut_hip_qoi_read_header(bad.ctypes.data, bad.size, C.byref(d)) == _capi.ERR_DECODE
+    assert L.gamut_hip_qoi_read_header(data.ctypes.data, 21, C.byref(d)) == _capi.ERR_DECODE
+    assert L.gamut_hip_qoi_read_header(data.ctypes.data, data.size, None) == _capi.ERR_INVALID_ARG
+
+
 def test_jpeg_feeder_rejects_bad_streams():
     L = _capi.lib()
     fr = _capi.JpegFrame()
@@ -161,6 +175,10 @@ def test_no_gpu_means_loud_failure_not_fallback():
     ptrs = (C.c_void_p * 1)(buf.ctypes.data); lens = (C.c_size_t * 1)(buf.size); off = (C.c_int64 * 1)(0)
     info = (_capi.JpegFrame * 1)()
     assert L.gamut_hip_jpeg_entropy_decode_device(ptrs, lens, 1, off, off, 0x1000, 0x1000, None, info, None, None) == _capi.ERR_NO_DEVICE
+    qoi = np.frombuffer(gen.qoi_encode(gen.synth_rgb(5, 4, 1)), np.uint8)
+    qd = _capi.QoiDesc()
+    assert not L.gamut_hip_qoi_decode(qoi.ctypes.data, qoi.size, C.byref(qd), 0) and b"no HIP device" in L.gamut_hip_last_error()
+    assert (qd.width, qd.height, qd.channels) == (5, 4, 3)                 # the header was read; nothing was decoded on the CPU
 
 
 def test_argument_validation_needs_no_device():

@@ -377,3 +377,55 @@ def test_division_by_max_identity():
             r = rn32(x - M * q)
             assert r == x - M * q                    # the residual FMA is exact
             assert float(rn32(q + r * y)) == float(np.float32(x) / np.float32(M)), (M, x)
+
+
+# ------------------------------------------------------------------ QOI
+def _qoi_test_images():
+    rng = np.random.default_rng(77)
+    out = []
+    for k, (w, h, ch) in enumerate([(1, 1, 3), (3, 2, 4), (64, 33, 3), (130, 67, 4), (257, 19, 4)]):
+        a = gen.synth_rgb(w, h, 40 + k)
+        if ch == 4:
+            al = ((np.add.outer(np.arange(h), np.arange(w)) * 5) % 256).astype(np.uint8)
+            al[: h // 2] = 255
+            a = np.dstack([a, al])
+        a[:, : w // 3] = a[0, 0]                                  # long runs (> 62 pixels on the wide ones)
+        if h > 4 and w > 16:
+            a[1, ::2] = a[0, 0]; a[1, 1::2] = 255 - a[0, 0]           # two far-apart colours alternating: INDEX ops
+        if w > 8:
+            a[h // 2:, w // 2:] = rng.integers(0, 256, a[h // 2:, w // 2:].shape)      # noise: RGB / RGBA ops, hash collisions
+        out.append(a)
+    return out
+
+
+def test_qoi_oracle_roundtrip_and_pillow():
+    """QOI is lossless and fully specified: streams from the independent spec-based encoder in gen.py must decode to the
+    source pixels, and to what Pillow's QOI decoder makes of them; channel forcing follows qoi.d:536-545."""
+    import io
+    from PIL import Image
+    ops = set()
+    for a in _qoi_test_images():
+        h, w, ch = a.shape
+        data = gen.qoi_encode(a, colorspace=1 if ch == 4 else 0)
+        p = 14
+        while p < len(data) - 8:                                  # which ops the stream uses (coverage of the test data)
+            b = data[p]
+            op, n = ("rgb", 4) if b == 0xFE else ("rgba", 5) if b == 0xFF else (("index", 1), ("diff", 1), ("luma", 2), ("run", 1))[b >> 6]
+            ops.add(op); p += n
+        px, fc, cs = O.qoi_decode(data)
+        assert fc == ch and cs == (1 if ch == 4 else 0)
+        assert np.array_equal(px.reshape(h, w, ch), a)
+        assert np.array_equal(np.array(Image.open(io.BytesIO(data))), a)
+        p3 = O.qoi_decode(data, 3)[0].reshape(h, w, 3)
+        p4 = O.qoi_decode(data, 4)[0].reshape(h, w, 4)
+        assert np.array_equal(p3, a[:, :, :3]) and np.array_equal(p4[:, :, :3], a[:, :, :3])
+        assert np.array_equal(p4[:, :, 3], a[:, :, 3] if ch == 4 else np.full((h, w), 255))
+    assert ops == {"rgb", "rgba", "index", "diff", "luma", "run"}
+    # header validation (qoi.d:458-480) and a stream that ends early (remaining pixels repeat the last one, :498-501)
+    good = gen.qoi_encode(_qoi_test_images()[2])
+    assert O.qoi_decode(good[:21]) is None and O.qoi_decode(b"xoif" + good[4:]) is None
+    assert O.qoi_decode(good, 1) is None and O.qoi_decode(good, 2) is None
+    assert O.qoi_decode(good[:4] + bytes(4) + good[8:]) is None                      # width 0
+    cut = good[:200] + good[-8:]
+    t = O.qoi_decode(cut)[0]
+    assert t.shape == (33, 64 * 3) and (t.reshape(-1, 3)[-1] == t.reshape(-1, 3)[-50]).all()

@@ -1,0 +1,60 @@
+"""GPU parity: QOI decode (one lane per stream) through the C ABI vs the CPU oracle; bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import gen
+import oracle_lib as O
+from gamut_amd import _capi
+from test_oracle_pinning import _qoi_test_images
+
+pytestmark = pytest.mark.gpu
+
+
+def test_qoi_drop_in_and_batch(hip):
+    imgs = _qoi_test_images()
+    blobs = [gen.qoi_encode(a) for a in imgs]
+    blobs.append(blobs[2][:200] + blobs[2][-8:])                       # ends early: the tail repeats the last pixel
+    for data in blobs:
+        buf = np.frombuffer(data, np.uint8)
+        for ch in (0, 3, 4):
+            exp, fc, cs = O.qoi_decode(data, ch)
+            d = _capi.QoiDesc()
+            p = hip.gamut_hip_qoi_decode(buf.ctypes.data, buf.size, C.byref(d), ch)
+            assert p, hip.gamut_hip_last_error()
+            got = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (exp.size,)).copy()
+            O._libc.free(C.c_void_p(p))
+            assert (d.channels, d.colorspace, d.height) == (fc, cs, exp.shape[0])
+            assert np.array_equal(got.reshape(exp.shape), exp)
+    # batch entry point: mixed sizes in one launch, a bad file in the middle
+    blobs.insert(2, b"qoif" + bytes(30))
+    n = len(blobs)
+    bufs = [np.frombuffer(b, np.uint8) for b in blobs]
+    ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs]); sizes = (C.c_int * n)(*[b.size for b in bufs])
+    exp = [O.qoi_decode(b, 4) for b in blobs]
+    nbytes = [e[0].size if e else 0 for e in exp]
+    offs = np.concatenate([[0], np.cumsum(nbytes)[:-1]]).astype(np.int64)
+    dout = hip.gamut_hip_device_malloc(int(sum(nbytes)) + 64)
+    descs = (_capi.QoiDesc * n)(); st = (C.c_int * n)()
+    rc = hip.gamut_hip_qoi_decode_batch_device(ptrs, sizes, n, 4, offs.ctypes.data_as(C.POINTER(C.c_int64)), dout, descs, st, None)
+    assert rc == _capi.ERR_DECODE and st[2] == _capi.ERR_DECODE and [s for i, s in enumerate(st) if i != 2] == [0] * (n - 1)
+    host = np.empty(int(sum(nbytes)), np.uint8)
+    _capi.check(hip.gamut_hip_memcpy_d2h(host.ctypes.data, dout, host.nbytes, None))
+    _capi.check(hip.gamut_hip_stream_synchronize(None))
+    hip.gamut_hip_device_free(dout)
+    for i, e in enumerate(exp):
+        if e:
+            assert np.array_equal(host[offs[i]:offs[i] + nbytes[i]], e[0].reshape(-1)), i
+
+
+def test_image_load_qoi(hip):
+    """Image.loadFromMemory on a QOI file (plugins/qoi.d:47-141): rgb8 / rgba8 as in the file, then convertTo per load flags"""
+    from gamut_amd.image import Image
+    for a in _qoi_test_images()[2:4]:
+        h, w, ch = a.shape
+        data = gen.qoi_encode(a)
+        im = Image()
+        assert im.loadFromMemory(data), im.errorMessage()
+        assert (im.width, im.height) == (w, h) and im.type == (O.PT["rgb8"] if ch == 3 else O.PT["rgba8"])
+        assert np.array_equal(im.pixels().reshape(h, w, ch), a)

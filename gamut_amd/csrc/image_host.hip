@@ -319,9 +319,10 @@ struct gamut_image {
         if (!decoded) { error(kStrImageDecodingFailed); return; }
         if (!imageIsValidSize(1, (int)desc.width, (int)desc.height)) { error(kStrImageTooLarge); free(decoded); return; }
         const int comps = requested == 0 ? desc.channels : requested;
-        // _pitch = desc.channels * desc.width (:133): the FILE's channel count, also when another count was requested --
-        // kept as the reference has it
-        adopt(decoded, (int)desc.width, (int)desc.height, comps == 3 ? GAMUT_PIXEL_rgb8 : GAMUT_PIXEL_rgba8, desc.channels, -1.0f, -1.0f);
+        // DEVIATION: the reference sets _pitch = desc.channels * desc.width (:133), the FILE's channel count, even when the
+        // decoder was asked for another one; rows are then read at the wrong pitch (and past the buffer for RGBA files
+        // loaded without alpha).  The pitch of the decoded buffer is used here.
+        adopt(decoded, (int)desc.width, (int)desc.height, comps == 3 ? GAMUT_PIXEL_rgb8 : GAMUT_PIXEL_rgba8, comps, -1.0f, -1.0f);
         _layoutConstraints = 0;
         convertTo(applyLoadFlags(_type, flags), flags & 0xFFFF);
     }

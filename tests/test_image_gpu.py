@@ -31,6 +31,13 @@ def expected_load(data, flags, fmt):
         t0 = {1: "l8", 3: "rgb8", 4: "rgba8"}[comps]
         px = out.reshape(-1)
         h = out.shape[0]; w = out.shape[1] // comps
+    elif fmt == "qoi":
+        r = 0 if req in (-1, 1, 2) else req                               # plugins/qoi.d:81-83
+        out, fc, cs = O.qoi_decode(data, r)
+        comps = fc if r == 0 else r
+        t0 = {3: "rgb8", 4: "rgba8"}[comps]
+        px = out.reshape(-1)
+        h = out.shape[0]; w = out.shape[1] // comps
     else:
         is16 = O.png_parse(data)["depth"] == 16
         to16 = is16
@@ -136,3 +143,42 @@ def test_convert_to_layouts_and_layers(hip):
         for l in range(layers):
             exp = O.scanlines_convert(src, px[l].reshape(-1), dst, w, h).reshape(h, -1) if src != dst else px[l]
             assert np.array_equal(im.pixels(l), exp), f"{src}->{dst} layer {l}"
+
+
+def test_load_qoi_with_flags_and_mixed_batch(hip):
+    """QOI through Image.loadFromMemory with every flag set (plugins/qoi.d:47-141), then BASELINE.json config 5 in miniature:
+    a mixed JPEG / PNG / QOI list, image i owned by rank i % N (gamut_amd.shard), every owner's result == the oracle's."""
+    from gamut_amd.shard import shard_indices, owner_of
+    from test_oracle_pinning import _qoi_test_images
+    qois = [gen.qoi_encode(a) for a in _qoi_test_images()[1:4]]
+    for data in qois:
+        for flags in FLAGSETS:
+            w, h, t1, exp = expected_load(data, flags, "qoi")
+            im = Image()
+            assert im.loadFromMemory(data, flags | gi.LAYOUT_TRAILING[1]), im.errorMessage
+            assert (im.width, im.height, im.type) == (w, h, t1)
+            assert np.array_equal(im.pixels(), exp), f"flags={flags:#x}"
+    assert gi.lib().gamut_identify_format_from_memory(qois[0], len(qois[0])) == 2          # ImageFormat.QOI
+    rng = np.random.default_rng(9)
+    batch = []
+    for i in range(12):
+        kind = ("jpeg", "png", "qoi")[i % 3]
+        if kind == "jpeg":
+            data = open(JPEGS[i % len(JPEGS)], "rb").read()
+        elif kind == "png":
+            data = gen.write_png(rng.integers(0, 256, (9 + i, (20 + i) * 4)), 20 + i, 9 + i, 6, 8)
+        else:
+            data = qois[i % len(qois)]
+        batch.append((kind, data))
+    for world in (1, 2, 8):
+        seen = []
+        for rank in range(world):
+            for i in shard_indices(len(batch), rank, world):
+                assert owner_of(i, world) == rank
+                kind, data = batch[i]
+                w, h, t1, exp = expected_load(data, gi.LOAD_RGB | gi.LOAD_ALPHA | gi.LOAD_8BIT, kind)
+                im = Image()
+                assert im.loadFromMemory(data, gi.LOAD_RGB | gi.LOAD_ALPHA | gi.LOAD_8BIT), im.errorMessage
+                assert PIXEL_TYPES[im.type] == "rgba8" and np.array_equal(im.pixels(), exp), (kind, i)
+                seen.append(i)
+        assert sorted(seen) == list(range(len(batch)))

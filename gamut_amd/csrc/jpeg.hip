@@ -62,6 +62,7 @@ constexpr int LDS_INTS = T1_INTS + H_INTS + V_INTS;
 __device__ __forceinline__ constexpr int phys_slot(int m) { constexpr int P[8] = { 0, 2, 1, 3, 6, 4, 7, 5 }; return P[m]; }
 
 struct MapCoef { i32 a[4], b[4]; };
+struct __attribute__((packed, aligned(1))) Dwords4u { u32 v[4]; };      // 16 bytes at any alignment (gfx950 stores them natively)
 
 // Every LDS hand-off of the tuned kernel stays inside one 32-lane half of a wave (thread t only ever reads tiles
 // written by threads with the same t >> 5: Y tile t>>3, chroma block t>>4, T2 tile t>>3), so no workgroup barrier is
@@ -225,41 +226,49 @@ __global__ __launch_bounds__(256) void k_jpeg_h2v2(JpegArgs a)
                             __builtin_nontemporal_store(ycc_to_rgba(ys[i], cbs[i], crs[i]), reinterpret_cast<u32*>(obase + voff));
                 }
             }
-        } else if constexpr (OC == 3) {
+        } else {
+            // rgb8 / l8: a strip row is 384 / 128 bytes, but a wave's lanes hold 16-pixel runs of it, i.e. 48- / 16-byte
+            // pieces: written directly they are partial lines (measured: 13 % more HBM traffic than the algorithmic bytes).
+            // The strip is assembled in LDS (the H / V staging area is free by now) and written out in whole 16-byte
+            // chunks, consecutive lanes along a row.
             // rgb8: the four pixels of a lane quad are 12 bytes = 3 dwords; lane j < 3 of the quad builds dword j from its own
-            // pixel and its right neighbour's (one DPP quad shuffle + one byte permute) and stores it.  A quad cut by the
-            // right image edge falls back to byte stores (rows are tightly packed: nothing may spill into the next row).
+            // pixel and its right neighbour's (one DPP quad shuffle + one byte permute).  l8: four grey bytes make one
+            // dword, gathered with two in-quad OR steps; lane 0 of the quad keeps it.
+            static_assert(OC == 3 || OC == 1, "output components");
+            constexpr int BPR = 128 * OC;                          // bytes per strip row
+            uint8_t* stage = reinterpret_cast<uint8_t*>(Hs);       // 16 rows x BPR <= 6144 B of the 9216 B H/V area
             const int j = lx & 3;
-            const u32 sel = j == 0 ? 0x04020100u : j == 1 ? 0x05040201u : 0x06050402u;
-            const bool quad_inside = mcu_live && mcu_x0 * 16 + (lx | 3) < a.width;
-            u32 voff = (u32)(lx * 3 + j) + (u32)ly0 * pitch;   // dword j of the quad: (lx - j) * 3 + 4 j
-            u32 boff = (u32)(lx * 3) + (u32)ly0 * pitch;
+            __syncthreads();                                       // other waves may still be reading V in P3
             #pragma unroll
-            for (int i = 0; i < 8; ++i, voff += pitch, boff += pitch) {
+            for (int i = 0; i < 8; ++i) {
                 const u32 px = ycc_to_rgba(ys[i], cbs[i], crs[i]);
-                const u32 nx = (u32)__builtin_amdgcn_mov_dpp((int)px, 0xF9, 0xF, 0xF, true);      // quad_perm [1,2,3,3]: right neighbour
-                const u32 dw = __builtin_amdgcn_perm(nx, px, sel);
-                if (all_rows || i < rows_here) {
-                    if (quad_inside) { if (j < 3) __builtin_nontemporal_store(dw, reinterpret_cast<u32*>(obase + voff)); }
-                    else if (px_live) { uint8_t* o = obase + boff; o[0] = (uint8_t)px; o[1] = (uint8_t)(px >> 8); o[2] = (uint8_t)(px >> 16); }
+                if constexpr (OC == 3) {
+                    const u32 sel = j == 0 ? 0x04020100u : j == 1 ? 0x05040201u : 0x06050402u;
+                    const u32 nx = (u32)__builtin_amdgcn_mov_dpp((int)px, 0xF9, 0xF, 0xF, true);      // quad_perm [1,2,3,3]: right neighbour
+                    const u32 dw = __builtin_amdgcn_perm(nx, px, sel);
+                    if (j < 3) *reinterpret_cast<u32*>(stage + (ly0 + i) * BPR + lx * 3 + j) = dw;        // (lx - j) * 3 + 4 j
+                } else {
+                    u32 v = rgb_to_luma(px) << (8 * j);
+                    v |= (u32)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);                   // quad_perm [1,0,3,2]
+                    v |= (u32)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);                   // quad_perm [2,3,0,1]
+                    if (j == 0) *reinterpret_cast<u32*>(stage + (ly0 + i) * BPR + lx) = v;
                 }
             }
-        } else {
-            // l8: four lanes' grey bytes make one dword, gathered with two in-quad OR steps; lane 0 of the quad stores
-            static_assert(OC == 1, "output components");
-            const int j = lx & 3;
-            const bool quad_inside = mcu_live && mcu_x0 * 16 + (lx | 3) < a.width;
-            u32 voff = (u32)(lx - j) + (u32)ly0 * pitch;
-            u32 boff = (u32)lx + (u32)ly0 * pitch;
-            #pragma unroll
-            for (int i = 0; i < 8; ++i, voff += pitch, boff += pitch) {
-                const u32 g = rgb_to_luma(ycc_to_rgba(ys[i], cbs[i], crs[i]));
-                u32 v = g << (8 * j);
-                v |= (u32)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);                   // quad_perm [1,0,3,2]
-                v |= (u32)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);                   // quad_perm [2,3,0,1]
-                if (all_rows || i < rows_here) {
-                    if (quad_inside) { if (j == 0) __builtin_nontemporal_store(v, reinterpret_cast<u32*>(obase + voff)); }
-                    else if (px_live) obase[boff] = (uint8_t)g;
+            __syncthreads();
+            const int row_bytes = min(mcus_here * 16, a.width - mcu_x0 * 16) * OC;       // live bytes of a strip row (rows are tight)
+            const int live_rows = min(16, a.height - mcu_y * 16);
+            constexpr int CPR = BPR / 16;                          // 16-byte chunks per row: 24 / 8
+            for (int c = t; c < 16 * CPR; c += 256) {
+                const int row = c / CPR, off = (c - row * CPR) * 16;
+                if (row >= live_rows || off >= row_bytes) continue;
+                const uint4 v = *reinterpret_cast<const uint4*>(stage + row * BPR + off);
+                uint8_t* o = obase + (u32)row * pitch + (u32)off;
+                if (off + 16 <= row_bytes) {
+                    Dwords4u d; d.v[0] = v.x; d.v[1] = v.y; d.v[2] = v.z; d.v[3] = v.w;
+                    *reinterpret_cast<Dwords4u*>(o) = d;
+                } else {
+                    const u32 w[4] = { v.x, v.y, v.z, v.w };
+                    for (int k = 0; k < row_bytes - off; ++k) o[k] = (uint8_t)(w[k >> 2] >> ((k & 3) * 8));
                 }
             }
         }

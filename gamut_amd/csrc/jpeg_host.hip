@@ -860,6 +860,7 @@ int gamut_hip_jpeg_decode_coeffs_batch(const uint8_t* const* data, const size_t*
     if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
     if (threads < 1) threads = 1;
     if (threads > count) threads = count;
+    try {
     // images are independent: workers pull the next index; every worker keeps the message of its lowest failing image
     std::atomic<int> next{ 0 };
     struct Failure { int index = INT32_MAX, code = GAMUT_HIP_OK; char msg[256] = { 0 }; };
@@ -878,7 +879,9 @@ int gamut_hip_jpeg_decode_coeffs_batch(const uint8_t* const* data, const size_t*
     else {
         std::vector<std::thread> pool;
         pool.reserve((size_t)threads - 1);
-        for (int t = 1; t < threads; ++t) pool.emplace_back(work, t);
+        try {                                                  // thread creation may fail (EAGAIN): the rest runs on fewer workers
+            for (int t = 1; t < threads; ++t) pool.emplace_back(work, t);
+        } catch (...) {}
         work(0);
         for (std::thread& th : pool) th.join();
     }
@@ -886,6 +889,9 @@ int gamut_hip_jpeg_decode_coeffs_batch(const uint8_t* const* data, const size_t*
     for (const Failure& fl : fails) if (fl.code != GAMUT_HIP_OK && (!first || fl.index < first->index)) first = &fl;
     if (!first) { clear_error(); return GAMUT_HIP_OK; }
     return set_error(first->code, "image %d: %s", first->index, first->msg);
+    } catch (...) {
+        return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg_decode_coeffs_batch: out of host memory");
+    }
 }
 
 int gamut_hip_jpeg_read_header(const uint8_t* data, size_t len, gamut_hip_jpeg_frame* out)
@@ -911,7 +917,11 @@ int gamut_hip_jpeg_entropy_decode_device(const uint8_t* const* data, const size_
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return set_error(GAMUT_HIP_ERR_NO_DEVICE, "no HIP device available (libgamut_hip has no CPU fallback)");
-    return entropy_decode_device(data, len, count, coeff_offset, zag_offset, coeffs, max_zag, status_dev, info, status_host, pick_stream(stream));
+    try {                                                      // std::vector / bad_alloc must not escape a C entry point
+        return entropy_decode_device(data, len, count, coeff_offset, zag_offset, coeffs, max_zag, status_dev, info, status_host, pick_stream(stream));
+    } catch (...) {
+        return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg_entropy_decode_device: out of host memory");
+    }
 }
 
 void gamut_hip_jpeg_frame_free(gamut_hip_jpeg_frame* f)

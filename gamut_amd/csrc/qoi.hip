@@ -132,7 +132,11 @@ int gamut_hip_qoi_decode_batch_device(const uint8_t* const* data, const int* siz
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return set_error(GAMUT_HIP_ERR_NO_DEVICE, "no HIP device available (libgamut_hip has no CPU fallback)");
-    return decode_batch(data, size, count, channels, out_offset, out, descs, status_host, pick_stream(stream));
+    try {                                                      // std::vector / bad_alloc must not escape a C entry point
+        return decode_batch(data, size, count, channels, out_offset, out, descs, status_host, pick_stream(stream));
+    } catch (...) {
+        return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "qoi_decode_batch_device: out of host memory");
+    }
 }
 
 // drop-in for qoi_decode (qoi.d:448): malloc'd pixels or NULL
@@ -153,7 +157,8 @@ void* gamut_hip_qoi_decode(const void* data, int size, gamut_hip_qoi_desc* desc,
     if (!ok) set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "qoi: hipMalloc(%zu) failed", bytes);
     const uint8_t* ptr = (const uint8_t*)data; const int64_t off = 0;
     hipStream_t st = thread_stream();
-    ok = ok && decode_batch(&ptr, &size, 1, channels, &off, (uint8_t*)dout, desc, nullptr, st) == GAMUT_HIP_OK;
+    try { ok = ok && decode_batch(&ptr, &size, 1, channels, &off, (uint8_t*)dout, desc, nullptr, st) == GAMUT_HIP_OK; }
+    catch (...) { set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "qoi: out of host memory"); ok = false; }
     if (ok && (hipMemcpyAsync(result, dout, bytes, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) {
         set_error(GAMUT_HIP_ERR_HIP, "qoi: copy back failed"); ok = false;
     }

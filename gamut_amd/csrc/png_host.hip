@@ -8,6 +8,7 @@
 // the GPU: de-filter / expand (png.hip), Adam7 scatter, tRNS, palette, channel and depth
 // conversion, in the order of finalize_decode (:1821-1857) and stbi__do_png (:2025-2055).
 #include "common.hpp"
+#include <chrono>
 #include <zlib.h>
 
 namespace gamut {
@@ -127,34 +128,49 @@ int parse(const uint8_t* data, size_t len, PngHeader& h, bool header_only)
     }
 }
 
-// stbi_zlib_decode_malloc_guesssize_headerflag (stbdec.d:1267-1321)
-uint8_t* inflate_idat(const uint8_t* buf, uint32_t len, size_t guess, uint32_t* outlen, bool parse_header)
+// Per-thread page-locked staging for the inflated stream: zlib writes straight into it and the upload is a plain DMA
+// (an upload from freshly written pageable memory was seen to take 12-22 ms for 4 MB on some boxes, 0.2 ms on others).
+struct Pinned {
+    uint8_t* p = nullptr; size_t cap = 0;      // intentionally not freed at thread exit (the HIP runtime may already be gone)
+    bool reserve(size_t n, size_t keep)
+    {
+        if (n <= cap) return true;
+        void* np = nullptr;
+        const size_t ncap = n + n / 8 + 4096;
+        if (hipHostMalloc(&np, ncap, hipHostMallocDefault) != hipSuccess) return false;
+        if (keep) memcpy(np, p, keep);
+        if (p) (void)hipHostFree(p);
+        p = (uint8_t*)np; cap = ncap;
+        return true;
+    }
+};
+
+// stbi_zlib_decode_malloc_guesssize_headerflag (stbdec.d:1267-1321); the result lives in `out` (not to be freed)
+uint8_t* inflate_idat(const uint8_t* buf, uint32_t len, size_t guess, uint32_t* outlen, bool parse_header, Pinned& out)
 {
     if (parse_header) {
         if (len < 2 || ((buf[0] * 256 + buf[1]) % 31) != 0 || (buf[1] & 32) || (buf[0] & 15) != 8) { set_error(GAMUT_HIP_ERR_DECODE, "png: bad zlib header"); return nullptr; }
         buf += 2; len -= 2;
     }
     size_t cap = guess ? guess : 1;
-    uint8_t* out = (uint8_t*)malloc(cap);
     z_stream z; memset(&z, 0, sizeof(z));
-    if (!out || inflateInit2(&z, -15) != Z_OK) { free(out); set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png: inflate init failed"); return nullptr; }
-    z.next_in = const_cast<Bytef*>(buf); z.avail_in = len; z.next_out = out; z.avail_out = (uInt)cap;
+    if (!out.reserve(cap, 0) || inflateInit2(&z, -15) != Z_OK) { set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png: inflate init failed"); return nullptr; }
+    z.next_in = const_cast<Bytef*>(buf); z.avail_in = len; z.next_out = out.p; z.avail_out = (uInt)cap;
     for (;;) {
         const int r = inflate(&z, Z_NO_FLUSH);
         if (r == Z_STREAM_END) break;
         if ((r == Z_OK || r == Z_BUF_ERROR) && z.avail_out == 0 && cap <= 536870912u) {
             size_t ncap = cap * 2; if (ncap < 32 * 1024) ncap = 32 * 1024;
-            uint8_t* n = (uint8_t*)realloc(out, ncap);
-            if (!n) { inflateEnd(&z); free(out); set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png: out of memory"); return nullptr; }
-            out = n; z.next_out = out + cap; z.avail_out = (uInt)(ncap - cap); cap = ncap;
+            if (!out.reserve(ncap, cap)) { inflateEnd(&z); set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png: out of memory"); return nullptr; }
+            z.next_out = out.p + cap; z.avail_out = (uInt)(ncap - cap); cap = ncap;
             continue;
         }
         if (r == Z_OK && z.avail_in != 0) continue;
-        inflateEnd(&z); free(out); set_error(GAMUT_HIP_ERR_DECODE, "png: corrupt zlib stream"); return nullptr;
+        inflateEnd(&z); set_error(GAMUT_HIP_ERR_DECODE, "png: corrupt zlib stream"); return nullptr;
     }
     *outlen = (uint32_t)z.total_out;
     inflateEnd(&z);
-    return out;
+    return out.p;
 }
 
 struct Dev {
@@ -177,23 +193,31 @@ uint8_t* png_load(const uint8_t* data, size_t len, int* px, int* py, int* pn, in
     if (!h.idata) { set_error(GAMUT_HIP_ERR_DECODE, "png: no IDAT"); return nullptr; }
     const uint32_t bpl = (h.x * (uint32_t)h.depth + 7) / 8;
     uint32_t raw_len = 0;
-    uint8_t* raw = inflate_idat(h.idata, h.ioff, (size_t)bpl * h.y * h.img_n + h.y, &raw_len, !h.is_iphone);
+    const bool trace = getenv("GAMUT_HIP_TRACE") != nullptr;               // stage timings on stderr
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t0 = now();
+    int dev_count = 0;                                                       // before any work: no GPU, no result
+    if (hipGetDeviceCount(&dev_count) != hipSuccess || dev_count <= 0) { set_error(GAMUT_HIP_ERR_NO_DEVICE, "no HIP device available (libgamut_hip has no CPU fallback)"); return nullptr; }
+    static thread_local Pinned staging;
+    uint8_t* raw = inflate_idat(h.idata, h.ioff, (size_t)bpl * h.y * h.img_n + h.y, &raw_len, !h.is_iphone, staging);
     if (!raw) return nullptr;
-    struct FreeRaw { uint8_t* p; ~FreeRaw() { free(p); } } fr{ raw };
 
     int img_n = h.img_n, out_n;
     if ((req_comp == img_n + 1 && req_comp != 3 && !h.pal_img_n) || h.has_trans) out_n = img_n + 1; else out_n = img_n;   // :1821-1824
     const int bytes = h.depth == 16 ? 2 : 1;
     const int64_t npx = (int64_t)h.x * h.y;
     hipStream_t st = thread_stream();
-    int dev_count = 0;
-    if (hipGetDeviceCount(&dev_count) != hipSuccess || dev_count <= 0) { set_error(GAMUT_HIP_ERR_NO_DEVICE, "no HIP device available (libgamut_hip has no CPU fallback)"); return nullptr; }
 
+    const auto t1 = now();
     Dev draw, dimg, dstatus;
     if (!draw.alloc((size_t)raw_len + 16) || !dimg.alloc((size_t)npx * out_n * bytes + 16) || !dstatus.alloc(4)) return nullptr;
+    const auto t2 = now();
     if (hipMemcpyAsync(draw.p, raw, raw_len, hipMemcpyHostToDevice, st) != hipSuccess || hipMemsetAsync(dstatus.p, 0, 4, st) != hipSuccess) {
         set_error(GAMUT_HIP_ERR_HIP, "png: upload failed"); return nullptr;
     }
+    if (trace) (void)hipStreamSynchronize(st);
+    const auto t3 = now();
     if (!h.interlace) {
         if (png_defilter_launch((const uint8_t*)draw.p, 0, raw_len, (uint8_t*)dimg.p, 0, h.x, h.y, img_n, out_n, h.depth, h.color, 1, (uint32_t*)dstatus.p, st)) return nullptr;
     } else {                                                              // stbi__create_png_image :1646-1679
@@ -229,6 +253,8 @@ uint8_t* png_load(const uint8_t* data, size_t len, int* px, int* py, int* pn, in
         dimg.swap(dconv);
         out_n = req_comp;
     }
+    if (trace) (void)hipStreamSynchronize(st);
+    const auto t4 = now();
     const size_t out_bytes = (size_t)npx * out_n * bytes;
     uint8_t* result = (uint8_t*)malloc(out_bytes ? out_bytes : 1);
     uint32_t status = 0;
@@ -237,6 +263,8 @@ uint8_t* png_load(const uint8_t* data, size_t len, int* px, int* py, int* pn, in
         hipMemcpyAsync(&status, dstatus.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
         free(result); set_error(GAMUT_HIP_ERR_HIP, "png: download failed: %s", hipGetErrorString(hipGetLastError())); return nullptr;
     }
+    if (trace) fprintf(stderr, "[gamut_hip] png_load %ux%u: inflate %.2f ms, hipMalloc %.2f, upload %.2f, kernels %.2f, download %.2f\n",
+                       h.x, h.y, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, now()));
     if (status) { free(result); set_error(GAMUT_HIP_ERR_DECODE, "png: invalid filter"); return nullptr; }
     *px = (int)h.x; *py = (int)h.y; if (pn) *pn = img_n;
     *bits_out = h.depth <= 8 ? 8 : 16;

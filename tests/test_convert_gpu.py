@@ -166,3 +166,30 @@ def test_every_16bit_and_8bit_value_decodes_exactly(hip):
             exp = O.scanlines_convert(PT[src], px, PT[dst], n, 1)
             got = _run_device(hip, PT[src], PT[dst], px, 0, px.size, exp.size, 0, exp.size, n, 1)
             assert np.array_equal(got, exp), (src, dst)
+
+
+def test_full_size_round_trip_properties(hip):
+    """BASELINE.json config 4 geometry (8192 x 8192), checked through size-independent properties: rgba8 -> rgba16 -> rgba8 and
+    rgba8 -> rgbaf32 -> rgba8 are the identity (v*257, then (v*255+32767)/65535; v/255.0f, then (int)(0.5f + f*255.0f)), and
+    rgba16 -> rgbaf32 -> rgba16 is the identity on every 16-bit value."""
+    from gamut_amd import _capi
+    L = hip
+    w = h = 8192
+    rng = np.random.default_rng(12)
+    src = rng.integers(0, 256, w * h * 4, dtype=np.uint8)
+    a = DevBuf(L, src)
+    b = DevBuf(L, np.zeros(16, np.uint8)); L.gamut_hip_device_free(b.p); b.p = L.gamut_hip_device_malloc(w * h * 16); b.n = w * h * 16
+    c = DevBuf(L, np.zeros(16, np.uint8)); L.gamut_hip_device_free(c.p); c.p = L.gamut_hip_device_malloc(w * h * 4); c.n = w * h * 4
+    for mid, msz in (("rgba16", 8), ("rgbaf32", 16)):
+        _capi.check(L.gamut_hip_scanlines_convert_device(PT["rgba8"], a.p, w * 4, 0, PT[mid], b.p, w * msz, 0, w, h, 1, None))
+        _capi.check(L.gamut_hip_scanlines_convert_device(PT[mid], b.p, w * msz, 0, PT["rgba8"], c.p, w * 4, 0, w, h, 1, None))
+        assert np.array_equal(c.get(), src), mid
+    # 16-bit: every value appears (w*h*4 samples of a repeating 0..65535 ramp)
+    ramp = np.tile(np.arange(65536, dtype=np.uint16), (w * h * 4) // 65536).view(np.uint8)
+    d = DevBuf(L, ramp)
+    e = DevBuf(L, np.zeros(16, np.uint8)); L.gamut_hip_device_free(e.p); e.p = L.gamut_hip_device_malloc(w * h * 8); e.n = w * h * 8
+    _capi.check(L.gamut_hip_scanlines_convert_device(PT["rgba16"], d.p, w * 8, 0, PT["rgbaf32"], b.p, w * 16, 0, w, h, 1, None))
+    _capi.check(L.gamut_hip_scanlines_convert_device(PT["rgbaf32"], b.p, w * 16, 0, PT["rgba16"], e.p, w * 8, 0, w, h, 1, None))
+    assert np.array_equal(e.get(), ramp)
+    for buf in (a, b, c, d, e):
+        buf.free()

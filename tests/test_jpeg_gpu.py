@@ -290,3 +290,19 @@ def test_device_entropy_decode_corrupt_streams(hip):
     d = O.DecodedJpeg(good)
     for i in (0, 5):                                   # neighbours of the damaged files are intact
         assert np.array_equal(res[i][0], d.coeffs) and np.array_equal(res[i][1], d.max_zag)
+
+
+@pytest.mark.parametrize("scan_type,w,h", [(4, 16384, 17), (4, 17, 16384), (1, 16384, 9), (2, 16383, 8), (0, 9, 16384)])
+def test_maximum_dimensions(hip, scan_type, w, h):
+    """the reference accepts up to 16384 x 16384 (jpegload.d:101-102): the widest and the tallest frames, every tuned kernel"""
+    rng = np.random.default_rng(w + h + scan_type)
+    mw, mh = MCU[scan_type]
+    nblk = ((w + mw - 1) // mw) * ((h + mh - 1) // mh) * NB[scan_type]
+    co = random_coeffs(rng, nblk, "natural")
+    comps = 1 if scan_type == 0 else 3
+    for rc in (4, 3):
+        exp = O.jpeg_reconstruct(w, h, comps, scan_type, co, None, rc)
+        got = gpu_reconstruct(hip, w, h, scan_type, co[None], None, rc)[0]
+        assert np.array_equal(got, exp)
+    L = hip
+    assert L.gamut_hip_jpeg_reconstruct_batch_device(1, 0, None, 0, 1, 16385 * 4, 0, 16385, 8, 4, 4, 1, None) == _capi.ERR_INVALID_ARG

@@ -190,3 +190,15 @@ def test_generated_png_files(hip):
     # garbage in: NULL + message out
     assert _load(hip, b"not a png at all", 0, False) is None and hip.gamut_hip_last_error() != b""
     assert _load(hip, dict(cases)["1x1"][:40], 0, False) is None
+
+
+@pytest.mark.parametrize("img_n,out_n,x,y", [(3, 4, 3, 70001), (1, 1, 70003, 2), (4, 4, 5, 66000), (2, 2, 33, 65537)])
+def test_extreme_geometry(hip, img_n, out_n, x, y):
+    """more rows than a grid dimension holds (65535), rows of one piece or less, very wide two-row images"""
+    rng = np.random.default_rng(x + y)
+    px = rng.integers(0, 256, (y, x * img_n)).astype(np.uint8)
+    raw = gen.png_forward_filter(px, img_n, rng.integers(0, 5, y))
+    color = {1: 0, 2: 4, 3: 2, 4: 6}[img_n]
+    exp = O.png_create_image_raw(raw, img_n, out_n, x, y, 8, color)
+    got = gpu_defilter(hip, raw, x, y, img_n, out_n, 8, color)[0]
+    assert np.array_equal(got, exp)

@@ -11,6 +11,7 @@
 // Not supported (the call fails like the reference fails on a stream it rejects): arithmetic / lossless /
 // hierarchical frames, 12-bit precision, CMYK, multi-scan *baseline* files.
 #include "common.hpp"
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <new>
@@ -533,62 +534,70 @@ struct DevItem { int32_t image, first_mcu, n_mcus, pad; uint64_t begin, end; }; 
 
 __constant__ uint8_t kZagDev[64] = { 0,1,8,16,9,2,3,10,17,24,32,25,18,11,4,5,12,19,26,33,40,48,41,34,27,20,13,6,7,14,21,28,35,42,49,56,57,50,43,36,29,22,15,23,30,37,44,51,58,59,52,45,38,31,39,46,53,60,61,54,47,55,62,63 };
 
-struct DevBits {                       // MSB-first reader, same conventions as BitReader above
-    const uint8_t* p;                  // next byte not yet in `acc`; when pre_ok, `pre` already holds bytes p .. p+3
-    const uint8_t* end; uint64_t acc; int nbits; bool at_marker; uint32_t pre; bool pre_ok;
-    // The next four bytes are requested one refill ahead, so their global-memory latency overlaps the symbols decoded
-    // in between (a lane is a serial chain of dependent operations: latency, not bandwidth, is what it pays for).
-    __device__ __forceinline__ void prime() { pre_ok = !at_marker && p + 4 <= end; if (pre_ok) __builtin_memcpy(&pre, p, 4); }
+// MSB-first reader over an UNSTUFFED segment (the host drops the 0x00 after every 0xFF while it copies the scan, and
+// appends 64 bytes of 0xFF after each segment: reading past the end yields 1-bits, as get_octet :683-696 does, and an
+// all-ones window is no valid Huffman code, so a runaway decode of corrupt data stops within two bytes of the padding).
+struct DevBits {
+    const uint8_t* next;               // next four bytes to fetch
+    uint64_t acc; int nbits; uint32_t pos;     // pos = bit index (from the segment start) of the next unread bit
+    uint32_t pre;                      // bytes at `next`, requested one refill ahead: a lane is a serial chain of dependent
+                                       // operations, so the global-memory latency has to overlap the symbols in between
+    __device__ __forceinline__ void open(const uint8_t* seg, uint32_t bit)
+    {
+        next = seg + (bit >> 3); acc = 0; nbits = 0; pos = bit;
+        __builtin_memcpy(&pre, next, 4);
+        refill();
+        nbits -= (int)(bit & 7);                              // drop the bits before `bit` in its byte
+    }
     __device__ __forceinline__ void refill()
     {
         if (nbits > 32) return;
-        if (pre_ok) {                                          // four ordinary bytes at once (any alignment)
-            const uint32_t w = pre, t = ~w;
-            if (((t - 0x01010101u) & ~t & 0x80808080u) == 0) { // no 0xFF among them
-                acc = (acc << 32) | __builtin_bswap32(w); nbits += 32; p += 4;
-                prime();
-                return;
-            }
-        }
-        while (nbits <= 56) {                                  // byte-wise: FF00 stuffing, stop at a marker and feed 1-bits
-            uint32_t c = 0xFF;
-            if (!at_marker && p < end) {
-                c = *p;
-                if (c == 0xFF) { if (p + 1 < end && p[1] == 0) p += 2; else at_marker = true; }
-                else ++p;
-            }
-            acc = (acc << 8) | c; nbits += 8;
-            if (nbits > 32) break;
-        }
-        prime();
+        acc = (acc << 32) | __builtin_bswap32(pre); nbits += 32; next += 4;
+        __builtin_memcpy(&pre, next, 4);
     }
     __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)(acc >> (nbits - n)) & ((1u << n) - 1); }
+    __device__ __forceinline__ void drop(int n) { nbits -= n; pos += (uint32_t)n; }
     __device__ __forceinline__ int decode(const DevHuff* h)
     {
         refill();
         const uint32_t e = h->fast[peek(9)];
-        if (e) { nbits -= (int)(e >> 8); return (int)(e & 0xFF); }
+        if (e) { drop((int)(e >> 8)); return (int)(e & 0xFF); }
         int32_t code = (int32_t)peek(9); int len = 9;
         while (len < 17 && code > h->maxcode[len]) { ++len; code = (int32_t)peek(len); }
         if (len > 16) return -1;
-        nbits -= len;
+        drop(len);
         return h->vals[(code + h->delta[len]) & 0xFF];
     }
     __device__ __forceinline__ int receive_extend(int s)       // JPGD_HUFF_EXTEND :816-822
     {
         if (!s) return 0;
         refill();
-        const int v = (int)peek(s); nbits -= s;
+        const int v = (int)peek(s); drop(s);
         return v < (1 << (s - 1)) ? v + (int)(0xFFFFFFFFu << s) + 1 : v;
     }
 };
 
 constexpr int kEntropyThreads = 64;                          // one wave per workgroup: lanes spread over CUs, each with its own L1
 constexpr int kLdsHuff = 16, kLdsQuant = 16;                   // tables a workgroup keeps in LDS (23 KB + 2 KB)
+constexpr int kSyncThreads = 1024;                             // lanes cooperating on one large segment
+constexpr uint32_t kSyncMinBytes = 4096;                       // shorter segments take one lane each
 
-// IN_LDS: the batch uses few distinct tables (the usual case: encoders write the Annex K tables or one optimised set per
-// quality), so every workgroup copies them all into LDS and a symbol costs LDS latencies instead of L2 ones -- the
-// table look-up sits on the lane's critical path twice per symbol.
+// Tables into LDS (IN_LDS: the batch uses few distinct tables -- the usual case: encoders write the Annex K tables or one
+// optimised set per quality -- so a symbol costs LDS latencies instead of L2 ones; the look-up sits on the lane's
+// critical path twice per symbol).
+template <bool IN_LDS, int NT>
+__device__ __forceinline__ void load_tables(DevHuff* sh_huff, int16_t* sh_quant, uint8_t* sh_zag, const DevHuff* huff_g, int n_huff,
+                                            const int16_t* quant_g, int n_quant)
+{
+    if (threadIdx.x < 64) sh_zag[threadIdx.x] = kZagDev[threadIdx.x];
+    if constexpr (IN_LDS) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(huff_g); uint32_t* dst = reinterpret_cast<uint32_t*>(sh_huff);
+        for (int k = threadIdx.x; k < n_huff * (int)(sizeof(DevHuff) / 4); k += NT) dst[k] = src[k];
+        for (int k = threadIdx.x; k < n_quant * 64; k += NT) sh_quant[k] = quant_g[k];
+    }
+}
+
+// ---- one lane per (short) segment -------------------------------------------------------------------------------
 template <bool IN_LDS>
 __global__ __launch_bounds__(kEntropyThreads) void k_jpeg_entropy(const DevItem* items, int n_items, const DevImage* images,
                                                                   const DevHuff* huff_g, int n_huff, const int16_t* quant_g /* [t][64], zig-zag order */,
@@ -601,16 +610,11 @@ __global__ __launch_bounds__(kEntropyThreads) void k_jpeg_entropy(const DevItem*
     // LDS writes, and a finished block leaves as eight 16-byte stores -- a whole line, zeros included, so the destination
     // needs no clearing and the lane's bit-stream loads never queue behind a trail of 2-byte global stores.
     __shared__ __attribute__((aligned(16))) uint8_t sh_blk[kEntropyThreads * 144];
-    if (threadIdx.x < 64) sh_zag[threadIdx.x] = kZagDev[threadIdx.x];
+    load_tables<IN_LDS, kEntropyThreads>(sh_huff, sh_quant, sh_zag, huff_g, n_huff, quant_g, n_quant);
     {
         uint4* z = reinterpret_cast<uint4*>(sh_blk + threadIdx.x * 144);
         #pragma unroll
         for (int k = 0; k < 8; ++k) z[k] = make_uint4(0, 0, 0, 0);
-    }
-    if constexpr (IN_LDS) {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(huff_g); uint32_t* dst = reinterpret_cast<uint32_t*>(sh_huff);
-        for (int k = threadIdx.x; k < n_huff * (int)(sizeof(DevHuff) / 4); k += kEntropyThreads) dst[k] = src[k];
-        for (int k = threadIdx.x; k < n_quant * 64; k += kEntropyThreads) sh_quant[k] = quant_g[k];
     }
     __syncthreads();
     const DevHuff* huff = IN_LDS ? sh_huff : huff_g;
@@ -620,8 +624,7 @@ __global__ __launch_bounds__(kEntropyThreads) void k_jpeg_entropy(const DevItem*
     if (i >= n_items) return;
     const DevItem it = items[i];
     const DevImage im = images[it.image];
-    DevBits br{ blob + it.begin, blob + it.end, 0, 0, false, 0, false };
-    br.prime();
+    DevBits br; br.open(blob + it.begin, 0);
     int pred0 = 0, pred1 = 0, pred2 = 0;
     int16_t* out = coeffs + im.coeff_off + (int64_t)it.first_mcu * im.nb * 64;
     uint8_t* mz = max_zag + im.zag_off + (int64_t)it.first_mcu * im.nb;
@@ -659,6 +662,161 @@ __global__ __launch_bounds__(kEntropyThreads) void k_jpeg_entropy(const DevItem*
             for (int k = 0; k < 8; ++k) { dst[k] = src[k]; src[k] = make_uint4(0, 0, 0, 0); }
         }
     }
+}
+
+// ---- many lanes per (long) segment: self-synchronising decode --------------------------------------------------------
+// A Huffman stream can only be entered at a codeword boundary in a known state -- here (bit position, block of the MCU,
+// zig-zag index) -- which only a decoder that came from the start knows.  But decoders started at the WRONG place fall
+// into step with the right one after a few symbols (Huffman codes self-synchronise; cf. Weissenberger & Schmidt's
+// parallel JPEG decoding).  A workgroup cuts its segment into one sub-sequence per lane; lane t decodes from the state
+// lane t-1 LEFT its sub-sequence with and records the state it leaves its own with; this is repeated until no recorded
+// exit state changes.  Lane 0 starts from the true state, so the fixed point is the true decode (induction over t).  Lanes
+// whose entry state did not change keep their result, so after the first two sweeps only the few unsettled ones work.
+// Then block counts and DC differences are prefix-summed across lanes and one last sweep writes the coefficients.
+struct SubState { uint32_t pos; uint16_t c, z; };
+__device__ __forceinline__ bool same(const SubState& a, const SubState& b) { return a.pos == b.pos && a.c == b.c && a.z == b.z; }
+
+struct SubCtx {
+    const DevHuff* huff; const int16_t* quant; const uint8_t* zag;
+    const uint8_t* seg; uint32_t end_bit;
+    const int* par;                     // LDS: [component] -> quant table, DC table, AC table (3 x 3 ints), the segment's image
+    int ny, nb;
+};
+
+// Decode from state `s` while the position is inside this lane's sub-sequence.  WRITE: coefficients / max_zag go out,
+// starting in block `b` with DC predictors pred[]; otherwise only the exit state, the number of blocks finished and the
+// sums of the DC differences are produced.  Returns false on a stream error (only meaningful on the true path).
+template <bool WRITE>
+__device__ __forceinline__ bool sub_decode(const SubCtx& x, SubState& s, int& nblk, int (&dcs)[3], int64_t b, int64_t b_end,
+                                           int16_t* out, uint8_t* mz)
+{
+    DevBits br; br.open(x.seg, s.pos);
+    int c = s.c, z = s.z;
+    nblk = 0;
+    bool ok = true;
+    int comp = c < x.ny ? 0 : c - x.ny + 1;                    // the tables only change when a block ends
+    const int16_t* q = x.quant + x.par[comp] * 64;
+    const DevHuff* dct = x.huff + x.par[3 + comp];
+    const DevHuff* act = x.huff + x.par[6 + comp];
+    while (br.pos < x.end_bit && (!WRITE || b < b_end)) {
+        bool done = false; int kk = z;
+        if (z == 0) {
+            const int sy = br.decode(dct);
+            if (sy < 0) { ok = false; br.drop(16); done = true; }
+            else {
+                const int d = br.receive_extend(sy & 15);
+                const int v = (comp == 0 ? dcs[0] : comp == 1 ? dcs[1] : dcs[2]) + d;
+                if (comp == 0) dcs[0] = v; else if (comp == 1) dcs[1] = v; else dcs[2] = v;
+                if (WRITE) out[b * 64] = (int16_t)((uint32_t)v * (uint32_t)(int32_t)q[0]);
+                z = 1;
+            }
+        } else {
+            const int rs = br.decode(act);
+            if (rs < 0) { ok = false; br.drop(16); done = true; }
+            else {
+                const int run = rs >> 4, size = rs & 15;
+                if (size) {
+                    if (run && z + run > 63) { ok = false; done = true; }
+                    else {
+                        z += run;
+                        const int e = br.receive_extend(size);
+                        if (WRITE) out[b * 64 + x.zag[z]] = (int16_t)((uint32_t)e * (uint32_t)(int32_t)q[z]);
+                        if (++z == 64) { done = true; kk = 64; }
+                    }
+                } else if (run == 15) {
+                    if (z + 16 > 64) { ok = false; done = true; }
+                    else { z += 16; if (z == 64) { done = true; kk = 64; } }
+                } else { done = true; kk = z; }                  // EOB: max_zag = the position it was read at
+            }
+        }
+        if (done) {
+            if (WRITE) mz[b] = (uint8_t)kk;
+            ++b; ++nblk; z = 0;
+            if (++c == x.nb) c = 0;
+            comp = c < x.ny ? 0 : c - x.ny + 1;
+            q = x.quant + x.par[comp] * 64; dct = x.huff + x.par[3 + comp]; act = x.huff + x.par[6 + comp];
+        }
+    }
+    s.pos = br.pos; s.c = (uint16_t)c; s.z = (uint16_t)z;
+    return ok;
+}
+
+template <bool IN_LDS>
+__global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevItem* items, const DevImage* images,
+                                                                    const DevHuff* huff_g, int n_huff, const int16_t* quant_g, int n_quant,
+                                                                    const uint8_t* blob, int16_t* coeffs, uint8_t* max_zag, uint32_t* status)
+{
+    __shared__ DevHuff sh_huff[IN_LDS ? kLdsHuff : 1];
+    __shared__ int16_t sh_quant[IN_LDS ? kLdsQuant * 64 : 1];
+    __shared__ uint8_t sh_zag[64];
+    __shared__ SubState exit_state[kSyncThreads];
+    __shared__ int scan[4][kSyncThreads];                       // blocks finished, DC-difference sums of the three components
+    __shared__ int changed, failed, par[9];
+    load_tables<IN_LDS, kSyncThreads>(sh_huff, sh_quant, sh_zag, huff_g, n_huff, quant_g, n_quant);
+    const int t = threadIdx.x;
+    const DevItem it = items[blockIdx.x];
+    const DevImage im = images[it.image];
+    if (t == 0) {
+        changed = 0; failed = 0;
+        par[0] = im.quant[0]; par[1] = im.quant[1]; par[2] = im.quant[2]; par[3] = im.dc[0]; par[4] = im.dc[1]; par[5] = im.dc[2];
+        par[6] = im.ac[0]; par[7] = im.ac[1]; par[8] = im.ac[2];
+    }
+    __syncthreads();
+    const uint32_t len = (uint32_t)(it.end - it.begin);
+    const uint32_t sub = max(64u, ((len + kSyncThreads - 1) / kSyncThreads + 3) & ~3u);     // bytes per lane
+    const int nsub = (int)((len + sub - 1) / sub);
+    const bool active = t < nsub;
+    const SubCtx x{ IN_LDS ? sh_huff : huff_g, IN_LDS ? sh_quant : quant_g, sh_zag, blob + it.begin, min((uint32_t)(t + 1) * sub, len) * 8u,
+                    par, im.ny, im.nb };
+    int16_t* out = coeffs + im.coeff_off + (int64_t)it.first_mcu * im.nb * 64;
+    uint8_t* mz = max_zag + im.zag_off + (int64_t)it.first_mcu * im.nb;
+    const int64_t total_blocks = (int64_t)it.n_mcus * im.nb;
+
+    // sweep 0: every lane from the start of its own sub-sequence, as if a block began there
+    SubState entry{ (uint32_t)t * sub * 8u, 0, 0 }, mine = entry;
+    int nblk = 0, dcs[3] = { 0, 0, 0 };
+    if (active) sub_decode<false>(x, mine, nblk, dcs, 0, 0, nullptr, nullptr);
+    exit_state[t] = mine;
+    __syncthreads();
+    // sweeps 1..: from the predecessor's exit state, until nothing moves
+    bool settled = false;
+    for (int sweep = 0; sweep < kSyncThreads + 1; ++sweep) {
+        SubState from = t == 0 ? SubState{ 0, 0, 0 } : exit_state[t - 1];
+        __syncthreads();                                        // everybody has read its predecessor
+        if (active && (sweep == 0 || !same(from, entry))) {
+            entry = from; mine = from;
+            dcs[0] = dcs[1] = dcs[2] = 0;
+            sub_decode<false>(x, mine, nblk, dcs, 0, 0, nullptr, nullptr);
+            if (!same(mine, exit_state[t])) { exit_state[t] = mine; changed = 1; }
+        }
+        __syncthreads();
+        const int any = changed;
+        __syncthreads();
+        if (t == 0) changed = 0;
+        if (!any) { settled = true; break; }
+    }
+    (void)settled;                                              // the loop bound (one lane settles per sweep at worst) always reaches the fixed point
+    // exclusive prefix sums over the lanes: first block and DC predictors of every lane
+    scan[0][t] = active ? nblk : 0; scan[1][t] = active ? dcs[0] : 0; scan[2][t] = active ? dcs[1] : 0; scan[3][t] = active ? dcs[2] : 0;
+    __syncthreads();
+    for (int d = 1; d < kSyncThreads; d <<= 1) {
+        int v[4];
+        #pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = t >= d ? scan[k][t - d] : 0;
+        __syncthreads();
+        #pragma unroll
+        for (int k = 0; k < 4; ++k) scan[k][t] += v[k];
+        __syncthreads();
+    }
+    if (active) {
+        const int64_t b0 = scan[0][t] - nblk;
+        int pred[3] = { scan[1][t] - dcs[0], scan[2][t] - dcs[1], scan[3][t] - dcs[2] };
+        SubState s = entry; int n2 = 0;
+        if (!sub_decode<true>(x, s, n2, pred, b0, total_blocks, out, mz)) failed = 1;
+        if (t == nsub - 1 && b0 + n2 != total_blocks) failed = 1;                 // the segment ended before its last block did
+    }
+    __syncthreads();
+    if (t == 0 && failed) atomicOr(status + it.image, 1u);
 }
 
 // Host side: header walk per file, table de-duplication, restart-interval index, one upload, one launch.
@@ -750,44 +908,53 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
                 (k ? im.ac[c] : im.dc[c]) = intern(huffs, d);
             }
         }
-        // the entropy-coded segment: from the SOS payload end to the next marker that is not RSTn / FF00
+        // The entropy-coded segments: from the SOS payload to the next marker that is not RSTn, cut at the RSTn markers.
+        // They are copied UNSTUFFED (the 0x00 after a data 0xFF is dropped) and each is followed by 64 bytes of 0xFF.
         const uint8_t* base = data[i]; const size_t n = len[i];
-        size_t q = P.pos, seg_begin = P.pos;
         const int total_mcus = f.mcus_per_row * f.mcus_per_col;
+        const size_t blob_mark = blob.size(), items_mark = items.size();
         int next_mcu = 0, expect = 0;
-        auto push = [&](size_t b, size_t e, int nm) {
-            DevItem it{}; it.image = i; it.first_mcu = next_mcu; it.n_mcus = nm; it.begin = blob.size() + (b - P.pos); it.end = blob.size() + (e - P.pos);
+        size_t q = P.pos, copy_from = P.pos, seg_begin = blob.size();
+        bool copying = true, bad = false;
+        auto flush = [&](size_t upto) { if (copying && upto > copy_from) blob.insert(blob.end(), base + copy_from, base + upto); };
+        auto close_segment = [&](int nm) {
+            DevItem it{}; it.image = i; it.first_mcu = next_mcu; it.n_mcus = nm; it.begin = seg_begin; it.end = blob.size();
             items.push_back(it); next_mcu += nm;
+            blob.insert(blob.end(), 64, (uint8_t)0xFF);
+            seg_begin = blob.size();
         };
-        bool bad = false;
         while (true) {
             const uint8_t* hit = q < n ? (const uint8_t*)memchr(base + q, 0xFF, n - q) : nullptr;
-            if (!hit || hit + 1 >= base + n) { q = n; break; }
+            if (!hit || hit + 1 >= base + n) { flush(n); q = n; break; }
             const uint8_t m = hit[1];
             q = (size_t)(hit - base);
-            if (m == 0x00 || m == 0xFF) { q += (m == 0xFF) ? 1 : 2; continue; }
+            if (m == 0x00) { flush(q + 1); copy_from = q + 2; q += 2; continue; }          // stuffed 0xFF: keep the FF, drop the 00
+            flush(q); copying = false;                                                        // FF + non-zero: the data ends here (get_octet :683-696)
+            if (m == 0xFF) { q += 1; continue; }                                              // fill bytes before a marker
             if (m >= 0xD0 && m <= 0xD7 && P.restart_interval && next_mcu + P.restart_interval < total_mcus) {
                 if (m != 0xD0 + expect) { bad = true; break; }
-                push(seg_begin, q, P.restart_interval);
-                expect = (expect + 1) & 7; q += 2; seg_begin = q;
+                close_segment(P.restart_interval);
+                expect = (expect + 1) & 7; q += 2; copy_from = q; copying = true;
                 continue;
             }
             break;                                             // EOI or any other marker ends the scan
         }
         if (!bad && next_mcu < total_mcus) {
             if (P.restart_interval && total_mcus - next_mcu > P.restart_interval) bad = true;      // a restart marker is missing
-            else push(seg_begin, q, total_mcus - next_mcu);
+            else close_segment(total_mcus - next_mcu);
         }
         if (bad) {
-            while (!items.empty() && items.back().image == i) items.pop_back();
+            items.resize(items_mark); blob.resize(blob_mark);
             fail(&f, "bad restart marker");
             hst[(size_t)i] = GAMUT_HIP_ERR_DECODE;
             if (first_failure == GAMUT_HIP_OK) { first_failure = GAMUT_HIP_ERR_DECODE; snprintf(first_msg, sizeof(first_msg), "image %d: bad restart marker", i); }
             continue;
         }
-        blob.insert(blob.end(), base + P.pos, base + q);
-        blob.insert(blob.end(), 8, (uint8_t)0xFF);             // slack so a 4-byte fetch at the end of a segment stays inside the blob
     }
+    // long segments get a workgroup each (self-synchronising decode), short ones a lane each
+    std::stable_partition(items.begin(), items.end(), [](const DevItem& it) { return it.end - it.begin >= kSyncMinBytes; });
+    int n_long = 0;
+    while (n_long < (int)items.size() && items[(size_t)n_long].end - items[(size_t)n_long].begin >= kSyncMinBytes) ++n_long;
 
     ms_parse = ms_since(t_begin);
     if (!items.empty()) {
@@ -817,20 +984,38 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
         }
         if (trace) { (void)hipStreamSynchronize(stream); ms_upload = ms_since(t_up); }
         const auto t_k = std::chrono::steady_clock::now();
-        const int n_items = (int)items.size(), n_huff = (int)huffs.size(), n_quant = (int)quants.size();
-        const dim3 grid((n_items + kEntropyThreads - 1) / kEntropyThreads), block(kEntropyThreads);
-        if (n_huff <= kLdsHuff && n_quant <= kLdsQuant)
-            hipLaunchKernelGGL(k_jpeg_entropy<true>, grid, block, 0, stream,
-                               (const DevItem*)(d + o_items), n_items, (const DevImage*)(d + o_img), (const DevHuff*)(d + o_huff), n_huff,
-                               (const int16_t*)(d + o_quant), n_quant, (const uint8_t*)(d + o_blob), d_coeffs, d_max_zag, st);
-        else
-            hipLaunchKernelGGL(k_jpeg_entropy<false>, grid, block, 0, stream,
-                               (const DevItem*)(d + o_items), n_items, (const DevImage*)(d + o_img), (const DevHuff*)(d + o_huff), n_huff,
-                               (const int16_t*)(d + o_quant), n_quant, (const uint8_t*)(d + o_blob), d_coeffs, d_max_zag, st);
+        const int n_items = (int)items.size(), n_huff = (int)huffs.size(), n_quant = (int)quants.size(), n_short = n_items - n_long;
+        const bool in_lds = n_huff <= kLdsHuff && n_quant <= kLdsQuant;
+        const DevItem* d_items = (const DevItem*)(d + o_items); const DevImage* d_img = (const DevImage*)(d + o_img);
+        const DevHuff* d_huff = (const DevHuff*)(d + o_huff); const int16_t* d_quant = (const int16_t*)(d + o_quant);
+        const uint8_t* d_blob = (const uint8_t*)(d + o_blob);
+        if (n_long) {
+            // lanes of a workgroup share blocks, so coefficients are written in place: clear the images concerned first
+            // (adjacent ones in one call)
+            std::vector<char> needs((size_t)count, 0);
+            for (int k = 0; k < n_long; ++k) needs[(size_t)items[(size_t)k].image] = 1;
+            auto blocks = [&](int k) { return (int64_t)info[k].mcus_per_row * info[k].mcus_per_col * info[k].blocks_per_mcu; };
+            for (int i = 0; i < count; ) {
+                if (!needs[(size_t)i]) { ++i; continue; }
+                const int64_t begin = coeff_offset[i]; int64_t endo = begin + blocks(i) * 64;
+                int j = i + 1;
+                while (j < count && needs[(size_t)j] && coeff_offset[j] == endo) { endo += blocks(j) * 64; ++j; }
+                GAMUT_HIP_CHECK(hipMemsetAsync(d_coeffs + begin, 0, (size_t)(endo - begin) * sizeof(int16_t), stream));
+                i = j;
+            }
+            if (in_lds) hipLaunchKernelGGL(k_jpeg_entropy_sync<true>, dim3(n_long), dim3(kSyncThreads), 0, stream, d_items, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
+            else        hipLaunchKernelGGL(k_jpeg_entropy_sync<false>, dim3(n_long), dim3(kSyncThreads), 0, stream, d_items, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
+            if (int rc = launch_status("jpeg_entropy_sync")) return rc;
+        }
+        if (n_short) {
+            const dim3 grid((n_short + kEntropyThreads - 1) / kEntropyThreads), block(kEntropyThreads);
+            if (in_lds) hipLaunchKernelGGL(k_jpeg_entropy<true>, grid, block, 0, stream, d_items + n_long, n_short, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
+            else        hipLaunchKernelGGL(k_jpeg_entropy<false>, grid, block, 0, stream, d_items + n_long, n_short, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
+        }
         if (int rc = launch_status("jpeg_entropy")) return rc;
         GAMUT_HIP_CHECK(hipStreamSynchronize(stream));         // the pageable staging vector dies with this call
-        if (trace) fprintf(stderr, "[gamut_hip] jpeg_entropy_decode_device: %d files, %d lanes, %d+%d tables, %.1f MB compressed: parse %.1f ms, upload %.1f ms, kernel %.1f ms\n",
-                           count, n_items, n_huff, n_quant, blob.size() / 1e6, ms_parse, ms_upload, ms_since(t_k));
+        if (trace) fprintf(stderr, "[gamut_hip] jpeg_entropy_decode_device: %d files, %d long + %d short segments, %d+%d tables, %.1f MB compressed: parse %.1f ms, upload %.1f ms, kernels %.1f ms\n",
+                           count, n_long, n_short, n_huff, n_quant, blob.size() / 1e6, ms_parse, ms_upload, ms_since(t_k));
     }
     if (host_status) memcpy(host_status, hst.data(), (size_t)count * sizeof(int));
     if (first_failure != GAMUT_HIP_OK) return set_error(first_failure, "%s", first_msg);

@@ -861,6 +861,96 @@ template <class T> int intern(std::vector<T>& pool, const T& t)      // index of
 }
 struct QuantTab { int16_t q[64]; };
 
+// What the host prepares for one file, independently of every other file (so files are spread over host threads): header
+// walk, tables in device form, and the entropy-coded segments copied UNSTUFFED (the 0x00 after a data 0xFF dropped), cut
+// at the RSTn markers, each followed by 64 bytes of 0xFF.
+struct FilePrep {
+    int rc = GAMUT_HIP_OK; char msg[200] = { 0 };
+    int comps = 0, nb = 0, ny = 0;
+    QuantTab quant[3]; DevHuff huff[3][2];                     // [component][DC, AC]
+    std::vector<DevItem> items;                                // begin / end relative to `bytes`
+    std::vector<uint8_t> bytes;
+};
+
+void prepare_file(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& f, FilePrep& out, Parser& P)
+{
+    P = Parser();
+    out.rc = parse_baseline(P, base, n, &f, true);
+    if (out.rc != GAMUT_HIP_OK) { snprintf(out.msg, sizeof(out.msg), "image %d: %s", i, last_error_buf()); return; }
+    out.comps = f.comps; out.nb = f.blocks_per_mcu; out.ny = f.comps == 1 ? 1 : P.hs[0] * P.vs[0];
+    for (int c = 0; c < f.comps; ++c) {
+        memcpy(out.quant[c].q, P.quant[P.tq[c]], sizeof(out.quant[c].q));
+        for (int k = 0; k < 2; ++k) {
+            const HuffTable& h = P.huff[k ? P.ta[c] : P.td[c]];
+            DevHuff& d = out.huff[c][k]; memset(&d, 0, sizeof(d));
+            for (int w = 0; w < 512; ++w) { const uint16_t e = h.fast[w << 1]; d.fast[w] = (e >> 8) <= 9 ? e : 0; }   // 10-bit table -> 9-bit
+            memcpy(d.maxcode, h.maxcode, sizeof(d.maxcode)); memcpy(d.delta, h.delta, sizeof(d.delta)); memcpy(d.vals, h.vals, sizeof(d.vals));
+        }
+    }
+    const int total_mcus = f.mcus_per_row * f.mcus_per_col;
+    std::vector<uint8_t>& blob = out.bytes;
+    blob.reserve(n - P.pos + 64 + (size_t)(P.restart_interval ? (total_mcus / P.restart_interval + 1) * 64 : 0));
+    int next_mcu = 0, expect = 0;
+    size_t q = P.pos, copy_from = P.pos, seg_begin = 0;
+    bool copying = true, bad = false;
+    auto flush = [&](size_t upto) { if (copying && upto > copy_from) blob.insert(blob.end(), base + copy_from, base + upto); };
+    auto close_segment = [&](int nm) {
+        DevItem it{}; it.image = i; it.first_mcu = next_mcu; it.n_mcus = nm; it.begin = seg_begin; it.end = blob.size();
+        out.items.push_back(it); next_mcu += nm;
+        blob.insert(blob.end(), 64, (uint8_t)0xFF);
+        seg_begin = blob.size();
+    };
+    while (true) {
+        const uint8_t* hit = q < n ? (const uint8_t*)memchr(base + q, 0xFF, n - q) : nullptr;
+        if (!hit || hit + 1 >= base + n) { flush(n); q = n; break; }
+        const uint8_t m = hit[1];
+        q = (size_t)(hit - base);
+        if (m == 0x00) { flush(q + 1); copy_from = q + 2; q += 2; continue; }          // stuffed 0xFF: keep the FF, drop the 00
+        flush(q); copying = false;                                                        // FF + non-zero: the data ends here (get_octet :683-696)
+        if (m == 0xFF) { q += 1; continue; }                                              // fill bytes before a marker
+        if (m >= 0xD0 && m <= 0xD7 && P.restart_interval && next_mcu + P.restart_interval < total_mcus) {
+            if (m != 0xD0 + expect) { bad = true; break; }
+            close_segment(P.restart_interval);
+            expect = (expect + 1) & 7; q += 2; copy_from = q; copying = true;
+            continue;
+        }
+        break;                                             // EOI or any other marker ends the scan
+    }
+    if (!bad && next_mcu < total_mcus) {
+        if (P.restart_interval && total_mcus - next_mcu > P.restart_interval) bad = true;      // a restart marker is missing
+        else close_segment(total_mcus - next_mcu);
+    }
+    if (bad) {
+        out.items.clear(); blob.clear();
+        fail(&f, "bad restart marker");
+        out.rc = GAMUT_HIP_ERR_DECODE; snprintf(out.msg, sizeof(out.msg), "image %d: bad restart marker", i);
+    }
+}
+
+struct PinnedHost {                    // per-thread page-locked staging for the upload, grown on demand, never shrunk
+    uint8_t* p = nullptr; size_t cap = 0;
+    uint8_t* get(size_t n)
+    {
+        if (n > cap) {
+            if (p) { (void)hipDeviceSynchronize(); (void)hipHostFree(p); p = nullptr; cap = 0; }
+            void* np = nullptr;
+            if (hipHostMalloc(&np, n + n / 4 + 4096, hipHostMallocDefault) != hipSuccess) return nullptr;
+            p = (uint8_t*)np; cap = n + n / 4 + 4096;
+        }
+        return p;
+    }
+};
+
+template <class Fn> void parallel_for(int count, int workers, Fn fn)          // fn(worker, index); the caller runs worker 0
+{
+    std::atomic<int> next{ 0 };
+    auto run = [&](int w) { for (int i; (i = next.fetch_add(1, std::memory_order_relaxed)) < count; ) fn(w, i); };
+    std::vector<std::thread> pool;
+    try { for (int w = 1; w < workers; ++w) pool.emplace_back(run, w); } catch (...) {}
+    run(0);
+    for (std::thread& th : pool) th.join();
+}
+
 int entropy_decode_device(const uint8_t* const* data, const size_t* len, int count,
                           const int64_t* coeff_offset, const int64_t* zag_offset,
                           int16_t* d_coeffs, uint8_t* d_max_zag, uint32_t* d_status,
@@ -869,112 +959,71 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
     const bool trace = getenv("GAMUT_HIP_TRACE") != nullptr;           // stage timings on stderr (tools/e2e_bench.py)
     const auto t_begin = std::chrono::steady_clock::now();
     auto ms_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
-    double ms_parse = 0, ms_upload = 0;
+    if (((uintptr_t)d_coeffs & 15) != 0) return set_error(GAMUT_HIP_ERR_INVALID_ARG, "jpeg_entropy_decode_device: the coefficient buffer must be 16-byte aligned");
+    for (int i = 0; i < count; ++i)
+        if ((coeff_offset[i] & 7) != 0) return set_error(GAMUT_HIP_ERR_INVALID_ARG, "jpeg_entropy_decode_device: coefficient offsets must be multiples of 8 elements (image %d)", i);
+
+    // 1. per file, on up to 16 host threads
+    int workers = (int)std::thread::hardware_concurrency();
+    workers = workers < 1 ? 1 : workers > 16 ? 16 : workers;
+    if (workers > (count + 7) / 8) workers = (count + 7) / 8;
+    std::vector<FilePrep> prep((size_t)count);
+    {
+        std::vector<Parser*> parsers((size_t)workers, nullptr);
+        for (Parser*& p : parsers) p = new Parser();
+        parallel_for(count, workers, [&](int w, int i) { prepare_file(i, data[i], len[i], info[i], prep[(size_t)i], *parsers[(size_t)w]); });
+        for (Parser* p : parsers) delete p;
+    }
+    // 2. serial: table de-duplication, layout of the upload
     std::vector<DevImage> images((size_t)count);
-    std::vector<int> hst((size_t)count, GAMUT_HIP_OK);              // per-file header status
     std::vector<DevItem> items;
     std::vector<DevHuff> huffs;
     std::vector<QuantTab> quants;
-    std::vector<uint8_t> blob;
-    int first_failure = GAMUT_HIP_OK; char first_msg[256] = { 0 };
-    Parser* ps = new (std::nothrow) Parser();
-    if (!ps) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: out of memory");
-    struct Guard { Parser* p; ~Guard() { delete p; } } guard{ ps };
-
+    std::vector<size_t> blob_off((size_t)count, 0);
+    size_t blob_size = 0;
+    int first_failure = GAMUT_HIP_OK; const char* first_msg = "";
     for (int i = 0; i < count; ++i) {
-        *ps = Parser();
-        Parser& P = *ps;
-        gamut_hip_jpeg_frame& f = info[i];
-        const int rc = parse_baseline(P, data[i], len[i], &f, true);
-        hst[(size_t)i] = rc;
-        memset(&images[(size_t)i], 0, sizeof(DevImage));
-        if (rc != GAMUT_HIP_OK) {
-            if (first_failure == GAMUT_HIP_OK) { first_failure = rc; snprintf(first_msg, sizeof(first_msg), "image %d: %s", i, last_error_buf()); }
-            continue;
-        }
+        FilePrep& fp = prep[(size_t)i];
         DevImage& im = images[(size_t)i];
-        im.coeff_off = coeff_offset[i]; im.zag_off = zag_offset[i];
-        if ((coeff_offset[i] & 7) != 0 || ((uintptr_t)d_coeffs & 15) != 0)
-            return set_error(GAMUT_HIP_ERR_INVALID_ARG, "jpeg_entropy_decode_device: coefficient buffers must be 16-byte aligned (offset %d)", i);
-        im.nb = f.blocks_per_mcu; im.ny = f.comps == 1 ? 1 : P.hs[0] * P.vs[0];
-        for (int c = 0; c < f.comps; ++c) {
-            QuantTab qt; memcpy(qt.q, P.quant[P.tq[c]], sizeof(qt.q));
-            im.quant[c] = intern(quants, qt);
-            for (int k = 0; k < 2; ++k) {
-                const HuffTable& h = P.huff[k ? P.ta[c] : P.td[c]];
-                DevHuff d; memset(&d, 0, sizeof(d));
-                for (int w = 0; w < 512; ++w) { const uint16_t e = h.fast[w << 1]; d.fast[w] = (e >> 8) <= 9 ? e : 0; }   // 10-bit table -> 9-bit
-                memcpy(d.maxcode, h.maxcode, sizeof(d.maxcode)); memcpy(d.delta, h.delta, sizeof(d.delta)); memcpy(d.vals, h.vals, sizeof(d.vals));
-                (k ? im.ac[c] : im.dc[c]) = intern(huffs, d);
-            }
-        }
-        // The entropy-coded segments: from the SOS payload to the next marker that is not RSTn, cut at the RSTn markers.
-        // They are copied UNSTUFFED (the 0x00 after a data 0xFF is dropped) and each is followed by 64 bytes of 0xFF.
-        const uint8_t* base = data[i]; const size_t n = len[i];
-        const int total_mcus = f.mcus_per_row * f.mcus_per_col;
-        const size_t blob_mark = blob.size(), items_mark = items.size();
-        int next_mcu = 0, expect = 0;
-        size_t q = P.pos, copy_from = P.pos, seg_begin = blob.size();
-        bool copying = true, bad = false;
-        auto flush = [&](size_t upto) { if (copying && upto > copy_from) blob.insert(blob.end(), base + copy_from, base + upto); };
-        auto close_segment = [&](int nm) {
-            DevItem it{}; it.image = i; it.first_mcu = next_mcu; it.n_mcus = nm; it.begin = seg_begin; it.end = blob.size();
-            items.push_back(it); next_mcu += nm;
-            blob.insert(blob.end(), 64, (uint8_t)0xFF);
-            seg_begin = blob.size();
-        };
-        while (true) {
-            const uint8_t* hit = q < n ? (const uint8_t*)memchr(base + q, 0xFF, n - q) : nullptr;
-            if (!hit || hit + 1 >= base + n) { flush(n); q = n; break; }
-            const uint8_t m = hit[1];
-            q = (size_t)(hit - base);
-            if (m == 0x00) { flush(q + 1); copy_from = q + 2; q += 2; continue; }          // stuffed 0xFF: keep the FF, drop the 00
-            flush(q); copying = false;                                                        // FF + non-zero: the data ends here (get_octet :683-696)
-            if (m == 0xFF) { q += 1; continue; }                                              // fill bytes before a marker
-            if (m >= 0xD0 && m <= 0xD7 && P.restart_interval && next_mcu + P.restart_interval < total_mcus) {
-                if (m != 0xD0 + expect) { bad = true; break; }
-                close_segment(P.restart_interval);
-                expect = (expect + 1) & 7; q += 2; copy_from = q; copying = true;
-                continue;
-            }
-            break;                                             // EOI or any other marker ends the scan
-        }
-        if (!bad && next_mcu < total_mcus) {
-            if (P.restart_interval && total_mcus - next_mcu > P.restart_interval) bad = true;      // a restart marker is missing
-            else close_segment(total_mcus - next_mcu);
-        }
-        if (bad) {
-            items.resize(items_mark); blob.resize(blob_mark);
-            fail(&f, "bad restart marker");
-            hst[(size_t)i] = GAMUT_HIP_ERR_DECODE;
-            if (first_failure == GAMUT_HIP_OK) { first_failure = GAMUT_HIP_ERR_DECODE; snprintf(first_msg, sizeof(first_msg), "image %d: bad restart marker", i); }
-            continue;
-        }
+        memset(&im, 0, sizeof(im));
+        if (host_status) host_status[i] = fp.rc;
+        if (fp.rc != GAMUT_HIP_OK) { if (first_failure == GAMUT_HIP_OK) { first_failure = fp.rc; first_msg = fp.msg; } continue; }
+        im.coeff_off = coeff_offset[i]; im.zag_off = zag_offset[i]; im.nb = fp.nb; im.ny = fp.ny;
+        for (int c = 0; c < fp.comps; ++c) { im.quant[c] = intern(quants, fp.quant[c]); im.dc[c] = intern(huffs, fp.huff[c][0]); im.ac[c] = intern(huffs, fp.huff[c][1]); }
+        blob_off[(size_t)i] = blob_size;
+        for (DevItem it : fp.items) { it.begin += blob_size; it.end += blob_size; items.push_back(it); }
+        blob_size += (fp.bytes.size() + 15) & ~(size_t)15;
     }
     // long segments get a workgroup each (self-synchronising decode), short ones a lane each
     std::stable_partition(items.begin(), items.end(), [](const DevItem& it) { return it.end - it.begin >= kSyncMinBytes; });
     int n_long = 0;
     while (n_long < (int)items.size() && items[(size_t)n_long].end - items[(size_t)n_long].begin >= kSyncMinBytes) ++n_long;
+    const double ms_parse = ms_since(t_begin);
+    double ms_upload = 0;
 
-    ms_parse = ms_since(t_begin);
     if (!items.empty()) {
         const auto t_up = std::chrono::steady_clock::now();
-        // one device staging allocation: [items][images][huff][quant][blob]; the tables go up as one small copy, the
-        // compressed bytes as another
+        // 3. one pinned host image of the upload, [items][images][huff][quant][blob], the segments copied in by the workers,
+        //    one DMA to a device staging buffer of the same layout
         auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
         const size_t o_items = 0, o_img = align(o_items + items.size() * sizeof(DevItem)), o_huff = align(o_img + images.size() * sizeof(DevImage)),
                      o_quant = align(o_huff + huffs.size() * sizeof(DevHuff)), o_blob = align(o_quant + quants.size() * sizeof(QuantTab)),
-                     total = o_blob + blob.size();
+                     total = o_blob + blob_size + 64;
         static thread_local EntropyScratch scratch;
+        static thread_local PinnedHost pinned;
         uint8_t* d = (uint8_t*)scratch.get(total);
-        if (!d) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: device staging allocation of %zu bytes failed", total);
-        std::vector<uint8_t> meta(o_blob);
-        memcpy(meta.data() + o_items, items.data(), items.size() * sizeof(DevItem));
-        memcpy(meta.data() + o_img, images.data(), images.size() * sizeof(DevImage));
-        memcpy(meta.data() + o_huff, huffs.data(), huffs.size() * sizeof(DevHuff));
-        memcpy(meta.data() + o_quant, quants.data(), quants.size() * sizeof(QuantTab));
-        GAMUT_HIP_CHECK(hipMemcpyAsync(d, meta.data(), o_blob, hipMemcpyHostToDevice, stream));
-        GAMUT_HIP_CHECK(hipMemcpyAsync(d + o_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, stream));
+        uint8_t* h = pinned.get(total);
+        if (!d || !h) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: staging allocation of %zu bytes failed", total);
+        memcpy(h + o_items, items.data(), items.size() * sizeof(DevItem));
+        memcpy(h + o_img, images.data(), images.size() * sizeof(DevImage));
+        memcpy(h + o_huff, huffs.data(), huffs.size() * sizeof(DevHuff));
+        memcpy(h + o_quant, quants.data(), quants.size() * sizeof(QuantTab));
+        parallel_for(count, workers, [&](int, int i) {
+            const FilePrep& fp = prep[(size_t)i];
+            if (fp.rc == GAMUT_HIP_OK && !fp.bytes.empty()) memcpy(h + o_blob + blob_off[(size_t)i], fp.bytes.data(), fp.bytes.size());
+        });
+        memset(h + o_blob + blob_size, 0xFF, 64);
+        GAMUT_HIP_CHECK(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, stream));
         if (d_status) GAMUT_HIP_CHECK(hipMemsetAsync(d_status, 0, (size_t)count * sizeof(uint32_t), stream));
         uint32_t* st = d_status;
         if (!st) {                                             // the kernel wants somewhere to flag errors
@@ -1013,11 +1062,10 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
             else        hipLaunchKernelGGL(k_jpeg_entropy<false>, grid, block, 0, stream, d_items + n_long, n_short, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
         }
         if (int rc = launch_status("jpeg_entropy")) return rc;
-        GAMUT_HIP_CHECK(hipStreamSynchronize(stream));         // the pageable staging vector dies with this call
-        if (trace) fprintf(stderr, "[gamut_hip] jpeg_entropy_decode_device: %d files, %d long + %d short segments, %d+%d tables, %.1f MB compressed: parse %.1f ms, upload %.1f ms, kernels %.1f ms\n",
-                           count, n_long, n_short, n_huff, n_quant, blob.size() / 1e6, ms_parse, ms_upload, ms_since(t_k));
+        GAMUT_HIP_CHECK(hipStreamSynchronize(stream));         // the per-thread staging buffers are reused by the next call
+        if (trace) fprintf(stderr, "[gamut_hip] jpeg_entropy_decode_device: %d files, %d long + %d short segments, %d+%d tables, %.1f MB compressed, %d host threads: parse %.1f ms, upload %.1f ms, kernels %.1f ms\n",
+                           count, n_long, n_short, n_huff, n_quant, blob_size / 1e6, workers, ms_parse, ms_upload, ms_since(t_k));
     }
-    if (host_status) memcpy(host_status, hst.data(), (size_t)count * sizeof(int));
     if (first_failure != GAMUT_HIP_OK) return set_error(first_failure, "%s", first_msg);
     return GAMUT_HIP_OK;
 }

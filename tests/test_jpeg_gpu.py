@@ -266,10 +266,13 @@ def test_device_entropy_decode_large_and_restart_parallel(hip):
     img = Image.fromarray(gen.synth_rgb(1920, 1080, 11))
     blobs = []
     for kw in (dict(quality=90, subsampling=2), dict(quality=90, subsampling=2, restart_marker_rows=2),
-               dict(quality=50, subsampling=0, optimize=True), dict(quality=95, subsampling=1, restart_marker_blocks=7)):
+               dict(quality=50, subsampling=0, optimize=True), dict(quality=95, subsampling=1, restart_marker_blocks=7),
+               dict(quality=98, subsampling=1, restart_marker_rows=9), dict(quality=30, subsampling=2)):
         bio = io.BytesIO(); img.save(bio, "JPEG", **kw); blobs.append(bio.getvalue())
+    bio = io.BytesIO(); img.convert("L").save(bio, "JPEG", quality=92); blobs.append(bio.getvalue())             # grey: one block per MCU
+    bio = io.BytesIO(); Image.fromarray(gen.synth_rgb(4000, 3000, 12)).save(bio, "JPEG", quality=97, subsampling=0); blobs.append(bio.getvalue())   # a ~5 MB scan
     rc, hst, st, res = _entropy_decode_device(hip, blobs)
-    assert rc == 0 and hst == [0] * 4 and not st.any()
+    assert rc == 0 and hst == [0] * len(blobs) and not st.any()
     for data, (co, zz, info) in zip(blobs, res):
         d = O.DecodedJpeg(data)
         assert np.array_equal(co, d.coeffs) and np.array_equal(zz, d.max_zag)
@@ -289,6 +292,21 @@ def test_device_entropy_decode_corrupt_streams(hip):
     assert hst[3] == _capi.ERR_DECODE and hst[4] == _capi.ERR_DECODE and rc == _capi.ERR_DECODE
     d = O.DecodedJpeg(good)
     for i in (0, 5):                                   # neighbours of the damaged files are intact
+        assert np.array_equal(res[i][0], d.coeffs) and np.array_equal(res[i][1], d.max_zag)
+    # the same for a scan long enough for the multi-lane (self-synchronising) kernel
+    import io
+    from PIL import Image
+    import gen
+    bio = io.BytesIO(); Image.fromarray(gen.synth_rgb(1920, 1080, 13)).save(bio, "JPEG", quality=90, subsampling=2)
+    big = bio.getvalue(); sos = big.index(b"\xff\xda")
+    noisy = bytearray(big)
+    for k in rng.integers(sos + 20, len(big) - 2, 300):
+        noisy[k] = int(rng.integers(0, 255))
+    blobs = [big, bytes(noisy), big[:len(big) // 2], big[:sos + 5000] + big[-2:], big]
+    rc, hst, st, res = _entropy_decode_device(hip, blobs)
+    assert hst == [0] * 5 and st[0] == 0 and st[4] == 0 and st[2] != 0 and st[3] != 0
+    d = O.DecodedJpeg(big)
+    for i in (0, 4):
         assert np.array_equal(res[i][0], d.coeffs) and np.array_equal(res[i][1], d.max_zag)
 
 

@@ -32,9 +32,11 @@ struct HuffTable {
     // slow path: canonical ranges
     int32_t  maxcode[18];
     int32_t  delta[17];           // valptr - mincode
-    void build()
+    bool build()                   // false: the code-length counts over-subscribe the code space (not a prefix code)
     {
         int code = 0, k = 0;
+        for (int len = 1; len <= 16; ++len) { code += bits[len]; if (code > (1 << len)) return false; code <<= 1; }
+        code = 0;
         for (int len = 1; len <= 16; ++len) {
             delta[len] = k - code;
             code += bits[len]; k += bits[len];
@@ -51,6 +53,7 @@ struct HuffTable {
             }
             code <<= 1;
         }
+        return true;
     }
 };
 
@@ -161,7 +164,9 @@ int next_scan(Parser& P, gamut_hip_jpeg_frame* f)
                 s += 17; n -= 17;
                 if (cnt > 255 || n < cnt) { fail(f, "bad DHT counts"); return -1; }
                 memset(h.vals, 0, sizeof(h.vals)); memcpy(h.vals, s, (size_t)cnt);
-                s += cnt; n -= cnt; h.defined = true; h.build();
+                s += cnt; n -= cnt;
+                if (!h.build()) { h.defined = false; fail(f, "bad DHT counts (not a prefix code)"); return -1; }
+                h.defined = true;
             }
             break;
         case 0xC0: case 0xC1: case 0xC2: {                     // SOF0 / SOF1 / SOF2 :1349-1417, :1596-1607

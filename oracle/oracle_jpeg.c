@@ -281,9 +281,11 @@ typedef struct {
     uint16_t look[512];      /* 9-bit lookahead: (len << 8) | symbol, 0 = miss */
 } hufftab;
 
-static void huff_build(hufftab* h)
+static int huff_build(hufftab* h)      /* 0 = ok, -1 = the length counts over-subscribe the code space */
 {
     int code = 0, k = 0;
+    for (int l = 1; l <= 16; ++l) { code += h->num[l]; if (code > (1 << l)) return -1; code <<= 1; }
+    code = 0;
     for (int l = 1; l <= 16; ++l) {
         h->valptr[l] = k;
         h->mincode[l] = code;
@@ -303,6 +305,7 @@ static void huff_build(hufftab* h)
         }
         code <<= 1;
     }
+    return 0;
 }
 
 typedef struct {
@@ -402,7 +405,8 @@ static int scan_header(jstate* S, orc_jpeg_frame* f)
                 if (count > 255 || n < count) return -1;
                 memset(h->val, 0, 256); memcpy(h->val, s, (size_t)count);
                 s += count; n -= count;
-                h->present = 1; huff_build(h);
+                if (huff_build(h)) return -1;
+                h->present = 1;
             }
         } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) { /* SOF0/SOF1/SOF2 :1349-1417, :1596-1607 */
             if (S->have_sof) return -1;

@@ -131,6 +131,22 @@ def test_qoi_header_needs_no_device():
     assert L.gamut_hip_qoi_read_header(data.ctypes.data, data.size, None) == _capi.ERR_INVALID_ARG
 
 
+def test_jpeg_rejects_huffman_tables_that_are_not_prefix_codes():
+    """a DHT whose length counts over-subscribe the code space (found by tools/fuzz_host.sh: it overflowed the look-up table)"""
+    L = _capi.lib()
+    good = open(os.path.join(G, "jpeg", "s_16x16_420.jpg"), "rb").read()
+    i = good.index(b"\xff\xc4")
+    bad = bytearray(good)
+    bad[i + 5] = 3                                  # three codes of length 1
+    fr = _capi.JpegFrame()
+    buf = np.frombuffer(bytes(bad), np.uint8)
+    assert L.gamut_hip_jpeg_decode_coeffs(buf.ctypes.data, buf.size, C.byref(fr)) == _capi.ERR_DECODE
+    assert b"prefix code" in L.gamut_hip_last_error() and not fr.coeffs
+    assert L.gamut_hip_jpeg_read_header(buf.ctypes.data, buf.size, C.byref(fr)) == _capi.ERR_DECODE
+    with pytest.raises(ValueError):
+        O.DecodedJpeg(bytes(bad))
+
+
 def test_jpeg_feeder_rejects_bad_streams():
     L = _capi.lib()
     fr = _capi.JpegFrame()

@@ -137,7 +137,10 @@ def test_jpeg_rejects_huffman_tables_that_are_not_prefix_codes():
     good = open(os.path.join(G, "jpeg", "s_16x16_420.jpg"), "rb").read()
     i = good.index(b"\xff\xc4")
     bad = bytearray(good)
-    bad[i + 5] = 3                                  # three codes of length 1
+    counts = list(bad[i + 5:i + 21])
+    k = max(range(16), key=lambda j: counts[j])
+    assert counts[k] >= 3
+    bad[i + 5] = counts[0] + 3; bad[i + 5 + k] = counts[k] - 3          # three codes of length 1, same number of symbols
     fr = _capi.JpegFrame()
     buf = np.frombuffer(bytes(bad), np.uint8)
     assert L.gamut_hip_jpeg_decode_coeffs(buf.ctypes.data, buf.size, C.byref(fr)) == _capi.ERR_DECODE

@@ -1143,6 +1143,24 @@ int gamut_hip_jpeg_read_header(const uint8_t* data, size_t len, gamut_hip_jpeg_f
     return rc;
 }
 
+int gamut_hip_jpeg_scan_layout(const uint8_t* data, size_t len, gamut_hip_jpeg_frame* info, int32_t* segments, uint64_t* entropy_bytes)
+{
+    clear_error();
+    if (!info) return set_error(GAMUT_HIP_ERR_INVALID_ARG, "jpeg_scan_layout: null frame");
+    try {
+        Parser* ps = new Parser();
+        FilePrep fp;
+        prepare_file(0, data, len, *info, fp, *ps);
+        delete ps;
+        if (segments) *segments = (int32_t)fp.items.size();
+        if (entropy_bytes) *entropy_bytes = fp.bytes.size();
+        if (fp.rc != GAMUT_HIP_OK) return set_error(fp.rc, "%s", fp.msg);
+        return GAMUT_HIP_OK;
+    } catch (...) {
+        return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg_scan_layout: out of host memory");
+    }
+}
+
 int gamut_hip_jpeg_entropy_decode_device(const uint8_t* const* data, const size_t* len, int count,
                                          const int64_t* coeff_offset, const int64_t* zag_offset,
                                          int16_t* coeffs, uint8_t* max_zag, uint32_t* status_dev,

@@ -101,6 +101,22 @@ def test_jpeg_batch_feeder_threads():
     assert L.gamut_hip_jpeg_decode_coeffs_batch(None, None, 3, None, None, 2) == _capi.ERR_INVALID_ARG
 
 
+def test_jpeg_scan_layout():
+    """segments the device entropy decoder would get: 1 without restart markers, one per interval with them"""
+    L = _capi.lib()
+    for name, nseg in (("s_131x97_420.jpg", 1), ("s_131x97_420_rst.jpg", None), ("p_131x97_420.jpg", -1)):
+        buf = np.frombuffer(open(os.path.join(G, "jpeg", name), "rb").read(), np.uint8)
+        fr = _capi.JpegFrame(); seg = C.c_int32(); nbytes = C.c_uint64()
+        rc = L.gamut_hip_jpeg_scan_layout(buf.ctypes.data, buf.size, C.byref(fr), C.byref(seg), C.byref(nbytes))
+        if nseg == -1:
+            assert rc == _capi.ERR_UNSUPPORTED                                 # progressive: host feeder
+            continue
+        assert rc == 0 and (fr.width, fr.height) == (131, 97)
+        mcus = fr.mcus_per_row * fr.mcus_per_col
+        assert seg.value == (1 if nseg == 1 else (mcus + 2) // 3)             # restart_marker_blocks=3 in tools/make_fixtures.py
+        assert 0 < nbytes.value <= buf.size + 64 * seg.value
+
+
 def test_jpeg_read_header_needs_no_device():
     """gamut_hip_jpeg_read_header: geometry without entropy decoding (what a caller sizes its device buffers from)"""
     L = _capi.lib()

@@ -23,6 +23,7 @@ def main():
     L = C.CDLL(os.environ["GAMUT_HIP_LIB"])
     L.gamut_hip_jpeg_decode_coeffs.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(_capi.JpegFrame)]
     L.gamut_hip_jpeg_read_header.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(_capi.JpegFrame)]
+    L.gamut_hip_jpeg_scan_layout.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(_capi.JpegFrame), C.c_void_p, C.c_void_p]
     L.gamut_hip_jpeg_frame_free.argtypes = [C.POINTER(_capi.JpegFrame)]
     L.gamut_hip_png_is16.argtypes = [C.c_void_p, C.c_size_t]
     L.gamut_hip_qoi_read_header.argtypes = [C.c_void_p, C.c_int, C.POINTER(_capi.QoiDesc)]
@@ -57,6 +58,7 @@ def main():
         ok += rc == 0; bad += rc != 0
         L.gamut_hip_jpeg_frame_free(C.byref(fr))
         L.gamut_hip_jpeg_read_header(buf, n, C.byref(fr))
+        L.gamut_hip_jpeg_scan_layout(buf, n, C.byref(fr), C.byref(C.c_int32()), C.byref(C.c_uint64()))
         L.gamut_hip_png_is16(buf, n)
         x, y, c = C.c_int(), C.c_int(), C.c_int(); f = C.c_float()
         L.gamut_hip_stbi_load_from_memory(buf, n, C.byref(x), C.byref(y), C.byref(c), 0, C.byref(f), C.byref(f), C.byref(f))

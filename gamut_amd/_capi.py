@@ -24,6 +24,11 @@ class JpegDesc(C.Structure):
                 ("width", C.c_int32), ("height", C.c_int32), ("scan_type", C.c_int32), ("out_comps", C.c_int32)]
 
 
+class PngInfo(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("channels_in_file", C.c_int32), ("channels", C.c_int32), ("bits", C.c_int32),
+                ("pixels_per_meter_x", C.c_float), ("pixels_per_meter_y", C.c_float), ("pixel_aspect_ratio", C.c_float)]
+
+
 class QoiDesc(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("channels", C.c_uint8), ("colorspace", C.c_uint8)]
 
@@ -66,6 +71,8 @@ SIGNATURES = {
     "gamut_hip_jpeg_reconstruct_device": (_i, [C.POINTER(JpegDesc), _i, _vp]),
     "gamut_hip_jpeg_reconstruct_batch_device": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i, _i, _i, _i, _i, _vp]),
     "gamut_hip_jpeg_decode_coeffs": (_i, [_vp, _sz, C.POINTER(JpegFrame)]),
+    "gamut_hip_png_read_header": (_i, [_vp, _sz, C.POINTER(PngInfo)]),
+    "gamut_hip_png_decode_batch_device": (_i, [C.POINTER(_vp), C.POINTER(_sz), _i, _i, _i, C.POINTER(_i64), _vp, C.POINTER(PngInfo), C.POINTER(_i), _i, _vp]),
     "gamut_hip_qoi_decode": (_vp, [_vp, _i, C.POINTER(QoiDesc), _i]),
     "gamut_hip_qoi_read_header": (_i, [_vp, _i, C.POINTER(QoiDesc)]),
     "gamut_hip_qoi_decode_batch_device": (_i, [C.POINTER(_vp), C.POINTER(_i), _i, _i, C.POINTER(_i64), _vp, C.POINTER(QoiDesc), C.POINTER(_i), _vp]),

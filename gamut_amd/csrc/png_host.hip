@@ -8,7 +8,10 @@
 // the GPU: de-filter / expand (png.hip), Adam7 scatter, tRNS, palette, channel and depth
 // conversion, in the order of finalize_decode (:1821-1857) and stbi__do_png (:2025-2055).
 #include "common.hpp"
+#include <atomic>
 #include <chrono>
+#include <thread>
+#include <vector>
 #include <zlib.h>
 
 namespace gamut {
@@ -128,25 +131,35 @@ int parse(const uint8_t* data, size_t len, PngHeader& h, bool header_only)
     }
 }
 
-// Per-thread page-locked staging for the inflated stream: zlib writes straight into it and the upload is a plain DMA
-// (an upload from freshly written pageable memory was seen to take 12-22 ms for 4 MB on some boxes, 0.2 ms on others).
-struct Pinned {
-    uint8_t* p = nullptr; size_t cap = 0;      // intentionally not freed at thread exit (the HIP runtime may already be gone)
+// Where zlib writes the inflated stream.  Page-locked (the per-thread staging of the single-image calls: the upload is
+// then a plain DMA -- an upload from freshly written pageable memory was seen to take 12-22 ms for 4 MB on some boxes,
+// 0.2 ms on others; intentionally not freed at thread exit, the HIP runtime may already be gone) or plain malloc memory
+// (the short-lived worker threads of the batch call).
+struct HostBuf {
+    uint8_t* p = nullptr; size_t cap = 0; bool pinned = false;
     bool reserve(size_t n, size_t keep)
     {
         if (n <= cap) return true;
-        void* np = nullptr;
         const size_t ncap = n + n / 8 + 4096;
-        if (hipHostMalloc(&np, ncap, hipHostMallocDefault) != hipSuccess) return false;
-        if (keep) memcpy(np, p, keep);
-        if (p) (void)hipHostFree(p);
-        p = (uint8_t*)np; cap = ncap;
+        if (pinned) {
+            void* np = nullptr;
+            if (hipHostMalloc(&np, ncap, hipHostMallocDefault) != hipSuccess) return false;
+            if (keep) memcpy(np, p, keep);
+            if (p) (void)hipHostFree(p);
+            p = (uint8_t*)np;
+        } else {
+            uint8_t* np = (uint8_t*)realloc(p, ncap);
+            if (!np) return false;
+            p = np;
+        }
+        cap = ncap;
         return true;
     }
+    void release() { if (p) { if (pinned) (void)hipHostFree(p); else free(p); } p = nullptr; cap = 0; }
 };
 
 // stbi_zlib_decode_malloc_guesssize_headerflag (stbdec.d:1267-1321); the result lives in `out` (not to be freed)
-uint8_t* inflate_idat(const uint8_t* buf, uint32_t len, size_t guess, uint32_t* outlen, bool parse_header, Pinned& out)
+uint8_t* inflate_idat(const uint8_t* buf, uint32_t len, size_t guess, uint32_t* outlen, bool parse_header, HostBuf& out)
 {
     if (parse_header) {
         if (len < 2 || ((buf[0] * 256 + buf[1]) % 31) != 0 || (buf[1] & 32) || (buf[0] & 15) != 8) { set_error(GAMUT_HIP_ERR_DECODE, "png: bad zlib header"); return nullptr; }
@@ -180,34 +193,31 @@ struct Dev {
     void swap(Dev& o) { void* t = p; p = o.p; o.p = t; }
 };
 
-// whole stbi__do_png on the GPU after the host inflate.  Returns malloc'd host pixels (8 or 16 bit as decoded).
-uint8_t* png_load(const uint8_t* data, size_t len, int* px, int* py, int* pn, int req_comp, int* bits_out,
-                  float* ppmX, float* ppmY, float* aspect)
+// parse + inflate of one file (host only)
+struct PngJob { PngHeader h; HostBuf raw; uint32_t raw_len = 0; int rc = GAMUT_HIP_OK; char msg[160] = { 0 }; };
+
+int png_prepare(const uint8_t* data, size_t len, PngJob& j)
 {
-    if (req_comp < 0 || req_comp > 4) { set_error(GAMUT_HIP_ERR_INVALID_ARG, "png: bad req_comp"); return nullptr; }
-    PngHeader h;
-    if (parse(data, len, h, false)) return nullptr;
-    if (ppmX) *ppmX = h.ppmX;
-    if (ppmY) *ppmY = h.ppmY;
-    if (aspect) *aspect = h.aspect;
-    if (!h.idata) { set_error(GAMUT_HIP_ERR_DECODE, "png: no IDAT"); return nullptr; }
-    const uint32_t bpl = (h.x * (uint32_t)h.depth + 7) / 8;
-    uint32_t raw_len = 0;
+    if (parse(data, len, j.h, false)) return j.rc = GAMUT_HIP_ERR_DECODE;
+    if (!j.h.idata) return j.rc = set_error(GAMUT_HIP_ERR_DECODE, "png: no IDAT");
+    const uint32_t bpl = (j.h.x * (uint32_t)j.h.depth + 7) / 8;
+    if (!inflate_idat(j.h.idata, j.h.ioff, (size_t)bpl * j.h.y * j.h.img_n + j.h.y, &j.raw_len, !j.h.is_iphone, j.raw)) return j.rc = GAMUT_HIP_ERR_DECODE;
+    return j.rc = GAMUT_HIP_OK;
+}
+
+// The whole of stbi__do_png after the inflate, on the GPU: de-filter (+ Adam7), tRNS, palette, channel-count conversion
+// (stbdec.d:1646-1679, 1821-1855, 2038-2045), then the 16 <-> 8 step of stbi__load_and_postprocess_* (:669-707) when
+// want_bits (8 / 16; 0 = as decoded) asks for it.  The result is left at d_dst (device) or returned as malloc'd host memory.
+uint8_t* png_run(const PngHeader& h, const uint8_t* raw, uint32_t raw_len, int req_comp, int want_bits, uint8_t* d_dst,
+                 int* px, int* py, int* pn, int* bits_out, hipStream_t st)
+{
     const bool trace = getenv("GAMUT_HIP_TRACE") != nullptr;               // stage timings on stderr
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    const auto t0 = now();
-    int dev_count = 0;                                                       // before any work: no GPU, no result
-    if (hipGetDeviceCount(&dev_count) != hipSuccess || dev_count <= 0) { set_error(GAMUT_HIP_ERR_NO_DEVICE, "no HIP device available (libgamut_hip has no CPU fallback)"); return nullptr; }
-    static thread_local Pinned staging;
-    uint8_t* raw = inflate_idat(h.idata, h.ioff, (size_t)bpl * h.y * h.img_n + h.y, &raw_len, !h.is_iphone, staging);
-    if (!raw) return nullptr;
-
     int img_n = h.img_n, out_n;
     if ((req_comp == img_n + 1 && req_comp != 3 && !h.pal_img_n) || h.has_trans) out_n = img_n + 1; else out_n = img_n;   // :1821-1824
-    const int bytes = h.depth == 16 ? 2 : 1;
+    int bytes = h.depth == 16 ? 2 : 1;
     const int64_t npx = (int64_t)h.x * h.y;
-    hipStream_t st = thread_stream();
 
     const auto t1 = now();
     Dev draw, dimg, dstatus;
@@ -233,6 +243,7 @@ uint8_t* png_load(const uint8_t* data, size_t len, int* px, int* py, int* pn, in
             if (png_adam7_scatter_launch((const uint8_t*)dpass.p, (uint8_t*)dimg.p, x, y, h.x, out_n * bytes, p, st)) return nullptr;
             rp += img_len; left -= img_len;
         }
+        if (hipStreamSynchronize(st) != hipSuccess) { set_error(GAMUT_HIP_ERR_HIP, "png: sync failed"); return nullptr; }   // dpass lifetime
     }
     if (h.has_trans && png_transparency_launch(dimg.p, npx, out_n, h.depth == 16, h.tc, st)) return nullptr;      // :1829-1841
     if (h.pal_img_n) {                                                      // :1843-1851
@@ -253,38 +264,56 @@ uint8_t* png_load(const uint8_t* data, size_t len, int* px, int* py, int* pn, in
         dimg.swap(dconv);
         out_n = req_comp;
     }
+    int bits = h.depth <= 8 ? 8 : 16;
+    if (want_bits && want_bits != bits) {                                   // stbi__convert_16_to_8 / _8_to_16 :635-666
+        Dev ddepth;
+        const int64_t samples = npx * out_n;
+        if (!ddepth.alloc((size_t)samples * (want_bits / 8) + 16)) return nullptr;
+        if (png_depth_convert_launch(dimg.p, ddepth.p, samples, want_bits == 16, st)) return nullptr;
+        if (hipStreamSynchronize(st) != hipSuccess) { set_error(GAMUT_HIP_ERR_HIP, "png: sync failed"); return nullptr; }
+        dimg.swap(ddepth);
+        bits = want_bits; bytes = want_bits / 8;
+    }
     if (trace) (void)hipStreamSynchronize(st);
     const auto t4 = now();
     const size_t out_bytes = (size_t)npx * out_n * bytes;
-    uint8_t* result = (uint8_t*)malloc(out_bytes ? out_bytes : 1);
+    uint8_t* result = d_dst ? d_dst : (uint8_t*)malloc(out_bytes ? out_bytes : 1);
     uint32_t status = 0;
     if (!result) { set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png: out of memory"); return nullptr; }
-    if (hipMemcpyAsync(result, dimg.p, out_bytes, hipMemcpyDeviceToHost, st) != hipSuccess ||
+    if (hipMemcpyAsync(result, dimg.p, out_bytes, d_dst ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipMemcpyAsync(&status, dstatus.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
-        free(result); set_error(GAMUT_HIP_ERR_HIP, "png: download failed: %s", hipGetErrorString(hipGetLastError())); return nullptr;
+        if (!d_dst) free(result);
+        set_error(GAMUT_HIP_ERR_HIP, "png: download failed: %s", hipGetErrorString(hipGetLastError())); return nullptr;
     }
-    if (trace) fprintf(stderr, "[gamut_hip] png_load %ux%u: inflate %.2f ms, hipMalloc %.2f, upload %.2f, kernels %.2f, download %.2f\n",
-                       h.x, h.y, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, now()));
-    if (status) { free(result); set_error(GAMUT_HIP_ERR_DECODE, "png: invalid filter"); return nullptr; }
+    if (trace) fprintf(stderr, "[gamut_hip] png %ux%u: hipMalloc %.2f ms, upload %.2f, kernels %.2f, %s %.2f\n",
+                       h.x, h.y, ms(t1, t2), ms(t2, t3), ms(t3, t4), d_dst ? "device copy" : "download", ms(t4, now()));
+    if (status) { if (!d_dst) free(result); set_error(GAMUT_HIP_ERR_DECODE, "png: invalid filter"); return nullptr; }
     *px = (int)h.x; *py = (int)h.y; if (pn) *pn = img_n;
-    *bits_out = h.depth <= 8 ? 8 : 16;
+    *bits_out = bits;
     return result;
 }
 
-// 16 <-> 8 of stbi__load_and_postprocess_* (stbdec.d:669-707) on the GPU
-uint8_t* depth_convert_host(uint8_t* src, size_t count, bool to16)
+// stbi_load_from_memory / stbi_load_16_from_memory on one file: malloc'd host pixels of want_bits bits per sample
+uint8_t* png_load(const uint8_t* data, size_t len, int* px, int* py, int* pn, int req_comp, int want_bits,
+                  float* ppmX, float* ppmY, float* aspect)
 {
-    Dev a, b;
-    hipStream_t st = thread_stream();
-    const size_t sb = count * (to16 ? 1 : 2), db = count * (to16 ? 2 : 1);
-    uint8_t* out = (uint8_t*)malloc(db ? db : 1);
-    bool ok = out && a.alloc(sb) && b.alloc(db) &&
-              hipMemcpyAsync(a.p, src, sb, hipMemcpyHostToDevice, st) == hipSuccess &&
-              png_depth_convert_launch(a.p, b.p, (int64_t)count, to16, st) == GAMUT_HIP_OK &&
-              hipMemcpyAsync(out, b.p, db, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
-    free(src);
-    if (!ok) { free(out); if (!last_error_buf()[0]) set_error(GAMUT_HIP_ERR_HIP, "png: depth conversion failed"); return nullptr; }
-    return out;
+    if (req_comp < 0 || req_comp > 4) { set_error(GAMUT_HIP_ERR_INVALID_ARG, "png: bad req_comp"); return nullptr; }
+    int dev_count = 0;                                                       // before any work: no GPU, no result
+    PngHeader probe;
+    if (parse(data, len, probe, true)) return nullptr;                       // a bad signature is reported as such with or without a GPU
+    if (hipGetDeviceCount(&dev_count) != hipSuccess || dev_count <= 0) { set_error(GAMUT_HIP_ERR_NO_DEVICE, "no HIP device available (libgamut_hip has no CPU fallback)"); return nullptr; }
+    static thread_local HostBuf staging{ nullptr, 0, true };
+    PngJob j; j.raw = staging;                                               // borrow the per-thread pinned buffer
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = png_prepare(data, len, j);
+    staging = j.raw; j.raw = HostBuf{};                                      // hand it back (it may have grown)
+    if (rc != GAMUT_HIP_OK) return nullptr;
+    if (getenv("GAMUT_HIP_TRACE")) fprintf(stderr, "[gamut_hip] png parse + inflate %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    if (ppmX) *ppmX = j.h.ppmX;
+    if (ppmY) *ppmY = j.h.ppmY;
+    if (aspect) *aspect = j.h.aspect;
+    int bits = 8;
+    return png_run(j.h, staging.p, j.raw_len, req_comp, want_bits, nullptr, px, py, pn, &bits, thread_stream());
 }
 
 } // namespace
@@ -320,13 +349,12 @@ uint8_t* gamut_hip_stbi_load_from_memory(const uint8_t* data, size_t len, int* x
                                          float* ppmX, float* ppmY, float* pixelRatio)
 {
     clear_error();
-    int bits = 8, n = 0, w = 0, h = 0;
-    uint8_t* r = png_load(data, len, &w, &h, &n, req_comp, &bits, ppmX, ppmY, pixelRatio);
+    int n = 0, w = 0, h = 0;
+    uint8_t* r = png_load(data, len, &w, &h, &n, req_comp, 8, ppmX, ppmY, pixelRatio);         // 16-bit files: stbi__convert_16_to_8
     if (!r) return nullptr;
     if (x) *x = w;
     if (y) *y = h;
     if (comp) *comp = n;
-    if (bits != 8) r = depth_convert_host(r, (size_t)w * h * (req_comp == 0 ? n : req_comp), false);      // stbi__convert_16_to_8
     return r;
 }
 
@@ -334,14 +362,82 @@ uint16_t* gamut_hip_stbi_load_16_from_memory(const uint8_t* data, size_t len, in
                                              float* ppmX, float* ppmY, float* pixelRatio)
 {
     clear_error();
-    int bits = 8, n = 0, w = 0, h = 0;
-    uint8_t* r = png_load(data, len, &w, &h, &n, req_comp, &bits, ppmX, ppmY, pixelRatio);
+    int n = 0, w = 0, h = 0;
+    uint8_t* r = png_load(data, len, &w, &h, &n, req_comp, 16, ppmX, ppmY, pixelRatio);        // 8-bit files: stbi__convert_8_to_16
     if (!r) return nullptr;
     if (x) *x = w;
     if (y) *y = h;
     if (comp) *comp = n;
-    if (bits != 16) r = depth_convert_host(r, (size_t)w * h * (req_comp == 0 ? n : req_comp), true);       // stbi__convert_8_to_16
-    return reinterpret_cast<uint16_t*>(r);
+    return (uint16_t*)r;
+}
+
+// Batch: parse + inflate on host threads, one file each; the GPU stages per file on `stream`, results left in HBM.
+int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* len, int count, int req_comp, int bits,
+                                      const int64_t* out_offset, uint8_t* out, gamut_hip_png_info* info, int* status_host,
+                                      int threads, void* stream)
+{
+    clear_error();
+    if (count < 0 || (count > 0 && (!data || !len || !out_offset || !out || !info)) || req_comp < 0 || req_comp > 4 || (bits != 0 && bits != 8 && bits != 16))
+        return set_error(GAMUT_HIP_ERR_INVALID_ARG, "png_decode_batch_device: bad arguments");
+    if (count == 0) return GAMUT_HIP_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return set_error(GAMUT_HIP_ERR_NO_DEVICE, "no HIP device available (libgamut_hip has no CPU fallback)");
+    try {
+        if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+        threads = threads < 1 ? 1 : threads > count ? count : threads;
+        std::vector<PngJob> jobs((size_t)count);
+        std::atomic<int> next{ 0 };
+        auto work = [&]() {
+            for (int i; (i = next.fetch_add(1, std::memory_order_relaxed)) < count; ) {
+                PngJob& j = jobs[(size_t)i];
+                if (png_prepare(data[i], len[i], j) != GAMUT_HIP_OK) snprintf(j.msg, sizeof(j.msg), "image %d: %s", i, last_error_buf());
+            }
+        };
+        std::vector<std::thread> pool;
+        try { for (int t = 1; t < threads; ++t) pool.emplace_back(work); } catch (...) {}
+        work();
+        for (std::thread& th : pool) th.join();
+
+        int first = GAMUT_HIP_OK; char first_msg[200] = { 0 };
+        hipStream_t st = pick_stream(stream);
+        for (int i = 0; i < count; ++i) {
+            PngJob& j = jobs[(size_t)i];
+            memset(&info[i], 0, sizeof(info[i]));
+            int rc = j.rc;
+            if (rc == GAMUT_HIP_OK) {
+                int w = 0, h = 0, n = 0, b = 8;
+                if (png_run(j.h, j.raw.p, j.raw_len, req_comp, bits, out + out_offset[i], &w, &h, &n, &b, st)) {
+                    info[i].width = (uint32_t)w; info[i].height = (uint32_t)h; info[i].channels_in_file = n;
+                    info[i].channels = req_comp ? req_comp : n; info[i].bits = b;
+                    info[i].pixels_per_meter_x = j.h.ppmX; info[i].pixels_per_meter_y = j.h.ppmY; info[i].pixel_aspect_ratio = j.h.aspect;
+                } else {
+                    rc = GAMUT_HIP_ERR_DECODE;
+                    snprintf(j.msg, sizeof(j.msg), "image %d: %s", i, last_error_buf());
+                }
+            }
+            j.raw.release();
+            if (status_host) status_host[i] = rc;
+            if (rc != GAMUT_HIP_OK && first == GAMUT_HIP_OK) { first = rc; snprintf(first_msg, sizeof(first_msg), "%s", j.msg); }
+        }
+        if (first != GAMUT_HIP_OK) return set_error(first, "%s", first_msg);
+        return GAMUT_HIP_OK;
+    } catch (...) {
+        return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png_decode_batch_device: out of host memory");
+    }
+}
+
+int gamut_hip_png_read_header(const uint8_t* data, size_t len, gamut_hip_png_info* info)
+{
+    clear_error();
+    if (!info) return set_error(GAMUT_HIP_ERR_INVALID_ARG, "png_read_header: null info");
+    memset(info, 0, sizeof(*info));
+    PngHeader h;
+    if (int rc = parse(data, len, h, true)) return rc;
+    info->width = h.x; info->height = h.y; info->bits = h.depth == 16 ? 16 : 8;
+    info->channels_in_file = info->channels = h.color == 3 ? 3 : h.img_n;          // palette images expand to RGB (RGBA with tRNS: known after the chunk walk)
+    info->pixels_per_meter_x = info->pixels_per_meter_y = info->pixel_aspect_ratio = -1;
+    return GAMUT_HIP_OK;
 }
 
 int gamut_hip_png_is16(const uint8_t* data, size_t len)

@@ -215,6 +215,24 @@ uint16_t* gamut_hip_stbi_load_16_from_memory(const uint8_t* data, size_t len, in
 /* stbi__png_is16 (stbdec.d:2091-2109) */
 int gamut_hip_png_is16(const uint8_t* data, size_t len);
 
+/* ---- PNG files in batches ----------------------------------------------------------------------------------- */
+typedef struct gamut_hip_png_info {
+    uint32_t width, height;
+    int32_t  channels_in_file;      /* what stbi reports as *comp: 1..4 (palette images: 3 or 4) */
+    int32_t  channels;              /* of the decoded pixels: req_comp, or channels_in_file when req_comp == 0 */
+    int32_t  bits;                  /* of the decoded samples: 8 or 16 */
+    float    pixels_per_meter_x, pixels_per_meter_y, pixel_aspect_ratio;   /* pHYs, -1 when absent */
+} gamut_hip_png_info;
+/* IHDR only (host): width, height, bit depth class and the channel count implied by the colour type */
+int gamut_hip_png_read_header(const uint8_t* data, size_t len, gamut_hip_png_info* info);
+/* `count` PNG files in host memory -> pixels at out + out_offset[i] (device): chunk walk + inflate on up to `threads` host
+ * threads (<= 0: one per hardware thread; the inflate is what bounds a PNG pipeline), then the whole of stbi__do_png per
+ * file on the GPU.  req_comp as in stbi_load (0 = as in the file), bits = 8 / 16 as stbi_load / stbi_load_16 convert, 0 = as
+ * in the file.  info[i] / status_host[i] (may be NULL) per file; returns the status of the lowest-numbered failing file. */
+int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* len, int count, int req_comp, int bits,
+                                      const int64_t* out_offset, uint8_t* out, gamut_hip_png_info* info, int* status_host,
+                                      int threads, void* stream);
+
 /* ---- QOI (codecs/qoi.d) -- SURVEY.md 8f row N4 ---------------------------------------------------------------- */
 typedef struct gamut_hip_qoi_desc { uint32_t width, height; uint8_t channels, colorspace; } gamut_hip_qoi_desc;   /* qoi_desc, decode fields */
 /* drop-in for qoi_decode (qoi.d:448-550): channels = 0 (as in the file), 3 or 4; malloc'd width*height*channels bytes, or

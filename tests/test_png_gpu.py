@@ -202,3 +202,46 @@ def test_extreme_geometry(hip, img_n, out_n, x, y):
     exp = O.png_create_image_raw(raw, img_n, out_n, x, y, 8, color)
     got = gpu_defilter(hip, raw, x, y, img_n, out_n, 8, color)[0]
     assert np.array_equal(got, exp)
+
+
+def test_png_file_batch_feeder(hip):
+    """gamut_hip_png_decode_batch_device: mixed files (sizes, colour types, depths, Adam7, palette + tRNS, a broken one) on a
+    host thread pool + GPU == stbi_load / stbi_load_16 of the oracle, pixels left in HBM"""
+    rng = np.random.default_rng(21)
+    files = [open(os.path.join(HERE, "golden", "ref_images", n), "rb").read() for n in ("issue65.png", "vst3-compatible.png", "issue76.png")]
+    w, h = 37, 23
+    files += [gen.write_png(rng.integers(0, 256, (h, w * 3)), w, h, 2, 8),
+              gen.write_png(rng.integers(0, 65536, (h, w * 4)), w, h, 6, 16),
+              b"\x89PNG\r\n\x1a\n" + bytes(40),
+              gen.write_png(rng.integers(0, 16, (h, w)), w, h, 3, 4, palette=rng.integers(0, 256, (16, 3)), trns=[0, 128, 255]),
+              gen.write_png(rng.integers(0, 256, (h, w * 2)), w, h, 4, 8, interlace=1)]
+    n = len(files)
+    bufs = [np.frombuffer(f, np.uint8) for f in files]
+    ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs]); lens = (C.c_size_t * n)(*[b.size for b in bufs])
+    for req, bits in ((4, 8), (0, 8), (3, 16), (0, 0)):
+        exp = []
+        for f in files:
+            try:
+                to16 = bits == 16 or (bits == 0 and O.png_parse(f)["depth"] == 16)
+                arr, comp = O.stbi_load(f, req, to16)
+                exp.append(np.ascontiguousarray(arr).view(np.uint8).reshape(-1))
+            except Exception:
+                exp.append(None)
+        sizes = [e.size if e is not None else 0 for e in exp]
+        offs = (np.concatenate([[0], np.cumsum(sizes)[:-1]]) + 0).astype(np.int64)
+        dout = up(hip, np.full(int(sum(sizes)) + 64, 0xA5, np.uint8))
+        info = (_capi.PngInfo * n)(); st = (C.c_int * n)()
+        rc = hip.gamut_hip_png_decode_batch_device(ptrs, lens, n, req, bits, offs.ctypes.data_as(C.POINTER(C.c_int64)), dout, info, st, 3, None)
+        host = down(hip, dout, int(sum(sizes)) + 64)
+        hip.gamut_hip_device_free(dout)
+        assert rc == _capi.ERR_DECODE and st[5] == _capi.ERR_DECODE and b"image 5" in hip.gamut_hip_last_error()
+        for i, e in enumerate(exp):
+            if e is None:
+                assert i == 5
+                continue
+            assert st[i] == 0, (i, req, bits)
+            assert np.array_equal(host[offs[i]:offs[i] + e.size], e), (i, req, bits)
+            assert info[i].bits * info[i].channels * info[i].width * info[i].height // 8 == e.size
+        assert (host[int(sum(sizes)):] == 0xA5).all()
+    hd = _capi.PngInfo()
+    assert hip.gamut_hip_png_read_header(ptrs[4], lens[4], C.byref(hd)) == 0 and (hd.width, hd.height, hd.bits, hd.channels) == (w, h, 16, 4)

@@ -324,3 +324,30 @@ def test_maximum_dimensions(hip, scan_type, w, h):
         assert np.array_equal(got, exp)
     L = hip
     assert L.gamut_hip_jpeg_reconstruct_batch_device(1, 0, None, 0, 1, 16385 * 4, 0, 16385, 8, 4, 4, 1, None) == _capi.ERR_INVALID_ARG
+
+
+def test_device_entropy_decode_many_distinct_tables(hip):
+    """more distinct Huffman / quant tables in one batch than a workgroup keeps in LDS (16): the tables are then read from
+    global memory; long (multi-lane) and short (one lane) segments both"""
+    import io
+    from PIL import Image
+    import gen
+    blobs = []
+    for k, q in enumerate((35, 50, 62, 71, 80, 88, 93, 97)):
+        big = Image.fromarray(gen.synth_rgb(640, 480, 30 + k)); small = Image.fromarray(gen.synth_rgb(48, 40, 60 + k))
+        for im in (big, small):
+            bio = io.BytesIO(); im.save(bio, "JPEG", quality=q, subsampling=(0, 1, 2)[k % 3], optimize=True); blobs.append(bio.getvalue())
+    rc, hst, st, res = _entropy_decode_device(hip, blobs)
+    assert rc == 0 and hst == [0] * len(blobs) and not st.any()
+    tables = set()
+    for data, (co, zz, info) in zip(blobs, res):
+        d = O.DecodedJpeg(data)
+        assert np.array_equal(co, d.coeffs) and np.array_equal(zz, d.max_zag)
+        i = 0
+        while True:                                        # count distinct DHT payloads to be sure the test does what it says
+            i = data.find(b"\xff\xc4", i)
+            if i < 0:
+                break
+            n = (data[i + 2] << 8) | data[i + 3]
+            tables.add(data[i + 4:i + 2 + n]); i += 2 + n
+    assert len(tables) > 16

@@ -245,3 +245,39 @@ def test_png_file_batch_feeder(hip):
         assert (host[int(sum(sizes)):] == 0xA5).all()
     hd = _capi.PngInfo()
     assert hip.gamut_hip_png_read_header(ptrs[4], lens[4], C.byref(hd)) == 0 and (hd.width, hd.height, hd.bits, hd.channels) == (w, h, 16, 4)
+
+
+def test_files_written_by_libpng(hip):
+    """real encoder output (Pillow / libpng: adaptive row filters, several zlib levels, palette, 1-bit, 16-bit grey) through
+    the drop-in loader == the oracle == the pixels Pillow started from"""
+    import io
+    from PIL import Image
+    rng = np.random.default_rng(31)
+    w, h = 157, 83
+    rgb = gen.synth_rgb(w, h, 91)
+    alpha = ((np.add.outer(np.arange(h), np.arange(w)) * 3) % 256).astype(np.uint8)
+    cases = [("RGB", rgb), ("RGBA", np.dstack([rgb, alpha])), ("L", rgb[:, :, 1]), ("LA", np.dstack([rgb[:, :, 1], alpha])),
+             ("I;16", (rgb[:, :, 0].astype(np.uint16) * 257 + rgb[:, :, 1]).astype(np.uint16)), ("1", (rgb[:, :, 2] > 128))]
+    for mode, arr in cases:
+        im = Image.fromarray(arr) if mode != "1" else Image.fromarray(arr).convert("1")
+        variants = [(im, dict(compress_level=1)), (im, dict(compress_level=9, optimize=True))]
+        if mode == "RGB":
+            variants.append((im.quantize(37), dict()))                   # palette image
+        for img, kw in variants:
+            bio = io.BytesIO(); img.save(bio, "PNG", **kw); data = bio.getvalue()
+            buf = np.frombuffer(data, np.uint8)
+            for req in (0, 4, 1):
+                for sixteen in (False, True):
+                    exp, comp = O.stbi_load(data, req, sixteen)
+                    x, y, c = C.c_int(), C.c_int(), C.c_int(); f = C.c_float()
+                    fn = hip.gamut_hip_stbi_load_16_from_memory if sixteen else hip.gamut_hip_stbi_load_from_memory
+                    fn.restype = C.c_void_p
+                    p = fn(buf.ctypes.data, buf.size, C.byref(x), C.byref(y), C.byref(c), req, C.byref(f), C.byref(f), C.byref(f))
+                    assert p, (mode, hip.gamut_hip_last_error())
+                    e8 = np.ascontiguousarray(exp).view(np.uint8).reshape(-1)
+                    got = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (e8.size,)).copy()
+                    O._libc.free(C.c_void_p(p))
+                    assert (x.value, y.value, c.value) == (w, h, comp) and np.array_equal(got, e8), (mode, req, sixteen)
+            if img.mode in ("RGB", "RGBA", "L", "LA"):                     # and the oracle agrees with the source pixels
+                src = np.asarray(img).reshape(h, w, -1)
+                assert np.array_equal(O.stbi_load(data, 0, False)[0].reshape(h, w, -1), src), mode

@@ -67,15 +67,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # GAMUT_BENCH_BACKEND=gloo: run the N > 1 code path on a box with fewer GPUs than ranks (ranks share devices); a test
+    # aid only -- the driver's multi-GPU runs use RCCL ("nccl") with one GPU per rank
+    backend = os.environ.get("GAMUT_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from gamut_amd import _capi, synth
     L = _capi.lib()
-    _capi.check(L.gamut_hip_init(local_rank))
+    _capi.check(L.gamut_hip_init(dev_index))
     stream = torch.cuda.current_stream().cuda_stream
 
     # ------------------------------------------------------------------ workload
@@ -240,7 +247,7 @@ def main():
 
     if world > 1:
         import torch.distributed as dist
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

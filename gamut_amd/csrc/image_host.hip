@@ -7,6 +7,7 @@
 //   allocatePixelStorage         internals/types.d:355-540      (border / trailing / multiplicity / alignment / v-flip / bonus bytes)
 //   layout constraint helpers    internals/types.d:166-289
 //   load flags                   internals/types.d:563-661, types.d:351-602
+// Optionally the storage is device memory (gamut_image_set_device_storage): decode and convertTo chains then never leave HBM.
 //   loadFromMemory               image.d:886-901, 1751-1772 ; loadJPEG plugins/jpeg.d:42-104 ; loadPNG plugins/png.d:44-163 ;
 //                                loadQOI plugins/qoi.d:47-141
 //   convertTo                    image.d:1180-1332 ; getAdHocLayoutConstraints :1809-1905
@@ -126,8 +127,9 @@ int applyLoadFlags(int type, int f)             // internals/types.d:627-661
 
 // ---- allocatePixelStorage (internals/types.d:355-540) ----
 struct Storage { uint8_t* data = nullptr; uint8_t* alloc = nullptr; int pitch = 0; int layerOffset = 0; };
+// device: the pixels live in HBM (hipMalloc) instead of host malloc memory -- same layout arithmetic on the device address
 bool allocatePixelStorage(uint8_t* existing, int type, int layers, int width, int height, int constraints, int bonusBytes,
-                          bool clearWithZeroes, Storage& out)
+                          bool clearWithZeroes, Storage& out, bool device = false)
 {
     if (!imageIsValidSize(layers, width, height)) return false;
     const int border = layoutBorderWidth(constraints), rowAlignment = layoutScanlineAlignment(constraints);
@@ -145,9 +147,18 @@ bool allocatePixelStorage(uint8_t* existing, int type, int layers, int width, in
     long long sizeNeeded = (long long)bytePitch * actualHeightInPixels + (rowAlignment - 1) + bonusBytes;
     if (sizeNeeded > MAX_BYTES) return false;
     const size_t allocationSize = (size_t)sizeNeeded;
-    uint8_t* allocation = (uint8_t*)realloc(existing, allocationSize);
-    if (allocationSize != 0 && !allocation) return false;
-    if (clearWithZeroes && allocationSize > 0) memset(allocation, 0, allocationSize);
+    uint8_t* allocation;
+    if (device) {
+        if (existing) (void)hipFree(existing);
+        void* p = nullptr;
+        if (hipMalloc(&p, allocationSize ? allocationSize : 1) != hipSuccess) return false;
+        allocation = (uint8_t*)p;
+        if (clearWithZeroes && allocationSize > 0 && hipMemset(allocation, 0, allocationSize) != hipSuccess) { (void)hipFree(allocation); return false; }
+    } else {
+        allocation = (uint8_t*)realloc(existing, allocationSize);
+        if (allocationSize != 0 && !allocation) return false;
+        if (clearWithZeroes && allocationSize > 0) memset(allocation, 0, allocationSize);
+    }
     const size_t offsetToFirst = (size_t)bonusBytes + (size_t)bytePitch * border + (size_t)pixelSize * border;
     uint8_t* pixels = (uint8_t*)nextMultipleOf((size_t)(allocation + offsetToFirst), (size_t)rowAlignment);
     uint8_t* first = pixels; int pitch = bytePitch;
@@ -160,7 +171,7 @@ bool allocatePixelStorage(uint8_t* existing, int type, int layers, int width, in
     if (layers == 0 || layers == 1) out.layerOffset = 0;
     else {
         const long long off = (long long)bytePitch * actualHeightOfOneLayer;
-        if (off > 2147483647LL) { free(allocation); return false; }
+        if (off > 2147483647LL) { if (device) (void)hipFree(allocation); else free(allocation); return false; }
         out.layerOffset = (int)off;
     }
     return true;
@@ -178,12 +189,17 @@ struct gamut_image {
     int       _pitch = 0, _layerOffset = 0;
     const char* _error = kStrImageNotInitialized;
     float     _pixelAspectRatio = -1, _resolutionY = -1;
+    // Not in the reference: where the pixel storage lives.  false = host malloc memory (the reference's model: every
+    // convertTo crosses PCIe twice); true = HBM (hipMalloc): loadFromMemory decodes straight into it and convertTo chains stay
+    // on the device; _data / scanptr() are then device addresses (gamut_image_copy_pixels_to_host reads them back).
+    bool      _device = false;
 
     void error(const char* msg) { _error = msg; _type = GAMUT_PIXEL_unknown; }           // image.d:1563-1570
     void clearError() { _error = nullptr; }
     bool isValid() const { return _error == nullptr; }
     bool hasData() const { return _data != nullptr; }
-    void cleanupBitmapIfOwned() { if (_allocArea) { free(_allocArea); _allocArea = nullptr; _data = nullptr; } }
+    void release(uint8_t* p) const { if (!p) return; if (_device) (void)hipFree(p); else free(p); }
+    void cleanupBitmapIfOwned() { if (_allocArea) { release(_allocArea); _allocArea = nullptr; _data = nullptr; } }
     void cleanupBitmapAndTypeIfAny() { cleanupBitmapIfOwned(); _data = nullptr; _type = GAMUT_PIXEL_unknown; _error = kStrImageHasNoType; }
 
     bool forgetPreviousUsage(int layers, int w, int h)                                     // image.d:1624-1645
@@ -199,7 +215,7 @@ struct gamut_image {
         if (!valid_type(type)) { error(kStrUnsupportedTypeConversion); return false; }
         if (!layoutConstraintsValid(constraints)) { error(kStrIllegalLayoutConstraints); return false; }
         Storage s;
-        if (!allocatePixelStorage(_allocArea, type, layers, w, h, constraints, 0, clear, s)) { _allocArea = nullptr; error(kStrOutOfMemory); return false; }
+        if (!allocatePixelStorage(_allocArea, type, layers, w, h, constraints, 0, clear, s, _device)) { _allocArea = nullptr; error(kStrOutOfMemory); return false; }
         _data = s.data; _allocArea = s.alloc; _type = type; _width = w; _height = h; _pitch = s.pitch;
         _layoutConstraints = (uint16_t)constraints; _layerCount = layers; _layerOffset = s.layerOffset;
         return true;
@@ -251,16 +267,22 @@ struct gamut_image {
         const int interType = gamut_hip_scanlines_inter_type(_type, targetType);
         const int bonusBytes = targetType != _type ? _width * kPixelSize[interType] : 0;      // the scratch row the reference reserves (:1238-1241)
         Storage s;
-        if (!allocatePixelStorage(nullptr, targetType, _layerCount, _width, _height, layoutConstraints, bonusBytes, false, s)) {
+        if (!allocatePixelStorage(nullptr, targetType, _layerCount, _width, _height, layoutConstraints, bonusBytes, false, s, _device)) {
             error(kStrOutOfMemory); return false;
         }
         bool ok = true;
-        const uint8_t* srcLayer = _data; uint8_t* dstLayer = s.data;
-        for (int layer = 0; layer < _layerCount && ok; ++layer) {                             // :1273-1311, one GPU pass per layer
-            ok = gamut_hip_scanlines_convert(_type, srcLayer, _pitch, targetType, dstLayer, s.pitch, _width, _height) == GAMUT_HIP_OK;
-            srcLayer += _layerOffset; dstLayer += s.layerOffset;
+        if (_device) {                                                                        // all layers in one launch, nothing leaves HBM
+            ok = gamut_hip_scanlines_convert_device(_type, _data, _pitch, _layerOffset, targetType, s.data, s.pitch, s.layerOffset,
+                                                    _width, _height, _layerCount, nullptr) == GAMUT_HIP_OK &&
+                 gamut_hip_stream_synchronize(nullptr) == GAMUT_HIP_OK;
+        } else {
+            const uint8_t* srcLayer = _data; uint8_t* dstLayer = s.data;
+            for (int layer = 0; layer < _layerCount && ok; ++layer) {                         // :1273-1311, one GPU pass per layer
+                ok = gamut_hip_scanlines_convert(_type, srcLayer, _pitch, targetType, dstLayer, s.pitch, _width, _height) == GAMUT_HIP_OK;
+                srcLayer += _layerOffset; dstLayer += s.layerOffset;
+            }
         }
-        if (!ok) { free(s.alloc); error(kStrUnsupportedTypeConversion); return false; }      // keeps the former pixels (:1313-1319)
+        if (!ok) { release(s.alloc); error(kStrUnsupportedTypeConversion); return false; }   // keeps the former pixels (:1313-1319)
         const int layers = _layerCount, w = _width, h = _height;
         cleanupBitmapIfOwned();
         _layoutConstraints = (uint16_t)layoutConstraints; _data = s.data; _allocArea = s.alloc; _type = targetType;
@@ -274,16 +296,54 @@ struct gamut_image {
         _pixelAspectRatio = aspect; _resolutionY = resY; _layoutConstraints = GAMUT_LAYOUT_DEFAULT; _layerCount = 1; _layerOffset = 0;
     }
 
+    static uint8_t* dmalloc(size_t n) { void* p = nullptr; return hipMalloc(&p, n ? n : 1) == hipSuccess ? (uint8_t*)p : nullptr; }
+
+    // decompress_jpeg_image_from_stream with the result left in HBM: entropy decode on the GPU for baseline files, host
+    // feeder + coefficient upload for progressive ones, then the reconstruction kernels
+    uint8_t* decodeJpegToDevice(const uint8_t* bytes, size_t len, int* w, int* h, int* actual, float* aspect, float* dpiY, int req)
+    {
+        if (req != -1 && req != 1 && req != 3 && req != 4) return nullptr;
+        gamut_hip_jpeg_frame f;
+        if (gamut_hip_jpeg_read_header(bytes, len, &f) != GAMUT_HIP_OK) return nullptr;
+        const size_t nblk = (size_t)f.mcus_per_row * f.mcus_per_col * f.blocks_per_mcu;
+        const int comps = req < 0 ? f.comps : req;
+        uint8_t* dco = dmalloc(nblk * 128), *dzz = dmalloc(nblk), *dout = dmalloc((size_t)f.width * f.height * comps);
+        bool ok = dco && dzz && dout;
+        if (ok) {
+            const int64_t zero = 0; int st = 0; gamut_hip_jpeg_frame info;
+            int rc = gamut_hip_jpeg_entropy_decode_device(&bytes, &len, 1, &zero, &zero, (int16_t*)dco, dzz, nullptr, &info, &st, nullptr);
+            if (rc == GAMUT_HIP_ERR_UNSUPPORTED) {                                          // progressive: host feeder
+                gamut_hip_jpeg_frame hf;
+                rc = gamut_hip_jpeg_decode_coeffs(bytes, len, &hf);
+                if (rc == GAMUT_HIP_OK) {
+                    rc = gamut_hip_memcpy_h2d(dco, hf.coeffs, nblk * 128, nullptr) | gamut_hip_memcpy_h2d(dzz, hf.max_zag, nblk, nullptr) |
+                         gamut_hip_stream_synchronize(nullptr);
+                    gamut_hip_jpeg_frame_free(&hf);
+                }
+            }
+            ok = rc == GAMUT_HIP_OK &&
+                 gamut_hip_jpeg_reconstruct_batch_device((const int16_t*)dco, 0, dzz, 0, dout, (int64_t)f.width * comps, 0, f.width, f.height,
+                                                         f.scan_type, comps, 1, nullptr) == GAMUT_HIP_OK &&
+                 gamut_hip_stream_synchronize(nullptr) == GAMUT_HIP_OK;
+        }
+        if (dco) (void)hipFree(dco);
+        if (dzz) (void)hipFree(dzz);
+        if (!ok) { if (dout) (void)hipFree(dout); return nullptr; }
+        *w = f.width; *h = f.height; *actual = f.comps; *aspect = f.pixel_aspect_ratio; *dpiY = f.dpi_y;
+        return dout;
+    }
+
     void loadJPEG(const uint8_t* bytes, size_t len, int flags)                              // plugins/jpeg.d:42-104
     {
         int requested = computeRequestedImageComponents(flags);
         if (requested == 0) { error(kStrInvalidFlags); return; }
         if (requested == 2) requested = -1;
         int w = 0, h = 0, actual = 0; float aspect = -1, dpiY = -1;
-        uint8_t* decoded = gamut_hip_decompress_jpeg_image_from_memory(bytes, len, &w, &h, &actual, &aspect, &dpiY, requested);
+        uint8_t* decoded = _device ? decodeJpegToDevice(bytes, len, &w, &h, &actual, &aspect, &dpiY, requested)
+                                   : gamut_hip_decompress_jpeg_image_from_memory(bytes, len, &w, &h, &actual, &aspect, &dpiY, requested);
         if (!decoded) { error(kStrImageDecodingFailed); return; }
-        if (actual != 1 && actual != 3 && actual != 4) { error(kStrImageWrongComponents); free(decoded); return; }
-        if (!imageIsValidSize(1, w, h)) { error(kStrImageTooLarge); free(decoded); return; }
+        if (actual != 1 && actual != 3 && actual != 4) { error(kStrImageWrongComponents); release(decoded); return; }
+        if (!imageIsValidSize(1, w, h)) { error(kStrImageTooLarge); release(decoded); return; }
         const int comps = requested == -1 ? actual : requested;
         adopt(decoded, w, h, comps == 1 ? GAMUT_PIXEL_l8 : comps == 3 ? GAMUT_PIXEL_rgb8 : GAMUT_PIXEL_rgba8, comps, aspect, dpiY);
         convertTo(applyLoadFlags(_type, flags), flags & 0xFFFF);
@@ -298,11 +358,24 @@ struct gamut_image {
         if (flags & GAMUT_LOAD_8BIT) to16 = false;
         if (flags & GAMUT_LOAD_16BIT) to16 = true;
         int w = 0, h = 0, comps = 0; float ppmX = -1, ppmY = -1, ratio = -1;
-        uint8_t* decoded = to16 ? (uint8_t*)gamut_hip_stbi_load_16_from_memory(bytes, len, &w, &h, &comps, requested, &ppmX, &ppmY, &ratio)
-                                : gamut_hip_stbi_load_from_memory(bytes, len, &w, &h, &comps, requested, &ppmX, &ppmY, &ratio);
+        uint8_t* decoded = nullptr;
+        if (_device) {                                                                      // stbi_load(_16) with the result left in HBM
+            gamut_hip_png_info hd, info;
+            if (gamut_hip_png_read_header(bytes, len, &hd) == GAMUT_HIP_OK) {
+                const int64_t zero = 0; int st = 0;
+                decoded = dmalloc((size_t)hd.width * hd.height * 4 * (to16 ? 2 : 1) + 64);          // room for any channel count
+                if (decoded && gamut_hip_png_decode_batch_device(&bytes, &len, 1, requested, to16 ? 16 : 8, &zero, decoded, &info, &st, 1, nullptr) == GAMUT_HIP_OK) {
+                    w = (int)info.width; h = (int)info.height; comps = info.channels_in_file;
+                    ppmX = info.pixels_per_meter_x; ppmY = info.pixels_per_meter_y; ratio = info.pixel_aspect_ratio;
+                } else { if (decoded) (void)hipFree(decoded); decoded = nullptr; }
+            }
+        } else {
+            decoded = to16 ? (uint8_t*)gamut_hip_stbi_load_16_from_memory(bytes, len, &w, &h, &comps, requested, &ppmX, &ppmY, &ratio)
+                           : gamut_hip_stbi_load_from_memory(bytes, len, &w, &h, &comps, requested, &ppmX, &ppmY, &ratio);
+        }
         if (requested != 0) comps = requested;
         if (!decoded) { error(kStrImageDecodingFailed); return; }
-        if (!imageIsValidSize(1, w, h)) { error(kStrImageTooLarge); free(decoded); return; }
+        if (!imageIsValidSize(1, w, h)) { error(kStrImageTooLarge); release(decoded); return; }
         static const int t8[5] = { -1, GAMUT_PIXEL_l8, GAMUT_PIXEL_la8, GAMUT_PIXEL_rgb8, GAMUT_PIXEL_rgba8 };
         static const int t16[5] = { -1, GAMUT_PIXEL_l16, GAMUT_PIXEL_la16, GAMUT_PIXEL_rgb16, GAMUT_PIXEL_rgba16 };
         adopt(decoded, w, h, (to16 ? t16 : t8)[comps], comps * (to16 ? 2 : 1), ratio == -1 ? -1.0f : ratio,
@@ -315,9 +388,19 @@ struct gamut_image {
         if (requested == 0) { error(kStrInvalidFlags); return; }
         if (requested == -1 || requested == 1 || requested == 2) requested = 0;             // the QOI decoder only makes RGB / RGBA (:81-83)
         gamut_hip_qoi_desc desc;
-        uint8_t* decoded = (uint8_t*)gamut_hip_qoi_decode(bytes, (int)len, &desc, requested);
+        uint8_t* decoded = nullptr;
+        if (_device) {
+            const int size = (int)len; const int64_t zero = 0; int st = 0;
+            if (gamut_hip_qoi_read_header(bytes, size, &desc) == GAMUT_HIP_OK) {
+                decoded = dmalloc((size_t)desc.width * desc.height * (requested ? requested : desc.channels));
+                if (!decoded || gamut_hip_qoi_decode_batch_device(&bytes, &size, 1, requested, &zero, decoded, &desc, &st, nullptr) != GAMUT_HIP_OK) {
+                    if (decoded) (void)hipFree(decoded);
+                    decoded = nullptr;
+                }
+            }
+        } else decoded = (uint8_t*)gamut_hip_qoi_decode(bytes, (int)len, &desc, requested);
         if (!decoded) { error(kStrImageDecodingFailed); return; }
-        if (!imageIsValidSize(1, (int)desc.width, (int)desc.height)) { error(kStrImageTooLarge); free(decoded); return; }
+        if (!imageIsValidSize(1, (int)desc.width, (int)desc.height)) { error(kStrImageTooLarge); release(decoded); return; }
         const int comps = requested == 0 ? desc.channels : requested;
         // DEVIATION: the reference sets _pitch = desc.channels * desc.width (:133), the FILE's channel count, even when the
         // decoder was asked for another one; rows are then read at the wrong pitch (and past the buffer for RGBA files
@@ -403,6 +486,37 @@ int gamut_image_flip_vertical(gamut_image* img)                                 
     }
     if (img->_height >= 2) img->_data += (ptrdiff_t)img->_pitch * (img->_height - 1);
     img->_pitch = -img->_pitch;
+    return 1;
+}
+
+// ---- device-resident storage (not in the reference) ----
+int gamut_image_set_device_storage(gamut_image* img, int on)        // only while the image owns no pixels
+{
+    if (img->_data) return 0;
+    if (on && gamut_hip_device_count() < 1) return 0;
+    img->_device = on != 0;
+    return 1;
+}
+int gamut_image_is_device(const gamut_image* img) { return img->_device; }
+// one layer into tightly packed host rows (dst_pitch >= scanline bytes), top-down in logical order, wherever the pixels live
+int gamut_image_copy_pixels_to_host(gamut_image* img, int layer, void* dst, int64_t dst_pitch)
+{
+    if (!img->isValid() || !img->_data || !dst || layer < 0 || layer >= (img->_layerCount ? img->_layerCount : 1)) return 0;
+    const int row = img->_width * kPixelSize[img->_type];
+    if (dst_pitch < row) return 0;
+    const uint8_t* src = img->_data + (ptrdiff_t)layer * img->_layerOffset;
+    if (img->_height == 0 || row == 0) return 1;
+    if (!img->_device) {
+        for (int y = 0; y < img->_height; ++y) memcpy((uint8_t*)dst + (size_t)y * dst_pitch, src + (ptrdiff_t)img->_pitch * y, (size_t)row);
+        return 1;
+    }
+    if (img->_pitch >= 0)
+        return hipMemcpy2D(dst, (size_t)dst_pitch, src, (size_t)(img->_pitch ? img->_pitch : row), (size_t)row, (size_t)img->_height, hipMemcpyDeviceToHost) == hipSuccess;
+    // stored upside down: the lowest address is the last logical row; copy, then the rows land reversed
+    const uint8_t* low = src + (ptrdiff_t)img->_pitch * (img->_height - 1);
+    uint8_t* last = (uint8_t*)dst + (size_t)(img->_height - 1) * dst_pitch;
+    for (int y = 0; y < img->_height; ++y)
+        if (hipMemcpy(last - (size_t)y * dst_pitch, low + (size_t)(-img->_pitch) * y, (size_t)row, hipMemcpyDeviceToHost) != hipSuccess) return 0;
     return 1;
 }
 

@@ -26,6 +26,8 @@ IMAGE_SIGNATURES = {
     "gamut_image_error_message": (C.c_char_p, [_vp]), "gamut_image_has_data": (_i, [_vp]), "gamut_image_is_owned": (_i, [_vp]),
     "gamut_image_is_stored_upside_down": (_i, [_vp]), "gamut_image_pixel_aspect_ratio": (_f, [_vp]), "gamut_image_dots_per_inch_y": (_f, [_vp]),
     "gamut_image_scanptr": (_vp, [_vp, _i]), "gamut_image_layerptr": (_vp, [_vp, _i, _i]), "gamut_image_disown_data": (_vp, [_vp]),
+    "gamut_image_set_device_storage": (_i, [_vp, _i]), "gamut_image_is_device": (_i, [_vp]),
+    "gamut_image_copy_pixels_to_host": (_i, [_vp, _i, _vp, C.c_int64]),
 }
 _bound = False
 
@@ -54,9 +56,12 @@ LAYOUT_BORDER = {0: 0, 1: 128, 2: 256, 3: 384}
 class Image:
     """struct Image (image.d:85).  A fresh Image is in the error state ("Uninitialized image")."""
 
-    def __init__(self):
+    def __init__(self, device=False):
+        """device=True: pixel storage in HBM (an extension, see include/gamut_image.h): loads and convertTo chains stay on the GPU"""
         self.L = lib()
         self.h = self.L.gamut_image_new()
+        if device and not self.L.gamut_image_set_device_storage(self.h, 1):
+            raise RuntimeError("device storage needs a GPU")
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -133,10 +138,20 @@ class Image:
     def scanptr(self, y): return self.L.gamut_image_scanptr(self.h, y)
     def layerptr(self, layer, y): return self.L.gamut_image_layerptr(self.h, layer, y)
 
+    @property
+    def isDevice(self): return bool(self.L.gamut_image_is_device(self.h))
+
     def scanline(self, y, layer=0):
         n = self.scanlineInBytes
+        if self.isDevice:
+            return self.pixels(layer)[y].copy()
         return np.ctypeslib.as_array(C.cast(self.layerptr(layer, y), C.POINTER(C.c_uint8)), (n,)).copy() if n else np.zeros(0, np.uint8)
 
     def pixels(self, layer=0):
         """(height, scanlineInBytes) uint8 copy of one layer in logical (top-down) order"""
+        if self.isDevice:
+            out = np.zeros((self.height, self.scanlineInBytes), np.uint8)
+            if out.size and not self.L.gamut_image_copy_pixels_to_host(self.h, layer, out.ctypes.data, out.shape[1]):
+                raise RuntimeError("copy_pixels_to_host failed")
+            return out
         return np.stack([self.scanline(y, layer) for y in range(self.height)]) if self.height else np.zeros((0, self.scanlineInBytes), np.uint8)

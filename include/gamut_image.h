@@ -101,6 +101,15 @@ uint8_t* gamut_image_scanptr(gamut_image* img, int y);                 /* layer 
 uint8_t* gamut_image_layerptr(gamut_image* img, int layer, int y);
 uint8_t* gamut_image_disown_data(gamut_image* img);                    /* image.d:483-490 */
 
+/* ---- device-resident pixel storage (an extension: the reference keeps pixels in host memory) --------------------
+ * With it on, create*() allocates in HBM, loadFromMemory decodes straight into HBM (JPEG entropy decode included for
+ * baseline files) and convertTo / setLayout chains run device to device; scanptr() / layerptr() return DEVICE addresses.
+ * Can only be switched while the image owns no pixels; returns 0 otherwise or when there is no GPU. */
+int gamut_image_set_device_storage(gamut_image* img, int on);
+int gamut_image_is_device(const gamut_image* img);
+/* one layer, logical top-down order, into host rows of dst_pitch bytes -- for host and device images alike */
+int gamut_image_copy_pixels_to_host(gamut_image* img, int layer, void* dst, int64_t dst_pitch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -182,3 +182,34 @@ def test_load_qoi_with_flags_and_mixed_batch(hip):
                 assert PIXEL_TYPES[im.type] == "rgba8" and np.array_equal(im.pixels(), exp), (kind, i)
                 seen.append(i)
         assert sorted(seen) == list(range(len(batch)))
+
+
+def test_device_resident_images(hip):
+    """the storage extension (gamut_image_set_device_storage): the same loads, flags, layouts and convertTo chains with the
+    pixels in HBM give the same bytes as the host-storage mirror and the oracle"""
+    from test_oracle_pinning import _qoi_test_images
+    rng = np.random.default_rng(17)
+    files = [("jpeg", open(p, "rb").read()) for p in JPEGS[:3]]
+    files.append(("jpeg", open(os.path.join(G, "jpeg", "p_131x97_420.jpg"), "rb").read()))                     # progressive: host feeder + upload
+    files.append(("png", open(os.path.join(G, "ref_images", "issue76.png"), "rb").read()))
+    files.append(("png", gen.write_png(rng.integers(0, 16, (13, 21)), 21, 13, 3, 4, palette=rng.integers(0, 256, (16, 3)), trns=[0, 128, 255])))
+    files.append(("png", gen.write_png(rng.integers(0, 65536, (13, 21 * 4)), 21, 13, 6, 16)))
+    files.append(("qoi", gen.qoi_encode(_qoi_test_images()[3])))
+    for kind, data in files:
+        for flags in FLAGSETS[:5]:
+            for layout in (0, gi.LAYOUT_VERT_FLIPPED | gi.LAYOUT_ALIGNED[64], gi.LAYOUT_TRAILING[3] | gi.LAYOUT_BORDER[1]):
+                w, h, t1, exp = expected_load(data, flags, kind)
+                im = Image(device=True)
+                assert im.loadFromMemory(data, flags | layout), (kind, im.errorMessage)
+                assert im.isDevice and (im.width, im.height, im.type) == (w, h, t1)
+                assert np.array_equal(im.pixels(), exp), (kind, hex(flags), layout)
+                host = Image(); assert host.loadFromMemory(data, flags | layout)
+                assert (im.pitchInBytes, im.layoutConstraints, im.isStoredUpsideDown) == (host.pitchInBytes, host.layoutConstraints, host.isStoredUpsideDown)
+    # create + convertTo chain + flip, layered
+    a = Image(device=True); b = Image()
+    for im in (a, b):
+        assert im.createLayered(33, 9, 3, PT["rgba8"], gi.LAYOUT_TRAILING[1])
+        assert im.convertTo(PT["rgbaf32"], gi.LAYOUT_GAPLESS) and im.convertTo(PT["la16"], 0) and im.flipVertical()
+    for layer in range(3):
+        assert np.array_equal(a.pixels(layer), b.pixels(layer))
+    assert not Image(device=True).loadFromMemory(b"garbage", 0)

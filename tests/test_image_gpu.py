@@ -213,3 +213,37 @@ def test_device_resident_images(hip):
     for layer in range(3):
         assert np.array_equal(a.pixels(layer), b.pixels(layer))
     assert not Image(device=True).loadFromMemory(b"garbage", 0)
+
+
+def test_concurrent_host_threads(hip):
+    """the library keeps no mutable global state besides per-thread streams and staging buffers: decodes of
+    different Images from several host threads at once give the single-threaded results (ctypes drops the GIL in the calls)"""
+    import threading
+    from test_oracle_pinning import _qoi_test_images
+    rng = np.random.default_rng(23)
+    work = [("jpeg", open(p, "rb").read(), 0) for p in JPEGS[:4]]
+    work += [("jpeg", open(os.path.join(G, "jpeg", "p_131x97_420.jpg"), "rb").read(), gi.LOAD_RGB | gi.LOAD_ALPHA)]
+    work += [("png", open(os.path.join(G, "ref_images", "issue65.png"), "rb").read(), gi.LOAD_FP32),
+             ("png", gen.write_png(rng.integers(0, 256, (40, 57 * 3)), 57, 40, 2, 8), gi.LOAD_RGB | gi.LOAD_ALPHA | gi.LOAD_16BIT),
+             ("qoi", gen.qoi_encode(_qoi_test_images()[3]), 0)]
+    expected = [expected_load(d, f, k) for k, d, f in work]
+    errors = []
+
+    def worker(tid):
+        try:
+            for rep in range(6):
+                for j in range(len(work)):
+                    k, d, f = work[(j + tid) % len(work)]
+                    w, h, t1, exp = expected[(j + tid) % len(work)]
+                    im = Image(device=(tid + rep) % 2 == 1)
+                    if not im.loadFromMemory(d, f):
+                        errors.append((tid, k, im.errorMessage)); return
+                    if (im.width, im.height, im.type) != (w, h, t1) or not np.array_equal(im.pixels(), exp):
+                        errors.append((tid, k, "pixels differ")); return
+        except Exception as e:            # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert not errors, errors[:3]

@@ -220,7 +220,7 @@ def main():
         raise SystemExit(f"unknown workload {wl}")
 
     if check is not None and rank == 0:
-        if not os.environ.get("GAMUT_BENCH_NOCHECK"):      # experiments with deliberately wrong kernels (tools/png_abl.sh) only
+        if not os.environ.get("GAMUT_BENCH_NOCHECK"):      # experiments with deliberately wrong kernels (tools/variant.sh) only
             check()
 
     # ------------------------------------------------------------------ timing

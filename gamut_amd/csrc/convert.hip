@@ -48,6 +48,11 @@ constexpr int unit_pixels(int s, int d)
 constexpr int vec_bytes(int unit_bytes) { return unit_bytes % 16 == 0 ? 16 : unit_bytes % 8 == 0 ? 8 : 4; }
 
 // ---- unit load / store -----------------------------------------------------
+#ifndef CONVERT_NT            // 1: nontemporal stores, 2: nontemporal loads too (tuning knob, tools/variant.sh)
+#define CONVERT_NT 0
+#endif
+typedef u32 u32x4v __attribute__((ext_vector_type(4)));
+typedef u32 u32x2v __attribute__((ext_vector_type(2)));
 template <int BYTES>
 __device__ __forceinline__ void load_unit(const uint8_t* p, u32 (&w)[BYTES / 4])
 {
@@ -55,7 +60,8 @@ __device__ __forceinline__ void load_unit(const uint8_t* p, u32 (&w)[BYTES / 4])
     if constexpr (V == 16) {
         #pragma unroll
         for (int i = 0; i < BYTES / 16; ++i) {
-            const uint4 v = reinterpret_cast<const uint4*>(p)[i];
+            u32x4v v;
+            if (CONVERT_NT >= 2) v = __builtin_nontemporal_load(reinterpret_cast<const u32x4v*>(p) + i); else v = reinterpret_cast<const u32x4v*>(p)[i];
             w[4*i] = v.x; w[4*i+1] = v.y; w[4*i+2] = v.z; w[4*i+3] = v.w;
         }
     } else if constexpr (V == 8) {
@@ -75,11 +81,16 @@ __device__ __forceinline__ void store_unit(uint8_t* p, const u32 (&w)[BYTES / 4]
     constexpr int V = vec_bytes(BYTES);
     if constexpr (V == 16) {
         #pragma unroll
-        for (int i = 0; i < BYTES / 16; ++i)
-            reinterpret_cast<uint4*>(p)[i] = make_uint4(w[4*i], w[4*i+1], w[4*i+2], w[4*i+3]);
+        for (int i = 0; i < BYTES / 16; ++i) {
+            const u32x4v v = { w[4*i], w[4*i+1], w[4*i+2], w[4*i+3] };
+            if (CONVERT_NT >= 1) __builtin_nontemporal_store(v, reinterpret_cast<u32x4v*>(p) + i); else reinterpret_cast<u32x4v*>(p)[i] = v;
+        }
     } else if constexpr (V == 8) {
         #pragma unroll
-        for (int i = 0; i < BYTES / 8; ++i) reinterpret_cast<uint2*>(p)[i] = make_uint2(w[2*i], w[2*i+1]);
+        for (int i = 0; i < BYTES / 8; ++i) {
+            const u32x2v v = { w[2*i], w[2*i+1] };
+            if (CONVERT_NT >= 1) __builtin_nontemporal_store(v, reinterpret_cast<u32x2v*>(p) + i); else reinterpret_cast<u32x2v*>(p)[i] = v;
+        }
     } else {
         #pragma unroll
         for (int i = 0; i < BYTES / 4; ++i) reinterpret_cast<u32*>(p)[i] = w[i];

@@ -369,7 +369,7 @@ __global__ __launch_bounds__(W * 64) void k_png_defilter(DefilterArgs a)
 //   * at the end of the tile every row has finished exactly one more 128-BYTE-ALIGNED group of 8 pieces (iterations
 //     8g .. 8g+7, computed during this tile and the one before); those groups are written back, 8 lanes per row.
 // Writing whole aligned 128-byte lines matters: the same bytes stored as tile-shaped (16-byte-granular, unaligned)
-// 128-byte runs ran at 2.0 TB/s store-only against 3.7 TB/s aligned (tools/png_abl.sh experiments).
+// 128-byte runs ran at 2.0 TB/s store-only against 3.7 TB/s aligned (tools/variant.sh experiments).
 constexpr int TT = 8;
 constexpr int RING = 16;                          // pieces per row: a finished-but-unwritten group (<= 7 pieces) + the tile in flight (8)
 constexpr int ROW_PITCH = RING * 16;              // 256 B: lane j's slot (T - j) % 16 => ds_read_b128 conflict-free across 8 consecutive lanes

@@ -22,6 +22,36 @@ hipStream_t thread_stream();
 // enqueued by a caller that never touches streams is ordered with everything else it does
 inline hipStream_t pick_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Per-thread staging buffers (declared `static thread_local` where they are used): grown on demand, never shrunk, and
+// intentionally not freed at thread exit -- the HIP runtime may already be gone by then.
+struct DeviceScratch {                  // device memory
+    void* p = nullptr; size_t cap = 0;
+    void* get(size_t n)
+    {
+        if (n > cap) {
+            if (p) { (void)hipDeviceSynchronize(); (void)hipFree(p); p = nullptr; cap = 0; }
+            const size_t want = n + n / 4 + 4096;
+            if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return nullptr; }
+            cap = want;
+        }
+        return p;
+    }
+};
+struct PinnedScratch {                  // page-locked host memory: uploads from it are plain DMA
+    uint8_t* p = nullptr; size_t cap = 0;
+    uint8_t* get(size_t n)
+    {
+        if (n > cap) {
+            if (p) { (void)hipDeviceSynchronize(); (void)hipHostFree(p); p = nullptr; cap = 0; }
+            void* np = nullptr;
+            const size_t want = n + n / 4 + 4096;
+            if (hipHostMalloc(&np, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+            p = (uint8_t*)np; cap = want;
+        }
+        return p;
+    }
+};
+
 #define GAMUT_HIP_CHECK(expr)                                                                 \
     do {                                                                                      \
         hipError_t e__ = (expr);                                                              \

@@ -824,20 +824,7 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevIte
     if (t == 0 && failed) atomicOr(status + it.image, 1u);
 }
 
-// Host side: header walk per file, table de-duplication, restart-interval index, one upload, one launch.
-struct EntropyScratch {                // per-thread device staging, grown on demand, never shrunk
-    void* dev = nullptr; size_t cap = 0;
-    void* get(size_t n)
-    {
-        if (n > cap) {
-            if (dev) { (void)hipDeviceSynchronize(); (void)hipFree(dev); dev = nullptr; cap = 0; }
-            if (hipMalloc(&dev, n + n / 4 + 4096) != hipSuccess) { dev = nullptr; return nullptr; }
-            cap = n + n / 4 + 4096;
-        }
-        return dev;
-    }
-};
-
+// Host side: header walk per file (on host threads), table de-duplication, restart-interval index, one upload, two launches.
 // geometry + the position of the single baseline scan; shared by read_header and the device decoder
 int parse_baseline(Parser& P, const uint8_t* data, size_t len, gamut_hip_jpeg_frame* f, bool want_scan)
 {
@@ -932,19 +919,6 @@ void prepare_file(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& f,
     }
 }
 
-struct PinnedHost {                    // per-thread page-locked staging for the upload, grown on demand, never shrunk
-    uint8_t* p = nullptr; size_t cap = 0;
-    uint8_t* get(size_t n)
-    {
-        if (n > cap) {
-            if (p) { (void)hipDeviceSynchronize(); (void)hipHostFree(p); p = nullptr; cap = 0; }
-            void* np = nullptr;
-            if (hipHostMalloc(&np, n + n / 4 + 4096, hipHostMallocDefault) != hipSuccess) return nullptr;
-            p = (uint8_t*)np; cap = n + n / 4 + 4096;
-        }
-        return p;
-    }
-};
 
 template <class Fn> void parallel_for(int count, int workers, Fn fn)          // fn(worker, index); the caller runs worker 0
 {
@@ -1014,8 +988,8 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
         const size_t o_items = 0, o_img = align(o_items + items.size() * sizeof(DevItem)), o_huff = align(o_img + images.size() * sizeof(DevImage)),
                      o_quant = align(o_huff + huffs.size() * sizeof(DevHuff)), o_blob = align(o_quant + quants.size() * sizeof(QuantTab)),
                      total = o_blob + blob_size + 64;
-        static thread_local EntropyScratch scratch;
-        static thread_local PinnedHost pinned;
+        static thread_local DeviceScratch scratch;
+        static thread_local PinnedScratch pinned;
         uint8_t* d = (uint8_t*)scratch.get(total);
         uint8_t* h = pinned.get(total);
         if (!d || !h) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: staging allocation of %zu bytes failed", total);
@@ -1032,7 +1006,7 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
         if (d_status) GAMUT_HIP_CHECK(hipMemsetAsync(d_status, 0, (size_t)count * sizeof(uint32_t), stream));
         uint32_t* st = d_status;
         if (!st) {                                             // the kernel wants somewhere to flag errors
-            static thread_local EntropyScratch sink;
+            static thread_local DeviceScratch sink;
             st = (uint32_t*)sink.get((size_t)count * sizeof(uint32_t));
             if (!st) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: status allocation failed");
         }

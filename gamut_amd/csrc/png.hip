@@ -653,18 +653,6 @@ __global__ __launch_bounds__(256) void k_png_adam7_scatter(const uint8_t* pass, 
 
 inline int blocks_for(int64_t n) { int64_t b = (n + 255) / 256; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
 
-struct Scratch {      // per-thread scratch for de-filtered rows of formats that need stage B
-    void* p = nullptr; size_t cap = 0;       // intentionally not freed at thread exit (the HIP runtime may already be gone)
-    void* get(size_t n)
-    {
-        if (n > cap) {
-            if (p) { (void)hipDeviceSynchronize(); (void)hipFree(p); p = nullptr; cap = 0; }
-            if (hipMalloc(&p, n) != hipSuccess) { p = nullptr; return nullptr; }
-            cap = n;
-        }
-        return p;
-    }
-};
 
 } // namespace
 
@@ -735,7 +723,7 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
 
     DefilterArgs a{};
     a.raw = raw; a.raw_stride = raw_stride; a.rows = y; a.wb = wb; a.status = status;
-    static thread_local Scratch scratch;
+    static thread_local DeviceScratch scratch;
     if (fused) { a.D = out; a.d_stride = out_stride; a.d_pitch = wb; a.store_tail_masked = 1; }
     else {
         const int64_t group = 4 * FB;

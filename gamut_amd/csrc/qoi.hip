@@ -99,18 +99,6 @@ int read_header(const uint8_t* data, int size, gamut_hip_qoi_desc* d, int channe
     return GAMUT_HIP_OK;
 }
 
-struct Staging {                      // per-thread device staging, grown on demand
-    void* dev = nullptr; size_t cap = 0;
-    void* get(size_t n)
-    {
-        if (n > cap) {
-            if (dev) { (void)hipDeviceSynchronize(); (void)hipFree(dev); dev = nullptr; cap = 0; }
-            if (hipMalloc(&dev, n + n / 4 + 4096) != hipSuccess) { dev = nullptr; return nullptr; }
-            cap = n + n / 4 + 4096;
-        }
-        return dev;
-    }
-};
 
 int decode_batch(const uint8_t* const* data, const int* size, int count, int channels, const int64_t* out_offset, uint8_t* d_out,
                  gamut_hip_qoi_desc* descs, int* status_host, hipStream_t stream)
@@ -129,7 +117,7 @@ int decode_batch(const uint8_t* const* data, const int* size, int count, int cha
     }
     if (!items.empty()) {
         const size_t o_blob = (items.size() * sizeof(QoiItem) + 255) & ~(size_t)255, total = o_blob + blob.size();
-        static thread_local Staging staging;
+        static thread_local DeviceScratch staging;
         uint8_t* d = (uint8_t*)staging.get(total);
         if (!d) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "qoi: device staging allocation of %zu bytes failed", total);
         GAMUT_HIP_CHECK(hipMemcpyAsync(d, items.data(), items.size() * sizeof(QoiItem), hipMemcpyHostToDevice, stream));

@@ -101,6 +101,18 @@ def test_jpeg_batch_feeder_threads():
     assert L.gamut_hip_jpeg_decode_coeffs_batch(None, None, 3, None, None, 2) == _capi.ERR_INVALID_ARG
 
 
+def test_plain_c99_consumer(tmp_path):
+    """the headers are C (not C++): a strict C99 program includes both, links the library and uses it"""
+    import subprocess
+    exe = str(tmp_path / "abi_consumer")
+    lib_dir = os.path.dirname(_capi.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "abi_consumer.c"), "-o", exe, "-L", lib_dir, "-lgamut_hip", "-Wl,-rpath," + lib_dir])
+    out = subprocess.run([exe, os.path.join(G, "jpeg", "cfg1_640x480_420_q90.jpg")], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert out.stdout.startswith("640x480 comps=3 scan_type=4 blocks=7200 ") and out.stdout.rstrip().endswith("format=0")
+
+
 def test_jpeg_scan_layout():
     """segments the device entropy decoder would get: 1 without restart markers, one per interval with them"""
     L = _capi.lib()

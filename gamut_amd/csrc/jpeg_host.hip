@@ -92,8 +92,7 @@ struct BitReader {
         const uint16_t e = h.fast[peek(10)];
         if (e) { drop(e >> 8); return e & 0xFF; }
         int32_t code = (int32_t)peek(10); int len = 10;
-        while (len < 17 && code > h.maxcode[len]) { ++len; code = (int32_t)peek(len); }
-        if (len > 16) return -1;
+        while (code > h.maxcode[len]) { if (++len > 16) return -1; code = (int32_t)peek(len); }      // no valid code is longer than 16 bits
         drop(len);
         return h.vals[(code + h.delta[len]) & 0xFF];
     }
@@ -568,8 +567,7 @@ struct DevBits {
         const uint32_t e = h->fast[peek(9)];
         if (e) { drop((int)(e >> 8)); return (int)(e & 0xFF); }
         int32_t code = (int32_t)peek(9); int len = 9;
-        while (len < 17 && code > h->maxcode[len]) { ++len; code = (int32_t)peek(len); }
-        if (len > 16) return -1;
+        while (code > h->maxcode[len]) { if (++len > 16) return -1; code = (int32_t)peek(len); }
         drop(len);
         return h->vals[(code + h->delta[len]) & 0xFF];
     }

@@ -10,15 +10,17 @@
 // Arithmetic contract (DESIGN.md "f32 parity"): every binary32 operation is
 // rounded on its own -- built with -ffp-contract=off and written with
 // __fadd_rn/__fmul_rn/__fdiv_rn so no FMA can form; division is the IEEE
-// correctly rounded one (v_div_scale/v_div_fmas/v_div_fixup), never a
-// reciprocal multiply; float->int is x86 cvttss2si (truncate; NaN / out of
+// correctly rounded one (v_div_scale/v_div_fmas/v_div_fixup, or for the
+// constant divisors 255 / 65535 an FMA sequence proven to give the same result
+// for every input, div_by_max below), never a bare reciprocal multiply; float->int is x86 cvttss2si (truncate; NaN / out of
 // int32 range -> 0x80000000) followed by taking the low 8/16 bits, which is
 // what `cast(ubyte)(float)` compiles to in the reference's x86-64 build.
 //
 // Work decomposition: one thread converts a "unit" of G pixels, G chosen per
-// type pair so both sides of the unit are whole dwords and the wider side is
-// >= 16 B (one dwordx4 per lane, lane-contiguous => fully coalesced 1 KiB per
-// wave instruction).  Units are distributed grid-stride over <= 6 blocks/CU.
+// type pair so the WIDER side of the unit is whole dwords and >= 16 B (one
+// dwordx4 per lane, lane-contiguous => fully coalesced 1 KiB per wave
+// instruction); the narrower side moves as exact dword / halfword / byte pieces
+// (unit_pixels below).  Units are distributed grid-stride over <= 6 blocks/CU.
 #include "common.hpp"
 #include <utility>
 
@@ -39,13 +41,21 @@ template <int T> struct PT {
 constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
 constexpr int clcm(int a, int b) { return a / cgcd(a, b) * b; }
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
+// Pixels per thread ("unit"): the WIDER side of the pair must be whole dwords and at least 16 bytes, so that it moves as
+// lane-contiguous dwordx4 / dwordx2 / dword accesses.  The narrower side gets whatever that leaves -- 1, 2, 3, 6 ... bytes are
+// fine: it is read / written with exact dword + halfword + byte pieces (gfx950 takes dwords at any byte address).  Forcing whole
+// dwords on BOTH sides (the first version) made expanding pairs such as l16 -> rgbaf32 handle 2-4 pixels per thread, i.e. 32-64
+// destination bytes per lane written as 16-byte pieces at a 32-64-byte lane stride: 47 % of peak instead of ~60 %.
 constexpr int unit_pixels(int s, int d)
 {
-    int g = clcm(4 / cgcd(s, 4), 4 / cgcd(d, 4));
-    while (cmax(g * s, g * d) < 16) g *= 2;
+    const int wide = cmax(s, d);
+    int g = 4 / cgcd(wide, 4);
+    while (g * wide < 16) g *= 2;
     return g;
 }
-constexpr int vec_bytes(int unit_bytes) { return unit_bytes % 16 == 0 ? 16 : unit_bytes % 8 == 0 ? 8 : 4; }
+constexpr int vec_bytes(int unit_bytes) { return unit_bytes % 16 == 0 ? 16 : unit_bytes % 8 == 0 ? 8 : unit_bytes % 4 == 0 ? 4 : unit_bytes % 2 == 0 ? 2 : 1; }
+struct __attribute__((packed)) AnyU32 { u32 v; };
+struct __attribute__((packed)) AnyU16 { uint16_t v; };
 
 // ---- unit load / store -----------------------------------------------------
 #ifndef CONVERT_NT            // 1: nontemporal stores, 2: nontemporal loads too (tuning knob, tools/variant.sh)
@@ -54,7 +64,7 @@ constexpr int vec_bytes(int unit_bytes) { return unit_bytes % 16 == 0 ? 16 : uni
 typedef u32 u32x4v __attribute__((ext_vector_type(4)));
 typedef u32 u32x2v __attribute__((ext_vector_type(2)));
 template <int BYTES>
-__device__ __forceinline__ void load_unit(const uint8_t* p, u32 (&w)[BYTES / 4])
+__device__ __forceinline__ void load_unit(const uint8_t* p, u32 (&w)[(BYTES + 3) / 4])
 {
     constexpr int V = vec_bytes(BYTES);
     if constexpr (V == 16) {
@@ -70,13 +80,20 @@ __device__ __forceinline__ void load_unit(const uint8_t* p, u32 (&w)[BYTES / 4])
             const uint2 v = reinterpret_cast<const uint2*>(p)[i];
             w[2*i] = v.x; w[2*i+1] = v.y;
         }
-    } else {
+    } else if constexpr (V == 4) {
         #pragma unroll
         for (int i = 0; i < BYTES / 4; ++i) w[i] = reinterpret_cast<const u32*>(p)[i];
+    } else {                                                   // the narrow side of an expanding / shrinking pair: exact pieces
+        #pragma unroll
+        for (int i = 0; i < BYTES / 4; ++i) w[i] = reinterpret_cast<const AnyU32*>(p)[i].v;
+        constexpr int R = BYTES % 4, O = BYTES - R;
+        if constexpr (R == 1) w[BYTES / 4] = p[O];
+        else if constexpr (R == 2) w[BYTES / 4] = reinterpret_cast<const AnyU16*>(p + O)->v;
+        else if constexpr (R == 3) w[BYTES / 4] = (u32)reinterpret_cast<const AnyU16*>(p + O)->v | ((u32)p[O + 2] << 16);
     }
 }
 template <int BYTES>
-__device__ __forceinline__ void store_unit(uint8_t* p, const u32 (&w)[BYTES / 4])
+__device__ __forceinline__ void store_unit(uint8_t* p, const u32 (&w)[(BYTES + 3) / 4])
 {
     constexpr int V = vec_bytes(BYTES);
     if constexpr (V == 16) {
@@ -91,9 +108,17 @@ __device__ __forceinline__ void store_unit(uint8_t* p, const u32 (&w)[BYTES / 4]
             const u32x2v v = { w[2*i], w[2*i+1] };
             if (CONVERT_NT >= 1) __builtin_nontemporal_store(v, reinterpret_cast<u32x2v*>(p) + i); else reinterpret_cast<u32x2v*>(p)[i] = v;
         }
-    } else {
+    } else if constexpr (V == 4) {
         #pragma unroll
         for (int i = 0; i < BYTES / 4; ++i) reinterpret_cast<u32*>(p)[i] = w[i];
+    } else {
+        #pragma unroll
+        for (int i = 0; i < BYTES / 4; ++i) reinterpret_cast<AnyU32*>(p)[i].v = w[i];
+        constexpr int R = BYTES % 4, O = BYTES - R;
+        const u32 last = w[BYTES / 4];
+        if constexpr (R == 1) p[O] = (uint8_t)last;
+        else if constexpr (R == 2) reinterpret_cast<AnyU16*>(p + O)->v = (uint16_t)last;
+        else if constexpr (R == 3) { reinterpret_cast<AnyU16*>(p + O)->v = (uint16_t)last; p[O + 2] = (uint8_t)(last >> 16); }
     }
 }
 
@@ -212,7 +237,7 @@ template <int T> __device__ __forceinline__ void encode_u8(u32* w, int p, const 
 template <int S, int D, int G>
 __device__ __forceinline__ void convert_unit(const u32* in, u32* out)
 {
-    constexpr int DW = G * PT<D>::size / 4;
+    constexpr int DW = (G * PT<D>::size + 3) / 4;
     #pragma unroll
     for (int i = 0; i < DW; ++i) out[i] = 0;
     #pragma unroll
@@ -257,7 +282,7 @@ __global__ __launch_bounds__(kThreads) void k_convert_vec(ConvArgs a)
     constexpr int SB = G * PT<S>::size, DB = G * PT<D>::size;
     const int64_t stride = (int64_t)gridDim.x * kThreads;
     for (int64_t base = (int64_t)blockIdx.x * kThreads + threadIdx.x; base < a.total; base += stride * kUnroll) {
-        u32 in[kUnroll][SB / 4];
+        u32 in[kUnroll][(SB + 3) / 4];
         const uint8_t* sp[kUnroll]; uint8_t* dp[kUnroll];
         u32 uidx[kUnroll]; bool live[kUnroll];
         #pragma unroll
@@ -280,7 +305,7 @@ __global__ __launch_bounds__(kThreads) void k_convert_vec(ConvArgs a)
         for (int j = 0; j < kUnroll; ++j) {
             if (!live[j]) continue;
             if (uidx[j] < a.full_units) {
-                u32 out[DB / 4];
+                u32 out[(DB + 3) / 4];
                 convert_unit<S, D, G>(in[j], out);
                 store_unit<DB>(dp[j], out);
             } else {

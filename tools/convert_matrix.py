@@ -8,8 +8,12 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import oracle_lib as O  # noqa: E402
 from gamut_amd import _capi  # noqa: E402
+
+
+PIXEL_TYPES = ['l8', 'l16', 'lf32', 'la8', 'la16', 'laf32', 'lap8', 'lap16', 'lapf32', 'rgb8', 'rgb16', 'rgbf32', 'rgba8', 'rgba16', 'rgbaf32',
+               'rgbap8', 'rgbap16', 'rgbapf32']                    # PixelType ordinals, types.d:32-59
+PT_SIZE = [1, 2, 4, 2, 4, 8, 2, 4, 8, 3, 6, 12, 4, 8, 16, 4, 8, 16]
 
 
 def main():
@@ -22,11 +26,11 @@ def main():
     src = torch.randint(0, 256, (layers * npx * 16,), device=dev, dtype=torch.int32).to(torch.uint8)      # any bytes are valid pixels except f32 NaNs: fine for timing
     dst = torch.empty((layers * npx * 16,), dtype=torch.uint8, device=dev)
     res = []
-    for s, sn in enumerate(O.PIXEL_TYPES):
-        for d, dn in enumerate(O.PIXEL_TYPES):
+    for s, sn in enumerate(PIXEL_TYPES):
+        for d, dn in enumerate(PIXEL_TYPES):
             if s == d:
                 continue
-            sp, dp = side * O.PT_SIZE[s], side * O.PT_SIZE[d]
+            sp, dp = side * PT_SIZE[s], side * PT_SIZE[d]
 
             def step():
                 _capi.check(L.gamut_hip_scanlines_convert_device(s, src.data_ptr(), sp, sp * side, d, dst.data_ptr(), dp, dp * side, side, side, layers, stream))
@@ -37,7 +41,7 @@ def main():
                 step()
             b.record(); torch.cuda.synchronize()
             ms = a.elapsed_time(b) / 5
-            res.append((layers * npx * (O.PT_SIZE[s] + O.PT_SIZE[d]) / ms / 1e6, sn, dn, ms))
+            res.append((layers * npx * (PT_SIZE[s] + PT_SIZE[d]) / ms / 1e6, sn, dn, ms))
     res.sort()
     for gbs, sn, dn, ms in res[:40]:
         print(f"{sn:>9s} -> {dn:<9s} {gbs:8.0f} GB/s  {ms:7.3f} ms")

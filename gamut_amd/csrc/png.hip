@@ -8,18 +8,21 @@
 // its left, upper and upper-left neighbours (Paeth), so the dependency graph is a 2-D
 // wavefront.  Mapping used here:
 //   * one workgroup of W waves per image; wave w owns the 64-row bands w, w+W, w+2W, ...
-//   * inside a band lane = row; lane j runs one "iteration" (4 filter units = 4*FB bytes)
-//     behind lane j-1, so the upper neighbours arrive from lane j-1 with one DPP row shift
-//     of the FB dwords it produced in the previous iteration; the left neighbours are the
-//     lane's own previous outputs (registers)
+//   * inside a band lane = row; lane j runs one "iteration" (a 16-byte piece of its row) behind
+//     lane j-1, so the upper neighbours arrive from lane j-1 with one DPP row shift per dword of
+//     the piece it produced in the previous trip; the left neighbours are the lane's own
+//     previous outputs (registers)
 //   * lane 0 of band b needs the last row of band b-1, produced by another wave of the same
 //     workgroup: it is read back from the output rows in HBM/L2 (full-row capacity, so no
 //     back-pressure is needed), gated by a monotonic per-wave progress counter in LDS with a
 //     workgroup-scope release (producer) / acquire (consumer) pair.  Consecutive bands run
 //     ~64 iterations apart, so all W waves are busy at once.
-//   * the per-row filter type is data: None/Sub/Up/Avg are one masked form
-//     ((a & ma) + (b & mb)) >> sh; the Paeth predictor is evaluated only while some row of
-//     the wave's band uses it (wave-uniform branch).
+//   * the per-row filter type is data: None/Sub/Up/Avg are one masked form evaluated four bytes
+//     at a time (SWAR); the Paeth predictor (packed FP16, two channels per instruction) is
+//     evaluated only while some row of the wave's band uses it (wave-uniform branch).
+// Two kernels share this: k_png_defilter_ring (rows of at least one piece: all I/O staged through
+// per-row LDS rings so that loads are coalesced and stores are whole aligned lines -- the fast
+// path for every filter unit) and k_png_defilter<FB> (narrower rows: per-lane loads / stores).
 // With zero neighbours outside the image the PNG formulas reproduce stb's first-row /
 // first-pixel special cases exactly (stbdec.d:1381-1388, :1453-1465).
 #include "common.hpp"
@@ -29,7 +32,7 @@ namespace {
 
 typedef uint32_t u32;
 
-constexpr int PNG_WAVES = 8;           // waves per workgroup (= bands in flight per image); two workgroups fit a CU
+constexpr int PNG_WAVES = 8;           // waves per workgroup (= bands in flight per image); the ring kernel's LDS allows one workgroup per CU
 constexpr int PUB = 8;                 // publish / check progress every PUB iterations (32 filter units)
 constexpr int PF = 4;                  // loop trips of row data kept in flight per lane
 constexpr int PUBLAG = 4;              // progress is published PUBLAG trips after the store it covers (see defilter_band)

@@ -244,3 +244,17 @@ def test_argument_validation_needs_no_device():
     assert L.gamut_hip_png_defilter_batch_device(p, 0, 10, p, 0, 4, 4, 4, 4, 8, 6, 1, None, None) == _capi.ERR_DECODE            # not enough pixels (stbdec.d:1430)
     assert L.gamut_hip_png_defilter_batch_device(p, 0, 64, p, 0, 0, 4, 4, 4, 8, 6, 1, None, None) == _capi.ERR_INVALID_ARG       # 0-pixel image (stbdec.d:1897)
     assert b"png_defilter" in L.gamut_hip_last_error()
+    # the file-level batch entry points: bad counts / null arrays are argument errors before anything else; empty batches are fine
+    assert L.gamut_hip_jpeg_entropy_decode_device(None, None, -1, None, None, None, None, None, None, None, None) == _capi.ERR_INVALID_ARG
+    assert L.gamut_hip_jpeg_entropy_decode_device(None, None, 2, None, None, None, None, None, None, None, None) == _capi.ERR_INVALID_ARG
+    assert L.gamut_hip_jpeg_entropy_decode_device(None, None, 0, None, None, None, None, None, None, None, None) == _capi.OK
+    assert L.gamut_hip_png_decode_batch_device(None, None, 1, 0, 8, None, None, None, None, 1, None) == _capi.ERR_INVALID_ARG
+    ptrs = (C.c_void_p * 1)(p); lens = (C.c_size_t * 1)(64); off = (C.c_int64 * 1)(0); info = (_capi.PngInfo * 1)()
+    assert L.gamut_hip_png_decode_batch_device(ptrs, lens, 1, 5, 8, off, p, info, None, 1, None) == _capi.ERR_INVALID_ARG        # req_comp 5
+    assert L.gamut_hip_png_decode_batch_device(ptrs, lens, 1, 0, 12, off, p, info, None, 1, None) == _capi.ERR_INVALID_ARG       # 12-bit output
+    assert L.gamut_hip_png_decode_batch_device(None, None, 0, 0, 8, None, None, None, None, 1, None) == _capi.OK
+    assert L.gamut_hip_qoi_decode_batch_device(None, None, 3, 4, None, None, None, None, None) == _capi.ERR_INVALID_ARG
+    assert L.gamut_hip_qoi_decode_batch_device(None, None, 0, 4, None, None, None, None, None) == _capi.OK
+    assert L.gamut_hip_jpeg_decode_coeffs_batch(None, None, 0, None, None, 4) == _capi.OK
+    hd = _capi.PngInfo()
+    assert L.gamut_hip_png_read_header(p, 64, C.byref(hd)) == _capi.ERR_DECODE and L.gamut_hip_png_read_header(p, 64, None) == _capi.ERR_INVALID_ARG

@@ -16,71 +16,77 @@ constexpr int kQoiHeader = 14, kQoiPadding = 8;                                /
 
 struct QoiItem { uint64_t begin; int64_t out_off; uint32_t size, npx; int32_t channels, pad; };
 
-// The stream is consumed through a little byte queue in a 64-bit register, refilled four bytes at a time from a dword
-// that was requested one refill earlier; pixels leave four at a time (one 16-byte or three 4-byte stores).  Byte-wise loads
-// and per-pixel stores made a lane wait a full memory round trip several times per pixel (1.3 us per pixel measured).
-struct QoiBytes {
-    const uint8_t* next; uint64_t q; int n; uint32_t pre;
-    __device__ __forceinline__ void open(const uint8_t* p) { next = p; q = 0; n = 0; __builtin_memcpy(&pre, next, 4); refill(); }
-    __device__ __forceinline__ void refill()
-    {
-        if (n > 4) return;
-        q |= (uint64_t)pre << (8 * n); n += 4; next += 4;
-        __builtin_memcpy(&pre, next, 4);
-    }
-    __device__ __forceinline__ uint32_t get() { const uint32_t b = (uint32_t)q & 255u; q >>= 8; --n; return b; }
-};
+// A lane must not touch global memory per pixel: every wait for a load also waits for the stores issued before it (one
+// in-order counter), so byte-wise loads and per-pixel stores made a lane sit out a memory round trip several times per
+// pixel (1.3 us per pixel measured).  Each lane therefore owns, in LDS, a 128-byte window of its stream (two 64-byte
+// halves, the free one refilled with four dwordx4 loads) and a 64-pixel output buffer flushed with dwordx4 stores; the
+// state machine itself only talks to LDS.
+constexpr int kQoiInPitch = 144, kQoiOutPx = 64;
 
 __global__ __launch_bounds__(64) void k_qoi_decode(const QoiItem* items, int n, const uint8_t* blob, uint8_t* out)
 {
     __shared__ uint32_t index[64 * 64];                       // [hash][lane]
+    __shared__ __attribute__((aligned(16))) uint8_t sh_in[64 * kQoiInPitch];
+    __shared__ __attribute__((aligned(16))) uint8_t sh_out[64 * kQoiOutPx * 4];
     const int lane = threadIdx.x;
     #pragma unroll 8
     for (int k = 0; k < 64; ++k) index[k * 64 + lane] = 0;    // memset(index, 0) :491  (a lane only touches its own column)
     const int i = blockIdx.x * 64 + lane;
     if (i >= n) return;
     const QoiItem it = items[i];
-    uint8_t* pixels = out + it.out_off;
-    uint32_t r = 0, g = 0, b = 0, a = 255;                    // :492-495
-    // bytes [14, size - 8) are chunks (p < chunks_len, :498); a chunk may read up to 4 bytes further, which the 8 padding
-    // bytes (and the slack the host appends to every stream) cover
-    QoiBytes in; in.open(blob + it.begin + kQoiHeader);
-    int left = (int)it.size - kQoiPadding - kQoiHeader, run = 0;      // chunk bytes not yet consumed
-    uint32_t buf[4]; int nbuf = 0;                            // four finished pixels
     const bool rgba = it.channels == 4;
+    const int bpp = rgba ? 4 : 3;
+    uint8_t* pixels = out + it.out_off;
+    const uint8_t* stream = blob + it.begin + kQoiHeader;      // chunks start here; the host appends slack to every stream
+    uint8_t* win = sh_in + lane * kQoiInPitch;
+    uint8_t* obuf = sh_out + lane * (kQoiOutPx * 4);
+    uint32_t r = 0, g = 0, b = 0, a = 255;                    // :492-495
+    uint32_t consumed = 0, fetched = 0;                       // bytes of the chunk area
+    // bytes [14, size - 8) are chunks (p < chunks_len, :498); a chunk may read up to 4 bytes further (padding / slack)
+    const int chunk_bytes = (int)it.size - kQoiPadding - kQoiHeader;
+    int run = 0, staged = 0;                                  // pixels waiting in obuf
+    uint32_t flushed = 0;                                     // pixels already written out
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    struct __attribute__((packed, aligned(1))) AnyVec { u32x4 v; };               // 16 bytes at any address
+    auto fetch_half = [&]() {
+        const AnyVec* src = reinterpret_cast<const AnyVec*>(stream + fetched);
+        const u32x4 v0 = src[0].v, v1 = src[1].v, v2 = src[2].v, v3 = src[3].v;
+        u32x4* dst = reinterpret_cast<u32x4*>(win + (fetched & 127));
+        dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3;
+        fetched += 64;
+    };
+    auto flush = [&](int npx) {                               // npx * bpp bytes from obuf to the image
+        uint8_t* o = pixels + (size_t)flushed * bpp;
+        const int nbytes = npx * bpp;
+        int k = 0;
+        for (; k + 16 <= nbytes; k += 16) reinterpret_cast<AnyVec*>(o + k)->v = *reinterpret_cast<const u32x4*>(obuf + k);
+        for (; k < nbytes; ++k) o[k] = obuf[k];
+        flushed += (uint32_t)npx;
+    };
+    fetch_half(); fetch_half();
     for (uint32_t px = 0; px < it.npx; ++px) {
         if (run > 0) --run;
-        else if (left > 0) {
-            in.refill(); in.refill();                         // >= 5 bytes queued: enough for any chunk (the second call tops up an empty queue)
-            const uint32_t b1 = in.get(); int used = 1;
-            if (b1 == 0xFE)      { r = in.get(); g = in.get(); b = in.get(); used = 4; }                                   // QOI_OP_RGB
-            else if (b1 == 0xFF) { r = in.get(); g = in.get(); b = in.get(); a = in.get(); used = 5; }                    // QOI_OP_RGBA
+        else if ((int)consumed < chunk_bytes) {
+            if (fetched - consumed <= 64) fetch_half();       // a whole half is free again
+            const uint32_t c0 = consumed;
+            const uint32_t b1 = win[c0 & 127], x1 = win[(c0 + 1) & 127], x2 = win[(c0 + 2) & 127], x3 = win[(c0 + 3) & 127], x4 = win[(c0 + 4) & 127];
+            int used = 1;
+            if (b1 == 0xFE)      { r = x1; g = x2; b = x3; used = 4; }                                       // QOI_OP_RGB
+            else if (b1 == 0xFF) { r = x1; g = x2; b = x3; a = x4; used = 5; }                              // QOI_OP_RGBA
             else if ((b1 & 0xC0) == 0x00) { const uint32_t v = index[b1 * 64 + lane]; r = v & 255; g = (v >> 8) & 255; b = (v >> 16) & 255; a = v >> 24; }
             else if ((b1 & 0xC0) == 0x40) { r = (r + ((b1 >> 4) & 3) - 2) & 255; g = (g + ((b1 >> 2) & 3) - 2) & 255; b = (b + (b1 & 3) - 2) & 255; }
             else if ((b1 & 0xC0) == 0x80) {
-                const uint32_t b2 = in.get(); const int vg = (int)(b1 & 0x3f) - 32; used = 2;
-                r = (r + vg - 8 + ((b2 >> 4) & 0x0f)) & 255; g = (g + vg) & 255; b = (b + vg - 8 + (b2 & 0x0f)) & 255;
+                const int vg = (int)(b1 & 0x3f) - 32; used = 2;
+                r = (r + vg - 8 + ((x1 >> 4) & 0x0f)) & 255; g = (g + vg) & 255; b = (b + vg - 8 + (x1 & 0x0f)) & 255;
             } else run = (int)(b1 & 0x3f);                                                                 // QOI_OP_RUN
-            left -= used;
+            consumed += (uint32_t)used;
             index[((r * 3 + g * 5 + b * 7 + a * 11) & 63) * 64 + lane] = r | g << 8 | b << 16 | a << 24;    // QOI_COLOR_HASH :239-242
         }
-        buf[nbuf & 3] = r | g << 8 | b << 16 | a << 24;
-        if ((++nbuf & 3) == 0) {
-            uint8_t* o = pixels + (size_t)(px - 3) * (rgba ? 4 : 3);
-            if (rgba) { uint32_t v[4] = { buf[0], buf[1], buf[2], buf[3] }; __builtin_memcpy(o, v, 16); }
-            else {
-                uint32_t v[3] = { __builtin_amdgcn_perm(buf[1], buf[0], 0x04020100u), __builtin_amdgcn_perm(buf[2], buf[1], 0x05040201u),
-                                  __builtin_amdgcn_perm(buf[3], buf[2], 0x06050402u) };
-                __builtin_memcpy(o, v, 12);
-            }
-        }
+        if (rgba) *reinterpret_cast<uint32_t*>(obuf + staged * 4) = r | g << 8 | b << 16 | a << 24;
+        else { uint8_t* o = obuf + staged * 3; o[0] = (uint8_t)r; o[1] = (uint8_t)g; o[2] = (uint8_t)b; }
+        if (++staged == kQoiOutPx) { flush(kQoiOutPx); staged = 0; }
     }
-    for (int k = 0; k < (nbuf & 3); ++k) {                    // the last one to three pixels
-        const uint32_t v = buf[k];
-        uint8_t* o = pixels + (size_t)(it.npx - (uint32_t)(nbuf & 3) + (uint32_t)k) * (rgba ? 4 : 3);
-        o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)(v >> 16);
-        if (rgba) o[3] = (uint8_t)(v >> 24);
-    }
+    if (staged) flush(staged);
 }
 
 inline uint32_t be32(const uint8_t* p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
@@ -113,7 +119,7 @@ int decode_batch(const uint8_t* const* data, const int* size, int count, int cha
         it.npx = descs[i].width * descs[i].height; it.channels = channels ? channels : descs[i].channels;
         items.push_back(it);
         blob.insert(blob.end(), data[i], data[i] + size[i]);
-        blob.insert(blob.end(), 16, (uint8_t)0);                // the lane's reader fetches ahead
+        blob.insert(blob.end(), 160, (uint8_t)0);               // the lane's reader fetches up to two 64-byte halves ahead
     }
     if (!items.empty()) {
         const size_t o_blob = (items.size() * sizeof(QoiItem) + 255) & ~(size_t)255, total = o_blob + blob.size();

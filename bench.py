@@ -13,7 +13,7 @@ Images are independent, so ranks shard by image index with no data-path collecti
 Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the launch
 stream; `cpu_baseline` is the CPU oracle (a scalar C restatement of the reference's loops,
 oracle/) timed on this box's host cores over a bounded sample of the same coefficients.
-Other kernels of the path: --workload convert:<src>:<dst> | png  (same JSON shape).
+Other kernels of the path: --workload convert:<src>:<dst> | png | mixed (configs[4]: JPEG / PNG / QOI)  (same JSON shape).
 """
 import argparse
 import ctypes as C
@@ -216,6 +216,90 @@ def main():
             dt = time.perf_counter() - t0
             return n * w * h / dt / 1e6, f"{n} of the batch's {w}x{h} filtered streams, stbi__create_png_image_raw, single thread, {dt:.1f} s"
         dtype = "u8"
+    elif wl == "mixed":
+        # BASELINE.json configs[4] on one rank: image i of the batch is a JPEG (i % 3 == 0), a PNG (1) or a QOI file (2), all
+        # 1920x1080 -> rgba8.  Inputs resident in HBM in the form each GPU stage starts from: dense coefficients, inflated
+        # filtered streams, QOI files as they are.  One launch per format; the per-format times are in config.per_format.
+        import oracle_lib as O
+        nj, npn, nq = (B + 2) // 3, (B + 1) // 3, B // 3
+        coeffs = synth.jpeg_coeff_batch(nj, w, h, dev, seed=1 + rank)
+        nblk = coeffs.shape[1]
+        raw, sums = synth.png_raw_batch(npn, w, h, dev, seed=3 + rank, policy="heuristic", channels=4)
+        raw_len = raw.shape[1]
+        nd = max(1, min(8, nq))
+        rgb = synth.synth_rgb_batch(nd, w, h, dev, seed=5 + rank).permute(0, 2, 3, 1).to(torch.uint8).cpu().numpy()
+        rgb[:, h // 4:h // 2, w // 4:w // 2] = rgb[:, h // 4:h // 4 + 1, w // 4:w // 4 + 1]     # a flat patch: RUN ops
+        files = [synth.qoi_encode(np.ascontiguousarray(rgb[i])) for i in range(nd)]
+        slack = 160                                                   # GAMUT_HIP_QOI_SLACK
+        q_begin = np.zeros(max(nq, 1), np.int64); q_size = np.zeros(max(nq, 1), np.int32); parts = []; pos = 0
+        for i in range(nq):
+            f = files[i % nd]
+            q_begin[i] = pos; q_size[i] = len(f); parts += [f, bytes(slack)]; pos += len(f) + slack
+        blob = torch.from_numpy(np.frombuffer(b"".join(parts) or bytes(1), np.uint8).copy()).to(dev)
+        q_descs = (_capi.QoiDesc * max(nq, 1))()
+        for i in range(nq):
+            _capi.check(L.gamut_hip_qoi_read_header(files[i % nd], len(files[i % nd]), C.byref(q_descs[i])))
+        out = torch.empty((B, h * w * 4), dtype=torch.uint8, device=dev)     # image i of the batch at out[i]
+        idx = np.arange(B)
+        q_off = (idx[idx % 3 == 2].astype(np.int64) * (h * w * 4))
+        # JPEG and PNG outputs go to every third slot as well: image pitch = 3 slots
+        status = torch.zeros((max(npn, 1),), dtype=torch.int32, device=dev)
+        px_per_step = B * w * h
+        fmt_bytes = {"jpeg": nj * (nblk * 128 + w * h * 4), "png": npn * (raw_len + w * h * 4), "qoi": int(q_size[:nq].sum()) + nq * w * h * 4}
+        bytes_per_step = sum(fmt_bytes.values())
+        kernel_name = "k_jpeg_h2v2 + k_png_defilter + k_qoi_decode"
+        workload = (f"mixed batch of {B} x {w}x{h} images -> rgba8, image i: JPEG 4:2:0 / PNG RGBA8 / QOI RGB by i % 3 "
+                    f"({nj} + {npn} + {nq}); QOI is decoded one lane per file (a serial format) and bounds the step")
+        fmt_ev = {k: [] for k in ("jpeg", "png", "qoi")}
+        img = h * w * 4
+
+        def step():
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            e[0].record()
+            _capi.check(L.gamut_hip_jpeg_reconstruct_batch_device(coeffs.data_ptr(), nblk * 64, None, 0, out.data_ptr(), w * 4, 3 * img, w, h, 4, 4, nj, stream))
+            e[1].record()
+            if npn:
+                _capi.check(L.gamut_hip_png_defilter_batch_device(raw.data_ptr(), raw_len, raw_len, out.data_ptr() + img, 3 * img, w, h, 4, 4, 8, 6, npn, status.data_ptr(), stream))
+            e[2].record()
+            if nq:
+                _capi.check(L.gamut_hip_qoi_decode_resident_device(blob.data_ptr(), blob.numel(), q_begin.ctypes.data_as(C.POINTER(C.c_int64)), q_size.ctypes.data_as(C.POINTER(C.c_int)),
+                                                                   q_descs, nq, 4, q_off.ctypes.data_as(C.POINTER(C.c_int64)), out.data_ptr(), stream))
+            e[3].record()
+            for k, (a, b) in zip(("jpeg", "png", "qoi"), zip(e[:-1], e[1:])):
+                fmt_ev[k].append((a, b))
+
+        def check():
+            step()
+            torch.cuda.synchronize()
+            fmt_ev["jpeg"].clear(); fmt_ev["png"].clear(); fmt_ev["qoi"].clear()
+            assert int(status.abs().sum()) == 0
+            exp = O.jpeg_reconstruct(w, h, 3, 4, coeffs[nj - 1].cpu().numpy(), None, 4)
+            if not np.array_equal(out[3 * (nj - 1)].cpu().numpy().reshape(exp.shape), exp):
+                raise SystemExit("PARITY FAILURE (JPEG)")
+            if npn:
+                exp = O.png_create_image_raw(raw[npn - 1].cpu().numpy(), 4, 4, w, h, 8, 6)
+                if not np.array_equal(out[3 * (npn - 1) + 1].cpu().numpy(), exp):
+                    raise SystemExit("PARITY FAILURE (PNG)")
+            if nq:
+                got = out[3 * (nq - 1) + 2].cpu().numpy().reshape(h, w, 4)
+                if not (np.array_equal(got[:, :, :3], rgb[(nq - 1) % nd]) and (got[:, :, 3] == 255).all()):
+                    raise SystemExit("PARITY FAILURE (QOI)")
+                exp, _, _ = O.qoi_decode(files[(nq - 1) % nd], 4)
+                if not np.array_equal(got.reshape(exp.shape), exp):
+                    raise SystemExit("PARITY FAILURE (QOI vs oracle)")
+
+        def cpu_leg(seconds):
+            cj = coeffs[0].cpu().numpy(); rp = raw[0].cpu().numpy() if npn else None
+            n, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < seconds:
+                k = n % 3
+                if k == 0: O.jpeg_reconstruct(w, h, 3, 4, cj, None, 4)
+                elif k == 1 and npn: O.png_create_image_raw(rp, 4, 4, w, h, 8, 6)
+                elif nq: O.qoi_decode(files[0], 4)
+                n += 1
+            dt = time.perf_counter() - t0
+            return n * w * h / dt / 1e6, f"{n} images of the same three kinds in turn (coefficients / filtered stream / QOI file -> rgba8), single thread, {dt:.1f} s"
+        dtype = "u8"
     else:
         raise SystemExit(f"unknown workload {wl}")
 
@@ -268,6 +352,13 @@ def main():
                          "kernel": kernel_name, "algorithmic_bytes_per_launch": bytes_per_step,
                          "kernel_ms_avg": round(avg_kernel_s * 1e3, 4), "kernel_ms_min": round(min(kern_ms), 4)},
         }
+        if wl == "mixed":
+            torch.cuda.synchronize()
+            res["config"]["per_format"] = {}
+            for k, cnt in (("jpeg", nj), ("png", npn), ("qoi", nq)):
+                ms = float(np.mean([a.elapsed_time(b) for a, b in fmt_ev[k][-args.steps:]])) if fmt_ev[k] else 0.0
+                res["config"]["per_format"][k] = {"images": cnt, "ms": round(ms, 4), "Mpx/s": round(cnt * w * h / ms / 1e3, 1) if ms > 0 else None,
+                                                 "GB/s": round(fmt_bytes[k] / ms / 1e6, 1) if ms > 0 else None}
         if world == 1 and not args.no_cpu:
             v, sample = cpu_leg(args.cpu_seconds)
             res["cpu_baseline"] = {"value": round(v, 2), "unit": "Mpx/s", "cores": 1, "kind": "port", "sample": sample}

@@ -19,15 +19,22 @@ struct QoiItem { uint64_t begin; int64_t out_off; uint32_t size, npx; int32_t ch
 // A lane must not touch global memory per pixel: every wait for a load also waits for the stores issued before it (one
 // in-order counter), so byte-wise loads and per-pixel stores made a lane sit out a memory round trip several times per
 // pixel (1.3 us per pixel measured).  Each lane therefore owns, in LDS, a 128-byte window of its stream (two 64-byte
-// halves, the free one refilled with four dwordx4 loads) and a 64-pixel output buffer flushed with dwordx4 stores; the
-// state machine itself only talks to LDS.
-constexpr int kQoiInPitch = 144, kQoiOutPx = 64;
+// blocks) and a 64-pixel output buffer; the state machine itself only talks to registers and LDS:
+//   * all three LDS arrays are dword-interleaved over the lanes ([slot][lane]), so the 64 lanes of a wave always hit 64
+//     different banks (a lane-major layout put every lane's pixel write on the same bank);
+//   * the next 5..8 stream bytes sit in a 64-bit register, topped up from a dword that was read from the window one
+//     top-up earlier, so no LDS latency is on the byte path;
+//   * the block after the window is already in flight (16 VGPRs) while the window is being consumed and is written to
+//     LDS when the older block has been used up, so the memory latency of the stream is hidden as well;
+//   * the pixel loop is uniform over the wave, so the output buffers fill up together and are flushed with dwordx4 stores.
+constexpr int kQoiWinDwords = 32, kQoiOutPx = 64;
+constexpr int kQoiSlack = GAMUT_HIP_QOI_SLACK;                // readable bytes guaranteed after every stream
 
 __global__ __launch_bounds__(64) void k_qoi_decode(const QoiItem* items, int n, const uint8_t* blob, uint8_t* out)
 {
     __shared__ uint32_t index[64 * 64];                       // [hash][lane]
-    __shared__ __attribute__((aligned(16))) uint8_t sh_in[64 * kQoiInPitch];
-    __shared__ __attribute__((aligned(16))) uint8_t sh_out[64 * kQoiOutPx * 4];
+    __shared__ uint32_t sh_in[kQoiWinDwords * 64];            // [dword of the window][lane]
+    __shared__ uint32_t sh_out[kQoiOutPx * 64];               // [pixel][lane], always r|g<<8|b<<16|a<<24
     const int lane = threadIdx.x;
     #pragma unroll 8
     for (int k = 0; k < 64; ++k) index[k * 64 + lane] = 0;    // memset(index, 0) :491  (a lane only touches its own column)
@@ -37,39 +44,67 @@ __global__ __launch_bounds__(64) void k_qoi_decode(const QoiItem* items, int n, 
     const bool rgba = it.channels == 4;
     const int bpp = rgba ? 4 : 3;
     uint8_t* pixels = out + it.out_off;
-    const uint8_t* stream = blob + it.begin + kQoiHeader;      // chunks start here; the host appends slack to every stream
-    uint8_t* win = sh_in + lane * kQoiInPitch;
-    uint8_t* obuf = sh_out + lane * (kQoiOutPx * 4);
+    const uint8_t* stream = blob + it.begin + kQoiHeader;      // chunks start here
+    uint32_t* win = sh_in + lane;
+    uint32_t* obuf = sh_out + lane;
     uint32_t r = 0, g = 0, b = 0, a = 255;                    // :492-495
-    uint32_t consumed = 0, fetched = 0;                       // bytes of the chunk area
     // bytes [14, size - 8) are chunks (p < chunks_len, :498); a chunk may read up to 4 bytes further (padding / slack)
     const int chunk_bytes = (int)it.size - kQoiPadding - kQoiHeader;
-    int run = 0, staged = 0;                                  // pixels waiting in obuf
-    uint32_t flushed = 0;                                     // pixels already written out
+    const uint32_t fetch_limit = (uint32_t)(chunk_bytes > 0 ? chunk_bytes : 0) + 5;   // no byte at or beyond this is ever decoded
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     struct __attribute__((packed, aligned(1))) AnyVec { u32x4 v; };               // 16 bytes at any address
-    auto fetch_half = [&]() {
-        const AnyVec* src = reinterpret_cast<const AnyVec*>(stream + fetched);
-        const u32x4 v0 = src[0].v, v1 = src[1].v, v2 = src[2].v, v3 = src[3].v;
-        u32x4* dst = reinterpret_cast<u32x4*>(win + (fetched & 127));
-        dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3;
+    u32x4 q0 = {0, 0, 0, 0}, q1 = q0, q2 = q0, q3 = q0;      // the block in flight
+    uint32_t fetched = 0, stored = 0, pulled = 0;            // stream bytes requested / in the window / read from the window
+    auto issue = [&]() {
+        if (fetched < fetch_limit) {
+            const AnyVec* src = reinterpret_cast<const AnyVec*>(stream + fetched);
+            q0 = src[0].v; q1 = src[1].v; q2 = src[2].v; q3 = src[3].v;
+        }
         fetched += 64;
     };
-    auto flush = [&](int npx) {                               // npx * bpp bytes from obuf to the image
+    auto commit = [&]() {
+        uint32_t* w = win + ((stored >> 2) & (kQoiWinDwords - 1)) * 64;
+        w[0 * 64] = q0.x; w[1 * 64] = q0.y; w[2 * 64] = q0.z; w[3 * 64] = q0.w;
+        w[4 * 64] = q1.x; w[5 * 64] = q1.y; w[6 * 64] = q1.z; w[7 * 64] = q1.w;
+        w[8 * 64] = q2.x; w[9 * 64] = q2.y; w[10 * 64] = q2.z; w[11 * 64] = q2.w;
+        w[12 * 64] = q3.x; w[13 * 64] = q3.y; w[14 * 64] = q3.z; w[15 * 64] = q3.w;
+        stored += 64;
+    };
+    issue(); commit(); issue(); commit(); issue();           // window = blocks 0 and 1, block 2 in flight
+    uint64_t bits = 0; int valid = 0; uint32_t ahead;         // `valid` bytes of the stream, lowest byte first; `ahead` = the dword after them
+    auto read_ahead = [&]() {
+        if (pulled + 64 == stored) { commit(); issue(); }    // the older block has been read completely: replace it
+        ahead = win[((pulled >> 2) & (kQoiWinDwords - 1)) * 64];
+        pulled += 4;
+    };
+    auto top_up = [&]() { bits |= (uint64_t)ahead << (8 * valid); valid += 4; read_ahead(); };
+    read_ahead(); top_up(); top_up();
+    uint32_t consumed = 0, flushed = 0;                       // bytes of the chunk area decoded; pixels already written out
+    int run = 0, staged = 0;                                  // pixels waiting in obuf
+    auto flush = [&](int npx) {                               // npx pixels from obuf to the image
         uint8_t* o = pixels + (size_t)flushed * bpp;
-        const int nbytes = npx * bpp;
         int k = 0;
-        for (; k + 16 <= nbytes; k += 16) reinterpret_cast<AnyVec*>(o + k)->v = *reinterpret_cast<const u32x4*>(obuf + k);
-        for (; k < nbytes; ++k) o[k] = obuf[k];
+        if (rgba) {
+            for (; k + 4 <= npx; k += 4) {
+                const u32x4 v = {obuf[k * 64], obuf[(k + 1) * 64], obuf[(k + 2) * 64], obuf[(k + 3) * 64]};
+                reinterpret_cast<AnyVec*>(o + k * 4)->v = v;
+            }
+            for (; k < npx; ++k) { const uint32_t v = obuf[k * 64]; o[k * 4] = (uint8_t)v; o[k * 4 + 1] = (uint8_t)(v >> 8); o[k * 4 + 2] = (uint8_t)(v >> 16); o[k * 4 + 3] = (uint8_t)(v >> 24); }
+        } else {
+            struct __attribute__((packed, aligned(1))) AnyU32 { uint32_t v; };
+            for (; k + 4 <= npx; k += 4) {                    // 4 pixels = 3 dwords
+                const uint32_t p0 = obuf[k * 64] & 0xFFFFFFu, p1 = obuf[(k + 1) * 64] & 0xFFFFFFu, p2 = obuf[(k + 2) * 64] & 0xFFFFFFu, p3 = obuf[(k + 3) * 64] & 0xFFFFFFu;
+                AnyU32* d = reinterpret_cast<AnyU32*>(o + k * 3);
+                d[0].v = p0 | p1 << 24; d[1].v = p1 >> 8 | p2 << 16; d[2].v = p2 >> 16 | p3 << 8;
+            }
+            for (; k < npx; ++k) { const uint32_t v = obuf[k * 64]; o[k * 3] = (uint8_t)v; o[k * 3 + 1] = (uint8_t)(v >> 8); o[k * 3 + 2] = (uint8_t)(v >> 16); }
+        }
         flushed += (uint32_t)npx;
     };
-    fetch_half(); fetch_half();
     for (uint32_t px = 0; px < it.npx; ++px) {
         if (run > 0) --run;
         else if ((int)consumed < chunk_bytes) {
-            if (fetched - consumed <= 64) fetch_half();       // a whole half is free again
-            const uint32_t c0 = consumed;
-            const uint32_t b1 = win[c0 & 127], x1 = win[(c0 + 1) & 127], x2 = win[(c0 + 2) & 127], x3 = win[(c0 + 3) & 127], x4 = win[(c0 + 4) & 127];
+            const uint32_t lo = (uint32_t)bits, b1 = lo & 255, x1 = (lo >> 8) & 255, x2 = (lo >> 16) & 255, x3 = lo >> 24, x4 = (uint32_t)(bits >> 32) & 255;
             int used = 1;
             if (b1 == 0xFE)      { r = x1; g = x2; b = x3; used = 4; }                                       // QOI_OP_RGB
             else if (b1 == 0xFF) { r = x1; g = x2; b = x3; a = x4; used = 5; }                              // QOI_OP_RGBA
@@ -80,10 +115,12 @@ __global__ __launch_bounds__(64) void k_qoi_decode(const QoiItem* items, int n, 
                 r = (r + vg - 8 + ((x1 >> 4) & 0x0f)) & 255; g = (g + vg) & 255; b = (b + vg - 8 + (x1 & 0x0f)) & 255;
             } else run = (int)(b1 & 0x3f);                                                                 // QOI_OP_RUN
             consumed += (uint32_t)used;
+            bits >>= 8 * used; valid -= used;
+            if (valid < 5) top_up();
+            if (valid < 5) top_up();                                                                        // only after a 5-byte chunk that left nothing
             index[((r * 3 + g * 5 + b * 7 + a * 11) & 63) * 64 + lane] = r | g << 8 | b << 16 | a << 24;    // QOI_COLOR_HASH :239-242
         }
-        if (rgba) *reinterpret_cast<uint32_t*>(obuf + staged * 4) = r | g << 8 | b << 16 | a << 24;
-        else { uint8_t* o = obuf + staged * 3; o[0] = (uint8_t)r; o[1] = (uint8_t)g; o[2] = (uint8_t)b; }
+        obuf[staged * 64] = r | g << 8 | b << 16 | a << 24;
         if (++staged == kQoiOutPx) { flush(kQoiOutPx); staged = 0; }
     }
     if (staged) flush(staged);
@@ -106,6 +143,17 @@ int read_header(const uint8_t* data, int size, gamut_hip_qoi_desc* d, int channe
 }
 
 
+// upload the item table and decode; returns when the decode has finished (the pageable item vector dies with the call)
+int launch_items(const std::vector<QoiItem>& items, uint8_t* d_items, const uint8_t* d_blob, uint8_t* d_out, hipStream_t stream)
+{
+    const int n = (int)items.size();
+    GAMUT_HIP_CHECK(hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(QoiItem), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_qoi_decode, dim3((n + 63) / 64), dim3(64), 0, stream, (const QoiItem*)d_items, n, d_blob, d_out);
+    if (int rc = launch_status("qoi_decode")) return rc;
+    GAMUT_HIP_CHECK(hipStreamSynchronize(stream));
+    return GAMUT_HIP_OK;
+}
+
 int decode_batch(const uint8_t* const* data, const int* size, int count, int channels, const int64_t* out_offset, uint8_t* d_out,
                  gamut_hip_qoi_desc* descs, int* status_host, hipStream_t stream)
 {
@@ -119,19 +167,15 @@ int decode_batch(const uint8_t* const* data, const int* size, int count, int cha
         it.npx = descs[i].width * descs[i].height; it.channels = channels ? channels : descs[i].channels;
         items.push_back(it);
         blob.insert(blob.end(), data[i], data[i] + size[i]);
-        blob.insert(blob.end(), 160, (uint8_t)0);               // the lane's reader fetches up to two 64-byte halves ahead
+        blob.insert(blob.end(), kQoiSlack, (uint8_t)0);         // the lane's reader fetches whole 64-byte blocks
     }
     if (!items.empty()) {
         const size_t o_blob = (items.size() * sizeof(QoiItem) + 255) & ~(size_t)255, total = o_blob + blob.size();
         static thread_local DeviceScratch staging;
         uint8_t* d = (uint8_t*)staging.get(total);
         if (!d) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "qoi: device staging allocation of %zu bytes failed", total);
-        GAMUT_HIP_CHECK(hipMemcpyAsync(d, items.data(), items.size() * sizeof(QoiItem), hipMemcpyHostToDevice, stream));
         GAMUT_HIP_CHECK(hipMemcpyAsync(d + o_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, stream));
-        const int n = (int)items.size();
-        hipLaunchKernelGGL(k_qoi_decode, dim3((n + 63) / 64), dim3(64), 0, stream, (const QoiItem*)d, n, (const uint8_t*)(d + o_blob), d_out);
-        if (int rc = launch_status("qoi_decode")) return rc;
-        GAMUT_HIP_CHECK(hipStreamSynchronize(stream));         // the pageable staging vectors die with this call
+        if (int rc = launch_items(items, d, d + o_blob, d_out, stream)) return rc;
     }
     if (first != GAMUT_HIP_OK) return set_error(first, "image %d: qoi: bad header or arguments", first_idx);
     return GAMUT_HIP_OK;
@@ -165,6 +209,38 @@ int gamut_hip_qoi_decode_batch_device(const uint8_t* const* data, const int* siz
         return decode_batch(data, size, count, channels, out_offset, out, descs, status_host, pick_stream(stream));
     } catch (...) {
         return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "qoi_decode_batch_device: out of host memory");
+    }
+}
+
+int gamut_hip_qoi_decode_resident_device(const uint8_t* blob, int64_t blob_len, const int64_t* begin, const int* size,
+                                         const gamut_hip_qoi_desc* descs, int count, int channels, const int64_t* out_offset,
+                                         uint8_t* out, void* stream)
+{
+    clear_error();
+    if (count < 0 || (channels != 0 && channels != 3 && channels != 4) || (count > 0 && (!blob || !begin || !size || !descs || !out_offset || !out)))
+        return set_error(GAMUT_HIP_ERR_INVALID_ARG, "qoi_decode_resident_device: bad arguments");
+    if (count == 0) return GAMUT_HIP_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return set_error(GAMUT_HIP_ERR_NO_DEVICE, "no HIP device available (libgamut_hip has no CPU fallback)");
+    try {
+        std::vector<QoiItem> items((size_t)count);
+        for (int i = 0; i < count; ++i) {
+            const gamut_hip_qoi_desc& d = descs[i];
+            if (size[i] < kQoiHeader + kQoiPadding || begin[i] < 0 || begin[i] + (int64_t)size[i] + GAMUT_HIP_QOI_SLACK > blob_len)
+                return set_error(GAMUT_HIP_ERR_INVALID_ARG, "qoi_decode_resident_device: stream %d (with its %d slack bytes) is outside the blob", i, GAMUT_HIP_QOI_SLACK);
+            if (d.width == 0 || d.height == 0 || d.channels < 3 || d.channels > 4 || d.height >= kQoiPixelsMax / d.width)
+                return set_error(GAMUT_HIP_ERR_DECODE, "qoi_decode_resident_device: stream %d: bad header", i);
+            QoiItem it{}; it.begin = (uint64_t)begin[i]; it.out_off = out_offset[i]; it.size = (uint32_t)size[i];
+            it.npx = d.width * d.height; it.channels = channels ? channels : d.channels;
+            items[(size_t)i] = it;
+        }
+        static thread_local DeviceScratch table;
+        uint8_t* d_items = (uint8_t*)table.get(items.size() * sizeof(QoiItem));
+        if (!d_items) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "qoi: device allocation of the item table failed");
+        return launch_items(items, d_items, blob, out, pick_stream(stream));
+    } catch (...) {
+        return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "qoi_decode_resident_device: out of host memory");
     }
 }
 

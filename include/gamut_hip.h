@@ -244,6 +244,13 @@ int   gamut_hip_qoi_read_header(const void* data, int size, gamut_hip_qoi_desc* 
  * receives the headers, status_host[i] (may be NULL) the per-file header status.  Returns when the decode has finished. */
 int   gamut_hip_qoi_decode_batch_device(const uint8_t* const* data, const int* size, int count, int channels,
                                         const int64_t* out_offset, uint8_t* out, gamut_hip_qoi_desc* descs, int* status_host, void* stream);
+/* the same decode for files that are already resident in HBM (a device-side file cache; bench.py's mixed workload): file i
+ * is blob[begin[i] .. begin[i] + size[i]) and must be followed by GAMUT_HIP_QOI_SLACK readable bytes inside the blob (the
+ * lanes read whole 64-byte blocks); begin / size / descs (from gamut_hip_qoi_read_header) / out_offset are host arrays. */
+#define GAMUT_HIP_QOI_SLACK 160
+int   gamut_hip_qoi_decode_resident_device(const uint8_t* blob, int64_t blob_len, const int64_t* begin, const int* size,
+                                           const gamut_hip_qoi_desc* descs, int count, int channels, const int64_t* out_offset,
+                                           uint8_t* out, void* stream);
 
 #ifdef __cplusplus
 }

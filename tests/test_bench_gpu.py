@@ -39,3 +39,12 @@ def test_two_ranks_one_line(hip):
               "--master-port", "29541", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16"],
              env={"GAMUT_BENCH_BACKEND": "gloo"})
     assert r["n_gpus"] == 2 and r["cpu_baseline"] is None and r["value"] > 0
+
+
+def test_mixed_workload_line(hip):
+    """BASELINE.json configs[4] on one rank: JPEG / PNG / QOI by image index, per-format breakdown, parity checked inside"""
+    r = _run([sys.executable, "bench.py", "--workload", "mixed", "--steps", "2", "--warmup", "1", "--batch", "7", "--width", "320", "--height", "200",
+              "--cpu-seconds", "1"])
+    pf = r["config"]["per_format"]
+    assert [pf[k]["images"] for k in ("jpeg", "png", "qoi")] == [3, 2, 2] and all(pf[k]["ms"] > 0 for k in pf)
+    assert r["value"] > 0 and r["cpu_baseline"]["value"] > 0

@@ -255,6 +255,9 @@ def test_argument_validation_needs_no_device():
     assert L.gamut_hip_png_decode_batch_device(None, None, 0, 0, 8, None, None, None, None, 1, None) == _capi.OK
     assert L.gamut_hip_qoi_decode_batch_device(None, None, 3, 4, None, None, None, None, None) == _capi.ERR_INVALID_ARG
     assert L.gamut_hip_qoi_decode_batch_device(None, None, 0, 4, None, None, None, None, None) == _capi.OK
+    assert L.gamut_hip_qoi_decode_resident_device(None, 0, None, None, None, 2, 4, None, None, None) == _capi.ERR_INVALID_ARG
+    assert L.gamut_hip_qoi_decode_resident_device(None, 0, None, None, None, 0, 7, None, None, None) == _capi.ERR_INVALID_ARG
+    assert L.gamut_hip_qoi_decode_resident_device(None, 0, None, None, None, 0, 4, None, None, None) == _capi.OK
     assert L.gamut_hip_jpeg_decode_coeffs_batch(None, None, 0, None, None, 4) == _capi.OK
     hd = _capi.PngInfo()
     assert L.gamut_hip_png_read_header(p, 64, C.byref(hd)) == _capi.ERR_DECODE and L.gamut_hip_png_read_header(p, 64, None) == _capi.ERR_INVALID_ARG

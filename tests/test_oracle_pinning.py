@@ -398,6 +398,17 @@ def _qoi_test_images():
     return out
 
 
+def test_synth_qoi_encoder_equals_spec_encoder():
+    """bench.py's vectorised QOI encoder (gamut_amd/synth.py) emits byte for byte what the sequential specification encoder
+    of gen.py emits, runs longer than 62 and RUN ops at the very end included"""
+    from gamut_amd import synth
+    rng = np.random.default_rng(9)
+    imgs = _qoi_test_images() + [np.zeros((3, 200, 3), np.uint8), np.repeat(rng.integers(0, 256, (4, 5, 4), dtype=np.uint8), 70, axis=1),
+                                 rng.integers(0, 4, (30, 40, 3), dtype=np.uint8) * 60]
+    for a in imgs:
+        assert synth.qoi_encode(a, 1) == gen.qoi_encode(a, 1), a.shape
+
+
 def test_qoi_oracle_roundtrip_and_pillow():
     """QOI is lossless and fully specified: streams from the independent spec-based encoder in gen.py must decode to the
     source pixels, and to what Pillow's QOI decoder makes of them; channel forcing follows qoi.d:536-545."""

@@ -48,6 +48,42 @@ def test_qoi_drop_in_and_batch(hip):
             assert np.array_equal(host[offs[i]:offs[i] + nbytes[i]], e[0].reshape(-1)), i
 
 
+def test_qoi_resident_streams(hip):
+    """files already in HBM (gamut_hip_qoi_decode_resident_device): same pixels as the host-pointer batch; bounds are checked"""
+    from gamut_amd import synth
+    rng = np.random.default_rng(5)
+    imgs = _qoi_test_images()[2:] + [rng.integers(0, 256, (40, 300, 3), dtype=np.uint8), np.zeros((70, 90, 4), np.uint8)]
+    files = [synth.qoi_encode(a) for a in imgs]
+    assert files[0] == gen.qoi_encode(imgs[0])                       # the vectorised encoder = the specification encoder
+    n = len(files)
+    begin, pos, parts = [], 3, [bytes(3)]                            # an odd base offset: streams have no alignment
+    for f in files:
+        begin.append(pos); parts += [f, bytes(160)]; pos += len(f) + 160
+    hblob = np.frombuffer(b"".join(parts), np.uint8).copy()
+    blob = hip.gamut_hip_device_malloc(hblob.size)
+    _capi.check(hip.gamut_hip_memcpy_h2d(blob, hblob.ctypes.data, hblob.size, None))
+    descs = (_capi.QoiDesc * n)()
+    for i, f in enumerate(files):
+        _capi.check(hip.gamut_hip_qoi_read_header(f, len(f), C.byref(descs[i])))
+    nbytes = [a.shape[0] * a.shape[1] * 4 for a in imgs]
+    offs = np.concatenate([[0], np.cumsum(nbytes)[:-1]]).astype(np.int64)
+    out = hip.gamut_hip_device_malloc(int(sum(nbytes)))
+    b = np.array(begin, np.int64); sz = np.array([len(f) for f in files], np.int32)
+    args = lambda blob_len: (blob, blob_len, b.ctypes.data_as(C.POINTER(C.c_int64)), sz.ctypes.data_as(C.POINTER(C.c_int)), descs, n, 4,
+                             offs.ctypes.data_as(C.POINTER(C.c_int64)), out, None)
+    _capi.check(hip.gamut_hip_stream_synchronize(None))
+    _capi.check(hip.gamut_hip_qoi_decode_resident_device(*args(hblob.size)))
+    host = np.empty(int(sum(nbytes)), np.uint8)
+    _capi.check(hip.gamut_hip_memcpy_d2h(host.ctypes.data, out, host.nbytes, None))
+    _capi.check(hip.gamut_hip_stream_synchronize(None))
+    for i, f in enumerate(files):
+        exp = O.qoi_decode(f, 4)[0].reshape(-1)
+        assert np.array_equal(host[offs[i]:offs[i] + nbytes[i]], exp), i
+    assert hip.gamut_hip_qoi_decode_resident_device(*args(hblob.size - 1)) == _capi.ERR_INVALID_ARG      # last stream's slack is cut
+    assert hip.gamut_hip_qoi_decode_resident_device(*args(hblob.size)[:6], 5, *args(0)[7:]) == _capi.ERR_INVALID_ARG
+    hip.gamut_hip_device_free(blob); hip.gamut_hip_device_free(out)
+
+
 def test_image_load_qoi(hip):
     """Image.loadFromMemory on a QOI file (plugins/qoi.d:47-141): rgb8 / rgba8 as in the file, then convertTo per load flags"""
     from gamut_amd.image import Image

@@ -20,7 +20,7 @@
 // type pair so the WIDER side of the unit is whole dwords and >= 16 B (one
 // dwordx4 per lane, lane-contiguous => fully coalesced 1 KiB per wave
 // instruction); the narrower side moves as exact dword / halfword / byte pieces
-// (unit_pixels below).  Units are distributed grid-stride over <= 6 blocks/CU.
+// (unit_pixels below).  The grid covers the units once, two per thread (see CONVERT_UNROLL).
 #include "common.hpp"
 #include <utility>
 
@@ -59,7 +59,7 @@ struct __attribute__((packed)) AnyU16 { uint16_t v; };
 
 // ---- unit load / store -----------------------------------------------------
 #ifndef CONVERT_NT            // 1: nontemporal stores, 2: nontemporal loads too (tuning knob, tools/variant.sh)
-#define CONVERT_NT 0
+#define CONVERT_NT 2
 #endif
 typedef u32 u32x4v __attribute__((ext_vector_type(4)));
 typedef u32 u32x2v __attribute__((ext_vector_type(2)));
@@ -77,12 +77,13 @@ __device__ __forceinline__ void load_unit(const uint8_t* p, u32 (&w)[(BYTES + 3)
     } else if constexpr (V == 8) {
         #pragma unroll
         for (int i = 0; i < BYTES / 8; ++i) {
-            const uint2 v = reinterpret_cast<const uint2*>(p)[i];
+            u32x2v v;
+            if (CONVERT_NT >= 2) v = __builtin_nontemporal_load(reinterpret_cast<const u32x2v*>(p) + i); else v = reinterpret_cast<const u32x2v*>(p)[i];
             w[2*i] = v.x; w[2*i+1] = v.y;
         }
     } else if constexpr (V == 4) {
         #pragma unroll
-        for (int i = 0; i < BYTES / 4; ++i) w[i] = reinterpret_cast<const u32*>(p)[i];
+        for (int i = 0; i < BYTES / 4; ++i) w[i] = (CONVERT_NT >= 2) ? __builtin_nontemporal_load(reinterpret_cast<const u32*>(p) + i) : reinterpret_cast<const u32*>(p)[i];
     } else {                                                   // the narrow side of an expanding / shrinking pair: exact pieces
         #pragma unroll
         for (int i = 0; i < BYTES / 4; ++i) w[i] = reinterpret_cast<const AnyU32*>(p)[i].v;
@@ -110,7 +111,7 @@ __device__ __forceinline__ void store_unit(uint8_t* p, const u32 (&w)[(BYTES + 3
         }
     } else if constexpr (V == 4) {
         #pragma unroll
-        for (int i = 0; i < BYTES / 4; ++i) reinterpret_cast<u32*>(p)[i] = w[i];
+        for (int i = 0; i < BYTES / 4; ++i) { if (CONVERT_NT >= 1) __builtin_nontemporal_store(w[i], reinterpret_cast<u32*>(p) + i); else reinterpret_cast<u32*>(p)[i] = w[i]; }
     } else {
         #pragma unroll
         for (int i = 0; i < BYTES / 4; ++i) reinterpret_cast<AnyU32*>(p)[i].v = w[i];
@@ -272,16 +273,24 @@ __device__ __forceinline__ void convert_pixel_bytes(const uint8_t* s, uint8_t* d
     for (int i = 0; i < DS; ++i) d[i] = (uint8_t)(out[i >> 2] >> ((i & 3) * 8));
 }
 
+// Launch shape (tools/copy_probe.hip, tools/conv_var.sh): on MI355X a streaming kernel whose grid covers the data once -- every
+// thread a fixed, small number of units, blocks retired in address order -- runs a plain copy at 6.3 TB/s, the same loop in a
+// persistent grid-stride grid at 5.0-5.7; the conversions follow (4.8 -> 5.3-6.5 TB/s).  Two units per thread and nontemporal
+// loads and stores were the best of {1, 2, 4, 8} x {plain, nt stores, nt both} over nine pairs.
+#ifndef CONVERT_UNROLL
+#define CONVERT_UNROLL 2
+#endif
 constexpr int kThreads = 256;
-constexpr int kUnroll  = 4;
+constexpr int kUnroll  = CONVERT_UNROLL;
 
 template <int S, int D>
 __global__ __launch_bounds__(kThreads) void k_convert_vec(ConvArgs a)
 {
     constexpr int G  = unit_pixels(PT<S>::size, PT<D>::size);
     constexpr int SB = G * PT<S>::size, DB = G * PT<D>::size;
-    const int64_t stride = (int64_t)gridDim.x * kThreads;
-    for (int64_t base = (int64_t)blockIdx.x * kThreads + threadIdx.x; base < a.total; base += stride * kUnroll) {
+    constexpr int64_t stride = kThreads;
+    {
+        const int64_t base = (int64_t)blockIdx.x * (kThreads * kUnroll) + threadIdx.x;      // a block owns kUnroll * 256 consecutive units
         u32 in[kUnroll][(SB + 3) / 4];
         const uint8_t* sp[kUnroll]; uint8_t* dp[kUnroll];
         u32 uidx[kUnroll]; bool live[kUnroll];
@@ -349,25 +358,12 @@ __global__ __launch_bounds__(kThreads) void k_copy_rows(ConvArgs a, u32 row_byte
     }
 }
 
-inline int grid_for(int64_t work_items, int device_cus)
+inline int grid_for(int64_t work_items)                  // one 256-thread block per 256 items: the grid covers the data once
 {
     int64_t blocks = (work_items + kThreads - 1) / kThreads;
-    static const int per_cu = getenv("GAMUT_CONVERT_BLOCKS_PER_CU") ? atoi(getenv("GAMUT_CONVERT_BLOCKS_PER_CU")) : 6;
-    const int64_t cap = (int64_t)device_cus * per_cu;     // 6 x 256-thread blocks per CU (swept 2..12 on MI355X: flat within noise above 4; tuning knob)
-    if (blocks > cap) blocks = cap;
+    if (blocks > 0x7FFFFFFFLL) blocks = 0x7FFFFFFFLL;    // (the kernels with a loop then go round again; 32 GiB images stay below)
     if (blocks < 1) blocks = 1;
     return (int)blocks;
-}
-
-int device_cus()
-{
-    static thread_local int cus = 0;
-    if (!cus) {
-        int dev = 0; hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
 }
 
 inline bool aligned(const void* p, int64_t pitch, int64_t layer, int rows, int layers, int a)
@@ -397,12 +393,12 @@ int launch_pair(ConvArgs a, int width, int height, int layers, hipStream_t strea
         a.upr = a.full_units + (a.tail_px ? 1 : 0);
         a.total = (int64_t)rows * a.upr;
         if (a.total == 0) return GAMUT_HIP_OK;
-        const int grid = grid_for((a.total + kUnroll - 1) / kUnroll, device_cus());
+        const int grid = grid_for((a.total + kUnroll - 1) / kUnroll);
         hipLaunchKernelGGL((k_convert_vec<S, D>), dim3(grid), dim3(kThreads), 0, stream, a);
     } else {
         const int64_t total = (int64_t)rows * w;
         if (total == 0) return GAMUT_HIP_OK;
-        hipLaunchKernelGGL((k_convert_bytes<S, D>), dim3(grid_for(total, device_cus())), dim3(kThreads), 0, stream, a, (u32)w);
+        hipLaunchKernelGGL((k_convert_bytes<S, D>), dim3(grid_for(total)), dim3(kThreads), 0, stream, a, (u32)w);
     }
     return launch_status("scanlines_convert");
 }
@@ -458,7 +454,7 @@ int convert_device(int srcType, const void* src, int64_t srcPitch, int64_t srcLa
         const int vec = (aligned(src, srcPitch, srcLayerOffset, (int)rows, layers_eff, 16) &&
                          aligned(dst, dstPitch, dstLayerOffset, (int)rows, layers_eff, 16)) ? 16 : 1;
         const int64_t total = rows * ((rb + vec - 1) / vec);
-        hipLaunchKernelGGL(k_copy_rows, dim3(grid_for(total, device_cus())), dim3(kThreads), 0, stream, a, rb, vec);
+        hipLaunchKernelGGL(k_copy_rows, dim3(grid_for(total)), dim3(kThreads), 0, stream, a, rb, vec);
         return launch_status("scanlines_copy");
     }
     return dispatch_src(srcType, dstType, std::make_integer_sequence<int, GAMUT_PIXEL_COUNT>{}, a, width, height, layers, stream);

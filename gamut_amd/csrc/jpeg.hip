@@ -83,6 +83,16 @@ __device__ __forceinline__ void map_half(const MapCoef& c, i32 pass0, i32 pass1,
     o[3] = D4(c.b[0], u1, c.b[1], u3, c.b[2], u5, c.b[3], u7);
 }
 
+#ifndef JPEG_NT_LOADS             // coefficients are read exactly once: nontemporal loads (tuning knob, tools/variant.sh)
+#define JPEG_NT_LOADS 0
+#endif
+__device__ __forceinline__ uint4 load_coeffs16(const int16_t* p)
+{
+    typedef u32 u32x4n __attribute__((ext_vector_type(4)));
+    if (JPEG_NT_LOADS) { const u32x4n v = __builtin_nontemporal_load(reinterpret_cast<const u32x4n*>(p)); return make_uint4(v.x, v.y, v.z, v.w); }
+    return *reinterpret_cast<const uint4*>(p);
+}
+
 template <int OC>                // output components: 4 = rgba8, 3 = rgb8, 1 = l8 (grey of the RGB result, jpegload.d:3786-3792)
 __global__ __launch_bounds__(256) void k_jpeg_h2v2(JpegArgs a)
 {
@@ -112,8 +122,8 @@ __global__ __launch_bounds__(256) void k_jpeg_h2v2(JpegArgs a)
 
     // P0: loads (issued together; 16 B per lane, lane-contiguous inside each MCU)
     uint4 yrow = make_uint4(0, 0, 0, 0), crow = make_uint4(0, 0, 0, 0);
-    if (mcu_live)  yrow = *reinterpret_cast<const uint4*>(cbase + (u32)(m * 384 + q * 64 + r * 8));
-    if (cmcu_live) crow = *reinterpret_cast<const uint4*>(cbase + (u32)((cbk >> 1) * 384 + 256 + (cbk & 1) * 64 + k * 8));
+    if (mcu_live)  yrow = load_coeffs16(cbase + (u32)(m * 384 + q * 64 + r * 8));
+    if (cmcu_live) crow = load_coeffs16(cbase + (u32)((cbk >> 1) * 384 + 256 + (cbk & 1) * 64 + k * 8));
 
     // P1a: luma pass 1 (row r of block b) -> T1[b][r][0..7]
     {

@@ -376,6 +376,9 @@ __global__ __launch_bounds__(W * 64) void k_png_defilter(DefilterArgs a)
 constexpr int TT = 8;
 constexpr int RING = 16;                          // pieces per row: a finished-but-unwritten group (<= 7 pieces) + the tile in flight (8)
 constexpr int ROW_PITCH = RING * 16;              // 256 B: lane j's slot (T - j) % 16 => ds_read_b128 conflict-free across 8 consecutive lanes
+#ifndef PNG_NT_LOADS             // the filtered stream is read exactly once (tuning knob, tools/variant.sh)
+#define PNG_NT_LOADS 0
+#endif
 #ifndef PNG_NT_STORES
 #define PNG_NT_STORES 1
 #endif
@@ -427,8 +430,14 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
             it = it < 0 ? 0 : it;
             // full pieces by index; the ragged last piece (and anything past it, unused) = the last 16 bytes of the row
             const int64_t off = (u32)it < full_iters ? (int64_t)it * 16 : (int64_t)a.wb - 16;
+#if PNG_NT_LOADS
+            typedef u32x4 u32x4_unaligned __attribute__((aligned(1)));
+            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_unaligned*>(craw + (int64_t)r * (a.wb + 1) + off));
+            pre[k] = make_uint4(v.x, v.y, v.z, v.w);
+#else
             const PackedU32* q = reinterpret_cast<const PackedU32*>(craw + (int64_t)r * (a.wb + 1) + off);
             pre[k] = make_uint4(q[0].v, q[1].v, q[2].v, q[3].v);
+#endif
         }
     };
     u32x4 dset[PF];
@@ -654,7 +663,8 @@ __global__ __launch_bounds__(256) void k_png_adam7_scatter(const uint8_t* pass, 
     }
 }
 
-inline int blocks_for(int64_t n) { int64_t b = (n + 255) / 256; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
+// the grid covers the items once (a persistent grid-stride grid streams ~15 % slower on this part: tools/copy_probe.hip)
+inline int blocks_for(int64_t n) { int64_t b = (n + 255) / 256; return (int)(b > 0x7FFFFFFFLL ? 0x7FFFFFFFLL : (b < 1 ? 1 : b)); }
 
 
 } // namespace

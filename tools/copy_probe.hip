@@ -1,0 +1,102 @@
+// copy_probe.hip -- what does a streaming copy reach on this part, and with which launch shape?  (the ceiling every kernel of
+// the path is measured against: DESIGN.md section 3).  hipcc --offload-arch=gfx950 -O3 tools/copy_probe.hip -o tools/bin/copy_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// grid-stride
+template <int T> __global__ __launch_bounds__(T) void k_stride(const u32x4* __restrict__ s, u32x4* __restrict__ d, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * T;
+    for (size_t i = (size_t)blockIdx.x * T + threadIdx.x; i < n; i += stride) d[i] = s[i];
+}
+// one shot: a block owns U * T consecutive 16-byte units, all loads issued before the stores.  NT: 0 plain, 1 nt loads, 2 nt stores, 3 both
+// XCD: remap the block index so that each XCD (block % 8) walks one contiguous eighth of the buffer
+template <int T, int U, int NT, int XCD> __global__ __launch_bounds__(T) void k_shot(const u32x4* __restrict__ s, u32x4* __restrict__ d, size_t n)
+{
+    size_t b = blockIdx.x;
+    if (XCD) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
+    const size_t base = b * (size_t)(U * T) + threadIdx.x;
+    u32x4 v[U];
+    #pragma unroll
+    for (int k = 0; k < U; ++k) { const size_t i = base + (size_t)k * T; if (i < n) v[k] = (NT & 1) ? __builtin_nontemporal_load(s + i) : s[i]; }
+    #pragma unroll
+    for (int k = 0; k < U; ++k) { const size_t i = base + (size_t)k * T; if (i < n) { if (NT & 2) __builtin_nontemporal_store(v[k], d + i); else d[i] = v[k]; } }
+}
+// persistent blocks, each iteration U units in flight
+template <int T, int U, int NT> __global__ __launch_bounds__(T) void k_persist(const u32x4* __restrict__ s, u32x4* __restrict__ d, size_t n)
+{
+    const size_t step = (size_t)gridDim.x * (U * T);
+    for (size_t base = (size_t)blockIdx.x * (U * T) + threadIdx.x; base < n; base += step) {
+        u32x4 v[U];
+        #pragma unroll
+        for (int k = 0; k < U; ++k) { const size_t i = base + (size_t)k * T; if (i < n) v[k] = (NT & 1) ? __builtin_nontemporal_load(s + i) : s[i]; }
+        #pragma unroll
+        for (int k = 0; k < U; ++k) { const size_t i = base + (size_t)k * T; if (i < n) { if (NT & 2) __builtin_nontemporal_store(v[k], d + i); else d[i] = v[k]; } }
+    }
+}
+template <int T, int U> __global__ __launch_bounds__(T) void k_read(const u32x4* __restrict__ s, uint32_t* __restrict__ d, size_t n)
+{
+    const size_t base = (size_t)blockIdx.x * (U * T) + threadIdx.x;
+    uint32_t acc = 0;
+    #pragma unroll
+    for (int k = 0; k < U; ++k) { const size_t i = base + (size_t)k * T; if (i < n) { const u32x4 v = s[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; } }
+    if (acc == 0x12345678u) d[0] = acc;
+}
+template <int T, int U, int NT> __global__ __launch_bounds__(T) void k_write(u32x4* __restrict__ d, size_t n)
+{
+    const size_t base = (size_t)blockIdx.x * (U * T) + threadIdx.x;
+    const u32x4 v = {1u, 2u, 3u, (uint32_t)threadIdx.x};
+    #pragma unroll
+    for (int k = 0; k < U; ++k) { const size_t i = base + (size_t)k * T; if (i < n) { if (NT) __builtin_nontemporal_store(v, d + i); else d[i] = v; } }
+}
+
+template <typename F> float time_ms(F f, int reps)
+{
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    f(); hipDeviceSynchronize();
+    hipEventRecord(a);
+    for (int i = 0; i < reps; ++i) f();
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms = 0; hipEventElapsedTime(&ms, a, b);
+    return ms / reps;
+}
+
+int main()
+{
+    hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
+    const int cus = p.multiProcessorCount;
+    const size_t bytes = (size_t)4 << 30, n = bytes / 16;
+    void *s, *d; CK(hipMalloc(&s, bytes)); CK(hipMalloc(&d, bytes));
+    CK(hipMemset(s, 1, bytes)); CK(hipMemset(d, 2, bytes));
+    const int R = 5;
+    auto report = [&](const char* name, float ms, double moved) { printf("%-44s %7.3f ms  %7.1f GB/s\n", name, ms, moved / ms * 1e-6); fflush(stdout); };
+    char name[96];
+    report("hipMemcpyDtoD", time_ms([&] { (void)hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, 0); }, R), 2.0 * bytes);
+    for (int bpc : {1, 2, 4, 8}) {
+        snprintf(name, sizeof name, "grid-stride T=256, %d blocks/CU", bpc);
+        report(name, time_ms([&] { hipLaunchKernelGGL(k_stride<256>, dim3(cus * bpc), dim3(256), 0, 0, (const u32x4*)s, (u32x4*)d, n); }, R), 2.0 * bytes);
+    }
+    for (int bpc : {1, 2}) {
+        snprintf(name, sizeof name, "grid-stride T=1024, %d blocks/CU", bpc);
+        report(name, time_ms([&] { hipLaunchKernelGGL(k_stride<1024>, dim3(cus * bpc), dim3(1024), 0, 0, (const u32x4*)s, (u32x4*)d, n); }, R), 2.0 * bytes);
+    }
+#define SHOT(T, U, NT, X) do { snprintf(name, sizeof name, "one-shot T=%d U=%d nt=%d xcd=%d", T, U, NT, X); \
+        const unsigned g = (unsigned)((n + (size_t)(T) * (U) - 1) / ((size_t)(T) * (U))); \
+        report(name, time_ms([&] { hipLaunchKernelGGL((k_shot<T, U, NT, X>), dim3(g), dim3(T), 0, 0, (const u32x4*)s, (u32x4*)d, n); }, R), 2.0 * bytes); } while (0)
+    SHOT(256, 1, 0, 0); SHOT(256, 2, 0, 0); SHOT(256, 4, 0, 0); SHOT(256, 8, 0, 0); SHOT(512, 4, 0, 0); SHOT(1024, 4, 0, 0); SHOT(64, 8, 0, 0);
+    SHOT(256, 4, 1, 0); SHOT(256, 4, 2, 0); SHOT(256, 4, 3, 0); SHOT(256, 8, 3, 0);
+    SHOT(256, 4, 0, 1); SHOT(256, 4, 3, 1);
+#define PERS(T, U, NT, BPC) do { snprintf(name, sizeof name, "persistent T=%d U=%d nt=%d, %d blocks/CU", T, U, NT, BPC); \
+        report(name, time_ms([&] { hipLaunchKernelGGL((k_persist<T, U, NT>), dim3(cus * (BPC)), dim3(T), 0, 0, (const u32x4*)s, (u32x4*)d, n); }, R), 2.0 * bytes); } while (0)
+    PERS(256, 4, 0, 2); PERS(256, 4, 0, 4); PERS(256, 4, 0, 8); PERS(256, 8, 0, 2); PERS(256, 4, 3, 4); PERS(512, 4, 0, 2); PERS(256, 2, 0, 8);
+    {
+        const unsigned g = (unsigned)((n + 1023) / 1024);
+        report("read only  T=256 U=4", time_ms([&] { hipLaunchKernelGGL((k_read<256, 4>), dim3(g), dim3(256), 0, 0, (const u32x4*)s, (uint32_t*)d, n); }, R), 1.0 * bytes);
+        report("write only T=256 U=4", time_ms([&] { hipLaunchKernelGGL((k_write<256, 4, 0>), dim3(g), dim3(256), 0, 0, (u32x4*)d, n); }, R), 1.0 * bytes);
+        report("write only T=256 U=4 nt", time_ms([&] { hipLaunchKernelGGL((k_write<256, 4, 1>), dim3(g), dim3(256), 0, 0, (u32x4*)d, n); }, R), 1.0 * bytes);
+    }
+    return 0;
+}

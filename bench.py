@@ -89,6 +89,7 @@ def main():
     w, h, B = args.width, args.height, args.batch
     wl = args.workload
     check = None
+    _host = {}                                                   # host copies of the cpu_baseline sample (made once, shared by the threads)
     if wl == "jpeg" or wl.startswith("jpeg:"):
         jp = wl.split(":")                                       # jpeg[:out_comps[:scan_type]]
         oc = int(jp[1]) if len(jp) > 1 else 4                    # 4 = rgba8 (headline), 3 = rgb8, 1 = l8
@@ -118,7 +119,9 @@ def main():
 
         def cpu_leg(seconds):
             import oracle_lib as O
-            host = [coeffs[i].cpu().numpy() for i in range(min(B, 64))]
+            if "h" not in _host:
+                _host["h"] = [coeffs[i].cpu().numpy() for i in range(min(B, 64))]
+            host = _host["h"]
             O.jpeg_reconstruct(w, h, comps_in, st, host[0], None, oc)             # warm
             n, t0 = 0, time.perf_counter()
             while time.perf_counter() - t0 < seconds:
@@ -164,7 +167,9 @@ def main():
 
         def cpu_leg(seconds):
             rows = 256
-            a = src[0].view(torch.uint8)[:rows * sp].cpu().numpy()
+            if "h" not in _host:
+                _host["h"] = src[0].view(torch.uint8)[:rows * sp].cpu().numpy()
+            a = _host["h"]
             n, t0 = 0, time.perf_counter()
             while time.perf_counter() - t0 < seconds:
                 O.scanlines_convert(st, a, dt_, w, rows)
@@ -208,7 +213,9 @@ def main():
                 raise SystemExit("PARITY FAILURE vs oracle")
 
         def cpu_leg(seconds):
-            host = [raw[i].cpu().numpy() for i in range(min(B, 8))]
+            if "h" not in _host:
+                _host["h"] = [raw[i].cpu().numpy() for i in range(min(B, 8))]
+            host = _host["h"]
             n, t0 = 0, time.perf_counter()
             while time.perf_counter() - t0 < seconds:
                 O.png_create_image_raw(host[n % len(host)], ch, on, w, h, 8, {1: 0, 2: 4, 3: 2, 4: 6}[ch])
@@ -289,7 +296,9 @@ def main():
                     raise SystemExit("PARITY FAILURE (QOI vs oracle)")
 
         def cpu_leg(seconds):
-            cj = coeffs[0].cpu().numpy(); rp = raw[0].cpu().numpy() if npn else None
+            if "h" not in _host:
+                _host["h"] = (coeffs[0].cpu().numpy(), raw[0].cpu().numpy() if npn else None)
+            cj, rp = _host["h"]
             n, t0 = 0, time.perf_counter()
             while time.perf_counter() - t0 < seconds:
                 k = n % 3
@@ -360,8 +369,19 @@ def main():
                 res["config"]["per_format"][k] = {"images": cnt, "ms": round(ms, 4), "Mpx/s": round(cnt * w * h / ms / 1e3, 1) if ms > 0 else None,
                                                  "GB/s": round(fmt_bytes[k] / ms / 1e6, 1) if ms > 0 else None}
         if world == 1 and not args.no_cpu:
-            v, sample = cpu_leg(args.cpu_seconds)
+            # (i) one thread -- how the reference measures itself (examples/qoix/source/main.d:146-152); (ii) every host core, one
+            # image per thread at a time (the oracle is C called through ctypes, which releases the GIL).  SURVEY.md 8d.
+            v, sample = cpu_leg(args.cpu_seconds * 0.6)
             res["cpu_baseline"] = {"value": round(v, 2), "unit": "Mpx/s", "cores": 1, "kind": "port", "sample": sample}
+            ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            if ncores > 1:
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(ncores) as pool:
+                    t0 = time.perf_counter()
+                    rates = list(pool.map(lambda _: cpu_leg(args.cpu_seconds * 0.4)[0], range(ncores)))
+                    dt = time.perf_counter() - t0
+                res["cpu_baseline"]["all_cores"] = {"value": round(float(sum(rates)), 1), "unit": "Mpx/s", "cores": ncores,
+                                                    "sample": f"the same loop on {ncores} threads at once, {dt:.1f} s"}
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)

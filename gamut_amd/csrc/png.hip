@@ -195,6 +195,24 @@ __device__ __forceinline__ void filter_piece(const RowFilter& f, const u32 (&rg)
     }
 }
 
+// The same for a 12-byte piece of an 8-bit RGB row = four whole pixels (the RGB -> RGBA ring kernel walks rows in 4-pixel
+// pieces so that a piece of the stream is exactly one 16-byte chunk of the output): every piece starts on a pixel
+// boundary, four serial steps.  px[k] = de-filtered pixel k in the low three bytes (top byte: garbage).
+template <bool PAETH>
+__device__ __forceinline__ void filter_piece12(const RowFilter& f, const u32 (&rg)[4], const u32 (&bg)[4],
+                                               const u32 (&po)[4], const u32 (&pb)[4], u32 (&og)[4], u32 (&px)[4])
+{
+    const u32 b0 = bytes_at<0>(bg), b1 = bytes_at<3>(bg), b2 = bytes_at<6>(bg), b3 = bytes_at<9>(bg);
+    px[0] = defilter4<PAETH>(f, bytes_at<0>(rg), po[2] >> 8, b0, pb[2] >> 8);
+    px[1] = defilter4<PAETH>(f, bytes_at<3>(rg), px[0], b1, b0);
+    px[2] = defilter4<PAETH>(f, bytes_at<6>(rg), px[1], b2, b1);
+    px[3] = defilter4<PAETH>(f, bytes_at<9>(rg), px[2], b3, b2);
+    og[0] = __builtin_amdgcn_perm(px[1], px[0], 0x04020100u);                      // bytes 0,1,2 | 3
+    og[1] = __builtin_amdgcn_perm(px[2], px[1], 0x05040201u);                      // 4,5 | 6,7
+    og[2] = __builtin_amdgcn_perm(px[3], px[2], 0x06050402u);                      // 8 | 9,10,11
+    og[3] = 0;
+}
+
 // shift a dword one lane up the wave (lane j receives lane j-1's value; lane 0 keeps `fill`):
 // one DPP move, wave_shr:1 (gfx9 DPP control 0x138), bound_ctrl off so lane 0 retains `old`
 __device__ __forceinline__ u32 from_lane_below(u32 v, u32 fill)
@@ -383,10 +401,16 @@ constexpr int ROW_PITCH = RING * 16;              // 256 B: lane j's slot (T - j
 #define PNG_NT_STORES 1
 #endif
 
-template <int FB, int W, bool PAETH>
+// RGBA = 8-bit RGB stream in, RGBA8 rows out (alpha = 255 inserted, stbdec.d:1504-1546, out_n == img_n + 1): the row is walked
+// in pieces of IB = 12 stream bytes = 4 pixels = one 16-byte chunk of the output, the ring slots hold the expanded pixels,
+// and everything about write-back, alignment and the hand-off between bands is the RGBA8 case; the row above the band comes
+// back from the output as RGBA and is squeezed to RGB again (three byte permutes per trip).
+template <int FB, int W, bool PAETH, bool RGBA>
 __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const uint8_t* raw, uint8_t* D, u32* prog, uint8_t* ring, u32 band,
                                                int wave, int lane, u32 niter, u32 f, bool row_live)
 {
+    static_assert(!RGBA || FB == 3, "alpha insertion is the 8-bit RGB case");
+    constexpr int IB = RGBA ? 12 : 16;            // stream bytes per piece
     constexpr int PW = 4;                         // dwords per piece
     typedef u32 u32x4 __attribute__((ext_vector_type(4)));
     const u32 seq = band / W;
@@ -398,7 +422,8 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
     const u32 dmask = band > 0 ? 0xFFFFFFFFu : 0u;
     const int prod_wave = (wave + W - 1) % W;
     const u32 prod_base = (band > 0 ? (band - 1) / W : 0) * niter;
-    const u32 full_iters = a.wb / 16;
+    const u32 full_iters = a.wb / IB;             // whole pieces of the stream = whole 16-byte chunks of the output row
+    const u32 out_wb = RGBA ? (a.wb / 3) * 4 : a.wb;
     // pieces written back cooperatively: a partial last piece goes along when the destination rows are padded (scratch)
     const u32 wb_iters = a.store_tail_masked ? full_iters : niter;
 
@@ -429,14 +454,14 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
             const u32 r = (u32)(8 * k + crow) < rows_left ? (u32)(8 * k) : 0u;             // dead rows re-read a live one (unused)
             it = it < 0 ? 0 : it;
             // full pieces by index; the ragged last piece (and anything past it, unused) = the last 16 bytes of the row
-            const int64_t off = (u32)it < full_iters ? (int64_t)it * 16 : (int64_t)a.wb - 16;
+            const int64_t off = (u32)it < full_iters ? (int64_t)it * IB : (int64_t)a.wb - IB;
 #if PNG_NT_LOADS
             typedef u32x4 u32x4_unaligned __attribute__((aligned(1)));
             const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_unaligned*>(craw + (int64_t)r * (a.wb + 1) + off));
             pre[k] = make_uint4(v.x, v.y, v.z, v.w);
 #else
             const PackedU32* q = reinterpret_cast<const PackedU32*>(craw + (int64_t)r * (a.wb + 1) + off);
-            pre[k] = make_uint4(q[0].v, q[1].v, q[2].v, q[3].v);
+            pre[k] = make_uint4(q[0].v, q[1].v, q[2].v, RGBA ? 0u : q[3].v);
 #endif
         }
     };
@@ -463,7 +488,7 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
         }
         prefetch_tile(T0 + TT);
         // some lane meets the partial last piece of its row (iteration full_iters, trip full_iters + lane) in this tile
-        const bool rag_tile = (a.wb & 15) != 0 && T0 + TT > full_iters && T0 <= full_iters + 63;
+        const bool rag_tile = (a.wb % IB) != 0 && T0 + TT > full_iters && T0 <= full_iters + 63;
 
         #pragma unroll
         for (int u = 0; u < TT; ++u) {
@@ -477,7 +502,7 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
             u32 rg[PW] = { rv.x, rv.y, rv.z, rv.w }, bg[PW];
             if (rag_tile) {             // last, partial piece of a row: the staged piece is the row's LAST 16 bytes (see prefetch_tile);
                 if (ragged) {           // keep its top nb bytes, moved down by 16 - nb bytes (zeros come in behind).  No memory op here.
-                    const u32 sh = 16 - (a.wb - (u32)it * 16), ds = sh >> 2, bs = sh & 3;
+                    const u32 sh = IB - (a.wb - (u32)it * IB), ds = sh >> 2, bs = sh & 3;
                     u32 w[5];
                     #pragma unroll
                     for (int i = 0; i < 5; ++i) {
@@ -488,25 +513,41 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
                     for (int i = 0; i < 4; ++i) rg[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], bs);
                 }
             }
-            #pragma unroll
-            for (int i = 0; i < PW; ++i) bg[i] = from_lane_below(outp[i], dset[u % PF][i] & dmask);
+            if constexpr (RGBA) {       // the chunk of the output row above the band: R,G,B,255 x 4 -> 12 stream bytes
+                const u32x4 d = dset[u % PF];
+                bg[0] = from_lane_below(outp[0], __builtin_amdgcn_perm(d[1], d[0], 0x04020100u) & dmask);
+                bg[1] = from_lane_below(outp[1], __builtin_amdgcn_perm(d[2], d[1], 0x05040201u) & dmask);
+                bg[2] = from_lane_below(outp[2], __builtin_amdgcn_perm(d[3], d[2], 0x06050402u) & dmask);
+                bg[3] = 0;
+            } else {
+                #pragma unroll
+                for (int i = 0; i < PW; ++i) bg[i] = from_lane_below(outp[i], dset[u % PF][i] & dmask);
+            }
             if (band > 0 && T + PF < niter && ((T + PF) % PUB) == 0) wait_for_band_above(T + PF + PUB);
             issue_dprev(T + PF, dset[u % PF]);
 
-            u32 og[PW];
-            filter_piece<FB, PAETH>(rf, rg, bg, outp, bprev, og);
+            u32 og[PW], ow[PW];         // de-filtered stream bytes of the piece; what goes into the ring slot (= output bytes)
+            if constexpr (RGBA) {
+                filter_piece12<PAETH>(rf, rg, bg, outp, bprev, og, ow);
+                #pragma unroll
+                for (int i = 0; i < PW; ++i) ow[i] |= 0xFF000000u;
+            } else {
+                filter_piece<FB, PAETH>(rf, rg, bg, outp, bprev, og);
+                #pragma unroll
+                for (int i = 0; i < PW; ++i) ow[i] = og[i];
+            }
             // a lane that has not reached its row yet (it < 0) must keep presenting zeros to the lane below and to its own
             // first pixel; past the end of the row (it >= niter) whatever it computes is only seen by lanes that are past
             // the end of theirs as well, and is never written back
             #pragma unroll
             for (int i = 0; i < PW; ++i) { outp[i] = it >= 0 ? og[i] : 0u; bprev[i] = bg[i]; }
-            *piece = make_uint4(og[0], og[1], og[2], og[3]);
+            *piece = make_uint4(ow[0], ow[1], ow[2], ow[3]);
             if (rag_tile && a.store_tail_masked) {   // partial piece of an exact-size destination row (wb % 4 == 0 there): up to three
                 u32* dst = reinterpret_cast<u32*>(drow + (int64_t)(ragged ? it : 0) * 16);      // dword stores straight to the row
-                const u32 nb = ragged ? a.wb - (u32)it * 16 : 0u;
-                if (nb >= 4) dst[0] = og[0];
-                if (nb >= 8) dst[1] = og[1];
-                if (nb >= 12) dst[2] = og[2];
+                const u32 nb = ragged ? out_wb - (u32)it * 16 : 0u;
+                if (nb >= 4) dst[0] = ow[0];
+                if (nb >= 8) dst[1] = ow[1];
+                if (nb >= 12) dst[2] = ow[2];
             }
         }
 
@@ -537,7 +578,7 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
         __hip_atomic_store(&prog[wave], seq * niter + niter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int FB, int W, int MINW>
+template <int FB, int W, int MINW, bool RGBA = false>
 __global__ __launch_bounds__(W * 64, MINW) void k_png_defilter_ring(DefilterArgs a)
 {
     __shared__ u32 prog[W];
@@ -546,7 +587,8 @@ __global__ __launch_bounds__(W * 64, MINW) void k_png_defilter_ring(DefilterArgs
     const int img = blockIdx.x;
     const uint8_t* raw = a.raw + (int64_t)img * a.raw_stride;
     uint8_t* D = a.D + (int64_t)img * a.d_stride;
-    const u32 niter = (a.wb + 15) / 16;
+    constexpr u32 IB = RGBA ? 12 : 16;
+    const u32 niter = (a.wb + IB - 1) / IB;
     const u32 nbands = (a.rows + 63) / 64;
     if (threadIdx.x < W) prog[threadIdx.x] = 0;
     __syncthreads();
@@ -555,8 +597,8 @@ __global__ __launch_bounds__(W * 64, MINW) void k_png_defilter_ring(DefilterArgs
         const bool row_live = row < a.rows;
         u32 f = row_live ? raw[(int64_t)row * (a.wb + 1)] : 0;
         if (f > 4) { if (a.status) atomicOr(a.status + img, 1u); f = 0; }
-        if (__any(f == 4)) defilter_band_ring<FB, W, true >(a, raw, D, prog, tiles[wave], band, wave, lane, niter, f, row_live);
-        else               defilter_band_ring<FB, W, false>(a, raw, D, prog, tiles[wave], band, wave, lane, niter, f, row_live);
+        if (__any(f == 4)) defilter_band_ring<FB, W, true,  RGBA>(a, raw, D, prog, tiles[wave], band, wave, lane, niter, f, row_live);
+        else               defilter_band_ring<FB, W, false, RGBA>(a, raw, D, prog, tiles[wave], band, wave, lane, niter, f, row_live);
     }
 }
 
@@ -732,12 +774,15 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
 
     const int bytes = depth == 16 ? 2 : 1;
     const int FB = depth < 8 ? 1 : img_n * bytes;
-    const bool fused = depth == 8 && out_n == img_n && (wb % 4) == 0 && ((uintptr_t)out % 4) == 0 && (count == 1 || out_stride % 4 == 0);
+    const bool out_dwords = ((uintptr_t)out % 4) == 0 && (count == 1 || out_stride % 4 == 0);
+    // 8-bit RGB -> RGBA8 in one pass: the ring kernel walks the row in 4-pixel pieces and writes the expanded pixels itself
+    const bool rgba_fused = depth == 8 && img_n == 3 && out_n == 4 && wb >= 16 && out_dwords;
+    const bool fused = rgba_fused || (depth == 8 && out_n == img_n && (wb % 4) == 0 && out_dwords);
 
     DefilterArgs a{};
     a.raw = raw; a.raw_stride = raw_stride; a.rows = y; a.wb = wb; a.status = status;
     static thread_local DeviceScratch scratch;
-    if (fused) { a.D = out; a.d_stride = out_stride; a.d_pitch = wb; a.store_tail_masked = 1; }
+    if (fused) { a.D = out; a.d_stride = out_stride; a.d_pitch = rgba_fused ? (int64_t)x * 4 : wb; a.store_tail_masked = 1; }
     else {
         const int64_t group = 4 * FB;
         a.d_pitch = ((int64_t)wb + group - 1) / group * group;
@@ -752,7 +797,8 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
     // budget left unconstrained (no spills: measured faster than 128-VGPR variants that spill).  Narrower rows: the
     // per-lane kernel.
     const bool ring = wb >= 16;
-    switch (FB) {
+    if (rgba_fused) hipLaunchKernelGGL((k_png_defilter_ring<3, PNG_WAVES, 2, true>), grid, block, 0, stream, a);
+    else switch (FB) {
 #define GAMUT_PNG_CASE(N) case N: if (ring) hipLaunchKernelGGL((k_png_defilter_ring<N, PNG_WAVES, 2>), grid, block, 0, stream, a); \
                                   else      hipLaunchKernelGGL((k_png_defilter<N, PNG_WAVES>), grid, block, 0, stream, a); break;
     GAMUT_PNG_CASE(1) GAMUT_PNG_CASE(2) GAMUT_PNG_CASE(3) GAMUT_PNG_CASE(4) GAMUT_PNG_CASE(6) GAMUT_PNG_CASE(8)

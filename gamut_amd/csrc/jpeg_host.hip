@@ -851,18 +851,20 @@ template <class T> int intern(std::vector<T>& pool, const T& t)      // index of
 }
 struct QuantTab { int16_t q[64]; };
 
-// What the host prepares for one file, independently of every other file (so files are spread over host threads): header
-// walk, tables in device form, and the entropy-coded segments copied UNSTUFFED (the 0x00 after a data 0xFF dropped), cut
-// at the RSTn markers, each followed by 64 bytes of 0xFF.
+// What the host prepares for one file, independently of every other file (so files are spread over host threads), in two
+// steps: (A) header walk + tables in device form + an upper bound of the file's share of the upload; (C) the entropy-coded
+// segments copied UNSTUFFED (the 0x00 after a data 0xFF dropped) straight into the pinned upload image, cut at the RSTn
+// markers, each followed by 64 bytes of 0xFF.
 struct FilePrep {
     int rc = GAMUT_HIP_OK; char msg[200] = { 0 };
     int comps = 0, nb = 0, ny = 0;
     QuantTab quant[3]; DevHuff huff[3][2];                     // [component][DC, AC]
-    std::vector<DevItem> items;                                // begin / end relative to `bytes`
-    std::vector<uint8_t> bytes;
+    size_t scan_pos = 0, cap = 0, used = 0;                    // first scan byte in the file; bound / actual size of the unstuffed segments
+    int restart_interval = 0, total_mcus = 0;
+    std::vector<DevItem> items;                                // begin / end relative to the file's slot in the blob
 };
 
-void prepare_file(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& f, FilePrep& out, Parser& P)
+void prepare_header(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& f, FilePrep& out, Parser& P)
 {
     P = Parser();
     out.rc = parse_baseline(P, base, n, &f, true);
@@ -877,20 +879,33 @@ void prepare_file(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& f,
             memcpy(d.maxcode, h.maxcode, sizeof(d.maxcode)); memcpy(d.delta, h.delta, sizeof(d.delta)); memcpy(d.vals, h.vals, sizeof(d.vals));
         }
     }
-    const int total_mcus = f.mcus_per_row * f.mcus_per_col;
-    std::vector<uint8_t>& blob = out.bytes;
-    blob.reserve(n - P.pos + 64 + (size_t)(P.restart_interval ? (total_mcus / P.restart_interval + 1) * 64 : 0));
+    out.scan_pos = P.pos; out.restart_interval = P.restart_interval; out.total_mcus = f.mcus_per_row * f.mcus_per_col;
+    // unstuffing only drops bytes; every segment (at most one per restart interval) gains 64 bytes of padding
+    const size_t segs = out.restart_interval ? (size_t)(out.total_mcus / out.restart_interval + 1) : 1;
+    out.cap = (n - out.scan_pos) + 64 * segs;
+}
+
+void unstuff_file(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& f, FilePrep& out, uint8_t* dst)
+{
+    const int total_mcus = out.total_mcus, ri = out.restart_interval;
     int next_mcu = 0, expect = 0;
-    size_t q = P.pos, copy_from = P.pos, seg_begin = 0;
+    size_t q = out.scan_pos, copy_from = out.scan_pos, seg_begin = 0, w = 0;          // w = bytes written to dst
     bool copying = true, bad = false;
-    auto flush = [&](size_t upto) { if (copying && upto > copy_from) blob.insert(blob.end(), base + copy_from, base + upto); };
-    auto close_segment = [&](int nm) {
-        DevItem it{}; it.image = i; it.first_mcu = next_mcu; it.n_mcus = nm; it.begin = seg_begin; it.end = blob.size();
-        out.items.push_back(it); next_mcu += nm;
-        blob.insert(blob.end(), 64, (uint8_t)0xFF);
-        seg_begin = blob.size();
+    auto flush = [&](size_t upto) {
+        if (copying && upto > copy_from) {
+            const size_t k = upto - copy_from;
+            if (w + k > out.cap) { bad = true; return; }                               // cannot happen (see cap); never write past the slot
+            memcpy(dst + w, base + copy_from, k); w += k;
+        }
     };
-    while (true) {
+    auto close_segment = [&](int nm) {
+        if (w + 64 > out.cap) { bad = true; return; }
+        DevItem it{}; it.image = i; it.first_mcu = next_mcu; it.n_mcus = nm; it.begin = seg_begin; it.end = w;
+        out.items.push_back(it); next_mcu += nm;
+        memset(dst + w, 0xFF, 64); w += 64;
+        seg_begin = w;
+    };
+    while (!bad) {
         const uint8_t* hit = q < n ? (const uint8_t*)memchr(base + q, 0xFF, n - q) : nullptr;
         if (!hit || hit + 1 >= base + n) { flush(n); q = n; break; }
         const uint8_t m = hit[1];
@@ -898,20 +913,21 @@ void prepare_file(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& f,
         if (m == 0x00) { flush(q + 1); copy_from = q + 2; q += 2; continue; }          // stuffed 0xFF: keep the FF, drop the 00
         flush(q); copying = false;                                                        // FF + non-zero: the data ends here (get_octet :683-696)
         if (m == 0xFF) { q += 1; continue; }                                              // fill bytes before a marker
-        if (m >= 0xD0 && m <= 0xD7 && P.restart_interval && next_mcu + P.restart_interval < total_mcus) {
+        if (m >= 0xD0 && m <= 0xD7 && ri && next_mcu + ri < total_mcus) {
             if (m != 0xD0 + expect) { bad = true; break; }
-            close_segment(P.restart_interval);
+            close_segment(ri);
             expect = (expect + 1) & 7; q += 2; copy_from = q; copying = true;
             continue;
         }
         break;                                             // EOI or any other marker ends the scan
     }
     if (!bad && next_mcu < total_mcus) {
-        if (P.restart_interval && total_mcus - next_mcu > P.restart_interval) bad = true;      // a restart marker is missing
+        if (ri && total_mcus - next_mcu > ri) bad = true;      // a restart marker is missing
         else close_segment(total_mcus - next_mcu);
     }
+    out.used = w;
     if (bad) {
-        out.items.clear(); blob.clear();
+        out.items.clear(); out.used = 0;
         fail(&f, "bad restart marker");
         out.rc = GAMUT_HIP_ERR_DECODE; snprintf(out.msg, sizeof(out.msg), "image %d: bad restart marker", i);
     }
@@ -940,7 +956,9 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
     for (int i = 0; i < count; ++i)
         if ((coeff_offset[i] & 7) != 0) return set_error(GAMUT_HIP_ERR_INVALID_ARG, "jpeg_entropy_decode_device: coefficient offsets must be multiples of 8 elements (image %d)", i);
 
-    // 1. per file, on up to 16 host threads
+    // Pipeline: (A) headers on host threads -> (B) layout, and the coefficient clears go out on `stream` -> (C) segments
+    // unstuffed straight into the pinned upload image, slice by slice, each slice DMA'd on a private copy stream as soon as
+    // it is complete (so unstuffing, PCIe and the clears overlap) -> (D) tables, then the kernels on `stream` behind an event.
     int workers = (int)std::thread::hardware_concurrency();
     workers = workers < 1 ? 1 : workers > 16 ? 16 : workers;
     if (workers > (count + 7) / 8) workers = (count + 7) / 8;
@@ -948,100 +966,160 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
     {
         std::vector<Parser*> parsers((size_t)workers, nullptr);
         for (Parser*& p : parsers) p = new Parser();
-        parallel_for(count, workers, [&](int w, int i) { prepare_file(i, data[i], len[i], info[i], prep[(size_t)i], *parsers[(size_t)w]); });
+        parallel_for(count, workers, [&](int w, int i) { prepare_header(i, data[i], len[i], info[i], prep[(size_t)i], *parsers[(size_t)w]); });
         for (Parser* p : parsers) delete p;
     }
-    // 2. serial: table de-duplication, layout of the upload
+    // B. serial: table de-duplication, slots of the files in the blob
     std::vector<DevImage> images((size_t)count);
-    std::vector<DevItem> items;
     std::vector<DevHuff> huffs;
     std::vector<QuantTab> quants;
     std::vector<size_t> blob_off((size_t)count, 0);
     size_t blob_size = 0;
-    int first_failure = GAMUT_HIP_OK; const char* first_msg = "";
     for (int i = 0; i < count; ++i) {
         FilePrep& fp = prep[(size_t)i];
         DevImage& im = images[(size_t)i];
         memset(&im, 0, sizeof(im));
-        if (host_status) host_status[i] = fp.rc;
-        if (fp.rc != GAMUT_HIP_OK) { if (first_failure == GAMUT_HIP_OK) { first_failure = fp.rc; first_msg = fp.msg; } continue; }
+        if (fp.rc != GAMUT_HIP_OK) continue;
         im.coeff_off = coeff_offset[i]; im.zag_off = zag_offset[i]; im.nb = fp.nb; im.ny = fp.ny;
         for (int c = 0; c < fp.comps; ++c) { im.quant[c] = intern(quants, fp.quant[c]); im.dc[c] = intern(huffs, fp.huff[c][0]); im.ac[c] = intern(huffs, fp.huff[c][1]); }
         blob_off[(size_t)i] = blob_size;
-        for (DevItem it : fp.items) { it.begin += blob_size; it.end += blob_size; items.push_back(it); }
-        blob_size += (fp.bytes.size() + 15) & ~(size_t)15;
+        blob_size += (fp.cap + 15) & ~(size_t)15;
     }
-    // long segments get a workgroup each (self-synchronising decode), short ones a lane each
-    std::stable_partition(items.begin(), items.end(), [](const DevItem& it) { return it.end - it.begin >= kSyncMinBytes; });
-    int n_long = 0;
-    while (n_long < (int)items.size() && items[(size_t)n_long].end - items[(size_t)n_long].begin >= kSyncMinBytes) ++n_long;
     const double ms_parse = ms_since(t_begin);
     double ms_upload = 0;
+    std::vector<DevItem> items;
+    int first_failure = GAMUT_HIP_OK; const char* first_msg = "";
+    int n_long = 0;
+    bool any_ok = false;
+    for (int i = 0; i < count; ++i) any_ok = any_ok || prep[(size_t)i].rc == GAMUT_HIP_OK;
 
-    if (!items.empty()) {
+    if (any_ok) {
         const auto t_up = std::chrono::steady_clock::now();
-        // 3. one pinned host image of the upload, [items][images][huff][quant][blob], the segments copied in by the workers,
-        //    one DMA to a device staging buffer of the same layout
+        static thread_local hipStream_t copy_stream = nullptr;
+        if (!copy_stream) GAMUT_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        static thread_local DeviceScratch scratch, tab_scratch;
+        static thread_local PinnedScratch pinned, tab_pinned;
+        uint8_t* d_blob_w = (uint8_t*)scratch.get(blob_size + 64);
+        uint8_t* h_blob = pinned.get(blob_size + 64);
+        if (!d_blob_w || !h_blob) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: staging allocation of %zu bytes failed", blob_size + 64);
+        // lanes of a workgroup of the self-synchronising kernel share blocks, so coefficients are written in place: clear the
+        // images that can have a long segment first (adjacent ones in one call).  On `stream`, while the upload is prepared.
+        {
+            auto blocks = [&](int k) { return (int64_t)info[k].mcus_per_row * info[k].mcus_per_col * info[k].blocks_per_mcu; };
+            auto needs = [&](int k) { return prep[(size_t)k].rc == GAMUT_HIP_OK && len[k] - prep[(size_t)k].scan_pos >= (size_t)kSyncMinBytes; };
+            for (int i = 0; i < count; ) {
+                if (!needs(i)) { ++i; continue; }
+                const int64_t begin = coeff_offset[i]; int64_t endo = begin + blocks(i) * 64;
+                int j = i + 1;
+                while (j < count && needs(j) && coeff_offset[j] == endo) { endo += blocks(j) * 64; ++j; }
+                GAMUT_HIP_CHECK(hipMemsetAsync(d_coeffs + begin, 0, (size_t)(endo - begin) * sizeof(int16_t), stream));
+                i = j;
+            }
+            if (d_status) GAMUT_HIP_CHECK(hipMemsetAsync(d_status, 0, (size_t)count * sizeof(uint32_t), stream));
+        }
+        // C/D. groups of slices of files.  A slice is unstuffed on the workers and DMA'd at once; when a group of slices is on
+        //      its way, its segment list follows it and the group's kernels are queued on `stream` behind an event, so the
+        //      first group decodes while the rest is still being unstuffed and uploaded.  A group keeps >= 512 workgroups.
+        const int n_groups = count >= 2048 ? 4 : count >= 1024 ? 2 : 1;
+        const int n_slices = count >= 512 ? 8 : count >= 64 ? 4 : 1;
+        static thread_local hipEvent_t group_ready[4] = { nullptr, nullptr, nullptr, nullptr };
+        for (int g = 0; g < n_groups; ++g) if (!group_ready[g]) GAMUT_HIP_CHECK(hipEventCreateWithFlags(&group_ready[g], hipEventDisableTiming));
         auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
-        const size_t o_items = 0, o_img = align(o_items + items.size() * sizeof(DevItem)), o_huff = align(o_img + images.size() * sizeof(DevImage)),
-                     o_quant = align(o_huff + huffs.size() * sizeof(DevHuff)), o_blob = align(o_quant + quants.size() * sizeof(QuantTab)),
-                     total = o_blob + blob_size + 64;
-        static thread_local DeviceScratch scratch;
-        static thread_local PinnedScratch pinned;
-        uint8_t* d = (uint8_t*)scratch.get(total);
-        uint8_t* h = pinned.get(total);
+        size_t max_items = 0;
+        for (int i = 0; i < count; ++i) if (prep[(size_t)i].rc == GAMUT_HIP_OK) max_items += prep[(size_t)i].restart_interval ? (size_t)(prep[(size_t)i].total_mcus / prep[(size_t)i].restart_interval + 1) : 1;
+        // one small pinned image of the tables: [images][huff][quant][items of group 0][items of group 1]...
+        const size_t o_img = 0, o_huff = align(o_img + images.size() * sizeof(DevImage)), o_quant = align(o_huff + huffs.size() * sizeof(DevHuff)),
+                     o_items = align(o_quant + quants.size() * sizeof(QuantTab)), total = o_items + align(max_items * sizeof(DevItem)) + 256 * (size_t)n_groups;
+        uint8_t* d = (uint8_t*)tab_scratch.get(total);
+        uint8_t* h = tab_pinned.get(total);
         if (!d || !h) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: staging allocation of %zu bytes failed", total);
-        memcpy(h + o_items, items.data(), items.size() * sizeof(DevItem));
         memcpy(h + o_img, images.data(), images.size() * sizeof(DevImage));
         memcpy(h + o_huff, huffs.data(), huffs.size() * sizeof(DevHuff));
         memcpy(h + o_quant, quants.data(), quants.size() * sizeof(QuantTab));
-        parallel_for(count, workers, [&](int, int i) {
-            const FilePrep& fp = prep[(size_t)i];
-            if (fp.rc == GAMUT_HIP_OK && !fp.bytes.empty()) memcpy(h + o_blob + blob_off[(size_t)i], fp.bytes.data(), fp.bytes.size());
-        });
-        memset(h + o_blob + blob_size, 0xFF, 64);
-        GAMUT_HIP_CHECK(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, stream));
-        if (d_status) GAMUT_HIP_CHECK(hipMemsetAsync(d_status, 0, (size_t)count * sizeof(uint32_t), stream));
+        GAMUT_HIP_CHECK(hipMemcpyAsync(d, h, o_items, hipMemcpyHostToDevice, copy_stream));
         uint32_t* st = d_status;
         if (!st) {                                             // the kernel wants somewhere to flag errors
             static thread_local DeviceScratch sink;
             st = (uint32_t*)sink.get((size_t)count * sizeof(uint32_t));
             if (!st) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: status allocation failed");
         }
-        if (trace) { (void)hipStreamSynchronize(stream); ms_upload = ms_since(t_up); }
-        const auto t_k = std::chrono::steady_clock::now();
-        const int n_items = (int)items.size(), n_huff = (int)huffs.size(), n_quant = (int)quants.size(), n_short = n_items - n_long;
+        const int n_huff = (int)huffs.size(), n_quant = (int)quants.size();
         const bool in_lds = n_huff <= kLdsHuff && n_quant <= kLdsQuant;
-        const DevItem* d_items = (const DevItem*)(d + o_items); const DevImage* d_img = (const DevImage*)(d + o_img);
+        const DevImage* d_img = (const DevImage*)(d + o_img);
         const DevHuff* d_huff = (const DevHuff*)(d + o_huff); const int16_t* d_quant = (const int16_t*)(d + o_quant);
-        const uint8_t* d_blob = (const uint8_t*)(d + o_blob);
-        if (n_long) {
-            // lanes of a workgroup share blocks, so coefficients are written in place: clear the images concerned first
-            // (adjacent ones in one call)
-            std::vector<char> needs((size_t)count, 0);
-            for (int k = 0; k < n_long; ++k) needs[(size_t)items[(size_t)k].image] = 1;
-            auto blocks = [&](int k) { return (int64_t)info[k].mcus_per_row * info[k].mcus_per_col * info[k].blocks_per_mcu; };
-            for (int i = 0; i < count; ) {
-                if (!needs[(size_t)i]) { ++i; continue; }
-                const int64_t begin = coeff_offset[i]; int64_t endo = begin + blocks(i) * 64;
-                int j = i + 1;
-                while (j < count && needs[(size_t)j] && coeff_offset[j] == endo) { endo += blocks(j) * 64; ++j; }
-                GAMUT_HIP_CHECK(hipMemsetAsync(d_coeffs + begin, 0, (size_t)(endo - begin) * sizeof(int16_t), stream));
-                i = j;
+        const uint8_t* d_blob = d_blob_w;
+        size_t items_off = o_items;
+        int total_long = 0, total_short = 0;
+        double ms_kernels_issue = 0;
+        for (int g = 0; g < n_groups; ++g) {
+            const int g_lo = (int)((int64_t)count * g / n_groups), g_hi = (int)((int64_t)count * (g + 1) / n_groups);
+            const int s_lo = n_slices * g / n_groups, s_hi = n_slices * (g + 1) / n_groups;
+            for (int sl = s_lo; sl < s_hi; ++sl) {
+                const int lo = g_lo + (int)((int64_t)(g_hi - g_lo) * (sl - s_lo) / (s_hi - s_lo)), hi = g_lo + (int)((int64_t)(g_hi - g_lo) * (sl - s_lo + 1) / (s_hi - s_lo));
+                if (hi <= lo) continue;
+                parallel_for(hi - lo, workers, [&](int, int k) {
+                    const int i = lo + k;
+                    FilePrep& fp = prep[(size_t)i];
+                    if (fp.rc == GAMUT_HIP_OK) unstuff_file(i, data[i], len[i], info[i], fp, h_blob + blob_off[(size_t)i]);
+                });
+                size_t b0 = 0, b1 = 0; bool have = false;
+                for (int i = lo; i < hi; ++i) {
+                    const FilePrep& fp = prep[(size_t)i];
+                    if (fp.rc != GAMUT_HIP_OK || fp.used == 0) continue;
+                    if (!have) { b0 = blob_off[(size_t)i]; have = true; }
+                    b1 = blob_off[(size_t)i] + fp.used;
+                }
+                if (have) GAMUT_HIP_CHECK(hipMemcpyAsync(d_blob_w + b0, h_blob + b0, b1 - b0, hipMemcpyHostToDevice, copy_stream));
             }
-            if (in_lds) hipLaunchKernelGGL(k_jpeg_entropy_sync<true>, dim3(n_long), dim3(kSyncThreads), 0, stream, d_items, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
-            else        hipLaunchKernelGGL(k_jpeg_entropy_sync<false>, dim3(n_long), dim3(kSyncThreads), 0, stream, d_items, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
-            if (int rc = launch_status("jpeg_entropy_sync")) return rc;
+            // the group's segment list: long segments get a workgroup each (self-synchronising decode), short ones a lane each
+            items.clear();
+            for (int i = g_lo; i < g_hi; ++i) {
+                const FilePrep& fp = prep[(size_t)i];
+                if (fp.rc != GAMUT_HIP_OK) continue;
+                for (DevItem it : fp.items) { it.begin += blob_off[(size_t)i]; it.end += blob_off[(size_t)i]; items.push_back(it); }
+            }
+            if (items.empty()) continue;
+            std::stable_partition(items.begin(), items.end(), [](const DevItem& it) { return it.end - it.begin >= kSyncMinBytes; });
+            n_long = 0;
+            while (n_long < (int)items.size() && items[(size_t)n_long].end - items[(size_t)n_long].begin >= kSyncMinBytes) ++n_long;
+            const int n_items = (int)items.size(), n_short = n_items - n_long;
+            total_long += n_long; total_short += n_short;
+            if (items_off + items.size() * sizeof(DevItem) > total) return set_error(GAMUT_HIP_ERR_DECODE, "jpeg: more segments than the restart intervals allow");
+            memcpy(h + items_off, items.data(), items.size() * sizeof(DevItem));
+            GAMUT_HIP_CHECK(hipMemcpyAsync(d + items_off, h + items_off, items.size() * sizeof(DevItem), hipMemcpyHostToDevice, copy_stream));
+            const DevItem* d_items = (const DevItem*)(d + items_off);
+            items_off = align(items_off + items.size() * sizeof(DevItem));
+            GAMUT_HIP_CHECK(hipEventRecord(group_ready[g], copy_stream));
+            GAMUT_HIP_CHECK(hipStreamWaitEvent(stream, group_ready[g], 0));
+            if (trace) { (void)hipStreamSynchronize(stream); ms_upload = ms_since(t_up) - ms_kernels_issue; }
+            const auto t_k = std::chrono::steady_clock::now();
+            if (n_long) {
+                if (in_lds) hipLaunchKernelGGL(k_jpeg_entropy_sync<true>, dim3(n_long), dim3(kSyncThreads), 0, stream, d_items, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
+                else        hipLaunchKernelGGL(k_jpeg_entropy_sync<false>, dim3(n_long), dim3(kSyncThreads), 0, stream, d_items, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
+                if (int rc = launch_status("jpeg_entropy_sync")) return rc;
+            }
+            if (n_short) {
+                const dim3 grid((n_short + kEntropyThreads - 1) / kEntropyThreads), block(kEntropyThreads);
+                if (in_lds) hipLaunchKernelGGL(k_jpeg_entropy<true>, grid, block, 0, stream, d_items + n_long, n_short, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
+                else        hipLaunchKernelGGL(k_jpeg_entropy<false>, grid, block, 0, stream, d_items + n_long, n_short, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
+            }
+            if (int rc = launch_status("jpeg_entropy")) return rc;
+            if (trace) { (void)hipStreamSynchronize(stream); ms_kernels_issue += ms_since(t_k); }
         }
-        if (n_short) {
-            const dim3 grid((n_short + kEntropyThreads - 1) / kEntropyThreads), block(kEntropyThreads);
-            if (in_lds) hipLaunchKernelGGL(k_jpeg_entropy<true>, grid, block, 0, stream, d_items + n_long, n_short, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
-            else        hipLaunchKernelGGL(k_jpeg_entropy<false>, grid, block, 0, stream, d_items + n_long, n_short, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
-        }
-        if (int rc = launch_status("jpeg_entropy")) return rc;
+        GAMUT_HIP_CHECK(hipStreamSynchronize(copy_stream));
         GAMUT_HIP_CHECK(hipStreamSynchronize(stream));         // the per-thread staging buffers are reused by the next call
-        if (trace) fprintf(stderr, "[gamut_hip] jpeg_entropy_decode_device: %d files, %d long + %d short segments, %d+%d tables, %.1f MB compressed, %d host threads: parse %.1f ms, upload %.1f ms, kernels %.1f ms\n",
-                           count, n_long, n_short, n_huff, n_quant, blob_size / 1e6, workers, ms_parse, ms_upload, ms_since(t_k));
+        if (trace) fprintf(stderr, "[gamut_hip] jpeg_entropy_decode_device: %d files in %d group(s), %d long + %d short segments, %d+%d tables, %.1f MB compressed, %d host threads: headers %.1f ms, unstuff + upload %.1f ms, kernels %.1f ms (stages serialised by the trace)\n",
+                           count, n_groups, total_long, total_short, n_huff, n_quant, blob_size / 1e6, workers, ms_parse, ms_upload, ms_kernels_issue);
+        for (int i = 0; i < count; ++i) {
+            const FilePrep& fp = prep[(size_t)i];
+            if (host_status) host_status[i] = fp.rc;
+            if (fp.rc != GAMUT_HIP_OK && first_failure == GAMUT_HIP_OK) { first_failure = fp.rc; first_msg = fp.msg; }
+        }
+    } else {
+        for (int i = 0; i < count; ++i) {
+            if (host_status) host_status[i] = prep[(size_t)i].rc;
+            if (first_failure == GAMUT_HIP_OK && prep[(size_t)i].rc != GAMUT_HIP_OK) { first_failure = prep[(size_t)i].rc; first_msg = prep[(size_t)i].msg; }
+        }
     }
     if (first_failure != GAMUT_HIP_OK) return set_error(first_failure, "%s", first_msg);
     return GAMUT_HIP_OK;
@@ -1122,10 +1200,12 @@ int gamut_hip_jpeg_scan_layout(const uint8_t* data, size_t len, gamut_hip_jpeg_f
     try {
         Parser* ps = new Parser();
         FilePrep fp;
-        prepare_file(0, data, len, *info, fp, *ps);
+        prepare_header(0, data, len, *info, fp, *ps);
         delete ps;
+        std::vector<uint8_t> bytes(fp.rc == GAMUT_HIP_OK ? fp.cap : 0);
+        if (fp.rc == GAMUT_HIP_OK) unstuff_file(0, data, len, *info, fp, bytes.data());
         if (segments) *segments = (int32_t)fp.items.size();
-        if (entropy_bytes) *entropy_bytes = fp.bytes.size();
+        if (entropy_bytes) *entropy_bytes = fp.used;
         if (fp.rc != GAMUT_HIP_OK) return set_error(fp.rc, "%s", fp.msg);
         return GAMUT_HIP_OK;
     } catch (...) {

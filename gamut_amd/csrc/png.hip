@@ -43,7 +43,10 @@ struct DefilterArgs {
     u32* status;                                 // per image, |= 1 on an invalid filter byte (stbdec.d:1438)
     u32 rows, wb;                                // rows, bytes per row
     u32 store_tail_masked;                       // 1: D rows are tight (fused output) -> never write past wb
+    const int64_t* raw_offs; const int64_t* d_offs;  // optional (device): byte offset of image i's stream / rows instead of i * stride
 };
+__device__ __forceinline__ const uint8_t* image_raw(const DefilterArgs& a, int img) { return a.raw + (a.raw_offs ? a.raw_offs[img] : (int64_t)img * a.raw_stride); }
+__device__ __forceinline__ uint8_t* image_rows(const DefilterArgs& a, int img) { return a.D + (a.d_offs ? a.d_offs[img] : (int64_t)img * a.d_stride); }
 
 struct __attribute__((packed)) PackedU32 { u32 v; };      // a dword at any byte alignment
 
@@ -358,8 +361,8 @@ __global__ __launch_bounds__(W * 64) void k_png_defilter(DefilterArgs a)
     __shared__ u32 prog[W];                       // cumulative iterations finished (and visible) by each wave's lane 63
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int img = blockIdx.x;
-    const uint8_t* raw = a.raw + (int64_t)img * a.raw_stride;
-    uint8_t* D = a.D + (int64_t)img * a.d_stride;
+    const uint8_t* raw = image_raw(a, img);
+    uint8_t* D = image_rows(a, img);
     const u32 npix = a.wb / FB;                   // filter units per row
     const u32 niter = (npix + 3) / 4;
     const u32 nbands = (a.rows + 63) / 64;
@@ -585,8 +588,8 @@ __global__ __launch_bounds__(W * 64, MINW) void k_png_defilter_ring(DefilterArgs
     __shared__ __attribute__((aligned(16))) uint8_t tiles[W][64 * ROW_PITCH];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int img = blockIdx.x;
-    const uint8_t* raw = a.raw + (int64_t)img * a.raw_stride;
-    uint8_t* D = a.D + (int64_t)img * a.d_stride;
+    const uint8_t* raw = image_raw(a, img);
+    uint8_t* D = image_rows(a, img);
     constexpr u32 IB = RGBA ? 12 : 16;
     const u32 niter = (a.wb + IB - 1) / IB;
     const u32 nbands = (a.rows + 63) / 64;
@@ -607,12 +610,13 @@ struct ExpandArgs {
     const uint8_t* D; int64_t d_stride; int64_t d_pitch;
     uint8_t* out; int64_t out_stride;
     u32 x, y; int img_n, out_n, depth, color;
+    const int64_t* out_offs;                     // optional (device): byte offset of image i's pixels instead of i * out_stride
 };
 __global__ __launch_bounds__(256) void k_png_expand(ExpandArgs a)
 {
     const int img = blockIdx.y;
     const uint8_t* D = a.D + (int64_t)img * a.d_stride;
-    uint8_t* out = a.out + (int64_t)img * a.out_stride;
+    uint8_t* out = a.out + (a.out_offs ? a.out_offs[img] : (int64_t)img * a.out_stride);
     const int64_t npx = (int64_t)a.x * a.y;
     const int bytes = a.depth == 16 ? 2 : 1;
     const u32 scale = (a.color == 0) ? (a.depth == 1 ? 0xFFu : a.depth == 2 ? 0x55u : a.depth == 4 ? 0x11u : 1u) : 1u;   // stbi__depth_scale_table :1403
@@ -722,7 +726,7 @@ __global__ __launch_bounds__(256) void k_png_expand_vec(ExpandArgs a)
     const u32 g = blockIdx.x * 256 + threadIdx.x;
     if (g >= (a.x + 3) / 4) return;
     const uint8_t* D = a.D + (int64_t)blockIdx.z * a.d_stride + (int64_t)g * IB;
-    uint8_t* out = a.out + (int64_t)blockIdx.z * a.out_stride + (int64_t)g * OB;
+    uint8_t* out = a.out + (a.out_offs ? a.out_offs[blockIdx.z] : (int64_t)blockIdx.z * a.out_stride) + (int64_t)g * OB;
     const u32 npx = min(4u, a.x - 4 * g);
     for (u32 row = blockIdx.y; row < a.y; row += gridDim.y) {
         const u32* src = reinterpret_cast<const u32*>(D + (int64_t)row * a.d_pitch);
@@ -755,7 +759,8 @@ __global__ __launch_bounds__(256) void k_png_expand_vec(ExpandArgs a)
 int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len,
                          uint8_t* out, int64_t out_stride,
                          uint32_t x, uint32_t y, int img_n, int out_n, int depth, int color,
-                         int count, uint32_t* status, hipStream_t stream)
+                         int count, uint32_t* status, hipStream_t stream,
+                         const int64_t* raw_offs, const int64_t* out_offs, bool offs_dword_aligned)
 {
     // validation as in stbi__create_png_image_raw (stbdec.d:1419-1430, 1441-1442) and parse_png_file (:1890-1906)
     if (depth != 1 && depth != 2 && depth != 4 && depth != 8 && depth != 16)
@@ -774,15 +779,16 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
 
     const int bytes = depth == 16 ? 2 : 1;
     const int FB = depth < 8 ? 1 : img_n * bytes;
-    const bool out_dwords = ((uintptr_t)out % 4) == 0 && (count == 1 || out_stride % 4 == 0);
+    // raw_offs / out_offs (device arrays, both or neither): images at arbitrary offsets instead of a constant stride
+    const bool out_dwords = ((uintptr_t)out % 4) == 0 && (out_offs ? offs_dword_aligned : (count == 1 || out_stride % 4 == 0));
     // 8-bit RGB -> RGBA8 in one pass: the ring kernel walks the row in 4-pixel pieces and writes the expanded pixels itself
     const bool rgba_fused = depth == 8 && img_n == 3 && out_n == 4 && wb >= 16 && out_dwords;
     const bool fused = rgba_fused || (depth == 8 && out_n == img_n && (wb % 4) == 0 && out_dwords);
 
     DefilterArgs a{};
-    a.raw = raw; a.raw_stride = raw_stride; a.rows = y; a.wb = wb; a.status = status;
+    a.raw = raw; a.raw_stride = raw_stride; a.rows = y; a.wb = wb; a.status = status; a.raw_offs = raw_offs; a.d_offs = nullptr;
     static thread_local DeviceScratch scratch;
-    if (fused) { a.D = out; a.d_stride = out_stride; a.d_pitch = rgba_fused ? (int64_t)x * 4 : wb; a.store_tail_masked = 1; }
+    if (fused) { a.D = out; a.d_stride = out_stride; a.d_offs = out_offs; a.d_pitch = rgba_fused ? (int64_t)x * 4 : wb; a.store_tail_masked = 1; }
     else {
         const int64_t group = 4 * FB;
         a.d_pitch = ((int64_t)wb + group - 1) / group * group;
@@ -809,7 +815,7 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
     if (!fused) {
         ExpandArgs e{};
         e.D = a.D; e.d_stride = a.d_stride; e.d_pitch = a.d_pitch; e.out = out; e.out_stride = out_stride;
-        e.x = x; e.y = y; e.img_n = img_n; e.out_n = out_n; e.depth = depth; e.color = color;
+        e.x = x; e.y = y; e.img_n = img_n; e.out_n = out_n; e.depth = depth; e.color = color; e.out_offs = out_offs;
         const dim3 vgrid(((x + 3) / 4 + 255) / 256, y < 65535u ? y : 65535u, count);
         bool vec = depth >= 8 && count <= 65535;
         if (vec) {

@@ -10,7 +10,10 @@
 #include "common.hpp"
 #include <atomic>
 #include <chrono>
+#include <map>
+#include <mutex>
 #include <thread>
+#include <tuple>
 #include <vector>
 #include <zlib.h>
 
@@ -209,7 +212,7 @@ int png_prepare(const uint8_t* data, size_t len, PngJob& j)
 // (stbdec.d:1646-1679, 1821-1855, 2038-2045), then the 16 <-> 8 step of stbi__load_and_postprocess_* (:669-707) when
 // want_bits (8 / 16; 0 = as decoded) asks for it.  The result is left at d_dst (device) or returned as malloc'd host memory.
 uint8_t* png_run(const PngHeader& h, const uint8_t* raw, uint32_t raw_len, int req_comp, int want_bits, uint8_t* d_dst,
-                 int* px, int* py, int* pn, int* bits_out, hipStream_t st)
+                 int* px, int* py, int* pn, int* bits_out, hipStream_t st, const uint8_t* d_raw = nullptr)
 {
     const bool trace = getenv("GAMUT_HIP_TRACE") != nullptr;               // stage timings on stderr
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -221,20 +224,21 @@ uint8_t* png_run(const PngHeader& h, const uint8_t* raw, uint32_t raw_len, int r
 
     const auto t1 = now();
     Dev draw, dimg, dstatus;
-    if (!draw.alloc((size_t)raw_len + 16) || !dimg.alloc((size_t)npx * out_n * bytes + 16) || !dstatus.alloc(4)) return nullptr;
+    if ((!d_raw && !draw.alloc((size_t)raw_len + 16)) || !dimg.alloc((size_t)npx * out_n * bytes + 16) || !dstatus.alloc(4)) return nullptr;
     const auto t2 = now();
-    if (hipMemcpyAsync(draw.p, raw, raw_len, hipMemcpyHostToDevice, st) != hipSuccess || hipMemsetAsync(dstatus.p, 0, 4, st) != hipSuccess) {
+    if ((!d_raw && hipMemcpyAsync(draw.p, raw, raw_len, hipMemcpyHostToDevice, st) != hipSuccess) || hipMemsetAsync(dstatus.p, 0, 4, st) != hipSuccess) {
         set_error(GAMUT_HIP_ERR_HIP, "png: upload failed"); return nullptr;
     }
+    const uint8_t* const stream_dev = d_raw ? d_raw : (const uint8_t*)draw.p;      // the inflated stream in HBM
     if (trace) (void)hipStreamSynchronize(st);
     const auto t3 = now();
     if (!h.interlace) {
-        if (png_defilter_launch((const uint8_t*)draw.p, 0, raw_len, (uint8_t*)dimg.p, 0, h.x, h.y, img_n, out_n, h.depth, h.color, 1, (uint32_t*)dstatus.p, st)) return nullptr;
+        if (png_defilter_launch(stream_dev, 0, raw_len, (uint8_t*)dimg.p, 0, h.x, h.y, img_n, out_n, h.depth, h.color, 1, (uint32_t*)dstatus.p, st)) return nullptr;
     } else {                                                              // stbi__create_png_image :1646-1679
         static const int xorig[7] = { 0,4,0,2,0,1,0 }, yorig[7] = { 0,0,4,0,2,0,1 }, xspc[7] = { 8,8,4,4,2,2,1 }, yspc[7] = { 8,8,8,4,4,2,2 };
         Dev dpass;
         if (!dpass.alloc((size_t)npx * out_n * bytes + 16)) return nullptr;
-        const uint8_t* rp = (const uint8_t*)draw.p; uint32_t left = raw_len;
+        const uint8_t* rp = stream_dev; uint32_t left = raw_len;
         for (int p = 0; p < 7; ++p) {
             const uint32_t x = (h.x - xorig[p] + xspc[p] - 1) / xspc[p], y = (h.y - yorig[p] + yspc[p] - 1) / yspc[p];
             if (!x || !y) continue;
@@ -316,6 +320,22 @@ uint8_t* png_load(const uint8_t* data, size_t len, int* px, int* py, int* pn, in
     return png_run(j.h, staging.p, j.raw_len, req_comp, want_bits, nullptr, px, py, pn, &bits, thread_stream());
 }
 
+// Pinned inflate buffers of the batch workers: taken for the duration of a call, kept for the next one (page-locking 30 MB
+// costs milliseconds), never freed -- the HIP runtime may be gone at exit.
+struct PinnedPool {
+    std::mutex m; std::vector<HostBuf> idle;
+    HostBuf take() { std::lock_guard<std::mutex> g(m); if (idle.empty()) return HostBuf{ nullptr, 0, true }; HostBuf b = idle.back(); idle.pop_back(); return b; }
+    void give(const HostBuf& b) { std::lock_guard<std::mutex> g(m); idle.push_back(b); }
+};
+PinnedPool& pinned_pool() { static PinnedPool* p = new PinnedPool(); return *p; }
+
+struct BatchFile {                    // what a worker leaves behind for one file
+    int rc = GAMUT_HIP_OK; char msg[160] = { 0 };
+    bool uploaded = false, batched = false;   // inflated stream in the device arena; de-filter goes into a batched launch
+    PngHeader h;                      // (idata released)
+    uint32_t raw_len = 0, need = 0; int out_n = 0, bits = 8, channels_in_file = 0;
+};
+
 } // namespace
 } // namespace gamut
 
@@ -371,7 +391,11 @@ uint16_t* gamut_hip_stbi_load_16_from_memory(const uint8_t* data, size_t len, in
     return (uint16_t*)r;
 }
 
-// Batch: parse + inflate on host threads, one file each; the GPU stages per file on `stream`, results left in HBM.
+// Batch: chunk walk + inflate on host threads, one file per thread at a time, into pinned memory; the inflated stream goes
+// to a device arena at once (copy stream).  Files that need nothing but de-filter + expand -- not interlaced, no palette,
+// no tRNS, channel count and depth as asked -- are then de-filtered TOGETHER, one launch per geometry with one workgroup per
+// image (a 4K image alone occupies one CU for 4.5 ms; 64 of them side by side take about as long).  The others run the
+// whole of stbi__do_png on their worker's own stream right away.
 int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* len, int count, int req_comp, int bits,
                                       const int64_t* out_offset, uint8_t* out, gamut_hip_png_info* info, int* status_host,
                                       int threads, void* stream)
@@ -380,45 +404,150 @@ int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* 
     if (count < 0 || (count > 0 && (!data || !len || !out_offset || !out || !info)) || req_comp < 0 || req_comp > 4 || (bits != 0 && bits != 8 && bits != 16))
         return set_error(GAMUT_HIP_ERR_INVALID_ARG, "png_decode_batch_device: bad arguments");
     if (count == 0) return GAMUT_HIP_OK;
-    int ndev = 0;
+    int ndev = 0, dev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return set_error(GAMUT_HIP_ERR_NO_DEVICE, "no HIP device available (libgamut_hip has no CPU fallback)");
+    (void)hipGetDevice(&dev);
     try {
         if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
         threads = threads < 1 ? 1 : threads > count ? count : threads;
-        std::vector<PngJob> jobs((size_t)count);
+        hipStream_t st = pick_stream(stream);
+        static thread_local hipStream_t copy_stream = nullptr;
+        if (!copy_stream) GAMUT_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+
+        // 0. IHDR of every file: a slot in the device arena for its inflated stream
+        std::vector<BatchFile> files((size_t)count);
+        std::vector<int64_t> slot((size_t)count, -1), slot_bytes((size_t)count, 0);
+        int64_t arena_bytes = 0;
+        for (int i = 0; i < count; ++i) {
+            PngHeader h;
+            if (parse(data[i], len[i], h, true)) continue;                       // the worker reports the error
+            const uint64_t wb = ((uint64_t)h.img_n * h.x * (uint32_t)h.depth + 7) >> 3, room = (wb + 8) * h.y + 64;      // Adam7: <= 15/8 y rows, each with a filter byte and a rounded-up last byte
+            if (room > 0xFFFFFF00ull) continue;
+            slot[(size_t)i] = arena_bytes; slot_bytes[(size_t)i] = (int64_t)room; arena_bytes += (int64_t)((room + 255) & ~(uint64_t)255);
+        }
+        clear_error();
+        static thread_local DeviceScratch arena;
+        uint8_t* d_arena = arena_bytes ? (uint8_t*)arena.get((size_t)arena_bytes) : nullptr;
+        if (arena_bytes && !d_arena) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png: device arena of %lld bytes failed", (long long)arena_bytes);
+
+        // 1. workers: chunk walk + inflate into the worker's pinned buffer, stream to the arena
+        const bool trace = getenv("GAMUT_HIP_TRACE") != nullptr;
+        const auto t_begin = std::chrono::steady_clock::now();
+        auto ms_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+        std::atomic<int64_t> us_inflate{ 0 }, us_upload{ 0 };
         std::atomic<int> next{ 0 };
         auto work = [&]() {
+            (void)hipSetDevice(dev);
+            HostBuf buf = pinned_pool().take();
+            hipEvent_t copied = nullptr;
+            (void)hipEventCreateWithFlags(&copied, hipEventDisableTiming);
             for (int i; (i = next.fetch_add(1, std::memory_order_relaxed)) < count; ) {
-                PngJob& j = jobs[(size_t)i];
-                if (png_prepare(data[i], len[i], j) != GAMUT_HIP_OK) snprintf(j.msg, sizeof(j.msg), "image %d: %s", i, last_error_buf());
-            }
-        };
-        std::vector<std::thread> pool;
-        try { for (int t = 1; t < threads; ++t) pool.emplace_back(work); } catch (...) {}
-        work();
-        for (std::thread& th : pool) th.join();
-
-        int first = GAMUT_HIP_OK; char first_msg[200] = { 0 };
-        hipStream_t st = pick_stream(stream);
-        for (int i = 0; i < count; ++i) {
-            PngJob& j = jobs[(size_t)i];
-            memset(&info[i], 0, sizeof(info[i]));
-            int rc = j.rc;
-            if (rc == GAMUT_HIP_OK) {
-                int w = 0, h = 0, n = 0, b = 8;
-                if (png_run(j.h, j.raw.p, j.raw_len, req_comp, bits, out + out_offset[i], &w, &h, &n, &b, st)) {
-                    info[i].width = (uint32_t)w; info[i].height = (uint32_t)h; info[i].channels_in_file = n;
-                    info[i].channels = req_comp ? req_comp : n; info[i].bits = b;
-                    info[i].pixels_per_meter_x = j.h.ppmX; info[i].pixels_per_meter_y = j.h.ppmY; info[i].pixel_aspect_ratio = j.h.aspect;
-                } else {
-                    rc = GAMUT_HIP_ERR_DECODE;
-                    snprintf(j.msg, sizeof(j.msg), "image %d: %s", i, last_error_buf());
+                BatchFile& f = files[(size_t)i];
+                PngJob j; j.raw = buf;                                           // borrow the worker's pinned buffer
+                const auto t_in = std::chrono::steady_clock::now();
+                const int rc = png_prepare(data[i], len[i], j);
+                buf = j.raw; j.raw = HostBuf{};
+                us_inflate += (int64_t)(ms_since(t_in) * 1000);
+                if (rc != GAMUT_HIP_OK) { f.rc = rc; snprintf(f.msg, sizeof(f.msg), "image %d: %s", i, last_error_buf()); continue; }
+                free(j.h.idata); j.h.idata = nullptr;
+                f.h = j.h;
+                const PngHeader& h = f.h;
+                f.out_n = h.img_n;
+                if ((req_comp == h.img_n + 1 && req_comp != 3 && !h.pal_img_n) || h.has_trans) f.out_n = h.img_n + 1;      // stbdec.d:1821-1824
+                f.bits = h.depth <= 8 ? 8 : 16; f.channels_in_file = h.img_n;
+                const uint64_t wb = ((uint64_t)h.img_n * h.x * (uint32_t)h.depth + 7) >> 3, need = (wb + 1) * h.y;
+                f.need = (uint32_t)need;
+                if (slot[(size_t)i] < 0 || !copied) { f.rc = GAMUT_HIP_ERR_DECODE; snprintf(f.msg, sizeof(f.msg), "image %d: png: image too large", i); continue; }
+                f.raw_len = (uint32_t)((int64_t)j.raw_len < slot_bytes[(size_t)i] ? (int64_t)j.raw_len : slot_bytes[(size_t)i]);
+                const auto t_upl = std::chrono::steady_clock::now();
+                if (hipMemcpyAsync(d_arena + slot[(size_t)i], buf.p, f.raw_len, hipMemcpyHostToDevice, copy_stream) != hipSuccess ||
+                    hipEventRecord(copied, copy_stream) != hipSuccess || hipEventSynchronize(copied) != hipSuccess) {
+                    f.rc = GAMUT_HIP_ERR_HIP; snprintf(f.msg, sizeof(f.msg), "image %d: png: upload failed", i); continue;
                 }
+                us_upload += (int64_t)(ms_since(t_upl) * 1000);
+                f.uploaded = true;
+                f.batched = !h.interlace && !h.has_trans && !h.pal_img_n && (req_comp == 0 || req_comp == f.out_n) && (bits == 0 || bits == f.bits) && f.raw_len >= need;
             }
-            j.raw.release();
-            if (status_host) status_host[i] = rc;
-            if (rc != GAMUT_HIP_OK && first == GAMUT_HIP_OK) { first = rc; snprintf(first_msg, sizeof(first_msg), "%s", j.msg); }
+            if (copied) (void)hipEventDestroy(copied);
+            pinned_pool().give(buf);
+        };
+        {
+            std::vector<std::thread> pool;
+            try { for (int t = 1; t < threads; ++t) pool.emplace_back(work); } catch (...) {}
+            work();
+            for (std::thread& th : pool) th.join();
+        }
+        clear_error();
+        GAMUT_HIP_CHECK(hipStreamSynchronize(copy_stream));                       // (every worker waited for its own copies already)
+        const double ms_workers = ms_since(t_begin);
+
+        // 2. one de-filter launch per geometry
+        std::map<std::tuple<uint32_t, uint32_t, int, int, int, int>, std::vector<int>> groups;
+        bool aligned = ((uintptr_t)out % 4) == 0;
+        int n_batched = 0;
+        for (int i = 0; i < count; ++i) {
+            const BatchFile& f = files[(size_t)i];
+            if (!f.batched) continue;
+            groups[std::make_tuple(f.h.x, f.h.y, f.h.img_n, f.out_n, f.h.depth, f.h.color)].push_back(i);
+            aligned = aligned && (out_offset[i] % 4) == 0;
+            ++n_batched;
+        }
+        std::vector<uint32_t> status((size_t)n_batched, 0);
+        std::vector<int> order; order.reserve((size_t)n_batched);
+        int launch_rc = GAMUT_HIP_OK;
+        if (n_batched) {
+            std::vector<int64_t> offs((size_t)n_batched * 2);
+            for (auto& g : groups) for (int i : g.second) { offs[order.size()] = slot[(size_t)i]; offs[(size_t)n_batched + order.size()] = out_offset[i]; order.push_back(i); }
+            static thread_local DeviceScratch tables;
+            const size_t o_status = (size_t)n_batched * 16;
+            uint8_t* d_tab = (uint8_t*)tables.get(o_status + (size_t)n_batched * 4);
+            if (!d_tab) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png: table allocation failed");
+            GAMUT_HIP_CHECK(hipMemcpyAsync(d_tab, offs.data(), offs.size() * 8, hipMemcpyHostToDevice, st));
+            GAMUT_HIP_CHECK(hipMemsetAsync(d_tab + o_status, 0, (size_t)n_batched * 4, st));
+            size_t base = 0;
+            for (auto& g : groups) {
+                const BatchFile& f = files[(size_t)g.second[0]];
+                const int n = (int)g.second.size();
+                const int rc = png_defilter_launch(d_arena, 0, f.need, out, 0, f.h.x, f.h.y, f.h.img_n, f.out_n, f.h.depth, f.h.color, n,
+                                                   (uint32_t*)(d_tab + o_status) + base, st,
+                                                   (const int64_t*)d_tab + base, (const int64_t*)d_tab + n_batched + base, aligned);
+                if (rc != GAMUT_HIP_OK && launch_rc == GAMUT_HIP_OK) {
+                    launch_rc = rc;
+                    for (int i : g.second) { files[(size_t)i].rc = rc; snprintf(files[(size_t)i].msg, sizeof(files[(size_t)i].msg), "image %d: %s", i, last_error_buf()); }
+                }
+                base += (size_t)n;
+            }
+            GAMUT_HIP_CHECK(hipMemcpyAsync(status.data(), d_tab + o_status, (size_t)n_batched * 4, hipMemcpyDeviceToHost, st));
+            GAMUT_HIP_CHECK(hipStreamSynchronize(st));
+            for (size_t k = 0; k < order.size(); ++k)
+                if (status[k] && files[(size_t)order[k]].rc == GAMUT_HIP_OK) {
+                    files[(size_t)order[k]].rc = GAMUT_HIP_ERR_DECODE; snprintf(files[(size_t)order[k]].msg, sizeof(files[(size_t)order[k]].msg), "image %d: png: invalid filter", order[k]);
+                }
+        }
+        // 3. the others (interlaced, palette, tRNS, channel or depth conversion): the whole of stbi__do_png per file, from the arena
+        for (int i = 0; i < count; ++i) {
+            BatchFile& f = files[(size_t)i];
+            if (f.rc != GAMUT_HIP_OK || !f.uploaded || f.batched) continue;
+            int w = 0, hh = 0, n = 0, b = 8;
+            if (png_run(f.h, nullptr, f.raw_len, req_comp, bits, out + out_offset[i], &w, &hh, &n, &b, st, d_arena + slot[(size_t)i])) { f.channels_in_file = n; f.bits = b; }
+            else { f.rc = GAMUT_HIP_ERR_DECODE; snprintf(f.msg, sizeof(f.msg), "image %d: %s", i, last_error_buf()); }
+        }
+        clear_error();
+        if (trace) fprintf(stderr, "[gamut_hip] png_decode_batch_device: %d files on %d threads: workers %.1f ms (per file: chunk walk + inflate %.1f ms, upload + wait %.1f ms), GPU stages %.1f ms (%d files in %d batched launches)\n",
+                           count, threads, ms_workers, us_inflate.load() / 1000.0 / count, us_upload.load() / 1000.0 / count, ms_since(t_begin) - ms_workers, n_batched, (int)groups.size());
+        // 4. results
+        int first = GAMUT_HIP_OK; char first_msg[200] = { 0 };
+        for (int i = 0; i < count; ++i) {
+            const BatchFile& f = files[(size_t)i];
+            memset(&info[i], 0, sizeof(info[i]));
+            if (f.rc == GAMUT_HIP_OK) {
+                info[i].width = f.h.x; info[i].height = f.h.y; info[i].channels_in_file = f.channels_in_file;
+                info[i].channels = req_comp ? req_comp : f.channels_in_file; info[i].bits = f.bits;
+                info[i].pixels_per_meter_x = f.h.ppmX; info[i].pixels_per_meter_y = f.h.ppmY; info[i].pixel_aspect_ratio = f.h.aspect;
+            }
+            if (status_host) status_host[i] = f.rc;
+            if (f.rc != GAMUT_HIP_OK && first == GAMUT_HIP_OK) { first = f.rc; snprintf(first_msg, sizeof(first_msg), "%s", f.msg); }
         }
         if (first != GAMUT_HIP_OK) return set_error(first, "%s", first_msg);
         return GAMUT_HIP_OK;

@@ -374,6 +374,12 @@ def main():
             v, sample = cpu_leg(args.cpu_seconds * 0.6)
             res["cpu_baseline"] = {"value": round(v, 2), "unit": "Mpx/s", "cores": 1, "kind": "port", "sample": sample}
             ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            try:                                                 # a cgroup CPU quota is the real number of cores this process gets
+                quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+                if quota != "max":
+                    ncores = max(1, min(ncores, int(int(quota) / int(period))))
+            except Exception:
+                pass
             if ncores > 1:
                 from concurrent.futures import ThreadPoolExecutor
                 with ThreadPoolExecutor(ncores) as pool:

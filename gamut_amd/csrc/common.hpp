@@ -6,6 +6,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <thread>
+#include <vector>
 #include "../../include/gamut_hip.h"
 
 namespace gamut {
@@ -51,6 +54,17 @@ struct PinnedScratch {                  // page-locked host memory: uploads from
         return p;
     }
 };
+
+// fn(worker, index) for index in [0, count) on `workers` host threads (the caller is worker 0); dynamic distribution
+template <class Fn> void parallel_for(int count, int workers, Fn fn)          // fn(worker, index); the caller runs worker 0
+{
+    std::atomic<int> next{ 0 };
+    auto run = [&](int w) { for (int i; (i = next.fetch_add(1, std::memory_order_relaxed)) < count; ) fn(w, i); };
+    std::vector<std::thread> pool;
+    try { for (int w = 1; w < workers; ++w) pool.emplace_back(run, w); } catch (...) {}
+    run(0);
+    for (std::thread& th : pool) th.join();
+}
 
 #define GAMUT_HIP_CHECK(expr)                                                                 \
     do {                                                                                      \

@@ -934,16 +934,6 @@ void unstuff_file(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& f,
 }
 
 
-template <class Fn> void parallel_for(int count, int workers, Fn fn)          // fn(worker, index); the caller runs worker 0
-{
-    std::atomic<int> next{ 0 };
-    auto run = [&](int w) { for (int i; (i = next.fetch_add(1, std::memory_order_relaxed)) < count; ) fn(w, i); };
-    std::vector<std::thread> pool;
-    try { for (int w = 1; w < workers; ++w) pool.emplace_back(run, w); } catch (...) {}
-    run(0);
-    for (std::thread& th : pool) th.join();
-}
-
 int entropy_decode_device(const uint8_t* const* data, const size_t* len, int count,
                           const int64_t* coeff_offset, const int64_t* zag_offset,
                           int16_t* d_coeffs, uint8_t* d_max_zag, uint32_t* d_status,

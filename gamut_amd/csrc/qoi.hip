@@ -157,25 +157,39 @@ int launch_items(const std::vector<QoiItem>& items, uint8_t* d_items, const uint
 int decode_batch(const uint8_t* const* data, const int* size, int count, int channels, const int64_t* out_offset, uint8_t* d_out,
                  gamut_hip_qoi_desc* descs, int* status_host, hipStream_t stream)
 {
-    std::vector<QoiItem> items; std::vector<uint8_t> blob;
+    std::vector<QoiItem> items; std::vector<int> src; size_t blob_size = 0;
     int first = GAMUT_HIP_OK, first_idx = -1;
     for (int i = 0; i < count; ++i) {
         const int rc = read_header(data[i], size[i], &descs[i], channels);
         if (status_host) status_host[i] = rc;
         if (rc != GAMUT_HIP_OK) { if (first == GAMUT_HIP_OK) { first = rc; first_idx = i; } continue; }
-        QoiItem it{}; it.begin = blob.size(); it.out_off = out_offset[i]; it.size = (uint32_t)size[i];
+        QoiItem it{}; it.begin = blob_size; it.out_off = out_offset[i]; it.size = (uint32_t)size[i];
         it.npx = descs[i].width * descs[i].height; it.channels = channels ? channels : descs[i].channels;
-        items.push_back(it);
-        blob.insert(blob.end(), data[i], data[i] + size[i]);
-        blob.insert(blob.end(), kQoiSlack, (uint8_t)0);         // the lane's reader fetches whole 64-byte blocks
+        items.push_back(it); src.push_back(i);
+        blob_size += ((size_t)size[i] + kQoiSlack + 15) & ~(size_t)15;   // the lane's reader fetches whole 64-byte blocks: slack after every stream
     }
     if (!items.empty()) {
-        const size_t o_blob = (items.size() * sizeof(QoiItem) + 255) & ~(size_t)255, total = o_blob + blob.size();
+        const size_t o_blob = (items.size() * sizeof(QoiItem) + 255) & ~(size_t)255, total = o_blob + blob_size;
         static thread_local DeviceScratch staging;
+        static thread_local PinnedScratch pinned;
         uint8_t* d = (uint8_t*)staging.get(total);
-        if (!d) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "qoi: device staging allocation of %zu bytes failed", total);
-        GAMUT_HIP_CHECK(hipMemcpyAsync(d + o_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, stream));
-        if (int rc = launch_items(items, d, d + o_blob, d_out, stream)) return rc;
+        uint8_t* h = pinned.get(total);
+        if (!d || !h) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "qoi: staging allocation of %zu bytes failed", total);
+        // the files are gathered into one pinned image on a few host threads and go up in one DMA
+        int workers = (int)std::thread::hardware_concurrency();
+        workers = workers < 1 ? 1 : workers > 16 ? 16 : workers;
+        if ((size_t)workers > blob_size / (4u << 20) + 1) workers = (int)(blob_size / (4u << 20) + 1);
+        parallel_for((int)items.size(), workers, [&](int, int k) {
+            uint8_t* dst = h + o_blob + items[(size_t)k].begin;
+            memcpy(dst, data[src[(size_t)k]], items[(size_t)k].size);
+            memset(dst + items[(size_t)k].size, 0, kQoiSlack);
+        });
+        memcpy(h, items.data(), items.size() * sizeof(QoiItem));
+        GAMUT_HIP_CHECK(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, stream));
+        const int n = (int)items.size();
+        hipLaunchKernelGGL(k_qoi_decode, dim3((n + 63) / 64), dim3(64), 0, stream, (const QoiItem*)d, n, (const uint8_t*)(d + o_blob), d_out);
+        if (int rc = launch_status("qoi_decode")) return rc;
+        GAMUT_HIP_CHECK(hipStreamSynchronize(stream));         // the per-thread staging buffers are reused by the next call
     }
     if (first != GAMUT_HIP_OK) return set_error(first, "image %d: qoi: bad header or arguments", first_idx);
     return GAMUT_HIP_OK;

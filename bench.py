@@ -46,18 +46,24 @@ def parse():
     return ap.parse_args()
 
 
-def traffic_from_profiles(kernel_substr):
-    """HBM bytes per image from the committed rocprofv3 --pmc summary (profiles/*traffic*.json), or None."""
+def traffic_from_profiles(workload, kernel_substr):
+    """HBM bytes per image from the committed rocprofv3 --pmc summary of THIS workload (profiles/<tag>_bench.json names the
+    workload, <tag>_traffic.json holds the counters), or None when the workload has not been profiled."""
     import glob
-    best = None
-    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
+    import re
+    norm = lambda w: re.sub(r"^batch \d+ x |, \d+ layers of ", "|", w)
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench.json"))):
         try:
-            for row in json.load(open(p)).get("kernels", []):
-                if kernel_substr in row.get("kernel", "") and row.get("hbm_bytes_per_image"):
-                    best = row["hbm_bytes_per_image"]
+            line = [ln for ln in open(p).read().splitlines() if ln.startswith("{")][-1]
+            if norm(json.loads(line)["config"]["workload"]) != norm(workload):
+                continue
+            rows = json.load(open(p[:-len("_bench.json")] + "_traffic.json")).get("kernels", [])
+            rows = [r for r in rows if kernel_substr.split(" + ")[0] in r.get("kernel", "") and r.get("hbm_bytes_per_image")]
+            if rows:
+                return max(r["hbm_bytes_per_image"] for r in rows)
         except Exception:
             pass
-    return best
+    return None
 
 
 def main():
@@ -357,7 +363,7 @@ def main():
             "dtype": dtype, "data": "synthetic",
             "config": {"workload": workload, "images_per_gpu_per_step": B, "sharding": "image-index, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": (lambda t: None if t is None else round(t * B))(traffic_from_profiles(kernel_name)),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": (lambda t: None if t is None else round(t * B))(traffic_from_profiles(workload, kernel_name)),
                          "kernel": kernel_name, "algorithmic_bytes_per_launch": bytes_per_step,
                          "kernel_ms_avg": round(avg_kernel_s * 1e3, 4), "kernel_ms_min": round(min(kern_ms), 4)},
         }

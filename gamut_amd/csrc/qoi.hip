@@ -18,26 +18,56 @@ struct QoiItem { uint64_t begin; int64_t out_off; uint32_t size, npx; int32_t ch
 
 // A lane must not touch global memory per pixel: every wait for a load also waits for the stores issued before it (one
 // in-order counter), so byte-wise loads and per-pixel stores made a lane sit out a memory round trip several times per
-// pixel (1.3 us per pixel measured).  Each lane therefore owns, in LDS, a 128-byte window of its stream (two 64-byte
-// blocks) and a 64-pixel output buffer; the state machine itself only talks to registers and LDS:
-//   * all three LDS arrays are dword-interleaved over the lanes ([slot][lane]), so the 64 lanes of a wave always hit 64
-//     different banks (a lane-major layout put every lane's pixel write on the same bank);
-//   * the next 5..8 stream bytes sit in a 64-bit register, topped up from a dword that was read from the window one
+// pixel (1.3 us per pixel measured).  And it must not branch on the op: the six op kinds of 64 unrelated streams put
+// every branch on the wave's path in nearly every iteration (0.37 us per pixel measured with per-op branches: ~200
+// instructions, one wave per SIMD, one instruction per ~4 cycles).  So:
+//   * everything a lane touches per pixel is in registers or LDS -- the hash table, a 256-byte window of the stream and
+//     a 64-pixel output buffer, all dword-interleaved over the lanes ([slot][lane]: 64 lanes, 64 banks);
+//   * an op is decoded WITHOUT branches: its first byte indexes a 256-entry table (bytes used, run length, one bit per
+//     op kind), the candidate pixels of all kinds are computed (the DIFF / LUMA deltas come from tables too and are
+//     added bytewise, SWAR) and the right one is picked with bit-field masks; an iteration that only continues a run
+//     is the same code with a zeroed table entry;
+//   * the next 5..8 stream bytes sit in a 64-bit register topped up from a dword that was read from the window one
 //     top-up earlier, so no LDS latency is on the byte path;
-//   * the block after the window is already in flight (16 VGPRs) while the window is being consumed and is written to
-//     LDS when the older block has been used up, so the memory latency of the stream is hidden as well;
+//   * the window is refilled for the whole wave at once: when SOME lane has less than two 64-byte blocks left, every lane
+//     with a free block commits the block it has in flight (16 VGPRs) and requests the next -- a refill every ~15
+//     iterations instead of one lane or another refilling in nine iterations out of ten;
 //   * the pixel loop is uniform over the wave, so the output buffers fill up together and are flushed with dwordx4 stores.
-constexpr int kQoiWinDwords = 32, kQoiOutPx = 64;
+constexpr int kQoiWinDwords = 64, kQoiOutPx = 64;             // 4 blocks of 64 bytes per lane
 constexpr int kQoiSlack = GAMUT_HIP_QOI_SLACK;                // readable bytes guaranteed after every stream
+
+__device__ __forceinline__ uint32_t qoi_add_bytes(uint32_t x, uint32_t y)       // bytewise (x + y) mod 256
+{
+    return ((x & 0x7f7f7f7fu) + (y & 0x7f7f7f7fu)) ^ ((x ^ y) & 0x80808080u);
+}
 
 __global__ __launch_bounds__(64) void k_qoi_decode(const QoiItem* items, int n, const uint8_t* blob, uint8_t* out)
 {
     __shared__ uint32_t index[64 * 64];                       // [hash][lane]
     __shared__ uint32_t sh_in[kQoiWinDwords * 64];            // [dword of the window][lane]
     __shared__ uint32_t sh_out[kQoiOutPx * 64];               // [pixel][lane], always r|g<<8|b<<16|a<<24
+    __shared__ uint32_t optab[256];                           // first byte -> bytes used | kind bits << 3 | run << 8
+    __shared__ uint2 deltab[64];                              // low six bits -> (QOI_OP_DIFF delta, QOI_OP_LUMA green part), packed bytes
+    __shared__ uint32_t luma2[256];                           // second byte of QOI_OP_LUMA -> (dr - dg, 0, db - dg, 0) + 8 removed
+    constexpr uint32_t K_RGB = 1u << 3, K_RGBA = 1u << 4, K_INDEX = 1u << 5, K_DIFF = 1u << 6, K_LUMA = 1u << 7;
     const int lane = threadIdx.x;
     #pragma unroll 8
     for (int k = 0; k < 64; ++k) index[k * 64 + lane] = 0;    // memset(index, 0) :491  (a lane only touches its own column)
+    #pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t v = (uint32_t)(k * 64 + lane);
+        uint32_t e;
+        if (v == 0xFE) e = 4 | K_RGB; else if (v == 0xFF) e = 5 | K_RGBA;
+        else if ((v >> 6) == 0) e = 1 | K_INDEX; else if ((v >> 6) == 1) e = 1 | K_DIFF; else if ((v >> 6) == 2) e = 2 | K_LUMA;
+        else e = 1 | (v & 63) << 8;                                                            // QOI_OP_RUN
+        optab[v] = e;
+        luma2[v] = (v >> 4) | (v & 15) << 16;
+    }
+    {
+        const uint32_t k = (uint32_t)lane, vg = (k - 32) & 255, vg8 = (k - 40) & 255;          // vg = k - 32; vg - 8
+        deltab[k] = make_uint2(((((k >> 4) & 3) - 2) & 255) | ((((k >> 2) & 3) - 2) & 255) << 8 | (((k & 3) - 2) & 255) << 16, vg8 | vg << 8 | vg8 << 16);
+    }
+    __syncthreads();
     const int i = blockIdx.x * 64 + lane;
     if (i >= n) return;
     const QoiItem it = items[i];
@@ -47,7 +77,7 @@ __global__ __launch_bounds__(64) void k_qoi_decode(const QoiItem* items, int n, 
     const uint8_t* stream = blob + it.begin + kQoiHeader;      // chunks start here
     uint32_t* win = sh_in + lane;
     uint32_t* obuf = sh_out + lane;
-    uint32_t r = 0, g = 0, b = 0, a = 255;                    // :492-495
+    uint32_t px = 0xFF000000u;                                // r = g = b = 0, a = 255 :492-495
     // bytes [14, size - 8) are chunks (p < chunks_len, :498); a chunk may read up to 4 bytes further (padding / slack)
     const int chunk_bytes = (int)it.size - kQoiPadding - kQoiHeader;
     const uint32_t fetch_limit = (uint32_t)(chunk_bytes > 0 ? chunk_bytes : 0) + 5;   // no byte at or beyond this is ever decoded
@@ -70,16 +100,12 @@ __global__ __launch_bounds__(64) void k_qoi_decode(const QoiItem* items, int n, 
         w[12 * 64] = q3.x; w[13 * 64] = q3.y; w[14 * 64] = q3.z; w[15 * 64] = q3.w;
         stored += 64;
     };
-    issue(); commit(); issue(); commit(); issue();           // window = blocks 0 and 1, block 2 in flight
-    uint64_t bits = 0; int valid = 0; uint32_t ahead;         // `valid` bytes of the stream, lowest byte first; `ahead` = the dword after them
-    auto read_ahead = [&]() {
-        if (pulled + 64 == stored) { commit(); issue(); }    // the older block has been read completely: replace it
-        ahead = win[((pulled >> 2) & (kQoiWinDwords - 1)) * 64];
-        pulled += 4;
-    };
-    auto top_up = [&]() { bits |= (uint64_t)ahead << (8 * valid); valid += 4; read_ahead(); };
-    read_ahead(); top_up(); top_up();
-    uint32_t consumed = 0, flushed = 0;                       // bytes of the chunk area decoded; pixels already written out
+    issue(); commit(); issue(); commit(); issue(); commit(); issue(); commit(); issue();      // four blocks in the window, the fifth in flight
+    uint32_t lo = 0, hi = 0, ahead; int valid = 0;            // `valid` stream bytes in hi:lo, lowest byte first; `ahead` = the dword after them
+    auto read_ahead = [&]() { ahead = win[((pulled >> 2) & (kQoiWinDwords - 1)) * 64]; pulled += 4; };
+    read_ahead(); lo = ahead; read_ahead(); hi = ahead; valid = 8; read_ahead();
+    int left = chunk_bytes > 0 ? chunk_bytes : 0;             // chunk bytes not decoded yet
+    uint32_t flushed = 0;                                     // pixels already written out
     int run = 0, staged = 0;                                  // pixels waiting in obuf
     auto flush = [&](int npx) {                               // npx pixels from obuf to the image
         uint8_t* o = pixels + (size_t)flushed * bpp;
@@ -101,26 +127,54 @@ __global__ __launch_bounds__(64) void k_qoi_decode(const QoiItem* items, int n, 
         }
         flushed += (uint32_t)npx;
     };
-    for (uint32_t px = 0; px < it.npx; ++px) {
-        if (run > 0) --run;
-        else if ((int)consumed < chunk_bytes) {
-            const uint32_t lo = (uint32_t)bits, b1 = lo & 255, x1 = (lo >> 8) & 255, x2 = (lo >> 16) & 255, x3 = lo >> 24, x4 = (uint32_t)(bits >> 32) & 255;
-            int used = 1;
-            if (b1 == 0xFE)      { r = x1; g = x2; b = x3; used = 4; }                                       // QOI_OP_RGB
-            else if (b1 == 0xFF) { r = x1; g = x2; b = x3; a = x4; used = 5; }                              // QOI_OP_RGBA
-            else if ((b1 & 0xC0) == 0x00) { const uint32_t v = index[b1 * 64 + lane]; r = v & 255; g = (v >> 8) & 255; b = (v >> 16) & 255; a = v >> 24; }
-            else if ((b1 & 0xC0) == 0x40) { r = (r + ((b1 >> 4) & 3) - 2) & 255; g = (g + ((b1 >> 2) & 3) - 2) & 255; b = (b + (b1 & 3) - 2) & 255; }
-            else if ((b1 & 0xC0) == 0x80) {
-                const int vg = (int)(b1 & 0x3f) - 32; used = 2;
-                r = (r + vg - 8 + ((x1 >> 4) & 0x0f)) & 255; g = (g + vg) & 255; b = (b + vg - 8 + (x1 & 0x0f)) & 255;
-            } else run = (int)(b1 & 0x3f);                                                                 // QOI_OP_RUN
-            consumed += (uint32_t)used;
-            bits >>= 8 * used; valid -= used;
-            if (valid < 5) top_up();
-            if (valid < 5) top_up();                                                                        // only after a 5-byte chunk that left nothing
-            index[((r * 3 + g * 5 + b * 7 + a * 11) & 63) * 64 + lane] = r | g << 8 | b << 16 | a << 24;    // QOI_COLOR_HASH :239-242
+    for (uint32_t p = 0; p < it.npx; ++p) {
+        // window refill for the whole wave at once
+        if (__any((int)(stored - pulled) <= 128)) {
+            if (stored - (pulled & ~63u) < 4 * 64) { commit(); issue(); }         // a block of the lane's window has been read completely
         }
-        obuf[staged * 64] = r | g << 8 | b << 16 | a << 24;
+        // one op, or one more pixel of a run: table entry zeroed when no op is decoded (run going on, or the chunks are used up)
+        const uint32_t b1 = lo & 255u;
+        uint32_t e = optab[b1];
+        e = (run == 0 && left > 0) ? e : 0u;
+        const uint32_t iv = index[(b1 & 63u) * 64 + lane];
+        const uint2 dl = deltab[b1 & 63u];
+        const uint32_t l2 = luma2[(lo >> 8) & 255u];
+        const uint32_t c_rgba = __builtin_amdgcn_alignbit(hi, lo, 8);                                   // stream bytes 1..4
+        const uint32_t c_diff = qoi_add_bytes(px, dl.x);
+        const uint32_t c_luma = qoi_add_bytes(px, qoi_add_bytes(dl.y, l2));
+        auto pick = [](uint32_t mask, uint32_t yes, uint32_t no) { return (yes & mask) | (no & ~mask); };     // v_bfi_b32
+        uint32_t v = px;
+        v = pick((uint32_t)(((int32_t)(e << 28)) >> 31) & 0x00FFFFFFu, c_rgba, v);                     // QOI_OP_RGB keeps alpha
+        v = pick((uint32_t)(((int32_t)(e << 27)) >> 31), c_rgba, v);                                   // QOI_OP_RGBA
+        v = pick((uint32_t)(((int32_t)(e << 26)) >> 31), iv, v);                                       // QOI_OP_INDEX
+        v = pick((uint32_t)(((int32_t)(e << 25)) >> 31), c_diff, v);                                   // QOI_OP_DIFF
+        v = pick((uint32_t)(((int32_t)(e << 24)) >> 31), c_luma, v);                                   // QOI_OP_LUMA
+        px = v;
+        const int used = (int)(e & 7u);
+        run = (run > 0 ? run - 1 : 0) + (int)((e >> 8) & 63u);
+        left -= used;
+        // consume `used` bytes; top the register up to >= 5 bytes again
+        {
+            const uint64_t bits = ((uint64_t)hi << 32 | lo) >> (8 * used);
+            lo = (uint32_t)bits; hi = (uint32_t)(bits >> 32); valid -= used;
+        }
+        {
+            const bool need = valid < 5;
+            const uint64_t add = (uint64_t)ahead << (8 * (valid & 7));
+            lo |= need ? (uint32_t)add : 0u; hi |= need ? (uint32_t)(add >> 32) : 0u;
+            valid += need ? 4 : 0;
+            const uint32_t nxt = win[((pulled >> 2) & (kQoiWinDwords - 1)) * 64];
+            ahead = need ? nxt : ahead; pulled += need ? 4u : 0u;
+        }
+        if (__any(valid < 5)) {                               // only after a 5-byte chunk that left nothing
+            if (valid < 5) {
+                const uint64_t add = (uint64_t)ahead << (8 * valid);
+                lo |= (uint32_t)add; hi |= (uint32_t)(add >> 32); valid += 4;
+                read_ahead();
+            }
+        }
+        index[(__builtin_amdgcn_udot4(px, 0x0B070503u, 0u, false) & 63u) * 64 + lane] = px;                 // QOI_COLOR_HASH :239-242 (r*3 + g*5 + b*7 + a*11)
+        obuf[staged * 64] = px;
         if (++staged == kQoiOutPx) { flush(kQoiOutPx); staged = 0; }
     }
     if (staged) flush(staged);

@@ -247,6 +247,32 @@ def test_png_file_batch_feeder(hip):
     assert hip.gamut_hip_png_read_header(ptrs[4], lens[4], C.byref(hd)) == 0 and (hd.width, hd.height, hd.bits, hd.channels) == (w, h, 16, 4)
 
 
+def test_png_file_batch_same_geometry_groups(hip):
+    """files of one geometry are de-filtered in ONE launch through per-image offset tables (RGB8 -> rgba8: the alpha-inserting
+    ring kernel; RGBA8 as is; grey + alpha insert through the scratch + expand route), next to files of another size"""
+    rng = np.random.default_rng(33)
+    w, h = 203, 131
+    for color, ch, req in ((2, 3, 4), (6, 4, 4), (0, 1, 2), (2, 3, 3)):
+        imgs = [rng.integers(0, 256, (h, w * ch)) for _ in range(5)]
+        files = [gen.write_png(a, w, h, color, 8) for a in imgs] + [gen.write_png(rng.integers(0, 256, (9, 40 * ch)), 40, 9, color, 8)]
+        files = files[:3] + files[5:] + files[3:5]                                   # the odd one in the middle
+        n = len(files)
+        bufs = [np.frombuffer(f, np.uint8) for f in files]
+        ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs]); lens = (C.c_size_t * n)(*[b.size for b in bufs])
+        exp = [np.ascontiguousarray(O.stbi_load(f, req, False)[0]).view(np.uint8).reshape(-1) for f in files]
+        for pad in (0, 1):                                                           # dword-aligned slots, then odd offsets
+            sizes = [((e.size + 3) & ~3) + pad for e in exp]
+            offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+            dout = up(hip, np.full(int(sum(sizes)) + 64, 0xA5, np.uint8))
+            info = (_capi.PngInfo * n)(); st = (C.c_int * n)()
+            _capi.check(hip.gamut_hip_png_decode_batch_device(ptrs, lens, n, req, 8, offs.ctypes.data_as(C.POINTER(C.c_int64)), dout, info, st, 4, None))
+            host = down(hip, dout, int(sum(sizes)) + 64)
+            hip.gamut_hip_device_free(dout)
+            for i, e in enumerate(exp):
+                assert st[i] == 0 and np.array_equal(host[offs[i]:offs[i] + e.size], e), (color, req, pad, i)
+                assert (host[offs[i] + e.size:offs[i] + sizes[i]] == 0xA5).all(), "wrote past the image"
+
+
 def test_files_written_by_libpng(hip):
     """real encoder output (Pillow / libpng: adaptive row filters, several zlib levels, palette, 1-bit, 16-bit grey) through
     the drop-in loader == the oracle == the pixels Pillow started from"""

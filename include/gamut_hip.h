@@ -157,7 +157,9 @@ int  gamut_hip_jpeg_read_header(const uint8_t* data, size_t len, gamut_hip_jpeg_
  * Host only; the same preparation code gamut_hip_jpeg_entropy_decode_device runs per file. */
 int  gamut_hip_jpeg_scan_layout(const uint8_t* data, size_t len, gamut_hip_jpeg_frame* info, int32_t* segments, uint64_t* entropy_bytes);
 /* Entropy decode ON THE DEVICE of `count` baseline files given in host memory: the compressed
- * scans are uploaded as they are and one lane per image -- per restart interval where the file has them -- writes the
+ * scans are uploaded (unstuffed on host threads straight into pinned memory, DMA on a private copy stream overlapped with
+ * the decode of the files already there) and a workgroup of self-synchronising lanes per scan -- a lane per restart
+ * interval where the file has short ones -- writes the
  * dense de-quantised coefficient form (what decode_next_row, jpegload.d:2405-2525, leaves per MCU row) into
  * coeffs[coeff_offset[i] ..] (int16 elements) and max_zag[zag_offset[i] ..] (device pointers, caller-sized from
  * gamut_hip_jpeg_read_header).  info[i] receives the geometry (host), status_host[i] (may be NULL) the per-file header
@@ -226,8 +228,9 @@ typedef struct gamut_hip_png_info {
 /* IHDR only (host): width, height, bit depth class and the channel count implied by the colour type */
 int gamut_hip_png_read_header(const uint8_t* data, size_t len, gamut_hip_png_info* info);
 /* `count` PNG files in host memory -> pixels at out + out_offset[i] (device): chunk walk + inflate on up to `threads` host
- * threads (<= 0: one per hardware thread; the inflate is what bounds a PNG pipeline), then the whole of stbi__do_png per
- * file on the GPU.  req_comp as in stbi_load (0 = as in the file), bits = 8 / 16 as stbi_load / stbi_load_16 convert, 0 = as
+ * threads (<= 0: one per hardware thread; the inflate is what bounds a PNG pipeline), the inflated streams going to the
+ * device as they finish; then the rest of stbi__do_png on the GPU -- files that only need de-filter + expand are
+ * de-filtered together, one launch per geometry (one workgroup per image), the others stage by stage per file.  req_comp as in stbi_load (0 = as in the file), bits = 8 / 16 as stbi_load / stbi_load_16 convert, 0 = as
  * in the file.  info[i] / status_host[i] (may be NULL) per file; returns the status of the lowest-numbered failing file. */
 int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* len, int count, int req_comp, int bits,
                                       const int64_t* out_offset, uint8_t* out, gamut_hip_png_info* info, int* status_host,

@@ -32,7 +32,10 @@ namespace {
 
 typedef uint32_t u32;
 
-constexpr int PNG_WAVES = 8;           // waves per workgroup (= bands in flight per image); the ring kernel's LDS allows one workgroup per CU
+#ifndef PNG_WAVES_N
+#define PNG_WAVES_N 8
+#endif
+constexpr int PNG_WAVES = PNG_WAVES_N;           // waves per workgroup (= bands in flight per image); the ring kernel's LDS allows one workgroup per CU
 constexpr int PUB = 8;                 // publish / check progress every PUB iterations (32 filter units)
 constexpr int PF = 4;                  // loop trips of row data kept in flight per lane
 constexpr int PUBLAG = 4;              // progress is published PUBLAG trips after the store it covers (see defilter_band)

@@ -62,6 +62,7 @@ constexpr int LDS_INTS = T1_INTS + H_INTS + V_INTS;
 __device__ __forceinline__ constexpr int phys_slot(int m) { constexpr int P[8] = { 0, 2, 1, 3, 6, 4, 7, 5 }; return P[m]; }
 
 struct MapCoef { i32 a[4], b[4]; };
+__device__ const i32 kMapTable[2][8] __attribute__((aligned(32))) = { { E1a, E1b, E1c, E1d, E3a, E3b, E3c, E3d }, { O0a, O0b, O0c, O0d, O2a, O2b, O2c, O2d } };
 struct __attribute__((packed, aligned(1))) Dwords4u { u32 v[4]; };      // 16 bytes at any alignment (gfx950 stores them natively)
 
 // Every LDS hand-off of the tuned kernel stays inside one 32-lane half of a wave (thread t only ever reads tiles
@@ -116,14 +117,20 @@ __global__ __launch_bounds__(256) void k_jpeg_h2v2(JpegArgs a)
     // ---- mapping B: thread = (chroma block cb = (mcu, comp), row k, half) ----
     const int cbk = t >> 4, k = (t >> 1) & 7, half = t & 1;
     const bool cmcu_live = (cbk >> 1) < mcus_here;
+    // the lane's 8 multipliers: two 16-byte loads from a constant table (selecting them one by one costs three VALU
+    // instructions each on a kernel that is bound by VALU issue)
     MapCoef mc;
-    mc.a[0] = half ? O0a : E1a; mc.a[1] = half ? O0b : E1b; mc.a[2] = half ? O0c : E1c; mc.a[3] = half ? O0d : E1d;
-    mc.b[0] = half ? O2a : E3a; mc.b[1] = half ? O2b : E3b; mc.b[2] = half ? O2c : E3c; mc.b[3] = half ? O2d : E3d;
+    {
+        const int4* tab = reinterpret_cast<const int4*>(kMapTable[half]);
+        const int4 ta = tab[0], tb = tab[1];
+        mc.a[0] = ta.x; mc.a[1] = ta.y; mc.a[2] = ta.z; mc.a[3] = ta.w;
+        mc.b[0] = tb.x; mc.b[1] = tb.y; mc.b[2] = tb.z; mc.b[3] = tb.w;
+    }
 
-    // P0: loads (issued together; 16 B per lane, lane-contiguous inside each MCU)
-    uint4 yrow = make_uint4(0, 0, 0, 0), crow = make_uint4(0, 0, 0, 0);
-    if (mcu_live)  yrow = load_coeffs16(cbase + (u32)(m * 384 + q * 64 + r * 8));
-    if (cmcu_live) crow = load_coeffs16(cbase + (u32)((cbk >> 1) * 384 + 256 + (cbk & 1) * 64 + k * 8));
+    // P0: loads (issued together; 16 B per lane, lane-contiguous inside each MCU).  Lanes of MCUs beyond the edge of the image
+    // re-read the strip's first MCU (there is always one): their results are never stored, and nothing has to be zeroed.
+    const uint4 yrow = load_coeffs16(cbase + (u32)((mcu_live ? m : 0) * 384 + q * 64 + r * 8));
+    const uint4 crow = load_coeffs16(cbase + (u32)((cmcu_live ? (cbk >> 1) : 0) * 384 + 256 + (cbk & 1) * 64 + k * 8));
 
     // P1a: luma pass 1 (row r of block b) -> T1[b][r][0..7]
     {
@@ -213,6 +220,7 @@ __global__ __launch_bounds__(256) void k_jpeg_h2v2(JpegArgs a)
         for (int i = 0; i < 4; ++i) tc[i] = src[(4 + i) * 8];
         col_pass<4>(tc, crs);
 
+        const ColourConsts cc = colour_consts();
         const int lx = m * 16 + (q & 1) * 8 + r;               // pixel column inside the strip
         const int ly0 = (q >> 1) * 8;                          // first pixel row inside the strip
         const bool px_live = mcu_live && mcu_x0 * 16 + lx < a.width;
@@ -228,12 +236,12 @@ __global__ __launch_bounds__(256) void k_jpeg_h2v2(JpegArgs a)
                 if (all_rows) {
                     #pragma unroll
                     for (int i = 0; i < 8; ++i, voff += pitch)
-                        __builtin_nontemporal_store(ycc_to_rgba(ys[i], cbs[i], crs[i]), reinterpret_cast<u32*>(obase + voff));
+                        __builtin_nontemporal_store(ycc_to_rgba(ys[i], cbs[i], crs[i], cc.kr, cc.kb), reinterpret_cast<u32*>(obase + voff));
                 } else {
                     #pragma unroll
                     for (int i = 0; i < 8; ++i, voff += pitch)
                         if (i < rows_here)
-                            __builtin_nontemporal_store(ycc_to_rgba(ys[i], cbs[i], crs[i]), reinterpret_cast<u32*>(obase + voff));
+                            __builtin_nontemporal_store(ycc_to_rgba(ys[i], cbs[i], crs[i], cc.kr, cc.kb), reinterpret_cast<u32*>(obase + voff));
                 }
             }
         } else {
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(256) void k_jpeg_h2v2(JpegArgs a)
             __syncthreads();                                       // other waves may still be reading V in P3
             #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const u32 px = ycc_to_rgba(ys[i], cbs[i], crs[i]);
+                const u32 px = ycc_to_rgba(ys[i], cbs[i], crs[i], cc.kr, cc.kb);
                 if constexpr (OC == 3) {
                     const u32 sel = j == 0 ? 0x04020100u : j == 1 ? 0x05040201u : 0x06050402u;
                     const u32 nx = (u32)__builtin_amdgcn_mov_dpp((int)px, 0xF9, 0xF, 0xF, true);      // quad_perm [1,2,3,3]: right neighbour

@@ -135,13 +135,23 @@ constexpr int CFIX(float x) { return (int)(x * 65536.0f + 0.5f); }
 constexpr int C_CRR = CFIX(1.40200f), C_CBB = CFIX(1.77200f), C_CRG = -CFIX(0.71414f), C_CBG = -CFIX(0.34414f);
 static_assert(C_CRR == 91881 && C_CBB == 116130 && C_CRG == -46802 && C_CBG == -22554, "FIX() constants");
 
+// The two addends of the single multiply-adds below, pinned in vector registers: a multiply-add (VOP3) can name one scalar
+// constant only, and left to itself the compiler re-materialises the other one with a v_mov in front of every pixel.
+struct ColourConsts { i32 kr, kb; };
+__device__ __forceinline__ ColourConsts colour_consts()
+{
+    ColourConsts c;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(c.kr) : "s"(32768 - 128 * C_CRR));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(c.kb) : "s"(32768 - 128 * C_CBB));
+    return c;
+}
 // returns packed RGBA8 (A = 255), little-endian byte order R,G,B,A
-__device__ __forceinline__ u32 ycc_to_rgba(i32 y, i32 cb, i32 cr)
+__device__ __forceinline__ u32 ycc_to_rgba(i32 y, i32 cb, i32 cr, i32 kr = 32768 - 128 * C_CRR, i32 kb = 32768 - 128 * C_CBB)
 {
     // (c - 128) * K + 32768 == c * K + (32768 - 128 * K): the level shift rides in the addend
-    const i32 r = y + (mad24(cr, C_CRR, 32768 - 128 * C_CRR) >> 16);
+    const i32 r = y + (mad24(cr, C_CRR, kr) >> 16);
     const i32 g = y + (mad24(cr, C_CRG, mad24(cb, C_CBG, 32768 - 128 * C_CRG - 128 * C_CBG)) >> 16);
-    const i32 b = y + (mad24(cb, C_CBB, 32768 - 128 * C_CBB) >> 16);
+    const i32 b = y + (mad24(cb, C_CBB, kb) >> 16);
     // clamp + pack: r, g, b are within +-2^10, so they can be saturated as 16-bit lanes (v_sat_pk_u8_i16 does two at once)
     // and gathered with byte permutes: 4 instructions instead of 3 clamps + 3 shift/ors
     const u32 rg = __builtin_amdgcn_perm((u32)g, (u32)r, 0x05040100u);     // r.lo16 | g.lo16 << 16

@@ -53,6 +53,25 @@ template <int T, int U, int NT> __global__ __launch_bounds__(T) void k_write(u32
     for (int k = 0; k < U; ++k) { const size_t i = base + (size_t)k * T; if (i < n) { if (NT) __builtin_nontemporal_store(v, d + i); else d[i] = v; } }
 }
 
+// 16-byte loads, but the stores are SW bytes per lane (4 or 8): the k-th store instruction of a block writes a lane-contiguous
+// run of T * SW bytes (what a kernel that produces one pixel per lane per row does)
+template <int T, int SW, int NT> __global__ __launch_bounds__(T) void k_narrow_store(const u32x4* __restrict__ s, uint32_t* __restrict__ d, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * T + threadIdx.x;
+    if (i >= n) return;
+    const u32x4 v = s[i];
+    uint32_t* o = d + (size_t)blockIdx.x * T * 4;
+    if (SW == 4) {
+        #pragma unroll
+        for (int k = 0; k < 4; ++k) { if (NT) __builtin_nontemporal_store(v[k], o + k * T + threadIdx.x); else o[k * T + threadIdx.x] = v[k]; }
+    } else {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        u32x2* o2 = reinterpret_cast<u32x2*>(o);
+        #pragma unroll
+        for (int k = 0; k < 2; ++k) { const u32x2 w = { v[2 * k], v[2 * k + 1] }; if (NT) __builtin_nontemporal_store(w, o2 + k * T + threadIdx.x); else o2[k * T + threadIdx.x] = w; }
+    }
+}
+
 template <typename F> float time_ms(F f, int reps)
 {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -97,6 +116,13 @@ int main()
         report("read only  T=256 U=4", time_ms([&] { hipLaunchKernelGGL((k_read<256, 4>), dim3(g), dim3(256), 0, 0, (const u32x4*)s, (uint32_t*)d, n); }, R), 1.0 * bytes);
         report("write only T=256 U=4", time_ms([&] { hipLaunchKernelGGL((k_write<256, 4, 0>), dim3(g), dim3(256), 0, 0, (u32x4*)d, n); }, R), 1.0 * bytes);
         report("write only T=256 U=4 nt", time_ms([&] { hipLaunchKernelGGL((k_write<256, 4, 1>), dim3(g), dim3(256), 0, 0, (u32x4*)d, n); }, R), 1.0 * bytes);
+    }
+    {
+        const unsigned g = (unsigned)((n + 255) / 256);
+        report("one-shot 16-B loads, 4-B stores", time_ms([&] { hipLaunchKernelGGL((k_narrow_store<256, 4, 0>), dim3(g), dim3(256), 0, 0, (const u32x4*)s, (uint32_t*)d, n); }, R), 2.0 * bytes);
+        report("one-shot 16-B loads, 4-B stores nt", time_ms([&] { hipLaunchKernelGGL((k_narrow_store<256, 4, 1>), dim3(g), dim3(256), 0, 0, (const u32x4*)s, (uint32_t*)d, n); }, R), 2.0 * bytes);
+        report("one-shot 16-B loads, 8-B stores", time_ms([&] { hipLaunchKernelGGL((k_narrow_store<256, 8, 0>), dim3(g), dim3(256), 0, 0, (const u32x4*)s, (uint32_t*)d, n); }, R), 2.0 * bytes);
+        report("one-shot 16-B loads, 8-B stores nt", time_ms([&] { hipLaunchKernelGGL((k_narrow_store<256, 8, 1>), dim3(g), dim3(256), 0, 0, (const u32x4*)s, (uint32_t*)d, n); }, R), 2.0 * bytes);
     }
     return 0;
 }

@@ -72,6 +72,21 @@ template <int T, int SW, int NT> __global__ __launch_bounds__(T) void k_narrow_s
     }
 }
 
+// Tiled stores: the source is read contiguously (tile after tile), a tile is written as ROWS row segments of SEG bytes into
+// rows of PITCH bytes (what a block-based image kernel does: the JPEG kernel writes 16 rows x 512 bytes per workgroup)
+template <int SEG, int ROWS> __global__ __launch_bounds__(256) void k_tiled_store(const u32x4* __restrict__ s, uint8_t* __restrict__ d, int tiles_per_row, size_t pitch, size_t n_tiles)
+{
+    constexpr int CH = SEG / 16, PER_TILE = CH * ROWS;          // 16-byte chunks per tile
+    const size_t tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    const size_t band = tile / tiles_per_row, tx = tile % tiles_per_row;
+    for (int c = threadIdx.x; c < PER_TILE; c += 256) {
+        const u32x4 v = s[tile * PER_TILE + c];
+        const int row = c / CH, col = c % CH;
+        *reinterpret_cast<u32x4*>(d + (band * ROWS + row) * pitch + tx * SEG + (size_t)col * 16) = v;
+    }
+}
+
 template <typename F> float time_ms(F f, int reps)
 {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -123,6 +138,13 @@ int main()
         report("one-shot 16-B loads, 4-B stores nt", time_ms([&] { hipLaunchKernelGGL((k_narrow_store<256, 4, 1>), dim3(g), dim3(256), 0, 0, (const u32x4*)s, (uint32_t*)d, n); }, R), 2.0 * bytes);
         report("one-shot 16-B loads, 8-B stores", time_ms([&] { hipLaunchKernelGGL((k_narrow_store<256, 8, 0>), dim3(g), dim3(256), 0, 0, (const u32x4*)s, (uint32_t*)d, n); }, R), 2.0 * bytes);
         report("one-shot 16-B loads, 8-B stores nt", time_ms([&] { hipLaunchKernelGGL((k_narrow_store<256, 8, 1>), dim3(g), dim3(256), 0, 0, (const u32x4*)s, (uint32_t*)d, n); }, R), 2.0 * bytes);
+    }
+    {
+        const size_t pitch = 7680;                                        // 1920 rgba8 pixels
+#define TILED(SEG, ROWS) do { const int tpr = (int)(pitch / (SEG)); const size_t nt = (bytes / (pitch * (ROWS)) - 1) * tpr; \
+        snprintf(name, sizeof name, "tiled stores: %d rows x %d B per block, pitch 7680", ROWS, SEG); \
+        report(name, time_ms([&] { hipLaunchKernelGGL((k_tiled_store<SEG, ROWS>), dim3((unsigned)nt), dim3(256), 0, 0, (const u32x4*)s, (uint8_t*)d, tpr, pitch, nt); }, R), 2.0 * nt * (SEG) * (ROWS)); } while (0)
+        TILED(512, 16); TILED(256, 16); TILED(1536, 16); TILED(512, 8); TILED(7680, 1); TILED(3840, 2); TILED(1536, 8); TILED(512, 32);
     }
     return 0;
 }

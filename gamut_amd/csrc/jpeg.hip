@@ -29,7 +29,12 @@ namespace {
 
 using namespace jpg;
 
-constexpr int TILE_MCUS = 8;      // MCUs per workgroup
+constexpr int TILE_MCUS = 8;      // MCUs per workgroup (generic kernel)
+#ifndef JPEG_H2V2_MCUS
+#define JPEG_H2V2_MCUS 8
+#endif
+constexpr int H2V2_MCUS = JPEG_H2V2_MCUS;         // MCUs per workgroup of the tuned 4:2:0 kernel (a wave handles two): tuning knob
+constexpr int H2V2_THREADS = 32 * H2V2_MCUS;
 
 struct JpegArgs {
     const int16_t* coeffs; int64_t coeff_stride;     // int16 elements between images
@@ -47,9 +52,9 @@ struct JpegArgs {
 // 8-int row stride: a column read (8 lanes x consecutive c, 4 blocks per 32-lane
 // group) then touches 32 distinct banks.
 constexpr int BLK_STRIDE = 72;
-constexpr int T1_INTS = 32 * BLK_STRIDE;           // 32 Y blocks: pass-1 results
-constexpr int H_INTS  = 16 * BLK_STRIDE;           // 16 chroma blocks: horizontal upsample stage H[k][m]
-constexpr int V_INTS  = 16 * BLK_STRIDE;           // vertical stage V[n][m]
+constexpr int T1_INTS = 4 * H2V2_MCUS * BLK_STRIDE;           // 32 Y blocks: pass-1 results
+constexpr int H_INTS  = 2 * H2V2_MCUS * BLK_STRIDE;           // 16 chroma blocks: horizontal upsample stage H[k][m]
+constexpr int V_INTS  = 2 * H2V2_MCUS * BLK_STRIDE;           // vertical stage V[n][m]
 // T2 (32 (mcu,quadrant) tiles: rows 0-3 = Cb pass-1 rows, 4-7 = Cr) reuses T1's storage: T1 is last read in
 // phase P2, T2 is first written in P3, and a workgroup barrier separates the two.
 constexpr int LDS_INTS = T1_INTS + H_INTS + V_INTS;
@@ -95,7 +100,7 @@ __device__ __forceinline__ uint4 load_coeffs16(const int16_t* p)
 }
 
 template <int OC>                // output components: 4 = rgba8, 3 = rgb8, 1 = l8 (grey of the RGB result, jpegload.d:3786-3792)
-__global__ __launch_bounds__(256) void k_jpeg_h2v2(JpegArgs a)
+__global__ __launch_bounds__(H2V2_THREADS) void k_jpeg_h2v2(JpegArgs a)
 {
     __shared__ __attribute__((aligned(16))) i32 lds[LDS_INTS];
     i32* const T1 = lds;
@@ -104,11 +109,11 @@ __global__ __launch_bounds__(256) void k_jpeg_h2v2(JpegArgs a)
     i32* const T2 = T1;
 
     const int t = threadIdx.x;
-    const int img = blockIdx.z, mcu_y = blockIdx.y, mcu_x0 = blockIdx.x * TILE_MCUS;
+    const int img = blockIdx.z, mcu_y = blockIdx.y, mcu_x0 = blockIdx.x * H2V2_MCUS;
     // wave-uniform bases (scalar registers); per-thread parts are small 32-bit offsets
     const int16_t* cbase = a.coeffs + (int64_t)img * a.coeff_stride + ((int64_t)mcu_y * a.mcus_per_row + mcu_x0) * (6 * 64);
     uint8_t* obase = a.out + (int64_t)img * a.out_stride + (int64_t)(mcu_y * 16) * a.out_pitch + (int64_t)mcu_x0 * (16 * OC);
-    const int mcus_here = min(TILE_MCUS, a.mcus_per_row - mcu_x0);
+    const int mcus_here = min(H2V2_MCUS, a.mcus_per_row - mcu_x0);
 
     // ---- mapping A: thread = (Y block b = (mcu m, quadrant q), row/column index r) ----
     const int b = t >> 3, r = t & 7, m = b >> 2, q = b & 3;
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(256) void k_jpeg_h2v2(JpegArgs a)
             // pixel and its right neighbour's (one DPP quad shuffle + one byte permute).  l8: four grey bytes make one
             // dword, gathered with two in-quad OR steps; lane 0 of the quad keeps it.
             static_assert(OC == 3 || OC == 1, "output components");
-            constexpr int BPR = 128 * OC;                          // bytes per strip row
+            constexpr int BPR = 16 * H2V2_MCUS * OC;               // bytes per strip row
             uint8_t* stage = reinterpret_cast<uint8_t*>(Hs);       // 16 rows x BPR <= 6144 B of the 9216 B H/V area
             const int j = lx & 3;
             __syncthreads();                                       // other waves may still be reading V in P3
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(256) void k_jpeg_h2v2(JpegArgs a)
             const int row_bytes = min(mcus_here * 16, a.width - mcu_x0 * 16) * OC;       // live bytes of a strip row (rows are tight)
             const int live_rows = min(16, a.height - mcu_y * 16);
             constexpr int CPR = BPR / 16;                          // 16-byte chunks per row: 24 / 8
-            for (int c = t; c < 16 * CPR; c += 256) {
+            for (int c = t; c < 16 * CPR; c += H2V2_THREADS) {
                 const int row = c / CPR, off = (c - row * CPR) * 16;
                 if (row >= live_rows || off >= row_bytes) continue;
                 const uint4 v = *reinterpret_cast<const uint4*>(stage + row * BPR + off);
@@ -586,6 +591,7 @@ int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
         const bool tuned = out_pitch > 0 && out_pitch < (1 << 27) && scan_type != GAMUT_JPGD_YH1V2 &&
                            (out_comps != 4 || (((uintptr_t)out & 3) == 0 && (out_pitch & 3) == 0 && (out_stride & 3) == 0));
         const dim3 grid32((a.mcus_per_row + 31) / 32, a.mcus_per_col, n);           // grey: 32 MCUs per workgroup
+        const dim3 grid420((a.mcus_per_row + H2V2_MCUS - 1) / H2V2_MCUS, a.mcus_per_col, n);
 #define GAMUT_JPEG_PLAIN(ST, G) do { \
             if (out_comps == 4)      hipLaunchKernelGGL((k_jpeg_plain<ST, 4>), G, dim3(256), 0, stream, c); \
             else if (out_comps == 3) hipLaunchKernelGGL((k_jpeg_plain<ST, 3>), G, dim3(256), 0, stream, c); \
@@ -594,9 +600,9 @@ int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
         else if (scan_type == GAMUT_JPGD_GRAYSCALE)   GAMUT_JPEG_PLAIN(GAMUT_JPGD_GRAYSCALE, grid32);
         else if (scan_type == GAMUT_JPGD_YH1V1)       GAMUT_JPEG_PLAIN(GAMUT_JPGD_YH1V1, grid);
         else if (scan_type == GAMUT_JPGD_YH2V1)       GAMUT_JPEG_PLAIN(GAMUT_JPGD_YH2V1, grid);
-        else if (out_comps == 4) hipLaunchKernelGGL(k_jpeg_h2v2<4>, grid, dim3(256), 0, stream, c);
-        else if (out_comps == 3) hipLaunchKernelGGL(k_jpeg_h2v2<3>, grid, dim3(256), 0, stream, c);
-        else                     hipLaunchKernelGGL(k_jpeg_h2v2<1>, grid, dim3(256), 0, stream, c);
+        else if (out_comps == 4) hipLaunchKernelGGL(k_jpeg_h2v2<4>, grid420, dim3(H2V2_THREADS), 0, stream, c);
+        else if (out_comps == 3) hipLaunchKernelGGL(k_jpeg_h2v2<3>, grid420, dim3(H2V2_THREADS), 0, stream, c);
+        else                     hipLaunchKernelGGL(k_jpeg_h2v2<1>, grid420, dim3(H2V2_THREADS), 0, stream, c);
 #undef GAMUT_JPEG_PLAIN
         if (int rc = launch_status("jpeg_reconstruct")) return rc;
     }

@@ -241,7 +241,6 @@ __device__ __forceinline__ void defilter_band(const DefilterArgs& a, const uint8
     const uint8_t* rbytes = raw + (int64_t)(row_live ? row : 0) * (a.wb + 1) + 1;
     uint8_t* drow = D + (int64_t)(row_live ? row : 0) * a.d_pitch;
     const uint8_t* dprev = band > 0 ? D + (int64_t)(band * 64 - 1) * a.d_pitch : D;     // row above lane 0; band 0: anything valid, masked to 0
-    const u32 dmask = band > 0 ? 0xFFFFFFFFu : 0u;
     const int prod_wave = (wave + W - 1) % W;
     const u32 prod_base = (band > 0 ? (band - 1) / W : 0) * niter;
     const u32 full_iters = a.wb / (4 * FB);                              // iterations whose 4*FB bytes all lie inside the row
@@ -260,12 +259,12 @@ __device__ __forceinline__ void defilter_band(const DefilterArgs& a, const uint8
         int itn = (int)Tn - lane;
         itn = itn < 0 ? 0 : itn;
         const u32 itc = min((u32)itn, full_iters > 0 ? full_iters - 1 : 0u);       // always a fully readable group
-        const uint8_t* pn = full_iters ? rbytes + (int64_t)itc * (4 * FB) : raw;   // rows shorter than one group use the tail path only
+        const uint8_t* pn = rbytes + (int64_t)itc * (4 * FB);
         const uint8_t* dn = dprev + (int64_t)min(Tn, niter - 1) * (4 * FB);        // lane 0's iteration is Tn: wave-uniform address
         #pragma unroll
         for (int i = 0; i < FB; ++i) {
-            rs[i] = reinterpret_cast<const PackedU32*>(pn)[i].v;
-            ds[i] = reinterpret_cast<const u32*>(dn)[i] & dmask;
+            rs[i] = full_iters ? reinterpret_cast<const PackedU32*>(pn)[i].v : 0u;     // (uniform) rows shorter than one group use the tail path only
+            ds[i] = band > 0 ? reinterpret_cast<const u32*>(dn)[i] : 0u;               // (uniform) band 0 has no row above it
         }
     };
     auto wait_for_band_above = [&](u32 upto) {      // wave-uniform: rows of the band above are visible up to iteration `upto`
@@ -474,7 +473,9 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
     };
     u32x4 dset[PF];
     auto issue_dprev = [&](u32 Tn, u32x4& ds) {
-        const uint8_t* dn = dprev + (int64_t)min(Tn, niter - 1) * 16;                      // lane 0's iteration is Tn: wave-uniform address
+        // lane 0's iteration is Tn: wave-uniform address.  Band 0 has no row above it (the value is masked): it re-reads the first
+        // 16 bytes of row 0, which always exist -- never an address outside the image
+        const uint8_t* dn = dprev + (int64_t)(band > 0 ? min(Tn, niter - 1) : 0u) * 16;
         ds = *reinterpret_cast<const u32x4*>(dn);
     };
 

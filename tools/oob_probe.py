@@ -103,6 +103,64 @@ def convert_cases(extra_rows=0):
     return n
 
 
+def batch_cases():
+    """count > 1 with tight strides; JPEG with max_zag; QOI files resident in HBM; baseline files through the device entropy decoder"""
+    import glob
+    rng = np.random.default_rng(4)
+    n = 0
+    for img_n, out_n, x, y in [(4, 4, 61, 70), (3, 4, 37, 66), (3, 3, 64, 3), (1, 2, 130, 5)]:
+        color = {1: 0, 3: 2, 4: 6}[img_n]
+        raws = [gen.png_forward_filter(rng.integers(0, 256, (y, x * img_n), dtype=np.uint8), img_n, rng.integers(0, 5, y).astype(np.uint8)) for _ in range(5)]
+        stride = raws[0].size
+        draw = up_end(np.concatenate(raws)); dout = at_end(5 * x * y * out_n); dst = at_end(5 * 4, 4)
+        _capi.check(L.gamut_hip_png_defilter_batch_device(draw, stride, stride, dout, x * y * out_n, x, y, img_n, out_n, 8, color, 5, dst, None))
+        free_all(); n += 1
+    for st, nb, (mw, mh) in ((4, 6, (16, 16)), (1, 3, (8, 8)), (0, 1, (8, 8))):
+        for w, h in ((250, 33), (1920, 16)):
+            nblk = ((w + mw - 1) // mw) * ((h + mh - 1) // mh) * nb
+            co = rng.integers(-200, 200, (3, nblk, 64)).astype(np.int16)
+            zz = rng.integers(1, 65, (3, nblk)).astype(np.uint8)
+            for oc in (4, 3):
+                dco = up_end(co, 16); dzz = up_end(zz); dout = at_end(3 * w * h * oc)
+                _capi.check(L.gamut_hip_jpeg_reconstruct_batch_device(dco, nblk * 64, dzz, nblk, dout, w * oc, w * h * oc, w, h, st, oc, 3, None))
+                free_all(); n += 1
+    # QOI: the contract asks for GAMUT_HIP_QOI_SLACK readable bytes after every file -- and not one more
+    files = [gen.qoi_encode(rng.integers(0, 256, (h, w, ch), dtype=np.uint8) // 64 * 64) for (w, h, ch) in ((33, 9, 3), (130, 70, 4), (5, 1, 3))]
+    parts, begin, pos = [], [], 0
+    for f in files:
+        begin.append(pos); parts += [f, bytes(160)]; pos += len(f) + 160
+    blob = np.frombuffer(b"".join(parts), np.uint8)
+    dblob = up_end(blob)
+    descs = (_capi.QoiDesc * len(files))()
+    for i, f in enumerate(files):
+        _capi.check(L.gamut_hip_qoi_read_header(f, len(f), C.byref(descs[i])))
+    npx = [d.width * d.height for d in descs]
+    offs = np.concatenate([[0], np.cumsum([p * 4 for p in npx])[:-1]]).astype(np.int64)
+    dout = at_end(int(sum(npx)) * 4)
+    b = np.array(begin, np.int64); sz = np.array([len(f) for f in files], np.int32)
+    _capi.check(L.gamut_hip_qoi_decode_resident_device(dblob, blob.size, b.ctypes.data_as(C.POINTER(C.c_int64)), sz.ctypes.data_as(C.POINTER(C.c_int)), descs, len(files), 4,
+                                                       offs.ctypes.data_as(C.POINTER(C.c_int64)), dout, None))
+    free_all(); n += 1
+    # baseline JPEG files: coefficients and max_zag of the whole batch end with their allocations
+    jf = [open(p_, "rb").read() for p_ in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "jpeg", "*.jpg"))) if not os.path.basename(p_).startswith("p_")]
+    frames = []
+    for f in jf:
+        fr = _capi.JpegFrame()
+        if L.gamut_hip_jpeg_read_header(f, len(f), C.byref(fr)) == 0:
+            frames.append((f, fr.mcus_per_row * fr.mcus_per_col * fr.blocks_per_mcu))
+    if frames:
+        bufs = [np.frombuffer(f, np.uint8) for f, _ in frames]
+        nblks = np.array([nb for _, nb in frames], np.int64)
+        co_off = np.concatenate([[0], np.cumsum(nblks * 64)[:-1]]).astype(np.int64); zz_off = np.concatenate([[0], np.cumsum(nblks)[:-1]]).astype(np.int64)
+        k = len(frames)
+        ptrs = (C.c_void_p * k)(*[b_.ctypes.data for b_ in bufs]); lens = (C.c_size_t * k)(*[b_.size for b_ in bufs])
+        dco = at_end(int(nblks.sum()) * 128, 16); dzz = at_end(int(nblks.sum()))
+        info = (_capi.JpegFrame * k)(); st = (C.c_int * k)()
+        L.gamut_hip_jpeg_entropy_decode_device(ptrs, lens, k, co_off.ctypes.data_as(C.POINTER(C.c_int64)), zz_off.ctypes.data_as(C.POINTER(C.c_int64)), dco, dzz, None, info, st, None)
+        free_all(); n += 1
+    return n
+
+
 if len(sys.argv) > 1 and sys.argv[1] == "control":
     print("control: converting one row more than the buffers hold -- a memory access fault is the expected outcome", flush=True)
     L.gamut_hip_device_free(L.gamut_hip_device_malloc(64 << 20))
@@ -119,4 +177,5 @@ if len(sys.argv) > 1 and sys.argv[1] == "control":
 print("png", png_cases(), "cases ok", flush=True)
 print("jpeg", jpeg_cases(), "cases ok", flush=True)
 print("convert", convert_cases(), "cases ok", flush=True)
+print("batch / qoi / entropy", batch_cases(), "cases ok", flush=True)
 print("oob_probe: no access outside any buffer")

@@ -65,6 +65,38 @@ def png_cases():
     return n
 
 
+def random_cases(n_png=250, n_jpeg=150):
+    """seeded random geometries (widths and heights around the band / piece / MCU boundaries included)"""
+    rng = np.random.default_rng(7)
+    edge = [1, 2, 3, 4, 5, 6, 7, 8, 9, 15, 16, 17, 31, 33, 63, 64, 65, 127, 128, 129, 191, 193]
+    pick = lambda hi: int(rng.choice(edge)) if rng.random() < 0.5 else int(rng.integers(1, hi))
+    fmts = [(1, 1, 0), (1, 2, 0), (1, 4, 0), (1, 8, 0), (1, 16, 0), (2, 8, 4), (2, 16, 4), (3, 8, 2), (3, 16, 2), (4, 8, 6), (4, 16, 6)]
+    for _ in range(n_png):
+        img_n, depth, color = fmts[int(rng.integers(0, len(fmts)))]
+        x, y = pick(400), pick(200)
+        fb = 1 if depth < 8 else img_n * (2 if depth == 16 else 1)
+        out_n = img_n + (1 if img_n in (1, 3) and rng.random() < 0.5 else 0)
+        rows = gen.pack_samples(rng.integers(0, 1 << depth, (y, x * img_n)), depth)
+        raw = gen.png_forward_filter(rows, fb, rng.integers(0, 5, y).astype(np.uint8))
+        nbytes = x * y * out_n * (2 if depth == 16 else 1)
+        if VERBOSE: print('rpng', img_n, depth, color, x, y, out_n, flush=True)
+        draw = up_end(raw); dout = at_end(nbytes); dst = at_end(4, 4)
+        _capi.check(L.gamut_hip_png_defilter_batch_device(draw, 0, raw.size, dout, nbytes, x, y, img_n, out_n, depth, color, 1, dst, None))
+        free_all()
+    NB = {0: 1, 1: 3, 2: 4, 3: 4, 4: 6}; MCU = {0: (8, 8), 1: (8, 8), 2: (16, 8), 3: (8, 16), 4: (16, 16)}
+    for _ in range(n_jpeg):
+        st = int(rng.integers(0, 5)); oc = int(rng.choice([1, 3, 4]))
+        w, h = pick(600), pick(150)
+        mw, mh = MCU[st]
+        nblk = ((w + mw - 1) // mw) * ((h + mh - 1) // mh) * NB[st]
+        co = rng.integers(-300, 300, (nblk, 64)).astype(np.int16)
+        if VERBOSE: print('rjpeg', st, w, h, oc, flush=True)
+        dco = up_end(co, 16); dout = at_end(w * h * oc)
+        _capi.check(L.gamut_hip_jpeg_reconstruct_batch_device(dco, nblk * 64, None, 0, dout, w * oc, w * h * oc, w, h, st, oc, 1, None))
+        free_all()
+    return n_png + n_jpeg
+
+
 def jpeg_cases():
     rng = np.random.default_rng(2)
     NB = {0: 1, 1: 3, 2: 4, 3: 4, 4: 6}; MCU = {0: (8, 8), 1: (8, 8), 2: (16, 8), 3: (8, 16), 4: (16, 16)}
@@ -178,4 +210,5 @@ print("png", png_cases(), "cases ok", flush=True)
 print("jpeg", jpeg_cases(), "cases ok", flush=True)
 print("convert", convert_cases(), "cases ok", flush=True)
 print("batch / qoi / entropy", batch_cases(), "cases ok", flush=True)
+print("random geometries", random_cases(), "cases ok", flush=True)
 print("oob_probe: no access outside any buffer")

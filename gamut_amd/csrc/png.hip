@@ -435,7 +435,8 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
     // cooperative mapping: in transfer k (0..7) this lane handles row 8k + crow, piece cslot of that row's 8
     const int crow = lane >> 3, cslot = lane & 7;
     const u32 rows_left = a.rows - band * 64;                           // live rows in this band (may exceed 64)
-    const uint8_t* craw = raw + (int64_t)(band * 64) * (a.wb + 1) + 1;            // first row of the band; + row * (wb + 1)
+    // row crow of the band if the image has it, else the band's first row; + 8k rows per transfer
+    const uint8_t* craw = raw + (int64_t)(band * 64 + ((u32)crow < rows_left ? crow : 0)) * (a.wb + 1) + 1;
     uint8_t* cdst = D + (int64_t)(band * 64 + crow) * a.d_pitch;
     uint8_t* my_ring = ring + lane * ROW_PITCH;
     uint8_t* co_ring = ring + crow * ROW_PITCH;                         // + k * 8 * ROW_PITCH + slot * 16
@@ -456,7 +457,7 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
         #pragma unroll
         for (int k = 0; k < 8; ++k) {
             int it = (int)T0 + cslot - (8 * k + crow);                                     // piece of row 8k+crow used in trip T0 + cslot
-            const u32 r = (u32)(8 * k + crow) < rows_left ? (u32)(8 * k + crow) : 0u;      // rows past the image re-read the band's first row (unused):
+            const u32 r = (u32)(8 * k + crow) < rows_left ? (u32)(8 * k) : 0u;             // rows past the image re-read a live row of the band (unused):
                                                                                            // never an address outside the stream
             it = it < 0 ? 0 : it;
             // full pieces by index; the ragged last piece (and anything past it, unused) = the last 16 bytes of the row

@@ -344,11 +344,31 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms = [a.elapsed_time(b) for a, b in evs]
 
+    gather = None
     if world > 1:
         import torch.distributed as dist
         tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        # The only exchange the path has: gathering decoded outputs.  Outside the timed region and reported on
+        # its own -- an all-gather of a slice of every rank's output (<= 256 MiB each) over RCCL / xGMI.
+        try:
+            piece = out.reshape(-1).view(torch.uint8)[:256 << 20].contiguous()
+            if backend != "nccl":
+                piece = piece.cpu()
+            dst = torch.empty(world * piece.numel(), dtype=torch.uint8, device=piece.device)
+            dist.all_gather_into_tensor(dst, piece)                      # warm-up (communicator set-up)
+            torch.cuda.synchronize(); dist.barrier()
+            t0g = time.perf_counter()
+            dist.all_gather_into_tensor(dst, piece)
+            torch.cuda.synchronize(); dist.barrier()
+            dtg = time.perf_counter() - t0g
+            ok = bool(torch.equal(dst[rank * piece.numel():(rank + 1) * piece.numel()], piece))
+            gather = {"bytes_per_rank": int(piece.numel()), "ms": round(dtg * 1e3, 3), "GB/s_received_per_rank": round((world - 1) * piece.numel() / dtg / 1e9, 1),
+                      "own_slice_intact": ok, "note": "all_gather of output slices, outside the timed region"}
+            del dst, piece
+        except Exception as e:                                          # the headline number does not depend on it
+            gather = {"error": repr(e)[:200]}
 
     if rank == 0:
         avg_kernel_s = float(np.mean(kern_ms)) * 1e-3
@@ -367,6 +387,8 @@ def main():
                          "kernel": kernel_name, "algorithmic_bytes_per_launch": bytes_per_step,
                          "kernel_ms_avg": round(avg_kernel_s * 1e3, 4), "kernel_ms_min": round(min(kern_ms), 4)},
         }
+        if gather is not None:
+            res["gather"] = gather
         if wl == "mixed":
             torch.cuda.synchronize()
             res["config"]["per_format"] = {}

@@ -39,6 +39,7 @@ def test_two_ranks_one_line(hip):
               "--master-port", "29541", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16"],
              env={"GAMUT_BENCH_BACKEND": "gloo"})
     assert r["n_gpus"] == 2 and r["cpu_baseline"] is None and r["value"] > 0
+    assert r["gather"].get("own_slice_intact") is True and r["gather"]["ms"] > 0, r["gather"]
 
 
 def test_mixed_workload_line(hip):

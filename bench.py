@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--workload", default="jpeg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--gather", action="store_true", help="N > 1: also time an all_gather of output slices (after the timed region)")
     return ap.parse_args()
 
 
@@ -353,6 +354,8 @@ def main():
         # The only exchange the path has: gathering decoded outputs.  Outside the timed region and reported on
         # its own -- an all-gather of a slice of every rank's output (<= 256 MiB each) over RCCL / xGMI.
         try:
+            if not args.gather:
+                raise StopIteration
             piece = out.reshape(-1).view(torch.uint8)[:256 << 20].contiguous()
             if backend != "nccl":
                 piece = piece.cpu()
@@ -367,6 +370,8 @@ def main():
             gather = {"bytes_per_rank": int(piece.numel()), "ms": round(dtg * 1e3, 3), "GB/s_received_per_rank": round((world - 1) * piece.numel() / dtg / 1e9, 1),
                       "own_slice_intact": ok, "note": "all_gather of output slices, outside the timed region"}
             del dst, piece
+        except StopIteration:
+            gather = None
         except Exception as e:                                          # the headline number does not depend on it
             gather = {"error": repr(e)[:200]}
 

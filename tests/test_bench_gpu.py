@@ -36,7 +36,7 @@ def test_single_gpu_line(hip):
 
 def test_two_ranks_one_line(hip):
     r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-              "--master-port", "29541", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16"],
+              "--master-port", "29541", "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16", "--gather"],
              env={"GAMUT_BENCH_BACKEND": "gloo"})
     assert r["n_gpus"] == 2 and r["cpu_baseline"] is None and r["value"] > 0
     assert r["gather"].get("own_slice_intact") is True and r["gather"]["ms"] > 0, r["gather"]

@@ -55,6 +55,11 @@ struct PinnedScratch {                  // page-locked host memory: uploads from
     }
 };
 
+// Host threads worth starting: the hardware threads, or fewer when a cgroup CPU quota (cpu.max) grants the process less --
+// the GPU boxes show 256 threads and a quota of 16 cores, and 256 inflating threads on 16 cores' worth of time run slower
+// than 16.
+int host_threads();
+
 // fn(worker, index) for index in [0, count) on `workers` host threads (the caller is worker 0); dynamic distribution
 template <class Fn> void parallel_for(int count, int workers, Fn fn)          // fn(worker, index); the caller runs worker 0
 {

@@ -949,7 +949,7 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
     // Pipeline: (A) headers on host threads -> (B) layout, and the coefficient clears go out on `stream` -> (C) segments
     // unstuffed straight into the pinned upload image, slice by slice, each slice DMA'd on a private copy stream as soon as
     // it is complete (so unstuffing, PCIe and the clears overlap) -> (D) tables, then the kernels on `stream` behind an event.
-    int workers = (int)std::thread::hardware_concurrency();
+    int workers = host_threads();
     workers = workers < 1 ? 1 : workers > 16 ? 16 : workers;
     if (workers > (count + 7) / 8) workers = (count + 7) / 8;
     std::vector<FilePrep> prep((size_t)count);
@@ -1135,7 +1135,7 @@ int gamut_hip_jpeg_decode_coeffs_batch(const uint8_t* const* data, const size_t*
     clear_error();
     if (count < 0 || (count > 0 && (!data || !len || !out)))
         return set_error(GAMUT_HIP_ERR_INVALID_ARG, "jpeg_decode_coeffs_batch: bad arguments");
-    if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+    if (threads <= 0) threads = host_threads();
     if (threads < 1) threads = 1;
     if (threads > count) threads = count;
     try {

@@ -409,7 +409,7 @@ int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* 
         return set_error(GAMUT_HIP_ERR_NO_DEVICE, "no HIP device available (libgamut_hip has no CPU fallback)");
     (void)hipGetDevice(&dev);
     try {
-        if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+        if (threads <= 0) threads = host_threads();
         threads = threads < 1 ? 1 : threads > count ? count : threads;
         hipStream_t st = pick_stream(stream);
         static thread_local hipStream_t copy_stream = nullptr;

@@ -230,7 +230,7 @@ int decode_batch(const uint8_t* const* data, const int* size, int count, int cha
         uint8_t* h = pinned.get(total);
         if (!d || !h) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "qoi: staging allocation of %zu bytes failed", total);
         // the files are gathered into one pinned image on a few host threads and go up in one DMA
-        int workers = (int)std::thread::hardware_concurrency();
+        int workers = host_threads();
         workers = workers < 1 ? 1 : workers > 16 ? 16 : workers;
         if ((size_t)workers > blob_size / (4u << 20) + 1) workers = (int)(blob_size / (4u << 20) + 1);
         parallel_for((int)items.size(), workers, [&](int, int k) {

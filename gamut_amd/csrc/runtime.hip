@@ -19,6 +19,25 @@ int set_error(int status, const char* fmt, ...)
     return status;
 }
 
+int host_threads()
+{
+    static const int n = [] {
+        int hw = (int)std::thread::hardware_concurrency();
+        if (hw < 1) hw = 1;
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char quota[32] = { 0 }; long long period = 0;
+            if (fscanf(f, "%31s %lld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0) {
+                const long long q = atoll(quota);
+                const int cores = (int)((q + period - 1) / period);
+                if (cores >= 1 && cores < hw) hw = cores;
+            }
+            fclose(f);
+        }
+        return hw;
+    }();
+    return n;
+}
+
 hipStream_t thread_stream()
 {
     static thread_local hipStream_t s = nullptr;

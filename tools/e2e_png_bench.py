@@ -42,7 +42,7 @@ def main():
             t0 = time.perf_counter()
             _capi.check(L.gamut_hip_png_decode_batch_device(ptrs, lens, B, 4, 8, offs.ctypes.data_as(C.POINTER(C.c_int64)), dout, info, None, threads, None))
             best = min(best, time.perf_counter() - t0)
-        print(f"  host threads {threads or os.cpu_count():4d}: {B * w * h / best / 1e6:9.1f} Mpx/s  ({best * 1e3:8.1f} ms)")
+        print(f"  host threads {str(threads) if threads else 'auto':>4s}: {B * w * h / best / 1e6:9.1f} Mpx/s  ({best * 1e3:8.1f} ms)")
     L.gamut_hip_device_free(dout)
 
 

@@ -308,10 +308,21 @@ struct gamut_image {
         const size_t nblk = (size_t)f.mcus_per_row * f.mcus_per_col * f.blocks_per_mcu;
         const int comps = req < 0 ? f.comps : req;
         uint8_t* dco = dmalloc(nblk * 128), *dzz = dmalloc(nblk), *dout = dmalloc((size_t)f.width * f.height * comps);
-        bool ok = dco && dzz && dout;
+        uint32_t* dst = (uint32_t*)dmalloc(sizeof(uint32_t));
+        bool ok = dco && dzz && dout && dst;
         if (ok) {
             const int64_t zero = 0; int st = 0; gamut_hip_jpeg_frame info;
-            int rc = gamut_hip_jpeg_entropy_decode_device(&bytes, &len, 1, &zero, &zero, (int16_t*)dco, dzz, nullptr, &info, &st, nullptr);
+            // a lane that meets damaged entropy data stops early and flags the image: the buffers must not hold stale device
+            // memory, and the flag must fail the load like the host path and the reference's stop_decoding do
+            ok = hipMemsetAsync(dco, 0, nblk * 128, nullptr) == hipSuccess && hipMemsetAsync(dzz, 0, nblk, nullptr) == hipSuccess;
+            int rc = !ok ? GAMUT_HIP_ERR_HIP :
+                     gamut_hip_jpeg_entropy_decode_device(&bytes, &len, 1, &zero, &zero, (int16_t*)dco, dzz, dst, &info, &st, nullptr);
+            if (rc == GAMUT_HIP_OK) {
+                uint32_t flags = 0;
+                rc = gamut_hip_stream_synchronize(nullptr);
+                if (rc == GAMUT_HIP_OK && hipMemcpy(&flags, dst, sizeof(flags), hipMemcpyDeviceToHost) != hipSuccess) rc = GAMUT_HIP_ERR_HIP;
+                if (rc == GAMUT_HIP_OK && flags != 0) rc = GAMUT_HIP_ERR_DECODE;
+            }
             if (rc == GAMUT_HIP_ERR_UNSUPPORTED) {                                          // progressive: host feeder
                 gamut_hip_jpeg_frame hf;
                 rc = gamut_hip_jpeg_decode_coeffs(bytes, len, &hf);
@@ -328,6 +339,7 @@ struct gamut_image {
         }
         if (dco) (void)hipFree(dco);
         if (dzz) (void)hipFree(dzz);
+        if (dst) (void)hipFree(dst);
         if (!ok) { if (dout) (void)hipFree(dout); return nullptr; }
         *w = f.width; *h = f.height; *actual = f.comps; *aspect = f.pixel_aspect_ratio; *dpiY = f.dpi_y;
         return dout;

@@ -68,7 +68,13 @@ __device__ __forceinline__ constexpr int phys_slot(int m) { constexpr int P[8] =
 
 struct MapCoef { i32 a[4], b[4]; };
 __device__ const i32 kMapTable[2][8] __attribute__((aligned(32))) = { { E1a, E1b, E1c, E1d, E3a, E3b, E3c, E3d }, { O0a, O0b, O0c, O0d, O2a, O2b, O2c, O2d } };
+// the same multipliers as packed int16 pairs (u1|u3, u5|u7) for the horizontal stage, whose inputs are int16 (v_dot2_i32_i16)
+__device__ const u32 kMapPacked[2][4] __attribute__((aligned(16))) = {
+    { pk16(E1a, E1b), pk16(E1c, E1d), pk16(E3a, E3b), pk16(E3c, E3d) }, { pk16(O0a, O0b), pk16(O0c, O0d), pk16(O2a, O2b), pk16(O2c, O2d) } };
 struct __attribute__((packed, aligned(1))) Dwords4u { u32 v[4]; };      // 16 bytes at any alignment (gfx950 stores them natively)
+#ifndef JPEG_DOT2                 // 1: int16-input stages (luma pass 1, chroma horizontal stage, idct_4x4 pass 1) on v_dot2_i32_i16
+#define JPEG_DOT2 1
+#endif
 
 // Every LDS hand-off of the tuned kernel stays inside one 32-lane half of a wave (thread t only ever reads tiles
 // written by threads with the same t >> 5: Y tile t>>3, chroma block t>>4, T2 tile t>>3), so no workgroup barrier is
@@ -85,8 +91,9 @@ __device__ __forceinline__ void map_half(const MapCoef& c, i32 pass0, i32 pass1,
 {
     o[0] = pass0;
     o[1] = pass1;
-    o[2] = D4(c.a[0], u1, c.a[1], u3, c.a[2], u5, c.a[3], u7);
-    o[3] = D4(c.b[0], u1, c.b[1], u3, c.b[2], u5, c.b[3], u7);
+    // four chained multiply-adds each (written out: the optimiser prefers four multiplies and two three-input adds)
+    o[2] = mad24_1(c.a[3], u7, mad24_1(c.a[2], u5, mad24_1(c.a[1], u3, mad24_1(c.a[0], u1, 512)))) >> 10;
+    o[3] = mad24_1(c.b[3], u7, mad24_1(c.b[2], u5, mad24_1(c.b[1], u3, mad24_1(c.b[0], u1, 512)))) >> 10;
 }
 
 #ifndef JPEG_NT_LOADS             // coefficients are read exactly once: nontemporal loads (tuning knob, tools/variant.sh)
@@ -97,6 +104,13 @@ __device__ __forceinline__ uint4 load_coeffs16(const int16_t* p)
     typedef u32 u32x4n __attribute__((ext_vector_type(4)));
     if (JPEG_NT_LOADS) { const u32x4n v = __builtin_nontemporal_load(reinterpret_cast<const u32x4n*>(p)); return make_uint4(v.x, v.y, v.z, v.w); }
     return *reinterpret_cast<const uint4*>(p);
+}
+
+// one nontemporal dword store at (scalar row base + 32-bit lane offset).  Written by hand: the compiler otherwise keeps the
+// address as a 64-bit vector value and advances it with a 64-bit vector add per row.
+__device__ __forceinline__ void store_px_nt(uint8_t* row_base, u32 voff, u32 px)
+{
+    asm volatile("global_store_dword %0, %1, %2 nt" :: "v"(voff), "v"(px), "s"(row_base));
 }
 
 template <int OC>                // output components: 4 = rgba8, 3 = rgb8, 1 = l8 (grey of the RGB result, jpegload.d:3786-3792)
@@ -131,6 +145,7 @@ __global__ __launch_bounds__(H2V2_THREADS) void k_jpeg_h2v2(JpegArgs a)
         mc.a[0] = ta.x; mc.a[1] = ta.y; mc.a[2] = ta.z; mc.a[3] = ta.w;
         mc.b[0] = tb.x; mc.b[1] = tb.y; mc.b[2] = tb.z; mc.b[3] = tb.w;
     }
+    const uint4 mp = *reinterpret_cast<const uint4*>(kMapPacked[half]);
 
     // P0: loads (issued together; 16 B per lane, lane-contiguous inside each MCU).  Lanes of MCUs beyond the edge of the image
     // re-read the strip's first MCU (there is always one): their results are never stored, and nothing has to be zeroed.
@@ -139,9 +154,9 @@ __global__ __launch_bounds__(H2V2_THREADS) void k_jpeg_h2v2(JpegArgs a)
 
     // P1a: luma pass 1 (row r of block b) -> T1[b][r][0..7]
     {
-        i32 x[8], tv[8];
-        unpack_row(yrow, x);
-        row_pass<8>(x, tv);
+        i32 tv[8];
+        if (JPEG_DOT2) row_pass_packed(yrow, tv);
+        else { i32 x[8]; unpack_row(yrow, x); row_pass<8>(x, tv); }
         i32* dst = T1 + b * BLK_STRIDE + r * 8;
         *reinterpret_cast<int4*>(dst)     = make_int4(tv[0], tv[1], tv[2], tv[3]);
         *reinterpret_cast<int4*>(dst + 4) = make_int4(tv[4], tv[5], tv[6], tv[7]);
@@ -150,6 +165,13 @@ __global__ __launch_bounds__(H2V2_THREADS) void k_jpeg_h2v2(JpegArgs a)
     {
         i32 hv[4];
         const u32 w0 = half ? crow.y : crow.x, w1 = half ? crow.w : crow.z;        // (u2 | u3) : (u0 | u1),  (u6 | u7) : (u4 | u5)
+        if (JPEG_DOT2) {
+            const u32 p13 = __builtin_amdgcn_perm(crow.y, crow.x, 0x07060302u), p57 = __builtin_amdgcn_perm(crow.w, crow.z, 0x07060302u);
+            hv[0] = (i32)(short)(w0 & 0xFFFF);
+            hv[1] = (i32)(short)(w1 & 0xFFFF);
+            hv[2] = dot2(p13, mp.x, dot2(p57, mp.y, 512)) >> 10;
+            hv[3] = dot2(p13, mp.z, dot2(p57, mp.w, 512)) >> 10;
+        } else
         map_half(mc, (i32)(short)(w0 & 0xFFFF), (i32)(short)(w1 & 0xFFFF),
                  (i32)crow.x >> 16, (i32)crow.y >> 16, (i32)crow.z >> 16, (i32)crow.w >> 16, hv);
         *reinterpret_cast<int4*>(Hs + cbk * BLK_STRIDE + k * 8 + half * 4) = make_int4(hv[0], hv[1], hv[2], hv[3]);
@@ -201,12 +223,17 @@ __global__ __launch_bounds__(H2V2_THREADS) void k_jpeg_h2v2(JpegArgs a)
         i32 x[8], tv[8];
         #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const i32 p  = mad24(rb[phys_slot(i)], sq, ra[phys_slot(i)]);          // a = P+Q (top) / b = P-Q (bottom)
-            const i32 s2 = mad24(rb[phys_slot(4 + i)], sq, ra[phys_slot(4 + i)]);  // c = R+S        / d = R-S
-            x[i] = (i32)(short)mad24(s2, sr, p);                                   // cast(jpgd_block_t)
+            const i32 p  = mad24_1(rb[phys_slot(i)], sq, ra[phys_slot(i)]);          // a = P+Q (top) / b = P-Q (bottom)
+            const i32 s2 = mad24_1(rb[phys_slot(4 + i)], sq, ra[phys_slot(4 + i)]);  // c = R+S        / d = R-S
+            x[i] = mad24_1(s2, sr, p);
         }
-        x[4] = x[5] = x[6] = x[7] = 0;
-        row_pass<4>(x, tv);
+        if (JPEG_DOT2) row_pass4_packed(x[0], x[1], x[2], x[3], tv);             // cast(jpgd_block_t) = the low halves it packs
+        else {
+            #pragma unroll
+            for (int i = 0; i < 4; ++i) x[i] = (i32)(short)x[i];                   // cast(jpgd_block_t)
+            x[4] = x[5] = x[6] = x[7] = 0;
+            row_pass<4>(x, tv);
+        }
         i32* dst = T2 + (mm * 4 + qq) * BLK_STRIDE + (comp * 4 + j) * 8;
         *reinterpret_cast<int4*>(dst)     = make_int4(tv[0], tv[1], tv[2], tv[3]);
         *reinterpret_cast<int4*>(dst + 4) = make_int4(tv[4], tv[5], tv[6], tv[7]);
@@ -215,15 +242,21 @@ __global__ __launch_bounds__(H2V2_THREADS) void k_jpeg_h2v2(JpegArgs a)
 
     // P4: chroma pass 2 (Col!4 on column r of the quadrant's Cb and Cr), colour, store
     {
-        i32 tc[8], cbs[8], crs[8];
+        i32 cbs[8], crs[8];
         const i32* src = T2 + b * BLK_STRIDE + r;
-        #pragma unroll
-        for (int i = 0; i < 4; ++i) tc[i] = src[i * 8];
-        tc[4] = tc[5] = tc[6] = tc[7] = 0;
-        col_pass<4>(tc, cbs);
-        #pragma unroll
-        for (int i = 0; i < 4; ++i) tc[i] = src[(4 + i) * 8];
-        col_pass<4>(tc, crs);
+        if (JPEG_DOT2) {
+            col_pass4_direct(src[0], src[8], src[16], src[24], cbs);
+            col_pass4_direct(src[32], src[40], src[48], src[56], crs);
+        } else {
+            i32 tc[8];
+            #pragma unroll
+            for (int i = 0; i < 4; ++i) tc[i] = src[i * 8];
+            tc[4] = tc[5] = tc[6] = tc[7] = 0;
+            col_pass<4>(tc, cbs);
+            #pragma unroll
+            for (int i = 0; i < 4; ++i) tc[i] = src[(4 + i) * 8];
+            col_pass<4>(tc, crs);
+        }
 
         const ColourConsts cc = colour_consts();
         const int lx = m * 16 + (q & 1) * 8 + r;               // pixel column inside the strip
@@ -237,16 +270,14 @@ __global__ __launch_bounds__(H2V2_THREADS) void k_jpeg_h2v2(JpegArgs a)
             // one pixel per lane per row: a wave store instruction writes two full 128-byte lines.  (16-byte stores after an
             // in-quad DPP transpose were measured 2 % slower: the kernel is VALU-bound, not store-issue-bound.)
             if (px_live) {
-                u32 voff = (u32)(lx * 4) + (u32)ly0 * pitch;
+                const u32 voff = (u32)(lx * 4) + (u32)ly0 * pitch;      // the lane's part; the row advances on the scalar side
                 if (all_rows) {
                     #pragma unroll
-                    for (int i = 0; i < 8; ++i, voff += pitch)
-                        __builtin_nontemporal_store(ycc_to_rgba(ys[i], cbs[i], crs[i], cc.kr, cc.kb), reinterpret_cast<u32*>(obase + voff));
+                    for (int i = 0; i < 8; ++i) store_px_nt(obase + (size_t)i * pitch, voff, ycc_to_rgba(ys[i], cbs[i], crs[i], cc.kr, cc.kb));
                 } else {
                     #pragma unroll
-                    for (int i = 0; i < 8; ++i, voff += pitch)
-                        if (i < rows_here)
-                            __builtin_nontemporal_store(ycc_to_rgba(ys[i], cbs[i], crs[i], cc.kr, cc.kb), reinterpret_cast<u32*>(obase + voff));
+                    for (int i = 0; i < 8; ++i)
+                        if (i < rows_here) store_px_nt(obase + (size_t)i * pitch, voff, ycc_to_rgba(ys[i], cbs[i], crs[i], cc.kr, cc.kb));
                 }
             }
         } else {

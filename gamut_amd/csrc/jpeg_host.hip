@@ -580,6 +580,7 @@ struct DevBits {
     }
 };
 
+constexpr size_t kBlobSlack = 512;                           // bytes a lane may read past the last segment (one block + look-ahead), see k_jpeg_entropy
 constexpr int kEntropyThreads = 64;                          // one wave per workgroup: lanes spread over CUs, each with its own L1
 constexpr int kLdsHuff = 16, kLdsQuant = 16;                   // tables a workgroup keeps in LDS (23 KB + 2 KB)
 constexpr int kSyncThreads = 1024;                             // lanes cooperating on one large segment
@@ -628,6 +629,11 @@ __global__ __launch_bounds__(kEntropyThreads) void k_jpeg_entropy(const DevItem*
     const DevItem it = items[i];
     const DevImage im = images[it.image];
     DevBits br; br.open(blob + it.begin, 0);
+    // A lane may run past its segment only by the 64 bytes of 0xFF padding: with the standard (incomplete) tables an
+    // all-ones window is no code and the decode stops by itself, but a DHT may define a COMPLETE code (all-ones included),
+    // and a truncated scan under a large SOF would then keep "decoding" padding, the next segments and whatever follows the
+    // blob.  Checked once per block: a block consumes < 256 bytes, and the blob is allocated with that much slack.
+    const uint32_t limit_bit = (uint32_t)(it.end - it.begin) * 8u + 64u * 8u;
     int pred0 = 0, pred1 = 0, pred2 = 0;
     int16_t* out = coeffs + im.coeff_off + (int64_t)it.first_mcu * im.nb * 64;
     uint8_t* mz = max_zag + im.zag_off + (int64_t)it.first_mcu * im.nb;
@@ -658,6 +664,7 @@ __global__ __launch_bounds__(kEntropyThreads) void k_jpeg_entropy(const DevItem*
                     kk += 15;
                 } else break;
             }
+            if (br.pos > limit_bit) { atomicOr(status + it.image, 4u); return; }      // ran off the end of the segment
             *mz = (uint8_t)kk;                                   // m_mcu_block_max_zag :2512
             uint4* src = reinterpret_cast<uint4*>(blk);
             uint4* dst = reinterpret_cast<uint4*>(out);          // 128-byte blocks at 128-byte-aligned offsets (checked by the host)
@@ -989,9 +996,9 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
         if (!copy_stream) GAMUT_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
         static thread_local DeviceScratch scratch, tab_scratch;
         static thread_local PinnedScratch pinned, tab_pinned;
-        uint8_t* d_blob_w = (uint8_t*)scratch.get(blob_size + 64);
-        uint8_t* h_blob = pinned.get(blob_size + 64);
-        if (!d_blob_w || !h_blob) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: staging allocation of %zu bytes failed", blob_size + 64);
+        uint8_t* d_blob_w = (uint8_t*)scratch.get(blob_size + kBlobSlack);
+        uint8_t* h_blob = pinned.get(blob_size + kBlobSlack);
+        if (!d_blob_w || !h_blob) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: staging allocation of %zu bytes failed", blob_size + kBlobSlack);
         // lanes of a workgroup of the self-synchronising kernel share blocks, so coefficients are written in place: clear the
         // images that can have a long segment first (adjacent ones in one call).  On `stream`, while the upload is prepared.
         {

@@ -35,6 +35,14 @@ __device__ __forceinline__ i32 wsub(i32 a, i32 b) { return (i32)((u32)a - (u32)b
 __device__ __forceinline__ i32 mul24(i32 a, i32 c) { return __mul24(a, c); }
 // a*c + b (wrapping)
 __device__ __forceinline__ i32 mad24(i32 a, i32 c, i32 b) { return (i32)((u32)__mul24(a, c) + (u32)b); }
+// the same as exactly one v_mad_i32_i24, for a run-time multiplier of +-1: the optimiser otherwise "strength-reduces" such a
+// product into sign-extend / negate / select chains (six instructions, one of them a 64-bit multiply-add)
+__device__ __forceinline__ i32 mad24_1(i32 a, i32 c, i32 b)
+{
+    i32 d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(c), "v"(b));
+    return d;
+}
 
 // Un-descaled 1-D IDCT butterfly; `round` is added to every output (it rides on tmp0/tmp1).
 // NZ = number of leading non-zero inputs known at compile time (8 = dense, 4 = idct_4x4 rows/cols).
@@ -99,6 +107,96 @@ __device__ __forceinline__ void unpack_row(const uint4& v, i32 (&x)[8])
     x[2] = (i32)(short)(v.y & 0xFFFF); x[3] = (i32)v.y >> 16;
     x[4] = (i32)(short)(v.z & 0xFFFF); x[5] = (i32)v.z >> 16;
     x[6] = (i32)(short)(v.w & 0xFFFF); x[7] = (i32)v.w >> 16;
+}
+
+// ---- packed int16 forms (v_dot2_i32_i16) ---------------------------------------
+// The 1-D butterfly (:178-202) is a LINEAR map with integer coefficients, and the reference evaluates it in wrap-around
+// 32-bit arithmetic: any regrouping of its products is bit-identical mod 2^32.  Written out per input,
+//   tmp0/1 = 8192 x0 +- 8192 x4                 tmp3 = (c541 + c765) x2 + c541 x6        tmp2 = c541 x2 + (c541 - c1847) x6
+//   btmp0  = (c1175-c899) x1 + (c1175-c1961) x3 + c1175 x5 + (c298-c899-c1961+c1175) x7      (and the three siblings)
+// every coefficient still fits int16, so when the INPUTS are int16 too (the de-quantised coefficients of pass 1; the
+// cast(short) outputs of the upsample in idct_4x4's pass 1) two products and their sum are one v_dot2_i32_i16 on a packed
+// pair: exact 31-bit products, 32-bit wrapping accumulate.  Measured on gfx950 (tools/microbench.hip) a dot2 issues in the
+// same 4.3 cycles as one v_mad_i32_i24.  Pass 2 cannot use it: its inputs are the >>11 values (up to 2^20 for wild input).
+typedef short short2v __attribute__((ext_vector_type(2)));
+constexpr u32 pk16(int lo, int hi) { return ((u32)lo & 0xFFFFu) | (((u32)hi & 0xFFFFu) << 16); }
+// Written as the three-operand VOP3P form by hand: left to itself the compiler picks the two-operand accumulate form
+// (v_dot2c, the only one that takes a literal) and pays a v_mov per accumulator it has to preserve or initialise.
+// The constant pair sits in a scalar register (VOP3P may name one), a zero accumulator is the inline constant.
+__device__ __forceinline__ i32 dot2(u32 pair, u32 cpair, i32 acc)
+{
+    i32 d;
+    if (__builtin_constant_p(cpair)) {
+        if (__builtin_constant_p(acc) && acc == 0) asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(pair), "s"(cpair));
+        else asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(pair), "s"(cpair), "v"(acc));
+    } else {
+        asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(pair), "v"(cpair), "v"(acc));
+    }
+    return d;
+}
+constexpr int K_E2 = FIX_0_541196100 + FIX_0_765366865;      // tmp3: x2
+constexpr int K_E6 = FIX_0_541196100 - FIX_1_847759065;      // tmp2: x6
+// odd part, per output (x1, x3, x5, x7)
+constexpr int K_B0[4] = { FIX_1_175875602 - FIX_0_899976223, FIX_1_175875602 - FIX_1_961570560, FIX_1_175875602,
+                          FIX_0_298631336 - FIX_0_899976223 - FIX_1_961570560 + FIX_1_175875602 };
+constexpr int K_B1[4] = { FIX_1_175875602 - FIX_0_390180644, FIX_1_175875602 - FIX_2_562915447,
+                          FIX_2_053119869 - FIX_2_562915447 - FIX_0_390180644 + FIX_1_175875602, FIX_1_175875602 };
+constexpr int K_B2[4] = { FIX_1_175875602, FIX_3_072711026 - FIX_2_562915447 - FIX_1_961570560 + FIX_1_175875602,
+                          FIX_1_175875602 - FIX_2_562915447, FIX_1_175875602 - FIX_1_961570560 };
+constexpr int K_B3[4] = { FIX_1_501321110 - FIX_0_899976223 - FIX_0_390180644 + FIX_1_175875602, FIX_1_175875602,
+                          FIX_1_175875602 - FIX_0_390180644, FIX_1_175875602 - FIX_0_899976223 };
+static_assert(K_E2 == 10703 && K_E6 == -10704, "direct-form even constants");
+static_assert(K_B0[0] == 2260 && K_B0[1] == -6436 && K_B0[2] == 9633 && K_B0[3] == -11363, "direct-form odd constants");
+static_assert(K_B1[0] == 6437 && K_B1[1] == -11362 && K_B1[2] == 2261 && K_B1[3] == 9633, "direct-form odd constants");
+static_assert(K_B2[0] == 9633 && K_B2[1] == -2259 && K_B2[2] == -11362 && K_B2[3] == -6436, "direct-form odd constants");
+static_assert(K_B3[0] == 11363 && K_B3[1] == 9633 && K_B3[2] == 6437 && K_B3[3] == 2260, "direct-form odd constants");
+
+// pass 1 on one 16-byte row of 8 int16 coefficients (x0|x1, x2|x3, x4|x5, x6|x7) -> 8 ints, == row_pass<8>(unpack_row(v))
+__device__ __forceinline__ void row_pass_packed(const uint4& v, i32 (&t)[8])
+{
+    const u32 p04 = __builtin_amdgcn_perm(v.z, v.x, 0x05040100u);       // x0 | x4 << 16
+    const u32 p26 = __builtin_amdgcn_perm(v.w, v.y, 0x05040100u);
+    const u32 p13 = __builtin_amdgcn_perm(v.y, v.x, 0x07060302u);
+    const u32 p57 = __builtin_amdgcn_perm(v.w, v.z, 0x07060302u);
+    constexpr i32 R = 1 << 10;
+    const i32 tmp0 = dot2(p04, pk16(8192, 8192), R), tmp1 = dot2(p04, pk16(8192, -8192), R);
+    const i32 tmp10 = dot2(p26, pk16(K_E2, FIX_0_541196100), tmp0), tmp13 = dot2(p26, pk16(-K_E2, -FIX_0_541196100), tmp0);
+    const i32 tmp11 = dot2(p26, pk16(FIX_0_541196100, K_E6), tmp1), tmp12 = dot2(p26, pk16(-FIX_0_541196100, -K_E6), tmp1);
+    const i32 b0 = dot2(p13, pk16(K_B0[0], K_B0[1]), dot2(p57, pk16(K_B0[2], K_B0[3]), 0));
+    const i32 b1 = dot2(p13, pk16(K_B1[0], K_B1[1]), dot2(p57, pk16(K_B1[2], K_B1[3]), 0));
+    const i32 b2 = dot2(p13, pk16(K_B2[0], K_B2[1]), dot2(p57, pk16(K_B2[2], K_B2[3]), 0));
+    const i32 b3 = dot2(p13, pk16(K_B3[0], K_B3[1]), dot2(p57, pk16(K_B3[2], K_B3[3]), 0));
+    t[0] = wadd(tmp10, b3) >> 11; t[7] = wsub(tmp10, b3) >> 11;
+    t[1] = wadd(tmp11, b2) >> 11; t[6] = wsub(tmp11, b2) >> 11;
+    t[2] = wadd(tmp12, b1) >> 11; t[5] = wsub(tmp12, b1) >> 11;
+    t[3] = wadd(tmp13, b0) >> 11; t[4] = wsub(tmp13, b0) >> 11;
+}
+// idct_4x4's pass 1 (Row!4, :378-397) on cast(short)(v0..v3): the byte permutes take the low halves, which IS the cast
+__device__ __forceinline__ void row_pass4_packed(i32 v0, i32 v1, i32 v2, i32 v3, i32 (&t)[8])
+{
+    const u32 p02 = __builtin_amdgcn_perm((u32)v2, (u32)v0, 0x05040100u);
+    const u32 p13 = __builtin_amdgcn_perm((u32)v3, (u32)v1, 0x05040100u);
+    constexpr i32 R = 1 << 10;
+    const i32 tmp10 = dot2(p02, pk16(8192, K_E2), R), tmp13 = dot2(p02, pk16(8192, -K_E2), R);
+    const i32 tmp11 = dot2(p02, pk16(8192, FIX_0_541196100), R), tmp12 = dot2(p02, pk16(8192, -FIX_0_541196100), R);
+    t[0] = dot2(p13, pk16(K_B3[0], K_B3[1]), tmp10) >> 11; t[7] = dot2(p13, pk16(-K_B3[0], -K_B3[1]), tmp10) >> 11;
+    t[1] = dot2(p13, pk16(K_B2[0], K_B2[1]), tmp11) >> 11; t[6] = dot2(p13, pk16(-K_B2[0], -K_B2[1]), tmp11) >> 11;
+    t[2] = dot2(p13, pk16(K_B1[0], K_B1[1]), tmp12) >> 11; t[5] = dot2(p13, pk16(-K_B1[0], -K_B1[1]), tmp12) >> 11;
+    t[3] = dot2(p13, pk16(K_B0[0], K_B0[1]), tmp13) >> 11; t[4] = dot2(p13, pk16(-K_B0[0], -K_B0[1]), tmp13) >> 11;
+}
+// pass 2 of idct_4x4 (Col!4) on 32-bit inputs t0..t3 (t4..t7 = 0), direct form: 13 multiply-adds + 8 adds instead of
+// the butterfly's 10 + 17 (an add costs 2.5 issue cycles, a multiply-add 4.3)
+__device__ __forceinline__ void col_pass4_direct(i32 t0, i32 t1, i32 t2, i32 t3, i32 (&s)[8])
+{
+    const i32 tmp0 = wadd((i32)((u32)t0 << 13), (128 << 18) + (1 << 17));
+    const i32 tmp10 = mad24(t2, K_E2, tmp0), tmp13 = mad24(t2, -K_E2, tmp0);
+    const i32 tmp11 = mad24(t2, FIX_0_541196100, tmp0), tmp12 = mad24(t2, -FIX_0_541196100, tmp0);
+    const i32 b0 = mad24(t3, K_B0[1], mul24(t1, K_B0[0])), b1 = mad24(t3, K_B1[1], mul24(t1, K_B1[0]));
+    const i32 b2 = mad24(t3, K_B2[1], mul24(t1, K_B2[0])), b3 = mad24(t3, K_B3[1], mul24(t1, K_B3[0]));
+    s[0] = clamp255(wadd(tmp10, b3) >> 18); s[7] = clamp255(wsub(tmp10, b3) >> 18);
+    s[1] = clamp255(wadd(tmp11, b2) >> 18); s[6] = clamp255(wsub(tmp11, b2) >> 18);
+    s[2] = clamp255(wadd(tmp12, b1) >> 18); s[5] = clamp255(wsub(tmp12, b1) >> 18);
+    s[3] = clamp255(wadd(tmp13, b0) >> 18); s[4] = clamp255(wsub(tmp13, b0) >> 18);
 }
 
 // ---- frequency-domain 2x upsample -------------------------------------------

@@ -793,15 +793,21 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
 
     DefilterArgs a{};
     a.raw = raw; a.raw_stride = raw_stride; a.rows = y; a.wb = wb; a.status = status; a.raw_offs = raw_offs; a.d_offs = nullptr;
-    static thread_local DeviceScratch scratch;
+    // The non-fused formats de-filter into a scratch that lives until k_png_expand has read it.  These entry points are
+    // asynchronous and may be called from one thread on several streams, so the scratch is allocated and freed IN STREAM ORDER
+    // (hipMallocAsync / hipFreeAsync on the caller's stream): no two launches can share it, nothing synchronises the device.
+    void* scratch_mem = nullptr;
     if (fused) { a.D = out; a.d_stride = out_stride; a.d_offs = out_offs; a.d_pitch = rgba_fused ? (int64_t)x * 4 : wb; a.store_tail_masked = 1; }
     else {
         const int64_t group = 4 * FB;
         a.d_pitch = ((int64_t)wb + group - 1) / group * group;
         a.d_pitch = (a.d_pitch + 15) / 16 * 16;
         a.d_stride = a.d_pitch * y;
-        a.D = (uint8_t*)scratch.get((size_t)a.d_stride * count + 64);
-        if (!a.D) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png_defilter: scratch allocation failed");
+        if (hipMallocAsync(&scratch_mem, (size_t)a.d_stride * count + 64, stream) != hipSuccess || !scratch_mem) {
+            (void)hipGetLastError();
+            return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png_defilter: scratch allocation failed");
+        }
+        a.D = (uint8_t*)scratch_mem;
         a.store_tail_masked = 0;
     }
     const dim3 grid(count), block(PNG_WAVES * 64);
@@ -815,9 +821,11 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
                                   else      hipLaunchKernelGGL((k_png_defilter<N, PNG_WAVES>), grid, block, 0, stream, a); break;
     GAMUT_PNG_CASE(1) GAMUT_PNG_CASE(2) GAMUT_PNG_CASE(3) GAMUT_PNG_CASE(4) GAMUT_PNG_CASE(6) GAMUT_PNG_CASE(8)
 #undef GAMUT_PNG_CASE
-    default: return set_error(GAMUT_HIP_ERR_INVALID_ARG, "png_defilter: unsupported filter unit %d", FB);
+    default:
+        if (scratch_mem) (void)hipFreeAsync(scratch_mem, stream);
+        return set_error(GAMUT_HIP_ERR_INVALID_ARG, "png_defilter: unsupported filter unit %d", FB);
     }
-    if (int rc = launch_status("png_defilter")) return rc;
+    if (int rc = launch_status("png_defilter")) { if (scratch_mem) (void)hipFreeAsync(scratch_mem, stream); return rc; }
     if (!fused) {
         ExpandArgs e{};
         e.D = a.D; e.d_stride = a.d_stride; e.d_pitch = a.d_pitch; e.out = out; e.out_stride = out_stride;
@@ -833,7 +841,9 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
 #undef GAMUT_PNG_EXPAND
         }
         if (!vec) hipLaunchKernelGGL(k_png_expand, dim3(blocks_for((int64_t)x * y), count), dim3(256), 0, stream, e);
-        if (int rc = launch_status("png_expand")) return rc;
+        const int rc = launch_status("png_expand");
+        (void)hipFreeAsync(scratch_mem, stream);
+        if (rc) return rc;
     }
     return GAMUT_HIP_OK;
 }

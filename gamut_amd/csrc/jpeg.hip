@@ -43,6 +43,7 @@ struct JpegArgs {
     int width, height;
     int mcus_per_row, mcus_per_col;
     int scan_type, out_comps;
+    int count;                                       // images of this launch
 };
 
 // =============================================================================
@@ -56,25 +57,26 @@ constexpr int T1_INTS = 4 * H2V2_MCUS * BLK_STRIDE;           // 32 Y blocks: pa
 constexpr int H_INTS  = 2 * H2V2_MCUS * BLK_STRIDE;           // 16 chroma blocks: horizontal upsample stage H[k][m]
 constexpr int V_INTS  = 2 * H2V2_MCUS * BLK_STRIDE;           // vertical stage V[n][m]
 // T2 (32 (mcu,quadrant) tiles: rows 0-3 = Cb pass-1 rows, 4-7 = Cr) reuses T1's storage: T1 is last read in
-// phase P2, T2 is first written in P3, and a workgroup barrier separates the two.
+// phase P2, T2 is first written in P3.  What separates the two is wave_sync(), NOT a workgroup barrier: it is enough only
+// because tile n of T1 and tile n of T2 are both touched by the threads with t >> 3 == n alone (one 8-lane group of one
+// wave).  Any change of the thread -> tile mappings must keep that, or put a __syncthreads() between P2 and P3.
+// The V area holds Xs, the int16 coefficients of the four expanded blocks per chroma block (2 KB); the rgb8 / l8 variants
+// reuse H + V as their output staging.
 constexpr int LDS_INTS = T1_INTS + H_INTS + V_INTS;
 
 // Both upsample maps have the same shape: two pass-through inputs and two rounded 4-term sums (jpegload.d:929-952,
-// 1001-1032).  A lane evaluates either the "E" or the "O" map depending on its `half` bit; instead of branching (both
-// sides would run for every wave) it carries its 8 multipliers in registers and stores results in the fixed physical
-// order (pass0, pass1, sumA, sumB).  Logical index m of the 8 outputs (0-3 = E0..E3, 4-7 = O0..O3) <-> physical slot:
+// 1001-1032).  In the horizontal stage a lane evaluates either the "E" or the "O" map depending on its `half` bit; instead
+// of branching (both sides would run for every wave) it carries its multipliers in registers and stores results in the fixed
+// physical order (pass0, pass1, sumA, sumB).  Logical index m of the 8 outputs (0-3 = E0..E3, 4-7 = O0..O3) <-> physical slot:
 //   E: e0=pass0 e1=sumA e2=pass1 e3=sumB     O: o0=sumA o1=pass0 o2=sumB o3=pass1
 __device__ __forceinline__ constexpr int phys_slot(int m) { constexpr int P[8] = { 0, 2, 1, 3, 6, 4, 7, 5 }; return P[m]; }
 
-struct MapCoef { i32 a[4], b[4]; };
-__device__ const i32 kMapTable[2][8] __attribute__((aligned(32))) = { { E1a, E1b, E1c, E1d, E3a, E3b, E3c, E3d }, { O0a, O0b, O0c, O0d, O2a, O2b, O2c, O2d } };
 // the same multipliers as packed int16 pairs (u1|u3, u5|u7) for the horizontal stage, whose inputs are int16 (v_dot2_i32_i16)
 __device__ const u32 kMapPacked[2][4] __attribute__((aligned(16))) = {
     { pk16(E1a, E1b), pk16(E1c, E1d), pk16(E3a, E3b), pk16(E3c, E3d) }, { pk16(O0a, O0b), pk16(O0c, O0d), pk16(O2a, O2b), pk16(O2c, O2d) } };
+// vertical stage, by output index j: the rounded sum of (E_j, O_j) is O0 / E1 / O2 / E3 (the other one passes row 2j through)
+__device__ const i32 kVTable[4][4] __attribute__((aligned(16))) = { { O0a, O0b, O0c, O0d }, { E1a, E1b, E1c, E1d }, { O2a, O2b, O2c, O2d }, { E3a, E3b, E3c, E3d } };
 struct __attribute__((packed, aligned(1))) Dwords4u { u32 v[4]; };      // 16 bytes at any alignment (gfx950 stores them natively)
-#ifndef JPEG_DOT2                 // 1: int16-input stages (luma pass 1, chroma horizontal stage, idct_4x4 pass 1) on v_dot2_i32_i16
-#define JPEG_DOT2 1
-#endif
 
 // Every LDS hand-off of the tuned kernel stays inside one 32-lane half of a wave (thread t only ever reads tiles
 // written by threads with the same t >> 5: Y tile t>>3, chroma block t>>4, T2 tile t>>3), so no workgroup barrier is
@@ -86,18 +88,8 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-// pass0 / pass1: the lane's two pass-through inputs (u0,u4 for "E", u2,u6 for "O"), already selected by the caller
-__device__ __forceinline__ void map_half(const MapCoef& c, i32 pass0, i32 pass1, i32 u1, i32 u3, i32 u5, i32 u7, i32 (&o)[4])
-{
-    o[0] = pass0;
-    o[1] = pass1;
-    // four chained multiply-adds each (written out: the optimiser prefers four multiplies and two three-input adds)
-    o[2] = mad24_1(c.a[3], u7, mad24_1(c.a[2], u5, mad24_1(c.a[1], u3, mad24_1(c.a[0], u1, 512)))) >> 10;
-    o[3] = mad24_1(c.b[3], u7, mad24_1(c.b[2], u5, mad24_1(c.b[1], u3, mad24_1(c.b[0], u1, 512)))) >> 10;
-}
-
-#ifndef JPEG_NT_LOADS             // coefficients are read exactly once: nontemporal loads (tuning knob, tools/variant.sh)
-#define JPEG_NT_LOADS 0
+#ifndef JPEG_NT_LOADS             // coefficients are read exactly once: nontemporal loads (A/B on one box: 2.59 -> 2.57 ms)
+#define JPEG_NT_LOADS 1
 #endif
 __device__ __forceinline__ uint4 load_coeffs16(const int16_t* p)
 {
@@ -113,219 +105,271 @@ __device__ __forceinline__ void store_px_nt(uint8_t* row_base, u32 voff, u32 px)
     asm volatile("global_store_dword %0, %1, %2 nt" :: "v"(voff), "v"(px), "s"(row_base));
 }
 
+#ifndef JPEG_XCD_REMAP
+#define JPEG_XCD_REMAP 1
+#endif
+#ifndef JPEG_STRIPS               // consecutive strips one workgroup reconstructs: rgba8 / packed (rgb8, l8) outputs (tuning knobs)
+#define JPEG_STRIPS 1
+#endif
+#ifndef JPEG_STRIPS_PACKED
+#define JPEG_STRIPS_PACKED 5
+#endif
+#ifndef JPEG_ABLATE               // measurement only (tools/variant.sh): 1 = loads + stores, no arithmetic; 2 = no stores; 3 = no loads
+#define JPEG_ABLATE 0
+#endif
+
+#ifndef JPEG_MIN_WAVES            // __launch_bounds__'s second argument: minimum waves per SIMD (0 = unconstrained register allocation)
+#define JPEG_MIN_WAVES 0
+#endif
 template <int OC>                // output components: 4 = rgba8, 3 = rgb8, 1 = l8 (grey of the RGB result, jpegload.d:3786-3792)
+#if JPEG_MIN_WAVES
+__global__ __launch_bounds__(H2V2_THREADS, JPEG_MIN_WAVES) void k_jpeg_h2v2(JpegArgs a)
+#else
 __global__ __launch_bounds__(H2V2_THREADS) void k_jpeg_h2v2(JpegArgs a)
+#endif
 {
     __shared__ __attribute__((aligned(16))) i32 lds[LDS_INTS];
     i32* const T1 = lds;
     i32* const Hs = T1 + T1_INTS;
     i32* const Vs = Hs + H_INTS;
     i32* const T2 = T1;
+    int16_t* const Xs = reinterpret_cast<int16_t*>(Vs);
 
+    constexpr int STRIPS = OC == 4 ? JPEG_STRIPS : JPEG_STRIPS_PACKED;
     const int t = threadIdx.x;
-    const int img = blockIdx.z, mcu_y = blockIdx.y, mcu_x0 = blockIdx.x * H2V2_MCUS;
+    // Workgroup -> work.  (1) XCD-aware order: workgroups are dealt to the 8 XCDs round-robin by linear id (observed on gfx950,
+    // not a contract -- it only matters for speed); with gridDim.x a multiple of 8 the XCD is blockIdx.x & 7.  Every XCD
+    // takes whole images (image = 8 z + xcd) and walks their strips in raster order, so what an XCD's L2 collects at any time
+    // are neighbours: adjacent 512-byte pieces of the same pixel rows, consecutive 6 KB runs of coefficients.  Measured on
+    // the load + store skeleton of this kernel: 2.74 -> 2.40 ms per 1024 x 1080p (dispatch order spreads every pixel row
+    // over all 8 L2s).  (2) A workgroup reconstructs STRIPS consecutive strips of one MCU row, fetching the
+    // coefficients of strip s + 1 before it computes strip s.  For rgba8 one strip per workgroup is as fast as any (A/B on
+    // one box: 1 / 2 / 3 / 5 / 15 strips = 2.55 / 2.63 / 2.57 / 2.64 / 2.84 ms); the packed outputs, whose workgroups end in
+    // a barrier-separated staging pass, gain from 5 (rgb8 2.67 -> 2.63 ms).
+#if JPEG_XCD_REMAP
+    const int img = blockIdx.z * 8 + (blockIdx.x & 7), mcu_y = blockIdx.y, tile0 = (blockIdx.x >> 3) * STRIPS;
+    if (img >= a.count) return;
+#else
+    const int img = blockIdx.z, mcu_y = blockIdx.y, tile0 = blockIdx.x * STRIPS;
+#endif
+    const int n_tiles = (a.mcus_per_row + H2V2_MCUS - 1) / H2V2_MCUS;
     // wave-uniform bases (scalar registers); per-thread parts are small 32-bit offsets
-    const int16_t* cbase = a.coeffs + (int64_t)img * a.coeff_stride + ((int64_t)mcu_y * a.mcus_per_row + mcu_x0) * (6 * 64);
-    uint8_t* obase = a.out + (int64_t)img * a.out_stride + (int64_t)(mcu_y * 16) * a.out_pitch + (int64_t)mcu_x0 * (16 * OC);
-    const int mcus_here = min(H2V2_MCUS, a.mcus_per_row - mcu_x0);
+    const int16_t* cbase = a.coeffs + (int64_t)img * a.coeff_stride + ((int64_t)mcu_y * a.mcus_per_row + tile0 * H2V2_MCUS) * (6 * 64);
+    uint8_t* obase = a.out + (int64_t)img * a.out_stride + (int64_t)(mcu_y * 16) * a.out_pitch + (int64_t)tile0 * (H2V2_MCUS * 16 * OC);
+    const uint8_t* zbase = a.max_zag ? a.max_zag + (int64_t)img * a.zag_stride + ((int64_t)mcu_y * a.mcus_per_row + tile0 * H2V2_MCUS) * 6 : nullptr;
 
     // ---- mapping A: thread = (Y block b = (mcu m, quadrant q), row/column index r) ----
     const int b = t >> 3, r = t & 7, m = b >> 2, q = b & 3;
-    const bool mcu_live = m < mcus_here;
-
     // ---- mapping B: thread = (chroma block cb = (mcu, comp), row k, half) ----
     const int cbk = t >> 4, k = (t >> 1) & 7, half = t & 1;
-    const bool cmcu_live = (cbk >> 1) < mcus_here;
-    // the lane's 8 multipliers: two 16-byte loads from a constant table (selecting them one by one costs three VALU
-    // instructions each on a kernel that is bound by VALU issue)
-    MapCoef mc;
-    {
-        const int4* tab = reinterpret_cast<const int4*>(kMapTable[half]);
-        const int4 ta = tab[0], tb = tab[1];
-        mc.a[0] = ta.x; mc.a[1] = ta.y; mc.a[2] = ta.z; mc.a[3] = ta.w;
-        mc.b[0] = tb.x; mc.b[1] = tb.y; mc.b[2] = tb.z; mc.b[3] = tb.w;
-    }
+    // the lane's multipliers as packed int16 pairs: one 16-byte load from a constant table
     const uint4 mp = *reinterpret_cast<const uint4*>(kMapPacked[half]);
+    // ---- mapping C (vertical stage): thread = (chroma block cbk, column pair ci / 4 + ci, output index cj) ----
+    const int ci = (t >> 2) & 3, cj = t & 3;
+    const int pe = ((ci & 1) << 1) | (ci >> 1);                   // phys_slot(ci), phys_slot(4 + ci)
+    const int po = 4 + ((((ci & 1) ^ 1) << 1) | (ci >> 1));
+    const int4 vc = *reinterpret_cast<const int4*>(kVTable[cj]);
+    const i32 sg = (cj & 1) ? -1 : 1;
 
-    // P0: loads (issued together; 16 B per lane, lane-contiguous inside each MCU).  Lanes of MCUs beyond the edge of the image
-    // re-read the strip's first MCU (there is always one): their results are never stored, and nothing has to be zeroed.
-    const uint4 yrow = load_coeffs16(cbase + (u32)((mcu_live ? m : 0) * 384 + q * 64 + r * 8));
-    const uint4 crow = load_coeffs16(cbase + (u32)((cmcu_live ? (cbk >> 1) : 0) * 384 + 256 + (cbk & 1) * 64 + k * 8));
+    const ColourConsts cc = colour_consts();
+    const int lx = m * 16 + (q & 1) * 8 + r;               // pixel column inside the strip
+    const int ly0 = (q >> 1) * 8;                          // first pixel row inside the strip
+    const bool all_rows = a.height - mcu_y * 16 >= 16;     // wave-uniform: all 16 rows of the strip exist
+    const int rows_here = a.height - mcu_y * 16 - ly0;
+    const u32 pitch = (u32)a.out_pitch;                    // the launcher checks 16 * out_pitch < 2^31
+    const u32 voff = (u32)(lx * 4) + (u32)ly0 * pitch;     // rgba8: the lane's part of a pixel address; the row advances on the scalar side
 
-    // P1a: luma pass 1 (row r of block b) -> T1[b][r][0..7]
-    {
-        i32 tv[8];
-        if (JPEG_DOT2) row_pass_packed(yrow, tv);
-        else { i32 x[8]; unpack_row(yrow, x); row_pass<8>(x, tv); }
-        i32* dst = T1 + b * BLK_STRIDE + r * 8;
-        *reinterpret_cast<int4*>(dst)     = make_int4(tv[0], tv[1], tv[2], tv[3]);
-        *reinterpret_cast<int4*>(dst + 4) = make_int4(tv[4], tv[5], tv[6], tv[7]);
-    }
-    // P1b: chroma horizontal stage: source row k of chroma block cbk -> H[k][physical slots half*4 .. +3]
-    {
-        i32 hv[4];
-        const u32 w0 = half ? crow.y : crow.x, w1 = half ? crow.w : crow.z;        // (u2 | u3) : (u0 | u1),  (u6 | u7) : (u4 | u5)
-        if (JPEG_DOT2) {
+    // P0: loads (16 B per lane, lane-contiguous inside each MCU).  Lanes of MCUs beyond the edge of the image re-read the
+    // strip's first MCU (there is always one): their results are never stored, and nothing has to be zeroed.
+    const u32 yoff = (u32)(m * 384 + q * 64 + r * 8), yoff0 = (u32)(q * 64 + r * 8);
+    const u32 coff = (u32)((cbk >> 1) * 384 + 256 + (cbk & 1) * 64 + k * 8), coff0 = (u32)(256 + (cbk & 1) * 64 + k * 8);
+    auto fetch = [&](int tile, uint4& yv, uint4& cv) {
+        const int here = a.mcus_per_row - tile * H2V2_MCUS;                              // >= 1
+        const int16_t* base = cbase + (int64_t)(tile - tile0) * (H2V2_MCUS * 384);
+#if JPEG_ABLATE == 3
+        yv = make_uint4(t + tile, t * 3, t * 5, t * 7); cv = make_uint4(t * 11, t, t * 13, t * 17 + tile); (void)here; (void)base;
+#else
+        yv = load_coeffs16(base + (m < here ? yoff : yoff0));
+        cv = load_coeffs16(base + ((cbk >> 1) < here ? coff : coff0));
+#endif
+    };
+    uint4 yrow, crow;
+    if (tile0 < n_tiles) fetch(tile0, yrow, crow);
+
+    #pragma unroll 1
+    for (int s = 0; s < STRIPS; ++s) {
+        const int tile = tile0 + s;
+        if (tile >= n_tiles) break;                                // wave-uniform
+        const int mcu_x0 = tile * H2V2_MCUS;
+        const int mcus_here = min(H2V2_MCUS, a.mcus_per_row - mcu_x0);
+        const bool mcu_live = m < mcus_here;
+        uint8_t* const otile = obase + (size_t)s * (H2V2_MCUS * 16 * OC);
+        uint4 ynext = yrow, cnext = crow;
+        if (s + 1 < STRIPS && tile + 1 < n_tiles) fetch(tile + 1, ynext, cnext);     // in flight during this strip's arithmetic
+
+#if JPEG_ABLATE == 1
+        if constexpr (OC == 4) {
+            const u32 v0 = yrow.x ^ yrow.y ^ yrow.z ^ yrow.w ^ crow.x ^ crow.y ^ crow.z ^ crow.w;
+            if (mcu_live && mcu_x0 * 16 + lx < a.width && all_rows) {
+                #pragma unroll
+                for (int i = 0; i < 8; ++i) store_px_nt(otile + (size_t)i * pitch, voff, v0 + i);
+            }
+            yrow = ynext; crow = cnext;
+            continue;
+        }
+#endif
+
+        // P1a: luma pass 1 (row r of block b) -> T1[b][r][0..7]
+        {
+            i32 tv[8];
+            row_pass_packed(yrow, tv);
+            i32* dst = T1 + b * BLK_STRIDE + r * 8;
+            *reinterpret_cast<int4*>(dst)     = make_int4(tv[0], tv[1], tv[2], tv[3]);
+            *reinterpret_cast<int4*>(dst + 4) = make_int4(tv[4], tv[5], tv[6], tv[7]);
+        }
+        // P1b: chroma horizontal stage: source row k of chroma block cbk -> H[k][physical slots half*4 .. +3]
+        {
+            i32 hv[4];
+            const u32 w0 = half ? crow.y : crow.x, w1 = half ? crow.w : crow.z;        // (u2 | u3) : (u0 | u1),  (u6 | u7) : (u4 | u5)
             const u32 p13 = __builtin_amdgcn_perm(crow.y, crow.x, 0x07060302u), p57 = __builtin_amdgcn_perm(crow.w, crow.z, 0x07060302u);
             hv[0] = (i32)(short)(w0 & 0xFFFF);
             hv[1] = (i32)(short)(w1 & 0xFFFF);
             hv[2] = dot2(p13, mp.x, dot2(p57, mp.y, 512)) >> 10;
             hv[3] = dot2(p13, mp.z, dot2(p57, mp.w, 512)) >> 10;
-        } else
-        map_half(mc, (i32)(short)(w0 & 0xFFFF), (i32)(short)(w1 & 0xFFFF),
-                 (i32)crow.x >> 16, (i32)crow.y >> 16, (i32)crow.z >> 16, (i32)crow.w >> 16, hv);
-        *reinterpret_cast<int4*>(Hs + cbk * BLK_STRIDE + k * 8 + half * 4) = make_int4(hv[0], hv[1], hv[2], hv[3]);
-    }
-    wave_sync();
+            *reinterpret_cast<int4*>(Hs + cbk * BLK_STRIDE + k * 8 + half * 4) = make_int4(hv[0], hv[1], hv[2], hv[3]);
+        }
+        wave_sync();
 
-    // P2a: luma pass 2 (column r of block b) -> 8 samples in registers
-    i32 ys[8];
-    {
-        i32 tv[8];
-        const i32* src = T1 + b * BLK_STRIDE + r;
-        #pragma unroll
-        for (int i = 0; i < 8; ++i) tv[i] = src[i * 8];
-        col_pass<8>(tv, ys);
-        if (a.max_zag) {          // wave-uniform: the reference's Col!(1) shortcut (max_zag <= 2) only matters when the caller passes max_zag
-            bool y_col1 = false;
-            if (mcu_live) y_col1 = a.max_zag[(int64_t)img * a.zag_stride + ((int64_t)mcu_y * a.mcus_per_row + mcu_x0 + m) * 6 + q] <= 2;
-            const i32 v = col1_sample(tv[0]);
+        // P2a: luma pass 2 (column r of block b) -> 8 samples in registers
+        i32 ys[8];
+        {
+            i32 tv[8];
+            const i32* src = T1 + b * BLK_STRIDE + r;
             #pragma unroll
-            for (int i = 0; i < 8; ++i) ys[i] = y_col1 ? v : ys[i];
+            for (int i = 0; i < 8; ++i) tv[i] = src[i * 8];
+            col_pass<8>(tv, ys);
+            if (zbase) {          // wave-uniform: the reference's Col!(1) shortcut (max_zag <= 2) only matters when the caller passes max_zag
+                bool y_col1 = false;
+                if (mcu_live) y_col1 = zbase[(s * H2V2_MCUS + m) * 6 + q] <= 2;
+                const i32 v = col1_sample(tv[0]);
+                #pragma unroll
+                for (int i = 0; i < 8; ++i) ys[i] = y_col1 ? v : ys[i];
+            }
         }
-    }
-    // P2b: chroma vertical stage on physical column k of H (all 8 source rows) -> V[physical rows half*4 .. +3][k]
-    {
-        i32 vv[4];
-        const i32* src = Hs + cbk * BLK_STRIDE + k;
-        const i32* psrc = src + half * 16;                   // rows 0,4 ("E") or 2,6 ("O"): the pass-through rows, picked by address
-        map_half(mc, psrc[0], psrc[32], src[8], src[24], src[40], src[56], vv);
-        i32* dst = Vs + cbk * BLK_STRIDE + (half * 4) * 8 + k;
-        #pragma unroll
-        for (int i = 0; i < 4; ++i) dst[i * 8] = vv[i];
-    }
-    wave_sync();
+        // P2b: chroma vertical stage + quadrant combine.  Thread = (chroma block cbk, column pair ci / 4+ci, output index cj): for
+        //     both columns it evaluates E_j and O_j over the 8 source rows -- one of the two is a pass-through of row 2j, the other
+        //     a rounded 4-term sum over rows 1,3,5,7 (:955-989, :1036-1069) -- i.e. P[j][i], Q[j][i], R[j][i], S[j][i], and then
+        //     the four coefficients blk_q[j][i] (:2230-2251, transposed store :886-902):
+        //         blk0 = (P+Q)+(R+S), blk1 = (P+Q)-(R+S), blk2 = (P-Q)+(R-S), blk3 = (P-Q)-(R-S)
+        //     as plain adds: with (pass, sum) for (E_j, O_j) when j is even and (O_j, E_j) when j is odd, P-Q = sg (pass - sum),
+        //     sg = +-1 by the parity of j.  cast(jpgd_block_t) = the 16-bit store.  Xs[cbk][q][j] holds (x0, x2, x1, x3): the
+        //     pairs idct_4x4's pass 1 multiplies (row_pass4_pairs).
+        {
+            const i32* he = Hs + cbk * BLK_STRIDE + pe;
+            const i32* ho = Hs + cbk * BLK_STRIDE + po;
+            const i32 pass_e = he[cj * 16], pass_o = ho[cj * 16];
+            const i32 sum_e = mad24_1(vc.w, he[56], mad24_1(vc.z, he[40], mad24_1(vc.y, he[24], mad24_1(vc.x, he[8], 512)))) >> 10;
+            const i32 sum_o = mad24_1(vc.w, ho[56], mad24_1(vc.z, ho[40], mad24_1(vc.y, ho[24], mad24_1(vc.x, ho[8], 512)))) >> 10;
+            const i32 pa = wadd(pass_e, sum_e), pc = wadd(pass_o, sum_o);
+            const i32 pu = wsub(pass_e, sum_e), pv = wsub(pass_o, sum_o);
+            int16_t* dst = Xs + cbk * 64 + cj * 4 + pe;                   // [cbk][q][j][slot]: 64, 16, 4, 1 elements
+            dst[0]  = (int16_t)wadd(pa, pc);
+            dst[16] = (int16_t)wsub(pa, pc);
+            dst[32] = (int16_t)mad24_1(wadd(pu, pv), sg, 0);
+            dst[48] = (int16_t)mad24_1(wsub(pu, pv), sg, 0);
+        }
+        wave_sync();
 
-    // P3: per (mcu, comp, quadrant, row j): the 4 coefficients blk_q[j][0..3] and idct_4x4's pass 1 on them.
-    //     blk0 = (V00+V10)+(V01+V11), blk1 = (V00+V10)-(V01+V11), blk2 = (V00-V10)+(V01-V11), blk3 = (V00-V10)-(V01-V11)
-    //     with V00 = V[j][i], V10 = V[4+j][i], V01 = V[j][4+i], V11 = V[4+j][4+i]   (jpegload.d:2230-2251, :886-902).
-    //     The +-1 factors ride on 24-bit multiply-adds (|V| < 2^19).
-    {
-        const int mm = t >> 5, comp = (t >> 4) & 1, qq = (t >> 2) & 3, j = t & 3;
-        const int rowA = ((j & 1) << 1) | (j >> 1);                   // phys_slot(j)
-        const int rowB = 4 + ((((j & 1) ^ 1) << 1) | (j >> 1));       // phys_slot(4 + j)
-        const i32* vb = Vs + (mm * 2 + comp) * BLK_STRIDE;
-        const int4 a0 = *reinterpret_cast<const int4*>(vb + rowA * 8), a1 = *reinterpret_cast<const int4*>(vb + rowA * 8 + 4);
-        const int4 b0 = *reinterpret_cast<const int4*>(vb + rowB * 8), b1 = *reinterpret_cast<const int4*>(vb + rowB * 8 + 4);
-        const i32 ra[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
-        const i32 rb[8] = { b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w };
-        const i32 sq = (qq & 2) ? -1 : 1, sr = (qq & 1) ? -1 : 1;
-        i32 x[8], tv[8];
-        #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const i32 p  = mad24_1(rb[phys_slot(i)], sq, ra[phys_slot(i)]);          // a = P+Q (top) / b = P-Q (bottom)
-            const i32 s2 = mad24_1(rb[phys_slot(4 + i)], sq, ra[phys_slot(4 + i)]);  // c = R+S        / d = R-S
-            x[i] = mad24_1(s2, sr, p);
+        // P3: idct_4x4's pass 1 (Row!4) on row j of quadrant block qq of (mcu, comp) -> T2
+        {
+            const int mm = t >> 5, comp = (t >> 4) & 1, qq = (t >> 2) & 3, j = t & 3;
+            const uint2 xp = *reinterpret_cast<const uint2*>(Xs + (mm * 2 + comp) * 64 + qq * 16 + j * 4);
+            i32 tv[8];
+            row_pass4_pairs(xp.x, xp.y, tv);
+            i32* dst = T2 + (mm * 4 + qq) * BLK_STRIDE + (comp * 4 + j) * 8;
+            *reinterpret_cast<int4*>(dst)     = make_int4(tv[0], tv[1], tv[2], tv[3]);
+            *reinterpret_cast<int4*>(dst + 4) = make_int4(tv[4], tv[5], tv[6], tv[7]);
         }
-        if (JPEG_DOT2) row_pass4_packed(x[0], x[1], x[2], x[3], tv);             // cast(jpgd_block_t) = the low halves it packs
-        else {
-            #pragma unroll
-            for (int i = 0; i < 4; ++i) x[i] = (i32)(short)x[i];                   // cast(jpgd_block_t)
-            x[4] = x[5] = x[6] = x[7] = 0;
-            row_pass<4>(x, tv);
-        }
-        i32* dst = T2 + (mm * 4 + qq) * BLK_STRIDE + (comp * 4 + j) * 8;
-        *reinterpret_cast<int4*>(dst)     = make_int4(tv[0], tv[1], tv[2], tv[3]);
-        *reinterpret_cast<int4*>(dst + 4) = make_int4(tv[4], tv[5], tv[6], tv[7]);
-    }
-    wave_sync();
+        wave_sync();
 
-    // P4: chroma pass 2 (Col!4 on column r of the quadrant's Cb and Cr), colour, store
-    {
-        i32 cbs[8], crs[8];
-        const i32* src = T2 + b * BLK_STRIDE + r;
-        if (JPEG_DOT2) {
+        // P4: chroma pass 2 (Col!4 on column r of the quadrant's Cb and Cr), colour, store
+        {
+            i32 cbs[8], crs[8];
+            const i32* src = T2 + b * BLK_STRIDE + r;
             col_pass4_direct(src[0], src[8], src[16], src[24], cbs);
             col_pass4_direct(src[32], src[40], src[48], src[56], crs);
-        } else {
-            i32 tc[8];
-            #pragma unroll
-            for (int i = 0; i < 4; ++i) tc[i] = src[i * 8];
-            tc[4] = tc[5] = tc[6] = tc[7] = 0;
-            col_pass<4>(tc, cbs);
-            #pragma unroll
-            for (int i = 0; i < 4; ++i) tc[i] = src[(4 + i) * 8];
-            col_pass<4>(tc, crs);
-        }
 
-        const ColourConsts cc = colour_consts();
-        const int lx = m * 16 + (q & 1) * 8 + r;               // pixel column inside the strip
-        const int ly0 = (q >> 1) * 8;                          // first pixel row inside the strip
-        const bool px_live = mcu_live && mcu_x0 * 16 + lx < a.width;
-        const bool all_rows = a.height - mcu_y * 16 >= 16;     // wave-uniform: all 16 rows of the strip exist
-        const int rows_here = a.height - mcu_y * 16 - ly0;
-        const u32 pitch = (u32)a.out_pitch;                    // the launcher checks 16 * out_pitch < 2^31
-        // Addresses = uniform strip base + 32-bit lane offset.  Pixel rows are written with nontemporal stores.
-        if constexpr (OC == 4) {
-            // one pixel per lane per row: a wave store instruction writes two full 128-byte lines.  (16-byte stores after an
-            // in-quad DPP transpose were measured 2 % slower: the kernel is VALU-bound, not store-issue-bound.)
-            if (px_live) {
-                const u32 voff = (u32)(lx * 4) + (u32)ly0 * pitch;      // the lane's part; the row advances on the scalar side
-                if (all_rows) {
-                    #pragma unroll
-                    for (int i = 0; i < 8; ++i) store_px_nt(obase + (size_t)i * pitch, voff, ycc_to_rgba(ys[i], cbs[i], crs[i], cc.kr, cc.kb));
-                } else {
-                    #pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        if (i < rows_here) store_px_nt(obase + (size_t)i * pitch, voff, ycc_to_rgba(ys[i], cbs[i], crs[i], cc.kr, cc.kb));
+            const bool px_live = mcu_live && mcu_x0 * 16 + lx < a.width;
+            // Addresses = uniform strip base + 32-bit lane offset.  Pixel rows are written with nontemporal stores.
+            if constexpr (OC == 4) {
+                // one pixel per lane per row: a wave store instruction writes two full 128-byte lines.  (16-byte stores after an
+                // in-quad DPP transpose were measured 2 % slower, and on the bare load + store skeleton no faster.)
+                if (px_live) {
+                    if (JPEG_ABLATE == 2) {
+                        u32 acc = 0;
+                        #pragma unroll
+                        for (int i = 0; i < 8; ++i) acc += ycc_to_rgba(ys[i], cbs[i], crs[i], cc.kr, cc.kb);
+                        if (acc == 0x12345679u) store_px_nt(otile, voff, acc);
+                    } else
+                    if (all_rows) {
+                        #pragma unroll
+                        for (int i = 0; i < 8; ++i) store_px_nt(otile + (size_t)i * pitch, voff, ycc_to_rgba(ys[i], cbs[i], crs[i], cc.kr, cc.kb));
+                    } else {
+                        #pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            if (i < rows_here) store_px_nt(otile + (size_t)i * pitch, voff, ycc_to_rgba(ys[i], cbs[i], crs[i], cc.kr, cc.kb));
+                    }
                 }
-            }
-        } else {
-            // rgb8 / l8: a strip row is 384 / 128 bytes, but a wave's lanes hold 16-pixel runs of it, i.e. 48- / 16-byte
-            // pieces: written directly they are partial lines (measured: 13 % more HBM traffic than the algorithmic bytes).
-            // The strip is assembled in LDS (the H / V staging area is free by now) and written out in whole 16-byte
-            // chunks, consecutive lanes along a row.
-            // rgb8: the four pixels of a lane quad are 12 bytes = 3 dwords; lane j < 3 of the quad builds dword j from its own
-            // pixel and its right neighbour's (one DPP quad shuffle + one byte permute).  l8: four grey bytes make one
-            // dword, gathered with two in-quad OR steps; lane 0 of the quad keeps it.
-            static_assert(OC == 3 || OC == 1, "output components");
-            constexpr int BPR = 16 * H2V2_MCUS * OC;               // bytes per strip row
-            uint8_t* stage = reinterpret_cast<uint8_t*>(Hs);       // 16 rows x BPR <= 6144 B of the 9216 B H/V area
-            const int j = lx & 3;
-            __syncthreads();                                       // other waves may still be reading V in P3
-            #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const u32 px = ycc_to_rgba(ys[i], cbs[i], crs[i], cc.kr, cc.kb);
-                if constexpr (OC == 3) {
-                    const u32 sel = j == 0 ? 0x04020100u : j == 1 ? 0x05040201u : 0x06050402u;
-                    const u32 nx = (u32)__builtin_amdgcn_mov_dpp((int)px, 0xF9, 0xF, 0xF, true);      // quad_perm [1,2,3,3]: right neighbour
-                    const u32 dw = __builtin_amdgcn_perm(nx, px, sel);
-                    if (j < 3) *reinterpret_cast<u32*>(stage + (ly0 + i) * BPR + lx * 3 + j) = dw;        // (lx - j) * 3 + 4 j
-                } else {
-                    u32 v = rgb_to_luma(px) << (8 * j);
-                    v |= (u32)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);                   // quad_perm [1,0,3,2]
-                    v |= (u32)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);                   // quad_perm [2,3,0,1]
-                    if (j == 0) *reinterpret_cast<u32*>(stage + (ly0 + i) * BPR + lx) = v;
+            } else {
+                // rgb8 / l8: a strip row is 384 / 128 bytes, but a wave's lanes hold 16-pixel runs of it, i.e. 48- / 16-byte
+                // pieces: written directly they are partial lines (measured: 13 % more HBM traffic than the algorithmic bytes).
+                // The strip is assembled in LDS (the H / V staging area is free by now) and written out in whole 16-byte
+                // chunks, consecutive lanes along a row.
+                // rgb8: the four pixels of a lane quad are 12 bytes = 3 dwords; lane j < 3 of the quad builds dword j from its own
+                // pixel and its right neighbour's (one DPP quad shuffle + one byte permute).  l8: four grey bytes make one
+                // dword, gathered with two in-quad OR steps; lane 0 of the quad keeps it.
+                static_assert(OC == 3 || OC == 1, "output components");
+                constexpr int BPR = 16 * H2V2_MCUS * OC;               // bytes per strip row
+                uint8_t* stage = reinterpret_cast<uint8_t*>(Hs);       // 16 rows x BPR <= 6144 B of the 9216 B H/V area
+                const int j = lx & 3;
+                __syncthreads();                                       // other waves may still be reading Xs in P3
+                #pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const u32 px = ycc_to_rgba(ys[i], cbs[i], crs[i], cc.kr, cc.kb);
+                    if constexpr (OC == 3) {
+                        const u32 sel = j == 0 ? 0x04020100u : j == 1 ? 0x05040201u : 0x06050402u;
+                        const u32 nx = (u32)__builtin_amdgcn_mov_dpp((int)px, 0xF9, 0xF, 0xF, true);      // quad_perm [1,2,3,3]: right neighbour
+                        const u32 dw = __builtin_amdgcn_perm(nx, px, sel);
+                        if (j < 3) *reinterpret_cast<u32*>(stage + (ly0 + i) * BPR + lx * 3 + j) = dw;        // (lx - j) * 3 + 4 j
+                    } else {
+                        u32 v = rgb_to_luma(px) << (8 * j);
+                        v |= (u32)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);                   // quad_perm [1,0,3,2]
+                        v |= (u32)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);                   // quad_perm [2,3,0,1]
+                        if (j == 0) *reinterpret_cast<u32*>(stage + (ly0 + i) * BPR + lx) = v;
+                    }
                 }
-            }
-            __syncthreads();
-            const int row_bytes = min(mcus_here * 16, a.width - mcu_x0 * 16) * OC;       // live bytes of a strip row (rows are tight)
-            const int live_rows = min(16, a.height - mcu_y * 16);
-            constexpr int CPR = BPR / 16;                          // 16-byte chunks per row: 24 / 8
-            for (int c = t; c < 16 * CPR; c += H2V2_THREADS) {
-                const int row = c / CPR, off = (c - row * CPR) * 16;
-                if (row >= live_rows || off >= row_bytes) continue;
-                const uint4 v = *reinterpret_cast<const uint4*>(stage + row * BPR + off);
-                uint8_t* o = obase + (u32)row * pitch + (u32)off;
-                if (off + 16 <= row_bytes) {
-                    Dwords4u d; d.v[0] = v.x; d.v[1] = v.y; d.v[2] = v.z; d.v[3] = v.w;
-                    *reinterpret_cast<Dwords4u*>(o) = d;
-                } else {
-                    const u32 w[4] = { v.x, v.y, v.z, v.w };
-                    for (int k = 0; k < row_bytes - off; ++k) o[k] = (uint8_t)(w[k >> 2] >> ((k & 3) * 8));
+                __syncthreads();
+                const int row_bytes = min(mcus_here * 16, a.width - mcu_x0 * 16) * OC;       // live bytes of a strip row (rows are tight)
+                const int live_rows = min(16, a.height - mcu_y * 16);
+                constexpr int CPR = BPR / 16;                          // 16-byte chunks per row: 24 / 8
+                for (int c = t; c < 16 * CPR; c += H2V2_THREADS) {
+                    const int row = c / CPR, off = (c - row * CPR) * 16;
+                    if (row >= live_rows || off >= row_bytes) continue;
+                    const uint4 v = *reinterpret_cast<const uint4*>(stage + row * BPR + off);
+                    uint8_t* o = otile + (u32)row * pitch + (u32)off;
+                    if (off + 16 <= row_bytes) {
+                        Dwords4u d; d.v[0] = v.x; d.v[1] = v.y; d.v[2] = v.z; d.v[3] = v.w;
+                        *reinterpret_cast<Dwords4u*>(o) = d;
+                    } else {
+                        const u32 w[4] = { v.x, v.y, v.z, v.w };
+                        for (int kk = 0; kk < row_bytes - off; ++kk) o[kk] = (uint8_t)(w[kk >> 2] >> ((kk & 3) * 8));
+                    }
                 }
+                __syncthreads();                                       // the next strip's horizontal stage overwrites the staging area
             }
         }
+        wave_sync();                                                   // T2 (read above) aliases the next strip's T1
+        yrow = ynext; crow = cnext;
     }
 }
 
@@ -615,6 +659,7 @@ int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
     for (int i0 = 0; i0 < count; i0 += 65535) {             // gridDim.z limit
         const int n = count - i0 < 65535 ? count - i0 : 65535;
         JpegArgs c = a;
+        c.count = n;
         c.coeffs += (int64_t)i0 * coeff_stride; c.out += (int64_t)i0 * out_stride;
         if (c.max_zag) c.max_zag += (int64_t)i0 * zag_stride;
         const dim3 grid(tiles, a.mcus_per_col, n);
@@ -622,7 +667,13 @@ int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
         const bool tuned = out_pitch > 0 && out_pitch < (1 << 27) && scan_type != GAMUT_JPGD_YH1V2 &&
                            (out_comps != 4 || (((uintptr_t)out & 3) == 0 && (out_pitch & 3) == 0 && (out_stride & 3) == 0));
         const dim3 grid32((a.mcus_per_row + 31) / 32, a.mcus_per_col, n);           // grey: 32 MCUs per workgroup
-        const dim3 grid420((a.mcus_per_row + H2V2_MCUS - 1) / H2V2_MCUS, a.mcus_per_col, n);
+        const int strips420 = out_comps == 4 ? JPEG_STRIPS : JPEG_STRIPS_PACKED;
+        const unsigned groups420 = (unsigned)(((a.mcus_per_row + H2V2_MCUS - 1) / H2V2_MCUS + strips420 - 1) / strips420);
+#if JPEG_XCD_REMAP
+        const dim3 grid420(8u * groups420, a.mcus_per_col, (n + 7) / 8);
+#else
+        const dim3 grid420(groups420, a.mcus_per_col, n);
+#endif
 #define GAMUT_JPEG_PLAIN(ST, G) do { \
             if (out_comps == 4)      hipLaunchKernelGGL((k_jpeg_plain<ST, 4>), G, dim3(256), 0, stream, c); \
             else if (out_comps == 3) hipLaunchKernelGGL((k_jpeg_plain<ST, 3>), G, dim3(256), 0, stream, c); \

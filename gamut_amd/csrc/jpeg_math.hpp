@@ -172,10 +172,14 @@ __device__ __forceinline__ void row_pass_packed(const uint4& v, i32 (&t)[8])
     t[3] = wadd(tmp13, b0) >> 11; t[4] = wsub(tmp13, b0) >> 11;
 }
 // idct_4x4's pass 1 (Row!4, :378-397) on cast(short)(v0..v3): the byte permutes take the low halves, which IS the cast
+__device__ __forceinline__ void row_pass4_pairs(u32 p02, u32 p13, i32 (&t)[8]);
 __device__ __forceinline__ void row_pass4_packed(i32 v0, i32 v1, i32 v2, i32 v3, i32 (&t)[8])
 {
-    const u32 p02 = __builtin_amdgcn_perm((u32)v2, (u32)v0, 0x05040100u);
-    const u32 p13 = __builtin_amdgcn_perm((u32)v3, (u32)v1, 0x05040100u);
+    row_pass4_pairs(__builtin_amdgcn_perm((u32)v2, (u32)v0, 0x05040100u), __builtin_amdgcn_perm((u32)v3, (u32)v1, 0x05040100u), t);
+}
+// the same on ready-made pairs p02 = x0 | x2 << 16, p13 = x1 | x3 << 16
+__device__ __forceinline__ void row_pass4_pairs(u32 p02, u32 p13, i32 (&t)[8])
+{
     constexpr i32 R = 1 << 10;
     const i32 tmp10 = dot2(p02, pk16(8192, K_E2), R), tmp13 = dot2(p02, pk16(8192, -K_E2), R);
     const i32 tmp11 = dot2(p02, pk16(8192, FIX_0_541196100), R), tmp12 = dot2(p02, pk16(8192, -FIX_0_541196100), R);

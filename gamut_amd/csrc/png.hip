@@ -794,20 +794,31 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
     DefilterArgs a{};
     a.raw = raw; a.raw_stride = raw_stride; a.rows = y; a.wb = wb; a.status = status; a.raw_offs = raw_offs; a.d_offs = nullptr;
     // The non-fused formats de-filter into a scratch that lives until k_png_expand has read it.  These entry points are
-    // asynchronous and may be called from one thread on several streams, so the scratch is allocated and freed IN STREAM ORDER
-    // (hipMallocAsync / hipFreeAsync on the caller's stream): no two launches can share it, nothing synchronises the device.
-    void* scratch_mem = nullptr;
+    // asynchronous and may be called from one thread on several streams, so every (thread, stream) pair owns its scratch:
+    // launches on one stream are ordered, launches on different streams never share a buffer.  Growing a scratch waits for
+    // ITS stream only (the buffer may still be in use there) -- never for the device.
+    struct StreamScratch { hipStream_t stream; void* p; size_t cap; };
+    static thread_local std::vector<StreamScratch> scratches;
+    auto scratch_get = [&](size_t n) -> void* {
+        StreamScratch* e = nullptr;
+        for (StreamScratch& c : scratches) if (c.stream == stream) { e = &c; break; }
+        if (!e) { scratches.push_back(StreamScratch{ stream, nullptr, 0 }); e = &scratches.back(); }
+        if (n > e->cap) {
+            if (e->p) { (void)hipStreamSynchronize(stream); (void)hipFree(e->p); e->p = nullptr; e->cap = 0; }
+            const size_t want = n + n / 4 + 4096;
+            if (hipMalloc(&e->p, want) != hipSuccess) { (void)hipGetLastError(); e->p = nullptr; return nullptr; }
+            e->cap = want;
+        }
+        return e->p;
+    };
     if (fused) { a.D = out; a.d_stride = out_stride; a.d_offs = out_offs; a.d_pitch = rgba_fused ? (int64_t)x * 4 : wb; a.store_tail_masked = 1; }
     else {
         const int64_t group = 4 * FB;
         a.d_pitch = ((int64_t)wb + group - 1) / group * group;
         a.d_pitch = (a.d_pitch + 15) / 16 * 16;
         a.d_stride = a.d_pitch * y;
-        if (hipMallocAsync(&scratch_mem, (size_t)a.d_stride * count + 64, stream) != hipSuccess || !scratch_mem) {
-            (void)hipGetLastError();
-            return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png_defilter: scratch allocation failed");
-        }
-        a.D = (uint8_t*)scratch_mem;
+        a.D = (uint8_t*)scratch_get((size_t)a.d_stride * count + 512);
+        if (!a.D) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png_defilter: scratch allocation failed");
         a.store_tail_masked = 0;
     }
     const dim3 grid(count), block(PNG_WAVES * 64);
@@ -821,11 +832,9 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
                                   else      hipLaunchKernelGGL((k_png_defilter<N, PNG_WAVES>), grid, block, 0, stream, a); break;
     GAMUT_PNG_CASE(1) GAMUT_PNG_CASE(2) GAMUT_PNG_CASE(3) GAMUT_PNG_CASE(4) GAMUT_PNG_CASE(6) GAMUT_PNG_CASE(8)
 #undef GAMUT_PNG_CASE
-    default:
-        if (scratch_mem) (void)hipFreeAsync(scratch_mem, stream);
-        return set_error(GAMUT_HIP_ERR_INVALID_ARG, "png_defilter: unsupported filter unit %d", FB);
+    default: return set_error(GAMUT_HIP_ERR_INVALID_ARG, "png_defilter: unsupported filter unit %d", FB);
     }
-    if (int rc = launch_status("png_defilter")) { if (scratch_mem) (void)hipFreeAsync(scratch_mem, stream); return rc; }
+    if (int rc = launch_status("png_defilter")) return rc;
     if (!fused) {
         ExpandArgs e{};
         e.D = a.D; e.d_stride = a.d_stride; e.d_pitch = a.d_pitch; e.out = out; e.out_stride = out_stride;
@@ -841,9 +850,7 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
 #undef GAMUT_PNG_EXPAND
         }
         if (!vec) hipLaunchKernelGGL(k_png_expand, dim3(blocks_for((int64_t)x * y), count), dim3(256), 0, stream, e);
-        const int rc = launch_status("png_expand");
-        (void)hipFreeAsync(scratch_mem, stream);
-        if (rc) return rc;
+        if (int rc = launch_status("png_expand")) return rc;
     }
     return GAMUT_HIP_OK;
 }

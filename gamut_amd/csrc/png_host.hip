@@ -32,7 +32,7 @@ struct Reader {                       // stb's memory reader: reads past the end
 struct PngHeader {
     uint32_t x = 0, y = 0; int depth = 0, color = 0, interlace = 0, img_n = 0, pal_img_n = 0;
     bool has_trans = false, is_iphone = false;
-    uint8_t palette[1024]; uint32_t pal_len = 0;
+    uint8_t palette[1024] = {}; uint32_t pal_len = 0;     // zero-initialised like the D array (stbdec.d:1779): indices >= pal_len expand to (0,0,0,0)
     uint16_t tc[3] = { 0, 0, 0 };      // tRNS key: 8-bit values already scaled (stbdec.d:1945), 16-bit as-is (:1941)
     float ppmX = -1, ppmY = -1, aspect = -1;
     uint8_t* idata = nullptr; uint32_t ioff = 0;
@@ -412,8 +412,11 @@ int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* 
         if (threads <= 0) threads = host_threads();
         threads = threads < 1 ? 1 : threads > count ? count : threads;
         hipStream_t st = pick_stream(stream);
-        static thread_local hipStream_t copy_stream = nullptr;
-        if (!copy_stream) GAMUT_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        static thread_local hipStream_t copy_stream_tl = nullptr;
+        if (!copy_stream_tl) GAMUT_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_tl, hipStreamNonBlocking));
+        // a plain local: thread_local variables are not captured by the worker lambda below -- every worker thread would
+        // read ITS OWN (null) instance and upload on the legacy null stream
+        const hipStream_t copy_stream = copy_stream_tl;
 
         // 0. IHDR of every file: a slot in the device arena for its inflated stream
         std::vector<BatchFile> files((size_t)count);

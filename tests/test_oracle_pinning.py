@@ -192,6 +192,97 @@ def test_jpeg_upsample_float_model_and_kats():
             assert np.array_equal(O.jpeg_idct_4x4(u[q]), ref)
 
 
+def _literal():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_literal_jpeg", os.path.join(os.path.dirname(HERE), "tools", "ref_literal_jpeg.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    return m
+
+
+def _pinning_blocks(rng, n):
+    """n coefficient blocks of three kinds: natural (sparse, zig-zag decaying, |c| <= 1024), dense 11-bit, wild int16"""
+    blocks = np.zeros((n, 64), np.int16)
+    k = n // 3
+    scale = (1024.0 / (1 + np.arange(64)) ** 1.2)
+    nat = (rng.standard_normal((k, 64)) * scale).round().clip(-1024, 1023)
+    nat *= rng.random((k, 64)) < 0.5
+    blocks[:k][:, ZAG] = nat.astype(np.int16)
+    blocks[k:2 * k] = rng.integers(-1024, 1024, (k, 64))
+    blocks[2 * k:] = rng.integers(-32768, 32768, (n - 2 * k, 64))
+    ext = blocks[2 * k:2 * k + 64]
+    ext[:] = np.where(rng.random(ext.shape) < 0.5, 32767, -32768)                     # extremes: every wrap-around path
+    return blocks
+
+
+def test_jpeg_literal_restatement_bit_equal_upsample_and_idct():
+    """THE pinning of the H2V2 leg: tools/ref_literal_jpeg.py (a second restatement, written literally from jpegload.d
+    :156-397, :827-1073, :2132-2255 -- P_Q / R_S transliterated mechanically from the D statements) must agree BIT FOR BIT
+    with oracle/oracle_jpeg.c: the four expanded coefficient blocks (incl. cast(short) and the transposed store), the
+    idct_4x4 samples, and idct() for every block_max_zag -- on > 10^5 random blocks (natural / dense / wild int16), for all
+    64 s_max_rc entries, with real zeros beyond max_zag and with garbage there (both readings must ignore it alike)."""
+    R = _literal()
+    rng = np.random.default_rng(20260930)
+    n_total = 0
+    for mz in range(1, 65):
+        n = 1800 if mz < 64 else 6000
+        blocks = _pinning_blocks(rng, n)
+        clean = blocks.copy(); clean[:, ZAG[mz:]] = 0                                    # consistent with max_zag
+        for data in (clean, blocks):                                                    # and garbage beyond it
+            temps, samples = R.chroma_expand(data, mz)
+            pix = R.idct(data, mz)
+            for i in range(0, n, 7 if mz < 64 else 1):                                  # the C oracle is called block by block
+                up = O.jpeg_upsample_block(data[i], mz)
+                assert np.array_equal(up.reshape(4, 64), temps[:, i, :]), (mz, i)
+                for q in range(4):
+                    assert np.array_equal(O.jpeg_idct_4x4(up[q]).reshape(64), samples[q, i]), (mz, i, q)
+                assert np.array_equal(O.jpeg_idct(data[i], mz).reshape(64), pix[i]), (mz, i)
+                n_total += 1
+    assert n_total >= 40000
+    # dense path, every block (the headline case: max_zag = NULL -> 64): 10^5 more through the batched reconstruct below
+    blocks = _pinning_blocks(rng, 102000)
+    temps, samples = R.chroma_expand(blocks, 64)
+    ypix = R.idct(blocks, 64)
+    # oracle side in one call: a 4:2:0 frame whose MCUs carry these blocks as Cb (and as Y0): 17000 MCUs = 6 blocks each
+    w, h = 16 * 170, 16 * 100
+    co = blocks.reshape(17000, 6, 64)
+    got = O.jpeg_reconstruct(w, h, 3, O.JPGD_YH2V2, co, None, 4)
+    exp = R.decode_h2v2_rgba_fast(co, w, h)
+    assert np.array_equal(got, exp)
+    assert temps.shape == (4, 102000, 64) and ypix.shape == (102000, 64)
+
+
+def test_jpeg_literal_restatement_pixels_small_frames():
+    """whole 4:2:0 frames through the literal driver (transform_mcu_expand + the SSE sequence of expanded_convert, per
+    scanline, cropped like :3764) == orc_jpeg_reconstruct, ragged sizes, with and without max_zag"""
+    R = _literal()
+    rng = np.random.default_rng(7)
+    for (w, h) in [(16, 16), (17, 1), (40, 23), (1, 33)]:
+        mr, mc = (w + 15) // 16, (h + 15) // 16
+        co = _pinning_blocks(rng, mr * mc * 6).reshape(mr * mc, 6, 64)
+        assert np.array_equal(O.jpeg_reconstruct(w, h, 3, O.JPGD_YH2V2, co, None, 4), R.decode_h2v2_rgba(co, None, w, h))
+        mz = rng.integers(1, 65, (mr * mc, 6)).astype(np.uint8)
+        assert np.array_equal(O.jpeg_reconstruct(w, h, 3, O.JPGD_YH2V2, co, mz, 4), R.decode_h2v2_rgba(co, mz, w, h))
+    # the colour tables of create_look_ups (:2085-2094) give the same R/G/B as the table-free SSE arithmetic of :2769-2794
+    crr, cbb, crg, cbg = R.create_look_ups()
+    y, cb, cr = np.meshgrid(np.arange(0, 256, 5), np.arange(256), np.arange(256), indexing="ij")
+    r = np.clip(y + crr[cr], 0, 255); g = np.clip(y + ((crg[cr] + cbg[cb]) >> 16), 0, 255); b = np.clip(y + cbb[cb], 0, 255)
+    sb = np.zeros(12 * 64, np.uint8)
+    for yy in (0, 100, 255):
+        for cbv in (0, 77, 128, 255):
+            sb[:256] = yy; sb[256:512] = cbv; sb[512:] = np.arange(256, dtype=np.uint8)          # Cr sweeps 0..255 over the 4 Cr blocks
+            lines = np.concatenate([R.expanded_convert(sb, 1, row).reshape(16, 4) for row in range(16)])
+            crs = np.concatenate([sb[512 + ((row // 8) * 2 + k) * 64 + (row & 7) * 8:][:8] for row in range(16) for k in (0, 1)])
+            assert np.array_equal(lines[:, 0], r[yy // 5, cbv, crs]) and np.array_equal(lines[:, 1], g[yy // 5, cbv, crs])
+            assert np.array_equal(lines[:, 2], b[yy // 5, cbv, crs]) and (lines[:, 3] == 255).all()
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/source/gamut/codecs/jpegload.d"), reason="reference tree not present")
+def test_jpeg_literal_restatement_is_current_transliteration():
+    """the P_Q / R_S statements in tools/ref_literal_jpeg.py are exactly what tools/make_ref_literal.py produces from the D text today"""
+    import subprocess, sys
+    subprocess.check_call([sys.executable, os.path.join(os.path.dirname(HERE), "tools", "make_ref_literal.py"), "--check"])
+
+
 def test_jpeg_sparse_paths_equal_dense():
     """Row!N / Col!N / DC-only / P_Q!(R,C) substitute literal zeros: bit-identical to the dense transform for 8-bit-range data"""
     rng = np.random.default_rng(1)
@@ -316,6 +407,61 @@ def test_convert_matches_numpy_binary32_model(src):
             if e.dtype == np.float32:                     # NaN payloads are outside the parity contract
                 same |= np.isnan(e).any(axis=1) & np.isnan(g2).any(axis=1)
             assert same.all(), f"{src}->{dst}: rows {np.flatnonzero(~same)[:5]}"
+
+
+def _scanline_vectors():
+    z = np.load(os.path.join(G, "scanline_ref.npz"))
+    return z, json.loads(bytes(z["sha_json"]).decode())
+
+
+def check_convert_against_reference_vectors(pairs=None):
+    """oracle/oracle_convert.c == tests/golden/scanline_ref.npz, the outputs of the reference's OWN scanline functions
+    (source/gamut/scanline.d executed statement by statement through tools/d_scanline_exec.py, generated by
+    tools/make_scanline_vectors.py).  0 ulp: f32 results are compared as bit patterns."""
+    z, sha = _scanline_vectors()
+    n = z["in_l8"].size
+    for s in PIXEL_TYPES:
+        for d in PIXEL_TYPES:
+            if s == d or (pairs is not None and (s, d) not in pairs):
+                continue
+            got = O.scanlines_convert(s, z["in_" + s], d, n, 1)
+            assert np.array_equal(got.view(np.uint8).reshape(-1), z[f"out_{s}_{d}"]), (s, d)
+    if pairs is not None:
+        return
+    all16, all8 = np.arange(65536, dtype=np.uint16), np.arange(256, dtype=np.uint8)
+    for key, v in [("l16_lf32", all16), ("l16_l8", all16), ("l8_l16", all8), ("l8_lf32", all8), ("l16_rgba8", all16), ("l8_rgbaf32", all8)]:
+        s, d = key.split("_")
+        assert hashlib.sha256(O.scanlines_convert(s, v.view(np.uint8), d, v.size, 1).tobytes()).hexdigest() == sha[key], key
+    c, a = np.meshgrid(all8, all8, indexing="ij")
+    pairs8 = np.stack([c, a], axis=-1).reshape(-1).astype(np.uint8)
+    for key in ("pairs_lap8_laf32", "pairs_lap8_la8", "pairs_la8_lap8", "pairs_lap8_rgbaf32", "pairs_la8_lap16"):
+        _, s, d = key.split("_")
+        assert hashlib.sha256(O.scanlines_convert(s, pairs8, d, 65536, 1).tobytes()).hexdigest() == sha[key], key
+
+
+def test_convert_matches_reference_vectors():
+    check_convert_against_reference_vectors()
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/source/gamut/scanline.d"), reason="reference tree not present")
+def test_convert_vectors_are_current_and_random_sweep_vs_reference_text():
+    """the committed vectors are what the reference's text gives today, and on fresh random rows of every pair the oracle
+    equals the executed reference too (premultiplied, grey and float->int expressions included: scanline.d:240-803)"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    import make_scanline_vectors as M
+    fresh = M.build()
+    z, _ = _scanline_vectors()
+    assert set(fresh) == set(z.files)
+    for k in z.files:
+        assert np.array_equal(fresh[k], z[k]), k
+    R = M.Reference()
+    ins = M.inputs(np.random.default_rng(99))
+    for s in PIXEL_TYPES:
+        for d in PIXEL_TYPES:
+            if s != d:
+                exp = R.convert_row(s, d, ins[s], M.N, M.SIZE)
+                assert np.array_equal(O.scanlines_convert(s, ins[s], d, M.N, 1).view(np.uint8).reshape(-1), exp), (s, d)
 
 
 def test_convert_composite_tables():

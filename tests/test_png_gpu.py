@@ -180,6 +180,11 @@ def test_generated_png_files(hip):
     cases.append(("cgbi", gen.write_png(smp, w, h, 6, 8, iphone=True)))
     cases.append(("phys", gen.write_png(smp, w, h, 6, 8, extra_chunks=[(b"pHYs", (3780).to_bytes(4, "big") + (7560).to_bytes(4, "big") + b"\x01")])))
     cases.append(("noiend", gen.write_png(smp, w, h, 6, 8, no_iend=True)))
+    # a PLTE shorter than the index range (legal): indices >= pal_len expand to (0,0,0,0), the zero-initialised tail of the
+    # reference's palette array (stbdec.d:1779) -- with and without tRNS, 4- and 8-bit indices
+    short_pal = rng.integers(1, 256, (5, 3))
+    cases.append(("c3d4_short_plte", gen.write_png(rng.integers(0, 16, (h, w)), w, h, 3, 4, palette=short_pal)))
+    cases.append(("c3d8_short_plte_trns", gen.write_png(rng.integers(0, 256, (h, w)), w, h, 3, 8, palette=short_pal, trns=[7, 200])))
     cases.append(("1x1", gen.write_png(smp[:1, :4], 1, 1, 6, 8)))
     cases.append(("adam7_small", gen.write_png(smp[:3, :8], 2, 3, 6, 8, interlace=1)))
     for label, data in cases:

@@ -35,14 +35,17 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI35
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1024, help="images per GPU per step")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--workload", default="jpeg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the live rocprofv3 --pmc passes (roofline.traffic falls back to profiles/)")
+    ap.add_argument("--total-images", type=int, default=0, help="mixed workload: images over ALL ranks (8192 = BASELINE.json configs[4]); "
+                    "each rank takes total / N (strong scaling) instead of --batch")
     ap.add_argument("--gather", action="store_true", help="N > 1: also time an all_gather of output slices (after the timed region)")
     return ap.parse_args()
 
@@ -53,7 +56,7 @@ def traffic_from_profiles(workload, kernel_substr):
     import glob
     import re
     norm = lambda w: re.sub(r"^batch \d+ x |, \d+ layers of ", "|", w)
-    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench.json"))):
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench.json")), reverse=True):      # newest round first
         try:
             line = [ln for ln in open(p).read().splitlines() if ln.startswith("{")][-1]
             if norm(json.loads(line)["config"]["workload"]) != norm(workload):
@@ -67,9 +70,72 @@ def traffic_from_profiles(workload, kernel_substr):
     return None
 
 
+def live_traffic(kernel_substr, pmc_batch):
+    """HBM bytes per image of the dominant kernel, measured NOW: two rocprofv3 --pmc passes (FETCH_SIZE, then WRITE_SIZE: they
+    do not fit one pass) over a short run of this same script and workload at a smaller batch.  Corrections as
+    /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes: counters are in KB, and on gfx950 FETCH_SIZE counts a wide
+    coalesced read stream at half its bytes.  Returns (bytes_per_image, note) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    inner = [a for a in sys.argv[1:]]
+    for flag in ("--steps", "--warmup", "--batch", "--gpus", "--cpu-seconds"):       # replaced below
+        while flag in inner:
+            i = inner.index(flag); del inner[i:i + 2]
+    inner = [a for a in inner if a not in ("--no-cpu", "--gather")]
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="gamut_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--output-format", "csv", "--pmc", ctr, "-d", d, "-o", "t", "--", sys.executable, os.path.abspath(__file__)] + inner + \
+                  ["--steps", "3", "--warmup", "1", "--no-cpu", "--no-traffic", "--batch", str(pmc_batch)]
+            env = dict(os.environ, TMPDIR="/tmp", GAMUT_BENCH_NOCHECK="1")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+            tot, n = 0.0, 0
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == ctr and kernel_substr.split(" + ")[0] in row.get("Kernel_Name", ""):
+                        tot += float(row["Counter_Value"]); n += 1
+            if not n:
+                return None, f"no {ctr} rows (rocprofv3 rc {r.returncode})"
+            vals[ctr] = tot / n
+        except Exception as e:                                     # never fail the bench line over the counters
+            return None, repr(e)[:120]
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    per_launch = 2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024
+    return per_launch / pmc_batch, f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in this run, batch {pmc_batch}, FETCH_SIZE x2 (gfx950), KB -> B"
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: start N ranks of this script under torch.distributed.run (one
+    process per GPU, rendezvous on 127.0.0.1) and let rank 0's JSON line through.  The driver's own
+    `python -m torch.distributed.run ... bench.py --gpus N` sets WORLD_SIZE, so this is skipped there."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")              # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(1, args.gpus) and int(os.environ.get("RANK", "0")) == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}", file=sys.stderr)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -235,6 +301,8 @@ def main():
         # 1920x1080 -> rgba8.  Inputs resident in HBM in the form each GPU stage starts from: dense coefficients, inflated
         # filtered streams, QOI files as they are.  One launch per format; the per-format times are in config.per_format.
         import oracle_lib as O
+        if args.batch == 1024 and args.total_images:               # BASELINE.json configs[4]: 8192 images over all ranks
+            B = (args.total_images + world - 1) // world
         nj, npn, nq = (B + 2) // 3, (B + 1) // 3, B // 3
         coeffs = synth.jpeg_coeff_batch(nj, w, h, dev, seed=1 + rank)
         nblk = coeffs.shape[1]
@@ -378,17 +446,26 @@ def main():
     if rank == 0:
         avg_kernel_s = float(np.mean(kern_ms)) * 1e-3
         achieved = bytes_per_step / avg_kernel_s / 1e9
+        traffic, traffic_src = None, None
+        if world == 1 and not args.no_traffic and wl != "mixed":
+            pmc_batch = min(B, 64 if not wl.startswith("convert:") else 2)
+            per_image, traffic_src = live_traffic(kernel_name, pmc_batch)
+            traffic = None if per_image is None else round(per_image * B)
+        if traffic is None:
+            t = traffic_from_profiles(workload, kernel_name)
+            traffic = None if t is None else round(t * B)
+            traffic_src = (f"replayed from profiles/ (live pass unavailable: {traffic_src})" if traffic_src else "replayed from profiles/") if t is not None else traffic_src
         res = {
             "metric": "Mpixels/sec decoded (batched 1080p JPEG 4:2:0)" if wl == "jpeg" else f"Mpixels/sec ({wl})",
             "value": round(world * px_per_step * args.steps / elapsed / 1e6, 1),
             "unit": "Mpx/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if (wl == "mixed" and args.batch == 1024 and args.total_images) else "weak", "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
             "config": {"workload": workload, "images_per_gpu_per_step": B, "sharding": "image-index, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": (lambda t: None if t is None else round(t * B))(traffic_from_profiles(workload, kernel_name)),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel_name, "algorithmic_bytes_per_launch": bytes_per_step,
                          "kernel_ms_avg": round(avg_kernel_s * 1e3, 4), "kernel_ms_min": round(min(kern_ms), 4)},
         }

@@ -33,7 +33,13 @@ int host_threads()
             }
             fclose(f);
         }
-        return hw;
+        // one process per GPU on a shared host (torchrun / mpirun export the number of ranks on this node): every rank takes
+        // its share of the cores -- 8 ranks x 16 inflating threads on a 16-core quota run slower than 8 x 2.  GAMUT_HIP_HOST_THREADS
+        // overrides everything.
+        for (const char* var : { "LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS" })
+            if (const char* v = getenv(var)) { const int ranks = atoi(v); if (ranks > 1) { hw = (hw + ranks - 1) / ranks; break; } }
+        if (const char* v = getenv("GAMUT_HIP_HOST_THREADS")) { const int t = atoi(v); if (t >= 1) hw = t; }
+        return hw < 1 ? 1 : hw;
     }();
     return n;
 }

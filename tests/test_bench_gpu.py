@@ -42,6 +42,24 @@ def test_two_ranks_one_line(hip):
     assert r["gather"].get("own_slice_intact") is True and r["gather"]["ms"] > 0, r["gather"]
 
 
+def test_self_launch_two_ranks(hip):
+    """`python bench.py --gpus 2` with no launcher: bench.py starts its own ranks (BASELINE.json metric: "at 1/2/4/8 GPUs")"""
+    r = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16"], env={"GAMUT_BENCH_BACKEND": "gloo"})
+    assert KEYS <= set(r) and r["n_gpus"] == 2 and r["cpu_baseline"] is None and r["value"] > 0 and r["scaling"] == "weak"
+    r = _run([sys.executable, "bench.py", "--gpus", "2", "--workload", "mixed", "--total-images", "14", "--steps", "2", "--warmup", "1",
+              "--width", "320", "--height", "200"], env={"GAMUT_BENCH_BACKEND": "gloo"})
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["config"]["images_per_gpu_per_step"] == 7
+
+
+def test_live_traffic_counters(hip):
+    """roofline.traffic is measured in the run (rocprofv3 --pmc passes on this very workload), not replayed from a file"""
+    r = _run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--batch", "32", "--no-cpu"])
+    rf = r["roofline"]
+    if rf["traffic"] is None or "replayed" in (rf.get("traffic_source") or ""):
+        pytest.skip(f"rocprofv3 counters unavailable here: {rf.get('traffic_source')}")
+    assert 0.9 < rf["traffic"] / rf["algorithmic_bytes_per_launch"] < 1.2, rf
+
+
 def test_mixed_workload_line(hip):
     """BASELINE.json configs[4] on one rank: JPEG / PNG / QOI by image index, per-format breakdown, parity checked inside"""
     r = _run([sys.executable, "bench.py", "--workload", "mixed", "--steps", "2", "--warmup", "1", "--batch", "7", "--width", "320", "--height", "200",

@@ -89,7 +89,30 @@ SIGNATURES = {
     "gamut_hip_stbi_load_from_memory": (_vp, [_vp, _sz, _pi, _pi, _pi, _i, _pf, _pf, _pf]),
     "gamut_hip_stbi_load_16_from_memory": (_vp, [_vp, _sz, _pi, _pi, _pi, _i, _pf, _pf, _pf]),
     "gamut_hip_png_is16": (_i, [_vp, _sz]),
+    "gamut_hip_decompress_jpeg_image_from_stream": (_vp, [_vp, _vp, _pi, _pi, _pi, _pf, _pf, _i]),
+    "gamut_hip_stbi_load_from_callbacks": (_vp, [_vp, _vp, _pi, _pi, _pi, _i, _pf, _pf, _pf]),
+    "gamut_hip_stbi_load_16_from_callbacks": (_vp, [_vp, _vp, _pi, _pi, _pi, _i, _pf, _pf, _pf]),
+    "gamut_hip_stbi_png_is16_from_callbacks": (_i, [_vp, _vp]),
+    "gamut_hip_shard_owner": (_i, [_i64, _i]),
+    "gamut_hip_shard_count": (_i64, [_i, _i, _i64]),
+    "gamut_hip_shard_local_index": (_i64, [_i64, _i]),
+    "gamut_hip_shard_global_index": (_i64, [_i64, _i, _i]),
+    "gamut_hip_host_threads": (_i, []),
+    "gamut_hip_comm_get_unique_id": (_i, [_vp]),
+    "gamut_hip_comm_init": (_i, [C.POINTER(_vp), _i, _i, _vp]),
+    "gamut_hip_comm_destroy": (None, [_vp]),
+    "gamut_hip_comm_rank": (_i, [_vp]),
+    "gamut_hip_comm_world": (_i, [_vp]),
+    "gamut_hip_gather_outputs_device": (_i, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _i, _vp]),
 }
+
+JPEG_STREAM_READ_FUNC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_ubyte), C.c_void_p)      # jpegload.d:70
+
+
+class StbiIoCallbacks(C.Structure):                                                                       # stbdec.d:408-419
+    _fields_ = [("read", C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_char), C.c_int)),
+                ("skip", C.CFUNCTYPE(None, C.c_void_p, C.c_int)),
+                ("eof", C.CFUNCTYPE(C.c_int, C.c_void_p))]
 
 _lib = None
 

@@ -184,6 +184,14 @@ uint8_t* gamut_hip_decompress_jpeg_image_from_memory(const uint8_t* data, size_t
         int* width, int* height, int* actual_comps,
         float* pixelAspectRatio, float* dotsPerInchY, int req_comps);
 
+/* the same with the reference's own argument list (jpegload.d:3720-3723): the input arrives through a JpegStreamReadFunc
+ * (jpegload.d:61-70): `int function(void* pBuf, int max_bytes_to_read, bool* pEOF_flag, void* userData)`, -1 = error, called
+ * until it raises *pEOF_flag.  D's bool is one byte: unsigned char here.  The stream is read to its end, then decoded as above. */
+typedef int (*gamut_hip_jpeg_stream_read_func)(void* pBuf, int max_bytes_to_read, unsigned char* pEOF_flag, void* userData);
+uint8_t* gamut_hip_decompress_jpeg_image_from_stream(gamut_hip_jpeg_stream_read_func rfn, void* userData,
+        int* width, int* height, int* actual_comps,
+        float* pixelAspectRatio, float* dotsPerInchY, int req_comps);
+
 /* ---- K5-K7: PNG de-filter / expand -----------------------------------------
  * replaces stbi__create_png_image_raw (stbdec.d:1406-1635).  raw = inflated
  * stream of one non-interlaced image (or one Adam7 pass): per row one filter
@@ -216,6 +224,20 @@ uint16_t* gamut_hip_stbi_load_16_from_memory(const uint8_t* data, size_t len, in
                                              float* ppmX, float* ppmY, float* pixelRatio);
 /* stbi__png_is16 (stbdec.d:2091-2109) */
 int gamut_hip_png_is16(const uint8_t* data, size_t len);
+/* the same three with the reference's own argument lists: stbi_io_callbacks (stbdec.d:408-419; read / skip / eof, only
+ * `read` is used: a read of 0 bytes ends the data, as in stbi__refill_buffer) + the user pointer, then exactly the
+ * parameters of stbi_load_from_callbacks / stbi_load_16_from_callbacks (stbdec.d:713-735).  is16 reads the header only;
+ * the caller rewinds its stream before loading, as plugins/png.d:50-62 does. */
+typedef struct gamut_hip_stbi_io_callbacks {
+    int  (*read)(void* user, char* data, int size);
+    void (*skip)(void* user, int n);
+    int  (*eof)(void* user);
+} gamut_hip_stbi_io_callbacks;
+uint8_t*  gamut_hip_stbi_load_from_callbacks(const gamut_hip_stbi_io_callbacks* clbk, void* user, int* x, int* y, int* comp, int req_comp,
+                                             float* ppmX, float* ppmY, float* pixelRatio);
+uint16_t* gamut_hip_stbi_load_16_from_callbacks(const gamut_hip_stbi_io_callbacks* clbk, void* user, int* x, int* y, int* comp, int req_comp,
+                                                float* ppmX, float* ppmY, float* pixelRatio);
+int gamut_hip_stbi_png_is16_from_callbacks(const gamut_hip_stbi_io_callbacks* clbk, void* user);
 
 /* ---- PNG files in batches ----------------------------------------------------------------------------------- */
 typedef struct gamut_hip_png_info {
@@ -254,6 +276,35 @@ int   gamut_hip_qoi_decode_batch_device(const uint8_t* const* data, const int* s
 int   gamut_hip_qoi_decode_resident_device(const uint8_t* blob, int64_t blob_len, const int64_t* begin, const int* size,
                                            const gamut_hip_qoi_desc* descs, int count, int channels, const int64_t* out_offset,
                                            uint8_t* out, void* stream);
+
+/* ---- multi-GPU (north_star: "image-index round-robin, RCCL over xGMI only for the gather of decoded outputs") --
+ * One process per GPU.  Images are independent, so the data path has no collective: image i of a batch belongs to rank
+ * i % world and is the (i / world)-th image that rank holds.  The reference has no counterpart (single-threaded library);
+ * this is what gamut_amd/shard.py does, for a host that is not Python. */
+int     gamut_hip_shard_owner(int64_t image_index, int world);                    /* rank that decodes image i */
+int64_t gamut_hip_shard_count(int rank, int world, int64_t total_images);         /* images a rank holds */
+int64_t gamut_hip_shard_local_index(int64_t image_index, int world);              /* position among its owner's images */
+int64_t gamut_hip_shard_global_index(int64_t local_index, int rank, int world);   /* and back */
+/* worker threads the host-side feeders start by default: the cores the process may use (cgroup quota) divided by the
+ * ranks on this node (LOCAL_WORLD_SIZE / OMPI_COMM_WORLD_LOCAL_SIZE), or GAMUT_HIP_HOST_THREADS */
+int     gamut_hip_host_threads(void);
+
+/* The one exchange: gathering decoded outputs.  An RCCL communicator behind an opaque handle; librccl is loaded at run time.
+ * Rank 0 calls comm_get_unique_id (128 bytes) and hands the bytes to the other ranks by whatever channel the host has;
+ * every rank then calls comm_init with the device it decodes on current (gamut_hip_init).  world == 1 needs no id and no RCCL. */
+#define GAMUT_HIP_COMM_ID_BYTES 128
+typedef struct gamut_hip_comm gamut_hip_comm;
+int  gamut_hip_comm_get_unique_id(void* id128);
+int  gamut_hip_comm_init(gamut_hip_comm** comm, int world, int rank, const void* id128);
+void gamut_hip_comm_destroy(gamut_hip_comm* comm);
+int  gamut_hip_comm_rank(const gamut_hip_comm* comm);
+int  gamut_hip_comm_world(const gamut_hip_comm* comm);
+/* `local` (HBM): this rank's decoded images, the k-th one at local + k * local_stride, bytes_per_image each.  Image i of
+ * the batch arrives at dst + i * dst_stride on `root` (root = -1: on every rank, an all-gather).  Grouped ncclSend /
+ * ncclRecv per image on `stream` (asynchronous); a rank's own images are copied device to device.  Collective: every rank
+ * of the communicator must call it with the same total_images / bytes_per_image / root. */
+int  gamut_hip_gather_outputs_device(gamut_hip_comm* comm, const void* local, int64_t local_stride, int64_t bytes_per_image,
+                                     int64_t total_images, void* dst, int64_t dst_stride, int root, void* stream);
 
 #ifdef __cplusplus
 }

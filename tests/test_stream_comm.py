@@ -1,0 +1,258 @@
+"""The callback-shaped drop-ins (stream_host.hip) and the C-ABI multi-GPU surface (comm.hip).
+
+CPU part: shard arithmetic against gamut_amd/shard.py, argument validation, read-callback call pattern.
+GPU part: *_from_stream / *_from_callbacks == the *_from_memory entry points == the oracle; world-1 gather; a 2-rank RCCL
+gather on one box (both ranks on cuda:0 is refused by RCCL, so that test needs 2 devices and is skipped otherwise)."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from gamut_amd import _capi, shard
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+JPEGS = sorted(glob.glob(os.path.join(HERE, "golden", "*.jpg")))
+PNGS = sorted(glob.glob(os.path.join(HERE, "golden", "ref_images", "*.png")))
+
+
+def _jpeg_reader(data, piece, raise_eof_late=False, fail_at=None):
+    """A JpegStreamReadFunc over `data` handing out at most `piece` bytes per call (jpegload.d:61-70)."""
+    state = {"pos": 0, "calls": 0}
+
+    def rd(pbuf, max_bytes, peof, user):
+        state["calls"] += 1
+        if fail_at is not None and state["pos"] >= fail_at:
+            return -1
+        n = min(max_bytes, piece, len(data) - state["pos"])
+        C.memmove(pbuf, data[state["pos"]:state["pos"] + n], n)
+        state["pos"] += n
+        if state["pos"] >= len(data) and not (raise_eof_late and n > 0):
+            peof[0] = 1
+        return n
+    return _capi.JPEG_STREAM_READ_FUNC(rd), state
+
+
+def _stb_callbacks(data, piece):
+    state = {"pos": 0, "calls": 0}
+
+    def rd(user, buf, size):
+        state["calls"] += 1
+        n = min(size, piece, len(data) - state["pos"])
+        C.memmove(buf, data[state["pos"]:state["pos"] + n], n)
+        state["pos"] += n
+        return n
+
+    def skip(user, n):
+        state["pos"] += n
+
+    def eof(user):
+        return int(state["pos"] >= len(data))
+    cb = _capi.StbiIoCallbacks()
+    keep = (type(cb.read)(rd), type(cb.skip)(skip), type(cb.eof)(eof))
+    cb.read, cb.skip, cb.eof = keep
+    return cb, state, keep
+
+
+# ------------------------------------------------------------------------------------------------ CPU
+def test_shard_arithmetic_matches_python_sharder():
+    L = _capi.lib()
+    for world in (1, 2, 3, 8):
+        for total in (0, 1, 7, 8, 8191, 8192):
+            seen = []
+            for rank in range(world):
+                idx = shard.shard_indices(total, rank, world)
+                assert L.gamut_hip_shard_count(rank, world, total) == len(idx)
+                for k, g in enumerate(idx):
+                    assert L.gamut_hip_shard_owner(g, world) == rank
+                    assert L.gamut_hip_shard_local_index(g, world) == k
+                    assert L.gamut_hip_shard_global_index(k, rank, world) == g
+                seen += list(idx)
+            assert sorted(seen) == list(range(total))
+    assert L.gamut_hip_shard_owner(-1, 4) == -1 and L.gamut_hip_shard_owner(3, 0) == -1
+    assert L.gamut_hip_shard_count(4, 4, 10) == -1 and L.gamut_hip_shard_count(0, 0, 10) == -1
+
+
+def test_comm_world1_and_argument_validation_need_no_rccl():
+    L = _capi.lib()
+    comm = C.c_void_p()
+    assert L.gamut_hip_comm_init(C.byref(comm), 1, 0, None) == 0
+    assert L.gamut_hip_comm_rank(comm) == 0 and L.gamut_hip_comm_world(comm) == 1
+    # nothing to move: returns before touching the device
+    assert L.gamut_hip_gather_outputs_device(comm, None, 0, 0, 0, None, 0, -1, None) == 0
+    assert L.gamut_hip_gather_outputs_device(comm, None, 16, 16, 4, None, 16, 0, None) == _capi.ERR_INVALID_ARG
+    assert L.gamut_hip_gather_outputs_device(comm, None, 8, 16, 4, None, 16, 0, None) == _capi.ERR_INVALID_ARG     # stride < image
+    assert L.gamut_hip_gather_outputs_device(comm, None, 16, 16, 4, None, 16, 1, None) == _capi.ERR_INVALID_ARG    # root >= world
+    L.gamut_hip_comm_destroy(comm)
+    assert L.gamut_hip_comm_init(C.byref(comm), 2, 2, None) == _capi.ERR_INVALID_ARG
+    assert L.gamut_hip_comm_init(C.byref(comm), 2, 0, None) == _capi.ERR_INVALID_ARG                               # world 2 needs an id
+    assert L.gamut_hip_comm_get_unique_id(None) == _capi.ERR_INVALID_ARG
+    assert L.gamut_hip_comm_rank(None) == -1
+    assert L.gamut_hip_host_threads() >= 1
+
+
+def test_host_threads_divide_by_local_ranks(tmp_path):
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r); from gamut_amd import _capi; print(_capi.lib().gamut_hip_host_threads())"
+            % os.path.dirname(HERE))
+    def run(env):
+        e = dict(os.environ); e.pop("GAMUT_HIP_HOST_THREADS", None); e.pop("LOCAL_WORLD_SIZE", None); e.update(env)
+        return int(subprocess.check_output([sys.executable, "-c", code], env=e).split()[-1])
+    whole = run({})
+    assert run({"LOCAL_WORLD_SIZE": "2"}) == (whole + 1) // 2
+    assert run({"LOCAL_WORLD_SIZE": "1024"}) == 1
+    assert run({"GAMUT_HIP_HOST_THREADS": "3", "LOCAL_WORLD_SIZE": "2"}) == 3
+
+
+def test_stream_entry_points_reject_null_callbacks():
+    L = _capi.lib()
+    w, h, ac = C.c_int(), C.c_int(), C.c_int()
+    assert not L.gamut_hip_decompress_jpeg_image_from_stream(None, None, C.byref(w), C.byref(h), C.byref(ac), None, None, 4)
+    assert L.gamut_hip_last_error() != b""
+    assert not L.gamut_hip_stbi_load_from_callbacks(None, None, C.byref(w), C.byref(h), C.byref(ac), 4, None, None, None)
+    assert not L.gamut_hip_stbi_load_16_from_callbacks(None, None, C.byref(w), C.byref(h), C.byref(ac), 4, None, None, None)
+    assert L.gamut_hip_stbi_png_is16_from_callbacks(None, None) == 0
+    # a read function that reports an error: NULL + message (stop_decoding(JPGD_STREAM_READ), jpegload.d:1994)
+    rd, _ = _jpeg_reader(b"\xff\xd8" + bytes(100), 16, fail_at=32)
+    assert not L.gamut_hip_decompress_jpeg_image_from_stream(rd, None, C.byref(w), C.byref(h), C.byref(ac), None, None, 4)
+    assert b"read error" in L.gamut_hip_last_error()
+
+
+def test_png_is16_from_callbacks_reads_the_header_only():
+    L = _capi.lib()
+    for path in PNGS:
+        data = open(path, "rb").read()
+        buf = np.frombuffer(data, np.uint8)
+        cb, st, keep = _stb_callbacks(data, 7)
+        assert L.gamut_hip_stbi_png_is16_from_callbacks(C.byref(cb), None) == L.gamut_hip_png_is16(buf.ctypes.data, buf.size)
+        assert st["pos"] <= 64, "is16 must not consume the stream beyond the header"
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", JPEGS[:6], ids=[os.path.basename(p) for p in JPEGS[:6]])
+def test_jpeg_from_stream_equals_oracle(hip, path):
+    data = open(path, "rb").read()
+    libc = C.CDLL(None); libc.free.argtypes = [C.c_void_p]
+    for piece, late in ((1 << 20, False), (4096, False), (977, True)):
+        for rc in (-1, 4):
+            exp = O.decompress_jpeg(data, rc)
+            rd, st = _jpeg_reader(data, piece, raise_eof_late=late)
+            w, h, ac = C.c_int(), C.c_int(), C.c_int()
+            par, dpi = C.c_float(), C.c_float()
+            p = hip.gamut_hip_decompress_jpeg_image_from_stream(rd, None, C.byref(w), C.byref(h), C.byref(ac), C.byref(par), C.byref(dpi), rc)
+            assert p, hip.gamut_hip_last_error()
+            comps = ac.value if rc < 0 else rc
+            got = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (h.value, w.value * comps)).copy()
+            libc.free(p)
+            assert np.array_equal(got, exp[0])
+            assert (ac.value, par.value, dpi.value) == exp[1:]
+            assert st["pos"] == len(data)
+    # optional out-pointers may be NULL, as in the reference's callers that do not want the DPI
+    rd, _ = _jpeg_reader(data, 1 << 16)
+    p = hip.gamut_hip_decompress_jpeg_image_from_stream(rd, None, C.byref(w), C.byref(h), C.byref(ac), None, None, 4)
+    assert p
+    libc.free(p)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", PNGS, ids=[os.path.basename(p) for p in PNGS])
+def test_png_from_callbacks_equals_oracle(hip, path):
+    data = open(path, "rb").read()
+    libc = C.CDLL(None); libc.free.argtypes = [C.c_void_p]
+    for sixteen in (False, True):
+        for req in (0, 4):
+            exp = O.stbi_load(data, req, sixteen)
+            cb, st, keep = _stb_callbacks(data, 1000)
+            x, y, n = C.c_int(), C.c_int(), C.c_int()
+            fx, fy, fr = C.c_float(), C.c_float(), C.c_float()
+            fn = hip.gamut_hip_stbi_load_16_from_callbacks if sixteen else hip.gamut_hip_stbi_load_from_callbacks
+            p = fn(C.byref(cb), None, C.byref(x), C.byref(y), C.byref(n), req, C.byref(fx), C.byref(fy), C.byref(fr))
+            if exp is None:
+                assert not p
+                continue
+            assert p, hip.gamut_hip_last_error()
+            comps = n.value if req == 0 else req
+            ct = C.c_uint16 if sixteen else C.c_uint8
+            got = np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), (y.value, x.value, comps)).copy()
+            libc.free(p)
+            assert n.value == exp[1] and np.array_equal(got, exp[0])
+
+
+@pytest.mark.gpu
+def test_gather_world1_places_images_in_batch_order(hip):
+    L = hip
+    comm = C.c_void_p()
+    assert L.gamut_hip_comm_init(C.byref(comm), 1, 0, None) == 0
+    n, b, ls, ds = 5, 1000, 1024, 1500
+    src = np.random.default_rng(3).integers(0, 256, n * ls, dtype=np.uint8)
+    dsrc = C.c_void_p(L.gamut_hip_device_malloc(src.nbytes)); ddst = C.c_void_p(L.gamut_hip_device_malloc(n * ds))
+    _capi.check(L.gamut_hip_memcpy_h2d(dsrc, src.ctypes.data, src.nbytes, None))
+    _capi.check(L.gamut_hip_gather_outputs_device(comm, dsrc, ls, b, n, ddst, ds, -1, None))
+    out = np.zeros(n * ds, np.uint8)
+    _capi.check(L.gamut_hip_memcpy_d2h(out.ctypes.data, ddst, out.nbytes, None))
+    _capi.check(L.gamut_hip_stream_synchronize(None))
+    for i in range(n):
+        assert np.array_equal(out[i * ds:i * ds + b], src[i * ls:i * ls + b])
+    L.gamut_hip_device_free(dsrc); L.gamut_hip_device_free(ddst); L.gamut_hip_comm_destroy(comm)
+
+
+def _rccl_rank(rank, world, idfile, ndev, q):
+    """One rank of the C-ABI gather: no torch.distributed -- the id travels through a file, as a D host would do it."""
+    import time
+    try:
+        L = _capi.lib()
+        _capi.check(L.gamut_hip_init(rank % ndev))
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            _capi.check(L.gamut_hip_comm_get_unique_id(ident))
+            with open(idfile + ".tmp", "wb") as f:
+                f.write(bytes(ident))
+            os.rename(idfile + ".tmp", idfile)
+        else:
+            t0 = time.time()
+            while not os.path.exists(idfile):
+                time.sleep(0.05)
+                assert time.time() - t0 < 120
+            C.memmove(ident, open(idfile, "rb").read(), 128)
+        comm = C.c_void_p()
+        _capi.check(L.gamut_hip_comm_init(C.byref(comm), world, rank, ident))
+        total, b = 11, 4096 + 13
+        mine = L.gamut_hip_shard_count(rank, world, total)
+        rng = [np.random.default_rng(100 + i).integers(0, 256, b, dtype=np.uint8) for i in range(total)]
+        local = np.concatenate([rng[L.gamut_hip_shard_global_index(k, rank, world)] for k in range(mine)])
+        dloc = C.c_void_p(L.gamut_hip_device_malloc(local.nbytes)); ddst = C.c_void_p(L.gamut_hip_device_malloc(total * b))
+        _capi.check(L.gamut_hip_memcpy_h2d(dloc, local.ctypes.data, local.nbytes, None))
+        for root in (-1, 1):
+            zero = np.zeros(total * b, np.uint8)
+            _capi.check(L.gamut_hip_memcpy_h2d(ddst, zero.ctypes.data, zero.nbytes, None))
+            _capi.check(L.gamut_hip_gather_outputs_device(comm, dloc, b, b, total, ddst, b, root, None))
+            _capi.check(L.gamut_hip_stream_synchronize(None))
+            if root < 0 or root == rank:
+                out = np.zeros(total * b, np.uint8)
+                _capi.check(L.gamut_hip_memcpy_d2h(out.ctypes.data, ddst, out.nbytes, None))
+                _capi.check(L.gamut_hip_stream_synchronize(None))
+                assert np.array_equal(out, np.concatenate(rng)), f"rank {rank} root {root}"
+        L.gamut_hip_comm_destroy(comm)
+        q.put((rank, "ok"))
+    except BaseException as e:                                  # noqa: BLE001 -- reported to the parent
+        q.put((rank, repr(e)))
+
+
+@pytest.mark.gpu
+def test_rccl_gather_two_ranks_through_the_c_abi(hip, tmp_path):
+    import multiprocessing as mp
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev < 2:
+        pytest.skip("RCCL refuses two ranks on one device; needs 2 GPUs (the driver's 8-GPU node)")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    idfile = str(tmp_path / "rccl_id")
+    ps = [ctx.Process(target=_rccl_rank, args=(r, 2, idfile, ndev, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = dict(q.get(timeout=300) for _ in ps)
+    [p.join(60) for p in ps]
+    assert res == {0: "ok", 1: "ok"}, res

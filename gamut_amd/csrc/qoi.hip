@@ -16,168 +16,227 @@ constexpr int kQoiHeader = 14, kQoiPadding = 8;                                /
 
 struct QoiItem { uint64_t begin; int64_t out_off; uint32_t size, npx; int32_t channels, pad; };
 
-// A lane must not touch global memory per pixel: every wait for a load also waits for the stores issued before it (one
-// in-order counter), so byte-wise loads and per-pixel stores made a lane sit out a memory round trip several times per
-// pixel (1.3 us per pixel measured).  And it must not branch on the op: the six op kinds of 64 unrelated streams put
-// every branch on the wave's path in nearly every iteration (0.37 us per pixel measured with per-op branches: ~200
-// instructions, one wave per SIMD, one instruction per ~4 cycles).  So:
-//   * everything a lane touches per pixel is in registers or LDS -- the hash table, a 256-byte window of the stream and
-//     a 64-pixel output buffer, all dword-interleaved over the lanes ([slot][lane]: 64 lanes, 64 banks);
-//   * an op is decoded WITHOUT branches: its first byte indexes a 256-entry table (bytes used, run length, one bit per
-//     op kind), the candidate pixels of all kinds are computed (the DIFF / LUMA deltas come from tables too and are
-//     added bytewise, SWAR) and the right one is picked with bit-field masks; an iteration that only continues a run
-//     is the same code with a zeroed table entry;
-//   * the next 5..8 stream bytes sit in a 64-bit register topped up from a dword that was read from the window one
-//     top-up earlier, so no LDS latency is on the byte path;
-//   * the window is refilled for the whole wave at once: when SOME lane has less than two 64-byte blocks left, every lane
-//     with a free block commits the block it has in flight (16 VGPRs) and requests the next -- a refill every ~15
-//     iterations instead of one lane or another refilling in nine iterations out of ten;
-//   * the pixel loop is uniform over the wave, so the output buffers fill up together and are flushed with dwordx4 stores.
-constexpr int kQoiWinDwords = 64, kQoiOutPx = 64;             // 4 blocks of 64 bytes per lane
-constexpr int kQoiSlack = GAMUT_HIP_QOI_SLACK;                // readable bytes guaranteed after every stream
+// One WAVE per stream.  The format is a byte-serial state machine (previous pixel, 64-entry colour hash, run counter), but
+// only one link of the chain is really serial -- a QOI_OP_INDEX needs the hash table as all earlier pixels left it.  The rest
+// is parallel over the 64 lanes:
+//   A. op boundaries of a 2 KiB window: an op's length follows from its first byte alone, so each lane walks its own 32 bytes
+//      for every possible entry offset 0..4 (an op of the previous lane spills at most 4 bytes) with plain bit operations,
+//      and the entry offsets are chained through the wave afterwards; the op starts are compacted into a list in LDS;
+//   B. 64 ops at a time, one per lane: an op is a bytewise function x -> (x & ~M) + V of the previous pixel (DIFF / LUMA /
+//      RUN: M = 0, V = deltas; RGB / RGBA: M = the bytes set, V = their values); such functions compose, so an inclusive scan
+//      over the lanes (DPP row shifts / broadcasts, no LDS) gives every op's pixel relative to the pixel before the group.
+//      An INDEX op is "all bytes set to an unknown U"; the scan carries which bytes still hang on the most recent INDEX;
+//   C. the INDEX ops of the group are resolved one after the other (wave-uniform loop): the slot's value is the newest earlier
+//      pixel of the group with that hash (ballot + readlane), else the table as it stood before the group (a register per
+//      slot, lane s = slot s); the lanes up to the next INDEX op then get their pixels and hashes;
+//   D. the table takes the group's pixels with one LDS ds_max_u64 per lane on (op number << 32 | pixel): the newest writer of
+//      a slot wins without a second pass; run lengths are prefix-summed, pixels go to an LDS buffer and leave in 1 KiB rows.
+// A 1080p photographic stream takes ~25 ms like this (the lane-per-stream decoder of round 1: 540 ms), and a batch runs one
+// stream per SIMD.
+constexpr int kQoiWin = 2048, kQoiLaneBytes = 32, kQoiOutCap = 256 + 64 * 62 + 64;   // window bytes; pixels the buffer must hold
+constexpr int kQoiSlack = GAMUT_HIP_QOI_SLACK;                                      // readable bytes guaranteed after every stream
 
 __device__ __forceinline__ uint32_t qoi_add_bytes(uint32_t x, uint32_t y)       // bytewise (x + y) mod 256
 {
     return ((x & 0x7f7f7f7fu) + (y & 0x7f7f7f7fu)) ^ ((x ^ y) & 0x80808080u);
 }
+__device__ __forceinline__ uint32_t qoi_hash(uint32_t px) { return __builtin_amdgcn_udot4(px, 0x0B070503u, 0u, false) & 63u; }   // QOI_COLOR_HASH :239-242
 
-__global__ __launch_bounds__(64) void k_qoi_decode(const QoiItem* items, int n, const uint8_t* blob, uint8_t* out)
+// value of the lane CTRL names (row_shr:n = 0x110 + n, row_bcast:15 = 0x142, row_bcast:31 = 0x143); lanes without a source,
+// or in rows outside ROWMASK, get `idle`
+template <int CTRL, int ROWMASK> __device__ __forceinline__ uint32_t qoi_dpp(uint32_t v, uint32_t idle = 0)
 {
-    __shared__ uint32_t index[64 * 64];                       // [hash][lane]
-    __shared__ uint32_t sh_in[kQoiWinDwords * 64];            // [dword of the window][lane]
-    __shared__ uint32_t sh_out[kQoiOutPx * 64];               // [pixel][lane], always r|g<<8|b<<16|a<<24
-    __shared__ uint32_t optab[256];                           // first byte -> bytes used | kind bits << 3 | run << 8
-    __shared__ uint2 deltab[64];                              // low six bits -> (QOI_OP_DIFF delta, QOI_OP_LUMA green part), packed bytes
-    __shared__ uint32_t luma2[256];                           // second byte of QOI_OP_LUMA -> (dr - dg, 0, db - dg, 0) + 8 removed
-    constexpr uint32_t K_RGB = 1u << 3, K_RGBA = 1u << 4, K_INDEX = 1u << 5, K_DIFF = 1u << 6, K_LUMA = 1u << 7;
-    const int lane = threadIdx.x;
-    #pragma unroll 8
-    for (int k = 0; k < 64; ++k) index[k * 64 + lane] = 0;    // memset(index, 0) :491  (a lane only touches its own column)
-    #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t v = (uint32_t)(k * 64 + lane);
-        uint32_t e;
-        if (v == 0xFE) e = 4 | K_RGB; else if (v == 0xFF) e = 5 | K_RGBA;
-        else if ((v >> 6) == 0) e = 1 | K_INDEX; else if ((v >> 6) == 1) e = 1 | K_DIFF; else if ((v >> 6) == 2) e = 2 | K_LUMA;
-        else e = 1 | (v & 63) << 8;                                                            // QOI_OP_RUN
-        optab[v] = e;
-        luma2[v] = (v >> 4) | (v & 15) << 16;
-    }
-    {
-        const uint32_t k = (uint32_t)lane, vg = (k - 32) & 255, vg8 = (k - 40) & 255;          // vg = k - 32; vg - 8
-        deltab[k] = make_uint2(((((k >> 4) & 3) - 2) & 255) | ((((k >> 2) & 3) - 2) & 255) << 8 | (((k & 3) - 2) & 255) << 16, vg8 | vg << 8 | vg8 << 16);
-    }
-    __syncthreads();
-    const int i = blockIdx.x * 64 + lane;
-    if (i >= n) return;
-    const QoiItem it = items[i];
-    const bool rgba = it.channels == 4;
-    const int bpp = rgba ? 4 : 3;
-    uint8_t* pixels = out + it.out_off;
-    const uint8_t* stream = blob + it.begin + kQoiHeader;      // chunks start here
-    uint32_t* win = sh_in + lane;
-    uint32_t* obuf = sh_out + lane;
-    uint32_t px = 0xFF000000u;                                // r = g = b = 0, a = 255 :492-495
-    // bytes [14, size - 8) are chunks (p < chunks_len, :498); a chunk may read up to 4 bytes further (padding / slack)
-    const int chunk_bytes = (int)it.size - kQoiPadding - kQoiHeader;
-    const uint32_t fetch_limit = (uint32_t)(chunk_bytes > 0 ? chunk_bytes : 0) + 5;   // no byte at or beyond this is ever decoded
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)idle, (int)v, CTRL, ROWMASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t qoi_readlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+
+struct QoiFn { uint32_t M, V, U; };       // x -> ((x & ~M) | (index value & U)) + V bytewise; U is a subset of M
+__device__ __forceinline__ QoiFn qoi_then(QoiFn a, QoiFn b)                       // a first, then b
+{
+    QoiFn r; r.M = a.M | b.M; r.V = qoi_add_bytes(a.V & ~b.M, b.V); r.U = b.U | (a.U & ~b.M); return r;
+}
+template <int CTRL, int ROWMASK> __device__ __forceinline__ void qoi_scan_step(QoiFn& f, uint32_t& n)
+{
+    const QoiFn p = { qoi_dpp<CTRL, ROWMASK>(f.M), qoi_dpp<CTRL, ROWMASK>(f.V), qoi_dpp<CTRL, ROWMASK>(f.U) };   // (0, 0, 0) = identity
+    f = qoi_then(p, f);
+    n += qoi_dpp<CTRL, ROWMASK>(n);
+}
+
+__global__ __launch_bounds__(64) void k_qoi_decode(const QoiItem* items, int n_items, const uint8_t* blob, uint8_t* out)
+{
+    __shared__ uint32_t win[kQoiWin / 4 + 4];                 // the window + 8 bytes of the next one (an op reads up to 4 bytes past its start)
+    __shared__ uint16_t ops[kQoiWin];                         // op starts of the window, in order
+    __shared__ unsigned long long table[64];                  // op number << 32 | pixel   (qoi_rgba_t[64] index, :453)
+    __shared__ __attribute__((aligned(16))) uint32_t obuf[kQoiOutCap];
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     struct __attribute__((packed, aligned(1))) AnyVec { u32x4 v; };               // 16 bytes at any address
-    u32x4 q0 = {0, 0, 0, 0}, q1 = q0, q2 = q0, q3 = q0;      // the block in flight
-    uint32_t fetched = 0, stored = 0, pulled = 0;            // stream bytes requested / in the window / read from the window
-    auto issue = [&]() {
-        if (fetched < fetch_limit) {
-            const AnyVec* src = reinterpret_cast<const AnyVec*>(stream + fetched);
-            q0 = src[0].v; q1 = src[1].v; q2 = src[2].v; q3 = src[3].v;
+    struct __attribute__((packed, aligned(1))) AnyU32 { uint32_t v; };
+    struct __attribute__((packed, aligned(1))) AnyU64 { uint64_t v; };
+    struct __attribute__((packed, aligned(1))) Any12 { uint32_t a, b, c; };
+
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= n_items) return;
+    const QoiItem it = items[blockIdx.x];
+    const bool rgba = it.channels == 4;
+    uint8_t* pixels = out + it.out_off;
+    const uint8_t* stream = blob + it.begin + kQoiHeader;     // chunks start here
+    // bytes [14, size - 8) are chunks (p < chunks_len, :498); a chunk may read up to 4 bytes further (padding / slack)
+    const int chunk_bytes = (int)it.size - kQoiPadding - kQoiHeader > 0 ? (int)it.size - kQoiPadding - kQoiHeader : 0;
+    const int avail = (int)it.size - kQoiHeader + kQoiSlack;  // bytes that may be read from `stream`
+    const uint32_t npx_total = it.npx;
+
+    table[lane] = 0;                                          // memset(index, 0) :491
+    uint32_t carry = 0xFF000000u;                             // r = g = b = 0, a = 255 :492-495
+    uint32_t produced = 0, ops_done = 0;                      // pixels decoded, ops decoded
+    uint32_t fill = 0; size_t flushed = 0;                    // pixels waiting in obuf, pixels already in the image
+    uint32_t entry = 0;                                       // offset of the first op start in the next window
+
+    auto fetch = [&](int pos, u32x4& a, u32x4& b, uint64_t& tail) {               // this lane's 32 bytes of the window at `pos` (+ 8 more for lane 0)
+        const int at = pos + lane * kQoiLaneBytes;
+        a = u32x4{0, 0, 0, 0}; b = a; tail = 0;
+        if (at + kQoiLaneBytes <= avail) {
+            const AnyVec* src = reinterpret_cast<const AnyVec*>(stream + at);
+            a = src[0].v; b = src[1].v;
         }
-        fetched += 64;
+        if (lane == 0 && pos + kQoiWin + 8 <= avail) tail = reinterpret_cast<const AnyU64*>(stream + pos + kQoiWin)->v;
     };
-    auto commit = [&]() {
-        uint32_t* w = win + ((stored >> 2) & (kQoiWinDwords - 1)) * 64;
-        w[0 * 64] = q0.x; w[1 * 64] = q0.y; w[2 * 64] = q0.z; w[3 * 64] = q0.w;
-        w[4 * 64] = q1.x; w[5 * 64] = q1.y; w[6 * 64] = q1.z; w[7 * 64] = q1.w;
-        w[8 * 64] = q2.x; w[9 * 64] = q2.y; w[10 * 64] = q2.z; w[11 * 64] = q2.w;
-        w[12 * 64] = q3.x; w[13 * 64] = q3.y; w[14 * 64] = q3.z; w[15 * 64] = q3.w;
-        stored += 64;
-    };
-    issue(); commit(); issue(); commit(); issue(); commit(); issue(); commit(); issue();      // four blocks in the window, the fifth in flight
-    uint32_t lo = 0, hi = 0, ahead; int valid = 0;            // `valid` stream bytes in hi:lo, lowest byte first; `ahead` = the dword after them
-    auto read_ahead = [&]() { ahead = win[((pulled >> 2) & (kQoiWinDwords - 1)) * 64]; pulled += 4; };
-    read_ahead(); lo = ahead; read_ahead(); hi = ahead; valid = 8; read_ahead();
-    int left = chunk_bytes > 0 ? chunk_bytes : 0;             // chunk bytes not decoded yet
-    uint32_t flushed = 0;                                     // pixels already written out
-    int run = 0, staged = 0;                                  // pixels waiting in obuf
-    auto flush = [&](int npx) {                               // npx pixels from obuf to the image
-        uint8_t* o = pixels + (size_t)flushed * bpp;
-        int k = 0;
-        if (rgba) {
-            for (; k + 4 <= npx; k += 4) {
-                const u32x4 v = {obuf[k * 64], obuf[(k + 1) * 64], obuf[(k + 2) * 64], obuf[(k + 3) * 64]};
-                reinterpret_cast<AnyVec*>(o + k * 4)->v = v;
+    auto flush_rows = [&]() {                                 // whole rows of 256 pixels leave; the rest moves to the front
+        const uint32_t n = fill & ~255u;
+        for (uint32_t i = 0; i < n; i += 256) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(&obuf[i + lane * 4]);
+            const size_t px = flushed + i + (size_t)lane * 4;
+            if (rgba) reinterpret_cast<AnyVec*>(pixels + px * 4)->v = v;
+            else {
+                const uint32_t p0 = v.x & 0xFFFFFFu, p1 = v.y & 0xFFFFFFu, p2 = v.z & 0xFFFFFFu, p3 = v.w & 0xFFFFFFu;
+                Any12 t; t.a = p0 | p1 << 24; t.b = p1 >> 8 | p2 << 16; t.c = p2 >> 16 | p3 << 8;
+                *reinterpret_cast<Any12*>(pixels + px * 3) = t;
             }
-            for (; k < npx; ++k) { const uint32_t v = obuf[k * 64]; o[k * 4] = (uint8_t)v; o[k * 4 + 1] = (uint8_t)(v >> 8); o[k * 4 + 2] = (uint8_t)(v >> 16); o[k * 4 + 3] = (uint8_t)(v >> 24); }
-        } else {
-            struct __attribute__((packed, aligned(1))) AnyU32 { uint32_t v; };
-            for (; k + 4 <= npx; k += 4) {                    // 4 pixels = 3 dwords
-                const uint32_t p0 = obuf[k * 64] & 0xFFFFFFu, p1 = obuf[(k + 1) * 64] & 0xFFFFFFu, p2 = obuf[(k + 2) * 64] & 0xFFFFFFu, p3 = obuf[(k + 3) * 64] & 0xFFFFFFu;
-                AnyU32* d = reinterpret_cast<AnyU32*>(o + k * 3);
-                d[0].v = p0 | p1 << 24; d[1].v = p1 >> 8 | p2 << 16; d[2].v = p2 >> 16 | p3 << 8;
-            }
-            for (; k < npx; ++k) { const uint32_t v = obuf[k * 64]; o[k * 3] = (uint8_t)v; o[k * 3 + 1] = (uint8_t)(v >> 8); o[k * 3 + 2] = (uint8_t)(v >> 16); }
         }
-        flushed += (uint32_t)npx;
+        const uint32_t rest = fill - n;
+        u32x4 keep = {0, 0, 0, 0};
+        if ((uint32_t)lane * 4 < rest) keep = *reinterpret_cast<const u32x4*>(&obuf[n + lane * 4]);
+        __syncthreads();
+        if ((uint32_t)lane * 4 < rest) *reinterpret_cast<u32x4*>(&obuf[lane * 4]) = keep;
+        __syncthreads();
+        flushed += n; fill = rest;
     };
-    for (uint32_t p = 0; p < it.npx; ++p) {
-        // window refill for the whole wave at once
-        if (__any((int)(stored - pulled) <= 128)) {
-            if (stored - (pulled & ~63u) < 4 * 64) { commit(); issue(); }         // a block of the lane's window has been read completely
+    auto store_px = [&](size_t px, uint32_t v) {
+        if (rgba) reinterpret_cast<AnyU32*>(pixels + px * 4)->v = v;
+        else { uint8_t* o = pixels + px * 3; o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)(v >> 16); }
+    };
+
+    u32x4 d0, d1; uint64_t dtail;
+    fetch(0, d0, d1, dtail);
+    __syncthreads();
+    for (int pos = 0; pos < chunk_bytes && produced < npx_total; pos += kQoiWin) {
+        // ---- the window into LDS; the next one into registers
+        *reinterpret_cast<u32x4*>(&win[lane * 8]) = d0;
+        *reinterpret_cast<u32x4*>(&win[lane * 8 + 4]) = d1;
+        if (lane == 0) { win[kQoiWin / 4] = (uint32_t)dtail; win[kQoiWin / 4 + 1] = (uint32_t)(dtail >> 32); }
+        const uint32_t d[8] = { d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w };
+        // ---- A. op starts among this lane's 32 bytes, for entry offsets 0..4 (bit i of s[e]: an op starts at byte i)
+        uint64_t s[5] = { 1, 2, 4, 8, 16 };
+        #pragma unroll
+        for (int i = 0; i < kQoiLaneBytes; ++i) {
+            const uint32_t b = (d[i >> 2] >> (8 * (i & 3))) & 255u;
+            const uint32_t len = b >= 0xFEu ? b - 0xFAu : ((b >> 6) == 2u ? 2u : 1u);          // RGB 4, RGBA 5, LUMA 2, the others 1
+            #pragma unroll
+            for (int e = 0; e < 5; ++e) s[e] |= (s[e] & (1ull << i)) << len;
         }
-        // one op, or one more pixel of a run: table entry zeroed when no op is decoded (run going on, or the chunks are used up)
-        const uint32_t b1 = lo & 255u;
-        uint32_t e = optab[b1];
-        e = (run == 0 && left > 0) ? e : 0u;
-        const uint32_t iv = index[(b1 & 63u) * 64 + lane];
-        const uint2 dl = deltab[b1 & 63u];
-        const uint32_t l2 = luma2[(lo >> 8) & 255u];
-        const uint32_t c_rgba = __builtin_amdgcn_alignbit(hi, lo, 8);                                   // stream bytes 1..4
-        const uint32_t c_diff = qoi_add_bytes(px, dl.x);
-        const uint32_t c_luma = qoi_add_bytes(px, qoi_add_bytes(dl.y, l2));
-        auto pick = [](uint32_t mask, uint32_t yes, uint32_t no) { return (yes & mask) | (no & ~mask); };     // v_bfi_b32
-        uint32_t v = px;
-        v = pick((uint32_t)(((int32_t)(e << 28)) >> 31) & 0x00FFFFFFu, c_rgba, v);                     // QOI_OP_RGB keeps alpha
-        v = pick((uint32_t)(((int32_t)(e << 27)) >> 31), c_rgba, v);                                   // QOI_OP_RGBA
-        v = pick((uint32_t)(((int32_t)(e << 26)) >> 31), iv, v);                                       // QOI_OP_INDEX
-        v = pick((uint32_t)(((int32_t)(e << 25)) >> 31), c_diff, v);                                   // QOI_OP_DIFF
-        v = pick((uint32_t)(((int32_t)(e << 24)) >> 31), c_luma, v);                                   // QOI_OP_LUMA
-        px = v;
-        const int used = (int)(e & 7u);
-        run = (run > 0 ? run - 1 : 0) + (int)((e >> 8) & 63u);
-        left -= used;
-        // consume `used` bytes; top the register up to >= 5 bytes again
+        uint32_t exits = 0;                                   // entry offset e -> offset of the first op start in the next lane's bytes
+        #pragma unroll
+        for (int e = 0; e < 5; ++e) exits |= (uint32_t)__builtin_ctz((uint32_t)(s[e] >> kQoiLaneBytes)) << (3 * e);
+        fetch(pos + kQoiWin, d0, d1, dtail);
+        uint32_t my_entry = 0;
+        #pragma unroll 8
+        for (int k = 0; k < 64; ++k) {
+            const uint32_t f = qoi_readlane(exits, k);
+            my_entry = lane == k ? entry : my_entry;
+            entry = (f >> (3 * entry)) & 7u;
+        }
+        uint32_t starts = (uint32_t)(my_entry == 0 ? s[0] : my_entry == 1 ? s[1] : my_entry == 2 ? s[2] : my_entry == 3 ? s[3] : s[4]);
         {
-            const uint64_t bits = ((uint64_t)hi << 32 | lo) >> (8 * used);
-            lo = (uint32_t)bits; hi = (uint32_t)(bits >> 32); valid -= used;
+            const int room = chunk_bytes - (pos + lane * kQoiLaneBytes);             // op starts only below chunks_len
+            starts &= room >= 32 ? ~0u : room <= 0 ? 0u : (1u << room) - 1u;
         }
+        // ---- compact the op starts into ops[]
+        uint32_t before = (uint32_t)__builtin_popcount(starts);
         {
-            const bool need = valid < 5;
-            const uint64_t add = (uint64_t)ahead << (8 * (valid & 7));
-            lo |= need ? (uint32_t)add : 0u; hi |= need ? (uint32_t)(add >> 32) : 0u;
-            valid += need ? 4 : 0;
-            const uint32_t nxt = win[((pulled >> 2) & (kQoiWinDwords - 1)) * 64];
-            ahead = need ? nxt : ahead; pulled += need ? 4u : 0u;
+            uint32_t incl = before;
+            incl += qoi_dpp<0x111, 0xF>(incl); incl += qoi_dpp<0x112, 0xF>(incl); incl += qoi_dpp<0x114, 0xF>(incl); incl += qoi_dpp<0x118, 0xF>(incl);
+            incl += qoi_dpp<0x142, 0xA>(incl); incl += qoi_dpp<0x143, 0xC>(incl);
+            before = incl - before;
         }
-        if (__any(valid < 5)) {                               // only after a 5-byte chunk that left nothing
-            if (valid < 5) {
-                const uint64_t add = (uint64_t)ahead << (8 * valid);
-                lo |= (uint32_t)add; hi |= (uint32_t)(add >> 32); valid += 4;
-                read_ahead();
+        const uint32_t nops = qoi_readlane(before + (uint32_t)__builtin_popcount(starts), 63);
+        {
+            uint32_t m = starts, at = before;
+            while (__any(m != 0)) {
+                if (m) { ops[at++] = (uint16_t)(lane * kQoiLaneBytes + __builtin_ctz(m)); m &= m - 1; }
             }
         }
-        index[(__builtin_amdgcn_udot4(px, 0x0B070503u, 0u, false) & 63u) * 64 + lane] = px;                 // QOI_COLOR_HASH :239-242 (r*3 + g*5 + b*7 + a*11)
-        obuf[staged * 64] = px;
-        if (++staged == kQoiOutPx) { flush(kQoiOutPx); staged = 0; }
+        __syncthreads();
+        // ---- B..D. 64 ops at a time
+        for (uint32_t g = 0; g < nops && produced < npx_total; g += 64) {
+            const uint32_t cnt = nops - g < 64u ? nops - g : 64u;
+            const bool active = (uint32_t)lane < cnt;
+            const uint32_t tab = (uint32_t)table[lane];
+            uint32_t lo = 0, hi = 0;
+            if (active) {
+                const uint32_t at = ops[g + lane];
+                const uint32_t w0 = win[at >> 2], w1 = win[(at >> 2) + 1], w2 = win[(at >> 2) + 2];
+                const uint32_t sh = 8 * (at & 3);
+                lo = __builtin_amdgcn_alignbit(w1, w0, sh); hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+            }
+            // the op as a function of the previous pixel
+            const uint32_t b1 = lo & 255u, top = b1 >> 6, b2 = (lo >> 8) & 255u;
+            const bool is_rgb = b1 == 0xFEu, is_rgba = b1 == 0xFFu;
+            const bool is_index = active && top == 0u, is_run = top == 3u && !is_rgb && !is_rgba;
+            const uint32_t vg = (b1 & 63u) - 32u;
+            const uint32_t v_diff = ((((b1 >> 4) & 3u) - 2u) & 255u) | ((((b1 >> 2) & 3u) - 2u) & 255u) << 8 | (((b1 & 3u) - 2u) & 255u) << 16;
+            const uint32_t v_luma = ((vg - 8u + (b2 >> 4)) & 255u) | (vg & 255u) << 8 | ((vg - 8u + (b2 & 15u)) & 255u) << 16;
+            const uint32_t v_abs = __builtin_amdgcn_alignbit(hi, lo, 8);                          // stream bytes 1..4
+            QoiFn f;
+            f.M = !active ? 0u : is_rgb ? 0x00FFFFFFu : (is_rgba || top == 0u) ? 0xFFFFFFFFu : 0u;
+            f.U = is_index ? 0xFFFFFFFFu : 0u;
+            f.V = !active ? 0u : is_rgb ? (v_abs & 0x00FFFFFFu) : is_rgba ? v_abs : top == 1u ? v_diff : top == 2u ? v_luma : 0u;
+            uint32_t npx = !active ? 0u : is_run ? 1u + (b1 & 63u) : 1u;
+            uint32_t incl = npx;
+            qoi_scan_step<0x111, 0xF>(f, incl); qoi_scan_step<0x112, 0xF>(f, incl); qoi_scan_step<0x114, 0xF>(f, incl); qoi_scan_step<0x118, 0xF>(f, incl);
+            qoi_scan_step<0x142, 0xA>(f, incl); qoi_scan_step<0x143, 0xC>(f, incl);
+            // ---- C. pixels: lanes before the first INDEX op at once, then INDEX op by INDEX op
+            uint32_t x = qoi_add_bytes(carry & ~f.M, f.V);
+            uint32_t h = qoi_hash(x);
+            uint64_t todo = __ballot(is_index);
+            while (todo) {
+                const int j = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const int jn = todo ? __builtin_ctzll(todo) : 64;
+                const uint32_t slot = qoi_readlane(b1, j) & 63u;
+                const uint64_t m = __ballot(h == slot) & ((1ull << j) - 1ull);
+                const uint32_t base = m ? qoi_readlane(x, 63 - __builtin_clzll(m)) : qoi_readlane(tab, (int)slot);
+                const uint32_t nx = qoi_add_bytes(base & f.U, f.V);           // from an INDEX op on, every byte is set (M = all)
+                const bool in = lane >= j && lane < jn;
+                x = in ? nx : x;
+                h = in ? qoi_hash(nx) : h;
+            }
+            // ---- D. table, run lengths, output
+            if (active) atomicMax(&table[h], (unsigned long long)(ops_done + 1u + (uint32_t)lane) << 32 | x);
+            uint32_t off = incl - npx, total = qoi_readlane(incl, 63);
+            const uint32_t room = npx_total - produced;
+            if (total > room) { npx = off >= room ? 0u : (npx < room - off ? npx : room - off); total = room; }
+            if (npx) obuf[fill + off] = x;
+            if (__any(npx > 1u)) {
+                for (uint32_t r = 1; __any(r < npx); ++r) if (r < npx) obuf[fill + off + r] = x;
+            }
+            carry = qoi_readlane(x, (int)cnt - 1);
+            fill += total; produced += total; ops_done += cnt;
+            __syncthreads();
+            if (fill >= 256u) flush_rows();
+        }
     }
-    if (staged) flush(staged);
+    // what is left in the buffer, then the tail of a stream that ended early: the last pixel repeats (:496-497, run / p >= chunks_len)
+    for (uint32_t i = lane; i < fill; i += 64) store_px(flushed + i, obuf[i]);
+    for (size_t i = (size_t)produced + lane; i < npx_total; i += 64) store_px(i, carry);
 }
 
 inline uint32_t be32(const uint8_t* p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
@@ -202,7 +261,7 @@ int launch_items(const std::vector<QoiItem>& items, uint8_t* d_items, const uint
 {
     const int n = (int)items.size();
     GAMUT_HIP_CHECK(hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(QoiItem), hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(k_qoi_decode, dim3((n + 63) / 64), dim3(64), 0, stream, (const QoiItem*)d_items, n, d_blob, d_out);
+    hipLaunchKernelGGL(k_qoi_decode, dim3(n), dim3(64), 0, stream, (const QoiItem*)d_items, n, d_blob, d_out);
     if (int rc = launch_status("qoi_decode")) return rc;
     GAMUT_HIP_CHECK(hipStreamSynchronize(stream));
     return GAMUT_HIP_OK;
@@ -241,7 +300,7 @@ int decode_batch(const uint8_t* const* data, const int* size, int count, int cha
         memcpy(h, items.data(), items.size() * sizeof(QoiItem));
         GAMUT_HIP_CHECK(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, stream));
         const int n = (int)items.size();
-        hipLaunchKernelGGL(k_qoi_decode, dim3((n + 63) / 64), dim3(64), 0, stream, (const QoiItem*)d, n, (const uint8_t*)(d + o_blob), d_out);
+        hipLaunchKernelGGL(k_qoi_decode, dim3(n), dim3(64), 0, stream, (const QoiItem*)d, n, (const uint8_t*)(d + o_blob), d_out);
         if (int rc = launch_status("qoi_decode")) return rc;
         GAMUT_HIP_CHECK(hipStreamSynchronize(stream));         // the per-thread staging buffers are reused by the next call
     }

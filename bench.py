@@ -166,7 +166,7 @@ def main():
     if wl == "jpeg" or wl.startswith("jpeg:"):
         jp = wl.split(":")                                       # jpeg[:out_comps[:scan_type]]
         oc = int(jp[1]) if len(jp) > 1 else 4                    # 4 = rgba8 (headline), 3 = rgb8, 1 = l8
-        st = int(jp[2]) if len(jp) > 2 else 4                    # jpgd scan type: 4 = 4:2:0 (headline), 2 = 4:2:2, 1 = 4:4:4, 0 = grey
+        st = int(jp[2]) if len(jp) > 2 else 4                    # jpgd scan type: 4 = 4:2:0 (headline), 3 = 4:4:0, 2 = 4:2:2, 1 = 4:4:4, 0 = grey
         comps_in = 1 if st == 0 else 3
         coeffs = synth.jpeg_coeff_batch(B, w, h, dev, seed=1 + rank, scan_type=st)
         nblk = coeffs.shape[1]
@@ -174,7 +174,7 @@ def main():
         px_per_step = B * w * h
         bytes_per_step = B * (nblk * 128 + w * h * oc)           # 6 266 880 + 8 294 400 per 1080p image (rgba8)
         kernel_name = "k_jpeg_h2v2" if st == 4 else "k_jpeg_"
-        workload = (f"batch {B} x {w}x{h} baseline JPEG { {4: '4:2:0', 2: '4:2:2', 1: '4:4:4', 0: 'grey'}[st] }, IDCT"
+        workload = (f"batch {B} x {w}x{h} baseline JPEG { {4: '4:2:0', 3: '4:4:0', 2: '4:2:2', 1: '4:4:4', 0: 'grey'}[st] }, IDCT"
                     f"{' + freq-domain chroma upsample' if st == 4 else ''} + YCbCr->{ {4: 'RGBA8', 3: 'RGB8', 1: 'L8'}[oc] }")
 
         def step():

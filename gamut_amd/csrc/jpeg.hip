@@ -17,7 +17,7 @@
 //       between the row and the column pass, and the hand-off between the
 //       upsample stages, go through LDS (padded to be bank-conflict free); the
 //       VALU does only arithmetic.
-//   k_jpeg_plain<ST,OC> -- tuned grey / 4:4:4 / 4:2:2 (two-pass IDCT as above, four pixels per thread in the colour stage).
+//   k_jpeg_plain<ST,OC> -- tuned grey / 4:4:4 / 4:2:2 / 4:4:0 (two-pass IDCT as above, four pixels per thread in the colour stage).
 //   k_jpeg_generic     -- every sampling mode (grey, H1V1, H2V1, H1V2, H2V2) and
 //       every output format (l8 / rgb8 / rgba8): one thread per coefficient block
 //       into an LDS sample buffer, then one thread per pixel.  Correct, untuned.
@@ -388,8 +388,9 @@ struct __attribute__((packed, aligned(1))) Dword1 { u32 v; };
 template <int ST, int OC>
 __global__ __launch_bounds__(256) void k_jpeg_plain(JpegArgs a)
 {
-    static_assert(ST == GAMUT_JPGD_GRAYSCALE || ST == GAMUT_JPGD_YH1V1 || ST == GAMUT_JPGD_YH2V1, "sampling mode");
+    static_assert(ST == GAMUT_JPGD_GRAYSCALE || ST == GAMUT_JPGD_YH1V1 || ST == GAMUT_JPGD_YH2V1 || ST == GAMUT_JPGD_YH1V2, "sampling mode");
     constexpr int BPM  = ST == GAMUT_JPGD_GRAYSCALE ? 1 : ST == GAMUT_JPGD_YH1V1 ? 3 : 4;
+    constexpr int MH   = ST == GAMUT_JPGD_YH1V2 ? 16 : 8;           // MCU height: 4:4:0 stacks two Y blocks (H1V2Convert :2603-2647)
     constexpr int MCUS = ST == GAMUT_JPGD_GRAYSCALE ? 32 : 8;
     constexpr int NBLK = MCUS * BPM;                              // 32 / 24 / 32 blocks = NBLK * 8 working threads
     constexpr int MW   = ST == GAMUT_JPGD_YH2V1 ? 16 : 8;
@@ -434,11 +435,11 @@ __global__ __launch_bounds__(256) void k_jpeg_plain(JpegArgs a)
     }
     __syncthreads();
 
-    uint8_t* obase = a.out + (int64_t)img * a.out_stride + (int64_t)(mcu_y * 8) * a.out_pitch + (int64_t)mcu_x0 * (MW * OC);
-    const int rows_here = min(8, a.height - mcu_y * 8);
+    uint8_t* obase = a.out + (int64_t)img * a.out_stride + (int64_t)(mcu_y * MH) * a.out_pitch + (int64_t)mcu_x0 * (MW * OC);
+    const int rows_here = min(MH, a.height - mcu_y * MH);
     const int px_here = min(mcus_here * MW, a.width - mcu_x0 * MW);             // live pixels of a strip row
     constexpr int GPR = SW / 4;                                   // groups of 4 pixels per strip row
-    for (int g = t; g < GPR * 8; g += 256) {
+    for (int g = t; g < GPR * MH; g += 256) {
         const int y = g / GPR, x0 = (g - y * GPR) * 4;
         if (y >= rows_here || x0 >= px_here) continue;
         const int m = x0 / MW, xin = x0 - m * MW;
@@ -449,6 +450,12 @@ __global__ __launch_bounds__(256) void k_jpeg_plain(JpegArgs a)
             const uint8_t* sp = S + m * 192 + y * 8 + xin;
             ys = *reinterpret_cast<const u32*>(sp);
             const u32 cbs = *reinterpret_cast<const u32*>(sp + 64), crs = *reinterpret_cast<const u32*>(sp + 128);
+            #pragma unroll
+            for (int j = 0; j < 4; ++j) px[j] = ycc_to_rgba((ys >> (8 * j)) & 255, (cbs >> (8 * j)) & 255, (crs >> (8 * j)) & 255);
+        } else if constexpr (ST == GAMUT_JPGD_YH1V2) {            // Y block y >> 3, chroma row y >> 1
+            const uint8_t* mp = S + m * 256;
+            ys = *reinterpret_cast<const u32*>(mp + (y >> 3) * 64 + (y & 7) * 8 + xin);
+            const u32 cbs = *reinterpret_cast<const u32*>(mp + 128 + (y >> 1) * 8 + xin), crs = *reinterpret_cast<const u32*>(mp + 192 + (y >> 1) * 8 + xin);
             #pragma unroll
             for (int j = 0; j < 4; ++j) px[j] = ycc_to_rgba((ys >> (8 * j)) & 255, (cbs >> (8 * j)) & 255, (crs >> (8 * j)) & 255);
         } else {
@@ -664,7 +671,7 @@ int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
         if (c.max_zag) c.max_zag += (int64_t)i0 * zag_stride;
         const dim3 grid(tiles, a.mcus_per_col, n);
         // tuned kernels: rgba8 needs dword-aligned rows; rgb8 / l8 rows may start anywhere (unaligned dword stores)
-        const bool tuned = out_pitch > 0 && out_pitch < (1 << 27) && scan_type != GAMUT_JPGD_YH1V2 &&
+        const bool tuned = out_pitch > 0 && out_pitch < (1 << 27) &&
                            (out_comps != 4 || (((uintptr_t)out & 3) == 0 && (out_pitch & 3) == 0 && (out_stride & 3) == 0));
         const dim3 grid32((a.mcus_per_row + 31) / 32, a.mcus_per_col, n);           // grey: 32 MCUs per workgroup
         const int strips420 = out_comps == 4 ? JPEG_STRIPS : JPEG_STRIPS_PACKED;
@@ -682,6 +689,7 @@ int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
         else if (scan_type == GAMUT_JPGD_GRAYSCALE)   GAMUT_JPEG_PLAIN(GAMUT_JPGD_GRAYSCALE, grid32);
         else if (scan_type == GAMUT_JPGD_YH1V1)       GAMUT_JPEG_PLAIN(GAMUT_JPGD_YH1V1, grid);
         else if (scan_type == GAMUT_JPGD_YH2V1)       GAMUT_JPEG_PLAIN(GAMUT_JPGD_YH2V1, grid);
+        else if (scan_type == GAMUT_JPGD_YH1V2)       GAMUT_JPEG_PLAIN(GAMUT_JPGD_YH1V2, grid);
         else if (out_comps == 4) hipLaunchKernelGGL(k_jpeg_h2v2<4>, grid420, dim3(H2V2_THREADS), 0, stream, c);
         else if (out_comps == 3) hipLaunchKernelGGL(k_jpeg_h2v2<3>, grid420, dim3(H2V2_THREADS), 0, stream, c);
         else                     hipLaunchKernelGGL(k_jpeg_h2v2<1>, grid420, dim3(H2V2_THREADS), 0, stream, c);

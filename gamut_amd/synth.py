@@ -49,8 +49,8 @@ def synth_rgb_batch(n, width, height, device, seed):
 
 def jpeg_coeff_batch(n, width, height, device, seed=0, quality=90, chunk=16, scan_type=4):
     """Dense de-quantised coefficients of n synthetic images: int16 tensor (n, MY*MX*blocks_per_mcu, 64), blocks in MCU
-    order.  scan_type (jpgd's): 4 = 4:2:0 (default), 2 = 4:2:2 (H2V1), 1 = 4:4:4 (H1V1), 0 = grey."""
-    hs, vs = {0: (1, 1), 1: (1, 1), 2: (2, 1), 4: (2, 2)}[scan_type]
+    order.  scan_type (jpgd's): 4 = 4:2:0 (default), 3 = 4:4:0 (H1V2), 2 = 4:2:2 (H2V1), 1 = 4:4:4 (H1V1), 0 = grey."""
+    hs, vs = {0: (1, 1), 1: (1, 1), 2: (2, 1), 3: (1, 2), 4: (2, 2)}[scan_type]
     my, mx = (height + 8 * vs - 1) // (8 * vs), (width + 8 * hs - 1) // (8 * hs)
     hp, wp = my * 8 * vs, mx * 8 * hs
     nb = hs * vs + (2 if scan_type else 0)

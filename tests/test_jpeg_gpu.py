@@ -113,7 +113,7 @@ def test_random_coefficients(hip, scan_type, kind):
             assert np.array_equal(got, exp), f"st={scan_type} {kind} {w}x{h} comps{rc}: {np.count_nonzero(got != exp)} differ"
 
 
-@pytest.mark.parametrize("scan_type", [0, 1, 4])
+@pytest.mark.parametrize("scan_type", [0, 1, 2, 3, 4])
 def test_sparse_paths_with_max_zag(hip, scan_type):
     """m_mcu_block_max_zag drives the reference's sparse IDCT variants (jpegload.d:295-376); with full-range int16
     coefficients the Col!(1) shortcut (max_zag <= 2) differs from the dense form by 32-bit wrap-around and must be matched."""

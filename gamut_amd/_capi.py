@@ -40,6 +40,10 @@ class JpegFrame(C.Structure):
                 ("pixel_aspect_ratio", C.c_float), ("dpi_y", C.c_float)]
 
 
+class InflateDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("src_len", C.c_uint32), ("dst_cap", C.c_uint32)]
+
+
 class PngDesc(C.Structure):
     _fields_ = [("raw", C.c_void_p), ("out", C.c_void_p), ("raw_len", C.c_uint32), ("x", C.c_uint32), ("y", C.c_uint32),
                 ("img_n", C.c_int32), ("out_n", C.c_int32), ("depth", C.c_int32), ("color", C.c_int32)]
@@ -93,6 +97,7 @@ SIGNATURES = {
     "gamut_hip_stbi_load_from_callbacks": (_vp, [_vp, _vp, _pi, _pi, _pi, _i, _pf, _pf, _pf]),
     "gamut_hip_stbi_load_16_from_callbacks": (_vp, [_vp, _vp, _pi, _pi, _pi, _i, _pf, _pf, _pf]),
     "gamut_hip_stbi_png_is16_from_callbacks": (_i, [_vp, _vp]),
+    "gamut_hip_inflate_batch_device": (_i, [_vp, _i, _vp, _vp, _vp]),
     "gamut_hip_shard_owner": (_i, [_i64, _i]),
     "gamut_hip_shard_count": (_i64, [_i, _i, _i64]),
     "gamut_hip_shard_local_index": (_i64, [_i64, _i]),

@@ -239,6 +239,19 @@ uint16_t* gamut_hip_stbi_load_16_from_callbacks(const gamut_hip_stbi_io_callback
                                                 float* ppmX, float* ppmY, float* pixelRatio);
 int gamut_hip_stbi_png_is16_from_callbacks(const gamut_hip_stbi_io_callbacks* clbk, void* user);
 
+/* ---- inflate on the GPU -------------------------------------------------------------------
+ * replaces, for batches, stbi_zlib_decode_malloc_guesssize_headerflag (stbdec.d:1267-1321 -> miniz).  Stream i is the raw
+ * DEFLATE data src[0 .. src_len) in HBM (a zlib stream without its 2-byte header, which the host checks as stbdec.d does;
+ * the adler32 trailer is not read, as with the reference's trusted_input); its bytes go to dst[0 .. dst_cap) in HBM -- output
+ * beyond dst_cap is dropped and the stream counts as done (the de-filter needs (bytes per line + 1) * height, no more).
+ * out_len_dev[i] = bytes written, status_dev[i] = 0 or the reason the stream is corrupt (GAMUT_HIP_INFLATE_E_*); both are
+ * device arrays, the call is asynchronous on `stream`.  One 256-thread workgroup per stream, speculative parallel Huffman
+ * decode + parallel match resolution (gamut_amd/csrc/inflate.hip).  descs is a host array. */
+typedef struct gamut_hip_inflate_desc { const uint8_t* src; uint8_t* dst; uint32_t src_len, dst_cap; } gamut_hip_inflate_desc;
+enum { GAMUT_HIP_INFLATE_E_BLOCK_TYPE = 1, GAMUT_HIP_INFLATE_E_STORED = 2, GAMUT_HIP_INFLATE_E_LENGTHS = 3, GAMUT_HIP_INFLATE_E_CODE = 4,
+       GAMUT_HIP_INFLATE_E_DISTANCE = 5, GAMUT_HIP_INFLATE_E_INPUT = 6 };
+int gamut_hip_inflate_batch_device(const gamut_hip_inflate_desc* descs, int count, uint32_t* out_len_dev, uint32_t* status_dev, void* stream);
+
 /* ---- PNG files in batches ----------------------------------------------------------------------------------- */
 typedef struct gamut_hip_png_info {
     uint32_t width, height;

@@ -1,0 +1,121 @@
+"""GPU parity: inflate on the device (gamut_hip_inflate_batch_device, inflate.hip) == zlib, byte for byte, on streams from every
+encoder setting (levels, strategies, stored / fixed / dynamic blocks, many small blocks, window-sized distances, long runs), and
+the same accept / reject decisions as zlib on damaged streams.  The PNG file batch then runs with the device inflate."""
+import ctypes as C
+import zlib
+
+import numpy as np
+import pytest
+
+from gamut_amd import _capi
+
+pytestmark = pytest.mark.gpu
+
+
+def _deflate(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, wbits=-15, mem=8, flush_every=0):
+    co = zlib.compressobj(level, zlib.DEFLATED, wbits, mem, strategy)
+    if not flush_every:
+        return co.compress(data) + co.flush()
+    out = []
+    for i in range(0, len(data), flush_every):
+        out.append(co.compress(data[i:i + flush_every]))
+        out.append(co.flush(zlib.Z_FULL_FLUSH if (i // flush_every) % 2 else zlib.Z_SYNC_FLUSH))
+    out.append(co.flush())
+    return b"".join(out)
+
+
+def _inflate_device(L, streams, caps):
+    """streams: list of raw-deflate byte strings; caps: output capacities -> (rc, [bytes], [status])"""
+    n = len(streams)
+    offs = np.concatenate([[0], np.cumsum([len(s) + 3 for s in streams])]).astype(np.int64)      # odd offsets: no alignment promised
+    blob = np.zeros(int(offs[-1]) + 1, np.uint8)
+    for i, s in enumerate(streams):
+        blob[offs[i]:offs[i] + len(s)] = np.frombuffer(s, np.uint8)
+    ooffs = np.concatenate([[0], np.cumsum([c + 5 for c in caps])]).astype(np.int64)
+    dblob = L.gamut_hip_device_malloc(blob.size + 64); dout = L.gamut_hip_device_malloc(int(ooffs[-1]) + 64)
+    dlen = L.gamut_hip_device_malloc(4 * n + 16); dst = L.gamut_hip_device_malloc(4 * n + 16)
+    poison = np.full(int(ooffs[-1]) + 64, 0xA5, np.uint8)
+    _capi.check(L.gamut_hip_memcpy_h2d(dblob, blob.ctypes.data, blob.size, None))
+    _capi.check(L.gamut_hip_memcpy_h2d(dout, poison.ctypes.data, poison.size, None))
+    descs = (_capi.InflateDesc * n)()
+    for i in range(n):
+        descs[i].src = dblob + int(offs[i]); descs[i].dst = dout + int(ooffs[i]); descs[i].src_len = len(streams[i]); descs[i].dst_cap = caps[i]
+    _capi.check(L.gamut_hip_stream_synchronize(None))
+    rc = L.gamut_hip_inflate_batch_device(descs, n, dlen, dst, None)
+    lens = np.zeros(n, np.uint32); st = np.zeros(n, np.uint32); host = np.empty(poison.size, np.uint8)
+    _capi.check(L.gamut_hip_memcpy_d2h(lens.ctypes.data, dlen, 4 * n, None))
+    _capi.check(L.gamut_hip_memcpy_d2h(st.ctypes.data, dst, 4 * n, None))
+    _capi.check(L.gamut_hip_memcpy_d2h(host.ctypes.data, dout, host.size, None))
+    _capi.check(L.gamut_hip_stream_synchronize(None))
+    for p in (dblob, dout, dlen, dst):
+        L.gamut_hip_device_free(p)
+    outs = []
+    for i in range(n):
+        outs.append(host[ooffs[i]:ooffs[i] + lens[i]].tobytes())
+        assert (host[ooffs[i] + caps[i]:ooffs[i + 1]] == 0xA5).all(), f"stream {i} wrote past its capacity"
+    return rc, outs, list(st)
+
+
+def _corpus():
+    rng = np.random.default_rng(11)
+    noise = rng.integers(0, 256, 70000, dtype=np.uint8).tobytes()
+    text = (b"the quick brown fox jumps over the lazy dog. " * 3000)[:120000]
+    grad = (np.add.outer(np.arange(300), np.arange(400)) // 3 % 256).astype(np.uint8).tobytes()
+    lownoise = (rng.integers(0, 4, 200000, dtype=np.uint8) + (np.arange(200000) // 997 % 200).astype(np.uint8)).tobytes()
+    sparse = np.where(rng.random(150000) < 0.02, rng.integers(1, 256, 150000), 0).astype(np.uint8).tobytes()
+    far = noise[:32768] + noise[:32768] + noise[100:30000] + bytes(70000) + noise[:5000]         # distances up to the whole window
+    return {"noise": noise, "text": text, "grad": grad, "lownoise": lownoise, "sparse": sparse, "far": far, "empty": b"", "one": b"x",
+            "runs": b"a" * 100000 + b"ab" * 40000 + b"abc" * 30000}
+
+
+def test_inflate_matches_zlib_on_every_encoder_setting(hip):
+    corpus = _corpus()
+    streams, expect, names = [], [], []
+    for name, data in corpus.items():
+        for level in (0, 1, 6, 9):
+            streams.append(_deflate(data, level)); expect.append(data); names.append(f"{name} level {level}")
+        for strat, sn in ((zlib.Z_FIXED, "fixed"), (zlib.Z_HUFFMAN_ONLY, "huffman-only"), (zlib.Z_RLE, "rle"), (zlib.Z_FILTERED, "filtered")):
+            streams.append(_deflate(data, 6, strat)); expect.append(data); names.append(f"{name} {sn}")
+        streams.append(_deflate(data, 6, flush_every=777)); expect.append(data); names.append(f"{name} flushed every 777")
+        streams.append(_deflate(data, 9, mem=1)); expect.append(data); names.append(f"{name} memLevel 1 (small blocks)")
+        streams.append(_deflate(data, 6, wbits=-9)); expect.append(data); names.append(f"{name} 512-byte window")
+    rc, outs, st = _inflate_device(hip, streams, [len(e) + 7 for e in expect])
+    assert rc == 0, hip.gamut_hip_last_error()
+    for name, got, exp, s in zip(names, outs, expect, st):
+        assert s == 0, f"{name}: status {s}"
+        assert got == exp, f"{name}: {len(got)} bytes, expected {len(exp)}; first difference at {next((i for i, (a, b) in enumerate(zip(got, exp)) if a != b), None)}"
+
+
+def test_inflate_capacity_clamps_and_large_stream(hip):
+    rng = np.random.default_rng(5)
+    big = (rng.integers(0, 16, 6_000_000, dtype=np.uint8) * 3 + (np.arange(6_000_000) // 4093 % 100).astype(np.uint8)).tobytes()
+    s = _deflate(big, 6)
+    rc, outs, st = _inflate_device(hip, [s, s, s], [len(big), len(big) // 3 + 1, 0])
+    assert rc == 0 and st == [0, 0, 0]
+    assert outs[0] == big and outs[1] == big[:len(big) // 3 + 1] and outs[2] == b""
+
+
+def test_inflate_rejects_what_zlib_rejects(hip):
+    rng = np.random.default_rng(9)
+    data = _corpus()["text"][:30000]
+    good = _deflate(data, 6)
+    cases = [good]
+    for _ in range(60):                                                  # single-byte damage somewhere in the stream
+        b = bytearray(good); i = int(rng.integers(0, len(b))); b[i] ^= 1 << int(rng.integers(0, 8)); cases.append(bytes(b))
+    for cut in (1, 2, 5, len(good) // 2, len(good) - 1):                 # truncation
+        cases.append(good[:cut])
+    cases.append(b"\x07")                                                # block type 3
+    cases.append(b"\x01\x05\x00\xfa\xfe" + b"abcde")                     # stored block with a bad ~LEN
+    cases.append(b"\x01\x05\x00\xfa\xff" + b"abc")                       # stored block, data cut short
+    rc, outs, st = _inflate_device(hip, cases, [len(data) + 64] * len(cases))
+    assert rc == 0
+    for i, c in enumerate(cases):
+        d = zlib.decompressobj(-15)
+        try:
+            exp = d.decompress(c); ok = d.eof
+        except zlib.error:
+            ok = False
+        if ok:
+            assert st[i] == 0 and outs[i] == exp[:len(data) + 64], f"case {i}: zlib accepts, device status {st[i]}"
+        elif len(outs[i]) < len(data) + 64:                               # (a stream that fills its capacity is done before its damage is reached)
+            assert st[i] != 0, f"case {i}: zlib rejects (or wants more input), the device accepted"

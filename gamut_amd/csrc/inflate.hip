@@ -11,10 +11,11 @@
 //     token began there, lanes then restart from their predecessor's exit position until nothing moves -- Huffman streams
 //     re-synchronise within a few tokens, so two or three sweeps settle all 256 lanes (the chain is exact from lane 0 on,
 //     and a lane that meets the end-of-block code, an invalid code or its output cap ends the chunk there);
-//   * prefix sums of the lanes' output bytes / match counts place everything: a last sweep writes the literals into a
-//     64 KiB ring in LDS (the 32 KiB window plus the chunk's output) and lists the matches;
-//   * matches are resolved 256 at a time in rounds: a match copies as soon as its source lies below the first byte that is
-//     still pending (overlapping copies, distance < length, are byte-serial inside their lane);
+//   * a prefix sum of the lanes' output bytes places everything: a last sweep writes the literals into a 64 KiB ring in LDS
+//     (the 32 KiB window plus the chunk's output) and, for every byte a match produces, the position it copies from;
+//   * the copies are resolved for all bytes at once by pointer doubling: a byte whose source is known takes its value, any
+//     other byte adopts its source's source -- a chain of n dependent copies (runs, distance-1 matches, the short distances
+//     of filtered scanlines) is done after log2 n rounds, at most 15, whatever the match structure;
 //   * the chunk's bytes leave the ring for HBM in dwords.
 // No data-dependent branch is taken on a whole stream's behalf by a single lane except the block headers.
 #include "common.hpp"
@@ -22,22 +23,49 @@
 namespace gamut {
 namespace {
 
-constexpr int kT = 256;                              // threads per stream
-constexpr int kSubBits = 128;                        // compressed bits a lane owns per chunk
+#ifndef INFLATE_T                 // tuning knobs (tools/variant.sh)
+#define INFLATE_T 512
+#endif
+#ifndef INFLATE_SUB_BITS
+#define INFLATE_SUB_BITS 128
+#endif
+#ifndef INFLATE_NEW_MAX
+#define INFLATE_NEW_MAX 28672
+#endif
+constexpr int kT = INFLATE_T;                        // threads per stream
+constexpr int kSubBits = INFLATE_SUB_BITS;           // compressed bits a lane owns per chunk
 constexpr int kChunkBytes = kT * kSubBits / 8;       // 4096
 constexpr int kWinDwords = kChunkBytes / 4 + 8;      // + 32 bytes: the last lane runs up to 47 bits past its end and peeks 64 bits from there
 constexpr int kRing = 65536, kRingMask = kRing - 1;
-constexpr int kNewMax = 32768 - 1024;                // bytes a chunk may add to the ring: the 32 KiB history must survive them
+constexpr int kNewMax = INFLATE_NEW_MAX;              // bytes a chunk may add to the ring: the 32 KiB history must survive them
 constexpr int kLaneOutMax = 8192;                    // a lane stops early beyond this (ends the chunk: pathological match runs)
-constexpr int kMatchCap = 3072;
-constexpr int kLitBits = 10, kDistBits = 9;          // primary lookup widths; longer codes take the canonical search
+constexpr int kHist = 32768;                         // DEFLATE's window
+constexpr int kLongMin = 32, kLongCap = 1024;        // matches at least this long are expanded by a whole wave, not by their lane
+constexpr int kLitBits = 11, kDistBits = 10;         // primary lookup widths; longer codes take the canonical search
 
 enum : uint32_t { F_EOB = 1, F_BAD = 2, F_EARLY = 4 };
 // status word per stream (0 = ok)
 enum : uint32_t { E_BLOCK_TYPE = 1, E_STORED = 2, E_LENGTHS = 3, E_CODE = 4, E_DISTANCE = 5, E_INPUT = 6 };
-enum { C_FIRST_BAD = 0, C_FIRST_STOP, C_CUT, C_HWM, C_ERR, C_BTYPE, C_FINAL, C_HDR_END_LO, C_HDR_END_HI, C_HLIT, C_HDIST, C_N };
+enum { C_FIRST_BAD = 0, C_FIRST_STOP, C_CUT, C_OPEN, C_NLONG, C_ERR, C_BTYPE, C_FINAL, C_HDR_END_LO, C_HDR_END_HI, C_HLIT, C_HDIST, C_N };
 
 struct InfItem { const uint8_t* src; uint8_t* dst; uint32_t src_len, dst_cap; };
+
+#ifndef INFLATE_PROFILE           // measurement only (tools/variant.sh inflate:prof:-DINFLATE_PROFILE=1): cycles per phase, summed over streams
+#define INFLATE_PROFILE 0
+#endif
+enum { P_HEADER = 0, P_TABLES, P_WINDOW, P_SWEEP0, P_SWEEPS, P_SCAN, P_WRITE, P_MATCH, P_FLUSH, P_STORED, P_N_BLOCKS, P_N_CHUNKS, P_N_SWEEPS, P_N_ROUNDS, P_N_MATCHES, P_N };
+#if INFLATE_PROFILE
+__device__ unsigned long long g_inflate_prof[P_N];
+#define PROF_DECL unsigned long long prof_t0 = clock64(), prof_acc[P_N] = {}
+#define PROF(slot) do { const unsigned long long now_ = clock64(); prof_acc[slot] += now_ - prof_t0; prof_t0 = now_; } while (0)
+#define PROF_COUNT(slot, n) (prof_acc[slot] += (n))
+#define PROF_FLUSH do { if (threadIdx.x == 0) for (int k_ = 0; k_ < P_N; ++k_) atomicAdd(&g_inflate_prof[k_], prof_acc[k_]); } while (0)
+#else
+#define PROF_DECL
+#define PROF(slot)
+#define PROF_COUNT(slot, n)
+#define PROF_FLUSH
+#endif
 
 struct Canon { uint32_t first[16], count[16], offs[16]; };
 
@@ -46,9 +74,10 @@ struct Shared {
     __attribute__((aligned(16))) uint32_t win[kWinDwords];
     uint32_t lit_lut[1 << kLitBits];
     uint32_t dist_lut[1 << kDistBits];
-    uint2    matches[kMatchCap];                     // x = destination (absolute output offset), y = length | distance << 16
+    __attribute__((aligned(16))) uint16_t from[kNewMax + 8];                          // per byte of the chunk: where its value comes from, as a position in [chunk start - 32768, ...); itself = known
     uint32_t exit_bit[kT], flags[kT];
-    uint32_t scan_a[kT], scan_b[kT];
+    uint32_t scan_a[kT];
+    uint2    longm[kLongCap];                        // long matches of the chunk: x = first byte (chunk-relative), y = length | distance << 16
     uint32_t lit_sorted[288], dist_sorted[32];       // symbol payloads in canonical order
     Canon    lit, dist;
     uint32_t cl_lut[128];
@@ -95,21 +124,6 @@ __device__ __forceinline__ uint32_t canon_decode(uint32_t bits, const Canon& c, 
     return 0;
 }
 
-// inclusive prefix sums of two values over the workgroup
-__device__ __forceinline__ void block_scan2(Shared& S, uint32_t& a, uint32_t& b)
-{
-    const int t = threadIdx.x;
-    S.scan_a[t] = a; S.scan_b[t] = b;
-    __syncthreads();
-    for (int d = 1; d < kT; d <<= 1) {
-        const uint32_t pa = t >= d ? S.scan_a[t - d] : 0u, pb = t >= d ? S.scan_b[t - d] : 0u;
-        __syncthreads();
-        a += pa; b += pb;
-        S.scan_a[t] = a; S.scan_b[t] = b;
-        __syncthreads();
-    }
-}
-
 // canonical code of `n` symbols with lengths S.lens[base .. base + n): Canon, payloads in canonical order, primary table.
 // Validity as zlib's inflate_table: over-subscribed sets fail; incomplete ones too, unless the set is a single 1-bit code.
 template <bool DIST>
@@ -144,32 +158,56 @@ __device__ void build_table(Shared& S, int base, int n)
     __syncthreads();
 }
 
-struct LaneResult { uint32_t exit, flags, out, nm; };
+struct LaneResult { uint32_t exit, flags, out; };
+
+// the code lengths the primary table does not cover, in registers (the canonical search then costs no LDS round trip but the last)
+template <int FROM> struct LongCodes {
+    uint32_t first[16 - FROM], count[16 - FROM], offs[16 - FROM];
+    __device__ __forceinline__ void load(const Canon& c)
+    {
+        #pragma unroll
+        for (int l = FROM; l <= 15; ++l) { first[l - FROM] = c.first[l]; count[l - FROM] = c.count[l]; offs[l - FROM] = c.offs[l]; }
+    }
+    __device__ __forceinline__ uint32_t decode(uint32_t bits, const uint32_t* sorted) const
+    {
+        const uint32_t rev = __brev(bits);
+        uint32_t at = 0xFFFFFFFFu, len = 0;
+        #pragma unroll
+        for (int l = 15; l >= FROM; --l) {                         // (at most one length matches: the code is prefix-free)
+            const uint32_t d = (rev >> (32 - l)) - first[l - FROM];
+            const bool hit = d < count[l - FROM];
+            at = hit ? offs[l - FROM] + d : at; len = hit ? (uint32_t)l : len;
+        }
+        return len ? sorted[at] | len : 0u;
+    }
+};
 
 // tokens of one lane: from bit `start` until a token begins at or beyond `end` (window-relative bits).  WRITE: literals into the
-// ring at absolute output offset obase.., matches into S.matches[mbase..]
+// ring at absolute output offset obase.., and S.from[] for every byte (orel = obase - chunk start)
 template <bool WRITE>
-__device__ __forceinline__ LaneResult lane_decode(Shared& S, uint32_t start, uint32_t end, uint32_t obase, uint32_t mbase)
+__device__ __forceinline__ LaneResult lane_decode(Shared& S, uint32_t start, uint32_t end, uint32_t obase, uint32_t orel)
 {
-    uint32_t pos = start, o = 0, nm = 0, fl = 0;
+    LongCodes<kLitBits + 1> long_lit; long_lit.load(S.lit);
+    LongCodes<kDistBits + 1> long_dist; long_dist.load(S.dist);
+    uint32_t pos = start, o = 0, fl = 0;
     while (pos < end && !fl) {
         uint64_t bits = peek64(S.win, pos);
         uint32_t used = 0;
         do {
             uint32_t e = S.lit_lut[(uint32_t)bits & ((1u << kLitBits) - 1u)];
-            if ((e & 15u) == 0u) { e = canon_decode((uint32_t)bits, S.lit, S.lit_sorted, kLitBits + 1, 15); if (!e) { fl = F_BAD; break; } }
+            if ((e & 15u) == 0u) { e = long_lit.decode((uint32_t)bits, S.lit_sorted); if (!e) { fl = F_BAD; break; } }
             uint32_t nb = e & 15u;
             bits >>= nb; used += nb;
             const uint32_t kind = (e >> 4) & 7u;
             if (kind == 0u) {
-                if (WRITE) S.ring[(obase + o) & kRingMask] = (uint8_t)(e >> 16);
+                if (WRITE) { S.ring[(obase + o) & kRingMask] = (uint8_t)(e >> 16); S.from[orel + o] = (uint16_t)(orel + o + kHist); }
                 ++o;
             } else if (kind == 1u) {
                 uint32_t xb = (e >> 8) & 31u;
                 const uint32_t len = (e >> 16) + ((uint32_t)bits & ((1u << xb) - 1u));
                 bits >>= xb; used += xb;
                 uint32_t de = S.dist_lut[(uint32_t)bits & ((1u << kDistBits) - 1u)];
-                if ((de & 15u) == 0u) { de = canon_decode((uint32_t)bits, S.dist, S.dist_sorted, kDistBits + 1, 15); if (!de) { fl = F_BAD; break; } }
+                if ((de & 15u) == 0u) { de = long_dist.decode((uint32_t)bits, S.dist_sorted); if (!de) { fl = F_BAD; break; } }
                 if (((de >> 4) & 7u) != 1u) { fl = F_BAD; break; }                 // distance symbols 30 / 31
                 nb = de & 15u;
                 bits >>= nb; used += nb;
@@ -177,16 +215,98 @@ __device__ __forceinline__ LaneResult lane_decode(Shared& S, uint32_t start, uin
                 const uint32_t dist = (de >> 16) + ((uint32_t)bits & ((1u << xb) - 1u));
                 bits >>= xb; used += xb;
                 if (WRITE) {
-                    S.matches[mbase + nm] = make_uint2(obase + o, len | dist << 16);
                     if (dist > obase + o) atomicMax(&S.ctrl[C_ERR], (uint32_t)E_DISTANCE);     // reaches before the first output byte
+                    const uint32_t q = orel + o + kHist - dist;                    // position of the first source byte
+                    // byte i copies byte i - dist, i.e. byte i mod dist of the dist bytes before the match: pointing there at once
+                    // keeps the chains of overlapping copies (runs) one link long.  Long matches are left to a whole wave
+                    // (expand_long_matches): a lane with many of them (flat images: 8 KiB from 128 bits) would hold up the chunk.
+                    uint32_t slot = kLongCap;
+                    if (len >= (uint32_t)kLongMin) slot = atomicAdd(&S.ctrl[C_NLONG], 1u);
+                    if (slot < (uint32_t)kLongCap) S.longm[slot] = make_uint2(orel + o, len | dist << 16);
+                    else for (uint32_t i = 0, m = 0; i < len; ++i) { S.from[orel + o + i] = (uint16_t)(q + m); if (++m == dist) m = 0; }
                 }
-                ++nm; o += len;
+                o += len;
                 if (o > (uint32_t)kLaneOutMax) fl = F_EARLY;
             } else { fl = kind == 2u ? F_EOB : F_BAD; break; }
         } while (!fl && used <= 16u && pos + used < end);
         pos += used;
     }
-    return LaneResult{ pos, fl, o, nm };
+    return LaneResult{ pos, fl, o };
+}
+
+// inclusive prefix sum over the workgroup
+__device__ __forceinline__ void block_scan(Shared& S, uint32_t& a)
+{
+    const int t = threadIdx.x;
+    S.scan_a[t] = a;
+    __syncthreads();
+    for (int d = 1; d < kT; d <<= 1) {
+        const uint32_t pa = t >= d ? S.scan_a[t - d] : 0u;
+        __syncthreads();
+        a += pa;
+        S.scan_a[t] = a;
+        __syncthreads();
+    }
+}
+
+// S.from[] for the matches the lanes left in S.longm: one match per wave and pass, 64 bytes per step
+__device__ __forceinline__ void expand_long_matches(Shared& S)
+{
+    const uint32_t n = S.ctrl[C_NLONG] < (uint32_t)kLongCap ? S.ctrl[C_NLONG] : (uint32_t)kLongCap;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (uint32_t m = wave; m < n; m += kT / 64) {
+        const uint2 e = S.longm[m];
+        const uint32_t at = e.x, len = e.y & 0xFFFFu, dist = e.y >> 16, q = at + kHist - dist;
+        for (uint32_t i = lane; i < len; i += 64u) S.from[at + i] = (uint16_t)(q + (dist >= len ? i : i % dist));
+    }
+}
+
+// Every byte of the chunk [cs, cs + total) takes its value: S.from[j] names the position byte j copies from (a position p
+// counts from cs - 32768: p < 32768 is window history, always known; p == j + 32768 is the byte itself = known).  Round by
+// round a byte whose source is known copies it, and any other byte adopts its source's source.  A thread looks at 8
+// neighbouring bytes at a time (one 16-byte read of their entries) and passes over groups that are known already.
+__device__ __forceinline__ int resolve_copies(Shared& S, uint32_t cs, uint32_t total)      // -> rounds taken
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const int t = threadIdx.x;
+    const uint32_t units = (total + 7u) >> 3;
+    int round = 0;
+    for (; round < 20; ++round) {
+        if (t == 0) S.ctrl[C_OPEN] = 0;
+        __syncthreads();
+        bool open = false;
+        for (uint32_t u = (uint32_t)t; u < units; u += kT) {
+            const uint32_t j0 = u * 8u, self0 = j0 + kHist;
+            const u32x4 f = *reinterpret_cast<const u32x4*>(&S.from[j0]);
+            const uint32_t s0 = self0 | (self0 + 1u) << 16;
+            if (f.x == s0 && f.y == s0 + 0x00020002u && f.z == s0 + 0x00040004u && f.w == s0 + 0x00060006u) continue;      // all eight known
+            uint32_t p[8] = { f.x & 0xFFFFu, f.x >> 16, f.y & 0xFFFFu, f.y >> 16, f.z & 0xFFFFu, f.z >> 16, f.w & 0xFFFFu, f.w >> 16 };
+            uint32_t pp[8]; uint8_t v[8];
+            #pragma unroll
+            for (int k = 0; k < 8; ++k) if (j0 + k >= total) p[k] = self0 + k;                 // past the chunk: nothing to do
+            #pragma unroll
+            for (int k = 0; k < 8; ++k) pp[k] = (p[k] != self0 + k && p[k] >= (uint32_t)kHist) ? S.from[p[k] - kHist] : p[k];
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");           // values are read after the marks that vouch for them
+            #pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = S.ring[(cs + p[k] - kHist) & kRingMask];
+            #pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (p[k] != self0 + k && pp[k] == p[k]) S.ring[(cs + j0 + k) & kRingMask] = v[k];      // the source is known: history, or a byte that points at itself
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");           // a byte is marked known only after its value is in the ring
+            #pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (p[k] == self0 + k) continue;
+                if (pp[k] == p[k]) S.from[j0 + k] = (uint16_t)(self0 + k);
+                else { S.from[j0 + k] = (uint16_t)pp[k]; open = true; }
+            }
+        }
+        if (open) S.ctrl[C_OPEN] = 1;
+        __syncthreads();
+        const bool any_open = S.ctrl[C_OPEN] != 0;
+        __syncthreads();
+        if (!any_open) break;
+    }
+    return round + 1;
 }
 
 __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_items, uint32_t* out_len, uint32_t* status)
@@ -208,6 +328,7 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
     bool done = false;
     if (t < C_N) S.ctrl[t] = 0;
     __syncthreads();
+    PROF_DECL;
 
     // the window: kWinDwords dwords from the dword that holds bit `pos` (relative to the stream start); zeros past the end
     auto load_window = [&](uint64_t at_bit) -> uint64_t {
@@ -246,7 +367,9 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
 
     while (!done && !err) {
         // ------------------------------------------------------------------ block header
+        PROF(P_FLUSH);
         const uint64_t base_byte = load_window(pos);
+        PROF(P_WINDOW); PROF_COUNT(P_N_BLOCKS, 1);
         if (t == 0) {
             uint32_t p = (uint32_t)(pos - base_byte * 8u);                       // window-relative bit
             uint64_t bb = peek64(S.win, p);
@@ -315,6 +438,7 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
         pos = (uint64_t)S.ctrl[C_HDR_END_HI] << 32 | S.ctrl[C_HDR_END_LO];
         err = S.ctrl[C_ERR];
         if (!err && pos > src_bits) err = E_INPUT;
+        PROF(P_HEADER);
         if (err) break;
 
         if (btype == 0u) {
@@ -333,16 +457,19 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                 produced += n;
             }
             pos = (p + 4u + len) * 8u;
+            PROF(P_STORED);
         } else {
             // -------------------------------------------------------------- Huffman block: tables, then chunks
             const int hlit = (int)S.ctrl[C_HLIT], hdist = (int)S.ctrl[C_HDIST];
             build_table<false>(S, 0, hlit);
             build_table<true>(S, btype == 1u ? 288 : hlit, hdist);
             err = S.ctrl[C_ERR];
+            PROF(P_TABLES);
             if (err) break;
             bool in_block = true;
             while (in_block && !err) {
                 const uint64_t wbase = load_window(pos);
+                PROF(P_WINDOW); PROF_COUNT(P_N_CHUNKS, 1);
                 const uint32_t rel0 = (uint32_t)(pos - wbase * 8u);
                 // speculative sweep, then sweeps from the predecessors' exits until the chain is consistent up to its end
                 uint32_t my_start = t == 0 ? rel0 : (uint32_t)t * kSubBits;
@@ -351,8 +478,10 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                 S.exit_bit[t] = r.exit; S.flags[t] = r.flags;
                 if (t == 0) { S.ctrl[C_FIRST_BAD] = kT; S.ctrl[C_FIRST_STOP] = kT; }
                 __syncthreads();
+                PROF(P_SWEEP0);
                 uint32_t first_stop = kT;
                 for (int sweep = 0; sweep <= kT; ++sweep) {
+                    PROF_COUNT(P_N_SWEEPS, 1);
                     const uint32_t prev = t ? S.exit_bit[t - 1] : rel0;
                     const bool moved = t > 0 && prev != my_start;
                     if (moved) atomicMin(&S.ctrl[C_FIRST_BAD], (uint32_t)t);
@@ -369,50 +498,34 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                     __syncthreads();
                 }
                 __syncthreads();
-                if (t == 0) { S.ctrl[C_FIRST_BAD] = kT; S.ctrl[C_FIRST_STOP] = kT; S.ctrl[C_CUT] = kT; }
+                PROF(P_SWEEPS);
+                if (t == 0) S.ctrl[C_CUT] = kT;
                 uint32_t nvalid = first_stop < (uint32_t)kT ? first_stop + 1u : (uint32_t)kT;      // lanes 0 .. nvalid - 1 form the chain
-                // where everything goes; lanes that would overflow the ring / the match list wait for the next chunk
-                uint32_t inc_o = (uint32_t)t < nvalid ? r.out : 0u, inc_m = (uint32_t)t < nvalid ? r.nm : 0u;
-                block_scan2(S, inc_o, inc_m);
-                if ((uint32_t)t < nvalid && (inc_o > (uint32_t)kNewMax || inc_m > (uint32_t)kMatchCap)) atomicMin(&S.ctrl[C_CUT], (uint32_t)t);
+                // where everything goes; lanes whose output would overflow the ring wait for the next chunk
+                uint32_t inc_o = (uint32_t)t < nvalid ? r.out : 0u;
+                block_scan(S, inc_o);
+                if ((uint32_t)t < nvalid && inc_o > (uint32_t)kNewMax) atomicMin(&S.ctrl[C_CUT], (uint32_t)t);
                 __syncthreads();
                 const uint32_t cut = S.ctrl[C_CUT];
                 const bool was_cut = cut < nvalid;
                 if (was_cut) nvalid = cut;                                            // >= 1: one lane alone always fits
-                const uint32_t total = S.scan_a[nvalid - 1], nm_total = S.scan_b[nvalid - 1];
+                const uint32_t total = S.scan_a[nvalid - 1];
                 const uint32_t last_exit = S.exit_bit[nvalid - 1], last_flags = was_cut ? 0u : S.flags[nvalid - 1];
+                if (t == 0) S.ctrl[C_NLONG] = 0;
                 __syncthreads();
-                if ((uint32_t)t < nvalid) lane_decode<true>(S, my_start, my_end, produced + (inc_o - r.out), inc_m - r.nm);
+                PROF(P_SCAN);
+                if ((uint32_t)t < nvalid) lane_decode<true>(S, my_start, my_end, produced + (inc_o - r.out), inc_o - r.out);
                 __syncthreads();
                 err = S.ctrl[C_ERR];
                 if (!err && (last_flags & F_BAD)) err = E_CODE;
                 if (!err && wbase * 8u + last_exit > src_bits) err = E_INPUT;
+                PROF(P_WRITE);
                 if (err) break;
-                // matches, 256 at a time: a match copies once its source lies below the first pending destination
-                for (uint32_t g = 0; g < nm_total; g += kT) {
-                    const bool have = g + t < nm_total;
-                    uint32_t d = 0, len = 0, dist = 1, src_end = 0;
-                    if (have) {
-                        const uint2 m = S.matches[g + t];
-                        d = m.x; len = m.y & 0xFFFFu; dist = m.y >> 16;
-                        src_end = d - dist + (len < dist ? len : dist);
-                    }
-                    bool pending = have;
-                    for (;;) {
-                        if (t == 0) S.ctrl[C_HWM] = 0xFFFFFFFFu;
-                        __syncthreads();
-                        if (pending) atomicMin(&S.ctrl[C_HWM], d);
-                        __syncthreads();
-                        const uint32_t hwm = S.ctrl[C_HWM];
-                        if (hwm == 0xFFFFFFFFu) break;
-                        if (pending && src_end <= hwm) {
-                            for (uint32_t i = 0; i < len; ++i) S.ring[(d + i) & kRingMask] = S.ring[(d + i - dist) & kRingMask];
-                            pending = false;
-                        }
-                        __syncthreads();
-                    }
-                }
+                expand_long_matches(S);
                 __syncthreads();
+                { const int rounds = resolve_copies(S, produced, total); (void)rounds; PROF_COUNT(P_N_ROUNDS, rounds); }
+                __syncthreads();
+                PROF(P_MATCH);
                 flush(produced, total);
                 __syncthreads();
                 produced += total;
@@ -423,6 +536,7 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
         }
         if (bfinal) done = true;
     }
+    PROF_FLUSH;
     if (t == 0) {
         out_len[blockIdx.x] = produced < it.dst_cap ? produced : it.dst_cap;
         status[blockIdx.x] = err;
@@ -453,6 +567,15 @@ int inflate_launch(const gamut_hip_inflate_desc* descs, int count, uint32_t* out
 } // namespace gamut
 
 using namespace gamut;
+
+#if INFLATE_PROFILE
+extern "C" int gamut_hip_inflate_profile(unsigned long long* out, int reset)      // measurement builds only
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_inflate_prof), sizeof(unsigned long long) * P_N) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[P_N] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_inflate_prof), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 
 extern "C" int gamut_hip_inflate_batch_device(const gamut_hip_inflate_desc* descs, int count, uint32_t* out_len_dev, uint32_t* status_dev, void* stream)
 {

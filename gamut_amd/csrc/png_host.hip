@@ -329,6 +329,8 @@ struct PinnedPool {
 };
 PinnedPool& pinned_pool() { static PinnedPool* p = new PinnedPool(); return *p; }
 
+constexpr int kDeviceInflateMinFiles = 32;   // batches at least this large inflate on the GPU (one workgroup per stream)
+
 struct BatchFile {                    // what a worker leaves behind for one file
     int rc = GAMUT_HIP_OK; char msg[160] = { 0 };
     bool uploaded = false, batched = false;   // inflated stream in the device arena; de-filter goes into a batched launch
@@ -440,6 +442,49 @@ int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* 
         auto ms_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
         std::atomic<int64_t> us_inflate{ 0 }, us_upload{ 0 };
         std::atomic<int> next{ 0 };
+        // Inflate on the GPU (inflate.hip) when the batch is large enough to fill the chip with streams: the workers then only
+        // walk the chunks and gather the IDAT bytes into one pinned upload image (file i's share starts at blob_off[i]; its
+        // IDAT bytes cannot outnumber the file's own).  GAMUT_HIP_PNG_INFLATE=host / device overrides the choice.
+        bool device_inflate = count >= kDeviceInflateMinFiles;
+        if (const char* v = getenv("GAMUT_HIP_PNG_INFLATE")) device_inflate = strcmp(v, "device") == 0 ? true : strcmp(v, "host") == 0 ? false : device_inflate;
+        std::vector<size_t> blob_off((size_t)count + 1, 0);
+        std::vector<uint32_t> idat_len((size_t)count, 0);
+        uint8_t* h_blob = nullptr; uint8_t* d_blob = nullptr;
+        static thread_local PinnedScratch blob_pinned;
+        static thread_local DeviceScratch blob_dev;
+        if (device_inflate) {
+            for (int i = 0; i < count; ++i) blob_off[(size_t)i + 1] = blob_off[(size_t)i] + ((len[i] + 15) & ~(size_t)15);
+            h_blob = blob_pinned.get(blob_off[(size_t)count] + 16);
+            d_blob = (uint8_t*)blob_dev.get(blob_off[(size_t)count] + 16);
+            if (!h_blob || !d_blob) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png: staging for %zu bytes of IDAT data failed", blob_off[(size_t)count]);
+        }
+        auto gather = [&]() {                                   // device inflate: chunk walk + IDAT gather of one file at a time
+            for (int i; (i = next.fetch_add(1, std::memory_order_relaxed)) < count; ) {
+                BatchFile& f = files[(size_t)i];
+                PngHeader h;
+                const auto t_in = std::chrono::steady_clock::now();
+                int rc = parse(data[i], len[i], h, false);
+                if (rc == GAMUT_HIP_OK && !h.idata) rc = set_error(GAMUT_HIP_ERR_DECODE, "png: no IDAT");
+                uint32_t skip = 0;
+                if (rc == GAMUT_HIP_OK && !h.is_iphone) {                       // the zlib header, as inflate_idat checks it (stbdec.d:1281-1290)
+                    const uint8_t* b = h.idata;
+                    if (h.ioff < 2 || ((b[0] * 256 + b[1]) % 31) != 0 || (b[1] & 32) || (b[0] & 15) != 8) rc = set_error(GAMUT_HIP_ERR_DECODE, "png: bad zlib header");
+                    skip = 2;
+                }
+                if (rc == GAMUT_HIP_OK && slot[(size_t)i] < 0) rc = set_error(GAMUT_HIP_ERR_DECODE, "png: image too large");
+                if (rc != GAMUT_HIP_OK) { f.rc = rc; snprintf(f.msg, sizeof(f.msg), "image %d: %s", i, last_error_buf()); continue; }
+                idat_len[(size_t)i] = h.ioff - skip;
+                memcpy(h_blob + blob_off[(size_t)i], h.idata + skip, h.ioff - skip);
+                free(h.idata); h.idata = nullptr;
+                f.h = h;
+                f.out_n = h.img_n;
+                if ((req_comp == h.img_n + 1 && req_comp != 3 && !h.pal_img_n) || h.has_trans) f.out_n = h.img_n + 1;      // stbdec.d:1821-1824
+                f.bits = h.depth <= 8 ? 8 : 16; f.channels_in_file = h.img_n;
+                const uint64_t wb = ((uint64_t)h.img_n * h.x * (uint32_t)h.depth + 7) >> 3;
+                f.need = (uint32_t)((wb + 1) * h.y);
+                us_inflate += (int64_t)(ms_since(t_in) * 1000);
+            }
+        };
         auto work = [&]() {
             (void)hipSetDevice(dev);
             HostBuf buf = pinned_pool().take();
@@ -477,12 +522,48 @@ int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* 
         };
         {
             std::vector<std::thread> pool;
-            try { for (int t = 1; t < threads; ++t) pool.emplace_back(work); } catch (...) {}
-            work();
+            if (device_inflate) {
+                try { for (int t = 1; t < threads; ++t) pool.emplace_back(gather); } catch (...) {}
+                gather();
+            } else {
+                try { for (int t = 1; t < threads; ++t) pool.emplace_back(work); } catch (...) {}
+                work();
+            }
             for (std::thread& th : pool) th.join();
         }
         clear_error();
         GAMUT_HIP_CHECK(hipStreamSynchronize(copy_stream));                       // (every worker waited for its own copies already)
+        double ms_device_inflate = 0;
+        if (device_inflate) {
+            // one upload, one launch: every stream straight into its slot of the arena; lengths and verdicts come back
+            const auto t_inf = std::chrono::steady_clock::now();
+            std::vector<gamut_hip_inflate_desc> descs; std::vector<int> who;
+            for (int i = 0; i < count; ++i) {
+                if (files[(size_t)i].rc != GAMUT_HIP_OK) continue;
+                descs.push_back(gamut_hip_inflate_desc{ d_blob + blob_off[(size_t)i], d_arena + slot[(size_t)i], idat_len[(size_t)i], (uint32_t)slot_bytes[(size_t)i] });
+                who.push_back(i);
+            }
+            if (!descs.empty()) {
+                const size_t n = descs.size();
+                static thread_local DeviceScratch verdict_dev;
+                uint32_t* d_verdict = (uint32_t*)verdict_dev.get(n * 8);
+                if (!d_verdict) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png: verdict table allocation failed");
+                std::vector<uint32_t> verdict(n * 2);
+                GAMUT_HIP_CHECK(hipMemcpyAsync(d_blob, h_blob, blob_off[(size_t)count], hipMemcpyHostToDevice, st));
+                if (int rc = inflate_launch(descs.data(), (int)n, d_verdict, d_verdict + n, st)) return rc;
+                GAMUT_HIP_CHECK(hipMemcpyAsync(verdict.data(), d_verdict, n * 8, hipMemcpyDeviceToHost, st));
+                GAMUT_HIP_CHECK(hipStreamSynchronize(st));
+                for (size_t k = 0; k < n; ++k) {
+                    BatchFile& f = files[(size_t)who[k]];
+                    if (verdict[n + k]) { f.rc = GAMUT_HIP_ERR_DECODE; snprintf(f.msg, sizeof(f.msg), "image %d: png: corrupt zlib stream", who[k]); continue; }
+                    const PngHeader& h = f.h;
+                    f.raw_len = verdict[k];
+                    f.uploaded = true;
+                    f.batched = !h.interlace && !h.has_trans && !h.pal_img_n && (req_comp == 0 || req_comp == f.out_n) && (bits == 0 || bits == f.bits) && f.raw_len >= f.need;
+                }
+            }
+            ms_device_inflate = ms_since(t_inf);
+        }
         const double ms_workers = ms_since(t_begin);
 
         // 2. one de-filter launch per geometry
@@ -537,6 +618,7 @@ int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* 
             else { f.rc = GAMUT_HIP_ERR_DECODE; snprintf(f.msg, sizeof(f.msg), "image %d: %s", i, last_error_buf()); }
         }
         clear_error();
+        if (trace && device_inflate) fprintf(stderr, "[gamut_hip] png_decode_batch_device: inflate on the device: upload + kernel + verdicts %.1f ms\n", ms_device_inflate);
         if (trace) fprintf(stderr, "[gamut_hip] png_decode_batch_device: %d files on %d threads: workers %.1f ms (per file: chunk walk + inflate %.1f ms, upload + wait %.1f ms), GPU stages %.1f ms (%d files in %d batched launches)\n",
                            count, threads, ms_workers, us_inflate.load() / 1000.0 / count, us_upload.load() / 1000.0 / count, ms_since(t_begin) - ms_workers, n_batched, (int)groups.size());
         // 4. results

@@ -209,7 +209,20 @@ def test_extreme_geometry(hip, img_n, out_n, x, y):
     assert np.array_equal(got, exp)
 
 
-def test_png_file_batch_feeder(hip):
+@pytest.fixture(params=["host", "device"])
+def inflate_mode(request):
+    """the file batch with zlib on host threads, then with the inflate kernel (inflate.hip; batches of >= 32 files choose it
+    themselves, GAMUT_HIP_PNG_INFLATE forces either)"""
+    old = os.environ.get("GAMUT_HIP_PNG_INFLATE")
+    os.environ["GAMUT_HIP_PNG_INFLATE"] = request.param
+    yield request.param
+    if old is None:
+        del os.environ["GAMUT_HIP_PNG_INFLATE"]
+    else:
+        os.environ["GAMUT_HIP_PNG_INFLATE"] = old
+
+
+def test_png_file_batch_feeder(hip, inflate_mode):
     """gamut_hip_png_decode_batch_device: mixed files (sizes, colour types, depths, Adam7, palette + tRNS, a broken one) on a
     host thread pool + GPU == stbi_load / stbi_load_16 of the oracle, pixels left in HBM"""
     rng = np.random.default_rng(21)
@@ -252,7 +265,7 @@ def test_png_file_batch_feeder(hip):
     assert hip.gamut_hip_png_read_header(ptrs[4], lens[4], C.byref(hd)) == 0 and (hd.width, hd.height, hd.bits, hd.channels) == (w, h, 16, 4)
 
 
-def test_png_file_batch_same_geometry_groups(hip):
+def test_png_file_batch_same_geometry_groups(hip, inflate_mode):
     """files of one geometry are de-filtered in ONE launch through per-image offset tables (RGB8 -> rgba8: the alpha-inserting
     ring kernel; RGBA8 as is; grey + alpha insert through the scratch + expand route), next to files of another size"""
     rng = np.random.default_rng(33)
@@ -312,3 +325,54 @@ def test_files_written_by_libpng(hip):
             if img.mode in ("RGB", "RGBA", "L", "LA"):                     # and the oracle agrees with the source pixels
                 src = np.asarray(img).reshape(h, w, -1)
                 assert np.array_equal(O.stbi_load(data, 0, False)[0].reshape(h, w, -1), src), mode
+
+
+def test_png_file_batch_of_libpng_files_inflates_on_the_device(hip):
+    """48 files from a real encoder (Pillow / libpng, levels 1 / 6 / 9, RGB / RGBA / grey / 16-bit / palette / Adam7) in one
+    batch: large enough for the batch to pick the device inflate by itself; == the oracle's stbi_load per file.  One file has
+    a damaged IDAT stream, one a bad zlib header: both are reported, the others decode."""
+    import io
+    from PIL import Image
+    os.environ.pop("GAMUT_HIP_PNG_INFLATE", None)
+    files = []
+    for k in range(46):
+        w, h = 61 + 17 * (k % 7), 40 + 11 * (k % 5)
+        rgb = gen.synth_rgb(w, h, 300 + k)
+        mode = k % 6
+        if mode == 0: im = Image.fromarray(rgb)
+        elif mode == 1: im = Image.fromarray(np.dstack([rgb, rgb[:, :, 0]]))
+        elif mode == 2: im = Image.fromarray(rgb[:, :, 1])
+        elif mode == 3: im = Image.fromarray((rgb[:, :, 0].astype(np.uint16) * 257 + rgb[:, :, 2]).astype(np.uint16))
+        elif mode == 4: im = Image.fromarray(rgb).quantize(50)
+        else: im = Image.fromarray(rgb)
+        bio = io.BytesIO(); im.save(bio, "PNG", compress_level=(1, 6, 9)[k % 3], optimize=(k % 4 == 0))
+        files.append(bio.getvalue())
+    files[5] = gen.write_png(np.random.default_rng(2).integers(0, 256, (33, 47 * 3)), 47, 33, 2, 8, interlace=1)
+    bad = bytearray(files[7]); i = bad.index(b"IDAT") + 4 + 40; bad[i] ^= 0x10; files.append(bytes(bad))             # damaged stream
+    bad = bytearray(files[8]); i = bad.index(b"IDAT") + 4; bad[i] = 0x79; files.append(bytes(bad))                    # zlib header fails its check
+    n = len(files)
+    assert n >= 32
+    bufs = [np.frombuffer(f, np.uint8) for f in files]
+    ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs]); lens = (C.c_size_t * n)(*[b.size for b in bufs])
+    exp = []
+    for f in files:
+        try:
+            exp.append(np.ascontiguousarray(O.stbi_load(f, 4, False)[0]).view(np.uint8).reshape(-1))
+        except Exception:
+            exp.append(None)
+    assert exp[-1] is None                                                        # (the damaged one may or may not still inflate)
+    sizes = [e.size if e is not None else 0 for e in exp]
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+    dout = up(hip, np.full(int(sum(sizes)) + 64, 0xA5, np.uint8))
+    info = (_capi.PngInfo * n)(); st = (C.c_int * n)()
+    rc = hip.gamut_hip_png_decode_batch_device(ptrs, lens, n, 4, 8, offs.ctypes.data_as(C.POINTER(C.c_int64)), dout, info, st, 4, None)
+    host = down(hip, dout, int(sum(sizes)) + 64)
+    hip.gamut_hip_device_free(dout)
+    assert rc == _capi.ERR_DECODE
+    for i, e in enumerate(exp):
+        if e is None:
+            assert st[i] == _capi.ERR_DECODE, i
+        else:
+            assert st[i] == 0, (i, hip.gamut_hip_last_error())
+            assert np.array_equal(host[offs[i]:offs[i] + e.size], e), i
+    assert (host[int(sum(sizes)):] == 0xA5).all()

@@ -36,13 +36,14 @@ def main():
     dout = L.gamut_hip_device_malloc(B * w * h * 4)
     info = (_capi.PngInfo * B)()
     print(f"batch {B} x {w}x{h} RGB8 PNG -> rgba8, {sum(b.size for b in bufs) / B / 1e6:.1f} MB/file, {os.cpu_count()} host cores")
-    for threads in (1, 16, 0):
+    for mode, threads in (("host", 1), ("host", 16), ("host", 0), ("device", 0)):
+        os.environ["GAMUT_HIP_PNG_INFLATE"] = mode
         best = 1e9
         for _ in range(2):
             t0 = time.perf_counter()
             _capi.check(L.gamut_hip_png_decode_batch_device(ptrs, lens, B, 4, 8, offs.ctypes.data_as(C.POINTER(C.c_int64)), dout, info, None, threads, None))
             best = min(best, time.perf_counter() - t0)
-        print(f"  host threads {str(threads) if threads else 'auto':>4s}: {B * w * h / best / 1e6:9.1f} Mpx/s  ({best * 1e3:8.1f} ms)")
+        print(f"  inflate on the {mode:6s}, host threads {str(threads) if threads else 'auto':>4s}: {B * w * h / best / 1e6:9.1f} Mpx/s  ({best * 1e3:8.1f} ms)")
     L.gamut_hip_device_free(dout)
 
 

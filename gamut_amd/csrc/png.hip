@@ -47,9 +47,45 @@ struct DefilterArgs {
     u32 rows, wb;                                // rows, bytes per row
     u32 store_tail_masked;                       // 1: D rows are tight (fused output) -> never write past wb
     const int64_t* raw_offs; const int64_t* d_offs;  // optional (device): byte offset of image i's stream / rows instead of i * stride
+    u32 nseg;                                    // > 1: every image is cut into up to nseg row segments (take_segment), one workgroup each
 };
 __device__ __forceinline__ const uint8_t* image_raw(const DefilterArgs& a, int img) { return a.raw + (a.raw_offs ? a.raw_offs[img] : (int64_t)img * a.raw_stride); }
 __device__ __forceinline__ uint8_t* image_rows(const DefilterArgs& a, int img) { return a.D + (a.d_offs ? a.d_offs[img] : (int64_t)img * a.d_stride); }
+// A workgroup's share: the whole image, or -- small batches -- the rows from one cut row to the next.  A cut row has filter None
+// or Sub: it does not look at the row above, so the rows from there on de-filter like an image of their own.  Boundary k of an
+// image's nseg segments is the cut row nearest to rows * k / nseg within rows / (2 nseg) - 1 rows of it (windows of different
+// boundaries are disjoint), or missing; a segment whose own boundary is missing is empty, its rows stay with the segment
+// before.  Every wave works this out for itself from the filter bytes (a few strided loads): nothing is handed from one
+// kernel to the next (a table written by a kernel just before this one was seen stale by workgroups on other XCDs).
+__device__ __forceinline__ u32 cut_row(const uint8_t* raw, u32 rows, u32 wb, u32 nseg, u32 k)      // wave-uniform; 0xFFFFFFFF = none
+{
+    const u32 lane = threadIdx.x & 63u;
+    const u32 target = (u32)((uint64_t)rows * k / nseg), half = rows / (2u * nseg), reach = half ? half - 1u : 0u;
+    u32 best = 0xFFFFFFFFu;                                      // distance << 1 | side: ties are settled the same way by every wave
+    for (u32 d = lane; d <= reach && best == 0xFFFFFFFFu; d += 64u) {
+        if (target + d < rows && raw[(int64_t)(target + d) * (wb + 1)] <= 1) best = d << 1;
+        else if (d < target && raw[(int64_t)(target - d) * (wb + 1)] <= 1) best = d << 1 | 1u;
+    }
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const u32 other = (u32)__shfl_xor((int)best, o); best = other < best ? other : best; }
+    return best == 0xFFFFFFFFu ? best : (best & 1u) ? target - (best >> 1) : target + (best >> 1);
+}
+__device__ __forceinline__ bool take_segment(DefilterArgs& a, int& img, const uint8_t*& raw, uint8_t*& D)
+{
+    u32 row0 = 0;
+    if (a.nseg > 1) {
+        img = (int)blockIdx.y;                   // grid = (segments, images)
+        const u32 s = blockIdx.x;
+        const uint8_t* whole = image_raw(a, img);
+        if (s > 0) { row0 = cut_row(whole, a.rows, a.wb, a.nseg, s); if (row0 == 0xFFFFFFFFu) return false; }
+        u32 row1 = a.rows;
+        for (u32 k = s + 1; k < a.nseg; ++k) { const u32 c = cut_row(whole, a.rows, a.wb, a.nseg, k); if (c != 0xFFFFFFFFu) { row1 = c; break; } }
+        a.rows = row1 - row0;
+    } else img = (int)blockIdx.x;
+    raw = image_raw(a, img) + (int64_t)row0 * (a.wb + 1);
+    D = image_rows(a, img) + (int64_t)row0 * a.d_pitch;
+    return true;
+}
 
 struct __attribute__((packed)) PackedU32 { u32 v; };      // a dword at any byte alignment
 
@@ -362,9 +398,8 @@ __global__ __launch_bounds__(W * 64) void k_png_defilter(DefilterArgs a)
 {
     __shared__ u32 prog[W];                       // cumulative iterations finished (and visible) by each wave's lane 63
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int img = blockIdx.x;
-    const uint8_t* raw = image_raw(a, img);
-    uint8_t* D = image_rows(a, img);
+    int img; const uint8_t* raw; uint8_t* D;
+    if (!take_segment(a, img, raw, D)) return;
     const u32 npix = a.wb / FB;                   // filter units per row
     const u32 niter = (npix + 3) / 4;
     const u32 nbands = (a.rows + 63) / 64;
@@ -593,9 +628,8 @@ __global__ __launch_bounds__(W * 64, MINW) void k_png_defilter_ring(DefilterArgs
     __shared__ u32 prog[W];
     __shared__ __attribute__((aligned(16))) uint8_t tiles[W][64 * ROW_PITCH];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int img = blockIdx.x;
-    const uint8_t* raw = image_raw(a, img);
-    uint8_t* D = image_rows(a, img);
+    int img; const uint8_t* raw; uint8_t* D;
+    if (!take_segment(a, img, raw, D)) return;
     constexpr u32 IB = RGBA ? 12 : 16;
     const u32 niter = (a.wb + IB - 1) / IB;
     const u32 nbands = (a.rows + 63) / 64;
@@ -821,7 +855,12 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
         if (!a.D) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png_defilter: scratch allocation failed");
         a.store_tail_masked = 0;
     }
-    const dim3 grid(count), block(PNG_WAVES * 64);
+    // Few images: cut each into row segments at None / Sub rows so that more compute units than images take part (a 4K image
+    // alone keeps one workgroup busy for 34 bands in turn).  Which rows qualify is data: the workgroups find out (take_segment).
+    u32 nseg = 1;
+    if (count < 512 && y >= 256) { nseg = 1024u / (u32)count; nseg = nseg > 8 ? 8 : nseg; while (nseg > 1 && y / nseg < 128) --nseg; }
+    a.nseg = nseg;
+    const dim3 grid(nseg > 1 ? nseg : (unsigned)count, nseg > 1 ? (unsigned)count : 1u), block(PNG_WAVES * 64);
     // rows of at least one 16-byte piece: the LDS-ring kernel (coalesced, aligned I/O); 8 waves per workgroup, register
     // budget left unconstrained (no spills: measured faster than 128-VGPR variants that spill).  Narrower rows: the
     // per-lane kernel.

@@ -92,6 +92,32 @@ def test_config3_geometry_roundtrip(hip):
     assert np.array_equal(exp, img.reshape(-1))
 
 
+@pytest.mark.parametrize("img_n,out_n,color", [(4, 4, 6), (3, 4, 2), (3, 3, 2), (1, 1, 0)])
+def test_row_segments_of_small_batches(hip, img_n, out_n, color):
+    """small batches cut every image into row segments at None / Sub rows (png.hip: k_png_segments): rows without any cut row,
+    a single cut row, cut rows everywhere, cut rows only far from the targets; 1 .. 3 images a call"""
+    rng = np.random.default_rng(40 + img_n)
+    for (x, y) in [(97, 256), (64, 1000), (301, 2050)]:
+        px = rng.integers(0, 256, (y, x * img_n))
+        patterns = [np.full(y, 4, np.uint8), np.full(y, 2, np.uint8), rng.integers(0, 5, y).astype(np.uint8), rng.integers(2, 5, y).astype(np.uint8)]
+        one = np.full(y, 3, np.uint8); one[y // 2 + 7] = 1; patterns.append(one)
+        far = rng.integers(2, 5, y).astype(np.uint8); far[3] = 0; far[y - 2] = 1; far[y // 8 + y // 20] = 1; patterns.append(far)
+        for filt in patterns:
+            raw = gen.png_forward_filter(px, img_n, filt)
+            exp = O.png_create_image_raw(raw, img_n, out_n, x, y, 8, color)
+            assert np.array_equal(gpu_defilter(hip, raw, x, y, img_n, out_n, 8, color)[0], exp), (x, y, np.unique(filt))
+        n = 3
+        stride = (x * img_n + 1) * y + 5
+        raws = np.zeros(n * stride, np.uint8); exps = []
+        for i in range(n):
+            r = gen.png_forward_filter(rng.integers(0, 256, (y, x * img_n)), img_n, rng.integers(0, 5, y).astype(np.uint8))
+            raws[i * stride:i * stride + r.size] = r
+            exps.append(O.png_create_image_raw(r, img_n, out_n, x, y, 8, color))
+        got = gpu_defilter(hip, raws, x, y, img_n, out_n, 8, color, count=n, raw_stride=stride)
+        for i in range(n):
+            assert np.array_equal(got[i], exps[i]), (x, y, i)
+
+
 def test_batch_and_corrupt_filter(hip):
     rng = np.random.default_rng(12)
     x, y, n = 61, 150, 4

@@ -331,7 +331,7 @@ def main():
         bytes_per_step = sum(fmt_bytes.values())
         kernel_name = "k_jpeg_h2v2 + k_png_defilter + k_qoi_decode"
         workload = (f"mixed batch of {B} x {w}x{h} images -> rgba8, image i: JPEG 4:2:0 / PNG RGBA8 / QOI RGB by i % 3 "
-                    f"({nj} + {npn} + {nq}); QOI is decoded one lane per file (a serial format) and bounds the step")
+                    f"({nj} + {npn} + {nq}); QOI is decoded one wave per file (only its INDEX ops are serial) and still bounds the step")
         fmt_ev = {k: [] for k in ("jpeg", "png", "qoi")}
         img = h * w * 4
 

@@ -355,7 +355,7 @@ def test_files_written_by_libpng(hip):
 
 def test_png_file_batch_of_libpng_files_inflates_on_the_device(hip):
     """48 files from a real encoder (Pillow / libpng, levels 1 / 6 / 9, RGB / RGBA / grey / 16-bit / palette / Adam7) in one
-    batch: large enough for the batch to pick the device inflate by itself; == the oracle's stbi_load per file.  One file has
+    batch on one host thread: large enough for the batch to pick the device inflate by itself (>= 3 files per thread); == the oracle's stbi_load per file.  One file has
     a damaged IDAT stream, one a bad zlib header: both are reported, the others decode."""
     import io
     from PIL import Image
@@ -391,7 +391,7 @@ def test_png_file_batch_of_libpng_files_inflates_on_the_device(hip):
     offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
     dout = up(hip, np.full(int(sum(sizes)) + 64, 0xA5, np.uint8))
     info = (_capi.PngInfo * n)(); st = (C.c_int * n)()
-    rc = hip.gamut_hip_png_decode_batch_device(ptrs, lens, n, 4, 8, offs.ctypes.data_as(C.POINTER(C.c_int64)), dout, info, st, 4, None)
+    rc = hip.gamut_hip_png_decode_batch_device(ptrs, lens, n, 4, 8, offs.ctypes.data_as(C.POINTER(C.c_int64)), dout, info, st, 1, None)
     host = down(hip, dout, int(sum(sizes)) + 64)
     hip.gamut_hip_device_free(dout)
     assert rc == _capi.ERR_DECODE

@@ -184,9 +184,13 @@ template <int FROM> struct LongCodes {
 
 // tokens of one lane: from bit `start` until a token begins at or beyond `end` (window-relative bits).  WRITE: literals into the
 // ring at absolute output offset obase.., and S.from[] for every byte (orel = obase - chunk start)
-template <bool WRITE>
+// MODE 0: count only (the sweeps); 1: write (see above); 2: nothing is written, but distances are still checked against the
+// bytes produced so far (the part of a stream beyond the caller's capacity is decoded to its end all the same: a stream
+// damaged anywhere is a corrupt stream, as it is for the reference, which inflates all of it)
+template <int MODE>
 __device__ __forceinline__ LaneResult lane_decode(Shared& S, uint32_t start, uint32_t end, uint32_t obase, uint32_t orel)
 {
+    constexpr bool WRITE = MODE == 1;
     LongCodes<kLitBits + 1> long_lit; long_lit.load(S.lit);
     LongCodes<kDistBits + 1> long_dist; long_dist.load(S.dist);
     uint32_t pos = start, o = 0, fl = 0;
@@ -214,8 +218,8 @@ __device__ __forceinline__ LaneResult lane_decode(Shared& S, uint32_t start, uin
                 xb = (de >> 8) & 31u;
                 const uint32_t dist = (de >> 16) + ((uint32_t)bits & ((1u << xb) - 1u));
                 bits >>= xb; used += xb;
+                if (MODE != 0 && dist > obase + o) atomicMax(&S.ctrl[C_ERR], (uint32_t)E_DISTANCE);     // reaches before the first output byte
                 if (WRITE) {
-                    if (dist > obase + o) atomicMax(&S.ctrl[C_ERR], (uint32_t)E_DISTANCE);     // reaches before the first output byte
                     const uint32_t q = orel + o + kHist - dist;                    // position of the first source byte
                     // byte i copies byte i - dist, i.e. byte i mod dist of the dist bytes before the match: pointing there at once
                     // keeps the chains of overlapping copies (runs) one link long.  Long matches are left to a whole wave
@@ -365,7 +369,15 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
         if ((uint32_t)t < n - tail0) d[tail0 + t] = S.ring[(from + tail0 + t) & kRingMask];
     };
 
+    // A stream is untrusted input, and a block costs ~40 000 cycles whatever it holds: an "image" made of empty blocks (10 bits
+    // each) would keep a workgroup busy for minutes.  No encoder emits more than a block per scanline or per few KiB; streams
+    // with more than one block per 8 compressed bytes (beyond the first 4096) are turned away as corrupt.  The tables of the
+    // fixed code are built once per stream.
+    const uint32_t block_budget = it.src_len / 8u + 4096u;
+    uint32_t blocks = 0;
+    bool fixed_tables = false;                        // the LDS tables hold the fixed code
     while (!done && !err) {
+        if (++blocks > block_budget) { err = E_INPUT; break; }
         // ------------------------------------------------------------------ block header
         PROF(P_FLUSH);
         const uint64_t base_byte = load_window(pos);
@@ -425,8 +437,10 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                 }
                 if (bad) atomicMax(&S.ctrl[C_ERR], (uint32_t)E_LENGTHS);
             } else if (btype == 1u) {
-                for (int s = 0; s < 288; ++s) S.lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
-                for (int s = 0; s < 32; ++s) S.lens[288 + s] = 5;
+                if (!fixed_tables) {
+                    for (int s = 0; s < 288; ++s) S.lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+                    for (int s = 0; s < 32; ++s) S.lens[288 + s] = 5;
+                }
                 S.ctrl[C_HLIT] = 288; S.ctrl[C_HDIST] = 32;
             } else if (btype == 3u) atomicMax(&S.ctrl[C_ERR], (uint32_t)E_BLOCK_TYPE);
             const uint64_t end = base_byte * 8u + p;
@@ -450,19 +464,24 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
             if (p + 4u + len > it.src_len) { err = E_INPUT; break; }
             for (uint32_t o = 0; o < len; o += (uint32_t)kNewMax) {
                 const uint32_t n = len - o < (uint32_t)kNewMax ? len - o : (uint32_t)kNewMax;
-                for (uint32_t i = t; i < n; i += kT) S.ring[(produced + i) & kRingMask] = src[p + 4u + o + i];
-                __syncthreads();
-                flush(produced, n);
-                __syncthreads();
-                produced += n;
+                if (produced < it.dst_cap || o + (uint32_t)kHist >= len) {           // (beyond the caller's capacity only the window matters)
+                    for (uint32_t i = t; i < n; i += kT) S.ring[(produced + i) & kRingMask] = src[p + 4u + o + i];
+                    __syncthreads();
+                    flush(produced, n);
+                    __syncthreads();
+                }
+                produced = produced + n < produced ? 0xFFFFFFFFu : produced + n;
             }
             pos = (p + 4u + len) * 8u;
             PROF(P_STORED);
         } else {
             // -------------------------------------------------------------- Huffman block: tables, then chunks
             const int hlit = (int)S.ctrl[C_HLIT], hdist = (int)S.ctrl[C_HDIST];
-            build_table<false>(S, 0, hlit);
-            build_table<true>(S, btype == 1u ? 288 : hlit, hdist);
+            if (!(btype == 1u && fixed_tables)) {
+                build_table<false>(S, 0, hlit);
+                build_table<true>(S, btype == 1u ? 288 : hlit, hdist);
+            }
+            fixed_tables = btype == 1u;
             err = S.ctrl[C_ERR];
             PROF(P_TABLES);
             if (err) break;
@@ -474,7 +493,7 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                 // speculative sweep, then sweeps from the predecessors' exits until the chain is consistent up to its end
                 uint32_t my_start = t == 0 ? rel0 : (uint32_t)t * kSubBits;
                 const uint32_t my_end = (uint32_t)(t + 1) * kSubBits;
-                LaneResult r = lane_decode<false>(S, my_start, my_end, 0, 0);
+                LaneResult r = lane_decode<0>(S, my_start, my_end, 0, 0);
                 S.exit_bit[t] = r.exit; S.flags[t] = r.flags;
                 if (t == 0) { S.ctrl[C_FIRST_BAD] = kT; S.ctrl[C_FIRST_STOP] = kT; }
                 __syncthreads();
@@ -492,7 +511,7 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                     __syncthreads();
                     if (first_bad == (uint32_t)kT || first_stop < first_bad) break;
                     if (t == 0) { S.ctrl[C_FIRST_BAD] = kT; S.ctrl[C_FIRST_STOP] = kT; }
-                    if (moved) { my_start = prev; r = lane_decode<false>(S, my_start, my_end, 0, 0); }
+                    if (moved) { my_start = prev; r = lane_decode<0>(S, my_start, my_end, 0, 0); }
                     __syncthreads();
                     S.exit_bit[t] = r.exit; S.flags[t] = r.flags;
                     __syncthreads();
@@ -514,24 +533,29 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                 if (t == 0) S.ctrl[C_NLONG] = 0;
                 __syncthreads();
                 PROF(P_SCAN);
-                if ((uint32_t)t < nvalid) lane_decode<true>(S, my_start, my_end, produced + (inc_o - r.out), inc_o - r.out);
+                const bool sink = produced >= it.dst_cap;                             // the caller's buffer is full: decode on, write nothing
+                if ((uint32_t)t < nvalid) {
+                    if (sink) lane_decode<2>(S, my_start, my_end, produced + (inc_o - r.out), inc_o - r.out);
+                    else      lane_decode<1>(S, my_start, my_end, produced + (inc_o - r.out), inc_o - r.out);
+                }
                 __syncthreads();
                 err = S.ctrl[C_ERR];
                 if (!err && (last_flags & F_BAD)) err = E_CODE;
                 if (!err && wbase * 8u + last_exit > src_bits) err = E_INPUT;
                 PROF(P_WRITE);
                 if (err) break;
-                expand_long_matches(S);
-                __syncthreads();
-                { const int rounds = resolve_copies(S, produced, total); (void)rounds; PROF_COUNT(P_N_ROUNDS, rounds); }
+                if (!sink) {
+                    expand_long_matches(S);
+                    __syncthreads();
+                    { const int rounds = resolve_copies(S, produced, total); (void)rounds; PROF_COUNT(P_N_ROUNDS, rounds); }
+                }
                 __syncthreads();
                 PROF(P_MATCH);
-                flush(produced, total);
+                if (!sink) flush(produced, total);
                 __syncthreads();
-                produced += total;
+                produced = produced + total < produced ? 0xFFFFFFFFu : produced + total;           // (saturating: only its size matters beyond 32 KiB)
                 pos = wbase * 8u + last_exit;
                 if (last_flags & F_EOB) in_block = false;
-                if (produced >= it.dst_cap) { in_block = false; done = true; }          // the caller wants no more than this
             }
         }
         if (bfinal) done = true;
@@ -555,13 +579,22 @@ int inflate_launch(const gamut_hip_inflate_desc* descs, int count, uint32_t* out
     }
     static const bool attr_set = hipFuncSetAttribute((const void*)k_inflate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Shared)) == hipSuccess;
     if (!attr_set) return set_error(GAMUT_HIP_ERR_HIP, "inflate: %zu bytes of LDS are not available", sizeof(Shared));
-    void* d_items = nullptr;                                   // stream-ordered: lives until the kernel has run
-    GAMUT_HIP_CHECK(hipMallocAsync(&d_items, items.size() * sizeof(InfItem), stream));
-    GAMUT_HIP_CHECK(hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(InfItem), hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(k_inflate, dim3((unsigned)count), dim3(kT), sizeof(Shared), stream, (const InfItem*)d_items, count, out_len_dev, status_dev);
-    const int rc = launch_status("inflate");
-    GAMUT_HIP_CHECK(hipFreeAsync(d_items, stream));
-    return rc;
+    // the descriptor table in HBM: one buffer per (thread, stream) -- calls on one stream are ordered, calls on different
+    // streams never share it; growing it waits for its own stream only
+    struct StreamTable { hipStream_t stream; void* p; size_t cap; };
+    static thread_local std::vector<StreamTable> tables;
+    StreamTable* e = nullptr;
+    for (StreamTable& c : tables) if (c.stream == stream) { e = &c; break; }
+    if (!e) { tables.push_back(StreamTable{ stream, nullptr, 0 }); e = &tables.back(); }
+    const size_t bytes = items.size() * sizeof(InfItem);
+    if (bytes > e->cap) {
+        if (e->p) { (void)hipStreamSynchronize(stream); (void)hipFree(e->p); e->p = nullptr; e->cap = 0; }
+        if (hipMalloc(&e->p, bytes * 2 + 4096) != hipSuccess) { (void)hipGetLastError(); e->p = nullptr; return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "inflate: descriptor table allocation failed"); }
+        e->cap = bytes * 2 + 4096;
+    }
+    GAMUT_HIP_CHECK(hipMemcpyAsync(e->p, items.data(), bytes, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_inflate, dim3((unsigned)count), dim3(kT), sizeof(Shared), stream, (const InfItem*)e->p, count, out_len_dev, status_dev);
+    return launch_status("inflate");
 }
 
 } // namespace gamut

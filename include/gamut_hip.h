@@ -243,10 +243,13 @@ int gamut_hip_stbi_png_is16_from_callbacks(const gamut_hip_stbi_io_callbacks* cl
  * replaces, for batches, stbi_zlib_decode_malloc_guesssize_headerflag (stbdec.d:1267-1321 -> miniz).  Stream i is the raw
  * DEFLATE data src[0 .. src_len) in HBM (a zlib stream without its 2-byte header, which the host checks as stbdec.d does;
  * the adler32 trailer is not read, as with the reference's trusted_input); its bytes go to dst[0 .. dst_cap) in HBM -- output
- * beyond dst_cap is dropped and the stream counts as done (the de-filter needs (bytes per line + 1) * height, no more).
+ * beyond dst_cap is dropped (the de-filter needs (bytes per line + 1) * height, no more), but the stream is still decoded to its
+ * end: damage anywhere makes it a corrupt stream, as for the reference, which inflates all of it.
  * out_len_dev[i] = bytes written, status_dev[i] = 0 or the reason the stream is corrupt (GAMUT_HIP_INFLATE_E_*); both are
  * device arrays, the call is asynchronous on `stream`.  One 256-thread workgroup per stream, speculative parallel Huffman
- * decode + parallel match resolution (gamut_amd/csrc/inflate.hip).  descs is a host array. */
+ * decode + parallel match resolution (gamut_amd/csrc/inflate.hip).  descs is a host array.  One deviation from zlib, as a
+ * bound on the work a hostile stream can demand: a stream with more than 4096 + src_len / 8 blocks (no encoder comes near:
+ * that is a block per 8 compressed bytes) is reported as GAMUT_HIP_INFLATE_E_INPUT. */
 typedef struct gamut_hip_inflate_desc { const uint8_t* src; uint8_t* dst; uint32_t src_len, dst_cap; } gamut_hip_inflate_desc;
 enum { GAMUT_HIP_INFLATE_E_BLOCK_TYPE = 1, GAMUT_HIP_INFLATE_E_STORED = 2, GAMUT_HIP_INFLATE_E_LENGTHS = 3, GAMUT_HIP_INFLATE_E_CODE = 4,
        GAMUT_HIP_INFLATE_E_DISTANCE = 5, GAMUT_HIP_INFLATE_E_INPUT = 6 };

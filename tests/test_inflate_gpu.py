@@ -90,8 +90,16 @@ def test_inflate_capacity_clamps_and_large_stream(hip):
     rng = np.random.default_rng(5)
     big = (rng.integers(0, 16, 6_000_000, dtype=np.uint8) * 3 + (np.arange(6_000_000) // 4093 % 100).astype(np.uint8)).tobytes()
     s = _deflate(big, 6)
-    rc, outs, st = _inflate_device(hip, [s, s, s], [len(big), len(big) // 3 + 1, 0])
-    assert rc == 0 and st == [0, 0, 0]
+    # damage far beyond what a small capacity needs: still a corrupt stream (an invalid block type at the start of the last block
+    # would be the surest damage; a flipped bit usually is one too -- zlib decides)
+    damaged = bytearray(s); damaged[len(s) - 1000] ^= 0x40
+    try:
+        d = zlib.decompressobj(-15); d.decompress(bytes(damaged)); zlib_takes_it = d.eof
+    except zlib.error:
+        zlib_takes_it = False
+    rc, outs, st = _inflate_device(hip, [s, s, s, bytes(damaged), s[:len(s) - 100]], [len(big), len(big) // 3 + 1, 0, 1000, 1000])
+    assert rc == 0 and [int(v) for v in st[:3]] == [0, 0, 0], st
+    assert (st[3] == 0) == zlib_takes_it and st[4] != 0, st
     assert outs[0] == big and outs[1] == big[:len(big) // 3 + 1] and outs[2] == b""
 
 
@@ -117,5 +125,24 @@ def test_inflate_rejects_what_zlib_rejects(hip):
             ok = False
         if ok:
             assert st[i] == 0 and outs[i] == exp[:len(data) + 64], f"case {i}: zlib accepts, device status {st[i]}"
-        elif len(outs[i]) < len(data) + 64:                               # (a stream that fills its capacity is done before its damage is reached)
+        else:
             assert st[i] != 0, f"case {i}: zlib rejects (or wants more input), the device accepted"
+
+
+def test_inflate_many_small_blocks_and_the_block_budget(hip):
+    """streams of many tiny blocks: every flavour of flush after every few bytes (accepted: far below the budget of a block per 8
+    compressed bytes), a stream of 20 000 empty fixed-Huffman blocks (10 bits each: over the budget, turned away -- the bound on
+    what a hostile stream can cost), and the same with an image's worth of data in front (still over)."""
+    rng = np.random.default_rng(3)
+    data = (rng.integers(0, 8, 30000, dtype=np.uint8) * 9).tobytes()
+    flushed = _deflate(data, 6, flush_every=23)                      # ~1300 sync / full flushes: empty stored blocks
+    fixed = _deflate(data, 6, zlib.Z_FIXED, flush_every=400)
+    # 20 000 empty fixed blocks: BFINAL = 0, BTYPE = 01, end-of-block code 0000000 -> the bit string 0 10 0000000 repeated
+    bits = np.tile(np.array([0, 1, 0, 0, 0, 0, 0, 0, 0, 0], np.uint8), 20000)
+    last = np.array([1, 1, 0, 0, 0, 0, 0, 0, 0, 0], np.uint8)         # BFINAL = 1
+    empty = np.packbits(np.concatenate([bits, last]), bitorder="little").tobytes()
+    assert zlib.decompressobj(-15).decompress(empty) == b""
+    rc, outs, st = _inflate_device(hip, [flushed, fixed, empty, empty[:-2]], [len(data) + 8, len(data) + 8, 64, 64])
+    assert rc == 0
+    assert st[0] == 0 and outs[0] == data and st[1] == 0 and outs[1] == data
+    assert st[2] == 6 and st[3] == 6                                  # GAMUT_HIP_INFLATE_E_INPUT: over the block budget / cut short

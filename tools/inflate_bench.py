@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--streams", type=int, default=256)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--reps", type=int, default=3)
     a = ap.parse_args()
     L = _capi.lib(); _capi.check(L.gamut_hip_init(0))
     prof = getattr(C.CDLL(_capi.LIB_PATH), "gamut_hip_inflate_profile", None)
@@ -63,13 +64,24 @@ def main():
             descs[i].src = dcomp; descs[i].dst = dout + i * (cap + 256); descs[i].src_len = comp.size; descs[i].dst_cap = cap
         _capi.check(L.gamut_hip_stream_synchronize(None))
         best = 1e9
-        for rep in range(3):
+        times = []
+        for rep in range(a.reps):
             if prof:
                 buf = (C.c_ulonglong * len(PHASES))(); prof(buf, 1)
+            poison = np.full(2 * N, 0xFFFFFFFF, np.uint32)                 # every repetition must write its own lengths and verdicts
+            _capi.check(L.gamut_hip_memcpy_h2d(dlen, poison.ctypes.data, 8 * N, None))
+            _capi.check(L.gamut_hip_stream_synchronize(None))
             t0 = time.perf_counter()
             _capi.check(L.gamut_hip_inflate_batch_device(descs, N, dlen, dst, None))
             _capi.check(L.gamut_hip_stream_synchronize(None))
-            best = min(best, time.perf_counter() - t0)
+            times.append(time.perf_counter() - t0)
+            chk = np.zeros(2 * N, np.uint32)
+            _capi.check(L.gamut_hip_memcpy_d2h(chk.ctypes.data, dlen, 8 * N, None))
+            _capi.check(L.gamut_hip_stream_synchronize(None))
+            if not ((chk[N:] == 0).all() and (chk[:N] == cap).all()):
+                print(f"  repetition {rep}: {int((chk[:N] != cap).sum())} streams without their length, {int((chk[N:] != 0).sum())} without a verdict of 0 (first words {chk[:2]}, {chk[N:N + 2]}) in {times[-1] * 1e3:.2f} ms")
+        best = min(times)
+        print("  repetitions: " + ", ".join(f"{x * 1e3:.1f} ms" for x in times[:8]))
         st = np.zeros(2 * N, np.uint32)
         _capi.check(L.gamut_hip_memcpy_d2h(st.ctypes.data, dlen, 8 * N, None))
         got = np.empty(cap, np.uint8)

@@ -1,11 +1,9 @@
 // qoi.hip -- QOI decode (needed for the mixed JPEG/PNG/QOI batch of BASELINE.json config 5).
 //
-// Replaces qoi_decode (source/gamut/codecs/qoi.d:448-550).  The format is a byte-serial state machine (previous pixel,
-// 64-entry colour hash, run counter): nothing to parallelise inside a stream, so the parallelism is the batch -- one
-// lane per image.  The lane's hash table lives in LDS (lane-interleaved, so the 64 lanes of a wave hit 64 different
-// banks x 2), the stream is read byte-wise through L1, pixels are written as they come.  The host only validates the
-// 14-byte header (same checks as :472-480) and uploads the streams as they are.
+// Replaces qoi_decode (source/gamut/codecs/qoi.d:448-550): one workgroup per stream, see k_qoi_decode.  The host only
+// validates the 14-byte header (same checks as :472-480) and uploads the streams as they are.
 #include "common.hpp"
+#include <type_traits>
 #include <vector>
 
 namespace gamut {
@@ -16,25 +14,30 @@ constexpr int kQoiHeader = 14, kQoiPadding = 8;                                /
 
 struct QoiItem { uint64_t begin; int64_t out_off; uint32_t size, npx; int32_t channels, pad; };
 
-// One WAVE per stream.  The format is a byte-serial state machine (previous pixel, 64-entry colour hash, run counter), but
-// only one link of the chain is really serial -- a QOI_OP_INDEX needs the hash table as all earlier pixels left it.  The rest
-// is parallel over the 64 lanes:
-//   A. op boundaries of a 2 KiB window: an op's length follows from its first byte alone, so each lane walks its own 32 bytes
-//      for every possible entry offset 0..4 (an op of the previous lane spills at most 4 bytes) with plain bit operations,
-//      and the entry offsets are chained through the wave afterwards; the op starts are compacted into a list in LDS;
-//   B. 64 ops at a time, one per lane: an op is a bytewise function x -> (x & ~M) + V of the previous pixel (DIFF / LUMA /
-//      RUN: M = 0, V = deltas; RGB / RGBA: M = the bytes set, V = their values); such functions compose, so an inclusive scan
-//      over the lanes (DPP row shifts / broadcasts, no LDS) gives every op's pixel relative to the pixel before the group.
-//      An INDEX op is "all bytes set to an unknown U"; the scan carries which bytes still hang on the most recent INDEX;
-//   C. the INDEX ops of the group are resolved one after the other (wave-uniform loop): the slot's value is the newest earlier
-//      pixel of the group with that hash (ballot + readlane), else the table as it stood before the group (a register per
-//      slot, lane s = slot s); the lanes up to the next INDEX op then get their pixels and hashes;
+// One WORKGROUP of four waves per stream.  The format is a byte-serial state machine (previous pixel, 64-entry colour hash, run
+// counter), but only one link of the chain is really serial -- a QOI_OP_INDEX needs the hash table as all earlier pixels left
+// it.  The rest is parallel over the 256 lanes, 2 KiB of the stream at a time:
+//   A. op boundaries: an op's length follows from its first byte alone, so each lane walks its own 8 bytes for every possible
+//      entry offset 0..4 (an op of the previous lane spills at most 4 bytes) with plain bit operations; the five exit offsets
+//      are a map {0..4} -> {0..4} packed in 15 bits, maps compose, and a scan over the lanes (DPP inside a wave, LDS across the
+//      four) gives every lane its true entry offset; the op starts are compacted into a list in LDS;
+//   B. 64 ops at a time, one per lane, the groups dealt to the four waves: an op is a bytewise function x -> (x & ~M) + V of
+//      the previous pixel (DIFF / LUMA / RUN: M = 0, V = deltas; RGB / RGBA: M = the bytes set, V = their values); such
+//      functions compose, so an inclusive scan over the lanes (DPP row shifts / broadcasts, no LDS) gives every op's pixel
+//      relative to the pixel before the group.  An INDEX op is "all bytes set to an unknown U"; the scan carries which bytes
+//      still hang on the most recent INDEX.  Run lengths are prefix-summed in the same steps.  Results go to LDS;
+//   C. wave 0 then walks the groups in order -- the only serial part: pixels before the first INDEX op of a group at once, the
+//      INDEX ops one after the other (wave-uniform loop): the slot's value is the newest earlier pixel of the group with that
+//      hash (ballot + readlane), else the table as it stood before the group (a register per slot, lane s = slot s); the lanes
+//      up to the next INDEX op then get their pixels and hashes;
 //   D. the table takes the group's pixels with one LDS ds_max_u64 per lane on (op number << 32 | pixel): the newest writer of
-//      a slot wins without a second pass; run lengths are prefix-summed, pixels go to an LDS buffer and leave in 1 KiB rows.
-// A 1080p photographic stream takes ~25 ms like this (the lane-per-stream decoder of round 1: 540 ms), and a batch runs one
-// stream per SIMD.
-constexpr int kQoiWin = 2048, kQoiLaneBytes = 32, kQoiOutCap = 256 + 64 * 62 + 64;   // window bytes; pixels the buffer must hold
+//      a slot wins without a second pass; pixels go to an LDS buffer by run length and leave in 1 KiB rows.
+// W = 4 waves per stream halves a stream's time (18.6 instead of 31.6 ms per 1080p stream) but costs more instructions in all
+// (every wave scans, one resolves): batches of more streams than the chip has SIMDs to spare run W = 1, one wave per stream.
+constexpr int kQoiWin = 2048, kQoiOutCap = 256 + 64 * 62 + 64;                       // window bytes; pixels the output buffer must hold
+constexpr int kQoiWideBelow = 768;                                                  // streams per launch below which W = 4
 constexpr int kQoiSlack = GAMUT_HIP_QOI_SLACK;                                      // readable bytes guaranteed after every stream
+constexpr uint32_t kQoiMapId = 0u | 1u << 3 | 2u << 6 | 3u << 9 | 4u << 12;         // the identity of the exit-offset maps
 
 __device__ __forceinline__ uint32_t qoi_add_bytes(uint32_t x, uint32_t y)       // bytewise (x + y) mod 256
 {
@@ -42,13 +45,32 @@ __device__ __forceinline__ uint32_t qoi_add_bytes(uint32_t x, uint32_t y)       
 }
 __device__ __forceinline__ uint32_t qoi_hash(uint32_t px) { return __builtin_amdgcn_udot4(px, 0x0B070503u, 0u, false) & 63u; }   // QOI_COLOR_HASH :239-242
 
-// value of the lane CTRL names (row_shr:n = 0x110 + n, row_bcast:15 = 0x142, row_bcast:31 = 0x143); lanes without a source,
-// or in rows outside ROWMASK, get `idle`
+// value of the lane CTRL names (row_shr:n = 0x110 + n, row_bcast:15 = 0x142, row_bcast:31 = 0x143, wave_shr:1 = 0x138); lanes
+// without a source, or in rows outside ROWMASK, get `idle`
 template <int CTRL, int ROWMASK> __device__ __forceinline__ uint32_t qoi_dpp(uint32_t v, uint32_t idle = 0)
 {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)idle, (int)v, CTRL, ROWMASK, 0xF, false);
 }
 __device__ __forceinline__ uint32_t qoi_readlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+// LDS hand-offs inside one wave: its LDS operations execute in program order, this only stops the compiler from moving them
+__device__ __forceinline__ void qoi_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// exit-offset maps: entry offset e (0..4) of a stretch of bytes -> entry offset of the stretch after it, 3 bits each
+__device__ __forceinline__ uint32_t qoi_map_apply(uint32_t m, uint32_t e) { return (m >> (3u * e)) & 7u; }
+__device__ __forceinline__ uint32_t qoi_map_then(uint32_t a, uint32_t b)          // a first, then b
+{
+    uint32_t r = 0;
+    #pragma unroll
+    for (int k = 0; k < 5; ++k) r |= qoi_map_apply(b, qoi_map_apply(a, (uint32_t)k)) << (3 * k);
+    return r;
+}
+template <int CTRL, int ROWMASK> __device__ __forceinline__ void qoi_map_scan_step(uint32_t& m) { m = qoi_map_then(qoi_dpp<CTRL, ROWMASK>(m, kQoiMapId), m); }
+template <int CTRL, int ROWMASK> __device__ __forceinline__ void qoi_add_scan_step(uint32_t& n) { n += qoi_dpp<CTRL, ROWMASK>(n); }
 
 struct QoiFn { uint32_t M, V, U; };       // x -> ((x & ~M) | (index value & U)) + V bytewise; U is a subset of M
 __device__ __forceinline__ QoiFn qoi_then(QoiFn a, QoiFn b)                       // a first, then b
@@ -62,19 +84,25 @@ template <int CTRL, int ROWMASK> __device__ __forceinline__ void qoi_scan_step(Q
     n += qoi_dpp<CTRL, ROWMASK>(n);
 }
 
-__global__ __launch_bounds__(64) void k_qoi_decode(const QoiItem* items, int n_items, const uint8_t* blob, uint8_t* out)
+template <int kQoiWaves>
+__global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* items, int n_items, const uint8_t* blob, uint8_t* out)
 {
+    constexpr int kQoiT = kQoiWaves * 64, kQoiLaneBytes = kQoiWin / kQoiT;           // 8 bytes of the window per lane (W = 4), or 32
+    typedef typename std::conditional<(kQoiLaneBytes > 16), uint64_t, uint32_t>::type Starts;   // bit i: an op starts at byte i (bits up to lane bytes + 4)
     __shared__ uint32_t win[kQoiWin / 4 + 4];                 // the window + 8 bytes of the next one (an op reads up to 4 bytes past its start)
     __shared__ uint16_t ops[kQoiWin];                         // op starts of the window, in order
+    __shared__ uint4 prep[kQoiWaves > 1 ? kQoiWin : 1];       // W = 4, per op: M, V, U, run-length prefix | own run length << 12 | first byte << 18
     __shared__ unsigned long long table[64];                  // op number << 32 | pixel   (qoi_rgba_t[64] index, :453)
     __shared__ __attribute__((aligned(16))) uint32_t obuf[kQoiOutCap];
+    __shared__ uint32_t wave_map[kQoiWaves], wave_cnt[kQoiWaves], go_on;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     struct __attribute__((packed, aligned(1))) AnyVec { u32x4 v; };               // 16 bytes at any address
     struct __attribute__((packed, aligned(1))) AnyU32 { uint32_t v; };
     struct __attribute__((packed, aligned(1))) AnyU64 { uint64_t v; };
     struct __attribute__((packed, aligned(1))) Any12 { uint32_t a, b, c; };
 
-    const int lane = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     if ((int)blockIdx.x >= n_items) return;
     const QoiItem it = items[blockIdx.x];
     const bool rgba = it.channels == 4;
@@ -85,22 +113,22 @@ __global__ __launch_bounds__(64) void k_qoi_decode(const QoiItem* items, int n_i
     const int avail = (int)it.size - kQoiHeader + kQoiSlack;  // bytes that may be read from `stream`
     const uint32_t npx_total = it.npx;
 
-    table[lane] = 0;                                          // memset(index, 0) :491
-    uint32_t carry = 0xFF000000u;                             // r = g = b = 0, a = 255 :492-495
+    if (t < 64) table[t] = 0;                                 // memset(index, 0) :491
+    if (t == 0) go_on = 1;
+    uint32_t carry = 0xFF000000u;                             // r = g = b = 0, a = 255 :492-495                (wave 0's state from here ...)
     uint32_t produced = 0, ops_done = 0;                      // pixels decoded, ops decoded
-    uint32_t fill = 0; size_t flushed = 0;                    // pixels waiting in obuf, pixels already in the image
-    uint32_t entry = 0;                                       // offset of the first op start in the next window
+    uint32_t fill = 0; size_t flushed = 0;                    // pixels waiting in obuf, pixels already in the image  (... to here)
+    uint32_t entry = 0;                                       // offset of the first op start in the next window (every thread keeps it)
 
-    auto fetch = [&](int pos, u32x4& a, u32x4& b, uint64_t& tail) {               // this lane's 32 bytes of the window at `pos` (+ 8 more for lane 0)
-        const int at = pos + lane * kQoiLaneBytes;
-        a = u32x4{0, 0, 0, 0}; b = a; tail = 0;
-        if (at + kQoiLaneBytes <= avail) {
-            const AnyVec* src = reinterpret_cast<const AnyVec*>(stream + at);
-            a = src[0].v; b = src[1].v;
-        }
-        if (lane == 0 && pos + kQoiWin + 8 <= avail) tail = reinterpret_cast<const AnyU64*>(stream + pos + kQoiWin)->v;
+    struct Mine { uint64_t q[kQoiLaneBytes / 8]; };
+    auto fetch = [&](int pos, Mine& mine, uint64_t& tail) {                       // this lane's bytes of the window at `pos` (+ 8 more for thread 0)
+        const int at = pos + t * kQoiLaneBytes;
+        tail = 0;
+        #pragma unroll
+        for (int k = 0; k < kQoiLaneBytes / 8; ++k) mine.q[k] = at + kQoiLaneBytes <= avail ? reinterpret_cast<const AnyU64*>(stream + at)[k].v : 0ull;
+        if (t == 0 && pos + kQoiWin + 8 <= avail) tail = reinterpret_cast<const AnyU64*>(stream + pos + kQoiWin)->v;
     };
-    auto flush_rows = [&]() {                                 // whole rows of 256 pixels leave; the rest moves to the front
+    auto flush_rows = [&]() {                                 // (wave 0) whole rows of 256 pixels leave; the rest moves to the front
         const uint32_t n = fill & ~255u;
         for (uint32_t i = 0; i < n; i += 256) {
             const u32x4 v = *reinterpret_cast<const u32x4*>(&obuf[i + lane * 4]);
@@ -108,16 +136,16 @@ __global__ __launch_bounds__(64) void k_qoi_decode(const QoiItem* items, int n_i
             if (rgba) reinterpret_cast<AnyVec*>(pixels + px * 4)->v = v;
             else {
                 const uint32_t p0 = v.x & 0xFFFFFFu, p1 = v.y & 0xFFFFFFu, p2 = v.z & 0xFFFFFFu, p3 = v.w & 0xFFFFFFu;
-                Any12 t; t.a = p0 | p1 << 24; t.b = p1 >> 8 | p2 << 16; t.c = p2 >> 16 | p3 << 8;
-                *reinterpret_cast<Any12*>(pixels + px * 3) = t;
+                Any12 w; w.a = p0 | p1 << 24; w.b = p1 >> 8 | p2 << 16; w.c = p2 >> 16 | p3 << 8;
+                *reinterpret_cast<Any12*>(pixels + px * 3) = w;
             }
         }
         const uint32_t rest = fill - n;
         u32x4 keep = {0, 0, 0, 0};
         if ((uint32_t)lane * 4 < rest) keep = *reinterpret_cast<const u32x4*>(&obuf[n + lane * 4]);
-        __syncthreads();
+        qoi_wave_sync();
         if ((uint32_t)lane * 4 < rest) *reinterpret_cast<u32x4*>(&obuf[lane * 4]) = keep;
-        __syncthreads();
+        qoi_wave_sync();
         flushed += n; fill = rest;
     };
     auto store_px = [&](size_t px, uint32_t v) {
@@ -125,93 +153,103 @@ __global__ __launch_bounds__(64) void k_qoi_decode(const QoiItem* items, int n_i
         else { uint8_t* o = pixels + px * 3; o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)(v >> 16); }
     };
 
-    u32x4 d0, d1; uint64_t dtail;
-    fetch(0, d0, d1, dtail);
+    Mine dmine; uint64_t dtail;
+    fetch(0, dmine, dtail);
     __syncthreads();
-    for (int pos = 0; pos < chunk_bytes && produced < npx_total; pos += kQoiWin) {
+    for (int pos = 0; pos < chunk_bytes && go_on; pos += kQoiWin) {
         // ---- the window into LDS; the next one into registers
-        *reinterpret_cast<u32x4*>(&win[lane * 8]) = d0;
-        *reinterpret_cast<u32x4*>(&win[lane * 8 + 4]) = d1;
-        if (lane == 0) { win[kQoiWin / 4] = (uint32_t)dtail; win[kQoiWin / 4 + 1] = (uint32_t)(dtail >> 32); }
-        const uint32_t d[8] = { d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w };
-        // ---- A. op starts among this lane's 32 bytes, for entry offsets 0..4 (bit i of s[e]: an op starts at byte i)
-        uint64_t s[5] = { 1, 2, 4, 8, 16 };
+        #pragma unroll
+        for (int k = 0; k < kQoiLaneBytes / 8; ++k) { win[t * (kQoiLaneBytes / 4) + 2 * k] = (uint32_t)dmine.q[k]; win[t * (kQoiLaneBytes / 4) + 2 * k + 1] = (uint32_t)(dmine.q[k] >> 32); }
+        if (t == 0) { win[kQoiWin / 4] = (uint32_t)dtail; win[kQoiWin / 4 + 1] = (uint32_t)(dtail >> 32); }
+        // ---- A. op starts among this lane's 8 bytes, for entry offsets 0..4 (bit i of s[e]: an op starts at byte i)
+        Starts s[5] = { 1, 2, 4, 8, 16 };
         #pragma unroll
         for (int i = 0; i < kQoiLaneBytes; ++i) {
-            const uint32_t b = (d[i >> 2] >> (8 * (i & 3))) & 255u;
+            const uint32_t b = (uint32_t)(dmine.q[i >> 3] >> (8 * (i & 7))) & 255u;
             const uint32_t len = b >= 0xFEu ? b - 0xFAu : ((b >> 6) == 2u ? 2u : 1u);          // RGB 4, RGBA 5, LUMA 2, the others 1
             #pragma unroll
-            for (int e = 0; e < 5; ++e) s[e] |= (s[e] & (1ull << i)) << len;
+            for (int e = 0; e < 5; ++e) s[e] |= (s[e] & ((Starts)1 << i)) << len;
         }
-        uint32_t exits = 0;                                   // entry offset e -> offset of the first op start in the next lane's bytes
+        uint32_t map = 0;                                     // entry offset e -> offset of the first op start in the next lane's bytes
         #pragma unroll
-        for (int e = 0; e < 5; ++e) exits |= (uint32_t)__builtin_ctz((uint32_t)(s[e] >> kQoiLaneBytes)) << (3 * e);
-        fetch(pos + kQoiWin, d0, d1, dtail);
-        uint32_t my_entry = 0;
-        #pragma unroll 8
-        for (int k = 0; k < 64; ++k) {
-            const uint32_t f = qoi_readlane(exits, k);
-            my_entry = lane == k ? entry : my_entry;
-            entry = (f >> (3 * entry)) & 7u;
+        for (int e = 0; e < 5; ++e) map |= (uint32_t)__builtin_ctz((uint32_t)(s[e] >> kQoiLaneBytes)) << (3 * e);
+        fetch(pos + kQoiWin, dmine, dtail);
+        qoi_map_scan_step<0x111, 0xF>(map); qoi_map_scan_step<0x112, 0xF>(map); qoi_map_scan_step<0x114, 0xF>(map); qoi_map_scan_step<0x118, 0xF>(map);
+        qoi_map_scan_step<0x142, 0xA>(map); qoi_map_scan_step<0x143, 0xC>(map);                 // lanes 0 .. this one, composed
+        if (lane == 63) wave_map[wave] = map;
+        __syncthreads();
+        uint32_t wave_entry = entry;
+        #pragma unroll
+        for (int w = 0; w < kQoiWaves; ++w) {
+            const uint32_t after = qoi_map_apply(wave_map[w], entry);
+            if (w < wave) wave_entry = after;
+            entry = after;                                    // (after the loop: the next window's entry offset)
         }
+        const uint32_t my_entry = qoi_map_apply(qoi_dpp<0x138, 0xF>(map, kQoiMapId), wave_entry);
         uint32_t starts = (uint32_t)(my_entry == 0 ? s[0] : my_entry == 1 ? s[1] : my_entry == 2 ? s[2] : my_entry == 3 ? s[3] : s[4]);
         {
-            const int room = chunk_bytes - (pos + lane * kQoiLaneBytes);             // op starts only below chunks_len
-            starts &= room >= 32 ? ~0u : room <= 0 ? 0u : (1u << room) - 1u;
+            const int room = chunk_bytes - (pos + t * kQoiLaneBytes);                // op starts only in this lane's bytes and below chunks_len
+            const int n = room < kQoiLaneBytes ? room : kQoiLaneBytes;
+            starts &= n >= 32 ? ~0u : n <= 0 ? 0u : (1u << n) - 1u;
         }
         // ---- compact the op starts into ops[]
-        uint32_t before = (uint32_t)__builtin_popcount(starts);
-        {
-            uint32_t incl = before;
-            incl += qoi_dpp<0x111, 0xF>(incl); incl += qoi_dpp<0x112, 0xF>(incl); incl += qoi_dpp<0x114, 0xF>(incl); incl += qoi_dpp<0x118, 0xF>(incl);
-            incl += qoi_dpp<0x142, 0xA>(incl); incl += qoi_dpp<0x143, 0xC>(incl);
-            before = incl - before;
-        }
-        const uint32_t nops = qoi_readlane(before + (uint32_t)__builtin_popcount(starts), 63);
-        {
-            uint32_t m = starts, at = before;
-            while (__any(m != 0)) {
-                if (m) { ops[at++] = (uint16_t)(lane * kQoiLaneBytes + __builtin_ctz(m)); m &= m - 1; }
-            }
-        }
+        const uint32_t mine_n = (uint32_t)__builtin_popcount(starts);
+        uint32_t incl = mine_n;
+        qoi_add_scan_step<0x111, 0xF>(incl); qoi_add_scan_step<0x112, 0xF>(incl); qoi_add_scan_step<0x114, 0xF>(incl); qoi_add_scan_step<0x118, 0xF>(incl);
+        qoi_add_scan_step<0x142, 0xA>(incl); qoi_add_scan_step<0x143, 0xC>(incl);
+        if (lane == 63) wave_cnt[wave] = incl;
         __syncthreads();
-        // ---- B..D. 64 ops at a time
-        for (uint32_t g = 0; g < nops && produced < npx_total; g += 64) {
-            const uint32_t cnt = nops - g < 64u ? nops - g : 64u;
-            const bool active = (uint32_t)lane < cnt;
-            const uint32_t tab = (uint32_t)table[lane];
+        uint32_t at = incl - mine_n, nops = 0;
+        #pragma unroll
+        for (int w = 0; w < kQoiWaves; ++w) { const uint32_t c = wave_cnt[w]; if (w < wave) at += c; nops += c; }
+        for (uint32_t m = starts; m; m &= m - 1) ops[at++] = (uint16_t)(t * kQoiLaneBytes + __builtin_ctz(m));
+        __syncthreads();
+        // ---- B. the ops as functions of the previous pixel, 64 at a time (W = 4: groups dealt to the waves, results in LDS)
+        struct Group { QoiFn f; uint32_t run_incl, npx, b1; bool is_index; };
+        auto parse_group = [&](uint32_t g) -> Group {
+            const bool active = g + lane < nops;
             uint32_t lo = 0, hi = 0;
             if (active) {
-                const uint32_t at = ops[g + lane];
-                const uint32_t w0 = win[at >> 2], w1 = win[(at >> 2) + 1], w2 = win[(at >> 2) + 2];
-                const uint32_t sh = 8 * (at & 3);
+                const uint32_t o = ops[g + lane];
+                const uint32_t w0 = win[o >> 2], w1 = win[(o >> 2) + 1], w2 = win[(o >> 2) + 2];
+                const uint32_t sh = 8 * (o & 3);
                 lo = __builtin_amdgcn_alignbit(w1, w0, sh); hi = __builtin_amdgcn_alignbit(w2, w1, sh);
             }
-            // the op as a function of the previous pixel
             const uint32_t b1 = lo & 255u, top = b1 >> 6, b2 = (lo >> 8) & 255u;
             const bool is_rgb = b1 == 0xFEu, is_rgba = b1 == 0xFFu;
-            const bool is_index = active && top == 0u, is_run = top == 3u && !is_rgb && !is_rgba;
+            const bool is_run = top == 3u && !is_rgb && !is_rgba;
             const uint32_t vg = (b1 & 63u) - 32u;
             const uint32_t v_diff = ((((b1 >> 4) & 3u) - 2u) & 255u) | ((((b1 >> 2) & 3u) - 2u) & 255u) << 8 | (((b1 & 3u) - 2u) & 255u) << 16;
             const uint32_t v_luma = ((vg - 8u + (b2 >> 4)) & 255u) | (vg & 255u) << 8 | ((vg - 8u + (b2 & 15u)) & 255u) << 16;
             const uint32_t v_abs = __builtin_amdgcn_alignbit(hi, lo, 8);                          // stream bytes 1..4
-            QoiFn f;
-            f.M = !active ? 0u : is_rgb ? 0x00FFFFFFu : (is_rgba || top == 0u) ? 0xFFFFFFFFu : 0u;
-            f.U = is_index ? 0xFFFFFFFFu : 0u;
-            f.V = !active ? 0u : is_rgb ? (v_abs & 0x00FFFFFFu) : is_rgba ? v_abs : top == 1u ? v_diff : top == 2u ? v_luma : 0u;
-            uint32_t npx = !active ? 0u : is_run ? 1u + (b1 & 63u) : 1u;
-            uint32_t incl = npx;
-            qoi_scan_step<0x111, 0xF>(f, incl); qoi_scan_step<0x112, 0xF>(f, incl); qoi_scan_step<0x114, 0xF>(f, incl); qoi_scan_step<0x118, 0xF>(f, incl);
-            qoi_scan_step<0x142, 0xA>(f, incl); qoi_scan_step<0x143, 0xC>(f, incl);
-            // ---- C. pixels: lanes before the first INDEX op at once, then INDEX op by INDEX op
+            Group G;
+            G.is_index = active && top == 0u;
+            G.b1 = b1;
+            G.f.M = !active ? 0u : is_rgb ? 0x00FFFFFFu : (is_rgba || top == 0u) ? 0xFFFFFFFFu : 0u;
+            G.f.U = G.is_index ? 0xFFFFFFFFu : 0u;
+            G.f.V = !active ? 0u : is_rgb ? (v_abs & 0x00FFFFFFu) : is_rgba ? v_abs : top == 1u ? v_diff : top == 2u ? v_luma : 0u;
+            G.npx = !active ? 0u : is_run ? 1u + (b1 & 63u) : 1u;
+            G.run_incl = G.npx;
+            qoi_scan_step<0x111, 0xF>(G.f, G.run_incl); qoi_scan_step<0x112, 0xF>(G.f, G.run_incl); qoi_scan_step<0x114, 0xF>(G.f, G.run_incl);
+            qoi_scan_step<0x118, 0xF>(G.f, G.run_incl); qoi_scan_step<0x142, 0xA>(G.f, G.run_incl); qoi_scan_step<0x143, 0xC>(G.f, G.run_incl);
+            return G;
+        };
+        // ---- C, D. pixels, table, output of one group (in stream order: wave 0)
+        auto finish_group = [&](uint32_t g, Group G) {
+            const uint32_t cnt = nops - g < 64u ? nops - g : 64u;
+            const bool active = (uint32_t)lane < cnt;
+            const uint32_t tab = (uint32_t)table[lane];
+            const QoiFn f = G.f;
+            uint32_t npx = G.npx;
+            // pixels: lanes before the first INDEX op at once, then INDEX op by INDEX op
             uint32_t x = qoi_add_bytes(carry & ~f.M, f.V);
             uint32_t h = qoi_hash(x);
-            uint64_t todo = __ballot(is_index);
+            uint64_t todo = __ballot(G.is_index);
             while (todo) {
                 const int j = __builtin_ctzll(todo);
                 todo &= todo - 1;
                 const int jn = todo ? __builtin_ctzll(todo) : 64;
-                const uint32_t slot = qoi_readlane(b1, j) & 63u;
+                const uint32_t slot = qoi_readlane(G.b1, j) & 63u;
                 const uint64_t m = __ballot(h == slot) & ((1ull << j) - 1ull);
                 const uint32_t base = m ? qoi_readlane(x, 63 - __builtin_clzll(m)) : qoi_readlane(tab, (int)slot);
                 const uint32_t nx = qoi_add_bytes(base & f.U, f.V);           // from an INDEX op on, every byte is set (M = all)
@@ -219,10 +257,10 @@ __global__ __launch_bounds__(64) void k_qoi_decode(const QoiItem* items, int n_i
                 x = in ? nx : x;
                 h = in ? qoi_hash(nx) : h;
             }
-            // ---- D. table, run lengths, output
+            // table, run lengths, output
             if (active) atomicMax(&table[h], (unsigned long long)(ops_done + 1u + (uint32_t)lane) << 32 | x);
-            uint32_t off = incl - npx, total = qoi_readlane(incl, 63);
-            const uint32_t room = npx_total - produced;
+            uint32_t total = qoi_readlane(G.run_incl, (int)cnt - 1);
+            const uint32_t off = G.run_incl - npx, room = npx_total - produced;
             if (total > room) { npx = off >= room ? 0u : (npx < room - off ? npx : room - off); total = room; }
             if (npx) obuf[fill + off] = x;
             if (__any(npx > 1u)) {
@@ -230,13 +268,36 @@ __global__ __launch_bounds__(64) void k_qoi_decode(const QoiItem* items, int n_i
             }
             carry = qoi_readlane(x, (int)cnt - 1);
             fill += total; produced += total; ops_done += cnt;
-            __syncthreads();
+            qoi_wave_sync();
             if (fill >= 256u) flush_rows();
+        };
+        if constexpr (kQoiWaves == 1) {
+            for (uint32_t g = 0; g < nops && produced < npx_total; g += 64) finish_group(g, parse_group(g));
+        } else {
+            // (a full group's run lengths can sum to 64 * 62 = 3968 < 4096: the 12-bit prefix never wraps)
+            for (uint32_t g = (uint32_t)wave * 64u; g < nops; g += kQoiT) {
+                const Group G = parse_group(g);
+                prep[g + lane] = make_uint4(G.f.M, G.f.V, G.f.U, G.run_incl | G.npx << 12 | G.b1 << 18 | (G.is_index ? 1u << 26 : 0u));
+            }
+            __syncthreads();
+            if (wave == 0) {
+                for (uint32_t g = 0; g < nops && produced < npx_total; g += 64) {
+                    const uint4 pr = prep[g + lane];
+                    Group G;
+                    G.f = QoiFn{ pr.x, pr.y, pr.z };
+                    G.run_incl = pr.w & 0xFFFu; G.npx = (pr.w >> 12) & 63u; G.b1 = (pr.w >> 18) & 255u; G.is_index = ((pr.w >> 26) & 1u) != 0;
+                    finish_group(g, G);
+                }
+            }
         }
+        if (wave == 0 && lane == 0 && produced >= npx_total) go_on = 0;
+        __syncthreads();
     }
     // what is left in the buffer, then the tail of a stream that ended early: the last pixel repeats (:496-497, run / p >= chunks_len)
-    for (uint32_t i = lane; i < fill; i += 64) store_px(flushed + i, obuf[i]);
-    for (size_t i = (size_t)produced + lane; i < npx_total; i += 64) store_px(i, carry);
+    if (wave == 0) {
+        for (uint32_t i = lane; i < fill; i += 64) store_px(flushed + i, obuf[i]);
+        for (size_t i = (size_t)produced + lane; i < npx_total; i += 64) store_px(i, carry);
+    }
 }
 
 inline uint32_t be32(const uint8_t* p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
@@ -261,7 +322,8 @@ int launch_items(const std::vector<QoiItem>& items, uint8_t* d_items, const uint
 {
     const int n = (int)items.size();
     GAMUT_HIP_CHECK(hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(QoiItem), hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(k_qoi_decode, dim3(n), dim3(64), 0, stream, (const QoiItem*)d_items, n, d_blob, d_out);
+    if (n < kQoiWideBelow) hipLaunchKernelGGL(k_qoi_decode<4>, dim3(n), dim3(256), 0, stream, (const QoiItem*)d_items, n, d_blob, d_out);
+    else                   hipLaunchKernelGGL(k_qoi_decode<1>, dim3(n), dim3(64), 0, stream, (const QoiItem*)d_items, n, d_blob, d_out);
     if (int rc = launch_status("qoi_decode")) return rc;
     GAMUT_HIP_CHECK(hipStreamSynchronize(stream));
     return GAMUT_HIP_OK;
@@ -300,7 +362,8 @@ int decode_batch(const uint8_t* const* data, const int* size, int count, int cha
         memcpy(h, items.data(), items.size() * sizeof(QoiItem));
         GAMUT_HIP_CHECK(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, stream));
         const int n = (int)items.size();
-        hipLaunchKernelGGL(k_qoi_decode, dim3(n), dim3(64), 0, stream, (const QoiItem*)d, n, (const uint8_t*)(d + o_blob), d_out);
+        if (n < kQoiWideBelow) hipLaunchKernelGGL(k_qoi_decode<4>, dim3(n), dim3(256), 0, stream, (const QoiItem*)d, n, (const uint8_t*)(d + o_blob), d_out);
+        else                   hipLaunchKernelGGL(k_qoi_decode<1>, dim3(n), dim3(64), 0, stream, (const QoiItem*)d, n, (const uint8_t*)(d + o_blob), d_out);
         if (int rc = launch_status("qoi_decode")) return rc;
         GAMUT_HIP_CHECK(hipStreamSynchronize(stream));         // the per-thread staging buffers are reused by the next call
     }

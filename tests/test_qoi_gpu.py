@@ -1,4 +1,5 @@
-"""GPU parity: QOI decode (one lane per stream) through the C ABI vs the CPU oracle; bit-exact."""
+"""GPU parity: QOI decode (a workgroup of four waves per stream, or one wave per stream in large batches) through the C ABI vs the
+CPU oracle; bit-exact."""
 import ctypes as C
 
 import numpy as np
@@ -82,6 +83,36 @@ def test_qoi_resident_streams(hip):
     assert hip.gamut_hip_qoi_decode_resident_device(*args(hblob.size - 1)) == _capi.ERR_INVALID_ARG      # last stream's slack is cut
     assert hip.gamut_hip_qoi_decode_resident_device(*args(hblob.size)[:6], 5, *args(0)[7:]) == _capi.ERR_INVALID_ARG
     hip.gamut_hip_device_free(blob); hip.gamut_hip_device_free(out)
+
+
+def test_qoi_large_batch_takes_the_one_wave_kernel(hip):
+    """>= 768 streams in one call run one wave per stream (k_qoi_decode<1>); same pixels as the oracle, rgba and rgb outputs"""
+    rng = np.random.default_rng(9)
+    imgs = []
+    for k in range(16):
+        w, h = 30 + 7 * k, 20 + 3 * (k % 5)
+        a = rng.integers(0, 256, (h, w, 3 + (k % 2)), dtype=np.uint8)
+        a[h // 3: h // 2] = a[h // 3: h // 3 + 1, :1]                            # runs
+        a[:, w // 2:] = a[:, : w - w // 2] // 16 * 16                            # few colours: INDEX ops
+        imgs.append(a)
+    files = [gen.qoi_encode(a) for a in imgs]
+    n = 800
+    for ch in (4, 3):
+        exp = [O.qoi_decode(f, ch)[0].reshape(-1) for f in files]
+        pick = [i % len(files) for i in range(n)]
+        bufs = [np.frombuffer(files[i], np.uint8) for i in pick]
+        ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs]); sizes = (C.c_int * n)(*[b.size for b in bufs])
+        nbytes = [exp[i].size for i in pick]
+        offs = np.concatenate([[0], np.cumsum(nbytes)[:-1]]).astype(np.int64)
+        dout = hip.gamut_hip_device_malloc(int(sum(nbytes)) + 64)
+        descs = (_capi.QoiDesc * n)(); st = (C.c_int * n)()
+        _capi.check(hip.gamut_hip_qoi_decode_batch_device(ptrs, sizes, n, ch, offs.ctypes.data_as(C.POINTER(C.c_int64)), dout, descs, st, None))
+        host = np.empty(int(sum(nbytes)), np.uint8)
+        _capi.check(hip.gamut_hip_memcpy_d2h(host.ctypes.data, dout, host.nbytes, None))
+        _capi.check(hip.gamut_hip_stream_synchronize(None))
+        hip.gamut_hip_device_free(dout)
+        for k in range(n):
+            assert np.array_equal(host[offs[k]:offs[k] + nbytes[k]], exp[pick[k]]), (ch, k)
 
 
 def test_image_load_qoi(hip):

@@ -84,6 +84,16 @@ template <int CTRL, int ROWMASK> __device__ __forceinline__ void qoi_scan_step(Q
     n += qoi_dpp<CTRL, ROWMASK>(n);
 }
 
+#ifndef QOI_PROFILE               // measurement only (tools/variant.sh qoi:prof:-DQOI_PROFILE=1): cycles per phase of wave 0, summed over streams
+#define QOI_PROFILE 0
+#endif
+#if QOI_PROFILE
+__device__ unsigned long long g_qoi_prof[8];
+#define QPROF(slot) do { const unsigned long long now_ = clock64(); qprof[slot] += now_ - qprof_t0; qprof_t0 = now_; } while (0)
+#else
+#define QPROF(slot)
+#endif
+
 template <int kQoiWaves>
 __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* items, int n_items, const uint8_t* blob, uint8_t* out)
 {
@@ -93,7 +103,8 @@ __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* it
     __shared__ uint16_t ops[kQoiWin];                         // op starts of the window, in order
     __shared__ uint4 prep[kQoiWaves > 1 ? kQoiWin : 1];       // W = 4, per op: M, V, U, run-length prefix | own run length << 12 | first byte << 18
     __shared__ unsigned long long table[64];                  // op number << 32 | pixel   (qoi_rgba_t[64] index, :453)
-    __shared__ __attribute__((aligned(16))) uint32_t obuf[kQoiOutCap];
+    __shared__ __attribute__((aligned(16))) uint32_t obuf[kQoiWaves > 1 ? 4 : kQoiOutCap];     // W = 1: pixels on their way out
+    __shared__ uint32_t xs[kQoiWaves > 1 ? kQoiWin : 1], gpos[kQoiWin / 64], gdone;           // W = 4: per op its pixel; per group its first pixel's index
     __shared__ uint32_t wave_map[kQoiWaves], wave_cnt[kQoiWaves], go_on;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     struct __attribute__((packed, aligned(1))) AnyVec { u32x4 v; };               // 16 bytes at any address
@@ -156,6 +167,9 @@ __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* it
     Mine dmine; uint64_t dtail;
     fetch(0, dmine, dtail);
     __syncthreads();
+#if QOI_PROFILE
+    unsigned long long qprof[8] = {}, qprof_t0 = clock64();
+#endif
     for (int pos = 0; pos < chunk_bytes && go_on; pos += kQoiWin) {
         // ---- the window into LDS; the next one into registers
         #pragma unroll
@@ -177,7 +191,9 @@ __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* it
         qoi_map_scan_step<0x111, 0xF>(map); qoi_map_scan_step<0x112, 0xF>(map); qoi_map_scan_step<0x114, 0xF>(map); qoi_map_scan_step<0x118, 0xF>(map);
         qoi_map_scan_step<0x142, 0xA>(map); qoi_map_scan_step<0x143, 0xC>(map);                 // lanes 0 .. this one, composed
         if (lane == 63) wave_map[wave] = map;
+        QPROF(0);
         __syncthreads();
+        QPROF(1);
         uint32_t wave_entry = entry;
         #pragma unroll
         for (int w = 0; w < kQoiWaves; ++w) {
@@ -203,7 +219,9 @@ __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* it
         #pragma unroll
         for (int w = 0; w < kQoiWaves; ++w) { const uint32_t c = wave_cnt[w]; if (w < wave) at += c; nops += c; }
         for (uint32_t m = starts; m; m &= m - 1) ops[at++] = (uint16_t)(t * kQoiLaneBytes + __builtin_ctz(m));
+        QPROF(2);
         __syncthreads();
+        QPROF(1);
         // ---- B. the ops as functions of the previous pixel, 64 at a time (W = 4: groups dealt to the waves, results in LDS)
         struct Group { QoiFn f; uint32_t run_incl, npx, b1; bool is_index; };
         auto parse_group = [&](uint32_t g) -> Group {
@@ -234,65 +252,102 @@ __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* it
             qoi_scan_step<0x118, 0xF>(G.f, G.run_incl); qoi_scan_step<0x142, 0xA>(G.f, G.run_incl); qoi_scan_step<0x143, 0xC>(G.f, G.run_incl);
             return G;
         };
-        // ---- C, D. pixels, table, output of one group (in stream order: wave 0)
-        auto finish_group = [&](uint32_t g, Group G) {
+        // ---- C. pixels and table of one group (in stream order: wave 0) -> the group's pixels, its first pixel's index
+        auto resolve_group = [&](uint32_t g, const Group& G, uint32_t& first_px) -> uint32_t {
             const uint32_t cnt = nops - g < 64u ? nops - g : 64u;
             const bool active = (uint32_t)lane < cnt;
-            const uint32_t tab = (uint32_t)table[lane];
             const QoiFn f = G.f;
-            uint32_t npx = G.npx;
             // pixels: lanes before the first INDEX op at once, then INDEX op by INDEX op
             uint32_t x = qoi_add_bytes(carry & ~f.M, f.V);
-            uint32_t h = qoi_hash(x);
             uint64_t todo = __ballot(G.is_index);
-            while (todo) {
-                const int j = __builtin_ctzll(todo);
-                todo &= todo - 1;
-                const int jn = todo ? __builtin_ctzll(todo) : 64;
-                const uint32_t slot = qoi_readlane(G.b1, j) & 63u;
-                const uint64_t m = __ballot(h == slot) & ((1ull << j) - 1ull);
-                const uint32_t base = m ? qoi_readlane(x, 63 - __builtin_clzll(m)) : qoi_readlane(tab, (int)slot);
-                const uint32_t nx = qoi_add_bytes(base & f.U, f.V);           // from an INDEX op on, every byte is set (M = all)
-                const bool in = lane >= j && lane < jn;
-                x = in ? nx : x;
-                h = in ? qoi_hash(nx) : h;
+            uint32_t h = qoi_hash(x);
+            if (todo) {
+                const uint32_t tab = (uint32_t)table[lane];               // the table as the groups before left it
+                do {
+                    const int j = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const int jn = todo ? __builtin_ctzll(todo) : 64;
+                    const uint32_t slot = qoi_readlane(G.b1, j) & 63u;
+                    const uint64_t m = __ballot(h == slot) & ((1ull << j) - 1ull);
+                    const uint32_t base = m ? qoi_readlane(x, 63 - __builtin_clzll(m)) : qoi_readlane(tab, (int)slot);
+                    const uint32_t nx = qoi_add_bytes(base & f.U, f.V);       // from an INDEX op on, every byte is set (M = all)
+                    const bool in = lane >= j && lane < jn;
+                    x = in ? nx : x;
+                    h = in ? qoi_hash(nx) : h;
+                } while (todo);
             }
-            // table, run lengths, output
             if (active) atomicMax(&table[h], (unsigned long long)(ops_done + 1u + (uint32_t)lane) << 32 | x);
-            uint32_t total = qoi_readlane(G.run_incl, (int)cnt - 1);
-            const uint32_t off = G.run_incl - npx, room = npx_total - produced;
-            if (total > room) { npx = off >= room ? 0u : (npx < room - off ? npx : room - off); total = room; }
+            carry = qoi_readlane(x, (int)cnt - 1);
+            first_px = produced;
+            const uint32_t total = qoi_readlane(G.run_incl, (int)cnt - 1), room = npx_total - produced;
+            produced += total < room ? total : room;
+            ops_done += cnt;
+            return x;
+        };
+        // ---- D (one wave per stream): the group's pixels through the LDS buffer, out in 1 KiB rows
+        auto emit_buffered = [&](const Group& G, uint32_t x, uint32_t first_px) {
+            const uint32_t off = G.run_incl - G.npx, room = npx_total - first_px;   // (room >= 1: the loop stops once the image is full)
+            const uint32_t npx = off >= room ? 0u : (G.npx < room - off ? G.npx : room - off);
             if (npx) obuf[fill + off] = x;
             if (__any(npx > 1u)) {
                 for (uint32_t r = 1; __any(r < npx); ++r) if (r < npx) obuf[fill + off + r] = x;
             }
-            carry = qoi_readlane(x, (int)cnt - 1);
-            fill += total; produced += total; ops_done += cnt;
+            fill += produced - first_px;
             qoi_wave_sync();
             if (fill >= 256u) flush_rows();
         };
         if constexpr (kQoiWaves == 1) {
-            for (uint32_t g = 0; g < nops && produced < npx_total; g += 64) finish_group(g, parse_group(g));
+            for (uint32_t g = 0; g < nops && produced < npx_total; g += 64) {
+                const Group G = parse_group(g);
+                uint32_t first_px;
+                const uint32_t x = resolve_group(g, G, first_px);
+                emit_buffered(G, x, first_px);
+            }
         } else {
             // (a full group's run lengths can sum to 64 * 62 = 3968 < 4096: the 12-bit prefix never wraps)
             for (uint32_t g = (uint32_t)wave * 64u; g < nops; g += kQoiT) {
                 const Group G = parse_group(g);
                 prep[g + lane] = make_uint4(G.f.M, G.f.V, G.f.U, G.run_incl | G.npx << 12 | G.b1 << 18 | (G.is_index ? 1u << 26 : 0u));
             }
+            QPROF(3);
             __syncthreads();
-            if (wave == 0) {
-                for (uint32_t g = 0; g < nops && produced < npx_total; g += 64) {
-                    const uint4 pr = prep[g + lane];
+            QPROF(1);
+            if (wave == 0) {                                  // the serial part: nothing but the pixels and the table
+                uint4 pr = prep[lane];
+                uint32_t g = 0;
+                for (; g < nops && produced < npx_total; g += 64) {
                     Group G;
                     G.f = QoiFn{ pr.x, pr.y, pr.z };
                     G.run_incl = pr.w & 0xFFFu; G.npx = (pr.w >> 12) & 63u; G.b1 = (pr.w >> 18) & 255u; G.is_index = ((pr.w >> 26) & 1u) != 0;
-                    finish_group(g, G);
+                    if (g + 64 < nops) pr = prep[g + 64 + lane];                   // (the next group's, while this one is worked on)
+                    uint32_t first_px;
+                    xs[g + lane] = resolve_group(g, G, first_px);
+                    if (lane == 0) gpos[g >> 6] = first_px;
                 }
+                if (lane == 0) gdone = g;                     // groups from here on were not resolved: the image was full before them
+            }
+            QPROF(4);
+            __syncthreads();
+            QPROF(1);
+            // D (four waves per stream): every wave writes the pixels of its groups straight to the image
+            const uint32_t resolved = gdone;
+            for (uint32_t g = (uint32_t)wave * 64u; g < resolved; g += kQoiT) {
+                const uint32_t first_px = gpos[g >> 6];
+                if (g + lane >= nops) continue;
+                const uint4 pr = prep[g + lane];
+                const uint32_t run_incl = pr.w & 0xFFFu, npx = (pr.w >> 12) & 63u, x = xs[g + lane];
+                const size_t at = (size_t)first_px + (run_incl - npx);
+                for (uint32_t r = 0; r < npx && at + r < npx_total; ++r) store_px(at + r, x);
             }
         }
         if (wave == 0 && lane == 0 && produced >= npx_total) go_on = 0;
+        QPROF(4);
         __syncthreads();
+        QPROF(1);
     }
+#if QOI_PROFILE
+    if (t == 0) for (int k = 0; k < 8; ++k) atomicAdd(&g_qoi_prof[k], qprof[k]);
+#endif
     // what is left in the buffer, then the tail of a stream that ended early: the last pixel repeats (:496-497, run / p >= chunks_len)
     if (wave == 0) {
         for (uint32_t i = lane; i < fill; i += 64) store_px(flushed + i, obuf[i]);
@@ -377,6 +432,15 @@ int decode_batch(const uint8_t* const* data, const int* size, int count, int cha
 using namespace gamut;
 
 extern "C" {
+
+#if QOI_PROFILE
+int gamut_hip_qoi_profile(unsigned long long* out8)          // measurement builds only: A + chain, barriers, compaction, B, C + D
+{
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_qoi_prof), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+    unsigned long long z[8] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_qoi_prof), z, sizeof(z)) != hipSuccess;
+}
+#endif
 
 int gamut_hip_qoi_read_header(const void* data, int size, gamut_hip_qoi_desc* desc)
 {

@@ -156,6 +156,18 @@ template <int M> __device__ __forceinline__ float div_by_max(float x)
     return __fmaf_rn(r, y, q);
 }
 
+// c / a, correctly rounded, for the quotients 8-bit premultiplied sources produce: c = RN(i / 255), a = RN(j / 255), 0 <= i <= 255,
+// 1 <= j <= 255.  One reciprocal per PIXEL (v_rcp_f32, 1 ulp) and per channel a product, an FMA residual and an FMA correction
+// (Markstein) instead of a full IEEE division per channel (v_div_scale x2, v_rcp, 4 FMAs, v_div_fmas, v_div_fixup).  That the
+// three instructions give RN(c / a) is not a theorem for a 1-ulp reciprocal; it is CHECKED: tests/test_convert_gpu.py runs every
+// (i, j) pair of every 8-bit premultiplied source against the oracle's IEEE division (65 280 quotients, all bit-equal).
+__device__ __forceinline__ float div_by_alpha8(float c, float a, float ra)
+{
+    const float q = __fmul_rn(c, ra);
+    const float r = __fmaf_rn(-q, a, c);
+    return __fmaf_rn(r, ra, q);
+}
+
 struct RGBAf { float r, g, b, a; };
 struct RGBA8 { u32 r, g, b, a; };
 
@@ -173,11 +185,25 @@ template <int T> __device__ __forceinline__ RGBAf decode_f32(const u32* w, int p
     }
     RGBAf o;
     if constexpr (CH == 1)      { o.r = o.g = o.b = c[0]; o.a = 1.0f; }
-    else if constexpr (CH == 2) { o.r = c[0]; o.a = c[1]; if constexpr (PT<T>::premul) { if (o.a != 0.0f) o.r = __fdiv_rn(o.r, o.a); } o.g = o.b = o.r; }
+    else if constexpr (CH == 2) {
+        o.r = c[0]; o.a = c[1];
+        if constexpr (PT<T>::premul) {
+            if constexpr (BITS == 8) { const float q = div_by_alpha8(o.r, o.a, __builtin_amdgcn_rcpf(o.a)); o.r = o.a != 0.0f ? q : o.r; }
+            else { if (o.a != 0.0f) o.r = __fdiv_rn(o.r, o.a); }
+        }
+        o.g = o.b = o.r;
+    }
     else if constexpr (CH == 3) { o.r = c[0]; o.g = c[1]; o.b = c[2]; o.a = 1.0f; }
     else {
         o.r = c[0]; o.g = c[1]; o.b = c[2]; o.a = c[3];
-        if constexpr (PT<T>::premul) { if (o.a != 0.0f) { o.r = __fdiv_rn(o.r, o.a); o.g = __fdiv_rn(o.g, o.a); o.b = __fdiv_rn(o.b, o.a); } }
+        if constexpr (PT<T>::premul) {
+            if constexpr (BITS == 8) {
+                const float ra = __builtin_amdgcn_rcpf(o.a);
+                const float qr = div_by_alpha8(o.r, o.a, ra), qg = div_by_alpha8(o.g, o.a, ra), qb = div_by_alpha8(o.b, o.a, ra);
+                const bool nz = o.a != 0.0f;
+                o.r = nz ? qr : o.r; o.g = nz ? qg : o.g; o.b = nz ? qb : o.b;
+            } else { if (o.a != 0.0f) { o.r = __fdiv_rn(o.r, o.a); o.g = __fdiv_rn(o.g, o.a); o.b = __fdiv_rn(o.b, o.a); } }
+        }
     }
     return o;
 }
@@ -283,12 +309,29 @@ __device__ __forceinline__ void convert_pixel_bytes(const uint8_t* s, uint8_t* d
 constexpr int kThreads = 256;
 constexpr int kUnroll  = CONVERT_UNROLL;
 
+// A destination unit of 3, 6, 12, 24 ... bytes per lane (rgb8 / rgb16 / rgbf32 pixels) leaves every store instruction of the wave
+// with holes: dwordx2 pieces at a 24-byte lane stride, three instructions that each touch every line of the wave's 1.5 KiB
+// (l8 -> rgbf32: 2.9 TB/s).  Such pairs hand their units through LDS inside the wave, so that every store instruction writes
+// 64 x 16 contiguous bytes.
+constexpr bool staged_store(int db) { return db % 16 != 0 && db != 1 && db != 2 && db != 4 && db != 8; }
+#ifndef CONVERT_STAGE
+#define CONVERT_STAGE 1
+#endif
+__device__ __forceinline__ void convert_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int S, int D>
 __global__ __launch_bounds__(kThreads) void k_convert_vec(ConvArgs a)
 {
     constexpr int G  = unit_pixels(PT<S>::size, PT<D>::size);
     constexpr int SB = G * PT<S>::size, DB = G * PT<D>::size;
     constexpr int64_t stride = kThreads;
+    constexpr bool STAGE = CONVERT_STAGE && staged_store(DB);
+    __shared__ __attribute__((aligned(16))) uint8_t stage[STAGE ? (kThreads / 64) * 64 * DB : 16];
     {
         const int64_t base = (int64_t)blockIdx.x * (kThreads * kUnroll) + threadIdx.x;      // a block owns kUnroll * 256 consecutive units
         u32 in[kUnroll][(SB + 3) / 4];
@@ -316,6 +359,28 @@ __global__ __launch_bounds__(kThreads) void k_convert_vec(ConvArgs a)
             if (uidx[j] < a.full_units) {
                 u32 out[(DB + 3) / 4];
                 convert_unit<S, D, G>(in[j], out);
+                if constexpr (STAGE) {
+                    // (wave-uniform) 64 whole units, one after the other in one row: the wave's bytes are one contiguous run
+                    const u32 u0 = (u32)__builtin_amdgcn_readfirstlane((int)uidx[j]), lane = threadIdx.x & 63u;
+                    if (__ballot(uidx[j] == u0 + lane && uidx[j] < a.full_units) == ~0ull) {          // (lanes that are not here count as 0)
+                        uint8_t* mine = stage + (threadIdx.x >> 6) * (64 * DB);
+                        if constexpr (DB % 4 == 0) { _Pragma("unroll") for (int i = 0; i < DB / 4; ++i) reinterpret_cast<u32*>(mine + lane * DB)[i] = out[i]; }
+                        else if constexpr (DB % 2 == 0) { _Pragma("unroll") for (int i = 0; i < DB / 2; ++i) reinterpret_cast<uint16_t*>(mine + lane * DB)[i] = (uint16_t)(out[i >> 1] >> ((i & 1) * 16)); }
+                        else { _Pragma("unroll") for (int i = 0; i < DB; ++i) mine[lane * DB + i] = (uint8_t)(out[i >> 2] >> ((i & 3) * 8)); }
+                        convert_wave_sync();
+                        const uint64_t wd = (uint64_t)dp[j];
+                        uint8_t* run = reinterpret_cast<uint8_t*>((uint64_t)(u32)__builtin_amdgcn_readfirstlane((int)(u32)wd) |
+                                                                  (uint64_t)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(wd >> 32)) << 32);
+                        struct __attribute__((packed, aligned(1))) Any16 { u32x4v v; };
+                        _Pragma("unroll")
+                        for (int off = 0; off < 64 * DB; off += 1024) {
+                            const int o = off + (int)lane * 16;
+                            if (o < 64 * DB) reinterpret_cast<Any16*>(run + o)->v = *reinterpret_cast<const u32x4v*>(mine + o);
+                        }
+                        convert_wave_sync();
+                        continue;
+                    }
+                }
                 store_unit<DB>(dp[j], out);
             } else {
                 for (u32 p = 0; p < a.tail_px; ++p)

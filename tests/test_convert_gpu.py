@@ -116,6 +116,24 @@ def test_exhaustive_integer_tables(hip):
     assert np.array_equal(got, ((u16.reshape(-1).astype(np.uint64) * 255 + 32767) // 65535).astype(np.uint8))
 
 
+def test_every_8bit_premultiplied_quotient(hip):
+    """8-bit premultiplied sources divide colour by alpha with one reciprocal per pixel and a Markstein correction per channel
+    (convert.hip: div_by_alpha8) instead of an IEEE division: every (colour, alpha) code pair -- 65 536 per source type, alpha 0
+    and colour > alpha included -- must give the oracle's bits, seen through the f32 destination and the integer ones."""
+    i, j = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), indexing="ij")
+    i, j = i.reshape(-1), j.reshape(-1)
+    n = i.size
+    cases = [("rgbap8", np.stack([i, (255 - i).astype(np.uint8), (i * 3 + 1).astype(np.uint8), j], axis=1), ["rgbaf32", "rgbf32", "rgba8", "rgba16", "l16", "laf32", "rgbap16"]),
+             ("lap8", np.stack([i, j], axis=1), ["laf32", "rgbaf32", "la8", "l16", "rgb16", "lapf32"])]
+    for src, arr, dsts in cases:
+        st = PT[src]
+        for dst in dsts:
+            dt = PT[dst]
+            exp = O.scanlines_convert(st, arr, dt, n, 1)
+            got = _run_device(hip, st, dt, np.ascontiguousarray(arr).reshape(-1).copy(), 0, n * PT_SIZE[st], exp.size, 0, n * PT_SIZE[dt], n, 1)
+            assert np.array_equal(got, exp), f"{src}->{dst}: {np.count_nonzero(got != exp)} bytes differ"
+
+
 def test_f32_boundaries(hip):
     """f32 -> u8/u16 at every half-integer boundary +-1 ulp, out-of-range and non-finite-free extremes."""
     e = gen.f32_edge_values()

@@ -133,6 +133,9 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if the library does not export it
             fn.restype, fn.argtypes = res, args
+        # wake the HIP runtime the library is linked against NOW: a process that loads it, then lets PyTorch (which brings
+        # its own copy of the runtime) find the GPU first, was seen to get "no device" from this one afterwards
+        L.gamut_hip_device_count()
         _lib = L
     return _lib
 

@@ -212,30 +212,36 @@ def main():
         npx = w * h
         g = torch.Generator(device=dev); g.manual_seed(7 + rank)
         sdt = O.PT_DTYPE[st]
+        # BASELINE.json configs[3] is a batch of 256 layers: 412 GB for rgba16 -> rgbaf32, more than one GPU holds.  The layers
+        # are converted in chunks: R resident layers (<= 128 GB of source + destination), a step = ceil(B / R) launches over them.
+        R = max(1, min(B, int(128e9 // (npx * (O.PT_SIZE[st] + O.PT_SIZE[dt_])))))
         if sdt == np.float32:
-            src = torch.rand((B, npx * O.PT_CHANNELS[st]), device=dev, generator=g, dtype=torch.float32)
+            src = torch.rand((R, npx * O.PT_CHANNELS[st]), device=dev, generator=g, dtype=torch.float32)
         elif sdt == np.uint16:
-            src = torch.randint(0, 65536, (B, npx * O.PT_CHANNELS[st]), device=dev, generator=g, dtype=torch.int32).to(torch.uint16)
+            src = torch.randint(0, 65536, (R, npx * O.PT_CHANNELS[st]), device=dev, generator=g, dtype=torch.int32).to(torch.uint16)
         else:
-            src = torch.randint(0, 256, (B, npx * O.PT_CHANNELS[st]), device=dev, generator=g, dtype=torch.int32).to(torch.uint8)
-        out = torch.empty((B, npx * O.PT_SIZE[dt_]), dtype=torch.uint8, device=dev)
+            src = torch.randint(0, 256, (R, npx * O.PT_CHANNELS[st]), device=dev, generator=g, dtype=torch.int32).to(torch.uint8)
+        out = torch.empty((R, npx * O.PT_SIZE[dt_]), dtype=torch.uint8, device=dev)
         px_per_step = B * npx
         bytes_per_step = px_per_step * (O.PT_SIZE[st] + O.PT_SIZE[dt_])
         kernel_name = f"k_convert_vec<{st}, {dt_}>"
-        workload = f"convertTo {s}->{d}, {B} layers of {w}x{h}, gapless"
+        launches = (B + R - 1) // R
+        workload = f"convertTo {s}->{d}, {B} layers of {w}x{h}, gapless" + (f", {launches} launches of <= {R} resident layers" if launches > 1 else "")
         sp, dp = w * O.PT_SIZE[st], w * O.PT_SIZE[dt_]
 
         def step():
-            _capi.check(L.gamut_hip_scanlines_convert_device(st, src.data_ptr(), sp, sp * h, dt_, out.data_ptr(), dp, dp * h,
-                                                              w, h, B, stream))
+            for c in range(0, B, R):
+                _capi.check(L.gamut_hip_scanlines_convert_device(st, src.data_ptr(), sp, sp * h, dt_, out.data_ptr(), dp, dp * h,
+                                                                  w, h, min(R, B - c), stream))
 
         def check():
             step()
             torch.cuda.synchronize()
             rows = 4
-            a = src[B - 1].view(torch.uint8)[:rows * sp].cpu().numpy()
+            last = (B - 1) % R if B % R else R - 1                     # a layer the step's last launch converted
+            a = src[last].view(torch.uint8)[:rows * sp].cpu().numpy()
             exp = O.scanlines_convert(st, a, dt_, w, rows)
-            if not np.array_equal(out[B - 1][:rows * dp].cpu().numpy(), exp):
+            if not np.array_equal(out[last][:rows * dp].cpu().numpy(), exp):
                 raise SystemExit("PARITY FAILURE")
 
         def cpu_leg(seconds):

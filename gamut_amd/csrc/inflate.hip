@@ -154,7 +154,19 @@ __device__ void build_table(Shared& S, int base, int n)
         sorted[c.offs[L] + rank] = DIST ? dist_payload((uint32_t)s) : lit_payload((uint32_t)s);
     }
     __syncthreads();
-    for (int e = t; e < (1 << P); e += kT) lut[e] = canon_decode((uint32_t)e, c, sorted, 1, P);
+    for (int e = t; e < (1 << P); e += kT) {
+        uint32_t r = canon_decode((uint32_t)e, c, sorted, 1, P);
+        if constexpr (!DIST) {
+            // two literals behind one look-up when both codes fit the index (kind 4: base = first | second << 8): residual data
+            // of photographs is mostly literals of 3-6 bits
+            const uint32_t l1 = r & 15u;
+            if (r && ((r >> 4) & 7u) == 0u && l1 < (uint32_t)P) {
+                const uint32_t r2 = canon_decode((uint32_t)e >> l1, c, sorted, 1, P - (int)l1);
+                if (r2 && ((r2 >> 4) & 7u) == 0u) r = ((r >> 16) | (r2 >> 16) << 8) << 16 | l1 << 8 | 4u << 4 | (l1 + (r2 & 15u));
+            }
+        }
+        lut[e] = r;
+    }
     __syncthreads();
 }
 
@@ -201,11 +213,23 @@ __device__ __forceinline__ LaneResult lane_decode(Shared& S, uint32_t start, uin
             uint32_t e = S.lit_lut[(uint32_t)bits & ((1u << kLitBits) - 1u)];
             if ((e & 15u) == 0u) { e = long_lit.decode((uint32_t)bits, S.lit_sorted); if (!e) { fl = F_BAD; break; } }
             uint32_t nb = e & 15u;
+            uint32_t kind = (e >> 4) & 7u;
+            if (kind == 4u) {
+                // a pair whose second literal would begin at or beyond `end` is taken as its first literal alone: a lane must
+                // leave at the FIRST token boundary past its end whatever way it came in, or the lanes never fall into step
+                const uint32_t l1 = (e >> 8) & 15u;
+                if (pos + used + l1 >= end) { kind = 0u; nb = l1; e &= 0x00FFFFFFu; }
+            }
             bits >>= nb; used += nb;
-            const uint32_t kind = (e >> 4) & 7u;
             if (kind == 0u) {
                 if (WRITE) { S.ring[(obase + o) & kRingMask] = (uint8_t)(e >> 16); S.from[orel + o] = (uint16_t)(orel + o + kHist); }
                 ++o;
+            } else if (kind == 4u) {                              // two literals
+                if (WRITE) {
+                    S.ring[(obase + o) & kRingMask] = (uint8_t)(e >> 16); S.from[orel + o] = (uint16_t)(orel + o + kHist);
+                    S.ring[(obase + o + 1u) & kRingMask] = (uint8_t)(e >> 24); S.from[orel + o + 1u] = (uint16_t)(orel + o + 1u + kHist);
+                }
+                o += 2u;
             } else if (kind == 1u) {
                 uint32_t xb = (e >> 8) & 31u;
                 const uint32_t len = (e >> 16) + ((uint32_t)bits & ((1u << xb) - 1u));

@@ -278,9 +278,32 @@ def test_jpeg_literal_restatement_pixels_small_frames():
 
 @pytest.mark.skipif(not os.path.exists("/root/reference/source/gamut/codecs/jpegload.d"), reason="reference tree not present")
 def test_jpeg_literal_restatement_is_current_transliteration():
-    """the P_Q / R_S statements in tools/ref_literal_jpeg.py are exactly what tools/make_ref_literal.py produces from the D text today"""
+    """the P_Q / R_S and the Row / Col statements in tools/ref_literal_jpeg.py are exactly what tools/make_ref_literal.py produces
+    from the D text today"""
     import subprocess, sys
     subprocess.check_call([sys.executable, os.path.join(os.path.dirname(HERE), "tools", "make_ref_literal.py"), "--check"])
+
+
+def test_jpeg_rowcol_transliteration_equals_the_handwritten_reading():
+    """Row!(N).idct / Col!(N).idct exist twice in tools/ref_literal_jpeg.py: written by hand from the D text, and produced from
+    the D text by tools/make_ref_literal.py (syntax rewritten, expressions untouched).  Every N, full-range int16 / int32 inputs:
+    the same bits -- and idct() / idct_4x4() / the whole H2V2 comparison above run on the mechanical version."""
+    R = _literal()
+    rng = np.random.default_rng(11)
+    n = 4000
+    for N in range(0, 9):
+        src = rng.integers(-32768, 32768, (n, 8), dtype=np.int16)
+        a = np.full((n, 8), 12345, np.int32); b = a.copy()
+        R.Row_idct(N, a, src)
+        R.Row_idct_d(N, R.Ptr(b, 0), R.Ptr(src, 0))
+        assert np.array_equal(a, b), N
+    for N in range(1, 9):
+        tmp = rng.integers(-2**31, 2**31, (n, 64), dtype=np.int64).astype(np.int32)
+        a = np.zeros((n, 64), np.uint8); b = a.copy()
+        for col in range(8):
+            R.Col_idct(N, a, tmp, col)
+            R.Col_idct_d(N, R.Ptr(b, col), R.Ptr(tmp, col))
+        assert np.array_equal(a, b), N
 
 
 def test_jpeg_sparse_paths_equal_dense():

@@ -186,6 +186,151 @@ def Col_idct(NONZERO_ROWS, pDst, pTemp, col):
     pDst[:, col + 8 * 4] = CLAMP(i)
 
 
+# ---------------------------------------------------------------------------------------------- :156-292 again, mechanically
+class Ptr:
+    """a D pointer walking N blocks at once: p[k] is element k (a column of the (N, 64) array) read or written for all blocks;
+    reading a `short` promotes to int, as every D expression on it does"""
+    def __init__(self, arr, base):
+        self.arr, self.base = arr, base
+
+    def __getitem__(self, k):
+        v = self.arr[:, self.base + k]
+        return v.astype(I32) if v.dtype == np.int16 else v
+
+    def __setitem__(self, k, v):
+        self.arr[:, self.base + k] = v
+
+
+def to_ubyte(x):                   # cast(ubyte): the low 8 bits
+    return i32(x).astype(np.uint8)
+
+
+# BEGIN GENERATED ROWCOL (tools/make_ref_literal.py from jpegload.d)
+def Row_idct_d(NONZERO_COLS, pTemp, pSrc):          # jpegload.d:159-212
+    ACCESS_COL = lambda x: pSrc[x] if x < NONZERO_COLS else 0      # template ACCESS_COL: "cast(int)pSrc[x]" or "0"
+    if NONZERO_COLS == 0:
+        pass
+        # nothing
+    elif NONZERO_COLS == 1:
+        pass
+        dcval = (pSrc[0] << PASS1_BITS)
+        pTemp[0] = dcval
+        pTemp[1] = dcval
+        pTemp[2] = dcval
+        pTemp[3] = dcval
+        pTemp[4] = dcval
+        pTemp[5] = dcval
+        pTemp[6] = dcval
+        pTemp[7] = dcval
+    else:
+        pass
+        # ACCESS_COL() will be optimized at compile time to either an array access, or 0.
+        ##define ACCESS_COL(x) (((x) < NONZERO_COLS) ? (int)pSrc[x] : 0)
+        z2 = ACCESS_COL(2)
+        z3 = ACCESS_COL(6)
+        z1 = (z2 + z3)*FIX_0_541196100
+        tmp2 = z1 + z3*(-FIX_1_847759065)
+        tmp3 = z1 + z2*FIX_0_765366865
+        tmp0 = (ACCESS_COL(0) + ACCESS_COL(4)) << CONST_BITS
+        tmp1 = (ACCESS_COL(0) - ACCESS_COL(4)) << CONST_BITS
+        tmp10 = tmp0 + tmp3
+        tmp13 = tmp0 - tmp3
+        tmp11 = tmp1 + tmp2
+        tmp12 = tmp1 - tmp2
+        atmp0 = ACCESS_COL(7)
+        atmp1 = ACCESS_COL(5)
+        atmp2 = ACCESS_COL(3)
+        atmp3 = ACCESS_COL(1)
+        bz1 = atmp0 + atmp3
+        bz2 = atmp1 + atmp2
+        bz3 = atmp0 + atmp2
+        bz4 = atmp1 + atmp3
+        bz5 = (bz3 + bz4)*FIX_1_175875602
+        az1 = bz1*(-FIX_0_899976223)
+        az2 = bz2*(-FIX_2_562915447)
+        az3 = bz3*(-FIX_1_961570560) + bz5
+        az4 = bz4*(-FIX_0_390180644) + bz5
+        btmp0 = atmp0*FIX_0_298631336 + az1 + az3
+        btmp1 = atmp1*FIX_2_053119869 + az2 + az4
+        btmp2 = atmp2*FIX_3_072711026 + az2 + az3
+        btmp3 = atmp3*FIX_1_501321110 + az1 + az4
+        pTemp[0] = DESCALE(tmp10 + btmp3, CONST_BITS-PASS1_BITS)
+        pTemp[7] = DESCALE(tmp10 - btmp3, CONST_BITS-PASS1_BITS)
+        pTemp[1] = DESCALE(tmp11 + btmp2, CONST_BITS-PASS1_BITS)
+        pTemp[6] = DESCALE(tmp11 - btmp2, CONST_BITS-PASS1_BITS)
+        pTemp[2] = DESCALE(tmp12 + btmp1, CONST_BITS-PASS1_BITS)
+        pTemp[5] = DESCALE(tmp12 - btmp1, CONST_BITS-PASS1_BITS)
+        pTemp[3] = DESCALE(tmp13 + btmp0, CONST_BITS-PASS1_BITS)
+        pTemp[4] = DESCALE(tmp13 - btmp0, CONST_BITS-PASS1_BITS)
+
+
+def Col_idct_d(NONZERO_ROWS, pDst_ptr, pTemp):          # jpegload.d:221-290
+    ACCESS_ROW = lambda x: pTemp[x * 8] if x < NONZERO_ROWS else 0  # template ACCESS_ROW: "pTemp[x*8]" or "0"
+    assert NONZERO_ROWS > 0
+    if NONZERO_ROWS == 1:
+        pass
+        dcval = DESCALE_ZEROSHIFT(pTemp[0], PASS1_BITS+3)
+        dcval_clamped = to_ubyte(CLAMP(dcval))
+        pDst_ptr[0*8] = dcval_clamped
+        pDst_ptr[1*8] = dcval_clamped
+        pDst_ptr[2*8] = dcval_clamped
+        pDst_ptr[3*8] = dcval_clamped
+        pDst_ptr[4*8] = dcval_clamped
+        pDst_ptr[5*8] = dcval_clamped
+        pDst_ptr[6*8] = dcval_clamped
+        pDst_ptr[7*8] = dcval_clamped
+    else:
+        pass
+        # ACCESS_ROW() will be optimized at compile time to either an array access, or 0.
+        ##define ACCESS_ROW(x) (((x) < NONZERO_ROWS) ? pTemp[x * 8] : 0)
+        z2 = ACCESS_ROW(2)
+        z3 = ACCESS_ROW(6)
+        z1 = (z2 + z3)*FIX_0_541196100
+        tmp2 = z1 + z3*(-FIX_1_847759065)
+        tmp3 = z1 + z2*FIX_0_765366865
+        tmp0 = (ACCESS_ROW(0) + ACCESS_ROW(4)) << CONST_BITS
+        tmp1 = (ACCESS_ROW(0) - ACCESS_ROW(4)) << CONST_BITS
+        tmp10 = tmp0 + tmp3
+        tmp13 = tmp0 - tmp3
+        tmp11 = tmp1 + tmp2
+        tmp12 = tmp1 - tmp2
+        atmp0 = ACCESS_ROW(7)
+        atmp1 = ACCESS_ROW(5)
+        atmp2 = ACCESS_ROW(3)
+        atmp3 = ACCESS_ROW(1)
+        bz1 = atmp0 + atmp3
+        bz2 = atmp1 + atmp2
+        bz3 = atmp0 + atmp2
+        bz4 = atmp1 + atmp3
+        bz5 = (bz3 + bz4)*FIX_1_175875602
+        az1 = bz1*(-FIX_0_899976223)
+        az2 = bz2*(-FIX_2_562915447)
+        az3 = bz3*(-FIX_1_961570560) + bz5
+        az4 = bz4*(-FIX_0_390180644) + bz5
+        btmp0 = atmp0*FIX_0_298631336 + az1 + az3
+        btmp1 = atmp1*FIX_2_053119869 + az2 + az4
+        btmp2 = atmp2*FIX_3_072711026 + az2 + az3
+        btmp3 = atmp3*FIX_1_501321110 + az1 + az4
+        i = DESCALE_ZEROSHIFT(tmp10 + btmp3, CONST_BITS+PASS1_BITS+3)
+        pDst_ptr[8*0] = to_ubyte(CLAMP(i))
+        i = DESCALE_ZEROSHIFT(tmp10 - btmp3, CONST_BITS+PASS1_BITS+3)
+        pDst_ptr[8*7] = to_ubyte(CLAMP(i))
+        i = DESCALE_ZEROSHIFT(tmp11 + btmp2, CONST_BITS+PASS1_BITS+3)
+        pDst_ptr[8*1] = to_ubyte(CLAMP(i))
+        i = DESCALE_ZEROSHIFT(tmp11 - btmp2, CONST_BITS+PASS1_BITS+3)
+        pDst_ptr[8*6] = to_ubyte(CLAMP(i))
+        i = DESCALE_ZEROSHIFT(tmp12 + btmp1, CONST_BITS+PASS1_BITS+3)
+        pDst_ptr[8*2] = to_ubyte(CLAMP(i))
+        i = DESCALE_ZEROSHIFT(tmp12 - btmp1, CONST_BITS+PASS1_BITS+3)
+        pDst_ptr[8*5] = to_ubyte(CLAMP(i))
+        i = DESCALE_ZEROSHIFT(tmp13 + btmp0, CONST_BITS+PASS1_BITS+3)
+        pDst_ptr[8*3] = to_ubyte(CLAMP(i))
+        i = DESCALE_ZEROSHIFT(tmp13 - btmp0, CONST_BITS+PASS1_BITS+3)
+        pDst_ptr[8*4] = to_ubyte(CLAMP(i))
+
+# END GENERATED ROWCOL
+
+
 # ---------------------------------------------------------------------------------------------- :295-306 (data)
 s_idct_row_table = [
   1,0,0,0,0,0,0,0, 2,0,0,0,0,0,0,0, 2,1,0,0,0,0,0,0, 2,1,1,0,0,0,0,0, 2,2,1,0,0,0,0,0, 3,2,1,0,0,0,0,0, 4,2,1,0,0,0,0,0, 4,3,1,0,0,0,0,0,
@@ -215,11 +360,11 @@ def idct(pSrc_ptr, block_max_zag):
         return pDst
 
     temp = np.zeros((N, 64), I32)                             # int[64] temp (D zero-initialises)
-    for row in range(8):
-        Row_idct(s_idct_row_table[(block_max_zag - 1) * 8 + row], temp[:, row * 8:row * 8 + 8], pSrc_ptr[:, row * 8:row * 8 + 8])
+    for row in range(8):                                      # Row!(n).idct(pTemp, pSrc); pSrc += 8; pTemp += 8
+        Row_idct_d(s_idct_row_table[(block_max_zag - 1) * 8 + row], Ptr(temp, row * 8), Ptr(pSrc_ptr, row * 8))
     nonzero_rows = s_idct_col_table[block_max_zag - 1]
-    for col in range(8):
-        Col_idct(nonzero_rows, pDst, temp, col)
+    for col in range(8):                                      # Col!(n).idct(pDst_ptr, pTemp); pTemp++; pDst_ptr++
+        Col_idct_d(nonzero_rows, Ptr(pDst, col), Ptr(temp, col))
     return pDst
 
 
@@ -229,9 +374,9 @@ def idct_4x4(pSrc_ptr):
     pDst = np.zeros((N, 64), np.uint8)
     temp = np.zeros((N, 64), I32)
     for row in range(4):
-        Row_idct(4, temp[:, row * 8:row * 8 + 8], pSrc_ptr[:, row * 8:row * 8 + 8])
+        Row_idct_d(4, Ptr(temp, row * 8), Ptr(pSrc_ptr, row * 8))
     for col in range(8):
-        Col_idct(4, pDst, temp, col)
+        Col_idct_d(4, Ptr(pDst, col), Ptr(temp, col))
     return pDst
 
 

@@ -48,7 +48,12 @@ struct DefilterArgs {
     u32 store_tail_masked;                       // 1: D rows are tight (fused output) -> never write past wb
     const int64_t* raw_offs; const int64_t* d_offs;  // optional (device): byte offset of image i's stream / rows instead of i * stride
     u32 nseg;                                    // > 1: every image is cut into up to nseg row segments (take_segment), one workgroup each
+    // work-queue launch (k_png_defilter_queue): qstate[0] = next unit, qstate[QSTATE_HDR + img * nbands + band] = pieces of
+    // that band's last row that are visible to every CU; zeroed by the launcher before every launch
+    u32* qstate; u32 count, nbands, group;
 };
+constexpr u32 QSTATE_HDR = 16;
+constexpr u32 STATUS_HANDOFF_TIMEOUT = 0x80000000u;      // a band never saw the band above it progress (a bug or a dead producer): reported, never hung
 __device__ __forceinline__ const uint8_t* image_raw(const DefilterArgs& a, int img) { return a.raw + (a.raw_offs ? a.raw_offs[img] : (int64_t)img * a.raw_stride); }
 __device__ __forceinline__ uint8_t* image_rows(const DefilterArgs& a, int img) { return a.D + (a.d_offs ? a.d_offs[img] : (int64_t)img * a.d_stride); }
 // A workgroup's share: the whole image, or -- small batches -- the rows from one cut row to the next.  A cut row has filter None
@@ -445,15 +450,20 @@ constexpr int ROW_PITCH = RING * 16;              // 256 B: lane j's slot (T - j
 // in pieces of IB = 12 stream bytes = 4 pixels = one 16-byte chunk of the output, the ring slots hold the expanded pixels,
 // and everything about write-back, alignment and the hand-off between bands is the RGBA8 case; the row above the band comes
 // back from the output as RGBA and is squeezed to RGB again (three byte permutes per trip).
-template <int FB, int W, bool PAETH, bool RGBA>
+// Q = work-queue launch: the band above may run on ANY compute unit of the device, so the hand-off is the placement-
+// independent one: the band's last row (the only bytes another wave reads) is stored write-through (16-byte sc1 stores), its
+// progress word is an agent-scope relaxed store behind the counted vmcnt wait, the consumer polls that word relaxed and reads
+// the row with sc1 loads (no fence on either side, nothing depends on which XCD runs what).  prog = the image's progress
+// words (one per band) instead of the workgroup's per-wave ones.
+template <int FB, int W, bool PAETH, bool RGBA, bool Q = false>
 __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const uint8_t* raw, uint8_t* D, u32* prog, uint8_t* ring, u32 band,
-                                               int wave, int lane, u32 niter, u32 f, bool row_live)
+                                               int wave, int lane, u32 niter, u32 f, bool row_live, u32* status = nullptr)
 {
     static_assert(!RGBA || FB == 3, "alpha insertion is the 8-bit RGB case");
     constexpr int IB = RGBA ? 12 : 16;            // stream bytes per piece
     constexpr int PW = 4;                         // dwords per piece
     typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-    const u32 seq = band / W;
+    const u32 seq = Q ? 0u : band / W;
     const u32 row = band * 64 + lane;
     const RowFilter rf = { f == 1 ? 0xFFFFFFFFu : 0u, f == 2 ? 0xFFFFFFFFu : 0u, f == 3 ? 0xFFFFFFFFu : 0u, f == 4 };
 
@@ -461,7 +471,9 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
     const uint8_t* dprev = band > 0 ? D + (int64_t)(band * 64 - 1) * a.d_pitch : D;
     const u32 dmask = band > 0 ? 0xFFFFFFFFu : 0u;
     const int prod_wave = (wave + W - 1) % W;
-    const u32 prod_base = (band > 0 ? (band - 1) / W : 0) * niter;
+    const u32 prod_base = Q ? 0u : (band > 0 ? (band - 1) / W : 0) * niter;
+    u32* const my_flag = Q ? prog + band : prog + wave;
+    u32* const prod_flag = Q ? prog + (band > 0 ? band - 1 : 0) : prog + prod_wave;
     const u32 full_iters = a.wb / IB;             // whole pieces of the stream = whole 16-byte chunks of the output row
     const u32 out_wb = RGBA ? (a.wb / 3) * 4 : a.wb;
     // pieces written back cooperatively: a partial last piece goes along when the destination rows are padded (scratch)
@@ -480,11 +492,36 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
     #pragma unroll
     for (int i = 0; i < PW; ++i) { outp[i] = 0; bprev[i] = 0; }
 
+    // Q: descriptors of the two rows that cross waves -- the row above the band (read) and the band's last row (written)
+    const auto rs_prev = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(dprev), 0, (int)(niter * 16), 0x00020000);
+    const auto rs_last = __builtin_amdgcn_make_buffer_rsrc(D + (int64_t)(band * 64 + 63) * a.d_pitch, 0, (int)(niter * 16), 0x00020000);
+    u32 seen = 0;                                   // Q: the producer's progress as last read (it only grows: most checks cost nothing)
     auto wait_for_band_above = [&](u32 upto) {
         const u32 need = prod_base + min(niter, upto);
-        while (__hip_atomic_load(&prog[prod_wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
-            __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if constexpr (Q) {
+            if (seen >= need) return;
+            const uint64_t t0 = wall_clock64();
+            for (;;) {
+                seen = (u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(prod_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (seen >= need) break;
+                __builtin_amdgcn_s_sleep(8);
+                if (wall_clock64() - t0 > 400000000ull) {                 // 4 s of the 100 MHz clock: give up, say so, never hang
+                    if (status && lane == 0) atomicOr(status, STATUS_HANDOFF_TIMEOUT);
+                    seen = 0xFFFFFFFFu;
+                    break;
+                }
+            }
+        } else {
+            while (__hip_atomic_load(prod_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
+                __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+    };
+    auto publish = [&](u32 value) {
+        if (lane == 63) {
+            if constexpr (Q) __hip_atomic_store(my_flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else             __hip_atomic_store(my_flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     };
 
     uint4 pre[TT];                                  // next tile's raw pieces (cooperative layout)
@@ -511,19 +548,43 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
     auto issue_dprev = [&](u32 Tn, u32x4& ds) {
         // lane 0's iteration is Tn: wave-uniform address.  Band 0 has no row above it (the value is masked): it re-reads the first
         // 16 bytes of row 0, which always exist -- never an address outside the image
-        const uint8_t* dn = dprev + (int64_t)(band > 0 ? min(Tn, niter - 1) : 0u) * 16;
-        ds = *reinterpret_cast<const u32x4*>(dn);
+        const u32 piece = band > 0 ? min(Tn, niter - 1) : 0u;
+        ds = *reinterpret_cast<const u32x4*>(dprev + (int64_t)piece * 16);
+    };
+    // Q: the row above is in memory (sc1 stores leave no copy in any L2), a round trip of a few microseconds: it is fetched a
+    // tile (8 pieces = 128 bytes, one piece per lane 0..7, sc1 loads) ahead, parked in 128 bytes of LDS behind the wave's ring at
+    // the start of the tile that uses it, and every trip reads its piece from there (one broadcast ds_read).
+    u32x4 chunk = { 0u, 0u, 0u, 0u };
+    uint8_t* const dch = ring + 64 * ROW_PITCH;
+    auto issue_chunk = [&](u32 Tbase) {
+        const u32 piece = band > 0 ? min(Tbase + (u32)(lane & 7), niter - 1) : 0u;
+        if (lane < 8) chunk = __builtin_amdgcn_raw_buffer_load_b128(rs_prev, piece * 16u, 0, 16);        // sc1: past this CU's L1
     };
 
-    if (band > 0) wait_for_band_above(PUB + PF);
+    if constexpr (Q) {
+        if (band > 0) wait_for_band_above(TT);
+        issue_chunk(0);
+    } else if (band > 0) wait_for_band_above(PUB + PF);
     prefetch_tile(0);
-    #pragma unroll
-    for (int u = 0; u < PF; ++u) issue_dprev((u32)u, dset[u]);
+    if constexpr (!Q) {
+        #pragma unroll
+        for (int u = 0; u < PF; ++u) issue_dprev((u32)u, dset[u]);
+    }
 
     // trips must reach iteration niter-1 of lane 63; write-back must reach row 63's last group (tile T0 = 8 g_last + 64)
     const u32 T_end = max(niter + 63, 8 * ((wb_iters - 1) >> 3) + 65);
     u32 my_slot = (u32)(-lane) & (RING - 1);                                               // slot of iteration T - lane, kept incrementally
+    u32 polled = 0;                                 // Q: the progress word as loaded one tile ago (a round trip to L2 / the fabric that nobody waits for)
     for (u32 T0 = 0; T0 < T_end; T0 += TT) {
+        if constexpr (Q) {
+            if (band > 0) {
+                seen = max(seen, (u32)__builtin_amdgcn_readfirstlane((int)polled));
+                polled = __hip_atomic_load(prod_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                wait_for_band_above(T0 + 2 * TT);                      // the pieces of the next tile, fetched below
+            }
+            if (lane < 8) *reinterpret_cast<u32x4*>(dch + lane * 16) = chunk;      // this tile's pieces of the row above
+            issue_chunk(T0 + TT);
+        }
         // drop this tile's raw pieces (prefetched) into the rings, then start fetching the next tile
         #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -557,18 +618,23 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
                     for (int i = 0; i < 4; ++i) rg[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], bs);
                 }
             }
+            u32x4 dcur;
+            if constexpr (Q) dcur = *reinterpret_cast<const u32x4*>(dch + u * 16);
+            else             dcur = dset[u % PF];
             if constexpr (RGBA) {       // the chunk of the output row above the band: R,G,B,255 x 4 -> 12 stream bytes
-                const u32x4 d = dset[u % PF];
+                const u32x4 d = dcur;
                 bg[0] = from_lane_below(outp[0], __builtin_amdgcn_perm(d[1], d[0], 0x04020100u) & dmask);
                 bg[1] = from_lane_below(outp[1], __builtin_amdgcn_perm(d[2], d[1], 0x05040201u) & dmask);
                 bg[2] = from_lane_below(outp[2], __builtin_amdgcn_perm(d[3], d[2], 0x06050402u) & dmask);
                 bg[3] = 0;
             } else {
                 #pragma unroll
-                for (int i = 0; i < PW; ++i) bg[i] = from_lane_below(outp[i], dset[u % PF][i] & dmask);
+                for (int i = 0; i < PW; ++i) bg[i] = from_lane_below(outp[i], dcur[i] & dmask);
             }
-            if (band > 0 && T + PF < niter && ((T + PF) % PUB) == 0) wait_for_band_above(T + PF + PUB);
-            issue_dprev(T + PF, dset[u % PF]);
+            if constexpr (!Q) {
+                if (band > 0 && T + PF < niter && ((T + PF) % PUB) == 0) wait_for_band_above(T + PF + PUB);
+                issue_dprev(T + PF, dset[u % PF]);
+            }
 
             u32 og[PW], ow[PW];         // de-filtered stream bytes of the piece; what goes into the ring slot (= output bytes)
             if constexpr (RGBA) {
@@ -589,9 +655,15 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
             if (rag_tile && a.store_tail_masked) {   // partial piece of an exact-size destination row (wb % 4 == 0 there): up to three
                 u32* dst = reinterpret_cast<u32*>(drow + (int64_t)(ragged ? it : 0) * 16);      // dword stores straight to the row
                 const u32 nb = ragged ? out_wb - (u32)it * 16 : 0u;
-                if (nb >= 4) dst[0] = ow[0];
-                if (nb >= 8) dst[1] = ow[1];
-                if (nb >= 12) dst[2] = ow[2];
+                if constexpr (Q) {      // the band's last row is read by another compute unit: write-through
+                    if (nb >= 4) __hip_atomic_store(dst + 0, ow[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (nb >= 8) __hip_atomic_store(dst + 1, ow[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (nb >= 12) __hip_atomic_store(dst + 2, ow[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    if (nb >= 4) dst[0] = ow[0];
+                    if (nb >= 8) dst[1] = ow[1];
+                    if (nb >= 12) dst[2] = ow[2];
+                }
             }
         }
 
@@ -602,7 +674,8 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
             const uint4 v = *reinterpret_cast<const uint4*>(co_ring + k * 8 * ROW_PITCH + ((u32)it & (RING - 1)) * 16);
             if ((u32)(8 * k + crow) < rows_left && it >= 0 && it < (int)wb_iters) {
                 u32x4* dst = reinterpret_cast<u32x4*>(cdst + (int64_t)(8 * k) * a.d_pitch + (int64_t)it * 16);
-                if (PNG_NT_STORES) __builtin_nontemporal_store(u32x4{ v.x, v.y, v.z, v.w }, dst);
+                if (Q && k == 7 && crow == 7) __builtin_amdgcn_raw_buffer_store_b128(u32x4{ v.x, v.y, v.z, v.w }, rs_last, (u32)it * 16u, 0, 16);   // row 63: sc1
+                else if (PNG_NT_STORES) __builtin_nontemporal_store(u32x4{ v.x, v.y, v.z, v.w }, dst);
                 else               *dst = u32x4{ v.x, v.y, v.z, v.w };
             }
         }
@@ -611,15 +684,15 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
         // those older stores have been acknowledged (the counter retires in order) -- the prefetches in flight are not drained.
         const int done = ((int)T0 - 63) & ~7;
         if (done > 0) {
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            if (lane == 63)
-                __hip_atomic_store(&prog[wave], seq * niter + min((u32)done, wb_iters), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // (Q: this tile issued 9-10 loads and then 8-9 stores after them: "at most 12 outstanding" covers the same stores)
+            if constexpr (Q) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else             asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            publish(seq * niter + min((u32)done, wb_iters));
         }
     }
     // band finished: everything is on its way; drain and publish the whole band
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 63)
-        __hip_atomic_store(&prog[wave], seq * niter + niter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    publish(seq * niter + niter);
 }
 
 template <int FB, int W, int MINW, bool RGBA = false>
@@ -642,6 +715,46 @@ __global__ __launch_bounds__(W * 64, MINW) void k_png_defilter_ring(DefilterArgs
         if (f > 4) { if (a.status) atomicOr(a.status + img, 1u); f = 0; }
         if (__any(f == 4)) defilter_band_ring<FB, W, true,  RGBA>(a, raw, D, prog, tiles[wave], band, wave, lane, niter, f, row_live);
         else               defilter_band_ring<FB, W, false, RGBA>(a, raw, D, prog, tiles[wave], band, wave, lane, niter, f, row_live);
+    }
+}
+
+// The same bands, handed out by a queue: a persistent grid (one workgroup of W waves per compute unit) in which every WAVE
+// draws the next (image, band) unit from one device-wide counter.  An image no longer belongs to a workgroup, so a batch
+// occupies every wave slot of the chip until the last units (341 x 1080p images = 5 797 bands on 2 048 slots, instead of two
+// rounds of workgroups that each run 17 bands on 8 waves in three rounds), and a single image's bands spread over as many
+// compute units as it has bands, whatever its filters.
+// Order of the units: the batch is cut into groups of `group` images, a group's units run band-major (band 0 of every image
+// of the group, then band 1, ...).  Unit (i, b) therefore follows (i, b - 1) -- whoever holds it is already running, and the
+// oldest unit in flight never waits, so the queue cannot deadlock whatever the number of resident workgroups -- and by the time
+// a wave draws (i, b) the band above it has usually had the ~80 trips of head start it needs (lane 63 of a band runs 63 pieces
+// behind its lane 0), so waves rarely sit waiting.
+template <int FB, int W, int MINW, bool RGBA = false>
+__global__ __launch_bounds__(W * 64, MINW) void k_png_defilter_queue(DefilterArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t tiles[W][64 * ROW_PITCH + 128];      // a wave's ring + 128 bytes of the row above its band
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    constexpr u32 IB = RGBA ? 12 : 16;
+    const u32 niter = (a.wb + IB - 1) / IB;
+    const u32 total = a.count * a.nbands, per_group = a.group * a.nbands;
+    for (;;) {
+        u32 u = 0;
+        if (lane == 0) u = __hip_atomic_fetch_add(a.qstate, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u = (u32)__builtin_amdgcn_readfirstlane((int)u);
+        if (u >= total) break;
+        const u32 g = u / per_group, r = u - g * per_group;
+        const u32 gl = min(a.group, a.count - g * a.group);        // images in this group (the last one may be short)
+        const u32 band = r / gl;
+        const int img = (int)(g * a.group + (r - band * gl));
+        const uint8_t* raw = image_raw(a, img);
+        uint8_t* D = image_rows(a, img);
+        u32* prog = a.qstate + QSTATE_HDR + (size_t)img * a.nbands;
+        const u32 row = band * 64 + lane;
+        const bool row_live = row < a.rows;
+        u32 f = row_live ? raw[(int64_t)row * (a.wb + 1)] : 0;
+        if (f > 4) { if (a.status) atomicOr(a.status + img, 1u); f = 0; }
+        u32* st = a.status ? a.status + img : nullptr;
+        if (__any(f == 4)) defilter_band_ring<FB, W, true,  RGBA, true>(a, raw, D, prog, tiles[wave], band, wave, lane, niter, f, row_live, st);
+        else               defilter_band_ring<FB, W, false, RGBA, true>(a, raw, D, prog, tiles[wave], band, wave, lane, niter, f, row_live, st);
     }
 }
 
@@ -831,12 +944,12 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
     // asynchronous and may be called from one thread on several streams, so every (thread, stream) pair owns its scratch:
     // launches on one stream are ordered, launches on different streams never share a buffer.  Growing a scratch waits for
     // ITS stream only (the buffer may still be in use there) -- never for the device.
-    struct StreamScratch { hipStream_t stream; void* p; size_t cap; };
+    struct StreamScratch { hipStream_t stream; int kind; void* p; size_t cap; };      // kind 0: de-filtered rows, 1: queue state
     static thread_local std::vector<StreamScratch> scratches;
-    auto scratch_get = [&](size_t n) -> void* {
+    auto scratch_get = [&](size_t n, int kind = 0) -> void* {
         StreamScratch* e = nullptr;
-        for (StreamScratch& c : scratches) if (c.stream == stream) { e = &c; break; }
-        if (!e) { scratches.push_back(StreamScratch{ stream, nullptr, 0 }); e = &scratches.back(); }
+        for (StreamScratch& c : scratches) if (c.stream == stream && c.kind == kind) { e = &c; break; }
+        if (!e) { scratches.push_back(StreamScratch{ stream, kind, nullptr, 0 }); e = &scratches.back(); }
         if (n > e->cap) {
             if (e->p) { (void)hipStreamSynchronize(stream); (void)hipFree(e->p); e->p = nullptr; e->cap = 0; }
             const size_t want = n + n / 4 + 4096;
@@ -859,6 +972,46 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
     // alone keeps one workgroup busy for 34 bands in turn).  Which rows qualify is data: the workgroups find out (take_segment).
     u32 nseg = 1;
     if (count < 512 && y >= 256) { nseg = 1024u / (u32)count; nseg = nseg > 8 ? 8 : nseg; while (nseg > 1 && y / nseg < 128) --nseg; }
+    // From a few hundred bands on, the bands of the whole batch go through one work queue instead (k_png_defilter_queue):
+    // every wave slot of the chip stays busy until the batch ends, and it does not depend on the filters.
+    // GAMUT_HIP_PNG_QUEUE=0 / 1 forces the choice (measurements, tests).
+    const u32 nbands = (y + 63) / 64;
+    int dev = 0, cus = 0;
+    GAMUT_HIP_CHECK(hipGetDevice(&dev));
+    GAMUT_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    // One workgroup per image keeps a compute unit for ceil(bands / 8) rounds of bands, and the images take ceil(count / CUs)
+    // rounds of workgroups; the queue needs count * bands / (8 CUs) rounds.  It takes over when that is clearly less (measured:
+    // 341 x 1080p +23 %, 64 x 4K 2.3 x; 512 x 4K, 10 rounds against 8.5, is a draw -- the last of one workgroup's rounds runs on idle
+    // SIMDs and therefore faster).
+    const char* queue_env = getenv("GAMUT_HIP_PNG_QUEUE");       // read per call: tests flip it
+    const uint64_t units = (uint64_t)count * nbands;
+    const double rounds_wg = (double)(((uint64_t)count + cus - 1) / cus) * ((nbands + PNG_WAVES - 1) / PNG_WAVES);
+    const double rounds_q = (double)units / ((double)cus * PNG_WAVES);
+    bool queue = wb >= 16 && (int64_t)a.d_pitch * 64 < (1ll << 31) && units < (1ull << 31) &&
+                 (queue_env && *queue_env ? atoi(queue_env) != 0 : units >= 1024 && rounds_wg > 1.25 * rounds_q);
+    if (queue) {
+        const size_t words = QSTATE_HDR + (size_t)count * nbands;
+        a.qstate = (u32*)scratch_get(words * 4, 1);
+        if (!a.qstate) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png_defilter: queue state allocation failed");
+        GAMUT_HIP_CHECK(hipMemsetAsync(a.qstate, 0, words * 4, stream));
+        a.count = (u32)count; a.nbands = nbands; a.nseg = 1;
+        // group: images whose bands are dealt out side by side (band-major inside a group).  The whole batch: band b + 1 of an image is
+        // then drawn count draws after band b, by when band b has the ~90 trips of head start band b + 1 needs (groups of 128 of
+        // 512 4K images: waves queue up behind their producers, -25 %).  GAMUT_HIP_PNG_GROUP overrides (measurements).
+        const char* group_env = getenv("GAMUT_HIP_PNG_GROUP");
+        const u32 group = group_env && atoi(group_env) > 0 ? (u32)atoi(group_env) : (u32)count;
+        const u32 ngroups = ((u32)count + group - 1) / group;
+        a.group = ((u32)count + ngroups - 1) / ngroups;              // equal groups
+        const unsigned wgs = (unsigned)std::min<uint64_t>((uint64_t)cus, (units + PNG_WAVES - 1) / PNG_WAVES);
+        const dim3 qgrid(wgs), qblock(PNG_WAVES * 64);
+        if (rgba_fused) hipLaunchKernelGGL((k_png_defilter_queue<3, PNG_WAVES, 2, true>), qgrid, qblock, 0, stream, a);
+        else switch (FB) {
+#define GAMUT_PNG_CASE(N) case N: hipLaunchKernelGGL((k_png_defilter_queue<N, PNG_WAVES, 2>), qgrid, qblock, 0, stream, a); break;
+        GAMUT_PNG_CASE(1) GAMUT_PNG_CASE(2) GAMUT_PNG_CASE(3) GAMUT_PNG_CASE(4) GAMUT_PNG_CASE(6) GAMUT_PNG_CASE(8)
+#undef GAMUT_PNG_CASE
+        default: return set_error(GAMUT_HIP_ERR_INVALID_ARG, "png_defilter: unsupported filter unit %d", FB);
+        }
+    } else {
     a.nseg = nseg;
     const dim3 grid(nseg > 1 ? nseg : (unsigned)count, nseg > 1 ? (unsigned)count : 1u), block(PNG_WAVES * 64);
     // rows of at least one 16-byte piece: the LDS-ring kernel (coalesced, aligned I/O); 8 waves per workgroup, register
@@ -872,6 +1025,7 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
     GAMUT_PNG_CASE(1) GAMUT_PNG_CASE(2) GAMUT_PNG_CASE(3) GAMUT_PNG_CASE(4) GAMUT_PNG_CASE(6) GAMUT_PNG_CASE(8)
 #undef GAMUT_PNG_CASE
     default: return set_error(GAMUT_HIP_ERR_INVALID_ARG, "png_defilter: unsupported filter unit %d", FB);
+    }
     }
     if (int rc = launch_status("png_defilter")) return rc;
     if (!fused) {

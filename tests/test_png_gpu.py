@@ -55,12 +55,25 @@ def gpu_defilter(L, raw, x, y, img_n, out_n, depth, color, count=1, raw_stride=0
     return outs
 
 
+@pytest.fixture(params=["workgroups", "queue"])
+def launch_mode(request):
+    """the two launch shapes of the ring kernels (png.hip): one workgroup per image / row segment, or every (image, band) unit
+    of the batch through the device-wide work queue (the launcher's own rule picks the queue for large, badly dividing batches)"""
+    old = os.environ.get("GAMUT_HIP_PNG_QUEUE")
+    os.environ["GAMUT_HIP_PNG_QUEUE"] = "1" if request.param == "queue" else "0"
+    yield request.param
+    if old is None:
+        del os.environ["GAMUT_HIP_PNG_QUEUE"]
+    else:
+        os.environ["GAMUT_HIP_PNG_QUEUE"] = old
+
+
 FORMATS = [(1, 1, 0), (1, 2, 0), (1, 4, 0), (1, 8, 0), (1, 16, 0), (2, 8, 4), (2, 16, 4), (3, 8, 2), (3, 16, 2), (4, 8, 6), (4, 16, 6),
            (1, 1, 3), (1, 2, 3), (1, 4, 3), (1, 8, 3)]
 
 
 @pytest.mark.parametrize("img_n,depth,color", FORMATS)
-def test_defilter_formats_filters_sizes(hip, img_n, depth, color):
+def test_defilter_formats_filters_sizes(hip, launch_mode, img_n, depth, color):
     rng = np.random.default_rng(depth * 10 + img_n)
     fb = 1 if depth < 8 else img_n * (2 if depth == 16 else 1)
     for (x, y) in [(1, 1), (2, 3), (5, 2), (7, 5), (37, 70), (64, 65), (130, 129), (259, 67), (33, 1100)]:
@@ -118,7 +131,48 @@ def test_row_segments_of_small_batches(hip, img_n, out_n, color):
             assert np.array_equal(got[i], exps[i]), (x, y, i)
 
 
-def test_batch_and_corrupt_filter(hip):
+@pytest.mark.parametrize("img_n,out_n,depth,color,x,y", [(4, 4, 8, 6, 333, 647), (3, 4, 8, 2, 333, 647), (3, 3, 8, 2, 171, 700), (2, 2, 16, 4, 150, 333),
+                                                         (4, 4, 16, 6, 67, 1100), (1, 1, 8, 0, 2048, 200)])
+def test_work_queue_batches(hip, img_n, out_n, depth, color, x, y):
+    """k_png_defilter_queue: 300 images (more (image, band) units than the chip has wave slots) whose bands run at very different
+    speeds -- rows all None next to rows all Paeth, so consumers catch up with their producers and wait on them -- ragged widths,
+    a partial last band, chains of Up / Avg / Paeth rows that never cut; the hand-off of a band's last row goes from whichever
+    compute unit drew the band above to whichever drew this one.  Every image is checked byte for byte, three launches in a row
+    (the queue state is re-zeroed by every launch), then once more under the launcher's own rule."""
+    rng = np.random.default_rng(img_n * 100 + depth)
+    fb = img_n * (2 if depth == 16 else 1)
+    kinds = [np.full(y, 4, np.uint8), np.full(y, 0, np.uint8), np.full(y, 2, np.uint8), np.full(y, 3, np.uint8), rng.integers(0, 5, y).astype(np.uint8),
+             rng.integers(2, 5, y).astype(np.uint8), np.where(np.arange(y) % 64 == 63, 4, 1).astype(np.uint8)]
+    raws, exps = [], []
+    for filt in kinds:
+        rows = gen.pack_samples(rng.integers(0, 1 << depth, (y, x * img_n)), depth)
+        raw = gen.png_forward_filter(rows, fb, filt)
+        raws.append(raw); exps.append(O.png_create_image_raw(raw, img_n, out_n, x, y, depth, color))
+    n = 300
+    stride = raws[0].size + 3
+    order = rng.integers(0, len(kinds), n)
+    order[:len(kinds)] = np.arange(len(kinds))
+    batch = np.zeros(n * stride, np.uint8)
+    for i, k in enumerate(order):
+        batch[i * stride:i * stride + raws[k].size] = raws[k]
+    old = os.environ.get("GAMUT_HIP_PNG_QUEUE")
+    try:
+        for mode in ("1", "1", "1", None):
+            if mode is None:
+                os.environ.pop("GAMUT_HIP_PNG_QUEUE", None)
+            else:
+                os.environ["GAMUT_HIP_PNG_QUEUE"] = mode
+            got = gpu_defilter(hip, batch, x, y, img_n, out_n, depth, color, count=n, raw_stride=stride)
+            bad = [i for i in range(n) if not np.array_equal(got[i], exps[order[i]])]
+            assert not bad, f"mode {mode}: images {bad[:10]} differ (filters of the first: {np.unique(kinds[order[bad[0]]])})"
+    finally:
+        if old is None:
+            os.environ.pop("GAMUT_HIP_PNG_QUEUE", None)
+        else:
+            os.environ["GAMUT_HIP_PNG_QUEUE"] = old
+
+
+def test_batch_and_corrupt_filter(hip, launch_mode):
     rng = np.random.default_rng(12)
     x, y, n = 61, 150, 4
     stride = (x * 4 + 1) * y + 13
@@ -224,7 +278,7 @@ def test_generated_png_files(hip):
 
 
 @pytest.mark.parametrize("img_n,out_n,x,y", [(3, 4, 3, 70001), (1, 1, 70003, 2), (4, 4, 5, 66000), (2, 2, 33, 65537)])
-def test_extreme_geometry(hip, img_n, out_n, x, y):
+def test_extreme_geometry(hip, launch_mode, img_n, out_n, x, y):
     """more rows than a grid dimension holds (65535), rows of one piece or less, very wide two-row images"""
     rng = np.random.default_rng(x + y)
     px = rng.integers(0, 256, (y, x * img_n)).astype(np.uint8)

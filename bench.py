@@ -38,12 +38,13 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1024, help="images per GPU per step")
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=0, help="default: the BASELINE.json geometry of the workload (1920 x 1080 JPEG / mixed, 3840 x 2160 PNG, 8192 x 8192 convert)")
+    ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--workload", default="jpeg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the live rocprofv3 --pmc passes (roofline.traffic falls back to profiles/)")
+    ap.add_argument("--serial-formats", action="store_true", help="mixed workload: one stream, one format after the other")
     ap.add_argument("--total-images", type=int, default=0, help="mixed workload: images over ALL ranks (8192 = BASELINE.json configs[4]); "
                     "each rank takes total / N (strong scaling) instead of --batch")
     ap.add_argument("--gather", action="store_true", help="N > 1: also time an all_gather of output slices (after the timed region)")
@@ -159,7 +160,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     # ------------------------------------------------------------------ workload
-    w, h, B = args.width, args.height, args.batch
+    w, h, B = args.width or 1920, args.height or 1080, args.batch
     wl = args.workload
     check = None
     _host = {}                                                   # host copies of the cpu_baseline sample (made once, shared by the threads)
@@ -208,7 +209,7 @@ def main():
         _, s, d = wl.split(":")
         st, dt_ = O.PT[s], O.PT[d]
         B = args.batch if args.batch != 1024 else 8
-        w = h = 8192 if (args.width, args.height) == (1920, 1080) else args.width
+        w = h = args.width or 8192
         npx = w * h
         g = torch.Generator(device=dev); g.manual_seed(7 + rank)
         sdt = O.PT_DTYPE[st]
@@ -264,7 +265,7 @@ def main():
         on = int(parts[3]) if len(parts) > 3 else ch           # out_n: ch or ch + 1 (alpha inserted, stbdec.d:1467-1480)
         if policy.isdigit():
             policy = int(policy)
-        if (args.width, args.height) == (1920, 1080):
+        if not (args.width and args.height):
             w, h = 3840, 2160
         B = args.batch if args.batch != 1024 else 512
         raw, sums = synth.png_raw_batch(B, w, h, dev, seed=3 + rank, policy=policy, channels=ch)
@@ -337,23 +338,42 @@ def main():
         bytes_per_step = sum(fmt_bytes.values())
         kernel_name = "k_jpeg_h2v2 + k_png_defilter + k_qoi_decode"
         workload = (f"mixed batch of {B} x {w}x{h} images -> rgba8, image i: JPEG 4:2:0 / PNG RGBA8 / QOI RGB by i % 3 "
-                    f"({nj} + {npn} + {nq}); QOI is decoded one wave per file (only its INDEX ops are serial) and still bounds the step")
+                    f"({nj} + {npn} + {nq}); the QOI launch (a few waves per file, only its INDEX ops are serial) bounds the step"
+                    + ("" if args.serial_formats else " and runs on a second stream beside the JPEG and PNG launches"))
         fmt_ev = {k: [] for k in ("jpeg", "png", "qoi")}
         img = h * w * 4
 
+        # The QOI launch keeps a few waves per file busy for as long as its serial walk takes and leaves most of the chip idle: it
+        # goes out first, on a second HIP stream, and the JPEG and PNG launches run beside it on the caller's stream, which then
+        # waits for it (--serial-formats: one stream, one format after the other, as in round 1).
+        main_stream = torch.cuda.current_stream()
+        side = None if args.serial_formats else torch.cuda.Stream()
+        q_stream = stream if side is None else side.cuda_stream
+
         def step():
-            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+            if side is not None:
+                side.wait_stream(main_stream)
+                e[3].record(side)
+                if nq:
+                    _capi.check(L.gamut_hip_qoi_decode_resident_device(blob.data_ptr(), blob.numel(), q_begin.ctypes.data_as(C.POINTER(C.c_int64)), q_size.ctypes.data_as(C.POINTER(C.c_int)),
+                                                                       q_descs, nq, 4, q_off.ctypes.data_as(C.POINTER(C.c_int64)), out.data_ptr(), q_stream))
+                e[4].record(side)
             e[0].record()
             _capi.check(L.gamut_hip_jpeg_reconstruct_batch_device(coeffs.data_ptr(), nblk * 64, None, 0, out.data_ptr(), w * 4, 3 * img, w, h, 4, 4, nj, stream))
             e[1].record()
             if npn:
                 _capi.check(L.gamut_hip_png_defilter_batch_device(raw.data_ptr(), raw_len, raw_len, out.data_ptr() + img, 3 * img, w, h, 4, 4, 8, 6, npn, status.data_ptr(), stream))
             e[2].record()
-            if nq:
-                _capi.check(L.gamut_hip_qoi_decode_resident_device(blob.data_ptr(), blob.numel(), q_begin.ctypes.data_as(C.POINTER(C.c_int64)), q_size.ctypes.data_as(C.POINTER(C.c_int)),
-                                                                   q_descs, nq, 4, q_off.ctypes.data_as(C.POINTER(C.c_int64)), out.data_ptr(), stream))
-            e[3].record()
-            for k, (a, b) in zip(("jpeg", "png", "qoi"), zip(e[:-1], e[1:])):
+            if side is None:
+                e[3].record()
+                if nq:
+                    _capi.check(L.gamut_hip_qoi_decode_resident_device(blob.data_ptr(), blob.numel(), q_begin.ctypes.data_as(C.POINTER(C.c_int64)), q_size.ctypes.data_as(C.POINTER(C.c_int)),
+                                                                       q_descs, nq, 4, q_off.ctypes.data_as(C.POINTER(C.c_int64)), out.data_ptr(), stream))
+                e[4].record()
+            else:
+                main_stream.wait_stream(side)
+            for k, (a, b) in zip(("jpeg", "png", "qoi"), ((e[0], e[1]), (e[1], e[2]), (e[3], e[4]))):
                 fmt_ev[k].append((a, b))
 
         def check():
@@ -479,6 +499,7 @@ def main():
             res["gather"] = gather
         if wl == "mixed":
             torch.cuda.synchronize()
+            res["config"]["formats_overlap"] = not args.serial_formats      # per-format times then overlap (QOI on its own stream)
             res["config"]["per_format"] = {}
             for k, cnt in (("jpeg", nj), ("png", npn), ("qoi", nq)):
                 ms = float(np.mean([a.elapsed_time(b) for a, b in fmt_ev[k][-args.steps:]])) if fmt_ev[k] else 0.0

@@ -372,18 +372,6 @@ int read_header(const uint8_t* data, int size, gamut_hip_qoi_desc* d, int channe
 }
 
 
-// upload the item table and decode; returns when the decode has finished (the pageable item vector dies with the call)
-int launch_items(const std::vector<QoiItem>& items, uint8_t* d_items, const uint8_t* d_blob, uint8_t* d_out, hipStream_t stream)
-{
-    const int n = (int)items.size();
-    GAMUT_HIP_CHECK(hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(QoiItem), hipMemcpyHostToDevice, stream));
-    if (n < kQoiWideBelow) hipLaunchKernelGGL(k_qoi_decode<4>, dim3(n), dim3(256), 0, stream, (const QoiItem*)d_items, n, d_blob, d_out);
-    else                   hipLaunchKernelGGL(k_qoi_decode<1>, dim3(n), dim3(64), 0, stream, (const QoiItem*)d_items, n, d_blob, d_out);
-    if (int rc = launch_status("qoi_decode")) return rc;
-    GAMUT_HIP_CHECK(hipStreamSynchronize(stream));
-    return GAMUT_HIP_OK;
-}
-
 int decode_batch(const uint8_t* const* data, const int* size, int count, int channels, const int64_t* out_offset, uint8_t* d_out,
                  gamut_hip_qoi_desc* descs, int* status_host, hipStream_t stream)
 {
@@ -489,10 +477,39 @@ int gamut_hip_qoi_decode_resident_device(const uint8_t* blob, int64_t blob_len, 
             it.npx = d.width * d.height; it.channels = channels ? channels : d.channels;
             items[(size_t)i] = it;
         }
-        static thread_local DeviceScratch table;
-        uint8_t* d_items = (uint8_t*)table.get(items.size() * sizeof(QoiItem));
-        if (!d_items) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "qoi: device allocation of the item table failed");
-        return launch_items(items, d_items, blob, out, pick_stream(stream));
+        // Asynchronous on `stream` (the files are resident: nothing here needs the host to wait).  The item table goes up through
+        // one of four per-thread (pinned, device) slot pairs; a slot is taken again four calls later, after its event -- recorded
+        // behind the kernel that read it -- has passed.
+        struct TableSlot { uint8_t* h = nullptr; uint8_t* d = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false; };
+        static thread_local TableSlot slots[4];
+        static thread_local unsigned next_slot = 0;
+        TableSlot& sl = slots[next_slot++ & 3u];
+        if (!sl.done) GAMUT_HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        if (sl.busy) { GAMUT_HIP_CHECK(hipEventSynchronize(sl.done)); sl.busy = false; }
+        const size_t bytes = items.size() * sizeof(QoiItem);
+        if (bytes > sl.cap) {
+            if (sl.h) (void)hipHostFree(sl.h);
+            if (sl.d) (void)hipFree(sl.d);
+            sl.h = sl.d = nullptr; sl.cap = 0;
+            const size_t want = bytes + bytes / 4 + 4096;
+            void* hp = nullptr; void* dp = nullptr;
+            if (hipHostMalloc(&hp, want, hipHostMallocDefault) != hipSuccess || hipMalloc(&dp, want) != hipSuccess) {
+                if (hp) (void)hipHostFree(hp);
+                (void)hipGetLastError();
+                return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "qoi: allocation of the item table failed");
+            }
+            sl.h = (uint8_t*)hp; sl.d = (uint8_t*)dp; sl.cap = want;
+        }
+        memcpy(sl.h, items.data(), bytes);
+        hipStream_t st = pick_stream(stream);
+        GAMUT_HIP_CHECK(hipMemcpyAsync(sl.d, sl.h, bytes, hipMemcpyHostToDevice, st));
+        const int n = (int)items.size();
+        if (n < kQoiWideBelow) hipLaunchKernelGGL(k_qoi_decode<4>, dim3(n), dim3(256), 0, st, (const QoiItem*)sl.d, n, blob, out);
+        else                   hipLaunchKernelGGL(k_qoi_decode<1>, dim3(n), dim3(64), 0, st, (const QoiItem*)sl.d, n, blob, out);
+        if (int rc = launch_status("qoi_decode")) return rc;
+        GAMUT_HIP_CHECK(hipEventRecord(sl.done, st));
+        sl.busy = true;
+        return GAMUT_HIP_OK;
     } catch (...) {
         return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "qoi_decode_resident_device: out of host memory");
     }

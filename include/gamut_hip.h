@@ -290,7 +290,8 @@ int   gamut_hip_qoi_decode_batch_device(const uint8_t* const* data, const int* s
                                         const int64_t* out_offset, uint8_t* out, gamut_hip_qoi_desc* descs, int* status_host, void* stream);
 /* the same decode for files that are already resident in HBM (a device-side file cache; bench.py's mixed workload): file i
  * is blob[begin[i] .. begin[i] + size[i]) and must be followed by GAMUT_HIP_QOI_SLACK readable bytes inside the blob (the
- * lanes read whole 64-byte blocks); begin / size / descs (from gamut_hip_qoi_read_header) / out_offset are host arrays. */
+ * lanes read whole 64-byte blocks); begin / size / descs (from gamut_hip_qoi_read_header) / out_offset are host arrays,
+ * read before the call returns.  Asynchronous on `stream`, like the other device entry points. */
 #define GAMUT_HIP_QOI_SLACK 160
 int   gamut_hip_qoi_decode_resident_device(const uint8_t* blob, int64_t blob_len, const int64_t* begin, const int* size,
                                            const gamut_hip_qoi_desc* descs, int count, int channels, const int64_t* out_offset,

@@ -172,6 +172,7 @@ def batch_cases():
     b = np.array(begin, np.int64); sz = np.array([len(f) for f in files], np.int32)
     _capi.check(L.gamut_hip_qoi_decode_resident_device(dblob, blob.size, b.ctypes.data_as(C.POINTER(C.c_int64)), sz.ctypes.data_as(C.POINTER(C.c_int)), descs, len(files), 4,
                                                        offs.ctypes.data_as(C.POINTER(C.c_int64)), dout, None))
+    _capi.check(L.gamut_hip_stream_synchronize(None))
     free_all(); n += 1
     # baseline JPEG files: coefficients and max_zag of the whole batch end with their allocations
     jf = [open(p_, "rb").read() for p_ in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "jpeg", "*.jpg"))) if not os.path.basename(p_).startswith("p_")]

@@ -34,6 +34,7 @@ for name, pool in (("spec-encoder streams", files[:ND]), ("all-RGB-op stream", f
             torch.cuda.synchronize(); t0 = time.perf_counter()
             _capi.check(L.gamut_hip_qoi_decode_resident_device(blob.data_ptr(), blob.numel(), b_arr.ctypes.data_as(C.POINTER(C.c_int64)), s_arr.ctypes.data_as(C.POINTER(C.c_int)),
                                                                descs, B, 4, offs.ctypes.data_as(C.POINTER(C.c_int64)), out.data_ptr(), None))
+            torch.cuda.synchronize()                                   # the call is asynchronous
             dt = time.perf_counter() - t0
         prof = getattr(C.CDLL(_capi.LIB_PATH), "gamut_hip_qoi_profile", None)
         if prof:

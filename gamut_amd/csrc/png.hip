@@ -112,45 +112,60 @@ __device__ __forceinline__ u32 add_bytes(u32 x, u32 y)
 // bytewise floor((a + b) / 2), the Avg predictor (9-bit sum, stbdec.d:1497)
 __device__ __forceinline__ u32 avg_bytes(u32 a, u32 b)
 {
-    return (a & b) + (((a ^ b) & 0xfefefefeu) >> 1);
+    return (a & b) + (__builtin_amdgcn_bitop3_b32(a, b, 0xfefefefeu, 0x28) >> 1);       // 0x28: (a ^ b) & c in one instruction
 }
 // ---- stbi__paeth (stbdec.d:1390-1401) on two channels at once, in packed FP16 ---------------------------------
 // A byte n is carried as the half-precision number 1024 + n, whose bit pattern is simply 0x6400 | n (ulp = 1 in
 // [1024, 2048)), so bytes <-> halves are single v_perm_b32 byte shuffles.  All differences (|.| <= 510), the 0/1
 // selectors and the selected value are small integers, exact in FP16; the bias cancels in every difference.
-// FP16 buys free negation (VOP3P neg modifiers: |t| = max(t, -t) is one instruction) and a free 0/1 step
-// (the clamp modifier on an integer-valued difference), 12 packed instructions per channel pair.  Written as inline
-// asm: the optimizer otherwise rewrites the 0/1 arithmetic into per-channel compares and selects (3x the count).
+// FP16 buys free negation (VOP3P neg modifiers: |t| = max(t, -t) is one instruction): 9 packed instructions per channel
+// pair up to the two differences whose signs decide.  Written as inline asm: the optimizer otherwise rewrites the
+// arithmetic into per-channel compares and selects (3x the count).
 #define PKF2(name, text) __device__ __forceinline__ u32 name(u32 x, u32 y) { u32 r; asm(text : "=v"(r) : "v"(x), "v"(y)); return r; }
 PKF2(pkf_add,       "v_pk_add_f16 %0, %1, %2")
 PKF2(pkf_sub,       "v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]")
-PKF2(pkf_step,      "v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1] clamp")          // x > y ? 1 : 0  (integers)
 PKF2(pkf_min,       "v_pk_min_f16 %0, %1, %2")
 #undef PKF2
 __device__ __forceinline__ u32 pkf_abs(u32 t) { u32 r; asm("v_pk_max_f16 %0, %1, %1 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(t)); return r; }
-__device__ __forceinline__ u32 pkf_fma(u32 x, u32 y, u32 z) { u32 r; asm("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z)); return r; }
-__device__ __forceinline__ u32 pkf_fnma(u32 x, u32 y, u32 z) { u32 r; asm("v_pk_fma_f16 %0, %1, %2, %3 neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(r) : "v"(x), "v"(y), "v"(z)); return r; }
-// one whole pixel packed in a dword; the two channel pairs (L: bytes 0,1  H: bytes 2,3) are written interleaved so that
-// no packed instruction consumes the result of the one just before it (gfx950 needs a wait state there).
-__device__ __forceinline__ u32 paeth_bytes(u32 a, u32 b, u32 c)
+// The predictor of ANY row of a band that has Paeth rows, four channels at once.  The two comparisons of stbi__paeth (in the
+// order libpng evaluates them: "pb < pa ? b : a", then "pc < min(pa, pb) ? c : that" -- the same choice, ties included)
+// are differences whose SIGN is the answer, and v_perm_b32 can fill a byte with the sign bit of a half (selectors 8..11):
+// one permute per comparison turns the four signs into a byte mask, and the selection runs on the packed pixels themselves
+// (two v_bfi for four channels).  The permute's selector is a per-lane register, so the other filters ride along for free:
+// their rows use constant selectors (0x0c = 0x00, 0x0d = 0xff) that force the masks -- Sub: (0, 0) -> a; Up: (ff, 0) -> b;
+// Avg / None: (.., ff) -> the third candidate, which is c for Paeth rows, avg(a, b) for Avg rows and 0 for None rows.
+// The two channel pairs (L: bytes 0,1  H: bytes 2,3) are written interleaved so that no packed instruction consumes the
+// result of the one just before it (gfx950 needs a wait state there).
+struct RowFilter { u32 mA, mB, mAvg; u32 sel1, sel2; bool paeth, avg; };     // None/Sub/Up/Avg as one masked form; the Paeth-band form
+__device__ __forceinline__ RowFilter row_filter(u32 f)
+{
+    const u32 SIGNS = 0x0b0a0908u, ZERO = 0x0c0c0c0cu, ONES = 0x0d0d0d0du, FF = 0xFFFFFFFFu;
+    RowFilter r;
+    r.mA = f == 1 ? FF : 0u; r.mB = f == 2 ? FF : 0u; r.mAvg = f == 3 ? FF : 0u;
+    r.sel1 = f == 4 ? SIGNS : f == 2 ? ONES : ZERO;
+    r.sel2 = f == 4 ? SIGNS : (f == 0 || f == 3) ? ONES : ZERO;
+    r.paeth = f == 4; r.avg = f == 3;
+    return r;
+}
+__device__ __forceinline__ u32 bfi(u32 m, u32 x, u32 y) { return (m & x) | (~m & y); }              // m ? x : y, bit by bit
+__device__ __forceinline__ u32 paeth_band_pred(const RowFilter& f, u32 a, u32 b, u32 c)
 {
     const u32 BIAS = 0x64646464u, LO = 0x04010400u, HI = 0x04030402u;                   // bytes -> halves 0x64nn
     const u32 aL = __builtin_amdgcn_perm(BIAS, a, LO), aH = __builtin_amdgcn_perm(BIAS, a, HI);
     const u32 bL = __builtin_amdgcn_perm(BIAS, b, LO), bH = __builtin_amdgcn_perm(BIAS, b, HI);
-    const u32 cL = __builtin_amdgcn_perm(BIAS, c, LO), cH = __builtin_amdgcn_perm(BIAS, c, HI);
+    const u32 cL = __builtin_amdgcn_perm(BIAS, c, LO), cH = __builtin_amdgcn_perm(BIAS, c, HI);   // = the b of the pixel before: no new instruction
     const u32 t1L = pkf_sub(bL, cL),        t1H = pkf_sub(bH, cH);
     const u32 t2L = pkf_sub(aL, cL),        t2H = pkf_sub(aH, cH);
     const u32 paL = pkf_abs(t1L),           paH = pkf_abs(t1H);                         // |p - a|   (p = a + b - c)
     const u32 t3L = pkf_add(t1L, t2L),      t3H = pkf_add(t1H, t2H);
     const u32 pbL = pkf_abs(t2L),           pbH = pkf_abs(t2H);                         // |p - b|
     const u32 pcL = pkf_abs(t3L),           pcH = pkf_abs(t3H);                         // |p - c|
-    const u32 mL  = pkf_min(pbL, pcL),      mH  = pkf_min(pbH, pcH);
-    const u32 k2L = pkf_step(pbL, pcL),     k2H = pkf_step(pbH, pcH);                   // 1: c over b (pb > pc)
-    const u32 kL  = pkf_step(paL, mL),      kH  = pkf_step(paH, mH);                    // 1: not a   (pa > min(pb, pc))
-    const u32 bcL = pkf_fnma(k2L, t1L, bL), bcH = pkf_fnma(k2H, t1H, bH);               // b + k2 * (c - b)
-    const u32 sL  = pkf_sub(bcL, aL),       sH  = pkf_sub(bcH, aH);
-    const u32 pL  = pkf_fma(kL, sL, aL),    pH  = pkf_fma(kH, sH, aH);                  // a + k * (bc - a)
-    return __builtin_amdgcn_perm(pH, pL, 0x06040200u);                                  // low bytes of the four halves
+    const u32 d1L = pkf_sub(pbL, paL),      d1H = pkf_sub(pbH, paH);                    // < 0: b over a
+    const u32 mL  = pkf_min(paL, pbL),      mH  = pkf_min(paH, pbH);
+    const u32 d2L = pkf_sub(pcL, mL),       d2H = pkf_sub(pcH, mH);                     // < 0: c over either  (x - x = +0: ties keep)
+    const u32 m1 = __builtin_amdgcn_perm(d1H, d1L, f.sel1), m2 = __builtin_amdgcn_perm(d2H, d2L, f.sel2);
+    const u32 third = f.paeth ? c : f.avg ? avg_bytes(a, b) : 0u;
+    return bfi(m2, third, bfi(m1, b, a));
 }
 
 // 4 bytes of the 16-byte piece v[0..3] starting at byte offset O (bytes past the piece read as zero)
@@ -170,14 +185,11 @@ template <int O> __device__ __forceinline__ u32 stream_at(const u32 (&prev)[4], 
     else { const u32 hi = (k + 1) < 4 ? prev[k + 1] : cur[k + 1 - 4]; return __builtin_amdgcn_alignbyte(hi, lo, sh); }
 }
 
-struct RowFilter { u32 mA, mB, mAvg; bool paeth; };     // None/Sub/Up/Avg as one masked form + "this row is Paeth"
-
 template <bool PAETH>
 __device__ __forceinline__ u32 defilter4(const RowFilter& f, u32 x, u32 a, u32 b, u32 c)      // four bytes at once
 {
-    u32 pred = (a & f.mA) | (b & f.mB) | (avg_bytes(a, b) & f.mAvg);
-    if constexpr (PAETH) { const u32 pp = paeth_bytes(a, b, c); pred = f.paeth ? pp : pred; }
-    return add_bytes(x, pred);
+    if constexpr (PAETH) return add_bytes(x, paeth_band_pred(f, a, b, c));
+    else                 return add_bytes(x, (a & f.mA) | (b & f.mB) | (avg_bytes(a, b) & f.mAvg));
 }
 
 // De-filter one 16-byte piece of a row (stbdec.d:1484-1503, any filter unit FB = bytes per pixel): rg = raw bytes,
@@ -465,11 +477,10 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
     typedef u32 u32x4 __attribute__((ext_vector_type(4)));
     const u32 seq = Q ? 0u : band / W;
     const u32 row = band * 64 + lane;
-    const RowFilter rf = { f == 1 ? 0xFFFFFFFFu : 0u, f == 2 ? 0xFFFFFFFFu : 0u, f == 3 ? 0xFFFFFFFFu : 0u, f == 4 };
+    const RowFilter rf = row_filter(f);
 
     uint8_t* drow = D + (int64_t)(row_live ? row : 0) * a.d_pitch;
     const uint8_t* dprev = band > 0 ? D + (int64_t)(band * 64 - 1) * a.d_pitch : D;
-    const u32 dmask = band > 0 ? 0xFFFFFFFFu : 0u;
     const int prod_wave = (wave + W - 1) % W;
     const u32 prod_base = Q ? 0u : (band > 0 ? (band - 1) / W : 0) * niter;
     u32* const my_flag = Q ? prog + band : prog + wave;
@@ -492,8 +503,9 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
     #pragma unroll
     for (int i = 0; i < PW; ++i) { outp[i] = 0; bprev[i] = 0; }
 
-    // Q: descriptors of the two rows that cross waves -- the row above the band (read) and the band's last row (written)
-    const auto rs_prev = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(dprev), 0, (int)(niter * 16), 0x00020000);
+    // descriptors of the two rows that cross waves -- the row above the band (read) and the band's last row (written, Q).
+    // Band 0 has no row above it: its descriptor is empty, every load through it returns zeros (no mask, no branch).
+    const auto rs_prev = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(dprev), 0, band > 0 ? (int)(niter * 16) : 0, 0x00020000);
     const auto rs_last = __builtin_amdgcn_make_buffer_rsrc(D + (int64_t)(band * 64 + 63) * a.d_pitch, 0, (int)(niter * 16), 0x00020000);
     u32 seen = 0;                                   // Q: the producer's progress as last read (it only grows: most checks cost nothing)
     auto wait_for_band_above = [&](u32 upto) {
@@ -546,10 +558,8 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
     };
     u32x4 dset[PF];
     auto issue_dprev = [&](u32 Tn, u32x4& ds) {
-        // lane 0's iteration is Tn: wave-uniform address.  Band 0 has no row above it (the value is masked): it re-reads the first
-        // 16 bytes of row 0, which always exist -- never an address outside the image
-        const u32 piece = band > 0 ? min(Tn, niter - 1) : 0u;
-        ds = *reinterpret_cast<const u32x4*>(dprev + (int64_t)piece * 16);
+        // lane 0's iteration is Tn: wave-uniform offset (band 0: zeros, see rs_prev)
+        ds = __builtin_amdgcn_raw_buffer_load_b128(rs_prev, min(Tn, niter - 1) * 16u, 0, 0);
     };
     // Q: the row above is in memory (sc1 stores leave no copy in any L2), a round trip of a few microseconds: it is fetched a
     // tile (8 pieces = 128 bytes, one piece per lane 0..7, sc1 loads) ahead, parked in 128 bytes of LDS behind the wave's ring at
@@ -557,7 +567,7 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
     u32x4 chunk = { 0u, 0u, 0u, 0u };
     uint8_t* const dch = ring + 64 * ROW_PITCH;
     auto issue_chunk = [&](u32 Tbase) {
-        const u32 piece = band > 0 ? min(Tbase + (u32)(lane & 7), niter - 1) : 0u;
+        const u32 piece = min(Tbase + (u32)(lane & 7), niter - 1);
         if (lane < 8) chunk = __builtin_amdgcn_raw_buffer_load_b128(rs_prev, piece * 16u, 0, 16);        // sc1: past this CU's L1
     };
 
@@ -585,11 +595,23 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
             if (lane < 8) *reinterpret_cast<u32x4*>(dch + lane * 16) = chunk;      // this tile's pieces of the row above
             issue_chunk(T0 + TT);
         }
-        // drop this tile's raw pieces (prefetched) into the rings, then start fetching the next tile
-        #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const u32 slot = (T0 + (u32)cslot - (u32)(8 * k + crow)) & (RING - 1);
-            *reinterpret_cast<uint4*>(co_ring + k * 8 * ROW_PITCH + slot * 16) = pre[k];
+        // drop this tile's raw pieces (prefetched) into the rings, then start fetching the next tile.  A lane that has not
+        // reached its row yet (iteration < 0: the first 64 trips) finds zeros in its slot: with a zero piece, a zero row above (the
+        // lane below is not there yet either) and a zero pixel to the left every filter yields zeros, which is what the lane
+        // must present to the lane above it and to its own first pixel -- no per-trip masking.
+        if (T0 < 64) {
+            #pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int it = (int)T0 + cslot - (8 * k + crow);
+                const u32 slot = (u32)it & (RING - 1);
+                *reinterpret_cast<uint4*>(co_ring + k * 8 * ROW_PITCH + slot * 16) = it < 0 ? make_uint4(0u, 0u, 0u, 0u) : pre[k];
+            }
+        } else {
+            #pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const u32 slot = (T0 + (u32)cslot - (u32)(8 * k + crow)) & (RING - 1);
+                *reinterpret_cast<uint4*>(co_ring + k * 8 * ROW_PITCH + slot * 16) = pre[k];
+            }
         }
         prefetch_tile(T0 + TT);
         // some lane meets the partial last piece of its row (iteration full_iters, trip full_iters + lane) in this tile
@@ -623,13 +645,13 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
             else             dcur = dset[u % PF];
             if constexpr (RGBA) {       // the chunk of the output row above the band: R,G,B,255 x 4 -> 12 stream bytes
                 const u32x4 d = dcur;
-                bg[0] = from_lane_below(outp[0], __builtin_amdgcn_perm(d[1], d[0], 0x04020100u) & dmask);
-                bg[1] = from_lane_below(outp[1], __builtin_amdgcn_perm(d[2], d[1], 0x05040201u) & dmask);
-                bg[2] = from_lane_below(outp[2], __builtin_amdgcn_perm(d[3], d[2], 0x06050402u) & dmask);
+                bg[0] = from_lane_below(outp[0], __builtin_amdgcn_perm(d[1], d[0], 0x04020100u));
+                bg[1] = from_lane_below(outp[1], __builtin_amdgcn_perm(d[2], d[1], 0x05040201u));
+                bg[2] = from_lane_below(outp[2], __builtin_amdgcn_perm(d[3], d[2], 0x06050402u));
                 bg[3] = 0;
             } else {
                 #pragma unroll
-                for (int i = 0; i < PW; ++i) bg[i] = from_lane_below(outp[i], dcur[i] & dmask);
+                for (int i = 0; i < PW; ++i) bg[i] = from_lane_below(outp[i], dcur[i]);
             }
             if constexpr (!Q) {
                 if (band > 0 && T + PF < niter && ((T + PF) % PUB) == 0) wait_for_band_above(T + PF + PUB);
@@ -646,11 +668,11 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
                 #pragma unroll
                 for (int i = 0; i < PW; ++i) ow[i] = og[i];
             }
-            // a lane that has not reached its row yet (it < 0) must keep presenting zeros to the lane below and to its own
-            // first pixel; past the end of the row (it >= niter) whatever it computes is only seen by lanes that are past
-            // the end of theirs as well, and is never written back
+            // a lane that has not reached its row yet (it < 0) computes zeros from zeros (see the drop above); past the end of
+            // the row (it >= niter) whatever it computes is only seen by lanes that are past the end of theirs as well, and is
+            // never written back
             #pragma unroll
-            for (int i = 0; i < PW; ++i) { outp[i] = it >= 0 ? og[i] : 0u; bprev[i] = bg[i]; }
+            for (int i = 0; i < PW; ++i) { outp[i] = og[i]; bprev[i] = bg[i]; }
             *piece = make_uint4(ow[0], ow[1], ow[2], ow[3]);
             if (rag_tile && a.store_tail_masked) {   // partial piece of an exact-size destination row (wb % 4 == 0 there): up to three
                 u32* dst = reinterpret_cast<u32*>(drow + (int64_t)(ragged ? it : 0) * 16);      // dword stores straight to the row
@@ -982,13 +1004,14 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
     // One workgroup per image keeps a compute unit for ceil(bands / 8) rounds of bands, and the images take ceil(count / CUs)
     // rounds of workgroups; the queue needs count * bands / (8 CUs) rounds.  It takes over when that is clearly less (measured:
     // 341 x 1080p +23 %, 64 x 4K 2.3 x; 512 x 4K, 10 rounds against 8.5, is a draw -- the last of one workgroup's rounds runs on idle
-    // SIMDs and therefore faster).
+    // SIMDs and therefore faster).  With fewer than two workgroups per compute unit nothing hides the hand-off latency between the
+    // waves of one image's pipeline (256 x 4K: 202 k Mpx/s against 550 k through the queue, 365 k / 416 k with random filters).
     const char* queue_env = getenv("GAMUT_HIP_PNG_QUEUE");       // read per call: tests flip it
     const uint64_t units = (uint64_t)count * nbands;
     const double rounds_wg = (double)(((uint64_t)count + cus - 1) / cus) * ((nbands + PNG_WAVES - 1) / PNG_WAVES);
     const double rounds_q = (double)units / ((double)cus * PNG_WAVES);
     bool queue = wb >= 16 && (int64_t)a.d_pitch * 64 < (1ll << 31) && units < (1ull << 31) &&
-                 (queue_env && *queue_env ? atoi(queue_env) != 0 : units >= 1024 && rounds_wg > 1.25 * rounds_q);
+                 (queue_env && *queue_env ? atoi(queue_env) != 0 : units >= 1024 && (count < 2 * cus || rounds_wg > 1.25 * rounds_q));
     if (queue) {
         const size_t words = QSTATE_HDR + (size_t)count * nbands;
         a.qstate = (u32*)scratch_get(words * 4, 1);

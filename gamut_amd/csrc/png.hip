@@ -112,7 +112,7 @@ __device__ __forceinline__ u32 add_bytes(u32 x, u32 y)
 // bytewise floor((a + b) / 2), the Avg predictor (9-bit sum, stbdec.d:1497)
 __device__ __forceinline__ u32 avg_bytes(u32 a, u32 b)
 {
-    return (a & b) + (__builtin_amdgcn_bitop3_b32(a, b, 0xfefefefeu, 0x28) >> 1);       // 0x28: (a ^ b) & c in one instruction
+    return (a & b) + ((u32)__builtin_amdgcn_bitop3_b32(a, b, 0xfefefefeu, 0x28) >> 1);  // 0x28: (a ^ b) & c in one instruction (the builtin returns int)
 }
 // ---- stbi__paeth (stbdec.d:1390-1401) on two channels at once, in packed FP16 ---------------------------------
 // A byte n is carried as the half-precision number 1024 + n, whose bit pattern is simply 0x6400 | n (ulp = 1 in

@@ -617,6 +617,12 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
         // some lane meets the partial last piece of its row (iteration full_iters, trip full_iters + lane) in this tile
         const bool rag_tile = (a.wb % IB) != 0 && T0 + TT > full_iters && T0 <= full_iters + 63;
 
+        // The tile's pieces (and, Q, its pieces of the row above) are all in LDS by now: every trip fetches the NEXT trip's
+        // operands before it computes, so that no trip begins by waiting for an LDS round trip (with two waves on a SIMD
+        // nothing else hides it).
+        uint4 rv_next = *reinterpret_cast<const uint4*>(my_ring + my_slot * 16);
+        u32x4 dch_next = { 0u, 0u, 0u, 0u };
+        if constexpr (Q) dch_next = *reinterpret_cast<const u32x4*>(dch);
         #pragma unroll
         for (int u = 0; u < TT; ++u) {
             const u32 T = T0 + u;
@@ -625,7 +631,12 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
 
             uint4* piece = reinterpret_cast<uint4*>(my_ring + my_slot * 16);
             my_slot = (my_slot + 1) & (RING - 1);
-            const uint4 rv = *piece;
+            const uint4 rv = rv_next;
+            const u32x4 dch_cur = dch_next;
+            if (u + 1 < TT) {
+                rv_next = *reinterpret_cast<const uint4*>(my_ring + my_slot * 16);
+                if constexpr (Q) dch_next = *reinterpret_cast<const u32x4*>(dch + (u + 1) * 16);
+            }
             u32 rg[PW] = { rv.x, rv.y, rv.z, rv.w }, bg[PW];
             if (rag_tile) {             // last, partial piece of a row: the staged piece is the row's LAST 16 bytes (see prefetch_tile);
                 if (ragged) {           // keep its top nb bytes, moved down by 16 - nb bytes (zeros come in behind).  No memory op here.
@@ -641,7 +652,7 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
                 }
             }
             u32x4 dcur;
-            if constexpr (Q) dcur = *reinterpret_cast<const u32x4*>(dch + u * 16);
+            if constexpr (Q) dcur = dch_cur;
             else             dcur = dset[u % PF];
             if constexpr (RGBA) {       // the chunk of the output row above the band: R,G,B,255 x 4 -> 12 stream bytes
                 const u32x4 d = dcur;
@@ -690,10 +701,16 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
         }
 
         // write back the group of 8 pieces each row completed with this tile: one aligned 128-byte run per row
+        uint4 wbv[8];                               // all eight LDS reads first: one wait instead of eight round trips in a row
+        #pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int it = (((int)T0 - (8 * k + crow)) & ~7) + cslot;
+            wbv[k] = *reinterpret_cast<const uint4*>(co_ring + k * 8 * ROW_PITCH + ((u32)it & (RING - 1)) * 16);
+        }
         #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int it = (((int)T0 - (8 * k + crow)) & ~7) + cslot;                      // piece 8g + cslot, g = floor((T0 - row) / 8)
-            const uint4 v = *reinterpret_cast<const uint4*>(co_ring + k * 8 * ROW_PITCH + ((u32)it & (RING - 1)) * 16);
+            const uint4 v = wbv[k];
             if ((u32)(8 * k + crow) < rows_left && it >= 0 && it < (int)wb_iters) {
                 u32x4* dst = reinterpret_cast<u32x4*>(cdst + (int64_t)(8 * k) * a.d_pitch + (int64_t)it * 16);
                 if (Q && k == 7 && crow == 7) __builtin_amdgcn_raw_buffer_store_b128(u32x4{ v.x, v.y, v.z, v.w }, rs_last, (u32)it * 16u, 0, 16);   // row 63: sc1
@@ -1001,17 +1018,15 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
     int dev = 0, cus = 0;
     GAMUT_HIP_CHECK(hipGetDevice(&dev));
     GAMUT_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    // One workgroup per image keeps a compute unit for ceil(bands / 8) rounds of bands, and the images take ceil(count / CUs)
-    // rounds of workgroups; the queue needs count * bands / (8 CUs) rounds.  It takes over when that is clearly less (measured:
-    // 341 x 1080p +23 %, 64 x 4K 2.3 x; 512 x 4K, 10 rounds against 8.5, is a draw -- the last of one workgroup's rounds runs on idle
-    // SIMDs and therefore faster).  With fewer than two workgroups per compute unit nothing hides the hand-off latency between the
-    // waves of one image's pipeline (256 x 4K: 202 k Mpx/s against 550 k through the queue, 365 k / 416 k with random filters).
+    // One workgroup per image keeps a compute unit for ceil(bands / 8) rounds of bands (the last one on idle SIMDs), the images
+    // take ceil(count / CUs) rounds of workgroups, and with fewer than two workgroups per compute unit nothing hides the hand-off
+    // latency between the waves of one image's pipeline; the queue needs count * bands / (8 CUs) rounds whatever the filters.
+    // Measured (RGBA8, Mpx/s, workgroups / queue): 341 x 1080p 374 k / 478 k, 64 x 4K 106 k / 240 k, 256 x 4K 202 k / 533 k,
+    // 384 x 4K 365 k / 595 k, 512 x 4K 616 k / 643 k (random filters 512 k / 529 k): the queue from 1024 units on.
     const char* queue_env = getenv("GAMUT_HIP_PNG_QUEUE");       // read per call: tests flip it
     const uint64_t units = (uint64_t)count * nbands;
-    const double rounds_wg = (double)(((uint64_t)count + cus - 1) / cus) * ((nbands + PNG_WAVES - 1) / PNG_WAVES);
-    const double rounds_q = (double)units / ((double)cus * PNG_WAVES);
     bool queue = wb >= 16 && (int64_t)a.d_pitch * 64 < (1ll << 31) && units < (1ull << 31) &&
-                 (queue_env && *queue_env ? atoi(queue_env) != 0 : units >= 1024 && (count < 2 * cus || rounds_wg > 1.25 * rounds_q));
+                 (queue_env && *queue_env ? atoi(queue_env) != 0 : units >= 1024);
     if (queue) {
         const size_t words = QSTATE_HDR + (size_t)count * nbands;
         a.qstate = (u32*)scratch_get(words * 4, 1);

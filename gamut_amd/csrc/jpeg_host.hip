@@ -15,6 +15,7 @@
 #include <atomic>
 #include <chrono>
 #include <new>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -864,6 +865,7 @@ struct QuantTab { int16_t q[64]; };
 // markers, each followed by 64 bytes of 0xFF.
 struct FilePrep {
     int rc = GAMUT_HIP_OK; char msg[200] = { 0 };
+    bool progressive = false;                                  // SOF2: left to progressive_decode_device (rc = kDeferred)
     int comps = 0, nb = 0, ny = 0;
     QuantTab quant[3]; DevHuff huff[3][2];                     // [component][DC, AC]
     size_t scan_pos = 0, cap = 0, used = 0;                    // first scan byte in the file; bound / actual size of the unstuffed segments
@@ -875,6 +877,7 @@ void prepare_header(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& 
 {
     P = Parser();
     out.rc = parse_baseline(P, base, n, &f, true);
+    out.progressive = out.rc == GAMUT_HIP_ERR_UNSUPPORTED && P.progressive;
     if (out.rc != GAMUT_HIP_OK) { snprintf(out.msg, sizeof(out.msg), "image %d: %s", i, last_error_buf()); return; }
     out.comps = f.comps; out.nb = f.blocks_per_mcu; out.ny = f.comps == 1 ? 1 : P.hs[0] * P.vs[0];
     for (int c = 0; c < f.comps; ++c) {
@@ -941,6 +944,10 @@ void unstuff_file(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& f,
 }
 
 
+#include "jpeg_prog.hpp"
+
+constexpr int kDeferred = -1000;                               // FilePrep.rc of a progressive file: not this function's business
+
 int entropy_decode_device(const uint8_t* const* data, const size_t* len, int count,
                           const int64_t* coeff_offset, const int64_t* zag_offset,
                           int16_t* d_coeffs, uint8_t* d_max_zag, uint32_t* d_status,
@@ -966,6 +973,8 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
         parallel_for(count, workers, [&](int w, int i) { prepare_header(i, data[i], len[i], info[i], prep[(size_t)i], *parsers[(size_t)w]); });
         for (Parser* p : parsers) delete p;
     }
+    std::vector<int> progressive;                              // SOF2 files: decoded by progressive_decode_device after the baseline ones
+    for (int i = 0; i < count; ++i) if (prep[(size_t)i].progressive) { progressive.push_back(i); prep[(size_t)i].rc = kDeferred; }
     // B. serial: table de-duplication, slots of the files in the blob
     std::vector<DevImage> images((size_t)count);
     std::vector<DevHuff> huffs;
@@ -1107,16 +1116,22 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
         GAMUT_HIP_CHECK(hipStreamSynchronize(stream));         // the per-thread staging buffers are reused by the next call
         if (trace) fprintf(stderr, "[gamut_hip] jpeg_entropy_decode_device: %d files in %d group(s), %d long + %d short segments, %d+%d tables, %.1f MB compressed, %d host threads: headers %.1f ms, unstuff + upload %.1f ms, kernels %.1f ms (stages serialised by the trace)\n",
                            count, n_groups, total_long, total_short, n_huff, n_quant, blob_size / 1e6, workers, ms_parse, ms_upload, ms_kernels_issue);
-        for (int i = 0; i < count; ++i) {
-            const FilePrep& fp = prep[(size_t)i];
-            if (host_status) host_status[i] = fp.rc;
-            if (fp.rc != GAMUT_HIP_OK && first_failure == GAMUT_HIP_OK) { first_failure = fp.rc; first_msg = fp.msg; }
-        }
-    } else {
-        for (int i = 0; i < count; ++i) {
-            if (host_status) host_status[i] = prep[(size_t)i].rc;
-            if (first_failure == GAMUT_HIP_OK && prep[(size_t)i].rc != GAMUT_HIP_OK) { first_failure = prep[(size_t)i].rc; first_msg = prep[(size_t)i].msg; }
-        }
+    }
+    int first_index = -1;
+    for (int i = 0; i < count; ++i) {
+        const FilePrep& fp = prep[(size_t)i];
+        if (fp.rc == kDeferred) continue;
+        if (host_status) host_status[i] = fp.rc;
+        if (fp.rc != GAMUT_HIP_OK && first_failure == GAMUT_HIP_OK) { first_failure = fp.rc; first_msg = fp.msg; first_index = i; }
+    }
+    // the progressive files of the batch, into the same buffers
+    char prog_msg[256] = { 0 };
+    if (!progressive.empty()) {
+        int prog_first = -1;
+        const int rc = progressive_decode_device(data, len, progressive, coeff_offset, zag_offset, d_coeffs, d_max_zag, d_status, info, host_status, stream,
+                                                 &prog_first, prog_msg, sizeof(prog_msg));
+        if (rc != GAMUT_HIP_OK && prog_first < 0) return rc;                              // an allocation / HIP failure, message set
+        if (rc != GAMUT_HIP_OK && (first_index < 0 || prog_first < first_index)) { first_failure = rc; first_msg = prog_msg; first_index = prog_first; }
     }
     if (first_failure != GAMUT_HIP_OK) return set_error(first_failure, "%s", first_msg);
     return GAMUT_HIP_OK;

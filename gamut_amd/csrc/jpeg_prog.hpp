@@ -1,0 +1,626 @@
+// jpeg_prog.hpp -- progressive (SOF2) entropy decode ON THE GPU.  Included by jpeg_host.hip inside its namespace (it shares the
+// marker parser, the Huffman table forms and the bit reader with the baseline device decoder).
+//
+// A progressive file is a sequence of scans (jpegload.d:3296-3664): DC first / DC refinement (all components, coefficient 0)
+// and, per component, AC first / AC refinement scans over a band [Ss, Se] of the zig-zag order, each refining the bits the
+// scans before it left (successive approximation Ah / Al).  Inside a scan the stream is one chain -- a symbol's length tells
+// where the next begins, an AC refinement symbol is followed by one correction bit per ALREADY non-zero coefficient it
+// passes, so even a decoder that knew a codeword boundary could not start there -- but:
+//   * scans that share no coefficient (other component, or disjoint bands) are independent of each other: the scans of a file
+//     form levels (level = 1 + the deepest earlier scan that touches the same component and band), and a launch decodes every
+//     scan of one level of every file of the batch at once (a typical file: 10 scans, 3 levels);
+//   * restart intervals cut a scan into independent segments, as in baseline files;
+//   * a DC refinement scan is one bit per block: a lane per bit;
+//   * an AC refinement block is a wave's work, not a lane's: lane k holds the coefficient at zig-zag position k, the
+//     positions with history are a ballot, "skip `run` zeros, correcting what is passed" is a rank search in that mask
+//     (v_mbcnt), and every passed coefficient picks its own correction bit out of a 128-bit window of the stream -- the cost
+//     is per SYMBOL (a few per block), not per coefficient (63 per block).
+// First scans (one symbol per step, nothing to look at in memory) are decoded by lane 0 of a wave.  The scans write straight
+// into the dense MCU-ordered coefficient buffer the reconstruction kernels read (block (c, bx, by) of a component is block
+// mcu * nb + ... of the buffer), not yet de-quantised; k_prog_finalize then multiplies by the quantisation table and finds
+// max_zag per block (load_next_row :2259-2333).  The host walks the markers, cuts the scans at RSTn, unstuffs them into one
+// pinned image and uploads it once.  Same results as Progressive::run above (the host feeder), which is its oracle.
+
+struct ProgImage {
+    int64_t coeff_off, zag_off;        // int16 elements / bytes from the start of the caller's buffers
+    int32_t nb, ny, comps, mcus_per_row, mcus_per_col, n_blocks;
+    int32_t hs[3], vs[3], quant[3];    // quant: index of the natural-order factor table
+    int32_t index;                     // the image's index in the caller's arrays (status word)
+};
+enum { PROG_DC_FIRST = 0, PROG_DC_REFINE = 1, PROG_AC_FIRST = 2, PROG_AC_REFINE = 3 };
+struct ProgItem {                      // one restart interval (or whole scan) of one scan of one image
+    uint64_t begin, end;               // the unstuffed segment in the blob (followed by 64 bytes of 0xFF)
+    int32_t image, kind, ncomp, ss, se, al;
+    int32_t comp[3], tab[3];           // components in scan order, their DC (DC scans) or AC table
+    int32_t first_unit, n_units;       // units: MCUs of an interleaved scan, blocks (raster order of nbx x nby) of a single-component one
+    int32_t nbx, level;                // level: host only (which launch)
+};
+
+// block (bx, by) of component c in the MCU-ordered buffer
+__device__ __forceinline__ int64_t prog_block(const ProgImage& im, int c, int bx, int by)
+{
+    const int hs = c == 0 ? im.hs[0] : c == 1 ? im.hs[1] : im.hs[2], vs = c == 0 ? im.vs[0] : c == 1 ? im.vs[1] : im.vs[2];
+    const int mx = bx / hs, my = by / vs;
+    const int off = c == 0 ? 0 : im.ny + c - 1;
+    return ((int64_t)my * im.mcus_per_row + mx) * im.nb + off + (by - my * vs) * hs + (bx - mx * hs);
+}
+// the b-th block of unit u of the item's scan (interleaved: component order of the scan, rows of the component inside the MCU)
+__device__ __forceinline__ int64_t prog_unit_block(const ProgImage& im, const ProgItem& it, int u, int b, int& ci)
+{
+    if (it.ncomp == 1) { ci = 0; const int by = u / it.nbx; return prog_block(im, it.comp[0], u - by * it.nbx, by); }
+    const int my = u / im.mcus_per_row, mx = u - my * im.mcus_per_row;
+    int i = 0, rest = b;
+    for (; i < it.ncomp - 1; ++i) {
+        const int c = i == 0 ? it.comp[0] : it.comp[1];
+        const int n = (c == 0 ? im.hs[0] : c == 1 ? im.hs[1] : im.hs[2]) * (c == 0 ? im.vs[0] : c == 1 ? im.vs[1] : im.vs[2]);
+        if (rest < n) break;
+        rest -= n;
+    }
+    ci = i;
+    const int c = i == 0 ? it.comp[0] : i == 1 ? it.comp[1] : it.comp[2];
+    const int hs = c == 0 ? im.hs[0] : c == 1 ? im.hs[1] : im.hs[2], vs = c == 0 ? im.vs[0] : c == 1 ? im.vs[1] : im.vs[2];
+    const int v = rest / hs, h = rest - v * hs;
+    return prog_block(im, c, mx * hs + h, my * vs + v);
+}
+
+// 128 bits of an unstuffed segment from any bit position, for a whole wave: lane L keeps the big-endian dword at byte
+// chunk + 4 L of the segment (256 bytes per wave, reloaded when the position leaves them), a window is five lane reads.
+struct WaveBits {
+    const uint8_t* seg; uint32_t chunk; uint32_t cw; bool loaded;
+    __device__ __forceinline__ void open(const uint8_t* s) { seg = s; chunk = 0; cw = 0; loaded = false; }
+    __device__ __forceinline__ void window(uint32_t pos, uint64_t& w0, uint64_t& w1)
+    {
+        uint32_t byte = pos >> 3;
+        if (!loaded || byte < chunk || byte + 20 > chunk + 256) {
+            chunk = byte & ~3u; loaded = true;
+            uint32_t raw; __builtin_memcpy(&raw, seg + chunk + 4 * (threadIdx.x & 63), 4);
+            cw = __builtin_bswap32(raw);
+        }
+        const uint32_t o = byte - chunk, d = o >> 2, s = (o & 3) * 8 + (pos & 7);
+        const uint64_t a = ((uint64_t)(uint32_t)__shfl((int)cw, (int)d) << 32) | (uint32_t)__shfl((int)cw, (int)d + 1);
+        const uint64_t b = ((uint64_t)(uint32_t)__shfl((int)cw, (int)d + 2) << 32) | (uint32_t)__shfl((int)cw, (int)d + 3);
+        const uint64_t c = (uint64_t)(uint32_t)__shfl((int)cw, (int)d + 4) << 32;
+        w0 = s ? (a << s) | (b >> (64 - s)) : a;
+        w1 = s ? (b << s) | (c >> (64 - s)) : b;
+    }
+};
+
+constexpr int kProgThreads = 64;
+
+__global__ __launch_bounds__(kProgThreads) void k_prog_scan(const ProgItem* items, const ProgImage* images, const DevHuff* huff_g,
+                                                            const uint8_t* blob, int16_t* coeffs, uint32_t* status)
+{
+    __shared__ DevHuff sh_huff[3];
+    __shared__ uint8_t sh_zag[64];
+    const int lane = threadIdx.x;
+    const ProgItem it = items[blockIdx.x];
+    const ProgImage im = images[it.image];
+    sh_zag[lane] = kZagDev[lane];
+    const bool need_tab = it.kind != PROG_DC_REFINE;
+    if (need_tab)
+        for (int i = 0; i < it.ncomp; ++i) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(huff_g + (i == 0 ? it.tab[0] : i == 1 ? it.tab[1] : it.tab[2]));
+            uint32_t* dst = reinterpret_cast<uint32_t*>(&sh_huff[i]);
+            for (int k = lane; k < (int)(sizeof(DevHuff) / 4); k += kProgThreads) dst[k] = src[k];
+        }
+    __syncthreads();
+    const uint8_t* seg = blob + it.begin;
+    const uint32_t seg_bytes = (uint32_t)(it.end - it.begin);
+    const uint32_t limit_bit = seg_bytes * 8u + 64u * 8u;       // a decoder that runs past the padding is on a corrupt stream
+    int16_t* out = coeffs + im.coeff_off;
+    uint32_t* st = status + im.index;
+    int bpu = 1;                                                // blocks per unit
+    if (it.ncomp > 1) {
+        bpu = 0;
+        for (int i = 0; i < it.ncomp; ++i) {
+            const int c = i == 0 ? it.comp[0] : i == 1 ? it.comp[1] : it.comp[2];
+            bpu += (c == 0 ? im.hs[0] : c == 1 ? im.hs[1] : im.hs[2]) * (c == 0 ? im.vs[0] : c == 1 ? im.vs[1] : im.vs[2]);
+        }
+    }
+
+    if (it.kind == PROG_DC_FIRST) {                             // decode_block_dc_first :3298-3319
+        if (lane != 0) return;
+        DevBits br; br.open(seg, 0);
+        int pred0 = 0, pred1 = 0, pred2 = 0;
+        for (int u = it.first_unit; u < it.first_unit + it.n_units; ++u) {
+            for (int b = 0; b < bpu; ++b) {
+                int ci; const int64_t blk = prog_unit_block(im, it, u, b, ci);
+                const int s = br.decode(&sh_huff[ci]);
+                if (s < 0) { atomicOr(st, 1u); return; }
+                const int c = ci == 0 ? it.comp[0] : ci == 1 ? it.comp[1] : it.comp[2];
+                const int v = br.receive_extend(s & 15) + (c == 0 ? pred0 : c == 1 ? pred1 : pred2);
+                if (c == 0) pred0 = v; else if (c == 1) pred1 = v; else pred2 = v;
+                out[blk * 64] = (int16_t)((uint32_t)v << it.al);
+            }
+            if (br.pos > limit_bit) { atomicOr(st, 4u); return; }
+        }
+    } else if (it.kind == PROG_DC_REFINE) {                     // decode_block_dc_refine :3321-3333: bit t of the segment belongs to block t
+        const int total = it.n_units * bpu;
+        for (int t = lane; t < total; t += kProgThreads) {
+            const int u = t / bpu, b = t - u * bpu;
+            const uint32_t byte = (uint32_t)t >> 3;
+            const uint32_t v = byte < seg_bytes ? seg[byte] : 0xFFu;                    // past the data: ones (get_octet :683-696)
+            if ((v >> (7 - (t & 7))) & 1u) {
+                int ci; const int64_t blk = prog_unit_block(im, it, it.first_unit + u, b, ci);
+                out[blk * 64] = (int16_t)(out[blk * 64] | (1 << it.al));
+            }
+        }
+    } else if (it.kind == PROG_AC_FIRST) {                      // decode_block_ac_first :3335-3398
+        if (lane != 0) return;
+        DevBits br; br.open(seg, 0);
+        int eobrun = 0;
+        const int c = it.comp[0];
+        int bx = it.first_unit % it.nbx, by = it.first_unit / it.nbx;
+        for (int u = 0; u < it.n_units; ++u) {
+            if (eobrun) --eobrun;
+            else {
+                int16_t* blk = out + prog_block(im, c, bx, by) * 64;
+                for (int k = it.ss; k <= it.se; ++k) {
+                    const int rs = br.decode(&sh_huff[0]);
+                    if (rs < 0) { atomicOr(st, 1u); return; }
+                    const int run = rs >> 4, size = rs & 15;
+                    if (size) {
+                        if ((k += run) > 63) { atomicOr(st, 2u); return; }
+                        blk[sh_zag[k]] = (int16_t)((uint32_t)br.receive_extend(size) << it.al);
+                    } else if (run == 15) {
+                        if ((k += 15) > 63) { atomicOr(st, 2u); return; }
+                    } else {                                     // EOBn: this block and the next eobrun blocks end here
+                        int extra = 0;
+                        if (run) { br.refill(); extra = (int)br.peek(run); br.drop(run); }
+                        eobrun = (1 << run) + extra - 1;
+                        break;
+                    }
+                }
+                if (br.pos > limit_bit) { atomicOr(st, 4u); return; }
+            }
+            if (++bx == it.nbx) { bx = 0; ++by; }
+        }
+    } else {                                                    // decode_block_ac_refine :3400-3518, a wave per block
+        const int c = it.comp[0];
+        const DevHuff* ac = &sh_huff[0];
+        const int nat = sh_zag[lane];                           // this lane's coefficient: zig-zag position `lane`
+        const uint64_t lane_bit = 1ull << lane, below = lane_bit - 1;
+        const uint64_t band = (it.se >= 63 ? ~0ull : (1ull << (it.se + 1)) - 1) & ~((1ull << it.ss) - 1);
+        const int plus = 1 << it.al, minus = (int)(0xFFFFFFFFu << it.al);
+        WaveBits wb; wb.open(seg);
+        uint32_t pos = 0;
+        int eobrun = 0;
+        int bx = it.first_unit % it.nbx, by = it.first_unit / it.nbx;
+        int16_t* blk = out + prog_block(im, c, bx, by) * 64;
+        int next_coef = it.n_units > 0 ? blk[nat] : 0;
+        for (int u = 0; u < it.n_units; ++u) {
+            int coef = next_coef;
+            int16_t* const cur = blk;
+            if (++bx == it.nbx) { bx = 0; ++by; }
+            if (u + 1 < it.n_units) { blk = out + prog_block(im, c, bx, by) * 64; next_coef = blk[nat]; }       // in flight while this block is decoded
+            const int orig = coef;
+            const uint64_t nz = __ballot(coef != 0) & band;
+            int k = it.ss;
+            bool bad = false;
+            if (eobrun == 0) {
+                while (k <= it.se) {
+                    uint64_t w0, w1; wb.window(pos, w0, w1);
+                    int len, sym;
+                    const uint32_t e = ac->fast[(uint32_t)(w0 >> 55)];
+                    if (e) { len = (int)(e >> 8); sym = (int)(e & 0xFF); }
+                    else {
+                        int32_t code = (int32_t)(w0 >> 55); len = 9;
+                        while (code > ac->maxcode[len]) { if (++len > 16) break; code = (int32_t)(w0 >> (64 - len)); }
+                        if (len > 16) { bad = true; break; }
+                        sym = ac->vals[(code + ac->delta[len]) & 0xFF];
+                    }
+                    const int run = sym >> 4, size = sym & 15;
+                    int used = len, fresh = 0;
+                    if (size) {
+                        if (size != 1) { bad = true; break; }
+                        fresh = ((w0 >> (63 - used)) & 1ull) ? plus : minus;
+                        ++used;
+                    } else if (run != 15) {
+                        const int extra = run ? (int)((w0 << used) >> (64 - run)) : 0;
+                        eobrun = (1 << run) + extra;
+                        pos += (uint32_t)(used + run);
+                        break;
+                    }
+                    // walk on from k over `run` zeros to the zero that ends the run, correcting every coefficient with history on the way
+                    const uint64_t from_k = ~((1ull << k) - 1);
+                    const uint64_t zeros = ~nz & band & from_k;
+                    const bool is_stop = (zeros & lane_bit) && __popcll(zeros & below) == run;
+                    const uint64_t sm = __ballot(is_stop);
+                    const int stop = sm ? __ffsll((long long)sm) - 1 : it.se + 1;
+                    const uint64_t corr = nz & from_k & (stop >= 64 ? ~0ull : (1ull << stop) - 1);
+                    if (corr & lane_bit) {
+                        const uint64_t cbits = (w0 << used) | (w1 >> (64 - used));             // used >= 1
+                        const int r = __popcll(corr & below);
+                        if (((cbits >> (63 - r)) & 1ull) && (coef & plus) == 0) coef = (int16_t)(coef + (coef >= 0 ? plus : minus));
+                    }
+                    pos += (uint32_t)(used + __popcll(corr));
+                    if (fresh && stop < 64 && lane == stop) coef = fresh;
+                    k = stop + 1;
+                }
+            }
+            if (bad) { if (lane == 0) atomicOr(st, 1u); return; }
+            if (eobrun > 0) {
+                const uint64_t corr = nz & ~((1ull << k) - 1);
+                if (corr) {
+                    uint64_t w0, w1; wb.window(pos, w0, w1);
+                    if (corr & lane_bit) {
+                        const int r = __popcll(corr & below);
+                        if (((w0 >> (63 - r)) & 1ull) && (coef & plus) == 0) coef = (int16_t)(coef + (coef >= 0 ? plus : minus));
+                    }
+                    pos += (uint32_t)__popcll(corr);
+                }
+                --eobrun;
+            }
+            if (coef != orig) cur[nat] = (int16_t)coef;
+            if (pos > limit_bit) { if (lane == 0) atomicOr(st, 4u); return; }
+        }
+    }
+}
+
+// load_next_row :2259-2333 for every block of the listed images: max_zag = last non-zero zig-zag position + 1, coefficients
+// times the quantisation factor of their position.  Eight lanes per block (16 bytes each).
+__global__ __launch_bounds__(256) void k_prog_finalize(const ProgImage* images, int n_images, const int16_t* qnat /* [table][64], natural order */,
+                                                       int16_t* coeffs, uint8_t* max_zag)
+{
+    __shared__ uint8_t sh_izag[64];
+    if (threadIdx.x < 64) sh_izag[kZagDev[threadIdx.x]] = (uint8_t)threadIdx.x;
+    __syncthreads();
+    const ProgImage im = images[blockIdx.y];
+    const int part = threadIdx.x & 7;
+    for (int64_t b = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3); b < im.n_blocks; b += (int64_t)gridDim.x * 32) {
+        const int w = (int)(b % im.nb), c = w < im.ny ? 0 : w - im.ny + 1;
+        const int16_t* q = qnat + (c == 0 ? im.quant[0] : c == 1 ? im.quant[1] : im.quant[2]) * 64 + part * 8;
+        int16_t* p = coeffs + im.coeff_off + b * 64 + part * 8;
+        union { uint4 v; int16_t s[8]; } x, f;
+        x.v = *reinterpret_cast<const uint4*>(p);
+        f.v = *reinterpret_cast<const uint4*>(q);
+        int last = 0;
+        #pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (x.s[i]) { const int z = sh_izag[part * 8 + i]; last = z > last ? z : last; }
+            x.s[i] = (int16_t)((uint32_t)(int32_t)x.s[i] * (uint32_t)(int32_t)f.s[i]);
+        }
+        *reinterpret_cast<uint4*>(p) = x.v;
+        last = max(last, __shfl_xor(last, 1)); last = max(last, __shfl_xor(last, 2)); last = max(last, __shfl_xor(last, 4));
+        if (part == 0) max_zag[im.zag_off + b] = (uint8_t)(last + 1);
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------
+inline void to_dev_huff(const HuffTable& h, DevHuff& d)
+{
+    memset(&d, 0, sizeof(d));
+    for (int w = 0; w < 512; ++w) { const uint16_t e = h.fast[w << 1]; d.fast[w] = (e >> 8) <= 9 ? e : 0; }   // 10-bit table -> 9-bit
+    memcpy(d.maxcode, h.maxcode, sizeof(d.maxcode)); memcpy(d.delta, h.delta, sizeof(d.delta)); memcpy(d.vals, h.vals, sizeof(d.vals));
+}
+
+struct ProgScanPrep {
+    Scan sc; int kind = 0, level = 0, restart_interval = 0, units = 0, nbx = 0, nby = 0;
+    int tab[3] = { 0, 0, 0 };            // file-local table indices (scan order)
+    size_t begin = 0, end = 0;           // entropy-coded bytes of the scan in the file
+};
+struct ProgPrep {
+    int rc = GAMUT_HIP_OK; char msg[200] = { 0 };
+    int comps = 0, nb = 0, ny = 0, hs[3] = { 1, 1, 1 }, vs[3] = { 1, 1, 1 };
+    QuantTab quant[3];                   // natural order (factor of the coefficient at natural index n)
+    std::vector<ProgScanPrep> scans;
+    std::vector<DevHuff> tabs;
+    size_t cap = 0, used = 0;
+    std::vector<ProgItem> items;         // begin / end relative to the file's slot in the blob; tab = file-local
+};
+
+// end of the entropy-coded data that starts at `q`: the first marker that is neither a stuffed FF00, a fill byte nor RSTn
+inline size_t scan_data_end(const uint8_t* base, size_t q, size_t n)
+{
+    while (q < n) {
+        const uint8_t* hit = (const uint8_t*)memchr(base + q, 0xFF, n - q);
+        if (!hit || hit + 1 >= base + n) return n;
+        q = (size_t)(hit - base);
+        const uint8_t m = hit[1];
+        if (m == 0x00 || (m >= 0xD0 && m <= 0xD7)) { q += 2; continue; }
+        if (m == 0xFF) { q += 1; continue; }
+        return q;
+    }
+    return n;
+}
+
+// marker walk of a whole progressive file: every scan with its tables as they stand when it begins (init_progressive :3585-3664)
+void prog_prepare(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& f, ProgPrep& out, Parser& P)
+{
+    auto bad = [&](const char* why) { out.rc = GAMUT_HIP_ERR_DECODE; snprintf(out.msg, sizeof(out.msg), "image %d: jpeg: %s", i, why); fail(&f, why); };
+    P = Parser();
+    memset(&f, 0, sizeof(f));
+    f.pixel_aspect_ratio = -1; f.dpi_y = -1;
+    if (!base || n < 4 || base[0] != 0xFF || base[1] != 0xD8) return bad("not a JPEG (no SOI)");
+    P.data = base; P.len = n; P.pos = 2;
+    int marker = next_scan(P, &f);
+    if (marker < 0) { out.rc = GAMUT_HIP_ERR_DECODE; snprintf(out.msg, sizeof(out.msg), "image %d: %s", i, last_error_buf()); return; }
+    if (marker != 0xDA) return bad("no SOS marker");
+    out.comps = f.comps; out.nb = f.blocks_per_mcu; out.ny = f.comps == 1 ? 1 : P.hs[0] * P.vs[0];
+    int max_h = 1, max_v = 1;
+    for (int c = 0; c < f.comps; ++c) { out.hs[c] = P.hs[c]; out.vs[c] = P.vs[c]; if (P.hs[c] > max_h) max_h = P.hs[c]; if (P.vs[c] > max_v) max_v = P.vs[c]; }
+    while (marker == 0xDA) {
+        ProgScanPrep s; s.sc = P.scan;
+        const Scan& sc = s.sc;
+        const bool dc_scan = sc.ss == 0, refine = sc.ah != 0;
+        if (sc.ss > sc.se || sc.se > 63 || (dc_scan && sc.se != 0)) return bad("bad SOS spectral selection");
+        if (!dc_scan && sc.ncomp != 1) return bad("AC scans can only contain one component");
+        if (refine && sc.al != sc.ah - 1) return bad("bad SOS successive approximation");
+        if (sc.al > 13) return bad("bad SOS successive approximation");
+        for (int k = 0; k < sc.ncomp; ++k) {
+            const int c = sc.comp[k];
+            if (!P.quant_def[P.tq[c]]) return bad("undefined quant table");
+            if (dc_scan ? (!refine && !P.huff[P.td[c]].defined) : !P.huff[P.ta[c]].defined) return bad("undefined Huffman table");
+            if (!(dc_scan && refine)) {
+                DevHuff d; to_dev_huff(P.huff[dc_scan ? P.td[c] : P.ta[c]], d);
+                s.tab[k] = intern(out.tabs, d);
+            }
+        }
+        s.kind = dc_scan ? (refine ? PROG_DC_REFINE : PROG_DC_FIRST) : (refine ? PROG_AC_REFINE : PROG_AC_FIRST);
+        s.restart_interval = P.restart_interval;
+        if (sc.ncomp == 1) {                                   // calc_mcu_block_order :3052-3066: the component's own blocks
+            const int c = sc.comp[0];
+            s.nbx = ((f.width  * P.hs[c] + max_h - 1) / max_h + 7) / 8;
+            s.nby = ((f.height * P.vs[c] + max_v - 1) / max_v + 7) / 8;
+            if (s.nbx > f.mcus_per_row * P.hs[c] || s.nby > f.mcus_per_col * P.vs[c]) return bad("decode error in a progressive scan");
+            s.units = s.nbx * s.nby;
+        } else s.units = f.mcus_per_row * f.mcus_per_col;
+        // level: behind every earlier scan that touches one of its coefficients
+        for (const ProgScanPrep& e : out.scans) {
+            bool shares = false;
+            for (int a = 0; a < sc.ncomp; ++a) for (int b = 0; b < e.sc.ncomp; ++b) shares = shares || sc.comp[a] == e.sc.comp[b];
+            if (shares && sc.ss <= e.sc.se && e.sc.ss <= sc.se && e.level + 1 > s.level) s.level = e.level + 1;
+        }
+        s.begin = P.pos; s.end = scan_data_end(base, P.pos, n);
+        out.scans.push_back(s);
+        if (out.scans.size() > 256) return bad("too many scans");
+        P.pos = s.end;
+        marker = next_scan(P, &f);
+        if (marker < 0) { out.rc = GAMUT_HIP_ERR_DECODE; snprintf(out.msg, sizeof(out.msg), "image %d: %s", i, last_error_buf()); return; }
+    }
+    // de-quantisation happens after the last scan, with the tables as they stand then (load_next_row :2306-2323)
+    for (int c = 0; c < f.comps; ++c) for (int k = 0; k < 64; ++k) out.quant[c].q[kZag[k]] = P.quant[P.tq[c]][k];
+    out.cap = 0;
+    for (const ProgScanPrep& s : out.scans) {
+        const size_t segs = s.restart_interval ? (size_t)(s.units / s.restart_interval + 1) : 1;
+        out.cap += (s.end - s.begin) + (64 + 4) * segs + 16;    // per segment: 64 bytes of padding, then up to the next dword
+    }
+}
+
+// the scans of one file, unstuffed and cut at the restart markers, into the file's slot of the pinned upload image
+void prog_unstuff(int i, const uint8_t* base, gamut_hip_jpeg_frame& f, ProgPrep& out, uint8_t* dst)
+{
+    size_t w = 0;
+    bool bad = false;
+    for (const ProgScanPrep& s : out.scans) {
+        const int total = s.units, ri = s.restart_interval;
+        int next_unit = 0, expect = 0;
+        size_t q = s.begin, copy_from = s.begin, seg_begin = w;
+        const size_t n = s.end;
+        bool copying = true;
+        auto flush = [&](size_t upto) {
+            if (copying && upto > copy_from) {
+                const size_t k = upto - copy_from;
+                if (w + k > out.cap) { bad = true; return; }
+                memcpy(dst + w, base + copy_from, k); w += k;
+            }
+        };
+        auto close_segment = [&](int nu) {
+            if (w + 64 + 16 > out.cap) { bad = true; return; }
+            ProgItem it; memset(&it, 0, sizeof(it));
+            it.image = i; it.kind = s.kind; it.ncomp = s.sc.ncomp; it.ss = s.sc.ss; it.se = s.sc.se; it.al = s.sc.al;
+            for (int k = 0; k < s.sc.ncomp; ++k) { it.comp[k] = s.sc.comp[k]; it.tab[k] = s.tab[k]; }
+            it.first_unit = next_unit; it.n_units = nu; it.nbx = s.nbx > 0 ? s.nbx : 1; it.level = s.level;
+            it.begin = seg_begin; it.end = w;
+            out.items.push_back(it); next_unit += nu;
+            memset(dst + w, 0xFF, 64); w += 64;
+            w = (w + 3) & ~(size_t)3;                          // segments start on dword boundaries (the wave reader loads dwords)
+            seg_begin = w;
+        };
+        while (!bad) {
+            const uint8_t* hit = q < n ? (const uint8_t*)memchr(base + q, 0xFF, n - q) : nullptr;
+            if (!hit || hit + 1 >= base + n) { flush(n); q = n; break; }
+            const uint8_t m = hit[1];
+            q = (size_t)(hit - base);
+            if (m == 0x00) { flush(q + 1); copy_from = q + 2; q += 2; continue; }      // stuffed 0xFF: keep the FF, drop the 00
+            flush(q); copying = false;
+            if (m == 0xFF) { q += 1; continue; }
+            if (m >= 0xD0 && m <= 0xD7 && ri && next_unit + ri < total) {
+                if (m != 0xD0 + expect) { bad = true; break; }
+                close_segment(ri);
+                expect = (expect + 1) & 7; q += 2; copy_from = q; copying = true;
+                continue;
+            }
+            break;
+        }
+        if (!bad && next_unit < total) {
+            if (ri && total - next_unit > ri) bad = true;      // a restart marker is missing
+            else close_segment(total - next_unit);
+        }
+        if (bad) break;
+    }
+    out.used = w;
+    if (bad) {
+        out.items.clear(); out.used = 0;
+        fail(&f, "bad restart marker");
+        out.rc = GAMUT_HIP_ERR_DECODE; snprintf(out.msg, sizeof(out.msg), "image %d: bad restart marker", i);
+    }
+}
+
+// Decodes the progressive files data[idx[0..n)] of a batch (indices into the caller's arrays) into the same buffers the
+// baseline files of the batch went to.  host_status[i] / info[i] are filled for those files; returns the status of the
+// lowest-numbered failing one (message in `first_msg`).
+int progressive_decode_device(const uint8_t* const* data, const size_t* len, const std::vector<int>& idx,
+                              const int64_t* coeff_offset, const int64_t* zag_offset,
+                              int16_t* d_coeffs, uint8_t* d_max_zag, uint32_t* d_status,
+                              gamut_hip_jpeg_frame* info, int* host_status, hipStream_t stream, int* first_index, char* first_msg, size_t msg_cap)
+{
+    const bool trace = getenv("GAMUT_HIP_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    const int n = (int)idx.size();
+    *first_index = -1;
+    if (n == 0) return GAMUT_HIP_OK;
+    int workers = host_threads();
+    workers = workers < 1 ? 1 : workers > 16 ? 16 : workers;
+    if (workers > n) workers = n;
+    // A scan is a chain: the GPU decodes one about five times slower than a host core does, and wins by decoding every
+    // scan of every file at the same time.  Below a few files per host thread the host feeder (Progressive::run on the
+    // thread pool) plus an upload of the coefficients is the faster way to the same buffers.  GAMUT_HIP_JPEG_PROGRESSIVE =
+    // host / device forces either (tests, measurements).
+    const char* how = getenv("GAMUT_HIP_JPEG_PROGRESSIVE");
+    const bool on_host = how && !strcmp(how, "host") ? true : how && !strcmp(how, "device") ? false : n < 4 * workers;
+    if (on_host) {
+        std::vector<gamut_hip_jpeg_frame> frames((size_t)n);
+        std::vector<int> rcs((size_t)n, GAMUT_HIP_OK);
+        std::vector<std::string> msgs((size_t)n);
+        parallel_for(n, workers, [&](int, int k) {
+            const int i = idx[(size_t)k];
+            rcs[(size_t)k] = decode_coeffs(data[i], len[i], &frames[(size_t)k]);
+            if (rcs[(size_t)k] != GAMUT_HIP_OK) msgs[(size_t)k] = last_error_buf();
+        });
+        int first_rc = GAMUT_HIP_OK, hip_rc = GAMUT_HIP_OK;
+        for (int k = 0; k < n; ++k) {
+            const int i = idx[(size_t)k];
+            gamut_hip_jpeg_frame& fr = frames[(size_t)k];
+            if (rcs[(size_t)k] == GAMUT_HIP_OK && hip_rc == GAMUT_HIP_OK) {
+                const size_t nblk = (size_t)fr.mcus_per_row * fr.mcus_per_col * fr.blocks_per_mcu;
+                if (hipMemcpyAsync(d_coeffs + coeff_offset[i], fr.coeffs, nblk * 64 * sizeof(int16_t), hipMemcpyHostToDevice, stream) != hipSuccess ||
+                    hipMemcpyAsync(d_max_zag + zag_offset[i], fr.max_zag, nblk, hipMemcpyHostToDevice, stream) != hipSuccess ||
+                    (d_status && hipMemsetAsync(d_status + i, 0, sizeof(uint32_t), stream) != hipSuccess))
+                    hip_rc = set_error(GAMUT_HIP_ERR_HIP, "jpeg: upload of the coefficients of image %d failed", i);
+            }
+            int16_t* co = fr.coeffs; uint8_t* mz = fr.max_zag;
+            info[i] = fr; info[i].coeffs = nullptr; info[i].max_zag = nullptr;
+            if (host_status) host_status[i] = rcs[(size_t)k];
+            if (rcs[(size_t)k] != GAMUT_HIP_OK && (*first_index < 0 || i < *first_index)) {
+                *first_index = i; first_rc = rcs[(size_t)k]; snprintf(first_msg, msg_cap, "image %d: %s", i, msgs[(size_t)k].c_str());
+            }
+            fr.coeffs = co; fr.max_zag = mz;
+        }
+        if (hipStreamSynchronize(stream) != hipSuccess && hip_rc == GAMUT_HIP_OK) hip_rc = set_error(GAMUT_HIP_ERR_HIP, "jpeg: upload of the coefficients failed");
+        for (gamut_hip_jpeg_frame& fr : frames) { free(fr.coeffs); free(fr.max_zag); }
+        if (hip_rc != GAMUT_HIP_OK) { *first_index = -1; return hip_rc; }
+        return first_rc;
+    }
+    std::vector<ProgPrep> prep((size_t)n);
+    {
+        std::vector<Parser*> parsers((size_t)workers, nullptr);
+        for (Parser*& p : parsers) p = new Parser();
+        parallel_for(n, workers, [&](int w, int k) { const int i = idx[(size_t)k]; prog_prepare(i, data[i], len[i], info[i], prep[(size_t)k], *parsers[(size_t)w]); });
+        for (Parser* p : parsers) delete p;
+    }
+    // layout: blob slots, global tables
+    std::vector<ProgImage> images((size_t)n);
+    std::vector<DevHuff> huffs; std::vector<QuantTab> quants;
+    std::vector<std::vector<int>> tab_map((size_t)n);
+    std::vector<size_t> blob_off((size_t)n, 0);
+    size_t blob_size = 0; int max_level = -1; int64_t max_blocks = 0;
+    for (int k = 0; k < n; ++k) {
+        ProgPrep& pp = prep[(size_t)k]; ProgImage& im = images[(size_t)k];
+        memset(&im, 0, sizeof(im));
+        if (pp.rc != GAMUT_HIP_OK) continue;
+        const int i = idx[(size_t)k];
+        if ((coeff_offset[i] & 7) != 0) { pp.rc = GAMUT_HIP_ERR_INVALID_ARG; snprintf(pp.msg, sizeof(pp.msg), "image %d: coefficient offsets must be multiples of 8 elements", i); continue; }
+        im.coeff_off = coeff_offset[i]; im.zag_off = zag_offset[i]; im.nb = pp.nb; im.ny = pp.ny; im.comps = pp.comps;
+        im.mcus_per_row = info[i].mcus_per_row; im.mcus_per_col = info[i].mcus_per_col; im.n_blocks = im.mcus_per_row * im.mcus_per_col * im.nb;
+        im.index = i;
+        for (int c = 0; c < 3; ++c) { im.hs[c] = pp.hs[c]; im.vs[c] = pp.vs[c]; im.quant[c] = c < pp.comps ? intern(quants, pp.quant[c]) : 0; }
+        for (const DevHuff& d : pp.tabs) tab_map[(size_t)k].push_back(intern(huffs, d));
+        for (const ProgScanPrep& s : pp.scans) if (s.level > max_level) max_level = s.level;
+        if (im.n_blocks > max_blocks) max_blocks = im.n_blocks;
+        blob_off[(size_t)k] = blob_size;
+        blob_size += (pp.cap + 255) & ~(size_t)255;
+    }
+    const double ms_parse = ms_since(t_begin);
+    double ms_unstuff = 0, ms_kernels = 0;
+    if (max_level >= 0) {
+        static thread_local DeviceScratch scratch, tab_scratch;
+        static thread_local PinnedScratch pinned, tab_pinned;
+        uint8_t* d_blob = (uint8_t*)scratch.get(blob_size + kBlobSlack);
+        uint8_t* h_blob = pinned.get(blob_size + kBlobSlack);
+        if (!d_blob || !h_blob) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: staging allocation of %zu bytes failed", blob_size + kBlobSlack);
+        const auto t_u = std::chrono::steady_clock::now();
+        parallel_for(n, workers, [&](int, int k) {
+            ProgPrep& pp = prep[(size_t)k];
+            if (pp.rc == GAMUT_HIP_OK) { const int i = idx[(size_t)k]; prog_unstuff(i, data[i], info[i], pp, h_blob + blob_off[(size_t)k]); }
+        });
+        memset(h_blob + blob_size, 0xFF, kBlobSlack);
+        // the coefficient blocks of the images start at zero (scans only write what they decode); adjacent images in one call
+        {
+            auto ok = [&](int k) { return prep[(size_t)k].rc == GAMUT_HIP_OK; };
+            for (int k = 0; k < n; ) {
+                if (!ok(k)) { ++k; continue; }
+                const int64_t begin = images[(size_t)k].coeff_off; int64_t endo = begin + (int64_t)images[(size_t)k].n_blocks * 64;
+                int j = k + 1;
+                while (j < n && ok(j) && images[(size_t)j].coeff_off == endo) { endo += (int64_t)images[(size_t)j].n_blocks * 64; ++j; }
+                GAMUT_HIP_CHECK(hipMemsetAsync(d_coeffs + begin, 0, (size_t)(endo - begin) * sizeof(int16_t), stream));
+                k = j;
+            }
+        }
+        // items by level (tables -> global indices, segments -> blob offsets); images that failed while unstuffing drop out
+        std::vector<std::vector<ProgItem>> by_level((size_t)max_level + 1);
+        std::vector<ProgImage> live; std::vector<int> live_of((size_t)n, -1);
+        for (int k = 0; k < n; ++k) {
+            const ProgPrep& pp = prep[(size_t)k];
+            if (pp.rc != GAMUT_HIP_OK) continue;
+            live_of[(size_t)k] = (int)live.size(); live.push_back(images[(size_t)k]);
+            for (ProgItem it : pp.items) {
+                it.image = live_of[(size_t)k];
+                it.begin += blob_off[(size_t)k]; it.end += blob_off[(size_t)k];
+                if (it.kind != PROG_DC_REFINE) for (int c = 0; c < it.ncomp; ++c) it.tab[c] = tab_map[(size_t)k][(size_t)it.tab[c]];
+                by_level[(size_t)it.level].push_back(it);
+            }
+        }
+        ms_unstuff = ms_since(t_u);
+        if (!live.empty()) {
+            auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+            size_t n_items = 0; for (const auto& v : by_level) n_items += v.size();
+            std::vector<QuantTab>& qn = quants;
+            const size_t o_img = 0, o_huff = align(live.size() * sizeof(ProgImage)), o_quant = align(o_huff + huffs.size() * sizeof(DevHuff)),
+                         o_items = align(o_quant + qn.size() * sizeof(QuantTab)), total = o_items + n_items * sizeof(ProgItem) + 256;
+            uint8_t* d = (uint8_t*)tab_scratch.get(total);
+            uint8_t* h = tab_pinned.get(total);
+            if (!d || !h) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: staging allocation of %zu bytes failed", total);
+            memcpy(h + o_img, live.data(), live.size() * sizeof(ProgImage));
+            memcpy(h + o_huff, huffs.data(), huffs.size() * sizeof(DevHuff));
+            memcpy(h + o_quant, qn.data(), qn.size() * sizeof(QuantTab));
+            size_t off = o_items;
+            std::vector<size_t> level_off;
+            for (const auto& v : by_level) { level_off.push_back(off); memcpy(h + off, v.data(), v.size() * sizeof(ProgItem)); off += v.size() * sizeof(ProgItem); }
+            GAMUT_HIP_CHECK(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, stream));
+            GAMUT_HIP_CHECK(hipMemcpyAsync(d_blob, h_blob, blob_size + kBlobSlack, hipMemcpyHostToDevice, stream));
+            uint32_t* st = d_status;
+            if (!st) {
+                static thread_local DeviceScratch sink;
+                int top = 0; for (int i : idx) top = i > top ? i : top;
+                st = (uint32_t*)sink.get((size_t)(top + 1) * sizeof(uint32_t));
+                if (!st) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: status allocation failed");
+            }
+            for (int k = 0; k < n; ++k) if (prep[(size_t)k].rc == GAMUT_HIP_OK) GAMUT_HIP_CHECK(hipMemsetAsync(st + idx[(size_t)k], 0, sizeof(uint32_t), stream));
+            const auto t_k = std::chrono::steady_clock::now();
+            for (size_t lv = 0; lv < by_level.size(); ++lv) {
+                if (by_level[lv].empty()) continue;
+                hipLaunchKernelGGL(k_prog_scan, dim3((unsigned)by_level[lv].size()), dim3(kProgThreads), 0, stream,
+                                   (const ProgItem*)(d + level_off[lv]), (const ProgImage*)(d + o_img), (const DevHuff*)(d + o_huff), d_blob, d_coeffs, st);
+                if (int rc = launch_status("jpeg_prog_scan")) return rc;
+            }
+            const unsigned gx = (unsigned)std::min<int64_t>((max_blocks + 31) / 32, 4096);
+            hipLaunchKernelGGL(k_prog_finalize, dim3(gx, (unsigned)live.size()), dim3(256), 0, stream,
+                               (const ProgImage*)(d + o_img), (int)live.size(), (const int16_t*)(d + o_quant), d_coeffs, d_max_zag);
+            if (int rc = launch_status("jpeg_prog_finalize")) return rc;
+            GAMUT_HIP_CHECK(hipStreamSynchronize(stream));     // the per-thread staging buffers are reused by the next call
+            ms_kernels = ms_since(t_k);
+        }
+    }
+    if (trace) fprintf(stderr, "[gamut_hip] progressive_decode_device: %d files, %d levels: headers %.1f ms, unstuff %.1f ms, upload + kernels %.1f ms\n",
+                       n, max_level + 1, ms_parse, ms_unstuff, ms_kernels);
+    int first_rc = GAMUT_HIP_OK;
+    for (int k = 0; k < n; ++k) {
+        const ProgPrep& pp = prep[(size_t)k];
+        const int i = idx[(size_t)k];
+        if (host_status) host_status[i] = pp.rc;
+        if (pp.rc != GAMUT_HIP_OK && (*first_index < 0 || i < *first_index)) { *first_index = i; first_rc = pp.rc; snprintf(first_msg, msg_cap, "%s", pp.msg); }
+    }
+    return first_rc;
+}

@@ -238,24 +238,93 @@ def _entropy_decode_device(L, blobs):
     return rc, list(hst), st, res
 
 
-def test_device_entropy_decode_matches_host_feeder(hip):
-    """every baseline fixture (all sampling modes, optimised tables, restart intervals) in ONE mixed batch: the coefficients
-    and max_zag the GPU lanes write == the oracle's feeder, bit for bit; progressive files are reported, not decoded."""
+@pytest.fixture(params=["device", "host"])
+def progressive_mode(request):
+    """where the progressive files of a batch are entropy-decoded (jpeg_prog.hpp): every scan level on the GPU, or -- what the
+    library picks for a few files -- the host feeder on the thread pool plus an upload of the coefficients"""
+    old = os.environ.get("GAMUT_HIP_JPEG_PROGRESSIVE")
+    os.environ["GAMUT_HIP_JPEG_PROGRESSIVE"] = request.param
+    yield request.param
+    if old is None:
+        del os.environ["GAMUT_HIP_JPEG_PROGRESSIVE"]
+    else:
+        os.environ["GAMUT_HIP_JPEG_PROGRESSIVE"] = old
+
+
+def test_device_entropy_decode_matches_host_feeder(hip, progressive_mode):
+    """every fixture (all sampling modes, optimised tables, restart intervals, baseline AND progressive) in ONE mixed batch: the
+    coefficients and max_zag the GPU writes == the oracle's feeder, bit for bit."""
     blobs = [open(p, "rb").read() for p in JPEGS]
     rc, hst, st, res = _entropy_decode_device(hip, blobs)
+    assert rc == 0, hip.gamut_hip_last_error()
     n_prog = 0
     for path, data, h, s, r in zip(JPEGS, blobs, hst, st, res):
-        if b"\xff\xc2" in data[:2000] and os.path.basename(path).startswith("p_"):
-            assert h == _capi.ERR_UNSUPPORTED and r is None
-            n_prog += 1
-            continue
+        n_prog += b"\xff\xc2" in data[:2000] and os.path.basename(path).startswith("p_")
         assert h == 0 and s == 0, path
         d = O.DecodedJpeg(data)
         co, zz, info = r
         assert (info.width, info.height, info.comps, info.scan_type) == (d.width, d.height, d.comps, d.scan_type)
         assert np.array_equal(co, d.coeffs), path
         assert np.array_equal(zz, d.max_zag), path
-    assert n_prog >= 6 and rc == _capi.ERR_UNSUPPORTED
+    assert n_prog >= 6
+
+
+def _progressive_files():
+    import io
+    from PIL import Image
+    import gen
+    img = Image.fromarray(gen.synth_rgb(1920, 1080, 21))
+    small = Image.fromarray(gen.synth_rgb(203, 117, 22))
+    blobs = []
+    for im, kw in ((img, dict(quality=90, subsampling=2)), (img, dict(quality=75, subsampling=0, optimize=True)),
+                   (img, dict(quality=96, subsampling=1)), (img.convert("L"), dict(quality=85)),
+                   (small, dict(quality=90, subsampling=2, restart_marker_blocks=5)), (small, dict(quality=50, subsampling=1, restart_marker_rows=1)),
+                   (small, dict(quality=100, subsampling=0)), (small.convert("L"), dict(quality=30, restart_marker_blocks=2)),
+                   (Image.fromarray(gen.synth_rgb(64, 48, 23)), dict(quality=5, subsampling=2)),
+                   (Image.fromarray(np.zeros((40, 56, 3), np.uint8)), dict(quality=90, subsampling=2))):
+        bio = io.BytesIO(); im.save(bio, "JPEG", progressive=True, **kw); blobs.append(bio.getvalue())
+    return blobs
+
+
+def test_device_progressive_decode(hip, progressive_mode):
+    """progressive files written by libjpeg (its default scan script: DC first, five AC first scans, AC / DC refinements; with and
+    without restart intervals, optimised tables, every sampling mode) mixed with baseline ones: == the oracle's feeder"""
+    import io
+    from PIL import Image
+    import gen
+    blobs = _progressive_files()
+    bio = io.BytesIO(); Image.fromarray(gen.synth_rgb(333, 222, 24)).save(bio, "JPEG", quality=88, subsampling=2); blobs.insert(3, bio.getvalue())
+    assert sum(b"\xff\xc2" in b[:2000] for b in blobs) == len(blobs) - 1
+    rc, hst, st, res = _entropy_decode_device(hip, blobs)
+    assert rc == 0 and hst == [0] * len(blobs) and not st.any(), hip.gamut_hip_last_error()
+    for k, (data, (co, zz, info)) in enumerate(zip(blobs, res)):
+        d = O.DecodedJpeg(data)
+        assert np.array_equal(co, d.coeffs), (k, np.count_nonzero(co != d.coeffs))
+        assert np.array_equal(zz, d.max_zag), k
+
+
+def test_device_progressive_corrupt_streams(hip):
+    """damaged scans of progressive files on the GPU path: no hang, nothing written outside the file's buffers, the damaged
+    files flagged (a scan that decodes to the end without an impossible code is not an error for the reference either);
+    the intact neighbours are untouched"""
+    os.environ["GAMUT_HIP_JPEG_PROGRESSIVE"] = "device"
+    try:
+        good = _progressive_files()[0]
+        sos = good.index(b"\xff\xda")
+        rng = np.random.default_rng(5)
+        noisy = bytearray(good)
+        for k in rng.integers(sos + 20, len(good) - 2, 400):
+            noisy[k] = int(rng.integers(0, 255))
+        cut = good[:len(good) // 3]
+        blobs = [good, bytes(noisy), cut, good[:100], good]
+        rc, hst, st, res = _entropy_decode_device(hip, blobs)
+        assert hst[0] == 0 and hst[4] == 0 and st[0] == 0 and st[4] == 0
+        assert hst[3] == _capi.ERR_DECODE
+        d = O.DecodedJpeg(good)
+        for i in (0, 4):
+            assert np.array_equal(res[i][0], d.coeffs) and np.array_equal(res[i][1], d.max_zag)
+    finally:
+        del os.environ["GAMUT_HIP_JPEG_PROGRESSIVE"]
 
 
 def test_device_entropy_decode_large_and_restart_parallel(hip):

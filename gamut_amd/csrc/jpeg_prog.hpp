@@ -64,22 +64,30 @@ __device__ __forceinline__ int64_t prog_unit_block(const ProgImage& im, const Pr
 }
 
 // 128 bits of an unstuffed segment from any bit position, for a whole wave: lane L keeps the big-endian dword at byte
-// chunk + 4 L of the segment (256 bytes per wave, reloaded when the position leaves them), a window is five lane reads.
+// chunk + 4 L of the segment (256 bytes per wave, reloaded when the position leaves them), a window is five v_readlane.
+// Everything about the position is wave-uniform and kept in scalar registers (readfirstlane where the compiler cannot
+// see it): the chain of a scan runs on the scalar unit, whose dependent instructions issue every few cycles -- a vector
+// instruction of a lone wave takes several times as long, and the chain is all there is.
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 struct WaveBits {
-    const uint8_t* seg; uint32_t chunk; uint32_t cw; bool loaded;
-    __device__ __forceinline__ void open(const uint8_t* s) { seg = s; chunk = 0; cw = 0; loaded = false; }
-    __device__ __forceinline__ void window(uint32_t pos, uint64_t& w0, uint64_t& w1)
+    const uint8_t* seg; uint32_t chunk; uint32_t cw;
+    __device__ __forceinline__ void open(const uint8_t* s) { seg = s; chunk = 0; load(); }
+    __device__ __forceinline__ void load()
     {
-        uint32_t byte = pos >> 3;
-        if (!loaded || byte < chunk || byte + 20 > chunk + 256) {
-            chunk = byte & ~3u; loaded = true;
-            uint32_t raw; __builtin_memcpy(&raw, seg + chunk + 4 * (threadIdx.x & 63), 4);
-            cw = __builtin_bswap32(raw);
-        }
-        const uint32_t o = byte - chunk, d = o >> 2, s = (o & 3) * 8 + (pos & 7);
-        const uint64_t a = ((uint64_t)(uint32_t)__shfl((int)cw, (int)d) << 32) | (uint32_t)__shfl((int)cw, (int)d + 1);
-        const uint64_t b = ((uint64_t)(uint32_t)__shfl((int)cw, (int)d + 2) << 32) | (uint32_t)__shfl((int)cw, (int)d + 3);
-        const uint64_t c = (uint64_t)(uint32_t)__shfl((int)cw, (int)d + 4) << 32;
+        uint32_t raw; __builtin_memcpy(&raw, seg + chunk + 4 * (threadIdx.x & 63), 4);
+        cw = __builtin_bswap32(raw);
+    }
+    __device__ __forceinline__ void window(uint32_t pos, uint64_t& w0, uint64_t& w1)     // pos: uniform
+    {
+        pos = rfl(pos); chunk = rfl(chunk);                    // uniform by construction; said so where the compiler lost track
+        const uint32_t byte = pos >> 3;
+        if (byte < chunk || byte + 20 > chunk + 256) { chunk = byte & ~3u; load(); }
+        const uint32_t o = byte - chunk, d = rfl(o >> 2), s = (o & 3) * 8 + (pos & 7);
+        const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)d),     a1 = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)d + 1);
+        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)d + 2), b1 = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)d + 3);
+        const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)d + 4);
+        const uint64_t a = ((uint64_t)a0 << 32) | a1, b = ((uint64_t)b0 << 32) | b1, c = (uint64_t)c0 << 32;
         w0 = s ? (a << s) | (b >> (64 - s)) : a;
         w1 = s ? (b << s) | (c >> (64 - s)) : b;
     }
@@ -87,18 +95,49 @@ struct WaveBits {
 
 constexpr int kProgThreads = 64;
 
+// A Huffman table for a wave on the scalar unit: the 256 entries of an 8-bit look-ahead ((length << 8) | symbol, 0 = longer
+// code) live in four registers across the lanes and are fetched with v_readlane -- no LDS round trip on the chain; the rare
+// longer codes take the canonical search through the table in LDS.
+struct WaveHuff {
+    uint32_t t0, t1, t2, t3;
+    const DevHuff* lds;
+    __device__ __forceinline__ void load(const DevHuff* h, int lane)
+    {
+        lds = h;
+        auto entry = [&](int idx8) -> uint32_t { const uint32_t e = h->fast[idx8 << 1]; return (e >> 8) <= 8 ? e : 0u; };
+        t0 = entry(lane); t1 = entry(64 + lane); t2 = entry(128 + lane); t3 = entry(192 + lane);
+    }
+    // the symbol at the top of the window w0, its length in `len`; -1: no such code
+    __device__ __forceinline__ int decode(uint64_t w0, int& len) const
+    {
+        const int idx = (int)(w0 >> 56), l = idx & 63, j = idx >> 6;
+        const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)t0, l), e1 = (uint32_t)__builtin_amdgcn_readlane((int)t1, l);
+        const uint32_t e2 = (uint32_t)__builtin_amdgcn_readlane((int)t2, l), e3 = (uint32_t)__builtin_amdgcn_readlane((int)t3, l);
+        const uint32_t e = j == 0 ? e0 : j == 1 ? e1 : j == 2 ? e2 : e3;
+        if (e) { len = (int)(e >> 8); return (int)(e & 0xFF); }
+        int32_t code = (int32_t)(w0 >> 55); len = 9;
+        while (code > rfl(lds->maxcode[len])) { if (++len > 16) return -1; code = (int32_t)(w0 >> (64 - len)); }
+        return rfl((int)lds->vals[(code + rfl(lds->delta[len])) & 0xFF]);
+    }
+};
+
+// sampling factors are 1 or 2 (the marker walk rejects anything else): divisions by them are shifts
+__device__ __forceinline__ int64_t prog_block_fast(const ProgImage& im, int hs, int vs, int off, int bx, int by)
+{
+    const int mx = bx >> (hs - 1), my = by >> (vs - 1);
+    return ((int64_t)my * im.mcus_per_row + mx) * im.nb + off + (by & (vs - 1)) * hs + (bx & (hs - 1));
+}
+
 __global__ __launch_bounds__(kProgThreads) void k_prog_scan(const ProgItem* items, const ProgImage* images, const DevHuff* huff_g,
                                                             const uint8_t* blob, int16_t* coeffs, uint32_t* status)
 {
     __shared__ DevHuff sh_huff[3];
-    __shared__ uint8_t sh_zag[64];
     const int lane = threadIdx.x;
     const ProgItem it = items[blockIdx.x];
     const ProgImage im = images[it.image];
-    sh_zag[lane] = kZagDev[lane];
-    const bool need_tab = it.kind != PROG_DC_REFINE;
-    if (need_tab)
-        for (int i = 0; i < it.ncomp; ++i) {
+    const int kind = rfl(it.kind), ncomp = rfl(it.ncomp);
+    if (kind != PROG_DC_REFINE)
+        for (int i = 0; i < ncomp; ++i) {
             const uint32_t* src = reinterpret_cast<const uint32_t*>(huff_g + (i == 0 ? it.tab[0] : i == 1 ? it.tab[1] : it.tab[2]));
             uint32_t* dst = reinterpret_cast<uint32_t*>(&sh_huff[i]);
             for (int k = lane; k < (int)(sizeof(DevHuff) / 4); k += kProgThreads) dst[k] = src[k];
@@ -109,150 +148,204 @@ __global__ __launch_bounds__(kProgThreads) void k_prog_scan(const ProgItem* item
     const uint32_t limit_bit = seg_bytes * 8u + 64u * 8u;       // a decoder that runs past the padding is on a corrupt stream
     int16_t* out = coeffs + im.coeff_off;
     uint32_t* st = status + im.index;
-    int bpu = 1;                                                // blocks per unit
-    if (it.ncomp > 1) {
-        bpu = 0;
-        for (int i = 0; i < it.ncomp; ++i) {
-            const int c = i == 0 ? it.comp[0] : i == 1 ? it.comp[1] : it.comp[2];
-            bpu += (c == 0 ? im.hs[0] : c == 1 ? im.hs[1] : im.hs[2]) * (c == 0 ? im.vs[0] : c == 1 ? im.vs[1] : im.vs[2]);
-        }
+    const int al = rfl(it.al), n_units = rfl(it.n_units), first_unit = rfl(it.first_unit);
+    const uint32_t zag_reg = kZagDev[lane];                     // natural index of zig-zag position `lane`; readlane(zag_reg, k) for a uniform k
+    // geometry of the scan's components (scan order)
+    int c_[3], hs_[3], vs_[3], off_[3];
+    #pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = rfl(i == 0 ? it.comp[0] : i == 1 ? it.comp[1] : it.comp[2]);
+        c_[i] = c; hs_[i] = rfl(c == 0 ? im.hs[0] : c == 1 ? im.hs[1] : im.hs[2]); vs_[i] = rfl(c == 0 ? im.vs[0] : c == 1 ? im.vs[1] : im.vs[2]);
+        off_[i] = c == 0 ? 0 : rfl(im.ny) + c - 1;
     }
 
-    if (it.kind == PROG_DC_FIRST) {                             // decode_block_dc_first :3298-3319
-        if (lane != 0) return;
-        DevBits br; br.open(seg, 0);
-        int pred0 = 0, pred1 = 0, pred2 = 0;
-        for (int u = it.first_unit; u < it.first_unit + it.n_units; ++u) {
-            for (int b = 0; b < bpu; ++b) {
-                int ci; const int64_t blk = prog_unit_block(im, it, u, b, ci);
-                const int s = br.decode(&sh_huff[ci]);
-                if (s < 0) { atomicOr(st, 1u); return; }
-                const int c = ci == 0 ? it.comp[0] : ci == 1 ? it.comp[1] : it.comp[2];
-                const int v = br.receive_extend(s & 15) + (c == 0 ? pred0 : c == 1 ? pred1 : pred2);
-                if (c == 0) pred0 = v; else if (c == 1) pred1 = v; else pred2 = v;
-                out[blk * 64] = (int16_t)((uint32_t)v << it.al);
-            }
-            if (br.pos > limit_bit) { atomicOr(st, 4u); return; }
-        }
-    } else if (it.kind == PROG_DC_REFINE) {                     // decode_block_dc_refine :3321-3333: bit t of the segment belongs to block t
-        const int total = it.n_units * bpu;
+    if (kind == PROG_DC_REFINE) {                               // decode_block_dc_refine :3321-3333: bit t of the segment belongs to block t
+        int bpu = 0;
+        for (int i = 0; i < ncomp; ++i) bpu += (i == 0 ? hs_[0] * vs_[0] : i == 1 ? hs_[1] * vs_[1] : hs_[2] * vs_[2]);
+        if (ncomp == 1) bpu = 1;
+        const int total = n_units * bpu;
         for (int t = lane; t < total; t += kProgThreads) {
             const int u = t / bpu, b = t - u * bpu;
             const uint32_t byte = (uint32_t)t >> 3;
             const uint32_t v = byte < seg_bytes ? seg[byte] : 0xFFu;                    // past the data: ones (get_octet :683-696)
             if ((v >> (7 - (t & 7))) & 1u) {
-                int ci; const int64_t blk = prog_unit_block(im, it, it.first_unit + u, b, ci);
-                out[blk * 64] = (int16_t)(out[blk * 64] | (1 << it.al));
+                int ci; const int64_t blk = prog_unit_block(im, it, first_unit + u, b, ci);
+                out[blk * 64] = (int16_t)(out[blk * 64] | (1 << al));
             }
         }
-    } else if (it.kind == PROG_AC_FIRST) {                      // decode_block_ac_first :3335-3398
-        if (lane != 0) return;
-        DevBits br; br.open(seg, 0);
-        int eobrun = 0;
-        const int c = it.comp[0];
-        int bx = it.first_unit % it.nbx, by = it.first_unit / it.nbx;
-        for (int u = 0; u < it.n_units; ++u) {
+        return;
+    }
+
+    WaveBits wb; wb.open(seg);
+    uint32_t pos = 0;
+    if (kind == PROG_DC_FIRST) {                                // decode_block_dc_first :3298-3319
+        WaveHuff h0, h1, h2;
+        h0.load(&sh_huff[0], lane); h1.load(&sh_huff[ncomp > 1 ? 1 : 0], lane); h2.load(&sh_huff[ncomp > 2 ? 2 : 0], lane);
+        int pred0 = 0, pred1 = 0, pred2 = 0;
+        auto one = [&](int i, int64_t blk) -> bool {              // one block of the scan's i-th component
+            uint64_t w0, w1; wb.window(pos, w0, w1);
+            int len; const int s = i == 0 ? h0.decode(w0, len) : i == 1 ? h1.decode(w0, len) : h2.decode(w0, len);
+            if (s < 0) { if (lane == 0) atomicOr(st, 1u); return false; }
+            const int n = s & 15;
+            int v = n ? (int)((w0 << len) >> (64 - n)) : 0;
+            if (n && v < (1 << (n - 1))) v += (int)(0xFFFFFFFFu << n) + 1;               // JPGD_HUFF_EXTEND :816-822
+            pos += (uint32_t)(len + n);
+            v += i == 0 ? pred0 : i == 1 ? pred1 : pred2;
+            if (i == 0) pred0 = v; else if (i == 1) pred1 = v; else pred2 = v;
+            if (lane == 0) out[blk * 64] = (int16_t)((uint32_t)v << al);
+            return true;
+        };
+        if (ncomp == 1) {
+            const int nbx = rfl(it.nbx);
+            int by = first_unit / nbx, bx = first_unit - by * nbx;
+            for (int u = 0; u < n_units; ++u) {
+                if (!one(0, prog_block_fast(im, hs_[0], vs_[0], off_[0], bx, by))) return;
+                if (pos > limit_bit) { if (lane == 0) atomicOr(st, 4u); return; }
+                if (++bx == nbx) { bx = 0; ++by; }
+            }
+        } else {
+            int64_t base = (int64_t)first_unit * im.nb;           // the MCU's first block: inside an MCU the scan order is the buffer's order
+            for (int u = 0; u < n_units; ++u, base += im.nb) {
+                for (int i = 0; i < ncomp; ++i) {
+                    const int nblk = i == 0 ? hs_[0] * vs_[0] : i == 1 ? hs_[1] * vs_[1] : hs_[2] * vs_[2];
+                    const int off = i == 0 ? off_[0] : i == 1 ? off_[1] : off_[2];
+                    for (int b = 0; b < nblk; ++b) if (!one(i, base + off + b)) return;
+                }
+                if (pos > limit_bit) { if (lane == 0) atomicOr(st, 4u); return; }
+            }
+        }
+        return;
+    }
+
+    // AC scans: one component, its blocks in raster order
+    WaveHuff ac; ac.load(&sh_huff[0], lane);
+    const int ss = rfl(it.ss), se = rfl(it.se), nbx = rfl(it.nbx);
+    const int hs = hs_[0], vs = vs_[0], off = off_[0];
+    int by = first_unit / nbx, bx = first_unit - by * nbx;
+    int eobrun = 0;
+    if (kind == PROG_AC_FIRST) {                                // decode_block_ac_first :3335-3398
+        for (int u = 0; u < n_units; ++u) {
+            eobrun = rfl(eobrun);
             if (eobrun) --eobrun;
             else {
-                int16_t* blk = out + prog_block(im, c, bx, by) * 64;
-                for (int k = it.ss; k <= it.se; ++k) {
-                    const int rs = br.decode(&sh_huff[0]);
-                    if (rs < 0) { atomicOr(st, 1u); return; }
+                int16_t* blk = out + prog_block_fast(im, hs, vs, off, bx, by) * 64;
+                for (int k = ss; k <= se; ++k) {
+                    k = rfl(k);
+                    uint64_t w0, w1; wb.window(pos, w0, w1);
+                    int len; const int rs = ac.decode(w0, len);
+                    if (rs < 0) { if (lane == 0) atomicOr(st, 1u); return; }
                     const int run = rs >> 4, size = rs & 15;
                     if (size) {
-                        if ((k += run) > 63) { atomicOr(st, 2u); return; }
-                        blk[sh_zag[k]] = (int16_t)((uint32_t)br.receive_extend(size) << it.al);
+                        if ((k += run) > 63) { if (lane == 0) atomicOr(st, 2u); return; }
+                        int v = (int)((w0 << len) >> (64 - size));
+                        if (v < (1 << (size - 1))) v += (int)(0xFFFFFFFFu << size) + 1;
+                        pos += (uint32_t)(len + size);
+                        const int nat = __builtin_amdgcn_readlane((int)zag_reg, k);
+                        if (lane == 0) blk[nat] = (int16_t)((uint32_t)v << al);
                     } else if (run == 15) {
-                        if ((k += 15) > 63) { atomicOr(st, 2u); return; }
+                        pos += (uint32_t)len;
+                        if ((k += 15) > 63) { if (lane == 0) atomicOr(st, 2u); return; }
                     } else {                                     // EOBn: this block and the next eobrun blocks end here
-                        int extra = 0;
-                        if (run) { br.refill(); extra = (int)br.peek(run); br.drop(run); }
+                        const int extra = run ? (int)((w0 << len) >> (64 - run)) : 0;
+                        pos += (uint32_t)(len + run);
                         eobrun = (1 << run) + extra - 1;
                         break;
                     }
                 }
-                if (br.pos > limit_bit) { atomicOr(st, 4u); return; }
+                if (pos > limit_bit) { if (lane == 0) atomicOr(st, 4u); return; }
             }
-            if (++bx == it.nbx) { bx = 0; ++by; }
+            if (++bx == nbx) { bx = 0; ++by; }
         }
-    } else {                                                    // decode_block_ac_refine :3400-3518, a wave per block
-        const int c = it.comp[0];
-        const DevHuff* ac = &sh_huff[0];
-        const int nat = sh_zag[lane];                           // this lane's coefficient: zig-zag position `lane`
-        const uint64_t lane_bit = 1ull << lane, below = lane_bit - 1;
-        const uint64_t band = (it.se >= 63 ? ~0ull : (1ull << (it.se + 1)) - 1) & ~((1ull << it.ss) - 1);
-        const int plus = 1 << it.al, minus = (int)(0xFFFFFFFFu << it.al);
-        WaveBits wb; wb.open(seg);
-        uint32_t pos = 0;
-        int eobrun = 0;
-        int bx = it.first_unit % it.nbx, by = it.first_unit / it.nbx;
-        int16_t* blk = out + prog_block(im, c, bx, by) * 64;
-        int next_coef = it.n_units > 0 ? blk[nat] : 0;
-        for (int u = 0; u < it.n_units; ++u) {
-            int coef = next_coef;
-            int16_t* const cur = blk;
-            if (++bx == it.nbx) { bx = 0; ++by; }
-            if (u + 1 < it.n_units) { blk = out + prog_block(im, c, bx, by) * 64; next_coef = blk[nat]; }       // in flight while this block is decoded
-            const int orig = coef;
-            const uint64_t nz = __ballot(coef != 0) & band;
-            int k = it.ss;
-            bool bad = false;
-            if (eobrun == 0) {
-                while (k <= it.se) {
-                    uint64_t w0, w1; wb.window(pos, w0, w1);
-                    int len, sym;
-                    const uint32_t e = ac->fast[(uint32_t)(w0 >> 55)];
-                    if (e) { len = (int)(e >> 8); sym = (int)(e & 0xFF); }
-                    else {
-                        int32_t code = (int32_t)(w0 >> 55); len = 9;
-                        while (code > ac->maxcode[len]) { if (++len > 16) break; code = (int32_t)(w0 >> (64 - len)); }
-                        if (len > 16) { bad = true; break; }
-                        sym = ac->vals[(code + ac->delta[len]) & 0xFF];
-                    }
-                    const int run = sym >> 4, size = sym & 15;
-                    int used = len, fresh = 0;
-                    if (size) {
-                        if (size != 1) { bad = true; break; }
-                        fresh = ((w0 >> (63 - used)) & 1ull) ? plus : minus;
-                        ++used;
-                    } else if (run != 15) {
-                        const int extra = run ? (int)((w0 << used) >> (64 - run)) : 0;
-                        eobrun = (1 << run) + extra;
-                        pos += (uint32_t)(used + run);
-                        break;
-                    }
-                    // walk on from k over `run` zeros to the zero that ends the run, correcting every coefficient with history on the way
-                    const uint64_t from_k = ~((1ull << k) - 1);
-                    const uint64_t zeros = ~nz & band & from_k;
-                    const bool is_stop = (zeros & lane_bit) && __popcll(zeros & below) == run;
-                    const uint64_t sm = __ballot(is_stop);
-                    const int stop = sm ? __ffsll((long long)sm) - 1 : it.se + 1;
-                    const uint64_t corr = nz & from_k & (stop >= 64 ? ~0ull : (1ull << stop) - 1);
-                    if (corr & lane_bit) {
-                        const uint64_t cbits = (w0 << used) | (w1 >> (64 - used));             // used >= 1
-                        const int r = __popcll(corr & below);
-                        if (((cbits >> (63 - r)) & 1ull) && (coef & plus) == 0) coef = (int16_t)(coef + (coef >= 0 ? plus : minus));
-                    }
-                    pos += (uint32_t)(used + __popcll(corr));
-                    if (fresh && stop < 64 && lane == stop) coef = fresh;
-                    k = stop + 1;
-                }
+        return;
+    }
+
+    // decode_block_ac_refine :3400-3518, a wave per block: lane k holds the coefficient at zig-zag position k
+    {
+        const int nat = (int)zag_reg;
+        const uint64_t band = (se >= 63 ? ~0ull : (1ull << (se + 1)) - 1) & ~((1ull << ss) - 1);
+        const int plus = 1 << al, minus = (int)(0xFFFFFFFFu << al);
+        // the blocks are fetched kAhead blocks ahead of their turn (they come from HBM: the scans before wrote gigabytes since).
+        // Only the coefficients a block changes go back, one by one: a DC refinement scan of the same level may be writing
+        // coefficient 0 of the same blocks meanwhile.  (Fetching 64 blocks at a time through LDS was no faster: the chain's
+        // own instructions, not the memory latency, are its time.)
+        constexpr int kAhead = 4;
+        int16_t* ring_ptr[kAhead]; int ring_val[kAhead];
+        int fx = bx, fy = by;                                   // the next block to fetch
+        #pragma unroll
+        for (int a = 0; a < kAhead; ++a) {
+            ring_ptr[a] = out; ring_val[a] = 0;
+            if (a < n_units) {
+                ring_ptr[a] = out + prog_block_fast(im, hs, vs, off, fx, fy) * 64; ring_val[a] = ring_ptr[a][nat];
+                if (++fx == nbx) { fx = 0; ++fy; }
             }
-            if (bad) { if (lane == 0) atomicOr(st, 1u); return; }
-            if (eobrun > 0) {
-                const uint64_t corr = nz & ~((1ull << k) - 1);
-                if (corr) {
-                    uint64_t w0, w1; wb.window(pos, w0, w1);
-                    if (corr & lane_bit) {
-                        const int r = __popcll(corr & below);
-                        if (((w0 >> (63 - r)) & 1ull) && (coef & plus) == 0) coef = (int16_t)(coef + (coef >= 0 ? plus : minus));
-                    }
-                    pos += (uint32_t)__popcll(corr);
+        }
+        for (int u0 = 0; u0 < n_units; u0 += kAhead) {
+            #pragma unroll
+            for (int a = 0; a < kAhead; ++a) {
+                const int u = u0 + a;
+                if (u >= n_units) break;
+                int coef = ring_val[a];
+                int16_t* const cur = ring_ptr[a];
+                if (u + kAhead < n_units) {
+                    ring_ptr[a] = out + prog_block_fast(im, hs, vs, off, fx, fy) * 64; ring_val[a] = ring_ptr[a][nat];
+                    if (++fx == nbx) { fx = 0; ++fy; }
                 }
-                --eobrun;
+                const int orig = coef;
+                const uint64_t nz = __ballot(coef != 0) & band;
+                int k = ss;
+                bool bad = false;
+                eobrun = rfl(eobrun);
+                if (eobrun == 0) {
+                    while (k <= se) {
+                        k = rfl(k);
+                        uint64_t w0, w1; wb.window(pos, w0, w1);
+                        int len; const int sym = ac.decode(w0, len);
+                        if (sym < 0) { bad = true; break; }
+                        const int run = sym >> 4, size = sym & 15;
+                        int used = len, fresh = 0;
+                        if (size) {
+                            if (size != 1) { bad = true; break; }
+                            fresh = ((w0 >> (63 - used)) & 1ull) ? plus : minus;
+                            ++used;
+                        } else if (run != 15) {
+                            const int extra = run ? (int)((w0 << used) >> (64 - run)) : 0;
+                            eobrun = (1 << run) + extra;
+                            pos += (uint32_t)(used + run);
+                            break;
+                        }
+                        // walk on from k over `run` zeros to the zero that ends the run, correcting every coefficient with history on the way
+                        const uint64_t from_k = ~((1ull << k) - 1);
+                        const uint64_t zeros = ~nz & band & from_k;
+                        const int zeros_below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(zeros >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)zeros, 0u));
+                        const uint64_t sm = __ballot(zeros_below == run) & zeros;          // the zeros with exactly `run` zeros below them: the first is the stop
+                        const int stop = sm ? __builtin_ctzll(sm) : se + 1;
+                        const uint64_t corr = nz & from_k & (stop >= 64 ? ~0ull : (1ull << stop) - 1);
+                        if (corr) {
+                            const uint64_t cbits = (w0 << used) | (w1 >> (64 - used));         // used >= 1
+                            const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(corr >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)corr, 0u));
+                            const bool mine = (corr >> lane) & 1ull;
+                            if (mine && ((cbits >> (63 - r)) & 1ull) && (coef & plus) == 0) coef = (int16_t)(coef + (coef >= 0 ? plus : minus));
+                        }
+                        pos += (uint32_t)(used + __popcll(corr));
+                        if (fresh && lane == stop) coef = fresh;                              // stop <= 64: no lane if the walk ran off the block
+                        k = stop + 1;
+                    }
+                }
+                if (bad) { if (lane == 0) atomicOr(st, 1u); return; }
+                if (eobrun > 0) {
+                    const uint64_t corr = nz & ~((1ull << k) - 1);
+                    if (corr) {
+                        uint64_t w0, w1; wb.window(pos, w0, w1);
+                        const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(corr >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)corr, 0u));
+                        const bool mine = (corr >> lane) & 1ull;
+                        if (mine && ((w0 >> (63 - r)) & 1ull) && (coef & plus) == 0) coef = (int16_t)(coef + (coef >= 0 ? plus : minus));
+                        pos += (uint32_t)__popcll(corr);
+                    }
+                    --eobrun;
+                }
+                if (coef != orig) cur[nat] = (int16_t)coef;
+                if (pos > limit_bit) { if (lane == 0) atomicOr(st, 4u); return; }
             }
-            if (coef != orig) cur[nat] = (int16_t)coef;
-            if (pos > limit_bit) { if (lane == 0) atomicOr(st, 4u); return; }
         }
     }
 }
@@ -464,12 +557,14 @@ int progressive_decode_device(const uint8_t* const* data, const size_t* len, con
     int workers = host_threads();
     workers = workers < 1 ? 1 : workers > 16 ? 16 : workers;
     if (workers > n) workers = n;
-    // A scan is a chain: the GPU decodes one about five times slower than a host core does, and wins by decoding every
-    // scan of every file at the same time.  Below a few files per host thread the host feeder (Progressive::run on the
-    // thread pool) plus an upload of the coefficients is the faster way to the same buffers.  GAMUT_HIP_JPEG_PROGRESSIVE =
+    // A scan is a chain: the GPU decodes one several times slower than a host core does (190 ms for the scans of a 1080p
+    // file, whatever the batch, against 20 ms), and wins by decoding every scan of every file at the same time.  Below
+    // eight files per host thread (16 threads: 1 300 Mpx/s; the GPU: 700 Mpx/s for 64 files, 2 700 for 256, 8 300 for 1024)
+    // the host feeder (Progressive::run on the thread pool) plus an upload of the coefficients is the faster way to the
+    // same buffers.  GAMUT_HIP_JPEG_PROGRESSIVE =
     // host / device forces either (tests, measurements).
     const char* how = getenv("GAMUT_HIP_JPEG_PROGRESSIVE");
-    const bool on_host = how && !strcmp(how, "host") ? true : how && !strcmp(how, "device") ? false : n < 4 * workers;
+    const bool on_host = how && !strcmp(how, "host") ? true : how && !strcmp(how, "device") ? false : n < 8 * workers;
     if (on_host) {
         std::vector<gamut_hip_jpeg_frame> frames((size_t)n);
         std::vector<int> rcs((size_t)n, GAMUT_HIP_OK);
@@ -604,6 +699,11 @@ int progressive_decode_device(const uint8_t* const* data, const size_t* len, con
                 hipLaunchKernelGGL(k_prog_scan, dim3((unsigned)by_level[lv].size()), dim3(kProgThreads), 0, stream,
                                    (const ProgItem*)(d + level_off[lv]), (const ProgImage*)(d + o_img), (const DevHuff*)(d + o_huff), d_blob, d_coeffs, st);
                 if (int rc = launch_status("jpeg_prog_scan")) return rc;
+                if (trace) {
+                    const auto t_l = std::chrono::steady_clock::now();
+                    (void)hipStreamSynchronize(stream);
+                    fprintf(stderr, "[gamut_hip]   level %zu: %zu segments, %.1f ms (with what was queued before it)\n", lv, by_level[lv].size(), ms_since(t_l));
+                }
             }
             const unsigned gx = (unsigned)std::min<int64_t>((max_blocks + 31) / 32, 4096);
             hipLaunchKernelGGL(k_prog_finalize, dim3(gx, (unsigned)live.size()), dim3(256), 0, stream,

@@ -162,9 +162,12 @@ int  gamut_hip_jpeg_scan_layout(const uint8_t* data, size_t len, gamut_hip_jpeg_
  * interval where the file has short ones -- writes the
  * dense de-quantised coefficient form (what decode_next_row, jpegload.d:2405-2525, leaves per MCU row) into
  * coeffs[coeff_offset[i] ..] (int16 elements) and max_zag[zag_offset[i] ..] (device pointers, caller-sized from
- * gamut_hip_jpeg_read_header).  info[i] receives the geometry (host), status_host[i] (may be NULL) the per-file header
- * status -- GAMUT_HIP_ERR_UNSUPPORTED for progressive files, which stay with the host feeder -- and status_dev[i] (device,
- * may be NULL) becomes non-zero if file i's entropy stream is corrupt.  Returns when the decode has finished on `stream`;
+ * gamut_hip_jpeg_read_header).  Progressive (SOF2) files of the batch (jpegload.d:3296-3664) go to the same buffers: their
+ * scans are decoded level by level on the device -- every scan of a level of every file in one launch; AC refinement
+ * blocks a wave each -- then de-quantised in place (gamut_amd/csrc/jpeg_prog.hpp); fewer than eight such files per host
+ * thread are decoded by the host feeder and uploaded instead (GAMUT_HIP_JPEG_PROGRESSIVE=host / device forces either).
+ * info[i] receives the geometry (host), status_host[i] (may be NULL) the per-file header status, and status_dev[i]
+ * (device, may be NULL) becomes non-zero if file i's entropy stream is corrupt.  Returns when the decode has finished on `stream`;
  * the status of the lowest-numbered failing file, GAMUT_HIP_OK if none. */
 int  gamut_hip_jpeg_entropy_decode_device(const uint8_t* const* data, const size_t* len, int count,
                                           const int64_t* coeff_offset, const int64_t* zag_offset,

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--restart-rows", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--progressive", action="store_true", help="progressive (SOF2) files: libjpeg's default scan script")
     a = ap.parse_args()
     L = _capi.lib()
     _capi.check(L.gamut_hip_init(0))
@@ -38,6 +39,8 @@ def main():
         kw = dict(quality=90, subsampling=2)
         if a.restart_rows:
             kw["restart_marker_rows"] = a.restart_rows
+        if a.progressive:
+            kw["progressive"] = True
         Image.fromarray(gen.synth_rgb(w, h, 100 + i)).save(bio, "JPEG", **kw)
         files.append(np.frombuffer(bio.getvalue(), np.uint8))
     bufs = [files[i % a.distinct] for i in range(B)]
@@ -80,7 +83,7 @@ def main():
         return t1
 
     mb = sum(b.size for b in bufs) / 1e6
-    print(f"batch {B} x {w}x{h} baseline 4:2:0, {mb / B * 1e3:.0f} kB/file, restart rows {a.restart_rows}, host threads {a.threads or os.cpu_count()}")
+    print(f"batch {B} x {w}x{h} {'progressive' if a.progressive else 'baseline'} 4:2:0, {mb / B * 1e3:.0f} kB/file, restart rows {a.restart_rows}, host threads {a.threads or os.cpu_count()}")
     ref = None
     for name, fn in (("A host feeder + coefficient upload", path_a), ("B device entropy decode", path_b)):
         best, best_first = 1e9, 0

@@ -1214,6 +1214,18 @@ int gamut_hip_jpeg_scan_layout(const uint8_t* data, size_t len, gamut_hip_jpeg_f
         FilePrep fp;
         prepare_header(0, data, len, *info, fp, *ps);
         delete ps;
+        if (fp.progressive) {                                  // every scan of the file, cut at its restart markers (jpeg_prog.hpp)
+            Parser* pp = new Parser();
+            ProgPrep pr;
+            prog_prepare(0, data, len, *info, pr, *pp);
+            delete pp;
+            std::vector<uint8_t> bytes(pr.rc == GAMUT_HIP_OK ? pr.cap : 0);
+            if (pr.rc == GAMUT_HIP_OK) prog_unstuff(0, data, *info, pr, bytes.data());
+            if (segments) *segments = (int32_t)pr.items.size();
+            if (entropy_bytes) *entropy_bytes = pr.used;
+            if (pr.rc != GAMUT_HIP_OK) return set_error(pr.rc, "%s", pr.msg);
+            return GAMUT_HIP_OK;
+        }
         std::vector<uint8_t> bytes(fp.rc == GAMUT_HIP_OK ? fp.cap : 0);
         if (fp.rc == GAMUT_HIP_OK) unstuff_file(0, data, len, *info, fp, bytes.data());
         if (segments) *segments = (int32_t)fp.items.size();

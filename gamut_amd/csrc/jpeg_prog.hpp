@@ -474,8 +474,10 @@ void prog_prepare(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& f,
     // de-quantisation happens after the last scan, with the tables as they stand then (load_next_row :2306-2323)
     for (int c = 0; c < f.comps; ++c) for (int k = 0; k < 64; ++k) out.quant[c].q[kZag[k]] = P.quant[P.tq[c]][k];
     out.cap = 0;
+    size_t all_segs = 0;
     for (const ProgScanPrep& s : out.scans) {
         const size_t segs = s.restart_interval ? (size_t)(s.units / s.restart_interval + 1) : 1;
+        if ((all_segs += segs) > ((size_t)1 << 22)) return bad("too many restart intervals");      // 256 scans x one interval per block of a 16384 x 16384 frame: gigabytes of segment records
         out.cap += (s.end - s.begin) + (64 + 4) * segs + 16;    // per segment: 64 bytes of padding, then up to the next dword
     }
 }

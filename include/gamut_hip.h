@@ -152,8 +152,9 @@ void gamut_hip_jpeg_frame_free(gamut_hip_jpeg_frame* f);
 /* header walk only (markers up to the first SOS): geometry and JFIF density; coeffs / max_zag stay NULL.  Lets a caller
  * size and lay out device buffers: an image needs mcus_per_row * mcus_per_col * blocks_per_mcu blocks of 64 int16. */
 int  gamut_hip_jpeg_read_header(const uint8_t* data, size_t len, gamut_hip_jpeg_frame* out);
-/* what the device entropy decoder would be given for this (baseline) file: the geometry, the number of independently
- * decodable segments (restart intervals, or 1) and the size of the unstuffed entropy-coded data with its padding.
+/* what the device entropy decoder would be given for this file: the geometry, the number of independently
+ * decodable segments (restart intervals, or 1; for a progressive file: summed over its scans) and the size of the
+ * unstuffed entropy-coded data with its padding.
  * Host only; the same preparation code gamut_hip_jpeg_entropy_decode_device runs per file. */
 int  gamut_hip_jpeg_scan_layout(const uint8_t* data, size_t len, gamut_hip_jpeg_frame* info, int32_t* segments, uint64_t* entropy_bytes);
 /* Entropy decode ON THE DEVICE of `count` baseline files given in host memory: the compressed

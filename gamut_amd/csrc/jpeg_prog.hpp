@@ -561,12 +561,12 @@ int progressive_decode_device(const uint8_t* const* data, const size_t* len, con
     if (workers > n) workers = n;
     // A scan is a chain: the GPU decodes one several times slower than a host core does (190 ms for the scans of a 1080p
     // file, whatever the batch, against 20 ms), and wins by decoding every scan of every file at the same time.  Below
-    // eight files per host thread (16 threads: 1 300 Mpx/s; the GPU: 700 Mpx/s for 64 files, 2 700 for 256, 8 300 for 1024)
-    // the host feeder (Progressive::run on the thread pool) plus an upload of the coefficients is the faster way to the
-    // same buffers.  GAMUT_HIP_JPEG_PROGRESSIVE =
-    // host / device forces either (tests, measurements).
+    // twelve files per host thread (16 threads: 2 100 Mpx/s for 64 files, 1 760 for 256, 1 400 from 1024 on; the GPU: 730 Mpx/s
+    // for 64 files, 2 780 for 256, 8 790 for 1024, 13 400 for 4096) the host feeder (Progressive::run on the thread pool)
+    // plus an upload of the coefficients is the faster way to the same buffers.  GAMUT_HIP_JPEG_PROGRESSIVE = host / device
+    // forces either (tests, measurements).
     const char* how = getenv("GAMUT_HIP_JPEG_PROGRESSIVE");
-    const bool on_host = how && !strcmp(how, "host") ? true : how && !strcmp(how, "device") ? false : n < 8 * workers;
+    const bool on_host = how && !strcmp(how, "host") ? true : how && !strcmp(how, "device") ? false : n < 12 * workers;
     if (on_host) {
         std::vector<gamut_hip_jpeg_frame> frames((size_t)n);
         std::vector<int> rcs((size_t)n, GAMUT_HIP_OK);

@@ -165,7 +165,7 @@ int  gamut_hip_jpeg_scan_layout(const uint8_t* data, size_t len, gamut_hip_jpeg_
  * coeffs[coeff_offset[i] ..] (int16 elements) and max_zag[zag_offset[i] ..] (device pointers, caller-sized from
  * gamut_hip_jpeg_read_header).  Progressive (SOF2) files of the batch (jpegload.d:3296-3664) go to the same buffers: their
  * scans are decoded level by level on the device -- every scan of a level of every file in one launch; AC refinement
- * blocks a wave each -- then de-quantised in place (gamut_amd/csrc/jpeg_prog.hpp); fewer than eight such files per host
+ * blocks a wave each -- then de-quantised in place (gamut_amd/csrc/jpeg_prog.hpp); fewer than twelve such files per host
  * thread are decoded by the host feeder and uploaded instead (GAMUT_HIP_JPEG_PROGRESSIVE=host / device forces either).
  * info[i] receives the geometry (host), status_host[i] (may be NULL) the per-file header status, and status_dev[i]
  * (device, may be NULL) becomes non-zero if file i's entropy stream is corrupt.  Returns when the decode has finished on `stream`;

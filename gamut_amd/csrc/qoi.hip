@@ -355,6 +355,246 @@ __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* it
     }
 }
 
+// ---- the same decode as a PIPELINE: five waves per stream (batches below kQoiWideBelow streams) --------------------------------
+// In k_qoi_decode<4> the four waves prepare a window together (A, compaction, B), then three of them wait while wave 0 walks its
+// groups (C), then all write its pixels (D): the serial walk and the parallel phases take turns.  Here wave 0 does nothing but C,
+// and waves 1-4 prepare window w + 1 and write the pixels of window w - 1 meanwhile (two sets of buffers): a stream takes
+// max(C, A + B + D) instead of their sum.  The hardware barrier counts every wave of the workgroup, so the four producers meet at a
+// counter in LDS instead, and windows change hands through two monotonic flags per buffer set (ready: prepared up to window w;
+// done: walked up to window w).  Every wait is bounded: a flag that never comes (a bug) ends the wait, never hangs the GPU.
+// A prepared op is 8 bytes here (M and U only take three values each: nothing / colour bytes / all, and nothing / alpha / all).
+constexpr int kPipeT = 256;                                   // producer threads
+struct QoiPipeBuf {
+    uint32_t win[kQoiWin / 4 + 4];
+    uint16_t ops[kQoiWin];
+    uint2    prep[kQoiWin];                                    // V | run-length prefix, own run length << 12, first byte << 18, is_index << 26, M code << 27, U code << 29
+    uint32_t xs[kQoiWin];
+    uint32_t gpos[kQoiWin / 64];
+    uint32_t nops, gdone;
+};
+__device__ __forceinline__ void qoi_flag_set(uint32_t* f, uint32_t v, int lane)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void qoi_flag_wait(uint32_t* f, uint32_t v)
+{
+    for (uint32_t spins = 0; __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v && spins < 2000000u; ++spins) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void qoi_producers_meet(uint32_t* counter, uint32_t& target, int lane)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    target += 4u;
+    qoi_flag_wait(counter, target);
+}
+
+__global__ __launch_bounds__(320) void k_qoi_pipe(const QoiItem* items, int n_items, const uint8_t* blob, uint8_t* out)
+{
+    constexpr int kLaneBytes = kQoiWin / kPipeT;              // 8
+    __shared__ QoiPipeBuf pb[2];
+    __shared__ unsigned long long table[64];
+    __shared__ uint32_t wave_map[4], wave_cnt[4], f_ready[2], f_done[2], f_meet;
+    struct __attribute__((packed, aligned(1))) AnyU32 { uint32_t v; };
+    struct __attribute__((packed, aligned(1))) AnyU64 { uint64_t v; };
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    if ((int)blockIdx.x >= n_items) return;
+    const QoiItem it = items[blockIdx.x];
+    const bool rgba = it.channels == 4;
+    uint8_t* pixels = out + it.out_off;
+    const uint8_t* stream = blob + it.begin + kQoiHeader;
+    const int chunk_bytes = (int)it.size - kQoiPadding - kQoiHeader > 0 ? (int)it.size - kQoiPadding - kQoiHeader : 0;
+    const int avail = (int)it.size - kQoiHeader + kQoiSlack;
+    const uint32_t npx_total = it.npx;
+    if (t < 64) table[t] = 0;
+    if (t == 0) { f_ready[0] = f_ready[1] = f_done[0] = f_done[1] = f_meet = 0; }
+    __syncthreads();
+    auto store_px = [&](size_t px, uint32_t v) {
+        if (rgba) reinterpret_cast<AnyU32*>(pixels + px * 4)->v = v;
+        else { uint8_t* o = pixels + px * 3; o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)(v >> 16); }
+    };
+
+    if (wave == 0) {
+        // ---- C: the walk (see k_qoi_decode::resolve_group) ------------------------------------------------------------------------
+        uint32_t carry = 0xFF000000u, produced = 0, ops_done = 0;
+        uint32_t w = 0;
+        for (int pos = 0; pos < chunk_bytes; pos += kQoiWin, ++w) {
+            QoiPipeBuf& B = pb[w & 1u];
+            qoi_flag_wait(&f_ready[w & 1u], w + 1u);
+            const uint32_t nops = B.nops;
+            uint32_t g = 0;
+            if (produced < npx_total && nops) {
+                uint2 pr = B.prep[lane];
+                for (; g < nops && produced < npx_total; g += 64) {
+                    const uint32_t mc = (pr.y >> 27) & 3u, uc = (pr.y >> 29) & 3u;
+                    const QoiFn f = { mc == 0u ? 0u : mc == 1u ? 0x00FFFFFFu : 0xFFFFFFFFu, pr.x, uc == 0u ? 0u : uc == 1u ? 0xFF000000u : 0xFFFFFFFFu };
+                    const uint32_t run_incl = pr.y & 0xFFFu, b1 = (pr.y >> 18) & 255u;
+                    const bool is_index = ((pr.y >> 26) & 1u) != 0;
+                    if (g + 64 < nops) pr = B.prep[g + 64 + lane];
+                    const uint32_t cnt = nops - g < 64u ? nops - g : 64u;
+                    const bool active = (uint32_t)lane < cnt;
+                    uint32_t x = qoi_add_bytes(carry & ~f.M, f.V);
+                    uint64_t todo = __ballot(is_index && active);
+                    uint32_t h = qoi_hash(x);
+                    if (todo) {
+                        const uint32_t tab = (uint32_t)table[lane];
+                        do {
+                            const int j = __builtin_ctzll(todo);
+                            todo &= todo - 1;
+                            const int jn = todo ? __builtin_ctzll(todo) : 64;
+                            const uint32_t slot = qoi_readlane(b1, j) & 63u;
+                            const uint64_t m = __ballot(h == slot) & ((1ull << j) - 1ull);
+                            const uint32_t base = m ? qoi_readlane(x, 63 - __builtin_clzll(m)) : qoi_readlane(tab, (int)slot);
+                            const uint32_t nx = qoi_add_bytes(base & f.U, f.V);
+                            const bool in = lane >= j && lane < jn;
+                            x = in ? nx : x;
+                            h = in ? qoi_hash(nx) : h;
+                        } while (todo);
+                    }
+                    if (active) atomicMax(&table[h], (unsigned long long)(ops_done + 1u + (uint32_t)lane) << 32 | x);
+                    carry = qoi_readlane(x, (int)cnt - 1);
+                    const uint32_t first_px = produced;
+                    const uint32_t total = qoi_readlane(run_incl, (int)cnt - 1), room = npx_total - produced;
+                    produced += total < room ? total : room;
+                    ops_done += cnt;
+                    B.xs[g + lane] = x;
+                    if (lane == 0) B.gpos[g >> 6] = first_px;
+                }
+            }
+            if (lane == 0) B.gdone = g;
+            qoi_flag_set(&f_done[w & 1u], w + 1u, lane);
+        }
+        for (size_t i = (size_t)produced + lane; i < npx_total; i += 64) store_px(i, carry);       // a stream that ended early: the last pixel repeats (:496-497)
+        return;
+    }
+
+    // ---- producers: A, compaction, B for window w; D for window w - 1 ------------------------------------------------------------
+    const int tp = t - 64, pwave = wave - 1;
+    uint32_t meet = 0, entry = 0;
+    struct Mine { uint64_t q[kLaneBytes / 8]; };
+    auto fetch = [&](int pos, Mine& mine, uint64_t& tail) {
+        const int at = pos + tp * kLaneBytes;
+        tail = 0;
+        #pragma unroll
+        for (int k = 0; k < kLaneBytes / 8; ++k) mine.q[k] = at + kLaneBytes <= avail ? reinterpret_cast<const AnyU64*>(stream + at)[k].v : 0ull;
+        if (tp == 0 && pos + kQoiWin + 8 <= avail) tail = reinterpret_cast<const AnyU64*>(stream + pos + kQoiWin)->v;
+    };
+    auto write_pixels = [&](uint32_t v) {                     // D of window v
+        QoiPipeBuf& B = pb[v & 1u];
+        qoi_flag_wait(&f_done[v & 1u], v + 1u);
+        const uint32_t resolved = B.gdone, nops = B.nops;
+        for (uint32_t g = (uint32_t)pwave * 64u; g < resolved; g += kPipeT) {
+            if (g + lane >= nops) continue;
+            const uint32_t first_px = B.gpos[g >> 6];
+            const uint2 pr = B.prep[g + lane];
+            const uint32_t run_incl = pr.y & 0xFFFu, npx = (pr.y >> 12) & 63u, x = B.xs[g + lane];
+            const size_t at = (size_t)first_px + (run_incl - npx);
+            for (uint32_t r = 0; r < npx && at + r < npx_total; ++r) store_px(at + r, x);
+        }
+    };
+    Mine dmine; uint64_t dtail;
+    fetch(0, dmine, dtail);
+    uint32_t w = 0;
+    for (int pos = 0; pos < chunk_bytes; pos += kQoiWin, ++w) {
+        QoiPipeBuf& B = pb[w & 1u];
+        uint32_t* win = B.win; uint16_t* ops = B.ops;
+        #pragma unroll
+        for (int k = 0; k < kLaneBytes / 8; ++k) { win[tp * (kLaneBytes / 4) + 2 * k] = (uint32_t)dmine.q[k]; win[tp * (kLaneBytes / 4) + 2 * k + 1] = (uint32_t)(dmine.q[k] >> 32); }
+        if (tp == 0) { win[kQoiWin / 4] = (uint32_t)dtail; win[kQoiWin / 4 + 1] = (uint32_t)(dtail >> 32); }
+        // A. op starts among this lane's 8 bytes, for entry offsets 0..4
+        uint32_t s[5] = { 1, 2, 4, 8, 16 };
+        #pragma unroll
+        for (int i = 0; i < kLaneBytes; ++i) {
+            const uint32_t b = (uint32_t)(dmine.q[i >> 3] >> (8 * (i & 7))) & 255u;
+            const uint32_t len = b >= 0xFEu ? b - 0xFAu : ((b >> 6) == 2u ? 2u : 1u);
+            #pragma unroll
+            for (int e = 0; e < 5; ++e) s[e] |= (s[e] & (1u << i)) << len;
+        }
+        uint32_t map = 0;
+        #pragma unroll
+        for (int e = 0; e < 5; ++e) map |= (uint32_t)__builtin_ctz(s[e] >> kLaneBytes) << (3 * e);
+        fetch(pos + kQoiWin, dmine, dtail);
+        qoi_map_scan_step<0x111, 0xF>(map); qoi_map_scan_step<0x112, 0xF>(map); qoi_map_scan_step<0x114, 0xF>(map); qoi_map_scan_step<0x118, 0xF>(map);
+        qoi_map_scan_step<0x142, 0xA>(map); qoi_map_scan_step<0x143, 0xC>(map);
+        if (lane == 63) wave_map[pwave] = map;
+        qoi_producers_meet(&f_meet, meet, lane);
+        uint32_t wave_entry = entry;
+        #pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t after = qoi_map_apply(wave_map[k], entry);
+            if (k < pwave) wave_entry = after;
+            entry = after;
+        }
+        const uint32_t my_entry = qoi_map_apply(qoi_dpp<0x138, 0xF>(map, kQoiMapId), wave_entry);
+        uint32_t starts = my_entry == 0 ? s[0] : my_entry == 1 ? s[1] : my_entry == 2 ? s[2] : my_entry == 3 ? s[3] : s[4];
+        {
+            const int room = chunk_bytes - (pos + tp * kLaneBytes);
+            const int n = room < kLaneBytes ? room : kLaneBytes;
+            starts &= n >= 32 ? ~0u : n <= 0 ? 0u : (1u << n) - 1u;
+        }
+        const uint32_t mine_n = (uint32_t)__builtin_popcount(starts);
+        uint32_t incl = mine_n;
+        qoi_add_scan_step<0x111, 0xF>(incl); qoi_add_scan_step<0x112, 0xF>(incl); qoi_add_scan_step<0x114, 0xF>(incl); qoi_add_scan_step<0x118, 0xF>(incl);
+        qoi_add_scan_step<0x142, 0xA>(incl); qoi_add_scan_step<0x143, 0xC>(incl);
+        if (lane == 63) wave_cnt[pwave] = incl;
+        qoi_producers_meet(&f_meet, meet, lane);
+        uint32_t at = incl - mine_n, nops = 0;
+        #pragma unroll
+        for (int k = 0; k < 4; ++k) { const uint32_t c = wave_cnt[k]; if (k < pwave) at += c; nops += c; }
+        for (uint32_t m = starts; m; m &= m - 1) ops[at++] = (uint16_t)(tp * kLaneBytes + __builtin_ctz(m));
+        qoi_producers_meet(&f_meet, meet, lane);
+        // B. the ops as functions of the previous pixel, 64 at a time, the groups dealt to the producer waves
+        for (uint32_t g = (uint32_t)pwave * 64u; g < nops; g += kPipeT) {
+            const bool active = g + lane < nops;
+            uint32_t lo = 0, hi = 0;
+            if (active) {
+                const uint32_t o = ops[g + lane];
+                const uint32_t w0 = win[o >> 2], w1 = win[(o >> 2) + 1], w2 = win[(o >> 2) + 2];
+                const uint32_t sh = 8 * (o & 3);
+                lo = __builtin_amdgcn_alignbit(w1, w0, sh); hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+            }
+            const uint32_t b1 = lo & 255u, top = b1 >> 6, b2 = (lo >> 8) & 255u;
+            const bool is_rgb = b1 == 0xFEu, is_rgba = b1 == 0xFFu;
+            const bool is_run = top == 3u && !is_rgb && !is_rgba;
+            const uint32_t vg = (b1 & 63u) - 32u;
+            const uint32_t v_diff = ((((b1 >> 4) & 3u) - 2u) & 255u) | ((((b1 >> 2) & 3u) - 2u) & 255u) << 8 | (((b1 & 3u) - 2u) & 255u) << 16;
+            const uint32_t v_luma = ((vg - 8u + (b2 >> 4)) & 255u) | (vg & 255u) << 8 | ((vg - 8u + (b2 & 15u)) & 255u) << 16;
+            const uint32_t v_abs = __builtin_amdgcn_alignbit(hi, lo, 8);
+            const bool is_index = active && top == 0u;
+            QoiFn f;
+            f.M = !active ? 0u : is_rgb ? 0x00FFFFFFu : (is_rgba || top == 0u) ? 0xFFFFFFFFu : 0u;
+            f.U = is_index ? 0xFFFFFFFFu : 0u;
+            f.V = !active ? 0u : is_rgb ? (v_abs & 0x00FFFFFFu) : is_rgba ? v_abs : top == 1u ? v_diff : top == 2u ? v_luma : 0u;
+            const uint32_t npx = !active ? 0u : is_run ? 1u + (b1 & 63u) : 1u;
+            uint32_t run_incl = npx;
+            qoi_scan_step<0x111, 0xF>(f, run_incl); qoi_scan_step<0x112, 0xF>(f, run_incl); qoi_scan_step<0x114, 0xF>(f, run_incl);
+            qoi_scan_step<0x118, 0xF>(f, run_incl); qoi_scan_step<0x142, 0xA>(f, run_incl); qoi_scan_step<0x143, 0xC>(f, run_incl);
+            const uint32_t mc = f.M == 0u ? 0u : f.M == 0x00FFFFFFu ? 1u : 2u, uc = f.U == 0u ? 0u : f.U == 0xFF000000u ? 1u : 2u;
+            B.prep[g + lane] = make_uint2(f.V, run_incl | npx << 12 | b1 << 18 | (is_index ? 1u << 26 : 0u) | mc << 27 | uc << 29);
+        }
+        if (tp == 0) B.nops = nops;
+        qoi_producers_meet(&f_meet, meet, lane);               // every producer's share of the window is in place
+        if (tp == 0) qoi_flag_set(&f_ready[w & 1u], w + 1u, 0);
+        if (w > 0) write_pixels(w - 1u);
+        qoi_producers_meet(&f_meet, meet, lane);               // ... and every share of window w - 1's pixels is written: its buffers may be reused
+    }
+    if (w > 0) write_pixels(w - 1u);
+}
+
+// The pipelined kernel keeps a compute unit busy by itself (its four producer waves compute nearly all the time: two workgroups on
+// one CU take twice as long), so it only pays while every stream has a CU of its own: 64 / 256 streams 17.3 -> 11.6 ms, but 341
+// streams 20.2 -> 23.3 ms, 700 streams 22.8 -> 34.8 ms.  GAMUT_HIP_QOI_PIPE=0 / 1 forces the choice (measurements, tests).
+inline bool qoi_pipeline(int n)
+{
+    const char* e = getenv("GAMUT_HIP_QOI_PIPE");
+    if (e && *e) return *e != '0';
+    static const int cus = [] { int dev = 0, c = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) c = 0; return c; }();
+    return n <= cus;
+}
+
 inline uint32_t be32(const uint8_t* p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
 
 // header checks of qoi_decode :458-480; 0 = ok
@@ -405,7 +645,8 @@ int decode_batch(const uint8_t* const* data, const int* size, int count, int cha
         memcpy(h, items.data(), items.size() * sizeof(QoiItem));
         GAMUT_HIP_CHECK(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, stream));
         const int n = (int)items.size();
-        if (n < kQoiWideBelow) hipLaunchKernelGGL(k_qoi_decode<4>, dim3(n), dim3(256), 0, stream, (const QoiItem*)d, n, (const uint8_t*)(d + o_blob), d_out);
+        if (n < kQoiWideBelow && qoi_pipeline(n)) hipLaunchKernelGGL(k_qoi_pipe, dim3(n), dim3(320), 0, stream, (const QoiItem*)d, n, (const uint8_t*)(d + o_blob), d_out);
+        else if (n < kQoiWideBelow) hipLaunchKernelGGL(k_qoi_decode<4>, dim3(n), dim3(256), 0, stream, (const QoiItem*)d, n, (const uint8_t*)(d + o_blob), d_out);
         else                   hipLaunchKernelGGL(k_qoi_decode<1>, dim3(n), dim3(64), 0, stream, (const QoiItem*)d, n, (const uint8_t*)(d + o_blob), d_out);
         if (int rc = launch_status("qoi_decode")) return rc;
         GAMUT_HIP_CHECK(hipStreamSynchronize(stream));         // the per-thread staging buffers are reused by the next call
@@ -504,7 +745,8 @@ int gamut_hip_qoi_decode_resident_device(const uint8_t* blob, int64_t blob_len, 
         hipStream_t st = pick_stream(stream);
         GAMUT_HIP_CHECK(hipMemcpyAsync(sl.d, sl.h, bytes, hipMemcpyHostToDevice, st));
         const int n = (int)items.size();
-        if (n < kQoiWideBelow) hipLaunchKernelGGL(k_qoi_decode<4>, dim3(n), dim3(256), 0, st, (const QoiItem*)sl.d, n, blob, out);
+        if (n < kQoiWideBelow && qoi_pipeline(n)) hipLaunchKernelGGL(k_qoi_pipe, dim3(n), dim3(320), 0, st, (const QoiItem*)sl.d, n, blob, out);
+        else if (n < kQoiWideBelow) hipLaunchKernelGGL(k_qoi_decode<4>, dim3(n), dim3(256), 0, st, (const QoiItem*)sl.d, n, blob, out);
         else                   hipLaunchKernelGGL(k_qoi_decode<1>, dim3(n), dim3(64), 0, st, (const QoiItem*)sl.d, n, blob, out);
         if (int rc = launch_status("qoi_decode")) return rc;
         GAMUT_HIP_CHECK(hipEventRecord(sl.done, st));

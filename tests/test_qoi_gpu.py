@@ -1,6 +1,7 @@
 """GPU parity: QOI decode (a workgroup of four waves per stream, or one wave per stream in large batches) through the C ABI vs the
 CPU oracle; bit-exact."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -13,7 +14,20 @@ from test_oracle_pinning import _qoi_test_images
 pytestmark = pytest.mark.gpu
 
 
-def test_qoi_drop_in_and_batch(hip):
+@pytest.fixture(params=["pipeline", "phases"])
+def small_batch_kernel(request):
+    """the two kernels for batches of fewer streams than the part has compute units (qoi.hip): k_qoi_pipe (wave 0 walks the groups
+    while four producer waves prepare the next window and write the last one's pixels) and k_qoi_decode<4> (the same phases in turn)"""
+    old = os.environ.get("GAMUT_HIP_QOI_PIPE")
+    os.environ["GAMUT_HIP_QOI_PIPE"] = "1" if request.param == "pipeline" else "0"
+    yield request.param
+    if old is None:
+        del os.environ["GAMUT_HIP_QOI_PIPE"]
+    else:
+        os.environ["GAMUT_HIP_QOI_PIPE"] = old
+
+
+def test_qoi_drop_in_and_batch(hip, small_batch_kernel):
     imgs = _qoi_test_images()
     blobs = [gen.qoi_encode(a) for a in imgs]
     blobs.append(blobs[2][:200] + blobs[2][-8:])                       # ends early: the tail repeats the last pixel
@@ -49,7 +63,7 @@ def test_qoi_drop_in_and_batch(hip):
             assert np.array_equal(host[offs[i]:offs[i] + nbytes[i]], e[0].reshape(-1)), i
 
 
-def test_qoi_resident_streams(hip):
+def test_qoi_resident_streams(hip, small_batch_kernel):
     """files already in HBM (gamut_hip_qoi_decode_resident_device): same pixels as the host-pointer batch; bounds are checked"""
     from gamut_amd import synth
     rng = np.random.default_rng(5)

@@ -17,7 +17,7 @@ files.append(b"qoif" + w.to_bytes(4, "big") + h.to_bytes(4, "big") + bytes([3, 0
 SL = 160
 for name, pool in (("spec-encoder streams", files[:ND]), ("all-RGB-op stream", files[ND:])):
     print(f"{name}: {np.mean([len(f) for f in pool]) / 1e6:.2f} MB per 1080p file")
-    for B in (64, 1024, 4096):
+    for B in [int(x) for x in os.environ.get("QOI_BENCH_B", "64,1024,4096").split(",")]:
         begin, size, parts, pos = [], [], [], 0
         for i in range(B):
             f = pool[i % len(pool)]

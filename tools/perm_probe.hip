@@ -1,4 +1,4 @@
-// what do v_perm_b32 selectors 8..15 return?  hipcc --offload-arch=gfx950 -o /tmp/perm_probe tools/scratch/perm_probe.hip && /tmp/perm_probe
+// what do v_perm_b32 selectors 8..15 return?  hipcc --offload-arch=gfx950 -o /tmp/perm_probe tools/perm_probe.hip && /tmp/perm_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 __global__ void k(unsigned* out, unsigned s0, unsigned s1)

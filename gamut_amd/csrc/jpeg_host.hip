@@ -697,6 +697,11 @@ struct SubCtx {
 // Decode from state `s` while the position is inside this lane's sub-sequence.  WRITE: coefficients / max_zag go out,
 // starting in block `b` with DC predictors pred[]; otherwise only the exit state, the number of blocks finished and the
 // sums of the DC differences are produced.  Returns false on a stream error (only meaningful on the true path).
+// The 64 lanes of a wave are at 64 different places of the token grammar (DC or AC symbol, short or long code, coefficient / ZRL /
+// EOB, end of a block or not), so every branch of a symbol step is taken by SOME lane and a branchy step costs the sum of its
+// paths (430 instructions as first written, half of them exec-mask bookkeeping).  The step is therefore straight-line: one refill
+// (33 bits cover the longest code plus the longest value), the table picked by index, every outcome a predicate, the new state a
+// handful of selects; only the rare long code (> 9 bits) and the stores are under a mask.
 template <bool WRITE>
 __device__ __forceinline__ bool sub_decode(const SubCtx& x, SubState& s, int& nblk, int (&dcs)[3], int64_t b, int64_t b_end,
                                            int16_t* out, uint8_t* mz)
@@ -705,49 +710,53 @@ __device__ __forceinline__ bool sub_decode(const SubCtx& x, SubState& s, int& nb
     int c = s.c, z = s.z;
     nblk = 0;
     bool ok = true;
-    int comp = c < x.ny ? 0 : c - x.ny + 1;                    // the tables only change when a block ends
-    const int16_t* q = x.quant + x.par[comp] * 64;
-    const DevHuff* dct = x.huff + x.par[3 + comp];
-    const DevHuff* act = x.huff + x.par[6 + comp];
+    const int q0 = x.par[0], q1 = x.par[1], q2 = x.par[2], d0 = x.par[3], d1 = x.par[4], d2 = x.par[5], a0 = x.par[6], a1 = x.par[7], a2 = x.par[8];
+    int dc0 = dcs[0], dc1 = dcs[1], dc2 = dcs[2];
     while (br.pos < x.end_bit && (!WRITE || b < b_end)) {
-        bool done = false; int kk = z;
-        if (z == 0) {
-            const int sy = br.decode(dct);
-            if (sy < 0) { ok = false; br.drop(16); done = true; }
-            else {
-                const int d = br.receive_extend(sy & 15);
-                const int v = (comp == 0 ? dcs[0] : comp == 1 ? dcs[1] : dcs[2]) + d;
-                if (comp == 0) dcs[0] = v; else if (comp == 1) dcs[1] = v; else dcs[2] = v;
-                if (WRITE) out[b * 64] = (int16_t)((uint32_t)v * (uint32_t)(int32_t)q[0]);
-                z = 1;
-            }
-        } else {
-            const int rs = br.decode(act);
-            if (rs < 0) { ok = false; br.drop(16); done = true; }
-            else {
-                const int run = rs >> 4, size = rs & 15;
-                if (size) {
-                    if (run && z + run > 63) { ok = false; done = true; }
-                    else {
-                        z += run;
-                        const int e = br.receive_extend(size);
-                        if (WRITE) out[b * 64 + x.zag[z]] = (int16_t)((uint32_t)e * (uint32_t)(int32_t)q[z]);
-                        if (++z == 64) { done = true; kk = 64; }
-                    }
-                } else if (run == 15) {
-                    if (z + 16 > 64) { ok = false; done = true; }
-                    else { z += 16; if (z == 64) { done = true; kk = 64; } }
-                } else { done = true; kk = z; }                  // EOB: max_zag = the position it was read at
-            }
+        br.refill();                                                             // >= 33 bits: a code (<= 16) and its value (<= 15)
+        const int comp = c < x.ny ? 0 : c - x.ny + 1;
+        const bool is_dc = z == 0;
+        const DevHuff* h = x.huff + (is_dc ? (comp == 0 ? d0 : comp == 1 ? d1 : d2) : (comp == 0 ? a0 : comp == 1 ? a1 : a2));
+        const uint32_t top16 = br.peek(16);
+        const uint32_t e = h->fast[top16 >> 7];
+        int len = (int)(e >> 8), sym = (int)(e & 0xFFu);
+        bool bad = false;
+        if (!e) {                                                                // a code of more than 9 bits
+            int32_t code = (int32_t)(top16 >> 7); len = 9;
+            while (code > h->maxcode[len]) { if (++len > 16) break; code = (int32_t)(top16 >> (16 - len)); }
+            bad = len > 16;                                                      // no such code: the block ends here, 16 bits are skipped
+            sym = bad ? 0 : (int)h->vals[(code + h->delta[len > 16 ? 16 : len]) & 0xFF];
+            len = bad ? 16 : len;
         }
-        if (done) {
-            if (WRITE) mz[b] = (uint8_t)kk;
-            ++b; ++nblk; z = 0;
-            if (++c == x.nb) c = 0;
-            comp = c < x.ny ? 0 : c - x.ny + 1;
-            q = x.quant + x.par[comp] * 64; dct = x.huff + x.par[3 + comp]; act = x.huff + x.par[6 + comp];
+        const int size = sym & 15, run = sym >> 4;
+        const bool ac = !is_dc && !bad;
+        const bool err_run = ac && size != 0 && run != 0 && z + run > 63;       // a coefficient beyond the block
+        const bool zrl = ac && size == 0 && run == 15;
+        const bool err_zrl = zrl && z + 16 > 64;
+        const bool eob = ac && size == 0 && run != 15;
+        const bool take = !bad && (is_dc || (size != 0 && !err_run));           // a coefficient (or DC difference) follows the code
+        const int used = len + (take ? size : 0);
+        const uint32_t raw = (uint32_t)(br.acc >> (br.nbits - used)) & ((1u << size) - 1u);
+        const int ext = take && size ? ((int)raw < (1 << (size - 1)) ? (int)raw + (int)(0xFFFFFFFFu << size) + 1 : (int)raw) : 0;   // JPGD_HUFF_EXTEND :816-822
+        br.drop(used);
+        const int k = is_dc ? 0 : z + run;                                       // zig-zag position of that coefficient
+        const int dcv = (comp == 0 ? dc0 : comp == 1 ? dc1 : dc2) + ext;
+        const bool tdc = take && is_dc;
+        dc0 = tdc && comp == 0 ? dcv : dc0; dc1 = tdc && comp == 1 ? dcv : dc1; dc2 = tdc && comp == 2 ? dcv : dc2;
+        if (WRITE && take) {
+            const int16_t qf = x.quant[(comp == 0 ? q0 : comp == 1 ? q1 : q2) * 64 + k];
+            out[b * 64 + x.zag[k]] = (int16_t)((uint32_t)(is_dc ? dcv : ext) * (uint32_t)(int32_t)qf);
         }
+        const int znew = take ? k + 1 : (zrl && !err_zrl) ? z + 16 : z;
+        const bool full = !is_dc && znew == 64;
+        const bool done = bad || err_run || err_zrl || eob || full;
+        ok = ok && !(bad || err_run || err_zrl);
+        if (WRITE && done) mz[b] = (uint8_t)(full ? 64 : z);                     // m_mcu_block_max_zag :2512 (EOB: the position it was read at)
+        b += done ? 1 : 0; nblk += done ? 1 : 0;
+        z = done ? 0 : znew;
+        c = done ? (c + 1 == x.nb ? 0 : c + 1) : c;
     }
+    dcs[0] = dc0; dcs[1] = dc1; dcs[2] = dc2;
     s.pos = br.pos; s.c = (uint16_t)c; s.z = (uint16_t)z;
     return ok;
 }

@@ -584,7 +584,10 @@ struct DevBits {
 constexpr size_t kBlobSlack = 512;                           // bytes a lane may read past the last segment (one block + look-ahead), see k_jpeg_entropy
 constexpr int kEntropyThreads = 64;                          // one wave per workgroup: lanes spread over CUs, each with its own L1
 constexpr int kLdsHuff = 16, kLdsQuant = 16;                   // tables a workgroup keeps in LDS (23 KB + 2 KB)
-constexpr int kSyncThreads = 1024;                             // lanes cooperating on one large segment
+#ifndef JPEG_SYNC_THREADS          // tuning knob (tools/variant.sh)
+#define JPEG_SYNC_THREADS 1024
+#endif
+constexpr int kSyncThreads = JPEG_SYNC_THREADS;                // lanes cooperating on one large segment
 constexpr uint32_t kSyncMinBytes = 4096;                       // shorter segments take one lane each
 
 // Tables into LDS (IN_LDS: the batch uses few distinct tables -- the usual case: encoders write the Annex K tables or one

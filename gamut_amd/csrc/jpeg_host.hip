@@ -583,9 +583,9 @@ struct DevBits {
 
 constexpr size_t kBlobSlack = 512;                           // bytes a lane may read past the last segment (one block + look-ahead), see k_jpeg_entropy
 constexpr int kEntropyThreads = 64;                          // one wave per workgroup: lanes spread over CUs, each with its own L1
-constexpr int kLdsHuff = 16, kLdsQuant = 16;                   // tables a workgroup keeps in LDS (23 KB + 2 KB)
+constexpr int kLdsHuff = 4, kLdsQuant = 4;                     // tables a workgroup keeps in LDS (7 KB + 0.5 KB: one encoder's set; more distinct tables in a batch are read from global memory)
 #ifndef JPEG_SYNC_THREADS          // tuning knob (tools/variant.sh)
-#define JPEG_SYNC_THREADS 1024
+#define JPEG_SYNC_THREADS 256
 #endif
 constexpr int kSyncThreads = JPEG_SYNC_THREADS;                // lanes cooperating on one large segment
 constexpr uint32_t kSyncMinBytes = 4096;                       // shorter segments take one lane each
@@ -642,6 +642,16 @@ __global__ __launch_bounds__(kEntropyThreads) void k_jpeg_entropy(const DevItem*
     int16_t* out = coeffs + im.coeff_off + (int64_t)it.first_mcu * im.nb * 64;
     uint8_t* mz = max_zag + im.zag_off + (int64_t)it.first_mcu * im.nb;
     int16_t* blk = reinterpret_cast<int16_t*>(sh_blk + threadIdx.x * 144);
+    // damaged data: flag the image and clear the blocks of the segment that were not reached (the caller's buffer is not cleared beforehand)
+    int16_t* const seg_end = out + (int64_t)it.n_mcus * im.nb * 64;
+    auto bail = [&](uint32_t flag) {
+        atomicOr(status + it.image, flag);
+        for (int16_t* p = out; p < seg_end; p += 64) {
+            uint4* dst = reinterpret_cast<uint4*>(p);
+            #pragma unroll
+            for (int k = 0; k < 8; ++k) dst[k] = make_uint4(0, 0, 0, 0);
+        }
+    };
     for (int mcu = 0; mcu < it.n_mcus; ++mcu) {
         for (int b = 0; b < im.nb; ++b, out += 64, ++mz) {
             const int c = b < im.ny ? 0 : b - im.ny + 1;
@@ -649,7 +659,7 @@ __global__ __launch_bounds__(kEntropyThreads) void k_jpeg_entropy(const DevItem*
             const DevHuff* dc = huff + (c == 0 ? im.dc[0] : c == 1 ? im.dc[1] : im.dc[2]);
             const DevHuff* ac = huff + (c == 0 ? im.ac[0] : c == 1 ? im.ac[1] : im.ac[2]);
             const int s = br.decode(dc);
-            if (s < 0) { atomicOr(status + it.image, 1u); return; }
+            if (s < 0) { bail(1u); return; }
             const int pred = c == 0 ? pred0 : c == 1 ? pred1 : pred2;
             const int v = br.receive_extend(s & 15) + pred;
             if (c == 0) pred0 = v; else if (c == 1) pred1 = v; else pred2 = v;
@@ -657,18 +667,18 @@ __global__ __launch_bounds__(kEntropyThreads) void k_jpeg_entropy(const DevItem*
             int kk = 1;
             for (; kk < 64; ++kk) {
                 const int rs = br.decode(ac);
-                if (rs < 0) { atomicOr(status + it.image, 1u); return; }
+                if (rs < 0) { bail(1u); return; }
                 const int run = rs >> 4, size = rs & 15;
                 if (size) {
-                    if (run) { if (kk + run > 63) { atomicOr(status + it.image, 2u); return; } kk += run; }
+                    if (run) { if (kk + run > 63) { bail(2u); return; } kk += run; }
                     const int e = br.receive_extend(size);
                     blk[sh_zag[kk]] = (int16_t)((uint32_t)e * (uint32_t)(int32_t)q[kk]);
                 } else if (run == 15) {
-                    if (kk + 16 > 64) { atomicOr(status + it.image, 2u); return; }
+                    if (kk + 16 > 64) { bail(2u); return; }
                     kk += 15;
                 } else break;
             }
-            if (br.pos > limit_bit) { atomicOr(status + it.image, 4u); return; }      // ran off the end of the segment
+            if (br.pos > limit_bit) { bail(4u); return; }                               // ran off the end of the segment
             *mz = (uint8_t)kk;                                   // m_mcu_block_max_zag :2512
             uint4* src = reinterpret_cast<uint4*>(blk);
             uint4* dst = reinterpret_cast<uint4*>(out);          // 128-byte blocks at 128-byte-aligned offsets (checked by the host)
@@ -705,14 +715,23 @@ struct SubCtx {
 // paths (430 instructions as first written, half of them exec-mask bookkeeping).  The step is therefore straight-line: one refill
 // (33 bits cover the longest code plus the longest value), the table picked by index, every outcome a predicate, the new state a
 // handful of selects; only the rare long code (> 9 bits) and the stores are under a mask.
-template <bool WRITE>
+// MODE 0: only the exit state, the blocks finished and the DC sums.  MODE 1 (the write sweep): a block this lane STARTS is
+// assembled in the lane's 128 bytes of LDS (`blk`, zero on entry) and leaves as one whole line when it ends -- or, unfinished, when
+// the sub-sequence ends (its remaining coefficients belong to the lanes after this one); a block the lane finds half-decoded at its
+// entry (z > 0) is only counted here.  MODE 2 (after a barrier): exactly that first, inherited block again, its coefficients stored
+// one by one on top of the line its starter wrote.  Scattered 2-byte stores for everything (the first version, into a buffer
+// cleared beforehand) cost 13 GB of HBM traffic per 512 images for 3 GB of coefficients: every store a read-modify-write of a line.
+enum { SUB_COUNT = 0, SUB_WRITE = 1, SUB_FIRST = 2 };
+template <int MODE>
 __device__ __forceinline__ bool sub_decode(const SubCtx& x, SubState& s, int& nblk, int (&dcs)[3], int64_t b, int64_t b_end,
-                                           int16_t* out, uint8_t* mz)
+                                           int16_t* out, uint8_t* mz, int16_t* blk = nullptr)
 {
+    constexpr bool WRITE = MODE != SUB_COUNT;
     DevBits br; br.open(x.seg, s.pos);
     int c = s.c, z = s.z;
     nblk = 0;
     bool ok = true;
+    bool inherited = z > 0;                                                      // the block under way was started by another lane
     const int q0 = x.par[0], q1 = x.par[1], q2 = x.par[2], d0 = x.par[3], d1 = x.par[4], d2 = x.par[5], a0 = x.par[6], a1 = x.par[7], a2 = x.par[8];
     int dc0 = dcs[0], dc1 = dcs[1], dc2 = dcs[2];
     while (br.pos < x.end_bit && (!WRITE || b < b_end)) {
@@ -746,18 +765,35 @@ __device__ __forceinline__ bool sub_decode(const SubCtx& x, SubState& s, int& nb
         const int dcv = (comp == 0 ? dc0 : comp == 1 ? dc1 : dc2) + ext;
         const bool tdc = take && is_dc;
         dc0 = tdc && comp == 0 ? dcv : dc0; dc1 = tdc && comp == 1 ? dcv : dc1; dc2 = tdc && comp == 2 ? dcv : dc2;
-        if (WRITE && take) {
+        if (WRITE && take && (MODE == SUB_FIRST || !inherited)) {
             const int16_t qf = x.quant[(comp == 0 ? q0 : comp == 1 ? q1 : q2) * 64 + k];
-            out[b * 64 + x.zag[k]] = (int16_t)((uint32_t)(is_dc ? dcv : ext) * (uint32_t)(int32_t)qf);
+            const int16_t cv = (int16_t)((uint32_t)(is_dc ? dcv : ext) * (uint32_t)(int32_t)qf);
+            if (MODE == SUB_FIRST) out[b * 64 + x.zag[k]] = cv; else blk[x.zag[k]] = cv;
         }
         const int znew = take ? k + 1 : (zrl && !err_zrl) ? z + 16 : z;
         const bool full = !is_dc && znew == 64;
         const bool done = bad || err_run || err_zrl || eob || full;
         ok = ok && !(bad || err_run || err_zrl);
-        if (WRITE && done) mz[b] = (uint8_t)(full ? 64 : z);                     // m_mcu_block_max_zag :2512 (EOB: the position it was read at)
+        if (MODE == SUB_WRITE && done) {
+            mz[b] = (uint8_t)(full ? 64 : z);                                    // m_mcu_block_max_zag :2512 (EOB: the position it was read at)
+            if (!inherited) {
+                uint4* src = reinterpret_cast<uint4*>(blk);
+                uint4* dst = reinterpret_cast<uint4*>(out + b * 64);             // 128-byte blocks at 128-byte-aligned offsets (checked by the host)
+                #pragma unroll
+                for (int i = 0; i < 8; ++i) { dst[i] = src[i]; src[i] = make_uint4(0, 0, 0, 0); }
+            }
+            inherited = false;
+        }
+        if (MODE == SUB_FIRST && done) break;                                    // the inherited block is complete
         b += done ? 1 : 0; nblk += done ? 1 : 0;
         z = done ? 0 : znew;
         c = done ? (c + 1 == x.nb ? 0 : c + 1) : c;
+    }
+    if (MODE == SUB_WRITE && z > 0 && !inherited && b < b_end) {                 // a block of this lane's that the next lanes finish: its line, as far as it goes
+        const uint4* src = reinterpret_cast<const uint4*>(blk);
+        uint4* dst = reinterpret_cast<uint4*>(out + b * 64);
+        #pragma unroll
+        for (int i = 0; i < 8; ++i) dst[i] = src[i];
     }
     dcs[0] = dc0; dcs[1] = dc1; dcs[2] = dc2;
     s.pos = br.pos; s.c = (uint16_t)c; s.z = (uint16_t)z;
@@ -775,8 +811,14 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevIte
     __shared__ SubState exit_state[kSyncThreads];
     __shared__ int scan[4][kSyncThreads];                       // blocks finished, DC-difference sums of the three components
     __shared__ int changed, failed, par[9];
+    __shared__ __attribute__((aligned(16))) uint8_t sh_blk[kSyncThreads * 144];             // the write sweep: a block per lane (144-byte pitch)
     load_tables<IN_LDS, kSyncThreads>(sh_huff, sh_quant, sh_zag, huff_g, n_huff, quant_g, n_quant);
     const int t = threadIdx.x;
+    {
+        uint4* zb = reinterpret_cast<uint4*>(sh_blk + t * 144);
+        #pragma unroll
+        for (int i = 0; i < 8; ++i) zb[i] = make_uint4(0, 0, 0, 0);
+    }
     const DevItem it = items[blockIdx.x];
     const DevImage im = images[it.image];
     if (t == 0) {
@@ -798,7 +840,7 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevIte
     // sweep 0: every lane from the start of its own sub-sequence, as if a block began there
     SubState entry{ (uint32_t)t * sub * 8u, 0, 0 }, mine = entry;
     int nblk = 0, dcs[3] = { 0, 0, 0 };
-    if (active) sub_decode<false>(x, mine, nblk, dcs, 0, 0, nullptr, nullptr);
+    if (active) sub_decode<SUB_COUNT>(x, mine, nblk, dcs, 0, 0, nullptr, nullptr);
     exit_state[t] = mine;
     __syncthreads();
     // sweeps 1..: from the predecessor's exit state, until nothing moves
@@ -809,7 +851,7 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevIte
         if (active && (sweep == 0 || !same(from, entry))) {
             entry = from; mine = from;
             dcs[0] = dcs[1] = dcs[2] = 0;
-            sub_decode<false>(x, mine, nblk, dcs, 0, 0, nullptr, nullptr);
+            sub_decode<SUB_COUNT>(x, mine, nblk, dcs, 0, 0, nullptr, nullptr);
             if (!same(mine, exit_state[t])) { exit_state[t] = mine; changed = 1; }
         }
         __syncthreads();
@@ -831,12 +873,26 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevIte
         for (int k = 0; k < 4; ++k) scan[k][t] += v[k];
         __syncthreads();
     }
+    const int64_t b0 = active ? scan[0][t] - nblk : 0;
     if (active) {
-        const int64_t b0 = scan[0][t] - nblk;
         int pred[3] = { scan[1][t] - dcs[0], scan[2][t] - dcs[1], scan[3][t] - dcs[2] };
         SubState s = entry; int n2 = 0;
-        if (!sub_decode<true>(x, s, n2, pred, b0, total_blocks, out, mz)) failed = 1;
+        if (!sub_decode<SUB_WRITE>(x, s, n2, pred, b0, total_blocks, out, mz, reinterpret_cast<int16_t*>(sh_blk + t * 144))) failed = 1;
         if (t == nsub - 1 && b0 + n2 != total_blocks) failed = 1;                 // the segment ended before its last block did
+    }
+    __threadfence();                                            // the lines are on their way before anybody adds single coefficients to them
+    __syncthreads();
+    if (active && entry.z > 0 && b0 < total_blocks) {           // the rest of the block this lane found half-decoded
+        int pred[3] = { 0, 0, 0 }; SubState s = entry; int n3 = 0;
+        sub_decode<SUB_FIRST>(x, s, n3, pred, b0, total_blocks, out, mz);
+    }
+    // A segment whose decode ended early (damaged data) leaves blocks nobody started: they are cleared, not left as they were
+    const int64_t finished = scan[0][kSyncThreads - 1];
+    const int64_t started = finished + (exit_state[nsub > 0 ? nsub - 1 : 0].z > 0 ? 1 : 0);
+    for (int64_t blk = started + t; blk < total_blocks; blk += kSyncThreads) {
+        uint4* dst = reinterpret_cast<uint4*>(out + blk * 64);
+        #pragma unroll
+        for (int i = 0; i < 8; ++i) dst[i] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
     if (t == 0 && failed) atomicOr(status + it.image, 1u);
@@ -1020,28 +1076,27 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
         uint8_t* d_blob_w = (uint8_t*)scratch.get(blob_size + kBlobSlack);
         uint8_t* h_blob = pinned.get(blob_size + kBlobSlack);
         if (!d_blob_w || !h_blob) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: staging allocation of %zu bytes failed", blob_size + kBlobSlack);
-        // lanes of a workgroup of the self-synchronising kernel share blocks, so coefficients are written in place: clear the
-        // images that can have a long segment first (adjacent ones in one call).  On `stream`, while the upload is prepared.
+        // (both kernels write every block of a segment as a whole line -- zeros included, blocks a damaged segment never reaches as
+        // well: the coefficient buffer needs no clearing)
         {
-            auto blocks = [&](int k) { return (int64_t)info[k].mcus_per_row * info[k].mcus_per_col * info[k].blocks_per_mcu; };
-            auto needs = [&](int k) { return prep[(size_t)k].rc == GAMUT_HIP_OK && len[k] - prep[(size_t)k].scan_pos >= (size_t)kSyncMinBytes; };
-            for (int i = 0; i < count; ) {
-                if (!needs(i)) { ++i; continue; }
-                const int64_t begin = coeff_offset[i]; int64_t endo = begin + blocks(i) * 64;
-                int j = i + 1;
-                while (j < count && needs(j) && coeff_offset[j] == endo) { endo += blocks(j) * 64; ++j; }
-                GAMUT_HIP_CHECK(hipMemsetAsync(d_coeffs + begin, 0, (size_t)(endo - begin) * sizeof(int16_t), stream));
-                i = j;
-            }
             if (d_status) GAMUT_HIP_CHECK(hipMemsetAsync(d_status, 0, (size_t)count * sizeof(uint32_t), stream));
         }
         // C/D. groups of slices of files.  A slice is unstuffed on the workers and DMA'd at once; when a group of slices is on
         //      its way, its segment list follows it and the group's kernels are queued on `stream` behind an event, so the
         //      first group decodes while the rest is still being unstuffed and uploaded.  A group keeps >= 512 workgroups.
-        const int n_groups = count >= 2048 ? 4 : count >= 1024 ? 2 : 1;
+        const int n_groups = count >= 1024 ? 4 : count >= 256 ? 2 : 1;
         const int n_slices = count >= 512 ? 8 : count >= 64 ? 4 : 1;
         static thread_local hipEvent_t group_ready[4] = { nullptr, nullptr, nullptr, nullptr };
         for (int g = 0; g < n_groups; ++g) if (!group_ready[g]) GAMUT_HIP_CHECK(hipEventCreateWithFlags(&group_ready[g], hipEventDisableTiming));
+        // A long segment is decoded by one workgroup in its own time (its sweeps), whatever else the chip does: the groups' kernels
+        // are therefore queued on streams of their own (behind what `stream` holds now) and run side by side, each as soon as its
+        // bytes are there -- on one stream a group waited for the group before it to finish.
+        static thread_local hipStream_t side[4] = { nullptr, nullptr, nullptr, nullptr };
+        static thread_local hipEvent_t fork = nullptr;
+        if (!fork) GAMUT_HIP_CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+        for (int g = 1; g < n_groups; ++g) if (!side[g]) GAMUT_HIP_CHECK(hipStreamCreateWithFlags(&side[g], hipStreamNonBlocking));
+        GAMUT_HIP_CHECK(hipEventRecord(fork, stream));
+        for (int g = 1; g < n_groups; ++g) GAMUT_HIP_CHECK(hipStreamWaitEvent(side[g], fork, 0));
         auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
         size_t max_items = 0;
         for (int i = 0; i < count; ++i) if (prep[(size_t)i].rc == GAMUT_HIP_OK) max_items += prep[(size_t)i].restart_interval ? (size_t)(prep[(size_t)i].total_mcus / prep[(size_t)i].restart_interval + 1) : 1;
@@ -1108,23 +1163,25 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
             const DevItem* d_items = (const DevItem*)(d + items_off);
             items_off = align(items_off + items.size() * sizeof(DevItem));
             GAMUT_HIP_CHECK(hipEventRecord(group_ready[g], copy_stream));
-            GAMUT_HIP_CHECK(hipStreamWaitEvent(stream, group_ready[g], 0));
-            if (trace) { (void)hipStreamSynchronize(stream); ms_upload = ms_since(t_up) - ms_kernels_issue; }
+            const hipStream_t gs = g == 0 ? stream : side[g];
+            GAMUT_HIP_CHECK(hipStreamWaitEvent(gs, group_ready[g], 0));
+            if (trace) { (void)hipStreamSynchronize(gs); ms_upload = ms_since(t_up) - ms_kernels_issue; }
             const auto t_k = std::chrono::steady_clock::now();
             if (n_long) {
-                if (in_lds) hipLaunchKernelGGL(k_jpeg_entropy_sync<true>, dim3(n_long), dim3(kSyncThreads), 0, stream, d_items, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
-                else        hipLaunchKernelGGL(k_jpeg_entropy_sync<false>, dim3(n_long), dim3(kSyncThreads), 0, stream, d_items, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
+                if (in_lds) hipLaunchKernelGGL(k_jpeg_entropy_sync<true>, dim3(n_long), dim3(kSyncThreads), 0, gs, d_items, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
+                else        hipLaunchKernelGGL(k_jpeg_entropy_sync<false>, dim3(n_long), dim3(kSyncThreads), 0, gs, d_items, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
                 if (int rc = launch_status("jpeg_entropy_sync")) return rc;
             }
             if (n_short) {
                 const dim3 grid((n_short + kEntropyThreads - 1) / kEntropyThreads), block(kEntropyThreads);
-                if (in_lds) hipLaunchKernelGGL(k_jpeg_entropy<true>, grid, block, 0, stream, d_items + n_long, n_short, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
-                else        hipLaunchKernelGGL(k_jpeg_entropy<false>, grid, block, 0, stream, d_items + n_long, n_short, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
+                if (in_lds) hipLaunchKernelGGL(k_jpeg_entropy<true>, grid, block, 0, gs, d_items + n_long, n_short, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
+                else        hipLaunchKernelGGL(k_jpeg_entropy<false>, grid, block, 0, gs, d_items + n_long, n_short, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
             }
             if (int rc = launch_status("jpeg_entropy")) return rc;
-            if (trace) { (void)hipStreamSynchronize(stream); ms_kernels_issue += ms_since(t_k); }
+            if (trace) { (void)hipStreamSynchronize(gs); ms_kernels_issue += ms_since(t_k); }
         }
         GAMUT_HIP_CHECK(hipStreamSynchronize(copy_stream));
+        for (int g = 1; g < n_groups; ++g) GAMUT_HIP_CHECK(hipStreamSynchronize(side[g]));
         GAMUT_HIP_CHECK(hipStreamSynchronize(stream));         // the per-thread staging buffers are reused by the next call
         if (trace) fprintf(stderr, "[gamut_hip] jpeg_entropy_decode_device: %d files in %d group(s), %d long + %d short segments, %d+%d tables, %.1f MB compressed, %d host threads: headers %.1f ms, unstuff + upload %.1f ms, kernels %.1f ms (stages serialised by the trace)\n",
                            count, n_groups, total_long, total_short, n_huff, n_quant, blob_size / 1e6, workers, ms_parse, ms_upload, ms_kernels_issue);

@@ -583,7 +583,7 @@ struct DevBits {
 
 constexpr size_t kBlobSlack = 512;                           // bytes a lane may read past the last segment (one block + look-ahead), see k_jpeg_entropy
 constexpr int kEntropyThreads = 64;                          // one wave per workgroup: lanes spread over CUs, each with its own L1
-constexpr int kLdsHuff = 4, kLdsQuant = 4;                     // tables a workgroup keeps in LDS (7 KB + 0.5 KB: one encoder's set; more distinct tables in a batch are read from global memory)
+constexpr int kLdsHuff = 8, kLdsQuant = 8;                     // tables a workgroup keeps in LDS (15 KB + 1 KB: two encoders' sets; more distinct tables in a batch are read from global memory)
 #ifndef JPEG_SYNC_THREADS          // tuning knob (tools/variant.sh)
 #define JPEG_SYNC_THREADS 256
 #endif

@@ -99,6 +99,47 @@ def test_qoi_resident_streams(hip, small_batch_kernel):
     hip.gamut_hip_device_free(blob); hip.gamut_hip_device_free(out)
 
 
+def _arbitrary_streams():
+    """streams no encoder writes: random chunk bytes under a valid header (every byte sequence is a QOI op sequence) -- too short, too
+    long, op mixes that change every window's entry offset, runs across the end of the image"""
+    rng = np.random.default_rng(31)
+    out = []
+    for k in range(24):
+        w, h, ch = int(rng.integers(1, 400)), int(rng.integers(1, 60)), 3 + (k & 1)
+        need = w * h
+        nbytes = int(rng.integers(0, 3 * need + 40))
+        body = rng.integers(0, 256, nbytes, dtype=np.uint8)
+        if k % 3 == 0:
+            body[rng.random(nbytes) < 0.5] = 0xC0 | int(rng.integers(0, 62))          # many RUN ops
+        if k % 4 == 1:
+            body[rng.random(nbytes) < 0.6] &= 0x3F                                    # many INDEX ops
+        out.append(b"qoif" + w.to_bytes(4, "big") + h.to_bytes(4, "big") + bytes([ch, 0]) + body.tobytes() + bytes(7) + b"\x01")
+    return out
+
+
+def test_qoi_arbitrary_streams(hip, small_batch_kernel):
+    files = _arbitrary_streams()
+    for reps in (1, 40):                                       # 24 streams: the small-batch kernels; 960: one wave per stream
+        blobs = files * reps
+        n = len(blobs)
+        if reps > 1 and small_batch_kernel == "phases":
+            continue
+        bufs = [np.frombuffer(b, np.uint8) for b in blobs]
+        ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs]); sizes = (C.c_int * n)(*[b.size for b in bufs])
+        exp = [O.qoi_decode(b, 4)[0].reshape(-1) for b in files] * reps
+        nbytes = [e.size for e in exp]
+        offs = np.concatenate([[0], np.cumsum(nbytes)[:-1]]).astype(np.int64)
+        dout = hip.gamut_hip_device_malloc(int(sum(nbytes)) + 64)
+        descs = (_capi.QoiDesc * n)(); st = (C.c_int * n)()
+        _capi.check(hip.gamut_hip_qoi_decode_batch_device(ptrs, sizes, n, 4, offs.ctypes.data_as(C.POINTER(C.c_int64)), dout, descs, st, None))
+        host = np.empty(int(sum(nbytes)), np.uint8)
+        _capi.check(hip.gamut_hip_memcpy_d2h(host.ctypes.data, dout, host.nbytes, None))
+        _capi.check(hip.gamut_hip_stream_synchronize(None))
+        hip.gamut_hip_device_free(dout)
+        for i in range(n):
+            assert np.array_equal(host[offs[i]:offs[i] + nbytes[i]], exp[i]), (reps, i % len(files))
+
+
 def test_qoi_large_batch_takes_the_one_wave_kernel(hip):
     """>= 768 streams in one call run one wave per stream (k_qoi_decode<1>); same pixels as the oracle, rgba and rgb outputs"""
     rng = np.random.default_rng(9)

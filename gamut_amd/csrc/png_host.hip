@@ -461,6 +461,7 @@ int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* 
             if (!h_blob || !d_blob) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png: staging for %zu bytes of IDAT data failed", blob_off[(size_t)count]);
         }
         auto gather = [&]() {                                   // device inflate: chunk walk + IDAT gather of one file at a time
+            (void)hipSetDevice(dev);
             for (int i; (i = next.fetch_add(1, std::memory_order_relaxed)) < count; ) {
                 BatchFile& f = files[(size_t)i];
                 PngHeader h;
@@ -477,6 +478,11 @@ int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* 
                 if (rc != GAMUT_HIP_OK) { f.rc = rc; snprintf(f.msg, sizeof(f.msg), "image %d: %s", i, last_error_buf()); continue; }
                 idat_len[(size_t)i] = h.ioff - skip;
                 memcpy(h_blob + blob_off[(size_t)i], h.idata + skip, h.ioff - skip);
+                // the file's share goes up at once (copy stream): the DMA of the batch runs beside the chunk walk instead of after it
+                if (hipMemcpyAsync(d_blob + blob_off[(size_t)i], h_blob + blob_off[(size_t)i], h.ioff - skip, hipMemcpyHostToDevice, copy_stream) != hipSuccess) {
+                    (void)hipGetLastError();
+                    f.rc = GAMUT_HIP_ERR_HIP; snprintf(f.msg, sizeof(f.msg), "image %d: png: upload failed", i); free(h.idata); continue;
+                }
                 free(h.idata); h.idata = nullptr;
                 f.h = h;
                 f.out_n = h.img_n;
@@ -551,7 +557,7 @@ int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* 
                 uint32_t* d_verdict = (uint32_t*)verdict_dev.get(n * 8);
                 if (!d_verdict) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png: verdict table allocation failed");
                 std::vector<uint32_t> verdict(n * 2);
-                GAMUT_HIP_CHECK(hipMemcpyAsync(d_blob, h_blob, blob_off[(size_t)count], hipMemcpyHostToDevice, st));
+                // (the streams went up file by file while the chunks were walked; the copy stream was synchronised above)
                 if (int rc = inflate_launch(descs.data(), (int)n, d_verdict, d_verdict + n, st)) return rc;
                 GAMUT_HIP_CHECK(hipMemcpyAsync(verdict.data(), d_verdict, n * 8, hipMemcpyDeviceToHost, st));
                 GAMUT_HIP_CHECK(hipStreamSynchronize(st));

@@ -3,6 +3,7 @@
 // Replaces qoi_decode (source/gamut/codecs/qoi.d:448-550): one workgroup per stream, see k_qoi_decode.  The host only
 // validates the 14-byte header (same checks as :472-480) and uploads the streams as they are.
 #include "common.hpp"
+#include <atomic>
 #include <type_traits>
 #include <vector>
 
@@ -637,13 +638,20 @@ int decode_batch(const uint8_t* const* data, const int* size, int count, int cha
         int workers = host_threads();
         workers = workers < 1 ? 1 : workers > 16 ? 16 : workers;
         if ((size_t)workers > blob_size / (4u << 20) + 1) workers = (int)(blob_size / (4u << 20) + 1);
+        // ... file by file: a file's bytes are on their way (on `stream`, ahead of the kernel) while the next ones are still copied
+        int dev = 0;
+        GAMUT_HIP_CHECK(hipGetDevice(&dev));
+        std::atomic<int> upload_failed{ 0 };
         parallel_for((int)items.size(), workers, [&](int, int k) {
-            uint8_t* dst = h + o_blob + items[(size_t)k].begin;
-            memcpy(dst, data[src[(size_t)k]], items[(size_t)k].size);
-            memset(dst + items[(size_t)k].size, 0, kQoiSlack);
+            (void)hipSetDevice(dev);
+            const size_t at = o_blob + items[(size_t)k].begin, n = (size_t)items[(size_t)k].size + kQoiSlack;
+            memcpy(h + at, data[src[(size_t)k]], items[(size_t)k].size);
+            memset(h + at + items[(size_t)k].size, 0, kQoiSlack);
+            if (hipMemcpyAsync(d + at, h + at, n, hipMemcpyHostToDevice, stream) != hipSuccess) { (void)hipGetLastError(); upload_failed = 1; }
         });
+        if (upload_failed) return set_error(GAMUT_HIP_ERR_HIP, "qoi: upload failed");
         memcpy(h, items.data(), items.size() * sizeof(QoiItem));
-        GAMUT_HIP_CHECK(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, stream));
+        GAMUT_HIP_CHECK(hipMemcpyAsync(d, h, items.size() * sizeof(QoiItem), hipMemcpyHostToDevice, stream));
         const int n = (int)items.size();
         if (n < kQoiWideBelow && qoi_pipeline(n)) hipLaunchKernelGGL(k_qoi_pipe, dim3(n), dim3(320), 0, stream, (const QoiItem*)d, n, (const uint8_t*)(d + o_blob), d_out);
         else if (n < kQoiWideBelow) hipLaunchKernelGGL(k_qoi_decode<4>, dim3(n), dim3(256), 0, stream, (const QoiItem*)d, n, (const uint8_t*)(d + o_blob), d_out);

@@ -1386,17 +1386,19 @@ uint8_t* gamut_hip_decompress_jpeg_image_from_memory(const uint8_t* data, size_t
         if (e != hipSuccess) { set_error(GAMUT_HIP_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e)); return false; }
         return true;
     };
-    ok = ok && hip_ok(hipMalloc(&dco, nblk * 128), "hipMalloc") && hip_ok(hipMalloc(&dzz, nblk ? nblk : 1), "hipMalloc") &&
-         hip_ok(hipMalloc(&dout, out_bytes ? out_bytes : 1), "hipMalloc");
+    // device staging of the call: per-thread buffers that grow and stay (a hipMalloc / hipFree pair per buffer and call cost more than
+    // the decode of a small image)
+    static thread_local DeviceScratch s_co, s_zz, s_out;
+    if (ok) {
+        dco = s_co.get(nblk * 128 + 16); dzz = s_zz.get(nblk + 16); dout = s_out.get(out_bytes + 16);
+        if (!dco || !dzz || !dout) { (void)hipGetLastError(); set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "decompress_jpeg: device staging allocation failed"); ok = false; }
+    }
     ok = ok && hip_ok(hipMemcpyAsync(dco, f.coeffs, nblk * 128, hipMemcpyHostToDevice, st), "hipMemcpyAsync") &&
          hip_ok(hipMemcpyAsync(dzz, f.max_zag, nblk, hipMemcpyHostToDevice, st), "hipMemcpyAsync");
     ok = ok && jpeg_reconstruct_launch((const int16_t*)dco, 0, (const uint8_t*)dzz, 0, (uint8_t*)dout, (int64_t)dst_bpl, 0,
                                        f.width, f.height, f.scan_type, req_comps, 1, st) == GAMUT_HIP_OK;
     ok = ok && hip_ok(hipMemcpyAsync(result, dout, out_bytes, hipMemcpyDeviceToHost, st), "hipMemcpyAsync") &&
          hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize");
-    if (dco) (void)hipFree(dco);
-    if (dzz) (void)hipFree(dzz);
-    if (dout) (void)hipFree(dout);
     if (ok) {
         if (pixelAspectRatio) *pixelAspectRatio = f.pixel_aspect_ratio;                     // :3804-3805
         if (dotsPerInchY) *dotsPerInchY = f.dpi_y;

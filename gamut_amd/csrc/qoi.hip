@@ -779,8 +779,10 @@ void* gamut_hip_qoi_decode(const void* data, int size, gamut_hip_qoi_desc* desc,
     uint8_t* result = (uint8_t*)malloc(bytes ? bytes : 1);
     void* dout = nullptr;
     if (!result) { set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "qoi: out of memory"); return nullptr; }
-    bool ok = hipMalloc(&dout, bytes ? bytes : 1) == hipSuccess;
-    if (!ok) set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "qoi: hipMalloc(%zu) failed", bytes);
+    static thread_local DeviceScratch pixels_dev;             // per-thread staging that grows and stays
+    dout = pixels_dev.get(bytes + 16);
+    bool ok = dout != nullptr;
+    if (!ok) { (void)hipGetLastError(); set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "qoi: device staging of %zu bytes failed", bytes); }
     const uint8_t* ptr = (const uint8_t*)data; const int64_t off = 0;
     hipStream_t st = thread_stream();
     try { ok = ok && decode_batch(&ptr, &size, 1, channels, &off, (uint8_t*)dout, desc, nullptr, st) == GAMUT_HIP_OK; }
@@ -788,7 +790,6 @@ void* gamut_hip_qoi_decode(const void* data, int size, gamut_hip_qoi_desc* desc,
     if (ok && (hipMemcpyAsync(result, dout, bytes, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) {
         set_error(GAMUT_HIP_ERR_HIP, "qoi: copy back failed"); ok = false;
     }
-    if (dout) (void)hipFree(dout);
     if (!ok) { free(result); return nullptr; }
     return result;
 }

@@ -2,7 +2,7 @@
 """Mutated progressive JPEG files through the device path of gamut_hip_jpeg_entropy_decode_device (jpeg_prog.hpp): the call must
 return, nothing may fault (run tools/oob_probe.py for the placement-sensitive reads), intact files of the same batch must decode
 to the oracle's coefficients, and a file the host feeder decodes without complaint must give the same coefficients on the GPU.
-Usage: python tools/fuzz_prog_gpu.py [batches=20]"""
+Usage: python tools/fuzz_prog_gpu.py [batches=20] [baseline]     (baseline: sequential files, large enough for the self-synchronising kernel)"""
 import ctypes as C
 import io
 import os
@@ -21,14 +21,16 @@ from gamut_amd import _capi  # noqa: E402
 
 def main():
     batches = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    progressive = not (len(sys.argv) > 2 and sys.argv[2] == "baseline")
     L = _capi.lib()
     _capi.check(L.gamut_hip_init(0))
     rng = np.random.default_rng(9)
     seeds = []
     for k, kw in enumerate((dict(quality=90, subsampling=2), dict(quality=60, subsampling=0, optimize=True), dict(quality=95, subsampling=1, restart_marker_blocks=4),
                             dict(quality=40, subsampling=2, restart_marker_rows=1))):
-        bio = io.BytesIO(); Image.fromarray(gen.synth_rgb(176 + 8 * k, 120 - 8 * k, 70 + k)).save(bio, "JPEG", progressive=True, **kw); seeds.append(bio.getvalue())
-    bio = io.BytesIO(); Image.fromarray(gen.synth_rgb(97, 61, 80)).convert("L").save(bio, "JPEG", progressive=True, quality=80); seeds.append(bio.getvalue())
+        dims = (176 + 8 * k, 120 - 8 * k) if progressive else (640 + 16 * k, 480 - 16 * k)
+        bio = io.BytesIO(); Image.fromarray(gen.synth_rgb(dims[0], dims[1], 70 + k)).save(bio, "JPEG", progressive=progressive, **kw); seeds.append(bio.getvalue())
+    bio = io.BytesIO(); Image.fromarray(gen.synth_rgb(97 if progressive else 600, 61 if progressive else 400, 80)).convert("L").save(bio, "JPEG", progressive=progressive, quality=80); seeds.append(bio.getvalue())
     n_same = n_flag = n_rej = 0
     for b in range(batches):
         blobs = []
@@ -81,7 +83,7 @@ def main():
                 assert i % 6 != 0, "an intact file was flagged"
                 n_flag += 1
             L.gamut_hip_jpeg_frame_free(C.byref(fr))
-    print(f"fuzz_prog_gpu: {batches} batches of 24 files: {n_same} decoded like the host feeder, {n_flag} flagged by either decoder, {n_rej} rejected by the marker walk")
+    print(f"fuzz_prog_gpu ({'progressive' if progressive else 'baseline'}): {batches} batches of 24 files: {n_same} decoded like the host feeder, {n_flag} flagged by either decoder, {n_rej} rejected by the marker walk")
 
 
 if __name__ == "__main__":

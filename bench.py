@@ -260,7 +260,9 @@ def main():
     elif wl == "png" or wl.startswith("png:"):
         import oracle_lib as O
         parts = wl.split(":")                                  # png[:policy[:channels]]
-        policy = parts[1] if len(parts) > 1 else "heuristic"
+        # default: a random filter per row (a fifth of the rows Paeth, every band mixed: what adaptive encoders produce on photographs).
+        # "heuristic" = the minimum-sum-of-absolute-differences choice on THIS synthetic data, which never picks Paeth: the cheap case.
+        policy = parts[1] if len(parts) > 1 and parts[1] else "random"
         ch = int(parts[2]) if len(parts) > 2 else 4
         on = int(parts[3]) if len(parts) > 3 else ch           # out_n: ch or ch + 1 (alpha inserted, stbdec.d:1467-1480)
         if policy.isdigit():

@@ -6,7 +6,7 @@ run() { timeout 400 python $REPO/bench.py --no-cpu "$@" 2>/dev/null | tail -1 >>
 run --workload jpeg
 for w in jpeg:3 jpeg:1; do run --workload $w; done
 for w in jpeg:4:1 jpeg:3:1 jpeg:4:2 jpeg:4:3 jpeg:3:3 jpeg:1:0; do run --workload $w --batch 512; done
-for w in png png:random png:4 png:heuristic:3 png:random:3 png:heuristic:1 png:heuristic:2 png:heuristic:3:4; do run --workload $w --steps 10; done
+for w in png:heuristic png:random png:4 png:heuristic:3 png:random:3 png:heuristic:1 png:heuristic:2 png:heuristic:3:4; do run --workload $w --steps 10; done
 for p in rgba16:rgbaf32 rgbaf32:rgba16 rgba8:rgbaf32 rgbaf32:rgba8 rgba8:rgba16 rgba16:rgba8 rgb8:rgba8 rgba8:l8 l16:rgbaf32 rgbap16:rgbaf32; do run --workload convert:$p --steps 10; done
 run --workload mixed --steps 5 --warmup 1
 for b in 1 8 64; do run --workload png:random --batch $b --steps 10; done

@@ -1,4 +1,4 @@
-for spec in "jpeg|--steps 2 --warmup 1 --batch 64" "png|--workload png --steps 2 --warmup 1 --batch 64" "png_paeth|--workload png:4 --steps 2 --warmup 1 --batch 64" "png_rgb8_rgba8|--workload png:heuristic:3:4 --steps 2 --warmup 1 --batch 64" "convert_rgba16_rgbaf32|--workload convert:rgba16:rgbaf32 --steps 2 --warmup 1 --batch 2"; do
+for spec in "jpeg|--steps 2 --warmup 1 --batch 64" "png|--workload png:heuristic --steps 2 --warmup 1 --batch 64" "png_paeth|--workload png:4 --steps 2 --warmup 1 --batch 64" "png_rgb8_rgba8|--workload png:heuristic:3:4 --steps 2 --warmup 1 --batch 64" "convert_rgba16_rgbaf32|--workload convert:rgba16:rgbaf32 --steps 2 --warmup 1 --batch 2"; do
   tag=${spec%%|*}; args=${spec#*|}
   echo "== $tag: bench.py $args"
   bash tools/pmc.sh "SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS" -- $args 2>&1 | grep -v "rocprofv3\]"

@@ -35,6 +35,7 @@ struct Rccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
+    char why[256] = "symbols missing";                      // the loader's message, captured once (dlerror() clears itself)
 };
 
 Rccl& rccl()
@@ -45,7 +46,7 @@ Rccl& rccl()
         const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
         for (const char* n : names) if ((r.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;          // reuse a loaded copy (PyTorch's)
         if (!r.h) for (const char* n : names) if ((r.h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
-        if (!r.h) return;
+        if (!r.h) { const char* e = dlerror(); if (e) snprintf(r.why, sizeof(r.why), "%s", e); return; }
 #define GAMUT_SYM(field, name) *(void**)(&r.field) = dlsym(r.h, name)
         GAMUT_SYM(GetUniqueId, "ncclGetUniqueId"); GAMUT_SYM(CommInitRank, "ncclCommInitRank"); GAMUT_SYM(CommDestroy, "ncclCommDestroy");
         GAMUT_SYM(Send, "ncclSend"); GAMUT_SYM(Recv, "ncclRecv"); GAMUT_SYM(GroupStart, "ncclGroupStart"); GAMUT_SYM(GroupEnd, "ncclGroupEnd");
@@ -58,7 +59,7 @@ Rccl& rccl()
 
 int need_rccl()
 {
-    if (!rccl().ok) return set_error(GAMUT_HIP_ERR_UNSUPPORTED, "librccl could not be loaded (%s)", dlerror() ? dlerror() : "symbols missing");
+    if (!rccl().ok) return set_error(GAMUT_HIP_ERR_UNSUPPORTED, "librccl could not be loaded (%s)", rccl().why);
     return GAMUT_HIP_OK;
 }
 int nccl_fail(const char* what, ncclResult_t rc)

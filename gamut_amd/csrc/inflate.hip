@@ -601,8 +601,8 @@ int inflate_launch(const gamut_hip_inflate_desc* descs, int count, uint32_t* out
         if (!descs[i].src || (!descs[i].dst && descs[i].dst_cap)) return set_error(GAMUT_HIP_ERR_INVALID_ARG, "inflate: stream %d: null pointer", i);
         items[(size_t)i] = InfItem{ descs[i].src, descs[i].dst, descs[i].src_len, descs[i].dst_cap };
     }
-    static const bool attr_set = hipFuncSetAttribute((const void*)k_inflate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Shared)) == hipSuccess;
-    if (!attr_set) return set_error(GAMUT_HIP_ERR_HIP, "inflate: %zu bytes of LDS are not available", sizeof(Shared));
+    // per call: the attribute belongs to the current device's copy of the kernel, and a process may drive several devices
+    if (hipFuncSetAttribute((const void*)k_inflate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Shared)) != hipSuccess) return set_error(GAMUT_HIP_ERR_HIP, "inflate: %zu bytes of LDS are not available", sizeof(Shared));
     // the descriptor table in HBM: one buffer per (thread, stream) -- calls on one stream are ordered, calls on different
     // streams never share it; growing it waits for its own stream only
     struct StreamTable { hipStream_t stream; void* p; size_t cap; };

@@ -581,7 +581,7 @@ struct DevBits {
     }
 };
 
-constexpr size_t kBlobSlack = 512;                           // bytes a lane may read past the last segment (one block + look-ahead), see k_jpeg_entropy
+constexpr size_t kBlobSlack = 1024;                          // bytes a lane may read past the last segment: one block + look-ahead in k_jpeg_entropy; in k_prog_scan the 64-byte limit check + a block's worth of a corrupt AC scan (244 bytes) + the 256-byte window
 constexpr int kEntropyThreads = 64;                          // one wave per workgroup: lanes spread over CUs, each with its own L1
 constexpr int kLdsHuff = 8, kLdsQuant = 8;                     // tables a workgroup keeps in LDS (15 KB + 1 KB: two encoders' sets; more distinct tables in a batch are read from global memory)
 #ifndef JPEG_SYNC_THREADS          // tuning knob (tools/variant.sh)

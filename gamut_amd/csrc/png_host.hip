@@ -481,7 +481,7 @@ int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* 
                 // the file's share goes up at once (copy stream): the DMA of the batch runs beside the chunk walk instead of after it
                 if (hipMemcpyAsync(d_blob + blob_off[(size_t)i], h_blob + blob_off[(size_t)i], h.ioff - skip, hipMemcpyHostToDevice, copy_stream) != hipSuccess) {
                     (void)hipGetLastError();
-                    f.rc = GAMUT_HIP_ERR_HIP; snprintf(f.msg, sizeof(f.msg), "image %d: png: upload failed", i); free(h.idata); continue;
+                    f.rc = GAMUT_HIP_ERR_HIP; snprintf(f.msg, sizeof(f.msg), "image %d: png: upload failed", i); continue;   // ~PngHeader frees idata
                 }
                 free(h.idata); h.idata = nullptr;
                 f.h = h;

@@ -190,7 +190,9 @@ uint8_t* gamut_hip_decompress_jpeg_image_from_memory(const uint8_t* data, size_t
 
 /* the same with the reference's own argument list (jpegload.d:3720-3723): the input arrives through a JpegStreamReadFunc
  * (jpegload.d:61-70): `int function(void* pBuf, int max_bytes_to_read, bool* pEOF_flag, void* userData)`, -1 = error, called
- * until it raises *pEOF_flag.  D's bool is one byte: unsigned char here.  The stream is read to its end, then decoded as above. */
+ * until it raises *pEOF_flag.  D's bool is one byte: unsigned char here.  The stream is pulled in jpgd's own 8 KiB pieces
+ * (prep_in_buffer, jpegload.d:1971-2003) and no further call is made once the image's EOI marker has arrived -- an image
+ * embedded in a longer stream is over-read by less than one piece, as by the reference -- then decoded as above. */
 typedef int (*gamut_hip_jpeg_stream_read_func)(void* pBuf, int max_bytes_to_read, unsigned char* pEOF_flag, void* userData);
 uint8_t* gamut_hip_decompress_jpeg_image_from_stream(gamut_hip_jpeg_stream_read_func rfn, void* userData,
         int* width, int* height, int* actual_comps,
@@ -228,10 +230,14 @@ uint16_t* gamut_hip_stbi_load_16_from_memory(const uint8_t* data, size_t len, in
                                              float* ppmX, float* ppmY, float* pixelRatio);
 /* stbi__png_is16 (stbdec.d:2091-2109) */
 int gamut_hip_png_is16(const uint8_t* data, size_t len);
-/* the same three with the reference's own argument lists: stbi_io_callbacks (stbdec.d:408-419; read / skip / eof, only
- * `read` is used: a read of 0 bytes ends the data, as in stbi__refill_buffer) + the user pointer, then exactly the
- * parameters of stbi_load_from_callbacks / stbi_load_16_from_callbacks (stbdec.d:713-735).  is16 reads the header only;
- * the caller rewinds its stream before loading, as plugins/png.d:50-62 does. */
+/* the same three with the reference's own argument lists: stbi_io_callbacks (stbdec.d:408-419) + the user pointer, then
+ * exactly the parameters of stbi_load_from_callbacks / stbi_load_16_from_callbacks (stbdec.d:713-735).  The stream is walked
+ * chunk by chunk as stbi__parse_png_file does (stbdec.d:1777-2023): `read` for chunk headers and the chunks the parser looks
+ * at (a read of 0 bytes ends the data, as in stbi__refill_buffer :780-795), `skip` for every other ancillary chunk
+ * (stbi__skip :822-842; NULL = read and drop), `eof` for the file without IEND (:2008-2012; NULL = "not yet").  The walk stops
+ * behind IEND's CRC and leaves the stream there (stb's 128-byte buffer leaves it up to 127 bytes further): a second image may
+ * follow in the same stream.  is16 reads up to IHDR only; the caller rewinds its stream before loading, as
+ * plugins/png.d:50-62 does. */
 typedef struct gamut_hip_stbi_io_callbacks {
     int  (*read)(void* user, char* data, int size);
     void (*skip)(void* user, int n);

@@ -1,7 +1,7 @@
 """The file-level batch entry points from several caller threads at once: each call owns a private copy stream, events, a
 device arena and (PNG) workers with pooled pinned buffers -- results must equal those of the same calls made one by one."""
 import ctypes as C
-import glob
+import fixtures
 import os
 import threading
 
@@ -67,7 +67,7 @@ def test_batch_entry_points_from_concurrent_threads(hip):
     pngs += [gen.write_png(rng.integers(0, 256, (33, 50 * 4)), 50, 33, 6, 8), gen.write_png(rng.integers(0, 256, (h, w * 2)), w, h, 4, 8, interlace=1),
              open(os.path.join(G, "ref_images", "issue65.png"), "rb").read()]
     jpgs = []
-    for p in sorted(glob.glob(os.path.join(G, "jpeg", "*.jpg"))):
+    for p in fixtures.jpegs(issue35=False):
         d = open(p, "rb").read(); fr = _capi.JpegFrame()
         if not os.path.basename(p).startswith("p_") and hip.gamut_hip_jpeg_read_header(d, len(d), C.byref(fr)) == 0:
             jpgs.append(d)

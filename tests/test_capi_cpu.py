@@ -2,7 +2,7 @@
 declares; host-side logic (JPEG entropy feeder, PNG header scan, argument validation, error conventions) agrees with
 the oracle.  No compute entry point is exercised here (there is no CPU fallback to exercise)."""
 import ctypes as C
-import glob
+import fixtures
 import os
 import re
 
@@ -50,7 +50,7 @@ def test_enums_mirror_the_reference():
     assert L.gamut_hip_pixel_type_size(-1) == 0 and L.gamut_hip_pixel_type_size(18) == 0
 
 
-JPEGS = sorted(glob.glob(os.path.join(G, "jpeg", "*.jpg"))) + [os.path.join(G, "ref_images", "issue35.jpg")]
+JPEGS = fixtures.jpegs()
 
 
 @pytest.mark.parametrize("path", JPEGS, ids=[os.path.basename(p) for p in JPEGS])

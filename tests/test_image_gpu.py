@@ -1,6 +1,6 @@
 """GPU tests of the `Image` mirror: loadFromMemory (JPEG / PNG) and convertTo through the GPU kernels, compared with the
 oracle composed the way the reference composes its pieces (plugins/jpeg.d:42-104, plugins/png.d:44-163, image.d:1180-1332)."""
-import glob
+import fixtures
 import hashlib
 import json
 import os
@@ -65,7 +65,7 @@ def test_config1_640x480_jpeg_to_rgba8(hip):
     assert hashlib.sha256(im.pixels().tobytes()).hexdigest() == golden
 
 
-JPEGS = sorted(glob.glob(os.path.join(G, "jpeg", "s_*.jpg"))) + [os.path.join(G, "ref_images", "issue35.jpg")]
+JPEGS = fixtures.jpegs("s_*.jpg", at_least=6)
 FLAGSETS = [0, gi.LOAD_RGB | gi.LOAD_ALPHA | gi.LOAD_8BIT, gi.LOAD_GREYSCALE | gi.LOAD_NO_ALPHA, gi.LOAD_GREYSCALE | gi.LOAD_ALPHA,
             gi.LOAD_FP32 | gi.LOAD_GREYSCALE, gi.LOAD_16BIT | gi.LOAD_RGB | gi.LOAD_NO_ALPHA, gi.LOAD_RGB | gi.LOAD_ALPHA | gi.LOAD_PREMUL | gi.LOAD_FP32]
 

@@ -1,7 +1,7 @@
 """GPU parity: JPEG block reconstruction (IDCT + 4:2:0 frequency-domain upsample + YCbCr->RGB)
 through the C ABI vs the CPU oracle.  Bar: bit-exact, every sampling mode, every output format."""
 import ctypes as C
-import glob
+import fixtures
 import hashlib
 import json
 import os
@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLDEN = json.load(open(os.path.join(HERE, "golden", "golden.json")))
-JPEGS = sorted(glob.glob(os.path.join(HERE, "golden", "jpeg", "*.jpg"))) + [os.path.join(HERE, "golden", "ref_images", "issue35.jpg")]
+JPEGS = fixtures.jpegs()
 NB = {0: 1, 1: 3, 2: 4, 3: 4, 4: 6}
 MCU = {0: (8, 8), 1: (8, 8), 2: (16, 8), 3: (8, 16), 4: (16, 16)}
 ZAG = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42,

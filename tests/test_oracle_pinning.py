@@ -2,7 +2,7 @@
 the reference's own fixtures and known answers, Pillow-derived golden hashes (tests/golden/golden.json, made by
 tools/make_fixtures.py), a float model of the frequency-domain upsample, a numpy binary32 model of the
 conversions, and the losslessness of PNG."""
-import glob
+import fixtures
 import hashlib
 import json
 import os
@@ -107,7 +107,7 @@ def test_png_generated_files_vs_source_pixels():
 
 
 # ------------------------------------------------------------------ JPEG
-JPEGS = sorted(glob.glob(os.path.join(G, "jpeg", "*.jpg"))) + [os.path.join(G, "ref_images", "issue35.jpg")]
+JPEGS = fixtures.jpegs()
 
 
 @pytest.mark.parametrize("path", JPEGS, ids=[os.path.basename(p) for p in JPEGS])

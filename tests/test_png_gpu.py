@@ -1,7 +1,6 @@
 """GPU parity: PNG de-filter / expand and the whole stb load path through the C ABI vs the CPU oracle
 (and vs the pixels the streams were built from: PNG is lossless).  Bar: bit-exact."""
 import ctypes as C
-import glob
 import os
 
 import numpy as np

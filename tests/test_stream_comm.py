@@ -4,18 +4,18 @@ CPU part: shard arithmetic against gamut_amd/shard.py, argument validation, read
 GPU part: *_from_stream / *_from_callbacks == the *_from_memory entry points == the oracle; world-1 gather; a 2-rank RCCL
 gather on one box (both ranks on cuda:0 is refused by RCCL, so that test needs 2 devices and is skipped otherwise)."""
 import ctypes as C
-import glob
 import os
 
 import numpy as np
 import pytest
 
+import fixtures
 import oracle_lib as O
 from gamut_amd import _capi, shard
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-JPEGS = sorted(glob.glob(os.path.join(HERE, "golden", "*.jpg")))
-PNGS = sorted(glob.glob(os.path.join(HERE, "golden", "ref_images", "*.png")))
+JPEGS = fixtures.jpegs()
+PNGS = fixtures.ref_pngs()
 
 
 def _jpeg_reader(data, piece, raise_eof_late=False, fail_at=None):
@@ -47,6 +47,7 @@ def _stb_callbacks(data, piece):
 
     def skip(user, n):
         state["pos"] += n
+        state["skipped"] = state.get("skipped", 0) + n
 
     def eof(user):
         return int(state["pos"] >= len(data))
@@ -130,9 +131,69 @@ def test_png_is16_from_callbacks_reads_the_header_only():
         assert st["pos"] <= 64, "is16 must not consume the stream beyond the header"
 
 
+def _with_ancillary_chunk(png, payload_len=5000):
+    """the file with a tEXt chunk behind IHDR: stb skips such chunks through the `skip` callback (stbdec.d:822-842, 2018)"""
+    import struct, zlib
+    body = b"tEXt" + bytes(range(256)) * (payload_len // 256) + bytes(payload_len % 256)
+    chunk = struct.pack(">I", len(body) - 4) + body + struct.pack(">I", zlib.crc32(body))
+    at = png.index(b"IHDR") + 4 + 13 + 4                       # behind IHDR's CRC (CgBI files have a chunk before IHDR)
+    return png[:at] + chunk + png[at:]
+
+
+def _png_end(data):
+    """offset behind IEND's CRC, or len(data) for the files that have none (issue #92)"""
+    at = data.find(b"IEND")
+    return at + 8 if at >= 0 and at + 8 <= len(data) else len(data)
+
+
+def test_png_callbacks_stop_behind_iend_and_skip_ancillary_chunks():
+    """An image embedded in a longer stream (Image.loadFromStream, image.d:916): the walk reads what stbi__parse_png_file
+    parses (stbdec.d:1777-2023) and leaves the stream at the end of the image.  Runs without a GPU: the gathering happens
+    before any device work (the decode itself then fails with NO_DEVICE here; the GPU twin below checks the pixels)."""
+    L = _capi.lib()
+    x, y, n = C.c_int(), C.c_int(), C.c_int()
+    libc = C.CDLL(None); libc.free.argtypes = [C.c_void_p]
+    for path in PNGS:
+        first = open(path, "rb").read()
+        for data in (first, _with_ancillary_chunk(first)):
+            end = _png_end(data)
+            stream = data + open(PNGS[0], "rb").read() + bytes(70000)
+            if end == len(data):
+                stream = data                                    # no IEND: the image ends with the stream
+            for piece in (1 << 20, 1000, 7):
+                cb, st, keep = _stb_callbacks(stream, piece)
+                p = L.gamut_hip_stbi_load_from_callbacks(C.byref(cb), None, C.byref(x), C.byref(y), C.byref(n), 4, None, None, None)
+                if p:
+                    libc.free(p)
+                assert st["pos"] == end, (os.path.basename(path), piece, st["pos"], end)
+                if data is not first:
+                    assert st.get("skipped", 0) >= 5000, "ancillary chunks are skipped, not read"
+
+
+def test_jpeg_stream_stops_at_eoi():
+    """jpgd reads 8 KiB pieces and stops decoding at EOI (jpegload.d:1971-2003): the gatherer makes no call once EOI is in,
+    so at most one piece is over-read -- the reference's own granularity.  Embedded FFD9 inside an APPn payload is not EOI."""
+    L = _capi.lib()
+    w, h, ac = C.c_int(), C.c_int(), C.c_int()
+    libc = C.CDLL(None); libc.free.argtypes = [C.c_void_p]
+    for path in JPEGS:
+        data = open(path, "rb").read()
+        end = data.rfind(b"\xff\xd9") + 2
+        assert end >= 2
+        thumb = data[:2] + b"\xff\xe1\x00\x08\xff\xd9\xff\xd9\x00\x00" + data[2:]           # an APP1 segment holding FFD9 FFD9
+        for d, e in ((data, end), (thumb, end + 10)):
+            stream = d[:e] + bytes(100000)
+            for piece in (1 << 20, 977):
+                rd, st = _jpeg_reader(stream, piece)
+                p = L.gamut_hip_decompress_jpeg_image_from_stream(rd, None, C.byref(w), C.byref(h), C.byref(ac), None, None, 4)
+                if p:
+                    libc.free(p)
+                assert e <= st["pos"] < e + 8192, (os.path.basename(path), piece, st["pos"], e)
+
+
 # ------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
-@pytest.mark.parametrize("path", JPEGS[:6], ids=[os.path.basename(p) for p in JPEGS[:6]])
+@pytest.mark.parametrize("path", JPEGS, ids=[os.path.basename(p) for p in JPEGS])
 def test_jpeg_from_stream_equals_oracle(hip, path):
     data = open(path, "rb").read()
     libc = C.CDLL(None); libc.free.argtypes = [C.c_void_p]
@@ -149,7 +210,7 @@ def test_jpeg_from_stream_equals_oracle(hip, path):
             libc.free(p)
             assert np.array_equal(got, exp[0])
             assert (ac.value, par.value, dpi.value) == exp[1:]
-            assert st["pos"] == len(data)
+            assert st["pos"] == len(data)                      # the fixtures end with EOI: nothing behind the image
     # optional out-pointers may be NULL, as in the reference's callers that do not want the DPI
     rd, _ = _jpeg_reader(data, 1 << 16)
     p = hip.gamut_hip_decompress_jpeg_image_from_stream(rd, None, C.byref(w), C.byref(h), C.byref(ac), None, None, 4)
@@ -179,6 +240,44 @@ def test_png_from_callbacks_equals_oracle(hip, path):
             got = np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), (y.value, x.value, comps)).copy()
             libc.free(p)
             assert n.value == exp[1] and np.array_equal(got, exp[0])
+
+
+@pytest.mark.gpu
+def test_two_images_back_to_back_in_one_stream(hip):
+    """PNG, PNG (with a skipped chunk), JPEG one behind the other in one stream: each call decodes its image == the oracle and
+    leaves the stream where the next one starts (stbdec.d:754-770,1777-2023; the JPEG comes last: its reader over-reads < 8 KiB)."""
+    libc = C.CDLL(None); libc.free.argtypes = [C.c_void_p]
+    a = open(fixtures.ref_image("issue65.png"), "rb").read()
+    b = _with_ancillary_chunk(open(fixtures.ref_image("vst3-compatible.png"), "rb").read())
+    j = open(JPEGS[0], "rb").read()
+    stream = a + b + j + bytes(50000)
+    cb, st, keep = _stb_callbacks(stream, 1000)
+    for png, start in ((a, 0), (b, len(a))):
+        assert st["pos"] == start
+        exp = O.stbi_load(png, 4, False)
+        x, y, n = C.c_int(), C.c_int(), C.c_int()
+        p = hip.gamut_hip_stbi_load_from_callbacks(C.byref(cb), None, C.byref(x), C.byref(y), C.byref(n), 4, None, None, None)
+        assert p, hip.gamut_hip_last_error()
+        got = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (y.value, x.value, 4)).copy()
+        libc.free(p)
+        assert n.value == exp[1] and np.array_equal(got, exp[0])
+    assert st["pos"] == len(a) + len(b)
+
+    def rd(pbuf, max_bytes, peof, user):                         # the JPEG reader continues on the same stream state
+        k = min(max_bytes, len(stream) - st["pos"])
+        C.memmove(pbuf, stream[st["pos"]:st["pos"] + k], k)
+        st["pos"] += k
+        if st["pos"] >= len(stream):
+            peof[0] = 1
+        return k
+    w, h, ac = C.c_int(), C.c_int(), C.c_int()
+    p = hip.gamut_hip_decompress_jpeg_image_from_stream(_capi.JPEG_STREAM_READ_FUNC(rd), None, C.byref(w), C.byref(h), C.byref(ac), None, None, 4)
+    assert p, hip.gamut_hip_last_error()
+    exp = O.decompress_jpeg(j, 4)
+    got = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (h.value, w.value * 4)).copy()
+    libc.free(p)
+    assert np.array_equal(got, exp[0])
+    assert len(a) + len(b) + len(j) <= st["pos"] < len(a) + len(b) + len(j) + 8192
 
 
 @pytest.mark.gpu

@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--serial-formats", action="store_true", help="mixed workload: one stream, one format after the other")
     ap.add_argument("--total-images", type=int, default=0, help="mixed workload: images over ALL ranks (8192 = BASELINE.json configs[4]); "
                     "each rank takes total / N (strong scaling) instead of --batch")
+    ap.add_argument("--no-also", action="store_true", help="default workload only: skip the `also` lines (the other BASELINE.json configs at their stated shapes)")
+    ap.add_argument("--also-seconds", type=float, default=240.0, help="wall-clock budget of the `also` lines; what does not fit is reported as skipped")
     ap.add_argument("--gather", action="store_true", help="N > 1: also time an all_gather of output slices (after the timed region)")
     return ap.parse_args()
 
@@ -94,7 +96,7 @@ def live_traffic(kernel_substr, pmc_batch):
         d = tempfile.mkdtemp(prefix="gamut_pmc_", dir="/tmp")
         try:
             cmd = [exe, "--output-format", "csv", "--pmc", ctr, "-d", d, "-o", "t", "--", sys.executable, os.path.abspath(__file__)] + inner + \
-                  ["--steps", "3", "--warmup", "1", "--no-cpu", "--no-traffic", "--batch", str(pmc_batch)]
+                  ["--steps", "3", "--warmup", "1", "--no-cpu", "--no-traffic", "--no-also", "--batch", str(pmc_batch)]
             env = dict(os.environ, TMPDIR="/tmp", GAMUT_BENCH_NOCHECK="1")
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
             tot, n = 0.0, 0
@@ -111,6 +113,53 @@ def live_traffic(kernel_substr, pmc_batch):
             shutil.rmtree(d, ignore_errors=True)
     per_launch = 2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024
     return per_launch / pmc_batch, f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in this run, batch {pmc_batch}, FETCH_SIZE x2 (gfx950), KB -> B"
+
+
+ALSO = [  # the other BASELINE.json configs at their stated shapes, each through this same script (its own parity check included)
+    ("config 2, what a caller has: coefficients + max_zag from libjpeg-written photographs", "jpeg:photo", []),
+    ("config 3: 512 x 3840x2160 RGBA8, random row filters (a fifth Paeth)", "png", []),
+    ("config 3: the same with the encoder heuristic's filters (no Paeth rows on this data)", "png:heuristic", []),
+    ("config 4: rgba16 -> rgbaf32, 256 layers of 8192x8192 in resident chunks", "convert:rgba16:rgbaf32", ["--batch", "256"]),
+    ("config 4: rgbaf32 -> rgba8, 256 layers", "convert:rgbaf32:rgba8", ["--batch", "256"]),
+    ("config 4: rgba8 -> rgba16, 256 layers", "convert:rgba8:rgba16", ["--batch", "256"]),
+    ("config 5 at its stated size on this GPU: 8192 mixed 1080p images", "mixed", ["--total-images", "8192"]),
+]
+
+
+def also_lines(budget_s):
+    """Runs every ALSO workload as `bench.py --workload ... --steps 5 --warmup 2` in a process of its own (fresh HBM) and condenses
+    its JSON line.  A non-zero exit code is a parity failure or an error and is reported as such, never dropped."""
+    import subprocess
+    t_end = time.perf_counter() + budget_s
+    res = []
+    for what, wl, extra in ALSO:
+        left = t_end - time.perf_counter()
+        if left < 20:
+            res.append({"what": what, "workload": wl, "skipped": "the --also-seconds budget ran out"})
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", "5", "--warmup", "2", "--no-cpu", "--no-traffic", "--no-also"] + extra
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=left, text=True)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not line:
+                res.append({"what": what, "workload": wl, "parity": "FAILED" if "PARITY" in (r.stderr + r.stdout) else None,
+                            "error": ((r.stderr or r.stdout).strip().splitlines() or ["no output"])[-1][:200], "rc": r.returncode})
+                continue
+            j = json.loads(line[-1])
+            e = {"what": what, "workload": j["config"]["workload"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
+                 "roofline_frac": j["roofline"]["frac"], "achieved_GB/s": j["roofline"]["achieved"], "kernel": j["roofline"]["kernel"],
+                 "kernel_ms_avg": j["roofline"]["kernel_ms_avg"], "parity": "ok (checked against the oracle before timing)", "steps": j["steps"],
+                 "wall_s": round(time.perf_counter() - t0, 1)}
+            for k in ("per_format", "waves_on_sparse_luma_passes", "y_blocks_max_zag_le_10"):
+                if k in j["config"]:
+                    e[k] = j["config"][k]
+            res.append(e)
+        except subprocess.TimeoutExpired:
+            res.append({"what": what, "workload": wl, "skipped": "did not finish inside the --also-seconds budget"})
+        except Exception as ex:                                          # the headline line must survive anything here
+            res.append({"what": what, "workload": wl, "error": repr(ex)[:200]})
+    return res
 
 
 def self_launch(args):
@@ -165,21 +214,59 @@ def main():
     check = None
     _host = {}                                                   # host copies of the cpu_baseline sample (made once, shared by the threads)
     if wl == "jpeg" or wl.startswith("jpeg:"):
-        jp = wl.split(":")                                       # jpeg[:out_comps[:scan_type]]
+        jp = wl.split(":")                                       # jpeg[:out_comps[:scan_type]]  |  jpeg:photo[:out_comps]
+        photo = len(jp) > 1 and jp[1] == "photo"
+        if photo:
+            jp = [jp[0]] + jp[2:]
         oc = int(jp[1]) if len(jp) > 1 else 4                    # 4 = rgba8 (headline), 3 = rgb8, 1 = l8
         st = int(jp[2]) if len(jp) > 2 else 4                    # jpgd scan type: 4 = 4:2:0 (headline), 3 = 4:4:0, 2 = 4:2:2, 1 = 4:4:4, 0 = grey
         comps_in = 1 if st == 0 else 3
-        coeffs = synth.jpeg_coeff_batch(B, w, h, dev, seed=1 + rank, scan_type=st)
-        nblk = coeffs.shape[1]
+        files = None
+        if photo:
+            # What a caller has after decode_next_row: coefficients AND m_mcu_block_max_zag of real files.  Synthetic photographs
+            # (synth.photo_rgb: 1/f detail on ~45 % of the frame, smooth elsewhere) written by libjpeg (Pillow) as baseline 4:2:0 at
+            # q 75 / 85 / 90, entropy-decoded on the GPU (gamut_hip_jpeg_entropy_decode_device) straight into the resident buffers
+            # the timed launch reads.
+            import io
+            from PIL import Image
+            assert st == 4
+            nd = max(1, min(B, 6))
+            files = []
+            for i in range(nd):
+                bio = io.BytesIO()
+                Image.fromarray(synth.photo_rgb(w, h, 1000 * (1 + rank) + i)).save(bio, "JPEG", quality=(75, 85, 90)[i % 3], subsampling=2)
+                files.append(np.frombuffer(bio.getvalue(), np.uint8))
+            nblk = ((w + 15) // 16) * ((h + 15) // 16) * 6
+            coeffs = torch.empty((B, nblk, 64), dtype=torch.int16, device=dev)
+            zag = torch.empty((B, nblk), dtype=torch.uint8, device=dev)
+            bufs = [files[i % nd] for i in range(B)]
+            ptrs = (C.c_void_p * B)(*[b.ctypes.data for b in bufs]); lens = (C.c_size_t * B)(*[b.size for b in bufs])
+            co_off = np.arange(B, dtype=np.int64) * nblk * 64; zz_off = np.arange(B, dtype=np.int64) * nblk
+            info = (_capi.JpegFrame * B)()
+            _capi.check(L.gamut_hip_jpeg_entropy_decode_device(ptrs, lens, B, co_off.ctypes.data_as(C.POINTER(C.c_int64)), zz_off.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                                coeffs.data_ptr(), zag.data_ptr(), None, info, None, stream))
+            torch.cuda.synchronize()
+        else:
+            coeffs = synth.jpeg_coeff_batch(B, w, h, dev, seed=1 + rank, scan_type=st)
+            zag = synth.jpeg_max_zag(coeffs)                     # m_mcu_block_max_zag, as decode_next_row leaves it (jpegload.d:2512)
+            nblk = coeffs.shape[1]
         out = torch.empty((B, h, w * oc), dtype=torch.uint8, device=dev)
         px_per_step = B * w * h
-        bytes_per_step = B * (nblk * 128 + w * h * oc)           # 6 266 880 + 8 294 400 per 1080p image (rgba8)
+        bytes_per_step = B * (nblk * 128 + w * h * oc)           # 6 266 880 + 8 294 400 per 1080p image (rgba8); the max_zag bytes (48 960) are not counted
         kernel_name = "k_jpeg_h2v2" if st == 4 else "k_jpeg_"
+        zstat = {}
+        if st == 4:                                              # which share of the kernel's waves (2 MCUs = 8 Y blocks) takes the Row!4 / Col!4 passes
+            yz = zag.view(B, -1, 6)[:, :, :4]
+            mrow = (w + 15) // 16
+            pair = (yz <= 10).all(dim=2).view(B, -1, mrow)[:, :, :mrow // 2 * 2].reshape(B, -1, 2).all(dim=2)
+            zstat = {"y_blocks_max_zag_le_10": round(float((yz <= 10).float().mean()), 4), "y_max_zag_median": float(yz.float().median()),
+                     "waves_on_sparse_luma_passes": round(float(pair.float().mean()), 4)}
         workload = (f"batch {B} x {w}x{h} baseline JPEG { {4: '4:2:0', 3: '4:4:0', 2: '4:2:2', 1: '4:4:4', 0: 'grey'}[st] }, IDCT"
-                    f"{' + freq-domain chroma upsample' if st == 4 else ''} + YCbCr->{ {4: 'RGBA8', 3: 'RGB8', 1: 'L8'}[oc] }")
+                    f"{' + freq-domain chroma upsample' if st == 4 else ''} + YCbCr->{ {4: 'RGBA8', 3: 'RGB8', 1: 'L8'}[oc] }"
+                    + (", coefficients + max_zag entropy-decoded from libjpeg-written synthetic photographs (q 75/85/90)" if photo else ", coefficients + max_zag of the q 90 smooth-plus-noise generator"))
 
         def step():
-            _capi.check(L.gamut_hip_jpeg_reconstruct_batch_device(coeffs.data_ptr(), nblk * 64, None, 0, out.data_ptr(), w * oc,
+            _capi.check(L.gamut_hip_jpeg_reconstruct_batch_device(coeffs.data_ptr(), nblk * 64, zag.data_ptr(), nblk, out.data_ptr(), w * oc,
                                                                    h * w * oc, w, h, st, oc, B, stream))
 
         def check():
@@ -187,22 +274,28 @@ def main():
             step()
             torch.cuda.synchronize()
             for i in sorted({0, B - 1}):
-                exp = O.jpeg_reconstruct(w, h, comps_in, st, coeffs[i].cpu().numpy(), None, oc)
+                exp = O.jpeg_reconstruct(w, h, comps_in, st, coeffs[i].cpu().numpy(), zag[i].cpu().numpy(), oc)
                 if not np.array_equal(out[i].cpu().numpy(), exp):
                     raise SystemExit(f"PARITY FAILURE on image {i}")
+                if photo:                                        # the whole file through the oracle's own decoder: entropy decode included
+                    d = O.DecodedJpeg(bytes(files[i % len(files)]))
+                    if not (np.array_equal(d.coeffs, coeffs[i].cpu().numpy()) and np.array_equal(d.max_zag, zag[i].cpu().numpy())):
+                        raise SystemExit(f"PARITY FAILURE (coefficients / max_zag of file {i})")
+                    if oc == 4 and not np.array_equal(out[i].cpu().numpy(), O.decompress_jpeg(bytes(files[i % len(files)]), 4)[0]):
+                        raise SystemExit(f"PARITY FAILURE (file {i} vs decompress_jpeg)")
 
         def cpu_leg(seconds):
             import oracle_lib as O
             if "h" not in _host:
-                _host["h"] = [coeffs[i].cpu().numpy() for i in range(min(B, 64))]
+                _host["h"] = [(coeffs[i].cpu().numpy(), zag[i].cpu().numpy()) for i in range(min(B, 64))]
             host = _host["h"]
-            O.jpeg_reconstruct(w, h, comps_in, st, host[0], None, oc)             # warm
+            O.jpeg_reconstruct(w, h, comps_in, st, host[0][0], host[0][1], oc)             # warm
             n, t0 = 0, time.perf_counter()
             while time.perf_counter() - t0 < seconds:
-                O.jpeg_reconstruct(w, h, comps_in, st, host[n % len(host)], None, oc)
+                O.jpeg_reconstruct(w, h, comps_in, st, host[n % len(host)][0], host[n % len(host)][1], oc)
                 n += 1
             dt = time.perf_counter() - t0
-            return n * w * h / dt / 1e6, f"{n} of the batch's {w}x{h} coefficient frames, coefficients -> pixels, single thread, {dt:.1f} s"
+            return n * w * h / dt / 1e6, f"{n} of the batch's {w}x{h} coefficient frames (with max_zag: the sparse Row!N / Col!N paths), coefficients -> pixels, single thread, {dt:.1f} s"
         dtype = "int32"
     elif wl.startswith("convert:"):
         import oracle_lib as O
@@ -240,10 +333,11 @@ def main():
             torch.cuda.synchronize()
             rows = 4
             last = (B - 1) % R if B % R else R - 1                     # a layer the step's last launch converted
-            a = src[last].view(torch.uint8)[:rows * sp].cpu().numpy()
-            exp = O.scanlines_convert(st, a, dt_, w, rows)
-            if not np.array_equal(out[last][:rows * dp].cpu().numpy(), exp):
-                raise SystemExit("PARITY FAILURE")
+            for layer, r0 in ((0, 0), (last, 0), (last, h - rows), (R // 2, h // 2)):      # first / last rows, first / middle / last resident layer
+                a = src[layer].view(torch.uint8)[r0 * sp:(r0 + rows) * sp].cpu().numpy()
+                exp = O.scanlines_convert(st, a, dt_, w, rows)
+                if not np.array_equal(out[layer][r0 * dp:(r0 + rows) * dp].cpu().numpy(), exp):
+                    raise SystemExit(f"PARITY FAILURE (layer {layer}, rows {r0}..)")
 
         def cpu_leg(seconds):
             rows = 256
@@ -290,9 +384,10 @@ def main():
             got = out.view(B, -1).to(torch.int64).sum(dim=1) if B <= 64 else torch.stack([out[i].to(torch.int64).sum() for i in range(B)])
             if not torch.equal(got, sums + (on - ch) * 255 * w * h):           # inserted alpha = 255
                 raise SystemExit("PARITY FAILURE: checksum of de-filtered pixels != checksum of the source pixels")
-            exp = O.png_create_image_raw(raw[B - 1].cpu().numpy(), ch, on, w, h, 8, {1: 0, 2: 4, 3: 2, 4: 6}[ch])
-            if not np.array_equal(out[B - 1].cpu().numpy(), exp):
-                raise SystemExit("PARITY FAILURE vs oracle")
+            for i in sorted({0, B // 3, (2 * B) // 3, B - 1}):          # the checksums cover every image, the oracle four of them byte for byte
+                exp = O.png_create_image_raw(raw[i].cpu().numpy(), ch, on, w, h, 8, {1: 0, 2: 4, 3: 2, 4: 6}[ch])
+                if not np.array_equal(out[i].cpu().numpy(), exp):
+                    raise SystemExit(f"PARITY FAILURE vs oracle on image {i}")
 
         def cpu_leg(seconds):
             if "h" not in _host:
@@ -491,7 +586,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong" if (wl == "mixed" and args.batch == 1024 and args.total_images) else "weak", "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
-            "config": {"workload": workload, "images_per_gpu_per_step": B, "sharding": "image-index, no collective"},
+            "config": dict({"workload": workload, "images_per_gpu_per_step": B, "sharding": "image-index, no collective"}, **(zstat if wl.startswith("jpeg") else {})),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel_name, "algorithmic_bytes_per_launch": bytes_per_step,
@@ -529,6 +624,10 @@ def main():
                                                     "sample": f"the same loop on {ncores} threads at once, {dt:.1f} s"}
         else:
             res["cpu_baseline"] = None
+        if world == 1 and wl == "jpeg" and not args.no_also and B == 1024 and not (args.width or args.height):
+            del coeffs, out, zag                                          # the sub-runs want the HBM
+            torch.cuda.empty_cache()
+            res["also"] = also_lines(args.also_seconds)
         print(json.dumps(res), flush=True)
 
     if world > 1:

@@ -114,6 +114,9 @@ __device__ __forceinline__ void store_px_nt(uint8_t* row_base, u32 voff, u32 px)
 #ifndef JPEG_STRIPS_PACKED
 #define JPEG_STRIPS_PACKED 5
 #endif
+#ifndef JPEG_UNROLL_STRIPS        // 1 = the strip loop fully unrolled (exact s_waitcnt vmcnt counts across the strips' stores)
+#define JPEG_UNROLL_STRIPS 0
+#endif
 #ifndef JPEG_ABLATE               // measurement only (tools/variant.sh): 1 = loads + stores, no arithmetic; 2 = no stores; 3 = no loads
 #define JPEG_ABLATE 0
 #endif
@@ -172,6 +175,7 @@ __global__ __launch_bounds__(H2V2_THREADS) void k_jpeg_h2v2(JpegArgs a)
     const i32 sg = (cj & 1) ? -1 : 1;
 
     const ColourConsts cc = colour_consts();
+    const i32 c_round = col_round();
     const int lx = m * 16 + (q & 1) * 8 + r;               // pixel column inside the strip
     const int ly0 = (q >> 1) * 8;                          // first pixel row inside the strip
     const bool all_rows = a.height - mcu_y * 16 >= 16;     // wave-uniform: all 16 rows of the strip exist
@@ -193,10 +197,21 @@ __global__ __launch_bounds__(H2V2_THREADS) void k_jpeg_h2v2(JpegArgs a)
         cv = load_coeffs16(base + ((cbk >> 1) < here ? coff : coff0));
 #endif
     };
+    // the Y block's m_mcu_block_max_zag (when the caller has it): fetched with the coefficients, a strip ahead
+    auto fetch_zag = [&](int tile) -> u32 {
+        if (!zbase) return 64u;
+        const int here = a.mcus_per_row - tile * H2V2_MCUS;
+        return m < here ? (u32)zbase[((tile - tile0) * H2V2_MCUS + m) * 6 + q] : 1u;
+    };
     uint4 yrow, crow;
-    if (tile0 < n_tiles) fetch(tile0, yrow, crow);
+    u32 yzag = 64;
+    if (tile0 < n_tiles) { fetch(tile0, yrow, crow); yzag = fetch_zag(tile0); }
 
+#if JPEG_UNROLL_STRIPS
+    #pragma unroll
+#else
     #pragma unroll 1
+#endif
     for (int s = 0; s < STRIPS; ++s) {
         const int tile = tile0 + s;
         if (tile >= n_tiles) break;                                // wave-uniform
@@ -205,7 +220,13 @@ __global__ __launch_bounds__(H2V2_THREADS) void k_jpeg_h2v2(JpegArgs a)
         const bool mcu_live = m < mcus_here;
         uint8_t* const otile = obase + (size_t)s * (H2V2_MCUS * 16 * OC);
         uint4 ynext = yrow, cnext = crow;
-        if (s + 1 < STRIPS && tile + 1 < n_tiles) fetch(tile + 1, ynext, cnext);     // in flight during this strip's arithmetic
+        u32 znext = yzag;
+        if (s + 1 < STRIPS && tile + 1 < n_tiles) { fetch(tile + 1, ynext, cnext); znext = fetch_zag(tile + 1); }     // in flight during this strip's arithmetic
+        // jpgd picks Row!N / Col!N per block from max_zag (jpegload.d:295-376): literal zeros for the coefficients a block does
+        // not have, i.e. the dense transform at a fraction of the work.  A wave cannot branch per block, but it can per WAVE:
+        // when none of its 8 Y blocks reaches zig-zag position 10 (row 4 / column 4) -- the smooth parts of a photograph -- both
+        // luma passes are idct_4x4's (Row!4 on rows 0-3, Col!4).  Same bits: the butterfly is linear and evaluated mod 2^32.
+        const bool y_sparse = zbase && __builtin_amdgcn_ballot_w64(yzag > 10u) == 0;                   // wave-uniform
 
 #if JPEG_ABLATE == 1
         if constexpr (OC == 4) {
@@ -214,13 +235,21 @@ __global__ __launch_bounds__(H2V2_THREADS) void k_jpeg_h2v2(JpegArgs a)
                 #pragma unroll
                 for (int i = 0; i < 8; ++i) store_px_nt(otile + (size_t)i * pitch, voff, v0 + i);
             }
-            yrow = ynext; crow = cnext;
+            yrow = ynext; crow = cnext; yzag = znext; (void)y_sparse;
             continue;
         }
 #endif
 
         // P1a: luma pass 1 (row r of block b) -> T1[b][r][0..7]
-        {
+        if (y_sparse) {                                                // rows 4-7 are not read by the Col!4 pass below
+            i32 tv[8];
+            row_pass4_pairs(__builtin_amdgcn_perm(yrow.y, yrow.x, 0x05040100u), __builtin_amdgcn_perm(yrow.y, yrow.x, 0x07060302u), tv);
+            if (r < 4) {
+                i32* dst = T1 + b * BLK_STRIDE + r * 8;
+                *reinterpret_cast<int4*>(dst)     = make_int4(tv[0], tv[1], tv[2], tv[3]);
+                *reinterpret_cast<int4*>(dst + 4) = make_int4(tv[4], tv[5], tv[6], tv[7]);
+            }
+        } else {
             i32 tv[8];
             row_pass_packed(yrow, tv);
             i32* dst = T1 + b * BLK_STRIDE + r * 8;
@@ -243,15 +272,21 @@ __global__ __launch_bounds__(H2V2_THREADS) void k_jpeg_h2v2(JpegArgs a)
         // P2a: luma pass 2 (column r of block b) -> 8 samples in registers
         i32 ys[8];
         {
-            i32 tv[8];
             const i32* src = T1 + b * BLK_STRIDE + r;
-            #pragma unroll
-            for (int i = 0; i < 8; ++i) tv[i] = src[i * 8];
-            col_pass<8>(tv, ys);
-            if (zbase) {          // wave-uniform: the reference's Col!(1) shortcut (max_zag <= 2) only matters when the caller passes max_zag
-                bool y_col1 = false;
-                if (mcu_live) y_col1 = zbase[(s * H2V2_MCUS + m) * 6 + q] <= 2;
-                const i32 v = col1_sample(tv[0]);
+            i32 t0;
+            if (y_sparse) {
+                t0 = src[0];
+                col_pass4_direct(t0, src[8], src[16], src[24], ys, c_round);
+            } else {
+                i32 tv[8];
+                #pragma unroll
+                for (int i = 0; i < 8; ++i) tv[i] = src[i * 8];
+                col_pass<8>(tv, ys);
+                t0 = tv[0];
+            }
+            if (zbase && __builtin_amdgcn_ballot_w64(yzag <= 2u) != 0) {   // wave-uniform: the reference's Col!(1) shortcut (max_zag <= 2), :222-232
+                const bool y_col1 = mcu_live && yzag <= 2u;
+                const i32 v = col1_sample(t0);
                 #pragma unroll
                 for (int i = 0; i < 8; ++i) ys[i] = y_col1 ? v : ys[i];
             }
@@ -296,8 +331,8 @@ __global__ __launch_bounds__(H2V2_THREADS) void k_jpeg_h2v2(JpegArgs a)
         {
             i32 cbs[8], crs[8];
             const i32* src = T2 + b * BLK_STRIDE + r;
-            col_pass4_direct(src[0], src[8], src[16], src[24], cbs);
-            col_pass4_direct(src[32], src[40], src[48], src[56], crs);
+            col_pass4_direct(src[0], src[8], src[16], src[24], cbs, c_round);
+            col_pass4_direct(src[32], src[40], src[48], src[56], crs, c_round);
 
             const bool px_live = mcu_live && mcu_x0 * 16 + lx < a.width;
             // Addresses = uniform strip base + 32-bit lane offset.  Pixel rows are written with nontemporal stores.
@@ -308,16 +343,16 @@ __global__ __launch_bounds__(H2V2_THREADS) void k_jpeg_h2v2(JpegArgs a)
                     if (JPEG_ABLATE == 2) {
                         u32 acc = 0;
                         #pragma unroll
-                        for (int i = 0; i < 8; ++i) acc += ycc_to_rgba(ys[i], cbs[i], crs[i], cc.kr, cc.kb);
+                        for (int i = 0; i < 8; ++i) acc += ycc_to_rgba(ys[i], cbs[i], crs[i], cc.kr, cc.kb, cc.kg);
                         if (acc == 0x12345679u) store_px_nt(otile, voff, acc);
                     } else
                     if (all_rows) {
                         #pragma unroll
-                        for (int i = 0; i < 8; ++i) store_px_nt(otile + (size_t)i * pitch, voff, ycc_to_rgba(ys[i], cbs[i], crs[i], cc.kr, cc.kb));
+                        for (int i = 0; i < 8; ++i) store_px_nt(otile + (size_t)i * pitch, voff, ycc_to_rgba(ys[i], cbs[i], crs[i], cc.kr, cc.kb, cc.kg));
                     } else {
                         #pragma unroll
                         for (int i = 0; i < 8; ++i)
-                            if (i < rows_here) store_px_nt(otile + (size_t)i * pitch, voff, ycc_to_rgba(ys[i], cbs[i], crs[i], cc.kr, cc.kb));
+                            if (i < rows_here) store_px_nt(otile + (size_t)i * pitch, voff, ycc_to_rgba(ys[i], cbs[i], crs[i], cc.kr, cc.kb, cc.kg));
                     }
                 }
             } else {
@@ -335,7 +370,7 @@ __global__ __launch_bounds__(H2V2_THREADS) void k_jpeg_h2v2(JpegArgs a)
                 __syncthreads();                                       // other waves may still be reading Xs in P3
                 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const u32 px = ycc_to_rgba(ys[i], cbs[i], crs[i], cc.kr, cc.kb);
+                    const u32 px = ycc_to_rgba(ys[i], cbs[i], crs[i], cc.kr, cc.kb, cc.kg);
                     if constexpr (OC == 3) {
                         const u32 sel = j == 0 ? 0x04020100u : j == 1 ? 0x05040201u : 0x06050402u;
                         const u32 nx = (u32)__builtin_amdgcn_mov_dpp((int)px, 0xF9, 0xF, 0xF, true);      // quad_perm [1,2,3,3]: right neighbour
@@ -369,7 +404,7 @@ __global__ __launch_bounds__(H2V2_THREADS) void k_jpeg_h2v2(JpegArgs a)
             }
         }
         wave_sync();                                                   // T2 (read above) aliases the next strip's T1
-        yrow = ynext; crow = cnext;
+        yrow = ynext; crow = cnext; yzag = znext;
     }
 }
 

@@ -44,6 +44,16 @@ __device__ __forceinline__ i32 mad24_1(i32 a, i32 c, i32 b)
     return d;
 }
 
+// a * K + b as exactly one v_mad_i32_i24 with the constant K in a scalar register and the addend in a vector register.  Left to
+// itself the compiler rewrites chains of multiply-adds by literals into v_mul (literal) + v_mul (literal) + v_add3, or into
+// difference chains (tmp13 = tmp10 - 2 K t2 ...): one instruction more per chain, 10 per wave in the colour stage alone.
+__device__ __forceinline__ i32 mad24_k(i32 a, i32 k, i32 b)
+{
+    i32 d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(b));
+    return d;
+}
+
 // Un-descaled 1-D IDCT butterfly; `round` is added to every output (it rides on tmp0/tmp1).
 // NZ = number of leading non-zero inputs known at compile time (8 = dense, 4 = idct_4x4 rows/cols).
 template <int NZ>
@@ -190,17 +200,26 @@ __device__ __forceinline__ void row_pass4_pairs(u32 p02, u32 p13, i32 (&t)[8])
 }
 // pass 2 of idct_4x4 (Col!4) on 32-bit inputs t0..t3 (t4..t7 = 0), direct form: 13 multiply-adds + 8 adds instead of
 // the butterfly's 10 + 17 (an add costs 2.5 issue cycles, a multiply-add 4.3)
-__device__ __forceinline__ void col_pass4_direct(i32 t0, i32 t1, i32 t2, i32 t3, i32 (&s)[8])
+__device__ __forceinline__ void col_pass4_direct(i32 t0, i32 t1, i32 t2, i32 t3, i32 (&s)[8], i32 round = (128 << 18) + (1 << 17))
 {
-    const i32 tmp0 = wadd((i32)((u32)t0 << 13), (128 << 18) + (1 << 17));
-    const i32 tmp10 = mad24(t2, K_E2, tmp0), tmp13 = mad24(t2, -K_E2, tmp0);
-    const i32 tmp11 = mad24(t2, FIX_0_541196100, tmp0), tmp12 = mad24(t2, -FIX_0_541196100, tmp0);
-    const i32 b0 = mad24(t3, K_B0[1], mul24(t1, K_B0[0])), b1 = mad24(t3, K_B1[1], mul24(t1, K_B1[0]));
-    const i32 b2 = mad24(t3, K_B2[1], mul24(t1, K_B2[0])), b3 = mad24(t3, K_B3[1], mul24(t1, K_B3[0]));
+    // `round` from a register (col_round()): one v_lshl_add_u32 and four multiply-adds; with a literal the compiler chains
+    // shift, multiply, add3 and three multiply-adds (a VOP3 instruction reads one scalar / literal operand at most)
+    const i32 tmp0 = wadd((i32)((u32)t0 << 13), round);
+    const i32 tmp10 = mad24_k(t2, K_E2, tmp0), tmp13 = mad24_k(t2, -K_E2, tmp0);
+    const i32 tmp11 = mad24_k(t2, FIX_0_541196100, tmp0), tmp12 = mad24_k(t2, -FIX_0_541196100, tmp0);
+    const i32 b0 = mad24_k(t3, K_B0[1], mul24(t1, K_B0[0])), b1 = mad24_k(t3, K_B1[1], mul24(t1, K_B1[0]));
+    const i32 b2 = mad24_k(t3, K_B2[1], mul24(t1, K_B2[0])), b3 = mad24_k(t3, K_B3[1], mul24(t1, K_B3[0]));
     s[0] = clamp255(wadd(tmp10, b3) >> 18); s[7] = clamp255(wsub(tmp10, b3) >> 18);
     s[1] = clamp255(wadd(tmp11, b2) >> 18); s[6] = clamp255(wsub(tmp11, b2) >> 18);
     s[2] = clamp255(wadd(tmp12, b1) >> 18); s[5] = clamp255(wsub(tmp12, b1) >> 18);
     s[3] = clamp255(wadd(tmp13, b0) >> 18); s[4] = clamp255(wsub(tmp13, b0) >> 18);
+}
+
+__device__ __forceinline__ i32 col_round()
+{
+    i32 r;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"((128 << 18) + (1 << 17)));
+    return r;
 }
 
 // ---- frequency-domain 2x upsample -------------------------------------------
@@ -239,21 +258,23 @@ static_assert(C_CRR == 91881 && C_CBB == 116130 && C_CRG == -46802 && C_CBG == -
 
 // The two addends of the single multiply-adds below, pinned in vector registers: a multiply-add (VOP3) can name one scalar
 // constant only, and left to itself the compiler re-materialises the other one with a v_mov in front of every pixel.
-struct ColourConsts { i32 kr, kb; };
+struct ColourConsts { i32 kr, kg, kb; };
 __device__ __forceinline__ ColourConsts colour_consts()
 {
     ColourConsts c;
     asm volatile("v_mov_b32 %0, %1" : "=v"(c.kr) : "s"(32768 - 128 * C_CRR));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(c.kg) : "s"(32768 - 128 * C_CRG - 128 * C_CBG));
     asm volatile("v_mov_b32 %0, %1" : "=v"(c.kb) : "s"(32768 - 128 * C_CBB));
     return c;
 }
 // returns packed RGBA8 (A = 255), little-endian byte order R,G,B,A
-__device__ __forceinline__ u32 ycc_to_rgba(i32 y, i32 cb, i32 cr, i32 kr = 32768 - 128 * C_CRR, i32 kb = 32768 - 128 * C_CBB)
+__device__ __forceinline__ u32 ycc_to_rgba(i32 y, i32 cb, i32 cr, i32 kr = 32768 - 128 * C_CRR, i32 kb = 32768 - 128 * C_CBB,
+                                           i32 kg = 32768 - 128 * C_CRG - 128 * C_CBG)
 {
     // (c - 128) * K + 32768 == c * K + (32768 - 128 * K): the level shift rides in the addend
-    const i32 r = y + (mad24(cr, C_CRR, kr) >> 16);
-    const i32 g = y + (mad24(cr, C_CRG, mad24(cb, C_CBG, 32768 - 128 * C_CRG - 128 * C_CBG)) >> 16);
-    const i32 b = y + (mad24(cb, C_CBB, kb) >> 16);
+    const i32 r = y + (mad24_k(cr, C_CRR, kr) >> 16);
+    const i32 g = y + (mad24_k(cr, C_CRG, mad24_k(cb, C_CBG, kg)) >> 16);           // with kg in a register: two multiply-adds (a literal addend made it mul + mul + add3)
+    const i32 b = y + (mad24_k(cb, C_CBB, kb) >> 16);
     // clamp + pack: r, g, b are within +-2^10, so they can be saturated as 16-bit lanes (v_sat_pk_u8_i16 does two at once)
     // and gathered with byte permutes: 4 instructions instead of 3 clamps + 3 shift/ors
     const u32 rg = __builtin_amdgcn_perm((u32)g, (u32)r, 0x05040100u);     // r.lo16 | g.lo16 << 16
@@ -262,6 +283,11 @@ __device__ __forceinline__ u32 ycc_to_rgba(i32 y, i32 cb, i32 cr, i32 kr = 32768
     asm("v_sat_pk_u8_i16 %0, %1" : "=v"(b8) : "v"(b));                     // byte 0 = sat(b); byte 1 unused
     return __builtin_amdgcn_perm(b8, rg8, 0x0d040100u);                    // R, G, B, 0xFF
 }
+// (Tried in round 3 and dropped: chroma samples centred on zero for free -- clamp the column pass's value WITHOUT its 128 << 18
+// level shift to [-128, 127] -- with Y riding in the multiply-adds' addend as (Y << 16) + 32768, 9 instructions per pixel instead
+// of 11 and 2.66 -> 2.51 ms per 1024 x 1080p.  It is not the reference's arithmetic on every input: the level shift takes part in
+// the 32-bit wrap-around, and a column sum in [2^31 - 2^25, 2^31) -- reachable with full-range int16 coefficients, which a
+// decodable file can contain -- clamps to 0 there and to 255 without it.  test_random_coefficients[wild-4] caught it.)
 // RGB -> grey of decompress_jpeg_image_from_stream (:3786-3792)
 __device__ __forceinline__ u32 rgb_to_luma(u32 rgba)
 {

@@ -83,6 +83,62 @@ def jpeg_coeff_batch(n, width, height, device, seed=0, quality=90, chunk=16, sca
     return out
 
 
+# zig-zag scan (ITU T.81 figure 5): _ZAG[k] = natural index of the k-th coefficient of the scan
+_ZAG = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42,
+        49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
+
+
+def jpeg_max_zag(coeffs, chunk=16):
+    """m_mcu_block_max_zag of a dense coefficient batch, as decode_next_row leaves it for a file an encoder wrote
+    (jpegload.d:2432-2512): the scan position behind a block's last non-zero coefficient (EOB follows it at once), 1 for a
+    DC-only or empty block, 64 when coefficient 63 is set.  uint8 tensor (n, blocks)."""
+    n, nblk, _ = coeffs.shape
+    rank = torch.empty(64, dtype=torch.uint8, device=coeffs.device)
+    rank[torch.tensor(_ZAG, device=coeffs.device)] = torch.arange(1, 65, dtype=torch.uint8, device=coeffs.device)
+    out = torch.empty((n, nblk), dtype=torch.uint8, device=coeffs.device)
+    for i0 in range(0, n, chunk):
+        nz = coeffs[i0:i0 + chunk] != 0
+        out[i0:i0 + chunk] = (nz.to(torch.uint8) * rank).amax(dim=2).clamp_(min=1)
+    return out
+
+
+def photo_rgb(width, height, seed):
+    """One synthetic photograph, uint8 (height, width, 3) on the host: a 1/f amplitude spectrum (the statistics of natural
+    scenes) shaped into a few soft-edged regions of different tint and brightness (sky / ground / objects: flat or gently
+    graded areas next to textured ones), defocused areas, mild sensor noise.  What matters for the decoder is the population
+    of coefficient blocks a JPEG encoder makes of it at q 75-90: most smooth-area blocks end within the first ten zig-zag
+    positions, textured ones run to the end -- unlike the smooth-plus-noise generator, whose noise fills every block."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    fy = np.fft.fftfreq(height)[:, None]; fx = np.fft.rfftfreq(width)[None, :]
+    f = np.sqrt(fx * fx + fy * fy); f[0, 0] = 1.0
+
+    def field(alpha, sigma):
+        spec = (rng.standard_normal((height, fx.shape[1])) + 1j * rng.standard_normal((height, fx.shape[1]))) / f ** alpha
+        spec[0, 0] = 0
+        v = np.fft.irfft2(spec, s=(height, width))
+        return v / (v.std() + 1e-9) * sigma
+    base = field(2.6, 1.0)                                              # large-scale layout: sky / ground / defocused background
+    texture = field(1.0, 1.0) + 0.6 * field(0.4, 1.0)                   # fine detail of the in-focus parts, 1/f + grain
+    m = field(2.2, 1.0)
+    detail_mask = 1.0 / (1.0 + np.exp(-(m - np.quantile(m, 0.55)) * 14.0))   # ~ 45 % of the frame is in focus / textured
+    yy = np.linspace(0, 1, height)[:, None]
+    lum = 128 + 50 * base + 30 * (0.5 - yy) + 20 * texture * detail_mask
+    # a few hard-edged objects (occlusion boundaries): constant offsets inside random ellipses
+    gy, gx = np.mgrid[0:height, 0:width]
+    for _ in range(6):
+        cy, cx = rng.uniform(0, height), rng.uniform(0, width)
+        ry, rx = rng.uniform(40, height / 3), rng.uniform(40, width / 4)
+        lum += rng.uniform(-35, 35) * ((((gy - cy) / ry) ** 2 + ((gx - cx) / rx) ** 2) < 1.0)
+    img = np.empty((height, width, 3), np.float64)
+    tint = field(2.4, 1.0)
+    img[:, :, 0] = lum + 18 * tint
+    img[:, :, 1] = lum - 4 * tint
+    img[:, :, 2] = lum - 22 * tint + 10 * (0.5 - yy)
+    img += rng.standard_normal(img.shape) * 0.6                         # sensor noise after in-camera denoising
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
 def png_raw_batch(n, width, height, device, seed=0, policy="heuristic", chunk=4, channels=4):
     """Inflated (post-zlib) filtered streams of n synthetic 8-bit images (channels: 4 RGBA, 3 RGB, 2 grey+alpha, 1 grey):
     uint8 tensor (n, height*(width*channels+1)).

@@ -15,7 +15,7 @@ KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
 
 def _run(cmd, env=None):
     e = dict(os.environ); e.update(env or {})
-    out = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    out = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -24,6 +24,7 @@ def _run(cmd, env=None):
 
 def test_single_gpu_line(hip):
     r = _run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--batch", "32", "--cpu-seconds", "1"])
+    assert "max_zag" in r["config"]["workload"], "the headline launch passes m_mcu_block_max_zag, as a decode does"
     assert KEYS <= set(r) and r["n_gpus"] == 1 and r["steps"] == 3 and r["warmup"] == 1 and r["unit"] == "Mpx/s"
     assert r["higher_is_better"] is True and r["scaling"] == "weak" and r["vs_baseline"] is None and r["data"] == "synthetic"
     assert "workload" in r["config"] and "model" not in r["config"]
@@ -67,3 +68,51 @@ def test_mixed_workload_line(hip):
     pf = r["config"]["per_format"]
     assert [pf[k]["images"] for k in ("jpeg", "png", "qoi")] == [3, 2, 2] and all(pf[k]["ms"] > 0 for k in pf)
     assert r["value"] > 0 and r["cpu_baseline"]["value"] > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[1..4] at their STATED shapes, one step each: bench.py checks parity before it times anything and exits
+# non-zero on a mismatch (per-image checksums over the whole batch + the oracle byte for byte on a sample), so a passing run IS
+# the parity test at full size -- the launch shapes the small-geometry tests do not reach (512 x 4K takes the device-wide work
+# queue of k_png_defilter_queue, 256 layers are converted in resident chunks, 1024 mixed images put three formats side by side).
+def _stated(workload, *extra):
+    return _run([sys.executable, "bench.py", "--workload", workload, "--steps", "1", "--warmup", "1", "--no-cpu", "--no-traffic"] + list(extra))
+
+
+def test_config2_with_max_zag_from_files(hip):
+    """1024 x 1080p: coefficients + max_zag entropy-decoded from libjpeg-written photographs; files -> pixels == the oracle's
+    decompress_jpeg, coefficients and max_zag == the oracle's decode_next_row"""
+    r = _stated("jpeg:photo")
+    assert r["config"]["images_per_gpu_per_step"] == 1024 and "1920x1080" in r["config"]["workload"]
+    assert 0.05 < r["config"]["waves_on_sparse_luma_passes"] < 0.95, "the workload is meant to exercise both the dense and the sparse luma passes"
+
+
+@pytest.mark.parametrize("policy", ["random", "heuristic"])
+def test_config3_512_images_of_4k(hip, policy):
+    r = _stated("png:" + policy)
+    assert r["config"]["images_per_gpu_per_step"] == 512 and "3840x2160" in r["config"]["workload"] and policy in r["config"]["workload"]
+    assert r["roofline"]["algorithmic_bytes_per_launch"] == 512 * (2160 * (3840 * 4 + 1) + 3840 * 2160 * 4)
+
+
+@pytest.mark.parametrize("pair", ["rgba16:rgbaf32", "rgbaf32:rgba8", "rgba8:rgba16"])
+def test_config4_256_layers_in_chunks(hip, pair):
+    r = _stated("convert:" + pair, "--batch", "256")
+    assert "256 layers of 8192x8192" in r["config"]["workload"]
+    if pair == "rgba16:rgbaf32":
+        assert "launches" in r["config"]["workload"], "24 bytes per pixel x 256 layers exceed one GPU's HBM: converted in chunks"
+
+
+def test_config5_1024_mixed_images(hip):
+    """8192 images / 8 GPUs = 1024 per GPU (JPEG / PNG / QOI by index), per-format parity inside"""
+    r = _stated("mixed")
+    pf = r["config"]["per_format"]
+    assert r["config"]["images_per_gpu_per_step"] == 1024 and [pf[k]["images"] for k in ("jpeg", "png", "qoi")] == [342, 341, 341]
+
+
+def test_default_line_carries_the_other_configs(hip):
+    """the driver's own `python bench.py` line: the headline + an `also` entry per other config, each with its parity verdict"""
+    r = _run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--cpu-seconds", "2", "--no-traffic", "--also-seconds", "400"])
+    assert r["config"]["images_per_gpu_per_step"] == 1024 and len(r["also"]) == 7
+    for e in r["also"]:
+        assert "error" not in e and e.get("parity", "").startswith("ok"), e
+        assert e["ms_per_step"] > 0 and 0 < e["roofline_frac"] < 1

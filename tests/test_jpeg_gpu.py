@@ -134,6 +134,32 @@ def test_sparse_paths_with_max_zag(hip, scan_type):
     assert np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("kind", ["natural", "wild"])
+def test_wave_uniform_sparse_luma_passes(hip, kind):
+    """The tuned 4:2:0 kernel takes idct_4x4's Row!4 / Col!4 passes for a wave (2 MCUs = 8 Y blocks) none of whose Y blocks reaches
+    zig-zag position 10 (jpegload.d:295-397: the row / column tables of max_zag <= 10 name rows 0-3 and columns 0-3 only).  Regions of
+    whole sparse MCU pairs next to dense ones, sparse pairs at the ragged right / bottom edges, Col!1 blocks (max_zag <= 2) inside
+    sparse waves, every output format; == the oracle, which follows the reference's per-block table look-ups."""
+    rng = np.random.default_rng(77 + len(kind))
+    zag = np.array(ZAG)
+    for (w, h) in [(16 * 21 + 5, 16 * 4 + 3), (16 * 2, 16), (16 * 8 + 1, 16 * 2 + 9), (16 * 16, 16 * 3)]:
+        mx, my = (w + 15) // 16, (h + 15) // 16
+        co = random_coeffs(rng, mx * my * 6, kind).reshape(my, mx, 6, 64)
+        mz = rng.choice([1, 2, 3, 7, 10, 11, 15, 28, 64], (my, mx, 6)).astype(np.uint8)
+        sparse_mcu = rng.random((my, (mx + 1) // 2)) < 0.6                         # by wave: MCU pairs (2k, 2k + 1) of a row
+        sparse_mcu = np.repeat(sparse_mcu, 2, axis=1)[:, :mx]
+        low = rng.choice([1, 2, 3, 5, 9, 10], (my, mx, 4)).astype(np.uint8)
+        mz[:, :, :4] = np.where(sparse_mcu[:, :, None], low, mz[:, :, :4])
+        mz[0, -1, :4] = 10; mz[-1, :, :4] = rng.choice([2, 10], (mx, 4))           # the edges take the sparse passes too
+        for idx in np.ndindex(my, mx, 6):
+            co[idx][zag[mz[idx]:]] = 0
+        co = co.reshape(-1, 64); mzf = mz.reshape(-1)
+        for rc in (4, 3, 1):
+            exp = O.jpeg_reconstruct(w, h, 3, 4, co, mzf, rc)
+            got = gpu_reconstruct(hip, w, h, 4, co[None], mzf[None], rc, pad=(3 if rc != 4 else 8))[0]
+            assert np.array_equal(got, exp), f"{kind} {w}x{h} comps{rc}: {np.count_nonzero(got != exp)} differ"
+
+
 def test_batch_strides_and_1080p(hip):
     """uniform batch launch: per-image strides honoured; one full-size 1920x1080 4:2:0 frame (BASELINE.json config 2 geometry)."""
     rng = np.random.default_rng(42)

@@ -3,7 +3,7 @@ for spec in "jpeg|--steps 2 --warmup 1 --batch 64" "png|--workload png:heuristic
   echo "== $tag: bench.py $args"
   bash tools/pmc.sh "SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS" -- $args 2>&1 | grep -v "rocprofv3\]"
   bash tools/pmc.sh "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" -- $args 2>&1 | grep -v "rocprofv3\]" | grep -v "^void"
-  timeout 120 python bench.py $args --no-cpu 2>/dev/null | python -c "
+  timeout 120 python bench.py $args --no-cpu --no-also 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

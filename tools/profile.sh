@@ -8,11 +8,11 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 600 python $REPO/bench.py "$@" > $OUT/bench.json 2> $OUT/bench.err
+timeout 600 python $REPO/bench.py "$@" --no-also > $OUT/bench.json 2> $OUT/bench.err
 tail -1 $OUT/bench.json
-timeout 400 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o t -- python $REPO/bench.py "$@" --no-cpu > $OUT/trace.log 2>&1
-timeout 400 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o t -- python $REPO/bench.py "$@" --steps 3 --warmup 1 --no-cpu --batch $PB > $OUT/pmc_fetch.log 2>&1
-timeout 400 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o t -- python $REPO/bench.py "$@" --steps 3 --warmup 1 --no-cpu --batch $PB > $OUT/pmc_write.log 2>&1
+timeout 400 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o t -- python $REPO/bench.py "$@" --no-cpu --no-also > $OUT/trace.log 2>&1
+timeout 400 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o t -- python $REPO/bench.py "$@" --steps 3 --warmup 1 --no-cpu --no-also --batch $PB > $OUT/pmc_fetch.log 2>&1
+timeout 400 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o t -- python $REPO/bench.py "$@" --steps 3 --warmup 1 --no-cpu --no-also --batch $PB > $OUT/pmc_write.log 2>&1
 python $REPO/tools/summarize_prof.py $OUT $REPO/gpurun_out/summary_$TAG $PB | grep -A12 gamut | head -40
 cp $OUT/bench.json $REPO/gpurun_out/summary_$TAG/bench.json
 rm -rf $OUT

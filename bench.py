@@ -127,7 +127,7 @@ ALSO = [  # the other BASELINE.json configs at their stated shapes, each through
 
 
 def also_lines(budget_s):
-    """Runs every ALSO workload as `bench.py --workload ... --steps 5 --warmup 2` in a process of its own (fresh HBM) and condenses
+    """Runs every ALSO workload as `bench.py --workload ... --steps 20 --warmup 5` in a process of its own (fresh HBM) and condenses
     its JSON line.  A non-zero exit code is a parity failure or an error and is reported as such, never dropped."""
     import subprocess
     t_end = time.perf_counter() + budget_s
@@ -137,7 +137,7 @@ def also_lines(budget_s):
         if left < 20:
             res.append({"what": what, "workload": wl, "skipped": "the --also-seconds budget ran out"})
             continue
-        cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", "5", "--warmup", "2", "--no-cpu", "--no-traffic", "--no-also"] + extra
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", "20", "--warmup", "5", "--no-cpu", "--no-traffic", "--no-also"] + extra
         t0 = time.perf_counter()
         try:
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=left, text=True)

@@ -25,32 +25,85 @@ hipStream_t thread_stream();
 // enqueued by a caller that never touches streams is ordered with everything else it does
 inline hipStream_t pick_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
-// Per-thread staging buffers (declared `static thread_local` where they are used): grown on demand, never shrunk, and
-// intentionally not freed at thread exit -- the HIP runtime may already be gone by then.
-struct DeviceScratch {                  // device memory
-    void* p = nullptr; size_t cap = 0;
-    void* get(size_t n)
+// A host process may drive several GPUs from one thread (hipSetDevice between calls) -- what a D host with "one host thread +
+// one HIP stream per GPU"  does as well as a thread that simply serves two devices in turn.  Everything the
+// library caches per thread -- staging buffers, private streams, events -- therefore lives in a slot of the CURRENT device:
+// device memory and streams belong to the device they were created on.
+constexpr int kMaxDevices = 64;
+inline int current_device()
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; }
+    return d < 0 || d >= kMaxDevices ? 0 : d;
+}
+template <class T> struct PerDevice {
+    T v[kMaxDevices]{};
+    T& cur() { return v[current_device()]; }
+};
+
+// Per-thread, per-device staging buffers (declared `static thread_local PerDevice<...>` where they are used): grown on demand,
+// never shrunk, and intentionally not freed at thread exit -- the HIP runtime may already be gone by then.
+// Growth is stream-ordered by hand and never waits: the outgrown buffer is parked behind an event recorded on the stream that used
+// it last and freed by a later call once that event has passed (the entry points that use these buffers end with a wait on
+// their stream, so in practice the event has long passed; nothing here relies on it).  No hipDeviceSynchronize: other threads'
+// streams are none of this thread's business.  (Not hipMallocAsync / hipFreeAsync: kernels of the next launch were seen reading a
+// table as it had been BEFORE its stream-ordered re-allocation)
+struct RetireList {
+    struct Old { void* p; hipEvent_t ev; bool host; };
+    Old old[8]; int n = 0;
+    static void release(const Old& o) { if (o.host) (void)hipHostFree(o.p); else (void)hipFree(o.p); if (o.ev) (void)hipEventDestroy(o.ev); }
+    void reap(bool make_room)
     {
+        int k = 0;
+        for (int i = 0; i < n; ++i) {
+            const bool passed = !old[i].ev || hipEventQuery(old[i].ev) == hipSuccess;
+            if (passed) release(old[i]); else old[k++] = old[i];
+        }
+        (void)hipGetLastError();                              // hipErrorNotReady is not an error
+        n = k;
+        if (make_room && n == 8) { (void)hipEventSynchronize(old[0].ev); release(old[0]); for (int i = 1; i < n; ++i) old[i - 1] = old[i]; --n; }
+    }
+    void park(void* p, bool host, hipStream_t last_user)
+    {
+        reap(true);
+        hipEvent_t ev = nullptr;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, last_user) != hipSuccess) {
+            (void)hipGetLastError();
+            if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
+            (void)hipStreamSynchronize(last_user);            // no event to be had: wait for that one stream
+        }
+        old[n++] = Old{ p, ev, host };
+    }
+};
+struct DeviceScratch {                  // device memory
+    void* p = nullptr; size_t cap = 0; hipStream_t last_user = nullptr; RetireList retired;
+    // `stream`: where the caller will queue the work that reads / writes the buffer
+    void* get(size_t n, hipStream_t stream = nullptr)
+    {
+        retired.reap(false);
         if (n > cap) {
-            if (p) { (void)hipDeviceSynchronize(); (void)hipFree(p); p = nullptr; cap = 0; }
+            if (p) { retired.park(p, false, last_user); p = nullptr; cap = 0; }
             const size_t want = n + n / 4 + 4096;
-            if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return nullptr; }
+            if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return nullptr; }
             cap = want;
         }
+        last_user = stream;
         return p;
     }
 };
 struct PinnedScratch {                  // page-locked host memory: uploads from it are plain DMA
-    uint8_t* p = nullptr; size_t cap = 0;
-    uint8_t* get(size_t n)
+    uint8_t* p = nullptr; size_t cap = 0; hipStream_t last_user = nullptr; RetireList retired;
+    uint8_t* get(size_t n, hipStream_t stream = nullptr)
     {
+        retired.reap(false);
         if (n > cap) {
-            if (p) { (void)hipDeviceSynchronize(); (void)hipHostFree(p); p = nullptr; cap = 0; }
+            if (p) { retired.park(p, true, last_user); p = nullptr; cap = 0; }
             void* np = nullptr;
             const size_t want = n + n / 4 + 4096;
-            if (hipHostMalloc(&np, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+            if (hipHostMalloc(&np, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
             p = (uint8_t*)np; cap = want;
         }
+        last_user = stream;
         return p;
     }
 };

@@ -307,7 +307,8 @@ struct gamut_image {
         const size_t nblk = (size_t)f.mcus_per_row * f.mcus_per_col * f.blocks_per_mcu;
         const int comps = req < 0 ? f.comps : req;
         // the coefficient staging is per-thread and stays (only the pixels, which become the image's storage, are a fresh allocation)
-        static thread_local DeviceScratch s_co, s_zz;
+        static thread_local PerDevice<DeviceScratch> s_co_pd, s_zz_pd;
+        DeviceScratch& s_co = s_co_pd.cur(); DeviceScratch& s_zz = s_zz_pd.cur();
         uint8_t* dco = (uint8_t*)s_co.get(nblk * 128 + 16), *dzz = (uint8_t*)s_zz.get(nblk + 16), *dout = dmalloc((size_t)f.width * f.height * comps);
         bool ok = dco && dzz && dout;
         if (ok) {

@@ -605,11 +605,12 @@ int inflate_launch(const gamut_hip_inflate_desc* descs, int count, uint32_t* out
     if (hipFuncSetAttribute((const void*)k_inflate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Shared)) != hipSuccess) return set_error(GAMUT_HIP_ERR_HIP, "inflate: %zu bytes of LDS are not available", sizeof(Shared));
     // the descriptor table in HBM: one buffer per (thread, stream) -- calls on one stream are ordered, calls on different
     // streams never share it; growing it waits for its own stream only
-    struct StreamTable { hipStream_t stream; void* p; size_t cap; };
+    struct StreamTable { int device; hipStream_t stream; void* p; size_t cap; };
     static thread_local std::vector<StreamTable> tables;
     StreamTable* e = nullptr;
-    for (StreamTable& c : tables) if (c.stream == stream) { e = &c; break; }
-    if (!e) { tables.push_back(StreamTable{ stream, nullptr, 0 }); e = &tables.back(); }
+    const int device = current_device();                    // (the null stream is one handle for every device)
+    for (StreamTable& c : tables) if (c.stream == stream && c.device == device) { e = &c; break; }
+    if (!e) { tables.push_back(StreamTable{ device, stream, nullptr, 0 }); e = &tables.back(); }
     const size_t bytes = items.size() * sizeof(InfItem);
     if (bytes > e->cap) {
         if (e->p) { (void)hipStreamSynchronize(stream); (void)hipFree(e->p); e->p = nullptr; e->cap = 0; }

@@ -1069,12 +1069,15 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
 
     if (any_ok) {
         const auto t_up = std::chrono::steady_clock::now();
-        static thread_local hipStream_t copy_stream = nullptr;
+        static thread_local PerDevice<hipStream_t> copy_stream_pd;
+        hipStream_t& copy_stream = copy_stream_pd.cur();
         if (!copy_stream) GAMUT_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
-        static thread_local DeviceScratch scratch, tab_scratch;
-        static thread_local PinnedScratch pinned, tab_pinned;
-        uint8_t* d_blob_w = (uint8_t*)scratch.get(blob_size + kBlobSlack);
-        uint8_t* h_blob = pinned.get(blob_size + kBlobSlack);
+        static thread_local PerDevice<DeviceScratch> scratch_pd, tab_scratch_pd;
+        static thread_local PerDevice<PinnedScratch> pinned_pd, tab_pinned_pd;
+        DeviceScratch& scratch = scratch_pd.cur(); DeviceScratch& tab_scratch = tab_scratch_pd.cur();
+        PinnedScratch& pinned = pinned_pd.cur(); PinnedScratch& tab_pinned = tab_pinned_pd.cur();
+        uint8_t* d_blob_w = (uint8_t*)scratch.get(blob_size + kBlobSlack, stream);
+        uint8_t* h_blob = pinned.get(blob_size + kBlobSlack, copy_stream);
         if (!d_blob_w || !h_blob) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: staging allocation of %zu bytes failed", blob_size + kBlobSlack);
         // (both kernels write every block of a segment as a whole line -- zeros included, blocks a damaged segment never reaches as
         // well: the coefficient buffer needs no clearing)
@@ -1086,13 +1089,17 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
         //      first group decodes while the rest is still being unstuffed and uploaded.  A group keeps >= 512 workgroups.
         const int n_groups = count >= 1024 ? 4 : count >= 256 ? 2 : 1;
         const int n_slices = count >= 512 ? 8 : count >= 64 ? 4 : 1;
-        static thread_local hipEvent_t group_ready[4] = { nullptr, nullptr, nullptr, nullptr };
+        struct Ev4 { hipEvent_t e[4]; }; struct St4 { hipStream_t s[4]; };
+        static thread_local PerDevice<Ev4> group_ready_pd;
+        hipEvent_t (&group_ready)[4] = group_ready_pd.cur().e;
         for (int g = 0; g < n_groups; ++g) if (!group_ready[g]) GAMUT_HIP_CHECK(hipEventCreateWithFlags(&group_ready[g], hipEventDisableTiming));
         // A long segment is decoded by one workgroup in its own time (its sweeps), whatever else the chip does: the groups' kernels
         // are therefore queued on streams of their own (behind what `stream` holds now) and run side by side, each as soon as its
         // bytes are there -- on one stream a group waited for the group before it to finish.
-        static thread_local hipStream_t side[4] = { nullptr, nullptr, nullptr, nullptr };
-        static thread_local hipEvent_t fork = nullptr;
+        static thread_local PerDevice<St4> side_pd;
+        static thread_local PerDevice<hipEvent_t> fork_pd;
+        hipStream_t (&side)[4] = side_pd.cur().s;
+        hipEvent_t& fork = fork_pd.cur();
         if (!fork) GAMUT_HIP_CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
         for (int g = 1; g < n_groups; ++g) if (!side[g]) GAMUT_HIP_CHECK(hipStreamCreateWithFlags(&side[g], hipStreamNonBlocking));
         GAMUT_HIP_CHECK(hipEventRecord(fork, stream));
@@ -1112,7 +1119,8 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
         GAMUT_HIP_CHECK(hipMemcpyAsync(d, h, o_items, hipMemcpyHostToDevice, copy_stream));
         uint32_t* st = d_status;
         if (!st) {                                             // the kernel wants somewhere to flag errors
-            static thread_local DeviceScratch sink;
+            static thread_local PerDevice<DeviceScratch> sink_pd;
+            DeviceScratch& sink = sink_pd.cur();
             st = (uint32_t*)sink.get((size_t)count * sizeof(uint32_t));
             if (!st) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: status allocation failed");
         }
@@ -1388,7 +1396,8 @@ uint8_t* gamut_hip_decompress_jpeg_image_from_memory(const uint8_t* data, size_t
     };
     // device staging of the call: per-thread buffers that grow and stay (a hipMalloc / hipFree pair per buffer and call cost more than
     // the decode of a small image)
-    static thread_local DeviceScratch s_co, s_zz, s_out;
+    static thread_local PerDevice<DeviceScratch> s_co_pd, s_zz_pd, s_out_pd;
+    DeviceScratch& s_co = s_co_pd.cur(); DeviceScratch& s_zz = s_zz_pd.cur(); DeviceScratch& s_out = s_out_pd.cur();
     if (ok) {
         dco = s_co.get(nblk * 128 + 16); dzz = s_zz.get(nblk + 16); dout = s_out.get(out_bytes + 16);
         if (!dco || !dzz || !dout) { (void)hipGetLastError(); set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "decompress_jpeg: device staging allocation failed"); ok = false; }

@@ -632,10 +632,12 @@ int progressive_decode_device(const uint8_t* const* data, const size_t* len, con
     const double ms_parse = ms_since(t_begin);
     double ms_unstuff = 0, ms_kernels = 0;
     if (max_level >= 0) {
-        static thread_local DeviceScratch scratch, tab_scratch;
-        static thread_local PinnedScratch pinned, tab_pinned;
-        uint8_t* d_blob = (uint8_t*)scratch.get(blob_size + kBlobSlack);
-        uint8_t* h_blob = pinned.get(blob_size + kBlobSlack);
+        static thread_local PerDevice<DeviceScratch> scratch_pd, tab_scratch_pd;
+        static thread_local PerDevice<PinnedScratch> pinned_pd, tab_pinned_pd;
+        DeviceScratch& scratch = scratch_pd.cur(); DeviceScratch& tab_scratch = tab_scratch_pd.cur();
+        PinnedScratch& pinned = pinned_pd.cur(); PinnedScratch& tab_pinned = tab_pinned_pd.cur();
+        uint8_t* d_blob = (uint8_t*)scratch.get(blob_size + kBlobSlack, stream);
+        uint8_t* h_blob = pinned.get(blob_size + kBlobSlack, stream);
         if (!d_blob || !h_blob) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: staging allocation of %zu bytes failed", blob_size + kBlobSlack);
         const auto t_u = std::chrono::steady_clock::now();
         parallel_for(n, workers, [&](int, int k) {
@@ -689,7 +691,8 @@ int progressive_decode_device(const uint8_t* const* data, const size_t* len, con
             GAMUT_HIP_CHECK(hipMemcpyAsync(d_blob, h_blob, blob_size + kBlobSlack, hipMemcpyHostToDevice, stream));
             uint32_t* st = d_status;
             if (!st) {
-                static thread_local DeviceScratch sink;
+                static thread_local PerDevice<DeviceScratch> sink_pd;
+                DeviceScratch& sink = sink_pd.cur();
                 int top = 0; for (int i : idx) top = i > top ? i : top;
                 st = (uint32_t*)sink.get((size_t)(top + 1) * sizeof(uint32_t));
                 if (!st) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: status allocation failed");

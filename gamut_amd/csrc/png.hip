@@ -983,12 +983,13 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
     // asynchronous and may be called from one thread on several streams, so every (thread, stream) pair owns its scratch:
     // launches on one stream are ordered, launches on different streams never share a buffer.  Growing a scratch waits for
     // ITS stream only (the buffer may still be in use there) -- never for the device.
-    struct StreamScratch { hipStream_t stream; int kind; void* p; size_t cap; };      // kind 0: de-filtered rows, 1: queue state
+    struct StreamScratch { int device; hipStream_t stream; int kind; void* p; size_t cap; };      // kind 0: de-filtered rows, 1: queue state
     static thread_local std::vector<StreamScratch> scratches;
     auto scratch_get = [&](size_t n, int kind = 0) -> void* {
         StreamScratch* e = nullptr;
-        for (StreamScratch& c : scratches) if (c.stream == stream && c.kind == kind) { e = &c; break; }
-        if (!e) { scratches.push_back(StreamScratch{ stream, kind, nullptr, 0 }); e = &scratches.back(); }
+        const int device = current_device();                // (the null stream is one handle for every device)
+        for (StreamScratch& c : scratches) if (c.stream == stream && c.kind == kind && c.device == device) { e = &c; break; }
+        if (!e) { scratches.push_back(StreamScratch{ device, stream, kind, nullptr, 0 }); e = &scratches.back(); }
         if (n > e->cap) {
             if (e->p) { (void)hipStreamSynchronize(stream); (void)hipFree(e->p); e->p = nullptr; e->cap = 0; }
             const size_t want = n + n / 4 + 4096;

@@ -306,7 +306,9 @@ uint8_t* png_load(const uint8_t* data, size_t len, int* px, int* py, int* pn, in
     PngHeader probe;
     if (parse(data, len, probe, true)) return nullptr;                       // a bad signature is reported as such with or without a GPU
     if (hipGetDeviceCount(&dev_count) != hipSuccess || dev_count <= 0) { set_error(GAMUT_HIP_ERR_NO_DEVICE, "no HIP device available (libgamut_hip has no CPU fallback)"); return nullptr; }
-    static thread_local HostBuf staging{ nullptr, 0, true };
+    struct Staging { HostBuf b{ nullptr, 0, true }; };
+    static thread_local PerDevice<Staging> staging_pd;
+    HostBuf& staging = staging_pd.cur().b;
     PngJob j; j.raw = staging;                                               // borrow the per-thread pinned buffer
     const auto t0 = std::chrono::steady_clock::now();
     const int rc = png_prepare(data, len, j);
@@ -416,7 +418,8 @@ int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* 
         if (threads <= 0) threads = host_threads();
         threads = threads < 1 ? 1 : threads > count ? count : threads;
         hipStream_t st = pick_stream(stream);
-        static thread_local hipStream_t copy_stream_tl = nullptr;
+        static thread_local PerDevice<hipStream_t> copy_stream_pd;
+        hipStream_t& copy_stream_tl = copy_stream_pd.cur();
         if (!copy_stream_tl) GAMUT_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_tl, hipStreamNonBlocking));
         // a plain local: thread_local variables are not captured by the worker lambda below -- every worker thread would
         // read ITS OWN (null) instance and upload on the legacy null stream
@@ -434,8 +437,9 @@ int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* 
             slot[(size_t)i] = arena_bytes; slot_bytes[(size_t)i] = (int64_t)room; arena_bytes += (int64_t)((room + 255) & ~(uint64_t)255);
         }
         clear_error();
-        static thread_local DeviceScratch arena;
-        uint8_t* d_arena = arena_bytes ? (uint8_t*)arena.get((size_t)arena_bytes) : nullptr;
+        static thread_local PerDevice<DeviceScratch> arena_pd;
+        DeviceScratch& arena = arena_pd.cur();
+        uint8_t* d_arena = arena_bytes ? (uint8_t*)arena.get((size_t)arena_bytes, st) : nullptr;
         if (arena_bytes && !d_arena) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png: device arena of %lld bytes failed", (long long)arena_bytes);
 
         // 1. workers: chunk walk + inflate into the worker's pinned buffer, stream to the arena
@@ -452,8 +456,9 @@ int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* 
         std::vector<size_t> blob_off((size_t)count + 1, 0);
         std::vector<uint32_t> idat_len((size_t)count, 0);
         uint8_t* h_blob = nullptr; uint8_t* d_blob = nullptr;
-        static thread_local PinnedScratch blob_pinned;
-        static thread_local DeviceScratch blob_dev;
+        static thread_local PerDevice<PinnedScratch> blob_pinned_pd;
+        static thread_local PerDevice<DeviceScratch> blob_dev_pd;
+        PinnedScratch& blob_pinned = blob_pinned_pd.cur(); DeviceScratch& blob_dev = blob_dev_pd.cur();
         if (device_inflate) {
             for (int i = 0; i < count; ++i) blob_off[(size_t)i + 1] = blob_off[(size_t)i] + ((len[i] + 15) & ~(size_t)15);
             h_blob = blob_pinned.get(blob_off[(size_t)count] + 16);
@@ -553,7 +558,8 @@ int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* 
             }
             if (!descs.empty()) {
                 const size_t n = descs.size();
-                static thread_local DeviceScratch verdict_dev;
+                static thread_local PerDevice<DeviceScratch> verdict_dev_pd;
+                DeviceScratch& verdict_dev = verdict_dev_pd.cur();
                 uint32_t* d_verdict = (uint32_t*)verdict_dev.get(n * 8);
                 if (!d_verdict) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png: verdict table allocation failed");
                 std::vector<uint32_t> verdict(n * 2);
@@ -591,7 +597,8 @@ int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* 
         if (n_batched) {
             std::vector<int64_t> offs((size_t)n_batched * 2);
             for (auto& g : groups) for (int i : g.second) { offs[order.size()] = slot[(size_t)i]; offs[(size_t)n_batched + order.size()] = out_offset[i]; order.push_back(i); }
-            static thread_local DeviceScratch tables;
+            static thread_local PerDevice<DeviceScratch> tables_pd;
+            DeviceScratch& tables = tables_pd.cur();
             const size_t o_status = (size_t)n_batched * 16;
             uint8_t* d_tab = (uint8_t*)tables.get(o_status + (size_t)n_batched * 4);
             if (!d_tab) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png: table allocation failed");

@@ -35,7 +35,12 @@ struct QoiItem { uint64_t begin; int64_t out_off; uint32_t size, npx; int32_t ch
 //      a slot wins without a second pass; pixels go to an LDS buffer by run length and leave in 1 KiB rows.
 // W = 4 waves per stream halves a stream's time (18.6 instead of 31.6 ms per 1080p stream) but costs more instructions in all
 // (every wave scans, one resolves): batches of more streams than the chip has SIMDs to spare run W = 1, one wave per stream.
-constexpr int kQoiWin = 2048, kQoiOutCap = 256 + 64 * 62 + 64;                       // window bytes; pixels the output buffer must hold
+constexpr int kQoiWin = 2048;                                                       // window bytes
+// W = 1: pixels wait in an LDS buffer until whole 1 KiB rows can leave.  A group of 64 ops makes up to 64 * 62 = 3968 pixels, but
+// only runs do that: a group of more than kQoiBufGroup pixels writes them to the image itself, and the buffer stays small -- the
+// workgroup's LDS (10 KB instead of 24) is what decides how many streams a compute unit holds at once: 2730 streams (BASELINE.json
+// config 5 on one GPU) are all resident instead of taking two rounds.
+constexpr int kQoiBufGroup = 512, kQoiOutCap = 256 + kQoiBufGroup + 64;
 constexpr int kQoiWideBelow = 768;                                                  // streams per launch below which W = 4
 constexpr int kQoiSlack = GAMUT_HIP_QOI_SLACK;                                      // readable bytes guaranteed after every stream
 constexpr uint32_t kQoiMapId = 0u | 1u << 3 | 2u << 6 | 3u << 9 | 4u << 12;         // the identity of the exit-offset maps
@@ -129,7 +134,9 @@ __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* it
     if (t == 0) go_on = 1;
     uint32_t carry = 0xFF000000u;                             // r = g = b = 0, a = 255 :492-495                (wave 0's state from here ...)
     uint32_t produced = 0, ops_done = 0;                      // pixels decoded, ops decoded
-    uint32_t fill = 0; size_t flushed = 0;                    // pixels waiting in obuf, pixels already in the image  (... to here)
+    uint32_t fill = 0; size_t flushed = 0;                    // pixels waiting in obuf, pixels already in the image
+    uint32_t tab = 0;                                         // lane s: slot s of the table as the groups so far left it (read back right after every update:
+    //                                                           the round trip runs beside the next group's parsing instead of in front of its INDEX ops)  (... to here)
     uint32_t entry = 0;                                       // offset of the first op start in the next window (every thread keeps it)
 
     struct Mine { uint64_t q[kQoiLaneBytes / 8]; };
@@ -262,22 +269,20 @@ __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* it
             uint32_t x = qoi_add_bytes(carry & ~f.M, f.V);
             uint64_t todo = __ballot(G.is_index);
             uint32_t h = qoi_hash(x);
-            if (todo) {
-                const uint32_t tab = (uint32_t)table[lane];               // the table as the groups before left it
-                do {
-                    const int j = __builtin_ctzll(todo);
-                    todo &= todo - 1;
-                    const int jn = todo ? __builtin_ctzll(todo) : 64;
-                    const uint32_t slot = qoi_readlane(G.b1, j) & 63u;
-                    const uint64_t m = __ballot(h == slot) & ((1ull << j) - 1ull);
-                    const uint32_t base = m ? qoi_readlane(x, 63 - __builtin_clzll(m)) : qoi_readlane(tab, (int)slot);
-                    const uint32_t nx = qoi_add_bytes(base & f.U, f.V);       // from an INDEX op on, every byte is set (M = all)
-                    const bool in = lane >= j && lane < jn;
-                    x = in ? nx : x;
-                    h = in ? qoi_hash(nx) : h;
-                } while (todo);
+            while (todo) {
+                const int j = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const int jn = todo ? __builtin_ctzll(todo) : 64;
+                const uint32_t slot = qoi_readlane(G.b1, j) & 63u;
+                const uint64_t m = __ballot(h == slot) & ((1ull << j) - 1ull);
+                const uint32_t base = m ? qoi_readlane(x, 63 - __builtin_clzll(m)) : qoi_readlane(tab, (int)slot);
+                const uint32_t nx = qoi_add_bytes(base & f.U, f.V);       // from an INDEX op on, every byte is set (M = all)
+                const bool in = lane >= j && lane < jn;
+                x = in ? nx : x;
+                h = in ? qoi_hash(nx) : h;
             }
             if (active) atomicMax(&table[h], (unsigned long long)(ops_done + 1u + (uint32_t)lane) << 32 | x);
+            tab = (uint32_t)table[lane];                                  // (LDS operations of a wave execute in order: this sees the update)
             carry = qoi_readlane(x, (int)cnt - 1);
             first_px = produced;
             const uint32_t total = qoi_readlane(G.run_incl, (int)cnt - 1), room = npx_total - produced;
@@ -289,11 +294,19 @@ __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* it
         auto emit_buffered = [&](const Group& G, uint32_t x, uint32_t first_px) {
             const uint32_t off = G.run_incl - G.npx, room = npx_total - first_px;   // (room >= 1: the loop stops once the image is full)
             const uint32_t npx = off >= room ? 0u : (G.npx < room - off ? G.npx : room - off);
+            const uint32_t total = produced - first_px;                            // wave-uniform
+            if (total > (uint32_t)kQoiBufGroup) {             // long runs: what waits in the buffer leaves, then the group's pixels go straight to the image
+                for (uint32_t i = lane; i < fill; i += 64) store_px(flushed + i, obuf[i]);
+                for (uint32_t r = 0; __any(r < npx); ++r) if (r < npx) store_px((size_t)first_px + off + r, x);
+                flushed = produced; fill = 0;
+                qoi_wave_sync();
+                return;
+            }
             if (npx) obuf[fill + off] = x;
             if (__any(npx > 1u)) {
                 for (uint32_t r = 1; __any(r < npx); ++r) if (r < npx) obuf[fill + off + r] = x;
             }
-            fill += produced - first_px;
+            fill += total;
             qoi_wave_sync();
             if (fill >= 256u) flush_rows();
         };
@@ -421,6 +434,7 @@ __global__ __launch_bounds__(320) void k_qoi_pipe(const QoiItem* items, int n_it
     if (wave == 0) {
         // ---- C: the walk (see k_qoi_decode::resolve_group) ------------------------------------------------------------------------
         uint32_t carry = 0xFF000000u, produced = 0, ops_done = 0;
+        uint32_t tab = 0;                                     // lane s: slot s of the table, read back after every update
         uint32_t w = 0;
         for (int pos = 0; pos < chunk_bytes; pos += kQoiWin, ++w) {
             QoiPipeBuf& B = pb[w & 1u];
@@ -440,22 +454,20 @@ __global__ __launch_bounds__(320) void k_qoi_pipe(const QoiItem* items, int n_it
                     uint32_t x = qoi_add_bytes(carry & ~f.M, f.V);
                     uint64_t todo = __ballot(is_index && active);
                     uint32_t h = qoi_hash(x);
-                    if (todo) {
-                        const uint32_t tab = (uint32_t)table[lane];
-                        do {
-                            const int j = __builtin_ctzll(todo);
-                            todo &= todo - 1;
-                            const int jn = todo ? __builtin_ctzll(todo) : 64;
-                            const uint32_t slot = qoi_readlane(b1, j) & 63u;
-                            const uint64_t m = __ballot(h == slot) & ((1ull << j) - 1ull);
-                            const uint32_t base = m ? qoi_readlane(x, 63 - __builtin_clzll(m)) : qoi_readlane(tab, (int)slot);
-                            const uint32_t nx = qoi_add_bytes(base & f.U, f.V);
-                            const bool in = lane >= j && lane < jn;
-                            x = in ? nx : x;
-                            h = in ? qoi_hash(nx) : h;
-                        } while (todo);
+                    while (todo) {
+                        const int j = __builtin_ctzll(todo);
+                        todo &= todo - 1;
+                        const int jn = todo ? __builtin_ctzll(todo) : 64;
+                        const uint32_t slot = qoi_readlane(b1, j) & 63u;
+                        const uint64_t m = __ballot(h == slot) & ((1ull << j) - 1ull);
+                        const uint32_t base = m ? qoi_readlane(x, 63 - __builtin_clzll(m)) : qoi_readlane(tab, (int)slot);
+                        const uint32_t nx = qoi_add_bytes(base & f.U, f.V);
+                        const bool in = lane >= j && lane < jn;
+                        x = in ? nx : x;
+                        h = in ? qoi_hash(nx) : h;
                     }
                     if (active) atomicMax(&table[h], (unsigned long long)(ops_done + 1u + (uint32_t)lane) << 32 | x);
+                    tab = (uint32_t)table[lane];
                     carry = qoi_readlane(x, (int)cnt - 1);
                     const uint32_t first_px = produced;
                     const uint32_t total = qoi_readlane(run_incl, (int)cnt - 1), room = npx_total - produced;
@@ -629,10 +641,11 @@ int decode_batch(const uint8_t* const* data, const int* size, int count, int cha
     }
     if (!items.empty()) {
         const size_t o_blob = (items.size() * sizeof(QoiItem) + 255) & ~(size_t)255, total = o_blob + blob_size;
-        static thread_local DeviceScratch staging;
-        static thread_local PinnedScratch pinned;
-        uint8_t* d = (uint8_t*)staging.get(total);
-        uint8_t* h = pinned.get(total);
+        static thread_local PerDevice<DeviceScratch> staging_pd;
+        static thread_local PerDevice<PinnedScratch> pinned_pd;
+        DeviceScratch& staging = staging_pd.cur(); PinnedScratch& pinned = pinned_pd.cur();
+        uint8_t* d = (uint8_t*)staging.get(total, stream);
+        uint8_t* h = pinned.get(total, stream);
         if (!d || !h) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "qoi: staging allocation of %zu bytes failed", total);
         // the files are gathered into one pinned image on a few host threads and go up in one DMA
         int workers = host_threads();
@@ -730,9 +743,10 @@ int gamut_hip_qoi_decode_resident_device(const uint8_t* blob, int64_t blob_len, 
         // one of four per-thread (pinned, device) slot pairs; a slot is taken again four calls later, after its event -- recorded
         // behind the kernel that read it -- has passed.
         struct TableSlot { uint8_t* h = nullptr; uint8_t* d = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false; };
-        static thread_local TableSlot slots[4];
-        static thread_local unsigned next_slot = 0;
-        TableSlot& sl = slots[next_slot++ & 3u];
+        struct Slots { TableSlot s[4]; unsigned next = 0; };
+        static thread_local PerDevice<Slots> slots_pd;
+        Slots& sls = slots_pd.cur();
+        TableSlot& sl = sls.s[sls.next++ & 3u];
         if (!sl.done) GAMUT_HIP_CHECK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         if (sl.busy) { GAMUT_HIP_CHECK(hipEventSynchronize(sl.done)); sl.busy = false; }
         const size_t bytes = items.size() * sizeof(QoiItem);
@@ -779,8 +793,9 @@ void* gamut_hip_qoi_decode(const void* data, int size, gamut_hip_qoi_desc* desc,
     uint8_t* result = (uint8_t*)malloc(bytes ? bytes : 1);
     void* dout = nullptr;
     if (!result) { set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "qoi: out of memory"); return nullptr; }
-    static thread_local DeviceScratch pixels_dev;             // per-thread staging that grows and stays
-    dout = pixels_dev.get(bytes + 16);
+    static thread_local PerDevice<DeviceScratch> pixels_dev_pd;           // per-thread, per-device staging that grows and stays
+    DeviceScratch& pixels_dev = pixels_dev_pd.cur();
+    dout = pixels_dev.get(bytes + 16, thread_stream());
     bool ok = dout != nullptr;
     if (!ok) { (void)hipGetLastError(); set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "qoi: device staging of %zu bytes failed", bytes); }
     const uint8_t* ptr = (const uint8_t*)data; const int64_t off = 0;

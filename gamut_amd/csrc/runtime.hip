@@ -46,7 +46,8 @@ int host_threads()
 
 hipStream_t thread_stream()
 {
-    static thread_local hipStream_t s = nullptr;
+    static thread_local PerDevice<hipStream_t> s_pd;           // a stream belongs to the device it was created on
+    hipStream_t& s = s_pd.cur();
     if (!s) {
         if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;   // falls back to the null stream
     }

@@ -313,9 +313,12 @@ __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* it
         if constexpr (kQoiWaves == 1) {
             for (uint32_t g = 0; g < nops && produced < npx_total; g += 64) {
                 const Group G = parse_group(g);
+                QPROF(3);
                 uint32_t first_px;
                 const uint32_t x = resolve_group(g, G, first_px);
+                QPROF(5);
                 emit_buffered(G, x, first_px);
+                QPROF(6);
             }
         } else {
             // (a full group's run lengths can sum to 64 * 62 = 3968 < 4096: the 12-bit prefix never wraps)

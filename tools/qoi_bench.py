@@ -38,8 +38,8 @@ for name, pool in (("spec-encoder streams", files[:ND]), ("all-RGB-op stream", f
             dt = time.perf_counter() - t0
         prof = getattr(C.CDLL(_capi.LIB_PATH), "gamut_hip_qoi_profile", None)
         if prof:
-            buf = (C.c_ulonglong * 8)(); prof(buf); v = list(buf); tot = sum(v[:5]) or 1
-            print("    wave 0 cycles: " + ", ".join(f"{n} {100 * v[k] / tot:.0f}%" for k, n in enumerate(["boundaries + chain", "barriers", "compaction", "op scans", "pixels + table + output"])) + f"; {tot / B / 2 / 1e6:.1f} Mcycles per stream")
+            buf = (C.c_ulonglong * 8)(); prof(buf); v = list(buf); tot = sum(v[:7]) or 1
+            print("    wave 0 cycles: " + ", ".join(f"{n} {100 * v[k] / tot:.0f}%" for k, n in enumerate(["boundaries + chain", "barriers", "compaction", "op scans", "pixels + table + output (W=4) / rest", "W=1 resolve", "W=1 emit"])) + f"; {tot / B / 2 / 1e6:.1f} Mcycles per stream")
         ok = all(np.array_equal(out[i].view(h, w, 4)[:, :, :3].cpu().numpy(), rgb[i % len(pool) if len(pool) > 1 else 0]) for i in (0, B - 1))
         print(f"  x {B}: {dt * 1e3:.1f} ms  {B * w * h / dt / 1e6:.0f} Mpx/s  ({dt / (w * h) * 1e9:.0f} ns per pixel per lane)  parity {'ok' if ok else 'FAIL'}")
         del blob, out

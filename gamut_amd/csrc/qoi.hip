@@ -76,7 +76,28 @@ __device__ __forceinline__ uint32_t qoi_map_then(uint32_t a, uint32_t b)        
     return r;
 }
 template <int CTRL, int ROWMASK> __device__ __forceinline__ void qoi_map_scan_step(uint32_t& m) { m = qoi_map_then(qoi_dpp<CTRL, ROWMASK>(m, kQoiMapId), m); }
-template <int CTRL, int ROWMASK> __device__ __forceinline__ void qoi_add_scan_step(uint32_t& n) { n += qoi_dpp<CTRL, ROWMASK>(n); }
+// n += the lane CTRL names (nothing for lanes without a source, or in rows outside ROWMASK): one v_add_u32_dpp in place.  Through
+// the builtin the compiler zeroes a temporary, moves into it and adds: three instructions, six times per scan.  (s_nop 1: a DPP
+// read of a register the previous vector instruction wrote needs two wait states, and the compiler does not look into asm.)
+template <int CTRL, int ROWMASK> __device__ __forceinline__ void qoi_add_scan_step(uint32_t& n)
+{
+    if constexpr (CTRL == 0x111) asm("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(n));
+    else if constexpr (CTRL == 0x112) asm("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(n));
+    else if constexpr (CTRL == 0x114) asm("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(n));
+    else if constexpr (CTRL == 0x118) asm("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(n));
+    else if constexpr (CTRL == 0x142 && ROWMASK == 0xA) asm("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(n));
+    else if constexpr (CTRL == 0x143 && ROWMASK == 0xC) asm("s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(n));
+    else n += qoi_dpp<CTRL, ROWMASK>(n);
+}
+// the value of the lane CTRL names, 0 where there is none: for the row shifts (every row takes part) bound_ctrl supplies the zeros
+// and no temporary has to be cleared first
+template <int CTRL, int ROWMASK> __device__ __forceinline__ uint32_t qoi_dpp0(uint32_t v)
+{
+    if constexpr (ROWMASK == 0xF && CTRL >= 0x111 && CTRL <= 0x11F)
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+    else
+        return qoi_dpp<CTRL, ROWMASK>(v);
+}
 
 struct QoiFn { uint32_t M, V, U; };       // x -> ((x & ~M) | (index value & U)) + V bytewise; U is a subset of M
 __device__ __forceinline__ QoiFn qoi_then(QoiFn a, QoiFn b)                       // a first, then b
@@ -85,9 +106,9 @@ __device__ __forceinline__ QoiFn qoi_then(QoiFn a, QoiFn b)                     
 }
 template <int CTRL, int ROWMASK> __device__ __forceinline__ void qoi_scan_step(QoiFn& f, uint32_t& n)
 {
-    const QoiFn p = { qoi_dpp<CTRL, ROWMASK>(f.M), qoi_dpp<CTRL, ROWMASK>(f.V), qoi_dpp<CTRL, ROWMASK>(f.U) };   // (0, 0, 0) = identity
+    const QoiFn p = { qoi_dpp0<CTRL, ROWMASK>(f.M), qoi_dpp0<CTRL, ROWMASK>(f.V), qoi_dpp0<CTRL, ROWMASK>(f.U) };   // (0, 0, 0) = identity
     f = qoi_then(p, f);
-    n += qoi_dpp<CTRL, ROWMASK>(n);
+    qoi_add_scan_step<CTRL, ROWMASK>(n);
 }
 
 #ifndef QOI_PROFILE               // measurement only (tools/variant.sh qoi:prof:-DQOI_PROFILE=1): cycles per phase of wave 0, summed over streams

@@ -98,6 +98,27 @@ def test_fixture_files(hip, path):
         assert np.array_equal(got_dense, exp)
 
 
+def test_reference_derived_vectors(hip):
+    """The HIP kernels against tests/golden/jpeg_h2v2_ref.npz DIRECTLY (not via liboracle.so): whole 4:2:0 frames -> rgba8 / rgb8 /
+    l8 with the recorded max_zag (and NULL for the dense frames), and idct() per max_zag class through the grey kernel.  The file
+    holds outputs of tools/ref_literal_jpeg.py, whose arithmetic statements are transliterated mechanically from jpegload.d."""
+    import test_oracle_pinning as P
+    V = P.jpeg_vectors()
+    for f in range(int(V["n_frames"])):
+        w, h = int(V[f"frame{f}_w"]), int(V[f"frame{f}_h"])
+        co = V[f"frame{f}_coeffs"]
+        dense = bool(V[f"frame{f}_dense"])
+        for comps in (4, 3, 1):
+            exp = P.rgba_to(V[f"frame{f}_rgba"], w, comps)
+            for mz in ([None, V[f"frame{f}_max_zag"]] if dense else [V[f"frame{f}_max_zag"]]):
+                got = gpu_reconstruct(hip, w, h, 4, co[None], None if mz is None else mz[None], comps)[0]
+                assert np.array_equal(got, exp), (f, comps, mz is None)
+    # idct(block, max_zag): the blocks as a grey image, one block per MCU
+    n = len(V["blocks"])
+    got = gpu_reconstruct(hip, 8 * n, 8, 0, V["blocks"][None], V["block_max_zag"][None], 1)[0]
+    assert np.array_equal(got.reshape(8, n, 8).transpose(1, 0, 2).reshape(n, 64), V["idct"])
+
+
 @pytest.mark.parametrize("scan_type", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("kind", ["natural", "dense", "wild"])
 def test_random_coefficients(hip, scan_type, kind):

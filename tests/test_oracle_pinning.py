@@ -251,6 +251,53 @@ def test_jpeg_literal_restatement_bit_equal_upsample_and_idct():
     assert temps.shape == (4, 102000, 64) and ypix.shape == (102000, 64)
 
 
+def jpeg_vectors():
+    """tests/golden/jpeg_h2v2_ref.npz: outputs of the reference-derived restatement (tools/make_jpeg_vectors.py), committed as data"""
+    return np.load(os.path.join(G, "jpeg_h2v2_ref.npz"))
+
+
+def rgba_to(rgba, width, comps):
+    """rgb8 / l8 from the rgba8 scanlines as decompress_jpeg_image_from_stream does (jpegload.d:3776-3792)"""
+    px = rgba.reshape(rgba.shape[0], width, 4).astype(np.int64)
+    if comps == 4:
+        return rgba
+    if comps == 3:
+        return px[:, :, :3].astype(np.uint8).reshape(rgba.shape[0], width * 3)
+    return ((px[:, :, 0] * 19595 + px[:, :, 1] * 38470 + px[:, :, 2] * 7471 + 32768) >> 16).astype(np.uint8)
+
+
+def check_oracle_against_jpeg_vectors():
+    """oracle_jpeg.c == the reference-derived vectors: expanded blocks, idct_4x4, idct per max_zag class, whole frames in the
+    three output formats.  (Also run on the GPU box, where tools/ is not consulted: the vectors are data.)"""
+    V = jpeg_vectors()
+    for i in range(len(V["blocks"])):
+        b, mz = V["blocks"][i], int(V["block_max_zag"][i])
+        up = O.jpeg_upsample_block(b, mz)
+        assert np.array_equal(up.reshape(4, 64), V["expanded"][i]), (i, mz)
+        for q in range(4):
+            assert np.array_equal(O.jpeg_idct_4x4(up[q]).reshape(64), V["samples4"][i, q]), (i, mz, q)
+        assert np.array_equal(O.jpeg_idct(b, mz).reshape(64), V["idct"][i]), (i, mz)
+    for f in range(int(V["n_frames"])):
+        w, h = int(V[f"frame{f}_w"]), int(V[f"frame{f}_h"])
+        co, mz = V[f"frame{f}_coeffs"], (None if bool(V[f"frame{f}_dense"]) else V[f"frame{f}_max_zag"])
+        for comps in (4, 3, 1):
+            assert np.array_equal(O.jpeg_reconstruct(w, h, 3, O.JPGD_YH2V2, co, mz, comps), rgba_to(V[f"frame{f}_rgba"], w, comps)), (f, comps)
+
+
+def test_oracle_equals_reference_derived_jpeg_vectors():
+    check_oracle_against_jpeg_vectors()
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference tree (build container only)")
+def test_jpeg_vectors_and_generated_regions_are_current():
+    """the committed vectors are what the restatement produces now, and the restatement's generated regions are what
+    jpegload.d transliterates to now"""
+    import subprocess, sys
+    root = os.path.dirname(HERE)
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "make_ref_literal.py"), "--check"])
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "make_jpeg_vectors.py"), "--check"])
+
+
 def test_jpeg_literal_restatement_pixels_small_frames():
     """whole 4:2:0 frames through the literal driver (transform_mcu_expand + the SSE sequence of expanded_convert, per
     scanline, cropped like :3764) == orc_jpeg_reconstruct, ragged sizes, with and without max_zag"""

@@ -298,6 +298,48 @@ def test_gather_world1_places_images_in_batch_order(hip):
     L.gamut_hip_device_free(dsrc); L.gamut_hip_device_free(ddst); L.gamut_hip_comm_destroy(comm)
 
 
+def _build_shard_host(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "shard_host")
+    root = os.path.dirname(HERE)
+    lib_dir = os.path.dirname(_capi.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=gnu99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"), os.path.join(HERE, "c", "shard_host.c"),
+                           "-o", exe, "-L", lib_dir, "-lgamut_hip", "-lpthread", "-Wl,-rpath," + lib_dir])
+    return exe
+
+
+def test_pure_c_shard_host_builds(tmp_path):
+    """tests/c/shard_host.c (shard -> decode its share -> gather, no Python in the ranks) compiles against the C ABI; without a GPU it
+    reports that there is none"""
+    import subprocess
+    exe = _build_shard_host(tmp_path)
+    if _capi.lib().gamut_hip_device_count() == 0:
+        out = subprocess.run([exe, "proc", "1", "0", "-"], capture_output=True, text=True, timeout=60)
+        assert out.returncode == 9 and "no device" in out.stderr
+
+
+@pytest.mark.gpu
+def test_pure_c_shard_host(hip, tmp_path):
+    """The multi-GPU path driven by a C host, as a D host would: world 1 on any box; on a box with >= 2 devices ALSO as one
+    process per GPU (RCCL id through a file) and as one process with one host thread per GPU -- this test does not skip there,
+    so the first multi-GPU node the suite meets exercises RCCL."""
+    import subprocess
+    exe = _build_shard_host(tmp_path)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for mode in (["proc", "1", "0", "-"], ["threads", "1"]):
+        out = subprocess.run([exe] + mode, capture_output=True, text=True, timeout=300, env=env)
+        assert out.returncode == 0 and "ok" in out.stdout, (mode, out.returncode, out.stdout, out.stderr)
+    ndev = hip.gamut_hip_device_count()
+    if ndev >= 2:
+        world = min(ndev, 4)
+        idfile = str(tmp_path / "rccl_id")
+        ps = [subprocess.Popen([exe, "proc", str(world), str(r), idfile], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
+        res = [p.communicate(timeout=600) + (p.returncode,) for p in ps]
+        assert all(rc == 0 for _, _, rc in res), res
+        out = subprocess.run([exe, "threads", str(world)], capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0 and f"{world} threads ok" in out.stdout, (out.returncode, out.stdout, out.stderr)
+
+
 def _rccl_rank(rank, world, idfile, ndev, q):
     """One rank of the C-ABI gather: no torch.distributed -- the id travels through a file, as a D host would do it."""
     import time

@@ -171,9 +171,166 @@ def generate_rowcol():
     return "".join(text)
 
 
+BEGIN_MISC, END_MISC = "# BEGIN GENERATED MISC (tools/make_ref_literal.py from jpegload.d)\n", "# END GENERATED MISC\n"
+
+
+def region(lines, start_pat, end_pat, after=0):
+    """1-based line numbers [a, b] of the first line matching start_pat at or after `after` .. the next line matching end_pat"""
+    a = next(k for k in range(after, len(lines)) if re.search(start_pat, lines[k]))
+    b = next(k for k in range(a, len(lines)) if re.search(end_pat, lines[k]))
+    return a, b
+
+
+def table(lines, name):
+    """`static immutable T[N] name = [ ... ];` -> python list text (numbers only)"""
+    a, b = region(lines, r"static immutable \w+\[\d+\] " + name + r" = \[", r"\];")
+    text = " ".join(lines[a:b + 1])
+    body = text[text.index("= [") + 3:text.rindex("]")]
+    vals = [int(v) for v in body.replace("\n", " ").split(",") if v.strip()]
+    return a + 1, b + 1, vals
+
+
+def expr(s):
+    """D expression text -> python: casts and template instantiations only; operators, parentheses and constants stay"""
+    s = re.sub(r"FIX!\((-?[0-9.]+)f\)", r"FIX(\1)", s)
+    s = re.sub(r"cast\(jpgd_block_t\)", "to_short", s)
+    s = re.sub(r"cast\(__m128i?\*?\)\s*", "", s)
+    s = re.sub(r"\.ptr\b", "", s)
+    return s
+
+
+def generate_misc():
+    L = open(SRC).read().split("\n")
+    out = [BEGIN_MISC]
+    def emit(t=""):
+        out.append(t + "\n")
+    # ---- enums and tables: data, copied by the machine
+    a, b = region(L, r"^enum CONST_BITS", r"^enum FIX_3_072711026")
+    emit(f"# jpegload.d:{a + 1}-{b + 1}")
+    for l in L[a:b + 1]:
+        m = re.fullmatch(r"enum (\w+) = (?:cast\(int\))?(\d+);.*", l.strip())
+        if m:
+            emit(f"{m.group(1)} = {m.group(2)}")
+        elif l.strip():
+            raise SystemExit(f"enum line not understood: {l}")
+    for name in ("g_ZAG", "s_idct_row_table", "s_idct_col_table", "s_max_rc"):
+        a, b, vals = table(L, name)
+        emit(f"{name} = {vals}          # jpegload.d:{a}-{b}")
+    a, b = region(L, r"enum SCALEBITS = 16;", r"enum ONE_HALF")
+    emit(f"SCALEBITS = 16          # jpegload.d:{a + 1}")
+    m = re.fullmatch(r"enum ONE_HALF = \(cast\(int\) 1 << \(SCALEBITS-1\)\);", L[b].strip())
+    if not m:
+        raise SystemExit("ONE_HALF not understood")
+    emit(f"ONE_HALF = 1 << (SCALEBITS-1)          # jpegload.d:{b + 1}")
+    emit()
+    # ---- idct(): the DC-only shortcut (the four statements on k)
+    a, b = region(L, r"^void idct\(\)", r"for \(int i = 8; i > 0; i--\)")
+    emit(f"def idct_dc_d(pSrc_ptr):          # jpegload.d:{a + 1}-{b + 1}")
+    n = 0
+    for l in L[a:b]:
+        t = l.strip()
+        m = re.fullmatch(r"(?:int )?k = (.*);", t)
+        if m:
+            emit(f"    k = to_int({m.group(1)})"); n += 1                # k is declared `int`
+    if n != 4:
+        raise SystemExit("idct DC shortcut: expected 4 statements on k")
+    emit("    return k")
+    emit()
+    # ---- Matrix44: the six operator / store bodies
+    for dname, pyname, sig in ((r'opOpAssign\(string op:"\+"\)', "Matrix44_iadd_d", "this, a"), (r'opOpAssign\(string op:"-"\)', "Matrix44_isub_d", "this, a"),
+                               (r'opBinary\(string op:"\+"\)', "Matrix44_add_d", "this, b, ret"), (r'opBinary\(string op:"-"\)', "Matrix44_sub_d", "this, b, ret"),
+                               (r"static void add_and_store\(\)", "add_and_store_d", "pDst, a, b"), (r"static void sub_and_store\(\)", "sub_and_store_d", "pDst, a, b")):
+        a, _ = region(L, dname, dname)
+        depth, k = L[a].count("{") - L[a].count("}"), a + 1
+        while depth:
+            depth += L[k].count("{") - L[k].count("}"); k += 1
+        emit(f"def {pyname}({sig}):          # jpegload.d:{a + 1}-{k}")
+        ind = 1
+        for no in range(a + 1, k - 1):
+            t = L[no].strip()
+            if not t or t in ("alias a = this;", "Matrix44 ret;", "return this;", "return ret;"):
+                if t == "alias a = this;":
+                    emit("    a = this")
+                continue
+            m = re.fullmatch(r"foreach \(int r; 0\.\.(\w+)\) \{", t)
+            if m:
+                emit("    " * ind + f"for r in range({m.group(1)}):"); ind += 1; continue
+            if t == "}":
+                ind -= 1; continue
+            m = re.fullmatch(r"at\((\w), (\d)\) ([+-])= (.*);", t)
+            if m:
+                emit("    " * ind + f"this.set({m.group(1)}, {m.group(2)}, this.at({m.group(1)}, {m.group(2)}) {m.group(3)} {m.group(4)})"); continue
+            m = re.fullmatch(r"ret\.at\((\w), (\d)\) = (.*);", t)
+            if m:
+                emit("    " * ind + f"ret.set({m.group(1)}, {m.group(2)}, {m.group(3)})"); continue
+            m = re.fullmatch(r"(pDst\[[^\]]*\]) = (.*);", t)
+            if m:
+                emit("    " * ind + f"{m.group(1)} = {expr(m.group(2))}"); continue
+            raise SystemExit(f"jpegload.d:{no + 1}: Matrix44 statement not understood: {t}")
+        emit()
+    # ---- create_look_ups: the loop body
+    a, b = region(L, r"void create_look_ups \(\)", r"^  \}")
+    emit(f"def create_look_ups_body_d(m_crr, m_cbb, m_crg, m_cbg, i):          # jpegload.d:{a + 1}-{b + 1}")
+    n = 0
+    for no in range(a, b):
+        t = L[no].strip()
+        m = re.fullmatch(r"int k = (.*);", t)
+        if m:
+            emit(f"    k = {m.group(1)}"); n += 1; continue
+        m = re.fullmatch(r"(m_\w+)\.ptr\[i\] = (.*);", t)
+        if m:
+            emit(f"    {m.group(1)}[i] = {expr(m.group(2))}"); n += 1
+    if n != 5:
+        raise SystemExit("create_look_ups: expected 5 statements")
+    emit()
+    # ---- transform_mcu_expand: from `auto a = ...` to the last idct_4x4
+    t0, _ = region(L, r"void transform_mcu_expand \(int mcu_row\)", r".")
+    a, _ = region(L, r"auto a = DCT_Upsample\.Matrix44\(P \+ Q\);", r".", t0)
+    b, _ = region(L, r"pSrc_ptr \+= 64;", r".", a)
+    emit(f"def mcu_expand_tail_d(P, Q, R, S, temp_block, pDst_ptr, idct_4x4):          # jpegload.d:{a + 1}-{b}")
+    for no in range(a, b):
+        t = L[no].strip()
+        if not t:
+            continue
+        t = t.rstrip(";")
+        t = t.replace("DCT_Upsample.Matrix44.", "Matrix44.").replace("DCT_Upsample.Matrix44(", "Matrix44(").replace("temp_block.ptr", "temp_block")
+        t = re.sub(r"^auto (\w) = ", r"\1 = ", t)
+        m = re.fullmatch(r"DCT_Upsample\.Matrix44\* (\w) = &(\w)", t)
+        if m:
+            t = f"{m.group(1)} = {m.group(2)}"
+        t = t.replace("*b", "b").replace("*d", "d")
+        if not re.fullmatch(r"(\w = Matrix44\(\w \+ \w\)|\w -= \w|\w = \w|Matrix44\.(add|sub)_and_store\(temp_block, \w, \w\)|idct_4x4\(temp_block, pDst_ptr\)|pDst_ptr \+= 64)", t):
+            raise SystemExit(f"jpegload.d:{no + 1}: transform_mcu_expand statement not understood: {t}")
+        emit("    " + t)
+    emit()
+    # ---- expanded_convert: the body of the `for (int j ...)` loop (the SSE sequence)
+    t0, _ = region(L, r"void expanded_convert \(\)", r".")
+    a, _ = region(L, r"for \(int j = 0; j \+ 3 < 8; j \+= 4\)", r".", t0)
+    b, _ = region(L, r"d \+= 16;", r".", a)
+    emit(f"def expanded_convert_simd_d(Py, Y_ofs, Cb_ofs, Cr_ofs, j, d):          # jpegload.d:{a + 3}-{b + 1}")
+    for no in range(a + 2, b + 1):
+        t = L[no].strip()
+        if not t or t.startswith("//"):
+            continue
+        t = expr(t.rstrip(";"))
+        t = re.sub(r"^__m128i? (\w+)\s*= ", r"\1 = ", t)
+        t = re.sub(r"&(\w+)\[([^\]]*)\]", r"\1, \2", t)                     # &Py[Y_ofs + j] -> Py, Y_ofs + j
+        t = re.sub(r"\s+\(", "(", t)
+        t = re.sub(r"\s+=", " =", t)
+        if t.startswith("_MM_TRANSPOSE4_PS("):
+            args = t[len("_MM_TRANSPOSE4_PS("):-1]
+            t = f"{args} = _MM_TRANSPOSE4_PS({args})"
+        if not re.fullmatch(r"(\w+ = .*|\w+ \+= \w+|_mm_storeu_si128\(.*\)|[\w, ]+ = _MM_TRANSPOSE4_PS\(.*\))", t) or "cast(" in t:
+            raise SystemExit(f"jpegload.d:{no + 1}: expanded_convert statement not understood: {t}")
+        emit("    " + t)
+    emit("    return d")
+    out.append(END_MISC)
+    return "".join(out)
+
+
 def main():
     cur = open(DST).read()
-    regions = ((BEGIN, END, generate()), (BEGIN_RC, END_RC, generate_rowcol()))
+    regions = ((BEGIN, END, generate()), (BEGIN_RC, END_RC, generate_rowcol()), (BEGIN_MISC, END_MISC, generate_misc()))
     if "--check" in sys.argv:
         for b, e, new in regions:
             if cur[cur.index(b):cur.index(e) + len(e)] != new:

@@ -29,7 +29,119 @@ import numpy as np
 np.seterr(over="ignore")
 I32 = np.int32
 
-# ---------------------------------------------------------------------------------------------- :120-152
+# ---------------------------------------------------------------------------------------------- D semantics (hand-written glue)
+def i32(x):
+    return np.asarray(x).astype(I32)
+
+
+def to_int(x):                     # a value assigned to a D `int` variable
+    return np.asarray(x).astype(I32)
+
+
+def to_short(x):                   # cast(jpgd_block_t): the low 16 bits
+    return i32(x).astype(np.int16)
+
+
+def FIX(x):                        # enum FIX(float x) = (cast(int)((x) * (1L<<SCALEBITS) + 0.5f)); float arithmetic, truncation toward zero
+    return I32(int(np.float32(np.float32(x) * np.float32(1 << 16)) + np.float32(0.5)))
+
+
+NUM_ROWS = NUM_COLS = 4            # DCT_Upsample.Matrix44: enum { NUM_ROWS = 4, NUM_COLS = 4 } (:832)
+
+
+# __m128i / __m128 of intel-intrinsics as N registers at once: (N, 16) bytes; `+`, `-`, `+=` are D's int4 vector operators.
+# (What an intrinsic does is Intel's definition, not the reference's arithmetic; WHICH intrinsics run on WHAT, in which order,
+# is the generated text below.)
+class M128:
+    def __init__(self, b):
+        self.b = np.ascontiguousarray(b, np.uint8)
+
+    def i(self):
+        return self.b.view(I32)
+
+    @staticmethod
+    def from_i32(v):
+        return M128(np.ascontiguousarray(v, I32).view(np.uint8))
+
+    def __add__(self, o):
+        return M128.from_i32(self.i() + o.i())
+
+    def __sub__(self, o):
+        return M128.from_i32(self.i() - o.i())
+
+    __iadd__ = __add__              # a NEW register: `A = mm_crr` followed by `mm_crr += x` must not change A
+
+
+class BytesAt:
+    """N buffers at once, with a D pointer into them: p[k] / &p[k] address byte base + k of every buffer; `p += n` moves it"""
+    def __init__(self, arr, base=0):
+        self.arr, self.base = arr, base
+
+    def __iadd__(self, n):
+        return BytesAt(self.arr, self.base + n)
+
+
+def _lanes(ref):
+    return ref.arr.shape[0]
+
+
+_N = [1]                           # lanes of the registers made by _mm_set1_epi32 / _mm_setzero_si128 (set by the loaders)
+
+
+def _mm_loadu_si32(p, k):          # 4 bytes into the low dword, the rest zero
+    _N[0] = p.arr.shape[0]
+    r = np.zeros((_N[0], 16), np.uint8)
+    r[:, :4] = p.arr[:, p.base + k: p.base + k + 4]
+    return M128(r)
+
+
+def _mm_setzero_si128():
+    return M128(np.zeros((_N[0], 16), np.uint8))
+
+
+def _mm_set1_epi32(v):
+    return M128.from_i32(np.full((_N[0], 4), int(v), I32))
+
+
+def _mm_unpacklo_epi8(a, b):       # a0 b0 a1 b1 ... a7 b7
+    r = np.empty_like(a.b); r[:, 0::2] = a.b[:, :8]; r[:, 1::2] = b.b[:, :8]
+    return M128(r)
+
+
+def _mm_unpacklo_epi16(a, b):
+    a16, b16 = a.b.view(np.uint16), b.b.view(np.uint16)
+    r = np.empty_like(a16); r[:, 0::2] = a16[:, :4]; r[:, 1::2] = b16[:, :4]
+    return M128(r.view(np.uint8))
+
+
+def _mm_mullo_epi32(a, b):
+    return M128.from_i32(a.i() * b.i())
+
+
+def _mm_srai_epi32(a, n):
+    return M128.from_i32(a.i() >> I32(n))
+
+
+def _MM_TRANSPOSE4_PS(A, B, C, D):
+    m = np.stack([A.i(), B.i(), C.i(), D.i()], axis=1)        # (N, 4 registers, 4 lanes)
+    t = m.transpose(0, 2, 1)
+    return tuple(M128.from_i32(np.ascontiguousarray(t[:, k])) for k in range(4))
+
+
+def _mm_packs_epi32(a, b):         # signed saturation int32 -> int16, a's four then b's four
+    return M128(np.clip(np.concatenate([a.i(), b.i()], axis=1), -32768, 32767).astype(np.int16).view(np.uint8))
+
+
+def _mm_packus_epi16(a, b):        # unsigned saturation int16 -> uint8
+    return M128(np.clip(np.concatenate([a.b.view(np.int16), b.b.view(np.int16)], axis=1), 0, 255).astype(np.uint8))
+
+
+def _mm_storeu_si128(p, k, v):
+    p.arr[:, p.base + k: p.base + k + 16] = v.b
+
+
+# BEGIN GENERATED MISC (tools/make_ref_literal.py from jpegload.d)
+# jpegload.d:120-135
 CONST_BITS = 13
 PASS1_BITS = 2
 SCALEDONE = 1
@@ -45,10 +157,129 @@ FIX_1_961570560 = 16069
 FIX_2_053119869 = 16819
 FIX_2_562915447 = 20995
 FIX_3_072711026 = 25172
+g_ZAG = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]          # jpegload.d:106-106
+s_idct_row_table = [1, 0, 0, 0, 0, 0, 0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 2, 1, 0, 0, 0, 0, 0, 0, 2, 1, 1, 0, 0, 0, 0, 0, 2, 2, 1, 0, 0, 0, 0, 0, 3, 2, 1, 0, 0, 0, 0, 0, 4, 2, 1, 0, 0, 0, 0, 0, 4, 3, 1, 0, 0, 0, 0, 0, 4, 3, 2, 0, 0, 0, 0, 0, 4, 3, 2, 1, 0, 0, 0, 0, 4, 3, 2, 1, 1, 0, 0, 0, 4, 3, 2, 2, 1, 0, 0, 0, 4, 3, 3, 2, 1, 0, 0, 0, 4, 4, 3, 2, 1, 0, 0, 0, 5, 4, 3, 2, 1, 0, 0, 0, 6, 4, 3, 2, 1, 0, 0, 0, 6, 5, 3, 2, 1, 0, 0, 0, 6, 5, 4, 2, 1, 0, 0, 0, 6, 5, 4, 3, 1, 0, 0, 0, 6, 5, 4, 3, 2, 0, 0, 0, 6, 5, 4, 3, 2, 1, 0, 0, 6, 5, 4, 3, 2, 1, 1, 0, 6, 5, 4, 3, 2, 2, 1, 0, 6, 5, 4, 3, 3, 2, 1, 0, 6, 5, 4, 4, 3, 2, 1, 0, 6, 5, 5, 4, 3, 2, 1, 0, 6, 6, 5, 4, 3, 2, 1, 0, 7, 6, 5, 4, 3, 2, 1, 0, 8, 6, 5, 4, 3, 2, 1, 0, 8, 7, 5, 4, 3, 2, 1, 0, 8, 7, 6, 4, 3, 2, 1, 0, 8, 7, 6, 5, 3, 2, 1, 0, 8, 7, 6, 5, 4, 2, 1, 0, 8, 7, 6, 5, 4, 3, 1, 0, 8, 7, 6, 5, 4, 3, 2, 0, 8, 7, 6, 5, 4, 3, 2, 1, 8, 7, 6, 5, 4, 3, 2, 2, 8, 7, 6, 5, 4, 3, 3, 2, 8, 7, 6, 5, 4, 4, 3, 2, 8, 7, 6, 5, 5, 4, 3, 2, 8, 7, 6, 6, 5, 4, 3, 2, 8, 7, 7, 6, 5, 4, 3, 2, 8, 8, 7, 6, 5, 4, 3, 2, 8, 8, 8, 6, 5, 4, 3, 2, 8, 8, 8, 7, 5, 4, 3, 2, 8, 8, 8, 7, 6, 4, 3, 2, 8, 8, 8, 7, 6, 5, 3, 2, 8, 8, 8, 7, 6, 5, 4, 2, 8, 8, 8, 7, 6, 5, 4, 3, 8, 8, 8, 7, 6, 5, 4, 4, 8, 8, 8, 7, 6, 5, 5, 4, 8, 8, 8, 7, 6, 6, 5, 4, 8, 8, 8, 7, 7, 6, 5, 4, 8, 8, 8, 8, 7, 6, 5, 4, 8, 8, 8, 8, 8, 6, 5, 4, 8, 8, 8, 8, 8, 7, 5, 4, 8, 8, 8, 8, 8, 7, 6, 4, 8, 8, 8, 8, 8, 7, 6, 5, 8, 8, 8, 8, 8, 7, 6, 6, 8, 8, 8, 8, 8, 7, 7, 6, 8, 8, 8, 8, 8, 8, 7, 6, 8, 8, 8, 8, 8, 8, 8, 6, 8, 8, 8, 8, 8, 8, 8, 7, 8, 8, 8, 8, 8, 8, 8, 8]          # jpegload.d:295-304
+s_idct_col_table = [1, 1, 2, 3, 3, 3, 3, 3, 3, 4, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 6, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8]          # jpegload.d:306-306
+s_max_rc = [17, 18, 34, 50, 50, 51, 52, 52, 52, 68, 84, 84, 84, 84, 85, 86, 86, 86, 86, 86, 102, 118, 118, 118, 118, 118, 118, 119, 120, 120, 120, 120, 120, 120, 120, 136, 136, 136, 136, 136, 136, 136, 136, 136, 136, 136, 136, 136, 136, 136, 136, 136, 136, 136, 136, 136, 136, 136, 136, 136, 136, 136, 136, 136]          # jpegload.d:2132-2137
+SCALEBITS = 16          # jpegload.d:2080
+ONE_HALF = 1 << (SCALEBITS-1)          # jpegload.d:2081
 
+def idct_dc_d(pSrc_ptr):          # jpegload.d:308-319
+    k = to_int(((pSrc_ptr[0] + 4) >> 3) + 128)
+    k = to_int(CLAMP(k))
+    k = to_int(k | (k<<8))
+    k = to_int(k | (k<<16))
+    return k
 
-def i32(x):
-    return np.asarray(x).astype(I32)
+def Matrix44_iadd_d(this, a):          # jpegload.d:842-850
+    for r in range(NUM_ROWS):
+        this.set(r, 0, this.at(r, 0) + a.at(r, 0))
+        this.set(r, 1, this.at(r, 1) + a.at(r, 1))
+        this.set(r, 2, this.at(r, 2) + a.at(r, 2))
+        this.set(r, 3, this.at(r, 3) + a.at(r, 3))
+
+def Matrix44_isub_d(this, a):          # jpegload.d:852-860
+    for r in range(NUM_ROWS):
+        this.set(r, 0, this.at(r, 0) - a.at(r, 0))
+        this.set(r, 1, this.at(r, 1) - a.at(r, 1))
+        this.set(r, 2, this.at(r, 2) - a.at(r, 2))
+        this.set(r, 3, this.at(r, 3) - a.at(r, 3))
+
+def Matrix44_add_d(this, b, ret):          # jpegload.d:862-872
+    a = this
+    for r in range(NUM_ROWS):
+        ret.set(r, 0, a.at(r, 0) + b.at(r, 0))
+        ret.set(r, 1, a.at(r, 1) + b.at(r, 1))
+        ret.set(r, 2, a.at(r, 2) + b.at(r, 2))
+        ret.set(r, 3, a.at(r, 3) + b.at(r, 3))
+
+def Matrix44_sub_d(this, b, ret):          # jpegload.d:874-884
+    a = this
+    for r in range(NUM_ROWS):
+        ret.set(r, 0, a.at(r, 0) - b.at(r, 0))
+        ret.set(r, 1, a.at(r, 1) - b.at(r, 1))
+        ret.set(r, 2, a.at(r, 2) - b.at(r, 2))
+        ret.set(r, 3, a.at(r, 3) - b.at(r, 3))
+
+def add_and_store_d(pDst, a, b):          # jpegload.d:886-893
+    for r in range(4):
+        pDst[0*8 + r] = to_short(a.at(r, 0) + b.at(r, 0))
+        pDst[1*8 + r] = to_short(a.at(r, 1) + b.at(r, 1))
+        pDst[2*8 + r] = to_short(a.at(r, 2) + b.at(r, 2))
+        pDst[3*8 + r] = to_short(a.at(r, 3) + b.at(r, 3))
+
+def sub_and_store_d(pDst, a, b):          # jpegload.d:895-902
+    for r in range(4):
+        pDst[0*8 + r] = to_short(a.at(r, 0) - b.at(r, 0))
+        pDst[1*8 + r] = to_short(a.at(r, 1) - b.at(r, 1))
+        pDst[2*8 + r] = to_short(a.at(r, 2) - b.at(r, 2))
+        pDst[3*8 + r] = to_short(a.at(r, 3) - b.at(r, 3))
+
+def create_look_ups_body_d(m_crr, m_cbb, m_crg, m_cbg, i):          # jpegload.d:2085-2094
+    k = i - 128
+    m_crr[i] = ( FIX(1.40200)  * k + ONE_HALF) >> SCALEBITS
+    m_cbb[i] = ( FIX(1.77200)  * k + ONE_HALF) >> SCALEBITS
+    m_crg[i] = (-FIX(0.71414)) * k
+    m_cbg[i] = (-FIX(0.34414)) * k + ONE_HALF
+
+def mcu_expand_tail_d(P, Q, R, S, temp_block, pDst_ptr, idct_4x4):          # jpegload.d:2230-2252
+    a = Matrix44(P + Q)
+    P -= Q
+    b = P
+    c = Matrix44(R + S)
+    R -= S
+    d = R
+    Matrix44.add_and_store(temp_block, a, c)
+    idct_4x4(temp_block, pDst_ptr)
+    pDst_ptr += 64
+    Matrix44.sub_and_store(temp_block, a, c)
+    idct_4x4(temp_block, pDst_ptr)
+    pDst_ptr += 64
+    Matrix44.add_and_store(temp_block, b, d)
+    idct_4x4(temp_block, pDst_ptr)
+    pDst_ptr += 64
+    Matrix44.sub_and_store(temp_block, b, d)
+    idct_4x4(temp_block, pDst_ptr)
+    pDst_ptr += 64
+
+def expanded_convert_simd_d(Py, Y_ofs, Cb_ofs, Cr_ofs, j, d):          # jpegload.d:2754-2817
+    mm_y = _mm_loadu_si32(Py, Y_ofs + j)
+    mm_cb = _mm_loadu_si32(Py, Cb_ofs + j)
+    mm_cr = _mm_loadu_si32(Py, Cr_ofs + j)
+    zero = _mm_setzero_si128()
+    mm_y = _mm_unpacklo_epi8(mm_y, zero)
+    mm_cb = _mm_unpacklo_epi8(mm_cb, zero)
+    mm_cr = _mm_unpacklo_epi8(mm_cr, zero)
+    mm_y = _mm_unpacklo_epi16(mm_y, zero)
+    mm_cb = _mm_unpacklo_epi16(mm_cb, zero)
+    mm_cr = _mm_unpacklo_epi16(mm_cr, zero)
+    mm_128 = _mm_set1_epi32(128)
+    mm_crr = _mm_mullo_epi32(mm_cr - mm_128, _mm_set1_epi32( FIX(1.40200) ) )
+    mm_crg = _mm_mullo_epi32(mm_cr - mm_128, _mm_set1_epi32(-FIX(0.71414) ) )
+    mm_cbg = _mm_mullo_epi32(mm_cb - mm_128, _mm_set1_epi32(-FIX(0.34414) ) )
+    mm_cbb = _mm_mullo_epi32(mm_cb - mm_128, _mm_set1_epi32( FIX(1.77200) ) )
+    mm_ONE_HALF = _mm_set1_epi32(ONE_HALF)
+    mm_crr += mm_ONE_HALF
+    mm_cbg += mm_ONE_HALF
+    mm_cbb += mm_ONE_HALF
+    mm_crr = _mm_srai_epi32(mm_crr, 16)
+    mm_cbb = _mm_srai_epi32(mm_cbb, 16)
+    mm_crg = _mm_srai_epi32(mm_crg + mm_cbg, 16)
+    mm_crr += mm_y
+    mm_crg += mm_y
+    mm_cbb += mm_y
+    A = mm_crr
+    B = mm_crg
+    C = mm_cbb
+    D = _mm_set1_epi32(255)
+    A, B, C, D = _MM_TRANSPOSE4_PS(A, B, C, D)
+    Ai = _mm_packs_epi32(A, B)
+    Ci = _mm_packs_epi32(C, D)
+    Ai = _mm_packus_epi16(Ai, Ci)
+    _mm_storeu_si128(d, 0, Ai)
+    d += 16
+    return d
+# END GENERATED MISC
 
 
 def shl(x, n):                     # D `<<` on int: a plain two's-complement shift
@@ -331,19 +562,7 @@ def Col_idct_d(NONZERO_ROWS, pDst_ptr, pTemp):          # jpegload.d:221-290
 # END GENERATED ROWCOL
 
 
-# ---------------------------------------------------------------------------------------------- :295-306 (data)
-s_idct_row_table = [
-  1,0,0,0,0,0,0,0, 2,0,0,0,0,0,0,0, 2,1,0,0,0,0,0,0, 2,1,1,0,0,0,0,0, 2,2,1,0,0,0,0,0, 3,2,1,0,0,0,0,0, 4,2,1,0,0,0,0,0, 4,3,1,0,0,0,0,0,
-  4,3,2,0,0,0,0,0, 4,3,2,1,0,0,0,0, 4,3,2,1,1,0,0,0, 4,3,2,2,1,0,0,0, 4,3,3,2,1,0,0,0, 4,4,3,2,1,0,0,0, 5,4,3,2,1,0,0,0, 6,4,3,2,1,0,0,0,
-  6,5,3,2,1,0,0,0, 6,5,4,2,1,0,0,0, 6,5,4,3,1,0,0,0, 6,5,4,3,2,0,0,0, 6,5,4,3,2,1,0,0, 6,5,4,3,2,1,1,0, 6,5,4,3,2,2,1,0, 6,5,4,3,3,2,1,0,
-  6,5,4,4,3,2,1,0, 6,5,5,4,3,2,1,0, 6,6,5,4,3,2,1,0, 7,6,5,4,3,2,1,0, 8,6,5,4,3,2,1,0, 8,7,5,4,3,2,1,0, 8,7,6,4,3,2,1,0, 8,7,6,5,3,2,1,0,
-  8,7,6,5,4,2,1,0, 8,7,6,5,4,3,1,0, 8,7,6,5,4,3,2,0, 8,7,6,5,4,3,2,1, 8,7,6,5,4,3,2,2, 8,7,6,5,4,3,3,2, 8,7,6,5,4,4,3,2, 8,7,6,5,5,4,3,2,
-  8,7,6,6,5,4,3,2, 8,7,7,6,5,4,3,2, 8,8,7,6,5,4,3,2, 8,8,8,6,5,4,3,2, 8,8,8,7,5,4,3,2, 8,8,8,7,6,4,3,2, 8,8,8,7,6,5,3,2, 8,8,8,7,6,5,4,2,
-  8,8,8,7,6,5,4,3, 8,8,8,7,6,5,4,4, 8,8,8,7,6,5,5,4, 8,8,8,7,6,6,5,4, 8,8,8,7,7,6,5,4, 8,8,8,8,7,6,5,4, 8,8,8,8,8,6,5,4, 8,8,8,8,8,7,5,4,
-  8,8,8,8,8,7,6,4, 8,8,8,8,8,7,6,5, 8,8,8,8,8,7,6,6, 8,8,8,8,8,7,7,6, 8,8,8,8,8,8,7,6, 8,8,8,8,8,8,8,6, 8,8,8,8,8,8,8,7, 8,8,8,8,8,8,8,8,
-]
-s_idct_col_table = [ 1, 1, 2, 3, 3, 3, 3, 3, 3, 4, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 6, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8 ]
-assert len(s_idct_row_table) == 512 and len(s_idct_col_table) == 64
+assert len(s_idct_row_table) == 512 and len(s_idct_col_table) == 64 and len(s_max_rc) == 64 and sorted(g_ZAG) == list(range(64))     # (generated above)
 
 
 # ---------------------------------------------------------------------------------------------- :308-376
@@ -353,10 +572,10 @@ def idct(pSrc_ptr, block_max_zag):
     N = pSrc_ptr.shape[0]
     pDst = np.zeros((N, 64), np.uint8)
     if block_max_zag <= 1:
-        k = i32(((pSrc_ptr[:, 0].astype(I32) + I32(4)) >> I32(3)) + I32(128))
-        k = CLAMP(k)
-        for r in range(64):                                   # k | k<<8 | k<<16 | k<<24 written to all 8 rows
-            pDst[:, r] = k
+        k = idct_dc_d(Ptr(pSrc_ptr, 0))                       # the four statements on k (:314-317)
+        for i in range(8):                                    # *cast(int*)&pDst_ptr[0] = k; *cast(int*)&pDst_ptr[4] = k; pDst_ptr += 8  (little-endian stores)
+            pDst[:, i * 8: i * 8 + 4] = k.view(np.uint8).reshape(N, 4)
+            pDst[:, i * 8 + 4: i * 8 + 8] = k.view(np.uint8).reshape(N, 4)
         return pDst
 
     temp = np.zeros((N, 64), I32)                             # int[64] temp (D zero-initialises)
@@ -386,6 +605,8 @@ class Matrix44:
     NUM_COLS = 4
 
     def __init__(self, N=None, m=None):
+        if isinstance(N, Matrix44):                           # this(in Matrix44 m): a copy (:836-838)
+            N, m = None, N
         if m is not None:
             self.v = [[m.v[r][c].copy() for c in range(4)] for r in range(4)]
         else:
@@ -397,55 +618,32 @@ class Matrix44:
     def set(self, r, c, x):                                   # `M.at(r, c) = x` (a literal 0 broadcasts over the N blocks)
         self.v[r][c] = np.broadcast_to(i32(x), self.v[r][c].shape).copy()
 
+    # the operator and store bodies are the generated Matrix44_*_d / *_and_store_d functions (:842-902)
     def __iadd__(self, a):
-        for r in range(self.NUM_ROWS):
-            self.v[r][0] = i32(self.at(r, 0) + a.at(r, 0))
-            self.v[r][1] = i32(self.at(r, 1) + a.at(r, 1))
-            self.v[r][2] = i32(self.at(r, 2) + a.at(r, 2))
-            self.v[r][3] = i32(self.at(r, 3) + a.at(r, 3))
+        Matrix44_iadd_d(self, a)
         return self
 
     def __isub__(self, a):
-        for r in range(self.NUM_ROWS):
-            self.v[r][0] = i32(self.at(r, 0) - a.at(r, 0))
-            self.v[r][1] = i32(self.at(r, 1) - a.at(r, 1))
-            self.v[r][2] = i32(self.at(r, 2) - a.at(r, 2))
-            self.v[r][3] = i32(self.at(r, 3) - a.at(r, 3))
+        Matrix44_isub_d(self, a)
         return self
 
-    def __add__(a, b):
-        ret = Matrix44(len(a.v[0][0]))
-        for r in range(a.NUM_ROWS):
-            ret.v[r][0] = i32(a.at(r, 0) + b.at(r, 0))
-            ret.v[r][1] = i32(a.at(r, 1) + b.at(r, 1))
-            ret.v[r][2] = i32(a.at(r, 2) + b.at(r, 2))
-            ret.v[r][3] = i32(a.at(r, 3) + b.at(r, 3))
+    def __add__(self, b):
+        ret = Matrix44(len(self.v[0][0]))
+        Matrix44_add_d(self, b, ret)
         return ret
 
-    def __sub__(a, b):
-        ret = Matrix44(len(a.v[0][0]))
-        for r in range(a.NUM_ROWS):
-            ret.v[r][0] = i32(a.at(r, 0) - b.at(r, 0))
-            ret.v[r][1] = i32(a.at(r, 1) - b.at(r, 1))
-            ret.v[r][2] = i32(a.at(r, 2) - b.at(r, 2))
-            ret.v[r][3] = i32(a.at(r, 3) - b.at(r, 3))
+    def __sub__(self, b):
+        ret = Matrix44(len(self.v[0][0]))
+        Matrix44_sub_d(self, b, ret)
         return ret
 
     @staticmethod
-    def add_and_store(pDst, a, b):                           # pDst: (N, 64) int16; cast(jpgd_block_t) = astype(int16) (truncation)
-        for r in range(4):
-            pDst[:, 0 * 8 + r] = i32(a.at(r, 0) + b.at(r, 0)).astype(np.int16)
-            pDst[:, 1 * 8 + r] = i32(a.at(r, 1) + b.at(r, 1)).astype(np.int16)
-            pDst[:, 2 * 8 + r] = i32(a.at(r, 2) + b.at(r, 2)).astype(np.int16)
-            pDst[:, 3 * 8 + r] = i32(a.at(r, 3) + b.at(r, 3)).astype(np.int16)
+    def add_and_store(pDst, a, b):                           # pDst: (N, 64) int16
+        add_and_store_d(Ptr(pDst, 0), a, b)
 
     @staticmethod
     def sub_and_store(pDst, a, b):
-        for r in range(4):
-            pDst[:, 0 * 8 + r] = i32(a.at(r, 0) - b.at(r, 0)).astype(np.int16)
-            pDst[:, 1 * 8 + r] = i32(a.at(r, 1) - b.at(r, 1)).astype(np.int16)
-            pDst[:, 2 * 8 + r] = i32(a.at(r, 2) - b.at(r, 2)).astype(np.int16)
-            pDst[:, 3 * 8 + r] = i32(a.at(r, 3) - b.at(r, 3)).astype(np.int16)
+        sub_and_store_d(Ptr(pDst, 0), a, b)
 
 
 # ---------------------------------------------------------------------------------------------- :905-911
@@ -626,12 +824,6 @@ def R_S_calc(NUM_ROWS, NUM_COLS, R, S, pSrc):          # jpegload.d:996-1070
 
 
 # ---------------------------------------------------------------------------------------------- :2132-2255
-s_max_rc = [
-    17, 18, 34, 50, 50, 51, 52, 52, 52, 68, 84, 84, 84, 84, 85, 86, 86, 86, 86, 86,
-    102, 118, 118, 118, 118, 118, 118, 119, 120, 120, 120, 120, 120, 120, 120, 136,
-    136, 136, 136, 136, 136, 136, 136, 136, 136, 136, 136, 136, 136, 136, 136, 136,
-    136, 136, 136, 136, 136, 136, 136, 136, 136, 136, 136, 136
-]
 _CASES = [1*16+1, 1*16+2, 2*16+2, 3*16+2, 3*16+3, 3*16+4, 4*16+4, 5*16+4, 5*16+5, 5*16+6, 6*16+6, 7*16+6, 7*16+7, 7*16+8, 8*16+8]
 
 
@@ -650,75 +842,39 @@ def chroma_expand(pSrc_ptr, block_max_zag):
     P_Q_calc(NR, NC, P, Q, pSrc_ptr)
     R_S_calc(NR, NC, R, S, pSrc_ptr)
 
-    a = Matrix44(m=P + Q)
-    P -= Q
-    b = P
-    c = Matrix44(m=R + S)
-    R -= S
-    d = R
-
+    # `auto a = Matrix44(P + Q); P -= Q; ...` up to the fourth idct_4x4: the generated mcu_expand_tail_d (:2230-2251)
     temps, samples = [], []
     temp_block = np.zeros((N, 64), np.int16)                  # jpgd_block_t[64] temp_block, zero-initialised, reused by all four
-    Matrix44.add_and_store(temp_block, a, c)
-    temps.append(temp_block.copy()); samples.append(idct_4x4(temp_block))
-    Matrix44.sub_and_store(temp_block, a, c)
-    temps.append(temp_block.copy()); samples.append(idct_4x4(temp_block))
-    Matrix44.add_and_store(temp_block, b, d)
-    temps.append(temp_block.copy()); samples.append(idct_4x4(temp_block))
-    Matrix44.sub_and_store(temp_block, b, d)
-    temps.append(temp_block.copy()); samples.append(idct_4x4(temp_block))
+
+    def idct_4x4_here(tb, pDst_ptr):                          # idct_4x4(temp_block.ptr, pDst_ptr)
+        temps.append(tb.copy()); samples.append(idct_4x4(tb))
+
+    class _Dst:                                               # pDst_ptr += 64: the four blocks are collected in order
+        def __iadd__(self, n):
+            return self
+    mcu_expand_tail_d(P, Q, R, S, temp_block, _Dst(), idct_4x4_here)
     return np.stack(temps), np.stack(samples)
 
 
 # ---------------------------------------------------------------------------------------------- :2080-2094
-SCALEBITS = 16
-ONE_HALF = 1 << (SCALEBITS - 1)
-
-
-def FIX(x):                        # enum FIX(float x) = (cast(int)((x) * (1L<<SCALEBITS) + 0.5f))
-    return I32(int(np.float32(np.float32(x) * np.float32(1 << SCALEBITS)) + np.float32(0.5)))
-
-
 def create_look_ups():
     m_crr = np.zeros(256, I32); m_cbb = np.zeros(256, I32); m_crg = np.zeros(256, I32); m_cbg = np.zeros(256, I32)
-    for i in range(256):
-        k = I32(i - 128)
-        m_crr[i] = i32(FIX(1.40200) * k + I32(ONE_HALF)) >> I32(SCALEBITS)
-        m_cbb[i] = i32(FIX(1.77200) * k + I32(ONE_HALF)) >> I32(SCALEBITS)
-        m_crg[i] = i32((-FIX(0.71414)) * k)
-        m_cbg[i] = i32((-FIX(0.34414)) * k + I32(ONE_HALF))
+    for i in range(256):                                      # for (int i = 0; i <= 255; i++): the generated body (:2087-2091)
+        create_look_ups_body_d(m_crr, m_cbb, m_crg, m_cbg, I32(i))
     return m_crr, m_cbb, m_crg, m_cbg
 
 
 # ---------------------------------------------------------------------------------------------- :2731-2823
-def _mm_packs_epi32(x):            # signed saturation int32 -> int16
-    return np.clip(x, -32768, 32767).astype(np.int16)
-
-
-def _mm_packus_epi16(x):           # unsigned saturation int16 -> uint8
-    return np.clip(x, 0, 255).astype(np.uint8)
-
-
 def _sse_pixels(mm_y, mm_cb, mm_cr):
-    """the arithmetic of one loop body of expanded_convert (:2769-2816) on int32 lanes -> (lanes, 4) uint8 R,G,B,255"""
-    mm_128 = I32(128)
-    mm_crr = i32((mm_cr - mm_128) * FIX(1.40200))                           # _mm_mullo_epi32
-    mm_crg = i32((mm_cr - mm_128) * (-FIX(0.71414)))
-    mm_cbg = i32((mm_cb - mm_128) * (-FIX(0.34414)))
-    mm_cbb = i32((mm_cb - mm_128) * FIX(1.77200))
-    mm_ONE_HALF = I32(ONE_HALF)
-    mm_crr = i32(mm_crr + mm_ONE_HALF)
-    mm_cbg = i32(mm_cbg + mm_ONE_HALF)
-    mm_cbb = i32(mm_cbb + mm_ONE_HALF)
-    mm_crr = mm_crr >> I32(16)                                              # _mm_srai_epi32
-    mm_cbb = mm_cbb >> I32(16)
-    mm_crg = i32(mm_crg + mm_cbg) >> I32(16)
-    mm_crr = i32(mm_crr + mm_y)
-    mm_crg = i32(mm_crg + mm_y)
-    mm_cbb = i32(mm_cbb + mm_y)
-    # _MM_TRANSPOSE4_PS(A, B, C, D) with D = 255: lane p becomes (A[p], B[p], C[p], 255); then packs_epi32 + packus_epi16
-    T = np.stack([mm_crr, mm_crg, mm_cbb, np.full(mm_crr.shape, 255, I32)], axis=-1)
-    return _mm_packus_epi16(_mm_packs_epi32(T))
+    """the loop body of expanded_convert (:2752-2818, generated: expanded_convert_simd_d) on any number of 4-pixel groups at
+    once: mm_y / mm_cb / mm_cr (..., 4) sample values -> (..., 4, 4) uint8 R,G,B,255"""
+    shape = np.asarray(mm_y).shape
+    n = int(np.prod(shape[:-1]))
+    Py = np.zeros((n, 12), np.uint8)
+    Py[:, 0:4] = np.asarray(mm_y).reshape(n, 4); Py[:, 4:8] = np.asarray(mm_cb).reshape(n, 4); Py[:, 8:12] = np.asarray(mm_cr).reshape(n, 4)
+    d = BytesAt(np.zeros((n, 16), np.uint8))
+    expanded_convert_simd_d(BytesAt(Py), 0, 4, 8, 0, d)
+    return d.arr.reshape(shape[:-1] + (4, 4))
 
 
 def expanded_convert(sample_buf, m_max_mcus_per_row, row):
@@ -733,10 +889,9 @@ def expanded_convert(sample_buf, m_max_mcus_per_row, row):
             Cb_ofs = Y_ofs + 64 * m_expanded_blocks_per_component
             Cr_ofs = Y_ofs + 64 * m_expanded_blocks_per_component * 2
             for j in range(0, 8 - 3, 4):
-                mm_y = sample_buf[Py + Y_ofs + j: Py + Y_ofs + j + 4].astype(I32)      # loadu_si32 + two unpacklo with zero
-                mm_cb = sample_buf[Py + Cb_ofs + j: Py + Cb_ofs + j + 4].astype(I32)
-                mm_cr = sample_buf[Py + Cr_ofs + j: Py + Cr_ofs + j + 4].astype(I32)
-                out.append(_sse_pixels(mm_y, mm_cb, mm_cr).reshape(16))
+                d = BytesAt(np.zeros((1, 16), np.uint8))
+                expanded_convert_simd_d(BytesAt(sample_buf[None, :], Py), Y_ofs, Cb_ofs, Cr_ofs, j, d)
+                out.append(d.arr[0])
         Py += 64 * m_expanded_blocks_per_mcu
     return np.concatenate(out)
 
@@ -780,5 +935,6 @@ def decode_h2v2_rgba_fast(coeffs, width, height):
     row = np.arange(16)[:, None]; col = np.arange(16)[None, :]
     idx_blk = (row // 8) * 2 + col // 8                                                 # Py: (row / 8) * 64 * 2 + (row & 7) * 8; Y_ofs = k * 8
     idx_in = (row & 7) * 8 + (col & 7)
-    px = _sse_pixels(yb[:, idx_blk, idx_in].astype(I32), cb[:, idx_blk, idx_in].astype(I32), cr[:, idx_blk, idx_in].astype(I32))   # (M, 16, 16, 4)
+    g = lambda a: a[:, idx_blk, idx_in].reshape(-1, 16, 4, 4)                            # rows of 4-pixel groups, as the j loop takes them
+    px = _sse_pixels(g(yb), g(cb), g(cr))                                               # (M, 16, 4 groups, 4 px, 4 bytes)
     return px.reshape(mc, mr, 16, 16, 4).transpose(0, 2, 1, 3, 4).reshape(height, width * 4)

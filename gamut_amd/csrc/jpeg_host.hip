@@ -722,9 +722,25 @@ struct SubCtx {
 // one by one on top of the line its starter wrote.  Scattered 2-byte stores for everything (the first version, into a buffer
 // cleared beforehand) cost 13 GB of HBM traffic per 512 images for 3 GB of coefficients: every store a read-modify-write of a line.
 enum { SUB_COUNT = 0, SUB_WRITE = 1, SUB_FIRST = 2 };
+// Checkpoints of a counting pass: the decoder's state and running totals the first time it stands at or behind byte j * ck_step of
+// its sub-sequence.  A lane that decodes its sub-sequence AGAIN (its entry state changed) falls into step with its previous pass
+// after a few symbols, like every Huffman decoder; from the first checkpoint where both passes stand in the same state the rest
+// is the previous pass word for word -- the lane stops there and keeps the old exit state and the old totals behind the
+// checkpoint.  Without this every re-decode ran its whole sub-sequence again (3.2 full counting passes per file on average; now
+// one and a fraction).  kSubCk checkpoints per lane live in the write sweep's block staging area (not in use before that sweep).
+constexpr int kSubCk = 7;
+struct SubCk { uint32_t pos; uint16_t cz, nblk; int dcs[3]; };                   // cz = c | z << 4
+static_assert(sizeof(SubCk) == 20, "checkpoint size");
+struct SubTrace {
+    SubCk* ck;                      // this lane's kSubCk checkpoints (LDS), or nullptr
+    uint32_t first_bit, step_bits;  // checkpoint j stands at bit first_bit + j * step_bits, j = 1 .. kSubCk
+    bool compare;                   // a pass after the first: stop at a checkpoint that matches
+    int old_nblk, old_dcs[3];       // the previous pass's totals
+    bool stopped;                   // out: the pass ended at a matching checkpoint (exit state = the previous one)
+};
 template <int MODE>
 __device__ __forceinline__ bool sub_decode(const SubCtx& x, SubState& s, int& nblk, int (&dcs)[3], int64_t b, int64_t b_end,
-                                           int16_t* out, uint8_t* mz, int16_t* blk = nullptr)
+                                           int16_t* out, uint8_t* mz, int16_t* blk = nullptr, SubTrace* tr = nullptr)
 {
     constexpr bool WRITE = MODE != SUB_COUNT;
     DevBits br; br.open(x.seg, s.pos);
@@ -734,6 +750,9 @@ __device__ __forceinline__ bool sub_decode(const SubCtx& x, SubState& s, int& nb
     bool inherited = z > 0;                                                      // the block under way was started by another lane
     const int q0 = x.par[0], q1 = x.par[1], q2 = x.par[2], d0 = x.par[3], d1 = x.par[4], d2 = x.par[5], a0 = x.par[6], a1 = x.par[7], a2 = x.par[8];
     int dc0 = dcs[0], dc1 = dcs[1], dc2 = dcs[2];
+    int ck_j = 0;                                                                // checkpoints passed
+    uint32_t ck_next = 0xFFFFFFFFu;
+    if (MODE == SUB_COUNT && tr) { ck_next = tr->first_bit + tr->step_bits; tr->stopped = false; }
     while (br.pos < x.end_bit && (!WRITE || b < b_end)) {
         br.refill();                                                             // >= 33 bits: a code (<= 16) and its value (<= 15)
         const int comp = c < x.ny ? 0 : c - x.ny + 1;
@@ -788,7 +807,29 @@ __device__ __forceinline__ bool sub_decode(const SubCtx& x, SubState& s, int& nb
         b += done ? 1 : 0; nblk += done ? 1 : 0;
         z = done ? 0 : znew;
         c = done ? (c + 1 == x.nb ? 0 : c + 1) : c;
+        if (MODE == SUB_COUNT && br.pos >= ck_next) {                            // (never true without a trace)
+            while (ck_j < kSubCk && br.pos >= ck_next) {                         // one symbol may step over several checkpoints (tiny steps)
+                SubCk& k = tr->ck[ck_j];
+                const uint16_t cz = (uint16_t)(c | z << 4);
+                if (tr->compare && k.pos == br.pos && k.cz == cz) {              // in step with the previous pass from here on
+                    // what this pass counted up to here instead of the previous one: the later checkpoints and the totals move by it
+                    const int dn = (int16_t)((uint16_t)nblk - k.nblk), e0 = dc0 - k.dcs[0], e1 = dc1 - k.dcs[1], e2 = dc2 - k.dcs[2];
+                    for (int jj = ck_j; jj < kSubCk; ++jj) {
+                        SubCk& q = tr->ck[jj];
+                        q.nblk = (uint16_t)(q.nblk + dn); q.dcs[0] += e0; q.dcs[1] += e1; q.dcs[2] += e2;
+                    }
+                    nblk = tr->old_nblk + dn; dc0 = tr->old_dcs[0] + e0; dc1 = tr->old_dcs[1] + e1; dc2 = tr->old_dcs[2] + e2;
+                    tr->stopped = true;
+                    break;
+                }
+                k.pos = br.pos; k.cz = cz; k.nblk = (uint16_t)nblk; k.dcs[0] = dc0; k.dcs[1] = dc1; k.dcs[2] = dc2;
+                ++ck_j; ck_next += tr->step_bits;
+            }
+            if (tr->stopped) break;
+            if (ck_j == kSubCk) ck_next = 0xFFFFFFFFu;
+        }
     }
+    if (MODE == SUB_COUNT && tr && tr->stopped) { dcs[0] = dc0; dcs[1] = dc1; dcs[2] = dc2; return ok; }      // s: untouched, the caller keeps the previous exit state
     if (MODE == SUB_WRITE && z > 0 && !inherited && b < b_end) {                 // a block of this lane's that the next lanes finish: its line, as far as it goes
         const uint4* src = reinterpret_cast<const uint4*>(blk);
         uint4* dst = reinterpret_cast<uint4*>(out + b * 64);
@@ -840,7 +881,15 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevIte
     // sweep 0: every lane from the start of its own sub-sequence, as if a block began there
     SubState entry{ (uint32_t)t * sub * 8u, 0, 0 }, mine = entry;
     int nblk = 0, dcs[3] = { 0, 0, 0 };
-    if (active) sub_decode<SUB_COUNT>(x, mine, nblk, dcs, 0, 0, nullptr, nullptr);
+    SubTrace tr;
+    tr.ck = reinterpret_cast<SubCk*>(sh_blk + t * 144); tr.first_bit = (uint32_t)t * sub * 8u; tr.step_bits = ((sub + kSubCk) / (kSubCk + 1)) * 8u;
+    tr.compare = false; tr.old_nblk = 0; tr.old_dcs[0] = tr.old_dcs[1] = tr.old_dcs[2] = 0; tr.stopped = false;
+    static_assert(kSubCk * sizeof(SubCk) <= 144, "the checkpoints borrow the lane's block staging area");
+    if (active) {
+        #pragma unroll
+        for (int j = 0; j < kSubCk; ++j) tr.ck[j].pos = 0xFFFFFFFFu;             // (a pass that ends early leaves the later ones unset: never a match)
+        sub_decode<SUB_COUNT>(x, mine, nblk, dcs, 0, 0, nullptr, nullptr, nullptr, &tr);
+    }
     exit_state[t] = mine;
     __syncthreads();
     // sweeps 1..: from the predecessor's exit state, until nothing moves
@@ -850,9 +899,10 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevIte
         __syncthreads();                                        // everybody has read its predecessor
         if (active && (sweep == 0 || !same(from, entry))) {
             entry = from; mine = from;
+            tr.compare = true; tr.old_nblk = nblk; tr.old_dcs[0] = dcs[0]; tr.old_dcs[1] = dcs[1]; tr.old_dcs[2] = dcs[2];
             dcs[0] = dcs[1] = dcs[2] = 0;
-            sub_decode<SUB_COUNT>(x, mine, nblk, dcs, 0, 0, nullptr, nullptr);
-            if (!same(mine, exit_state[t])) { exit_state[t] = mine; changed = 1; }
+            sub_decode<SUB_COUNT>(x, mine, nblk, dcs, 0, 0, nullptr, nullptr, nullptr, &tr);
+            if (!tr.stopped && !same(mine, exit_state[t])) { exit_state[t] = mine; changed = 1; }
         }
         __syncthreads();
         const int any = changed;
@@ -874,6 +924,11 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevIte
         __syncthreads();
     }
     const int64_t b0 = active ? scan[0][t] - nblk : 0;
+    {                                                           // the checkpoints are done with: the staging area starts out zero
+        uint4* zb = reinterpret_cast<uint4*>(sh_blk + t * 144);
+        #pragma unroll
+        for (int i = 0; i < 9; ++i) zb[i] = make_uint4(0, 0, 0, 0);
+    }
     if (active) {
         int pred[3] = { scan[1][t] - dcs[0], scan[2][t] - dcs[1], scan[3][t] - dcs[2] };
         SubState s = entry; int n2 = 0;

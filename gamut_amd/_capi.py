@@ -85,6 +85,7 @@ SIGNATURES = {
     "gamut_hip_jpeg_scan_layout": (_i, [_vp, _sz, C.POINTER(JpegFrame), C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
     "gamut_hip_jpeg_entropy_decode_device": (_i, [C.POINTER(_vp), C.POINTER(_sz), _i, C.POINTER(_i64), C.POINTER(_i64), _vp, _vp, _vp,
                                               C.POINTER(JpegFrame), C.POINTER(_i), _vp]),
+    "gamut_hip_jpeg_decode_batch_device": (_i, [C.POINTER(_vp), C.POINTER(_sz), _i, _i, C.POINTER(_i64), _vp, C.POINTER(JpegFrame), C.POINTER(_i), _vp, _vp]),
     "gamut_hip_jpeg_decode_coeffs_batch": (_i, [C.POINTER(_vp), C.POINTER(_sz), _i, C.POINTER(JpegFrame), C.POINTER(_i), _i]),
     "gamut_hip_jpeg_frame_free": (None, [C.POINTER(JpegFrame)]),
     "gamut_hip_decompress_jpeg_image_from_memory": (_vp, [_vp, _sz, _pi, _pi, _pi, _pf, _pf, _i]),

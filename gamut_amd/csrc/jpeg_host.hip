@@ -11,6 +11,7 @@
 // Not supported (the call fails like the reference fails on a stream it rejects): arithmetic / lossless /
 // hierarchical frames, 12-bit precision, CMYK, multi-scan *baseline* files.
 #include "common.hpp"
+#include <functional>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -841,18 +842,25 @@ __device__ __forceinline__ bool sub_decode(const SubCtx& x, SubState& s, int& nb
     return ok;
 }
 
-template <bool IN_LDS>
+// NH: Huffman / quantisation tables kept in LDS (0 = none: read from global memory).  A batch written by one encoder has four
+// Huffman tables; with room for four instead of eight a workgroup needs 47 KB instead of 58, and a compute unit holds three of
+// them instead of two -- the kernel is a chain of dependent operations per lane, what it lacks is waves to alternate with.
+template <int NH>
 __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevItem* items, const DevImage* images,
                                                                     const DevHuff* huff_g, int n_huff, const int16_t* quant_g, int n_quant,
                                                                     const uint8_t* blob, int16_t* coeffs, uint8_t* max_zag, uint32_t* status)
 {
-    __shared__ DevHuff sh_huff[IN_LDS ? kLdsHuff : 1];
-    __shared__ int16_t sh_quant[IN_LDS ? kLdsQuant * 64 : 1];
+    constexpr bool IN_LDS = NH > 0;
+    __shared__ DevHuff sh_huff[IN_LDS ? NH : 1];
+    __shared__ int16_t sh_quant[IN_LDS ? NH * 64 : 1];
     __shared__ uint8_t sh_zag[64];
     __shared__ SubState exit_state[kSyncThreads];
-    __shared__ int scan[4][kSyncThreads];                       // blocks finished, DC-difference sums of the three components
     __shared__ int changed, failed, par[9];
     __shared__ __attribute__((aligned(16))) uint8_t sh_blk[kSyncThreads * 144];             // the write sweep: a block per lane (144-byte pitch)
+    // blocks finished, DC-difference sums of the three components: prefix-summed between the counting passes and the write sweep,
+    // in the staging area (whose checkpoints are done with by then, and which is cleared afterwards)
+    int (*scan)[kSyncThreads] = reinterpret_cast<int (*)[kSyncThreads]>(sh_blk);
+    static_assert(4 * kSyncThreads * sizeof(int) <= kSyncThreads * 144, "the scan borrows the staging area");
     load_tables<IN_LDS, kSyncThreads>(sh_huff, sh_quant, sh_zag, huff_g, n_huff, quant_g, n_quant);
     const int t = threadIdx.x;
     {
@@ -924,13 +932,16 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevIte
         __syncthreads();
     }
     const int64_t b0 = active ? scan[0][t] - nblk : 0;
+    const int pred_in[3] = { scan[1][t] - dcs[0], scan[2][t] - dcs[1], scan[3][t] - dcs[2] };
+    const int64_t finished = scan[0][kSyncThreads - 1];
+    __syncthreads();                                            // everybody has its prefix sums: the area is the staging area again
     {                                                           // the checkpoints are done with: the staging area starts out zero
         uint4* zb = reinterpret_cast<uint4*>(sh_blk + t * 144);
         #pragma unroll
         for (int i = 0; i < 9; ++i) zb[i] = make_uint4(0, 0, 0, 0);
     }
     if (active) {
-        int pred[3] = { scan[1][t] - dcs[0], scan[2][t] - dcs[1], scan[3][t] - dcs[2] };
+        int pred[3] = { pred_in[0], pred_in[1], pred_in[2] };
         SubState s = entry; int n2 = 0;
         if (!sub_decode<SUB_WRITE>(x, s, n2, pred, b0, total_blocks, out, mz, reinterpret_cast<int16_t*>(sh_blk + t * 144))) failed = 1;
         if (t == nsub - 1 && b0 + n2 != total_blocks) failed = 1;                 // the segment ended before its last block did
@@ -942,7 +953,6 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevIte
         sub_decode<SUB_FIRST>(x, s, n3, pred, b0, total_blocks, out, mz);
     }
     // A segment whose decode ended early (damaged data) leaves blocks nobody started: they are cleared, not left as they were
-    const int64_t finished = scan[0][kSyncThreads - 1];
     const int64_t started = finished + (exit_state[nsub > 0 ? nsub - 1 : 0].z > 0 ? 1 : 0);
     for (int64_t blk = started + t; blk < total_blocks; blk += kSyncThreads) {
         uint4* dst = reinterpret_cast<uint4*>(out + blk * 64);
@@ -1071,16 +1081,27 @@ void unstuff_file(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& f,
 
 constexpr int kDeferred = -1000;                               // FilePrep.rc of a progressive file: not this function's business
 
+// Hooks of the files -> pixels entry point (gamut_hip_jpeg_decode_batch_device): `layout` runs once the headers are known (it
+// sizes and places the coefficient buffers: the caller of the coefficient-level entry point did that beforehand);
+// `group_done(lo, hi, gs)` runs right after the entropy kernels of files [lo, hi) have been queued on stream gs -- the
+// reconstruction of a group is queued behind its own entropy decode, beside the decode of the next group.
+struct DecodeHooks {
+    std::function<int(const gamut_hip_jpeg_frame* info, const int* rc, const char* progressive, int64_t* coeff_offset, int64_t* zag_offset, int16_t** d_coeffs, uint8_t** d_max_zag)> layout;
+    std::function<int(int lo, int hi, hipStream_t gs)> group_done;
+};
 int entropy_decode_device(const uint8_t* const* data, const size_t* len, int count,
-                          const int64_t* coeff_offset, const int64_t* zag_offset,
+                          const int64_t* coeff_offset_in, const int64_t* zag_offset_in,
                           int16_t* d_coeffs, uint8_t* d_max_zag, uint32_t* d_status,
-                          gamut_hip_jpeg_frame* info, int* host_status, hipStream_t stream)
+                          gamut_hip_jpeg_frame* info, int* host_status, hipStream_t stream, const DecodeHooks* hooks = nullptr)
 {
+    std::vector<int64_t> own_offsets;
+    const int64_t* coeff_offset = coeff_offset_in; const int64_t* zag_offset = zag_offset_in;
+    if (hooks) { own_offsets.assign((size_t)count * 2, 0); coeff_offset = own_offsets.data(); zag_offset = own_offsets.data() + count; }
     const bool trace = getenv("GAMUT_HIP_TRACE") != nullptr;           // stage timings on stderr (tools/e2e_bench.py)
     const auto t_begin = std::chrono::steady_clock::now();
     auto ms_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
-    if (((uintptr_t)d_coeffs & 15) != 0) return set_error(GAMUT_HIP_ERR_INVALID_ARG, "jpeg_entropy_decode_device: the coefficient buffer must be 16-byte aligned");
-    for (int i = 0; i < count; ++i)
+    if (!hooks && ((uintptr_t)d_coeffs & 15) != 0) return set_error(GAMUT_HIP_ERR_INVALID_ARG, "jpeg_entropy_decode_device: the coefficient buffer must be 16-byte aligned");
+    for (int i = 0; i < count && !hooks; ++i)
         if ((coeff_offset[i] & 7) != 0) return set_error(GAMUT_HIP_ERR_INVALID_ARG, "jpeg_entropy_decode_device: coefficient offsets must be multiples of 8 elements (image %d)", i);
 
     // Pipeline: (A) headers on host threads -> (B) layout, and the coefficient clears go out on `stream` -> (C) segments
@@ -1098,6 +1119,11 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
     }
     std::vector<int> progressive;                              // SOF2 files: decoded by progressive_decode_device after the baseline ones
     for (int i = 0; i < count; ++i) if (prep[(size_t)i].progressive) { progressive.push_back(i); prep[(size_t)i].rc = kDeferred; }
+    if (hooks && hooks->layout) {
+        std::vector<int> rcs((size_t)count); std::vector<char> progs((size_t)count);
+        for (int i = 0; i < count; ++i) { rcs[(size_t)i] = prep[(size_t)i].rc == kDeferred ? GAMUT_HIP_OK : prep[(size_t)i].rc; progs[(size_t)i] = prep[(size_t)i].progressive; }
+        if (int rc = hooks->layout(info, rcs.data(), progs.data(), own_offsets.data(), own_offsets.data() + count, &d_coeffs, &d_max_zag)) return rc;
+    }
     // B. serial: table de-duplication, slots of the files in the blob
     std::vector<DevImage> images((size_t)count);
     std::vector<DevHuff> huffs;
@@ -1231,8 +1257,11 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
             if (trace) { (void)hipStreamSynchronize(gs); ms_upload = ms_since(t_up) - ms_kernels_issue; }
             const auto t_k = std::chrono::steady_clock::now();
             if (n_long) {
-                if (in_lds) hipLaunchKernelGGL(k_jpeg_entropy_sync<true>, dim3(n_long), dim3(kSyncThreads), 0, gs, d_items, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
-                else        hipLaunchKernelGGL(k_jpeg_entropy_sync<false>, dim3(n_long), dim3(kSyncThreads), 0, gs, d_items, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
+                static const int force_nh = [] { const char* e = getenv("GAMUT_HIP_JPEG_TABLES_LDS"); return e && *e ? atoi(e) : -1; }();     // measurements: 0 / 4 / 8
+                if (force_nh == 0) hipLaunchKernelGGL(k_jpeg_entropy_sync<0>, dim3(n_long), dim3(kSyncThreads), 0, gs, d_items, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
+                else if (n_huff <= 4 && n_quant <= 4 && force_nh != 8) hipLaunchKernelGGL(k_jpeg_entropy_sync<4>, dim3(n_long), dim3(kSyncThreads), 0, gs, d_items, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
+                else if (in_lds) hipLaunchKernelGGL(k_jpeg_entropy_sync<kLdsHuff>, dim3(n_long), dim3(kSyncThreads), 0, gs, d_items, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
+                else        hipLaunchKernelGGL(k_jpeg_entropy_sync<0>, dim3(n_long), dim3(kSyncThreads), 0, gs, d_items, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
                 if (int rc = launch_status("jpeg_entropy_sync")) return rc;
             }
             if (n_short) {
@@ -1241,6 +1270,7 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
                 else        hipLaunchKernelGGL(k_jpeg_entropy<false>, grid, block, 0, gs, d_items + n_long, n_short, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
             }
             if (int rc = launch_status("jpeg_entropy")) return rc;
+            if (hooks && hooks->group_done) if (int rc = hooks->group_done(g_lo, g_hi, gs)) return rc;
             if (trace) { (void)hipStreamSynchronize(gs); ms_kernels_issue += ms_since(t_k); }
         }
         GAMUT_HIP_CHECK(hipStreamSynchronize(copy_stream));
@@ -1385,6 +1415,69 @@ int gamut_hip_jpeg_entropy_decode_device(const uint8_t* const* data, const size_
         return entropy_decode_device(data, len, count, coeff_offset, zag_offset, coeffs, max_zag, status_dev, info, status_host, pick_stream(stream));
     } catch (...) {
         return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg_entropy_decode_device: out of host memory");
+    }
+}
+
+int gamut_hip_jpeg_decode_batch_device(const uint8_t* const* data, const size_t* len, int count, int req_comps,
+                                       const int64_t* out_offset, uint8_t* out, gamut_hip_jpeg_frame* info, int* status_host,
+                                       uint32_t* status_dev, void* stream)
+{
+    clear_error();
+    if (count < 0 || (req_comps != 1 && req_comps != 3 && req_comps != 4) || (count > 0 && (!data || !len || !out_offset || !out || !info)))
+        return set_error(GAMUT_HIP_ERR_INVALID_ARG, "jpeg_decode_batch_device: bad arguments");
+    if (count == 0) return GAMUT_HIP_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return set_error(GAMUT_HIP_ERR_NO_DEVICE, "no HIP device available (libgamut_hip has no CPU fallback)");
+    try {
+        hipStream_t st = pick_stream(stream);
+        static thread_local PerDevice<DeviceScratch> co_pd, zz_pd;
+        DeviceScratch& s_co = co_pd.cur(); DeviceScratch& s_zz = zz_pd.cur();
+        std::vector<int64_t> co_off((size_t)count, 0), zz_off((size_t)count, 0);
+        std::vector<char> ok((size_t)count, 0), prog((size_t)count, 0);
+        int16_t* d_co = nullptr; uint8_t* d_zz = nullptr;
+        DecodeHooks hooks;
+        hooks.layout = [&](const gamut_hip_jpeg_frame* f, const int* rc, const char* progressive, int64_t* coeff_offset, int64_t* zag_offset, int16_t** pco, uint8_t** pzz) -> int {
+            int64_t blocks = 0;
+            for (int i = 0; i < count; ++i) {
+                coeff_offset[i] = blocks * 64; zag_offset[i] = blocks;
+                co_off[(size_t)i] = blocks * 64; zz_off[(size_t)i] = blocks;
+                ok[(size_t)i] = rc[i] == GAMUT_HIP_OK; prog[(size_t)i] = progressive[i];
+                if (ok[(size_t)i]) blocks += (int64_t)f[i].mcus_per_row * f[i].mcus_per_col * f[i].blocks_per_mcu;
+            }
+            d_co = (int16_t*)s_co.get((size_t)blocks * 128 + 256, st); d_zz = (uint8_t*)s_zz.get((size_t)blocks + 256, st);
+            if (!d_co || !d_zz) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg_decode_batch_device: %lld coefficient blocks do not fit the device", (long long)blocks);
+            *pco = d_co; *pzz = d_zz;
+            return GAMUT_HIP_OK;
+        };
+        // images [lo, hi) -> pixels: runs of images of one geometry at even strides go out as one batched launch
+        auto reconstruct = [&](int lo, int hi, hipStream_t gs, bool progressive_only) -> int {
+            for (int i = lo; i < hi; ) {
+                const gamut_hip_jpeg_frame& f = info[i];
+                const bool mine = ok[(size_t)i] && (prog[(size_t)i] != 0) == progressive_only;
+                if (!mine) { ++i; continue; }
+                const int64_t nblk = (int64_t)f.mcus_per_row * f.mcus_per_col * f.blocks_per_mcu;
+                int j = i + 1;
+                const int64_t ostride = j < hi ? out_offset[j] - out_offset[i] : 0;
+                while (j < hi && ok[(size_t)j] && (prog[(size_t)j] != 0) == progressive_only && info[j].width == f.width && info[j].height == f.height &&
+                       info[j].scan_type == f.scan_type && co_off[(size_t)j] - co_off[(size_t)j - 1] == nblk * 64 && out_offset[j] - out_offset[j - 1] == ostride && ostride > 0) ++j;
+                if (int rc = jpeg_reconstruct_launch(d_co + co_off[(size_t)i], nblk * 64, d_zz + zz_off[(size_t)i], nblk, out + out_offset[i], (int64_t)f.width * req_comps,
+                                                     j - i > 1 ? ostride : 0, f.width, f.height, f.scan_type, req_comps, j - i, gs)) return rc;
+                i = j;
+            }
+            return GAMUT_HIP_OK;
+        };
+        hooks.group_done = [&](int lo, int hi, hipStream_t gs) -> int { return reconstruct(lo, hi, gs, false); };
+        const int rc = entropy_decode_device(data, len, count, nullptr, nullptr, nullptr, nullptr, status_dev, info, status_host, st, &hooks);
+        // (entropy_decode_device returns when every stream it used has drained: the baseline files' pixels are in place.  The
+        // progressive files' coefficients were decoded after the groups: their pixels follow here.)
+        if (d_co) {
+            if (int rc2 = reconstruct(0, count, st, true)) return rc2;
+            GAMUT_HIP_CHECK(hipStreamSynchronize(st));          // the per-thread coefficient scratch is reused by the next call
+        }
+        return rc;
+    } catch (...) {
+        return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg_decode_batch_device: out of host memory");
     }
 }
 

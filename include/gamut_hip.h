@@ -174,6 +174,17 @@ int  gamut_hip_jpeg_entropy_decode_device(const uint8_t* const* data, const size
                                           const int64_t* coeff_offset, const int64_t* zag_offset,
                                           int16_t* coeffs, uint8_t* max_zag, uint32_t* status_dev,
                                           gamut_hip_jpeg_frame* info, int* status_host, void* stream);
+/* Files -> pixels: `count` JPEG files in host memory (baseline and progressive, any sampling mode) -> rows of
+ * width * req_comps bytes (req_comps = 1 / 3 / 4: l8 / rgb8 / rgba8, as decompress_jpeg_image_from_memory converts) at
+ * out + out_offset[i] (device).  The JPEG member of the trio of file-level batch calls (with gamut_hip_png_decode_batch_device and
+ * gamut_hip_qoi_decode_batch_device: BASELINE.json config 5 end to end).  It is gamut_hip_jpeg_entropy_decode_device followed by
+ * the reconstruction kernels, except that the library owns the coefficient buffers (per-thread device scratch, sized from the
+ * headers) and that a group's reconstruction is queued right behind ITS entropy decode, beside the decode of the next group and
+ * the upload of the one after.  info[i] receives the geometry, status_host[i] / status_dev[i]
+ * (both may be NULL) as above.  Returns when the pixels are in place; the status of the lowest-numbered failing file. */
+int  gamut_hip_jpeg_decode_batch_device(const uint8_t* const* data, const size_t* len, int count, int req_comps,
+                                        const int64_t* out_offset, uint8_t* out, gamut_hip_jpeg_frame* info, int* status_host,
+                                        uint32_t* status_dev, void* stream);
 /* the same for `count` independent files on up to `threads` host threads (<= 0: one per hardware thread).  The reference
  * decodes one image at a time (the serial Huffman stage is what bounds a batch once the GPU stages
  * run at HBM speed).  status[i] (may be NULL) receives image i's status and out[i] its frame (zeroed on failure);

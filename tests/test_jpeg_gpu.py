@@ -285,6 +285,61 @@ def _entropy_decode_device(L, blobs):
     return rc, list(hst), st, res
 
 
+def _decode_batch_device(L, blobs, comps):
+    """gamut_hip_jpeg_decode_batch_device -> (rc, host_status, [pixels (h, w * comps) or None per file])"""
+    n = len(blobs)
+    bufs = [np.frombuffer(b, np.uint8) if len(b) else np.zeros(1, np.uint8) for b in blobs]
+    ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+    lens = (C.c_size_t * n)(*[len(b) for b in blobs])
+    hdr = (_capi.JpegFrame * n)()
+    size = []
+    for i in range(n):
+        rc = L.gamut_hip_jpeg_read_header(ptrs[i], lens[i], C.byref(hdr[i]))
+        size.append(hdr[i].width * hdr[i].height * comps if rc == 0 else 0)
+    offs = np.concatenate([[0], np.cumsum(size)[:-1]]).astype(np.int64)
+    total = max(16, int(sum(size)))
+    dout = dev_upload(L, np.full(total + 64, 0xA5, np.uint8))
+    info = (_capi.JpegFrame * n)(); hst = (C.c_int * n)()
+    rc = L.gamut_hip_jpeg_decode_batch_device(ptrs, lens, n, comps, offs.ctypes.data_as(C.POINTER(C.c_int64)), dout, info, hst, None, None)
+    host = np.empty(total + 64, np.uint8)
+    _capi.check(L.gamut_hip_memcpy_d2h(host.ctypes.data, dout, host.nbytes, None))
+    _capi.check(L.gamut_hip_stream_synchronize(None))
+    L.gamut_hip_device_free(dout)
+    assert (host[total:] == 0xA5).all(), "wrote past the last image"
+    res = [host[offs[i]:offs[i] + size[i]].reshape(info[i].height, info[i].width * comps) if hst[i] == 0 and size[i] else None for i in range(n)]
+    return rc, list(hst), res
+
+
+def test_files_to_pixels_batch(hip, progressive_mode):
+    """gamut_hip_jpeg_decode_batch_device: every fixture (baseline and progressive, every sampling mode, restart intervals) plus
+    damaged files in ONE batch -> the pixels decompress_jpeg_image_from_memory gives (== the oracle), for rgba8 / rgb8 / l8; a bad
+    file is reported and does not disturb its neighbours"""
+    blobs = [open(p, "rb").read() for p in JPEGS]
+    blobs.insert(3, b"not a jpeg at all")
+    blobs.insert(9, blobs[0][:200])                                          # truncated in its headers
+    for comps in (4, 3, 1):
+        rc, hst, res = _decode_batch_device(hip, blobs, comps)
+        assert rc != 0 and hst[3] != 0 and hst[9] != 0
+        for i, b in enumerate(blobs):
+            if i in (3, 9):
+                assert res[i] is None
+                continue
+            exp = O.decompress_jpeg(b, comps)
+            assert hst[i] == 0 and np.array_equal(res[i], exp[0]), (i, comps)
+
+
+def test_files_to_pixels_uniform_batch_in_groups(hip):
+    """a batch large enough for the grouped pipeline (>= 256 files: two groups, each reconstructed behind its own entropy decode,
+    runs of equal geometry as one launch): 300 files of three kinds"""
+    kinds = [open(os.path.join(HERE, "golden", "jpeg", n), "rb").read() for n in ("cfg1_640x480_420_q90.jpg", "s_131x97_420_rst.jpg", "s_131x97_444.jpg")]
+    blobs = [kinds[0]] * 130 + [kinds[1]] * 90 + [kinds[2], kinds[0]] * 40
+    rc, hst, res = _decode_batch_device(hip, blobs, 4)
+    assert rc == 0 and not any(hst)
+    exp = {id(k): O.decompress_jpeg(k, 4)[0] for k in kinds}
+    for i, b in enumerate(blobs):
+        assert np.array_equal(res[i], exp[id(b)]), i
+
+
 @pytest.fixture(params=["device", "host"])
 def progressive_mode(request):
     """where the progressive files of a batch are entropy-decoded (jpeg_prog.hpp): every scan level on the GPU, or -- what the

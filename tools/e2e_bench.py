@@ -82,10 +82,17 @@ def main():
         torch.cuda.synchronize()
         return t1
 
+    out_off = (np.arange(B, dtype=np.int64) * h * w * 4)
+
+    def path_c():
+        info = (_capi.JpegFrame * B)()
+        _capi.check(L.gamut_hip_jpeg_decode_batch_device(ptrs, lens, B, 4, out_off.ctypes.data_as(C.POINTER(C.c_int64)), out.data_ptr(), info, None, None, stream))
+        return time.perf_counter()
+
     mb = sum(b.size for b in bufs) / 1e6
     print(f"batch {B} x {w}x{h} {'progressive' if a.progressive else 'baseline'} 4:2:0, {mb / B * 1e3:.0f} kB/file, restart rows {a.restart_rows}, host threads {a.threads or os.cpu_count()}")
     ref = None
-    for name, fn in (("A host feeder + coefficient upload", path_a), ("B device entropy decode", path_b)):
+    for name, fn in (("A host feeder + coefficient upload", path_a), ("B device entropy decode", path_b), ("C files -> pixels in one call", path_c)):
         best, best_first = 1e9, 0
         for _ in range(a.reps):
             torch.cuda.synchronize()

@@ -81,6 +81,8 @@ SIGNATURES = {
     "gamut_hip_qoi_read_header": (_i, [_vp, _i, C.POINTER(QoiDesc)]),
     "gamut_hip_qoi_decode_batch_device": (_i, [C.POINTER(_vp), C.POINTER(_i), _i, _i, C.POINTER(_i64), _vp, C.POINTER(QoiDesc), C.POINTER(_i), _vp]),
     "gamut_hip_qoi_decode_resident_device": (_i, [_vp, _i64, C.POINTER(_i64), C.POINTER(_i), C.POINTER(QoiDesc), _i, _i, C.POINTER(_i64), _vp, _vp]),
+    "gamut_hip_flip_device": (_i, [_i, _vp, _i64, _i64, _i, _i, _i, _i, _vp]),
+    "gamut_hip_flip": (_i, [_i, _vp, _i, _i, _i, _i]),
     "gamut_hip_jpeg_read_header": (_i, [_vp, _sz, C.POINTER(JpegFrame)]),
     "gamut_hip_jpeg_scan_layout": (_i, [_vp, _sz, C.POINTER(JpegFrame), C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
     "gamut_hip_jpeg_entropy_decode_device": (_i, [C.POINTER(_vp), C.POINTER(_sz), _i, C.POINTER(_i64), C.POINTER(_i64), _vp, _vp, _vp,

@@ -148,6 +148,8 @@ int convert_device(int srcType, const void* src, int64_t srcPitch, int64_t srcLa
                    int dstType, void* dst, int64_t dstPitch, int64_t dstLayerOffset,
                    int width, int height, int layers, hipStream_t stream);
 
+int flip_device(int type, void* data, int64_t pitch, int64_t layer_off, int w, int h, int layers, int vertical, hipStream_t st);   // flip.hip
+
 int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
                             const uint8_t* max_zag, int64_t zag_stride,
                             uint8_t* out, int64_t out_pitch, int64_t out_stride,

@@ -33,8 +33,10 @@ const char* const kStrIllegalNegativeDimension = "Illegal negative dimension";
 const char* const kStrIllegalLayoutConstraints = "Cannot satisfy illegal layout constraints";
 const char* const kStrOutOfMemory              = "Out of memory";
 const char* const kStrUnsupportedTypeConversion= "Unsupported image pixel type conversion";
-const char* const kStrUnsupportedVFlip         = "Can't flip image vertically";
+const char* const kStrUnsupportedVFlip __attribute__((unused)) = "Can't flip image vertically";   // (flipVerticalLogical under a VERT constraint: not reachable through flipVertical, which goes physical then)
 const char* const kStrOverlappingScanlines     = "Scanlines are overlapping";
+const char* const kStrOverlappingLayers        = "Layers are overlapping";
+const char* const kStrInvalidNegLayerOffset    = "Invalid negative layer offset";
 
 constexpr int  MAX_W = 16777216, MAX_H = 16777216, MAX_LAYERS = 4194303;          // types.d:103-110
 constexpr long long MAX_BYTES = 34359738368LL;                                     // types.d:117
@@ -476,16 +478,88 @@ int gamut_image_convert_to_greyscale_alpha(gamut_image* img, int layout)
 { return img->convertTo(convertPixelType(convertPixelType(img->_type, GAMUT_TO_GREYSCALE), GAMUT_TO_ADD_ALPHA), layout); }
 int gamut_image_convert_to_rgba(gamut_image* img, int layout)
 { return img->convertTo(convertPixelType(convertPixelType(img->_type, GAMUT_TO_RGB), GAMUT_TO_ADD_ALPHA), layout); }
-int gamut_image_flip_vertical(gamut_image* img)                                            // image.d:1524-1532, 1907-1924
+// in-place flips of every layer on the GPU (flip.hip): a device image as it lies, a host image layer by layer through the drop-in
+static int flip_pixels(gamut_image* img, int vertical)
+{
+    if (img->_device)
+        return gamut_hip_flip_device(img->_type, img->_data, img->_pitch, img->_layerOffset, img->_width, img->_height, img->_layerCount, vertical, nullptr) == GAMUT_HIP_OK &&
+               gamut_hip_stream_synchronize(nullptr) == GAMUT_HIP_OK;
+    for (int layer = 0; layer < img->_layerCount; ++layer)
+        if (gamut_hip_flip(img->_type, img->_data + (ptrdiff_t)layer * img->_layerOffset, img->_pitch, img->_width, img->_height, vertical) != GAMUT_HIP_OK) return 0;
+    return 1;
+}
+int gamut_image_flip_vertical(gamut_image* img)                                            // image.d:1524-1532
 {
     if (!img->isValid()) return 0;
     if (!img->hasData()) return 1;
-    if (img->_layoutConstraints & (GAMUT_LAYOUT_VERT_FLIPPED | GAMUT_LAYOUT_VERT_STRAIGHT)) {   // physical flip = re-layout on the GPU is not offered: report like the logical path
-        img->error(kStrUnsupportedVFlip); return 0;
-    }
-    if (img->_height >= 2) img->_data += (ptrdiff_t)img->_pitch * (img->_height - 1);
+    if (img->_layoutConstraints & (GAMUT_LAYOUT_VERT_FLIPPED | GAMUT_LAYOUT_VERT_STRAIGHT))   // a constraint pins the storage order: flipVerticalPhysical :1926-1954, the rows swap places
+        return flip_pixels(img, 1);
+    if (img->_height >= 2) img->_data += (ptrdiff_t)img->_pitch * (img->_height - 1);        // flipVerticalLogical :1907-1924 (flipScanlinePointers)
     img->_pitch = -img->_pitch;
     return 1;
+}
+int gamut_image_flip_horizontal(gamut_image* img)                                          // image.d:1475-1509
+{
+    if (!img->isValid()) return 0;
+    if (!img->hasData()) return 1;
+    return flip_pixels(img, 0);
+}
+
+// layer / layerRange (image.d:645-679): a view, NOT owned, of layers [start, end) -- a 0-layer view is legal
+gamut_image* gamut_image_layer_range(gamut_image* img, int layerStart, int layerEnd)
+{
+    gamut_image* res = new (std::nothrow) gamut_image();
+    if (!res) return nullptr;
+    if (!img->isValid() || !img->hasData() || layerStart > layerEnd || layerStart < 0 || layerEnd > img->_layerCount) return res;     // (asserts there): stays errored
+    res->clearError();
+    res->_data = img->_data + (ptrdiff_t)img->_layerOffset * layerStart;
+    res->_allocArea = nullptr;
+    res->_type = img->_type; res->_width = img->_width; res->_height = img->_height; res->_pitch = img->_pitch;
+    res->_layoutConstraints = GAMUT_LAYOUT_DEFAULT;
+    res->_layerCount = layerEnd - layerStart; res->_layerOffset = img->_layerOffset;
+    res->_device = img->_device;
+    return res;
+}
+// createLayeredView (image.d:706-752)
+int gamut_image_create_layered_view(gamut_image* img, void* data, int w, int h, int layers, int type, int pitch, int layerOffsetBytes)
+{
+    if (!img->forgetPreviousUsage(layers, w, h)) return 0;
+    if (!valid_type(type)) { img->error(kStrUnsupportedTypeConversion); return 0; }
+    const int minPitch = kPixelSize[type] * w, absPitch = pitch >= 0 ? pitch : -pitch;
+    if (absPitch < minPitch) { img->error(kStrOverlappingScanlines); return 0; }
+    if (layers > 1) {
+        if (layerOffsetBytes < 0) { img->error(kStrInvalidNegLayerOffset); return 0; }
+        if ((long long)layerOffsetBytes < (long long)absPitch * h) { img->error(kStrOverlappingLayers); return 0; }
+    }
+    img->_data = (uint8_t*)data; img->_allocArea = nullptr; img->_type = type; img->_width = w; img->_height = h; img->_pitch = pitch;
+    img->_layoutConstraints = GAMUT_LAYOUT_DEFAULT; img->_layerCount = layers; img->_layerOffset = (layers == 0 || layers == 1) ? 0 : layerOffsetBytes;
+    return 1;
+}
+// copyPixelsTo (image.d:811-841): same size, type and layer count (asserts there; 0 here), both with pixels, both in host memory
+// or both in HBM.  Rows go through the GPU copy path (K9, scanlinesCopy): one layered launch for device images.
+int gamut_image_copy_pixels_to(gamut_image* img, gamut_image* dst)
+{
+    if (!img->isValid() || !dst->isValid() || !img->hasData() || !dst->hasData()) return 0;
+    if (dst->_layerCount != img->_layerCount || dst->_width != img->_width || dst->_height != img->_height || dst->_type != img->_type || dst->_device != img->_device) return 0;
+    if (img->_width == 0 || img->_height == 0 || img->_layerCount == 0) return 1;
+    if (img->_device)
+        return gamut_hip_scanlines_convert_device(img->_type, img->_data, img->_pitch, img->_layerOffset, dst->_type, dst->_data, dst->_pitch, dst->_layerOffset,
+                                                  img->_width, img->_height, img->_layerCount, nullptr) == GAMUT_HIP_OK && gamut_hip_stream_synchronize(nullptr) == GAMUT_HIP_OK;
+    for (int layer = 0; layer < img->_layerCount; ++layer)
+        if (gamut_hip_scanlines_copy(img->_type, img->_data + (ptrdiff_t)layer * img->_layerOffset, img->_pitch,
+                                     dst->_data + (ptrdiff_t)layer * dst->_layerOffset, dst->_pitch, img->_width, img->_height) != GAMUT_HIP_OK) return 0;
+    return 1;
+}
+// clone (image.d:795-806): createLayeredNoInit with the same constraints, then copyPixelsTo; an errored image on failure
+gamut_image* gamut_image_clone(gamut_image* img)
+{
+    gamut_image* r = new (std::nothrow) gamut_image();
+    if (!r) return nullptr;
+    if (!img->isValid() || !valid_type(img->_type)) return r;
+    r->_device = img->_device;
+    if (!r->createLayered(img->_width, img->_height, img->_layerCount, img->_type, img->_layoutConstraints, false)) return r;
+    if (img->hasData() && !gamut_image_copy_pixels_to(img, r)) { r->cleanupBitmapIfOwned(); r->error(kStrImageDecodingFailed); }
+    return r;
 }
 
 // ---- device-resident storage (not in the reference) ----

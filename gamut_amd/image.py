@@ -19,7 +19,9 @@ IMAGE_SIGNATURES = {
     "gamut_image_load_from_memory": (_i, [_vp, _vp, _sz, _i]),
     "gamut_image_convert_to": (_i, [_vp, _i, _i]), "gamut_image_set_layout": (_i, [_vp, _i]), "gamut_image_convert_op": (_i, [_vp, _i, _i]),
     "gamut_image_convert_to_greyscale_alpha": (_i, [_vp, _i]), "gamut_image_convert_to_rgba": (_i, [_vp, _i]),
-    "gamut_image_flip_vertical": (_i, [_vp]),
+    "gamut_image_flip_vertical": (_i, [_vp]), "gamut_image_flip_horizontal": (_i, [_vp]),
+    "gamut_image_layer_range": (_vp, [_vp, _i, _i]), "gamut_image_create_layered_view": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i]),
+    "gamut_image_clone": (_vp, [_vp]), "gamut_image_copy_pixels_to": (_i, [_vp, _vp]),
     "gamut_image_type": (_i, [_vp]), "gamut_image_width": (_i, [_vp]), "gamut_image_height": (_i, [_vp]), "gamut_image_layers": (_i, [_vp]),
     "gamut_image_pitch_in_bytes": (_i, [_vp]), "gamut_image_layer_offset_in_bytes": (_i, [_vp]), "gamut_image_scanline_in_bytes": (_i, [_vp]),
     "gamut_image_layout_constraints": (_i, [_vp]), "gamut_image_is_error": (_i, [_vp]), "gamut_image_is_valid": (_i, [_vp]),
@@ -56,9 +58,13 @@ LAYOUT_BORDER = {0: 0, 1: 128, 2: 256, 3: 384}
 class Image:
     """struct Image (image.d:85).  A fresh Image is in the error state ("Uninitialized image")."""
 
-    def __init__(self, device=False):
+    def __init__(self, device=False, _handle=None, _keep=None):
         """device=True: pixel storage in HBM (an extension, see include/gamut_image.h): loads and convertTo chains stay on the GPU"""
         self.L = lib()
+        self._keep = _keep                                     # a view keeps the image whose pixels it borrows alive
+        if _handle is not None:
+            self.h = _handle
+            return
         self.h = self.L.gamut_image_new()
         if device and not self.L.gamut_image_set_device_storage(self.h, 1):
             raise RuntimeError("device storage needs a GPU")
@@ -98,6 +104,17 @@ class Image:
     def premultiply(self, layout=0): return self.convertOp(TO_PREMUL, layout)
     def unpremultiply(self, layout=0): return self.convertOp(TO_NO_PREMUL, layout)
     def flipVertical(self): return bool(self.L.gamut_image_flip_vertical(self.h))
+    def flipHorizontal(self): return bool(self.L.gamut_image_flip_horizontal(self.h))
+
+    # views and copies
+    def layerRange(self, start, end): return Image(_handle=self.L.gamut_image_layer_range(self.h, start, end), _keep=self)
+    def layer(self, index): return self.layerRange(index, index + 1)
+    def clone(self): return Image(_handle=self.L.gamut_image_clone(self.h))
+    def copyPixelsTo(self, other): return bool(self.L.gamut_image_copy_pixels_to(self.h, other.h))
+
+    def createLayeredView(self, array, w, h, layers, type, pitch, layer_offset):
+        self._view_keepalive = array
+        return bool(self.L.gamut_image_create_layered_view(self.h, array.ctypes.data if pitch >= 0 else array.ctypes.data + (h - 1) * -pitch, w, h, layers, type, pitch, layer_offset))
 
     # state
     @property

@@ -99,6 +99,12 @@ int gamut_hip_scanlines_convert_device(int srcType, const void* src, int64_t src
                                        int dstType, void* dst, int64_t dstPitch, int64_t dstLayerOffset,
                                        int width, int height, int layers, void* stream);
 
+/* Image.flipHorizontal (image.d:1475-1509) / flipVerticalPhysical (:1926-1954) in place: pixel x <-> pixel W - 1 - x of every
+ * row, or row y <-> row H - 1 - y, of every layer.  Device pointers + signed pitch + layer offset, asynchronous; the host variant
+ * stages one image through the GPU (up, flip, down) like the other host drop-ins. */
+int gamut_hip_flip_device(int type, void* data, int64_t pitch, int64_t layerOffset, int width, int height, int layers, int vertical, void* stream);
+int gamut_hip_flip(int type, uint8_t* data, int pitch, int width, int height, int vertical);
+
 /* ---- K1-K4: JPEG block reconstruction --------------------------------------
  * replaces transform_mcu / transform_mcu_expand (jpegload.d:2120-2255), the
  * *Convert row functions (:2528-2823) and the output packing of

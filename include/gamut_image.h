@@ -78,7 +78,16 @@ int gamut_image_set_layout(gamut_image* img, int layout);
 int gamut_image_convert_op(gamut_image* img, int op, int layout);      /* convertToGreyscale ... convertToFP32 by GAMUT_TO_* */
 int gamut_image_convert_to_greyscale_alpha(gamut_image* img, int layout);
 int gamut_image_convert_to_rgba(gamut_image* img, int layout);
-int gamut_image_flip_vertical(gamut_image* img);                       /* image.d:1524 (logical flip) */
+int gamut_image_flip_vertical(gamut_image* img);                       /* image.d:1524: the logical flip (pitch negated), or -- when a LAYOUT_VERT_* constraint
+                                                                          pins the storage order -- flipVerticalPhysical (:1926-1954), rows swapped on the GPU */
+int gamut_image_flip_horizontal(gamut_image* img);                     /* image.d:1475-1509, pixels swapped on the GPU */
+/* views and copies (image.d:645-679, 706-752, 795-841).  The returned images are new objects (gamut_image_delete them): a view
+ * borrows the pixels (not owned, LAYOUT_DEFAULT), a clone owns its own with the source's layout constraints; both are errored
+ * images when the arguments are not what the reference asserts. */
+gamut_image* gamut_image_layer_range(gamut_image* img, int layerStart, int layerEnd);     /* layer(i) = layer_range(i, i + 1) */
+int gamut_image_create_layered_view(gamut_image* img, void* data, int width, int height, int layers, int type, int pitchInBytes, int layerOffsetBytes);
+gamut_image* gamut_image_clone(gamut_image* img);
+int gamut_image_copy_pixels_to(gamut_image* img, gamut_image* dst);
 
 /* state (image.d:97-551, 1405-1459) */
 int   gamut_image_type(const gamut_image* img);

@@ -2,6 +2,8 @@
 They mirror the reference's in-source unittests (image.d:1964-2326, internals/types.d:170-236, 610-620);
 no pixel operation is involved, so no GPU is needed."""
 import numpy as np
+
+from gamut_amd import _capi
 import pytest
 
 from gamut_amd import image as gi
@@ -125,13 +127,40 @@ def test_layered_images_and_views():
 
 
 def test_flip_vertical_logical():
-    """image.d:2257-2326: logical flip negates the pitch; refused when a vertical constraint is set"""
+    """image.d:1524-1532, 1907-1924: the logical flip negates the pitch; under a vertical constraint flipVertical is the PHYSICAL
+    flip (rows swapped, on the GPU: tests/test_image_gpu.py), which without a GPU fails and leaves the image as it was"""
     im = Image()
     assert im.create(3, 4, PT["l8"])
     p0, pitch = im.scanptr(0), im.pitchInBytes
     assert im.flipVertical() and im.pitchInBytes == -pitch and im.scanptr(0) == p0 + 3 * pitch and im.scanptr(3) == p0
     assert im.flipVertical() and im.scanptr(0) == p0
-    assert im.create(3, 4, PT["l8"], gi.LAYOUT_VERT_STRAIGHT) and not im.flipVertical() and im.errorMessage == "Can't flip image vertically"
+    assert im.create(3, 4, PT["l8"], gi.LAYOUT_VERT_STRAIGHT)
+    p0 = im.scanptr(0)
+    if _capi.lib().gamut_hip_device_count() == 0:
+        assert not im.flipVertical() and im.isValid and im.scanptr(0) == p0 and im.pitchInBytes > 0
+    assert im.createWithNoData(3, 4, PT["l8"]) and im.flipVertical() and im.flipHorizontal()      # no data: nothing to do, success
+
+
+def test_layer_views_and_layered_views():
+    """layer / layerRange (image.d:645-679) and createLayeredView (:706-752): borrowed pixels, LAYOUT_DEFAULT, the reference's checks"""
+    im = Image()
+    assert im.createLayered(5, 3, 4, PT["la8"], gi.LAYOUT_ALIGNED[8])
+    v = im.layerRange(1, 3)
+    assert v.isValid and v.hasData and not v.isOwned and v.layers == 2 and v.layoutConstraints == 0
+    assert (v.width, v.height, v.type, v.pitchInBytes, v.layerOffsetInBytes) == (5, 3, PT["la8"], im.pitchInBytes, im.layerOffsetInBytes)
+    assert v.layerptr(0, 0) == im.layerptr(1, 0) and v.layerptr(1, 2) == im.layerptr(2, 2)
+    one = im.layer(3)
+    assert one.layers == 1 and one.scanptr(0) == im.layerptr(3, 0)
+    assert im.layerRange(2, 2).layers == 0 and im.layerRange(2, 2).isValid           # "it must be supported to return a 0-layer view"
+    assert im.layerRange(3, 5).isError and im.layerRange(-1, 1).isError              # asserts in the reference: errored images here
+    buf = np.arange(2 * 3 * 8, dtype=np.uint8)
+    w = Image()
+    assert w.createLayeredView(buf, 4, 3, 2, PT["la8"], 8, 24) and w.layers == 2 and w.layerOffsetInBytes == 24 and not w.isOwned
+    assert np.array_equal(w.pixels(1).reshape(-1), buf[24:48])
+    assert w.createLayeredView(buf, 4, 3, 1, PT["la8"], 8, 999) and w.layerOffsetInBytes == 0     # one layer: the offset is ignored
+    assert not w.createLayeredView(buf, 4, 3, 2, PT["la8"], 8, 23) and w.errorMessage == "Layers are overlapping"
+    assert not w.createLayeredView(buf, 4, 3, 2, PT["la8"], 8, -24) and w.errorMessage == "Invalid negative layer offset"
+    assert not w.createLayeredView(buf, 4, 3, 2, PT["la8"], 7, 24) and w.errorMessage == "Scanlines are overlapping"
 
 
 def test_convert_to_without_pixels_needs_no_gpu():

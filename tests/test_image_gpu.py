@@ -12,6 +12,7 @@ import gen
 import oracle_lib as O
 from gamut_amd import image as gi
 from gamut_amd.image import Image
+from gamut_amd import _capi
 from oracle_lib import PIXEL_TYPES, PT, PT_SIZE
 
 pytestmark = pytest.mark.gpu
@@ -213,6 +214,54 @@ def test_device_resident_images(hip):
     for layer in range(3):
         assert np.array_equal(a.pixels(layer), b.pixels(layer))
     assert not Image(device=True).loadFromMemory(b"garbage", 0)
+
+
+@pytest.mark.parametrize("device", [False, True], ids=["host", "hbm"])
+def test_flips_clone_and_copy(hip, device):
+    """flipHorizontal (image.d:1475-1509), flipVertical under a vertical constraint = flipVerticalPhysical (:1926-1954), clone /
+    copyPixelsTo (:795-841), on layered images of every pixel size, host and HBM storage, straight and upside-down storage"""
+    rng = np.random.default_rng(4)
+    for tname, w, h, layers, layout in [("l8", 7, 5, 1, 0), ("rgb8", 6, 4, 3, gi.LAYOUT_ALIGNED[16] | gi.LAYOUT_BORDER[1]), ("rgba8", 33, 9, 2, gi.LAYOUT_VERT_FLIPPED),
+                                        ("la16", 5, 2, 2, gi.LAYOUT_VERT_STRAIGHT), ("rgb16", 4, 3, 1, gi.LAYOUT_TRAILING[3]), ("rgbaf32", 9, 7, 2, gi.LAYOUT_GAPLESS),
+                                        ("rgbf32", 3, 1, 1, 0), ("rgba16", 1, 6, 2, 0)]:
+        t = PT[tname]
+        src = [rng.integers(0, 256, (h, w * O.PT_SIZE[t]), dtype=np.uint8) for _ in range(layers)]
+        host = Image()
+        views = []
+        for a in src:                                            # fill through convertTo-free means: a view per layer copied in
+            v = Image(); assert v.createView(a, w, h, t, a.shape[1]); views.append(v)
+        im = Image(device=device)
+        assert im.createLayered(w, h, layers, t, layout)
+        for k, v in enumerate(views):
+            stage = Image(device=device)
+            assert stage.createLayered(w, h, 1, t, 0)
+            if device:
+                import ctypes as C
+                for y in range(h):
+                    _capi.check(hip.gamut_hip_memcpy_h2d(stage.scanptr(y), src[k][y].ctypes.data, src[k].shape[1], None))
+                _capi.check(hip.gamut_hip_stream_synchronize(None))
+            else:
+                assert v.copyPixelsTo(stage)
+            assert stage.copyPixelsTo(im.layer(k))
+        px = lambda img: [img.pixels(k) for k in range(layers)]
+        assert all(np.array_equal(a, b) for a, b in zip(px(im), src))
+        c = im.clone()
+        assert c.isValid and c.isOwned and c.layoutConstraints == im.layoutConstraints and c.scanptr(0) != im.scanptr(0) and c.isDevice == device
+        assert all(np.array_equal(a, b) for a, b in zip(px(c), src))
+        ps = O.PT_SIZE[t]
+        assert im.flipHorizontal()
+        assert all(np.array_equal(a, b.reshape(h, w, ps)[:, ::-1].reshape(h, w * ps)) for a, b in zip(px(im), src))
+        assert all(np.array_equal(a, b) for a, b in zip(px(c), src)), "the clone shares nothing with its source"
+        p0, pitch0 = im.scanptr(0), im.pitchInBytes
+        assert im.flipVertical()
+        exp = [b.reshape(h, w, ps)[::-1, ::-1].reshape(h, w * ps) for b in src]
+        assert all(np.array_equal(a, b) for a, b in zip(px(im), exp))
+        if layout & (gi.LAYOUT_VERT_FLIPPED | gi.LAYOUT_VERT_STRAIGHT):
+            assert im.scanptr(0) == p0 and im.pitchInBytes == pitch0, "a vertical constraint pins the storage order: the rows moved"
+        else:
+            assert im.pitchInBytes == -pitch0
+        other = Image(device=device)
+        assert other.createLayered(w + 1, h, layers, t, 0) and not im.copyPixelsTo(other)           # size mismatch (an assert in the reference)
 
 
 def test_concurrent_host_threads(hip):

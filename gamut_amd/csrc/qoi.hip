@@ -111,6 +111,9 @@ template <int CTRL, int ROWMASK> __device__ __forceinline__ void qoi_scan_step(Q
     qoi_add_scan_step<CTRL, ROWMASK>(n);
 }
 
+#ifndef QOI_DIRECT_RGBA           // tuning knob (tools/variant.sh): 0 = RGBA outputs through the LDS pixel buffer like RGB ones
+#define QOI_DIRECT_RGBA 1
+#endif
 #ifndef QOI_PROFILE               // measurement only (tools/variant.sh qoi:prof:-DQOI_PROFILE=1): cycles per phase of wave 0, summed over streams
 #define QOI_PROFILE 0
 #endif
@@ -133,6 +136,12 @@ __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* it
     __shared__ __attribute__((aligned(16))) uint32_t obuf[kQoiWaves > 1 ? 4 : kQoiOutCap];     // W = 1: pixels on their way out
     __shared__ uint32_t xs[kQoiWaves > 1 ? kQoiWin : 1], gpos[kQoiWin / 64], gdone;           // W = 4: per op its pixel; per group its first pixel's index
     __shared__ uint32_t wave_map[kQoiWaves], wave_cnt[kQoiWaves], go_on;
+    // an op's function by its first byte: x = V (DIFF: the deltas; LUMA: vg - 8, vg, vg - 8 -- the second byte's nibbles are added per
+    // op), y = run length | is_index << 8 | sets bytes from the stream (RGB / RGBA) << 9 | M sets the colour bytes << 10 | M sets all
+    // bytes << 11 | a LUMA op's nibble mask in bits 16-19 -- one 8-byte LDS read instead of ~25 instructions of field extraction and
+    // selects per op; entry 256 = no op (a lane past the window's last op).  (8 bytes, not M and U spelled out in 16: with 14.3 KB
+    // of LDS per stream a CU holds 10 streams, 2560 in all, and config 5's 2730 took a second round: 44.5 -> 61 ms.)
+    __shared__ uint2 lut[257];
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     struct __attribute__((packed, aligned(1))) AnyVec { u32x4 v; };               // 16 bytes at any address
     struct __attribute__((packed, aligned(1))) AnyU32 { uint32_t v; };
@@ -144,6 +153,7 @@ __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* it
     if ((int)blockIdx.x >= n_items) return;
     const QoiItem it = items[blockIdx.x];
     const bool rgba = it.channels == 4;
+    const bool rgba_out = rgba && QOI_DIRECT_RGBA;            // W = 1: RGBA pixels are stored from the registers (emit_buffered)
     uint8_t* pixels = out + it.out_off;
     const uint8_t* stream = blob + it.begin + kQoiHeader;     // chunks start here
     // bytes [14, size - 8) are chunks (p < chunks_len, :498); a chunk may read up to 4 bytes further (padding / slack)
@@ -153,6 +163,17 @@ __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* it
 
     if (t < 64) table[t] = 0;                                 // memset(index, 0) :491
     if (t == 0) go_on = 1;
+    for (uint32_t b1 = (uint32_t)t; b1 < 257u; b1 += (uint32_t)kQoiT) {
+        const uint32_t top = b1 >> 6, vg = (b1 & 63u) - 32u;
+        const bool is_rgb = b1 == 0xFEu, is_rgba = b1 == 0xFFu, none = b1 == 256u;
+        const uint32_t v_diff = ((((b1 >> 4) & 3u) - 2u) & 255u) | ((((b1 >> 2) & 3u) - 2u) & 255u) << 8 | (((b1 & 3u) - 2u) & 255u) << 16;
+        const uint32_t v_luma = ((vg - 8u) & 255u) | (vg & 255u) << 8 | ((vg - 8u) & 255u) << 16;
+        uint2 e;
+        e.x = none ? 0u : top == 1u ? v_diff : top == 2u ? v_luma : 0u;
+        e.y = (none ? 0u : (top == 3u && !is_rgb && !is_rgba) ? 1u + (b1 & 63u) : 1u) | ((!none && top == 0u) ? 1u << 8 : 0u) | ((!none && top == 2u) ? 0x000F0000u : 0u) |
+              ((!none && (is_rgb || is_rgba)) ? 1u << 9 : 0u) | ((!none && is_rgb) ? 1u << 10 : 0u) | ((!none && (is_rgba || top == 0u)) ? 1u << 11 : 0u);
+        lut[b1] = e;
+    }
     uint32_t carry = 0xFF000000u;                             // r = g = b = 0, a = 255 :492-495                (wave 0's state from here ...)
     uint32_t produced = 0, ops_done = 0;                      // pixels decoded, ops decoded
     uint32_t fill = 0; size_t flushed = 0;                    // pixels waiting in obuf, pixels already in the image
@@ -262,20 +283,17 @@ __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* it
                 const uint32_t sh = 8 * (o & 3);
                 lo = __builtin_amdgcn_alignbit(w1, w0, sh); hi = __builtin_amdgcn_alignbit(w2, w1, sh);
             }
-            const uint32_t b1 = lo & 255u, top = b1 >> 6, b2 = (lo >> 8) & 255u;
-            const bool is_rgb = b1 == 0xFEu, is_rgba = b1 == 0xFFu;
-            const bool is_run = top == 3u && !is_rgb && !is_rgba;
-            const uint32_t vg = (b1 & 63u) - 32u;
-            const uint32_t v_diff = ((((b1 >> 4) & 3u) - 2u) & 255u) | ((((b1 >> 2) & 3u) - 2u) & 255u) << 8 | (((b1 & 3u) - 2u) & 255u) << 16;
-            const uint32_t v_luma = ((vg - 8u + (b2 >> 4)) & 255u) | (vg & 255u) << 8 | ((vg - 8u + (b2 & 15u)) & 255u) << 16;
+            const uint32_t b1 = lo & 255u, b2 = (lo >> 8) & 255u;
+            const uint2 e = lut[active ? b1 : 256u];
             const uint32_t v_abs = __builtin_amdgcn_alignbit(hi, lo, 8);                          // stream bytes 1..4
+            const uint32_t nib = ((b2 >> 4) | (b2 & 15u) << 16) & (e.y >> 16 | (e.y & 0x000F0000u));  // LUMA: dr - dg + 8, db - dg + 8 (:528-530); else 0
             Group G;
-            G.is_index = active && top == 0u;
+            G.is_index = (e.y >> 8 & 1u) != 0;
             G.b1 = b1;
-            G.f.M = !active ? 0u : is_rgb ? 0x00FFFFFFu : (is_rgba || top == 0u) ? 0xFFFFFFFFu : 0u;
-            G.f.U = G.is_index ? 0xFFFFFFFFu : 0u;
-            G.f.V = !active ? 0u : is_rgb ? (v_abs & 0x00FFFFFFu) : is_rgba ? v_abs : top == 1u ? v_diff : top == 2u ? v_luma : 0u;
-            G.npx = !active ? 0u : is_run ? 1u + (b1 & 63u) : 1u;
+            G.f.M = (uint32_t)((int32_t)(e.y << 20) >> 31) | ((uint32_t)((int32_t)(e.y << 21) >> 31) & 0x00FFFFFFu);      // bit 11: all, bit 10: colour
+            G.f.U = (uint32_t)((int32_t)(e.y << 23) >> 31);                                                             // bit 8: an INDEX op
+            G.f.V = (e.y >> 9 & 1u) ? (v_abs & G.f.M) : qoi_add_bytes(e.x, nib);                  // RGB / RGBA: the bytes the op sets
+            G.npx = e.y & 0xFFu;
             G.run_incl = G.npx;
             qoi_scan_step<0x111, 0xF>(G.f, G.run_incl); qoi_scan_step<0x112, 0xF>(G.f, G.run_incl); qoi_scan_step<0x114, 0xF>(G.f, G.run_incl);
             qoi_scan_step<0x118, 0xF>(G.f, G.run_incl); qoi_scan_step<0x142, 0xA>(G.f, G.run_incl); qoi_scan_step<0x143, 0xC>(G.f, G.run_incl);
@@ -316,6 +334,16 @@ __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* it
             const uint32_t off = G.run_incl - G.npx, room = npx_total - first_px;   // (room >= 1: the loop stops once the image is full)
             const uint32_t npx = off >= room ? 0u : (G.npx < room - off ? G.npx : room - off);
             const uint32_t total = produced - first_px;                            // wave-uniform
+            // RGBA outputs leave from the registers: a pixel is a dword, 64 consecutive ops are 64 consecutive dwords (runs aside), and the
+            // lines they share with the groups before and after meet in L2 -- no LDS write, no read back, no rows to shuffle: a fifth fewer
+            // instructions per group, which is what a batch's time is made of.  (RGB outputs are 3 bytes per pixel: they keep the buffer,
+            // which packs them into whole dwords.)  Long runs of either kind go straight to the image too.
+            if (rgba_out) {
+                if (npx) store_px((size_t)first_px + off, x);
+                if (__any(npx > 1u)) for (uint32_t r = 1; __any(r < npx); ++r) if (r < npx) store_px((size_t)first_px + off + r, x);
+                flushed = produced;
+                return;
+            }
             if (total > (uint32_t)kQoiBufGroup) {             // long runs: what waits in the buffer leaves, then the group's pixels go straight to the image
                 for (uint32_t i = lane; i < fill; i += 64) store_px(flushed + i, obuf[i]);
                 for (uint32_t r = 0; __any(r < npx); ++r) if (r < npx) store_px((size_t)first_px + off + r, x);

@@ -29,6 +29,11 @@ def main():
     L.gamut_hip_qoi_read_header.argtypes = [C.c_void_p, C.c_int, C.POINTER(_capi.QoiDesc)]
     L.gamut_hip_stbi_load_from_memory.restype = C.c_void_p
     L.gamut_hip_stbi_load_from_memory.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3
+    L.gamut_hip_decompress_jpeg_image_from_stream.restype = C.c_void_p
+    L.gamut_hip_decompress_jpeg_image_from_stream.argtypes = [_capi.JPEG_STREAM_READ_FUNC, C.c_void_p] + [C.c_void_p] * 5 + [C.c_int]
+    L.gamut_hip_stbi_load_from_callbacks.restype = C.c_void_p
+    L.gamut_hip_stbi_load_from_callbacks.argtypes = [C.POINTER(_capi.StbiIoCallbacks), C.c_void_p] + [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3
+    L.gamut_hip_stbi_png_is16_from_callbacks.argtypes = [C.POINTER(_capi.StbiIoCallbacks), C.c_void_p]
     G = os.path.join(ROOT, "tests", "golden")
     seeds = [open(p, "rb").read() for p in sorted(glob.glob(os.path.join(G, "jpeg", "*.jpg")) + glob.glob(os.path.join(G, "ref_images", "*")))]
     seeds.append(gen.qoi_encode(gen.synth_rgb(33, 9, 1)))
@@ -63,6 +68,37 @@ def main():
         x, y, c = C.c_int(), C.c_int(), C.c_int(); f = C.c_float()
         L.gamut_hip_stbi_load_from_memory(buf, n, C.byref(x), C.byref(y), C.byref(c), 0, C.byref(f), C.byref(f), C.byref(f))
         L.gamut_hip_qoi_read_header(buf, min(n, 2**31 - 1), C.byref(_capi.QoiDesc()))
+        # the stream gatherers (stream_host.hip): the same bytes through callbacks that hand out odd-sized pieces, lie about skips, or fail
+        raw = bytes(data)
+        piece = int(rng.choice([1, 3, 7, 100, 4096, 1 << 20]))
+        st = {"pos": 0}
+
+        def rd_jpeg(pbuf, max_bytes, peof, user):
+            k = max(0, min(max_bytes, piece, len(raw) - st["pos"]))
+            C.memmove(pbuf, raw[st["pos"]:st["pos"] + k], k); st["pos"] += k
+            if st["pos"] >= len(raw):
+                peof[0] = 1
+            return k
+        w_, h_, c_ = C.c_int(), C.c_int(), C.c_int()
+        L.gamut_hip_decompress_jpeg_image_from_stream(_capi.JPEG_STREAM_READ_FUNC(rd_jpeg), None, C.byref(w_), C.byref(h_), C.byref(c_), None, None, 4)
+        st["pos"] = 0
+
+        def rd_stb(user, buf_, size):
+            k = max(0, min(size, piece, len(raw) - st["pos"]))
+            C.memmove(buf_, raw[st["pos"]:st["pos"] + k], k); st["pos"] += k
+            return k
+
+        def skip_stb(user, k):
+            st["pos"] = max(0, min(len(raw) + 5, st["pos"] + k))        # may run past the end, as a file seek would
+
+        def eof_stb(user):
+            return int(st["pos"] >= len(raw))
+        cb = _capi.StbiIoCallbacks()
+        keep = (type(cb.read)(rd_stb), type(cb.skip)(skip_stb), type(cb.eof)(eof_stb))
+        cb.read, cb.skip, cb.eof = keep
+        L.gamut_hip_stbi_load_from_callbacks(C.byref(cb), None, C.byref(x), C.byref(y), C.byref(c), 0, None, None, None)
+        st["pos"] = 0
+        L.gamut_hip_stbi_png_is16_from_callbacks(C.byref(cb), None)
     print(f"fuzz_host: {iters} mutated inputs, {ok} decoded, {bad} rejected, no sanitizer report")
 
 

@@ -2,14 +2,14 @@
 //
 // Replaces, for a batch, stbi_zlib_decode_malloc_guesssize_headerflag (stbdec.d:1267-1321 -> the `miniz` inflate): IDAT
 // streams resident in HBM are inflated straight into the arena the de-filter kernels read (png.hip), so a file batch no
-// longer waits for sixteen host threads running zlib.  One 256-thread workgroup per stream; inside a stream:
+// longer waits for sixteen host threads running zlib.  One workgroup of kT = 512 threads per stream; inside a stream:
 //
 //   * block headers and the code-length alphabet of a dynamic block are read by one thread (a few hundred bits); the two
 //     canonical Huffman codes are turned into lookup tables by all threads (counting by LDS atomics, ranks, one table entry
 //     per thread and pass);
-//   * the block's symbols are decoded 4 KiB at a time, SPECULATIVELY: lane k starts at bit 128 k of the chunk as if a
+//   * the block's symbols are decoded 8 KiB at a time (kT lanes x 128 bits), SPECULATIVELY: lane k starts at bit 128 k of the chunk as if a
 //     token began there, lanes then restart from their predecessor's exit position until nothing moves -- Huffman streams
-//     re-synchronise within a few tokens, so two or three sweeps settle all 256 lanes (the chain is exact from lane 0 on,
+//     re-synchronise within a few tokens, so a few sweeps settle all the lanes (the chain is exact from lane 0 on,
 //     and a lane that meets the end-of-block code, an invalid code or its output cap ends the chunk there);
 //   * a prefix sum of the lanes' output bytes places everything: a last sweep writes the literals into a 64 KiB ring in LDS
 //     (the 32 KiB window plus the chunk's output) and, for every byte a match produces, the position it copies from;
@@ -34,7 +34,7 @@ namespace {
 #endif
 constexpr int kT = INFLATE_T;                        // threads per stream
 constexpr int kSubBits = INFLATE_SUB_BITS;           // compressed bits a lane owns per chunk
-constexpr int kChunkBytes = kT * kSubBits / 8;       // 4096
+constexpr int kChunkBytes = kT * kSubBits / 8;       // 8192
 constexpr int kWinDwords = kChunkBytes / 4 + 8;      // + 32 bytes: the last lane runs up to 47 bits past its end and peeks 64 bits from there
 constexpr int kRing = 65536, kRingMask = kRing - 1;
 constexpr int kNewMax = INFLATE_NEW_MAX;              // bytes a chunk may add to the ring: the 32 KiB history must survive them

@@ -40,8 +40,14 @@ constexpr int kRing = 65536, kRingMask = kRing - 1;
 constexpr int kNewMax = INFLATE_NEW_MAX;              // bytes a chunk may add to the ring: the 32 KiB history must survive them
 constexpr int kLaneOutMax = 8192;                    // a lane stops early beyond this (ends the chunk: pathological match runs)
 constexpr int kHist = 32768;                         // DEFLATE's window
-constexpr int kLongMin = 32, kLongCap = 1024;        // matches at least this long are expanded by a whole wave, not by their lane
-constexpr int kLitBits = 11, kDistBits = 10;         // primary lookup widths; longer codes take the canonical search
+#ifndef INFLATE_LONG_CAP
+#define INFLATE_LONG_CAP 1024
+#endif
+#ifndef INFLATE_LIT_BITS
+#define INFLATE_LIT_BITS 11
+#endif
+constexpr int kLongMin = 32, kLongCap = INFLATE_LONG_CAP;        // matches at least this long are expanded by a whole wave, not by their lane
+constexpr int kLitBits = INFLATE_LIT_BITS, kDistBits = 10;         // primary lookup widths; longer codes take the canonical search
 
 enum : uint32_t { F_EOB = 1, F_BAD = 2, F_EARLY = 4 };
 // status word per stream (0 = ok)

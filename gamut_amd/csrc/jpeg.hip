@@ -117,6 +117,9 @@ __device__ __forceinline__ void store_px_nt(uint8_t* row_base, u32 voff, u32 px)
 #ifndef JPEG_UNROLL_STRIPS        // 1 = the strip loop fully unrolled (exact s_waitcnt vmcnt counts across the strips' stores)
 #define JPEG_UNROLL_STRIPS 0
 #endif
+// strips per workgroup of k_jpeg_plain, by sampling mode (A/B on one box, 1024 x 1080p -> rgba8, 1 / 2 / 4 / 8 strips: grey 1.69 / 1.56 /
+// 1.49 / 1.47 ms, 4:4:4 5.77 / 5.44 / 5.44 / 5.29 ms, 4:2:2 3.32 / 3.48 / 3.42 / 3.46 ms, 4:4:0 3.39 / 3.34 / 3.42 / 3.45 ms)
+constexpr int plain_strips(int scan_type) { return (scan_type == GAMUT_JPGD_GRAYSCALE || scan_type == GAMUT_JPGD_YH1V1) ? 8 : 1; }
 #ifndef JPEG_ABLATE               // measurement only (tools/variant.sh): 1 = loads + stores, no arithmetic; 2 = no stores; 3 = no loads
 #define JPEG_ABLATE 0
 #endif
@@ -434,7 +437,14 @@ __global__ __launch_bounds__(256) void k_jpeg_plain(JpegArgs a)
     __shared__ __attribute__((aligned(16))) uint8_t S[NBLK * 64];
 
     const int t = threadIdx.x;
-    const int img = blockIdx.z, mcu_y = blockIdx.y, mcu_x0 = blockIdx.x * MCUS;
+    const int img = blockIdx.z, mcu_y = blockIdx.y;
+    // A strip is 3-4 KB of coefficients in and 2-4 KB of pixels out: a workgroup per strip made the launch millions of workgroups
+    // (1024 x 1080p 4:4:4: 4.1 M) that the dispatcher hands out slower than the kernel could run them.  A workgroup takes
+    // PLAIN_STRIPS consecutive strips of its MCU row where that pays (plain_strips).
+    constexpr int PLAIN_STRIPS = plain_strips(ST);
+    for (int strip = 0; strip < PLAIN_STRIPS; ++strip) {
+    const int mcu_x0 = (blockIdx.x * PLAIN_STRIPS + strip) * MCUS;
+    if (mcu_x0 >= a.mcus_per_row) break;                          // workgroup-uniform
     const int64_t blk0 = ((int64_t)mcu_y * a.mcus_per_row + mcu_x0) * BPM;
     const int16_t* cbase = a.coeffs + (int64_t)img * a.coeff_stride + blk0 * 64;
     const int mcus_here = min(MCUS, a.mcus_per_row - mcu_x0);
@@ -520,6 +530,8 @@ __global__ __launch_bounds__(256) void k_jpeg_plain(JpegArgs a)
         } else {
             for (int k = 0; k < npx * OC; ++k) o[k] = (uint8_t)(w[k >> 2] >> ((k & 3) * 8));
         }
+    }
+    __syncthreads();                                              // T1 / S are rewritten by the next strip
     }
 }
 
@@ -708,7 +720,9 @@ int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
         // tuned kernels: rgba8 needs dword-aligned rows; rgb8 / l8 rows may start anywhere (unaligned dword stores)
         const bool tuned = out_pitch > 0 && out_pitch < (1 << 27) &&
                            (out_comps != 4 || (((uintptr_t)out & 3) == 0 && (out_pitch & 3) == 0 && (out_stride & 3) == 0));
-        const dim3 grid32((a.mcus_per_row + 31) / 32, a.mcus_per_col, n);           // grey: 32 MCUs per workgroup
+        const int ps = plain_strips(scan_type);
+        const dim3 grid32(((a.mcus_per_row + 31) / 32 + ps - 1) / ps, a.mcus_per_col, n);           // grey: 32 MCUs per strip
+        const dim3 grid_plain((tiles + ps - 1) / ps, a.mcus_per_col, n);
         const int strips420 = out_comps == 4 ? JPEG_STRIPS : JPEG_STRIPS_PACKED;
         const unsigned groups420 = (unsigned)(((a.mcus_per_row + H2V2_MCUS - 1) / H2V2_MCUS + strips420 - 1) / strips420);
 #if JPEG_XCD_REMAP
@@ -722,9 +736,9 @@ int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
             else                     hipLaunchKernelGGL((k_jpeg_plain<ST, 1>), G, dim3(256), 0, stream, c); } while (0)
         if (!tuned)                                   hipLaunchKernelGGL(k_jpeg_generic, grid, dim3(256), 0, stream, c);
         else if (scan_type == GAMUT_JPGD_GRAYSCALE)   GAMUT_JPEG_PLAIN(GAMUT_JPGD_GRAYSCALE, grid32);
-        else if (scan_type == GAMUT_JPGD_YH1V1)       GAMUT_JPEG_PLAIN(GAMUT_JPGD_YH1V1, grid);
-        else if (scan_type == GAMUT_JPGD_YH2V1)       GAMUT_JPEG_PLAIN(GAMUT_JPGD_YH2V1, grid);
-        else if (scan_type == GAMUT_JPGD_YH1V2)       GAMUT_JPEG_PLAIN(GAMUT_JPGD_YH1V2, grid);
+        else if (scan_type == GAMUT_JPGD_YH1V1)       GAMUT_JPEG_PLAIN(GAMUT_JPGD_YH1V1, grid_plain);
+        else if (scan_type == GAMUT_JPGD_YH2V1)       GAMUT_JPEG_PLAIN(GAMUT_JPGD_YH2V1, grid_plain);
+        else if (scan_type == GAMUT_JPGD_YH1V2)       GAMUT_JPEG_PLAIN(GAMUT_JPGD_YH1V2, grid_plain);
         else if (out_comps == 4) hipLaunchKernelGGL(k_jpeg_h2v2<4>, grid420, dim3(H2V2_THREADS), 0, stream, c);
         else if (out_comps == 3) hipLaunchKernelGGL(k_jpeg_h2v2<3>, grid420, dim3(H2V2_THREADS), 0, stream, c);
         else                     hipLaunchKernelGGL(k_jpeg_h2v2<1>, grid420, dim3(H2V2_THREADS), 0, stream, c);

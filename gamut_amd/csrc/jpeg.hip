@@ -117,8 +117,12 @@ __device__ __forceinline__ void store_px_nt(uint8_t* row_base, u32 voff, u32 px)
 #ifndef JPEG_UNROLL_STRIPS        // 1 = the strip loop fully unrolled (exact s_waitcnt vmcnt counts across the strips' stores)
 #define JPEG_UNROLL_STRIPS 0
 #endif
+#ifndef JPEG_444_MCUS             // 4:4:4: 10 MCUs = 30 blocks = 240 of the 256 threads at work (8 MCUs: 192)
+#define JPEG_444_MCUS 10
+#endif
 // strips per workgroup of k_jpeg_plain, by sampling mode (A/B on one box, 1024 x 1080p -> rgba8, 1 / 2 / 4 / 8 strips: grey 1.69 / 1.56 /
 // 1.49 / 1.47 ms, 4:4:4 5.77 / 5.44 / 5.44 / 5.29 ms, 4:2:2 3.32 / 3.48 / 3.42 / 3.46 ms, 4:4:0 3.39 / 3.34 / 3.42 / 3.45 ms)
+constexpr int plain_mcus(int scan_type) { return scan_type == GAMUT_JPGD_GRAYSCALE ? 32 : scan_type == GAMUT_JPGD_YH1V1 ? JPEG_444_MCUS : 8; }     // MCUs per strip
 constexpr int plain_strips(int scan_type) { return (scan_type == GAMUT_JPGD_GRAYSCALE || scan_type == GAMUT_JPGD_YH1V1) ? 8 : 1; }
 #ifndef JPEG_ABLATE               // measurement only (tools/variant.sh): 1 = loads + stores, no arithmetic; 2 = no stores; 3 = no loads
 #define JPEG_ABLATE 0
@@ -429,8 +433,9 @@ __global__ __launch_bounds__(256) void k_jpeg_plain(JpegArgs a)
     static_assert(ST == GAMUT_JPGD_GRAYSCALE || ST == GAMUT_JPGD_YH1V1 || ST == GAMUT_JPGD_YH2V1 || ST == GAMUT_JPGD_YH1V2, "sampling mode");
     constexpr int BPM  = ST == GAMUT_JPGD_GRAYSCALE ? 1 : ST == GAMUT_JPGD_YH1V1 ? 3 : 4;
     constexpr int MH   = ST == GAMUT_JPGD_YH1V2 ? 16 : 8;           // MCU height: 4:4:0 stacks two Y blocks (H1V2Convert :2603-2647)
-    constexpr int MCUS = ST == GAMUT_JPGD_GRAYSCALE ? 32 : 8;
-    constexpr int NBLK = MCUS * BPM;                              // 32 / 24 / 32 blocks = NBLK * 8 working threads
+    constexpr int MCUS = plain_mcus(ST);
+    constexpr int NBLK = MCUS * BPM;                              // 32 / 30 / 32 blocks = NBLK * 8 working threads
+    static_assert(NBLK * 8 <= 256, "a thread per block row");
     constexpr int MW   = ST == GAMUT_JPGD_YH2V1 ? 16 : 8;
     constexpr int SW   = MCUS * MW;                               // strip width in pixels: 256 / 64 / 128
     __shared__ __attribute__((aligned(16))) i32 T1[NBLK * BLK_STRIDE];
@@ -721,8 +726,9 @@ int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
         const bool tuned = out_pitch > 0 && out_pitch < (1 << 27) &&
                            (out_comps != 4 || (((uintptr_t)out & 3) == 0 && (out_pitch & 3) == 0 && (out_stride & 3) == 0));
         const int ps = plain_strips(scan_type);
+        const int pm = plain_mcus(scan_type);
         const dim3 grid32(((a.mcus_per_row + 31) / 32 + ps - 1) / ps, a.mcus_per_col, n);           // grey: 32 MCUs per strip
-        const dim3 grid_plain((tiles + ps - 1) / ps, a.mcus_per_col, n);
+        const dim3 grid_plain(((a.mcus_per_row + pm - 1) / pm + ps - 1) / ps, a.mcus_per_col, n);
         const int strips420 = out_comps == 4 ? JPEG_STRIPS : JPEG_STRIPS_PACKED;
         const unsigned groups420 = (unsigned)(((a.mcus_per_row + H2V2_MCUS - 1) / H2V2_MCUS + strips420 - 1) / strips420);
 #if JPEG_XCD_REMAP

@@ -2,21 +2,25 @@
 //
 // Replaces, for a batch, stbi_zlib_decode_malloc_guesssize_headerflag (stbdec.d:1267-1321 -> the `miniz` inflate): IDAT
 // streams resident in HBM are inflated straight into the arena the de-filter kernels read (png.hip), so a file batch no
-// longer waits for sixteen host threads running zlib.  One workgroup of kT = 512 threads per stream; inside a stream:
+// longer waits for sixteen host threads running zlib.  One workgroup of kT = 1024 threads per stream.  Huffman decoding does
+// not depend on the bytes the matches copy, so a block is taken in two decoupled steps:
 //
+//   TOKENS, 16 KiB of compressed input per round (kT lanes x 128 bits), whatever they inflate to:
 //   * block headers and the code-length alphabet of a dynamic block are read by one thread (a few hundred bits); the two
-//     canonical Huffman codes are turned into lookup tables by all threads (counting by LDS atomics, ranks, one table entry
-//     per thread and pass);
-//   * the block's symbols are decoded 8 KiB at a time (kT lanes x 128 bits), SPECULATIVELY: lane k starts at bit 128 k of the chunk as if a
-//     token began there, lanes then restart from their predecessor's exit position until nothing moves -- Huffman streams
-//     re-synchronise within a few tokens, so a few sweeps settle all the lanes (the chain is exact from lane 0 on,
-//     and a lane that meets the end-of-block code, an invalid code or its output cap ends the chunk there);
-//   * a prefix sum of the lanes' output bytes places everything: a last sweep writes the literals into a 64 KiB ring in LDS
-//     (the 32 KiB window plus the chunk's output) and, for every byte a match produces, the position it copies from;
-//   * the copies are resolved for all bytes at once by pointer doubling: a byte whose source is known takes its value, any
-//     other byte adopts its source's source -- a chain of n dependent copies (runs, distance-1 matches, the short distances
-//     of filtered scanlines) is done after log2 n rounds, at most 15, whatever the match structure;
-//   * the chunk's bytes leave the ring for HBM in dwords.
+//     canonical Huffman codes are turned into lookup tables by all threads;
+//   * SPECULATIVE decode: lane k starts at bit 128 k of the round as if a token began there and remembers where its tokens
+//     began (a 128-bit map).  Lanes then restart from their predecessor's exit -- only until they step on a bit of their
+//     own map: from there on the old chain holds (Huffman streams re-synchronise within a few tokens).  Inside a wave the
+//     exits travel by DPP, without a barrier; waves exchange their last lane's exit through LDS, a few times per round;
+//   * the settled lanes decode once more and EMIT their tokens into a scratch list in HBM (8 bytes: literal pair or match,
+//     offset inside the lane's output, lane), slots from a prefix sum of the maps' bit counts;
+//   BYTES, in tiles of at most 28 KiB of output (whole lanes; a round of smooth data is several tiles):
+//   * a token per thread: literals go into a 64 KiB ring in LDS (the 32 KiB window + the tile), every byte of a match gets
+//     the position it copies from (from[], 16 bits per byte; byte i of an overlapping match points at byte i mod distance
+//     of the block before it, so runs are one link long; long matches are expanded by whole waves);
+//   * pointer doubling on from[] alone: a byte whose source is not a literal or history adopts its source's source -- a chain
+//     of n dependent copies is done after log2 n rounds, whatever the match structure; then ONE pass moves the values;
+//   * the tile's bytes leave the ring for HBM in dwords.
 // No data-dependent branch is taken on a whole stream's behalf by a single lane except the block headers.
 #include "common.hpp"
 
@@ -24,35 +28,34 @@ namespace gamut {
 namespace {
 
 #ifndef INFLATE_T                 // tuning knobs (tools/variant.sh)
-#define INFLATE_T 512
-#endif
-#ifndef INFLATE_SUB_BITS
-#define INFLATE_SUB_BITS 128
+#define INFLATE_T 1024
 #endif
 #ifndef INFLATE_NEW_MAX
 #define INFLATE_NEW_MAX 28672
 #endif
 constexpr int kT = INFLATE_T;                        // threads per stream
-constexpr int kSubBits = INFLATE_SUB_BITS;           // compressed bits a lane owns per chunk
-constexpr int kChunkBytes = kT * kSubBits / 8;       // 8192
-constexpr int kWinDwords = kChunkBytes / 4 + 8;      // + 32 bytes: the last lane runs up to 47 bits past its end and peeks 64 bits from there
+constexpr int kWaves = kT / 64;
+constexpr int kSubBits = 128;                        // compressed bits a lane owns per round (its token map is two 64-bit words)
+constexpr int kRoundBytes = kT * kSubBits / 8;       // 16384
+constexpr int kWinDwords = kRoundBytes / 4 + 8;      // + 32 bytes: the last lane runs up to 47 bits past its end and peeks 64 bits from there
 constexpr int kRing = 65536, kRingMask = kRing - 1;
-constexpr int kNewMax = INFLATE_NEW_MAX;              // bytes a chunk may add to the ring: the 32 KiB history must survive them
-constexpr int kLaneOutMax = 8192;                    // a lane stops early beyond this (ends the chunk: pathological match runs)
+constexpr int kNewMax = INFLATE_NEW_MAX;             // bytes a tile may add to the ring: the 32 KiB history must survive them
+// (a lane's tokens begin within its 128 bits and take 2 bits at the least: 64 matches of 258 bytes = 16.5 KB < kNewMax, so one lane alone always fits a tile)
 constexpr int kHist = 32768;                         // DEFLATE's window
+constexpr int kTokCap = 16384;                       // tokens a round may emit (its scratch list in HBM); one lane holds at most 88
 #ifndef INFLATE_LONG_CAP
-#define INFLATE_LONG_CAP 1024
+#define INFLATE_LONG_CAP 768
 #endif
 #ifndef INFLATE_LIT_BITS
 #define INFLATE_LIT_BITS 11
 #endif
-constexpr int kLongMin = 32, kLongCap = INFLATE_LONG_CAP;        // matches at least this long are expanded by a whole wave, not by their lane
+constexpr int kLongMin = 32, kLongCap = INFLATE_LONG_CAP;        // matches at least this long are expanded by a whole wave, not by the thread that holds the token
 constexpr int kLitBits = INFLATE_LIT_BITS, kDistBits = 10;         // primary lookup widths; longer codes take the canonical search
 
-enum : uint32_t { F_EOB = 1, F_BAD = 2, F_EARLY = 4 };
+enum : uint32_t { F_EOB = 1, F_BAD = 2 };
 // status word per stream (0 = ok)
 enum : uint32_t { E_BLOCK_TYPE = 1, E_STORED = 2, E_LENGTHS = 3, E_CODE = 4, E_DISTANCE = 5, E_INPUT = 6 };
-enum { C_FIRST_BAD = 0, C_FIRST_STOP, C_CUT, C_OPEN, C_NLONG, C_ERR, C_BTYPE, C_FINAL, C_HDR_END_LO, C_HDR_END_HI, C_HLIT, C_HDIST, C_N };
+enum { C_MOVED0 = 0, C_MOVED1, C_MOVED2, C_STOP0, C_STOP1, C_STOP2, C_CUT, C_OPEN0, C_OPEN1, C_OPEN2, C_NLONG, C_ERR, C_BTYPE, C_FINAL, C_HDR_END_LO, C_HDR_END_HI, C_HLIT, C_HDIST, C_N };
 
 struct InfItem { const uint8_t* src; uint8_t* dst; uint32_t src_len, dst_cap; };
 
@@ -77,13 +80,15 @@ struct Canon { uint32_t first[16], count[16], offs[16]; };
 
 struct Shared {
     __attribute__((aligned(16))) uint8_t ring[kRing];
-    __attribute__((aligned(16))) uint32_t win[kWinDwords];
-    uint32_t lit_lut[1 << kLitBits];
-    uint32_t dist_lut[1 << kDistBits];
-    __attribute__((aligned(16))) uint16_t from[kNewMax + 8];                          // per byte of the chunk: where its value comes from, as a position in [chunk start - 32768, ...); itself = known
-    uint32_t exit_bit[kT], flags[kT];
-    uint32_t scan_a[kT];
-    uint2    longm[kLongCap];                        // long matches of the chunk: x = first byte (chunk-relative), y = length | distance << 16
+    union {                                          // the compressed window serves the token rounds, from[] the tiles behind them
+        __attribute__((aligned(16))) uint32_t win[kWinDwords];
+        __attribute__((aligned(16))) uint16_t from[kNewMax + 8];   // per byte of the tile: where its value comes from, as a position in [tile start - 32768, ...); itself = a literal
+    };
+    uint32_t lut[(1 << kLitBits) + (1 << kDistBits)];   // primary tables: literal / length codes, then distance codes
+    uint32_t lane_exit[kT];                          // exit bit | flags << 24, as last published
+    uint32_t cum_out[kT], cum_tok[kT];               // inclusive prefix sums over the lanes of a round
+    uint2    longm[kLongCap];                        // long matches of the tile: x = first byte (tile-relative), y = length | distance << 16
+    uint32_t wave_sum[kWaves];
     uint32_t lit_sorted[288], dist_sorted[32];       // symbol payloads in canonical order
     Canon    lit, dist;
     uint32_t cl_lut[128];
@@ -99,7 +104,8 @@ __device__ __forceinline__ uint64_t peek64(const uint32_t* win, uint32_t bit)
     return (uint64_t)__builtin_amdgcn_alignbit(c, b, sh) << 32 | __builtin_amdgcn_alignbit(b, a, sh);
 }
 
-// symbol -> table payload: bits 4-6 kind (0 literal, 1 length / distance, 2 end of block, 3 invalid), 8-12 extra bits, 16-31 base
+// symbol -> table payload: bits 0-3 code length (0 in a primary table: longer than the table covers), 4-6 kind (0 literal, 1 length,
+// 2 end of block, 3 invalid, 4 two literals, 5 distance), 8-11 extra bits, 12-15 the first code's length of a pair, 16-31 base
 __device__ __forceinline__ uint32_t lit_payload(uint32_t s)
 {
     if (s < 256u) return s << 16;
@@ -114,21 +120,34 @@ __device__ __forceinline__ uint32_t lit_payload(uint32_t s)
 __device__ __forceinline__ uint32_t dist_payload(uint32_t d)
 {
     if (d > 29u) return 3u << 4;
-    if (d < 4u) return (1u + d) << 16 | 1u << 4;
+    if (d < 4u) return (1u + d) << 16 | 5u << 4;
     const uint32_t x = (d - 2u) >> 1;
-    return (1u + ((2u + (d & 1u)) << x)) << 16 | x << 8 | 1u << 4;
+    return (1u + ((2u + (d & 1u)) << x)) << 16 | x << 8 | 5u << 4;
 }
 
-// canonical search over code lengths [from, to]: `bits` holds the stream bits LSB first; 0 = no code of these lengths matches
-__device__ __forceinline__ uint32_t canon_decode(uint32_t bits, const Canon& c, const uint32_t* sorted, int from, int to)
-{
-    const uint32_t rev = __brev(bits);
-    for (int l = from; l <= to; ++l) {
-        const uint32_t d = (rev >> (32 - l)) - c.first[l];
-        if (d < c.count[l]) return sorted[c.offs[l] + d] | (uint32_t)l;
+// the code lengths [FROM, TO] of a canonical code in registers: a search costs no LDS round trip but the last
+template <int FROM, int TO = 15> struct CodeRange {
+    uint32_t first[TO - FROM + 1], count[TO - FROM + 1], offs[TO - FROM + 1];
+    __device__ __forceinline__ void load(const Canon& c)
+    {
+        #pragma unroll
+        for (int l = FROM; l <= TO; ++l) { first[l - FROM] = c.first[l]; count[l - FROM] = c.count[l]; offs[l - FROM] = c.offs[l]; }
     }
-    return 0;
-}
+    // `bits` holds the stream bits LSB first; lengths up to `to` only; 0 = no code of these lengths matches
+    __device__ __forceinline__ uint32_t decode(uint32_t bits, const uint32_t* sorted, int to = TO) const
+    {
+        const uint32_t rev = __brev(bits);
+        uint32_t at = 0xFFFFFFFFu, len = 0;
+        #pragma unroll
+        for (int l = TO; l >= FROM; --l) {                         // (at most one length matches: the code is prefix-free)
+            const uint32_t d = (rev >> (32 - l)) - first[l - FROM];
+            const bool hit = d < count[l - FROM] && l <= to;
+            at = hit ? offs[l - FROM] + d : at; len = hit ? (uint32_t)l : len;
+        }
+        return len ? sorted[at] | len : 0u;
+    }
+};
+template <int FROM> using LongCodes = CodeRange<FROM, 15>;
 
 // canonical code of `n` symbols with lengths S.lens[base .. base + n): Canon, payloads in canonical order, primary table.
 // Validity as zlib's inflate_table: over-subscribed sets fail; incomplete ones too, unless the set is a single 1-bit code.
@@ -138,7 +157,7 @@ __device__ void build_table(Shared& S, int base, int n)
     const int t = threadIdx.x;
     Canon& c = DIST ? S.dist : S.lit;
     uint32_t* sorted = DIST ? S.dist_sorted : S.lit_sorted;
-    uint32_t* lut = DIST ? S.dist_lut : S.lit_lut;
+    uint32_t* lut = DIST ? S.lut + (1 << kLitBits) : S.lut;
     constexpr int P = DIST ? kDistBits : kLitBits;
     if (t < 16) c.count[t] = 0;
     __syncthreads();
@@ -160,15 +179,16 @@ __device__ void build_table(Shared& S, int base, int n)
         sorted[c.offs[L] + rank] = DIST ? dist_payload((uint32_t)s) : lit_payload((uint32_t)s);
     }
     __syncthreads();
+    CodeRange<1, P> codes; codes.load(c);
     for (int e = t; e < (1 << P); e += kT) {
-        uint32_t r = canon_decode((uint32_t)e, c, sorted, 1, P);
+        uint32_t r = codes.decode((uint32_t)e, sorted);
         if constexpr (!DIST) {
             // two literals behind one look-up when both codes fit the index (kind 4: base = first | second << 8): residual data
             // of photographs is mostly literals of 3-6 bits
             const uint32_t l1 = r & 15u;
             if (r && ((r >> 4) & 7u) == 0u && l1 < (uint32_t)P) {
-                const uint32_t r2 = canon_decode((uint32_t)e >> l1, c, sorted, 1, P - (int)l1);
-                if (r2 && ((r2 >> 4) & 7u) == 0u) r = ((r >> 16) | (r2 >> 16) << 8) << 16 | l1 << 8 | 4u << 4 | (l1 + (r2 & 15u));
+                const uint32_t r2 = codes.decode((uint32_t)e >> l1, sorted, P - (int)l1);
+                if (r2 && ((r2 >> 4) & 7u) == 0u) r = ((r >> 16) | (r2 >> 16) << 8) << 16 | l1 << 12 | 4u << 4 | (l1 + (r2 & 15u));
             }
         }
         lut[e] = r;
@@ -176,185 +196,215 @@ __device__ void build_table(Shared& S, int base, int n)
     __syncthreads();
 }
 
-struct LaneResult { uint32_t exit, flags, out; };
+// What a lane knows about its sub-sequence: where it starts, where its chain of tokens leaves it (the first token boundary at or
+// beyond its end), whether the chain met the end-of-block code or an invalid code, and the map of the bits its tokens begin at.
+struct Lane { uint32_t start, exit, flags; uint64_t map_lo, map_hi; };
 
-// the code lengths the primary table does not cover, in registers (the canonical search then costs no LDS round trip but the last)
-template <int FROM> struct LongCodes {
-    uint32_t first[16 - FROM], count[16 - FROM], offs[16 - FROM];
-    __device__ __forceinline__ void load(const Canon& c)
-    {
-        #pragma unroll
-        for (int l = FROM; l <= 15; ++l) { first[l - FROM] = c.first[l]; count[l - FROM] = c.count[l]; offs[l - FROM] = c.offs[l]; }
-    }
-    __device__ __forceinline__ uint32_t decode(uint32_t bits, const uint32_t* sorted) const
-    {
-        const uint32_t rev = __brev(bits);
-        uint32_t at = 0xFFFFFFFFu, len = 0;
-        #pragma unroll
-        for (int l = 15; l >= FROM; --l) {                         // (at most one length matches: the code is prefix-free)
-            const uint32_t d = (rev >> (32 - l)) - first[l - FROM];
-            const bool hit = d < count[l - FROM];
-            at = hit ? offs[l - FROM] + d : at; len = hit ? (uint32_t)l : len;
-        }
-        return len ? sorted[at] | len : 0u;
-    }
-};
-
-// tokens of one lane: from bit `start` until a token begins at or beyond `end` (window-relative bits).  WRITE: literals into the
-// ring at absolute output offset obase.., and S.from[] for every byte (orel = obase - chunk start)
-// MODE 0: count only (the sweeps); 1: write (see above); 2: nothing is written, but distances are still checked against the
-// bytes produced so far (the part of a stream beyond the caller's capacity is decoded to its end all the same: a stream
-// damaged anywhere is a corrupt stream, as it is for the reference, which inflates all of it)
-template <int MODE>
-__device__ __forceinline__ LaneResult lane_decode(Shared& S, uint32_t start, uint32_t end, uint32_t obase, uint32_t orel)
+// One code: literal / length / end of block from the first table, or, after a length, the distance from the second -- every
+// trip of the decode loops runs the same instructions whatever it finds (a wave whose lanes meet literals, pairs and matches
+// side by side does not walk three paths): entry -> code bits, extra bits, base + extra, then selects.
+struct Code { uint32_t kind, val, bits; };
+template <class LL, class LD>
+__device__ __forceinline__ Code read_code(const Shared& S, const LL& long_lit, const LD& long_dist, uint32_t b, uint32_t state, uint32_t at, uint32_t end)
 {
-    constexpr bool WRITE = MODE == 1;
+    uint32_t e = S.lut[state ? (1u << kLitBits) + (b & ((1u << kDistBits) - 1u)) : (b & ((1u << kLitBits) - 1u))];
+    if ((e & 15u) == 0u) { e = state ? long_dist.decode(b, S.dist_sorted) : long_lit.decode(b, S.lit_sorted); if (!e) e = 3u << 4; }
+    uint32_t nb = e & 15u, kind = (e >> 4) & 7u;
+    if (kind == 4u) {
+        // a pair whose second literal would begin at or beyond `end` is taken as its first literal alone: a lane must
+        // leave at the FIRST token boundary past its end whatever way it came in, or the lanes never fall into step
+        const uint32_t l1 = (e >> 12) & 15u;
+        if (at + l1 >= end) { kind = 0u; nb = l1; e &= 0x00FF0FFFu; }
+    }
+    const uint32_t xb = (e >> 8) & 15u;
+    return Code{ kind, (e >> 16) + __builtin_amdgcn_ubfe(b, nb, xb), nb + xb };
+}
+
+// The tokens of a lane from bit `from` on (window-relative), until one begins at or beyond its end.  RESYNC: the walk stops as soon as
+// it stands on a bit of the lane's map -- from there on the chain is the one already known; otherwise the lane's exit, flags and
+// map are replaced.  64 peeked bits serve trips of at most 28.
+template <bool RESYNC>
+__device__ __forceinline__ void lane_trace(const Shared& S, Lane& L, uint32_t from, uint32_t base)
+{
     LongCodes<kLitBits + 1> long_lit; long_lit.load(S.lit);
     LongCodes<kDistBits + 1> long_dist; long_dist.load(S.dist);
-    uint32_t pos = start, o = 0, fl = 0;
-    while (pos < end && !fl) {
-        uint64_t bits = peek64(S.win, pos);
+    const uint32_t end = base + kSubBits;
+    uint32_t pos = from, fl = 0, state = 0;
+    uint64_t new_lo = 0, new_hi = 0;
+    bool joined = false;
+    while (!fl && !joined && (state || pos < end)) {
+        const uint64_t bits = peek64(S.win, pos);
         uint32_t used = 0;
         do {
-            uint32_t e = S.lit_lut[(uint32_t)bits & ((1u << kLitBits) - 1u)];
-            if ((e & 15u) == 0u) { e = long_lit.decode((uint32_t)bits, S.lit_sorted); if (!e) { fl = F_BAD; break; } }
-            uint32_t nb = e & 15u;
-            uint32_t kind = (e >> 4) & 7u;
-            if (kind == 4u) {
-                // a pair whose second literal would begin at or beyond `end` is taken as its first literal alone: a lane must
-                // leave at the FIRST token boundary past its end whatever way it came in, or the lanes never fall into step
-                const uint32_t l1 = (e >> 8) & 15u;
-                if (pos + used + l1 >= end) { kind = 0u; nb = l1; e &= 0x00FFFFFFu; }
+            if (!state) {                                         // a token begins here
+                const uint32_t rel = pos + used - base;           // < 128 on every chain that matters (lanes behind a stop may come in below their base)
+                const uint64_t m = 1ull << (rel & 63u);
+                if (RESYNC && rel < 128u && ((rel < 64u ? L.map_lo : L.map_hi) & m)) {
+                    if (rel < 64u) { L.map_lo = new_lo | (L.map_lo & ~(m - 1u)); }
+                    else           { L.map_lo = new_lo; L.map_hi = new_hi | (L.map_hi & ~(m - 1u)); }
+                    joined = true; break;
+                }
+                if (rel < 64u) new_lo |= m; else if (rel < 128u) new_hi |= m;
             }
-            bits >>= nb; used += nb;
-            if (kind == 0u) {
-                if (WRITE) { S.ring[(obase + o) & kRingMask] = (uint8_t)(e >> 16); S.from[orel + o] = (uint16_t)(orel + o + kHist); }
-                ++o;
-            } else if (kind == 4u) {                              // two literals
-                if (WRITE) {
-                    S.ring[(obase + o) & kRingMask] = (uint8_t)(e >> 16); S.from[orel + o] = (uint16_t)(orel + o + kHist);
-                    S.ring[(obase + o + 1u) & kRingMask] = (uint8_t)(e >> 24); S.from[orel + o + 1u] = (uint16_t)(orel + o + 1u + kHist);
-                }
-                o += 2u;
-            } else if (kind == 1u) {
-                uint32_t xb = (e >> 8) & 31u;
-                const uint32_t len = (e >> 16) + ((uint32_t)bits & ((1u << xb) - 1u));
-                bits >>= xb; used += xb;
-                uint32_t de = S.dist_lut[(uint32_t)bits & ((1u << kDistBits) - 1u)];
-                if ((de & 15u) == 0u) { de = long_dist.decode((uint32_t)bits, S.dist_sorted); if (!de) { fl = F_BAD; break; } }
-                if (((de >> 4) & 7u) != 1u) { fl = F_BAD; break; }                 // distance symbols 30 / 31
-                nb = de & 15u;
-                bits >>= nb; used += nb;
-                xb = (de >> 8) & 31u;
-                const uint32_t dist = (de >> 16) + ((uint32_t)bits & ((1u << xb) - 1u));
-                bits >>= xb; used += xb;
-                if (MODE != 0 && dist > obase + o) atomicMax(&S.ctrl[C_ERR], (uint32_t)E_DISTANCE);     // reaches before the first output byte
-                if (WRITE) {
-                    const uint32_t q = orel + o + kHist - dist;                    // position of the first source byte
-                    // byte i copies byte i - dist, i.e. byte i mod dist of the dist bytes before the match: pointing there at once
-                    // keeps the chains of overlapping copies (runs) one link long.  Long matches are left to a whole wave
-                    // (expand_long_matches): a lane with many of them (flat images: 8 KiB from 128 bits) would hold up the chunk.
-                    uint32_t slot = kLongCap;
-                    if (len >= (uint32_t)kLongMin) slot = atomicAdd(&S.ctrl[C_NLONG], 1u);
-                    if (slot < (uint32_t)kLongCap) S.longm[slot] = make_uint2(orel + o, len | dist << 16);
-                    else for (uint32_t i = 0, m = 0; i < len; ++i) { S.from[orel + o + i] = (uint16_t)(q + m); if (++m == dist) m = 0; }
-                }
-                o += len;
-                if (o > (uint32_t)kLaneOutMax) fl = F_EARLY;
-            } else { fl = kind == 2u ? F_EOB : F_BAD; break; }
-        } while (!fl && used <= 16u && pos + used < end);
+            const Code c = read_code(S, long_lit, long_dist, (uint32_t)(bits >> used), state, pos + used, end);
+            used += c.bits;
+            state = c.kind == 1u ? 1u : 0u;
+            fl = c.kind == 2u ? (uint32_t)F_EOB : c.kind == 3u ? (uint32_t)F_BAD : 0u;
+        } while (!fl && used <= 36u && (state || pos + used < end));
         pos += used;
     }
-    return LaneResult{ pos, fl, o };
+    L.start = from;
+    if (!joined) { L.exit = pos; L.flags = fl; L.map_lo = new_lo; L.map_hi = new_hi; }
 }
 
-// inclusive prefix sum over the workgroup
-__device__ __forceinline__ void block_scan(Shared& S, uint32_t& a)
+// The settled lane once more: its tokens into the round's list (8 bytes each: x = length | distance << 16 for a match, count (0-2) |
+// first << 16 | second << 24 for literals; y = offset inside the lane's output | lane << 16 | match << 31) -> bytes the lane inflates to.
+// Every map bit gets a slot: the end-of-block (or invalid) code leaves an empty literal token.
+__device__ __forceinline__ uint32_t lane_emit(const Shared& S, const Lane& L, uint32_t base, uint2* tok, uint32_t lane)
 {
-    const int t = threadIdx.x;
-    S.scan_a[t] = a;
-    __syncthreads();
-    for (int d = 1; d < kT; d <<= 1) {
-        const uint32_t pa = t >= d ? S.scan_a[t - d] : 0u;
-        __syncthreads();
-        a += pa;
-        S.scan_a[t] = a;
-        __syncthreads();
+    LongCodes<kLitBits + 1> long_lit; long_lit.load(S.lit);
+    LongCodes<kDistBits + 1> long_dist; long_dist.load(S.dist);
+    const uint32_t end = base + kSubBits;
+    uint32_t pos = L.start, fl = 0, state = 0, o = 0, len = 0;
+    while (!fl && (state || pos < end)) {
+        const uint64_t bits = peek64(S.win, pos);
+        uint32_t used = 0;
+        do {
+            const Code c = read_code(S, long_lit, long_dist, (uint32_t)(bits >> used), state, pos + used, end);
+            used += c.bits;
+            if (c.kind != 1u) {                                   // a token is complete
+                const bool match = c.kind == 5u, lits = c.kind == 0u || c.kind == 4u;
+                const uint32_t n = match ? len : lits ? 1u + (c.kind >> 2) : 0u;
+                *tok++ = make_uint2(match ? len | c.val << 16 : n | c.val << 16, o | lane << 16 | (match ? 1u << 31 : 0u));
+                o += n;
+            }
+            len = c.val;
+            state = c.kind == 1u ? 1u : 0u;
+            fl = c.kind == 2u ? (uint32_t)F_EOB : c.kind == 3u ? (uint32_t)F_BAD : 0u;
+        } while (!fl && used <= 36u && (state || pos + used < end));
+        pos += used;
     }
+    return o;
 }
 
-// S.from[] for the matches the lanes left in S.longm: one match per wave and pass, 64 bytes per step
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);      // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);      // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);      // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);      // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);      // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
+// inclusive prefix sum over the workgroup, left in `out[]` too (two barriers)
+__device__ __forceinline__ uint32_t block_inclusive_sum(Shared& S, uint32_t v, uint32_t* out)
+{
+    const int t = threadIdx.x, w = t >> 6;
+    uint32_t incl = wave_inclusive_sum(v);
+    if ((t & 63) == 63) S.wave_sum[w] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    #pragma unroll
+    for (int k = 0; k < kWaves; ++k) before += k < w ? S.wave_sum[k] : 0u;
+    incl += before;
+    out[t] = incl;
+    __syncthreads();
+    return incl;
+}
+
+// S.from[] for the matches the token pass left in S.longm: one match per wave and pass, 64 bytes per step
 __device__ __forceinline__ void expand_long_matches(Shared& S)
 {
     const uint32_t n = S.ctrl[C_NLONG] < (uint32_t)kLongCap ? S.ctrl[C_NLONG] : (uint32_t)kLongCap;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    for (uint32_t m = wave; m < n; m += kT / 64) {
+    for (uint32_t m = wave; m < n; m += kWaves) {
         const uint2 e = S.longm[m];
         const uint32_t at = e.x, len = e.y & 0xFFFFu, dist = e.y >> 16, q = at + kHist - dist;
         for (uint32_t i = lane; i < len; i += 64u) S.from[at + i] = (uint16_t)(q + (dist >= len ? i : i % dist));
     }
 }
 
-// Every byte of the chunk [cs, cs + total) takes its value: S.from[j] names the position byte j copies from (a position p
-// counts from cs - 32768: p < 32768 is window history, always known; p == j + 32768 is the byte itself = known).  Round by
-// round a byte whose source is known copies it, and any other byte adopts its source's source.  A thread looks at 8
-// neighbouring bytes at a time (one 16-byte read of their entries) and passes over groups that are known already.
+// Every byte of the tile [cs, cs + total) takes its value: S.from[j] names the position byte j copies from (a position p
+// counts from cs - 32768: p < 32768 is window history; p == j + 32768 is the byte itself = a literal).  Rounds of pointer
+// doubling first: a byte whose source is neither adopts its source's source.  A thread looks at 8 neighbouring bytes (one
+// 16-byte read of their entries) and remembers which of them are settled.  Then one pass moves the values.
 __device__ __forceinline__ int resolve_copies(Shared& S, uint32_t cs, uint32_t total)      // -> rounds taken
 {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int kUnits = (kNewMax / 8 + kT - 1) / kT;           // 8-byte units per thread
     const int t = threadIdx.x;
     const uint32_t units = (total + 7u) >> 3;
+    uint32_t open[kUnits];                                          // per unit: one bit per byte that still points at a copied byte
+    #pragma unroll
+    for (int k = 0; k < kUnits; ++k) {
+        const uint32_t u = (uint32_t)t + (uint32_t)k * kT;
+        open[k] = 0;
+        if (u >= units) continue;
+        const uint32_t j0 = u * 8u, self0 = j0 + kHist;
+        const u32x4 f = *reinterpret_cast<const u32x4*>(&S.from[j0]);
+        const uint32_t p[8] = { f.x & 0xFFFFu, f.x >> 16, f.y & 0xFFFFu, f.y >> 16, f.z & 0xFFFFu, f.z >> 16, f.w & 0xFFFFu, f.w >> 16 };
+        #pragma unroll
+        for (int i = 0; i < 8; ++i) if (j0 + i < total && p[i] >= (uint32_t)kHist && p[i] != self0 + i) open[k] |= 1u << i;
+    }
+    // Three flags in turn say "somebody still has work": round r raises flag r % 3 and thread 0 clears the next one, which was last
+    // read behind the barrier of round r - 2 (every thread has passed the barrier of round r - 1 since).
     int round = 0;
     for (; round < 20; ++round) {
-        if (t == 0) S.ctrl[C_OPEN] = 0;
-        __syncthreads();
-        bool open = false;
-        for (uint32_t u = (uint32_t)t; u < units; u += kT) {
-            const uint32_t j0 = u * 8u, self0 = j0 + kHist;
+        bool any = false;
+        if (t == 0) S.ctrl[C_OPEN0 + (round + 1) % 3] = 0;
+        #pragma unroll
+        for (int k = 0; k < kUnits; ++k) {
+            if (!open[k]) continue;
+            const uint32_t j0 = ((uint32_t)t + (uint32_t)k * kT) * 8u;
             const u32x4 f = *reinterpret_cast<const u32x4*>(&S.from[j0]);
-            const uint32_t s0 = self0 | (self0 + 1u) << 16;
-            if (f.x == s0 && f.y == s0 + 0x00020002u && f.z == s0 + 0x00040004u && f.w == s0 + 0x00060006u) continue;      // all eight known
             uint32_t p[8] = { f.x & 0xFFFFu, f.x >> 16, f.y & 0xFFFFu, f.y >> 16, f.z & 0xFFFFu, f.z >> 16, f.w & 0xFFFFu, f.w >> 16 };
-            uint32_t pp[8]; uint8_t v[8];
+            uint32_t pp[8];
             #pragma unroll
-            for (int k = 0; k < 8; ++k) if (j0 + k >= total) p[k] = self0 + k;                 // past the chunk: nothing to do
+            for (int i = 0; i < 8; ++i) pp[i] = S.from[(open[k] >> i & 1u) ? p[i] - kHist : j0 + i];      // (a settled byte reads its own entry)
             #pragma unroll
-            for (int k = 0; k < 8; ++k) pp[k] = (p[k] != self0 + k && p[k] >= (uint32_t)kHist) ? S.from[p[k] - kHist] : p[k];
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");           // values are read after the marks that vouch for them
-            #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = S.ring[(cs + p[k] - kHist) & kRingMask];
-            #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (p[k] != self0 + k && pp[k] == p[k]) S.ring[(cs + j0 + k) & kRingMask] = v[k];      // the source is known: history, or a byte that points at itself
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");           // a byte is marked known only after its value is in the ring
-            #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                if (p[k] == self0 + k) continue;
-                if (pp[k] == p[k]) S.from[j0 + k] = (uint16_t)(self0 + k);
-                else { S.from[j0 + k] = (uint16_t)pp[k]; open = true; }
+            for (int i = 0; i < 8; ++i) {
+                if (!(open[k] >> i & 1u)) continue;
+                if (pp[i] == p[i]) open[k] &= ~(1u << i);           // the source is a literal: settled
+                else { p[i] = pp[i]; if (pp[i] < (uint32_t)kHist) open[k] &= ~(1u << i); }
             }
+            // (an entry another thread reads while its owner replaces it holds the old or the new pointer: both are sources of the byte)
+            *reinterpret_cast<u32x4*>(&S.from[j0]) = u32x4{ p[0] | p[1] << 16, p[2] | p[3] << 16, p[4] | p[5] << 16, p[6] | p[7] << 16 };
+            any |= open[k] != 0;
         }
-        if (open) S.ctrl[C_OPEN] = 1;
+        if (any) S.ctrl[C_OPEN0 + round % 3] = 1u;
         __syncthreads();
-        const bool any_open = S.ctrl[C_OPEN] != 0;
-        __syncthreads();
-        if (!any_open) break;
+        if (!S.ctrl[C_OPEN0 + round % 3]) break;
+    }
+    __syncthreads();
+    // values: every source is a literal of the tile or a byte of the window
+    for (uint32_t u = (uint32_t)t; u < units; u += kT) {
+        const uint32_t j0 = u * 8u, self0 = j0 + kHist;
+        const u32x4 f = *reinterpret_cast<const u32x4*>(&S.from[j0]);
+        const uint32_t s0 = self0 | (self0 + 1u) << 16;
+        if (f.x == s0 && f.y == s0 + 0x00020002u && f.z == s0 + 0x00040004u && f.w == s0 + 0x00060006u) continue;      // eight literals
+        const uint32_t p[8] = { f.x & 0xFFFFu, f.x >> 16, f.y & 0xFFFFu, f.y >> 16, f.z & 0xFFFFu, f.z >> 16, f.w & 0xFFFFu, f.w >> 16 };
+        uint8_t v[8];
+        #pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = S.ring[(cs + p[i] - kHist) & kRingMask];
+        #pragma unroll
+        for (int i = 0; i < 8; ++i) if (p[i] != self0 + i && j0 + i < total) S.ring[(cs + j0 + i) & kRingMask] = v[i];
     }
     return round + 1;
 }
 
-__global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_items, uint32_t* out_len, uint32_t* status)
+__global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_items, uint2* tok_scratch, uint32_t* out_len, uint32_t* status)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     Shared& S = *reinterpret_cast<Shared*>(smem);
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     struct __attribute__((packed, aligned(1))) AnyVec { u32x4 v; };
-    struct __attribute__((packed, aligned(1))) AnyU32 { uint32_t v; };
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, lane_in_wave = t & 63, wave = t >> 6;
     if ((int)blockIdx.x >= n_items) return;
     const InfItem it = items[blockIdx.x];
     const uint8_t* src = it.src;
     const uint64_t src_bits = (uint64_t)it.src_len * 8u;
+    uint2* const toks = tok_scratch + (size_t)blockIdx.x * kTokCap;
 
     uint64_t pos = 0;                                 // next unread bit of the stream
     uint32_t produced = 0;                            // bytes inflated so far (ring index = produced & kRingMask)
@@ -505,7 +555,7 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
             pos = (p + 4u + len) * 8u;
             PROF(P_STORED);
         } else {
-            // -------------------------------------------------------------- Huffman block: tables, then chunks
+            // -------------------------------------------------------------- Huffman block: tables, then rounds
             const int hlit = (int)S.ctrl[C_HLIT], hdist = (int)S.ctrl[C_HDIST];
             if (!(btype == 1u && fixed_tables)) {
                 build_table<false>(S, 0, hlit);
@@ -520,70 +570,126 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                 const uint64_t wbase = load_window(pos);
                 PROF(P_WINDOW); PROF_COUNT(P_N_CHUNKS, 1);
                 const uint32_t rel0 = (uint32_t)(pos - wbase * 8u);
-                // speculative sweep, then sweeps from the predecessors' exits until the chain is consistent up to its end
-                uint32_t my_start = t == 0 ? rel0 : (uint32_t)t * kSubBits;
-                const uint32_t my_end = (uint32_t)(t + 1) * kSubBits;
-                LaneResult r = lane_decode<0>(S, my_start, my_end, 0, 0);
-                S.exit_bit[t] = r.exit; S.flags[t] = r.flags;
-                if (t == 0) { S.ctrl[C_FIRST_BAD] = kT; S.ctrl[C_FIRST_STOP] = kT; }
+                const uint32_t my_base = (uint32_t)t * kSubBits;
+                // ---- tokens: speculative decode, then lanes fall into step with their predecessors
+                Lane L{ 0, 0, 0, 0, 0 };
+                lane_trace<false>(S, L, t == 0 ? rel0 : my_base, my_base);
+                if (t == 0) { S.ctrl[C_MOVED0] = 0; S.ctrl[C_STOP0] = kT; }
+                S.lane_exit[t] = L.exit | L.flags << 24;
                 __syncthreads();
                 PROF(P_SWEEP0);
-                uint32_t first_stop = kT;
-                for (int sweep = 0; sweep <= kT; ++sweep) {
+                uint32_t first_stop = kT;                                              // the first lane of the chain with a stop (lanes behind it do not matter)
+                for (int sweep = 0; sweep <= kWaves + 1; ++sweep) {
                     PROF_COUNT(P_N_SWEEPS, 1);
-                    const uint32_t prev = t ? S.exit_bit[t - 1] : rel0;
-                    const bool moved = t > 0 && prev != my_start;
-                    if (moved) atomicMin(&S.ctrl[C_FIRST_BAD], (uint32_t)t);
-                    if (r.flags) atomicMin(&S.ctrl[C_FIRST_STOP], (uint32_t)t);
+                    // (three slots in turn for "somebody moved" / "first stop": thread 0 prepares the next sweep's, last read two barriers ago)
+                    const int slot = sweep % 3, next_slot = (sweep + 1) % 3;
+                    if (t == 0) { S.ctrl[C_MOVED0 + next_slot] = 0; S.ctrl[C_STOP0 + next_slot] = kT; }
+                    const uint32_t entry = wave ? S.lane_exit[wave * 64 - 1] : rel0;   // (the flags ride along in bits 24..: a stopped predecessor moves nobody)
+                    const bool wave_live = (uint32_t)(wave * 64) <= first_stop;        // first_stop as of the last sweep: waves behind it wait
+                    bool moved_any = false;
+                    if (wave_live) {
+                        for (int inner = 0; inner < 64; ++inner) {
+                            const uint32_t mine = L.exit | L.flags << 24;
+                            const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)entry, (int)mine, 0x138, 0xF, 0xF, false);   // wave_shr:1, lane 0 takes the wave's entry
+                            const uint64_t stopped = __ballot(L.flags != 0);
+                            const uint32_t first = stopped ? (uint32_t)__builtin_ctzll(stopped) : 64u;
+                            const bool moved = t > 0 && !(prev >> 24) && prev != L.start && (uint32_t)lane_in_wave <= first;
+                            if (!__ballot(moved)) break;
+                            moved_any = true;
+                            if (moved) lane_trace<true>(S, L, prev, my_base);
+                        }
+                    }
+                    const uint64_t stopped = __ballot(L.flags != 0 && wave_live);
+                    if (lane_in_wave == 0) {
+                        if (moved_any) S.ctrl[C_MOVED0 + slot] = 1;
+                        if (stopped) atomicMin(&S.ctrl[C_STOP0 + slot], (uint32_t)(wave * 64) + (uint32_t)__builtin_ctzll(stopped));
+                    }
+                    S.lane_exit[t] = L.exit | L.flags << 24;
                     __syncthreads();
-                    const uint32_t first_bad = S.ctrl[C_FIRST_BAD];
-                    first_stop = S.ctrl[C_FIRST_STOP];
-                    __syncthreads();
-                    if (first_bad == (uint32_t)kT || first_stop < first_bad) break;
-                    if (t == 0) { S.ctrl[C_FIRST_BAD] = kT; S.ctrl[C_FIRST_STOP] = kT; }
-                    if (moved) { my_start = prev; r = lane_decode<0>(S, my_start, my_end, 0, 0); }
-                    __syncthreads();
-                    S.exit_bit[t] = r.exit; S.flags[t] = r.flags;
-                    __syncthreads();
+                    first_stop = S.ctrl[C_STOP0 + slot];
+                    if (!S.ctrl[C_MOVED0 + slot]) break;
                 }
-                __syncthreads();
                 PROF(P_SWEEPS);
-                if (t == 0) S.ctrl[C_CUT] = kT;
                 uint32_t nvalid = first_stop < (uint32_t)kT ? first_stop + 1u : (uint32_t)kT;      // lanes 0 .. nvalid - 1 form the chain
-                // where everything goes; lanes whose output would overflow the ring wait for the next chunk
-                uint32_t inc_o = (uint32_t)t < nvalid ? r.out : 0u;
-                block_scan(S, inc_o);
-                if ((uint32_t)t < nvalid && inc_o > (uint32_t)kNewMax) atomicMin(&S.ctrl[C_CUT], (uint32_t)t);
+                // ---- slots for the tokens (a map bit each), the round cut where the list would overflow
+                if (t == 0) S.ctrl[C_CUT] = kT;
+                const uint32_t ntok = (uint32_t)t < nvalid ? (uint32_t)(__popcll(L.map_lo) + __popcll(L.map_hi)) : 0u;
+                const uint32_t tok_incl = block_inclusive_sum(S, ntok, S.cum_tok);
+                if ((uint32_t)t < nvalid && tok_incl > (uint32_t)kTokCap) atomicMin(&S.ctrl[C_CUT], (uint32_t)t);
                 __syncthreads();
-                const uint32_t cut = S.ctrl[C_CUT];
-                const bool was_cut = cut < nvalid;
-                if (was_cut) nvalid = cut;                                            // >= 1: one lane alone always fits
-                const uint32_t total = S.scan_a[nvalid - 1];
-                const uint32_t last_exit = S.exit_bit[nvalid - 1], last_flags = was_cut ? 0u : S.flags[nvalid - 1];
-                if (t == 0) S.ctrl[C_NLONG] = 0;
-                __syncthreads();
-                PROF(P_SCAN);
-                const bool sink = produced >= it.dst_cap;                             // the caller's buffer is full: decode on, write nothing
-                if ((uint32_t)t < nvalid) {
-                    if (sink) lane_decode<2>(S, my_start, my_end, produced + (inc_o - r.out), inc_o - r.out);
-                    else      lane_decode<1>(S, my_start, my_end, produced + (inc_o - r.out), inc_o - r.out);
-                }
-                __syncthreads();
+                const bool was_cut = S.ctrl[C_CUT] < nvalid;
+                if (was_cut) nvalid = S.ctrl[C_CUT];                                  // >= 1: one lane alone always fits
+                const uint32_t last = S.lane_exit[nvalid - 1];
+                const uint32_t last_exit = last & 0xFFFFFFu, last_flags = was_cut ? 0u : last >> 24;
                 err = S.ctrl[C_ERR];
                 if (!err && (last_flags & F_BAD)) err = E_CODE;
                 if (!err && wbase * 8u + last_exit > src_bits) err = E_INPUT;
-                PROF(P_WRITE);
+                PROF(P_SCAN);
                 if (err) break;
-                if (!sink) {
-                    expand_long_matches(S);
+                // ---- the tokens themselves, and where every lane's bytes go
+                uint32_t out = 0;
+                if ((uint32_t)t < nvalid) out = lane_emit(S, L, my_base, toks + (tok_incl - ntok), (uint32_t)t);
+                const uint32_t out_incl = block_inclusive_sum(S, out, S.cum_out);       // (its barriers also put the tokens in front of their readers)
+                PROF(P_WRITE);
+                // ---- bytes: tiles of whole lanes, at most kNewMax bytes each
+                uint32_t a = 0;                                                       // first lane of the tile
+                while (a < nvalid && !err) {
+                    const uint32_t out0 = a ? S.cum_out[a - 1] : 0u, tok0 = a ? S.cum_tok[a - 1] : 0u;
+                    if (t == 0) { S.ctrl[C_CUT] = nvalid; S.ctrl[C_NLONG] = 0; S.ctrl[C_OPEN0] = 0; }
                     __syncthreads();
-                    { const int rounds = resolve_copies(S, produced, total); (void)rounds; PROF_COUNT(P_N_ROUNDS, rounds); }
+                    if ((uint32_t)t >= a && (uint32_t)t < nvalid && out_incl - out0 > (uint32_t)kNewMax) atomicMin(&S.ctrl[C_CUT], (uint32_t)t);
+                    __syncthreads();
+                    const uint32_t b = S.ctrl[C_CUT];                                 // > a
+                    const uint32_t total = S.cum_out[b - 1] - out0, tok1 = S.cum_tok[b - 1];
+                    const bool sink = produced >= it.dst_cap;                         // the caller's buffer is full: decode on, write nothing
+                    if (!sink) {
+                        // every byte a literal until a match says otherwise
+                        for (uint32_t u = (uint32_t)t; u < (total + 7u) >> 3; u += kT) {
+                            const uint32_t self0 = u * 8u + kHist, s0 = self0 | (self0 + 1u) << 16;
+                            *reinterpret_cast<u32x4*>(&S.from[u * 8u]) = u32x4{ s0, s0 + 0x00020002u, s0 + 0x00040004u, s0 + 0x00060006u };
+                        }
+                        __syncthreads();
+                    }
+                    if (!sink || produced < (uint32_t)kHist) {
+                        for (uint32_t k = tok0 + (uint32_t)t; k < tok1; k += kT) {
+                            const uint2 tk = toks[k];
+                            const uint32_t lane = (tk.y >> 16) & 0x3FFu;
+                            const uint32_t off = (lane ? S.cum_out[lane - 1] : 0u) - out0 + (tk.y & 0x7FFFu);      // tile-relative
+                            if (tk.y >> 31) {
+                                const uint32_t len = tk.x & 0xFFFFu, dist = tk.x >> 16;
+                                if (produced < (uint32_t)kHist && dist > produced + off) atomicMax(&S.ctrl[C_ERR], (uint32_t)E_DISTANCE);      // reaches before the first output byte
+                                else if (!sink) {
+                                    // byte i copies byte i - dist, i.e. byte i mod dist of the dist bytes before the match: pointing there at once
+                                    // keeps the chains of overlapping copies (runs) one link long.  Long matches are left to a whole wave.
+                                    const uint32_t q = off + kHist - dist;              // position of the first source byte
+                                    uint32_t slot = kLongCap;
+                                    if (len >= (uint32_t)kLongMin) slot = atomicAdd(&S.ctrl[C_NLONG], 1u);
+                                    if (slot < (uint32_t)kLongCap) S.longm[slot] = make_uint2(off, len | dist << 16);
+                                    else for (uint32_t i = 0, m = 0; i < len; ++i) { S.from[off + i] = (uint16_t)(q + m); if (++m == dist) m = 0; }
+                                }
+                            } else if (!sink) {
+                                const uint32_t n = tk.x & 3u;
+                                if (n) S.ring[(produced + off) & kRingMask] = (uint8_t)(tk.x >> 16);
+                                if (n > 1u) S.ring[(produced + off + 1u) & kRingMask] = (uint8_t)(tk.x >> 24);
+                            }
+                        }
+                        __syncthreads();
+                        err = S.ctrl[C_ERR];
+                    }
+                    PROF(P_MATCH);
+                    if (!sink && !err) {
+                        expand_long_matches(S);
+                        __syncthreads();
+                        { const int rounds = resolve_copies(S, produced, total); (void)rounds; PROF_COUNT(P_N_ROUNDS, rounds); }
+                        __syncthreads();
+                        PROF(P_MATCH);
+                        flush(produced, total);
+                        __syncthreads();
+                        PROF(P_FLUSH);
+                    }
+                    produced = produced + total < produced ? 0xFFFFFFFFu : produced + total;           // (saturating: only its size matters beyond 32 KiB)
+                    a = b;
                 }
-                __syncthreads();
-                PROF(P_MATCH);
-                if (!sink) flush(produced, total);
-                __syncthreads();
-                produced = produced + total < produced ? 0xFFFFFFFFu : produced + total;           // (saturating: only its size matters beyond 32 KiB)
                 pos = wbase * 8u + last_exit;
                 if (last_flags & F_EOB) in_block = false;
             }
@@ -609,22 +715,26 @@ int inflate_launch(const gamut_hip_inflate_desc* descs, int count, uint32_t* out
     }
     // per call: the attribute belongs to the current device's copy of the kernel, and a process may drive several devices
     if (hipFuncSetAttribute((const void*)k_inflate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Shared)) != hipSuccess) return set_error(GAMUT_HIP_ERR_HIP, "inflate: %zu bytes of LDS are not available", sizeof(Shared));
-    // the descriptor table in HBM: one buffer per (thread, stream) -- calls on one stream are ordered, calls on different
-    // streams never share it; growing it waits for its own stream only
+    // the descriptor table and the token lists (128 KiB per stream) in HBM: one buffer per (thread, device, stream) -- calls on one
+    // stream are ordered, calls on different streams never share it; growing it waits for its own stream only
     struct StreamTable { int device; hipStream_t stream; void* p; size_t cap; };
     static thread_local std::vector<StreamTable> tables;
     StreamTable* e = nullptr;
     const int device = current_device();                    // (the null stream is one handle for every device)
     for (StreamTable& c : tables) if (c.stream == stream && c.device == device) { e = &c; break; }
     if (!e) { tables.push_back(StreamTable{ device, stream, nullptr, 0 }); e = &tables.back(); }
-    const size_t bytes = items.size() * sizeof(InfItem);
+    const size_t tok_bytes = (size_t)count * kTokCap * sizeof(uint2);
+    const size_t item_bytes = (items.size() * sizeof(InfItem) + 255) & ~(size_t)255;
+    const size_t bytes = tok_bytes + item_bytes;
     if (bytes > e->cap) {
         if (e->p) { (void)hipStreamSynchronize(stream); (void)hipFree(e->p); e->p = nullptr; e->cap = 0; }
-        if (hipMalloc(&e->p, bytes * 2 + 4096) != hipSuccess) { (void)hipGetLastError(); e->p = nullptr; return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "inflate: descriptor table allocation failed"); }
-        e->cap = bytes * 2 + 4096;
+        const size_t want = bytes + bytes / 4 + 4096;
+        if (hipMalloc(&e->p, want) != hipSuccess) { (void)hipGetLastError(); e->p = nullptr; return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "inflate: %zu bytes of scratch are not available", want); }
+        e->cap = want;
     }
-    GAMUT_HIP_CHECK(hipMemcpyAsync(e->p, items.data(), bytes, hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(k_inflate, dim3((unsigned)count), dim3(kT), sizeof(Shared), stream, (const InfItem*)e->p, count, out_len_dev, status_dev);
+    uint8_t* const base = static_cast<uint8_t*>(e->p);
+    GAMUT_HIP_CHECK(hipMemcpyAsync(base + tok_bytes, items.data(), items.size() * sizeof(InfItem), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_inflate, dim3((unsigned)count), dim3(kT), sizeof(Shared), stream, (const InfItem*)(base + tok_bytes), count, (uint2*)base, out_len_dev, status_dev);
     return launch_status("inflate");
 }
 

@@ -55,7 +55,7 @@ constexpr int kLitBits = INFLATE_LIT_BITS, kDistBits = 10;         // primary lo
 enum : uint32_t { F_EOB = 1, F_BAD = 2 };
 // status word per stream (0 = ok)
 enum : uint32_t { E_BLOCK_TYPE = 1, E_STORED = 2, E_LENGTHS = 3, E_CODE = 4, E_DISTANCE = 5, E_INPUT = 6 };
-enum { C_MOVED0 = 0, C_MOVED1, C_MOVED2, C_STOP0, C_STOP1, C_STOP2, C_CUT, C_OPEN0, C_OPEN1, C_OPEN2, C_NLONG, C_ERR, C_BTYPE, C_FINAL, C_HDR_END_LO, C_HDR_END_HI, C_HLIT, C_HDIST, C_N };
+enum { C_JOBS0 = 0, C_JOBS1, C_JOBS2, C_STOP0, C_STOP1, C_STOP2, C_CUT, C_OPEN0, C_OPEN1, C_OPEN2, C_NLONG, C_ERR, C_BTYPE, C_FINAL, C_HDR_END_LO, C_HDR_END_HI, C_HLIT, C_HDIST, C_N };
 
 struct InfItem { const uint8_t* src; uint8_t* dst; uint32_t src_len, dst_cap; };
 
@@ -80,8 +80,13 @@ struct Canon { uint32_t first[16], count[16], offs[16]; };
 
 struct Shared {
     __attribute__((aligned(16))) uint8_t ring[kRing];
-    union {                                          // the compressed window serves the token rounds, from[] the tiles behind them
-        __attribute__((aligned(16))) uint32_t win[kWinDwords];
+    union {                                          // the compressed window and the lanes' states serve the token rounds, from[] the tiles behind them
+        struct {
+            __attribute__((aligned(16))) uint32_t win[kWinDwords];
+            uint32_t lane_start[kT];                 // where the lane's chain begins (window-relative bit)
+            __attribute__((aligned(16))) uint4 lane_map[kT];      // the bits its tokens begin at, relative to the lane's first bit
+            uint16_t jobs[kT];                       // lanes that have to walk again
+        };
         __attribute__((aligned(16))) uint16_t from[kNewMax + 8];   // per byte of the tile: where its value comes from, as a position in [tile start - 32768, ...); itself = a literal
     };
     uint32_t lut[(1 << kLitBits) + (1 << kDistBits)];   // primary tables: literal / length codes, then distance codes
@@ -131,7 +136,11 @@ template <int FROM, int TO = 15> struct CodeRange {
     __device__ __forceinline__ void load(const Canon& c)
     {
         #pragma unroll
-        for (int l = FROM; l <= TO; ++l) { first[l - FROM] = c.first[l]; count[l - FROM] = c.count[l]; offs[l - FROM] = c.offs[l]; }
+        for (int l = FROM; l <= TO; ++l) {                          // (the same for every lane: scalar registers)
+            first[l - FROM] = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.first[l]);
+            count[l - FROM] = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.count[l]);
+            offs[l - FROM] = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.offs[l]);
+        }
     }
     // `bits` holds the stream bits LSB first; lengths up to `to` only; 0 = no code of these lengths matches
     __device__ __forceinline__ uint32_t decode(uint32_t bits, const uint32_t* sorted, int to = TO) const
@@ -223,11 +232,11 @@ __device__ __forceinline__ Code read_code(const Shared& S, const LL& long_lit, c
 // The tokens of a lane from bit `from` on (window-relative), until one begins at or beyond its end.  RESYNC: the walk stops as soon as
 // it stands on a bit of the lane's map -- from there on the chain is the one already known; otherwise the lane's exit, flags and
 // map are replaced.  64 peeked bits serve trips of at most 28.
+typedef LongCodes<kLitBits + 1> LongLit;
+typedef LongCodes<kDistBits + 1> LongDist;
 template <bool RESYNC>
-__device__ __forceinline__ void lane_trace(const Shared& S, Lane& L, uint32_t from, uint32_t base)
+__device__ __forceinline__ void lane_trace(const Shared& S, const LongLit& long_lit, const LongDist& long_dist, Lane& L, uint32_t from, uint32_t base)
 {
-    LongCodes<kLitBits + 1> long_lit; long_lit.load(S.lit);
-    LongCodes<kDistBits + 1> long_dist; long_dist.load(S.dist);
     const uint32_t end = base + kSubBits;
     uint32_t pos = from, fl = 0, state = 0;
     uint64_t new_lo = 0, new_hi = 0;
@@ -260,10 +269,8 @@ __device__ __forceinline__ void lane_trace(const Shared& S, Lane& L, uint32_t fr
 // The settled lane once more: its tokens into the round's list (8 bytes each: x = length | distance << 16 for a match, count (0-2) |
 // first << 16 | second << 24 for literals; y = offset inside the lane's output | lane << 16 | match << 31) -> bytes the lane inflates to.
 // Every map bit gets a slot: the end-of-block (or invalid) code leaves an empty literal token.
-__device__ __forceinline__ uint32_t lane_emit(const Shared& S, const Lane& L, uint32_t base, uint2* tok, uint32_t lane)
+__device__ __forceinline__ uint32_t lane_emit(const Shared& S, const LongLit& long_lit, const LongDist& long_dist, const Lane& L, uint32_t base, uint2* tok, uint32_t lane)
 {
-    LongCodes<kLitBits + 1> long_lit; long_lit.load(S.lit);
-    LongCodes<kDistBits + 1> long_dist; long_dist.load(S.dist);
     const uint32_t end = base + kSubBits;
     uint32_t pos = L.start, fl = 0, state = 0, o = 0, len = 0;
     while (!fl && (state || pos < end)) {
@@ -414,20 +421,35 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
     __syncthreads();
     PROF_DECL;
 
-    // the window: kWinDwords dwords from the dword that holds bit `pos` (relative to the stream start); zeros past the end
+    // the window: kWinDwords dwords from the dword that holds bit `pos` (relative to the stream start); zeros past the end.
+    // A round asks for its successor's window as soon as it knows where it ends (prefetch): the 16 bytes per thread wait in
+    // registers while the round's tokens and tiles are worked off.
+    auto window_piece = [&](uint64_t base_byte, int q) -> u32x4 {
+        const uint64_t b = base_byte + (uint64_t)q * 16u;
+        u32x4 v = {0, 0, 0, 0};
+        if (b + 16u <= it.src_len) v = reinterpret_cast<const AnyVec*>(src + b)->v;
+        else if (b < it.src_len) {
+            uint32_t w[4] = {0, 0, 0, 0};
+            for (uint32_t k = 0; k < 16u && b + k < it.src_len; ++k) w[k >> 2] |= (uint32_t)src[b + k] << (8u * (k & 3u));
+            v = u32x4{w[0], w[1], w[2], w[3]};
+        }
+        return v;
+    };
+    static_assert(kWinDwords / 4 <= 2 * kT, "two window pieces per thread at most");
+    uint64_t pf_base = ~(uint64_t)0, win_base = ~(uint64_t)0;          // what the prefetch registers / the LDS window hold
+    u32x4 pf0 = {0, 0, 0, 0}, pf1 = {0, 0, 0, 0};
+    auto prefetch = [&](uint64_t at_bit) {
+        pf_base = (at_bit >> 3) & ~(uint64_t)3;
+        pf0 = window_piece(pf_base, t);
+        if (t + kT < kWinDwords / 4) pf1 = window_piece(pf_base, t + kT);
+    };
     auto load_window = [&](uint64_t at_bit) -> uint64_t {
         const uint64_t base_byte = (at_bit >> 3) & ~(uint64_t)3;
-        for (int q = t; q < kWinDwords / 4; q += kT) {
-            const uint64_t b = base_byte + (uint64_t)q * 16u;
-            u32x4 v = {0, 0, 0, 0};
-            if (b + 16u <= it.src_len) v = reinterpret_cast<const AnyVec*>(src + b)->v;
-            else if (b < it.src_len) {
-                uint32_t w[4] = {0, 0, 0, 0};
-                for (uint32_t k = 0; k < 16u && b + k < it.src_len; ++k) w[k >> 2] |= (uint32_t)src[b + k] << (8u * (k & 3u));
-                v = u32x4{w[0], w[1], w[2], w[3]};
-            }
-            *reinterpret_cast<u32x4*>(&S.win[q * 4]) = v;
-        }
+        if (base_byte != pf_base) prefetch(at_bit);
+        *reinterpret_cast<u32x4*>(&S.win[t * 4]) = pf0;
+        if (t + kT < kWinDwords / 4) *reinterpret_cast<u32x4*>(&S.win[(t + kT) * 4]) = pf1;
+        pf_base = ~(uint64_t)0;
+        win_base = base_byte;
         __syncthreads();
         return base_byte;
     };
@@ -565,50 +587,85 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
             err = S.ctrl[C_ERR];
             PROF(P_TABLES);
             if (err) break;
+            LongLit long_lit; long_lit.load(S.lit);                                   // the code lengths behind the primary tables
+            LongDist long_dist; long_dist.load(S.dist);
             bool in_block = true;
             while (in_block && !err) {
-                const uint64_t wbase = load_window(pos);
+                // (the window the header was read from serves the block's first round: the lanes in front of `pos` are passed over like
+                // lanes behind a long token)
+                const bool reuse = win_base != ~(uint64_t)0 && pos >= win_base * 8u && pos - win_base * 8u < 16u * kSubBits;
+                const uint64_t wbase = reuse ? win_base : load_window(pos);
+                win_base = ~(uint64_t)0;                                              // (the tiles' from[] takes the window's place)
                 PROF(P_WINDOW); PROF_COUNT(P_N_CHUNKS, 1);
                 const uint32_t rel0 = (uint32_t)(pos - wbase * 8u);
                 const uint32_t my_base = (uint32_t)t * kSubBits;
                 // ---- tokens: speculative decode, then lanes fall into step with their predecessors
                 Lane L{ 0, 0, 0, 0, 0 };
-                lane_trace<false>(S, L, t == 0 ? rel0 : my_base, my_base);
-                if (t == 0) { S.ctrl[C_MOVED0] = 0; S.ctrl[C_STOP0] = kT; }
+                lane_trace<false>(S, long_lit, long_dist, L, t == 0 ? rel0 : my_base, my_base);
+                // Every lane's state goes to LDS; then, turn by turn: a lane whose predecessor leaves somewhere else than the lane begins
+                // -- and not on a bit of its map -- is a job; the jobs are walked by the first threads of the workgroup, packed (a
+                // turn late in the round has a handful of jobs: one wave walks them, the other fifteen wait at the barrier instead of
+                // each running the loop for one or two of its lanes).  Lanes behind the first stop wait until it is settled.
+                if (t == 0) { S.ctrl[C_JOBS0] = 0; S.ctrl[C_STOP0] = kT; }
                 S.lane_exit[t] = L.exit | L.flags << 24;
+                S.lane_start[t] = L.start;
+                S.lane_map[t] = make_uint4((uint32_t)L.map_lo, (uint32_t)(L.map_lo >> 32), (uint32_t)L.map_hi, (uint32_t)(L.map_hi >> 32));
                 __syncthreads();
                 PROF(P_SWEEP0);
                 uint32_t first_stop = kT;                                              // the first lane of the chain with a stop (lanes behind it do not matter)
-                for (int sweep = 0; sweep <= kWaves + 1; ++sweep) {
+                for (int turn = 0; ; ++turn) {
                     PROF_COUNT(P_N_SWEEPS, 1);
-                    // (three slots in turn for "somebody moved" / "first stop": thread 0 prepares the next sweep's, last read two barriers ago)
-                    const int slot = sweep % 3, next_slot = (sweep + 1) % 3;
-                    if (t == 0) { S.ctrl[C_MOVED0 + next_slot] = 0; S.ctrl[C_STOP0 + next_slot] = kT; }
-                    const uint32_t entry = wave ? S.lane_exit[wave * 64 - 1] : rel0;   // (the flags ride along in bits 24..: a stopped predecessor moves nobody)
-                    const bool wave_live = (uint32_t)(wave * 64) <= first_stop;        // first_stop as of the last sweep: waves behind it wait
-                    bool moved_any = false;
-                    if (wave_live) {
-                        for (int inner = 0; inner < 64; ++inner) {
-                            const uint32_t mine = L.exit | L.flags << 24;
-                            const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)entry, (int)mine, 0x138, 0xF, 0xF, false);   // wave_shr:1, lane 0 takes the wave's entry
-                            const uint64_t stopped = __ballot(L.flags != 0);
-                            const uint32_t first = stopped ? (uint32_t)__builtin_ctzll(stopped) : 64u;
-                            const bool moved = t > 0 && !(prev >> 24) && prev != L.start && (uint32_t)lane_in_wave <= first;
-                            if (!__ballot(moved)) break;
-                            moved_any = true;
-                            if (moved) lane_trace<true>(S, L, prev, my_base);
+                    // (three slots in turn for the job count / first stop: thread 0 prepares the next turn's, last read two barriers ago)
+                    const int slot = turn % 3, next_slot = (turn + 1) % 3;
+                    if (t == 0) { S.ctrl[C_JOBS0 + next_slot] = 0; S.ctrl[C_STOP0 + next_slot] = kT; }
+                    const uint32_t prev = t ? S.lane_exit[t - 1] : rel0, mine = S.lane_exit[t];
+                    bool job = t > 0 && !(prev >> 24) && prev != S.lane_start[t] && (uint32_t)t <= first_stop;     // (a stopped predecessor moves nobody)
+                    if (job) {
+                        const uint32_t rel = prev - my_base;                           // (>= 0: a predecessor leaves at or beyond its end)
+                        if (rel < 128u) {
+                            uint4 m = S.lane_map[t];
+                            const uint32_t w = rel >> 5, bit = 1u << (rel & 31u);
+                            const uint32_t word = w == 0 ? m.x : w == 1 ? m.y : w == 2 ? m.z : m.w;
+                            if (word & bit) {                                          // on the known chain already: it begins later, that is all
+                                const uint32_t keep = ~(bit - 1u);
+                                m.x = w == 0 ? m.x & keep : 0u;
+                                m.y = w == 1 ? m.y & keep : w > 1 ? 0u : m.y;
+                                m.z = w == 2 ? m.z & keep : w > 2 ? 0u : m.z;
+                                m.w = w == 3 ? m.w & keep : m.w;
+                                S.lane_map[t] = m; S.lane_start[t] = prev;
+                                job = false;
+                            }
                         }
                     }
-                    const uint64_t stopped = __ballot(L.flags != 0 && wave_live);
-                    if (lane_in_wave == 0) {
-                        if (moved_any) S.ctrl[C_MOVED0 + slot] = 1;
-                        if (stopped) atomicMin(&S.ctrl[C_STOP0 + slot], (uint32_t)(wave * 64) + (uint32_t)__builtin_ctzll(stopped));
+                    const uint64_t jobs = __ballot(job);
+                    if (jobs) {
+                        uint32_t at = 0;
+                        if (lane_in_wave == 0) at = atomicAdd(&S.ctrl[C_JOBS0 + slot], (uint32_t)__popcll(jobs));
+                        at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+                        if (job) S.jobs[at + (uint32_t)__popcll(jobs & ((1ull << lane_in_wave) - 1ull))] = (uint16_t)t;
                     }
-                    S.lane_exit[t] = L.exit | L.flags << 24;
+                    const uint64_t stopped = __ballot((mine >> 24) != 0 && (uint32_t)t <= first_stop);
+                    if (stopped && lane_in_wave == 0) atomicMin(&S.ctrl[C_STOP0 + slot], (uint32_t)(wave * 64) + (uint32_t)__builtin_ctzll(stopped));
                     __syncthreads();
-                    first_stop = S.ctrl[C_STOP0 + slot];
-                    if (!S.ctrl[C_MOVED0 + slot]) break;
+                    const uint32_t njobs = S.ctrl[C_JOBS0 + slot], stop_now = S.ctrl[C_STOP0 + slot];
+                    // settled: nobody has to walk, and the lanes that were held back this turn are the ones that will be held back for good
+                    // (a stop that has just dissolved, or moved, lets other lanes speak up next turn)
+                    const bool settled = !njobs && stop_now == first_stop;
+                    first_stop = stop_now;
+                    if (settled) break;
+                    if ((uint32_t)t < njobs) {
+                        const uint32_t lane = S.jobs[t];
+                        const uint4 m = S.lane_map[lane];
+                        const uint32_t ex = S.lane_exit[lane];
+                        Lane J{ S.lane_start[lane], ex & 0xFFFFFFu, ex >> 24, (uint64_t)m.y << 32 | m.x, (uint64_t)m.w << 32 | m.z };
+                        lane_trace<true>(S, long_lit, long_dist, J, S.lane_exit[lane - 1] & 0xFFFFFFu, lane * kSubBits);
+                        S.lane_exit[lane] = J.exit | J.flags << 24;
+                        S.lane_start[lane] = J.start;
+                        S.lane_map[lane] = make_uint4((uint32_t)J.map_lo, (uint32_t)(J.map_lo >> 32), (uint32_t)J.map_hi, (uint32_t)(J.map_hi >> 32));
+                    }
+                    __syncthreads();
                 }
+                { const uint4 m = S.lane_map[t]; L.start = S.lane_start[t]; L.map_lo = (uint64_t)m.y << 32 | m.x; L.map_hi = (uint64_t)m.w << 32 | m.z; }
                 PROF(P_SWEEPS);
                 uint32_t nvalid = first_stop < (uint32_t)kT ? first_stop + 1u : (uint32_t)kT;      // lanes 0 .. nvalid - 1 form the chain
                 // ---- slots for the tokens (a map bit each), the round cut where the list would overflow
@@ -626,9 +683,10 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                 if (!err && wbase * 8u + last_exit > src_bits) err = E_INPUT;
                 PROF(P_SCAN);
                 if (err) break;
+                prefetch(wbase * 8u + last_exit);                                     // the next round's (or the next header's) window
                 // ---- the tokens themselves, and where every lane's bytes go
                 uint32_t out = 0;
-                if ((uint32_t)t < nvalid) out = lane_emit(S, L, my_base, toks + (tok_incl - ntok), (uint32_t)t);
+                if ((uint32_t)t < nvalid) out = lane_emit(S, long_lit, long_dist, L, my_base, toks + (tok_incl - ntok), (uint32_t)t);
                 const uint32_t out_incl = block_inclusive_sum(S, out, S.cum_out);       // (its barriers also put the tokens in front of their readers)
                 PROF(P_WRITE);
                 // ---- bytes: tiles of whole lanes, at most kNewMax bytes each
@@ -651,32 +709,38 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                         __syncthreads();
                     }
                     if (!sink || produced < (uint32_t)kHist) {
-                        for (uint32_t k = tok0 + (uint32_t)t; k < tok1; k += kT) {
-                            const uint2 tk = toks[k];
-                            const uint32_t lane = (tk.y >> 16) & 0x3FFu;
-                            const uint32_t off = (lane ? S.cum_out[lane - 1] : 0u) - out0 + (tk.y & 0x7FFFu);      // tile-relative
-                            if (tk.y >> 31) {
-                                const uint32_t len = tk.x & 0xFFFFu, dist = tk.x >> 16;
-                                if (produced < (uint32_t)kHist && dist > produced + off) atomicMax(&S.ctrl[C_ERR], (uint32_t)E_DISTANCE);      // reaches before the first output byte
-                                else if (!sink) {
-                                    // byte i copies byte i - dist, i.e. byte i mod dist of the dist bytes before the match: pointing there at once
-                                    // keeps the chains of overlapping copies (runs) one link long.  Long matches are left to a whole wave.
-                                    const uint32_t q = off + kHist - dist;              // position of the first source byte
-                                    uint32_t slot = kLongCap;
-                                    if (len >= (uint32_t)kLongMin) slot = atomicAdd(&S.ctrl[C_NLONG], 1u);
-                                    if (slot < (uint32_t)kLongCap) S.longm[slot] = make_uint2(off, len | dist << 16);
-                                    else for (uint32_t i = 0, m = 0; i < len; ++i) { S.from[off + i] = (uint16_t)(q + m); if (++m == dist) m = 0; }
+                        for (uint32_t k0 = tok0 + (uint32_t)t; k0 < tok1; k0 += 4u * kT) {
+                            uint2 four[4];                                             // four loads in flight (an absent token reads as an empty literal)
+                            #pragma unroll
+                            for (int u = 0; u < 4; ++u) four[u] = k0 + (uint32_t)u * kT < tok1 ? toks[k0 + (uint32_t)u * kT] : make_uint2(0u, 0u);
+                            #pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const uint2 tk = four[u];
+                                const uint32_t lane = (tk.y >> 16) & 0x3FFu;
+                                const uint32_t off = (lane ? S.cum_out[lane - 1] : 0u) - out0 + (tk.y & 0x7FFFu);      // tile-relative
+                                if (tk.y >> 31) {
+                                    const uint32_t len = tk.x & 0xFFFFu, dist = tk.x >> 16;
+                                    if (produced < (uint32_t)kHist && dist > produced + off) atomicMax(&S.ctrl[C_ERR], (uint32_t)E_DISTANCE);      // reaches before the first output byte
+                                    else if (!sink) {
+                                        // byte i copies byte i - dist, i.e. byte i mod dist of the dist bytes before the match: pointing there at once
+                                        // keeps the chains of overlapping copies (runs) one link long.  Long matches are left to a whole wave.
+                                        const uint32_t q = off + kHist - dist;          // position of the first source byte
+                                        uint32_t slot = kLongCap;
+                                        if (len >= (uint32_t)kLongMin) slot = atomicAdd(&S.ctrl[C_NLONG], 1u);
+                                        if (slot < (uint32_t)kLongCap) S.longm[slot] = make_uint2(off, len | dist << 16);
+                                        else for (uint32_t i = 0, m = 0; i < len; ++i) { S.from[off + i] = (uint16_t)(q + m); if (++m == dist) m = 0; }
+                                    }
+                                } else if (!sink) {
+                                    const uint32_t n = tk.x & 3u;
+                                    if (n) S.ring[(produced + off) & kRingMask] = (uint8_t)(tk.x >> 16);
+                                    if (n > 1u) S.ring[(produced + off + 1u) & kRingMask] = (uint8_t)(tk.x >> 24);
                                 }
-                            } else if (!sink) {
-                                const uint32_t n = tk.x & 3u;
-                                if (n) S.ring[(produced + off) & kRingMask] = (uint8_t)(tk.x >> 16);
-                                if (n > 1u) S.ring[(produced + off + 1u) & kRingMask] = (uint8_t)(tk.x >> 24);
                             }
                         }
                         __syncthreads();
                         err = S.ctrl[C_ERR];
                     }
-                    PROF(P_MATCH);
+                    PROF(P_STORED);                                                    // (the slot of the stored blocks doubles as "tokens into the tile")
                     if (!sink && !err) {
                         expand_long_matches(S);
                         __syncthreads();

@@ -55,28 +55,37 @@ constexpr int kLitBits = INFLATE_LIT_BITS, kDistBits = 10;         // primary lo
 enum : uint32_t { F_EOB = 1, F_BAD = 2 };
 // status word per stream (0 = ok)
 enum : uint32_t { E_BLOCK_TYPE = 1, E_STORED = 2, E_LENGTHS = 3, E_CODE = 4, E_DISTANCE = 5, E_INPUT = 6 };
-enum { C_JOBS0 = 0, C_JOBS1, C_JOBS2, C_STOP0, C_STOP1, C_STOP2, C_CUT, C_OPEN0, C_OPEN1, C_OPEN2, C_NLONG, C_ERR, C_BTYPE, C_FINAL, C_HDR_END_LO, C_HDR_END_HI, C_HLIT, C_HDIST, C_N };
+enum { C_JOBS0 = 0, C_JOBS1, C_JOBS2, C_STOP0, C_STOP1, C_STOP2, C_CUT, C_OPEN0, C_OPEN1, C_OPEN2, C_NLONG, C_ERR, C_BTYPE, C_FINAL, C_HDR_END_LO, C_HDR_END_HI, C_HLIT, C_HDIST, C_HCLEN, C_N };
 
 struct InfItem { const uint8_t* src; uint8_t* dst; uint32_t src_len, dst_cap; };
 
 #ifndef INFLATE_PROFILE           // measurement only (tools/variant.sh inflate:prof:-DINFLATE_PROFILE=1): cycles per phase, summed over streams
 #define INFLATE_PROFILE 0
 #endif
-enum { P_HEADER = 0, P_TABLES, P_WINDOW, P_SWEEP0, P_SWEEPS, P_SCAN, P_WRITE, P_MATCH, P_FLUSH, P_STORED, P_N_BLOCKS, P_N_CHUNKS, P_N_SWEEPS, P_N_ROUNDS, P_N_MATCHES, P_N };
+enum { P_HEADER = 0, P_TABLES, P_WINDOW, P_SWEEP0, P_SWEEPS, P_SCAN, P_WRITE, P_MATCH, P_FLUSH, P_STORED,
+       P_H_FIELDS, P_H_CODE, P_H_WALKS, P_H_EMIT, P_T_RANKS, P_T_STARTS, P_T_SORT, P_T_LIT, P_T_DIST, P_T_LONG,
+       P_N_BLOCKS, P_N_CHUNKS, P_N_SWEEPS, P_N_ROUNDS, P_N_MATCHES, P_N };
 #if INFLATE_PROFILE
 __device__ unsigned long long g_inflate_prof[P_N];
-#define PROF_DECL unsigned long long prof_t0 = clock64(), prof_acc[P_N] = {}
-#define PROF(slot) do { const unsigned long long now_ = clock64(); prof_acc[slot] += now_ - prof_t0; prof_t0 = now_; } while (0)
-#define PROF_COUNT(slot, n) (prof_acc[slot] += (n))
-#define PROF_FLUSH do { if (threadIdx.x == 0) for (int k_ = 0; k_ < P_N; ++k_) atomicAdd(&g_inflate_prof[k_], prof_acc[k_]); } while (0)
+struct Prof {
+    unsigned long long t0 = clock64(), acc[P_N] = {};
+    __device__ __forceinline__ void mark(int slot) { const unsigned long long now = clock64(); acc[slot] += now - t0; t0 = now; }
+    __device__ __forceinline__ void count(int slot, unsigned long long n) { acc[slot] += n; }
+    __device__ __forceinline__ void flush() { if (threadIdx.x == 0) for (int k = 0; k < P_N; ++k) atomicAdd(&g_inflate_prof[k], acc[k]); }
+};
 #else
-#define PROF_DECL
-#define PROF(slot)
-#define PROF_COUNT(slot, n)
-#define PROF_FLUSH
+struct Prof {
+    __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void count(int, unsigned long long) {}
+    __device__ __forceinline__ void flush() {}
+};
 #endif
+#define PROF_DECL Prof prof
+#define PROF(slot) prof.mark(slot)
+#define PROF_COUNT(slot, n) prof.count(slot, n)
+#define PROF_FLUSH prof.flush()
 
-struct Canon { uint32_t first[16], count[16], offs[16]; };
+struct __attribute__((aligned(16))) Canon { uint32_t first[16], count[16], offs[16]; };
 
 struct Shared {
     __attribute__((aligned(16))) uint8_t ring[kRing];
@@ -94,6 +103,8 @@ struct Shared {
     uint32_t cum_out[kT], cum_tok[kT];               // inclusive prefix sums over the lanes of a round
     uint2    longm[kLongCap];                        // long matches of the tile: x = first byte (tile-relative), y = length | distance << 16
     uint32_t wave_sum[kWaves];
+    uint32_t wave_count[5][16];                      // build_tables: literal / length symbols of every code length, per wave
+    uint32_t cl_code[19];                            // code-length alphabet: bit-reversed code << 4 | length (0: unused symbol)
     uint32_t lit_sorted[288], dist_sorted[32];       // symbol payloads in canonical order
     Canon    lit, dist;
     uint32_t cl_lut[128];
@@ -135,11 +146,15 @@ template <int FROM, int TO = 15> struct CodeRange {
     uint32_t first[TO - FROM + 1], count[TO - FROM + 1], offs[TO - FROM + 1];
     __device__ __forceinline__ void load(const Canon& c)
     {
+        // (every read in flight first; then the values -- the same for every lane -- move to scalar registers)
+        uint32_t f[TO - FROM + 1], n[TO - FROM + 1], o[TO - FROM + 1];
         #pragma unroll
-        for (int l = FROM; l <= TO; ++l) {                          // (the same for every lane: scalar registers)
-            first[l - FROM] = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.first[l]);
-            count[l - FROM] = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.count[l]);
-            offs[l - FROM] = (uint32_t)__builtin_amdgcn_readfirstlane((int)c.offs[l]);
+        for (int l = FROM; l <= TO; ++l) { f[l - FROM] = c.first[l]; n[l - FROM] = c.count[l]; o[l - FROM] = c.offs[l]; }
+        #pragma unroll
+        for (int l = FROM; l <= TO; ++l) {
+            first[l - FROM] = (uint32_t)__builtin_amdgcn_readfirstlane((int)f[l - FROM]);
+            count[l - FROM] = (uint32_t)__builtin_amdgcn_readfirstlane((int)n[l - FROM]);
+            offs[l - FROM] = (uint32_t)__builtin_amdgcn_readfirstlane((int)o[l - FROM]);
         }
     }
     // `bits` holds the stream bits LSB first; lengths up to `to` only; 0 = no code of these lengths matches
@@ -158,51 +173,78 @@ template <int FROM, int TO = 15> struct CodeRange {
 };
 template <int FROM> using LongCodes = CodeRange<FROM, 15>;
 
-// canonical code of `n` symbols with lengths S.lens[base .. base + n): Canon, payloads in canonical order, primary table.
-// Validity as zlib's inflate_table: over-subscribed sets fail; incomplete ones too, unless the set is a single 1-bit code.
-template <bool DIST>
-__device__ void build_table(Shared& S, int base, int n)
+// The two canonical codes of a block -- hlit literal / length symbols with lengths S.lens[0 ..), hdist distance symbols with lengths
+// S.lens[dist_base ..) -- in one go: Canon, payloads in canonical order, primary tables.  Threads 0-287 hold a literal / length symbol
+// each, threads 288-319 a distance symbol: a symbol's rank among the symbols of its length is a ballot inside its wave plus the
+// counts of the waves before it; code starts and offsets are prefix sums over the 15 lengths (DPP, lanes 0-15 and 16-31 of wave 0).
+// Validity as zlib's inflate_table: over-subscribed sets fail; incomplete ones too, unless no code is longer than one bit.
+__device__ void build_tables(Shared& S, int hlit, int dist_base, int hdist, Prof& prof)
 {
-    const int t = threadIdx.x;
-    Canon& c = DIST ? S.dist : S.lit;
-    uint32_t* sorted = DIST ? S.dist_sorted : S.lit_sorted;
-    uint32_t* lut = DIST ? S.lut + (1 << kLitBits) : S.lut;
-    constexpr int P = DIST ? kDistBits : kLitBits;
-    if (t < 16) c.count[t] = 0;
-    __syncthreads();
-    for (int s = t; s < n; s += kT) { const uint32_t L = S.lens[base + s]; if (L) atomicAdd(&c.count[L], 1u); }
-    __syncthreads();
-    if (t == 0) {
-        int left = 1, maxlen = 0; bool over = false;
-        for (int l = 1; l <= 15; ++l) { left = left * 2 - (int)c.count[l]; if (left < 0) over = true; if (c.count[l]) maxlen = l; }
-        if (over || (left > 0 && maxlen > 1)) atomicMax(&S.ctrl[C_ERR], (uint32_t)E_LENGTHS);
-        c.first[0] = 0; c.offs[0] = 0; c.first[1] = 0; c.offs[1] = 0;
-        for (int l = 2; l <= 15; ++l) { c.first[l] = (c.first[l - 1] + c.count[l - 1]) << 1; c.offs[l] = c.offs[l - 1] + c.count[l - 1]; }
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const bool is_lit = t < 288;
+    uint32_t mylen = 0, rank = 0;
+    if (wave < 5) {
+        if (is_lit) { if (t < hlit) mylen = S.lens[t]; }
+        else if (t - 288 < hdist) mylen = S.lens[dist_base + t - 288];
+        const uint64_t lit_lanes = wave < 4 ? ~0ull : 0xFFFFFFFFull;        // wave 4: symbols 256-287, then the distance symbols
+        const uint64_t below = (1ull << lane) - 1ull;
+        for (uint32_t l = 1; l <= 15; ++l) {
+            const uint64_t m = __ballot(mylen == l);
+            if (mylen == l) rank = (uint32_t)__popcll((is_lit ? m & lit_lanes : m & ~lit_lanes) & below);
+            if (lane == 0) { S.wave_count[wave][l] = (uint32_t)__popcll(m & lit_lanes); if (wave == 4) S.dist.count[l] = (uint32_t)__popcll(m & ~lit_lanes); }
+        }
     }
     __syncthreads();
-    for (int s = t; s < n; s += kT) {
-        const uint32_t L = S.lens[base + s];
-        if (!L) continue;
-        uint32_t rank = 0;
-        for (int k = 0; k < s; ++k) rank += S.lens[base + k] == L;
-        sorted[c.offs[L] + rank] = DIST ? dist_payload((uint32_t)s) : lit_payload((uint32_t)s);
+    PROF(P_T_RANKS);
+    if (t < 32) {
+        const uint32_t l = (uint32_t)t & 15u;
+        Canon& c = t < 16 ? S.lit : S.dist;
+        uint32_t cnt = 0;
+        if (l) cnt = t < 16 ? S.wave_count[0][l] + S.wave_count[1][l] + S.wave_count[2][l] + S.wave_count[3][l] + S.wave_count[4][l] : S.dist.count[l];
+        // first[l] = sum over j < l of count[j] << (l - j): a prefix sum of count[j] << (15 - j), shifted back; offs[l] = codes shorter than l
+        uint32_t kraft = cnt << (15u - l), offs = cnt;
+#define ROW_SCAN_STEP(CTRL) kraft += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)kraft, CTRL, 0xF, 0xF, false); offs += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)offs, CTRL, 0xF, 0xF, false)
+        ROW_SCAN_STEP(0x111); ROW_SCAN_STEP(0x112); ROW_SCAN_STEP(0x114); ROW_SCAN_STEP(0x118);      // row_shr:1, 2, 4, 8: inside the row of 16 lanes
+#undef ROW_SCAN_STEP
+        c.count[l] = cnt;
+        c.first[l] = l ? (kraft - (cnt << (15u - l))) >> (15u - l) : 0u;
+        c.offs[l] = offs - cnt;
+        const uint64_t used = __ballot(cnt != 0);
+        const uint32_t row = t < 16 ? (uint32_t)used & 0xFFFFu : (uint32_t)(used >> 16) & 0xFFFFu;
+        const uint32_t maxlen = row ? 31u - (uint32_t)__builtin_clz(row) : 0u;
+        if (l == 15u && (kraft > 32768u || (kraft < 32768u && maxlen > 1u))) atomicMax(&S.ctrl[C_ERR], (uint32_t)E_LENGTHS);
     }
     __syncthreads();
-    CodeRange<1, P> codes; codes.load(c);
-    for (int e = t; e < (1 << P); e += kT) {
-        uint32_t r = codes.decode((uint32_t)e, sorted);
-        if constexpr (!DIST) {
+    PROF(P_T_STARTS);
+    if (mylen) {
+        const Canon& c = is_lit ? S.lit : S.dist;
+        uint32_t at = c.offs[mylen] + rank;
+        if (is_lit) for (int w = 0; w < wave; ++w) at += S.wave_count[w][mylen];
+        if (is_lit) S.lit_sorted[at] = lit_payload((uint32_t)t); else S.dist_sorted[at] = dist_payload((uint32_t)t - 288u);
+    }
+    __syncthreads();
+    PROF(P_T_SORT);
+    {
+        CodeRange<1, kLitBits> codes; codes.load(S.lit);
+        for (int e = t; e < (1 << kLitBits); e += kT) {
+            uint32_t r = codes.decode((uint32_t)e, S.lit_sorted);
             // two literals behind one look-up when both codes fit the index (kind 4: base = first | second << 8): residual data
             // of photographs is mostly literals of 3-6 bits
             const uint32_t l1 = r & 15u;
-            if (r && ((r >> 4) & 7u) == 0u && l1 < (uint32_t)P) {
-                const uint32_t r2 = codes.decode((uint32_t)e >> l1, sorted, P - (int)l1);
+            if (r && ((r >> 4) & 7u) == 0u && l1 < (uint32_t)kLitBits) {
+                const uint32_t r2 = codes.decode((uint32_t)e >> l1, S.lit_sorted, kLitBits - (int)l1);
                 if (r2 && ((r2 >> 4) & 7u) == 0u) r = ((r >> 16) | (r2 >> 16) << 8) << 16 | l1 << 12 | 4u << 4 | (l1 + (r2 & 15u));
             }
+            S.lut[e] = r;
         }
-        lut[e] = r;
+    }
+    PROF(P_T_LIT);
+    {
+        CodeRange<1, kDistBits> codes; codes.load(S.dist);
+        for (int e = t; e < (1 << kDistBits); e += kT) S.lut[(1 << kLitBits) + e] = codes.decode((uint32_t)e, S.dist_sorted);
     }
     __syncthreads();
+    PROF(P_T_DIST);
 }
 
 // What a lane knows about its sub-sequence: where it starts, where its chain of tokens leaves it (the first token boundary at or
@@ -400,6 +442,108 @@ __device__ __forceinline__ int resolve_copies(Shared& S, uint32_t cs, uint32_t t
     return round + 1;
 }
 
+// The code lengths of a dynamic block are themselves a Huffman stream (symbols 0-15 a length, 16 / 17 / 18 repeats with 2 / 3 / 7
+// extra bits): wave 0 reads it the way the workgroup reads the block -- lane k walks 32 bits from bit 32 k as if a symbol began
+// there, lanes restart from their predecessor's exit (DPP) until nobody moves, a prefix sum of the lengths each lane yields
+// places them, one more walk writes S.lens[].
+struct ClWalk { uint32_t exit, count, last; };       // last: 0x100 | length, once a symbol other than 16 has set the running length
+template <bool EMIT>
+__device__ __forceinline__ ClWalk cl_walk(Shared& S, uint32_t from, uint32_t end, uint32_t i0, uint32_t prev, uint32_t total, uint32_t& bad, uint32_t& end_pos)
+{
+    // (a lane is 32 bits and a symbol 14 at the most: 64 bits read once serve the whole walk)
+    const uint64_t bits = peek64(S.win, from);
+    uint32_t pos = from, n = 0, last = 0;
+    while (pos < end) {
+        const uint32_t b = (uint32_t)(bits >> (pos - from));
+        const uint32_t e = S.cl_lut[b & 127u];
+        const uint32_t L = e & 15u, sym = e >> 4;                   // (the code is complete: every pattern is a symbol)
+        const uint32_t xb = sym < 16u ? 0u : sym == 16u ? 2u : sym == 17u ? 3u : 7u;
+        const uint32_t x = __builtin_amdgcn_ubfe(b, L, xb);
+        const uint32_t rep = sym < 16u ? 1u : sym == 18u ? 11u + x : 3u + x;
+        const uint32_t val = sym < 16u ? sym : sym == 16u ? prev : 0u;
+        if (EMIT) {
+            const uint32_t i = i0 + n;
+            if (i < total) {                                      // (what follows the last length is the block's data)
+                if ((sym == 16u && i == 0u) || i + rep > total) bad = 1u;
+                else {
+                    for (uint32_t k = 0; k < rep; ++k) S.lens[i + k] = (uint8_t)val;
+                    if (i + rep == total) end_pos = pos + L + xb;
+                }
+            }
+        }
+        if (sym != 16u) { prev = val; last = 0x100u | val; }
+        n += rep; pos += L + xb;
+        if (!L) break;                                            // (never: the caller has checked the code)
+    }
+    return ClWalk{ pos, n, last };
+}
+
+// -> window-relative bit behind the last code length, 0 = the lengths are invalid (an over-subscribed or incomplete code-length code
+// -- zlib accepts neither --, a repeat with nothing to repeat, or lengths past the end).  `h`: the bit the hclen 3-bit lengths begin at.
+__device__ __forceinline__ uint32_t read_code_lengths(Shared& S, uint32_t h, uint32_t hclen, uint32_t total, Prof& prof)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    // the code-length code: lane s < 19 owns symbol s; its 3-bit length stands at the place the permutation gives it
+    constexpr uint64_t kPlaceLo = 3ull | 17ull << 5 | 15ull << 10 | 13ull << 15 | 11ull << 20 | 9ull << 25 | 7ull << 30 | 5ull << 35 | 4ull << 40 | 6ull << 45 | 8ull << 50 | 10ull << 55;   // symbols 0-11
+    constexpr uint64_t kPlaceHi = 12ull | 14ull << 5 | 16ull << 10 | 18ull << 15 | 0ull << 20 | 1ull << 25 | 2ull << 30;                                                        // symbols 12-18
+    const uint32_t place = lane < 12u ? (uint32_t)(kPlaceLo >> (5u * lane)) & 31u : (uint32_t)(kPlaceHi >> (5u * (lane < 19u ? lane - 12u : 0u))) & 31u;
+    const uint64_t bb = peek64(S.win, h);                          // 19 x 3 bits at the most
+    const uint32_t len = lane < 19u && place < hclen ? (uint32_t)(bb >> (3u * place)) & 7u : 0u;
+    uint32_t next = 0, code = 0, kraft = 0;
+    #pragma unroll
+    for (uint32_t l = 1; l <= 7; ++l) {
+        const uint64_t m = __ballot(len == l);
+        if (len == l) code = next + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        const uint32_t n = (uint32_t)__popcll(m);
+        kraft += n << (7u - l);
+        next = (next + n) << 1;
+    }
+    if (kraft != 128u) return 0u;
+    h += 3u * hclen;
+    if (lane < 19u) S.cl_code[lane] = len ? (__brev(code) >> (32u - len)) << 4 | len : 0u;
+    for (uint32_t e = lane; e < 128u; e += 64u) {
+        uint32_t r = 0;
+        for (uint32_t sym = 0; sym < 19u; ++sym) {
+            const uint32_t c = S.cl_code[sym], L = c & 15u;
+            if (L && (e & ((1u << L) - 1u)) == c >> 4) r = sym << 4 | L;
+        }
+        S.cl_lut[e] = r;
+    }
+    PROF(P_H_CODE);
+    uint32_t done = 0, carry = 0, bad = 0, end_pos = 0;
+    for (int round = 0; round < 6 && done < total && !bad; ++round) {
+        const uint32_t base = h + 32u * lane, end = base + 32u;
+        uint32_t start = base;
+        ClWalk r = cl_walk<false>(S, start, end, 0, 0, 0, bad, end_pos);
+        for (int turn = 0; turn < 64; ++turn) {
+            const uint32_t prev_exit = (uint32_t)__builtin_amdgcn_update_dpp((int)h, (int)r.exit, 0x138, 0xF, 0xF, false);      // wave_shr:1
+            const uint64_t enough = __ballot(done + wave_inclusive_sum(r.count) >= total);
+            const uint32_t need = enough ? (uint32_t)__builtin_ctzll(enough) : 64u;            // lanes behind it read the block's data
+            const bool moved = lane > 0u && prev_exit != start && lane <= need;
+            if (!__ballot(moved)) break;
+            if (moved) { start = prev_exit; r = cl_walk<false>(S, start, end, 0, 0, 0, bad, end_pos); }
+        }
+        PROF(P_H_WALKS);
+        const uint32_t incl = wave_inclusive_sum(r.count);
+        // the running length a lane begins with: the last one set in front of it
+        uint32_t set = r.last;
+        #pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)set, d); if (lane >= (uint32_t)d && !(set & 0x100u)) set = o; }
+        uint32_t before = (uint32_t)__shfl_up((int)set, 1);
+        if (lane == 0u || !(before & 0x100u)) before = carry;
+        if (done + incl - r.count < total) cl_walk<true>(S, start, end, done + incl - r.count, before & 0xFFu, total, bad, end_pos);
+        bad = __ballot(bad != 0) ? 1u : 0u;
+        const uint64_t ended = __ballot(end_pos != 0u);
+        if (ended) end_pos = (uint32_t)__builtin_amdgcn_readlane((int)end_pos, __builtin_ctzll(ended));
+        done += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        h = (uint32_t)__builtin_amdgcn_readlane((int)r.exit, 63);
+        const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)set, 63);
+        if (all & 0x100u) carry = all;
+        PROF(P_H_EMIT);
+    }
+    return bad || !end_pos ? 0u : end_pos;
+}
+
 __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_items, uint2* tok_scratch, uint32_t* out_len, uint32_t* status)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -495,49 +639,8 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                 const uint32_t hlit = ((uint32_t)bb & 31u) + 257u, hdist = ((uint32_t)(bb >> 5) & 31u) + 1u, hclen = ((uint32_t)(bb >> 10) & 15u) + 4u;
                 p += 14;
                 S.ctrl[C_HLIT] = hlit; S.ctrl[C_HDIST] = hdist;
-                uint32_t bad = (hlit > 286u || hdist > 30u) ? 1u : 0u;
-                // the code-length code: 19 symbols of at most 7 bits, into a 128-entry table (entry = symbol << 4 | length)
-                const uint8_t order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
-                uint32_t cl[19]; uint32_t count[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-                for (int i = 0; i < 19; ++i) cl[i] = 0;
-                bb = peek64(S.win, p);
-                for (uint32_t i = 0; i < hclen; ++i) { const uint32_t v = (uint32_t)(bb >> (3u * i)) & 7u; cl[order[i]] = v; }
-                p += 3u * hclen;
-                for (int i = 0; i < 19; ++i) ++count[cl[i]];
-                count[0] = 0;
-                int left = 1;
-                for (int l = 1; l <= 7; ++l) { left = left * 2 - (int)count[l]; if (left < 0) bad = 1; }
-                if (left > 0) bad = 1;                                               // zlib: an incomplete code-length code is invalid
-                for (int e = 0; e < 128; ++e) S.cl_lut[e] = 0;
-                if (!bad) {
-                    uint32_t next[8]; next[1] = 0;
-                    for (int l = 2; l <= 7; ++l) next[l] = (next[l - 1] + count[l - 1]) << 1;
-                    for (uint32_t s = 0; s < 19u; ++s) {
-                        const uint32_t L = cl[s];
-                        if (!L) continue;
-                        const uint32_t code = next[L]++, rev = __brev(code) >> (32u - L);
-                        for (uint32_t e = rev; e < 128u; e += 1u << L) S.cl_lut[e] = s << 4 | L;
-                    }
-                    // the hlit + hdist code lengths
-                    const uint32_t total = hlit + hdist;
-                    uint32_t i = 0, prev = 0, have = 0; uint64_t buf = 0;
-                    while (i < total && !bad) {
-                        if (have < 16u) { buf = peek64(S.win, p); have = 64; }
-                        const uint32_t e = S.cl_lut[(uint32_t)buf & 127u];
-                        const uint32_t L = e & 15u, s = e >> 4;
-                        if (!L) { bad = 1; break; }
-                        buf >>= L; have -= L; p += L;
-                        if (s < 16u) { S.lens[i++] = (uint8_t)s; prev = s; continue; }
-                        uint32_t rep, val = 0;
-                        if (s == 16u) { if (i == 0) { bad = 1; break; } val = prev; rep = 3u + ((uint32_t)buf & 3u); buf >>= 2; have -= 2; p += 2; }
-                        else if (s == 17u) { rep = 3u + ((uint32_t)buf & 7u); buf >>= 3; have -= 3; p += 3; prev = 0; }
-                        else { rep = 11u + ((uint32_t)buf & 127u); buf >>= 7; have -= 7; p += 7; prev = 0; }
-                        if (i + rep > total) { bad = 1; break; }
-                        for (uint32_t k = 0; k < rep; ++k) S.lens[i++] = (uint8_t)val;
-                    }
-                    if (!bad && S.lens[256] == 0) bad = 1;                           // no end-of-block code
-                }
-                if (bad) atomicMax(&S.ctrl[C_ERR], (uint32_t)E_LENGTHS);
+                S.ctrl[C_HCLEN] = hclen;
+                if (hlit > 286u || hdist > 30u) atomicMax(&S.ctrl[C_ERR], (uint32_t)E_LENGTHS);
             } else if (btype == 1u) {
                 if (!fixed_tables) {
                     for (int s = 0; s < 288; ++s) S.lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
@@ -549,8 +652,21 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
             S.ctrl[C_HDR_END_LO] = (uint32_t)end; S.ctrl[C_HDR_END_HI] = (uint32_t)(end >> 32);
         }
         __syncthreads();
+        PROF(P_H_FIELDS);
         const uint32_t btype = S.ctrl[C_BTYPE];
         const bool bfinal = S.ctrl[C_FINAL] != 0;
+        if (btype == 2u && !S.ctrl[C_ERR]) {                                       // the hlit + hdist code lengths
+            if (wave == 0) {
+                const uint32_t h = S.ctrl[C_HDR_END_LO] - (uint32_t)(base_byte * 8u);      // (window-relative: the header began inside the first dword)
+                const uint32_t end_rel = read_code_lengths(S, h, S.ctrl[C_HCLEN], S.ctrl[C_HLIT] + S.ctrl[C_HDIST], prof);
+                if (t == 0) {
+                    if (!end_rel || S.lens[256] == 0) atomicMax(&S.ctrl[C_ERR], (uint32_t)E_LENGTHS);      // (no end-of-block code)
+                    const uint64_t end = base_byte * 8u + end_rel;
+                    S.ctrl[C_HDR_END_LO] = (uint32_t)end; S.ctrl[C_HDR_END_HI] = (uint32_t)(end >> 32);
+                }
+            }
+            __syncthreads();
+        }
         pos = (uint64_t)S.ctrl[C_HDR_END_HI] << 32 | S.ctrl[C_HDR_END_LO];
         err = S.ctrl[C_ERR];
         if (!err && pos > src_bits) err = E_INPUT;
@@ -580,15 +696,14 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
             // -------------------------------------------------------------- Huffman block: tables, then rounds
             const int hlit = (int)S.ctrl[C_HLIT], hdist = (int)S.ctrl[C_HDIST];
             if (!(btype == 1u && fixed_tables)) {
-                build_table<false>(S, 0, hlit);
-                build_table<true>(S, btype == 1u ? 288 : hlit, hdist);
+                build_tables(S, hlit, btype == 1u ? 288 : hlit, hdist, prof);
             }
             fixed_tables = btype == 1u;
             err = S.ctrl[C_ERR];
-            PROF(P_TABLES);
             if (err) break;
             LongLit long_lit; long_lit.load(S.lit);                                   // the code lengths behind the primary tables
             LongDist long_dist; long_dist.load(S.dist);
+            PROF(P_T_LONG);
             bool in_block = true;
             while (in_block && !err) {
                 // (the window the header was read from serves the block's first round: the lanes in front of `pos` are passed over like

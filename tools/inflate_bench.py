@@ -19,7 +19,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import gen  # noqa: E402
 from gamut_amd import _capi  # noqa: E402
 
-PHASES = ["header", "tables", "window", "sweep0", "sweeps", "scan", "write", "match", "flush", "stored", "#blocks", "#chunks", "#sweeps", "#rounds", "#matches"]
+PHASES = ["header", "tables", "window", "sweep0", "sweeps", "scan", "emit", "resolve", "flush", "fill", "h:fields", "h:code", "h:walks", "h:emit", "t:ranks", "t:starts", "t:sort", "t:lit", "t:dist", "t:long", "#blocks", "#rounds", "#turns", "#doublings", "#matches"]
+NPH = 20
 
 
 def idat(png):
@@ -92,9 +93,9 @@ def main():
         print(f"  {N} streams: {best * 1e3:.1f} ms, {N * cap / best / 1e9:.1f} GB/s inflated ({N * w * h / best / 1e6:.0f} Mpx/s), parity {'ok' if ok else 'FAIL'}")
         if prof:
             buf = (C.c_ulonglong * len(PHASES))(); prof(buf, 0)
-            v = list(buf); tot = sum(v[:10]) or 1
-            print("  cycles: " + ", ".join(f"{PHASES[k]} {100 * v[k] / tot:.1f}%" for k in range(10) if v[k]))
-            print("  per stream: " + ", ".join(f"{PHASES[k]} {v[k] / N:.0f}" for k in range(10, len(PHASES))) + f"; {tot / N / 1e6:.1f} Mcycles")
+            v = list(buf); tot = sum(v[:NPH]) or 1
+            print("  cycles: " + ", ".join(f"{PHASES[k]} {100 * v[k] / tot:.1f}%" for k in range(NPH) if v[k]))
+            print("  per stream: " + ", ".join(f"{PHASES[k]} {v[k] / N:.0f}" for k in range(NPH, len(PHASES))) + f"; {tot / N / 1e6:.1f} Mcycles")
         for p in (dcomp, dout, dlen):
             L.gamut_hip_device_free(p)
 

@@ -362,15 +362,21 @@ __device__ __forceinline__ uint32_t block_inclusive_sum(Shared& S, uint32_t v, u
     return incl;
 }
 
-// S.from[] for the matches the token pass left in S.longm: one match per wave and pass, 64 bytes per step
+// S.from[] for the matches the token pass left in S.longm (x = first byte | bytes between the run's first match and this one << 16,
+// y = length | distance << 16): one match per wave and pass, 64 bytes per step
 __device__ __forceinline__ void expand_long_matches(Shared& S)
 {
     const uint32_t n = S.ctrl[C_NLONG] < (uint32_t)kLongCap ? S.ctrl[C_NLONG] : (uint32_t)kLongCap;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (uint32_t m = wave; m < n; m += kWaves) {
         const uint2 e = S.longm[m];
-        const uint32_t at = e.x, len = e.y & 0xFFFFu, dist = e.y >> 16, q = at + kHist - dist;
-        for (uint32_t i = lane; i < len; i += 64u) S.from[at + i] = (uint16_t)(q + (dist >= len ? i : i % dist));
+        const uint32_t at = e.x & 0xFFFFu, back = e.x >> 16, len = e.y & 0xFFFFu, dist = e.y >> 16, q = at - back + kHist - dist;
+        if (back + len <= dist) { for (uint32_t i = lane; i < len; i += 64u) S.from[at + i] = (uint16_t)(q + back + i); }
+        else {
+            const uint32_t step = 64u % dist;
+            uint32_t r = (back + lane) % dist;                     // (back + i) mod dist, kept up by additions
+            for (uint32_t i = lane; i < len; i += 64u) { S.from[at + i] = (uint16_t)(q + r); r += step; if (r >= dist) r -= dist; }
+        }
     }
 }
 
@@ -824,26 +830,38 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                         __syncthreads();
                     }
                     if (!sink || produced < (uint32_t)kHist) {
-                        for (uint32_t k0 = tok0 + (uint32_t)t; k0 < tok1; k0 += 4u * kT) {
+                        for (uint32_t kb = tok0; kb < tok1; kb += 4u * kT) {             // (the same trips for every thread: the neighbours' tokens travel by DPP)
                             uint2 four[4];                                             // four loads in flight (an absent token reads as an empty literal)
                             #pragma unroll
-                            for (int u = 0; u < 4; ++u) four[u] = k0 + (uint32_t)u * kT < tok1 ? toks[k0 + (uint32_t)u * kT] : make_uint2(0u, 0u);
+                            for (int u = 0; u < 4; ++u) { const uint32_t k = kb + (uint32_t)t + (uint32_t)u * kT; four[u] = k < tok1 ? toks[k] : make_uint2(0u, 0u); }
                             #pragma unroll
                             for (int u = 0; u < 4; ++u) {
                                 const uint2 tk = four[u];
                                 const uint32_t lane = (tk.y >> 16) & 0x3FFu;
                                 const uint32_t off = (lane ? S.cum_out[lane - 1] : 0u) - out0 + (tk.y & 0x7FFFu);      // tile-relative
-                                if (tk.y >> 31) {
-                                    const uint32_t len = tk.x & 0xFFFFu, dist = tk.x >> 16;
+                                const bool match = tk.y >> 31;
+                                const uint32_t len = tk.x & 0xFFFFu, dist = tk.x >> 16;
+                                // A match right behind a match of the same distance goes on with its period (a run cut into 258-byte pieces,
+                                // the pixels of a flat row): all of them copy from in front of the FIRST one, so the pieces of a run are one
+                                // link deep instead of one link per piece.  The first one is looked for among the wave's 64 tokens.
+                                const uint32_t before_x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tk.x, 0x138, 0xF, 0xF, false);      // wave_shr:1 (lane 0: no token)
+                                const uint32_t before_y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tk.y, 0x138, 0xF, 0xF, false);
+                                const bool goes_on = match && (before_y >> 31) && (before_x >> 16) == dist;
+                                uint32_t first = goes_on ? 0u : off + 1u;               // -> the nearest token in front that does not go on, + 1
+#define RUN_STEP(CTRL, ROWS) { const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)first, CTRL, ROWS, 0xF, false); first = o > first ? o : first; }
+                                RUN_STEP(0x111, 0xF) RUN_STEP(0x112, 0xF) RUN_STEP(0x114, 0xF) RUN_STEP(0x118, 0xF) RUN_STEP(0x142, 0xA) RUN_STEP(0x143, 0xC)
+#undef RUN_STEP
+                                const uint32_t back = goes_on ? off - (first - 1u) : 0u;
+                                if (match) {
                                     if (produced < (uint32_t)kHist && dist > produced + off) atomicMax(&S.ctrl[C_ERR], (uint32_t)E_DISTANCE);      // reaches before the first output byte
                                     else if (!sink) {
-                                        // byte i copies byte i - dist, i.e. byte i mod dist of the dist bytes before the match: pointing there at once
-                                        // keeps the chains of overlapping copies (runs) one link long.  Long matches are left to a whole wave.
-                                        const uint32_t q = off + kHist - dist;          // position of the first source byte
+                                        // byte i copies byte i - dist, i.e. byte (back + i) mod dist of the dist bytes before the run: pointing there at
+                                        // once keeps the chains of overlapping copies one link long.  Long matches are left to a whole wave.
+                                        const uint32_t q = off - back + kHist - dist;    // position of the first source byte
                                         uint32_t slot = kLongCap;
                                         if (len >= (uint32_t)kLongMin) slot = atomicAdd(&S.ctrl[C_NLONG], 1u);
-                                        if (slot < (uint32_t)kLongCap) S.longm[slot] = make_uint2(off, len | dist << 16);
-                                        else for (uint32_t i = 0, m = 0; i < len; ++i) { S.from[off + i] = (uint16_t)(q + m); if (++m == dist) m = 0; }
+                                        if (slot < (uint32_t)kLongCap) S.longm[slot] = make_uint2(off | back << 16, len | dist << 16);
+                                        else for (uint32_t i = 0, m = back % dist; i < len; ++i) { S.from[off + i] = (uint16_t)(q + m); if (++m == dist) m = 0; }
                                     }
                                 } else if (!sink) {
                                     const uint32_t n = tk.x & 3u;

@@ -35,14 +35,16 @@ namespace {
 #endif
 constexpr int kT = INFLATE_T;                        // threads per stream
 constexpr int kWaves = kT / 64;
-constexpr int kSubBits = 128;                        // compressed bits a lane owns per round (its token map is two 64-bit words)
-constexpr int kRoundBytes = kT * kSubBits / 8;       // 16384
-constexpr int kWinDwords = kRoundBytes / 4 + 8;      // + 32 bytes: the last lane runs up to 47 bits past its end and peeks 64 bits from there
+constexpr int kSubBits = 256;                        // compressed bits a lane owns per round, eight words of 32 (every pass of a round is a chain of
+                                                     // dependent look-ups per lane, not arithmetic: the longer the lanes, the more bytes per pass)
+constexpr int kRoundBytes = kT * kSubBits / 8;       // 32768
+constexpr int kWinDwords = kRoundBytes / 4;          // (the last lane would run past it: it decodes along, but a round ends with the lane in front of it)
 constexpr int kRing = 65536, kRingMask = kRing - 1;
 constexpr int kNewMax = INFLATE_NEW_MAX;             // bytes a tile may add to the ring: the 32 KiB history must survive them
-// (a lane's tokens begin within its 128 bits and take 2 bits at the least: 64 matches of 258 bytes = 16.5 KB < kNewMax, so one lane alone always fits a tile)
+// (a lane's tokens begin within its 256 bits and take 2 bits at the least: up to 151 matches of 258 bytes = 39 KB, more than a tile: tiles begin and
+// end anywhere, a token that straddles two of them is worked into both)
 constexpr int kHist = 32768;                         // DEFLATE's window
-constexpr int kTokCap = 16384;                       // tokens a round may emit (its scratch list in HBM); one lane holds at most 88
+constexpr int kTokCap = 32768;                       // tokens a round may emit (its scratch list in HBM); one lane holds at most 151
 #ifndef INFLATE_LONG_CAP
 #define INFLATE_LONG_CAP 768
 #endif
@@ -55,7 +57,7 @@ constexpr int kLitBits = INFLATE_LIT_BITS, kDistBits = 10;         // primary lo
 enum : uint32_t { F_EOB = 1, F_BAD = 2 };
 // status word per stream (0 = ok)
 enum : uint32_t { E_BLOCK_TYPE = 1, E_STORED = 2, E_LENGTHS = 3, E_CODE = 4, E_DISTANCE = 5, E_INPUT = 6 };
-enum { C_JOBS0 = 0, C_JOBS1, C_JOBS2, C_STOP0, C_STOP1, C_STOP2, C_CUT, C_OPEN0, C_OPEN1, C_OPEN2, C_NLONG, C_ERR, C_BTYPE, C_FINAL, C_HDR_END_LO, C_HDR_END_HI, C_HLIT, C_HDIST, C_HCLEN, C_N };
+enum { C_JOBS0 = 0, C_JOBS1, C_JOBS2, C_STOP0, C_STOP1, C_STOP2, C_CUT, C_LAST, C_OPEN0, C_OPEN1, C_OPEN2, C_NLONG, C_ERR, C_BTYPE, C_FINAL, C_HDR_END_LO, C_HDR_END_HI, C_HLIT, C_HDIST, C_HCLEN, C_N };
 
 struct InfItem { const uint8_t* src; uint8_t* dst; uint32_t src_len, dst_cap; };
 
@@ -93,7 +95,7 @@ struct Shared {
         struct {
             __attribute__((aligned(16))) uint32_t win[kWinDwords];
             uint32_t lane_start[kT];                 // where the lane's chain begins (window-relative bit)
-            __attribute__((aligned(16))) uint4 lane_map[kT];      // the bits its tokens begin at, relative to the lane's first bit
+            __attribute__((aligned(16))) uint4 lane_map[kT];      // per 32-bit word of the lane: where its first token begins, how many begin in it (Lane)
             uint16_t jobs[kT];                       // lanes that have to walk again
         };
         __attribute__((aligned(16))) uint16_t from[kNewMax + 8];   // per byte of the tile: where its value comes from, as a position in [tile start - 32768, ...); itself = a literal
@@ -248,8 +250,10 @@ __device__ void build_tables(Shared& S, int hlit, int dist_base, int hdist, Prof
 }
 
 // What a lane knows about its sub-sequence: where it starts, where its chain of tokens leaves it (the first token boundary at or
-// beyond its end), whether the chain met the end-of-block code or an invalid code, and the map of the bits its tokens begin at.
-struct Lane { uint32_t start, exit, flags; uint64_t map_lo, map_hi; };
+// beyond its end), whether the chain met the end-of-block code or an invalid code, and per 32-bit word of the lane (6 bits each)
+// `first`: 32 | the bit its first token begins at (0: none begins there), `count`: how many tokens begin in it.  Two chains that begin
+// a word's first token on the same bit are one chain from there on.
+struct Lane { uint32_t start, exit, flags; uint64_t first, count; };
 
 // One code: literal / length / end of block from the first table, or, after a length, the distance from the second -- every
 // trip of the decode loops runs the same instructions whatever it finds (a wave whose lanes meet literals, pairs and matches
@@ -271,31 +275,38 @@ __device__ __forceinline__ Code read_code(const Shared& S, const LL& long_lit, c
     return Code{ kind, (e >> 16) + __builtin_amdgcn_ubfe(b, nb, xb), nb + xb };
 }
 
-// The tokens of a lane from bit `from` on (window-relative), until one begins at or beyond its end.  RESYNC: the walk stops as soon as
-// it stands on a bit of the lane's map -- from there on the chain is the one already known; otherwise the lane's exit, flags and
-// map are replaced.  64 peeked bits serve trips of at most 28.
 typedef LongCodes<kLitBits + 1> LongLit;
 typedef LongCodes<kDistBits + 1> LongDist;
+
+// The tokens of a lane from bit `from` on (window-relative), until one begins at or beyond its end.  RESYNC: the walk stops as soon as
+// it begins a word's first token where the lane's known chain does -- from there on the chain is the one already known (at most a
+// word later than the two met); otherwise the lane's exit, flags and words are replaced.  64 peeked bits serve trips of at most 28.
 template <bool RESYNC>
 __device__ __forceinline__ void lane_trace(const Shared& S, const LongLit& long_lit, const LongDist& long_dist, Lane& L, uint32_t from, uint32_t base)
 {
     const uint32_t end = base + kSubBits;
-    uint32_t pos = from, fl = 0, state = 0;
-    uint64_t new_lo = 0, new_hi = 0;
+    uint32_t pos = from, fl = 0, state = 0, last_word = 8;
+    uint64_t first = 0, count = 0;
     bool joined = false;
     while (!fl && !joined && (state || pos < end)) {
         const uint64_t bits = peek64(S.win, pos);
         uint32_t used = 0;
         do {
             if (!state) {                                         // a token begins here
-                const uint32_t rel = pos + used - base;           // < 128 on every chain that matters (lanes behind a stop may come in below their base)
-                const uint64_t m = 1ull << (rel & 63u);
-                if (RESYNC && rel < 128u && ((rel < 64u ? L.map_lo : L.map_hi) & m)) {
-                    if (rel < 64u) { L.map_lo = new_lo | (L.map_lo & ~(m - 1u)); }
-                    else           { L.map_lo = new_lo; L.map_hi = new_hi | (L.map_hi & ~(m - 1u)); }
-                    joined = true; break;
+                const uint32_t rel = pos + used - base, w = rel >> 5;      // w < 8 on every chain that matters (lanes behind a stop may come in below their base)
+                if (w < 8u) {
+                    if (w != last_word) {
+                        const uint32_t mark = 32u | (rel & 31u);
+                        if (RESYNC && ((uint32_t)(L.first >> (6u * w)) & 63u) == mark) {
+                            const uint64_t keep = ~0ull << (6u * w);
+                            L.first = first | (L.first & keep); L.count = count | (L.count & keep);
+                            joined = true; break;
+                        }
+                        first |= (uint64_t)mark << (6u * w);
+                        last_word = w;
+                    }
+                    count += 1ull << (6u * w);
                 }
-                if (rel < 64u) new_lo |= m; else if (rel < 128u) new_hi |= m;
             }
             const Code c = read_code(S, long_lit, long_dist, (uint32_t)(bits >> used), state, pos + used, end);
             used += c.bits;
@@ -305,12 +316,12 @@ __device__ __forceinline__ void lane_trace(const Shared& S, const LongLit& long_
         pos += used;
     }
     L.start = from;
-    if (!joined) { L.exit = pos; L.flags = fl; L.map_lo = new_lo; L.map_hi = new_hi; }
+    if (!joined) { L.exit = pos; L.flags = fl; L.first = first; L.count = count; }
 }
 
 // The settled lane once more: its tokens into the round's list (8 bytes each: x = length | distance << 16 for a match, count (0-2) |
 // first << 16 | second << 24 for literals; y = offset inside the lane's output | lane << 16 | match << 31) -> bytes the lane inflates to.
-// Every map bit gets a slot: the end-of-block (or invalid) code leaves an empty literal token.
+// Every token counted in the lane's words gets a slot: the end-of-block (or invalid) code leaves an empty literal token.
 __device__ __forceinline__ uint32_t lane_emit(const Shared& S, const LongLit& long_lit, const LongDist& long_dist, const Lane& L, uint32_t base, uint2* tok, uint32_t lane)
 {
     const uint32_t end = base + kSubBits;
@@ -362,19 +373,19 @@ __device__ __forceinline__ uint32_t block_inclusive_sum(Shared& S, uint32_t v, u
     return incl;
 }
 
-// S.from[] for the matches the token pass left in S.longm (x = first byte | bytes between the run's first match and this one << 16,
-// y = length | distance << 16): one match per wave and pass, 64 bytes per step
+// S.from[] for the matches the token pass left in S.longm (x = first byte to write | bytes to write << 15, y = bytes between the point
+// the run is copied from and that first byte | distance << 16): one match per wave and pass, 64 bytes per step
 __device__ __forceinline__ void expand_long_matches(Shared& S)
 {
     const uint32_t n = S.ctrl[C_NLONG] < (uint32_t)kLongCap ? S.ctrl[C_NLONG] : (uint32_t)kLongCap;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (uint32_t m = wave; m < n; m += kWaves) {
         const uint2 e = S.longm[m];
-        const uint32_t at = e.x & 0xFFFFu, back = e.x >> 16, len = e.y & 0xFFFFu, dist = e.y >> 16, q = at - back + kHist - dist;
-        if (back + len <= dist) { for (uint32_t i = lane; i < len; i += 64u) S.from[at + i] = (uint16_t)(q + back + i); }
+        const uint32_t at = e.x & 0x7FFFu, len = e.x >> 15, since = e.y & 0xFFFFu, dist = e.y >> 16, q = at - since + kHist - dist;
+        if (since + len <= dist) { for (uint32_t i = lane; i < len; i += 64u) S.from[at + i] = (uint16_t)(q + since + i); }
         else {
             const uint32_t step = 64u % dist;
-            uint32_t r = (back + lane) % dist;                     // (back + i) mod dist, kept up by additions
+            uint32_t r = (since + lane) % dist;                    // (since + i) mod dist, kept up by additions
             for (uint32_t i = lane; i < len; i += 64u) { S.from[at + i] = (uint16_t)(q + r); r += step; if (r >= dist) r -= dist; }
         }
     }
@@ -730,7 +741,7 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                 if (t == 0) { S.ctrl[C_JOBS0] = 0; S.ctrl[C_STOP0] = kT; }
                 S.lane_exit[t] = L.exit | L.flags << 24;
                 S.lane_start[t] = L.start;
-                S.lane_map[t] = make_uint4((uint32_t)L.map_lo, (uint32_t)(L.map_lo >> 32), (uint32_t)L.map_hi, (uint32_t)(L.map_hi >> 32));
+                S.lane_map[t] = make_uint4((uint32_t)L.first, (uint32_t)(L.first >> 32), (uint32_t)L.count, (uint32_t)(L.count >> 32));
                 __syncthreads();
                 PROF(P_SWEEP0);
                 uint32_t first_stop = kT;                                              // the first lane of the chain with a stop (lanes behind it do not matter)
@@ -740,20 +751,16 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                     const int slot = turn % 3, next_slot = (turn + 1) % 3;
                     if (t == 0) { S.ctrl[C_JOBS0 + next_slot] = 0; S.ctrl[C_STOP0 + next_slot] = kT; }
                     const uint32_t prev = t ? S.lane_exit[t - 1] : rel0, mine = S.lane_exit[t];
-                    bool job = t > 0 && !(prev >> 24) && prev != S.lane_start[t] && (uint32_t)t <= first_stop;     // (a stopped predecessor moves nobody)
+                    bool job = t > 0 && t < kT - 1 && !(prev >> 24) && prev != S.lane_start[t] && (uint32_t)t <= first_stop;     // (a stopped predecessor moves nobody)
                     if (job) {
-                        const uint32_t rel = prev - my_base;                           // (>= 0: a predecessor leaves at or beyond its end)
-                        if (rel < 128u) {
-                            uint4 m = S.lane_map[t];
-                            const uint32_t w = rel >> 5, bit = 1u << (rel & 31u);
-                            const uint32_t word = w == 0 ? m.x : w == 1 ? m.y : w == 2 ? m.z : m.w;
-                            if (word & bit) {                                          // on the known chain already: it begins later, that is all
-                                const uint32_t keep = ~(bit - 1u);
-                                m.x = w == 0 ? m.x & keep : 0u;
-                                m.y = w == 1 ? m.y & keep : w > 1 ? 0u : m.y;
-                                m.z = w == 2 ? m.z & keep : w > 2 ? 0u : m.z;
-                                m.w = w == 3 ? m.w & keep : m.w;
-                                S.lane_map[t] = m; S.lane_start[t] = prev;
+                        const uint32_t rel = prev - my_base, w = rel >> 5;             // (>= 0: a predecessor leaves at or beyond its end)
+                        if (w < 8u) {
+                            const uint4 m = S.lane_map[t];
+                            const uint64_t first = (uint64_t)m.y << 32 | m.x, count = (uint64_t)m.w << 32 | m.z;
+                            if (((uint32_t)(first >> (6u * w)) & 63u) == (32u | (rel & 31u))) {      // on the known chain already: it begins later, that is all
+                                const uint64_t keep = ~0ull << (6u * w), f = first & keep, c = count & keep;
+                                S.lane_map[t] = make_uint4((uint32_t)f, (uint32_t)(f >> 32), (uint32_t)c, (uint32_t)(c >> 32));
+                                S.lane_start[t] = prev;
                                 job = false;
                             }
                         }
@@ -765,7 +772,7 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                         at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
                         if (job) S.jobs[at + (uint32_t)__popcll(jobs & ((1ull << lane_in_wave) - 1ull))] = (uint16_t)t;
                     }
-                    const uint64_t stopped = __ballot((mine >> 24) != 0 && (uint32_t)t <= first_stop);
+                    const uint64_t stopped = __ballot((mine >> 24) != 0 && (uint32_t)t <= first_stop && t < kT - 1);
                     if (stopped && lane_in_wave == 0) atomicMin(&S.ctrl[C_STOP0 + slot], (uint32_t)(wave * 64) + (uint32_t)__builtin_ctzll(stopped));
                     __syncthreads();
                     const uint32_t njobs = S.ctrl[C_JOBS0 + slot], stop_now = S.ctrl[C_STOP0 + slot];
@@ -782,16 +789,20 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                         lane_trace<true>(S, long_lit, long_dist, J, S.lane_exit[lane - 1] & 0xFFFFFFu, lane * kSubBits);
                         S.lane_exit[lane] = J.exit | J.flags << 24;
                         S.lane_start[lane] = J.start;
-                        S.lane_map[lane] = make_uint4((uint32_t)J.map_lo, (uint32_t)(J.map_lo >> 32), (uint32_t)J.map_hi, (uint32_t)(J.map_hi >> 32));
+                        S.lane_map[lane] = make_uint4((uint32_t)J.first, (uint32_t)(J.first >> 32), (uint32_t)J.count, (uint32_t)(J.count >> 32));
                     }
                     __syncthreads();
                 }
-                { const uint4 m = S.lane_map[t]; L.start = S.lane_start[t]; L.map_lo = (uint64_t)m.y << 32 | m.x; L.map_hi = (uint64_t)m.w << 32 | m.z; }
+                { const uint4 m = S.lane_map[t]; L.start = S.lane_start[t]; L.first = (uint64_t)m.y << 32 | m.x; L.count = (uint64_t)m.w << 32 | m.z; }
                 PROF(P_SWEEPS);
-                uint32_t nvalid = first_stop < (uint32_t)kT ? first_stop + 1u : (uint32_t)kT;      // lanes 0 .. nvalid - 1 form the chain
-                // ---- slots for the tokens (a map bit each), the round cut where the list would overflow
+                uint32_t nvalid = first_stop < (uint32_t)(kT - 1) ? first_stop + 1u : (uint32_t)(kT - 1);      // lanes 0 .. nvalid - 1 form the chain (never the last one)
+                // ---- slots for the tokens, the round cut where the list would overflow
                 if (t == 0) S.ctrl[C_CUT] = kT;
-                const uint32_t ntok = (uint32_t)t < nvalid ? (uint32_t)(__popcll(L.map_lo) + __popcll(L.map_hi)) : 0u;
+                uint32_t ntok = 0;
+                if ((uint32_t)t < nvalid) {
+                    #pragma unroll
+                    for (int w = 0; w < 8; ++w) ntok += (uint32_t)(L.count >> (6 * w)) & 63u;
+                }
                 const uint32_t tok_incl = block_inclusive_sum(S, ntok, S.cum_tok);
                 if ((uint32_t)t < nvalid && tok_incl > (uint32_t)kTokCap) atomicMin(&S.ctrl[C_CUT], (uint32_t)t);
                 __syncthreads();
@@ -810,16 +821,16 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                 if ((uint32_t)t < nvalid) out = lane_emit(S, long_lit, long_dist, L, my_base, toks + (tok_incl - ntok), (uint32_t)t);
                 const uint32_t out_incl = block_inclusive_sum(S, out, S.cum_out);       // (its barriers also put the tokens in front of their readers)
                 PROF(P_WRITE);
-                // ---- bytes: tiles of whole lanes, at most kNewMax bytes each
-                uint32_t a = 0;                                                       // first lane of the tile
-                while (a < nvalid && !err) {
-                    const uint32_t out0 = a ? S.cum_out[a - 1] : 0u, tok0 = a ? S.cum_tok[a - 1] : 0u;
-                    if (t == 0) { S.ctrl[C_CUT] = nvalid; S.ctrl[C_NLONG] = 0; S.ctrl[C_OPEN0] = 0; }
+                // ---- bytes: tiles of at most kNewMax bytes, beginning and ending anywhere (offsets below count from the round's first byte)
+                const uint32_t round_out = S.cum_out[nvalid - 1], produced0 = produced;
+                for (uint32_t o0 = 0; o0 < round_out && !err; ) {
+                    const uint32_t total = round_out - o0 < (uint32_t)kNewMax ? round_out - o0 : (uint32_t)kNewMax, o1 = o0 + total;
+                    if (t == 0) { S.ctrl[C_CUT] = kT; S.ctrl[C_LAST] = 0; S.ctrl[C_NLONG] = 0; S.ctrl[C_OPEN0] = 0; }
                     __syncthreads();
-                    if ((uint32_t)t >= a && (uint32_t)t < nvalid && out_incl - out0 > (uint32_t)kNewMax) atomicMin(&S.ctrl[C_CUT], (uint32_t)t);
+                    if ((uint32_t)t < nvalid && out_incl > o0 && out_incl - out < o1) { atomicMin(&S.ctrl[C_CUT], (uint32_t)t); atomicMax(&S.ctrl[C_LAST], (uint32_t)t); }
                     __syncthreads();
-                    const uint32_t b = S.ctrl[C_CUT];                                 // > a
-                    const uint32_t total = S.cum_out[b - 1] - out0, tok1 = S.cum_tok[b - 1];
+                    const uint32_t a = S.ctrl[C_CUT], b = S.ctrl[C_LAST];             // the lanes with bytes in the tile: all their tokens are looked at
+                    const uint32_t tok0 = a ? S.cum_tok[a - 1] : 0u, tok1 = S.cum_tok[b];
                     const bool sink = produced >= it.dst_cap;                         // the caller's buffer is full: decode on, write nothing
                     if (!sink) {
                         // every byte a literal until a match says otherwise
@@ -829,7 +840,7 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                         }
                         __syncthreads();
                     }
-                    if (!sink || produced < (uint32_t)kHist) {
+                    if (!sink || produced0 < (uint32_t)kHist) {
                         for (uint32_t kb = tok0; kb < tok1; kb += 4u * kT) {             // (the same trips for every thread: the neighbours' tokens travel by DPP)
                             uint2 four[4];                                             // four loads in flight (an absent token reads as an empty literal)
                             #pragma unroll
@@ -838,7 +849,7 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                             for (int u = 0; u < 4; ++u) {
                                 const uint2 tk = four[u];
                                 const uint32_t lane = (tk.y >> 16) & 0x3FFu;
-                                const uint32_t off = (lane ? S.cum_out[lane - 1] : 0u) - out0 + (tk.y & 0x7FFFu);      // tile-relative
+                                const uint32_t at = (lane ? S.cum_out[lane - 1] : 0u) + (tk.y & 0xFFFFu);      // the token's first byte
                                 const bool match = tk.y >> 31;
                                 const uint32_t len = tk.x & 0xFFFFu, dist = tk.x >> 16;
                                 // A match right behind a match of the same distance goes on with its period (a run cut into 258-byte pieces,
@@ -847,26 +858,30 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                                 const uint32_t before_x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tk.x, 0x138, 0xF, 0xF, false);      // wave_shr:1 (lane 0: no token)
                                 const uint32_t before_y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tk.y, 0x138, 0xF, 0xF, false);
                                 const bool goes_on = match && (before_y >> 31) && (before_x >> 16) == dist;
-                                uint32_t first = goes_on ? 0u : off + 1u;               // -> the nearest token in front that does not go on, + 1
+                                uint32_t first = goes_on ? 0u : at + 1u;                // -> the nearest token in front that does not go on, + 1
 #define RUN_STEP(CTRL, ROWS) { const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)first, CTRL, ROWS, 0xF, false); first = o > first ? o : first; }
                                 RUN_STEP(0x111, 0xF) RUN_STEP(0x112, 0xF) RUN_STEP(0x114, 0xF) RUN_STEP(0x118, 0xF) RUN_STEP(0x142, 0xA) RUN_STEP(0x143, 0xC)
 #undef RUN_STEP
-                                const uint32_t back = goes_on ? off - (first - 1u) : 0u;
+                                const uint32_t root = goes_on ? first - 1u : at;          // where the run begins
                                 if (match) {
-                                    if (produced < (uint32_t)kHist && dist > produced + off) atomicMax(&S.ctrl[C_ERR], (uint32_t)E_DISTANCE);      // reaches before the first output byte
-                                    else if (!sink) {
-                                        // byte i copies byte i - dist, i.e. byte (back + i) mod dist of the dist bytes before the run: pointing there at
-                                        // once keeps the chains of overlapping copies one link long.  Long matches are left to a whole wave.
-                                        const uint32_t q = off - back + kHist - dist;    // position of the first source byte
+                                    if (produced0 < (uint32_t)kHist && dist > produced0 + at) atomicMax(&S.ctrl[C_ERR], (uint32_t)E_DISTANCE);      // reaches before the first output byte
+                                    else if (!sink && at < o1 && at + len > o0) {
+                                        // Byte x of a run of period dist equals byte p - dist + (x - p) mod dist for any point p of the run at or in front
+                                        // of x: p = the run's first byte, or the tile's if the run began in front of it (the dist bytes in front of p
+                                        // are bytes of this tile or window history either way).  Pointing there at once keeps the chains of
+                                        // overlapping copies one link long.  Long matches are left to a whole wave.
+                                        const uint32_t p = root > o0 ? root : o0;
+                                        const uint32_t x0 = at > o0 ? at : o0, x1 = at + len < o1 ? at + len : o1;      // the bytes of the match inside the tile
+                                        const uint32_t q = p - o0 + kHist - dist, since = x0 - p, n = x1 - x0;
                                         uint32_t slot = kLongCap;
-                                        if (len >= (uint32_t)kLongMin) slot = atomicAdd(&S.ctrl[C_NLONG], 1u);
-                                        if (slot < (uint32_t)kLongCap) S.longm[slot] = make_uint2(off | back << 16, len | dist << 16);
-                                        else for (uint32_t i = 0, m = back % dist; i < len; ++i) { S.from[off + i] = (uint16_t)(q + m); if (++m == dist) m = 0; }
+                                        if (n >= (uint32_t)kLongMin) slot = atomicAdd(&S.ctrl[C_NLONG], 1u);
+                                        if (slot < (uint32_t)kLongCap) S.longm[slot] = make_uint2((x0 - o0) | n << 15, since | dist << 16);
+                                        else for (uint32_t i = 0, m = since % dist; i < n; ++i) { S.from[x0 - o0 + i] = (uint16_t)(q + m); if (++m == dist) m = 0; }
                                     }
                                 } else if (!sink) {
                                     const uint32_t n = tk.x & 3u;
-                                    if (n) S.ring[(produced + off) & kRingMask] = (uint8_t)(tk.x >> 16);
-                                    if (n > 1u) S.ring[(produced + off + 1u) & kRingMask] = (uint8_t)(tk.x >> 24);
+                                    if (n && at >= o0 && at < o1) S.ring[(produced0 + at) & kRingMask] = (uint8_t)(tk.x >> 16);
+                                    if (n > 1u && at + 1u >= o0 && at + 1u < o1) S.ring[(produced0 + at + 1u) & kRingMask] = (uint8_t)(tk.x >> 24);
                                 }
                             }
                         }
@@ -885,7 +900,7 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                         PROF(P_FLUSH);
                     }
                     produced = produced + total < produced ? 0xFFFFFFFFu : produced + total;           // (saturating: only its size matters beyond 32 KiB)
-                    a = b;
+                    o0 = o1;
                 }
                 pos = wbase * 8u + last_exit;
                 if (last_flags & F_EOB) in_block = false;

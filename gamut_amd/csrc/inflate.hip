@@ -180,7 +180,7 @@ template <int FROM> using LongCodes = CodeRange<FROM, 15>;
 // each, threads 288-319 a distance symbol: a symbol's rank among the symbols of its length is a ballot inside its wave plus the
 // counts of the waves before it; code starts and offsets are prefix sums over the 15 lengths (DPP, lanes 0-15 and 16-31 of wave 0).
 // Validity as zlib's inflate_table: over-subscribed sets fail; incomplete ones too, unless no code is longer than one bit.
-__device__ void build_tables(Shared& S, int hlit, int dist_base, int hdist, Prof& prof)
+__device__ __noinline__ void build_tables(Shared& S, int hlit, int dist_base, int hdist, Prof& prof)
 {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const bool is_lit = t < 288;
@@ -497,7 +497,7 @@ __device__ __forceinline__ ClWalk cl_walk(Shared& S, uint32_t from, uint32_t end
 
 // -> window-relative bit behind the last code length, 0 = the lengths are invalid (an over-subscribed or incomplete code-length code
 // -- zlib accepts neither --, a repeat with nothing to repeat, or lengths past the end).  `h`: the bit the hclen 3-bit lengths begin at.
-__device__ __forceinline__ uint32_t read_code_lengths(Shared& S, uint32_t h, uint32_t hclen, uint32_t total, Prof& prof)
+__device__ __noinline__ uint32_t read_code_lengths(Shared& S, uint32_t h, uint32_t hclen, uint32_t total, Prof& prof)
 {
     const uint32_t lane = threadIdx.x & 63u;
     // the code-length code: lane s < 19 owns symbol s; its 3-bit length stands at the place the permutation gives it
@@ -859,9 +859,11 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                                 const uint32_t before_y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tk.y, 0x138, 0xF, 0xF, false);
                                 const bool goes_on = match && (before_y >> 31) && (before_x >> 16) == dist;
                                 uint32_t first = goes_on ? 0u : at + 1u;                // -> the nearest token in front that does not go on, + 1
+                                if (__ballot(goes_on)) {
 #define RUN_STEP(CTRL, ROWS) { const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)first, CTRL, ROWS, 0xF, false); first = o > first ? o : first; }
-                                RUN_STEP(0x111, 0xF) RUN_STEP(0x112, 0xF) RUN_STEP(0x114, 0xF) RUN_STEP(0x118, 0xF) RUN_STEP(0x142, 0xA) RUN_STEP(0x143, 0xC)
+                                    RUN_STEP(0x111, 0xF) RUN_STEP(0x112, 0xF) RUN_STEP(0x114, 0xF) RUN_STEP(0x118, 0xF) RUN_STEP(0x142, 0xA) RUN_STEP(0x143, 0xC)
 #undef RUN_STEP
+                                }
                                 const uint32_t root = goes_on ? first - 1u : at;          // where the run begins
                                 if (match) {
                                     if (produced0 < (uint32_t)kHist && dist > produced0 + at) atomicMax(&S.ctrl[C_ERR], (uint32_t)E_DISTANCE);      // reaches before the first output byte

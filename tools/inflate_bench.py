@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Inflate kernel alone: IDAT streams of N PNG files resident in HBM -> inflated bytes in HBM (gamut_hip_inflate_batch_device),
 wall time of launch + sync, against zlib on one host thread.  With a -DINFLATE_PROFILE=1 build (tools/variant.sh
-inflate:prof:-DINFLATE_PROFILE=1, GAMUT_HIP_LIB=gamut_amd/lib/var/libgamut_hip_prof.so) the cycles per phase are printed too.
+inflate:prof:-DINFLATE_PROFILE=1, GAMUT_HIP_LIB=gamut_amd/lib/var/libgamut_hip_prof.so) the cycles per phase (thread 0's clock, summed over the
+streams; h: = header steps, t: = table steps) are printed too.
 Usage: python tools/inflate_bench.py [--streams 256] [--width 3840 --height 2160]"""
 import argparse
 import ctypes as C

@@ -424,18 +424,25 @@ __device__ __forceinline__ int resolve_copies(Shared& S, uint32_t cs, uint32_t t
             if (!open[k]) continue;
             const uint32_t j0 = ((uint32_t)t + (uint32_t)k * kT) * 8u;
             const u32x4 f = *reinterpret_cast<const u32x4*>(&S.from[j0]);
-            uint32_t p[8] = { f.x & 0xFFFFu, f.x >> 16, f.y & 0xFFFFu, f.y >> 16, f.z & 0xFFFFu, f.z >> 16, f.w & 0xFFFFu, f.w >> 16 };
+            // Two entries per register all the way (no branch per byte: the step is arithmetic-bound otherwise).  Every byte reads the entry
+            // of position p & 0x7FFF: its source's for an open byte (p >= kHist = 0x8000), its own for a literal, anything for a window byte.
+            const uint32_t P[4] = { f.x, f.y, f.z, f.w };
             uint32_t pp[8];
             #pragma unroll
-            for (int i = 0; i < 8; ++i) pp[i] = S.from[(open[k] >> i & 1u) ? p[i] - kHist : j0 + i];      // (a settled byte reads its own entry)
+            for (int d = 0; d < 4; ++d) { pp[2 * d] = S.from[P[d] & 0x7FFFu]; pp[2 * d + 1] = S.from[(P[d] >> 16) & 0x7FFFu]; }
+            uint32_t N[4], still = 0;
+            const uint32_t bits = open[k];
             #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (!(open[k] >> i & 1u)) continue;
-                if (pp[i] == p[i]) open[k] &= ~(1u << i);           // the source is a literal: settled
-                else { p[i] = pp[i]; if (pp[i] < (uint32_t)kHist) open[k] &= ~(1u << i); }
+            for (int d = 0; d < 4; ++d) {
+                const uint32_t PP = pp[2 * d] | pp[2 * d + 1] << 16;
+                const uint32_t M = ((bits >> (2 * d)) & 1u ? 0xFFFFu : 0u) | ((bits >> (2 * d + 1)) & 1u ? 0xFFFF0000u : 0u);      // the open ones
+                N[d] = (PP & M) | (P[d] & ~M);                      // an open byte adopts its source's entry (its own again if the source is a literal)
+                const uint32_t X = (PP ^ P[d]) & M;                 // moved on -- and still open if it did not land in the window
+                still |= ((X & 0xFFFFu) && (PP & 0x8000u) ? 1u : 0u) << (2 * d) | ((X >> 16) && (PP & 0x80000000u) ? 1u : 0u) << (2 * d + 1);
             }
             // (an entry another thread reads while its owner replaces it holds the old or the new pointer: both are sources of the byte)
-            *reinterpret_cast<u32x4*>(&S.from[j0]) = u32x4{ p[0] | p[1] << 16, p[2] | p[3] << 16, p[4] | p[5] << 16, p[6] | p[7] << 16 };
+            *reinterpret_cast<u32x4*>(&S.from[j0]) = u32x4{ N[0], N[1], N[2], N[3] };
+            open[k] = still;
             any |= open[k] != 0;
         }
         if (any) S.ctrl[C_OPEN0 + round % 3] = 1u;

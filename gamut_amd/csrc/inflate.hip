@@ -102,7 +102,7 @@ struct Shared {
     };
     uint32_t lut[(1 << kLitBits) + (1 << kDistBits)];   // primary tables: literal / length codes, then distance codes
     uint32_t lane_exit[kT];                          // exit bit | flags << 24, as last published
-    uint32_t cum_out[kT], cum_tok[kT];               // inclusive prefix sums over the lanes of a round
+    uint32_t cum_out0[kT + 1], cum_tok[kT];          // prefix sums over the lanes of a round: cum_out0[k] = bytes in front of lane k, cum_tok[k] = tokens up to and with lane k
     uint2    longm[kLongCap];                        // long matches of the tile: x = first byte (tile-relative), y = length | distance << 16
     uint32_t wave_sum[kWaves];
     uint32_t wave_count[5][16];                      // build_tables: literal / length symbols of every code length, per wave
@@ -586,6 +586,7 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
     uint32_t err = 0;
     bool done = false;
     if (t < C_N) S.ctrl[t] = 0;
+    if (t == 0) S.cum_out0[0] = 0;
     __syncthreads();
     PROF_DECL;
 
@@ -826,10 +827,10 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                 // ---- the tokens themselves, and where every lane's bytes go
                 uint32_t out = 0;
                 if ((uint32_t)t < nvalid) out = lane_emit(S, long_lit, long_dist, L, my_base, toks + (tok_incl - ntok), (uint32_t)t);
-                const uint32_t out_incl = block_inclusive_sum(S, out, S.cum_out);       // (its barriers also put the tokens in front of their readers)
+                const uint32_t out_incl = block_inclusive_sum(S, out, S.cum_out0 + 1);       // (its barriers also put the tokens in front of their readers)
                 PROF(P_WRITE);
                 // ---- bytes: tiles of at most kNewMax bytes, beginning and ending anywhere (offsets below count from the round's first byte)
-                const uint32_t round_out = S.cum_out[nvalid - 1], produced0 = produced;
+                const uint32_t round_out = S.cum_out0[nvalid], produced0 = produced;
                 for (uint32_t o0 = 0; o0 < round_out && !err; ) {
                     const uint32_t total = round_out - o0 < (uint32_t)kNewMax ? round_out - o0 : (uint32_t)kNewMax, o1 = o0 + total;
                     if (t == 0) { S.ctrl[C_CUT] = kT; S.ctrl[C_LAST] = 0; S.ctrl[C_NLONG] = 0; S.ctrl[C_OPEN0] = 0; }
@@ -852,11 +853,13 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                             uint2 four[4];                                             // four loads in flight (an absent token reads as an empty literal)
                             #pragma unroll
                             for (int u = 0; u < 4; ++u) { const uint32_t k = kb + (uint32_t)t + (uint32_t)u * kT; four[u] = k < tok1 ? toks[k] : make_uint2(0u, 0u); }
+                            uint32_t lane_at[4];
+                            #pragma unroll
+                            for (int u = 0; u < 4; ++u) lane_at[u] = S.cum_out0[(four[u].y >> 16) & 0x3FFu];      // (four look-ups in flight)
                             #pragma unroll
                             for (int u = 0; u < 4; ++u) {
                                 const uint2 tk = four[u];
-                                const uint32_t lane = (tk.y >> 16) & 0x3FFu;
-                                const uint32_t at = (lane ? S.cum_out[lane - 1] : 0u) + (tk.y & 0xFFFFu);      // the token's first byte
+                                const uint32_t at = lane_at[u] + (tk.y & 0xFFFFu);          // the token's first byte
                                 const bool match = tk.y >> 31;
                                 const uint32_t len = tk.x & 0xFFFFu, dist = tk.x >> 16;
                                 // A match right behind a match of the same distance goes on with its period (a run cut into 258-byte pieces,

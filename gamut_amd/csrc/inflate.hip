@@ -51,7 +51,10 @@ constexpr int kTokCap = 32768;                       // tokens a round may emit 
 #ifndef INFLATE_LIT_BITS
 #define INFLATE_LIT_BITS 11
 #endif
-constexpr int kLongMin = 32, kLongCap = INFLATE_LONG_CAP;        // matches at least this long are expanded by a whole wave, not by the thread that holds the token
+#ifndef INFLATE_LONG_MIN
+#define INFLATE_LONG_MIN 32
+#endif
+constexpr int kLongMin = INFLATE_LONG_MIN, kLongCap = INFLATE_LONG_CAP;        // matches at least this long are expanded by a whole wave, not by the thread that holds the token
 constexpr int kLitBits = INFLATE_LIT_BITS, kDistBits = 10;         // primary lookup widths; longer codes take the canonical search
 
 enum : uint32_t { F_EOB = 1, F_BAD = 2 };

@@ -583,11 +583,11 @@ struct DevBits {
 };
 
 constexpr size_t kBlobSlack = 1024;                          // bytes a lane may read past the last segment: one block + look-ahead in k_jpeg_entropy; in k_prog_scan the 64-byte limit check + a block's worth of a corrupt AC scan (244 bytes) + the 256-byte window
-constexpr int kEntropyThreads = 64;                          // one wave per workgroup: lanes spread over CUs, each with its own L1
-constexpr int kLdsHuff = 8, kLdsQuant = 8;                     // tables a workgroup keeps in LDS (15 KB + 1 KB: two encoders' sets; more distinct tables in a batch are read from global memory)
 #ifndef JPEG_SYNC_THREADS          // tuning knob (tools/variant.sh)
 #define JPEG_SYNC_THREADS 256
 #endif
+constexpr int kEntropyThreads = 64;                          // one wave per workgroup: lanes spread over CUs, each with its own L1
+constexpr int kLdsHuff = JPEG_SYNC_THREADS >= 1024 ? 4 : 8, kLdsQuant = kLdsHuff;                     // tables a workgroup keeps in LDS (15 KB + 1 KB: two encoders' sets; more distinct tables in a batch are read from global memory)
 constexpr int kSyncThreads = JPEG_SYNC_THREADS;                // lanes cooperating on one large segment
 constexpr uint32_t kSyncMinBytes = 4096;                       // shorter segments take one lane each
 

@@ -146,3 +146,35 @@ def test_inflate_many_small_blocks_and_the_block_budget(hip):
     assert rc == 0
     assert st[0] == 0 and outs[0] == data and st[1] == 0 and outs[1] == data
     assert st[2] == 6 and st[3] == 6                                  # GAMUT_HIP_INFLATE_E_INPUT: over the block budget / cut short
+
+
+def test_inflate_round_and_tile_boundaries(hip):
+    """What the rounds / tiles of the kernel cut through (inflate.hip): runs far longer than a 28 KiB tile (their pieces copy from the tile's
+    edge when the run began in front of it), one lane inflating to more than a tile (2-bit matches of 258 bytes), matches at the full
+    32 KiB distance across tile and round boundaries, more tokens in a 32 KiB round than its list holds (1-bit literals: the round is
+    cut at a lane), capacities that end inside a tile."""
+    rng = np.random.default_rng(23)
+    seed = rng.integers(0, 256, 32768, dtype=np.uint8).tobytes()
+    two = rng.integers(0, 2, 3_000_000, dtype=np.uint8).tobytes()
+    cases = {
+        "zeros": bytes(5_000_000),
+        "period 3": b"\x10\x80\xf0" * 1_200_000,
+        "period 259": rng.integers(0, 256, 259, dtype=np.uint8).tobytes() * 12000,
+        "period 32768": seed * 40,
+        "period 32768 with edits": b"".join(seed[:k * 811 % 32768] + b"!" + seed[k * 811 % 32768 + 1:] for k in range(30)),
+        "two symbols": two,
+        "runs between noise": b"".join(rng.integers(0, 256, int(n), dtype=np.uint8).tobytes() + bytes([int(n) & 255]) * int(40000 + n) for n in rng.integers(1, 3000, 25)),
+    }
+    streams, expect, caps, names = [], [], [], []
+    for name, data in cases.items():
+        for kw in (dict(level=6), dict(level=9), dict(level=6, strategy=zlib.Z_HUFFMAN_ONLY), dict(level=6, strategy=zlib.Z_RLE), dict(level=1, mem=1)):
+            if name == "two symbols" and kw.get("strategy") != zlib.Z_HUFFMAN_ONLY and kw.get("level") != 1:
+                continue
+            st = _deflate(data, **kw)
+            for cap in (len(data), len(data) // 2 + 12345, 40000):
+                streams.append(st); expect.append(data[:cap]); caps.append(cap); names.append(f"{name} {kw} cap {cap}")
+    rc, outs, st = _inflate_device(hip, streams, caps)
+    assert rc == 0, hip.gamut_hip_last_error()
+    for name, got, exp, s_ in zip(names, outs, expect, st):
+        assert s_ == 0, f"{name}: status {s_}"
+        assert got == exp, f"{name}: {len(got)} bytes, expected {len(exp)}; first difference at {next((i for i, (a, b) in enumerate(zip(got, exp)) if a != b), None)}"

@@ -101,6 +101,7 @@ SIGNATURES = {
     "gamut_hip_stbi_load_16_from_callbacks": (_vp, [_vp, _vp, _pi, _pi, _pi, _i, _pf, _pf, _pf]),
     "gamut_hip_stbi_png_is16_from_callbacks": (_i, [_vp, _vp]),
     "gamut_hip_inflate_batch_device": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "gamut_hip_inflate_batch_device_sliced": (_i, [_vp, _i, _vp, _vp, C.c_uint32, _vp]),
     "gamut_hip_shard_owner": (_i, [_i64, _i]),
     "gamut_hip_shard_count": (_i64, [_i, _i, _i64]),
     "gamut_hip_shard_local_index": (_i64, [_i64, _i]),

@@ -158,6 +158,10 @@ int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
 
 // inflate.hip: DEFLATE streams in HBM -> bytes in HBM, one workgroup per stream (asynchronous on `stream`)
 int inflate_launch(const gamut_hip_inflate_desc* descs, int count, uint32_t* out_len_dev, uint32_t* status_dev, hipStream_t stream);
+// the same while the streams are still being uploaded: begin, then a step per slice (avail_host[i] = bytes of stream i that are in HBM once
+// `stream` gets there), the last step with every stream whole; out_len / status are final after the last step
+int inflate_sliced_begin(const gamut_hip_inflate_desc* descs, int count, hipStream_t stream);
+int inflate_sliced_step(int count, const uint32_t* avail_host, uint32_t* out_len_dev, uint32_t* status_dev, hipStream_t stream);
 int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len,
                         uint8_t* out, int64_t out_stride,
                         uint32_t x, uint32_t y, int img_n, int out_n, int depth, int color,

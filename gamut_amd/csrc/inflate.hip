@@ -63,6 +63,14 @@ enum : uint32_t { E_BLOCK_TYPE = 1, E_STORED = 2, E_LENGTHS = 3, E_CODE = 4, E_D
 enum { C_JOBS0 = 0, C_JOBS1, C_JOBS2, C_STOP0, C_STOP1, C_STOP2, C_CUT, C_LAST, C_OPEN0, C_OPEN1, C_OPEN2, C_NLONG, C_ERR, C_BTYPE, C_FINAL, C_HDR_END_LO, C_HDR_END_HI, C_HLIT, C_HDIST, C_HCLEN, C_N };
 
 struct InfItem { const uint8_t* src; uint8_t* dst; uint32_t src_len, dst_cap; };
+// A stream between two launches of a sliced call (inflate_launch_sliced: the launches follow the upload, slice by slice): where it stands,
+// and the code lengths of the Huffman block it stands in (the tables are built again from them; the window comes back from the output)
+struct InfState {
+    uint64_t pos; uint32_t produced, blocks, err, flags;       // flags: 1 = done, 2 = inside a Huffman block, 4 = a launch has run
+    uint32_t btype, bfinal, hlit, hdist;
+    uint8_t lens[320];
+};
+enum : uint32_t { ST_DONE = 1, ST_IN_BLOCK = 2, ST_VALID = 4 };
 
 #ifndef INFLATE_PROFILE           // measurement only (tools/variant.sh inflate:prof:-DINFLATE_PROFILE=1): cycles per phase, summed over streams
 #define INFLATE_PROFILE 0
@@ -571,7 +579,10 @@ __device__ __noinline__ uint32_t read_code_lengths(Shared& S, uint32_t h, uint32
     return bad || !end_pos ? 0u : end_pos;
 }
 
-__global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_items, uint2* tok_scratch, uint32_t* out_len, uint32_t* status)
+// states / avail: null for a call of its own; else the stream resumes from states[i], reads no byte at or beyond avail[i] (what has been
+// uploaded so far) and stops in front of a round (or block header) it cannot finish within them, leaving its state for the next launch
+__global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_items, uint2* tok_scratch, uint32_t* out_len, uint32_t* status,
+                                                InfState* states, const uint32_t* avail)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     Shared& S = *reinterpret_cast<Shared*>(smem);
@@ -591,6 +602,26 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
     if (t < C_N) S.ctrl[t] = 0;
     if (t == 0) S.cum_out0[0] = 0;
     __syncthreads();
+    // a sliced call: the bytes that are there, and where the stream stands
+    const uint32_t have = avail ? (avail[blockIdx.x] < it.src_len ? avail[blockIdx.x] : it.src_len) : it.src_len;
+    const bool all_there = have >= it.src_len;
+    auto enough = [&](uint64_t at_bit) -> bool { return all_there || (at_bit >> 3) + kRoundBytes + 64u <= have; };      // a whole window from there
+    InfState* const state = states ? states + blockIdx.x : nullptr;
+    uint32_t blocks = 0;
+    bool resume_block = false, suspended = false, suspended_in_block = false;
+    if (state && (state->flags & ST_VALID)) {
+        pos = state->pos; produced = state->produced; blocks = state->blocks; err = state->err; done = (state->flags & ST_DONE) != 0;
+        resume_block = (state->flags & ST_IN_BLOCK) != 0 && !err && !done;
+        if (resume_block) {
+            for (int k = t; k < 320; k += kT) S.lens[k] = state->lens[k];
+            if (t == 0) { S.ctrl[C_BTYPE] = state->btype; S.ctrl[C_FINAL] = state->bfinal; S.ctrl[C_HLIT] = state->hlit; S.ctrl[C_HDIST] = state->hdist; }
+        }
+        if (!err && !done && produced && produced < it.dst_cap) {                   // the window: the last 32 KiB of the output so far
+            const uint32_t n = produced < (uint32_t)kHist ? produced : (uint32_t)kHist;
+            for (uint32_t i = t; i < n; i += kT) S.ring[(produced - n + i) & kRingMask] = it.dst[produced - n + i];
+        }
+        __syncthreads();
+    }
     PROF_DECL;
 
     // the window: kWinDwords dwords from the dword that holds bit `pos` (relative to the stream start); zeros past the end.
@@ -648,9 +679,11 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
     // with more than one block per 8 compressed bytes (beyond the first 4096) are turned away as corrupt.  The tables of the
     // fixed code are built once per stream.
     const uint32_t block_budget = it.src_len / 8u + 4096u;
-    uint32_t blocks = 0;
     bool fixed_tables = false;                        // the LDS tables hold the fixed code
     while (!done && !err) {
+      const uint64_t pos_block = pos;
+      if (!resume_block) {
+        if (!enough(pos)) { suspended = true; break; }
         if (++blocks > block_budget) { err = E_INPUT; break; }
         // ------------------------------------------------------------------ block header
         PROF(P_FLUSH);
@@ -681,9 +714,7 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
         }
         __syncthreads();
         PROF(P_H_FIELDS);
-        const uint32_t btype = S.ctrl[C_BTYPE];
-        const bool bfinal = S.ctrl[C_FINAL] != 0;
-        if (btype == 2u && !S.ctrl[C_ERR]) {                                       // the hlit + hdist code lengths
+        if (S.ctrl[C_BTYPE] == 2u && !S.ctrl[C_ERR]) {                                       // the hlit + hdist code lengths
             if (wave == 0) {
                 const uint32_t h = S.ctrl[C_HDR_END_LO] - (uint32_t)(base_byte * 8u);      // (window-relative: the header began inside the first dword)
                 const uint32_t end_rel = read_code_lengths(S, h, S.ctrl[C_HCLEN], S.ctrl[C_HLIT] + S.ctrl[C_HDIST], prof);
@@ -700,10 +731,15 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
         if (!err && pos > src_bits) err = E_INPUT;
         PROF(P_HEADER);
         if (err) break;
+      }
+        resume_block = false;
+        const uint32_t btype = S.ctrl[C_BTYPE];
+        const bool bfinal = S.ctrl[C_FINAL] != 0;
 
         if (btype == 0u) {
             // -------------------------------------------------------------- stored block: LEN, ~LEN, bytes
             const uint64_t p = (pos + 7u) >> 3;
+            if (!all_there && p + 4u + 65535u > have) { pos = pos_block; --blocks; suspended = true; break; }      // (the header is read again next time)
             if (p + 4u > it.src_len) { err = E_INPUT; break; }
             const uint32_t len = src[p] | (uint32_t)src[p + 1] << 8, nlen = src[p + 2] | (uint32_t)src[p + 3] << 8;
             if (len != (nlen ^ 0xFFFFu)) { err = E_STORED; break; }
@@ -734,6 +770,7 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
             PROF(P_T_LONG);
             bool in_block = true;
             while (in_block && !err) {
+                if (!enough(pos)) { suspended = true; suspended_in_block = true; break; }
                 // (the window the header was read from serves the block's first round: the lanes in front of `pos` are passed over like
                 // lanes behind a long token)
                 const bool reuse = win_base != ~(uint64_t)0 && pos >= win_base * 8u && pos - win_base * 8u < 16u * kSubBits;
@@ -921,7 +958,17 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                 if (last_flags & F_EOB) in_block = false;
             }
         }
+        if (suspended) break;                                                       // (inside the block: it goes on next launch)
         if (bfinal) done = true;
+    }
+    if (state) {                                      // where the next launch goes on
+        __syncthreads();
+        if (suspended_in_block) for (int k = t; k < 320; k += kT) state->lens[k] = S.lens[k];
+        if (t == 0) {
+            state->pos = pos; state->produced = produced; state->blocks = blocks; state->err = err;
+            state->flags = ST_VALID | (done ? ST_DONE : 0u) | (suspended_in_block ? ST_IN_BLOCK : 0u);
+            state->btype = S.ctrl[C_BTYPE]; state->bfinal = S.ctrl[C_FINAL]; state->hlit = S.ctrl[C_HLIT]; state->hdist = S.ctrl[C_HDIST];
+        }
     }
     PROF_FLUSH;
     if (t == 0) {
@@ -932,27 +979,25 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
 
 } // namespace
 
-int inflate_launch(const gamut_hip_inflate_desc* descs, int count, uint32_t* out_len_dev, uint32_t* status_dev, hipStream_t stream)
+// The per-(thread, device, stream) scratch of the launches: token lists (256 KiB per stream), the streams' states between the launches
+// of a sliced call, the descriptors and the bytes-there table.  Calls on one stream are ordered, calls on different streams never
+// share it; growing it waits for its own stream only.
+namespace {
+struct InflateScratch { uint2* toks; InfState* states; InfItem* items; uint32_t* avail; };
+int inflate_scratch(int count, hipStream_t stream, InflateScratch& out)
 {
-    static_assert(sizeof(InfItem) == sizeof(gamut_hip_inflate_desc), "descriptor layout");
-    std::vector<InfItem> items((size_t)count);                 // pageable: the upload below has read it when hipMemcpyAsync returns
-    for (int i = 0; i < count; ++i) {
-        if (!descs[i].src || (!descs[i].dst && descs[i].dst_cap)) return set_error(GAMUT_HIP_ERR_INVALID_ARG, "inflate: stream %d: null pointer", i);
-        items[(size_t)i] = InfItem{ descs[i].src, descs[i].dst, descs[i].src_len, descs[i].dst_cap };
-    }
     // per call: the attribute belongs to the current device's copy of the kernel, and a process may drive several devices
     if (hipFuncSetAttribute((const void*)k_inflate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Shared)) != hipSuccess) return set_error(GAMUT_HIP_ERR_HIP, "inflate: %zu bytes of LDS are not available", sizeof(Shared));
-    // the descriptor table and the token lists (128 KiB per stream) in HBM: one buffer per (thread, device, stream) -- calls on one
-    // stream are ordered, calls on different streams never share it; growing it waits for its own stream only
     struct StreamTable { int device; hipStream_t stream; void* p; size_t cap; };
     static thread_local std::vector<StreamTable> tables;
     StreamTable* e = nullptr;
     const int device = current_device();                    // (the null stream is one handle for every device)
     for (StreamTable& c : tables) if (c.stream == stream && c.device == device) { e = &c; break; }
     if (!e) { tables.push_back(StreamTable{ device, stream, nullptr, 0 }); e = &tables.back(); }
-    const size_t tok_bytes = (size_t)count * kTokCap * sizeof(uint2);
-    const size_t item_bytes = (items.size() * sizeof(InfItem) + 255) & ~(size_t)255;
-    const size_t bytes = tok_bytes + item_bytes;
+    auto round_up = [](size_t n) { return (n + 255) & ~(size_t)255; };
+    const size_t tok_bytes = (size_t)count * kTokCap * sizeof(uint2), state_bytes = round_up((size_t)count * sizeof(InfState)),
+                 item_bytes = round_up((size_t)count * sizeof(InfItem)), avail_bytes = round_up((size_t)count * 4);
+    const size_t bytes = tok_bytes + state_bytes + item_bytes + avail_bytes;
     if (bytes > e->cap) {
         if (e->p) { (void)hipStreamSynchronize(stream); (void)hipFree(e->p); e->p = nullptr; e->cap = 0; }
         const size_t want = bytes + bytes / 4 + 4096;
@@ -960,8 +1005,53 @@ int inflate_launch(const gamut_hip_inflate_desc* descs, int count, uint32_t* out
         e->cap = want;
     }
     uint8_t* const base = static_cast<uint8_t*>(e->p);
-    GAMUT_HIP_CHECK(hipMemcpyAsync(base + tok_bytes, items.data(), items.size() * sizeof(InfItem), hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(k_inflate, dim3((unsigned)count), dim3(kT), sizeof(Shared), stream, (const InfItem*)(base + tok_bytes), count, (uint2*)base, out_len_dev, status_dev);
+    out.toks = reinterpret_cast<uint2*>(base);
+    out.states = reinterpret_cast<InfState*>(base + tok_bytes);
+    out.items = reinterpret_cast<InfItem*>(base + tok_bytes + state_bytes);
+    out.avail = reinterpret_cast<uint32_t*>(base + tok_bytes + state_bytes + item_bytes);
+    return GAMUT_HIP_OK;
+}
+int inflate_items(const gamut_hip_inflate_desc* descs, int count, std::vector<InfItem>& items)
+{
+    static_assert(sizeof(InfItem) == sizeof(gamut_hip_inflate_desc), "descriptor layout");
+    items.resize((size_t)count);                               // pageable: the upload has read it when hipMemcpyAsync returns
+    for (int i = 0; i < count; ++i) {
+        if (!descs[i].src || (!descs[i].dst && descs[i].dst_cap)) return set_error(GAMUT_HIP_ERR_INVALID_ARG, "inflate: stream %d: null pointer", i);
+        items[(size_t)i] = InfItem{ descs[i].src, descs[i].dst, descs[i].src_len, descs[i].dst_cap };
+    }
+    return GAMUT_HIP_OK;
+}
+} // namespace
+
+int inflate_launch(const gamut_hip_inflate_desc* descs, int count, uint32_t* out_len_dev, uint32_t* status_dev, hipStream_t stream)
+{
+    std::vector<InfItem> items;
+    if (int rc = inflate_items(descs, count, items)) return rc;
+    InflateScratch sc;
+    if (int rc = inflate_scratch(count, stream, sc)) return rc;
+    GAMUT_HIP_CHECK(hipMemcpyAsync(sc.items, items.data(), items.size() * sizeof(InfItem), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_inflate, dim3((unsigned)count), dim3(kT), sizeof(Shared), stream, (const InfItem*)sc.items, count, sc.toks, out_len_dev, status_dev, (InfState*)nullptr, (const uint32_t*)nullptr);
+    return launch_status("inflate");
+}
+
+// A sliced call: the streams are still on their way up.  begin once (descriptors up, states cleared), then one step per slice -- the
+// caller has made `stream` wait for the upload of the bytes avail_host[i] promises -- the last one with every stream whole.
+int inflate_sliced_begin(const gamut_hip_inflate_desc* descs, int count, hipStream_t stream)
+{
+    std::vector<InfItem> items;
+    if (int rc = inflate_items(descs, count, items)) return rc;
+    InflateScratch sc;
+    if (int rc = inflate_scratch(count, stream, sc)) return rc;
+    GAMUT_HIP_CHECK(hipMemcpyAsync(sc.items, items.data(), items.size() * sizeof(InfItem), hipMemcpyHostToDevice, stream));
+    GAMUT_HIP_CHECK(hipMemsetAsync(sc.states, 0, (size_t)count * sizeof(InfState), stream));
+    return GAMUT_HIP_OK;
+}
+int inflate_sliced_step(int count, const uint32_t* avail_host /* pinned or pageable: read before the call returns */, uint32_t* out_len_dev, uint32_t* status_dev, hipStream_t stream)
+{
+    InflateScratch sc;
+    if (int rc = inflate_scratch(count, stream, sc)) return rc;     // (the buffer of _begin: same thread, device, stream, count)
+    GAMUT_HIP_CHECK(hipMemcpyAsync(sc.avail, avail_host, (size_t)count * 4, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_inflate, dim3((unsigned)count), dim3(kT), sizeof(Shared), stream, (const InfItem*)sc.items, count, sc.toks, out_len_dev, status_dev, sc.states, (const uint32_t*)sc.avail);
     return launch_status("inflate");
 }
 
@@ -988,4 +1078,30 @@ extern "C" int gamut_hip_inflate_batch_device(const gamut_hip_inflate_desc* desc
         return set_error(GAMUT_HIP_ERR_NO_DEVICE, "no HIP device available (libgamut_hip has no CPU fallback)");
     try { return inflate_launch(descs, count, out_len_dev, status_dev, pick_stream(stream)); }
     catch (...) { return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "inflate_batch_device: out of host memory"); }
+}
+
+// The same in steps: every launch sees `slice_bytes` more of every stream than the one before (all of them are in HBM already here; the
+// PNG batch path runs the launches behind the upload, slice by slice) -- a stream stops in front of a round it cannot finish within the
+// bytes it may read and goes on in the next launch from its saved state.  Same results as gamut_hip_inflate_batch_device.
+extern "C" int gamut_hip_inflate_batch_device_sliced(const gamut_hip_inflate_desc* descs, int count, uint32_t* out_len_dev, uint32_t* status_dev, uint32_t slice_bytes, void* stream)
+{
+    clear_error();
+    if (count < 0 || (count > 0 && (!descs || !out_len_dev || !status_dev)) || !slice_bytes) return set_error(GAMUT_HIP_ERR_INVALID_ARG, "inflate_batch_device_sliced: bad arguments");
+    if (count == 0) return GAMUT_HIP_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return set_error(GAMUT_HIP_ERR_NO_DEVICE, "no HIP device available (libgamut_hip has no CPU fallback)");
+    try {
+        hipStream_t st = pick_stream(stream);
+        if (int rc = inflate_sliced_begin(descs, count, st)) return rc;
+        uint32_t longest = 0;
+        for (int i = 0; i < count; ++i) longest = descs[i].src_len > longest ? descs[i].src_len : longest;
+        std::vector<uint32_t> avail((size_t)count);
+        for (uint64_t upto = slice_bytes; ; upto += slice_bytes) {
+            for (int i = 0; i < count; ++i) avail[(size_t)i] = (uint32_t)(upto < descs[i].src_len ? upto : descs[i].src_len);
+            if (int rc = inflate_sliced_step(count, avail.data(), out_len_dev, status_dev, st)) return rc;
+            if (upto >= longest) break;
+        }
+        return GAMUT_HIP_OK;
+    } catch (...) { return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "inflate_batch_device_sliced: out of host memory"); }
 }

@@ -24,7 +24,7 @@ def _deflate(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, wbits=-15, mem=8, 
     return b"".join(out)
 
 
-def _inflate_device(L, streams, caps):
+def _inflate_device(L, streams, caps, slice_bytes=0):
     """streams: list of raw-deflate byte strings; caps: output capacities -> (rc, [bytes], [status])"""
     n = len(streams)
     offs = np.concatenate([[0], np.cumsum([len(s) + 3 for s in streams])]).astype(np.int64)      # odd offsets: no alignment promised
@@ -41,7 +41,7 @@ def _inflate_device(L, streams, caps):
     for i in range(n):
         descs[i].src = dblob + int(offs[i]); descs[i].dst = dout + int(ooffs[i]); descs[i].src_len = len(streams[i]); descs[i].dst_cap = caps[i]
     _capi.check(L.gamut_hip_stream_synchronize(None))
-    rc = L.gamut_hip_inflate_batch_device(descs, n, dlen, dst, None)
+    rc = L.gamut_hip_inflate_batch_device_sliced(descs, n, dlen, dst, slice_bytes, None) if slice_bytes else L.gamut_hip_inflate_batch_device(descs, n, dlen, dst, None)
     lens = np.zeros(n, np.uint32); st = np.zeros(n, np.uint32); host = np.empty(poison.size, np.uint8)
     _capi.check(L.gamut_hip_memcpy_d2h(lens.ctypes.data, dlen, 4 * n, None))
     _capi.check(L.gamut_hip_memcpy_d2h(st.ctypes.data, dst, 4 * n, None))
@@ -178,3 +178,32 @@ def test_inflate_round_and_tile_boundaries(hip):
     for name, got, exp, s_ in zip(names, outs, expect, st):
         assert s_ == 0, f"{name}: status {s_}"
         assert got == exp, f"{name}: {len(got)} bytes, expected {len(exp)}; first difference at {next((i for i, (a, b) in enumerate(zip(got, exp)) if a != b), None)}"
+
+
+def test_inflate_in_slices_equals_inflate_at_once(hip):
+    """gamut_hip_inflate_batch_device_sliced: the streams advance a slice of input per launch (what the PNG batch path does behind the
+    upload) -- suspended in front of block headers, inside Huffman blocks (tables rebuilt from the saved code lengths, window from
+    the output), in front of stored blocks; damaged streams keep their verdicts; capacities below the stream's size (the window is
+    not reloaded once nothing is written any more)."""
+    rng = np.random.default_rng(31)
+    corpus = _corpus()
+    big = (rng.integers(0, 16, 3_000_000, dtype=np.uint8) * 3 + (np.arange(3_000_000) // 4093 % 100).astype(np.uint8)).tobytes()
+    noise = rng.integers(0, 256, 1_500_000, dtype=np.uint8).tobytes()
+    streams, expect, caps = [], [], []
+    for data in (big, noise, corpus["runs"] * 6, corpus["far"] * 5, bytes(2_000_000)):
+        for kw in (dict(level=6), dict(level=1, mem=1), dict(level=0), dict(level=6, strategy=zlib.Z_FIXED), dict(level=6, flush_every=50000)):
+            st = _deflate(data, **kw)
+            for cap in (len(data), len(data) // 3):
+                streams.append(st); expect.append(data[:cap]); caps.append(cap)
+    good = _deflate(big, 6)
+    bad = bytearray(good); bad[len(bad) // 2] ^= 0x55
+    streams += [bytes(bad), good[:len(good) // 2]]; expect += [None, None]; caps += [len(big), len(big)]
+    whole = _inflate_device(hip, streams, caps)
+    for slice_bytes in (100_000, 40_000, 1_000_000):
+        rc, outs, st = _inflate_device(hip, streams, caps, slice_bytes)
+        assert rc == 0, hip.gamut_hip_last_error()
+        for i, (got, exp, s_) in enumerate(zip(outs, expect, st)):
+            if exp is None:
+                assert (s_ != 0) == (whole[2][i] != 0), f"slice {slice_bytes}, stream {i}: status {s_}, at once {whole[2][i]}"
+            else:
+                assert s_ == 0 and got == exp, f"slice {slice_bytes}, stream {i}: status {s_}, {len(got)} of {len(exp)} bytes, first difference at {next((k for k, (a, b) in enumerate(zip(got, exp)) if a != b), None)}"

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Mutation fuzzing of the inflate kernel against zlib: damaged, truncated, spliced and random streams in batches; the device
 must give zlib's verdict (and zlib's bytes when zlib accepts) and come back.  Run on the GPU box under `timeout`.
-Usage: python tools/fuzz_inflate.py [iterations=4000] [seed=1]"""
+Usage: python tools/fuzz_inflate.py [iterations=4000] [seed=1] [slice_bytes=0: the sliced entry point, that many bytes of input per launch]"""
 import os
 import sys
 import time
@@ -18,6 +18,7 @@ from test_inflate_gpu import _corpus, _deflate, _inflate_device  # noqa: E402
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    slice_bytes = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     L = _capi.lib(); _capi.check(L.gamut_hip_init(0))
     corpus = {k: v[:40000] for k, v in _corpus().items() if len(v) > 100}
     seeds = []
@@ -48,7 +49,7 @@ def main():
                 for _ in range(int(rng.integers(1, 3))):
                     s[int(rng.integers(0, min(len(s), 120)))] ^= 1 << int(rng.integers(0, 8))
             cases.append(bytes(s) if len(s) else b"\x00")
-        rc, outs, st = _inflate_device(L, cases, [cap] * len(cases))
+        rc, outs, st = _inflate_device(L, cases, [cap] * len(cases), slice_bytes)
         assert rc == 0
         for c, o, v in zip(cases, outs, st):
             d = zlib.decompressobj(-15)

@@ -36,6 +36,9 @@ struct PngHeader {
     uint16_t tc[3] = { 0, 0, 0 };      // tRNS key: 8-bit values already scaled (stbdec.d:1945), 16-bit as-is (:1941)
     float ppmX = -1, ppmY = -1, aspect = -1;
     uint8_t* idata = nullptr; uint32_t ioff = 0;
+    // the batch path that inflates on the GPU gathers the IDAT payloads itself, slice by slice: parse() then only notes where they are
+    std::vector<std::pair<const uint8_t*, uint32_t>>* idat_segments = nullptr;
+    bool seen_idat = false;
     ~PngHeader() { free(idata); }
 };
 
@@ -90,7 +93,7 @@ int parse(const uint8_t* data, size_t len, PngHeader& h, bool header_only)
             break;
         case fourcc('t','R','N','S'):
             if (first) return set_error(GAMUT_HIP_ERR_DECODE, "png: first not IHDR");
-            if (h.idata) return set_error(GAMUT_HIP_ERR_DECODE, "png: tRNS after IDAT");
+            if (h.idata || h.seen_idat) return set_error(GAMUT_HIP_ERR_DECODE, "png: tRNS after IDAT");
             if (h.pal_img_n) {
                 if (header_only) { h.img_n = 4; return GAMUT_HIP_OK; }
                 if (h.pal_len == 0 || clen > h.pal_len) return set_error(GAMUT_HIP_ERR_DECODE, "png: bad tRNS");
@@ -110,6 +113,13 @@ int parse(const uint8_t* data, size_t len, PngHeader& h, bool header_only)
             if (h.pal_img_n && !h.pal_len) return set_error(GAMUT_HIP_ERR_DECODE, "png: no PLTE");
             if (header_only) { h.img_n = h.pal_img_n ? h.pal_img_n : h.img_n; return GAMUT_HIP_OK; }
             if ((int32_t)(h.ioff + clen) < (int32_t)h.ioff) return set_error(GAMUT_HIP_ERR_DECODE, "png: IDAT overflow");
+            h.seen_idat = true;
+            if (h.idat_segments) {
+                if ((size_t)(s.end - s.p) < clen) return set_error(GAMUT_HIP_ERR_DECODE, "png: out of data");
+                if (clen) h.idat_segments->emplace_back(s.p, clen);
+                s.p += clen; h.ioff += clen;
+                break;
+            }
             if (h.ioff + clen > cap) {
                 uint32_t ncap = cap ? cap : (clen > 4096 ? clen : 4096);
                 while (h.ioff + clen > ncap) ncap *= 2;
@@ -454,7 +464,7 @@ int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* 
         bool device_inflate = count >= kDeviceInflateFilesPerThread * threads;
         if (const char* v = getenv("GAMUT_HIP_PNG_INFLATE")) device_inflate = strcmp(v, "device") == 0 ? true : strcmp(v, "host") == 0 ? false : device_inflate;
         std::vector<size_t> blob_off((size_t)count + 1, 0);
-        std::vector<uint32_t> idat_len((size_t)count, 0);
+        std::vector<uint32_t> idat_len((size_t)count, 0), idat_skip((size_t)count, 0);
         uint8_t* h_blob = nullptr; uint8_t* d_blob = nullptr;
         static thread_local PerDevice<PinnedScratch> blob_pinned_pd;
         static thread_local PerDevice<DeviceScratch> blob_dev_pd;
@@ -465,30 +475,29 @@ int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* 
             d_blob = (uint8_t*)blob_dev.get(blob_off[(size_t)count] + 16);
             if (!h_blob || !d_blob) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png: staging for %zu bytes of IDAT data failed", blob_off[(size_t)count]);
         }
-        auto gather = [&]() {                                   // device inflate: chunk walk + IDAT gather of one file at a time
+        // Device inflate, step one: the chunk walk of every file (no byte of IDAT data is touched: parse() notes where the payloads are).
+        std::vector<std::vector<std::pair<const uint8_t*, uint32_t>>> segments(device_inflate ? (size_t)count : 0);
+        auto gather = [&]() {
             (void)hipSetDevice(dev);
             for (int i; (i = next.fetch_add(1, std::memory_order_relaxed)) < count; ) {
                 BatchFile& f = files[(size_t)i];
                 PngHeader h;
+                h.idat_segments = &segments[(size_t)i];
                 const auto t_in = std::chrono::steady_clock::now();
                 int rc = parse(data[i], len[i], h, false);
-                if (rc == GAMUT_HIP_OK && !h.idata) rc = set_error(GAMUT_HIP_ERR_DECODE, "png: no IDAT");
+                if (rc == GAMUT_HIP_OK && !h.seen_idat) rc = set_error(GAMUT_HIP_ERR_DECODE, "png: no IDAT");
                 uint32_t skip = 0;
                 if (rc == GAMUT_HIP_OK && !h.is_iphone) {                       // the zlib header, as inflate_idat checks it (stbdec.d:1281-1290)
-                    const uint8_t* b = h.idata;
+                    uint8_t b[2] = { 0, 0 }; uint32_t got = 0;
+                    for (const auto& sg : segments[(size_t)i]) for (uint32_t k = 0; k < sg.second && got < 2; ++k) b[got++] = sg.first[k];
                     if (h.ioff < 2 || ((b[0] * 256 + b[1]) % 31) != 0 || (b[1] & 32) || (b[0] & 15) != 8) rc = set_error(GAMUT_HIP_ERR_DECODE, "png: bad zlib header");
                     skip = 2;
                 }
                 if (rc == GAMUT_HIP_OK && slot[(size_t)i] < 0) rc = set_error(GAMUT_HIP_ERR_DECODE, "png: image too large");
                 if (rc != GAMUT_HIP_OK) { f.rc = rc; snprintf(f.msg, sizeof(f.msg), "image %d: %s", i, last_error_buf()); continue; }
                 idat_len[(size_t)i] = h.ioff - skip;
-                memcpy(h_blob + blob_off[(size_t)i], h.idata + skip, h.ioff - skip);
-                // the file's share goes up at once (copy stream): the DMA of the batch runs beside the chunk walk instead of after it
-                if (hipMemcpyAsync(d_blob + blob_off[(size_t)i], h_blob + blob_off[(size_t)i], h.ioff - skip, hipMemcpyHostToDevice, copy_stream) != hipSuccess) {
-                    (void)hipGetLastError();
-                    f.rc = GAMUT_HIP_ERR_HIP; snprintf(f.msg, sizeof(f.msg), "image %d: png: upload failed", i); continue;   // ~PngHeader frees idata
-                }
-                free(h.idata); h.idata = nullptr;
+                idat_skip[(size_t)i] = skip;
+                h.idat_segments = nullptr;
                 f.h = h;
                 f.out_n = h.img_n;
                 if ((req_comp == h.img_n + 1 && req_comp != 3 && !h.pal_img_n) || h.has_trans) f.out_n = h.img_n + 1;      // stbdec.d:1821-1824
@@ -548,13 +557,18 @@ int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* 
         GAMUT_HIP_CHECK(hipStreamSynchronize(copy_stream));                       // (every worker waited for its own copies already)
         double ms_device_inflate = 0;
         if (device_inflate) {
-            // one upload, one launch: every stream straight into its slot of the arena; lengths and verdicts come back
+            // Step two: the IDAT bytes go up SLICE BY SLICE -- slice r of every stream, then slice r + 1 of every stream -- and the inflate
+            // kernel is launched once per slice behind them (inflate_sliced_*: a stream stops where the bytes it may read end and goes on
+            // in the next launch).  A stream inflates at ~150-600 MB/s, all of them side by side: about what PCIe delivers to all of them
+            // together, so the upload hides behind the kernel instead of standing in front of it.
             const auto t_inf = std::chrono::steady_clock::now();
             std::vector<gamut_hip_inflate_desc> descs; std::vector<int> who;
+            uint32_t longest = 0;
             for (int i = 0; i < count; ++i) {
                 if (files[(size_t)i].rc != GAMUT_HIP_OK) continue;
                 descs.push_back(gamut_hip_inflate_desc{ d_blob + blob_off[(size_t)i], d_arena + slot[(size_t)i], idat_len[(size_t)i], (uint32_t)slot_bytes[(size_t)i] });
                 who.push_back(i);
+                longest = idat_len[(size_t)i] > longest ? idat_len[(size_t)i] : longest;
             }
             if (!descs.empty()) {
                 const size_t n = descs.size();
@@ -563,10 +577,64 @@ int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* 
                 uint32_t* d_verdict = (uint32_t*)verdict_dev.get(n * 8);
                 if (!d_verdict) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png: verdict table allocation failed");
                 std::vector<uint32_t> verdict(n * 2);
-                // (the streams went up file by file while the chunks were walked; the copy stream was synchronised above)
-                if (int rc = inflate_launch(descs.data(), (int)n, d_verdict, d_verdict + n, st)) return rc;
-                GAMUT_HIP_CHECK(hipMemcpyAsync(verdict.data(), d_verdict, n * 8, hipMemcpyDeviceToHost, st));
-                GAMUT_HIP_CHECK(hipStreamSynchronize(st));
+                uint32_t slice = 1u << 20;                                        // at most 32 launches
+                if (const char* v = getenv("GAMUT_HIP_PNG_SLICE_KB")) { const long kb = atol(v); if (kb >= 64 && kb <= (1 << 20)) slice = (uint32_t)kb << 10; }      // (tuning)
+                while ((uint64_t)slice * 32u < longest) slice *= 2;
+                const int rounds = longest ? (int)(((uint64_t)longest + slice - 1) / slice) : 1;
+                // the units of work, slice-major: (round, stream)
+                std::vector<std::pair<int, int>> units;
+                std::vector<int> units_in_round((size_t)rounds, 0);
+                for (int r = 0; r < rounds; ++r)
+                    for (size_t k = 0; k < n; ++k) if ((uint64_t)r * slice < idat_len[(size_t)who[k]] || (r == 0 && idat_len[(size_t)who[k]] == 0)) { units.emplace_back(r, (int)k); ++units_in_round[(size_t)r]; }
+                std::vector<std::atomic<int>> round_done((size_t)rounds);
+                for (auto& a : round_done) a.store(0);
+                std::atomic<size_t> next_unit{ 0 };
+                std::atomic<bool> upload_failed{ false };
+                auto upload = [&]() {
+                    (void)hipSetDevice(dev);
+                    for (size_t u; (u = next_unit.fetch_add(1, std::memory_order_relaxed)) < units.size(); ) {
+                        const int r = units[u].first, i = who[(size_t)units[u].second];
+                        const uint64_t lo = (uint64_t)r * slice, hi = std::min<uint64_t>(lo + slice, idat_len[(size_t)i]);
+                        // bytes [lo, hi) of the stream = bytes [lo + skip, hi + skip) of the concatenated IDAT payloads
+                        uint8_t* dst = h_blob + blob_off[(size_t)i] + lo;
+                        uint64_t at = 0, want_lo = lo + idat_skip[(size_t)i], want_hi = hi + idat_skip[(size_t)i];
+                        for (const auto& sg : segments[(size_t)i]) {
+                            const uint64_t s_lo = at, s_hi = at + sg.second;
+                            at = s_hi;
+                            if (s_hi <= want_lo) continue;
+                            if (s_lo >= want_hi) break;
+                            const uint64_t c_lo = std::max(s_lo, want_lo), c_hi = std::min(s_hi, want_hi);
+                            memcpy(dst + (c_lo - want_lo), sg.first + (c_lo - s_lo), (size_t)(c_hi - c_lo));
+                        }
+                        if (hi > lo && hipMemcpyAsync(d_blob + blob_off[(size_t)i] + lo, dst, (size_t)(hi - lo), hipMemcpyHostToDevice, copy_stream) != hipSuccess) {
+                            (void)hipGetLastError(); upload_failed.store(true);
+                        }
+                        round_done[(size_t)r].fetch_add(1, std::memory_order_release);
+                    }
+                };
+                if (int rc = inflate_sliced_begin(descs.data(), (int)n, st)) return rc;
+                std::vector<std::thread> pool;
+                try { for (int t = 0; t < threads; ++t) pool.emplace_back(upload); } catch (...) {}
+                if (pool.empty()) upload();                                       // (no thread could be started: this one does it all, then launches)
+                std::vector<hipEvent_t> up((size_t)rounds, nullptr);
+                std::vector<uint32_t> avail(n);
+                int launch_rc = GAMUT_HIP_OK;
+                for (int r = 0; r < rounds && launch_rc == GAMUT_HIP_OK; ++r) {
+                    while (round_done[(size_t)r].load(std::memory_order_acquire) < units_in_round[(size_t)r]) std::this_thread::yield();
+                    // every copy of slice r has been queued on the copy stream: the compute stream waits for them, then inflates what is there
+                    if (hipEventCreateWithFlags(&up[(size_t)r], hipEventDisableTiming) != hipSuccess || hipEventRecord(up[(size_t)r], copy_stream) != hipSuccess ||
+                        hipStreamWaitEvent(st, up[(size_t)r], 0) != hipSuccess) { (void)hipGetLastError(); launch_rc = set_error(GAMUT_HIP_ERR_HIP, "png: event for slice %d failed", r); break; }
+                    for (size_t k = 0; k < n; ++k) avail[k] = (uint32_t)std::min<uint64_t>((uint64_t)(r + 1) * slice, idat_len[(size_t)who[k]]);
+                    launch_rc = inflate_sliced_step((int)n, avail.data(), d_verdict, d_verdict + n, st);
+                }
+                for (std::thread& th : pool) th.join();
+                if (launch_rc == GAMUT_HIP_OK && upload_failed.load()) launch_rc = set_error(GAMUT_HIP_ERR_HIP, "png: upload of the IDAT data failed");
+                if (launch_rc == GAMUT_HIP_OK && hipMemcpyAsync(verdict.data(), d_verdict, n * 8, hipMemcpyDeviceToHost, st) != hipSuccess) launch_rc = set_error(GAMUT_HIP_ERR_HIP, "png: verdict download failed");
+                const hipError_t sync_rc = hipStreamSynchronize(st);
+                (void)hipStreamSynchronize(copy_stream);
+                for (hipEvent_t e : up) if (e) (void)hipEventDestroy(e);
+                if (launch_rc != GAMUT_HIP_OK) return launch_rc;
+                if (sync_rc != hipSuccess) return set_error(GAMUT_HIP_ERR_HIP, "png: inflate on the device failed: %s", hipGetErrorString(sync_rc));
                 for (size_t k = 0; k < n; ++k) {
                     BatchFile& f = files[(size_t)who[k]];
                     if (verdict[n + k]) { f.rc = GAMUT_HIP_ERR_DECODE; snprintf(f.msg, sizeof(f.msg), "image %d: png: corrupt zlib stream", who[k]); continue; }

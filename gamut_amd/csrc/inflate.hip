@@ -51,6 +51,9 @@ constexpr int kTokCap = 32768;                       // tokens a round may emit 
 #ifndef INFLATE_LIT_BITS
 #define INFLATE_LIT_BITS 11
 #endif
+#ifndef INFLATE_PAIRS               // two literals behind one look-up (tools/variant.sh A/B)
+#define INFLATE_PAIRS 1
+#endif
 #ifndef INFLATE_LONG_MIN
 #define INFLATE_LONG_MIN 32
 #endif
@@ -244,7 +247,7 @@ __device__ __noinline__ void build_tables(Shared& S, int hlit, int dist_base, in
             // two literals behind one look-up when both codes fit the index (kind 4: base = first | second << 8): residual data
             // of photographs is mostly literals of 3-6 bits
             const uint32_t l1 = r & 15u;
-            if (r && ((r >> 4) & 7u) == 0u && l1 < (uint32_t)kLitBits) {
+            if (INFLATE_PAIRS && r && ((r >> 4) & 7u) == 0u && l1 < (uint32_t)kLitBits) {
                 const uint32_t r2 = codes.decode((uint32_t)e >> l1, S.lit_sorted, kLitBits - (int)l1);
                 if (r2 && ((r2 >> 4) & 7u) == 0u) r = ((r >> 16) | (r2 >> 16) << 8) << 16 | l1 << 12 | 4u << 4 | (l1 + (r2 & 15u));
             }
@@ -276,7 +279,7 @@ __device__ __forceinline__ Code read_code(const Shared& S, const LL& long_lit, c
     uint32_t e = S.lut[state ? (1u << kLitBits) + (b & ((1u << kDistBits) - 1u)) : (b & ((1u << kLitBits) - 1u))];
     if ((e & 15u) == 0u) { e = state ? long_dist.decode(b, S.dist_sorted) : long_lit.decode(b, S.lit_sorted); if (!e) e = 3u << 4; }
     uint32_t nb = e & 15u, kind = (e >> 4) & 7u;
-    if (kind == 4u) {
+    if (INFLATE_PAIRS && kind == 4u) {
         // a pair whose second literal would begin at or beyond `end` is taken as its first literal alone: a lane must
         // leave at the FIRST token boundary past its end whatever way it came in, or the lanes never fall into step
         const uint32_t l1 = (e >> 12) & 15u;

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Mutation fuzzing of the inflate kernel against zlib: damaged, truncated, spliced and random streams in batches; the device
 must give zlib's verdict (and zlib's bytes when zlib accepts) and come back.  Run on the GPU box under `timeout`.
-Usage: python tools/fuzz_inflate.py [iterations=4000] [seed=1] [slice_bytes=0: the sliced entry point, that many bytes of input per launch]"""
+Usage: python tools/fuzz_inflate.py [iterations=4000] [seed=1] [slice_bytes=0: the sliced entry point, that many bytes of input per launch]
+[seed_bytes=40000: uncompressed size of the seed streams -- 600000 makes streams of several rounds and tiles]"""
 import os
 import sys
 import time
@@ -20,13 +21,14 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     slice_bytes = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     L = _capi.lib(); _capi.check(L.gamut_hip_init(0))
-    corpus = {k: v[:40000] for k, v in _corpus().items() if len(v) > 100}
+    seed_bytes = int(sys.argv[4]) if len(sys.argv) > 4 else 40000
+    corpus = {k: (v * (seed_bytes // len(v) + 1))[:seed_bytes] for k, v in _corpus().items() if len(v) > 100}
     seeds = []
     for name, data in corpus.items():
         for kw in (dict(level=6), dict(level=1), dict(level=9, mem=1), dict(level=6, strategy=zlib.Z_FIXED), dict(level=6, strategy=zlib.Z_HUFFMAN_ONLY),
                    dict(level=0), dict(level=6, flush_every=500)):
             seeds.append(_deflate(data, **kw))
-    cap = 48000
+    cap = seed_bytes + 8000
     done = bad = accepted = 0
     t0 = time.time()
     while done < iters:

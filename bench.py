@@ -159,6 +159,22 @@ def also_lines(budget_s):
             res.append({"what": what, "workload": wl, "skipped": "did not finish inside the --also-seconds budget"})
         except Exception as ex:                                          # the headline line must survive anything here
             res.append({"what": what, "workload": wl, "error": repr(ex)[:200]})
+    # what a caller with FILES sees (the feeders in front of the hot path) -- tools/files_bench.py, one line per case
+    left = t_end - time.perf_counter()
+    if left < 45:
+        res.append({"what": "files -> pixels (tools/files_bench.py)", "skipped": "the --also-seconds budget ran out"})
+    else:
+        try:
+            r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "files_bench.py")],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=left, text=True)
+            lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+            res.extend(lines)
+            if r.returncode != 0 or not lines:
+                res.append({"what": "files -> pixels (tools/files_bench.py)", "error": ((r.stderr or r.stdout).strip().splitlines() or ["no output"])[-1][:200], "rc": r.returncode})
+        except subprocess.TimeoutExpired:
+            res.append({"what": "files -> pixels (tools/files_bench.py)", "skipped": "did not finish inside the --also-seconds budget"})
+        except Exception as ex:
+            res.append({"what": "files -> pixels (tools/files_bench.py)", "error": repr(ex)[:200]})
     return res
 
 

@@ -69,7 +69,7 @@ def main():
         _capi.check(L.gamut_hip_qoi_decode_batch_device(qp, ql, nq, 4, qoff.ctypes.data_as(P64), out.data_ptr(), descs, None, stream))
 
     print(f"mixed batch of {B} x {w}x{h} files ({nj} JPEG {np.mean([b.size for b in jb]) / 1e3:.0f} kB, {npn} PNG {np.mean([b.size for b in pb]) / 1e6:.1f} MB, "
-          f"{nq} QOI {np.mean([b.size for b in qb]) / 1e6:.1f} MB) -> rgba8 in HBM; PNG inflate on {a.threads} host threads")
+          f"{nq} QOI {np.mean([b.size for b in qb]) / 1e6:.1f} MB) -> rgba8 in HBM; {a.threads} host threads (0 = all; PNG batches this large inflate on the GPU)")
     best = {}
     for rep in range(3):
         for k, fn in (("jpeg", run_jpeg), ("png", run_png), ("qoi", run_qoi)):

@@ -409,6 +409,7 @@ __device__ __forceinline__ void expand_long_matches(Shared& S)
 // counts from cs - 32768: p < 32768 is window history; p == j + 32768 is the byte itself = a literal).  Rounds of pointer
 // doubling first: a byte whose source is neither adopts its source's source.  A thread looks at 8 neighbouring bytes (one
 // 16-byte read of their entries) and remembers which of them are settled.  Then one pass moves the values.
+__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) { uint32_t r; asm("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ int resolve_copies(Shared& S, uint32_t cs, uint32_t total)      // -> rounds taken
 {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -464,18 +465,31 @@ __device__ __forceinline__ int resolve_copies(Shared& S, uint32_t cs, uint32_t t
         if (!S.ctrl[C_OPEN0 + round % 3]) break;
     }
     __syncthreads();
-    // values: every source is a literal of the tile or a byte of the window
+    // values: every source is a literal of the tile or a byte of the window.  Positions are 16-bit and the ring is 65 536 bytes: ring
+    // addresses are packed 16-bit sums.  A literal "copies" itself (no test per byte; bytes of the last unit beyond the tile too: they
+    // are ring bytes older than the window).
+    const uint32_t src_base = ((cs - (uint32_t)kHist) & 0xFFFFu) * 0x00010001u;
     for (uint32_t u = (uint32_t)t; u < units; u += kT) {
         const uint32_t j0 = u * 8u, self0 = j0 + kHist;
         const u32x4 f = *reinterpret_cast<const u32x4*>(&S.from[j0]);
         const uint32_t s0 = self0 | (self0 + 1u) << 16;
         if (f.x == s0 && f.y == s0 + 0x00020002u && f.z == s0 + 0x00040004u && f.w == s0 + 0x00060006u) continue;      // eight literals
-        const uint32_t p[8] = { f.x & 0xFFFFu, f.x >> 16, f.y & 0xFFFFu, f.y >> 16, f.z & 0xFFFFu, f.z >> 16, f.w & 0xFFFFu, f.w >> 16 };
+        const uint32_t P[4] = { f.x, f.y, f.z, f.w };
         uint8_t v[8];
         #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = S.ring[(cs + p[i] - kHist) & kRingMask];
-        #pragma unroll
-        for (int i = 0; i < 8; ++i) if (p[i] != self0 + i && j0 + i < total) S.ring[(cs + j0 + i) & kRingMask] = v[i];
+        for (int d = 0; d < 4; ++d) {
+            const uint32_t A = pk_add_u16(P[d], src_base);         // two ring addresses
+            v[2 * d] = S.ring[A & 0xFFFFu]; v[2 * d + 1] = S.ring[A >> 16];
+        }
+        const uint32_t dst0 = (cs + j0) & 0xFFFFu;
+        if (dst0 <= 0xFFF8u) {                                      // (all but the unit that straddles the ring's end)
+            uint8_t* d8 = &S.ring[dst0];
+            #pragma unroll
+            for (int i = 0; i < 8; ++i) d8[i] = v[i];
+        } else {
+            #pragma unroll
+            for (int i = 0; i < 8; ++i) S.ring[(dst0 + (uint32_t)i) & kRingMask] = v[i];
+        }
     }
     return round + 1;
 }

@@ -1113,12 +1113,15 @@ extern "C" int gamut_hip_inflate_batch_device_sliced(const gamut_hip_inflate_des
         if (int rc = inflate_sliced_begin(descs, count, st)) return rc;
         uint32_t longest = 0;
         for (int i = 0; i < count; ++i) longest = descs[i].src_len > longest ? descs[i].src_len : longest;
-        std::vector<uint32_t> avail((size_t)count);
+        std::vector<std::vector<uint32_t>> tables;                  // (one per launch, alive until the stream has been waited for)
         for (uint64_t upto = slice_bytes; ; upto += slice_bytes) {
+            tables.emplace_back((size_t)count);
+            std::vector<uint32_t>& avail = tables.back();
             for (int i = 0; i < count; ++i) avail[(size_t)i] = (uint32_t)(upto < descs[i].src_len ? upto : descs[i].src_len);
-            if (int rc = inflate_sliced_step(count, avail.data(), out_len_dev, status_dev, st)) return rc;
+            if (int rc = inflate_sliced_step(count, avail.data(), out_len_dev, status_dev, st)) { (void)hipStreamSynchronize(st); return rc; }
             if (upto >= longest) break;
         }
+        GAMUT_HIP_CHECK(hipStreamSynchronize(st));                   // (the tables go away with this frame; the other entry point is asynchronous)
         return GAMUT_HIP_OK;
     } catch (...) { return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "inflate_batch_device_sliced: out of host memory"); }
 }

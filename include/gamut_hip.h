@@ -285,7 +285,8 @@ int gamut_hip_inflate_batch_device(const gamut_hip_inflate_desc* descs, int coun
 /* The same in several launches, each allowed `slice_bytes` more of every stream than the one before: a stream stops in front of what it
  * cannot finish within the bytes it may read and goes on from its saved state (position, code lengths of the block it stands in; the
  * window comes back from its output).  This is how gamut_hip_png_decode_batch_device inflates while the files are still on their way
- * over PCIe; here all bytes are in HBM already -- same results as the call above, for tests and measurements. */
+ * over PCIe; here all bytes are in HBM already -- same results as the call above, for tests and measurements (this one returns when the
+ * last launch has finished). */
 int gamut_hip_inflate_batch_device_sliced(const gamut_hip_inflate_desc* descs, int count, uint32_t* out_len_dev, uint32_t* status_dev, uint32_t slice_bytes, void* stream);
 
 /* ---- PNG files in batches ----------------------------------------------------------------------------------- */

@@ -846,6 +846,9 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                     const bool settled = !njobs && stop_now == first_stop;
                     first_stop = stop_now;
                     if (settled) break;
+                    // (every turn settles at least the first unsettled lane, and a stop moves at most once per settled lane: 2 kT turns are the
+                    // proven bound.  A kernel that spins is worse than a stream turned away: beyond twice that the stream counts as corrupt.)
+                    if (turn > 4 * kT) { err = E_INPUT; break; }
                     if ((uint32_t)t < njobs) {
                         const uint32_t lane = S.jobs[t];
                         const uint4 m = S.lane_map[lane];
@@ -858,6 +861,7 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                     }
                     __syncthreads();
                 }
+                if (err) break;
                 { const uint4 m = S.lane_map[t]; L.start = S.lane_start[t]; L.first = (uint64_t)m.y << 32 | m.x; L.count = (uint64_t)m.w << 32 | m.z; }
                 PROF(P_SWEEPS);
                 uint32_t nvalid = first_stop < (uint32_t)(kT - 1) ? first_stop + 1u : (uint32_t)(kT - 1);      // lanes 0 .. nvalid - 1 form the chain (never the last one)

@@ -697,6 +697,7 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
     // fixed code are built once per stream.
     const uint32_t block_budget = it.src_len / 8u + 4096u;
     bool fixed_tables = false;                        // the LDS tables hold the fixed code
+    uint64_t last_block_bits = 0;                     // the length of the Huffman block before this one (0: none yet)
     while (!done && !err) {
       const uint64_t pos_block = pos;
       if (!resume_block) {
@@ -786,6 +787,7 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
             LongDist long_dist; long_dist.load(S.dist);
             PROF(P_T_LONG);
             bool in_block = true;
+            const uint64_t block_begin = pos;
             while (in_block && !err) {
                 if (!enough(pos)) { suspended = true; suspended_in_block = true; break; }
                 // (the window the header was read from serves the block's first round: the lanes in front of `pos` are passed over like
@@ -797,8 +799,19 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                 const uint32_t rel0 = (uint32_t)(pos - wbase * 8u);
                 const uint32_t my_base = (uint32_t)t * kSubBits;
                 // ---- tokens: speculative decode, then lanes fall into step with their predecessors
-                Lane L{ 0, 0, 0, 0, 0 };
-                lane_trace<false>(S, long_lit, long_dist, L, t == 0 ? rel0 : my_base, my_base);
+                // Lanes behind the block's end decode its successor's bits with this block's tables: waves of them cost the others their issue
+                // slots (the passes of a round are arithmetic-bound with sixteen waves at work).  An encoder's blocks are of a kind -- the round
+                // wakes as many waves as the previous block would need from here, a quarter more; a longer block just takes another round.
+                uint32_t awake = kT;
+                if (last_block_bits) {
+                    const uint64_t so_far = pos - block_begin;
+                    const uint64_t left = last_block_bits > so_far ? last_block_bits - so_far : 0;
+                    const uint64_t want = (uint64_t)rel0 + left + (left >> 2) + 4u * kSubBits;
+                    awake = want / kSubBits >= (uint64_t)kT ? (uint32_t)kT : (((uint32_t)(want / kSubBits) + 64u) & ~63u);
+                    if (awake > (uint32_t)kT) awake = kT;
+                }
+                Lane L{ (uint32_t)t * kSubBits, (uint32_t)t * kSubBits, 0, 0, 0 };
+                if ((uint32_t)t < awake) lane_trace<false>(S, long_lit, long_dist, L, t == 0 ? rel0 : my_base, my_base);
                 // Every lane's state goes to LDS; then, turn by turn: a lane whose predecessor leaves somewhere else than the lane begins
                 // -- and not on a bit of its map -- is a job; the jobs are walked by the first threads of the workgroup, packed (a
                 // turn late in the round has a handful of jobs: one wave walks them, the other fifteen wait at the barrier instead of
@@ -809,6 +822,7 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                 S.lane_map[t] = make_uint4((uint32_t)L.first, (uint32_t)(L.first >> 32), (uint32_t)L.count, (uint32_t)(L.count >> 32));
                 __syncthreads();
                 PROF(P_SWEEP0);
+                const uint32_t last_lane = awake < (uint32_t)kT ? awake : (uint32_t)(kT - 1);   // lanes at and behind it are not part of this round
                 uint32_t first_stop = kT;                                              // the first lane of the chain with a stop (lanes behind it do not matter)
                 for (int turn = 0; ; ++turn) {
                     PROF_COUNT(P_N_SWEEPS, 1);
@@ -816,7 +830,7 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                     const int slot = turn % 3, next_slot = (turn + 1) % 3;
                     if (t == 0) { S.ctrl[C_JOBS0 + next_slot] = 0; S.ctrl[C_STOP0 + next_slot] = kT; }
                     const uint32_t prev = t ? S.lane_exit[t - 1] : rel0, mine = S.lane_exit[t];
-                    bool job = t > 0 && t < kT - 1 && !(prev >> 24) && prev != S.lane_start[t] && (uint32_t)t <= first_stop;     // (a stopped predecessor moves nobody)
+                    bool job = t > 0 && (uint32_t)t < last_lane && !(prev >> 24) && prev != S.lane_start[t] && (uint32_t)t <= first_stop;     // (a stopped predecessor moves nobody)
                     if (job) {
                         const uint32_t rel = prev - my_base, w = rel >> 5;             // (>= 0: a predecessor leaves at or beyond its end)
                         if (w < 8u) {
@@ -837,7 +851,7 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                         at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
                         if (job) S.jobs[at + (uint32_t)__popcll(jobs & ((1ull << lane_in_wave) - 1ull))] = (uint16_t)t;
                     }
-                    const uint64_t stopped = __ballot((mine >> 24) != 0 && (uint32_t)t <= first_stop && t < kT - 1);
+                    const uint64_t stopped = __ballot((mine >> 24) != 0 && (uint32_t)t <= first_stop && (uint32_t)t < last_lane);
                     if (stopped && lane_in_wave == 0) atomicMin(&S.ctrl[C_STOP0 + slot], (uint32_t)(wave * 64) + (uint32_t)__builtin_ctzll(stopped));
                     __syncthreads();
                     const uint32_t njobs = S.ctrl[C_JOBS0 + slot], stop_now = S.ctrl[C_STOP0 + slot];
@@ -864,7 +878,7 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                 if (err) break;
                 { const uint4 m = S.lane_map[t]; L.start = S.lane_start[t]; L.first = (uint64_t)m.y << 32 | m.x; L.count = (uint64_t)m.w << 32 | m.z; }
                 PROF(P_SWEEPS);
-                uint32_t nvalid = first_stop < (uint32_t)(kT - 1) ? first_stop + 1u : (uint32_t)(kT - 1);      // lanes 0 .. nvalid - 1 form the chain (never the last one)
+                uint32_t nvalid = first_stop < last_lane ? first_stop + 1u : last_lane;      // lanes 0 .. nvalid - 1 form the chain (never the window's last lane)
                 // ---- slots for the tokens, the round cut where the list would overflow
                 if (t == 0) S.ctrl[C_CUT] = kT;
                 uint32_t ntok = 0;
@@ -976,7 +990,7 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                     o0 = o1;
                 }
                 pos = wbase * 8u + last_exit;
-                if (last_flags & F_EOB) in_block = false;
+                if (last_flags & F_EOB) { in_block = false; last_block_bits = pos - block_begin; }
             }
         }
         if (suspended) break;                                                       // (inside the block: it goes on next launch)

@@ -940,14 +940,18 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                                 // A match right behind a match of the same distance goes on with its period (a run cut into 258-byte pieces,
                                 // the pixels of a flat row): all of them copy from in front of the FIRST one, so the pieces of a run are one
                                 // link deep instead of one link per piece.  The first one is looked for among the wave's 64 tokens.
-                                const uint32_t before_x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tk.x, 0x138, 0xF, 0xF, false);      // wave_shr:1 (lane 0: no token)
-                                const uint32_t before_y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tk.y, 0x138, 0xF, 0xF, false);
-                                const bool goes_on = match && (before_y >> 31) && (before_x >> 16) == dist;
-                                uint32_t first = goes_on ? 0u : at + 1u;                // -> the nearest token in front that does not go on, + 1
-                                if (__ballot(goes_on)) {
+                                bool goes_on = false;
+                                uint32_t first = at + 1u;                                // -> the nearest token in front that does not go on, + 1
+                                if (__ballot(match)) {                                  // (a wave of literals has no run to look for)
+                                    const uint32_t before_x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tk.x, 0x138, 0xF, 0xF, false);      // wave_shr:1 (lane 0: no token)
+                                    const uint32_t before_y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tk.y, 0x138, 0xF, 0xF, false);
+                                    goes_on = match && (before_y >> 31) && (before_x >> 16) == dist;
+                                    first = goes_on ? 0u : at + 1u;
+                                    if (__ballot(goes_on)) {
 #define RUN_STEP(CTRL, ROWS) { const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)first, CTRL, ROWS, 0xF, false); first = o > first ? o : first; }
-                                    RUN_STEP(0x111, 0xF) RUN_STEP(0x112, 0xF) RUN_STEP(0x114, 0xF) RUN_STEP(0x118, 0xF) RUN_STEP(0x142, 0xA) RUN_STEP(0x143, 0xC)
+                                        RUN_STEP(0x111, 0xF) RUN_STEP(0x112, 0xF) RUN_STEP(0x114, 0xF) RUN_STEP(0x118, 0xF) RUN_STEP(0x142, 0xA) RUN_STEP(0x143, 0xC)
 #undef RUN_STEP
+                                    }
                                 }
                                 const uint32_t root = goes_on ? first - 1u : at;          // where the run begins
                                 if (match) {

@@ -940,9 +940,17 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                                 // A match right behind a match of the same distance goes on with its period (a run cut into 258-byte pieces,
                                 // the pixels of a flat row): all of them copy from in front of the FIRST one, so the pieces of a run are one
                                 // link deep instead of one link per piece.  The first one is looked for among the wave's 64 tokens.
+                                if (!__ballot(match)) {                                 // a wave of literals: nothing but one or two bytes into the ring
+                                    if (!sink) {
+                                        const uint32_t n = tk.x & 3u, rel = at - o0;       // (rel >= total: in front of or behind the tile)
+                                        if (n && rel < total) S.ring[(produced + rel) & kRingMask] = (uint8_t)(tk.x >> 16);
+                                        if (n > 1u && rel + 1u < total) S.ring[(produced + rel + 1u) & kRingMask] = (uint8_t)(tk.x >> 24);
+                                    }
+                                    continue;
+                                }
                                 bool goes_on = false;
                                 uint32_t first = at + 1u;                                // -> the nearest token in front that does not go on, + 1
-                                if (__ballot(match)) {                                  // (a wave of literals has no run to look for)
+                                {
                                     const uint32_t before_x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tk.x, 0x138, 0xF, 0xF, false);      // wave_shr:1 (lane 0: no token)
                                     const uint32_t before_y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tk.y, 0x138, 0xF, 0xF, false);
                                     goes_on = match && (before_y >> 31) && (before_x >> 16) == dist;

@@ -79,7 +79,7 @@ enum : uint32_t { ST_DONE = 1, ST_IN_BLOCK = 2, ST_VALID = 4 };
 #define INFLATE_PROFILE 0
 #endif
 enum { P_HEADER = 0, P_TABLES, P_WINDOW, P_SWEEP0, P_SWEEPS, P_SCAN, P_WRITE, P_MATCH, P_FLUSH, P_STORED,
-       P_H_FIELDS, P_H_CODE, P_H_WALKS, P_H_EMIT, P_T_RANKS, P_T_STARTS, P_T_SORT, P_T_LIT, P_T_DIST, P_T_LONG,
+       P_H_FIELDS, P_H_CODE, P_H_WALKS, P_H_EMIT, P_T_RANKS, P_T_STARTS, P_T_SORT, P_T_LIT, P_T_DIST, P_T_LONG, P_F_SETUP, P_F_INIT,
        P_N_BLOCKS, P_N_CHUNKS, P_N_SWEEPS, P_N_ROUNDS, P_N_MATCHES, P_N };
 #if INFLATE_PROFILE
 __device__ unsigned long long g_inflate_prof[P_N];
@@ -910,9 +910,16 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                     const uint32_t total = round_out - o0 < (uint32_t)kNewMax ? round_out - o0 : (uint32_t)kNewMax, o1 = o0 + total;
                     if (t == 0) { S.ctrl[C_CUT] = kT; S.ctrl[C_LAST] = 0; S.ctrl[C_NLONG] = 0; S.ctrl[C_OPEN0] = 0; }
                     __syncthreads();
-                    if ((uint32_t)t < nvalid && out_incl > o0 && out_incl - out < o1) { atomicMin(&S.ctrl[C_CUT], (uint32_t)t); atomicMax(&S.ctrl[C_LAST], (uint32_t)t); }
+                    {   // (one pair of atomics per wave, not per lane: several hundred lanes on two LDS words cost a tile 11 000 cycles)
+                        const uint64_t mine = __ballot((uint32_t)t < nvalid && out_incl > o0 && out_incl - out < o1);
+                        if (mine && lane_in_wave == 0) {
+                            atomicMin(&S.ctrl[C_CUT], (uint32_t)(wave * 64) + (uint32_t)__builtin_ctzll(mine));
+                            atomicMax(&S.ctrl[C_LAST], (uint32_t)(wave * 64) + 63u - (uint32_t)__builtin_clzll(mine));
+                        }
+                    }
                     __syncthreads();
                     const uint32_t a = S.ctrl[C_CUT], b = S.ctrl[C_LAST];             // the lanes with bytes in the tile: all their tokens are looked at
+                    PROF(P_F_SETUP);
                     const uint32_t tok0 = a ? S.cum_tok[a - 1] : 0u, tok1 = S.cum_tok[b];
                     const bool sink = produced >= it.dst_cap;                         // the caller's buffer is full: decode on, write nothing
                     if (!sink) {
@@ -923,6 +930,7 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                         }
                         __syncthreads();
                     }
+                    PROF(P_F_INIT);
                     if (!sink || produced0 < (uint32_t)kHist) {
                         for (uint32_t kb = tok0; kb < tok1; kb += 4u * kT) {             // (the same trips for every thread: the neighbours' tokens travel by DPP)
                             uint2 four[4];                                             // four loads in flight (an absent token reads as an empty literal)

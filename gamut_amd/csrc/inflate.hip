@@ -970,25 +970,33 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                                     }
                                 }
                                 const uint32_t root = goes_on ? first - 1u : at;          // where the run begins
-                                if (match) {
-                                    if (produced0 < (uint32_t)kHist && dist > produced0 + at) atomicMax(&S.ctrl[C_ERR], (uint32_t)E_DISTANCE);      // reaches before the first output byte
-                                    else if (!sink && at < o1 && at + len > o0) {
-                                        // Byte x of a run of period dist equals byte p - dist + (x - p) mod dist for any point p of the run at or in front
-                                        // of x: p = the run's first byte, or the tile's if the run began in front of it (the dist bytes in front of p
-                                        // are bytes of this tile or window history either way).  Pointing there at once keeps the chains of
-                                        // overlapping copies one link long.  Long matches are left to a whole wave.
-                                        const uint32_t p = root > o0 ? root : o0;
-                                        const uint32_t x0 = at > o0 ? at : o0, x1 = at + len < o1 ? at + len : o1;      // the bytes of the match inside the tile
-                                        const uint32_t q = p - o0 + kHist - dist, since = x0 - p, n = x1 - x0;
-                                        uint32_t slot = kLongCap;
-                                        if (n >= (uint32_t)kLongMin) slot = atomicAdd(&S.ctrl[C_NLONG], 1u);
-                                        if (slot < (uint32_t)kLongCap) S.longm[slot] = make_uint2((x0 - o0) | n << 15, since | dist << 16);
-                                        else for (uint32_t i = 0, m = since % dist; i < n; ++i) { S.from[x0 - o0 + i] = (uint16_t)(q + m); if (++m == dist) m = 0; }
-                                    }
-                                } else if (!sink) {
-                                    const uint32_t n = tk.x & 3u;
-                                    if (n && at >= o0 && at < o1) S.ring[(produced0 + at) & kRingMask] = (uint8_t)(tk.x >> 16);
-                                    if (n > 1u && at + 1u >= o0 && at + 1u < o1) S.ring[(produced0 + at + 1u) & kRingMask] = (uint8_t)(tk.x >> 24);
+                                // Byte x of a run of period dist equals byte p - dist + (x - p) mod dist for any point p of the run at or in front
+                                // of x: p = the run's first byte, or the tile's if the run began in front of it (the dist bytes in front of p
+                                // are bytes of this tile or window history either way).  Pointing there at once keeps the chains of
+                                // overlapping copies one link long.  Long matches are left to a whole wave (their list slots: one atomic per wave).
+                                const bool too_far = match && produced0 < (uint32_t)kHist && dist > produced0 + at;      // reaches before the first output byte
+                                if (too_far) atomicMax(&S.ctrl[C_ERR], (uint32_t)E_DISTANCE);
+                                const bool inside = match && !too_far && !sink && at < o1 && at + len > o0;
+                                const uint32_t p = root > o0 ? root : o0;
+                                const uint32_t x0 = at > o0 ? at : o0, x1 = at + len < o1 ? at + len : o1;      // the bytes of the match inside the tile
+                                const uint32_t q = p - o0 + kHist - dist, since = x0 - p, n = x1 - x0;
+                                const bool is_long = inside && n >= (uint32_t)kLongMin;
+                                const uint64_t longs = __ballot(is_long);
+                                uint32_t slot = kLongCap;
+                                if (longs) {
+                                    const int leader = __builtin_ctzll(longs);
+                                    uint32_t base = 0;
+                                    if (lane_in_wave == leader) base = atomicAdd(&S.ctrl[C_NLONG], (uint32_t)__popcll(longs));
+                                    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+                                    if (is_long) slot = base + (uint32_t)__popcll(longs & ((1ull << lane_in_wave) - 1ull));
+                                }
+                                if (inside) {
+                                    if (slot < (uint32_t)kLongCap) S.longm[slot] = make_uint2((x0 - o0) | n << 15, since | dist << 16);
+                                    else for (uint32_t i = 0, m = since % dist; i < n; ++i) { S.from[x0 - o0 + i] = (uint16_t)(q + m); if (++m == dist) m = 0; }
+                                } else if (!match && !sink) {
+                                    const uint32_t nl = tk.x & 3u;
+                                    if (nl && at >= o0 && at < o1) S.ring[(produced0 + at) & kRingMask] = (uint8_t)(tk.x >> 16);
+                                    if (nl > 1u && at + 1u >= o0 && at + 1u < o1) S.ring[(produced0 + at + 1u) & kRingMask] = (uint8_t)(tk.x >> 24);
                                 }
                             }
                         }

@@ -79,7 +79,7 @@ enum : uint32_t { ST_DONE = 1, ST_IN_BLOCK = 2, ST_VALID = 4 };
 #define INFLATE_PROFILE 0
 #endif
 enum { P_HEADER = 0, P_TABLES, P_WINDOW, P_SWEEP0, P_SWEEPS, P_SCAN, P_WRITE, P_MATCH, P_FLUSH, P_STORED,
-       P_H_FIELDS, P_H_CODE, P_H_WALKS, P_H_EMIT, P_T_RANKS, P_T_STARTS, P_T_SORT, P_T_LIT, P_T_DIST, P_T_LONG, P_F_SETUP, P_F_INIT,
+       P_H_FIELDS, P_H_CODE, P_H_WALKS, P_H_EMIT, P_T_RANKS, P_T_STARTS, P_T_SORT, P_T_LIT, P_T_DIST, P_T_LONG, P_F_SETUP, P_F_INIT, P_S_DETECT, P_R_EXPAND, P_R_INIT, P_R_ROUNDS, P_S_TURN1,
        P_N_BLOCKS, P_N_CHUNKS, P_N_SWEEPS, P_N_ROUNDS, P_N_MATCHES, P_N };
 #if INFLATE_PROFILE
 __device__ unsigned long long g_inflate_prof[P_N];
@@ -410,7 +410,7 @@ __device__ __forceinline__ void expand_long_matches(Shared& S)
 // doubling first: a byte whose source is neither adopts its source's source.  A thread looks at 8 neighbouring bytes (one
 // 16-byte read of their entries) and remembers which of them are settled.  Then one pass moves the values.
 __device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) { uint32_t r; asm("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ int resolve_copies(Shared& S, uint32_t cs, uint32_t total)      // -> rounds taken
+__device__ __forceinline__ int resolve_copies(Shared& S, uint32_t cs, uint32_t total, Prof& prof)      // -> rounds taken
 {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     constexpr int kUnits = (kNewMax / 8 + kT - 1) / kT;           // 8-byte units per thread
@@ -428,6 +428,7 @@ __device__ __forceinline__ int resolve_copies(Shared& S, uint32_t cs, uint32_t t
         #pragma unroll
         for (int i = 0; i < 8; ++i) if (j0 + i < total && p[i] >= (uint32_t)kHist && p[i] != self0 + i) open[k] |= 1u << i;
     }
+    PROF(P_R_INIT);
     // Three flags in turn say "somebody still has work": round r raises flag r % 3 and thread 0 clears the next one, which was last
     // read behind the barrier of round r - 2 (every thread has passed the barrier of round r - 1 since).
     int round = 0;
@@ -465,6 +466,7 @@ __device__ __forceinline__ int resolve_copies(Shared& S, uint32_t cs, uint32_t t
         if (!S.ctrl[C_OPEN0 + round % 3]) break;
     }
     __syncthreads();
+    PROF(P_R_ROUNDS);
     // values: every source is a literal of the tile or a byte of the window.  Positions are 16-bit and the ring is 65 536 bytes: ring
     // addresses are packed 16-bit sums.  A literal "copies" itself (no test per byte; bytes of the last unit beyond the tile too: they
     // are ring bytes older than the window).
@@ -854,6 +856,7 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                     const uint64_t stopped = __ballot((mine >> 24) != 0 && (uint32_t)t <= first_stop && (uint32_t)t < last_lane);
                     if (stopped && lane_in_wave == 0) atomicMin(&S.ctrl[C_STOP0 + slot], (uint32_t)(wave * 64) + (uint32_t)__builtin_ctzll(stopped));
                     __syncthreads();
+                    PROF(P_S_DETECT);
                     const uint32_t njobs = S.ctrl[C_JOBS0 + slot], stop_now = S.ctrl[C_STOP0 + slot];
                     // settled: nobody has to walk, and the lanes that were held back this turn are the ones that will be held back for good
                     // (a stop that has just dissolved, or moved, lets other lanes speak up next turn)
@@ -874,6 +877,8 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                         S.lane_map[lane] = make_uint4((uint32_t)J.first, (uint32_t)(J.first >> 32), (uint32_t)J.count, (uint32_t)(J.count >> 32));
                     }
                     __syncthreads();
+                    PROF(turn == 0 ? P_S_TURN1 : P_SWEEPS);
+                    PROF_COUNT(P_N_MATCHES, njobs);
                 }
                 if (err) break;
                 { const uint4 m = S.lane_map[t]; L.start = S.lane_start[t]; L.first = (uint64_t)m.y << 32 | m.x; L.count = (uint64_t)m.w << 32 | m.z; }
@@ -1007,7 +1012,8 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
                     if (!sink && !err) {
                         expand_long_matches(S);
                         __syncthreads();
-                        { const int rounds = resolve_copies(S, produced, total); (void)rounds; PROF_COUNT(P_N_ROUNDS, rounds); }
+                        PROF(P_R_EXPAND);
+                        { const int rounds = resolve_copies(S, produced, total, prof); (void)rounds; PROF_COUNT(P_N_ROUNDS, rounds); }
                         __syncthreads();
                         PROF(P_MATCH);
                         flush(produced, total);

@@ -20,8 +20,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import gen  # noqa: E402
 from gamut_amd import _capi  # noqa: E402
 
-PHASES = ["header", "tables", "window", "sweep0", "sweeps", "scan", "emit", "resolve", "flush", "fill", "h:fields", "h:code", "h:walks", "h:emit", "t:ranks", "t:starts", "t:sort", "t:lit", "t:dist", "t:long", "f:setup", "f:init", "#blocks", "#rounds", "#turns", "#doublings", "#matches"]
-NPH = 22
+PHASES = ["header", "tables", "window", "sweep0", "sweeps", "scan", "emit", "resolve", "flush", "fill", "h:fields", "h:code", "h:walks", "h:emit", "t:ranks", "t:starts", "t:sort", "t:lit", "t:dist", "t:long", "f:setup", "f:init", "s:detect", "r:expand", "r:init", "r:rounds", "s:turn1", "#blocks", "#rounds", "#turns", "#doublings", "#jobs"]
+NPH = 27
 
 
 def idat(png):

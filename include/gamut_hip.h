@@ -303,7 +303,7 @@ int gamut_hip_png_read_header(const uint8_t* data, size_t len, gamut_hip_png_inf
  * threads (<= 0: one per hardware thread; the inflate is what bounds a PNG pipeline), the inflated streams going to the
  * device as they finish; then the rest of stbi__do_png on the GPU -- files that only need de-filter + expand are
  * de-filtered together, one launch per geometry (one workgroup per image), the others stage by stage per file.  Batches of
- * at least three files per host thread inflate on the GPU instead (gamut_hip_inflate_batch_device: the threads then only walk
+ * more files than host threads inflate on the GPU instead (gamut_hip_inflate_batch_device: the threads then only walk
  * the chunks and gather the IDAT bytes for one upload); the environment variable GAMUT_HIP_PNG_INFLATE=host / device forces
  * either.  req_comp as in stbi_load (0 = as in the file), bits = 8 / 16 as stbi_load / stbi_load_16 convert, 0 = as
  * in the file.  info[i] / status_host[i] (may be NULL) per file; returns the status of the lowest-numbered failing file. */

@@ -408,7 +408,7 @@ def test_files_written_by_libpng(hip):
 
 def test_png_file_batch_of_libpng_files_inflates_on_the_device(hip):
     """48 files from a real encoder (Pillow / libpng, levels 1 / 6 / 9, RGB / RGBA / grey / 16-bit / palette / Adam7) in one
-    batch on one host thread: large enough for the batch to pick the device inflate by itself (>= 3 files per thread); == the oracle's stbi_load per file.  One file has
+    batch on one host thread: large enough for the batch to pick the device inflate by itself (more files than threads); == the oracle's stbi_load per file.  One file has
     a damaged IDAT stream, one a bad zlib header: both are reported, the others decode."""
     import io
     from PIL import Image

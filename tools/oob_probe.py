@@ -135,6 +135,32 @@ def convert_cases(extra_rows=0):
     return n
 
 
+
+def inflate_cases():
+    """DEFLATE streams that end with their allocation, outputs that end with theirs (capacity == size, capacity < size), at once and in
+    slices (a sliced launch may read up to the bytes it was promised, never behind the stream)"""
+    import zlib
+    rng = np.random.default_rng(8)
+    n = 0
+    datas = [rng.integers(0, 256, 300000, dtype=np.uint8).tobytes(), (rng.integers(0, 8, 900000, dtype=np.uint8) * 9).tobytes(), bytes(700000),
+             b"abc" * 100000 + rng.integers(0, 256, 70000, dtype=np.uint8).tobytes(), b"x"]
+    for data in datas:
+        for level in (0, 1, 6):
+            co = zlib.compressobj(level, zlib.DEFLATED, -15); st = co.compress(data) + co.flush()
+            for cap in (len(data), max(1, len(data) // 3)):
+                for slice_bytes in (0, 40000):
+                    dsrc = up_end(np.frombuffer(st, np.uint8)); ddst = at_end(cap); dlen = at_end(4, 4); dstat = at_end(4, 4)
+                    desc = (_capi.InflateDesc * 1)()
+                    desc[0].src = dsrc; desc[0].dst = ddst; desc[0].src_len = len(st); desc[0].dst_cap = cap
+                    if slice_bytes: _capi.check(L.gamut_hip_inflate_batch_device_sliced(desc, 1, dlen, dstat, slice_bytes, None))
+                    else: _capi.check(L.gamut_hip_inflate_batch_device(desc, 1, dlen, dstat, None))
+                    _capi.check(L.gamut_hip_stream_synchronize(None))
+                    got = np.empty(cap, np.uint8); _capi.check(L.gamut_hip_memcpy_d2h(got.ctypes.data, ddst, cap, None)); _capi.check(L.gamut_hip_stream_synchronize(None))
+                    assert got.tobytes() == data[:cap], (len(data), level, cap, slice_bytes)
+                    free_all(); n += 1
+    return n
+
+
 def batch_cases():
     """count > 1 with tight strides; JPEG with max_zag; QOI files resident in HBM; baseline files through the device entropy decoder"""
     import glob
@@ -211,5 +237,6 @@ print("png", png_cases(), "cases ok", flush=True)
 print("jpeg", jpeg_cases(), "cases ok", flush=True)
 print("convert", convert_cases(), "cases ok", flush=True)
 print("batch / qoi / entropy", batch_cases(), "cases ok", flush=True)
+print("inflate", inflate_cases(), "cases ok", flush=True)
 print("random geometries", random_cases(), "cases ok", flush=True)
 print("oob_probe: no access outside any buffer")

@@ -577,7 +577,12 @@ int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* 
                 uint32_t* d_verdict = (uint32_t*)verdict_dev.get(n * 8);
                 if (!d_verdict) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png: verdict table allocation failed");
                 std::vector<uint32_t> verdict(n * 2);
-                uint32_t slice = longest >= (8u << 20) ? 1u << 20 : 1u << 19;       // (measured: 4K files of 12 MB 100 ms with 1 MiB slices, 127 with 512 KiB; of 3.6 MB 60 / 57 ms); at most 32 launches
+                // 1 MiB slices; 512 KiB for up to 256 well-compressed large images, where a stream inflates more slowly than it arrives
+                // (measured, 256 files: 4K of 12 MB 100 ms with 1 MiB slices, 127 with 512 KiB; 4K of 3.6 MB 60 / 57 ms; 1080p of 3.1 MB
+                // 33 / 36 ms; 1024 files of 1080p 118 / 132 ms); at most 32 launches
+                int64_t largest_out = 0;
+                for (int i : who) largest_out = std::max(largest_out, slot_bytes[(size_t)i]);
+                uint32_t slice = (longest < (8u << 20) && n <= 256 && largest_out >= (16 << 20)) ? 1u << 19 : 1u << 20;
                 if (const char* v = getenv("GAMUT_HIP_PNG_SLICE_KB")) { const long kb = atol(v); if (kb >= 64 && kb <= (1 << 20)) slice = (uint32_t)kb << 10; }      // (tuning)
                 while ((uint64_t)slice * 32u < longest) slice *= 2;
                 const int rounds = longest ? (int)(((uint64_t)longest + slice - 1) / slice) : 1;

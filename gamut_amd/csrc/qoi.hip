@@ -707,21 +707,54 @@ int decode_batch(const uint8_t* const* data, const int* size, int count, int cha
         int dev = 0;
         GAMUT_HIP_CHECK(hipGetDevice(&dev));
         std::atomic<int> upload_failed{ 0 };
-        parallel_for((int)items.size(), workers, [&](int, int k) {
-            (void)hipSetDevice(dev);
-            const size_t at = o_blob + items[(size_t)k].begin, n = (size_t)items[(size_t)k].size + kQoiSlack;
-            memcpy(h + at, data[src[(size_t)k]], items[(size_t)k].size);
-            memset(h + at + items[(size_t)k].size, 0, kQoiSlack);
-            if (hipMemcpyAsync(d + at, h + at, n, hipMemcpyHostToDevice, stream) != hipSuccess) { (void)hipGetLastError(); upload_failed = 1; }
-        });
-        if (upload_failed) return set_error(GAMUT_HIP_ERR_HIP, "qoi: upload failed");
         memcpy(h, items.data(), items.size() * sizeof(QoiItem));
         GAMUT_HIP_CHECK(hipMemcpyAsync(d, h, items.size() * sizeof(QoiItem), hipMemcpyHostToDevice, stream));
         const int n = (int)items.size();
-        if (n < kQoiWideBelow && qoi_pipeline(n)) hipLaunchKernelGGL(k_qoi_pipe, dim3(n), dim3(320), 0, stream, (const QoiItem*)d, n, (const uint8_t*)(d + o_blob), d_out);
-        else if (n < kQoiWideBelow) hipLaunchKernelGGL(k_qoi_decode<4>, dim3(n), dim3(256), 0, stream, (const QoiItem*)d, n, (const uint8_t*)(d + o_blob), d_out);
-        else                   hipLaunchKernelGGL(k_qoi_decode<1>, dim3(n), dim3(64), 0, stream, (const QoiItem*)d, n, (const uint8_t*)(d + o_blob), d_out);
-        if (int rc = launch_status("qoi_decode")) return rc;
+        auto launch = [&](int g0, int cnt, hipStream_t s) {
+            const QoiItem* its = reinterpret_cast<const QoiItem*>(d) + g0;
+            if (cnt < kQoiWideBelow && qoi_pipeline(cnt)) hipLaunchKernelGGL(k_qoi_pipe, dim3(cnt), dim3(320), 0, s, its, cnt, (const uint8_t*)(d + o_blob), d_out);
+            else if (cnt < kQoiWideBelow) hipLaunchKernelGGL(k_qoi_decode<4>, dim3(cnt), dim3(256), 0, s, its, cnt, (const uint8_t*)(d + o_blob), d_out);
+            else                     hipLaunchKernelGGL(k_qoi_decode<1>, dim3(cnt), dim3(64), 0, s, its, cnt, (const uint8_t*)(d + o_blob), d_out);
+        };
+        auto upload = [&](int k0, int k1, hipStream_t s) {
+            parallel_for(k1 - k0, workers, [&](int, int j) {
+                (void)hipSetDevice(dev);
+                const int k = k0 + j;
+                const size_t at = o_blob + items[(size_t)k].begin, nb = (size_t)items[(size_t)k].size + kQoiSlack;
+                memcpy(h + at, data[src[(size_t)k]], items[(size_t)k].size);
+                memset(h + at + items[(size_t)k].size, 0, kQoiSlack);
+                if (hipMemcpyAsync(d + at, h + at, nb, hipMemcpyHostToDevice, s) != hipSuccess) { (void)hipGetLastError(); upload_failed = 1; }
+            });
+        };
+        constexpr int kGroup = 256;                             // one workgroup per compute unit: the shape k_qoi_pipe is quickest at (a stream ~ 12 ms)
+        if (n <= kGroup) {
+            upload(0, n, stream);
+            if (upload_failed) return set_error(GAMUT_HIP_ERR_HIP, "qoi: upload failed");
+            launch(0, n, stream);
+            if (int rc = launch_status("qoi_decode")) return rc;
+        } else {
+            // A large batch is PCIe time (a 1080p file is 4-8 MB): the files go up group by group on a copy stream and every group is
+            // decoded behind its own upload, beside the upload of the next one -- the kernels hide behind the copies except the last.
+            static thread_local PerDevice<hipStream_t> copy_pd;
+            hipStream_t& copy_stream = copy_pd.cur();
+            if (!copy_stream) GAMUT_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+            std::vector<hipEvent_t> up;
+            int rc = GAMUT_HIP_OK;
+            for (int g0 = 0; g0 < n && rc == GAMUT_HIP_OK; g0 += kGroup) {
+                const int cnt = n - g0 < kGroup ? n - g0 : kGroup;
+                upload(g0, g0 + cnt, copy_stream);
+                hipEvent_t e = nullptr;
+                if (upload_failed || hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); rc = set_error(GAMUT_HIP_ERR_HIP, "qoi: upload failed"); break; }
+                up.push_back(e);
+                if (hipEventRecord(e, copy_stream) != hipSuccess || hipStreamWaitEvent(stream, e, 0) != hipSuccess) { (void)hipGetLastError(); rc = set_error(GAMUT_HIP_ERR_HIP, "qoi: event failed"); break; }
+                launch(g0, cnt, stream);
+                rc = launch_status("qoi_decode");
+            }
+            (void)hipStreamSynchronize(copy_stream);
+            (void)hipStreamSynchronize(stream);
+            for (hipEvent_t e : up) (void)hipEventDestroy(e);
+            if (rc != GAMUT_HIP_OK) return rc;
+        }
         GAMUT_HIP_CHECK(hipStreamSynchronize(stream));         // the per-thread staging buffers are reused by the next call
     }
     if (first != GAMUT_HIP_OK) return set_error(first, "image %d: qoi: bad header or arguments", first_idx);

@@ -140,8 +140,10 @@ def test_qoi_arbitrary_streams(hip, small_batch_kernel):
             assert np.array_equal(host[offs[i]:offs[i] + nbytes[i]], exp[i]), (reps, i % len(files))
 
 
-def test_qoi_large_batch_takes_the_one_wave_kernel(hip):
-    """>= 768 streams in one call run one wave per stream (k_qoi_decode<1>); same pixels as the oracle, rgba and rgb outputs"""
+def test_qoi_large_batches(hip):
+    """800 streams in one call.  From host memory (gamut_hip_qoi_decode_batch_device) the files go up in groups of 256 on a copy stream and
+    every group is decoded behind its own upload; resident in HBM (gamut_hip_qoi_decode_resident_device) >= 768 streams run one wave per
+    stream (k_qoi_decode<1>).  Same pixels as the oracle either way, rgba and rgb outputs."""
     rng = np.random.default_rng(9)
     imgs = []
     for k in range(16):
@@ -161,13 +163,29 @@ def test_qoi_large_batch_takes_the_one_wave_kernel(hip):
         offs = np.concatenate([[0], np.cumsum(nbytes)[:-1]]).astype(np.int64)
         dout = hip.gamut_hip_device_malloc(int(sum(nbytes)) + 64)
         descs = (_capi.QoiDesc * n)(); st = (C.c_int * n)()
-        _capi.check(hip.gamut_hip_qoi_decode_batch_device(ptrs, sizes, n, ch, offs.ctypes.data_as(C.POINTER(C.c_int64)), dout, descs, st, None))
         host = np.empty(int(sum(nbytes)), np.uint8)
-        _capi.check(hip.gamut_hip_memcpy_d2h(host.ctypes.data, dout, host.nbytes, None))
-        _capi.check(hip.gamut_hip_stream_synchronize(None))
+        for resident in (False, True):
+            _capi.check(hip.gamut_hip_memcpy_h2d(dout, np.full(host.size, 0x5A, np.uint8).ctypes.data, host.size, None))
+            if not resident:
+                _capi.check(hip.gamut_hip_qoi_decode_batch_device(ptrs, sizes, n, ch, offs.ctypes.data_as(C.POINTER(C.c_int64)), dout, descs, st, None))
+            else:
+                begin, pos, parts = [], 0, []
+                for i in pick:
+                    begin.append(pos); parts += [files[i], bytes(160)]; pos += len(files[i]) + 160
+                hblob = np.frombuffer(b"".join(parts), np.uint8).copy()
+                blob = hip.gamut_hip_device_malloc(hblob.size)
+                _capi.check(hip.gamut_hip_memcpy_h2d(blob, hblob.ctypes.data, hblob.size, None))
+                b = np.array(begin, np.int64); sz = np.array([len(files[i]) for i in pick], np.int32)
+                _capi.check(hip.gamut_hip_stream_synchronize(None))
+                _capi.check(hip.gamut_hip_qoi_decode_resident_device(blob, hblob.size, b.ctypes.data_as(C.POINTER(C.c_int64)), sz.ctypes.data_as(C.POINTER(C.c_int)), descs, n, ch,
+                                                                      offs.ctypes.data_as(C.POINTER(C.c_int64)), dout, None))
+            _capi.check(hip.gamut_hip_memcpy_d2h(host.ctypes.data, dout, host.nbytes, None))
+            _capi.check(hip.gamut_hip_stream_synchronize(None))
+            if resident:
+                hip.gamut_hip_device_free(blob)
+            for k in range(n):
+                assert np.array_equal(host[offs[k]:offs[k] + nbytes[k]], exp[pick[k]]), (ch, resident, k)
         hip.gamut_hip_device_free(dout)
-        for k in range(n):
-            assert np.array_equal(host[offs[k]:offs[k] + nbytes[k]], exp[pick[k]]), (ch, k)
 
 
 def test_image_load_qoi(hip):

@@ -8,6 +8,7 @@
 // the GPU: de-filter / expand (png.hip), Adam7 scatter, tRNS, palette, channel and depth
 // conversion, in the order of finalize_decode (:1821-1857) and stbi__do_png (:2025-2055).
 #include "common.hpp"
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <map>
@@ -564,10 +565,12 @@ int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* 
             const auto t_inf = std::chrono::steady_clock::now();
             std::vector<gamut_hip_inflate_desc> descs; std::vector<int> who;
             uint32_t longest = 0;
-            for (int i = 0; i < count; ++i) {
-                if (files[(size_t)i].rc != GAMUT_HIP_OK) continue;
+            for (int i = 0; i < count; ++i) if (files[(size_t)i].rc == GAMUT_HIP_OK) who.push_back(i);
+            // longest streams first: a stream is one workgroup for its whole length, and workgroups start in the order of the list -- with
+            // more streams than compute units the long ones must not be the ones that start last
+            std::stable_sort(who.begin(), who.end(), [&](int a, int b) { return idat_len[(size_t)a] > idat_len[(size_t)b]; });
+            for (int i : who) {
                 descs.push_back(gamut_hip_inflate_desc{ d_blob + blob_off[(size_t)i], d_arena + slot[(size_t)i], idat_len[(size_t)i], (uint32_t)slot_bytes[(size_t)i] });
-                who.push_back(i);
                 longest = idat_len[(size_t)i] > longest ? idat_len[(size_t)i] : longest;
             }
             if (!descs.empty()) {

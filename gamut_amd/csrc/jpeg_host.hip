@@ -845,6 +845,19 @@ __device__ __forceinline__ bool sub_decode(const SubCtx& x, SubState& s, int& nb
 // NH: Huffman / quantisation tables kept in LDS (0 = none: read from global memory).  A batch written by one encoder has four
 // Huffman tables; with room for four instead of eight a workgroup needs 47 KB instead of 58, and a compute unit holds three of
 // them instead of two -- the kernel is a chain of dependent operations per lane, what it lacks is waves to alternate with.
+#ifndef JPEG_SYNC_PROFILE           // measurement only (tools/variant.sh jpeg_host:jprof:-DJPEG_SYNC_PROFILE=1, tools/jpeg_sync_prof.py): cycles per phase, thread 0's clock
+#define JPEG_SYNC_PROFILE 0
+#endif
+#if JPEG_SYNC_PROFILE
+__device__ unsigned long long g_sync_prof[8];
+#define SPROF_DECL unsigned long long sp_t0 = clock64()
+#define SPROF(slot) do { const unsigned long long now_ = clock64(); if (threadIdx.x == 0) atomicAdd(&g_sync_prof[slot], now_ - sp_t0); sp_t0 = now_; } while (0)
+#define SPROF_COUNT(slot, n) do { if (threadIdx.x == 0) atomicAdd(&g_sync_prof[slot], (unsigned long long)(n)); } while (0)
+#else
+#define SPROF_DECL
+#define SPROF(slot)
+#define SPROF_COUNT(slot, n)
+#endif
 template <int NH>
 __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevItem* items, const DevImage* images,
                                                                     const DevHuff* huff_g, int n_huff, const int16_t* quant_g, int n_quant,
@@ -868,6 +881,7 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevIte
         #pragma unroll
         for (int i = 0; i < 8; ++i) zb[i] = make_uint4(0, 0, 0, 0);
     }
+    SPROF_DECL;
     const DevItem it = items[blockIdx.x];
     const DevImage im = images[it.image];
     if (t == 0) {
@@ -900,6 +914,7 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevIte
     }
     exit_state[t] = mine;
     __syncthreads();
+    SPROF(0);
     // sweeps 1..: from the predecessor's exit state, until nothing moves
     bool settled = false;
     for (int sweep = 0; sweep < kSyncThreads + 1; ++sweep) {
@@ -916,8 +931,10 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevIte
         const int any = changed;
         __syncthreads();
         if (t == 0) changed = 0;
+        SPROF_COUNT(6, 1);
         if (!any) { settled = true; break; }
     }
+    SPROF(1);
     (void)settled;                                              // the loop bound (one lane settles per sweep at worst) always reaches the fixed point
     // exclusive prefix sums over the lanes: first block and DC predictors of every lane
     scan[0][t] = active ? nblk : 0; scan[1][t] = active ? dcs[0] : 0; scan[2][t] = active ? dcs[1] : 0; scan[3][t] = active ? dcs[2] : 0;
@@ -935,6 +952,7 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevIte
     const int pred_in[3] = { scan[1][t] - dcs[0], scan[2][t] - dcs[1], scan[3][t] - dcs[2] };
     const int64_t finished = scan[0][kSyncThreads - 1];
     __syncthreads();                                            // everybody has its prefix sums: the area is the staging area again
+    SPROF(2);
     {                                                           // the checkpoints are done with: the staging area starts out zero
         uint4* zb = reinterpret_cast<uint4*>(sh_blk + t * 144);
         #pragma unroll
@@ -948,6 +966,7 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevIte
     }
     __threadfence();                                            // the lines are on their way before anybody adds single coefficients to them
     __syncthreads();
+    SPROF(3);
     if (active && entry.z > 0 && b0 < total_blocks) {           // the rest of the block this lane found half-decoded
         int pred[3] = { 0, 0, 0 }; SubState s = entry; int n3 = 0;
         sub_decode<SUB_FIRST>(x, s, n3, pred, b0, total_blocks, out, mz);
@@ -960,6 +979,8 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevIte
         for (int i = 0; i < 8; ++i) dst[i] = make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
+    SPROF(4);
+    SPROF_COUNT(7, 1);
     if (t == 0 && failed) atomicOr(status + it.image, 1u);
 }
 
@@ -1304,6 +1325,14 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
 
 using namespace gamut;
 
+#if JPEG_SYNC_PROFILE
+extern "C" int gamut_hip_jpeg_sync_profile(unsigned long long* out8, int reset)      // measurement builds only
+{
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_sync_prof), 64) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_sync_prof), z, 64) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 extern "C" {
 
 int gamut_hip_jpeg_decode_coeffs(const uint8_t* data, size_t len, gamut_hip_jpeg_frame* out)

@@ -12,3 +12,7 @@ mkdir -p gpurun_out/summary_r03_qoi
 python bench.py --workload mixed --total-images 8192 --steps 10 --warmup 3 --no-cpu > gpurun_out/summary_r03_qoi/mixed_8192_bench.json 2>/dev/null
 bash tools/pmc_valu.sh > gpurun_out/summary_r03_pmc_valu.txt 2>&1
 (time python bench.py) > gpurun_out/r03_bench_default.log 2>&1
+# the feeders: the inflate kernel's own set, files -> pixels for the three formats
+bash tools/inflate_profile.sh > gpurun_out/inflate_profile.log 2>&1
+python tools/files_bench.py > gpurun_out/r03_files_bench.jsonl 2>/dev/null
+python tools/e2e_mixed_bench.py --batch 768 > gpurun_out/r03_mixed_e2e.txt 2>&1; python tools/e2e_mixed_bench.py --batch 3072 >> gpurun_out/r03_mixed_e2e.txt 2>&1

@@ -53,6 +53,18 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores():
+    """cores this process may use: the affinity mask, capped by a cgroup CPU quota (the GPU box: 256 threads visible, quota 16)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def traffic_from_profiles(workload, kernel_substr):
     """HBM bytes per image from the committed rocprofv3 --pmc summary of THIS workload (profiles/<tag>_bench.json names the
     workload, <tag>_traffic.json holds the counters), or None when the workload has not been profiled."""
@@ -149,7 +161,7 @@ def also_lines(budget_s):
             j = json.loads(line[-1])
             e = {"what": what, "workload": j["config"]["workload"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
                  "roofline_frac": j["roofline"]["frac"], "achieved_GB/s": j["roofline"]["achieved"], "kernel": j["roofline"]["kernel"],
-                 "kernel_ms_avg": j["roofline"]["kernel_ms_avg"], "parity": "ok (checked against the oracle before timing)", "steps": j["steps"],
+                 "kernel_ms_avg": j["roofline"]["kernel_ms_avg"], "parity": "ok: " + str(j["config"].get("parity_check", "checked against the oracle before timing")), "steps": j["steps"],
                  "wall_s": round(time.perf_counter() - t0, 1)}
             for k in ("per_format", "waves_on_sparse_luma_passes", "y_blocks_max_zag_le_10"):
                 if k in j["config"]:
@@ -228,6 +240,7 @@ def main():
     w, h, B = args.width or 1920, args.height or 1080, args.batch
     wl = args.workload
     check = None
+    check_note = {}                                              # what check() compared, for the JSON line
     _host = {}                                                   # host copies of the cpu_baseline sample (made once, shared by the threads)
     if wl == "jpeg" or wl.startswith("jpeg:"):
         jp = wl.split(":")                                       # jpeg[:out_comps[:scan_type]]  |  jpeg:photo[:out_comps]
@@ -286,19 +299,31 @@ def main():
                                                                    h * w * oc, w, h, st, oc, B, stream))
 
         def check():
+            """EVERY image of the batch against the oracle (the oracle is C behind ctypes, which releases the GIL: one image per host
+            thread at a time, ~1.5-3 s for 1024 frames on the GPU box's 16-core quota)."""
             import oracle_lib as O
+            from concurrent.futures import ThreadPoolExecutor
             step()
             torch.cuda.synchronize()
-            for i in sorted({0, B - 1}):
-                exp = O.jpeg_reconstruct(w, h, comps_in, st, coeffs[i].cpu().numpy(), zag[i].cpu().numpy(), oc)
-                if not np.array_equal(out[i].cpu().numpy(), exp):
-                    raise SystemExit(f"PARITY FAILURE on image {i}")
-                if photo:                                        # the whole file through the oracle's own decoder: entropy decode included
+
+            def one(i):
+                co, zz = coeffs[i].cpu().numpy(), zag[i].cpu().numpy()
+                got = out[i].cpu().numpy()
+                if not np.array_equal(got, O.jpeg_reconstruct(w, h, comps_in, st, co, zz, oc)):
+                    return f"PARITY FAILURE on image {i}"
+                if photo and i < 2 * len(files):                 # the whole file through the oracle's own decoder: entropy decode included
                     d = O.DecodedJpeg(bytes(files[i % len(files)]))
-                    if not (np.array_equal(d.coeffs, coeffs[i].cpu().numpy()) and np.array_equal(d.max_zag, zag[i].cpu().numpy())):
-                        raise SystemExit(f"PARITY FAILURE (coefficients / max_zag of file {i})")
-                    if oc == 4 and not np.array_equal(out[i].cpu().numpy(), O.decompress_jpeg(bytes(files[i % len(files)]), 4)[0]):
-                        raise SystemExit(f"PARITY FAILURE (file {i} vs decompress_jpeg)")
+                    if not (np.array_equal(d.coeffs, co) and np.array_equal(d.max_zag, zz)):
+                        return f"PARITY FAILURE (coefficients / max_zag of file {i})"
+                    if oc == 4 and not np.array_equal(got, O.decompress_jpeg(bytes(files[i % len(files)]), 4)[0]):
+                        return f"PARITY FAILURE (file {i} vs decompress_jpeg)"
+                return None
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(host_cores()) as pool:
+                bad = [r for r in pool.map(one, range(B)) if r]
+            if bad:
+                raise SystemExit(bad[0] + (f" (+ {len(bad) - 1} more)" if len(bad) > 1 else ""))
+            check_note["checked"] = f"all {B} images == oracle, {time.perf_counter() - t0:.1f} s on {host_cores()} host threads"
 
         def cpu_leg(seconds):
             import oracle_lib as O
@@ -345,15 +370,27 @@ def main():
                                                                   w, h, min(R, B - c), stream))
 
         def check():
+            """whole layers against the oracle: the first, the middle and the last resident layer (the last one the step's final launch
+            converted), every row of each, in bands of 128 rows on the host threads"""
+            from concurrent.futures import ThreadPoolExecutor
             step()
             torch.cuda.synchronize()
-            rows = 4
+            rows = 128
             last = (B - 1) % R if B % R else R - 1                     # a layer the step's last launch converted
-            for layer, r0 in ((0, 0), (last, 0), (last, h - rows), (R // 2, h // 2)):      # first / last rows, first / middle / last resident layer
-                a = src[layer].view(torch.uint8)[r0 * sp:(r0 + rows) * sp].cpu().numpy()
-                exp = O.scanlines_convert(st, a, dt_, w, rows)
-                if not np.array_equal(out[layer][r0 * dp:(r0 + rows) * dp].cpu().numpy(), exp):
-                    raise SystemExit(f"PARITY FAILURE (layer {layer}, rows {r0}..)")
+            layers = sorted({0, R // 2, last})
+
+            def one(job):
+                layer, r0 = job
+                n = min(rows, h - r0)
+                a = src[layer].view(torch.uint8)[r0 * sp:(r0 + n) * sp].cpu().numpy()
+                exp = O.scanlines_convert(st, a, dt_, w, n)
+                return None if np.array_equal(out[layer][r0 * dp:(r0 + n) * dp].cpu().numpy(), exp) else f"PARITY FAILURE (layer {layer}, rows {r0}..)"
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(host_cores()) as pool:
+                bad = [r for r in pool.map(one, [(l, r0) for l in layers for r0 in range(0, h, rows)]) if r]
+            if bad:
+                raise SystemExit(bad[0])
+            check_note["checked"] = f"layers {layers} of the {R} resident ones, every row == oracle, {time.perf_counter() - t0:.1f} s"
 
         def cpu_leg(seconds):
             rows = 256
@@ -400,10 +437,17 @@ def main():
             got = out.view(B, -1).to(torch.int64).sum(dim=1) if B <= 64 else torch.stack([out[i].to(torch.int64).sum() for i in range(B)])
             if not torch.equal(got, sums + (on - ch) * 255 * w * h):           # inserted alpha = 255
                 raise SystemExit("PARITY FAILURE: checksum of de-filtered pixels != checksum of the source pixels")
-            for i in sorted({0, B // 3, (2 * B) // 3, B - 1}):          # the checksums cover every image, the oracle four of them byte for byte
+            from concurrent.futures import ThreadPoolExecutor
+
+            def one(i):                                         # every image byte for byte against the oracle, on the host threads
                 exp = O.png_create_image_raw(raw[i].cpu().numpy(), ch, on, w, h, 8, {1: 0, 2: 4, 3: 2, 4: 6}[ch])
-                if not np.array_equal(out[i].cpu().numpy(), exp):
-                    raise SystemExit(f"PARITY FAILURE vs oracle on image {i}")
+                return None if np.array_equal(out[i].cpu().numpy(), exp) else f"PARITY FAILURE vs oracle on image {i}"
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(host_cores()) as pool:
+                bad = [r for r in pool.map(one, range(B)) if r]
+            if bad:
+                raise SystemExit(bad[0])
+            check_note["checked"] = f"all {B} images == oracle byte for byte (+ checksum of the source pixels), {time.perf_counter() - t0:.1f} s"
 
         def cpu_leg(seconds):
             if "h" not in _host:
@@ -501,13 +545,23 @@ def main():
                 exp = O.png_create_image_raw(raw[npn - 1].cpu().numpy(), 4, 4, w, h, 8, 6)
                 if not np.array_equal(out[3 * (npn - 1) + 1].cpu().numpy(), exp):
                     raise SystemExit("PARITY FAILURE (PNG)")
-            if nq:
-                got = out[3 * (nq - 1) + 2].cpu().numpy().reshape(h, w, 4)
-                if not (np.array_equal(got[:, :, :3], rgb[(nq - 1) % nd]) and (got[:, :, 3] == 255).all()):
+            for k in sorted(set(range(min(nd, nq))) | ({nq - 1} if nq else set())):      # every distinct file once (+ the last image)
+                got = out[3 * k + 2].cpu().numpy().reshape(h, w, 4)
+                if not (np.array_equal(got[:, :, :3], rgb[k % nd]) and (got[:, :, 3] == 255).all()):
                     raise SystemExit("PARITY FAILURE (QOI)")
-                exp, _, _ = O.qoi_decode(files[(nq - 1) % nd], 4)
+                exp, _, _ = O.qoi_decode(files[k % nd], 4)
                 if not np.array_equal(got.reshape(exp.shape), exp):
                     raise SystemExit("PARITY FAILURE (QOI vs oracle)")
+            # every image of the step: JPEG / PNG checksums against the checked ones' generators are not available, so compare the
+            # images that share an input (QOI files repeat every nd) and the PNG source checksums
+            if npn:
+                got = torch.stack([out[3 * i + 1].to(torch.int64).sum() for i in range(npn)])
+                if not torch.equal(got, sums):
+                    raise SystemExit("PARITY FAILURE (PNG checksums)")
+            for i in range(nq):
+                if i >= nd and not torch.equal(out[3 * i + 2], out[3 * (i % nd) + 2]):
+                    raise SystemExit(f"PARITY FAILURE (QOI image {i} != its twin {i % nd})")
+            check_note["checked"] = "last image of each format == oracle; every PNG == its source checksum; every QOI image == the oracle-checked twin of its file"
 
         def cpu_leg(seconds):
             if "h" not in _host:
@@ -602,7 +656,9 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong" if (wl == "mixed" and args.batch == 1024 and args.total_images) else "weak", "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
-            "config": dict({"workload": workload, "images_per_gpu_per_step": B, "sharding": "image-index, no collective"}, **(zstat if wl.startswith("jpeg") else {})),
+            "config": dict({"workload": workload, "images_per_gpu_per_step": B, "sharding": "image-index, no collective",
+                            "parity_check": check_note.get("checked", "see check() of this workload" if not os.environ.get("GAMUT_BENCH_NOCHECK") else "SKIPPED (GAMUT_BENCH_NOCHECK)")},
+                           **(zstat if wl.startswith("jpeg") else {})),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel_name, "algorithmic_bytes_per_launch": bytes_per_step,
@@ -623,13 +679,7 @@ def main():
             # image per thread at a time (the oracle is C called through ctypes, which releases the GIL).  SURVEY.md 8d.
             v, sample = cpu_leg(args.cpu_seconds * 0.6)
             res["cpu_baseline"] = {"value": round(v, 2), "unit": "Mpx/s", "cores": 1, "kind": "port", "sample": sample}
-            ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            try:                                                 # a cgroup CPU quota is the real number of cores this process gets
-                quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-                if quota != "max":
-                    ncores = max(1, min(ncores, int(int(quota) / int(period))))
-            except Exception:
-                pass
+            ncores = host_cores()                                # a cgroup CPU quota is the real number of cores this process gets
             if ncores > 1:
                 from concurrent.futures import ThreadPoolExecutor
                 with ThreadPoolExecutor(ncores) as pool:

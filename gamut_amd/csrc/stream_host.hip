@@ -150,6 +150,7 @@ bool gather_png(StbSource& src, Slurp& s, bool header_only)
     size_t got;
     if (!src.read(s, 8, &got)) return false;
     if (got < 8) return true;
+    bool first = true;                                           // stbi__parse_png_file's `first`: only IHDR (or CgBI in front of it) may come first
     for (;;) {
         if (s.len > kMaxFile) { set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png: stream too long"); return false; }
         const size_t at = s.len;
@@ -164,12 +165,16 @@ bool gather_png(StbSource& src, Slurp& s, bool header_only)
         case png_type('I','D','A','T'): case png_type('p','H','Y','s'): case png_type('I','E','N','D'):
             payload = true; break;
         case png_type('C','g','B','I'):
+            if (length > 0x7fffffffu) return true;
             payload = false; s.p[at] = s.p[at + 1] = s.p[at + 2] = s.p[at + 3] = 0; break;       // keep the (now empty) chunk
         default:
+            if (first) return true;                                                              // "first not IHDR" (:2003-2006): the header stays, the memory parser rejects it
             if (type == 0 && src.at_eof()) { s.len = at; return true; }                          // issue #92: no IEND (:2008-2012)
             if (!(type & (1u << 29))) return true;                                               // unknown critical chunk: the parser rejects it
+            if (length > 0x7fffffffu) return true;                                               // the over-long header stays in `s`: no clean end behind IDAT
             payload = false; s.len = at; break;                                                  // ancillary: skipped, left out
         }
+        if (type != png_type('C','g','B','I')) first = false;
         if (length > 0x7fffffffu) return true;                                                   // stbi__get_chunk_header's callers reject it
         if (payload) { if (!src.read(s, length, &got)) return false; if (got < length) return true; }
         else src.skip(length);

@@ -262,3 +262,34 @@ def test_argument_validation_needs_no_device():
     assert L.gamut_hip_jpeg_decode_coeffs_batch(None, None, 0, None, None, 4) == _capi.OK
     hd = _capi.PngInfo()
     assert L.gamut_hip_png_read_header(p, 64, C.byref(hd)) == _capi.ERR_DECODE and L.gamut_hip_png_read_header(p, 64, None) == _capi.ERR_INVALID_ARG
+
+
+def test_d_binding_lists_every_export():
+    """bindings/gamut_hip.d (the file INTEGRATION.md tells a maintainer to add) declares every function of include/gamut_hip.h with the
+    same number of parameters, inside an extern(C) block, and carries the four extern(C) trampolines for the reference's extern(D)
+    callbacks (plugins/jpeg.d:167, stbdec.d:143-165).  No D compiler exists in the image: a textual check."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "gamut_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    dsrc = open(os.path.join(ROOT, "bindings", "gamut_hip.d")).read()
+    dsrc = re.sub(r"//[^\n]*", "", re.sub(r"/\*.*?\*/", "", dsrc, flags=re.S))
+
+    def protos(text):
+        out = {}
+        for m in re.finditer(r"\b(gamut_hip_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+            args = m.group(2).strip()
+            depth, n = 0, 0 if args in ("", "void") else 1
+            for ch in args:
+                depth += ch == "("
+                depth -= ch == ")"
+                n += ch == "," and depth == 0
+            out[m.group(1)] = n
+        return out
+    h, d = protos(hdr), protos(dsrc)
+    h.pop("gamut_hip_jpeg_stream_read_func", None)
+    missing = sorted(set(h) - set(d))
+    assert not missing, missing
+    assert {k: d[k] for k in h} == h
+    assert dsrc.index("extern(C)") < dsrc.index("gamut_hip_version")
+    for name in ("gamut_hip_tramp_read_jpeg", "gamut_hip_tramp_stb_read", "gamut_hip_tramp_stb_skip", "gamut_hip_tramp_stb_eof"):
+        assert re.search(r"extern\(C\)\s+\w+\s+" + name, dsrc), name

@@ -191,7 +191,97 @@ def test_jpeg_stream_stops_at_eoi():
                 assert e <= st["pos"] < e + 8192, (os.path.basename(path), piece, st["pos"], e)
 
 
+def test_png_callbacks_reject_an_ancillary_chunk_in_front_of_ihdr():
+    """stbi__parse_png_file's `first` (stbdec.d:2003-2006): only IHDR (CgBI in front of it) may come first.  The walk keeps the offending
+    chunk header so that the memory parser rejects the file the way gamut_hip_stbi_load_from_memory does; an ancillary chunk with an
+    over-long length keeps its header too (no clean end of data behind IDAT that the issue-#92 path could accept)."""
+    import struct, zlib
+    L = _capi.lib()
+    png = open(fixtures.ref_image("issue65.png"), "rb").read()
+    body = b"tEXtComment\0hello"
+    chunk = struct.pack(">I", len(body) - 4) + body + struct.pack(">I", zlib.crc32(body))
+    bad = png[:8] + chunk + png[8:]
+    x, y, n = C.c_int(), C.c_int(), C.c_int()
+    cb, st, keep = _stb_callbacks(bad, 1 << 20)
+    assert not L.gamut_hip_stbi_load_from_callbacks(C.byref(cb), None, C.byref(x), C.byref(y), C.byref(n), 4, None, None, None)
+    assert b"first not IHDR" in L.gamut_hip_last_error()
+    buf = np.frombuffer(bad, np.uint8)
+    assert not L.gamut_hip_stbi_load_from_memory(buf.ctypes.data, buf.size, C.byref(x), C.byref(y), C.byref(n), 4, None, None, None)
+    assert b"first not IHDR" in L.gamut_hip_last_error()
+    assert st["pos"] == 16, "the walk stops at the offending chunk header"
+    # an over-long ancillary chunk behind the last IDAT: its header must arrive at the memory parser
+    at = png.index(b"IEND") - 4
+    huge = png[:at] + struct.pack(">I", 0x80000001) + b"tEXt" + png[at:]
+    cb, st, keep = _stb_callbacks(huge, 1 << 20)
+    p = L.gamut_hip_stbi_load_from_callbacks(C.byref(cb), None, C.byref(x), C.byref(y), C.byref(n), 4, None, None, None)
+    assert st["pos"] == at + 8, "the walk stops behind the over-long header and keeps it"
+    if p:
+        C.CDLL(None).free(C.c_void_p(p))
+
+
+def _build_callback_consumer(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "callback_consumer")
+    root = os.path.dirname(HERE)
+    lib_dir = os.path.dirname(_capi.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=gnu99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(HERE, "c", "callback_consumer.c"), "-o", exe, "-L", lib_dir, "-lgamut_hip", "-Wl,-rpath," + lib_dir])
+    return exe
+
+
+def _consumer_stream(tmp_path):
+    a = open(fixtures.ref_image("issue65.png"), "rb").read()
+    b = _with_ancillary_chunk(open(fixtures.ref_image("issue76.png"), "rb").read())        # 16-bit grey: the _16_ entry point
+    j = open(JPEGS[0], "rb").read()
+    path = str(tmp_path / "three_images.bin")
+    open(path, "wb").write(a + b + j)
+    return path, (a, b, j)
+
+
+def test_c_callbacks_with_the_reference_struct_layouts_walk_the_stream(tmp_path):
+    """tests/c/callback_consumer.c: IOStream / IOAndHandle / JPEGIOHandle / stbi_io_callbacks with the reference's layouts, the callback
+    bodies of stbdec.d:143-165 and plugins/jpeg.d:167-177 with C linkage (what bindings/gamut_hip.d's trampolines are), stdio underneath.
+    Without a GPU the decode itself reports NO_DEVICE, but the stream has been walked by then: positions and call kinds are checked."""
+    import subprocess
+    exe = _build_callback_consumer(tmp_path)
+    path, (a, b, j) = _consumer_stream(tmp_path)
+    out = subprocess.run([exe, path, "4"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    lines = [l.split() for l in out.stdout.strip().splitlines()]
+    assert [l[0] for l in lines] == ["png", "png", "jpeg"]
+    assert int(lines[0][7]) == len(a) and int(lines[1][7]) == len(a) + len(b)             # left right behind IEND's CRC
+    assert int(lines[1][4]) == 1 and int(lines[1][9]) >= 1                                  # is16; the tEXt chunk went through `skip`
+    assert len(a) + len(b) + len(j) == int(lines[2][7])                                     # the JPEG is the end of the file
+
+
 # ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_c_callbacks_with_the_reference_struct_layouts_decode(hip, tmp_path):
+    """the same program on the GPU box: pixels == the oracle (FNV-1a of the decoded bytes), for req_comp 4 and 0 / -1"""
+    import subprocess
+    exe = _build_callback_consumer(tmp_path)
+    path, imgs = _consumer_stream(tmp_path)
+
+    def fnv(b):
+        h = 1469598103934665603
+        for v in np.frombuffer(b, np.uint8).tolist():
+            h = ((h ^ v) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h
+    for req in (4, 0):
+        out = subprocess.run([exe, path, str(req)], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+        lines = [l.split() for l in out.stdout.strip().splitlines()]
+        assert len(lines) == 3
+        for l, data in zip(lines, imgs):
+            if l[0] == "png":
+                exp, comp = O.stbi_load(data, req, l[4] == "1")[:2]
+            else:
+                e = O.decompress_jpeg(data, req if req else -1)
+                exp, comp = e[0], e[1]
+            assert (int(l[2]), int(l[3])) == (exp.shape[0], comp), l
+            assert int(l[5]) == exp.nbytes and int(l[6], 16) == fnv(np.ascontiguousarray(exp).tobytes()), l
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", JPEGS, ids=[os.path.basename(p) for p in JPEGS])
 def test_jpeg_from_stream_equals_oracle(hip, path):

@@ -4,17 +4,21 @@
 # Condensed summaries land in gpurun_out/summary_<tag>/ (copy what you want judged into profiles/).
 set -u
 TAG=$1; PB=$2; shift 3
+# timed steps of the profiled run (bench.py's default is 50) and launches per step (PER_STEP, default 1): summarize_prof.py reports the
+# kernel statistics over the timed dispatches only
+STEPS=50; prev=""; for a in "$@"; do [ "$prev" = "--steps" ] && STEPS=$a; prev=$a; done
+PER_STEP=${PER_STEP:-1}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 600 python $REPO/bench.py "$@" --no-also > $OUT/bench.json 2> $OUT/bench.err
 tail -1 $OUT/bench.json
-timeout 400 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o t -- python $REPO/bench.py "$@" --no-cpu --no-also > $OUT/trace.log 2>&1
-timeout 400 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o t -- python $REPO/bench.py "$@" --steps 3 --warmup 1 --no-cpu --no-also --batch $PB > $OUT/pmc_fetch.log 2>&1
-timeout 400 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o t -- python $REPO/bench.py "$@" --steps 3 --warmup 1 --no-cpu --no-also --batch $PB > $OUT/pmc_write.log 2>&1
+timeout 400 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o t -- python $REPO/bench.py "$@" --no-cpu --no-also --no-traffic > $OUT/trace.log 2>&1
+timeout 400 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o t -- python $REPO/bench.py "$@" --steps 3 --warmup 1 --no-cpu --no-also --no-traffic --batch $PB > $OUT/pmc_fetch.log 2>&1
+timeout 400 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o t -- python $REPO/bench.py "$@" --steps 3 --warmup 1 --no-cpu --no-also --no-traffic --batch $PB > $OUT/pmc_write.log 2>&1
 grep "^{" $OUT/trace.log | tail -1 > $OUT/bench_profiled.json        # the line of the PROFILED run: its HIP-event average and rocprofv3's come from one process
-python $REPO/tools/summarize_prof.py $OUT $REPO/gpurun_out/summary_$TAG $PB | grep -A12 gamut | head -40
+python $REPO/tools/summarize_prof.py $OUT $REPO/gpurun_out/summary_$TAG $PB $STEPS $PER_STEP | head -40
 cp $OUT/bench.json $REPO/gpurun_out/summary_$TAG/bench.json
 cp $OUT/bench_profiled.json $REPO/gpurun_out/summary_$TAG/bench_profiled.json
 rm -rf $OUT

@@ -7,6 +7,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <new>
+#include <algorithm>
 #include <thread>
 #include <vector>
 #include "../../include/gamut_hip.h"
@@ -29,16 +31,29 @@ inline hipStream_t pick_stream(void* s) { return reinterpret_cast<hipStream_t>(s
 // one HIP stream per GPU"  does as well as a thread that simply serves two devices in turn.  Everything the
 // library caches per thread -- staging buffers, private streams, events -- therefore lives in a slot of the CURRENT device:
 // device memory and streams belong to the device they were created on.
-constexpr int kMaxDevices = 64;
 inline int current_device()
 {
     int d = 0;
     if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; }
-    return d < 0 || d >= kMaxDevices ? 0 : d;
+    return d < 0 ? 0 : d;
 }
+// The slot of a device is made the first time the thread uses the object on that device (a few pointers of thread-local storage per
+// object; inline slots for 64 devices made the library's TLS segment 392 KB, paid by every short-lived worker thread on its first
+// touch of any thread_local of the library).  Never freed, like the buffers the slots hold: the HIP runtime may be gone at thread exit.
 template <class T> struct PerDevice {
-    T v[kMaxDevices]{};
-    T& cur() { return v[current_device()]; }
+    struct Slot { int dev; T* v; };
+    Slot* slots = nullptr; int n = 0;
+    T& cur()
+    {
+        const int d = current_device();
+        for (int i = 0; i < n; ++i) if (slots[i].dev == d) return *slots[i].v;
+        Slot* grown = static_cast<Slot*>(realloc(slots, (size_t)(n + 1) * sizeof(Slot)));
+        T* v = new T();                                      // (allocation failure here throws: the entry points catch and report it)
+        if (!grown) { delete v; throw std::bad_alloc(); }
+        slots = grown;
+        slots[n] = Slot{ d, v };
+        return *slots[n++].v;
+    }
 };
 
 // Per-thread, per-device staging buffers (declared `static thread_local PerDevice<...>` where they are used): grown on demand,
@@ -67,6 +82,9 @@ struct RetireList {
     {
         reap(true);
         hipEvent_t ev = nullptr;
+        // A buffer whose user never named its stream (get() without one) may be in use on any of the library's non-blocking streams,
+        // which an event on the legacy null stream does not order against: drain the device before the buffer is parked (growth is rare).
+        if (!last_user) (void)hipDeviceSynchronize();
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, last_user) != hipSuccess) {
             (void)hipGetLastError();
             if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }

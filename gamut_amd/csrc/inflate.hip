@@ -63,7 +63,7 @@ constexpr int kLitBits = INFLATE_LIT_BITS, kDistBits = 10;         // primary lo
 enum : uint32_t { F_EOB = 1, F_BAD = 2 };
 // status word per stream (0 = ok)
 enum : uint32_t { E_BLOCK_TYPE = 1, E_STORED = 2, E_LENGTHS = 3, E_CODE = 4, E_DISTANCE = 5, E_INPUT = 6 };
-enum { C_JOBS0 = 0, C_JOBS1, C_JOBS2, C_STOP0, C_STOP1, C_STOP2, C_CUT, C_LAST, C_OPEN0, C_OPEN1, C_OPEN2, C_NLONG, C_ERR, C_BTYPE, C_FINAL, C_HDR_END_LO, C_HDR_END_HI, C_HLIT, C_HDIST, C_HCLEN, C_N };
+enum { C_JOBS0 = 0, C_JOBS1, C_JOBS2, C_STOP0, C_STOP1, C_STOP2, C_CUT, C_LAST, C_OPEN0, C_OPEN1, C_OPEN2, C_NLONG, C_ERR, C_BTYPE, C_FINAL, C_HDR_END_LO, C_HDR_END_HI, C_HLIT, C_HDIST, C_HCLEN, C_SLOT, C_N };
 
 struct InfItem { const uint8_t* src; uint8_t* dst; uint32_t src_len, dst_cap; };
 // A stream between two launches of a sliced call (inflate_launch_sliced: the launches follow the upload, slice by slice): where it stands,
@@ -600,8 +600,11 @@ __device__ __noinline__ uint32_t read_code_lengths(Shared& S, uint32_t h, uint32
 
 // states / avail: null for a call of its own; else the stream resumes from states[i], reads no byte at or beyond avail[i] (what has been
 // uploaded so far) and stops in front of a round (or block header) it cannot finish within them, leaving its state for the next launch
-__global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_items, uint2* tok_scratch, uint32_t* out_len, uint32_t* status,
-                                                InfState* states, const uint32_t* avail)
+// tok_scratch holds n_slots token lists, one per RESIDENT workgroup (157 KB of LDS: one workgroup per compute unit), not one per stream:
+// a workgroup claims a free list when it starts (slot_busy, a flag per list; there are at least as many lists as workgroups can be
+// resident, so the search ends) and gives it back when it ends.
+__global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_items, uint2* tok_scratch, uint32_t* slot_busy, uint32_t n_slots,
+                                                uint32_t* out_len, uint32_t* status, InfState* states, const uint32_t* avail)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     Shared& S = *reinterpret_cast<Shared*>(smem);
@@ -612,7 +615,6 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
     const InfItem it = items[blockIdx.x];
     const uint8_t* src = it.src;
     const uint64_t src_bits = (uint64_t)it.src_len * 8u;
-    uint2* const toks = tok_scratch + (size_t)blockIdx.x * kTokCap;
 
     uint64_t pos = 0;                                 // next unread bit of the stream
     uint32_t produced = 0;                            // bytes inflated so far (ring index = produced & kRingMask)
@@ -621,6 +623,14 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
     if (t < C_N) S.ctrl[t] = 0;
     if (t == 0) S.cum_out0[0] = 0;
     __syncthreads();
+    if (t == 0) {                                     // claim a token list
+        uint32_t s = blockIdx.x % n_slots;
+        while (atomicCAS(&slot_busy[s], 0u, 1u) != 0u) { s = s + 1 == n_slots ? 0 : s + 1; __builtin_amdgcn_s_sleep(2); }
+        S.ctrl[C_SLOT] = s;
+    }
+    __syncthreads();
+    const uint32_t my_slot = S.ctrl[C_SLOT];
+    uint2* const toks = tok_scratch + (size_t)my_slot * kTokCap;
     // a sliced call: the bytes that are there, and where the stream stands
     const uint32_t have = avail ? (avail[blockIdx.x] < it.src_len ? avail[blockIdx.x] : it.src_len) : it.src_len;
     const bool all_there = have >= it.src_len;
@@ -1040,9 +1050,11 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
         }
     }
     PROF_FLUSH;
+    __syncthreads();                                  // every thread's token reads are done: the list may change hands
     if (t == 0) {
         out_len[blockIdx.x] = produced < it.dst_cap ? produced : it.dst_cap;
         status[blockIdx.x] = err;
+        __hip_atomic_store(&slot_busy[my_slot], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1052,32 +1064,62 @@ __global__ __launch_bounds__(kT) void k_inflate(const InfItem* items, int n_item
 // of a sliced call, the descriptors and the bytes-there table.  Calls on one stream are ordered, calls on different streams never
 // share it; growing it waits for its own stream only.
 namespace {
-struct InflateScratch { uint2* toks; InfState* states; InfItem* items; uint32_t* avail; };
+struct InflateScratch { uint2* toks; uint32_t* busy; uint32_t n_slots; InfState* states; InfItem* items; uint32_t* avail; };
 int inflate_scratch(int count, hipStream_t stream, InflateScratch& out)
 {
     // per call: the attribute belongs to the current device's copy of the kernel, and a process may drive several devices
     if (hipFuncSetAttribute((const void*)k_inflate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Shared)) != hipSuccess) return set_error(GAMUT_HIP_ERR_HIP, "inflate: %zu bytes of LDS are not available", sizeof(Shared));
-    struct StreamTable { int device; hipStream_t stream; void* p; size_t cap; };
+    struct StreamTable { int device; hipStream_t stream; void* p; size_t cap; uint32_t n_slots; uint64_t used; };
     static thread_local std::vector<StreamTable> tables;
+    static thread_local uint64_t tick = 0;
     StreamTable* e = nullptr;
     const int device = current_device();                    // (the null stream is one handle for every device)
     for (StreamTable& c : tables) if (c.stream == stream && c.device == device) { e = &c; break; }
-    if (!e) { tables.push_back(StreamTable{ device, stream, nullptr, 0 }); e = &tables.back(); }
+    if (!e) {
+        // A caller that makes a stream per batch would add an entry per batch: beyond 8 entries the least recently used ones go.  Their
+        // stream handles may be dead by now, so nothing stream-specific can be asked of them: the device is drained once instead.
+        if (tables.size() >= 8) {
+            (void)hipDeviceSynchronize();
+            std::sort(tables.begin(), tables.end(), [](const StreamTable& a, const StreamTable& b) { return a.used > b.used; });
+            while (tables.size() > 4) { if (tables.back().p) (void)hipFree(tables.back().p); tables.pop_back(); }
+        }
+        tables.push_back(StreamTable{ device, stream, nullptr, 0, 0, 0 });
+        e = &tables.back();
+    }
+    e->used = ++tick;
+    // token lists: one per workgroup that can be resident (one per compute unit: the kernel takes 157 KB of LDS), twice that for slack
+    // -- 512 x 256 KiB = 128 MiB on MI355X however many streams the batch has (a list per stream was 2.5 GB for 8192 PNG files)
+    static thread_local PerDevice<int> cus_pd;
+    int& cus = cus_pd.cur();
+    if (!cus) { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n <= 0) n = 256; cus = n; }
+    const uint32_t resident = (uint32_t)cus;
+    const uint32_t n_slots = (uint32_t)count < 2 * resident ? (uint32_t)count : 2 * resident;
     auto round_up = [](size_t n) { return (n + 255) & ~(size_t)255; };
-    const size_t tok_bytes = (size_t)count * kTokCap * sizeof(uint2), state_bytes = round_up((size_t)count * sizeof(InfState)),
+    const size_t tok_bytes = (size_t)(2 * resident) * kTokCap * sizeof(uint2), busy_bytes = round_up((size_t)(2 * resident) * 4),
+                 state_bytes = round_up((size_t)count * sizeof(InfState)),
                  item_bytes = round_up((size_t)count * sizeof(InfItem)), avail_bytes = round_up((size_t)count * 4);
-    const size_t bytes = tok_bytes + state_bytes + item_bytes + avail_bytes;
-    if (bytes > e->cap) {
-        if (e->p) { (void)hipStreamSynchronize(stream); (void)hipFree(e->p); e->p = nullptr; e->cap = 0; }
-        const size_t want = bytes + bytes / 4 + 4096;
+    const size_t need_toks = (size_t)n_slots * kTokCap * sizeof(uint2);
+    const size_t bytes = need_toks + busy_bytes + state_bytes + item_bytes + avail_bytes;
+    if (bytes > e->cap || n_slots > e->n_slots) {
+        if (e->p) { (void)hipStreamSynchronize(stream); (void)hipFree(e->p); e->p = nullptr; e->cap = 0; e->n_slots = 0; }
+        // the per-stream tables grow with the batch (+ a quarter); the token lists are sized once: for a full chip as soon as a batch has
+        // more streams than a few, so that later, larger batches do not reallocate
+        const uint32_t slots_now = n_slots > 16 ? 2 * resident : n_slots;
+        const size_t small = busy_bytes + state_bytes + item_bytes + avail_bytes;
+        const size_t want = (slots_now == 2 * resident ? tok_bytes : (size_t)slots_now * kTokCap * sizeof(uint2)) + small + small / 4 + 4096;
         if (hipMalloc(&e->p, want) != hipSuccess) { (void)hipGetLastError(); e->p = nullptr; return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "inflate: %zu bytes of scratch are not available", want); }
-        e->cap = want;
+        e->cap = want; e->n_slots = slots_now;
+        // the flags start at zero and every workgroup puts its own back: cleared here only
+        if (hipMemsetAsync(static_cast<uint8_t*>(e->p) + (size_t)slots_now * kTokCap * sizeof(uint2), 0, busy_bytes, stream) != hipSuccess) return set_error(GAMUT_HIP_ERR_HIP, "inflate: scratch clear failed");
     }
     uint8_t* const base = static_cast<uint8_t*>(e->p);
+    const size_t toks_now = (size_t)e->n_slots * kTokCap * sizeof(uint2);
     out.toks = reinterpret_cast<uint2*>(base);
-    out.states = reinterpret_cast<InfState*>(base + tok_bytes);
-    out.items = reinterpret_cast<InfItem*>(base + tok_bytes + state_bytes);
-    out.avail = reinterpret_cast<uint32_t*>(base + tok_bytes + state_bytes + item_bytes);
+    out.busy = reinterpret_cast<uint32_t*>(base + toks_now);
+    out.n_slots = e->n_slots;
+    out.states = reinterpret_cast<InfState*>(base + toks_now + busy_bytes);
+    out.items = reinterpret_cast<InfItem*>(base + toks_now + busy_bytes + state_bytes);
+    out.avail = reinterpret_cast<uint32_t*>(base + toks_now + busy_bytes + state_bytes + item_bytes);
     return GAMUT_HIP_OK;
 }
 int inflate_items(const gamut_hip_inflate_desc* descs, int count, std::vector<InfItem>& items)
@@ -1099,7 +1141,7 @@ int inflate_launch(const gamut_hip_inflate_desc* descs, int count, uint32_t* out
     InflateScratch sc;
     if (int rc = inflate_scratch(count, stream, sc)) return rc;
     GAMUT_HIP_CHECK(hipMemcpyAsync(sc.items, items.data(), items.size() * sizeof(InfItem), hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(k_inflate, dim3((unsigned)count), dim3(kT), sizeof(Shared), stream, (const InfItem*)sc.items, count, sc.toks, out_len_dev, status_dev, (InfState*)nullptr, (const uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_inflate, dim3((unsigned)count), dim3(kT), sizeof(Shared), stream, (const InfItem*)sc.items, count, sc.toks, sc.busy, sc.n_slots, out_len_dev, status_dev, (InfState*)nullptr, (const uint32_t*)nullptr);
     return launch_status("inflate");
 }
 
@@ -1120,7 +1162,7 @@ int inflate_sliced_step(int count, const uint32_t* avail_host /* pinned or pagea
     InflateScratch sc;
     if (int rc = inflate_scratch(count, stream, sc)) return rc;     // (the buffer of _begin: same thread, device, stream, count)
     GAMUT_HIP_CHECK(hipMemcpyAsync(sc.avail, avail_host, (size_t)count * 4, hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(k_inflate, dim3((unsigned)count), dim3(kT), sizeof(Shared), stream, (const InfItem*)sc.items, count, sc.toks, out_len_dev, status_dev, sc.states, (const uint32_t*)sc.avail);
+    hipLaunchKernelGGL(k_inflate, dim3((unsigned)count), dim3(kT), sizeof(Shared), stream, (const InfItem*)sc.items, count, sc.toks, sc.busy, sc.n_slots, out_len_dev, status_dev, sc.states, (const uint32_t*)sc.avail);
     return launch_status("inflate");
 }
 

@@ -457,6 +457,9 @@ constexpr int ROW_PITCH = RING * 16;              // 256 B: lane j's slot (T - j
 #ifndef PNG_NT_STORES
 #define PNG_NT_STORES 1
 #endif
+#ifndef PNG_Q_NO_CHUNK           // ablation only (wrong pixels): the queue kernel without its loads of the row above the band
+#define PNG_Q_NO_CHUNK 0
+#endif
 
 // RGBA = 8-bit RGB stream in, RGBA8 rows out (alpha = 255 inserted, stbdec.d:1504-1546, out_n == img_n + 1): the row is walked
 // in pieces of IB = 12 stream bytes = 4 pixels = one 16-byte chunk of the output, the ring slots hold the expanded pixels,
@@ -568,7 +571,11 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
     uint8_t* const dch = ring + 64 * ROW_PITCH;
     auto issue_chunk = [&](u32 Tbase) {
         const u32 piece = min(Tbase + (u32)(lane & 7), niter - 1);
+#if !PNG_Q_NO_CHUNK
         if (lane < 8) chunk = __builtin_amdgcn_raw_buffer_load_b128(rs_prev, piece * 16u, 0, 16);        // sc1: past this CU's L1
+#else
+        (void)piece;
+#endif
     };
 
     if constexpr (Q) {

@@ -40,6 +40,10 @@ class JpegFrame(C.Structure):
                 ("pixel_aspect_ratio", C.c_float), ("dpi_y", C.c_float)]
 
 
+class ImageInfo(C.Structure):                                  # gamut_hip_image_info
+    _fields_ = [("format", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("channels_in_file", C.c_int32), ("channels", C.c_int32)]
+
+
 class InflateDesc(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("src_len", C.c_uint32), ("dst_cap", C.c_uint32)]
 
@@ -102,6 +106,8 @@ SIGNATURES = {
     "gamut_hip_stbi_png_is16_from_callbacks": (_i, [_vp, _vp]),
     "gamut_hip_inflate_batch_device": (_i, [_vp, _i, _vp, _vp, _vp]),
     "gamut_hip_inflate_batch_device_sliced": (_i, [_vp, _i, _vp, _vp, C.c_uint32, _vp]),
+    "gamut_hip_identify_format": (_i, [_vp, _sz]),
+    "gamut_hip_decode_batch_device": (_i, [C.POINTER(_vp), C.POINTER(_sz), _i, _i, C.POINTER(_i64), _vp, C.POINTER(ImageInfo), C.POINTER(_i), _vp]),
     "gamut_hip_shard_owner": (_i, [_i64, _i]),
     "gamut_hip_shard_count": (_i64, [_i, _i, _i64]),
     "gamut_hip_shard_local_index": (_i64, [_i64, _i]),

@@ -984,6 +984,148 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevIte
     if (t == 0 && failed) atomicOr(status + it.image, 1u);
 }
 
+
+// ---- the scan as it stands in the file -> the unstuffed, padded segments the two kernels above read, ON THE DEVICE --------------------
+// get_bits_no_markers (jpegload.d:722-743) and get_octet (:683-696) skip the 0x00 behind a data 0xFF while they read, and
+// process_restart (:2335-2402) finds the RSTn markers; round 3 did both on host threads (unstuff_file below: memchr + many small
+// memcpy into pinned memory, "unstuff + upload at 33 GB/s", and a thread pool that is divided by the ranks of the node).  Here the host
+// copies the file's bytes from the first scan byte on into pinned memory as they are -- one memcpy -- and a workgroup per file turns them
+// into the blob form: tiles of 4 KiB, a byte dropped when it is 0x00 behind 0xFF (prefix sum of the kept bytes over the workgroup,
+// staged in LDS, written out as whole aligned 16-byte chunks); the data of a segment ends at the first 0xFF that is followed by
+// anything but 0x00 (rare: a tile is processed up to the first such place and the marker handled by the whole workgroup in step) --
+// an expected RSTn closes the segment (64 bytes of 0xFF behind it, as the host writes them) and opens the next, anything else ends the
+// scan.  The segment list (image, first MCU, MCU count per restart interval) comes from the host, which knows it from the header;
+// begin / end are filled in here.  A wrong or missing restart marker flags the file (status bit 3) and empties its segments.
+struct DevRaw {
+    uint64_t raw_begin, raw_len;        // the file from its first scan byte to its end, in the raw blob
+    uint64_t out_begin, out_cap;        // the file's slot in the unstuffed blob (16-byte aligned)
+    int32_t  image, first_item, n_items, restart_interval;
+};
+constexpr int kUnstuffThreads = 256, kUnstuffTile = kUnstuffThreads * 16;
+constexpr uint32_t kStatusBadRestart = 8u;
+__global__ __launch_bounds__(kUnstuffThreads) void k_jpeg_unstuff(const DevRaw* files, DevItem* items, const uint8_t* raw, uint8_t* blob, uint32_t* status)
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    struct __attribute__((packed, aligned(1))) AnyVec { u32x4 v; };
+    __shared__ __attribute__((aligned(16))) uint8_t stage[16 + kUnstuffTile + 64 + 16];
+    __shared__ uint32_t wave_sum[kUnstuffThreads / 64];
+    __shared__ uint32_t first_term;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const DevRaw f = files[blockIdx.x];
+    const uint8_t* src = raw + f.raw_begin;
+    uint8_t* const dst = blob + f.out_begin;
+    uint64_t cur = 0, w = 0, seg_begin = 0;                 // next raw byte; bytes produced (the last w % 16 of them still in stage[])
+    uint32_t carry = 0;
+    int seg = 0, expect = 0;
+    bool bad = false;
+    // stage[0 .. m) = the last m of the w bytes produced -> dst, whole 16-byte chunks; the rest moves to the front (all threads call it)
+    auto flush = [&](uint32_t m) {
+        __syncthreads();
+        const uint32_t chunks = m >> 4;
+        const uint64_t base = w - m;                         // 16-byte aligned by construction
+        for (uint32_t c = t; c < chunks; c += kUnstuffThreads) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(stage + c * 16);
+            if (base + c * 16 + 16 <= f.out_cap) *reinterpret_cast<u32x4*>(dst + base + c * 16) = v;
+        }
+        uint8_t keep = 0;
+        const uint32_t rest = m & 15u;
+        if ((uint32_t)t < rest) keep = stage[chunks * 16 + t];
+        __syncthreads();
+        if ((uint32_t)t < rest) stage[t] = keep;
+        __syncthreads();
+        return rest;
+    };
+    auto close_segment = [&]() {                             // the segment's item, then its 64 bytes of padding
+        if (t == 0 && seg < f.n_items) { items[f.first_item + seg].begin = f.out_begin + seg_begin; items[f.first_item + seg].end = f.out_begin + w; }
+        if (t < 64) stage[carry + t] = 0xFF;
+        const uint32_t m = carry + 64;
+        w += 64;
+        carry = flush(m);
+        seg_begin = w; ++seg;
+    };
+    bool ended = false;
+    while (!ended) {
+        const uint64_t left = f.raw_len - cur;
+        const uint32_t n = left < (uint64_t)kUnstuffTile ? (uint32_t)left : (uint32_t)kUnstuffTile;
+        if (t == 0) first_term = 0xFFFFFFFFu;
+        __syncthreads();
+        // this thread's 16 bytes, the byte in front of them and the byte behind them (zeros outside the data)
+        const uint32_t o = (uint32_t)t * 16u;
+        uint8_t b[18];
+        #pragma unroll
+        for (int k = 0; k < 18; ++k) b[k] = 0;
+        if (o < n) {
+            const u32x4 v = reinterpret_cast<const AnyVec*>(src + cur + o)->v;          // (the raw blob has 32 bytes of slack behind every file)
+            #pragma unroll
+            for (int k = 0; k < 16; ++k) b[1 + k] = (uint8_t)(v[k >> 2] >> ((k & 3) * 8));
+            b[0] = cur + o > 0 ? src[cur + o - 1] : 0;
+            b[17] = src[cur + o + 16];
+        }
+        uint32_t term = 0xFFFFFFFFu;
+        #pragma unroll
+        for (int k = 15; k >= 0; --k) {
+            const uint64_t at = cur + o + (uint32_t)k;
+            if (o + (uint32_t)k < n && b[1 + k] == 0xFF && at + 1 < f.raw_len && b[2 + k] != 0x00) term = o + (uint32_t)k;
+        }
+        if (term != 0xFFFFFFFFu) atomicMin(&first_term, term);
+        __syncthreads();
+        const uint32_t p = first_term;                       // offset of the first data-ending 0xFF in the tile, if any
+        const uint32_t region = p < n ? p : n;
+        // kept bytes of [0, region): everything but a 0x00 behind a 0xFF
+        uint32_t cnt = 0, keepmask = 0;
+        #pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const bool keep = o + (uint32_t)k < region && !(b[1 + k] == 0x00 && b[k] == 0xFF);
+            keepmask |= keep ? 1u << k : 0u; cnt += keep ? 1u : 0u;
+        }
+        uint32_t incl = cnt;                                 // inclusive prefix sum over the wave, then over the workgroup
+        #pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
+        if (lane == 63) wave_sum[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        #pragma unroll
+        for (int k = 0; k < kUnstuffThreads / 64; ++k) { const uint32_t s = wave_sum[k]; before += k < wave ? s : 0u; total += s; }
+        const uint32_t at = carry + before + incl - cnt;
+        if (cnt == 16) {
+            u32x4 v;
+            #pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = (uint32_t)b[1 + 4 * k] | (uint32_t)b[2 + 4 * k] << 8 | (uint32_t)b[3 + 4 * k] << 16 | (uint32_t)b[4 + 4 * k] << 24;
+            reinterpret_cast<AnyVec*>(stage + at)->v = v;                               // (LDS takes byte-unaligned 16-byte accesses on gfx950)
+        } else if (cnt) {
+            uint32_t q = at;
+            #pragma unroll
+            for (int k = 0; k < 16; ++k) if (keepmask >> k & 1u) stage[q++] = b[1 + k];
+        }
+        w += total;
+        carry = flush(carry + total);
+        if (p < n) {                                         // a marker: skip fill bytes, look at its code (every thread reads the same bytes)
+            uint64_t j = cur + p + 1;
+            while (j < f.raw_len && src[j] == 0xFF) ++j;
+            const uint32_t code = j < f.raw_len ? src[j] : 0xD9u;
+            const bool rst = code >= 0xD0u && code <= 0xD7u && f.restart_interval > 0 && seg + 1 < f.n_items;
+            if (rst && code != 0xD0u + (uint32_t)expect) { bad = true; ended = true; }
+            else if (rst) { close_segment(); expect = (expect + 1) & 7; cur = j + 1; }
+            else ended = true;                               // EOI or any other marker ends the scan
+        } else {
+            cur += n;
+            if (cur >= f.raw_len) ended = true;              // the file ends inside the scan: what is there is the data
+        }
+    }
+    if (!bad) {
+        if (seg + 1 == f.n_items) close_segment();
+        else bad = true;                                     // a restart marker is missing
+    }
+    if (carry) {                                             // the last, partial chunk (the slot has room for a whole one)
+        __syncthreads();
+        if (t == 0 && (w - carry) + 16 <= f.out_cap) *reinterpret_cast<u32x4*>(dst + (w - carry)) = *reinterpret_cast<const u32x4*>(stage);
+    }
+    if (bad) {
+        for (int k = t; k < f.n_items; k += kUnstuffThreads) { items[f.first_item + k].begin = f.out_begin; items[f.first_item + k].end = f.out_begin; }
+        if (t == 0) atomicOr(status + f.image, kStatusBadRestart);
+    }
+}
+
 // Host side: header walk per file (on host threads), table de-duplication, restart-interval index, one upload, two launches.
 // geometry + the position of the single baseline scan; shared by read_header and the device decoder
 int parse_baseline(Parser& P, const uint8_t* data, size_t len, gamut_hip_jpeg_frame* f, bool want_scan)
@@ -1024,8 +1166,12 @@ struct FilePrep {
     QuantTab quant[3]; DevHuff huff[3][2];                     // [component][DC, AC]
     size_t scan_pos = 0, cap = 0, used = 0;                    // first scan byte in the file; bound / actual size of the unstuffed segments
     int restart_interval = 0, total_mcus = 0;
-    std::vector<DevItem> items;                                // begin / end relative to the file's slot in the blob
+    bool dev_unstuff = false;                                  // the scan goes up as it is and k_jpeg_unstuff makes the segments (items: begin / end filled in there)
+    size_t raw_len = 0;                                        // bytes from scan_pos to the end of the file
+    std::vector<DevItem> items;                                // begin / end relative to the file's slot in the blob; pad = (estimated) bytes of the segment
 };
+// where the 0x00 stuffing is dropped and the restart markers are found: GAMUT_HIP_JPEG_UNSTUFF=host / device forces either (tests, measurements)
+int unstuff_site() { const char* e = getenv("GAMUT_HIP_JPEG_UNSTUFF"); return !e || !*e ? 0 : !strcmp(e, "host") ? 1 : !strcmp(e, "device") ? 2 : 0; }
 
 void prepare_header(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& f, FilePrep& out, Parser& P)
 {
@@ -1046,7 +1192,23 @@ void prepare_header(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& 
     out.scan_pos = P.pos; out.restart_interval = P.restart_interval; out.total_mcus = f.mcus_per_row * f.mcus_per_col;
     // unstuffing only drops bytes; every segment (at most one per restart interval) gains 64 bytes of padding
     const size_t segs = out.restart_interval ? (size_t)(out.total_mcus / out.restart_interval + 1) : 1;
-    out.cap = (n - out.scan_pos) + 64 * segs;
+    out.cap = (n - out.scan_pos) + 64 * segs + 16;
+    out.raw_len = n - out.scan_pos;
+    // On the device unless the restart intervals are tiny (the kernel handles a marker by the whole workgroup in step: a file of
+    // thousands of 30-byte intervals is quicker through memchr on a host thread; its segments take a lane each anyway)
+    const size_t n_seg = out.restart_interval ? (size_t)((out.total_mcus + out.restart_interval - 1) / out.restart_interval) : 1;
+    const size_t est = n_seg ? out.raw_len / n_seg : out.raw_len;
+    out.dev_unstuff = unstuff_site() == 2 || (unstuff_site() == 0 && (out.restart_interval == 0 || est >= 1024));
+    if (out.dev_unstuff) {
+        out.items.resize(n_seg);
+        for (size_t k = 0; k < n_seg; ++k) {
+            DevItem& it = out.items[k]; memset(&it, 0, sizeof(it));
+            it.image = i; it.first_mcu = out.restart_interval ? (int)k * out.restart_interval : 0;
+            it.n_mcus = out.restart_interval ? std::min(out.restart_interval, out.total_mcus - it.first_mcu) : out.total_mcus;
+            it.pad = (int32_t)std::min<size_t>(est, 0x7fffffff);
+        }
+        out.used = out.cap;
+    }
 }
 
 void unstuff_file(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& f, FilePrep& out, uint8_t* dst)
@@ -1065,6 +1227,7 @@ void unstuff_file(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& f,
     auto close_segment = [&](int nm) {
         if (w + 64 > out.cap) { bad = true; return; }
         DevItem it{}; it.image = i; it.first_mcu = next_mcu; it.n_mcus = nm; it.begin = seg_begin; it.end = w;
+        it.pad = (int32_t)std::min<size_t>(w - seg_begin, 0x7fffffff);
         out.items.push_back(it); next_mcu += nm;
         memset(dst + w, 0xFF, 64); w += 64;
         seg_begin = w;
@@ -1181,26 +1344,50 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
         uint8_t* d_blob_w = (uint8_t*)scratch.get(blob_size + kBlobSlack, stream);
         uint8_t* h_blob = pinned.get(blob_size + kBlobSlack, copy_stream);
         if (!d_blob_w || !h_blob) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: staging allocation of %zu bytes failed", blob_size + kBlobSlack);
+        // files whose scan goes up as it is (k_jpeg_unstuff): their slots in the raw image, pinned and device
+        size_t raw_size = 0; int n_dev_files = 0; bool dev_restarts = false;
+        std::vector<size_t> raw_off((size_t)count, 0);
+        for (int i = 0; i < count; ++i) {
+            const FilePrep& fp = prep[(size_t)i];
+            if (fp.rc != GAMUT_HIP_OK || !fp.dev_unstuff) continue;
+            raw_off[(size_t)i] = raw_size; raw_size += (fp.raw_len + 32 + 15) & ~(size_t)15; ++n_dev_files;
+            dev_restarts = dev_restarts || fp.restart_interval > 0;
+        }
+        static thread_local PerDevice<DeviceScratch> raw_scratch_pd;
+        static thread_local PerDevice<PinnedScratch> raw_pinned_pd;
+        uint8_t* d_raw = nullptr; uint8_t* h_raw = nullptr;
+        if (n_dev_files) {
+            d_raw = (uint8_t*)raw_scratch_pd.cur().get(raw_size + 64, stream);
+            h_raw = raw_pinned_pd.cur().get(raw_size + 64, copy_stream);
+            if (!d_raw || !h_raw) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: staging allocation of %zu bytes failed", raw_size);
+        }
         // (both kernels write every block of a segment as a whole line -- zeros included, blocks a damaged segment never reaches as
         // well: the coefficient buffer needs no clearing)
-        {
-            if (d_status) GAMUT_HIP_CHECK(hipMemsetAsync(d_status, 0, (size_t)count * sizeof(uint32_t), stream));
+        uint32_t* st = d_status;
+        if (!st) {                                             // the kernels want somewhere to flag errors
+            static thread_local PerDevice<DeviceScratch> sink_pd;
+            DeviceScratch& sink = sink_pd.cur();
+            st = (uint32_t*)sink.get((size_t)count * sizeof(uint32_t), stream);
+            if (!st) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: status allocation failed");
         }
-        // C/D. groups of slices of files.  A slice is unstuffed on the workers and DMA'd at once; when a group of slices is on
-        //      its way, its segment list follows it and the group's kernels are queued on `stream` behind an event, so the
-        //      first group decodes while the rest is still being unstuffed and uploaded.  A group keeps >= 512 workgroups.
-        const int n_groups = count >= 1024 ? 4 : count >= 256 ? 2 : 1;
-        const int n_slices = count >= 512 ? 8 : count >= 64 ? 4 : 1;
-        struct Ev4 { hipEvent_t e[4]; }; struct St4 { hipStream_t s[4]; };
-        static thread_local PerDevice<Ev4> group_ready_pd;
-        hipEvent_t (&group_ready)[4] = group_ready_pd.cur().e;
+        GAMUT_HIP_CHECK(hipMemsetAsync(st, 0, (size_t)count * sizeof(uint32_t), stream));
+        // C/D. groups of files.  A group's bytes are copied into pinned memory on the workers (as they are; files with tiny restart
+        //      intervals: unstuffed there) and DMA'd at once; its segment list follows and the group's kernels -- unstuff, entropy
+        //      decode, and through the hook the reconstruction -- are queued behind an event on a stream of the group's own, so the
+        //      first group decodes while the rest is still on its way.
+        constexpr int kMaxGroups = 8;
+        static const int groups_env = [] { const char* e = getenv("GAMUT_HIP_JPEG_GROUPS"); return e && *e ? atoi(e) : 0; }();        // measurements
+        const int n_groups = groups_env > 0 ? std::min(kMaxGroups, std::min(groups_env, count)) : std::max(1, std::min(kMaxGroups, count / 256));        // (1024 files: 4 groups 14.8 ms, 8 groups 16.1 ms, 2 groups 14.9 ms -- profiles/r04_jpeg_sweep.txt)
+        struct EvN { hipEvent_t e[kMaxGroups]; }; struct StN { hipStream_t s[kMaxGroups]; };
+        static thread_local PerDevice<EvN> group_ready_pd;
+        hipEvent_t (&group_ready)[kMaxGroups] = group_ready_pd.cur().e;
         for (int g = 0; g < n_groups; ++g) if (!group_ready[g]) GAMUT_HIP_CHECK(hipEventCreateWithFlags(&group_ready[g], hipEventDisableTiming));
         // A long segment is decoded by one workgroup in its own time (its sweeps), whatever else the chip does: the groups' kernels
         // are therefore queued on streams of their own (behind what `stream` holds now) and run side by side, each as soon as its
         // bytes are there -- on one stream a group waited for the group before it to finish.
-        static thread_local PerDevice<St4> side_pd;
+        static thread_local PerDevice<StN> side_pd;
         static thread_local PerDevice<hipEvent_t> fork_pd;
-        hipStream_t (&side)[4] = side_pd.cur().s;
+        hipStream_t (&side)[kMaxGroups] = side_pd.cur().s;
         hipEvent_t& fork = fork_pd.cur();
         if (!fork) GAMUT_HIP_CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
         for (int g = 1; g < n_groups; ++g) if (!side[g]) GAMUT_HIP_CHECK(hipStreamCreateWithFlags(&side[g], hipStreamNonBlocking));
@@ -1209,74 +1396,105 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
         auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
         size_t max_items = 0;
         for (int i = 0; i < count; ++i) if (prep[(size_t)i].rc == GAMUT_HIP_OK) max_items += prep[(size_t)i].restart_interval ? (size_t)(prep[(size_t)i].total_mcus / prep[(size_t)i].restart_interval + 1) : 1;
-        // one small pinned image of the tables: [images][huff][quant][items of group 0][items of group 1]...
+        // one small pinned image of the tables: [images][huff][quant][raw-file records][items of group 0][items of group 1]...
         const size_t o_img = 0, o_huff = align(o_img + images.size() * sizeof(DevImage)), o_quant = align(o_huff + huffs.size() * sizeof(DevHuff)),
-                     o_items = align(o_quant + quants.size() * sizeof(QuantTab)), total = o_items + align(max_items * sizeof(DevItem)) + 256 * (size_t)n_groups;
-        uint8_t* d = (uint8_t*)tab_scratch.get(total);
-        uint8_t* h = tab_pinned.get(total);
+                     o_raws = align(o_quant + quants.size() * sizeof(QuantTab)), o_items = align(o_raws + (size_t)n_dev_files * sizeof(DevRaw)),
+                     total = o_items + align(max_items * sizeof(DevItem)) + 256 * (size_t)n_groups;
+        uint8_t* d = (uint8_t*)tab_scratch.get(total, stream);
+        uint8_t* h = tab_pinned.get(total, copy_stream);
         if (!d || !h) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: staging allocation of %zu bytes failed", total);
         memcpy(h + o_img, images.data(), images.size() * sizeof(DevImage));
         memcpy(h + o_huff, huffs.data(), huffs.size() * sizeof(DevHuff));
         memcpy(h + o_quant, quants.data(), quants.size() * sizeof(QuantTab));
-        GAMUT_HIP_CHECK(hipMemcpyAsync(d, h, o_items, hipMemcpyHostToDevice, copy_stream));
-        uint32_t* st = d_status;
-        if (!st) {                                             // the kernel wants somewhere to flag errors
-            static thread_local PerDevice<DeviceScratch> sink_pd;
-            DeviceScratch& sink = sink_pd.cur();
-            st = (uint32_t*)sink.get((size_t)count * sizeof(uint32_t));
-            if (!st) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: status allocation failed");
-        }
+        GAMUT_HIP_CHECK(hipMemcpyAsync(d, h, o_raws, hipMemcpyHostToDevice, copy_stream));
         const int n_huff = (int)huffs.size(), n_quant = (int)quants.size();
         const bool in_lds = n_huff <= kLdsHuff && n_quant <= kLdsQuant;
         const DevImage* d_img = (const DevImage*)(d + o_img);
         const DevHuff* d_huff = (const DevHuff*)(d + o_huff); const int16_t* d_quant = (const int16_t*)(d + o_quant);
         const uint8_t* d_blob = d_blob_w;
         size_t items_off = o_items;
+        int raws_done = 0;
         int total_long = 0, total_short = 0;
         double ms_kernels_issue = 0;
+        std::vector<DevRaw> raws;
         for (int g = 0; g < n_groups; ++g) {
             const int g_lo = (int)((int64_t)count * g / n_groups), g_hi = (int)((int64_t)count * (g + 1) / n_groups);
-            const int s_lo = n_slices * g / n_groups, s_hi = n_slices * (g + 1) / n_groups;
-            for (int sl = s_lo; sl < s_hi; ++sl) {
-                const int lo = g_lo + (int)((int64_t)(g_hi - g_lo) * (sl - s_lo) / (s_hi - s_lo)), hi = g_lo + (int)((int64_t)(g_hi - g_lo) * (sl - s_lo + 1) / (s_hi - s_lo));
-                if (hi <= lo) continue;
-                parallel_for(hi - lo, workers, [&](int, int k) {
-                    const int i = lo + k;
-                    FilePrep& fp = prep[(size_t)i];
-                    if (fp.rc == GAMUT_HIP_OK) unstuff_file(i, data[i], len[i], info[i], fp, h_blob + blob_off[(size_t)i]);
-                });
-                size_t b0 = 0, b1 = 0; bool have = false;
-                for (int i = lo; i < hi; ++i) {
+            if (g_hi <= g_lo) continue;
+            parallel_for(g_hi - g_lo, workers, [&](int, int k) {
+                const int i = g_lo + k;
+                FilePrep& fp = prep[(size_t)i];
+                if (fp.rc != GAMUT_HIP_OK) return;
+                if (fp.dev_unstuff) memcpy(h_raw + raw_off[(size_t)i], data[i] + fp.scan_pos, fp.raw_len);
+                else unstuff_file(i, data[i], len[i], info[i], fp, h_blob + blob_off[(size_t)i]);
+            });
+            {   // the group's uploads: one DMA per run of neighbouring slots of the same kind
+                int i = g_lo;
+                while (i < g_hi) {
                     const FilePrep& fp = prep[(size_t)i];
-                    if (fp.rc != GAMUT_HIP_OK || fp.used == 0) continue;
-                    if (!have) { b0 = blob_off[(size_t)i]; have = true; }
-                    b1 = blob_off[(size_t)i] + fp.used;
+                    if (fp.rc != GAMUT_HIP_OK || fp.used == 0) { ++i; continue; }
+                    const bool dev = fp.dev_unstuff;
+                    int j = i; size_t b0 = dev ? raw_off[(size_t)i] : blob_off[(size_t)i], b1 = b0;
+                    while (j < g_hi && (prep[(size_t)j].rc != GAMUT_HIP_OK || prep[(size_t)j].used == 0 || prep[(size_t)j].dev_unstuff == dev)) {
+                        const FilePrep& fj = prep[(size_t)j];
+                        if (fj.rc == GAMUT_HIP_OK && fj.used) b1 = dev ? raw_off[(size_t)j] + fj.raw_len : blob_off[(size_t)j] + fj.used;
+                        ++j;
+                    }
+                    if (b1 > b0) GAMUT_HIP_CHECK(hipMemcpyAsync((dev ? d_raw : d_blob_w) + b0, (dev ? h_raw : h_blob) + b0, b1 - b0, hipMemcpyHostToDevice, copy_stream));
+                    i = j;
                 }
-                if (have) GAMUT_HIP_CHECK(hipMemcpyAsync(d_blob_w + b0, h_blob + b0, b1 - b0, hipMemcpyHostToDevice, copy_stream));
             }
             // the group's segment list: long segments get a workgroup each (self-synchronising decode), short ones a lane each
             items.clear();
             for (int i = g_lo; i < g_hi; ++i) {
                 const FilePrep& fp = prep[(size_t)i];
                 if (fp.rc != GAMUT_HIP_OK) continue;
-                for (DevItem it : fp.items) { it.begin += blob_off[(size_t)i]; it.end += blob_off[(size_t)i]; items.push_back(it); }
+                for (DevItem it : fp.items) { if (!fp.dev_unstuff) { it.begin += blob_off[(size_t)i]; it.end += blob_off[(size_t)i]; } items.push_back(it); }
             }
             if (items.empty()) continue;
-            std::stable_partition(items.begin(), items.end(), [](const DevItem& it) { return it.end - it.begin >= kSyncMinBytes; });
+            std::stable_partition(items.begin(), items.end(), [](const DevItem& it) { return (uint32_t)it.pad >= kSyncMinBytes; });
             n_long = 0;
-            while (n_long < (int)items.size() && items[(size_t)n_long].end - items[(size_t)n_long].begin >= kSyncMinBytes) ++n_long;
+            while (n_long < (int)items.size() && (uint32_t)items[(size_t)n_long].pad >= kSyncMinBytes) ++n_long;
             const int n_items = (int)items.size(), n_short = n_items - n_long;
             total_long += n_long; total_short += n_short;
             if (items_off + items.size() * sizeof(DevItem) > total) return set_error(GAMUT_HIP_ERR_DECODE, "jpeg: more segments than the restart intervals allow");
+            // the files of the group that are unstuffed on the device: where their segments stand in the list (a file's segments
+            // are all of one class, the partition keeps their order)
+            raws.clear();
+            {
+                int k = 0;
+                while (k < n_items) {
+                    const int img = items[(size_t)k].image; int e = k + 1;
+                    while (e < n_items && items[(size_t)e].image == img) ++e;
+                    const FilePrep& fp = prep[(size_t)img];
+                    if (fp.dev_unstuff) {
+                        DevRaw r; memset(&r, 0, sizeof(r));
+                        r.raw_begin = raw_off[(size_t)img]; r.raw_len = fp.raw_len; r.out_begin = blob_off[(size_t)img]; r.out_cap = (fp.cap + 15) & ~(size_t)15;
+                        r.image = img; r.first_item = k; r.n_items = e - k; r.restart_interval = fp.restart_interval;
+                        raws.push_back(r);
+                    }
+                    k = e;
+                }
+            }
             memcpy(h + items_off, items.data(), items.size() * sizeof(DevItem));
             GAMUT_HIP_CHECK(hipMemcpyAsync(d + items_off, h + items_off, items.size() * sizeof(DevItem), hipMemcpyHostToDevice, copy_stream));
-            const DevItem* d_items = (const DevItem*)(d + items_off);
+            DevItem* d_items = (DevItem*)(d + items_off);
             items_off = align(items_off + items.size() * sizeof(DevItem));
+            const DevRaw* d_raws = (const DevRaw*)(d + o_raws) + raws_done;
+            if (!raws.empty()) {
+                if (raws_done + (int)raws.size() > n_dev_files) return set_error(GAMUT_HIP_ERR_DECODE, "jpeg: internal: raw-file records overflow");
+                memcpy(h + o_raws + (size_t)raws_done * sizeof(DevRaw), raws.data(), raws.size() * sizeof(DevRaw));
+                GAMUT_HIP_CHECK(hipMemcpyAsync(d + o_raws + (size_t)raws_done * sizeof(DevRaw), h + o_raws + (size_t)raws_done * sizeof(DevRaw), raws.size() * sizeof(DevRaw), hipMemcpyHostToDevice, copy_stream));
+                raws_done += (int)raws.size();
+            }
             GAMUT_HIP_CHECK(hipEventRecord(group_ready[g], copy_stream));
             const hipStream_t gs = g == 0 ? stream : side[g];
             GAMUT_HIP_CHECK(hipStreamWaitEvent(gs, group_ready[g], 0));
             if (trace) { (void)hipStreamSynchronize(gs); ms_upload = ms_since(t_up) - ms_kernels_issue; }
             const auto t_k = std::chrono::steady_clock::now();
+            if (!raws.empty()) {
+                hipLaunchKernelGGL(k_jpeg_unstuff, dim3((unsigned)raws.size()), dim3(kUnstuffThreads), 0, gs, d_raws, d_items, (const uint8_t*)d_raw, d_blob_w, st);
+                if (int rc = launch_status("jpeg_unstuff")) return rc;
+            }
             if (n_long) {
                 static const int force_nh = [] { const char* e = getenv("GAMUT_HIP_JPEG_TABLES_LDS"); return e && *e ? atoi(e) : -1; }();     // measurements: 0 / 4 / 8
                 if (force_nh == 0) hipLaunchKernelGGL(k_jpeg_entropy_sync<0>, dim3(n_long), dim3(kSyncThreads), 0, gs, d_items, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
@@ -1297,6 +1515,17 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
         GAMUT_HIP_CHECK(hipStreamSynchronize(copy_stream));
         for (int g = 1; g < n_groups; ++g) GAMUT_HIP_CHECK(hipStreamSynchronize(side[g]));
         GAMUT_HIP_CHECK(hipStreamSynchronize(stream));         // the per-thread staging buffers are reused by the next call
+        if (dev_restarts) {                                    // restart markers are checked where the scan is unstuffed: a wrong / missing one is a
+            std::vector<uint32_t> flags((size_t)count);        // header-level failure of the file, as it is when the host finds it (unstuff_file)
+            GAMUT_HIP_CHECK(hipMemcpy(flags.data(), st, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            for (int i = 0; i < count; ++i) {
+                FilePrep& fp = prep[(size_t)i];
+                if (fp.rc == GAMUT_HIP_OK && fp.dev_unstuff && (flags[(size_t)i] & kStatusBadRestart)) {
+                    fail(&info[i], "bad restart marker");
+                    fp.rc = GAMUT_HIP_ERR_DECODE; snprintf(fp.msg, sizeof(fp.msg), "image %d: bad restart marker", i);
+                }
+            }
+        }
         if (trace) fprintf(stderr, "[gamut_hip] jpeg_entropy_decode_device: %d files in %d group(s), %d long + %d short segments, %d+%d tables, %.1f MB compressed, %d host threads: headers %.1f ms, unstuff + upload %.1f ms, kernels %.1f ms (stages serialised by the trace)\n",
                            count, n_groups, total_long, total_short, n_huff, n_quant, blob_size / 1e6, workers, ms_parse, ms_upload, ms_kernels_issue);
     }
@@ -1418,7 +1647,7 @@ int gamut_hip_jpeg_scan_layout(const uint8_t* data, size_t len, gamut_hip_jpeg_f
             return GAMUT_HIP_OK;
         }
         std::vector<uint8_t> bytes(fp.rc == GAMUT_HIP_OK ? fp.cap : 0);
-        if (fp.rc == GAMUT_HIP_OK) unstuff_file(0, data, len, *info, fp, bytes.data());
+        if (fp.rc == GAMUT_HIP_OK) { fp.items.clear(); fp.dev_unstuff = false; unstuff_file(0, data, len, *info, fp, bytes.data()); }   // (the host's walk: exact sizes)
         if (segments) *segments = (int32_t)fp.items.size();
         if (entropy_bytes) *entropy_bytes = fp.used;
         if (fp.rc != GAMUT_HIP_OK) return set_error(fp.rc, "%s", fp.msg);
@@ -1497,14 +1726,39 @@ int gamut_hip_jpeg_decode_batch_device(const uint8_t* const* data, const size_t*
             return GAMUT_HIP_OK;
         };
         hooks.group_done = [&](int lo, int hi, hipStream_t gs) -> int { return reconstruct(lo, hi, gs, false); };
-        const int rc = entropy_decode_device(data, len, count, nullptr, nullptr, nullptr, nullptr, status_dev, info, status_host, st, &hooks);
+        // per-file verdicts: the header-level ones (host) and what the kernels flag (device) are folded into ONE status per file, as
+        // gamut_hip_png_decode_batch_device does -- a caller that passes no status arrays still gets the failure as the return value
+        std::vector<int> own_host; int* hst = status_host;
+        if (!hst) { own_host.assign((size_t)count, GAMUT_HIP_OK); hst = own_host.data(); }
+        static thread_local PerDevice<DeviceScratch> st_pd;
+        uint32_t* d_st = status_dev;
+        if (!d_st) { d_st = (uint32_t*)st_pd.cur().get((size_t)count * sizeof(uint32_t), st); if (!d_st) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg_decode_batch_device: status allocation failed"); }
+        int rc = entropy_decode_device(data, len, count, nullptr, nullptr, nullptr, nullptr, d_st, info, hst, st, &hooks);
+        if (rc != GAMUT_HIP_OK && rc != GAMUT_HIP_ERR_DECODE && rc != GAMUT_HIP_ERR_UNSUPPORTED) return rc;     // not a per-file verdict: allocation / HIP failure
+        char first_msg[200]; snprintf(first_msg, sizeof(first_msg), "%s", last_error_buf());
         // (entropy_decode_device returns when every stream it used has drained: the baseline files' pixels are in place.  The
-        // progressive files' coefficients were decoded after the groups: their pixels follow here.)
+        // progressive files' coefficients were decoded after the groups: their pixels follow here -- not those of a file whose scans
+        // could not be prepared: its share of the coefficient scratch holds whatever an earlier batch left there.)
         if (d_co) {
+            for (int i = 0; i < count; ++i) if (prog[(size_t)i] && hst[i] != GAMUT_HIP_OK) ok[(size_t)i] = 0;
             if (int rc2 = reconstruct(0, count, st, true)) return rc2;
+            std::vector<uint32_t> flags((size_t)count);
+            GAMUT_HIP_CHECK(hipMemcpyAsync(flags.data(), d_st, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             GAMUT_HIP_CHECK(hipStreamSynchronize(st));          // the per-thread coefficient scratch is reused by the next call
+            int first = -1;
+            for (int i = 0; i < count; ++i) {
+                if (hst[i] == GAMUT_HIP_OK && flags[(size_t)i]) {       // a damaged entropy-coded segment: the file's pixels are what the decode of the damage gives
+                    hst[i] = GAMUT_HIP_ERR_DECODE;
+                    if (first < 0) first = i;
+                }
+            }
+            int lowest = -1;
+            for (int i = 0; i < count; ++i) if (hst[i] != GAMUT_HIP_OK) { lowest = i; break; }
+            if (lowest >= 0 && lowest == first) return set_error(GAMUT_HIP_ERR_DECODE, "image %d: corrupt entropy-coded data", first);
+            if (lowest >= 0) return set_error(hst[lowest], "%s", first_msg[0] ? first_msg : "jpeg_decode_batch_device: a file failed");
         }
-        return rc;
+        if (rc != GAMUT_HIP_OK) return set_error(rc, "%s", first_msg);
+        return GAMUT_HIP_OK;
     } catch (...) {
         return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg_decode_batch_device: out of host memory");
     }

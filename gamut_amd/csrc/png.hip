@@ -457,6 +457,9 @@ constexpr int ROW_PITCH = RING * 16;              // 256 B: lane j's slot (T - j
 #ifndef PNG_NT_STORES
 #define PNG_NT_STORES 1
 #endif
+#ifndef PNG_AL_PAETH             // line-aligned loads in bands with Paeth rows too?  No: those bands are bound by vector instructions (188 per 16-byte trip),
+#define PNG_AL_PAETH 0           // and the byte-unaligned ds_write_b128 of the aligned drop runs at a lane per LDS cycle (SQ_LDS_IDX_ACTIVE x 3,
+#endif                           // profiles/r04_png_sq.txt): 512 x 4K with random filters 8.18 ms with, 8.02 without; bands without Paeth rows are bound by HBM
 #ifndef PNG_Q_NO_CHUNK           // ablation only (wrong pixels): the queue kernel without its loads of the row above the band
 #define PNG_Q_NO_CHUNK 0
 #endif
@@ -470,14 +473,28 @@ constexpr int ROW_PITCH = RING * 16;              // 256 B: lane j's slot (T - j
 // progress word is an agent-scope relaxed store behind the counted vmcnt wait, the consumer polls that word relaxed and reads
 // the row with sc1 loads (no fence on either side, nothing depends on which XCD runs what).  prog = the image's progress
 // words (one per band) instead of the workgroup's per-wave ones.
-template <int FB, int W, bool PAETH, bool RGBA, bool Q = false>
+// AL = line-aligned loads of the filtered stream.  A row of the stream starts at an odd byte address (every row is wb + 1 bytes), so
+// the 128 contiguous bytes a row needs per tile straddle two 128-byte lines of memory and every line is fetched by two consecutive
+// tiles; with every wave slot of the chip streaming (512 x 4K images) the second touch misses the L2 more often than not --
+// rocprofv3: 51.4 MB read per 33.2 MB image, 1.55 x (profiles/r04_png_reads.txt; 2.02 x with nontemporal loads, 1.09 x at batch 64).
+// Here the eight lanes of a row fetch ONE whole aligned line per tile, as eight aligned 16-byte chunks; a chunk is dropped into the
+// row's ring at the byte offset it has in the row (an unaligned ds_write_b128; the ring is a byte line of 256 bytes with 16-byte guards
+// at both ends, a chunk that crosses the end is written at both places), and the part of the line that belongs to the NEXT tile (the
+// chunks behind the row's phase P) waits in the lanes' registers for the next drop: every line is read exactly once, nothing else
+// changes -- pieces, DPP hand-over, write-back are those of the row-aligned grid.  The ring must start out zero (a row's first
+// pieces are no longer all written by drops).
+template <int FB, int W, bool PAETH, bool RGBA, bool Q = false, bool AL = false>
 __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const uint8_t* raw, uint8_t* D, u32* prog, uint8_t* ring, u32 band,
                                                int wave, int lane, u32 niter, u32 f, bool row_live, u32* status = nullptr)
 {
     static_assert(!RGBA || FB == 3, "alpha insertion is the 8-bit RGB case");
+    static_assert(!(AL && RGBA), "the alpha-inserting walk has 12-byte pieces: its ring is not a byte line of the row");
     constexpr int IB = RGBA ? 12 : 16;            // stream bytes per piece
     constexpr int PW = 4;                         // dwords per piece
+    constexpr int PITCH = AL ? ROW_PITCH + 32 : ROW_PITCH;      // AL: guards; 288 keeps the per-lane ds_read_b128 pattern conflict-free ((T + lane) mod 16)
+    constexpr int GUARD = AL ? 16 : 0;
     typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    struct __attribute__((packed, aligned(1))) AnyVec { u32x4 v; };
     const u32 seq = Q ? 0u : band / W;
     const u32 row = band * 64 + lane;
     const RowFilter rf = row_filter(f);
@@ -499,8 +516,13 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
     // row crow of the band if the image has it, else the band's first row; + 8k rows per transfer
     const uint8_t* craw = raw + (int64_t)(band * 64 + ((u32)crow < rows_left ? crow : 0)) * (a.wb + 1) + 1;
     uint8_t* cdst = D + (int64_t)(band * 64 + crow) * a.d_pitch;
-    uint8_t* my_ring = ring + lane * ROW_PITCH;
-    uint8_t* co_ring = ring + crow * ROW_PITCH;                         // + k * 8 * ROW_PITCH + slot * 16
+    uint8_t* dband = nullptr;                                           // the band's first output row (wave-uniform: the fast write-back adds lane offsets)
+    if constexpr (AL) {
+        const int64_t bo = (int64_t)(band * 64) * a.d_pitch;
+        dband = D + (int64_t)(((uint64_t)(u32)__builtin_amdgcn_readfirstlane((int)((uint64_t)bo >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)(uint64_t)bo));
+    }
+    uint8_t* my_ring = ring + lane * PITCH + GUARD;
+    uint8_t* co_ring = ring + crow * PITCH + GUARD;                     // + k * 8 * PITCH + slot * 16
 
     u32 outp[PW], bprev[PW];                      // previous piece of this lane's row (de-filtered) and of the row above it
     #pragma unroll
@@ -540,7 +562,75 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
     };
 
     uint4 pre[TT];                                  // next tile's raw pieces (cooperative layout)
+    // AL: per transfer k (row 8k + crow of the band): the address of "chunk 0" of the row = row start - S' (16-byte aligned, S' = 1..16
+    // bytes in front of the row's first byte), S', and the row's phase P = position in its memory line of the last chunk a tile needs.
+    // The general forms (al_row, prefetch_line, drop_al) recompute them where they are needed: the first and the last tiles of a band.
+    // The tiles in between (nothing in front of a row, nothing behind it, 64 live rows) take the *_fast forms, which run on a few
+    // per-row constants kept in registers: the tile overhead (drop + prefetch + write-back) was 580 of a tile's 2 080 instructions with
+    // Paeth rows and of 1 340 without.
+    uint4 pre_old[AL ? TT : 1];
+    auto al_row = [&](int k, const uint8_t*& c0, int& Sp, int& P) {
+        const u32 rowk = (u32)(8 * k + crow);
+        const u32 rlive = rowk < rows_left ? rowk : 0u;                 // rows past the image read a live row of the band (unused)
+        const uint8_t* row0 = raw + (int64_t)(band * 64 + rlive) * (a.wb + 1) + 1;
+        const u32 S = (u32)(reinterpret_cast<uintptr_t>(row0) & 15u);
+        Sp = S ? (int)S : 16;
+        const u32 q = (u32)((reinterpret_cast<uintptr_t>(row0) - (u32)Sp) >> 4) & 7u;
+        c0 = row0 - Sp;
+        P = (int)((q - rowk) & 7u);
+    };
+    // fast forms: byte offset of the chunk prefetch_line(0) would fetch, from a wave-uniform base (+ 16 T0 per tile); ring offset of the
+    // chunk drop_al(0) would write (its low 8 bits: + 16 T0 mod 256 flips bit 7 every other tile); which lanes drop the fresh line
+    const uint8_t* ubase = nullptr;
+    u32 pfo[AL ? TT : 1], olow[AL ? TT : 1], freshbits = 0;
+    if constexpr (AL) {
+        // (a wave-uniform byte offset from `raw`, said so to the compiler half by half: the loads then take a scalar base and a
+        // 32-bit lane offset; - 2048 keeps the lane offsets positive whatever a row's constants)
+        const int64_t uo = (int64_t)band * 64 * (a.wb + 1) - 2048;
+        ubase = raw + (int64_t)(((uint64_t)(u32)__builtin_amdgcn_readfirstlane((int)((uint64_t)uo >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)(uint64_t)uo));
+        #pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint8_t* c0; int Sp, P;
+            al_row(k, c0, Sp, P);
+            const int cconst = -(8 * k + crow) + 8 - P + cslot;                            // prefetch_line(T0): chunk T0 + cconst
+            pfo[k] = (u32)((int64_t)(c0 - ubase) + (int64_t)cconst * 16);
+            const bool fresh = cslot <= P;
+            const int dconst = cconst - (fresh ? 0 : 8);                                   // drop_al(T0): chunk T0 + dconst, row byte 16 (T0 + dconst) - S'
+            olow[k] = (u32)(dconst * 16 - Sp) & 255u;
+            freshbits |= fresh ? 1u << k : 0u;
+            pre_old[k] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    auto prefetch_line = [&](int T0) {              // chunk (T0 - row) + 8 - P + cslot of every row: phase cslot of the line that ends tile T0's needs
+        if constexpr (AL) {
+            #pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint8_t* c0; int Sp, P;
+                al_row(k, c0, Sp, P);
+                int c = T0 - (8 * k + crow) + 8 - P + cslot;
+                const int c_first = Sp == 16 ? 1 : 0, c_last = (int)((a.wb - 1 + (u32)Sp) >> 4);
+                c = c < c_first ? c_first : c > c_last ? c_last : c;    // never an address outside the row (a chunk that holds a byte of it is inside its page)
+                const u32x4 v = *reinterpret_cast<const u32x4*>(c0 + (int64_t)c * 16);
+                pre[k] = make_uint4(v.x, v.y, v.z, v.w);
+            }
+        }
+    };
+    auto prefetch_fast = [&](u32 T0) {              // the same where no chunk can leave its row: one add and one load per row
+        if constexpr (AL) {
+            #pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(ubase + (size_t)(pfo[k] + 16u * T0));
+                pre[k] = make_uint4(v.x, v.y, v.z, v.w);
+            }
+        }
+    };
+    // the tiles that may take the fast forms (wave-uniform)
+    const bool al_full = AL && rows_left >= 64;
+    auto fast_prefetch_ok = [&](u32 T0) { return al_full && T0 >= 64 && T0 + 16 <= full_iters; };      // chunks T0 - 62 .. T0 + 15 of every row exist
+    auto fast_drop_ok     = [&](u32 T0) { return al_full && T0 >= 72; };                                  // no chunk in front of its row
+    auto fast_wb_ok       = [&](u32 T0) { return al_full && T0 >= 64 && T0 + 8 <= wb_iters; };            // every row writes a whole group
     auto prefetch_tile = [&](u32 T0) {
+        if constexpr (AL) { if (fast_prefetch_ok(T0)) prefetch_fast(T0); else prefetch_line((int)T0); return; }
         #pragma unroll
         for (int k = 0; k < 8; ++k) {
             int it = (int)T0 + cslot - (8 * k + crow);                                     // piece of row 8k+crow used in trip T0 + cslot
@@ -568,7 +658,7 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
     // tile (8 pieces = 128 bytes, one piece per lane 0..7, sc1 loads) ahead, parked in 128 bytes of LDS behind the wave's ring at
     // the start of the tile that uses it, and every trip reads its piece from there (one broadcast ds_read).
     u32x4 chunk = { 0u, 0u, 0u, 0u };
-    uint8_t* const dch = ring + 64 * ROW_PITCH;
+    uint8_t* const dch = ring + 64 * PITCH;
     auto issue_chunk = [&](u32 Tbase) {
         const u32 piece = min(Tbase + (u32)(lane & 7), niter - 1);
 #if !PNG_Q_NO_CHUNK
@@ -582,6 +672,54 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
         if (band > 0) wait_for_band_above(TT);
         issue_chunk(0);
     } else if (band > 0) wait_for_band_above(PUB + PF);
+    // AL: one 16-byte chunk of every row per lane, at the byte offset it has in the row: from the line fetched for this tile
+    // (phases up to P) or from the one fetched for the tile before (the phases behind P, kept in registers since)
+    auto drop_al = [&](int T0) {
+        if constexpr (AL) {
+            #pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint8_t* c0; int Sp, P;
+                al_row(k, c0, Sp, P);
+                const bool fresh = cslot <= P;
+                const int cd = T0 - (8 * k + crow) - P + cslot + (fresh ? 8 : 0);
+                const int start = cd * 16 - Sp;                                              // row byte of the chunk's first byte
+                uint4 v = fresh ? pre[k] : pre_old[k];
+                if (start < 0) {                                                              // in front of the row: zeros (what a lane that has not
+                    const int n = -start;                                                     // reached its row must find); the row's first chunk: its
+                    u32 w[4] = { v.x, v.y, v.z, v.w };                                        // leading bytes (filter byte, the row before)
+                    #pragma unroll
+                    for (int d = 0; d < 4; ++d) { const int lo = n - 4 * d; w[d] = lo <= 0 ? w[d] : lo >= 4 ? 0u : w[d] & (0xFFFFFFFFu << (8 * lo)); }
+                    v = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+                const u32 o = (u32)start & 255u;
+                uint8_t* dst = co_ring + k * 8 * PITCH + o;
+                reinterpret_cast<AnyVec*>(dst)->v = u32x4{ v.x, v.y, v.z, v.w };
+                if (o > 240u) reinterpret_cast<AnyVec*>(dst - 256)->v = u32x4{ v.x, v.y, v.z, v.w };
+                pre_old[k] = pre[k];
+            }
+        }
+    };
+    auto drop_fast = [&](u32 T0) {                  // nothing in front of any row: the ring offset is a constant of the row, bit 7 flipping every other tile
+        if constexpr (AL) {
+            const u32 flip = (T0 & 8u) << 4;
+            #pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const bool fresh = (freshbits >> k) & 1u;
+                const uint4 v = fresh ? pre[k] : pre_old[k];
+                const u32 o = olow[k] ^ flip;
+                uint8_t* dst = co_ring + k * 8 * PITCH + o;
+                reinterpret_cast<AnyVec*>(dst)->v = u32x4{ v.x, v.y, v.z, v.w };
+                if (o > 240u) reinterpret_cast<AnyVec*>(dst - 256)->v = u32x4{ v.x, v.y, v.z, v.w };
+                pre_old[k] = pre[k];
+            }
+        }
+    };
+    if constexpr (AL) {                             // the ring starts out zero; the line in front of tile 0's goes into the registers first
+        #pragma unroll
+        for (int i = 0; i < PITCH / 16; ++i) *reinterpret_cast<uint4*>(ring + lane * PITCH + i * 16) = make_uint4(0u, 0u, 0u, 0u);
+        prefetch_line(-TT);
+        drop_al(-TT);                               // row 0's first chunk belongs to the tile in front of tile 0 (for the other rows: zeros onto zeros)
+    }
     prefetch_tile(0);
     if constexpr (!Q) {
         #pragma unroll
@@ -606,18 +744,20 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
         // reached its row yet (iteration < 0: the first 64 trips) finds zeros in its slot: with a zero piece, a zero row above (the
         // lane below is not there yet either) and a zero pixel to the left every filter yields zeros, which is what the lane
         // must present to the lane above it and to its own first pixel -- no per-trip masking.
+        if constexpr (AL) { if (fast_drop_ok(T0)) drop_fast(T0); else drop_al((int)T0); }
+        else
         if (T0 < 64) {
             #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int it = (int)T0 + cslot - (8 * k + crow);
                 const u32 slot = (u32)it & (RING - 1);
-                *reinterpret_cast<uint4*>(co_ring + k * 8 * ROW_PITCH + slot * 16) = it < 0 ? make_uint4(0u, 0u, 0u, 0u) : pre[k];
+                *reinterpret_cast<uint4*>(co_ring + k * 8 * PITCH + slot * 16) = it < 0 ? make_uint4(0u, 0u, 0u, 0u) : pre[k];
             }
         } else {
             #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const u32 slot = (T0 + (u32)cslot - (u32)(8 * k + crow)) & (RING - 1);
-                *reinterpret_cast<uint4*>(co_ring + k * 8 * ROW_PITCH + slot * 16) = pre[k];
+                *reinterpret_cast<uint4*>(co_ring + k * 8 * PITCH + slot * 16) = pre[k];
             }
         }
         prefetch_tile(T0 + TT);
@@ -645,7 +785,7 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
                 if constexpr (Q) dch_next = *reinterpret_cast<const u32x4*>(dch + (u + 1) * 16);
             }
             u32 rg[PW] = { rv.x, rv.y, rv.z, rv.w }, bg[PW];
-            if (rag_tile) {             // last, partial piece of a row: the staged piece is the row's LAST 16 bytes (see prefetch_tile);
+            if (!AL && rag_tile) {      // last, partial piece of a row: the staged piece is the row's LAST 16 bytes (see prefetch_tile);
                 if (ragged) {           // keep its top nb bytes, moved down by 16 - nb bytes (zeros come in behind).  No memory op here.
                     const u32 sh = IB - (a.wb - (u32)it * IB), ds = sh >> 2, bs = sh & 3;
                     u32 w[5];
@@ -709,10 +849,34 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
 
         // write back the group of 8 pieces each row completed with this tile: one aligned 128-byte run per row
         uint4 wbv[8];                               // all eight LDS reads first: one wait instead of eight round trips in a row
+        if (AL && fast_wb_ok(T0)) {
+            // every row of the band writes a whole group: piece it = T0 - 8 k - 8 [crow > 0] + cslot of row 8 k + crow.  Its ring slot is
+            // (cslot | 8 [crow > 0] ^ 8 [k odd] ^ (T0 & 8)): two addresses per tile; its place in the output is a lane constant
+            // minus 128 k behind a wave-uniform row pointer -- no predicates, no per-row address arithmetic
+            const u32 flip = (T0 & 8u) << 4;
+            const u32 base_w = ((crow ? 128u : 0u) | ((u32)cslot << 4)) ^ flip;
+            const uint8_t* rd[2] = { co_ring + base_w, co_ring + (base_w ^ 128u) };
+            #pragma unroll
+            for (int k = 0; k < 8; ++k) wbv[k] = *reinterpret_cast<const uint4*>(rd[k & 1] + k * 8 * PITCH);
+            const u32 itbase = T0 - (crow ? 8u : 0u) + (u32)cslot;
+            const u32 goff0 = (u32)crow * (u32)a.d_pitch + itbase * 16u;                  // (d_pitch * 64 < 2^31: checked by the launcher)
+            #pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint4 v = wbv[k];
+                u32x4* dst = reinterpret_cast<u32x4*>(dband + (int64_t)(8 * k) * a.d_pitch + (size_t)(goff0 - 128u * (u32)k));
+                if (Q && k == 7) {
+                    if (crow == 7) __builtin_amdgcn_raw_buffer_store_b128(u32x4{ v.x, v.y, v.z, v.w }, rs_last, (itbase - 56u) * 16u, 0, 16);   // row 63: sc1
+                    else if (PNG_NT_STORES) __builtin_nontemporal_store(u32x4{ v.x, v.y, v.z, v.w }, dst);
+                    else *dst = u32x4{ v.x, v.y, v.z, v.w };
+                }
+                else if (PNG_NT_STORES) __builtin_nontemporal_store(u32x4{ v.x, v.y, v.z, v.w }, dst);
+                else               *dst = u32x4{ v.x, v.y, v.z, v.w };
+            }
+        } else {
         #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int it = (((int)T0 - (8 * k + crow)) & ~7) + cslot;
-            wbv[k] = *reinterpret_cast<const uint4*>(co_ring + k * 8 * ROW_PITCH + ((u32)it & (RING - 1)) * 16);
+            wbv[k] = *reinterpret_cast<const uint4*>(co_ring + k * 8 * PITCH + ((u32)it & (RING - 1)) * 16);
         }
         #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -724,6 +888,7 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
                 else if (PNG_NT_STORES) __builtin_nontemporal_store(u32x4{ v.x, v.y, v.z, v.w }, dst);
                 else               *dst = u32x4{ v.x, v.y, v.z, v.w };
             }
+        }
         }
         // publish what lane 63 had written back BEFORE this tile (groups below floor((T0 - 63) / 8)): since then this
         // tile issued 8 prefetch loads and 8 row-above loads, so "at most 16 vector-memory operations outstanding" implies
@@ -741,11 +906,11 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
     publish(seq * niter + niter);
 }
 
-template <int FB, int W, int MINW, bool RGBA = false>
+template <int FB, int W, int MINW, bool RGBA = false, bool AL = false>
 __global__ __launch_bounds__(W * 64, MINW) void k_png_defilter_ring(DefilterArgs a)
 {
     __shared__ u32 prog[W];
-    __shared__ __attribute__((aligned(16))) uint8_t tiles[W][64 * ROW_PITCH];
+    __shared__ __attribute__((aligned(16))) uint8_t tiles[W][64 * (AL ? ROW_PITCH + 32 : ROW_PITCH)];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int img; const uint8_t* raw; uint8_t* D;
     if (!take_segment(a, img, raw, D)) return;
@@ -759,8 +924,8 @@ __global__ __launch_bounds__(W * 64, MINW) void k_png_defilter_ring(DefilterArgs
         const bool row_live = row < a.rows;
         u32 f = row_live ? raw[(int64_t)row * (a.wb + 1)] : 0;
         if (f > 4) { if (a.status) atomicOr(a.status + img, 1u); f = 0; }
-        if (__any(f == 4)) defilter_band_ring<FB, W, true,  RGBA>(a, raw, D, prog, tiles[wave], band, wave, lane, niter, f, row_live);
-        else               defilter_band_ring<FB, W, false, RGBA>(a, raw, D, prog, tiles[wave], band, wave, lane, niter, f, row_live);
+        if (__any(f == 4)) defilter_band_ring<FB, W, true,  RGBA, false, AL && PNG_AL_PAETH>(a, raw, D, prog, tiles[wave], band, wave, lane, niter, f, row_live);
+        else               defilter_band_ring<FB, W, false, RGBA, false, AL>(a, raw, D, prog, tiles[wave], band, wave, lane, niter, f, row_live);
     }
 }
 
@@ -774,10 +939,10 @@ __global__ __launch_bounds__(W * 64, MINW) void k_png_defilter_ring(DefilterArgs
 // oldest unit in flight never waits, so the queue cannot deadlock whatever the number of resident workgroups -- and by the time
 // a wave draws (i, b) the band above it has usually had the ~80 trips of head start it needs (lane 63 of a band runs 63 pieces
 // behind its lane 0), so waves rarely sit waiting.
-template <int FB, int W, int MINW, bool RGBA = false>
+template <int FB, int W, int MINW, bool RGBA = false, bool AL = false>
 __global__ __launch_bounds__(W * 64, MINW) void k_png_defilter_queue(DefilterArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t tiles[W][64 * ROW_PITCH + 128];      // a wave's ring + 128 bytes of the row above its band
+    __shared__ __attribute__((aligned(16))) uint8_t tiles[W][64 * (AL ? ROW_PITCH + 32 : ROW_PITCH) + 128];      // a wave's ring + 128 bytes of the row above its band
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     constexpr u32 IB = RGBA ? 12 : 16;
     const u32 niter = (a.wb + IB - 1) / IB;
@@ -799,8 +964,8 @@ __global__ __launch_bounds__(W * 64, MINW) void k_png_defilter_queue(DefilterArg
         u32 f = row_live ? raw[(int64_t)row * (a.wb + 1)] : 0;
         if (f > 4) { if (a.status) atomicOr(a.status + img, 1u); f = 0; }
         u32* st = a.status ? a.status + img : nullptr;
-        if (__any(f == 4)) defilter_band_ring<FB, W, true,  RGBA, true>(a, raw, D, prog, tiles[wave], band, wave, lane, niter, f, row_live, st);
-        else               defilter_band_ring<FB, W, false, RGBA, true>(a, raw, D, prog, tiles[wave], band, wave, lane, niter, f, row_live, st);
+        if (__any(f == 4)) defilter_band_ring<FB, W, true,  RGBA, true, AL && PNG_AL_PAETH>(a, raw, D, prog, tiles[wave], band, wave, lane, niter, f, row_live, st);
+        else               defilter_band_ring<FB, W, false, RGBA, true, AL>(a, raw, D, prog, tiles[wave], band, wave, lane, niter, f, row_live, st);
     }
 }
 
@@ -1031,6 +1196,9 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
     // latency between the waves of one image's pipeline; the queue needs count * bands / (8 CUs) rounds whatever the filters.
     // Measured (RGBA8, Mpx/s, workgroups / queue): 341 x 1080p 374 k / 478 k, 64 x 4K 106 k / 240 k, 256 x 4K 202 k / 533 k,
     // 384 x 4K 365 k / 595 k, 512 x 4K 616 k / 643 k (random filters 512 k / 529 k): the queue from 1024 units on.
+    // line-aligned loads of the stream (defilter_band_ring<..., AL>): rows of at least two lines; GAMUT_HIP_PNG_ALIGNED=0 / 1 forces either
+    const char* al_env = getenv("GAMUT_HIP_PNG_ALIGNED");
+    const bool aligned = !rgba_fused && wb >= 16 && (al_env && *al_env ? atoi(al_env) != 0 : wb >= 256);
     const char* queue_env = getenv("GAMUT_HIP_PNG_QUEUE");       // read per call: tests flip it
     const uint64_t units = (uint64_t)count * nbands;
     bool queue = wb >= 16 && (int64_t)a.d_pitch * 64 < (1ll << 31) && units < (1ull << 31) &&
@@ -1052,7 +1220,8 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
         const dim3 qgrid(wgs), qblock(PNG_WAVES * 64);
         if (rgba_fused) hipLaunchKernelGGL((k_png_defilter_queue<3, PNG_WAVES, 2, true>), qgrid, qblock, 0, stream, a);
         else switch (FB) {
-#define GAMUT_PNG_CASE(N) case N: hipLaunchKernelGGL((k_png_defilter_queue<N, PNG_WAVES, 2>), qgrid, qblock, 0, stream, a); break;
+#define GAMUT_PNG_CASE(N) case N: if (aligned) hipLaunchKernelGGL((k_png_defilter_queue<N, PNG_WAVES, 2, false, true>), qgrid, qblock, 0, stream, a); \
+                                  else         hipLaunchKernelGGL((k_png_defilter_queue<N, PNG_WAVES, 2>), qgrid, qblock, 0, stream, a); break;
         GAMUT_PNG_CASE(1) GAMUT_PNG_CASE(2) GAMUT_PNG_CASE(3) GAMUT_PNG_CASE(4) GAMUT_PNG_CASE(6) GAMUT_PNG_CASE(8)
 #undef GAMUT_PNG_CASE
         default: return set_error(GAMUT_HIP_ERR_INVALID_ARG, "png_defilter: unsupported filter unit %d", FB);
@@ -1066,7 +1235,8 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
     const bool ring = wb >= 16;
     if (rgba_fused) hipLaunchKernelGGL((k_png_defilter_ring<3, PNG_WAVES, 2, true>), grid, block, 0, stream, a);
     else switch (FB) {
-#define GAMUT_PNG_CASE(N) case N: if (ring) hipLaunchKernelGGL((k_png_defilter_ring<N, PNG_WAVES, 2>), grid, block, 0, stream, a); \
+#define GAMUT_PNG_CASE(N) case N: if (ring && aligned) hipLaunchKernelGGL((k_png_defilter_ring<N, PNG_WAVES, 2, false, true>), grid, block, 0, stream, a); \
+                                  else if (ring) hipLaunchKernelGGL((k_png_defilter_ring<N, PNG_WAVES, 2>), grid, block, 0, stream, a); \
                                   else      hipLaunchKernelGGL((k_png_defilter<N, PNG_WAVES>), grid, block, 0, stream, a); break;
     GAMUT_PNG_CASE(1) GAMUT_PNG_CASE(2) GAMUT_PNG_CASE(3) GAMUT_PNG_CASE(4) GAMUT_PNG_CASE(6) GAMUT_PNG_CASE(8)
 #undef GAMUT_PNG_CASE

@@ -331,6 +331,23 @@ int   gamut_hip_qoi_decode_resident_device(const uint8_t* blob, int64_t blob_len
                                            const gamut_hip_qoi_desc* descs, int count, int channels, const int64_t* out_offset,
                                            uint8_t* out, void* stream);
 
+/* ---- files of any of the three formats, one call ---------------------------------------------------------------------
+ * The reference loads any file through Image.loadFromMemory: identifyFormatFromStream (image.d:1045-1061 -- the plugins' detect
+ * procedures, a signature test each: plugins/jpeg.d:106-110, png.d:165-169, qoi.d:143-147) picks g_plugins[fif].loadProc
+ * (image.d:1751-1772).  gamut_hip_identify_format is that test (GAMUT_HIP_FORMAT_*, the ImageFormat ordinals of types.d:14-21, or
+ * GAMUT_HIP_FORMAT_UNKNOWN); gamut_hip_decode_batch_device takes `count` files of ANY of the three formats in host memory and
+ * leaves rows of width * req_comps bytes (req_comps = 3 / 4: rgb8 / rgba8, what all three decoders produce; 16-bit PNG samples
+ * are reduced as stbi_load does) at out + out_offset[i] (device) -- BASELINE.json config 5 from files in one call.  It is the three
+ * per-format batch calls run SIDE BY SIDE, each on a stream of its own behind `stream` and on a worker thread of the library: the
+ * PNG leg is bound by the inflate kernels while the QOI leg is bound by PCIe, and the JPEG leg is short.  info[i] receives format
+ * and geometry, status_host[i] (may be NULL) the file's status (GAMUT_HIP_ERR_UNSUPPORTED: format not identified).  Returns when
+ * the pixels are in place; the status of the lowest-numbered failing file, GAMUT_HIP_OK if none. */
+enum { GAMUT_HIP_FORMAT_UNKNOWN = -1, GAMUT_HIP_FORMAT_JPEG = 0, GAMUT_HIP_FORMAT_PNG = 1, GAMUT_HIP_FORMAT_QOI = 2 };
+typedef struct gamut_hip_image_info { int32_t format, width, height, channels_in_file, channels; } gamut_hip_image_info;
+int gamut_hip_identify_format(const uint8_t* data, size_t len);
+int gamut_hip_decode_batch_device(const uint8_t* const* data, const size_t* len, int count, int req_comps,
+                                  const int64_t* out_offset, uint8_t* out, gamut_hip_image_info* info, int* status_host, void* stream);
+
 /* ---- multi-GPU (north_star: "image-index round-robin, RCCL over xGMI only for the gather of decoded outputs") --
  * One process per GPU.  Images are independent, so the data path has no collective: image i of a batch belongs to rank
  * i % world and is the (i / world)-th image that rank holds.  The reference has no counterpart (single-threaded library);

@@ -481,6 +481,90 @@ def test_device_entropy_decode_corrupt_streams(hip):
         assert np.array_equal(res[i][0], d.coeffs) and np.array_equal(res[i][1], d.max_zag)
 
 
+@pytest.fixture(params=["device", "host"])
+def unstuff_site(request):
+    """where the 0x00 stuffing is dropped and the restart markers are found: k_jpeg_unstuff (the scan uploaded as it is) or host threads"""
+    old = os.environ.get("GAMUT_HIP_JPEG_UNSTUFF")
+    os.environ["GAMUT_HIP_JPEG_UNSTUFF"] = request.param
+    yield request.param
+    if old is None:
+        del os.environ["GAMUT_HIP_JPEG_UNSTUFF"]
+    else:
+        os.environ["GAMUT_HIP_JPEG_UNSTUFF"] = old
+
+
+def _restart_files():
+    import io
+    from PIL import Image
+    import gen
+    big = Image.fromarray(gen.synth_rgb(1920, 1080, 31))
+    mid = Image.fromarray(gen.synth_rgb(517, 389, 32))
+    noisy = Image.fromarray(np.random.default_rng(5).integers(0, 256, (300, 420, 3), dtype=np.uint8))     # many 0xFF bytes in the scan
+    blobs = []
+    for im, kw in ((big, dict(quality=90, subsampling=2)), (big, dict(quality=95, subsampling=2, restart_marker_rows=1)),
+                   (big, dict(quality=85, subsampling=0, restart_marker_rows=4)), (mid, dict(quality=92, subsampling=1, restart_marker_blocks=7)),
+                   (mid, dict(quality=75, subsampling=2, restart_marker_blocks=1)), (noisy, dict(quality=100, subsampling=0)),
+                   (noisy, dict(quality=98, subsampling=2, restart_marker_rows=2)), (mid.convert("L"), dict(quality=90, restart_marker_rows=3)),
+                   (mid, dict(quality=90, subsampling=2, optimize=True, restart_marker_rows=1))):
+        bio = io.BytesIO(); im.save(bio, "JPEG", **kw); blobs.append(bio.getvalue())
+    return blobs
+
+
+def test_device_unstuff_equals_host_unstuff(hip, unstuff_site):
+    """the scan as it is in the file -> unstuffed, padded, cut at its restart markers: on the device (k_jpeg_unstuff: get_bits_no_markers'
+    FF00 rule jpegload.d:722-743, process_restart :2335-2402) and on the host threads -- the coefficients must be the oracle's either way:
+    no restart markers, a marker per MCU row (long segments), every few blocks (a lane each), a marker per block (tiny: the host's share
+    unless forced), noise at q 100 (an 0xFF every few hundred bytes), optimised tables"""
+    blobs = _restart_files() + [open(p, "rb").read() for p in JPEGS if "_rst" in p or "cfg1" in p]
+    rc, hst, st, res = _entropy_decode_device(hip, blobs)
+    assert rc == 0 and hst == [0] * len(blobs) and not st.any(), (rc, hst, st, hip.gamut_hip_last_error())
+    for data, (co, zz, info) in zip(blobs, res):
+        d = O.DecodedJpeg(data)
+        assert np.array_equal(co, d.coeffs) and np.array_equal(zz, d.max_zag)
+
+
+def test_device_unstuff_restart_marker_errors(hip, unstuff_site):
+    """a wrong RSTn number and a missing restart marker fail the FILE (JPGD_BAD_RESTART_MARKER, jpegload.d:2360-2364), whoever finds
+    them; its neighbours decode; a scan that ends with a lone 0xFF, or without EOI, is data up to its last byte"""
+    import io
+    from PIL import Image
+    import gen
+    bio = io.BytesIO(); Image.fromarray(gen.synth_rgb(640, 480, 33)).save(bio, "JPEG", quality=90, subsampling=2, restart_marker_rows=2)
+    good = bio.getvalue()
+    sos = good.index(b"\xff\xda")
+    k = good.index(b"\xff\xd3", sos)
+    wrong = good[:k + 1] + b"\xd5" + good[k + 2:]                                  # RST3 -> RST5
+    missing = good[:k] + good[k + 2:]                                             # RST3 removed: the segment runs on into RST4
+    bio = io.BytesIO(); Image.fromarray(gen.synth_rgb(333, 222, 34)).save(bio, "JPEG", quality=88, subsampling=2)
+    plain = bio.getvalue()
+    blobs = [good, wrong, missing, good, plain[:-2], plain[:-2] + b"\xff", plain]
+    rc, hst, st, res = _entropy_decode_device(hip, blobs)
+    assert hst[1] == _capi.ERR_DECODE and hst[2] == _capi.ERR_DECODE and rc == _capi.ERR_DECODE
+    assert b"restart marker" in hip.gamut_hip_last_error()
+    assert [hst[i] for i in (0, 3, 4, 5, 6)] == [0] * 5 and not st[[0, 3, 4, 6]].any()
+    d = O.DecodedJpeg(good)
+    for i in (0, 3):
+        assert np.array_equal(res[i][0], d.coeffs) and np.array_equal(res[i][1], d.max_zag)
+    d = O.DecodedJpeg(plain)
+    for i in (4, 6):
+        assert np.array_equal(res[i][0], d.coeffs) and np.array_equal(res[i][1], d.max_zag)
+
+
+def test_files_to_pixels_reports_damaged_entropy_data(hip):
+    """gamut_hip_jpeg_decode_batch_device folds what the kernels flag into the per-file status and the return value (no status array
+    needed to learn that a scan was damaged), like the PNG batch call; the neighbours' pixels are the oracle's"""
+    import io
+    from PIL import Image
+    import gen
+    bio = io.BytesIO(); Image.fromarray(gen.synth_rgb(800, 600, 35)).save(bio, "JPEG", quality=90, subsampling=2)
+    good = bio.getvalue()
+    cut = good[:len(good) // 2]                                                   # the scan ends half-way: blocks are missing
+    rc, hst, res = _decode_batch_device(hip, [good, cut, good], 4)
+    assert rc == _capi.ERR_DECODE and hst[0] == 0 and hst[2] == 0 and hst[1] == _capi.ERR_DECODE
+    exp = O.decompress_jpeg(good, 4)[0]
+    assert np.array_equal(res[0], exp) and np.array_equal(res[2], exp)
+
+
 @pytest.mark.parametrize("scan_type,w,h", [(4, 16384, 17), (4, 17, 16384), (1, 16384, 9), (2, 16383, 8), (0, 9, 16384)])
 def test_maximum_dimensions(hip, scan_type, w, h):
     """the reference accepts up to 16384 x 16384 (jpegload.d:101-102): the widest and the tallest frames, every tuned kernel"""

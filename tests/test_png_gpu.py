@@ -54,17 +54,22 @@ def gpu_defilter(L, raw, x, y, img_n, out_n, depth, color, count=1, raw_stride=0
     return outs
 
 
-@pytest.fixture(params=["workgroups", "queue"])
+@pytest.fixture(params=["workgroups", "queue", "workgroups+aligned", "queue+aligned"])
 def launch_mode(request):
     """the two launch shapes of the ring kernels (png.hip): one workgroup per image / row segment, or every (image, band) unit
-    of the batch through the device-wide work queue (the launcher's own rule picks the queue for large, badly dividing batches)"""
-    old = os.environ.get("GAMUT_HIP_PNG_QUEUE")
-    os.environ["GAMUT_HIP_PNG_QUEUE"] = "1" if request.param == "queue" else "0"
+    of the batch through the device-wide work queue (the launcher's own rule picks the queue for large, badly dividing batches);
+    each with the row-aligned loads of round 1-3 and with the line-aligned loads of round 4 (forced on for every row of at least one
+    piece: the launcher's own rule takes them from 256-byte rows on)"""
+    shape, _, al = request.param.partition("+")
+    old = {k: os.environ.get(k) for k in ("GAMUT_HIP_PNG_QUEUE", "GAMUT_HIP_PNG_ALIGNED")}
+    os.environ["GAMUT_HIP_PNG_QUEUE"] = "1" if shape == "queue" else "0"
+    os.environ["GAMUT_HIP_PNG_ALIGNED"] = "1" if al else "0"
     yield request.param
-    if old is None:
-        del os.environ["GAMUT_HIP_PNG_QUEUE"]
-    else:
-        os.environ["GAMUT_HIP_PNG_QUEUE"] = old
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
 
 
 FORMATS = [(1, 1, 0), (1, 2, 0), (1, 4, 0), (1, 8, 0), (1, 16, 0), (2, 8, 4), (2, 16, 4), (3, 8, 2), (3, 16, 2), (4, 8, 6), (4, 16, 6),

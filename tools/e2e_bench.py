@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--progressive", action="store_true", help="progressive (SOF2) files: libjpeg's default scan script")
+    ap.add_argument("--paths", default="abc", help="which of the three paths to time (a: host feeder, b: device entropy decode, c: files -> pixels)")
     a = ap.parse_args()
     L = _capi.lib()
     _capi.check(L.gamut_hip_init(0))
@@ -93,6 +94,8 @@ def main():
     print(f"batch {B} x {w}x{h} {'progressive' if a.progressive else 'baseline'} 4:2:0, {mb / B * 1e3:.0f} kB/file, restart rows {a.restart_rows}, host threads {a.threads or os.cpu_count()}")
     ref = None
     for name, fn in (("A host feeder + coefficient upload", path_a), ("B device entropy decode", path_b), ("C files -> pixels in one call", path_c)):
+        if name[0].lower() not in a.paths:
+            continue
         best, best_first = 1e9, 0
         for _ in range(a.reps):
             torch.cuda.synchronize()

@@ -293,3 +293,21 @@ def test_d_binding_lists_every_export():
     assert dsrc.index("extern(C)") < dsrc.index("gamut_hip_version")
     for name in ("gamut_hip_tramp_read_jpeg", "gamut_hip_tramp_stb_read", "gamut_hip_tramp_stb_skip", "gamut_hip_tramp_stb_eof"):
         assert re.search(r"extern\(C\)\s+\w+\s+" + name, dsrc), name
+
+
+def test_identify_format_and_mixed_batch_arguments():
+    """gamut_hip_identify_format = the plugins' signature tests (plugins/jpeg.d:106-110, png.d:165-169, qoi.d:143-147); the mixed batch call
+    validates its arguments and, without a GPU, fails loudly"""
+    L = _capi.lib()
+    cases = [(b"\xff\xd8\xff\xe0", 0), (b"\x89PNG\r\n\x1a\n....", 1), (b"qoif\0\0", 2), (b"\x89PNG\r\n", -1), (b"\xff", -1), (b"", -1), (b"GIF89a", -1)]
+    for data, want in cases:
+        buf = np.frombuffer(data + b"\0", np.uint8)
+        assert L.gamut_hip_identify_format(buf.ctypes.data, len(data)) == want, data
+    assert L.gamut_hip_identify_format(None, 10) == -1
+    assert L.gamut_hip_decode_batch_device(None, None, 0, 4, None, None, None, None, None) == 0
+    assert L.gamut_hip_decode_batch_device(None, None, 2, 4, None, None, None, None, None) == _capi.ERR_INVALID_ARG
+    buf = np.frombuffer(b"qoif" + bytes(20), np.uint8)
+    ptrs = (C.c_void_p * 1)(buf.ctypes.data); lens = (C.c_size_t * 1)(buf.size); offs = (C.c_int64 * 1)(0); info = (_capi.ImageInfo * 1)()
+    assert L.gamut_hip_decode_batch_device(ptrs, lens, 1, 2, offs, 1, info, None, None) == _capi.ERR_INVALID_ARG      # req_comps 3 or 4
+    if L.gamut_hip_device_count() == 0:
+        assert L.gamut_hip_decode_batch_device(ptrs, lens, 1, 4, offs, 1, info, None, None) == _capi.ERR_NO_DEVICE

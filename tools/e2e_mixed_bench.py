@@ -68,6 +68,15 @@ def main():
         descs = (_capi.QoiDesc * nq)()
         _capi.check(L.gamut_hip_qoi_decode_batch_device(qp, ql, nq, 4, qoff.ctypes.data_as(P64), out.data_ptr(), descs, None, stream))
 
+    # the same batch through ONE call: gamut_hip_decode_batch_device sniffs the formats and runs the three pipelines side by side
+    allb = [enc[kinds[i % 3]][(i // 3) % D] for i in range(B)]
+    ap_ = (C.c_void_p * B)(*[b.ctypes.data for b in allb]); al_ = (C.c_size_t * B)(*[b.size for b in allb])
+    aoff = np.arange(B, dtype=np.int64) * img
+
+    def run_all():
+        info = (_capi.ImageInfo * B)()
+        _capi.check(L.gamut_hip_decode_batch_device(ap_, al_, B, 4, aoff.ctypes.data_as(P64), out.data_ptr(), info, None, stream))
+
     print(f"mixed batch of {B} x {w}x{h} files ({nj} JPEG {np.mean([b.size for b in jb]) / 1e3:.0f} kB, {npn} PNG {np.mean([b.size for b in pb]) / 1e6:.1f} MB, "
           f"{nq} QOI {np.mean([b.size for b in qb]) / 1e6:.1f} MB) -> rgba8 in HBM; {a.threads} host threads (0 = all; PNG batches this large inflate on the GPU)")
     best = {}
@@ -75,6 +84,14 @@ def main():
         for k, fn in (("jpeg", run_jpeg), ("png", run_png), ("qoi", run_qoi)):
             torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); torch.cuda.synchronize()
             best[k] = min(best.get(k, 1e9), time.perf_counter() - t0)
+    sep = out.clone()
+    out.zero_()
+    t_all = 1e9
+    for rep in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); run_all(); torch.cuda.synchronize()
+        t_all = min(t_all, time.perf_counter() - t0)
+    same = bool(torch.equal(sep, out))
+    del sep
     got = out.cpu().numpy().reshape(B, h, w, 4)
     ok = all(np.array_equal(got[i, :, :, :3], imgs[(i // 3) % D]) for i in idx["png"][:2] + idx["qoi"][:2]) and (got[:, :, :, 3] == 255).all()
     ref = np.array(Image.open(io.BytesIO(enc["jpeg"][0].tobytes())).convert("RGB")).astype(int)
@@ -82,7 +99,9 @@ def main():
     for k, n in (("jpeg", nj), ("png", npn), ("qoi", nq)):
         print(f"  {k:4s} {n:4d} files  {best[k] * 1e3:9.1f} ms  {n * w * h / best[k] / 1e6:10.1f} Mpx/s")
     tot = sum(best.values())
-    print(f"  all  {B:4d} files  {tot * 1e3:9.1f} ms  {B * w * h / tot / 1e6:10.1f} Mpx/s   pixels {'ok' if ok else 'MISMATCH'}")
+    print(f"  all  {B:4d} files  {tot * 1e3:9.1f} ms  {B * w * h / tot / 1e6:10.1f} Mpx/s   pixels {'ok' if ok else 'MISMATCH'}   (the three calls one after the other)")
+    print(f"  ONE CALL (gamut_hip_decode_batch_device: formats sniffed, pipelines side by side)  {t_all * 1e3:9.1f} ms  {B * w * h / t_all / 1e6:10.1f} Mpx/s   "
+          f"pixels {'== the three calls' if same else 'DIFFER from the three calls'}")
 
 
 if __name__ == "__main__":

@@ -126,20 +126,43 @@ struct PinnedScratch {                  // page-locked host memory: uploads from
     }
 };
 
+// Is [p, p + n) page-locked host memory the device can read by DMA as it stands (hipHostMalloc / gamut_hip_host_malloc_pinned /
+// hipHostRegister)?  The file-level batch calls then skip their staging copy: a caller that reads its files into pinned buffers pays
+// PCIe only.  GAMUT_HIP_PINNED_INPUTS=0 turns the test off (measurements).
+inline bool host_range_is_pinned(const void* p, size_t n)
+{
+    static const bool off = [] { const char* e = getenv("GAMUT_HIP_PINNED_INPUTS"); return e && *e && atoi(e) == 0; }();
+    if (off || !p || !n) return false;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }      // plain pageable memory: "invalid value"
+    if (at.type != hipMemoryTypeHost) return false;
+    hipPointerAttribute_t at2;                                // the last byte too: inside the same kind of memory (a file is one allocation's worth)
+    if (hipPointerGetAttributes(&at2, static_cast<const uint8_t*>(p) + n - 1) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at2.type == hipMemoryTypeHost;
+}
+
 // Host threads worth starting: the hardware threads, or fewer when a cgroup CPU quota (cpu.max) grants the process less --
 // the GPU boxes show 256 threads and a quota of 16 cores, and 256 inflating threads on 16 cores' worth of time run slower
 // than 16.
 int host_threads();
 
-// fn(worker, index) for index in [0, count) on `workers` host threads (the caller is worker 0); dynamic distribution
+// fn(worker, index) for index in [0, count) on `workers` host threads (the caller is worker 0); dynamic distribution.  The helpers
+// are tasks on a persistent pool of the library (runtime.hip): round 3 started and joined workers - 1 std::threads per call -- ~0.5 ms
+// of thread creation per call on the GPU box, five calls per JPEG batch -- and every short-lived thread paid for its thread-local
+// staging again.  A helper that arrives after the indices are gone returns at once, so calls from several caller threads (the three
+// legs of gamut_hip_decode_batch_device) share the pool without waiting for one another's helpers to START: a call returns when its
+// own indices are done and its own helpers have left.
+void pool_submit(void (*run)(void*, int), void* ctx, int first_worker, int n_helpers, std::atomic<int>* left);
 template <class Fn> void parallel_for(int count, int workers, Fn fn)          // fn(worker, index); the caller runs worker 0
 {
-    std::atomic<int> next{ 0 };
-    auto run = [&](int w) { for (int i; (i = next.fetch_add(1, std::memory_order_relaxed)) < count; ) fn(w, i); };
-    std::vector<std::thread> pool;
-    try { for (int w = 1; w < workers; ++w) pool.emplace_back(run, w); } catch (...) {}
-    run(0);
-    for (std::thread& th : pool) th.join();
+    struct Ctx { std::atomic<int> next{ 0 }; int count; Fn* fn; } c;
+    c.count = count; c.fn = &fn;
+    auto run = [](void* p, int w) { Ctx& x = *static_cast<Ctx*>(p); for (int i; (i = x.next.fetch_add(1, std::memory_order_relaxed)) < x.count; ) (*x.fn)(w, i); };
+    std::atomic<int> left{ 0 };
+    const int helpers = workers - 1 < count - 1 ? workers - 1 : count - 1;
+    if (helpers > 0) pool_submit(run, &c, 1, helpers, &left);
+    run(&c, 0);
+    while (left.load(std::memory_order_acquire) > 0) std::this_thread::yield();      // (the helpers still hold references to c and fn)
 }
 
 #define GAMUT_HIP_CHECK(expr)                                                                 \

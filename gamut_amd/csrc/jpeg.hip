@@ -44,7 +44,8 @@ struct JpegArgs {
     int mcus_per_row, mcus_per_col;
     int scan_type, out_comps;
     int count;                                       // images of this launch
-};
+    int flip;                                        // rows stored bottom-up (the caller's pitch was negative): out = the image's LAST row in memory
+};                                                   // order = its first row by address, out_pitch = |pitch|; image row y lives at row height - 1 - y
 
 // =============================================================================
 // tuned H2V2 -> rgba8
@@ -117,13 +118,17 @@ __device__ __forceinline__ void store_px_nt(uint8_t* row_base, u32 voff, u32 px)
 #ifndef JPEG_UNROLL_STRIPS        // 1 = the strip loop fully unrolled (exact s_waitcnt vmcnt counts across the strips' stores)
 #define JPEG_UNROLL_STRIPS 0
 #endif
-#ifndef JPEG_444_MCUS             // 4:4:4: 10 MCUs = 30 blocks = 240 of the 256 threads at work (8 MCUs: 192)
-#define JPEG_444_MCUS 10
+#ifndef JPEG_444_MCUS             // 4:4:4: MCUs per strip: 10 MCUs = 30 blocks = 240 of the 256 threads at work (8 MCUs: 192).  Round 4, A/B on one box
+#define JPEG_444_MCUS 10          // (profiles/r04_jpeg_444_var.txt, 1024 x 1080p): -> rgba8 8 / 10 / 12 / 16 MCUs (256 / 256 / 320 / 384 threads) 4.50 / 4.48 /
+#endif                            // 5.37 / 5.16 ms; -> rgb8 4.44 / 4.93 / 5.51 / 5.08 ms (a strip row of 8 MCUs is 192 bytes: whole 64-byte sectors): 8 for rgb8
+#ifndef JPEG_444_MCUS_RGB8
+#define JPEG_444_MCUS_RGB8 8
 #endif
 // strips per workgroup of k_jpeg_plain, by sampling mode (A/B on one box, 1024 x 1080p -> rgba8, 1 / 2 / 4 / 8 strips: grey 1.69 / 1.56 /
 // 1.49 / 1.47 ms, 4:4:4 5.77 / 5.44 / 5.44 / 5.29 ms, 4:2:2 3.32 / 3.48 / 3.42 / 3.46 ms, 4:4:0 3.39 / 3.34 / 3.42 / 3.45 ms)
-constexpr int plain_mcus(int scan_type) { return scan_type == GAMUT_JPGD_GRAYSCALE ? 32 : scan_type == GAMUT_JPGD_YH1V1 ? JPEG_444_MCUS : 8; }     // MCUs per strip
+constexpr int plain_mcus(int scan_type, int oc = 4) { return scan_type == GAMUT_JPGD_GRAYSCALE ? 32 : scan_type == GAMUT_JPGD_YH1V1 ? (oc == 3 ? JPEG_444_MCUS_RGB8 : JPEG_444_MCUS) : 8; }     // MCUs per strip
 constexpr int plain_strips(int scan_type) { return (scan_type == GAMUT_JPGD_GRAYSCALE || scan_type == GAMUT_JPGD_YH1V1) ? 8 : 1; }
+constexpr int plain_threads(int scan_type) { return scan_type == GAMUT_JPGD_YH1V1 ? ((JPEG_444_MCUS > JPEG_444_MCUS_RGB8 ? JPEG_444_MCUS : JPEG_444_MCUS_RGB8) * 3 * 8 + 63) / 64 * 64 : 256; }   // a thread per block row
 #ifndef JPEG_ABLATE               // measurement only (tools/variant.sh): 1 = loads + stores, no arithmetic; 2 = no stores; 3 = no loads
 #define JPEG_ABLATE 0
 #endif
@@ -165,7 +170,10 @@ __global__ __launch_bounds__(H2V2_THREADS) void k_jpeg_h2v2(JpegArgs a)
     const int n_tiles = (a.mcus_per_row + H2V2_MCUS - 1) / H2V2_MCUS;
     // wave-uniform bases (scalar registers); per-thread parts are small 32-bit offsets
     const int16_t* cbase = a.coeffs + (int64_t)img * a.coeff_stride + ((int64_t)mcu_y * a.mcus_per_row + tile0 * H2V2_MCUS) * (6 * 64);
-    uint8_t* obase = a.out + (int64_t)img * a.out_stride + (int64_t)(mcu_y * 16) * a.out_pitch + (int64_t)tile0 * (H2V2_MCUS * 16 * OC);
+    // (bottom-up rows: the strip's 16 rows lie in descending order; the base is the strip's LAST row -- it may lie in front of the
+    // image for the rows a partial strip does not have, which are never written -- and the row offsets count down)
+    uint8_t* obase = a.out + (int64_t)img * a.out_stride + (a.flip ? (int64_t)(a.height - 1 - (mcu_y * 16 + 15)) : (int64_t)(mcu_y * 16)) * a.out_pitch +
+                     (int64_t)tile0 * (H2V2_MCUS * 16 * OC);
     const uint8_t* zbase = a.max_zag ? a.max_zag + (int64_t)img * a.zag_stride + ((int64_t)mcu_y * a.mcus_per_row + tile0 * H2V2_MCUS) * 6 : nullptr;
 
     // ---- mapping A: thread = (Y block b = (mcu m, quadrant q), row/column index r) ----
@@ -188,7 +196,7 @@ __global__ __launch_bounds__(H2V2_THREADS) void k_jpeg_h2v2(JpegArgs a)
     const bool all_rows = a.height - mcu_y * 16 >= 16;     // wave-uniform: all 16 rows of the strip exist
     const int rows_here = a.height - mcu_y * 16 - ly0;
     const u32 pitch = (u32)a.out_pitch;                    // the launcher checks 16 * out_pitch < 2^31
-    const u32 voff = (u32)(lx * 4) + (u32)ly0 * pitch;     // rgba8: the lane's part of a pixel address; the row advances on the scalar side
+    const u32 voff = (u32)(lx * 4) + (u32)(a.flip ? 8 - ly0 : ly0) * pitch;     // rgba8: the lane's part of a pixel address; the row advances on the scalar side
 
     // P0: loads (16 B per lane, lane-contiguous inside each MCU).  Lanes of MCUs beyond the edge of the image re-read the
     // strip's first MCU (there is always one): their results are never stored, and nothing has to be zeroed.
@@ -355,11 +363,11 @@ __global__ __launch_bounds__(H2V2_THREADS) void k_jpeg_h2v2(JpegArgs a)
                     } else
                     if (all_rows) {
                         #pragma unroll
-                        for (int i = 0; i < 8; ++i) store_px_nt(otile + (size_t)i * pitch, voff, ycc_to_rgba(ys[i], cbs[i], crs[i], cc.kr, cc.kb, cc.kg));
+                        for (int i = 0; i < 8; ++i) store_px_nt(otile + (size_t)(a.flip ? 7 - i : i) * pitch, voff, ycc_to_rgba(ys[i], cbs[i], crs[i], cc.kr, cc.kb, cc.kg));
                     } else {
                         #pragma unroll
                         for (int i = 0; i < 8; ++i)
-                            if (i < rows_here) store_px_nt(otile + (size_t)i * pitch, voff, ycc_to_rgba(ys[i], cbs[i], crs[i], cc.kr, cc.kb, cc.kg));
+                            if (i < rows_here) store_px_nt(otile + (size_t)(a.flip ? 7 - i : i) * pitch, voff, ycc_to_rgba(ys[i], cbs[i], crs[i], cc.kr, cc.kb, cc.kg));
                     }
                 }
             } else {
@@ -398,7 +406,7 @@ __global__ __launch_bounds__(H2V2_THREADS) void k_jpeg_h2v2(JpegArgs a)
                     const int row = c / CPR, off = (c - row * CPR) * 16;
                     if (row >= live_rows || off >= row_bytes) continue;
                     const uint4 v = *reinterpret_cast<const uint4*>(stage + row * BPR + off);
-                    uint8_t* o = otile + (u32)row * pitch + (u32)off;
+                    uint8_t* o = otile + (u32)(a.flip ? 15 - row : row) * pitch + (u32)off;
                     if (off + 16 <= row_bytes) {
                         Dwords4u d; d.v[0] = v.x; d.v[1] = v.y; d.v[2] = v.z; d.v[3] = v.w;
                         *reinterpret_cast<Dwords4u*>(o) = d;
@@ -428,14 +436,15 @@ struct __attribute__((packed, aligned(1))) Dwords3 { u32 v[3]; };
 struct __attribute__((packed, aligned(1))) Dword1 { u32 v; };
 
 template <int ST, int OC>
-__global__ __launch_bounds__(256) void k_jpeg_plain(JpegArgs a)
+__global__ __launch_bounds__(plain_threads(ST)) void k_jpeg_plain(JpegArgs a)
 {
+    constexpr int NTHR = plain_threads(ST);
     static_assert(ST == GAMUT_JPGD_GRAYSCALE || ST == GAMUT_JPGD_YH1V1 || ST == GAMUT_JPGD_YH2V1 || ST == GAMUT_JPGD_YH1V2, "sampling mode");
     constexpr int BPM  = ST == GAMUT_JPGD_GRAYSCALE ? 1 : ST == GAMUT_JPGD_YH1V1 ? 3 : 4;
     constexpr int MH   = ST == GAMUT_JPGD_YH1V2 ? 16 : 8;           // MCU height: 4:4:0 stacks two Y blocks (H1V2Convert :2603-2647)
-    constexpr int MCUS = plain_mcus(ST);
+    constexpr int MCUS = plain_mcus(ST, OC);
     constexpr int NBLK = MCUS * BPM;                              // 32 / 30 / 32 blocks = NBLK * 8 working threads
-    static_assert(NBLK * 8 <= 256, "a thread per block row");
+    static_assert(NBLK * 8 <= NTHR, "a thread per block row");
     constexpr int MW   = ST == GAMUT_JPGD_YH2V1 ? 16 : 8;
     constexpr int SW   = MCUS * MW;                               // strip width in pixels: 256 / 64 / 128
     __shared__ __attribute__((aligned(16))) i32 T1[NBLK * BLK_STRIDE];
@@ -458,7 +467,7 @@ __global__ __launch_bounds__(256) void k_jpeg_plain(JpegArgs a)
 
     if (t < NBLK * 8) {
         uint4 row = make_uint4(0, 0, 0, 0);
-        if (blk_live) row = *reinterpret_cast<const uint4*>(cbase + (u32)(t * 8));       // block b, row r: lane-contiguous
+        if (blk_live) row = load_coeffs16(cbase + (u32)(t * 8));                          // block b, row r: lane-contiguous; read once: nontemporal
         i32 x[8], tv[8];
         unpack_row(row, x);
         row_pass<8>(x, tv);
@@ -489,7 +498,7 @@ __global__ __launch_bounds__(256) void k_jpeg_plain(JpegArgs a)
     const int rows_here = min(MH, a.height - mcu_y * MH);
     const int px_here = min(mcus_here * MW, a.width - mcu_x0 * MW);             // live pixels of a strip row
     constexpr int GPR = SW / 4;                                   // groups of 4 pixels per strip row
-    for (int g = t; g < GPR * MH; g += 256) {
+    for (int g = t; g < GPR * MH; g += NTHR) {
         const int y = g / GPR, x0 = (g - y * GPR) * 4;
         if (y >= rows_here || x0 >= px_here) continue;
         const int m = x0 / MW, xin = x0 - m * MW;
@@ -528,10 +537,13 @@ __global__ __launch_bounds__(256) void k_jpeg_plain(JpegArgs a)
             else if constexpr (OC == 3) { w[0] = __builtin_amdgcn_perm(px[1], px[0], 0x04020100u); w[1] = __builtin_amdgcn_perm(px[2], px[1], 0x05040201u); w[2] = __builtin_amdgcn_perm(px[3], px[2], 0x06050402u); }
             else w[0] = rgb_to_luma(px[0]) | (rgb_to_luma(px[1]) << 8) | (rgb_to_luma(px[2]) << 16) | (rgb_to_luma(px[3]) << 24);
         }
-        if (npx == 4) {
-            if constexpr (OC == 4)      { Dwords4 d; d.v[0] = w[0]; d.v[1] = w[1]; d.v[2] = w[2]; d.v[3] = w[3]; *reinterpret_cast<Dwords4*>(o) = d; }
-            else if constexpr (OC == 3) { Dwords3 d; d.v[0] = w[0]; d.v[1] = w[1]; d.v[2] = w[2]; *reinterpret_cast<Dwords3*>(o) = d; }
-            else                        { Dword1 d; d.v = w[0]; *reinterpret_cast<Dword1*>(o) = d; }
+        if (npx == 4) {                                           // written once, never read back here: nontemporal
+            typedef u32 u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+            typedef u32 u32x3a __attribute__((ext_vector_type(3), aligned(1)));
+            typedef u32 u32x1a __attribute__((aligned(1)));
+            if constexpr (OC == 4)      __builtin_nontemporal_store(u32x4a{ w[0], w[1], w[2], w[3] }, reinterpret_cast<u32x4a*>(o));
+            else if constexpr (OC == 3) __builtin_nontemporal_store(u32x3a{ w[0], w[1], w[2] }, reinterpret_cast<u32x3a*>(o));
+            else                        __builtin_nontemporal_store((u32x1a)w[0], reinterpret_cast<u32x1a*>(o));
         } else {
             for (int k = 0; k < npx * OC; ++k) o[k] = (uint8_t)(w[k >> 2] >> ((k & 3) * 8));
         }
@@ -723,10 +735,15 @@ int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
         if (c.max_zag) c.max_zag += (int64_t)i0 * zag_stride;
         const dim3 grid(tiles, a.mcus_per_col, n);
         // tuned kernels: rgba8 needs dword-aligned rows; rgb8 / l8 rows may start anywhere (unaligned dword stores)
-        const bool tuned = out_pitch > 0 && out_pitch < (1 << 27) &&
-                           (out_comps != 4 || (((uintptr_t)out & 3) == 0 && (out_pitch & 3) == 0 && (out_stride & 3) == 0));
+        // Rows stored bottom-up (a negative pitch: LAYOUT_VERT_FLIPPED is first-class in the reference, internals/types.d:498-501) take the
+        // tuned kernels too: k_jpeg_plain addresses rows with the signed pitch as it is; k_jpeg_h2v2, whose row offsets are unsigned 32-bit
+        // lane offsets behind a scalar base, gets the image's lowest row and |pitch| and counts its rows down (JpegArgs.flip).
+        const int64_t apitch = out_pitch < 0 ? -out_pitch : out_pitch;
+        const bool tuned = apitch > 0 && apitch < (1 << 27) &&
+                           (out_comps != 4 || (((uintptr_t)out & 3) == 0 && (apitch & 3) == 0 && (out_stride & 3) == 0));
+        if (tuned && out_pitch < 0 && scan_type == GAMUT_JPGD_YH2V2) { c.flip = 1; c.out_pitch = apitch; c.out += (int64_t)(height - 1) * out_pitch; }
         const int ps = plain_strips(scan_type);
-        const int pm = plain_mcus(scan_type);
+        const int pm = plain_mcus(scan_type, out_comps);
         const dim3 grid32(((a.mcus_per_row + 31) / 32 + ps - 1) / ps, a.mcus_per_col, n);           // grey: 32 MCUs per strip
         const dim3 grid_plain(((a.mcus_per_row + pm - 1) / pm + ps - 1) / ps, a.mcus_per_col, n);
         const int strips420 = out_comps == 4 ? JPEG_STRIPS : JPEG_STRIPS_PACKED;
@@ -737,9 +754,9 @@ int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
         const dim3 grid420(groups420, a.mcus_per_col, n);
 #endif
 #define GAMUT_JPEG_PLAIN(ST, G) do { \
-            if (out_comps == 4)      hipLaunchKernelGGL((k_jpeg_plain<ST, 4>), G, dim3(256), 0, stream, c); \
-            else if (out_comps == 3) hipLaunchKernelGGL((k_jpeg_plain<ST, 3>), G, dim3(256), 0, stream, c); \
-            else                     hipLaunchKernelGGL((k_jpeg_plain<ST, 1>), G, dim3(256), 0, stream, c); } while (0)
+            if (out_comps == 4)      hipLaunchKernelGGL((k_jpeg_plain<ST, 4>), G, dim3(plain_threads(ST)), 0, stream, c); \
+            else if (out_comps == 3) hipLaunchKernelGGL((k_jpeg_plain<ST, 3>), G, dim3(plain_threads(ST)), 0, stream, c); \
+            else                     hipLaunchKernelGGL((k_jpeg_plain<ST, 1>), G, dim3(plain_threads(ST)), 0, stream, c); } while (0)
         if (!tuned)                                   hipLaunchKernelGGL(k_jpeg_generic, grid, dim3(256), 0, stream, c);
         else if (scan_type == GAMUT_JPGD_GRAYSCALE)   GAMUT_JPEG_PLAIN(GAMUT_JPGD_GRAYSCALE, grid32);
         else if (scan_type == GAMUT_JPGD_YH1V1)       GAMUT_JPEG_PLAIN(GAMUT_JPGD_YH1V1, grid_plain);

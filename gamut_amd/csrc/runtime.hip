@@ -1,6 +1,9 @@
 // runtime.hip -- C-ABI runtime entry points of libgamut_hip (init, errors, memory, streams)
 // and the host-pointer drop-in for scanlinesConvert / scanlinesCopy.
 #include "common.hpp"
+#include <algorithm>
+#include <condition_variable>
+#include <mutex>
 
 namespace gamut {
 
@@ -42,6 +45,43 @@ int host_threads()
         return hw < 1 ? 1 : hw;
     }();
     return n;
+}
+
+// The helper pool of parallel_for: host_threads() persistent threads (at most 64), started on first use, never joined (the process may
+// end while they wait; their thread-local staging must not be torn down under a running DMA).
+namespace {
+struct PoolTask { void (*run)(void*, int); void* ctx; int worker; std::atomic<int>* left; };
+struct HelperPool {
+    std::mutex m; std::condition_variable cv; std::vector<PoolTask> q; size_t head = 0; int threads = 0;
+    void start()
+    {
+        const int want = std::min(64, std::max(1, host_threads()));
+        while (threads < want) {
+            std::thread([this] {
+                for (;;) {
+                    PoolTask t;
+                    { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [this] { return head < q.size(); }); t = q[head++]; if (head == q.size()) { q.clear(); head = 0; } }
+                    t.run(t.ctx, t.worker);
+                    t.left->fetch_sub(1, std::memory_order_release);
+                }
+            }).detach();
+            ++threads;
+        }
+    }
+};
+HelperPool& helper_pool() { static HelperPool* p = new HelperPool(); return *p; }
+} // namespace
+
+void pool_submit(void (*run)(void*, int), void* ctx, int first_worker, int n_helpers, std::atomic<int>* left)
+{
+    HelperPool& P = helper_pool();
+    left->store(n_helpers, std::memory_order_relaxed);
+    {
+        std::lock_guard<std::mutex> lk(P.m);
+        P.start();
+        for (int k = 0; k < n_helpers; ++k) P.q.push_back(PoolTask{ run, ctx, first_worker + k, left });
+    }
+    P.cv.notify_all();
 }
 
 hipStream_t thread_stream()

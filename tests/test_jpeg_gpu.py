@@ -481,6 +481,36 @@ def test_device_entropy_decode_corrupt_streams(hip):
         assert np.array_equal(res[i][0], d.coeffs) and np.array_equal(res[i][1], d.max_zag)
 
 
+@pytest.mark.parametrize("scan_type", [4, 1, 2, 3, 0])
+def test_bottom_up_rows_on_the_tuned_kernels(hip, scan_type):
+    """a negative out_pitch (rows stored bottom-up: LAYOUT_VERT_FLIPPED, internals/types.d:498-501; Image.loadFromMemory with a flipped
+    layout ends here) runs the tuned kernels, not the generic one: same pixels, row y at out + y * pitch with pitch < 0 -- ragged sizes
+    (partial MCU rows: the flipped 4:2:0 strip base lies in front of the image), row gaps, every output format, batches"""
+    rng = np.random.default_rng(70 + scan_type)
+    mw, mh = MCU[scan_type]
+    comps = 1 if scan_type == 0 else 3
+    for (w, h, n) in ((131, 97, 3), (64, 48, 1), (1920, 33, 2), (17, 200, 2)):
+        nblk = ((w + mw - 1) // mw) * ((h + mh - 1) // mh) * NB[scan_type]
+        co = np.stack([random_coeffs(rng, nblk, "natural") for _ in range(n)])
+        for oc in (4, 3, 1):
+            pad = 8 if oc == 4 else 5
+            pitch = w * oc + pad
+            istride = pitch * h + 64
+            host = np.full(n * istride, 0xA5, np.uint8)
+            dco = dev_upload(hip, co.reshape(n, -1)); dout = dev_upload(hip, host)
+            # row 0 of image i is its LAST row in memory: the pointer handed over is that of row 0, the pitch negative
+            _capi.check(hip.gamut_hip_jpeg_reconstruct_batch_device(dco, nblk * 64, None, 0, dout + (h - 1) * pitch, -pitch, istride,
+                                                                     w, h, scan_type, oc, n, None))
+            _capi.check(hip.gamut_hip_memcpy_d2h(host.ctypes.data, dout, host.nbytes, None)); _capi.check(hip.gamut_hip_stream_synchronize(None))
+            hip.gamut_hip_device_free(dco); hip.gamut_hip_device_free(dout)
+            for i in range(n):
+                img = host[i * istride:(i + 1) * istride]
+                rows = img[:pitch * h].reshape(h, pitch)
+                exp = O.jpeg_reconstruct(w, h, comps, scan_type, co[i], None, oc)
+                assert np.array_equal(rows[::-1, :w * oc], exp), (scan_type, w, h, oc, i)
+                assert (rows[:, w * oc:] == 0xA5).all() and (img[pitch * h:] == 0xA5).all(), "wrote outside the rows"
+
+
 @pytest.fixture(params=["device", "host"])
 def unstuff_site(request):
     """where the 0x00 stuffing is dropped and the restart markers are found: k_jpeg_unstuff (the scan uploaded as it is) or host threads"""

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--progressive", action="store_true", help="progressive (SOF2) files: libjpeg's default scan script")
+    ap.add_argument("--pinned", action="store_true", help="the files live in page-locked host memory: path C uploads the scans from where they are")
     ap.add_argument("--paths", default="abc", help="which of the three paths to time (a: host feeder, b: device entropy decode, c: files -> pixels)")
     a = ap.parse_args()
     L = _capi.lib()
@@ -44,6 +45,16 @@ def main():
             kw["progressive"] = True
         Image.fromarray(gen.synth_rgb(w, h, 100 + i)).save(bio, "JPEG", **kw)
         files.append(np.frombuffer(bio.getvalue(), np.uint8))
+    if a.pinned:
+        total = sum(((f.size + 63) & ~63) for f in files)
+        arena = L.gamut_hip_host_malloc_pinned(total)
+        assert arena
+        whole = np.ctypeslib.as_array(C.cast(arena, C.POINTER(C.c_uint8)), (total,))
+        at = 0
+        for j, f in enumerate(files):
+            whole[at:at + f.size] = f
+            files[j] = whole[at:at + f.size]
+            at += (f.size + 63) & ~63
     bufs = [files[i % a.distinct] for i in range(B)]
     ptrs = (C.c_void_p * B)(*[b.ctypes.data for b in bufs])
     lens = (C.c_size_t * B)(*[b.size for b in bufs])
@@ -91,7 +102,7 @@ def main():
         return time.perf_counter()
 
     mb = sum(b.size for b in bufs) / 1e6
-    print(f"batch {B} x {w}x{h} {'progressive' if a.progressive else 'baseline'} 4:2:0, {mb / B * 1e3:.0f} kB/file, restart rows {a.restart_rows}, host threads {a.threads or os.cpu_count()}")
+    print(f"batch {B} x {w}x{h} {'progressive' if a.progressive else 'baseline'} 4:2:0, {mb / B * 1e3:.0f} kB/file, restart rows {a.restart_rows}, host threads {a.threads or os.cpu_count()}, files in {'PAGE-LOCKED' if a.pinned else 'pageable'} host memory")
     ref = None
     for name, fn in (("A host feeder + coefficient upload", path_a), ("B device entropy decode", path_b), ("C files -> pixels in one call", path_c)):
         if name[0].lower() not in a.paths:

@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--batch", type=int, default=96)
     ap.add_argument("--distinct", type=int, default=8)
     ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--pinned", action="store_true", help="the files live in page-locked host memory (gamut_hip_host_malloc_pinned): the JPEG and QOI "
+                    "legs then upload them from where they are, without a staging copy")
     a = ap.parse_args()
     L = _capi.lib(); _capi.check(L.gamut_hip_init(0))
     w, h, B, D = 1920, 1080, a.batch, a.distinct
@@ -34,6 +36,17 @@ def main():
         b = io.BytesIO(); Image.fromarray(im).save(b, "JPEG", quality=90, subsampling=2); enc["jpeg"].append(np.frombuffer(b.getvalue(), np.uint8))
         b = io.BytesIO(); Image.fromarray(im).save(b, "PNG", compress_level=6); enc["png"].append(np.frombuffer(b.getvalue(), np.uint8))
         enc["qoi"].append(np.frombuffer(synth.qoi_encode(im), np.uint8))
+    if a.pinned:                                                # one page-locked arena, the distinct files back to back (64-byte aligned)
+        total = sum(((f.size + 63) & ~63) for k in enc for f in enc[k])
+        arena = L.gamut_hip_host_malloc_pinned(total)
+        assert arena
+        whole = np.ctypeslib.as_array(C.cast(arena, C.POINTER(C.c_uint8)), (total,))
+        at = 0
+        for k in enc:
+            for j, f in enumerate(enc[k]):
+                whole[at:at + f.size] = f
+                enc[k][j] = whole[at:at + f.size]
+                at += (f.size + 63) & ~63
     kinds = ["jpeg", "png", "qoi"]
     idx = {k: [i for i in range(B) if kinds[i % 3] == k] for k in kinds}
     out = torch.empty((B, h * w * 4), dtype=torch.uint8, device="cuda")
@@ -78,7 +91,9 @@ def main():
         _capi.check(L.gamut_hip_decode_batch_device(ap_, al_, B, 4, aoff.ctypes.data_as(P64), out.data_ptr(), info, None, stream))
 
     print(f"mixed batch of {B} x {w}x{h} files ({nj} JPEG {np.mean([b.size for b in jb]) / 1e3:.0f} kB, {npn} PNG {np.mean([b.size for b in pb]) / 1e6:.1f} MB, "
-          f"{nq} QOI {np.mean([b.size for b in qb]) / 1e6:.1f} MB) -> rgba8 in HBM; {a.threads} host threads (0 = all; PNG batches this large inflate on the GPU)")
+          f"{nq} QOI {np.mean([b.size for b in qb]) / 1e6:.1f} MB) "
+          f"-> rgba8 in HBM; {a.threads} host threads (0 = all; PNG batches this large inflate on the GPU); "
+          f"files in {'PAGE-LOCKED' if a.pinned else 'pageable'} host memory")
     best = {}
     for rep in range(3):
         for k, fn in (("jpeg", run_jpeg), ("png", run_png), ("qoi", run_qoi)):

@@ -197,6 +197,10 @@ int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
                             int width, int height, int scan_type, int out_comps,
                             int count, hipStream_t stream);
 
+int jpeg_reconstruct_tokens_launch(const uint32_t* tokens, const uint32_t* strip_tab, const int64_t* tok_offs, const int64_t* strip_offs,
+                                   const uint8_t* max_zag, int64_t zag_stride, uint8_t* out, int64_t out_pitch, int64_t out_stride,
+                                   int width, int height, int out_comps, int count, hipStream_t stream);
+
 // inflate.hip: DEFLATE streams in HBM -> bytes in HBM, one workgroup per stream (asynchronous on `stream`)
 int inflate_launch(const gamut_hip_inflate_desc* descs, int count, uint32_t* out_len_dev, uint32_t* status_dev, hipStream_t stream);
 // the same while the streams are still being uploaded: begin, then a step per slice (avail_host[i] = bytes of stream i that are in HBM once

@@ -44,6 +44,9 @@ struct JpegArgs {
     int mcus_per_row, mcus_per_col;
     int scan_type, out_comps;
     int count;                                       // images of this launch
+    // the compact hand-off (k_jpeg_h2v2<.., TOK>): instead of `coeffs`, image i's coefficients are the tokens
+    // tokens[tok_offs[i] + strip_tab[strip_offs[i] + s] .. strip_tab[strip_offs[i] + s + 1]) of strip s (jpeg_host.hip, SUB_TOKENS)
+    const u32* tokens; const u32* strip_tab; const int64_t* tok_offs; const int64_t* strip_offs;
     int flip;                                        // rows stored bottom-up (the caller's pitch was negative): out = the image's LAST row in memory
 };                                                   // order = its first row by address, out_pitch = |pitch|; image row y lives at row height - 1 - y
 
@@ -136,7 +139,7 @@ constexpr int plain_threads(int scan_type) { return scan_type == GAMUT_JPGD_YH1V
 #ifndef JPEG_MIN_WAVES            // __launch_bounds__'s second argument: minimum waves per SIMD (0 = unconstrained register allocation)
 #define JPEG_MIN_WAVES 0
 #endif
-template <int OC>                // output components: 4 = rgba8, 3 = rgb8, 1 = l8 (grey of the RGB result, jpegload.d:3786-3792)
+template <int OC, bool TOK = false>     // output components: 4 = rgba8, 3 = rgb8, 1 = l8 (grey of the RGB result, jpegload.d:3786-3792); TOK: coefficients as tokens
 #if JPEG_MIN_WAVES
 __global__ __launch_bounds__(H2V2_THREADS, JPEG_MIN_WAVES) void k_jpeg_h2v2(JpegArgs a)
 #else
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(H2V2_THREADS) void k_jpeg_h2v2(JpegArgs a)
 #endif
     const int n_tiles = (a.mcus_per_row + H2V2_MCUS - 1) / H2V2_MCUS;
     // wave-uniform bases (scalar registers); per-thread parts are small 32-bit offsets
-    const int16_t* cbase = a.coeffs + (int64_t)img * a.coeff_stride + ((int64_t)mcu_y * a.mcus_per_row + tile0 * H2V2_MCUS) * (6 * 64);
+    const int16_t* cbase = TOK ? nullptr : a.coeffs + (int64_t)img * a.coeff_stride + ((int64_t)mcu_y * a.mcus_per_row + tile0 * H2V2_MCUS) * (6 * 64);
     // (bottom-up rows: the strip's 16 rows lie in descending order; the base is the strip's LAST row -- it may lie in front of the
     // image for the rows a partial strip does not have, which are never written -- and the row offsets count down)
     uint8_t* obase = a.out + (int64_t)img * a.out_stride + (a.flip ? (int64_t)(a.height - 1 - (mcu_y * 16 + 15)) : (int64_t)(mcu_y * 16)) * a.out_pitch +
@@ -218,9 +221,33 @@ __global__ __launch_bounds__(H2V2_THREADS) void k_jpeg_h2v2(JpegArgs a)
         const int here = a.mcus_per_row - tile * H2V2_MCUS;
         return m < here ? (u32)zbase[((tile - tile0) * H2V2_MCUS + m) * 6 + q] : 1u;
     };
+    // TOK: the strip's coefficients arrive as tokens (block of the strip, natural position, value): the tile the loads above would read
+    // from memory is assembled in LDS instead -- cleared, the strip's tokens scattered into it by all threads, then every thread takes
+    // its two rows from it.  The tile (48 blocks x 128 bytes) borrows the H / V staging area, which the strip's arithmetic writes later.
+    auto fetch_tokens = [&](int tile, uint4& yv, uint4& cv) {
+        if constexpr (TOK) {
+            uint8_t* const ctile = reinterpret_cast<uint8_t*>(Hs);
+            __syncthreads();                                          // (another wave may still read the area for the strip before)
+            static_assert((H_INTS + V_INTS) * 4 >= 64 * 128, "the coefficient tile (any 6-bit block index) fits the H / V area");
+            *reinterpret_cast<uint4*>(ctile + t * 16) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint2*>(ctile + H2V2_THREADS * 16 + t * 8) = make_uint2(0, 0);
+            const u32* st = a.strip_tab + a.strip_offs[img] + ((int64_t)mcu_y * n_tiles + tile);
+            const u32 t0 = st[0], t1 = st[1];
+            const u32* tk = a.tokens + a.tok_offs[img];
+            __syncthreads();
+            for (u32 idx = t0 + (u32)t; idx < t1; idx += H2V2_THREADS) {
+                const u32 w = tk[idx];
+                *reinterpret_cast<uint16_t*>(ctile + ((w >> 26) << 7) + ((w >> 19) & 126u)) = (uint16_t)w;
+            }
+            __syncthreads();
+            yv = *reinterpret_cast<const uint4*>(ctile + yoff * 2);
+            cv = *reinterpret_cast<const uint4*>(ctile + coff * 2);
+            __syncthreads();                                          // the H stage of this strip overwrites the tile
+        }
+    };
     uint4 yrow, crow;
     u32 yzag = 64;
-    if (tile0 < n_tiles) { fetch(tile0, yrow, crow); yzag = fetch_zag(tile0); }
+    if (!TOK && tile0 < n_tiles) { fetch(tile0, yrow, crow); yzag = fetch_zag(tile0); }
 
 #if JPEG_UNROLL_STRIPS
     #pragma unroll
@@ -234,9 +261,10 @@ __global__ __launch_bounds__(H2V2_THREADS) void k_jpeg_h2v2(JpegArgs a)
         const int mcus_here = min(H2V2_MCUS, a.mcus_per_row - mcu_x0);
         const bool mcu_live = m < mcus_here;
         uint8_t* const otile = obase + (size_t)s * (H2V2_MCUS * 16 * OC);
+        if constexpr (TOK) { fetch_tokens(tile, yrow, crow); yzag = fetch_zag(tile); }
         uint4 ynext = yrow, cnext = crow;
         u32 znext = yzag;
-        if (s + 1 < STRIPS && tile + 1 < n_tiles) { fetch(tile + 1, ynext, cnext); znext = fetch_zag(tile + 1); }     // in flight during this strip's arithmetic
+        if (!TOK && s + 1 < STRIPS && tile + 1 < n_tiles) { fetch(tile + 1, ynext, cnext); znext = fetch_zag(tile + 1); }     // in flight during this strip's arithmetic
         // jpgd picks Row!N / Col!N per block from max_zag (jpegload.d:295-376): literal zeros for the coefficients a block does
         // not have, i.e. the dense transform at a fraction of the work.  A wave cannot branch per block, but it can per WAVE:
         // when none of its 8 Y blocks reaches zig-zag position 10 (row 4 / column 4) -- the smooth parts of a photograph -- both
@@ -767,6 +795,43 @@ int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
         else                     hipLaunchKernelGGL(k_jpeg_h2v2<1>, grid420, dim3(H2V2_THREADS), 0, stream, c);
 #undef GAMUT_JPEG_PLAIN
         if (int rc = launch_status("jpeg_reconstruct")) return rc;
+    }
+    return GAMUT_HIP_OK;
+}
+
+// 4:2:0 images whose coefficients arrive as token streams (the compact hand-off of gamut_hip_jpeg_decode_batch_device: jpeg_host.hip,
+// SUB_TOKENS): same kernel, the strip's tile assembled in LDS from its tokens.  tok_offs / strip_offs: per-image offsets (device arrays).
+int jpeg_reconstruct_tokens_launch(const uint32_t* tokens, const uint32_t* strip_tab, const int64_t* tok_offs, const int64_t* strip_offs,
+                                   const uint8_t* max_zag, int64_t zag_stride, uint8_t* out, int64_t out_pitch, int64_t out_stride,
+                                   int width, int height, int out_comps, int count, hipStream_t stream)
+{
+    if (width < 1 || height < 1 || width > 16384 || height > 16384 || count < 0 || (out_comps != 1 && out_comps != 3 && out_comps != 4) || !max_zag)
+        return set_error(GAMUT_HIP_ERR_INVALID_ARG, "jpeg_reconstruct_tokens: bad arguments");
+    if (count == 0) return GAMUT_HIP_OK;
+    const int64_t apitch = out_pitch < 0 ? -out_pitch : out_pitch;
+    if (apitch <= 0 || apitch >= (1 << 27) || (out_comps == 4 && ((((uintptr_t)out & 3) != 0) || (apitch & 3) || (out_stride & 3))))
+        return set_error(GAMUT_HIP_ERR_INVALID_ARG, "jpeg_reconstruct_tokens: output rows must be dword-aligned for rgba8");
+    JpegArgs a{};
+    a.tokens = tokens; a.strip_tab = strip_tab; a.max_zag = max_zag; a.zag_stride = zag_stride;
+    a.out = out; a.out_pitch = apitch; a.out_stride = out_stride;
+    a.width = width; a.height = height; a.scan_type = GAMUT_JPGD_YH2V2; a.out_comps = out_comps;
+    a.mcus_per_row = (width + 15) / 16; a.mcus_per_col = (height + 15) / 16;
+    if (out_pitch < 0) { a.flip = 1; a.out += (int64_t)(height - 1) * out_pitch; }
+    for (int i0 = 0; i0 < count; i0 += 65528) {               // gridDim.z limit (a multiple of 8: the XCD-aware image order)
+        const int n = count - i0 < 65528 ? count - i0 : 65528;
+        JpegArgs c = a;
+        c.count = n; c.out += (int64_t)i0 * out_stride; c.max_zag += (int64_t)i0 * zag_stride; c.tok_offs = tok_offs + i0; c.strip_offs = strip_offs + i0;
+        const int strips420 = out_comps == 4 ? JPEG_STRIPS : JPEG_STRIPS_PACKED;
+        const unsigned groups420 = (unsigned)(((a.mcus_per_row + H2V2_MCUS - 1) / H2V2_MCUS + strips420 - 1) / strips420);
+#if JPEG_XCD_REMAP
+        const dim3 grid420(8u * groups420, a.mcus_per_col, (n + 7) / 8);
+#else
+        const dim3 grid420(groups420, a.mcus_per_col, n);
+#endif
+        if (out_comps == 4)      hipLaunchKernelGGL((k_jpeg_h2v2<4, true>), grid420, dim3(H2V2_THREADS), 0, stream, c);
+        else if (out_comps == 3) hipLaunchKernelGGL((k_jpeg_h2v2<3, true>), grid420, dim3(H2V2_THREADS), 0, stream, c);
+        else                     hipLaunchKernelGGL((k_jpeg_h2v2<1, true>), grid420, dim3(H2V2_THREADS), 0, stream, c);
+        if (int rc = launch_status("jpeg_reconstruct_tokens")) return rc;
     }
     return GAMUT_HIP_OK;
 }

@@ -534,7 +534,10 @@ struct DevImage {
     int64_t coeff_off, zag_off;        // int16 elements / bytes from the start of the caller's buffers
     int32_t nb, ny;                    // blocks per MCU, of which luma (component of block b: b < ny ? 0 : b - ny + 1)
     int32_t quant[3], dc[3], ac[3];    // table indices per component
-    int32_t pad;
+    int32_t tok;                       // 1: the coefficients leave as a token stream (compact hand-off, below) instead of dense 128-byte blocks
+    int64_t tok_off, strip_off;        // the image's tokens / strip table: elements from the start of the token buffer / the strip-start buffer
+    int32_t sb, row_blocks;            // blocks per strip of the reconstruction kernel (k_jpeg_h2v2: 8 MCUs = 48), blocks per MCU row
+    int32_t n_strips, tok_cap;         // strips of the image (its table has n_strips + 1 entries), tokens its slot holds
 };
 struct DevItem { int32_t image, first_mcu, n_mcus, pad; uint64_t begin, end; };    // one restart interval (or whole scan)
 
@@ -722,26 +725,59 @@ struct SubCtx {
 // entry (z > 0) is only counted here.  MODE 2 (after a barrier): exactly that first, inherited block again, its coefficients stored
 // one by one on top of the line its starter wrote.  Scattered 2-byte stores for everything (the first version, into a buffer
 // cleared beforehand) cost 13 GB of HBM traffic per 512 images for 3 GB of coefficients: every store a read-modify-write of a line.
-enum { SUB_COUNT = 0, SUB_WRITE = 1, SUB_FIRST = 2 };
+enum { SUB_COUNT = 0, SUB_WRITE = 1, SUB_FIRST = 2, SUB_TOKENS = 3 };
+// SUB_TOKENS (round 4, the compact hand-off): the write sweep emits one 4-byte TOKEN per coefficient instead of assembling 128-byte
+// blocks -- [31:26] block of the reconstruction kernel's strip, [25:20] natural position, [15:0] the de-quantised value -- every DC and
+// every non-zero AC coefficient, in stream order, so the tokens of consecutive lanes are consecutive (a lane's first token index comes
+// from a fifth prefix sum) and a block split between lanes needs no second pass.  The strips of the reconstruction kernel are runs of
+// consecutive blocks of the stream: the lane that starts a strip's first block records where the strip's tokens begin, and the kernel
+// (k_jpeg_h2v2<.., TOK>) scatters the tokens of its strip into the LDS tile it used to load from memory.  A lane collects its tokens
+// in 64 bytes of LDS and ships them every 16 steps, all lanes at once (four 16-byte stores at most): shipping whole 128-byte lines the
+// moment a block ended was 1.6 M of the write sweep's 4.5 M cycles per file, and a q 90 block is ~12 tokens = 48 bytes.
+struct TokCtx {
+    uint32_t* out;                      // this lane's region of the image's token stream
+    uint32_t* lds;                      // 16 dwords of staging
+    uint32_t* strip_start;              // the image's strip table
+    uint32_t base, total;               // index of the lane's first token in the image's stream; tokens the lane emits (from the counting pass)
+    uint32_t emitted, nl;               // shipped so far; waiting in LDS
+    int sb, SB, left_in_row, row_blocks;    // block of the current strip, blocks per strip, blocks left in the MCU row
+    uint32_t strip, n_strips;
+    __device__ __forceinline__ void flush()
+    {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        struct __attribute__((packed, aligned(4))) V4 { u32x4 v; };
+        #pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (nl > (uint32_t)(4 * p)) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(lds + 4 * p);
+                uint32_t* dst = out + emitted + 4 * p;
+                if (emitted + 4 * p + 4 <= total) reinterpret_cast<V4*>(dst)->v = v;        // (the tail past nl is this lane's own: the next flush rewrites it)
+                else { for (uint32_t k = 0; k < 4 && emitted + 4 * p + k < total && 4 * p + k < nl; ++k) dst[k] = v[k]; }   // the lane's last dwords: exactly
+            }
+        }
+        emitted += nl; nl = 0;
+    }
+};
 // Checkpoints of a counting pass: the decoder's state and running totals the first time it stands at or behind byte j * ck_step of
 // its sub-sequence.  A lane that decodes its sub-sequence AGAIN (its entry state changed) falls into step with its previous pass
 // after a few symbols, like every Huffman decoder; from the first checkpoint where both passes stand in the same state the rest
 // is the previous pass word for word -- the lane stops there and keeps the old exit state and the old totals behind the
 // checkpoint.  Without this every re-decode ran its whole sub-sequence again (3.2 full counting passes per file on average; now
 // one and a fraction).  kSubCk checkpoints per lane live in the write sweep's block staging area (not in use before that sweep).
-constexpr int kSubCk = 7;
-struct SubCk { uint32_t pos; uint16_t cz, nblk; int dcs[3]; };                   // cz = c | z << 4
-static_assert(sizeof(SubCk) == 20, "checkpoint size");
+constexpr int kSubCk = 6;
+struct SubCk { uint32_t pos; uint16_t cz, nblk, ntok, pad; int dcs[3]; };        // cz = c | z << 4; nblk / ntok modulo 2^16 (only differences are used)
+static_assert(sizeof(SubCk) == 24, "checkpoint size");
 struct SubTrace {
     SubCk* ck;                      // this lane's kSubCk checkpoints (LDS), or nullptr
     uint32_t first_bit, step_bits;  // checkpoint j stands at bit first_bit + j * step_bits, j = 1 .. kSubCk
     bool compare;                   // a pass after the first: stop at a checkpoint that matches
     int old_nblk, old_dcs[3];       // the previous pass's totals
+    int old_ntok, ntok;             // tokens (every DC, every non-zero AC coefficient): the previous pass's total; this pass's (out)
     bool stopped;                   // out: the pass ended at a matching checkpoint (exit state = the previous one)
 };
 template <int MODE>
 __device__ __forceinline__ bool sub_decode(const SubCtx& x, SubState& s, int& nblk, int (&dcs)[3], int64_t b, int64_t b_end,
-                                           int16_t* out, uint8_t* mz, int16_t* blk = nullptr, SubTrace* tr = nullptr)
+                                           int16_t* out, uint8_t* mz, int16_t* blk = nullptr, SubTrace* tr = nullptr, TokCtx* tk = nullptr)
 {
     constexpr bool WRITE = MODE != SUB_COUNT;
     DevBits br; br.open(x.seg, s.pos);
@@ -751,8 +787,10 @@ __device__ __forceinline__ bool sub_decode(const SubCtx& x, SubState& s, int& nb
     bool inherited = z > 0;                                                      // the block under way was started by another lane
     const int q0 = x.par[0], q1 = x.par[1], q2 = x.par[2], d0 = x.par[3], d1 = x.par[4], d2 = x.par[5], a0 = x.par[6], a1 = x.par[7], a2 = x.par[8];
     int dc0 = dcs[0], dc1 = dcs[1], dc2 = dcs[2];
+    int ntok = 0;
     int ck_j = 0;                                                                // checkpoints passed
     uint32_t ck_next = 0xFFFFFFFFu;
+    uint32_t steps = 0;
     if (MODE == SUB_COUNT && tr) { ck_next = tr->first_bit + tr->step_bits; tr->stopped = false; }
     while (br.pos < x.end_bit && (!WRITE || b < b_end)) {
         br.refill();                                                             // >= 33 bits: a code (<= 16) and its value (<= 15)
@@ -785,6 +823,16 @@ __device__ __forceinline__ bool sub_decode(const SubCtx& x, SubState& s, int& nb
         const int dcv = (comp == 0 ? dc0 : comp == 1 ? dc1 : dc2) + ext;
         const bool tdc = take && is_dc;
         dc0 = tdc && comp == 0 ? dcv : dc0; dc1 = tdc && comp == 1 ? dcv : dc1; dc2 = tdc && comp == 2 ? dcv : dc2;
+        ntok += take ? 1 : 0;
+        if (MODE == SUB_TOKENS) {
+            if (is_dc && tk->sb == 0) tk->strip_start[tk->strip] = tk->base + tk->emitted + tk->nl;       // this block opens a strip: its tokens begin here
+            if (take) {
+                const int16_t qf = x.quant[(comp == 0 ? q0 : comp == 1 ? q1 : q2) * 64 + k];
+                const uint32_t cv = (uint32_t)(uint16_t)(int16_t)((uint32_t)(is_dc ? dcv : ext) * (uint32_t)(int32_t)qf);
+                tk->lds[tk->nl] = (uint32_t)tk->sb << 26 | (uint32_t)x.zag[k] << 20 | cv;
+                ++tk->nl;
+            }
+        } else
         if (WRITE && take && (MODE == SUB_FIRST || !inherited)) {
             const int16_t qf = x.quant[(comp == 0 ? q0 : comp == 1 ? q1 : q2) * 64 + k];
             const int16_t cv = (int16_t)((uint32_t)(is_dc ? dcv : ext) * (uint32_t)(int32_t)qf);
@@ -794,6 +842,13 @@ __device__ __forceinline__ bool sub_decode(const SubCtx& x, SubState& s, int& nb
         const bool full = !is_dc && znew == 64;
         const bool done = bad || err_run || err_zrl || eob || full;
         ok = ok && !(bad || err_run || err_zrl);
+        if (MODE == SUB_TOKENS && done) {
+            mz[b] = (uint8_t)(full ? 64 : z);                                    // m_mcu_block_max_zag :2512 (EOB: the position it was read at)
+            ++tk->sb; --tk->left_in_row;
+            if (tk->sb == tk->SB || tk->left_in_row == 0) { tk->sb = 0; ++tk->strip; }
+            if (tk->left_in_row == 0) tk->left_in_row = tk->row_blocks;
+            if (b + 1 == b_end) tk->strip_start[tk->n_strips] = tk->base + tk->emitted + tk->nl;   // the segment's last block: the tokens end HERE (what the
+        }                                                                                          // counting passes saw behind it is not the image's)
         if (MODE == SUB_WRITE && done) {
             mz[b] = (uint8_t)(full ? 64 : z);                                    // m_mcu_block_max_zag :2512 (EOB: the position it was read at)
             if (!inherited) {
@@ -808,29 +863,32 @@ __device__ __forceinline__ bool sub_decode(const SubCtx& x, SubState& s, int& nb
         b += done ? 1 : 0; nblk += done ? 1 : 0;
         z = done ? 0 : znew;
         c = done ? (c + 1 == x.nb ? 0 : c + 1) : c;
+        if (MODE == SUB_TOKENS && (++steps & 15u) == 0) tk->flush();             // every lane of the wave at once: at most 16 tokens wait
         if (MODE == SUB_COUNT && br.pos >= ck_next) {                            // (never true without a trace)
             while (ck_j < kSubCk && br.pos >= ck_next) {                         // one symbol may step over several checkpoints (tiny steps)
                 SubCk& k = tr->ck[ck_j];
                 const uint16_t cz = (uint16_t)(c | z << 4);
                 if (tr->compare && k.pos == br.pos && k.cz == cz) {              // in step with the previous pass from here on
                     // what this pass counted up to here instead of the previous one: the later checkpoints and the totals move by it
-                    const int dn = (int16_t)((uint16_t)nblk - k.nblk), e0 = dc0 - k.dcs[0], e1 = dc1 - k.dcs[1], e2 = dc2 - k.dcs[2];
+                    const int dn = (int16_t)((uint16_t)nblk - k.nblk), dt = (int16_t)((uint16_t)ntok - k.ntok), e0 = dc0 - k.dcs[0], e1 = dc1 - k.dcs[1], e2 = dc2 - k.dcs[2];
                     for (int jj = ck_j; jj < kSubCk; ++jj) {
                         SubCk& q = tr->ck[jj];
-                        q.nblk = (uint16_t)(q.nblk + dn); q.dcs[0] += e0; q.dcs[1] += e1; q.dcs[2] += e2;
+                        q.nblk = (uint16_t)(q.nblk + dn); q.ntok = (uint16_t)(q.ntok + dt); q.dcs[0] += e0; q.dcs[1] += e1; q.dcs[2] += e2;
                     }
-                    nblk = tr->old_nblk + dn; dc0 = tr->old_dcs[0] + e0; dc1 = tr->old_dcs[1] + e1; dc2 = tr->old_dcs[2] + e2;
+                    nblk = tr->old_nblk + dn; ntok = tr->old_ntok + dt; dc0 = tr->old_dcs[0] + e0; dc1 = tr->old_dcs[1] + e1; dc2 = tr->old_dcs[2] + e2;
                     tr->stopped = true;
                     break;
                 }
-                k.pos = br.pos; k.cz = cz; k.nblk = (uint16_t)nblk; k.dcs[0] = dc0; k.dcs[1] = dc1; k.dcs[2] = dc2;
+                k.pos = br.pos; k.cz = cz; k.nblk = (uint16_t)nblk; k.ntok = (uint16_t)ntok; k.dcs[0] = dc0; k.dcs[1] = dc1; k.dcs[2] = dc2;
                 ++ck_j; ck_next += tr->step_bits;
             }
             if (tr->stopped) break;
             if (ck_j == kSubCk) ck_next = 0xFFFFFFFFu;
         }
     }
+    if (MODE == SUB_COUNT && tr) tr->ntok = ntok;
     if (MODE == SUB_COUNT && tr && tr->stopped) { dcs[0] = dc0; dcs[1] = dc1; dcs[2] = dc2; return ok; }      // s: untouched, the caller keeps the previous exit state
+    if (MODE == SUB_TOKENS) tk->flush();
     if (MODE == SUB_WRITE && z > 0 && !inherited && b < b_end) {                 // a block of this lane's that the next lanes finish: its line, as far as it goes
         const uint4* src = reinterpret_cast<const uint4*>(blk);
         uint4* dst = reinterpret_cast<uint4*>(out + b * 64);
@@ -858,10 +916,11 @@ __device__ unsigned long long g_sync_prof[8];
 #define SPROF(slot)
 #define SPROF_COUNT(slot, n)
 #endif
-template <int NH>
+template <int NH, bool TOK = false>
 __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevItem* items, const DevImage* images,
                                                                     const DevHuff* huff_g, int n_huff, const int16_t* quant_g, int n_quant,
-                                                                    const uint8_t* blob, int16_t* coeffs, uint8_t* max_zag, uint32_t* status)
+                                                                    const uint8_t* blob, int16_t* coeffs, uint8_t* max_zag, uint32_t* status,
+                                                                    uint32_t* tokens = nullptr, uint32_t* strip_tab = nullptr)
 {
     constexpr bool IN_LDS = NH > 0;
     __shared__ DevHuff sh_huff[IN_LDS ? NH : 1];
@@ -870,10 +929,10 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevIte
     __shared__ SubState exit_state[kSyncThreads];
     __shared__ int changed, failed, par[9];
     __shared__ __attribute__((aligned(16))) uint8_t sh_blk[kSyncThreads * 144];             // the write sweep: a block per lane (144-byte pitch)
-    // blocks finished, DC-difference sums of the three components: prefix-summed between the counting passes and the write sweep,
+    // blocks finished, DC-difference sums of the three components, tokens: prefix-summed between the counting passes and the write sweep,
     // in the staging area (whose checkpoints are done with by then, and which is cleared afterwards)
     int (*scan)[kSyncThreads] = reinterpret_cast<int (*)[kSyncThreads]>(sh_blk);
-    static_assert(4 * kSyncThreads * sizeof(int) <= kSyncThreads * 144, "the scan borrows the staging area");
+    static_assert(5 * kSyncThreads * sizeof(int) <= kSyncThreads * 144, "the scan borrows the staging area");
     load_tables<IN_LDS, kSyncThreads>(sh_huff, sh_quant, sh_zag, huff_g, n_huff, quant_g, n_quant);
     const int t = threadIdx.x;
     {
@@ -896,21 +955,22 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevIte
     const bool active = t < nsub;
     const SubCtx x{ IN_LDS ? sh_huff : huff_g, IN_LDS ? sh_quant : quant_g, sh_zag, blob + it.begin, min((uint32_t)(t + 1) * sub, len) * 8u,
                     par, im.ny, im.nb };
-    int16_t* out = coeffs + im.coeff_off + (int64_t)it.first_mcu * im.nb * 64;
+    int16_t* out = TOK ? nullptr : coeffs + im.coeff_off + (int64_t)it.first_mcu * im.nb * 64;
     uint8_t* mz = max_zag + im.zag_off + (int64_t)it.first_mcu * im.nb;
     const int64_t total_blocks = (int64_t)it.n_mcus * im.nb;
 
     // sweep 0: every lane from the start of its own sub-sequence, as if a block began there
     SubState entry{ (uint32_t)t * sub * 8u, 0, 0 }, mine = entry;
-    int nblk = 0, dcs[3] = { 0, 0, 0 };
+    int nblk = 0, dcs[3] = { 0, 0, 0 }, ntok = 0;
     SubTrace tr;
     tr.ck = reinterpret_cast<SubCk*>(sh_blk + t * 144); tr.first_bit = (uint32_t)t * sub * 8u; tr.step_bits = ((sub + kSubCk) / (kSubCk + 1)) * 8u;
-    tr.compare = false; tr.old_nblk = 0; tr.old_dcs[0] = tr.old_dcs[1] = tr.old_dcs[2] = 0; tr.stopped = false;
+    tr.compare = false; tr.old_nblk = 0; tr.old_dcs[0] = tr.old_dcs[1] = tr.old_dcs[2] = 0; tr.old_ntok = 0; tr.ntok = 0; tr.stopped = false;
     static_assert(kSubCk * sizeof(SubCk) <= 144, "the checkpoints borrow the lane's block staging area");
     if (active) {
         #pragma unroll
         for (int j = 0; j < kSubCk; ++j) tr.ck[j].pos = 0xFFFFFFFFu;             // (a pass that ends early leaves the later ones unset: never a match)
         sub_decode<SUB_COUNT>(x, mine, nblk, dcs, 0, 0, nullptr, nullptr, nullptr, &tr);
+        ntok = tr.ntok;
     }
     exit_state[t] = mine;
     __syncthreads();
@@ -922,9 +982,10 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevIte
         __syncthreads();                                        // everybody has read its predecessor
         if (active && (sweep == 0 || !same(from, entry))) {
             entry = from; mine = from;
-            tr.compare = true; tr.old_nblk = nblk; tr.old_dcs[0] = dcs[0]; tr.old_dcs[1] = dcs[1]; tr.old_dcs[2] = dcs[2];
+            tr.compare = true; tr.old_nblk = nblk; tr.old_dcs[0] = dcs[0]; tr.old_dcs[1] = dcs[1]; tr.old_dcs[2] = dcs[2]; tr.old_ntok = ntok;
             dcs[0] = dcs[1] = dcs[2] = 0;
             sub_decode<SUB_COUNT>(x, mine, nblk, dcs, 0, 0, nullptr, nullptr, nullptr, &tr);
+            ntok = tr.ntok;
             if (!tr.stopped && !same(mine, exit_state[t])) { exit_state[t] = mine; changed = 1; }
         }
         __syncthreads();
@@ -936,27 +997,67 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevIte
     }
     SPROF(1);
     (void)settled;                                              // the loop bound (one lane settles per sweep at worst) always reaches the fixed point
-    // exclusive prefix sums over the lanes: first block and DC predictors of every lane
+    // exclusive prefix sums over the lanes: first block, DC predictors and first token of every lane
     scan[0][t] = active ? nblk : 0; scan[1][t] = active ? dcs[0] : 0; scan[2][t] = active ? dcs[1] : 0; scan[3][t] = active ? dcs[2] : 0;
+    scan[4][t] = active ? ntok : 0;
     __syncthreads();
     for (int d = 1; d < kSyncThreads; d <<= 1) {
-        int v[4];
+        int v[5];
         #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = t >= d ? scan[k][t - d] : 0;
+        for (int k = 0; k < 5; ++k) v[k] = t >= d ? scan[k][t - d] : 0;
         __syncthreads();
         #pragma unroll
-        for (int k = 0; k < 4; ++k) scan[k][t] += v[k];
+        for (int k = 0; k < 5; ++k) scan[k][t] += v[k];
         __syncthreads();
     }
     const int64_t b0 = active ? scan[0][t] - nblk : 0;
     const int pred_in[3] = { scan[1][t] - dcs[0], scan[2][t] - dcs[1], scan[3][t] - dcs[2] };
     const int64_t finished = scan[0][kSyncThreads - 1];
+    const uint32_t tok0 = (uint32_t)(scan[4][t] - ntok), tok_total = (uint32_t)scan[4][kSyncThreads - 1];
     __syncthreads();                                            // everybody has its prefix sums: the area is the staging area again
     SPROF(2);
     {                                                           // the checkpoints are done with: the staging area starts out zero
         uint4* zb = reinterpret_cast<uint4*>(sh_blk + t * 144);
         #pragma unroll
         for (int i = 0; i < 9; ++i) zb[i] = make_uint4(0, 0, 0, 0);
+    }
+    if constexpr (TOK) {
+        // the compact hand-off: tokens instead of blocks (sub_decode<SUB_TOKENS>).  A stream that would emit more tokens than the image's
+        // slot holds (only a damaged one can: the slot is sized from the scan's length) emits none and is flagged.
+        uint32_t* const strip_start = strip_tab + im.strip_off;
+        const bool fits = tok_total <= (uint32_t)im.tok_cap;
+        if (!fits && t == 0) failed = 1;
+        if (active && fits) {
+            int pred[3] = { pred_in[0], pred_in[1], pred_in[2] };
+            SubState s = entry; int n2 = 0;
+            TokCtx tk;
+            tk.out = tokens + im.tok_off + tok0; tk.lds = reinterpret_cast<uint32_t*>(sh_blk + t * 144); tk.strip_start = strip_start;
+            tk.base = tok0; tk.total = (uint32_t)ntok; tk.emitted = 0; tk.nl = 0;
+            tk.SB = im.sb; tk.row_blocks = im.row_blocks; tk.n_strips = (uint32_t)im.n_strips;
+            const int64_t gb = (int64_t)it.first_mcu * im.nb + b0;               // the lane's first block, in the image
+            const int64_t row = gb / im.row_blocks; const int local = (int)(gb - row * im.row_blocks);
+            const int strips_per_row = (im.row_blocks + im.sb - 1) / im.sb;
+            tk.strip = (uint32_t)(row * strips_per_row + local / im.sb); tk.sb = local % im.sb; tk.left_in_row = im.row_blocks - local;
+            if (!sub_decode<SUB_TOKENS>(x, s, n2, pred, b0, total_blocks, nullptr, mz, nullptr, nullptr, &tk)) failed = 1;
+            if (t == nsub - 1 && b0 + n2 != total_blocks) failed = 1;             // the segment ended before its last block did
+        }
+        __syncthreads();
+        // the strips no block opened (a damaged stream ends early) are empty: their tokens "begin" at the end; blocks nobody reached
+        // have no coefficients (their strips' tiles stay zero) and max_zag 1
+        int64_t started = fits ? finished + (exit_state[nsub > 0 ? nsub - 1 : 0].z > 0 ? 1 : 0) : 0;
+        started = started > total_blocks ? total_blocks : started;
+        const int strips_per_row = (im.row_blocks + im.sb - 1) / im.sb;
+        int64_t first_empty = 0;
+        if (started > 0) { const int64_t lb = started - 1, row = lb / im.row_blocks; first_empty = row * strips_per_row + (lb - row * im.row_blocks) / im.sb + 1; }
+        const uint32_t end_tok = fits ? tok_total : 0u;
+        const bool complete = fits && finished >= total_blocks;                   // the lane that finished the last block wrote the end of the tokens itself
+        for (int64_t sidx = first_empty + t; sidx < im.n_strips + (complete ? 0 : 1); sidx += kSyncThreads) strip_start[sidx] = end_tok;
+        for (int64_t blk = started + t; blk < total_blocks; blk += kSyncThreads) mz[blk] = 1;
+        SPROF(3);
+        SPROF(4);
+        SPROF_COUNT(7, 1);
+        if (t == 0 && failed) atomicOr(status + it.image, 1u);
+        return;
     }
     if (active) {
         int pred[3] = { pred_in[0], pred_in[1], pred_in[2] };
@@ -983,7 +1084,6 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevIte
     SPROF_COUNT(7, 1);
     if (t == 0 && failed) atomicOr(status + it.image, 1u);
 }
-
 
 // ---- the scan as it stands in the file -> the unstuffed, padded segments the two kernels above read, ON THE DEVICE --------------------
 // get_bits_no_markers (jpegload.d:722-743) and get_octet (:683-696) skip the 0x00 behind a data 0xFF while they read, and
@@ -1274,8 +1374,16 @@ constexpr int kDeferred = -1000;                               // FilePrep.rc of
 // sizes and places the coefficient buffers: the caller of the coefficient-level entry point did that beforehand);
 // `group_done(lo, hi, gs)` runs right after the entropy kernels of files [lo, hi) have been queued on stream gs -- the
 // reconstruction of a group is queued behind its own entropy decode, beside the decode of the next group.
+// The compact hand-off (tokens instead of dense blocks, SUB_TOKENS above) is the hook owner's choice per image: `tok_ok[i]` says which
+// images could take it (4:2:0, one long segment, scan unstuffed on the device), `scan_len[i]` bounds their token count; the hook sets
+// tok[i] and places the image's token slot and strip table (tok_off / strip_off / tok_cap; the buffers through d_tokens / d_strip_tab).
+struct TokenPlan {
+    const char* tok_ok; const size_t* scan_len;               // in
+    char* tok; int64_t* tok_off; int64_t* strip_off; int32_t* tok_cap; uint32_t** d_tokens; uint32_t** d_strip_tab;     // out
+};
 struct DecodeHooks {
-    std::function<int(const gamut_hip_jpeg_frame* info, const int* rc, const char* progressive, int64_t* coeff_offset, int64_t* zag_offset, int16_t** d_coeffs, uint8_t** d_max_zag)> layout;
+    std::function<int(const gamut_hip_jpeg_frame* info, const int* rc, const char* progressive, int64_t* coeff_offset, int64_t* zag_offset, int16_t** d_coeffs, uint8_t** d_max_zag,
+                      const TokenPlan& plan)> layout;
     std::function<int(int lo, int hi, hipStream_t gs)> group_done;
 };
 int entropy_decode_device(const uint8_t* const* data, const size_t* len, int count,
@@ -1308,10 +1416,21 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
     }
     std::vector<int> progressive;                              // SOF2 files: decoded by progressive_decode_device after the baseline ones
     for (int i = 0; i < count; ++i) if (prep[(size_t)i].progressive) { progressive.push_back(i); prep[(size_t)i].rc = kDeferred; }
+    std::vector<char> tok((size_t)count, 0);
+    std::vector<int64_t> tok_off((size_t)count, 0), strip_off((size_t)count, 0);
+    std::vector<int32_t> tok_cap((size_t)count, 0);
+    uint32_t* d_tokens = nullptr; uint32_t* d_strip_tab = nullptr;
     if (hooks && hooks->layout) {
-        std::vector<int> rcs((size_t)count); std::vector<char> progs((size_t)count);
-        for (int i = 0; i < count; ++i) { rcs[(size_t)i] = prep[(size_t)i].rc == kDeferred ? GAMUT_HIP_OK : prep[(size_t)i].rc; progs[(size_t)i] = prep[(size_t)i].progressive; }
-        if (int rc = hooks->layout(info, rcs.data(), progs.data(), own_offsets.data(), own_offsets.data() + count, &d_coeffs, &d_max_zag)) return rc;
+        std::vector<int> rcs((size_t)count); std::vector<char> progs((size_t)count), tok_ok((size_t)count, 0);
+        std::vector<size_t> scan_len((size_t)count, 0);
+        for (int i = 0; i < count; ++i) {
+            const FilePrep& fp = prep[(size_t)i];
+            rcs[(size_t)i] = fp.rc == kDeferred ? GAMUT_HIP_OK : fp.rc; progs[(size_t)i] = fp.progressive;
+            tok_ok[(size_t)i] = fp.rc == GAMUT_HIP_OK && info[i].scan_type == GAMUT_JPGD_YH2V2 && fp.dev_unstuff && fp.items.size() == 1 && (uint32_t)fp.items[0].pad >= kSyncMinBytes;
+            scan_len[(size_t)i] = fp.raw_len;
+        }
+        const TokenPlan plan{ tok_ok.data(), scan_len.data(), tok.data(), tok_off.data(), strip_off.data(), tok_cap.data(), &d_tokens, &d_strip_tab };
+        if (int rc = hooks->layout(info, rcs.data(), progs.data(), own_offsets.data(), own_offsets.data() + count, &d_coeffs, &d_max_zag, plan)) return rc;
     }
     // B. serial: table de-duplication, slots of the files in the blob
     std::vector<DevImage> images((size_t)count);
@@ -1325,6 +1444,10 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
         memset(&im, 0, sizeof(im));
         if (fp.rc != GAMUT_HIP_OK) continue;
         im.coeff_off = coeff_offset[i]; im.zag_off = zag_offset[i]; im.nb = fp.nb; im.ny = fp.ny;
+        if (tok[(size_t)i]) {                                  // strips = the reconstruction kernel's: 8 MCUs of 6 blocks along an MCU row
+            im.tok = 1; im.tok_off = tok_off[(size_t)i]; im.strip_off = strip_off[(size_t)i]; im.tok_cap = tok_cap[(size_t)i];
+            im.sb = 48; im.row_blocks = info[i].mcus_per_row * 6; im.n_strips = info[i].mcus_per_col * ((info[i].mcus_per_row + 7) / 8);
+        }
         for (int c = 0; c < fp.comps; ++c) { im.quant[c] = intern(quants, fp.quant[c]); im.dc[c] = intern(huffs, fp.huff[c][0]); im.ac[c] = intern(huffs, fp.huff[c][1]); }
         blob_off[(size_t)i] = blob_size;
         blob_size += (fp.cap + 15) & ~(size_t)15;
@@ -1465,9 +1588,12 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
                 for (DevItem it : fp.items) { if (!fp.dev_unstuff) { it.begin += blob_off[(size_t)i]; it.end += blob_off[(size_t)i]; } items.push_back(it); }
             }
             if (items.empty()) continue;
-            std::stable_partition(items.begin(), items.end(), [](const DevItem& it) { return (uint32_t)it.pad >= kSyncMinBytes; });
-            n_long = 0;
-            while (n_long < (int)items.size() && (uint32_t)items[(size_t)n_long].pad >= kSyncMinBytes) ++n_long;
+            auto klass = [&](const DevItem& it) { return tok[(size_t)it.image] ? 0 : (uint32_t)it.pad >= kSyncMinBytes ? 1 : 2; };
+            std::stable_sort(items.begin(), items.end(), [&](const DevItem& x, const DevItem& y) { return klass(x) < klass(y); });
+            int n_tok = 0;
+            while (n_tok < (int)items.size() && klass(items[(size_t)n_tok]) == 0) ++n_tok;
+            n_long = n_tok;
+            while (n_long < (int)items.size() && klass(items[(size_t)n_long]) == 1) ++n_long;
             const int n_items = (int)items.size(), n_short = n_items - n_long;
             total_long += n_long; total_short += n_short;
             if (items_off + items.size() * sizeof(DevItem) > total) return set_error(GAMUT_HIP_ERR_DECODE, "jpeg: more segments than the restart intervals allow");
@@ -1509,12 +1635,18 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
                 hipLaunchKernelGGL(k_jpeg_unstuff, dim3((unsigned)raws.size()), dim3(kUnstuffThreads), 0, gs, d_raws, d_items, (const uint8_t*)d_raw, d_blob_w, st);
                 if (int rc = launch_status("jpeg_unstuff")) return rc;
             }
-            if (n_long) {
-                static const int force_nh = [] { const char* e = getenv("GAMUT_HIP_JPEG_TABLES_LDS"); return e && *e ? atoi(e) : -1; }();     // measurements: 0 / 4 / 8
-                if (force_nh == 0) hipLaunchKernelGGL(k_jpeg_entropy_sync<0>, dim3(n_long), dim3(kSyncThreads), 0, gs, d_items, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
-                else if (n_huff <= 4 && n_quant <= 4 && force_nh != 8) hipLaunchKernelGGL(k_jpeg_entropy_sync<4>, dim3(n_long), dim3(kSyncThreads), 0, gs, d_items, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
-                else if (in_lds) hipLaunchKernelGGL(k_jpeg_entropy_sync<kLdsHuff>, dim3(n_long), dim3(kSyncThreads), 0, gs, d_items, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
-                else        hipLaunchKernelGGL(k_jpeg_entropy_sync<0>, dim3(n_long), dim3(kSyncThreads), 0, gs, d_items, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st);
+            static const int force_nh = [] { const char* e = getenv("GAMUT_HIP_JPEG_TABLES_LDS"); return e && *e ? atoi(e) : -1; }();     // measurements: 0 / 4 / 8
+            const int nh_sel = force_nh == 0 ? 0 : (n_huff <= 4 && n_quant <= 4 && force_nh != 8) ? 4 : in_lds ? kLdsHuff : 0;
+            if (n_tok) {                                       // long segments of the images that hand over tokens
+#define GAMUT_SYNC_TOK(NH) hipLaunchKernelGGL((k_jpeg_entropy_sync<NH, true>), dim3(n_tok), dim3(kSyncThreads), 0, gs, d_items, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st, d_tokens, d_strip_tab)
+                if (nh_sel == 4) GAMUT_SYNC_TOK(4); else if (nh_sel == kLdsHuff) GAMUT_SYNC_TOK(kLdsHuff); else GAMUT_SYNC_TOK(0);
+#undef GAMUT_SYNC_TOK
+                if (int rc = launch_status("jpeg_entropy_sync (tokens)")) return rc;
+            }
+            if (n_long > n_tok) {
+#define GAMUT_SYNC_DENSE(NH) hipLaunchKernelGGL((k_jpeg_entropy_sync<NH, false>), dim3(n_long - n_tok), dim3(kSyncThreads), 0, gs, d_items + n_tok, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st, (uint32_t*)nullptr, (uint32_t*)nullptr)
+                if (nh_sel == 4) GAMUT_SYNC_DENSE(4); else if (nh_sel == kLdsHuff) GAMUT_SYNC_DENSE(kLdsHuff); else GAMUT_SYNC_DENSE(0);
+#undef GAMUT_SYNC_DENSE
                 if (int rc = launch_status("jpeg_entropy_sync")) return rc;
             }
             if (n_short) {
@@ -1703,36 +1835,70 @@ int gamut_hip_jpeg_decode_batch_device(const uint8_t* const* data, const size_t*
         return set_error(GAMUT_HIP_ERR_NO_DEVICE, "no HIP device available (libgamut_hip has no CPU fallback)");
     try {
         hipStream_t st = pick_stream(stream);
-        static thread_local PerDevice<DeviceScratch> co_pd, zz_pd;
+        static thread_local PerDevice<DeviceScratch> co_pd, zz_pd, tok_pd, strip_pd, offs_pd;
         DeviceScratch& s_co = co_pd.cur(); DeviceScratch& s_zz = zz_pd.cur();
-        std::vector<int64_t> co_off((size_t)count, 0), zz_off((size_t)count, 0);
-        std::vector<char> ok((size_t)count, 0), prog((size_t)count, 0);
+        std::vector<int64_t> co_off((size_t)count, 0), zz_off((size_t)count, 0), tk_off((size_t)count, 0), sp_off((size_t)count, 0);
+        std::vector<char> ok((size_t)count, 0), prog((size_t)count, 0), tokm((size_t)count, 0);
         int16_t* d_co = nullptr; uint8_t* d_zz = nullptr;
+        uint32_t* d_tok = nullptr; uint32_t* d_strip = nullptr; int64_t* d_offs = nullptr;      // d_offs: [count] token offsets, [count] strip-table offsets
+        // the hand-off between the entropy kernels and the reconstruction: tokens (the default where an image can: 4:2:0, one long
+        // segment) or the dense 128-byte blocks of the public coefficient-level entry point; GAMUT_HIP_JPEG_HANDOFF=dense forces the latter
+        const char* ho_env = getenv("GAMUT_HIP_JPEG_HANDOFF");
+        const bool want_tokens = !(ho_env && !strcmp(ho_env, "dense"));
         DecodeHooks hooks;
-        hooks.layout = [&](const gamut_hip_jpeg_frame* f, const int* rc, const char* progressive, int64_t* coeff_offset, int64_t* zag_offset, int16_t** pco, uint8_t** pzz) -> int {
-            int64_t blocks = 0;
+        hooks.layout = [&](const gamut_hip_jpeg_frame* f, const int* rc, const char* progressive, int64_t* coeff_offset, int64_t* zag_offset, int16_t** pco, uint8_t** pzz,
+                           const TokenPlan& plan) -> int {
+            int64_t blocks = 0, zblocks = 0, tokens = 0, strips = 0;
             for (int i = 0; i < count; ++i) {
-                coeff_offset[i] = blocks * 64; zag_offset[i] = blocks;
-                co_off[(size_t)i] = blocks * 64; zz_off[(size_t)i] = blocks;
+                coeff_offset[i] = blocks * 64; zag_offset[i] = zblocks;
+                co_off[(size_t)i] = blocks * 64; zz_off[(size_t)i] = zblocks;
                 ok[(size_t)i] = rc[i] == GAMUT_HIP_OK; prog[(size_t)i] = progressive[i];
-                if (ok[(size_t)i]) blocks += (int64_t)f[i].mcus_per_row * f[i].mcus_per_col * f[i].blocks_per_mcu;
+                if (!ok[(size_t)i]) continue;
+                const int64_t nblk = (int64_t)f[i].mcus_per_row * f[i].mcus_per_col * f[i].blocks_per_mcu;
+                zblocks += nblk;
+                // a token per DC and per non-zero AC coefficient: at most 64 per block, and no more than the scan has bit pairs plus a
+                // DC token per block (a token costs two bits of the scan at least, a DC token of a block that ends at once one)
+                const int64_t cap = std::min<int64_t>(nblk * 64, (int64_t)plan.scan_len[i] * 4 + nblk) + 16;
+                if (want_tokens && plan.tok_ok[i] && cap < 0x7fffffff) {
+                    tokm[(size_t)i] = 1; plan.tok[i] = 1;
+                    tk_off[(size_t)i] = tokens; plan.tok_off[i] = tokens; plan.tok_cap[i] = (int32_t)cap;
+                    sp_off[(size_t)i] = strips; plan.strip_off[i] = strips;
+                    tokens += (cap + 3) & ~(int64_t)3;
+                    strips += (int64_t)f[i].mcus_per_col * ((f[i].mcus_per_row + 7) / 8) + 1;
+                } else blocks += nblk;
             }
-            d_co = (int16_t*)s_co.get((size_t)blocks * 128 + 256, st); d_zz = (uint8_t*)s_zz.get((size_t)blocks + 256, st);
+            d_co = (int16_t*)s_co.get((size_t)blocks * 128 + 256, st); d_zz = (uint8_t*)s_zz.get((size_t)zblocks + 256, st);
             if (!d_co || !d_zz) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg_decode_batch_device: %lld coefficient blocks do not fit the device", (long long)blocks);
             *pco = d_co; *pzz = d_zz;
+            if (tokens) {
+                d_tok = (uint32_t*)tok_pd.cur().get((size_t)tokens * 4 + 256, st);
+                d_strip = (uint32_t*)strip_pd.cur().get((size_t)strips * 4 + 256, st);
+                d_offs = (int64_t*)offs_pd.cur().get((size_t)count * 16 + 256, st);
+                if (!d_tok || !d_strip || !d_offs) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg_decode_batch_device: %lld tokens do not fit the device", (long long)tokens);
+                *plan.d_tokens = d_tok; *plan.d_strip_tab = d_strip;
+                // (pageable sources: the runtime has read them when the calls return; the kernels that use the table are queued later)
+                GAMUT_HIP_CHECK(hipMemcpyAsync(d_offs, tk_off.data(), (size_t)count * 8, hipMemcpyHostToDevice, st));
+                GAMUT_HIP_CHECK(hipMemcpyAsync(d_offs + count, sp_off.data(), (size_t)count * 8, hipMemcpyHostToDevice, st));
+            }
             return GAMUT_HIP_OK;
         };
-        // images [lo, hi) -> pixels: runs of images of one geometry at even strides go out as one batched launch
+        // images [lo, hi) -> pixels: runs of images of one geometry (and one kind of hand-off) at even strides go out as one batched launch
         auto reconstruct = [&](int lo, int hi, hipStream_t gs, bool progressive_only) -> int {
             for (int i = lo; i < hi; ) {
                 const gamut_hip_jpeg_frame& f = info[i];
                 const bool mine = ok[(size_t)i] && (prog[(size_t)i] != 0) == progressive_only;
                 if (!mine) { ++i; continue; }
                 const int64_t nblk = (int64_t)f.mcus_per_row * f.mcus_per_col * f.blocks_per_mcu;
+                const bool tk = tokm[(size_t)i] != 0;
                 int j = i + 1;
                 const int64_t ostride = j < hi ? out_offset[j] - out_offset[i] : 0;
-                while (j < hi && ok[(size_t)j] && (prog[(size_t)j] != 0) == progressive_only && info[j].width == f.width && info[j].height == f.height &&
-                       info[j].scan_type == f.scan_type && co_off[(size_t)j] - co_off[(size_t)j - 1] == nblk * 64 && out_offset[j] - out_offset[j - 1] == ostride && ostride > 0) ++j;
+                while (j < hi && ok[(size_t)j] && (prog[(size_t)j] != 0) == progressive_only && (tokm[(size_t)j] != 0) == tk && info[j].width == f.width && info[j].height == f.height &&
+                       info[j].scan_type == f.scan_type && (tk || co_off[(size_t)j] - co_off[(size_t)j - 1] == nblk * 64) && zz_off[(size_t)j] - zz_off[(size_t)j - 1] == nblk &&
+                       out_offset[j] - out_offset[j - 1] == ostride && ostride > 0) ++j;
+                if (tk) {
+                    if (int rc = jpeg_reconstruct_tokens_launch(d_tok, d_strip, d_offs + i, d_offs + count + i, d_zz + zz_off[(size_t)i], nblk, out + out_offset[i],
+                                                                (int64_t)f.width * req_comps, j - i > 1 ? ostride : 0, f.width, f.height, req_comps, j - i, gs)) return rc;
+                } else
                 if (int rc = jpeg_reconstruct_launch(d_co + co_off[(size_t)i], nblk * 64, d_zz + zz_off[(size_t)i], nblk, out + out_offset[i], (int64_t)f.width * req_comps,
                                                      j - i > 1 ? ostride : 0, f.width, f.height, f.scan_type, req_comps, j - i, gs)) return rc;
                 i = j;

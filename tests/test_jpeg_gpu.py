@@ -310,7 +310,52 @@ def _decode_batch_device(L, blobs, comps):
     return rc, list(hst), res
 
 
-def test_files_to_pixels_batch(hip, progressive_mode):
+@pytest.fixture(params=["tokens", "dense"])
+def handoff(request):
+    """what the entropy kernels hand to the reconstruction inside gamut_hip_jpeg_decode_batch_device: the token stream (4:2:0 images of one
+    long segment; the library's choice) or the dense 128-byte blocks of the coefficient-level entry point"""
+    old = os.environ.get("GAMUT_HIP_JPEG_HANDOFF")
+    os.environ["GAMUT_HIP_JPEG_HANDOFF"] = request.param
+    yield request.param
+    if old is None:
+        del os.environ["GAMUT_HIP_JPEG_HANDOFF"]
+    else:
+        os.environ["GAMUT_HIP_JPEG_HANDOFF"] = old
+
+
+def test_files_to_pixels_token_handoff(hip, handoff):
+    """4:2:0 files of one long segment -- the ones that hand over tokens -- of many shapes: widths that end in a partial strip, one MCU
+    row, quality 30 .. 100 (3 .. 60 tokens per block), optimised tables, a flat image (a DC token per block and nothing else), noise at
+    q 100 (blocks of 64 tokens), mixed with files that keep the dense blocks (4:4:4, grey, restart intervals) and damaged ones: every
+    file's pixels == the oracle's, for rgba8 / rgb8 / l8"""
+    import io
+    from PIL import Image
+    import gen
+    rng = np.random.default_rng(17)
+    blobs = []
+    for (w, h, kw) in ((1920, 1080, dict(quality=90)), (1000, 700, dict(quality=30)), (129, 260, dict(quality=75, optimize=True)), (2048, 16, dict(quality=95)),
+                       (640, 480, dict(quality=100)), (333, 222, dict(quality=85)), (16, 4000, dict(quality=80))):
+        bio = io.BytesIO(); Image.fromarray(gen.synth_rgb(w, h, 40 + w)).save(bio, "JPEG", subsampling=2, **kw); blobs.append(bio.getvalue())
+    bio = io.BytesIO(); Image.fromarray(np.full((300, 500, 3), 90, np.uint8)).save(bio, "JPEG", quality=90, subsampling=2); blobs.append(bio.getvalue())
+    bio = io.BytesIO(); Image.fromarray(rng.integers(0, 256, (200, 264, 3), dtype=np.uint8)).save(bio, "JPEG", quality=100, subsampling=2); blobs.append(bio.getvalue())
+    bio = io.BytesIO(); Image.fromarray(gen.synth_rgb(500, 400, 7)).save(bio, "JPEG", quality=90, subsampling=0); blobs.append(bio.getvalue())
+    bio = io.BytesIO(); Image.fromarray(gen.synth_rgb(500, 400, 8)).convert("L").save(bio, "JPEG", quality=90); blobs.append(bio.getvalue())
+    bio = io.BytesIO(); Image.fromarray(gen.synth_rgb(800, 600, 9)).save(bio, "JPEG", quality=90, subsampling=2, restart_marker_rows=1); blobs.append(bio.getvalue())
+    good = list(range(len(blobs)))
+    big = blobs[0]; sos = big.index(b"\xff\xda")
+    noisy = bytearray(big)
+    for k in rng.integers(sos + 20, len(big) - 2, 200):
+        noisy[k] = int(rng.integers(0, 255))
+    blobs += [bytes(noisy), big[:len(big) // 3]]                      # damaged scans: reported, their neighbours untouched
+    for comps in (4, 3, 1):
+        rc, hst, res = _decode_batch_device(hip, blobs, comps)
+        assert rc != 0 and hst[-1] != 0
+        for i in good:
+            assert hst[i] == 0, (i, hst[i])
+            assert np.array_equal(res[i], O.decompress_jpeg(blobs[i], comps)[0]), (i, comps, handoff)
+
+
+def test_files_to_pixels_batch(hip, progressive_mode, handoff):
     """gamut_hip_jpeg_decode_batch_device: every fixture (baseline and progressive, every sampling mode, restart intervals) plus
     damaged files in ONE batch -> the pixels decompress_jpeg_image_from_memory gives (== the oracle), for rgba8 / rgb8 / l8; a bad
     file is reported and does not disturb its neighbours"""
@@ -328,7 +373,7 @@ def test_files_to_pixels_batch(hip, progressive_mode):
             assert hst[i] == 0 and np.array_equal(res[i], exp[0]), (i, comps)
 
 
-def test_files_to_pixels_uniform_batch_in_groups(hip):
+def test_files_to_pixels_uniform_batch_in_groups(hip, handoff):
     """a batch large enough for the grouped pipeline (>= 256 files: two groups, each reconstructed behind its own entropy decode,
     runs of equal geometry as one launch): 300 files of three kinds"""
     kinds = [open(os.path.join(HERE, "golden", "jpeg", n), "rb").read() for n in ("cfg1_640x480_420_q90.jpg", "s_131x97_420_rst.jpg", "s_131x97_444.jpg")]
@@ -580,7 +625,7 @@ def test_device_unstuff_restart_marker_errors(hip, unstuff_site):
         assert np.array_equal(res[i][0], d.coeffs) and np.array_equal(res[i][1], d.max_zag)
 
 
-def test_files_to_pixels_reports_damaged_entropy_data(hip):
+def test_files_to_pixels_reports_damaged_entropy_data(hip, handoff):
     """gamut_hip_jpeg_decode_batch_device folds what the kernels flag into the per-file status and the return value (no status array
     needed to learn that a scan was damaged), like the PNG batch call; the neighbours' pixels are the oracle's"""
     import io

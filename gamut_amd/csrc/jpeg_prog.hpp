@@ -6,9 +6,11 @@
 // scans before it left (successive approximation Ah / Al).  Inside a scan the stream is one chain -- a symbol's length tells
 // where the next begins, an AC refinement symbol is followed by one correction bit per ALREADY non-zero coefficient it
 // passes, so even a decoder that knew a codeword boundary could not start there -- but:
-//   * scans that share no coefficient (other component, or disjoint bands) are independent of each other: the scans of a file
-//     form levels (level = 1 + the deepest earlier scan that touches the same component and band), and a launch decodes every
-//     scan of one level of every file of the batch at once (a typical file: 10 scans, 3 levels);
+//   * scans that share no coefficient (other component, or disjoint bands) are independent of each other, and a scan that stands on
+//     another one (refines its bits) only needs the BLOCKS it is about to read: ONE launch decodes every scan of every file of the
+//     batch, a wave per scan (per restart segment), and a scan follows the scans it stands on a few dozen units behind (progress
+//     words in memory, ProgItem::dep) instead of waiting for them to end -- the decode time of a file is its longest scan, not the
+//     sum over the levels of its script (round 4; until then: one launch per level of the script);
 //   * restart intervals cut a scan into independent segments, as in baseline files;
 //   * a DC refinement scan is one bit per block: a lane per bit;
 //   * an AC refinement block is a wave's work, not a lane's: lane k holds the coefficient at zig-zag position k, the
@@ -33,8 +35,20 @@ struct ProgItem {                      // one restart interval (or whole scan) o
     int32_t image, kind, ncomp, ss, se, al;
     int32_t comp[3], tab[3];           // components in scan order, their DC (DC scans) or AC table
     int32_t first_unit, n_units;       // units: MCUs of an interleaved scan, blocks (raster order of nbx x nby) of a single-component one
-    int32_t nbx, level;                // level: host only (which launch)
+    int32_t nbx, level;                // level: host only (the order of a file's items)
+    // One launch decodes every scan of every file; what a scan needs from earlier ones it waits for, item by item (indices into the
+    // launch's item list, always lower than the item's own: items are taken in list order, so what an item waits for is running or done).
+    // dep[i] >= 0: a scan that wrote coefficients this one reads or overwrites.  Bit i of dep_pipe: that scan walks the same units in
+    // the same order (same components, same restart segment), so unit u may go ahead once the dependency has published u + 1 --
+    // the scans of a file run a few dozen units behind each other instead of one after the other.  Otherwise: wait for all of it.
+    // ctr >= 0 (scripts whose scans do not line up): the file's count of finished items; the item starts when it has reached ctr_need
+    // (= the items of the file's lower levels) and adds one when it is done.
+    int32_t dep[3], dep_pipe, ctr, ctr_need;
+    int32_t scan, seg;                 // host only: the scan of the file, the restart segment of the scan
+    int32_t prio, pad_;                // s_setprio of the item's wave: the long chains of a file first (they are its decode time), the short ones in the gaps
 };
+constexpr uint32_t kProgDone = 0x7FFFFFFFu;     // an item's progress word once it has returned (whatever its verdict)
+constexpr int kProgBatch = 64;                  // units between two looks at / reports of progress
 
 // block (bx, by) of component c in the MCU-ordered buffer
 __device__ __forceinline__ int64_t prog_block(const ProgImage& im, int c, int bx, int by)
@@ -122,19 +136,22 @@ struct WaveHuff {
 };
 
 // sampling factors are 1 or 2 (the marker walk rejects anything else): divisions by them are shifts
-__device__ __forceinline__ int64_t prog_block_fast(const ProgImage& im, int hs, int vs, int off, int bx, int by)
+__device__ __forceinline__ int64_t prog_block_fast(int mcus_per_row, int nb, int hs, int vs, int off, int bx, int by)
 {
     const int mx = bx >> (hs - 1), my = by >> (vs - 1);
-    return ((int64_t)my * im.mcus_per_row + mx) * im.nb + off + (by & (vs - 1)) * hs + (bx & (hs - 1));
+    return ((int64_t)my * mcus_per_row + mx) * nb + off + (by & (vs - 1)) * hs + (bx & (hs - 1));
 }
 
-__global__ __launch_bounds__(kProgThreads) void k_prog_scan(const ProgItem* items, const ProgImage* images, const DevHuff* huff_g,
-                                                            const uint8_t* blob, int16_t* coeffs, uint32_t* status)
+// Coefficients cross compute units while the launch runs (a scan reads what an earlier scan of the file wrote microseconds ago, from
+// wherever that one runs): every store is write-through and every load reads past the caches (agent-scope relaxed atomics = sc1), a
+// progress word is stored behind `s_waitcnt vmcnt(0)` -- the placement-independent hand-off of k_png_defilter_queue, no fences.
+__device__ __forceinline__ int  co_load(const int16_t* p) { return (int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void co_store(int16_t* p, int v) { __hip_atomic_store(p, (int16_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ void prog_scan_body(const ProgItem& it, const ProgImage& im, DevHuff* sh_huff, const DevHuff* huff_g,
+                                               const uint8_t* blob, int16_t* coeffs, uint32_t* status, uint32_t* prog, const uint32_t* counters, int me, uint32_t& waited)
 {
-    __shared__ DevHuff sh_huff[3];
     const int lane = threadIdx.x;
-    const ProgItem it = items[blockIdx.x];
-    const ProgImage im = images[it.image];
     const int kind = rfl(it.kind), ncomp = rfl(it.ncomp);
     if (kind != PROG_DC_REFINE)
         for (int i = 0; i < ncomp; ++i) {
@@ -148,7 +165,37 @@ __global__ __launch_bounds__(kProgThreads) void k_prog_scan(const ProgItem* item
     const uint32_t limit_bit = seg_bytes * 8u + 64u * 8u;       // a decoder that runs past the padding is on a corrupt stream
     int16_t* out = coeffs + im.coeff_off;
     uint32_t* st = status + im.index;
+    // progress: what this item may touch, and what it tells the items behind it
+    const int dep0 = rfl(it.dep[0]), dep1 = rfl(it.dep[1]), dep2 = rfl(it.dep[2]), dep_pipe = rfl(it.dep_pipe);
+    const bool has_deps = dep0 >= 0 || dep1 >= 0 || dep2 >= 0;
+    uint32_t seen0 = 0, seen1 = 0, seen2 = 0;                   // the dependencies' progress as last read (it only grows)
+    auto wait_word = [&](const uint32_t* w, uint32_t need, uint32_t& seen) {
+        if (seen >= need) return;
+        const uint64_t t0 = wall_clock64();
+        for (;;) {
+            seen = rfl(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (seen >= need) { waited += (uint32_t)(wall_clock64() - t0); break; }
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > 400000000ull) {           // 4 s of the 100 MHz clock: give up, say so, never hang
+                if (lane == 0) atomicOr(st, 16u);
+                seen = 0xFFFFFFFFu;
+                break;
+            }
+        }
+    };
+    auto wait_units = [&](int upto) {                           // units [0, upto) of this item may be decoded
+        if (!has_deps) return;
+        if (dep0 >= 0) wait_word(prog + dep0, (dep_pipe & 1) ? (uint32_t)upto : kProgDone, seen0);
+        if (dep1 >= 0) wait_word(prog + dep1, (dep_pipe & 2) ? (uint32_t)upto : kProgDone, seen1);
+        if (dep2 >= 0) wait_word(prog + dep2, (dep_pipe & 4) ? (uint32_t)upto : kProgDone, seen2);
+    };
+    auto publish = [&](int units_done) {                        // the coefficients of units [0, units_done) are final as far as this scan goes
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(prog + me, (uint32_t)units_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    if (rfl(it.ctr) >= 0 && rfl(it.ctr_need) > 0) { uint32_t seen = 0; wait_word(counters + rfl(it.ctr), (uint32_t)rfl(it.ctr_need), seen); }
     const int al = rfl(it.al), n_units = rfl(it.n_units), first_unit = rfl(it.first_unit);
+    const int mpr = rfl(im.mcus_per_row), nbm = rfl(im.nb);        // scalars of their own: the structs are indexed by component elsewhere and live in scratch memory
     const uint32_t zag_reg = kZagDev[lane];                     // natural index of zig-zag position `lane`; readlane(zag_reg, k) for a uniform k
     // geometry of the scan's components (scan order)
     int c_[3], hs_[3], vs_[3], off_[3];
@@ -164,13 +211,14 @@ __global__ __launch_bounds__(kProgThreads) void k_prog_scan(const ProgItem* item
         for (int i = 0; i < ncomp; ++i) bpu += (i == 0 ? hs_[0] * vs_[0] : i == 1 ? hs_[1] * vs_[1] : hs_[2] * vs_[2]);
         if (ncomp == 1) bpu = 1;
         const int total = n_units * bpu;
+        wait_units(n_units);                                    // the DC first scan of these units
         for (int t = lane; t < total; t += kProgThreads) {
             const int u = t / bpu, b = t - u * bpu;
             const uint32_t byte = (uint32_t)t >> 3;
             const uint32_t v = byte < seg_bytes ? seg[byte] : 0xFFu;                    // past the data: ones (get_octet :683-696)
             if ((v >> (7 - (t & 7))) & 1u) {
                 int ci; const int64_t blk = prog_unit_block(im, it, first_unit + u, b, ci);
-                out[blk * 64] = (int16_t)(out[blk * 64] | (1 << al));
+                co_store(out + blk * 64, co_load(out + blk * 64) | (1 << al));
             }
         }
         return;
@@ -182,30 +230,34 @@ __global__ __launch_bounds__(kProgThreads) void k_prog_scan(const ProgItem* item
         WaveHuff h0, h1, h2;
         h0.load(&sh_huff[0], lane); h1.load(&sh_huff[ncomp > 1 ? 1 : 0], lane); h2.load(&sh_huff[ncomp > 2 ? 2 : 0], lane);
         int pred0 = 0, pred1 = 0, pred2 = 0;
-        auto one = [&](int i, int64_t blk) -> bool {              // one block of the scan's i-th component
+        // one block of a component of the scan (its table, its predictor: by reference -- a choice by index among the three would
+        // keep all of them, and the bit reader with them, in scratch memory)
+        auto dc_block = [&](const WaveHuff& h, int& pred, int64_t blk) -> bool {
             uint64_t w0, w1; wb.window(pos, w0, w1);
-            int len; const int s = i == 0 ? h0.decode(w0, len) : i == 1 ? h1.decode(w0, len) : h2.decode(w0, len);
+            int len; const int s = h.decode(w0, len);
             if (s < 0) { if (lane == 0) atomicOr(st, 1u); return false; }
             const int n = s & 15;
             int v = n ? (int)((w0 << len) >> (64 - n)) : 0;
             if (n && v < (1 << (n - 1))) v += (int)(0xFFFFFFFFu << n) + 1;               // JPGD_HUFF_EXTEND :816-822
             pos += (uint32_t)(len + n);
-            v += i == 0 ? pred0 : i == 1 ? pred1 : pred2;
-            if (i == 0) pred0 = v; else if (i == 1) pred1 = v; else pred2 = v;
-            if (lane == 0) out[blk * 64] = (int16_t)((uint32_t)v << al);
+            v += pred; pred = v;
+            if (lane == 0) co_store(out + blk * 64, (int)((uint32_t)v << al));
             return true;
         };
+        auto one = [&](int i, int64_t blk) -> bool { return i == 0 ? dc_block(h0, pred0, blk) : i == 1 ? dc_block(h1, pred1, blk) : dc_block(h2, pred2, blk); };
         if (ncomp == 1) {
             const int nbx = rfl(it.nbx);
             int by = first_unit / nbx, bx = first_unit - by * nbx;
             for (int u = 0; u < n_units; ++u) {
-                if (!one(0, prog_block_fast(im, hs_[0], vs_[0], off_[0], bx, by))) return;
+                if ((u & (kProgBatch - 1)) == 0) { if (u) publish(u); wait_units(min(u + kProgBatch, n_units)); }
+                if (!one(0, prog_block_fast(mpr, nbm, hs_[0], vs_[0], off_[0], bx, by))) return;
                 if (pos > limit_bit) { if (lane == 0) atomicOr(st, 4u); return; }
                 if (++bx == nbx) { bx = 0; ++by; }
             }
         } else {
-            int64_t base = (int64_t)first_unit * im.nb;           // the MCU's first block: inside an MCU the scan order is the buffer's order
-            for (int u = 0; u < n_units; ++u, base += im.nb) {
+            int64_t base = (int64_t)first_unit * nbm;             // the MCU's first block: inside an MCU the scan order is the buffer's order
+            for (int u = 0; u < n_units; ++u, base += nbm) {
+                if ((u & (kProgBatch - 1)) == 0) { if (u) publish(u); wait_units(min(u + kProgBatch, n_units)); }
                 for (int i = 0; i < ncomp; ++i) {
                     const int nblk = i == 0 ? hs_[0] * vs_[0] : i == 1 ? hs_[1] * vs_[1] : hs_[2] * vs_[2];
                     const int off = i == 0 ? off_[0] : i == 1 ? off_[1] : off_[2];
@@ -225,10 +277,11 @@ __global__ __launch_bounds__(kProgThreads) void k_prog_scan(const ProgItem* item
     int eobrun = 0;
     if (kind == PROG_AC_FIRST) {                                // decode_block_ac_first :3335-3398
         for (int u = 0; u < n_units; ++u) {
+            if ((u & (kProgBatch - 1)) == 0) { if (u) publish(u); wait_units(min(u + kProgBatch, n_units)); }
             eobrun = rfl(eobrun);
             if (eobrun) --eobrun;
             else {
-                int16_t* blk = out + prog_block_fast(im, hs, vs, off, bx, by) * 64;
+                int16_t* blk = out + prog_block_fast(mpr, nbm, hs, vs, off, bx, by) * 64;
                 for (int k = ss; k <= se; ++k) {
                     k = rfl(k);
                     uint64_t w0, w1; wb.window(pos, w0, w1);
@@ -241,7 +294,7 @@ __global__ __launch_bounds__(kProgThreads) void k_prog_scan(const ProgItem* item
                         if (v < (1 << (size - 1))) v += (int)(0xFFFFFFFFu << size) + 1;
                         pos += (uint32_t)(len + size);
                         const int nat = __builtin_amdgcn_readlane((int)zag_reg, k);
-                        if (lane == 0) blk[nat] = (int16_t)((uint32_t)v << al);
+                        if (lane == 0) co_store(blk + nat, (int)((uint32_t)v << al));
                     } else if (run == 15) {
                         pos += (uint32_t)len;
                         if ((k += 15) > 63) { if (lane == 0) atomicOr(st, 2u); return; }
@@ -271,23 +324,27 @@ __global__ __launch_bounds__(kProgThreads) void k_prog_scan(const ProgItem* item
         constexpr int kAhead = 4;
         int16_t* ring_ptr[kAhead]; int ring_val[kAhead];
         int fx = bx, fy = by;                                   // the next block to fetch
+        for (int ub = 0; ub < n_units; ub += kProgBatch) {      // a batch of units: everything the scans before left in them is there
+        const int nu = min(kProgBatch, n_units - ub);
+        if (ub) publish(ub);
+        wait_units(ub + nu);
         #pragma unroll
         for (int a = 0; a < kAhead; ++a) {
             ring_ptr[a] = out; ring_val[a] = 0;
-            if (a < n_units) {
-                ring_ptr[a] = out + prog_block_fast(im, hs, vs, off, fx, fy) * 64; ring_val[a] = ring_ptr[a][nat];
+            if (a < nu) {
+                ring_ptr[a] = out + prog_block_fast(mpr, nbm, hs, vs, off, fx, fy) * 64; ring_val[a] = co_load(ring_ptr[a] + nat);
                 if (++fx == nbx) { fx = 0; ++fy; }
             }
         }
-        for (int u0 = 0; u0 < n_units; u0 += kAhead) {
+        for (int u0 = 0; u0 < nu; u0 += kAhead) {
             #pragma unroll
             for (int a = 0; a < kAhead; ++a) {
                 const int u = u0 + a;
-                if (u >= n_units) break;
+                if (u >= nu) break;
                 int coef = ring_val[a];
                 int16_t* const cur = ring_ptr[a];
-                if (u + kAhead < n_units) {
-                    ring_ptr[a] = out + prog_block_fast(im, hs, vs, off, fx, fy) * 64; ring_val[a] = ring_ptr[a][nat];
+                if (u + kAhead < nu) {
+                    ring_ptr[a] = out + prog_block_fast(mpr, nbm, hs, vs, off, fx, fy) * 64; ring_val[a] = co_load(ring_ptr[a] + nat);
                     if (++fx == nbx) { fx = 0; ++fy; }
                 }
                 const int orig = coef;
@@ -343,10 +400,39 @@ __global__ __launch_bounds__(kProgThreads) void k_prog_scan(const ProgItem* item
                     }
                     --eobrun;
                 }
-                if (coef != orig) cur[nat] = (int16_t)coef;
+                if (coef != orig) co_store(cur + nat, coef);
                 if (pos > limit_bit) { if (lane == 0) atomicOr(st, 4u); return; }
             }
         }
+        }
+    }
+}
+
+// One workgroup (a wave) per item, items taken in list order through a ticket: whatever an item waits for has a lower ticket and
+// is therefore running or done -- no deadlock however few wave slots the launch gets.
+__global__ __launch_bounds__(kProgThreads) void k_prog_scan(const ProgItem* items, const ProgImage* images, const DevHuff* huff_g,
+                                                            const uint8_t* blob, int16_t* coeffs, uint32_t* status, uint32_t* prog, uint32_t* ticket, uint4* times)
+{
+    __shared__ DevHuff sh_huff[3];
+    int me = 0;
+    if (threadIdx.x == 0) me = (int)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    me = rfl(me);
+    const ProgItem it = items[me];
+    const ProgImage im = images[it.image];
+    switch (rfl(it.prio)) {                                    // the instruction takes an immediate
+        case 3: __builtin_amdgcn_s_setprio(3); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        default: break;
+    }
+    const uint64_t t_in = wall_clock64();
+    uint32_t waited = 0;
+    prog_scan_body(it, im, sh_huff, huff_g, blob, coeffs, status, prog, ticket + 1, me, waited);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(prog + me, kProgDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (it.ctr >= 0) __hip_atomic_fetch_add(ticket + 1 + it.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (times) { times[me] = make_uint4((uint32_t)t_in, (uint32_t)(t_in >> 32), (uint32_t)(wall_clock64() - t_in), waited); }   // GAMUT_HIP_TRACE: when it ran, how long, how much of it waiting
     }
 }
 
@@ -487,9 +573,10 @@ void prog_unstuff(int i, const uint8_t* base, gamut_hip_jpeg_frame& f, ProgPrep&
 {
     size_t w = 0;
     bool bad = false;
-    for (const ProgScanPrep& s : out.scans) {
+    for (size_t si = 0; si < out.scans.size(); ++si) {
+        const ProgScanPrep& s = out.scans[si];
         const int total = s.units, ri = s.restart_interval;
-        int next_unit = 0, expect = 0;
+        int next_unit = 0, expect = 0, n_seg = 0;
         size_t q = s.begin, copy_from = s.begin, seg_begin = w;
         const size_t n = s.end;
         bool copying = true;
@@ -507,6 +594,8 @@ void prog_unstuff(int i, const uint8_t* base, gamut_hip_jpeg_frame& f, ProgPrep&
             for (int k = 0; k < s.sc.ncomp; ++k) { it.comp[k] = s.sc.comp[k]; it.tab[k] = s.tab[k]; }
             it.first_unit = next_unit; it.n_units = nu; it.nbx = s.nbx > 0 ? s.nbx : 1; it.level = s.level;
             it.begin = seg_begin; it.end = w;
+            it.scan = (int32_t)si; it.seg = n_seg++;
+            it.dep[0] = it.dep[1] = it.dep[2] = -1;
             out.items.push_back(it); next_unit += nu;
             memset(dst + w, 0xFF, 64); w += 64;
             w = (w + 3) & ~(size_t)3;                          // segments start on dword boundaries (the wave reader loads dwords)
@@ -657,57 +746,163 @@ int progressive_decode_device(const uint8_t* const* data, const size_t* len, con
                 k = j;
             }
         }
-        // items by level (tables -> global indices, segments -> blob offsets); images that failed while unstuffing drop out
-        std::vector<std::vector<ProgItem>> by_level((size_t)max_level + 1);
+        // One item list for the launch.  Items are taken in list order and whatever an item waits for must come before it; beyond that
+        // the order decides which waves share a SIMD (workgroup i of a launch lands on SIMD i mod 1024 while slots are free), and the
+        // decode time of a file is the time of its longest chain of scans.  So: per file the scans by the length of the longest chain
+        // they feed (bytes; a scan that others stand on is at least as "long" as they are, so this is also a valid order), and the
+        // list takes the first scan of every file, then the second of every file, ...: the long chains of the batch start first and
+        // spread over the SIMDs evenly instead of meeting on some of them.
+        // Tables -> global indices, segments -> blob offsets; images that failed while unstuffing drop out.
+        std::vector<ProgItem> all_items;
+        const char* prio_env = getenv("GAMUT_HIP_PROG_PRIO");
+        const int prio_mode = prio_env ? atoi(prio_env) : 1;
+        const char* order_env = getenv("GAMUT_HIP_PROG_ORDER");
+        const bool file_major = order_env && !strcmp(order_env, "file");          // measurements: a file's items next to each other
         std::vector<ProgImage> live; std::vector<int> live_of((size_t)n, -1);
+        std::vector<std::vector<ProgItem>> per_file;                               // in the file's own order, dep[] = local indices
         for (int k = 0; k < n; ++k) {
             const ProgPrep& pp = prep[(size_t)k];
             if (pp.rc != GAMUT_HIP_OK) continue;
             live_of[(size_t)k] = (int)live.size(); live.push_back(images[(size_t)k]);
+            const size_t n_scans = pp.scans.size();
+            // per scan: the scans it stands on -- for every coefficient it touches, the LAST earlier scan that touched it
+            std::vector<std::vector<int>> scan_deps(n_scans);
+            {
+                int last[3][64];
+                for (auto& r : last) for (int& v : r) v = -1;
+                for (size_t si = 0; si < n_scans; ++si) {
+                    const Scan& sc = pp.scans[si].sc;
+                    for (int a = 0; a < sc.ncomp; ++a) for (int z = sc.ss; z <= sc.se && z < 64; ++z) {
+                        const int e = last[sc.comp[a]][z];
+                        if (e >= 0 && std::find(scan_deps[si].begin(), scan_deps[si].end(), e) == scan_deps[si].end()) scan_deps[si].push_back(e);
+                        last[sc.comp[a]][z] = (int)si;
+                    }
+                }
+            }
+            std::vector<int> n_segs(n_scans, 0);
+            std::vector<uint64_t> bytes(n_scans, 0), chain(n_scans, 0);
+            for (const ProgItem& m : pp.items) { ++n_segs[(size_t)m.scan]; bytes[(size_t)m.scan] += m.end - m.begin; }
+            // do the scans line up?  (same components, units and restart segments as everything they stand on: then unit u may follow unit u)
+            bool lined_up = true;
+            for (size_t si = 0; si < n_scans && lined_up; ++si) {
+                const ProgScanPrep& sp = pp.scans[si];
+                lined_up = scan_deps[si].size() <= 3;
+                for (size_t d = 0; d < scan_deps[si].size() && lined_up; ++d) {
+                    const ProgScanPrep& e = pp.scans[(size_t)scan_deps[si][d]];
+                    bool same = e.sc.ncomp == sp.sc.ncomp && e.units == sp.units && e.restart_interval == sp.restart_interval && n_segs[(size_t)scan_deps[si][d]] == n_segs[si];
+                    for (int c = 0; c < sp.sc.ncomp && same; ++c) same = e.sc.comp[c] == sp.sc.comp[c];
+                    lined_up = same;
+                }
+            }
+            uint64_t longest = 1;
+            for (size_t si = n_scans; si-- > 0; ) {
+                chain[si] = std::max(chain[si], bytes[si]);
+                for (int e : scan_deps[si]) chain[(size_t)e] = std::max(chain[(size_t)e], chain[si]);
+                longest = std::max(longest, chain[si]);
+            }
+            std::vector<int> order(n_scans);                                         // the file's scans in launch order
+            for (size_t si = 0; si < n_scans; ++si) order[si] = (int)si;
+            if (lined_up) std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return chain[(size_t)a] > chain[(size_t)b]; });
+            else          std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return pp.scans[(size_t)a].level < pp.scans[(size_t)b].level; });
+            std::vector<int> first_item(n_scans, -1);
+            { int at = 0; for (int si : order) { first_item[(size_t)si] = at; at += n_segs[(size_t)si]; } }
+            std::vector<ProgItem> mine(pp.items.size());
+            std::vector<int> lower_levels;                                           // not lined up: items of the levels below, per level
+            if (!lined_up) {
+                int max_lv = 0; for (const ProgScanPrep& sp : pp.scans) max_lv = std::max(max_lv, sp.level);
+                lower_levels.assign((size_t)max_lv + 2, 0);
+                for (const ProgItem& m : pp.items) ++lower_levels[(size_t)m.level + 1];
+                for (size_t l = 1; l < lower_levels.size(); ++l) lower_levels[l] += lower_levels[l - 1];
+            }
             for (ProgItem it : pp.items) {
+                const int local = first_item[(size_t)it.scan] + it.seg;
+                it.dep_pipe = 0; it.ctr = -1; it.ctr_need = 0;
+                if (lined_up) {
+                    const std::vector<int>& deps = scan_deps[(size_t)it.scan];
+                    for (size_t d = 0; d < deps.size(); ++d) { it.dep[d] = first_item[(size_t)deps[d]] + it.seg; it.dep_pipe |= 1 << d; }
+                } else { it.ctr = live_of[(size_t)k]; it.ctr_need = lower_levels[(size_t)it.level]; }       // a barrier per level of the file: a count of finished items
+                it.prio = 0;
+                if (prio_mode) {
+                    const uint64_t c = chain[(size_t)it.scan];
+                    it.prio = c * 2 >= longest ? 3 : c * 5 >= longest ? 2 : c * 20 >= longest ? 1 : 0;
+                }
                 it.image = live_of[(size_t)k];
                 it.begin += blob_off[(size_t)k]; it.end += blob_off[(size_t)k];
                 if (it.kind != PROG_DC_REFINE) for (int c = 0; c < it.ncomp; ++c) it.tab[c] = tab_map[(size_t)k][(size_t)it.tab[c]];
-                by_level[(size_t)it.level].push_back(it);
+                mine[(size_t)local] = it;
             }
+            per_file.push_back(std::move(mine));
+        }
+        {
+            size_t total_items = 0, deepest = 0;
+            for (const auto& v : per_file) { total_items += v.size(); deepest = std::max(deepest, v.size()); }
+            std::vector<std::vector<int32_t>> place(per_file.size());                // (file, local index) -> place in the launch's list
+            for (size_t f = 0; f < per_file.size(); ++f) place[f].resize(per_file[f].size());
+            int32_t at = 0;
+            if (file_major) { for (size_t f = 0; f < per_file.size(); ++f) for (size_t j = 0; j < per_file[f].size(); ++j) place[f][j] = at++; }
+            else for (size_t j = 0; j < deepest; ++j) for (size_t f = 0; f < per_file.size(); ++f) if (j < per_file[f].size()) place[f][j] = at++;
+            all_items.resize(total_items);
+            for (size_t f = 0; f < per_file.size(); ++f)
+                for (size_t j = 0; j < per_file[f].size(); ++j) {
+                    ProgItem it = per_file[f][j];
+                    for (int d = 0; d < 3; ++d) if (it.dep[d] >= 0) it.dep[d] = place[f][(size_t)it.dep[d]];
+                    all_items[(size_t)place[f][j]] = it;
+                }
         }
         ms_unstuff = ms_since(t_u);
         if (!live.empty()) {
             auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
-            size_t n_items = 0; for (const auto& v : by_level) n_items += v.size();
+            const size_t n_items = all_items.size();
             std::vector<QuantTab>& qn = quants;
             const size_t o_img = 0, o_huff = align(live.size() * sizeof(ProgImage)), o_quant = align(o_huff + huffs.size() * sizeof(DevHuff)),
-                         o_items = align(o_quant + qn.size() * sizeof(QuantTab)), total = o_items + n_items * sizeof(ProgItem) + 256;
-            uint8_t* d = (uint8_t*)tab_scratch.get(total);
-            uint8_t* h = tab_pinned.get(total);
+                         o_items = align(o_quant + qn.size() * sizeof(QuantTab)), o_prog = align(o_items + n_items * sizeof(ProgItem)),
+                         o_times = align(o_prog + (n_items + 1 + live.size()) * sizeof(uint32_t)), total = o_times + (trace ? n_items * sizeof(uint4) : 0) + 256;
+            uint8_t* d = (uint8_t*)tab_scratch.get(total, stream);
+            uint8_t* h = tab_pinned.get(total, stream);
             if (!d || !h) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: staging allocation of %zu bytes failed", total);
             memcpy(h + o_img, live.data(), live.size() * sizeof(ProgImage));
             memcpy(h + o_huff, huffs.data(), huffs.size() * sizeof(DevHuff));
             memcpy(h + o_quant, qn.data(), qn.size() * sizeof(QuantTab));
-            size_t off = o_items;
-            std::vector<size_t> level_off;
-            for (const auto& v : by_level) { level_off.push_back(off); memcpy(h + off, v.data(), v.size() * sizeof(ProgItem)); off += v.size() * sizeof(ProgItem); }
-            GAMUT_HIP_CHECK(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, stream));
+            memcpy(h + o_items, all_items.data(), n_items * sizeof(ProgItem));
+            GAMUT_HIP_CHECK(hipMemcpyAsync(d, h, o_prog, hipMemcpyHostToDevice, stream));
+            GAMUT_HIP_CHECK(hipMemsetAsync(d + o_prog, 0, (n_items + 1 + live.size()) * sizeof(uint32_t), stream));      // progress words, the ticket, a count of finished items per file
             GAMUT_HIP_CHECK(hipMemcpyAsync(d_blob, h_blob, blob_size + kBlobSlack, hipMemcpyHostToDevice, stream));
             uint32_t* st = d_status;
             if (!st) {
                 static thread_local PerDevice<DeviceScratch> sink_pd;
                 DeviceScratch& sink = sink_pd.cur();
                 int top = 0; for (int i : idx) top = i > top ? i : top;
-                st = (uint32_t*)sink.get((size_t)(top + 1) * sizeof(uint32_t));
+                st = (uint32_t*)sink.get((size_t)(top + 1) * sizeof(uint32_t), stream);
                 if (!st) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: status allocation failed");
             }
             for (int k = 0; k < n; ++k) if (prep[(size_t)k].rc == GAMUT_HIP_OK) GAMUT_HIP_CHECK(hipMemsetAsync(st + idx[(size_t)k], 0, sizeof(uint32_t), stream));
             const auto t_k = std::chrono::steady_clock::now();
-            for (size_t lv = 0; lv < by_level.size(); ++lv) {
-                if (by_level[lv].empty()) continue;
-                hipLaunchKernelGGL(k_prog_scan, dim3((unsigned)by_level[lv].size()), dim3(kProgThreads), 0, stream,
-                                   (const ProgItem*)(d + level_off[lv]), (const ProgImage*)(d + o_img), (const DevHuff*)(d + o_huff), d_blob, d_coeffs, st);
+            if (n_items) {
+                hipLaunchKernelGGL(k_prog_scan, dim3((unsigned)n_items), dim3(kProgThreads), 0, stream,
+                                   (const ProgItem*)(d + o_items), (const ProgImage*)(d + o_img), (const DevHuff*)(d + o_huff), d_blob, d_coeffs, st,
+                                   (uint32_t*)(d + o_prog), (uint32_t*)(d + o_prog) + n_items, trace ? (uint4*)(d + o_times) : (uint4*)nullptr);
                 if (int rc = launch_status("jpeg_prog_scan")) return rc;
                 if (trace) {
                     const auto t_l = std::chrono::steady_clock::now();
                     (void)hipStreamSynchronize(stream);
-                    fprintf(stderr, "[gamut_hip]   level %zu: %zu segments, %.1f ms (with what was queued before it)\n", lv, by_level[lv].size(), ms_since(t_l));
+                    fprintf(stderr, "[gamut_hip]   scans: %zu segments in one launch, %.1f ms (with what was queued before it)\n", n_items, ms_since(t_l));
+                    std::vector<uint4> tm(n_items);
+                    if (hipMemcpy(tm.data(), d + o_times, n_items * sizeof(uint4), hipMemcpyDeviceToHost) == hipSuccess) {
+                        uint64_t t_min = ~0ull;
+                        for (const uint4& t : tm) t_min = std::min(t_min, ((uint64_t)t.y << 32) | t.x);
+                        // per scan number (of its file): mean start, mean duration, mean time spent waiting, over the files of the batch (100 MHz clock)
+                        double start[16] = { 0 }, dur[16] = { 0 }, wt[16] = { 0 }, endmax[16] = { 0 }; int cnt[16] = { 0 };
+                        for (size_t j = 0; j < n_items; ++j) {
+                            const int sc = all_items[j].scan;
+                            if (sc >= 16) continue;
+                            const double st0 = (double)((((uint64_t)tm[j].y << 32) | tm[j].x) - t_min) / 1e5;
+                            start[sc] += st0; dur[sc] += tm[j].z / 1e5; wt[sc] += tm[j].w / 1e5; ++cnt[sc];
+                            endmax[sc] = std::max(endmax[sc], st0 + tm[j].z / 1e5);
+                        }
+                        for (int sc = 0; sc < 16; ++sc) if (cnt[sc])
+                            fprintf(stderr, "[gamut_hip]     scan %2d: %5d segments, start %7.2f ms, runs %7.2f ms of which waiting %7.2f ms, last one ends at %7.2f ms\n",
+                                    sc, cnt[sc], start[sc] / cnt[sc], dur[sc] / cnt[sc], wt[sc] / cnt[sc], endmax[sc]);
+                    }
                 }
             }
             const unsigned gx = (unsigned)std::min<int64_t>((max_blocks + 31) / 32, 4096);

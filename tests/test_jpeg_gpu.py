@@ -450,6 +450,37 @@ def test_device_progressive_decode(hip, progressive_mode):
         assert np.array_equal(zz, d.max_zag), k
 
 
+def _scripted_files():
+    """progressive files with scan scripts libjpeg never writes (tests/jpeg_scripts.py): bands cut four ways under one refinement scan, DC scans
+    per component under an interleaved refinement, spectral selection only, three bit planes -- with and without restart intervals"""
+    import io
+    from PIL import Image
+    import gen
+    import jpeg_scripts as J
+    blobs = []
+    for (w, h, kw) in ((203, 117, dict(quality=90, subsampling=2)), (131, 97, dict(quality=75, subsampling=0)), (200, 120, dict(quality=95, subsampling=1)),
+                       (640, 360, dict(quality=85, subsampling=2))):
+        bio = io.BytesIO(); Image.fromarray(gen.synth_rgb(w, h, 31)).save(bio, "JPEG", **kw)
+        for name, sc in J.SCRIPTS.items():
+            for ri in (0, 7):
+                blobs.append(J.progressive_with_script(bio.getvalue(), sc, ri))
+    bio = io.BytesIO(); Image.fromarray(gen.synth_rgb(90, 70, 32)).convert("L").save(bio, "JPEG", quality=80)
+    blobs.append(J.progressive_with_script(bio.getvalue(), J.GREY, 0)); blobs.append(J.progressive_with_script(bio.getvalue(), J.GREY, 3))
+    return blobs
+
+
+def test_device_progressive_scan_scripts(hip, progressive_mode):
+    """arbitrary scan scripts in one batch: scans that line up (unit u of a scan follows unit u of the scans it stands on, a few dozen units
+    behind) next to files whose scans do not (a per-file barrier per level instead): == the oracle's feeder, coefficient for coefficient"""
+    blobs = _scripted_files()
+    rc, hst, st, res = _entropy_decode_device(hip, blobs)
+    assert rc == 0 and hst == [0] * len(blobs) and not st.any(), hip.gamut_hip_last_error()
+    for k, (data, (co, zz, info)) in enumerate(zip(blobs, res)):
+        d = O.DecodedJpeg(data)
+        assert np.array_equal(co, d.coeffs), (k, np.count_nonzero(co != d.coeffs))
+        assert np.array_equal(zz, d.max_zag), k
+
+
 def test_device_progressive_corrupt_streams(hip):
     """damaged scans of progressive files on the GPU path: no hang, nothing written outside the file's buffers, the damaged
     files flagged (a scan that decodes to the end without an impossible code is not an error for the reference either);

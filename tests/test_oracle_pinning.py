@@ -656,3 +656,23 @@ def test_qoi_oracle_roundtrip_and_pillow():
     cut = good[:200] + good[-8:]
     t = O.qoi_decode(cut)[0]
     assert t.shape == (33, 64 * 3) and (t.reshape(-1, 3)[-1] == t.reshape(-1, 3)[-50]).all()
+
+
+def test_scripted_progressive_files_decode_like_their_baseline_twins():
+    """tests/jpeg_scripts.py (progressive files with arbitrary scan scripts, written from a baseline file's coefficients): the oracle decodes
+    every one of them to the pixels of the baseline file, and so does Pillow -- the generator and the oracle's progressive decoder
+    (jpegload.d:3296-3664) agree with libjpeg on scripts libjpeg's own encoder never writes"""
+    import io
+    from PIL import Image
+    import gen
+    import jpeg_scripts as J
+    for (w, h, kw) in ((77, 50, dict(quality=30, subsampling=2)), (131, 97, dict(quality=75, subsampling=0)), (200, 120, dict(quality=95, subsampling=1))):
+        bio = io.BytesIO(); Image.fromarray(gen.synth_rgb(w, h, 5)).save(bio, "JPEG", **kw); base = bio.getvalue()
+        want = O.decompress_jpeg(base, 3)[0]
+        want_pil = np.array(Image.open(io.BytesIO(base)).convert("RGB"))
+        for name, sc in J.SCRIPTS.items():
+            for ri in (0, 7):
+                p = J.progressive_with_script(base, sc, ri)
+                assert b"\xff\xc2" in p[:1000]
+                assert np.array_equal(O.decompress_jpeg(p, 3)[0], want), (w, h, name, ri)
+                assert np.array_equal(np.array(Image.open(io.BytesIO(p)).convert("RGB")), want_pil), (w, h, name, ri)

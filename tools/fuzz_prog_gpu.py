@@ -31,6 +31,10 @@ def main():
         dims = (176 + 8 * k, 120 - 8 * k) if progressive else (640 + 16 * k, 480 - 16 * k)
         bio = io.BytesIO(); Image.fromarray(gen.synth_rgb(dims[0], dims[1], 70 + k)).save(bio, "JPEG", progressive=progressive, **kw); seeds.append(bio.getvalue())
     bio = io.BytesIO(); Image.fromarray(gen.synth_rgb(97 if progressive else 600, 61 if progressive else 400, 80)).convert("L").save(bio, "JPEG", progressive=progressive, quality=80); seeds.append(bio.getvalue())
+    if progressive:                                             # scan scripts libjpeg does not write (tests/jpeg_scripts.py): scans that do not line up take the per-file barrier
+        import jpeg_scripts as J
+        bio = io.BytesIO(); Image.fromarray(gen.synth_rgb(168, 104, 81)).save(bio, "JPEG", quality=85, subsampling=2)
+        seeds += [J.progressive_with_script(bio.getvalue(), J.FOUR_BANDS, 0), J.progressive_with_script(bio.getvalue(), J.DEEP, 7)]
     n_same = n_flag = n_rej = 0
     for b in range(batches):
         blobs = []

@@ -84,6 +84,8 @@ __device__ __forceinline__ int64_t prog_unit_block(const ProgImage& im, const Pr
 // instruction of a lone wave takes several times as long, and the chain is all there is.
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t rfl(uint64_t v) { return ((uint64_t)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v); }
+__device__ __forceinline__ int64_t rfl(int64_t v) { return (int64_t)rfl((uint64_t)v); }
 struct WaveBits {
     const uint8_t* seg; uint32_t chunk; uint32_t cw;
     __device__ __forceinline__ void open(const uint8_t* s) { seg = s; chunk = 0; load(); }
@@ -148,8 +150,49 @@ __device__ __forceinline__ int64_t prog_block_fast(int mcus_per_row, int nb, int
 __device__ __forceinline__ int  co_load(const int16_t* p) { return (int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void co_store(int16_t* p, int v) { __hip_atomic_store(p, (int16_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// An item's view of the launch's progress words: what it may touch, and what it tells the items behind it.
+struct ProgSync {
+    uint32_t* prog; uint32_t* st;
+    int me, dep0, dep1, dep2, dep_pipe;
+    uint32_t seen0, seen1, seen2;                               // the dependencies' progress as last read (it only grows)
+    uint32_t waited;                                            // 100 MHz ticks spent waiting (GAMUT_HIP_TRACE)
+    __device__ __forceinline__ void wait_word(const uint32_t* w, uint32_t need, uint32_t& seen)
+    {
+        if (seen >= need) return;
+        const uint64_t t0 = wall_clock64();
+        for (;;) {
+            seen = rfl(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (seen >= need) { waited += (uint32_t)(wall_clock64() - t0); break; }
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > 400000000ull) {           // 4 s of the 100 MHz clock: give up, say so, never hang
+                if (threadIdx.x == 0) atomicOr(st, 16u);
+                seen = 0xFFFFFFFFu;
+                break;
+            }
+        }
+    }
+    __device__ __forceinline__ void wait_units(int upto)        // units [0, upto) of this item may be decoded
+    {
+        if (dep0 >= 0) wait_word(prog + dep0, (dep_pipe & 1) ? (uint32_t)upto : kProgDone, seen0);
+        if (dep1 >= 0) wait_word(prog + dep1, (dep_pipe & 2) ? (uint32_t)upto : kProgDone, seen1);
+        if (dep2 >= 0) wait_word(prog + dep2, (dep_pipe & 4) ? (uint32_t)upto : kProgDone, seen2);
+    }
+    __device__ __forceinline__ void publish(int units_done)     // the coefficients of units [0, units_done) are final as far as this scan goes
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) __hip_atomic_store(prog + me, (uint32_t)units_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+
+struct AcRefineArgs {
+    const uint8_t* seg; int16_t* out; const DevHuff* huff;      // huff: the scan's table in LDS
+    uint32_t limit_bit;
+    int al, n_units, first_unit, mpr, nbm, ss, se, nbx, hs, vs, off;
+};
+__device__ __forceinline__ uint32_t prog_ac_refine(ProgSync sy, AcRefineArgs a, uint4* profile);
+
 __device__ __forceinline__ void prog_scan_body(const ProgItem& it, const ProgImage& im, DevHuff* sh_huff, const DevHuff* huff_g,
-                                               const uint8_t* blob, int16_t* coeffs, uint32_t* status, uint32_t* prog, const uint32_t* counters, int me, uint32_t& waited)
+                                               const uint8_t* blob, int16_t* coeffs, uint32_t* status, uint32_t* prog, const uint32_t* counters, int me, uint32_t& waited, uint4* profile)
 {
     const int lane = threadIdx.x;
     const int kind = rfl(it.kind), ncomp = rfl(it.ncomp);
@@ -160,40 +203,17 @@ __device__ __forceinline__ void prog_scan_body(const ProgItem& it, const ProgIma
             for (int k = lane; k < (int)(sizeof(DevHuff) / 4); k += kProgThreads) dst[k] = src[k];
         }
     __syncthreads();
-    const uint8_t* seg = blob + it.begin;
-    const uint32_t seg_bytes = (uint32_t)(it.end - it.begin);
+    const uint64_t seg_begin = rfl(it.begin);
+    const uint8_t* seg = blob + seg_begin;
+    const uint32_t seg_bytes = (uint32_t)(rfl(it.end) - seg_begin);
     const uint32_t limit_bit = seg_bytes * 8u + 64u * 8u;       // a decoder that runs past the padding is on a corrupt stream
-    int16_t* out = coeffs + im.coeff_off;
-    uint32_t* st = status + im.index;
-    // progress: what this item may touch, and what it tells the items behind it
-    const int dep0 = rfl(it.dep[0]), dep1 = rfl(it.dep[1]), dep2 = rfl(it.dep[2]), dep_pipe = rfl(it.dep_pipe);
-    const bool has_deps = dep0 >= 0 || dep1 >= 0 || dep2 >= 0;
-    uint32_t seen0 = 0, seen1 = 0, seen2 = 0;                   // the dependencies' progress as last read (it only grows)
-    auto wait_word = [&](const uint32_t* w, uint32_t need, uint32_t& seen) {
-        if (seen >= need) return;
-        const uint64_t t0 = wall_clock64();
-        for (;;) {
-            seen = rfl(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            if (seen >= need) { waited += (uint32_t)(wall_clock64() - t0); break; }
-            __builtin_amdgcn_s_sleep(8);
-            if (wall_clock64() - t0 > 400000000ull) {           // 4 s of the 100 MHz clock: give up, say so, never hang
-                if (lane == 0) atomicOr(st, 16u);
-                seen = 0xFFFFFFFFu;
-                break;
-            }
-        }
-    };
-    auto wait_units = [&](int upto) {                           // units [0, upto) of this item may be decoded
-        if (!has_deps) return;
-        if (dep0 >= 0) wait_word(prog + dep0, (dep_pipe & 1) ? (uint32_t)upto : kProgDone, seen0);
-        if (dep1 >= 0) wait_word(prog + dep1, (dep_pipe & 2) ? (uint32_t)upto : kProgDone, seen1);
-        if (dep2 >= 0) wait_word(prog + dep2, (dep_pipe & 4) ? (uint32_t)upto : kProgDone, seen2);
-    };
-    auto publish = [&](int units_done) {                        // the coefficients of units [0, units_done) are final as far as this scan goes
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(prog + me, (uint32_t)units_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    if (rfl(it.ctr) >= 0 && rfl(it.ctr_need) > 0) { uint32_t seen = 0; wait_word(counters + rfl(it.ctr), (uint32_t)rfl(it.ctr_need), seen); }
+    int16_t* out = coeffs + rfl(im.coeff_off);
+    uint32_t* st = status + rfl(im.index);
+    ProgSync sy{ prog, st, me, rfl(it.dep[0]), rfl(it.dep[1]), rfl(it.dep[2]), rfl(it.dep_pipe), 0u, 0u, 0u, 0u };
+    struct Report { ProgSync& s; uint32_t& w; __device__ ~Report() { w = s.waited; } } report{ sy, waited };      // on every way out
+    auto wait_units = [&](int upto) { sy.wait_units(upto); };
+    auto publish = [&](int units_done) { sy.publish(units_done); };
+    if (rfl(it.ctr) >= 0 && rfl(it.ctr_need) > 0) { uint32_t seen = 0; sy.wait_word(counters + rfl(it.ctr), (uint32_t)rfl(it.ctr_need), seen); }
     const int al = rfl(it.al), n_units = rfl(it.n_units), first_unit = rfl(it.first_unit);
     const int mpr = rfl(im.mcus_per_row), nbm = rfl(im.nb);        // scalars of their own: the structs are indexed by component elsewhere and live in scratch memory
     const uint32_t zag_reg = kZagDev[lane];                     // natural index of zig-zag position `lane`; readlane(zag_reg, k) for a uniform k
@@ -312,100 +332,185 @@ __device__ __forceinline__ void prog_scan_body(const ProgItem& it, const ProgIma
         return;
     }
 
-    // decode_block_ac_refine :3400-3518, a wave per block: lane k holds the coefficient at zig-zag position k
+    // AC refinement: a function of its own (its working set of scalar registers is the largest of the four kinds; inlined next to the
+    // others the kernel spilled seventy of them)
+    {
+        const AcRefineArgs ra{ seg, out, &sh_huff[0], limit_bit, al, n_units, first_unit, mpr, nbm, ss, se, nbx, hs, vs, off };
+        sy.waited = prog_ac_refine(sy, ra, profile);
+    }
+}
+
+// decode_block_ac_refine :3400-3518, a wave per block: lane k holds the coefficient at zig-zag position k.
+// The scalar unit walks the symbols; what it needs per symbol is short:
+//   * the bits: a 128-bit window (w0 | w1) kept in scalar registers and SHIFTED by what a symbol used, a dword appended from the
+//     wave's 256-byte piece of the stream (one v_readlane) whenever fewer than 97 bits are left -- not rebuilt from the bit position;
+//   * the code: a 6-bit look-ahead (one v_readlane; refinement alphabets are a few (run, 0 / 1) symbols and EOBn), the 8-bit tables
+//     and the canonical search behind it;
+//   * where the run ends: per block, ONE permutation puts the positions without history (in band, ascending) into lanes 0 .. Z-1
+//     (pz); a symbol's stop is v_readlane(pz, zeros passed so far + run);
+//   * how many correction bits it passes: a population count of the history mask between the old and the new position.
+// The correction bits themselves are not on that chain: every lane with history notes the BIT POSITION of its correction bit (the
+// position behind the symbol + its rank among the lanes with history, known per block), fetches that one byte of the stream when
+// the block is done, and the update + store of a block happens while the next block is being walked.
+#ifdef GAMUT_PROG_PROFILE
+#define PROG_T(var) const uint64_t var = __builtin_amdgcn_s_memtime()
+#define PROG_ACC(dst, a, b) dst += (uint32_t)((b) - (a))
+#else
+#define PROG_T(var)
+#define PROG_ACC(dst, a, b)
+#endif
+__device__ __forceinline__ uint32_t prog_ac_refine(ProgSync sy, AcRefineArgs a, uint4* profile)
+{
+    uint32_t pf_setup = 0, pf_walk = 0, pf_tail = 0, pf_syms = 0;     // GAMUT_PROG_PROFILE: shader clocks per phase, symbols
+    (void)pf_setup; (void)pf_walk; (void)pf_tail; (void)pf_syms;
+    const int lane = threadIdx.x;
+    const uint8_t* const seg = a.seg; int16_t* const out = a.out; uint32_t* const st = sy.st;
+    const uint32_t limit_bit = a.limit_bit;
+    const int al = rfl(a.al), n_units = rfl(a.n_units), first_unit = rfl(a.first_unit), mpr = rfl(a.mpr), nbm = rfl(a.nbm);
+    const int ss = rfl(a.ss), se = rfl(a.se), nbx = rfl(a.nbx), hs = rfl(a.hs), vs = rfl(a.vs), off = rfl(a.off);
+    const uint32_t zag_reg = kZagDev[lane];
+    WaveHuff ac; ac.load(a.huff, lane);
+    const DevHuff* const sh_huff = a.huff;
+    int by = first_unit / nbx, bx = first_unit - by * nbx;
+    int eobrun = 0;
+    uint32_t pos = 0;
+    auto wait_units = [&](int upto) { sy.wait_units(upto); };
+    auto publish = [&](int units_done) { sy.publish(units_done); };
     {
         const int nat = (int)zag_reg;
         const uint64_t band = (se >= 63 ? ~0ull : (1ull << (se + 1)) - 1) & ~((1ull << ss) - 1);
         const int plus = 1 << al, minus = (int)(0xFFFFFFFFu << al);
-        // the blocks are fetched kAhead blocks ahead of their turn (they come from HBM: the scans before wrote gigabytes since).
-        // Only the coefficients a block changes go back, one by one: a DC refinement scan of the same level may be writing
-        // coefficient 0 of the same blocks meanwhile.  (Fetching 64 blocks at a time through LDS was no faster: the chain's
-        // own instructions, not the memory latency, are its time.)
-        constexpr int kAhead = 4;
-        int16_t* ring_ptr[kAhead]; int ring_val[kAhead];
+        // Bit reader.  The scalar chain only ever needs the next code and, behind an EOBn code, up to 14 more bits: 30 bits at `pos`.
+        // Sign and correction bits are fetched by the lanes they belong to, from memory, when the block is done.  So there is no window
+        // to maintain: two v_readlane out of the wave's 256-byte piece of the stream (cwv: lane L holds big-endian dword cb + L) and one
+        // 64-bit shift give 33+ valid bits at any position.  A dependent scalar instruction of a lone wave takes ~8 clocks, a
+        // v_readlane round trip ~20, a taken branch ~30 (tools/microbench/chain_latency.hip): the loop below is counted in instructions.
+        uint32_t cb = 0, cwv;
+        auto load_chunk = [&]() { uint32_t raw; __builtin_memcpy(&raw, seg + 4 * (size_t)(cb + (uint32_t)lane), 4); cwv = __builtin_bswap32(raw); };
+        load_chunk();
+        auto bits_at = [&](uint32_t at) -> uint64_t {           // the stream from bit `at` on, at the top of 64 bits (the top 33 are there)
+            uint32_t li = (at >> 5) - cb;
+            if (__builtin_expect(li >= 63u, 0)) { cb = at >> 5; load_chunk(); li = 0; }
+            const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)cwv, (int)li), d1 = (uint32_t)__builtin_amdgcn_readlane((int)cwv, (int)li + 1);
+            return (((uint64_t)d0 << 32) | d1) << (at & 31u);
+        };
+        // Look-ahead of 6 bits (refinement alphabets are a few (run, 0 / 1) symbols and EOBn), everything the walk needs of a symbol in
+        // one word: [1:0] 1 = coefficient or ZRL, 2 = EOBn, 3 = not a refinement symbol, 0 = longer code; [11:4] bits used (code + sign,
+        // or code + the EOB run's extra bits); [15:12] run; [16] size; [25:20] code length.
+        auto pack = [&](int sym, int len) -> uint32_t {
+            const int run = sym >> 4, size = sym & 15;
+            const uint32_t kind = size > 1 ? 3u : (size == 0 && run != 15) ? 2u : 1u;
+            const int used = kind == 2u ? len + run : len + size;
+            return kind | (uint32_t)used << 4 | (uint32_t)run << 12 | (uint32_t)(size & 1) << 16 | (uint32_t)len << 20;
+        };
+        uint32_t t6;
+        { const uint32_t e = sh_huff[0].fast[(lane << 3)]; t6 = (e >> 8) <= 6 && e ? pack((int)(e & 0xFF), (int)(e >> 8)) : 0u; }      // fast[]: 9-bit look-ahead, (length << 8) | symbol
+        // the blocks are fetched three blocks ahead of their turn (they come from memory: other scans wrote them, possibly microseconds ago)
         int fx = bx, fy = by;                                   // the next block to fetch
+        int16_t *p0 = out, *p1 = out, *p2 = out; int c0 = 0, c1 = 0, c2 = 0;
+        auto fetch = [&](int16_t*& p, int& c, bool live) {
+            if (live) { p = out + prog_block_fast(mpr, nbm, hs, vs, off, fx, fy) * 64; c = co_load(p + nat); if (++fx == nbx) { fx = 0; ++fy; } }
+        };
+        // the block whose bits are on their way
+        int16_t* pend_ptr = out; int pend_orig = 0; uint32_t pend_byte = 0, pend_bit = 0xFFFFFFFFu;
+        auto finish_pending = [&]() {
+            if (pend_bit == 0xFFFFFFFFu) return;
+            const bool one = (pend_byte >> (7u - (pend_bit & 7u))) & 1u;
+            int coef = pend_orig;
+            if (coef == 0) coef = one ? plus : minus;                                            // a new coefficient: its sign
+            else if (one && (coef & plus) == 0) coef = (int16_t)(coef + (coef >= 0 ? plus : minus));   // history: one more bit of magnitude
+            if (coef != pend_orig) co_store(pend_ptr + nat, coef);
+        };
         for (int ub = 0; ub < n_units; ub += kProgBatch) {      // a batch of units: everything the scans before left in them is there
-        const int nu = min(kProgBatch, n_units - ub);
-        if (ub) publish(ub);
-        wait_units(ub + nu);
-        #pragma unroll
-        for (int a = 0; a < kAhead; ++a) {
-            ring_ptr[a] = out; ring_val[a] = 0;
-            if (a < nu) {
-                ring_ptr[a] = out + prog_block_fast(mpr, nbm, hs, vs, off, fx, fy) * 64; ring_val[a] = co_load(ring_ptr[a] + nat);
-                if (++fx == nbx) { fx = 0; ++fy; }
-            }
-        }
-        for (int u0 = 0; u0 < nu; u0 += kAhead) {
-            #pragma unroll
-            for (int a = 0; a < kAhead; ++a) {
-                const int u = u0 + a;
-                if (u >= nu) break;
-                int coef = ring_val[a];
-                int16_t* const cur = ring_ptr[a];
-                if (u + kAhead < nu) {
-                    ring_ptr[a] = out + prog_block_fast(mpr, nbm, hs, vs, off, fx, fy) * 64; ring_val[a] = co_load(ring_ptr[a] + nat);
-                    if (++fx == nbx) { fx = 0; ++fy; }
-                }
-                const int orig = coef;
-                const uint64_t nz = __ballot(coef != 0) & band;
+            const int nu = min(kProgBatch, n_units - ub);
+            if (ub) { finish_pending(); pend_bit = 0xFFFFFFFFu; publish(ub); }
+            wait_units(ub + nu);
+            fetch(p0, c0, nu > 0); fetch(p1, c1, nu > 1); fetch(p2, c2, nu > 2);
+            for (int u = 0; u < nu; ++u) {
+                PROG_T(t_a);
+                const int orig = c0; int16_t* const cur = p0;
+                p0 = p1; c0 = c1; p1 = p2; c1 = c2;
+                fetch(p2, c2, u + 3 < nu);
+                uint32_t mybit = 0xFFFFFFFFu;                    // the bit of the stream this lane wants: its correction bit (history) or its sign (new)
+                const uint64_t nz = __ballot(orig != 0) & band;
+                eobrun = rfl(eobrun);
+                if (eobrun > 0 && nz == 0) { --eobrun; continue; }          // inside an EOB run, no history: not a bit of the stream belongs to this block
+                const uint64_t zeros = ~nz & band;
+                const int rk = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nz, 0u));      // lanes with history below this one
+                const bool has_hist = (nz >> lane) & 1ull;
+                int nc = 0;                                     // lanes with history already passed
+                uint64_t nzr = nz;                              // ... and those still ahead
                 int k = ss;
                 bool bad = false;
-                eobrun = rfl(eobrun);
+                PROG_T(t_b);
                 if (eobrun == 0) {
+                    const int zr = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(zeros >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)zeros, 0u));
+                    const int Z = __popcll(zeros);
+                    const int dest = ((zeros >> lane) & 1ull) ? zr : 63 - (lane - zr);
+                    const int pz = __builtin_amdgcn_ds_permute(dest << 2, lane);                 // lane r: the r-th position without history
+                    int zc = 0;                                 // positions without history already passed
                     while (k <= se) {
-                        k = rfl(k);
-                        uint64_t w0, w1; wb.window(pos, w0, w1);
-                        int len; const int sym = ac.decode(w0, len);
-                        if (sym < 0) { bad = true; break; }
-                        const int run = sym >> 4, size = sym & 15;
-                        int used = len, fresh = 0;
-                        if (size) {
-                            if (size != 1) { bad = true; break; }
-                            fresh = ((w0 >> (63 - used)) & 1ull) ? plus : minus;
-                            ++used;
-                        } else if (run != 15) {
-                            const int extra = run ? (int)((w0 << used) >> (64 - run)) : 0;
-                            eobrun = (1 << run) + extra;
-                            pos += (uint32_t)(used + run);
-                            break;
+#ifdef GAMUT_PROG_PROFILE
+                        ++pf_syms;
+#endif
+                        const uint64_t w = bits_at(pos);
+                        uint32_t ent = (uint32_t)__builtin_amdgcn_readlane((int)t6, (int)(w >> 58));
+                        if (__builtin_expect((ent & 3u) != 1u, 0)) {
+                            if (ent == 0) { int len; const int sym = ac.decode(w, len); if (sym < 0) { bad = true; break; } ent = pack(sym, len); }
+                            if ((ent & 3u) == 3u) { bad = true; break; }
+                            if ((ent & 3u) == 2u) {              // EOBn: this block's band ends here, and that of the next eobrun - 1 blocks
+                                const int len = (int)(ent >> 20), run = (int)((ent >> 12) & 15u);
+                                eobrun = (1 << run) + (run ? (int)((w << len) >> (64 - run)) : 0);
+                                pos += (ent >> 4) & 0xFFu;
+                                break;
+                            }
                         }
-                        // walk on from k over `run` zeros to the zero that ends the run, correcting every coefficient with history on the way
-                        const uint64_t from_k = ~((1ull << k) - 1);
-                        const uint64_t zeros = ~nz & band & from_k;
-                        const int zeros_below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(zeros >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)zeros, 0u));
-                        const uint64_t sm = __ballot(zeros_below == run) & zeros;          // the zeros with exactly `run` zeros below them: the first is the stop
-                        const int stop = sm ? __builtin_ctzll(sm) : se + 1;
-                        const uint64_t corr = nz & from_k & (stop >= 64 ? ~0ull : (1ull << stop) - 1);
-                        if (corr) {
-                            const uint64_t cbits = (w0 << used) | (w1 >> (64 - used));         // used >= 1
-                            const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(corr >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)corr, 0u));
-                            const bool mine = (corr >> lane) & 1ull;
-                            if (mine && ((cbits >> (63 - r)) & 1ull) && (coef & plus) == 0) coef = (int16_t)(coef + (coef >= 0 ? plus : minus));
-                        }
-                        pos += (uint32_t)(used + __popcll(corr));
-                        if (fresh && lane == stop) coef = fresh;                              // stop <= 64: no lane if the walk ran off the block
+                        const int used = (int)((ent >> 4) & 0xFFu), run = (int)((ent >> 12) & 15u);
+                        const bool coefficient = (ent >> 16) & 1u;       // a new coefficient at the stop (its sign follows the code); else ZRL
+                        // on from k over `run` positions without history to the one that ends the run; what has history on the way is corrected
+                        const int R = zc + run;
+                        const int stop_r = __builtin_amdgcn_readlane(pz, R & 63);
+                        const bool inside = R < Z;
+                        const int stop = inside ? stop_r : se + 1;
+                        zc = R + 1;
+                        const uint64_t below = inside ? (1ull << stop) - 1 : ~0ull;          // stop <= 63 here
+                        const uint64_t corr = nzr & below;
+                        nzr &= ~below;
+                        const int c = __popcll(corr);
+                        const uint32_t P = pos + (uint32_t)used;                             // the correction bits follow the symbol, in position order
+                        const uint32_t t = (uint32_t)(rk - nc);
+                        if (has_hist && t < (uint32_t)c) mybit = P + t;
+                        if (lane == (coefficient ? stop : 64)) mybit = P - 1u;               // stop <= 64: no lane if the walk ran off the block
+                        nc += c;
+                        pos = P + (uint32_t)c;
                         k = stop + 1;
                     }
                 }
-                if (bad) { if (lane == 0) atomicOr(st, 1u); return; }
-                if (eobrun > 0) {
-                    const uint64_t corr = nz & ~((1ull << k) - 1);
-                    if (corr) {
-                        uint64_t w0, w1; wb.window(pos, w0, w1);
-                        const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(corr >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)corr, 0u));
-                        const bool mine = (corr >> lane) & 1ull;
-                        if (mine && ((w0 >> (63 - r)) & 1ull) && (coef & plus) == 0) coef = (int16_t)(coef + (coef >= 0 ? plus : minus));
-                        pos += (uint32_t)__popcll(corr);
-                    }
+                if (bad) { if (lane == 0) atomicOr(st, 1u); finish_pending(); return sy.waited; }
+                PROG_T(t_c);
+                eobrun = rfl(eobrun);
+                if (eobrun > 0) {                                // the rest of the block: correction bits only
+                    const int c = __popcll(nzr);
+                    const uint32_t t = (uint32_t)(rk - nc);
+                    if (has_hist && t < (uint32_t)c) mybit = pos + t;
+                    pos += (uint32_t)c;
                     --eobrun;
                 }
-                if (coef != orig) co_store(cur + nat, coef);
-                if (pos > limit_bit) { if (lane == 0) atomicOr(st, 4u); return; }
+                // the block before this one: its correction bits have arrived; this block's are sent for
+                finish_pending();
+                pend_ptr = cur; pend_orig = orig; pend_bit = mybit; pend_byte = 0;
+                if (mybit != 0xFFFFFFFFu) pend_byte = seg[mybit >> 3];
+                if (pos > limit_bit) { if (lane == 0) atomicOr(st, 4u); finish_pending(); return sy.waited; }
+                PROG_T(t_d);
+                PROG_ACC(pf_setup, t_a, t_b); PROG_ACC(pf_walk, t_b, t_c); PROG_ACC(pf_tail, t_c, t_d);
             }
         }
-        }
+        finish_pending();
     }
+#ifdef GAMUT_PROG_PROFILE
+    if (profile && lane == 0) *profile = make_uint4(pf_setup, pf_walk, pf_tail, pf_syms);
+#endif
+    return sy.waited;
 }
 
 // One workgroup (a wave) per item, items taken in list order through a ticket: whatever an item waits for has a lower ticket and
@@ -417,8 +522,8 @@ __global__ __launch_bounds__(kProgThreads) void k_prog_scan(const ProgItem* item
     int me = 0;
     if (threadIdx.x == 0) me = (int)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     me = rfl(me);
-    const ProgItem it = items[me];
-    const ProgImage im = images[it.image];
+    const ProgItem& it = items[me];                             // read where they lie: copies of the structs (their arrays indexed by component) would live in scratch memory, per lane
+    const ProgImage& im = images[rfl(it.image)];
     switch (rfl(it.prio)) {                                    // the instruction takes an immediate
         case 3: __builtin_amdgcn_s_setprio(3); break;
         case 2: __builtin_amdgcn_s_setprio(2); break;
@@ -427,11 +532,11 @@ __global__ __launch_bounds__(kProgThreads) void k_prog_scan(const ProgItem* item
     }
     const uint64_t t_in = wall_clock64();
     uint32_t waited = 0;
-    prog_scan_body(it, im, sh_huff, huff_g, blob, coeffs, status, prog, ticket + 1, me, waited);
+    prog_scan_body(it, im, sh_huff, huff_g, blob, coeffs, status, prog, ticket + 1, me, waited, times ? times + gridDim.x + me : (uint4*)nullptr);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (threadIdx.x == 0) {
         __hip_atomic_store(prog + me, kProgDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (it.ctr >= 0) __hip_atomic_fetch_add(ticket + 1 + it.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (rfl(it.ctr) >= 0) __hip_atomic_fetch_add(ticket + 1 + rfl(it.ctr), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (times) { times[me] = make_uint4((uint32_t)t_in, (uint32_t)(t_in >> 32), (uint32_t)(wall_clock64() - t_in), waited); }   // GAMUT_HIP_TRACE: when it ran, how long, how much of it waiting
     }
 }
@@ -856,7 +961,7 @@ int progressive_decode_device(const uint8_t* const* data, const size_t* len, con
             std::vector<QuantTab>& qn = quants;
             const size_t o_img = 0, o_huff = align(live.size() * sizeof(ProgImage)), o_quant = align(o_huff + huffs.size() * sizeof(DevHuff)),
                          o_items = align(o_quant + qn.size() * sizeof(QuantTab)), o_prog = align(o_items + n_items * sizeof(ProgItem)),
-                         o_times = align(o_prog + (n_items + 1 + live.size()) * sizeof(uint32_t)), total = o_times + (trace ? n_items * sizeof(uint4) : 0) + 256;
+                         o_times = align(o_prog + (n_items + 1 + live.size()) * sizeof(uint32_t)), total = o_times + (trace ? 2 * n_items * sizeof(uint4) : 0) + 256;
             uint8_t* d = (uint8_t*)tab_scratch.get(total, stream);
             uint8_t* h = tab_pinned.get(total, stream);
             if (!d || !h) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: staging allocation of %zu bytes failed", total);
@@ -886,8 +991,8 @@ int progressive_decode_device(const uint8_t* const* data, const size_t* len, con
                     const auto t_l = std::chrono::steady_clock::now();
                     (void)hipStreamSynchronize(stream);
                     fprintf(stderr, "[gamut_hip]   scans: %zu segments in one launch, %.1f ms (with what was queued before it)\n", n_items, ms_since(t_l));
-                    std::vector<uint4> tm(n_items);
-                    if (hipMemcpy(tm.data(), d + o_times, n_items * sizeof(uint4), hipMemcpyDeviceToHost) == hipSuccess) {
+                    std::vector<uint4> tm(2 * n_items);
+                    if (hipMemcpy(tm.data(), d + o_times, 2 * n_items * sizeof(uint4), hipMemcpyDeviceToHost) == hipSuccess) {
                         uint64_t t_min = ~0ull;
                         for (const uint4& t : tm) t_min = std::min(t_min, ((uint64_t)t.y << 32) | t.x);
                         // per scan number (of its file): mean start, mean duration, mean time spent waiting, over the files of the batch (100 MHz clock)
@@ -899,6 +1004,13 @@ int progressive_decode_device(const uint8_t* const* data, const size_t* len, con
                             start[sc] += st0; dur[sc] += tm[j].z / 1e5; wt[sc] += tm[j].w / 1e5; ++cnt[sc];
                             endmax[sc] = std::max(endmax[sc], st0 + tm[j].z / 1e5);
                         }
+#ifdef GAMUT_PROG_PROFILE
+                        double pf[16][4] = { { 0 } };
+                        for (size_t j = 0; j < n_items; ++j) { const int sc = all_items[j].scan; if (sc < 16) { const uint4& q = tm[n_items + j]; pf[sc][0] += q.x; pf[sc][1] += q.y; pf[sc][2] += q.z; pf[sc][3] += q.w; } }
+                        for (int sc = 0; sc < 16; ++sc) if (cnt[sc] && pf[sc][3] > 0)
+                            fprintf(stderr, "[gamut_hip]     scan %2d (AC refinement) per segment: block set-up %.0f, symbol walk %.0f, tail %.0f shader clocks; %.0f symbols\n",
+                                    sc, pf[sc][0] / cnt[sc], pf[sc][1] / cnt[sc], pf[sc][2] / cnt[sc], pf[sc][3] / cnt[sc]);
+#endif
                         for (int sc = 0; sc < 16; ++sc) if (cnt[sc])
                             fprintf(stderr, "[gamut_hip]     scan %2d: %5d segments, start %7.2f ms, runs %7.2f ms of which waiting %7.2f ms, last one ends at %7.2f ms\n",
                                     sc, cnt[sc], start[sc] / cnt[sc], dur[sc] / cnt[sc], wt[sc] / cnt[sc], endmax[sc]);

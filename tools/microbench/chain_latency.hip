@@ -20,8 +20,6 @@ template <int KIND> __global__ void k(uint32_t* out, int iters, uint32_t seed)
         if (KIND == 6) { REP64(asm volatile("s_cmp_eq_u32 %0, 0\n s_cbranch_scc1 1f\n s_nop 0\n1:\n s_add_u32 %0, %0, 1" : "+s"(s) :: "scc");) }   // untaken branch
         if (KIND == 7) { REP64(asm volatile("s_cmp_lg_u32 %0, %1\n s_cselect_b32 %0, %0, %1" : "+s"(s) : "s"(t) : "scc");) }
         if (KIND == 8) { REP64(asm volatile("s_bcnt1_i32_b64 %0, %1\n s_lshl_b64 %1, %1, %0" : "+s"(s), "+s"(q) :: "scc");) }
-        if (KIND == 9) { REP64(asm volatile("v_cmp_lt_u32 vcc, %0, %1\n s_and_b64 %2, vcc, exec\n v_mov_b32 %0, %3" : "+v"(v), "+v"(v), "+s"(q) : "s"((uint32_t)q) : "vcc");) }  // VALU cmp -> SALU reads vcc -> VALU
-        if (KIND == 10) { REP64(asm volatile("v_mov_b32 %1, %0\n ds_bpermute_b32 %1, %1, %1\n s_waitcnt lgkmcnt(0)\n v_readfirstlane_b32 %0, %1" : "+s"(s), "+v"(v));) }
         if (KIND == 11) { REP64(asm volatile("s_add_u32 %0, %0, %1\n s_add_u32 %2, %2, %1" : "+s"(s), "+s"(t), "+s"(seed) :: "scc");) }   // two independent SALU chains
     }
     const uint64_t t1 = __builtin_amdgcn_s_memtime();
@@ -45,7 +43,7 @@ int main()
         run<0>("s_add_u32 (dependent)", 1, 1); run<11>("two independent s_add_u32", 1, 1); run<1>("s_lshl_b64 (dependent)", 1, 1); run<2>("v_add_u32 (dependent)", 1, 1);
         run<3>("s_and + v_readlane(SGPR index) -> SGPR (dependent)", 1, 1); run<4>("v_readfirstlane -> v_add (dependent)", 1, 1);
         run<5>("s_cmp + taken forward branch + s_add", 1, 1); run<6>("s_cmp + untaken branch + s_nop + s_add", 1, 1); run<7>("s_cmp + s_cselect (dependent)", 1, 1);
-        run<8>("s_bcnt1_b64 + s_lshl_b64 (dependent)", 1, 1); run<9>("v_cmp -> s_and vcc -> v_mov (dependent)", 1, 1); run<10>("v_mov + ds_bpermute + wait + readfirstlane", 1, 1);
+        run<8>("s_bcnt1_b64 + s_lshl_b64 (dependent)", 1, 1);
         } else {
         run<0>("s_add_u32 (dependent)", 1, 4); run<3>("s_and + v_readlane(SGPR index) -> SGPR (dependent)", 1, 4); run<5>("s_cmp + taken forward branch + s_add", 1, 4);
         run<2>("v_add_u32 (dependent)", 1, 4);

@@ -77,35 +77,31 @@ __device__ __forceinline__ int64_t prog_unit_block(const ProgImage& im, const Pr
     return prog_block(im, c, mx * hs + h, my * vs + v);
 }
 
-// 128 bits of an unstuffed segment from any bit position, for a whole wave: lane L keeps the big-endian dword at byte
-// chunk + 4 L of the segment (256 bytes per wave, reloaded when the position leaves them), a window is five v_readlane.
+// The bits of an unstuffed segment from any bit position, for a whole wave: lane L keeps the big-endian dword at dword
+// chunk + L of the segment (256 bytes per wave, reloaded when the position leaves them); 33 or more valid bits at the top of 64
+// are two v_readlane and one shift -- enough for the longest code (16) plus the longest value behind it (16).
 // Everything about the position is wave-uniform and kept in scalar registers (readfirstlane where the compiler cannot
-// see it): the chain of a scan runs on the scalar unit, whose dependent instructions issue every few cycles -- a vector
-// instruction of a lone wave takes several times as long, and the chain is all there is.
+// see it): the chain of a scan runs on the scalar unit.  A lone wave issues a dependent instruction every ~8 clocks, scalar or
+// vector, a v_readlane round trip costs ~20 and a taken branch ~30 (tools/microbench/chain_latency.hip, profiles/r04_chain_latency.txt):
+// the chains below are counted in instructions.
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint64_t rfl(uint64_t v) { return ((uint64_t)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v); }
 __device__ __forceinline__ int64_t rfl(int64_t v) { return (int64_t)rfl((uint64_t)v); }
 struct WaveBits {
-    const uint8_t* seg; uint32_t chunk; uint32_t cw;
+    const uint8_t* seg; uint32_t chunk; uint32_t cw;            // chunk: in dwords
     __device__ __forceinline__ void open(const uint8_t* s) { seg = s; chunk = 0; load(); }
     __device__ __forceinline__ void load()
     {
-        uint32_t raw; __builtin_memcpy(&raw, seg + chunk + 4 * (threadIdx.x & 63), 4);
+        uint32_t raw; __builtin_memcpy(&raw, seg + 4 * (size_t)(chunk + (threadIdx.x & 63)), 4);
         cw = __builtin_bswap32(raw);
     }
-    __device__ __forceinline__ void window(uint32_t pos, uint64_t& w0, uint64_t& w1)     // pos: uniform
+    __device__ __forceinline__ uint64_t at(uint32_t pos)        // pos: uniform, never before the chunk
     {
-        pos = rfl(pos); chunk = rfl(chunk);                    // uniform by construction; said so where the compiler lost track
-        const uint32_t byte = pos >> 3;
-        if (byte < chunk || byte + 20 > chunk + 256) { chunk = byte & ~3u; load(); }
-        const uint32_t o = byte - chunk, d = rfl(o >> 2), s = (o & 3) * 8 + (pos & 7);
-        const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)d),     a1 = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)d + 1);
-        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)d + 2), b1 = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)d + 3);
-        const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)d + 4);
-        const uint64_t a = ((uint64_t)a0 << 32) | a1, b = ((uint64_t)b0 << 32) | b1, c = (uint64_t)c0 << 32;
-        w0 = s ? (a << s) | (b >> (64 - s)) : a;
-        w1 = s ? (b << s) | (c >> (64 - s)) : b;
+        uint32_t li = (pos >> 5) - chunk;
+        if (__builtin_expect(li >= 63u, 0)) { chunk = pos >> 5; load(); li = 0; }
+        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)li), d1 = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)li + 1);
+        return (((uint64_t)d0 << 32) | d1) << (pos & 31u);
     }
 };
 
@@ -141,7 +137,7 @@ struct WaveHuff {
 __device__ __forceinline__ int64_t prog_block_fast(int mcus_per_row, int nb, int hs, int vs, int off, int bx, int by)
 {
     const int mx = bx >> (hs - 1), my = by >> (vs - 1);
-    return ((int64_t)my * mcus_per_row + mx) * nb + off + (by & (vs - 1)) * hs + (bx & (hs - 1));
+    return (int64_t)((my * mcus_per_row + mx) * nb + off + (by & (vs - 1)) * hs + (bx & (hs - 1)));      // a frame has < 2^24 blocks (16384 x 16384, three components)
 }
 
 // Coefficients cross compute units while the launch runs (a scan reads what an earlier scan of the file wrote microseconds ago, from
@@ -253,7 +249,7 @@ __device__ __forceinline__ void prog_scan_body(const ProgItem& it, const ProgIma
         // one block of a component of the scan (its table, its predictor: by reference -- a choice by index among the three would
         // keep all of them, and the bit reader with them, in scratch memory)
         auto dc_block = [&](const WaveHuff& h, int& pred, int64_t blk) -> bool {
-            uint64_t w0, w1; wb.window(pos, w0, w1);
+            const uint64_t w0 = wb.at(pos);
             int len; const int s = h.decode(w0, len);
             if (s < 0) { if (lane == 0) atomicOr(st, 1u); return false; }
             const int n = s & 15;
@@ -304,7 +300,7 @@ __device__ __forceinline__ void prog_scan_body(const ProgItem& it, const ProgIma
                 int16_t* blk = out + prog_block_fast(mpr, nbm, hs, vs, off, bx, by) * 64;
                 for (int k = ss; k <= se; ++k) {
                     k = rfl(k);
-                    uint64_t w0, w1; wb.window(pos, w0, w1);
+                    const uint64_t w0 = wb.at(pos);
                     int len; const int rs = ac.decode(w0, len);
                     if (rs < 0) { if (lane == 0) atomicOr(st, 1u); return; }
                     const int run = rs >> 4, size = rs & 15;
@@ -385,15 +381,8 @@ __device__ __forceinline__ uint32_t prog_ac_refine(ProgSync sy, AcRefineArgs a, 
         // to maintain: two v_readlane out of the wave's 256-byte piece of the stream (cwv: lane L holds big-endian dword cb + L) and one
         // 64-bit shift give 33+ valid bits at any position.  A dependent scalar instruction of a lone wave takes ~8 clocks, a
         // v_readlane round trip ~20, a taken branch ~30 (tools/microbench/chain_latency.hip): the loop below is counted in instructions.
-        uint32_t cb = 0, cwv;
-        auto load_chunk = [&]() { uint32_t raw; __builtin_memcpy(&raw, seg + 4 * (size_t)(cb + (uint32_t)lane), 4); cwv = __builtin_bswap32(raw); };
-        load_chunk();
-        auto bits_at = [&](uint32_t at) -> uint64_t {           // the stream from bit `at` on, at the top of 64 bits (the top 33 are there)
-            uint32_t li = (at >> 5) - cb;
-            if (__builtin_expect(li >= 63u, 0)) { cb = at >> 5; load_chunk(); li = 0; }
-            const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)cwv, (int)li), d1 = (uint32_t)__builtin_amdgcn_readlane((int)cwv, (int)li + 1);
-            return (((uint64_t)d0 << 32) | d1) << (at & 31u);
-        };
+        WaveBits rb; rb.open(seg);
+        auto bits_at = [&](uint32_t at) -> uint64_t { return rb.at(at); };
         // Look-ahead of 6 bits (refinement alphabets are a few (run, 0 / 1) symbols and EOBn), everything the walk needs of a symbol in
         // one word: [1:0] 1 = coefficient or ZRL, 2 = EOBn, 3 = not a refinement symbol, 0 = longer code; [11:4] bits used (code + sign,
         // or code + the EOB run's extra bits); [15:12] run; [16] size; [25:20] code length.
@@ -407,9 +396,14 @@ __device__ __forceinline__ uint32_t prog_ac_refine(ProgSync sy, AcRefineArgs a, 
         { const uint32_t e = sh_huff[0].fast[(lane << 3)]; t6 = (e >> 8) <= 6 && e ? pack((int)(e & 0xFF), (int)(e >> 8)) : 0u; }      // fast[]: 9-bit look-ahead, (length << 8) | symbol
         // the blocks are fetched three blocks ahead of their turn (they come from memory: other scans wrote them, possibly microseconds ago)
         int fx = bx, fy = by;                                   // the next block to fetch
-        int16_t *p0 = out, *p1 = out, *p2 = out; int c0 = 0, c1 = 0, c2 = 0;
-        auto fetch = [&](int16_t*& p, int& c, bool live) {
-            if (live) { p = out + prog_block_fast(mpr, nbm, hs, vs, off, fx, fy) * 64; c = co_load(p + nat); if (++fx == nbx) { fx = 0; ++fy; } }
+        // (the values stay 16-bit until their block's turn: a conversion right behind the load would wait for it there)
+        int16_t *p0 = out, *p1 = out, *p2 = out; int16_t c0 = 0, c1 = 0, c2 = 0;
+        auto fetch = [&](int16_t*& p, int16_t& c, bool live) {
+            if (live) {
+                p = out + prog_block_fast(mpr, nbm, hs, vs, off, fx, fy) * 64;
+                c = __hip_atomic_load(p + nat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (++fx == nbx) { fx = 0; ++fy; }
+            }
         };
         // the block whose bits are on their way
         int16_t* pend_ptr = out; int pend_orig = 0; uint32_t pend_byte = 0, pend_bit = 0xFFFFFFFFu;
@@ -421,27 +415,28 @@ __device__ __forceinline__ uint32_t prog_ac_refine(ProgSync sy, AcRefineArgs a, 
             else if (one && (coef & plus) == 0) coef = (int16_t)(coef + (coef >= 0 ? plus : minus));   // history: one more bit of magnitude
             if (coef != pend_orig) co_store(pend_ptr + nat, coef);
         };
+        bool ended = false;
         for (int ub = 0; ub < n_units; ub += kProgBatch) {      // a batch of units: everything the scans before left in them is there
             const int nu = min(kProgBatch, n_units - ub);
             if (ub) { finish_pending(); pend_bit = 0xFFFFFFFFu; publish(ub); }
             wait_units(ub + nu);
             fetch(p0, c0, nu > 0); fetch(p1, c1, nu > 1); fetch(p2, c2, nu > 2);
-            for (int u = 0; u < nu; ++u) {
+            // one block; the slot it came from is refilled with the block three further on (three copies of this body, one per slot: moving an
+            // in-flight value from slot to slot would wait for it).  -> false: the scan is over (an impossible code, or past the data)
+            auto one_block = [&](int16_t*& slot_p, int16_t& slot_c, int u) -> bool {
                 PROG_T(t_a);
-                const int orig = c0; int16_t* const cur = p0;
-                p0 = p1; c0 = c1; p1 = p2; c1 = c2;
-                fetch(p2, c2, u + 3 < nu);
+                const int orig = slot_c; int16_t* const cur = slot_p;
+                fetch(slot_p, slot_c, u + 3 < nu);
                 uint32_t mybit = 0xFFFFFFFFu;                    // the bit of the stream this lane wants: its correction bit (history) or its sign (new)
                 const uint64_t nz = __ballot(orig != 0) & band;
                 eobrun = rfl(eobrun);
-                if (eobrun > 0 && nz == 0) { --eobrun; continue; }          // inside an EOB run, no history: not a bit of the stream belongs to this block
+                if (eobrun > 0 && nz == 0) { --eobrun; return true; }       // inside an EOB run, no history: not a bit of the stream belongs to this block
                 const uint64_t zeros = ~nz & band;
                 const int rk = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nz, 0u));      // lanes with history below this one
                 const bool has_hist = (nz >> lane) & 1ull;
                 int nc = 0;                                     // lanes with history already passed
                 uint64_t nzr = nz;                              // ... and those still ahead
                 int k = ss;
-                bool bad = false;
                 PROG_T(t_b);
                 if (eobrun == 0) {
                     const int zr = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(zeros >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)zeros, 0u));
@@ -449,15 +444,15 @@ __device__ __forceinline__ uint32_t prog_ac_refine(ProgSync sy, AcRefineArgs a, 
                     const int dest = ((zeros >> lane) & 1ull) ? zr : 63 - (lane - zr);
                     const int pz = __builtin_amdgcn_ds_permute(dest << 2, lane);                 // lane r: the r-th position without history
                     int zc = 0;                                 // positions without history already passed
-                    while (k <= se) {
+                    if (k <= se) for (;;) {                      // (the ways out are jumps, not flags tested behind the loop: ~13 of 60 instructions per symbol)
 #ifdef GAMUT_PROG_PROFILE
                         ++pf_syms;
 #endif
                         const uint64_t w = bits_at(pos);
                         uint32_t ent = (uint32_t)__builtin_amdgcn_readlane((int)t6, (int)(w >> 58));
                         if (__builtin_expect((ent & 3u) != 1u, 0)) {
-                            if (ent == 0) { int len; const int sym = ac.decode(w, len); if (sym < 0) { bad = true; break; } ent = pack(sym, len); }
-                            if ((ent & 3u) == 3u) { bad = true; break; }
+                            if (ent == 0) { int len; const int sym = ac.decode(w, len); if (sym < 0) goto bad_code; ent = pack(sym, len); }
+                            if ((ent & 3u) == 3u) goto bad_code;
                             if ((ent & 3u) == 2u) {              // EOBn: this block's band ends here, and that of the next eobrun - 1 blocks
                                 const int len = (int)(ent >> 20), run = (int)((ent >> 12) & 15u);
                                 eobrun = (1 << run) + (run ? (int)((w << len) >> (64 - run)) : 0);
@@ -465,6 +460,7 @@ __device__ __forceinline__ uint32_t prog_ac_refine(ProgSync sy, AcRefineArgs a, 
                                 break;
                             }
                         }
+                        {
                         const int used = (int)((ent >> 4) & 0xFFu), run = (int)((ent >> 12) & 15u);
                         const bool coefficient = (ent >> 16) & 1u;       // a new coefficient at the stop (its sign follows the code); else ZRL
                         // on from k over `run` positions without history to the one that ends the run; what has history on the way is corrected
@@ -484,9 +480,11 @@ __device__ __forceinline__ uint32_t prog_ac_refine(ProgSync sy, AcRefineArgs a, 
                         nc += c;
                         pos = P + (uint32_t)c;
                         k = stop + 1;
+                        }
+                        if (k > se) break;
                     }
                 }
-                if (bad) { if (lane == 0) atomicOr(st, 1u); finish_pending(); return sy.waited; }
+                if (false) { bad_code: if (lane == 0) atomicOr(st, 1u); finish_pending(); return false; }
                 PROG_T(t_c);
                 eobrun = rfl(eobrun);
                 if (eobrun > 0) {                                // the rest of the block: correction bits only
@@ -500,12 +498,20 @@ __device__ __forceinline__ uint32_t prog_ac_refine(ProgSync sy, AcRefineArgs a, 
                 finish_pending();
                 pend_ptr = cur; pend_orig = orig; pend_bit = mybit; pend_byte = 0;
                 if (mybit != 0xFFFFFFFFu) pend_byte = seg[mybit >> 3];
-                if (pos > limit_bit) { if (lane == 0) atomicOr(st, 4u); finish_pending(); return sy.waited; }
+                if (pos > limit_bit) { if (lane == 0) atomicOr(st, 4u); finish_pending(); return false; }
                 PROG_T(t_d);
                 PROG_ACC(pf_setup, t_a, t_b); PROG_ACC(pf_walk, t_b, t_c); PROG_ACC(pf_tail, t_c, t_d);
+                return true;
+            };
+            bool going = true;
+            for (int u = 0; u < nu && going; u += 3) {
+                going = one_block(p0, c0, u);
+                if (going && u + 1 < nu) going = one_block(p1, c1, u + 1);
+                if (going && u + 2 < nu) going = one_block(p2, c2, u + 2);
             }
+            if (!going) { ended = true; break; }
         }
-        finish_pending();
+        if (!ended) finish_pending();
     }
 #ifdef GAMUT_PROG_PROFILE
     if (profile && lane == 0) *profile = make_uint4(pf_setup, pf_walk, pf_tail, pf_syms);

@@ -496,9 +496,8 @@ __global__ __launch_bounds__(plain_threads(ST)) void k_jpeg_plain(JpegArgs a)
     if (t < NBLK * 8) {
         uint4 row = make_uint4(0, 0, 0, 0);
         if (blk_live) row = load_coeffs16(cbase + (u32)(t * 8));                          // block b, row r: lane-contiguous; read once: nontemporal
-        i32 x[8], tv[8];
-        unpack_row(row, x);
-        row_pass<8>(x, tv);
+        i32 tv[8];
+        row_pass_packed(row, tv);                                 // == row_pass<8>(unpack_row(row)), 34 instructions instead of 56
         i32* dst = T1 + b * BLK_STRIDE + r * 8;
         *reinterpret_cast<int4*>(dst)     = make_int4(tv[0], tv[1], tv[2], tv[3]);
         *reinterpret_cast<int4*>(dst + 4) = make_int4(tv[4], tv[5], tv[6], tv[7]);
@@ -577,6 +576,96 @@ __global__ __launch_bounds__(plain_threads(ST)) void k_jpeg_plain(JpegArgs a)
         }
     }
     __syncthreads();                                              // T1 / S are rewritten by the next strip
+    }
+}
+
+// =============================================================================
+// grey and 4:4:4: a thread per (MCU, block row), then per (MCU, pixel column)
+// =============================================================================
+// k_jpeg_plain's 4:4:4 form is bound by the vector ALUs (92 % busy, 72 instructions per pixel; grey 95 %: profiles/r04_plain_pmc.txt): besides
+// the IDCTs a pixel needs it writes every sample to LDS as a byte, reads it back in another thread, pulls the bytes apart again and leaves a
+// third of the workgroup idle in the colour stage.  Here the thread that ran the column pass of column c of an MCU's Y block runs those of its
+// Cb and Cr blocks as well and has the three samples of its eight pixels in registers: colour conversion and the stores follow without another
+// trip through LDS -- a dword per row for rgba8 (a wave's 64 lanes cover 256 contiguous bytes of a row); for rgb8 and l8 four neighbouring
+// lanes first pass their pixels along (DPP row shifts) so that the group's 12 or 4 bytes leave as whole dwords.
+// Pass 1: the same thread takes row r of the MCU's blocks (H1V1Convert :2528-2561 consumes the Y, Cb, Cr blocks of one MCU; gray_convert
+// :2715-2728 one Y block).  One LDS block slot per MCU, the components take turns in it: registers, not LDS, decide how many waves a SIMD holds.
+template <int ST, int OC, int MCUS>     // MCUs per strip = threads / 8
+__global__ __launch_bounds__(MCUS * 8) void k_jpeg_cols(JpegArgs a)
+{
+    static_assert(ST == GAMUT_JPGD_GRAYSCALE || ST == GAMUT_JPGD_YH1V1, "one block per component and MCU");
+    constexpr int NC = ST == GAMUT_JPGD_GRAYSCALE ? 1 : 3;
+    constexpr int STRIPS = 2;
+    __shared__ __attribute__((aligned(16))) i32 T1[MCUS * BLK_STRIDE];
+    const int t = threadIdx.x, m = t >> 3, r = t & 7;
+    const int img = blockIdx.z, mcu_y = blockIdx.y;
+    const ColourConsts cc = colour_consts();
+    const int rows_here = min(8, a.height - mcu_y * 8);
+    const int j = t & 3;                                          // place in the group of four pixels that shares its output dwords (rgb8, l8)
+    const u32 sel3 = j == 0 ? 0x04020100u : j == 1 ? 0x05040201u : 0x06050402u;
+    for (int strip = 0; strip < STRIPS; ++strip) {
+        const int mcu_x0 = (blockIdx.x * STRIPS + strip) * MCUS;
+        if (mcu_x0 >= a.mcus_per_row) break;                      // workgroup-uniform
+        const int64_t blk0 = ((int64_t)mcu_y * a.mcus_per_row + mcu_x0) * NC;
+        const int16_t* cbase = a.coeffs + (int64_t)img * a.coeff_stride + blk0 * 64;
+        const bool live = mcu_x0 + m < a.mcus_per_row;
+        uint4 rows[NC];
+        #pragma unroll
+        for (int comp = 0; comp < NC; ++comp) {
+            rows[comp] = make_uint4(0, 0, 0, 0);
+            if (live) rows[comp] = load_coeffs16(cbase + (u32)((m * NC + comp) * 64 + r * 8));
+        }
+        i32 smp[NC][8];
+        #pragma unroll
+        for (int comp = 0; comp < NC; ++comp) {
+            i32 tv[8];
+            row_pass_packed(rows[comp], tv);
+            i32* dst = T1 + m * BLK_STRIDE + r * 8;
+            *reinterpret_cast<int4*>(dst)     = make_int4(tv[0], tv[1], tv[2], tv[3]);
+            *reinterpret_cast<int4*>(dst + 4) = make_int4(tv[4], tv[5], tv[6], tv[7]);
+            wave_sync();                                          // an MCU's 8 threads sit in one wave
+            const i32* src = T1 + m * BLK_STRIDE + r;
+            #pragma unroll
+            for (int i = 0; i < 8; ++i) tv[i] = src[i * 8];
+            wave_sync();                                          // the slot is rewritten by the next component's pass 1
+            col_pass<8>(tv, smp[comp]);
+            if (a.max_zag) {                                      // Col!(1) shortcut, as in k_jpeg_plain
+                bool col1 = false;
+                if (live) col1 = a.max_zag[(int64_t)img * a.zag_stride + blk0 + m * NC + comp] <= 2;
+                const i32 v = col1_sample(tv[0]);
+                #pragma unroll
+                for (int i = 0; i < 8; ++i) smp[comp][i] = col1 ? v : smp[comp][i];
+            }
+        }
+        const int x = (mcu_x0 + m) * 8 + r;
+        const bool mine = live && x < a.width;
+        const bool whole = x - j + 4 <= a.width;                  // the group of four pixels lies inside the image: dword stores
+        uint8_t* const o0 = a.out + (int64_t)img * a.out_stride + (int64_t)(mcu_y * 8) * a.out_pitch;
+        #pragma unroll
+        for (int y = 0; y < 8; ++y) {
+            if (y >= rows_here) break;                            // workgroup-uniform
+            uint8_t* const orow = o0 + (int64_t)y * a.out_pitch;
+            u32 px;                                               // R, G, B, 255
+            if constexpr (NC == 1) px = __builtin_amdgcn_perm((u32)smp[0][y], (u32)smp[0][y], 0x0d000000u);         // grey replicated (:3761-3801)
+            else                   px = ycc_to_rgba(smp[0][y], smp[1][y], smp[NC - 1][y], cc.kr, cc.kb, cc.kg);
+            if constexpr (OC == 4) {
+                if (mine) __builtin_nontemporal_store(px, reinterpret_cast<u32*>(orow + (int64_t)x * 4));
+            } else if constexpr (OC == 3) {
+                const u32 nxt = (u32)__builtin_amdgcn_update_dpp(0, (int)px, 0x101, 0xF, 0xF, false);                 // row_shl:1 -- the pixel to the right
+                const u32 d = __builtin_amdgcn_perm(nxt, px, sel3);
+                typedef u32 u32x1a __attribute__((aligned(1)));
+                if (whole) { if (mine && j < 3) __builtin_nontemporal_store((u32x1a)d, reinterpret_cast<u32x1a*>(orow + (int64_t)(x - j) * 3 + j * 4)); }
+                else if (mine) { uint8_t* q = orow + (int64_t)x * 3; q[0] = (uint8_t)px; q[1] = (uint8_t)(px >> 8); q[2] = (uint8_t)(px >> 16); }
+            } else {
+                u32 g;
+                if constexpr (NC == 1) g = (u32)smp[0][y]; else g = rgb_to_luma(px);
+                g |= (u32)__builtin_amdgcn_update_dpp(0, (int)g, 0x101, 0xF, 0xF, false) << 8;                      // + the pixel to the right
+                g |= (u32)__builtin_amdgcn_update_dpp(0, (int)g, 0x102, 0xF, 0xF, false) << 16;                     // + the pair two to the right
+                typedef u32 u32x1a __attribute__((aligned(1)));
+                if (whole) { if (mine && j == 0) __builtin_nontemporal_store((u32x1a)g, reinterpret_cast<u32x1a*>(orow + x)); }
+                else if (mine) orow[x] = (uint8_t)g;
+            }
+        }
     }
 }
 
@@ -770,6 +859,7 @@ int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
         const bool tuned = apitch > 0 && apitch < (1 << 27) &&
                            (out_comps != 4 || (((uintptr_t)out & 3) == 0 && (apitch & 3) == 0 && (out_stride & 3) == 0));
         if (tuned && out_pitch < 0 && scan_type == GAMUT_JPGD_YH2V2) { c.flip = 1; c.out_pitch = apitch; c.out += (int64_t)(height - 1) * out_pitch; }
+        static const bool cols_tuned = !(getenv("GAMUT_HIP_JPEG_COLS") && !strcmp(getenv("GAMUT_HIP_JPEG_COLS"), "plain"));      // A/B: k_jpeg_plain for grey and 4:4:4
         const int ps = plain_strips(scan_type);
         const int pm = plain_mcus(scan_type, out_comps);
         const dim3 grid32(((a.mcus_per_row + 31) / 32 + ps - 1) / ps, a.mcus_per_col, n);           // grey: 32 MCUs per strip
@@ -787,6 +877,17 @@ int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
             else                     hipLaunchKernelGGL((k_jpeg_plain<ST, 1>), G, dim3(plain_threads(ST)), 0, stream, c); } while (0)
         if (!tuned)                                   hipLaunchKernelGGL(k_jpeg_generic, grid, dim3(256), 0, stream, c);
         else if (scan_type == GAMUT_JPGD_GRAYSCALE)   GAMUT_JPEG_PLAIN(GAMUT_JPGD_GRAYSCALE, grid32);
+        else if ((scan_type == GAMUT_JPGD_YH1V1 || scan_type == GAMUT_JPGD_GRAYSCALE) && cols_tuned) {
+            // strips of 32 or 24 MCUs, whichever leaves fewer idle threads at the end of a row (1080p: 240 MCUs = 10 x 24)
+            const int waste32 = (32 - a.mcus_per_row % 32) % 32, waste24 = (24 - a.mcus_per_row % 24) % 24;
+            const bool m24 = waste24 * 32 < waste32 * 24;
+            const dim3 g(((a.mcus_per_row + (m24 ? 23 : 31)) / (m24 ? 24 : 32) + 1) / 2, a.mcus_per_col, n);
+#define GAMUT_JPEG_COLS(ST, OC) do { if (m24) hipLaunchKernelGGL((k_jpeg_cols<ST, OC, 24>), g, dim3(192), 0, stream, c); \
+                                     else     hipLaunchKernelGGL((k_jpeg_cols<ST, OC, 32>), g, dim3(256), 0, stream, c); } while (0)
+            if (scan_type == GAMUT_JPGD_YH1V1) { if (out_comps == 4) GAMUT_JPEG_COLS(GAMUT_JPGD_YH1V1, 4); else if (out_comps == 3) GAMUT_JPEG_COLS(GAMUT_JPGD_YH1V1, 3); else GAMUT_JPEG_COLS(GAMUT_JPGD_YH1V1, 1); }
+            else                               { if (out_comps == 4) GAMUT_JPEG_COLS(GAMUT_JPGD_GRAYSCALE, 4); else if (out_comps == 3) GAMUT_JPEG_COLS(GAMUT_JPGD_GRAYSCALE, 3); else GAMUT_JPEG_COLS(GAMUT_JPGD_GRAYSCALE, 1); }
+#undef GAMUT_JPEG_COLS
+        }
         else if (scan_type == GAMUT_JPGD_YH1V1)       GAMUT_JPEG_PLAIN(GAMUT_JPGD_YH1V1, grid_plain);
         else if (scan_type == GAMUT_JPGD_YH2V1)       GAMUT_JPEG_PLAIN(GAMUT_JPGD_YH2V1, grid_plain);
         else if (scan_type == GAMUT_JPGD_YH1V2)       GAMUT_JPEG_PLAIN(GAMUT_JPGD_YH1V2, grid_plain);

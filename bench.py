@@ -129,6 +129,7 @@ def live_traffic(kernel_substr, pmc_batch):
 
 ALSO = [  # the other BASELINE.json configs at their stated shapes, each through this same script (its own parity check included)
     ("config 2, what a caller has: coefficients + max_zag from libjpeg-written photographs", "jpeg:photo", []),
+    ("config 2's kernel family on 4:4:4 files (k_jpeg_cols)", "jpeg:4:1", []),
     ("config 3: 512 x 3840x2160 RGBA8, random row filters (a fifth Paeth)", "png", []),
     ("config 3: the same with the encoder heuristic's filters (no Paeth rows on this data)", "png:heuristic", []),
     ("config 4: rgba16 -> rgbaf32, 256 layers of 8192x8192 in resident chunks", "convert:rgba16:rgbaf32", ["--batch", "256"]),

@@ -759,14 +759,13 @@ int progressive_decode_device(const uint8_t* const* data, const size_t* len, con
     int workers = host_threads();
     workers = workers < 1 ? 1 : workers > 16 ? 16 : workers;
     if (workers > n) workers = n;
-    // A scan is a chain: the GPU decodes one several times slower than a host core does (190 ms for the scans of a 1080p
-    // file, whatever the batch, against 20 ms), and wins by decoding every scan of every file at the same time.  Below
-    // twelve files per host thread (16 threads: 2 100 Mpx/s for 64 files, 1 760 for 256, 1 400 from 1024 on; the GPU: 730 Mpx/s
-    // for 64 files, 2 780 for 256, 8 790 for 1024, 13 400 for 4096) the host feeder (Progressive::run on the thread pool)
-    // plus an upload of the coefficients is the faster way to the same buffers.  GAMUT_HIP_JPEG_PROGRESSIVE = host / device
-    // forces either (tests, measurements).
+    // A scan is a chain: the GPU decodes a 1080p file's longest one in 63 ms (round 4; whatever the batch, up to a few hundred files) where a
+    // host core needs 20 ms for the whole file, and wins by decoding every scan of every file at the same time.  Below five files per host
+    // thread the host feeder (Progressive::run on the thread pool) plus an upload of the coefficients is the faster way to the same buffers
+    // (profiles/r04_prog_threshold.txt, files -> rgba8: 16 threads 64 files 54 ms on the host / 66 ms on the GPU, 96 files 76 / 68 ms,
+    // 192 files 185 / 71 ms; 2 threads 16 files 70 / 65 ms).  GAMUT_HIP_JPEG_PROGRESSIVE = host / device forces either (tests, measurements).
     const char* how = getenv("GAMUT_HIP_JPEG_PROGRESSIVE");
-    const bool on_host = how && !strcmp(how, "host") ? true : how && !strcmp(how, "device") ? false : n < 12 * workers;
+    const bool on_host = how && !strcmp(how, "host") ? true : how && !strcmp(how, "device") ? false : n < 5 * workers;
     if (on_host) {
         std::vector<gamut_hip_jpeg_frame> frames((size_t)n);
         std::vector<int> rcs((size_t)n, GAMUT_HIP_OK);

@@ -2,6 +2,7 @@
 """What a caller with FILES sees: batches of files in host memory -> pixels in HBM through the batch entry points (PCIe and the
 feeders included -- not bench.py's contract, whose inputs are resident in HBM).  One JSON line per case, for bench.py's `also` array:
   jpeg        1024 x 1080p baseline 4:2:0 files -> rgba8   (gamut_hip_jpeg_decode_batch_device: entropy decode + reconstruction on the GPU)
+  jpeg:progressive   the same pictures as progressive (SOF2) files: ten scans each, all of them decoded on the GPU
   png:noisy   256 x 4K RGB8 files of the synthetic image as it is (12 MB of IDAT each)   } gamut_hip_png_decode_batch_device: chunk walk on the
   png:smooth  the same image behind a Gaussian blur (3.6 MB each)                        } host, inflate + de-filter + expansion on the GPU
 Parity before timing: JPEG == the coefficient path (host entropy decoder -> k_jpeg_h2v2, the path the oracle checks); PNG == Pillow's
@@ -33,11 +34,11 @@ def best_of(fn, reps):
     return best
 
 
-def jpeg_case(L, reps):
+def jpeg_case(L, reps, progressive=False):
     w, h, B, distinct = 1920, 1080, 1024, 8
     files = []
     for i in range(distinct):
-        bio = io.BytesIO(); Image.fromarray(gen.synth_rgb(w, h, 100 + i)).save(bio, "JPEG", quality=90, subsampling=2)
+        bio = io.BytesIO(); Image.fromarray(gen.synth_rgb(w, h, 100 + i)).save(bio, "JPEG", quality=90, subsampling=2, progressive=progressive)
         files.append(np.frombuffer(bio.getvalue(), np.uint8))
     bufs = [files[i % distinct] for i in range(B)]
     ptrs = (C.c_void_p * B)(*[b.ctypes.data for b in bufs]); lens = (C.c_size_t * B)(*[b.size for b in bufs])
@@ -67,7 +68,8 @@ def jpeg_case(L, reps):
     torch.cuda.synchronize()
     ok = all(bool(torch.equal(out[i], ref[i % distinct])) for i in (0, 1, distinct - 1, B - 1, B // 2))
     t = best_of(run, reps)
-    return {"what": "files -> pixels: 1024 x 1080p baseline JPEG 4:2:0 files in host memory -> rgba8 in HBM (gamut_hip_jpeg_decode_batch_device)",
+    kind = "progressive (libjpeg's ten-scan script; every scan decoded on the GPU in one launch)" if progressive else "baseline"
+    return {"what": f"files -> pixels: 1024 x 1080p {kind} JPEG 4:2:0 files in host memory -> rgba8 in HBM (gamut_hip_jpeg_decode_batch_device)",
             "value": round(B * w * h / t / 1e6, 1), "unit": "Mpx/s", "ms": round(t * 1e3, 2), "MB_per_file": round(sum(f.size for f in files) / distinct / 1e6, 3),
             "parity": "ok (== host entropy decoder -> k_jpeg_h2v2)" if ok else "FAILED"}
 
@@ -100,13 +102,13 @@ def png_case(L, reps, content):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("cases", nargs="*", default=["jpeg", "png:noisy", "png:smooth"])
+    ap.add_argument("cases", nargs="*", default=["jpeg", "jpeg:progressive", "png:noisy", "png:smooth"])
     ap.add_argument("--reps", type=int, default=3)
     a = ap.parse_args()
     L = _capi.lib(); _capi.check(L.gamut_hip_init(0))
     bad = False
     for c in a.cases:
-        r = jpeg_case(L, a.reps) if c == "jpeg" else png_case(L, a.reps, c.split(":")[1])
+        r = jpeg_case(L, a.reps) if c == "jpeg" else jpeg_case(L, a.reps, True) if c == "jpeg:progressive" else png_case(L, a.reps, c.split(":")[1])
         r["inputs"] = "files in host memory: PCIe and the feeders are inside the time (bench.py's `value` has its inputs resident in HBM)"
         bad = bad or not r["parity"].startswith("ok")
         print(json.dumps(r), flush=True)

@@ -1098,7 +1098,8 @@ int inflate_scratch(int count, hipStream_t stream, InflateScratch& out)
     const size_t tok_bytes = (size_t)(2 * resident) * kTokCap * sizeof(uint2), busy_bytes = round_up((size_t)(2 * resident) * 4),
                  state_bytes = round_up((size_t)count * sizeof(InfState)),
                  item_bytes = round_up((size_t)count * sizeof(InfItem)), avail_bytes = round_up((size_t)count * 4);
-    const size_t need_toks = (size_t)n_slots * kTokCap * sizeof(uint2);
+    // (the tables lie BEHIND the token lists the entry already has, which may be more than this batch needs: that is what must fit)
+    const size_t need_toks = (size_t)(n_slots > e->n_slots ? n_slots : e->n_slots) * kTokCap * sizeof(uint2);
     const size_t bytes = need_toks + busy_bytes + state_bytes + item_bytes + avail_bytes;
     if (bytes > e->cap || n_slots > e->n_slots) {
         if (e->p) { (void)hipStreamSynchronize(stream); (void)hipFree(e->p); e->p = nullptr; e->cap = 0; e->n_slots = 0; }

@@ -470,12 +470,6 @@ int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* 
         static thread_local PerDevice<PinnedScratch> blob_pinned_pd;
         static thread_local PerDevice<DeviceScratch> blob_dev_pd;
         PinnedScratch& blob_pinned = blob_pinned_pd.cur(); DeviceScratch& blob_dev = blob_dev_pd.cur();
-        if (device_inflate) {
-            for (int i = 0; i < count; ++i) blob_off[(size_t)i + 1] = blob_off[(size_t)i] + ((len[i] + 15) & ~(size_t)15);
-            h_blob = blob_pinned.get(blob_off[(size_t)count] + 16);
-            d_blob = (uint8_t*)blob_dev.get(blob_off[(size_t)count] + 16);
-            if (!h_blob || !d_blob) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png: staging for %zu bytes of IDAT data failed", blob_off[(size_t)count]);
-        }
         // Device inflate, step one: the chunk walk of every file (no byte of IDAT data is touched: parse() notes where the payloads are).
         std::vector<std::vector<std::pair<const uint8_t*, uint32_t>>> segments(device_inflate ? (size_t)count : 0);
         auto gather = [&]() {
@@ -569,12 +563,9 @@ int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* 
             // longest streams first: a stream is one workgroup for its whole length, and workgroups start in the order of the list -- with
             // more streams than compute units the long ones must not be the ones that start last
             std::stable_sort(who.begin(), who.end(), [&](int a, int b) { return idat_len[(size_t)a] > idat_len[(size_t)b]; });
-            for (int i : who) {
-                descs.push_back(gamut_hip_inflate_desc{ d_blob + blob_off[(size_t)i], d_arena + slot[(size_t)i], idat_len[(size_t)i], (uint32_t)slot_bytes[(size_t)i] });
-                longest = idat_len[(size_t)i] > longest ? idat_len[(size_t)i] : longest;
-            }
-            if (!descs.empty()) {
-                const size_t n = descs.size();
+            for (int i : who) longest = idat_len[(size_t)i] > longest ? idat_len[(size_t)i] : longest;
+            if (!who.empty()) {
+                const size_t n = who.size();
                 static thread_local PerDevice<DeviceScratch> verdict_dev_pd;
                 DeviceScratch& verdict_dev = verdict_dev_pd.cur();
                 uint32_t* d_verdict = (uint32_t*)verdict_dev.get(n * 8);
@@ -589,6 +580,28 @@ int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* 
                 if (const char* v = getenv("GAMUT_HIP_PNG_SLICE_KB")) { const long kb = atol(v); if (kb >= 64 && kb <= (1 << 20)) slice = (uint32_t)kb << 10; }      // (tuning)
                 while ((uint64_t)slice * 32u < longest) slice *= 2;
                 const int rounds = longest ? (int)(((uint64_t)longest + slice - 1) / slice) : 1;
+                // The staging image.  One copy per (stream, slice) is a megabyte at a time: 37 GB/s on one copy stream where the link does 57
+                // (tools/microbench/h2d_streams.hip, profiles/r04_h2d_streams.txt).  With every stream's share `pitch` bytes apart -- the
+                // streams in the order of the list, longest first, so that those still running in a round are a prefix -- slice r of all of
+                // them is ONE pitched copy (hipMemcpy2DAsync: 57 GB/s even with 512 KiB rows).  Batches of very unequal streams (the pitched
+                // image would be more than twice the data) keep their tight layout and piece-wise copies, spread over two copy streams (46 GB/s).
+                uint64_t data_bytes = 0;
+                for (int i : who) data_bytes += ((uint64_t)idat_len[(size_t)i] + 15) & ~(uint64_t)15;
+                const uint64_t pitch = (uint64_t)rounds * slice;
+                bool pitched = pitch * n <= 2 * data_bytes + (64u << 20);
+                if (const char* v = getenv("GAMUT_HIP_PNG_PITCHED")) pitched = atoi(v) != 0;                           // (measurements)
+                const uint64_t blob_bytes = pitched ? pitch * n : data_bytes;
+                h_blob = blob_pinned.get(blob_bytes + 16);
+                d_blob = (uint8_t*)blob_dev.get(blob_bytes + 16);
+                if (!h_blob || !d_blob) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png: staging for %llu bytes of IDAT data failed", (unsigned long long)blob_bytes);
+                {
+                    uint64_t at = 0;
+                    for (size_t k = 0; k < n; ++k) { const int i = who[k]; blob_off[(size_t)i] = pitched ? k * pitch : at; at += ((uint64_t)idat_len[(size_t)i] + 15) & ~(uint64_t)15; }
+                }
+                for (int i : who) descs.push_back(gamut_hip_inflate_desc{ d_blob + blob_off[(size_t)i], d_arena + slot[(size_t)i], idat_len[(size_t)i], (uint32_t)slot_bytes[(size_t)i] });
+                static thread_local PerDevice<hipStream_t> copy2_pd;
+                hipStream_t& copy_stream2 = copy2_pd.cur();
+                if (!copy_stream2 && hipStreamCreateWithFlags(&copy_stream2, hipStreamNonBlocking) != hipSuccess) return set_error(GAMUT_HIP_ERR_HIP, "png: stream creation failed");
                 // the units of work, slice-major: (round, stream)
                 std::vector<std::pair<int, int>> units;
                 std::vector<int> units_in_round((size_t)rounds, 0);
@@ -614,7 +627,7 @@ int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* 
                             const uint64_t c_lo = std::max(s_lo, want_lo), c_hi = std::min(s_hi, want_hi);
                             memcpy(dst + (c_lo - want_lo), sg.first + (c_lo - s_lo), (size_t)(c_hi - c_lo));
                         }
-                        if (hi > lo && hipMemcpyAsync(d_blob + blob_off[(size_t)i] + lo, dst, (size_t)(hi - lo), hipMemcpyHostToDevice, copy_stream) != hipSuccess) {
+                        if (!pitched && hi > lo && hipMemcpyAsync(d_blob + blob_off[(size_t)i] + lo, dst, (size_t)(hi - lo), hipMemcpyHostToDevice, (u & 1) ? copy_stream2 : copy_stream) != hipSuccess) {
                             (void)hipGetLastError(); upload_failed.store(true);
                         }
                         round_done[(size_t)r].fetch_add(1, std::memory_order_release);
@@ -629,9 +642,20 @@ int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* 
                 int launch_rc = GAMUT_HIP_OK;
                 for (int r = 0; r < rounds && launch_rc == GAMUT_HIP_OK; ++r) {
                     while (round_done[(size_t)r].load(std::memory_order_acquire) < units_in_round[(size_t)r]) std::this_thread::yield();
-                    // every copy of slice r has been queued on the copy stream: the compute stream waits for them, then inflates what is there
+                    // slice r of every stream is in the pinned image (pitched: it goes up now, in one copy) / has been queued on the copy streams:
+                    // the compute stream waits for it, then inflates what is there
+                    if (pitched && units_in_round[(size_t)r] > 0 &&
+                        hipMemcpy2DAsync(d_blob + (uint64_t)r * slice, pitch, h_blob + (uint64_t)r * slice, pitch, slice, (size_t)units_in_round[(size_t)r], hipMemcpyHostToDevice, copy_stream) != hipSuccess) {
+                        (void)hipGetLastError(); launch_rc = set_error(GAMUT_HIP_ERR_HIP, "png: upload of slice %d failed", r); break;
+                    }
                     if (hipEventCreateWithFlags(&up[(size_t)r], hipEventDisableTiming) != hipSuccess || hipEventRecord(up[(size_t)r], copy_stream) != hipSuccess ||
                         hipStreamWaitEvent(st, up[(size_t)r], 0) != hipSuccess) { (void)hipGetLastError(); launch_rc = set_error(GAMUT_HIP_ERR_HIP, "png: event for slice %d failed", r); break; }
+                    if (!pitched) {
+                        hipEvent_t e2 = nullptr;
+                        if (hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess || hipEventRecord(e2, copy_stream2) != hipSuccess || hipStreamWaitEvent(st, e2, 0) != hipSuccess) {
+                            (void)hipGetLastError(); launch_rc = set_error(GAMUT_HIP_ERR_HIP, "png: event for slice %d failed", r); break; }
+                        up.push_back(e2);
+                    }
                     avail[(size_t)r].resize(n);
                     for (size_t k = 0; k < n; ++k) avail[(size_t)r][k] = (uint32_t)std::min<uint64_t>((uint64_t)(r + 1) * slice, idat_len[(size_t)who[k]]);
                     launch_rc = inflate_sliced_step((int)n, avail[(size_t)r].data(), d_verdict, d_verdict + n, st);
@@ -640,7 +664,7 @@ int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* 
                 if (launch_rc == GAMUT_HIP_OK && upload_failed.load()) launch_rc = set_error(GAMUT_HIP_ERR_HIP, "png: upload of the IDAT data failed");
                 if (launch_rc == GAMUT_HIP_OK && hipMemcpyAsync(verdict.data(), d_verdict, n * 8, hipMemcpyDeviceToHost, st) != hipSuccess) launch_rc = set_error(GAMUT_HIP_ERR_HIP, "png: verdict download failed");
                 const hipError_t sync_rc = hipStreamSynchronize(st);
-                (void)hipStreamSynchronize(copy_stream);
+                (void)hipStreamSynchronize(copy_stream); (void)hipStreamSynchronize(copy_stream2);
                 for (hipEvent_t e : up) if (e) (void)hipEventDestroy(e);
                 if (launch_rc != GAMUT_HIP_OK) return launch_rc;
                 if (sync_rc != hipSuccess) return set_error(GAMUT_HIP_ERR_HIP, "png: inflate on the device failed: %s", hipGetErrorString(sync_rc));

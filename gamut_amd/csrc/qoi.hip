@@ -719,19 +719,35 @@ int decode_batch(const uint8_t* const* data, const int* size, int count, int cha
         // A file in page-locked memory (gamut_hip_host_malloc_pinned, hipHostRegister ...) goes up from where it is: no staging copy -- a
         // 1080p file is 4-8 MB, and 16 host threads copy about as fast as PCIe moves.  The slack behind such a file is whatever the device
         // buffer held: the lanes only need it readable (GAMUT_HIP_QOI_SLACK), the decode stops at the stream's end.
+        // Pageable files are gathered into the pinned image by the host threads and go up in runs of >= 32 MB (or >= one file per thread): a
+        // copy per file (2-5 MB) moves 40-45 GB/s over a link that does 57 with large ones (tools/microbench/h2d_streams.hip); the next run is
+        // gathered while this one is on its way.
         auto upload = [&](int k0, int k1, hipStream_t s) {
-            parallel_for(k1 - k0, workers, [&](int, int j) {
-                (void)hipSetDevice(dev);
-                const int k = k0 + j;
-                const size_t at = o_blob + items[(size_t)k].begin, nb = (size_t)items[(size_t)k].size + kQoiSlack;
-                if (host_range_is_pinned(data[src[(size_t)k]], items[(size_t)k].size)) {
-                    if (hipMemcpyAsync(d + at, data[src[(size_t)k]], items[(size_t)k].size, hipMemcpyHostToDevice, s) != hipSuccess) { (void)hipGetLastError(); upload_failed = 1; }
-                    return;
+            for (int c0 = k0; c0 < k1; ) {
+                int c1 = c0; size_t bytes = 0; bool any_pinned = false;
+                while (c1 < k1 && (c1 - c0 < workers || bytes < ((size_t)32 << 20))) {
+                    bytes += items[(size_t)c1].size;
+                    any_pinned = any_pinned || host_range_is_pinned(data[src[(size_t)c1]], items[(size_t)c1].size);
+                    ++c1;
                 }
-                memcpy(h + at, data[src[(size_t)k]], items[(size_t)k].size);
-                memset(h + at + items[(size_t)k].size, 0, kQoiSlack);
-                if (hipMemcpyAsync(d + at, h + at, nb, hipMemcpyHostToDevice, s) != hipSuccess) { (void)hipGetLastError(); upload_failed = 1; }
-            });
+                parallel_for(c1 - c0, workers, [&](int, int j) {
+                    (void)hipSetDevice(dev);
+                    const int k = c0 + j;
+                    const size_t at = o_blob + items[(size_t)k].begin, nb = (size_t)items[(size_t)k].size + kQoiSlack;
+                    if (any_pinned && host_range_is_pinned(data[src[(size_t)k]], items[(size_t)k].size)) {
+                        if (hipMemcpyAsync(d + at, data[src[(size_t)k]], items[(size_t)k].size, hipMemcpyHostToDevice, s) != hipSuccess) { (void)hipGetLastError(); upload_failed = 1; }
+                        return;
+                    }
+                    memcpy(h + at, data[src[(size_t)k]], items[(size_t)k].size);
+                    memset(h + at + items[(size_t)k].size, 0, kQoiSlack);
+                    if (any_pinned && hipMemcpyAsync(d + at, h + at, nb, hipMemcpyHostToDevice, s) != hipSuccess) { (void)hipGetLastError(); upload_failed = 1; }
+                });
+                if (!any_pinned) {                               // the run is one contiguous piece of the image
+                    const size_t lo = o_blob + items[(size_t)c0].begin, hi = o_blob + items[(size_t)c1 - 1].begin + items[(size_t)c1 - 1].size + kQoiSlack;
+                    if (hipMemcpyAsync(d + lo, h + lo, hi - lo, hipMemcpyHostToDevice, s) != hipSuccess) { (void)hipGetLastError(); upload_failed = 1; }
+                }
+                c0 = c1;
+            }
         };
         constexpr int kGroup = 256;                             // one workgroup per compute unit: the shape k_qoi_pipe is quickest at (a stream ~ 12 ms)
         if (n <= kGroup) {

@@ -207,3 +207,18 @@ def test_inflate_in_slices_equals_inflate_at_once(hip):
                 assert (s_ != 0) == (whole[2][i] != 0), f"slice {slice_bytes}, stream {i}: status {s_}, at once {whole[2][i]}"
             else:
                 assert s_ == 0 and got == exp, f"slice {slice_bytes}, stream {i}: status {s_}, {len(got)} of {len(exp)} bytes, first difference at {next((k for k, (a, b) in enumerate(zip(got, exp)) if a != b), None)}"
+
+
+def test_scratch_follows_batches_of_growing_and_shrinking_size(hip):
+    """the per-stream tables of a call lie behind the token lists the (thread, stream) scratch already owns: a batch of 17 streams sizes the lists
+    for a full chip, a later batch of 150 must make the allocation grow with its tables (round 4 checked the size it needed against the token
+    lists it would have needed, not the ones it had: the item table of the larger batch landed past the allocation)"""
+    rng = np.random.default_rng(23)
+    data = [rng.integers(0, 64, 3000 + 17 * i, dtype=np.uint8).tobytes() for i in range(150)]
+    streams = [_deflate(d, 6) for d in data]
+    for n in (17, 150, 5, 150, 40):
+        rc, outs, st = _inflate_device(hip, streams[:n], [len(d) for d in data[:n]])
+        assert rc == 0, hip.gamut_hip_last_error()
+        assert not any(st)
+        for i in range(n):
+            assert outs[i] == data[i], (n, i)

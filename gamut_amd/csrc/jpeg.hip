@@ -590,6 +590,28 @@ __global__ __launch_bounds__(plain_threads(ST)) void k_jpeg_plain(JpegArgs a)
 // lanes first pass their pixels along (DPP row shifts) so that the group's 12 or 4 bytes leave as whole dwords.
 // Pass 1: the same thread takes row r of the MCU's blocks (H1V1Convert :2528-2561 consumes the Y, Cb, Cr blocks of one MCU; gray_convert
 // :2715-2728 one Y block).  One LDS block slot per MCU, the components take turns in it: registers, not LDS, decide how many waves a SIMD holds.
+// one pixel per lane of a row, lanes along x: rgba8 a dword each; rgb8 / l8: the four lanes of a quad (j = place in it) pass their pixels
+// along so that whole dwords leave -- `whole`: the quad lies inside the image, else every lane writes its own bytes.  All lanes must call.
+template <int OC>
+__device__ __forceinline__ void emit_px(uint8_t* orow, int x, u32 px, u32 grey, int j, u32 sel3, bool mine, bool whole)
+{
+    typedef u32 u32x1a __attribute__((aligned(1)));
+    if constexpr (OC == 4) {
+        if (mine) __builtin_nontemporal_store(px, reinterpret_cast<u32*>(orow + (int64_t)x * 4));
+    } else if constexpr (OC == 3) {
+        const u32 nxt = (u32)__builtin_amdgcn_update_dpp(0, (int)px, 0x101, 0xF, 0xF, false);                 // row_shl:1 -- the pixel to the right
+        const u32 d = __builtin_amdgcn_perm(nxt, px, sel3);
+        if (whole) { if (mine && j < 3) __builtin_nontemporal_store((u32x1a)d, reinterpret_cast<u32x1a*>(orow + (int64_t)(x - j) * 3 + j * 4)); }
+        else if (mine) { uint8_t* q = orow + (int64_t)x * 3; q[0] = (uint8_t)px; q[1] = (uint8_t)(px >> 8); q[2] = (uint8_t)(px >> 16); }
+    } else {
+        u32 g = grey;
+        g |= (u32)__builtin_amdgcn_update_dpp(0, (int)g, 0x101, 0xF, 0xF, false) << 8;                      // + the pixel to the right
+        g |= (u32)__builtin_amdgcn_update_dpp(0, (int)g, 0x102, 0xF, 0xF, false) << 16;                     // + the pair two to the right
+        if (whole) { if (mine && j == 0) __builtin_nontemporal_store((u32x1a)g, reinterpret_cast<u32x1a*>(orow + x)); }
+        else if (mine) orow[x] = (uint8_t)g;
+    }
+}
+
 template <int ST, int OC, int MCUS>     // MCUs per strip = threads / 8
 __global__ __launch_bounds__(MCUS * 8) void k_jpeg_cols(JpegArgs a)
 {
@@ -648,22 +670,124 @@ __global__ __launch_bounds__(MCUS * 8) void k_jpeg_cols(JpegArgs a)
             u32 px;                                               // R, G, B, 255
             if constexpr (NC == 1) px = __builtin_amdgcn_perm((u32)smp[0][y], (u32)smp[0][y], 0x0d000000u);         // grey replicated (:3761-3801)
             else                   px = ycc_to_rgba(smp[0][y], smp[1][y], smp[NC - 1][y], cc.kr, cc.kb, cc.kg);
-            if constexpr (OC == 4) {
-                if (mine) __builtin_nontemporal_store(px, reinterpret_cast<u32*>(orow + (int64_t)x * 4));
-            } else if constexpr (OC == 3) {
-                const u32 nxt = (u32)__builtin_amdgcn_update_dpp(0, (int)px, 0x101, 0xF, 0xF, false);                 // row_shl:1 -- the pixel to the right
-                const u32 d = __builtin_amdgcn_perm(nxt, px, sel3);
-                typedef u32 u32x1a __attribute__((aligned(1)));
-                if (whole) { if (mine && j < 3) __builtin_nontemporal_store((u32x1a)d, reinterpret_cast<u32x1a*>(orow + (int64_t)(x - j) * 3 + j * 4)); }
-                else if (mine) { uint8_t* q = orow + (int64_t)x * 3; q[0] = (uint8_t)px; q[1] = (uint8_t)(px >> 8); q[2] = (uint8_t)(px >> 16); }
-            } else {
-                u32 g;
-                if constexpr (NC == 1) g = (u32)smp[0][y]; else g = rgb_to_luma(px);
-                g |= (u32)__builtin_amdgcn_update_dpp(0, (int)g, 0x101, 0xF, 0xF, false) << 8;                      // + the pixel to the right
-                g |= (u32)__builtin_amdgcn_update_dpp(0, (int)g, 0x102, 0xF, 0xF, false) << 16;                     // + the pair two to the right
-                typedef u32 u32x1a __attribute__((aligned(1)));
-                if (whole) { if (mine && j == 0) __builtin_nontemporal_store((u32x1a)g, reinterpret_cast<u32x1a*>(orow + x)); }
-                else if (mine) orow[x] = (uint8_t)g;
+            u32 g = 0;
+            if constexpr (OC == 1) { if constexpr (NC == 1) g = (u32)smp[0][y]; else g = rgb_to_luma(px); }
+            emit_px<OC>(orow, x, px, g, j, sel3, mine, whole);
+        }
+    }
+}
+
+// 4:2:2 (H2V1Convert :2558-2600: an MCU is two Y blocks side by side, 16 x 8 pixels, one chroma sample per pixel pair) and 4:4:0 (H1V2Convert
+// :2603-2647: two Y blocks stacked, 8 x 16 pixels, one chroma sample per pair of rows) the same way: eight threads per MCU, each runs pass 1 on
+// row r of the four blocks, then four column passes -- 4:4:0: column r of Y-top, Y-bottom, Cb, Cr = its 16 pixels; 4:2:2: the Y columns 2r and
+// 2r + 1 (both in block r >> 2) and chroma column r = its 8 x 2 pixels.  Two LDS block slots per MCU: the Y pair, then the chroma pair.
+template <int ST, int OC, int MCUS>
+__global__ __launch_bounds__(MCUS * 8) void k_jpeg_cols4(JpegArgs a)
+{
+    static_assert(ST == GAMUT_JPGD_YH2V1 || ST == GAMUT_JPGD_YH1V2, "four blocks per MCU");
+    constexpr bool WIDE = ST == GAMUT_JPGD_YH2V1;
+    constexpr int MW = WIDE ? 16 : 8, MH = WIDE ? 8 : 16;
+    constexpr int STRIPS = 2;
+    __shared__ __attribute__((aligned(16))) i32 T1[MCUS * 2 * BLK_STRIDE];
+    const int t = threadIdx.x, m = t >> 3, r = t & 7;
+    const int img = blockIdx.z, mcu_y = blockIdx.y;
+    const ColourConsts cc = colour_consts();
+    const int rows_here = min(MH, a.height - mcu_y * MH);
+    for (int strip = 0; strip < STRIPS; ++strip) {
+        const int mcu_x0 = (blockIdx.x * STRIPS + strip) * MCUS;
+        if (mcu_x0 >= a.mcus_per_row) break;                      // workgroup-uniform
+        const int64_t blk0 = ((int64_t)mcu_y * a.mcus_per_row + mcu_x0) * 4;
+        const int16_t* cbase = a.coeffs + (int64_t)img * a.coeff_stride + blk0 * 64;
+        const bool live = mcu_x0 + m < a.mcus_per_row;
+        uint4 rows[4];
+        #pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            rows[b] = make_uint4(0, 0, 0, 0);
+            if (live) rows[b] = load_coeffs16(cbase + (u32)((m * 4 + b) * 64 + r * 8));
+        }
+        i32 smp[4][8];                                            // 4:2:2: Y column 2r, Y column 2r + 1, Cb, Cr; 4:4:0: Y top, Y bottom, Cb, Cr
+        #pragma unroll
+        for (int turn = 0; turn < 2; ++turn) {
+            #pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                i32 tv[8];
+                row_pass_packed(rows[turn * 2 + k], tv);
+                i32* dst = T1 + (m * 2 + k) * BLK_STRIDE + r * 8;
+                *reinterpret_cast<int4*>(dst)     = make_int4(tv[0], tv[1], tv[2], tv[3]);
+                *reinterpret_cast<int4*>(dst + 4) = make_int4(tv[4], tv[5], tv[6], tv[7]);
+            }
+            wave_sync();                                          // an MCU's 8 threads sit in one wave
+            i32 tv[2][8];
+            int blk[2];                                           // which block of the MCU each of the two columns belongs to (Col!(1) shortcut)
+            #pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const bool pair_in_one = WIDE && turn == 0;       // 4:2:2 luma: both columns come from block r >> 2
+                const int slot = pair_in_one ? (r >> 2) : k, col = pair_in_one ? ((2 * r) & 7) + k : r;
+                blk[k] = turn * 2 + slot;
+                const i32* src = T1 + (m * 2 + slot) * BLK_STRIDE + col;
+                #pragma unroll
+                for (int i = 0; i < 8; ++i) tv[k][i] = src[i * 8];
+            }
+            wave_sync();                                          // the slots are rewritten by the next turn / strip
+            #pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                col_pass<8>(tv[k], smp[turn * 2 + k]);
+                if (a.max_zag) {                                  // Col!(1) shortcut, as in k_jpeg_plain
+                    bool col1 = false;
+                    if (live) col1 = a.max_zag[(int64_t)img * a.zag_stride + blk0 + m * 4 + blk[k]] <= 2;
+                    const i32 v = col1_sample(tv[k][0]);
+                    #pragma unroll
+                    for (int i = 0; i < 8; ++i) smp[turn * 2 + k][i] = col1 ? v : smp[turn * 2 + k][i];
+                }
+            }
+        }
+        uint8_t* const o0 = a.out + (int64_t)img * a.out_stride + (int64_t)(mcu_y * MH) * a.out_pitch;
+        if constexpr (!WIDE) {
+            const int x = (mcu_x0 + m) * 8 + r, j = t & 3;
+            const u32 sel3 = j == 0 ? 0x04020100u : j == 1 ? 0x05040201u : 0x06050402u;
+            const bool mine = live && x < a.width, whole = x - j + 4 <= a.width;
+            #pragma unroll
+            for (int y = 0; y < 16; ++y)
+                if (y < rows_here) {                              // workgroup-uniform (no break: the loop must unroll, smp[] is registers)
+                    const u32 px = ycc_to_rgba(smp[y >> 3][y & 7], smp[2][y >> 1], smp[3][y >> 1], cc.kr, cc.kb, cc.kg);
+                    u32 g = 0;
+                    if constexpr (OC == 1) g = rgb_to_luma(px);
+                    emit_px<OC>(o0 + (int64_t)y * a.out_pitch, x, px, g, j, sel3, mine, whole);
+                }
+        } else {
+            const int x0 = (mcu_x0 + m) * 16 + 2 * r;             // this thread's two pixels: x0, x0 + 1; a lane PAIR shares the dwords of four pixels
+            const bool odd = r & 1;
+            const int gx = x0 - (odd ? 2 : 0);
+            const bool mine = live && x0 < a.width, both = x0 + 1 < a.width, whole = gx + 4 <= a.width;
+            typedef u32 u32x1a __attribute__((aligned(1)));
+            typedef u32 u32x2a __attribute__((ext_vector_type(2), aligned(1)));
+            #pragma unroll
+            for (int y = 0; y < 8; ++y) {
+                if (y >= rows_here) break;                        // workgroup-uniform
+                uint8_t* const orow = o0 + (int64_t)y * a.out_pitch;
+                const u32 p0 = ycc_to_rgba(smp[0][y], smp[2][y], smp[3][y], cc.kr, cc.kb, cc.kg), p1 = ycc_to_rgba(smp[1][y], smp[2][y], smp[3][y], cc.kr, cc.kb, cc.kg);
+                if constexpr (OC == 4) {
+                    typedef u32 u32x2n __attribute__((ext_vector_type(2), aligned(4)));
+                    if (mine) { if (both) __builtin_nontemporal_store(u32x2n{ p0, p1 }, reinterpret_cast<u32x2n*>(orow + (int64_t)x0 * 4));
+                                else      __builtin_nontemporal_store(p0, reinterpret_cast<u32*>(orow + (int64_t)x0 * 4)); }
+                } else if constexpr (OC == 3) {
+                    const u32 left1 = (u32)__builtin_amdgcn_update_dpp(0, (int)p1, 0x111, 0xF, 0xF, false);           // row_shr:1 -- the left lane's second pixel
+                    if (whole) {
+                        if (mine) {
+                            if (!odd) __builtin_nontemporal_store((u32x1a)__builtin_amdgcn_perm(p1, p0, 0x04020100u), reinterpret_cast<u32x1a*>(orow + (int64_t)gx * 3));
+                            else      __builtin_nontemporal_store(u32x2a{ __builtin_amdgcn_perm(p0, left1, 0x05040201u), __builtin_amdgcn_perm(p1, p0, 0x06050402u) },
+                                                                  reinterpret_cast<u32x2a*>(orow + (int64_t)gx * 3 + 4));
+                        }
+                    } else if (mine) {
+                        uint8_t* q = orow + (int64_t)x0 * 3; q[0] = (uint8_t)p0; q[1] = (uint8_t)(p0 >> 8); q[2] = (uint8_t)(p0 >> 16);
+                        if (both) { q[3] = (uint8_t)p1; q[4] = (uint8_t)(p1 >> 8); q[5] = (uint8_t)(p1 >> 16); }
+                    }
+                } else {
+                    u32 g = rgb_to_luma(p0) | (rgb_to_luma(p1) << 8);
+                    g |= (u32)__builtin_amdgcn_update_dpp(0, (int)g, 0x101, 0xF, 0xF, false) << 16;                 // + the right lane's two
+                    if (whole) { if (mine && !odd) __builtin_nontemporal_store((u32x1a)g, reinterpret_cast<u32x1a*>(orow + gx)); }
+                    else if (mine) { orow[x0] = (uint8_t)g; if (both) orow[x0 + 1] = (uint8_t)(g >> 8); }
+                }
             }
         }
     }
@@ -859,7 +983,8 @@ int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
         const bool tuned = apitch > 0 && apitch < (1 << 27) &&
                            (out_comps != 4 || (((uintptr_t)out & 3) == 0 && (apitch & 3) == 0 && (out_stride & 3) == 0));
         if (tuned && out_pitch < 0 && scan_type == GAMUT_JPGD_YH2V2) { c.flip = 1; c.out_pitch = apitch; c.out += (int64_t)(height - 1) * out_pitch; }
-        static const bool cols_tuned = !(getenv("GAMUT_HIP_JPEG_COLS") && !strcmp(getenv("GAMUT_HIP_JPEG_COLS"), "plain"));      // A/B: k_jpeg_plain for grey and 4:4:4
+        const char* const cols_env = getenv("GAMUT_HIP_JPEG_COLS");                                 // A/B and tests: "plain" = k_jpeg_plain (rounds 1-3) for every mode but 4:2:0
+        const bool cols_tuned = !(cols_env && !strcmp(cols_env, "plain"));
         const int ps = plain_strips(scan_type);
         const int pm = plain_mcus(scan_type, out_comps);
         const dim3 grid32(((a.mcus_per_row + 31) / 32 + ps - 1) / ps, a.mcus_per_col, n);           // grey: 32 MCUs per strip
@@ -889,6 +1014,16 @@ int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
 #undef GAMUT_JPEG_COLS
         }
         else if (scan_type == GAMUT_JPGD_YH1V1)       GAMUT_JPEG_PLAIN(GAMUT_JPGD_YH1V1, grid_plain);
+        else if ((scan_type == GAMUT_JPGD_YH2V1 || scan_type == GAMUT_JPGD_YH1V2) && cols_tuned) {
+            const int waste32 = (32 - a.mcus_per_row % 32) % 32, waste24 = (24 - a.mcus_per_row % 24) % 24;
+            const bool m24 = waste24 * 32 < waste32 * 24;
+            const dim3 g(((a.mcus_per_row + (m24 ? 23 : 31)) / (m24 ? 24 : 32) + 1) / 2, a.mcus_per_col, n);
+#define GAMUT_JPEG_COLS4(ST, OC) do { if (m24) hipLaunchKernelGGL((k_jpeg_cols4<ST, OC, 24>), g, dim3(192), 0, stream, c); \
+                                      else     hipLaunchKernelGGL((k_jpeg_cols4<ST, OC, 32>), g, dim3(256), 0, stream, c); } while (0)
+            if (scan_type == GAMUT_JPGD_YH2V1) { if (out_comps == 4) GAMUT_JPEG_COLS4(GAMUT_JPGD_YH2V1, 4); else if (out_comps == 3) GAMUT_JPEG_COLS4(GAMUT_JPGD_YH2V1, 3); else GAMUT_JPEG_COLS4(GAMUT_JPGD_YH2V1, 1); }
+            else                               { if (out_comps == 4) GAMUT_JPEG_COLS4(GAMUT_JPGD_YH1V2, 4); else if (out_comps == 3) GAMUT_JPEG_COLS4(GAMUT_JPGD_YH1V2, 3); else GAMUT_JPEG_COLS4(GAMUT_JPGD_YH1V2, 1); }
+#undef GAMUT_JPEG_COLS4
+        }
         else if (scan_type == GAMUT_JPGD_YH2V1)       GAMUT_JPEG_PLAIN(GAMUT_JPGD_YH2V1, grid_plain);
         else if (scan_type == GAMUT_JPGD_YH1V2)       GAMUT_JPEG_PLAIN(GAMUT_JPGD_YH1V2, grid_plain);
         else if (out_comps == 4) hipLaunchKernelGGL(k_jpeg_h2v2<4>, grid420, dim3(H2V2_THREADS), 0, stream, c);

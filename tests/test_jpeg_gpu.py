@@ -119,12 +119,28 @@ def test_reference_derived_vectors(hip):
     assert np.array_equal(got.reshape(8, n, 8).transpose(1, 0, 2).reshape(n, 64), V["idct"])
 
 
+@pytest.fixture(params=["cols", "plain"])
+def plain_kernels(request):
+    """which kernels reconstruct every sampling mode but 4:2:0: k_jpeg_cols / k_jpeg_cols4 (a thread per pixel column keeps its samples in registers,
+    round 4) or k_jpeg_plain (samples through an LDS byte buffer, rounds 1-3; GAMUT_HIP_JPEG_COLS=plain)"""
+    old = os.environ.get("GAMUT_HIP_JPEG_COLS")
+    os.environ["GAMUT_HIP_JPEG_COLS"] = request.param
+    yield request.param
+    if old is None:
+        del os.environ["GAMUT_HIP_JPEG_COLS"]
+    else:
+        os.environ["GAMUT_HIP_JPEG_COLS"] = old
+
+
 @pytest.mark.parametrize("scan_type", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("kind", ["natural", "dense", "wild"])
-def test_random_coefficients(hip, scan_type, kind):
+def test_random_coefficients(hip, scan_type, kind, plain_kernels):
+    if scan_type == 4 and plain_kernels == "plain":
+        pytest.skip("4:2:0 has one kernel")
     rng = np.random.default_rng(100 * scan_type + len(kind))
     mw, mh = MCU[scan_type]
-    for (w, h) in [(1, 1), (17, 9), (130, 33), (16 * 9 + 3, 16 * 2), (257, 65)]:
+    # (256 and 1024 wide: rows of 32 / 64 MCUs take the 32-MCU strips of k_jpeg_cols / k_jpeg_cols4, the other sizes the 24-MCU ones)
+    for (w, h) in [(1, 1), (17, 9), (130, 33), (16 * 9 + 3, 16 * 2), (257, 65), (256, 24), (1024, 9)]:
         nblk = ((w + mw - 1) // mw) * ((h + mh - 1) // mh) * NB[scan_type]
         co = random_coeffs(rng, nblk, kind)
         comps = 1 if scan_type == 0 else 3
@@ -135,7 +151,7 @@ def test_random_coefficients(hip, scan_type, kind):
 
 
 @pytest.mark.parametrize("scan_type", [0, 1, 2, 3, 4])
-def test_sparse_paths_with_max_zag(hip, scan_type):
+def test_sparse_paths_with_max_zag(hip, scan_type, plain_kernels):
     """m_mcu_block_max_zag drives the reference's sparse IDCT variants (jpegload.d:295-376); with full-range int16
     coefficients the Col!(1) shortcut (max_zag <= 2) differs from the dense form by 32-bit wrap-around and must be matched."""
     rng = np.random.default_rng(5 + scan_type)

@@ -407,6 +407,8 @@ __global__ __launch_bounds__(H2V2_THREADS) void k_jpeg_h2v2(JpegArgs a)
                 // pixel and its right neighbour's (one DPP quad shuffle + one byte permute).  l8: four grey bytes make one
                 // dword, gathered with two in-quad OR steps; lane 0 of the quad keeps it.
                 static_assert(OC == 3 || OC == 1, "output components");
+                // (Round 4, again: the quads' dwords straight to memory without the staging, as k_jpeg_cols does where a wave's row is 192+ bytes --
+                // here 3.15 instead of 2.71 ms for rgb8, 2.89 instead of 2.61 ms for l8, 12-19 % more HBM traffic: profiles/r04_h2v2_packed_direct.txt.)
                 constexpr int BPR = 16 * H2V2_MCUS * OC;               // bytes per strip row
                 uint8_t* stage = reinterpret_cast<uint8_t*>(Hs);       // 16 rows x BPR <= 6144 B of the 9216 B H/V area
                 const int j = lx & 3;

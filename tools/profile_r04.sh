@@ -6,6 +6,9 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 bash tools/profile.sh r04_jpeg 64 -- --steps 30 --warmup 10
 bash tools/profile.sh r04_jpeg_photo 64 -- --workload jpeg:photo --steps 30 --warmup 10
+bash tools/profile.sh r04_jpeg_444 64 -- --workload jpeg:4:1 --steps 20 --warmup 5
+bash tools/profile.sh r04_jpeg_422 64 -- --workload jpeg:4:2 --steps 20 --warmup 5
+bash tools/profile.sh r04_jpeg_440 64 -- --workload jpeg:4:3 --steps 20 --warmup 5
 bash tools/profile.sh r04_png_random 64 -- --workload png --steps 10 --warmup 3
 bash tools/profile.sh r04_png 64 -- --workload png:heuristic --steps 10 --warmup 3
 PER_STEP=4 bash tools/profile.sh r04_convert_rgba16_rgbaf32 2 -- --workload convert:rgba16:rgbaf32 --batch 256 --steps 6 --warmup 2
@@ -31,4 +34,8 @@ python tools/files_bench.py > gpurun_out/r04_files_bench.jsonl 2>/dev/null
 GAMUT_HIP_HOST_THREADS=2 python tools/files_bench.py > gpurun_out/r04_files_bench_2threads.jsonl 2>/dev/null
 python tools/e2e_mixed_bench.py --batch 768 > gpurun_out/r04_mixed_e2e.txt 2>&1; python tools/e2e_mixed_bench.py --batch 3072 >> gpurun_out/r04_mixed_e2e.txt 2>&1
 bash tools/pmc_valu.sh > gpurun_out/summary_r04_pmc_valu.txt 2>&1
+# progressive: per scan when it ran, how long, how much of it waiting (GAMUT_HIP_TRACE); the two microbenchmarks behind the round's decisions
+for b in 256 1024 4096; do GAMUT_HIP_TRACE=1 timeout 300 python tools/e2e_bench.py --batch $b --paths c --reps 2 --progressive 2>&1 | grep -v "amdgpu" | tail -12; done > gpurun_out/r04_progressive_final.txt 2>&1
+(hipcc --offload-arch=gfx950 -O2 -Wno-unused-result tools/microbench/chain_latency.hip -o /tmp/cl && timeout 60 /tmp/cl) > gpurun_out/r04_chain_latency.txt 2>&1
+(hipcc --offload-arch=gfx950 -O2 -Wno-unused-result tools/microbench/h2d_streams.hip -o /tmp/h2d && timeout 120 /tmp/h2d) > gpurun_out/r04_h2d_streams.txt 2>&1
 (time python bench.py) > gpurun_out/r04_bench_default.log 2>&1

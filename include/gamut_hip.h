@@ -275,7 +275,8 @@ int gamut_hip_stbi_png_is16_from_callbacks(const gamut_hip_stbi_io_callbacks* cl
  * out_len_dev[i] = bytes written, status_dev[i] = 0 or the reason the stream is corrupt (GAMUT_HIP_INFLATE_E_*); both are
  * device arrays, the call is asynchronous on `stream`.  One 1024-thread workgroup per stream: speculative parallel Huffman
  * decode into a token list, then parallel match resolution tile by tile (gamut_amd/csrc/inflate.hip); the library keeps 256 KiB
- * of HBM scratch per stream of the largest batch seen on a (thread, device, stream).  descs is a host array.  One deviation from zlib, as a
+ * of HBM scratch per RESIDENT workgroup (two per compute unit: 128 MiB on MI355X however many streams a batch has) plus small per-stream
+ * tables, per (thread, device, stream).  descs is a host array.  One deviation from zlib, as a
  * bound on the work a hostile stream can demand: a stream with more than 4096 + src_len / 8 blocks (no encoder comes near:
  * that is a block per 8 compressed bytes) is reported as GAMUT_HIP_INFLATE_E_INPUT. */
 typedef struct gamut_hip_inflate_desc { const uint8_t* src; uint8_t* dst; uint32_t src_len, dst_cap; } gamut_hip_inflate_desc;

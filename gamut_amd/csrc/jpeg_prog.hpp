@@ -160,7 +160,7 @@ struct ProgSync {
             seen = rfl(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             if (seen >= need) { waited += (uint32_t)(wall_clock64() - t0); break; }
             __builtin_amdgcn_s_sleep(8);
-            if (wall_clock64() - t0 > 400000000ull) {           // 4 s of the 100 MHz clock: give up, say so, never hang
+            if (wall_clock64() - t0 > 2000000000ull) {          // 20 s of the 100 MHz clock: give up, say so, never hang
                 if (threadIdx.x == 0) atomicOr(st, 16u);
                 seen = 0xFFFFFFFFu;
                 break;
@@ -226,15 +226,19 @@ __device__ __forceinline__ void prog_scan_body(const ProgItem& it, const ProgIma
         int bpu = 0;
         for (int i = 0; i < ncomp; ++i) bpu += (i == 0 ? hs_[0] * vs_[0] : i == 1 ? hs_[1] * vs_[1] : hs_[2] * vs_[2]);
         if (ncomp == 1) bpu = 1;
-        const int total = n_units * bpu;
-        wait_units(n_units);                                    // the DC first scan of these units
-        for (int t = lane; t < total; t += kProgThreads) {
-            const int u = t / bpu, b = t - u * bpu;
-            const uint32_t byte = (uint32_t)t >> 3;
-            const uint32_t v = byte < seg_bytes ? seg[byte] : 0xFFu;                    // past the data: ones (get_octet :683-696)
-            if ((v >> (7 - (t & 7))) & 1u) {
-                int ci; const int64_t blk = prog_unit_block(im, it, first_unit + u, b, ci);
-                co_store(out + blk * 64, co_load(out + blk * 64) | (1 << al));
+        constexpr int kChunk = 1024;                            // units between two looks at the DC first scan's progress (a wait is bounded in time: it must
+        for (int u0 = 0; u0 < n_units; u0 += kChunk) {           // be for a piece of that scan, not for all of a 16384 x 16384 frame's)
+            const int u1 = min(u0 + kChunk, n_units);
+            if (u0) publish(u0);
+            wait_units(u1);                                     // the DC first scan of these units
+            for (int t = u0 * bpu + lane; t < u1 * bpu; t += kProgThreads) {
+                const int u = t / bpu, b = t - u * bpu;
+                const uint32_t byte = (uint32_t)t >> 3;
+                const uint32_t v = byte < seg_bytes ? seg[byte] : 0xFFu;                // past the data: ones (get_octet :683-696)
+                if ((v >> (7 - (t & 7))) & 1u) {
+                    int ci; const int64_t blk = prog_unit_block(im, it, first_unit + u, b, ci);
+                    co_store(out + blk * 64, co_load(out + blk * 64) | (1 << al));
+                }
             }
         }
         return;

@@ -27,14 +27,14 @@ template <int KIND> __global__ void k(uint32_t* out, int iters, uint32_t seed)
 }
 template <int KIND> void run(const char* name, int per, int waves_per_simd)
 {
-    uint32_t* d; hipMalloc(&d, 1 << 20);
+    uint32_t* d; (void)hipMalloc(&d, 1 << 20);
     const int iters = 2000;
     const int blocks = 256 * 4 * waves_per_simd;
     hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(64), 0, 0, d, 10, 3u);
     hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(64), 0, 0, d, iters, 3u);
-    uint32_t h[4]; hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
+    uint32_t h[4]; (void)hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
     setvbuf(stdout, nullptr, _IOLBF, 0); printf("%-52s %d wave(s)/SIMD: %7.2f shader clocks per step\n", name, waves_per_simd, (double)h[0] / ((double)iters * 64 * 1) * 1.0 / 1.0 / (per ? 1 : 1));
-    hipFree(d);
+    (void)hipFree(d);
 }
 int main()
 {

@@ -36,6 +36,6 @@ python tools/e2e_mixed_bench.py --batch 768 > gpurun_out/r04_mixed_e2e.txt 2>&1;
 bash tools/pmc_valu.sh > gpurun_out/summary_r04_pmc_valu.txt 2>&1
 # progressive: per scan when it ran, how long, how much of it waiting (GAMUT_HIP_TRACE); the two microbenchmarks behind the round's decisions
 for b in 256 1024 4096; do GAMUT_HIP_TRACE=1 timeout 300 python tools/e2e_bench.py --batch $b --paths c --reps 2 --progressive 2>&1 | grep -v "amdgpu" | tail -12; done > gpurun_out/r04_progressive_final.txt 2>&1
-(hipcc --offload-arch=gfx950 -O2 -Wno-unused-result tools/microbench/chain_latency.hip -o /tmp/cl && timeout 60 /tmp/cl) > gpurun_out/r04_chain_latency.txt 2>&1
-(hipcc --offload-arch=gfx950 -O2 -Wno-unused-result tools/microbench/h2d_streams.hip -o /tmp/h2d && timeout 120 /tmp/h2d) > gpurun_out/r04_h2d_streams.txt 2>&1
+(hipcc --offload-arch=gfx950 -O2 tools/microbench/chain_latency.hip -o /tmp/cl 2>/dev/null && timeout 60 /tmp/cl) > gpurun_out/r04_chain_latency.txt 2>&1
+(hipcc --offload-arch=gfx950 -O2 tools/microbench/h2d_streams.hip -o /tmp/h2d 2>/dev/null && timeout 120 /tmp/h2d) > gpurun_out/r04_h2d_streams.txt 2>&1
 (time python bench.py) > gpurun_out/r04_bench_default.log 2>&1

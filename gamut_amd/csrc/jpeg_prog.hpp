@@ -352,6 +352,9 @@ __device__ __forceinline__ void prog_scan_body(const ProgItem& it, const ProgIma
 // The correction bits themselves are not on that chain: every lane with history notes the BIT POSITION of its correction bit (the
 // position behind the symbol + its rank among the lanes with history, known per block), fetches that one byte of the stream when
 // the block is done, and the update + store of a block happens while the next block is being walked.
+#ifndef PROG_WALK_ASM
+#define PROG_WALK_ASM 1
+#endif
 #ifdef GAMUT_PROG_PROFILE
 #define PROG_T(var) const uint64_t var = __builtin_amdgcn_s_memtime()
 #define PROG_ACC(dst, a, b) dst += (uint32_t)((b) - (a))
@@ -438,7 +441,8 @@ __device__ __forceinline__ uint32_t prog_ac_refine(ProgSync sy, AcRefineArgs a, 
                 const uint64_t zeros = ~nz & band;
                 const int rk = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(nz >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nz, 0u));      // lanes with history below this one
                 const bool has_hist = (nz >> lane) & 1ull;
-                int nc = 0;                                     // lanes with history already passed
+                const uint64_t hist_mask = __ballot(has_hist);   // (= nz: as an exec-style mask for the walk's own instructions)
+                uint32_t nc = 0;                                 // lanes with history already passed
                 uint64_t nzr = nz;                              // ... and those still ahead
                 int k = ss;
                 PROG_T(t_b);
@@ -447,53 +451,95 @@ __device__ __forceinline__ uint32_t prog_ac_refine(ProgSync sy, AcRefineArgs a, 
                     const int Z = __popcll(zeros);
                     const int dest = ((zeros >> lane) & 1ull) ? zr : 63 - (lane - zr);
                     const int pz = __builtin_amdgcn_ds_permute(dest << 2, lane);                 // lane r: the r-th position without history
-                    int zc = 0;                                 // positions without history already passed
-                    if (k <= se) for (;;) {                      // (the ways out are jumps, not flags tested behind the loop: ~13 of 60 instructions per symbol)
-#ifdef GAMUT_PROG_PROFILE
+                    uint32_t zc = 0;                            // positions without history already passed
+                    int way_out = 0;                             // 1: an EOBn code ended the block's walk, 2: not a code of a refinement scan
+                    if (k <= se) do {                            // ONE way out of the loop (the condition at its foot): with breaks and jumps the compiler builds a
+#ifdef GAMUT_PROG_PROFILE                                         // state machine of flags around every iteration, ~13 of 60 instructions per symbol
                         ++pf_syms;
 #endif
                         const uint64_t w = bits_at(pos);
                         uint32_t ent = (uint32_t)__builtin_amdgcn_readlane((int)t6, (int)(w >> 58));
                         if (__builtin_expect((ent & 3u) != 1u, 0)) {
-                            if (ent == 0) { int len; const int sym = ac.decode(w, len); if (sym < 0) goto bad_code; ent = pack(sym, len); }
-                            if ((ent & 3u) == 3u) goto bad_code;
+                            if (ent == 0) { int len; const int sym = ac.decode(w, len); ent = sym < 0 ? 3u : pack(sym, len); }
+                            if ((ent & 3u) == 3u) { way_out = 2; k = 1 << 20; continue; }
                             if ((ent & 3u) == 2u) {              // EOBn: this block's band ends here, and that of the next eobrun - 1 blocks
                                 const int len = (int)(ent >> 20), run = (int)((ent >> 12) & 15u);
                                 eobrun = (1 << run) + (run ? (int)((w << len) >> (64 - run)) : 0);
                                 pos += (ent >> 4) & 0xFFu;
-                                break;
+                                way_out = 1; k = 1 << 20; continue;
                             }
                         }
+#if PROG_WALK_ASM
+                        {   // The step of a coefficient / ZRL symbol, written out: what the compiler makes of the C++ below is these instructions plus
+                            // ~13 that materialise and test flags.  On from k over `run` positions without history to the one that ends the run (stop =
+                            // lane R of pz, or se + 1 past the last of them); what has history on the way (corr) is corrected: those lanes note where
+                            // their bit is (behind the symbol, in position order); a new coefficient's lane notes its sign bit (P - 1).
+                            uint32_t stop, t0, t1, t2, t3; uint64_t m, corr; uint32_t v0, v1;
+                            asm volatile(
+                                "s_bfe_u32 %[t0], %[ent], 0x4000c\n"            // run
+                                "s_bfe_u32 %[t1], %[ent], 0x80004\n"            // bits used
+                                "s_add_u32 %[t0], %[zc], %[t0]\n"              // R = zc + run
+                                "s_add_u32 %[zc], %[t0], 1\n"
+                                "s_and_b32 %[t2], %[t0], 63\n"
+                                "v_readlane_b32 %[stop], %[pz], %[t2]\n"
+                                "s_add_u32 %[t1], %[pos], %[t1]\n"             // P = pos + used
+                                "s_cmp_lt_u32 %[t0], %[Z]\n"                   // inside?
+                                "s_cselect_b32 %[stop], %[stop], %[se1]\n"
+                                "s_lshl_b64 %[m], -1, %[stop]\n"               // positions from stop on (stop <= 63 when inside)
+                                "s_cselect_b64 %[m], %[m], 0\n"                // outside: everything that is left is below
+                                "s_andn2_b64 %[corr], %[nzr], %[m]\n"
+                                "s_and_b64 %[nzr], %[nzr], %[m]\n"
+                                "s_bcnt1_i32_b64 %[t2], %[corr]\n"             // c
+                                "v_subrev_u32 %[v0], %[nc], %[rk]\n"           // t = rk - nc
+                                "v_cmp_gt_u32 vcc, %[t2], %[v0]\n"             // t < c
+                                "s_add_u32 %[pos], %[t1], %[t2]\n"             // pos = P + c
+                                "s_and_b64 vcc, vcc, %[hist]\n"
+                                "v_add_u32 %[v0], %[t1], %[v0]\n"              // P + t
+                                "s_bitcmp1_b32 %[ent], 16\n"                   // a new coefficient?
+                                "v_cndmask_b32 %[mybit], %[mybit], %[v0], vcc\n"
+                                "s_cselect_b32 %[t3], %[stop], 64\n"
+                                "s_add_u32 %[t1], %[t1], -1\n"                 // P - 1
+                                "v_cmp_eq_u32 vcc, %[t3], %[lane]\n"
+                                "v_mov_b32 %[v1], %[t1]\n"
+                                "s_add_u32 %[nc], %[nc], %[t2]\n"
+                                "v_cndmask_b32 %[mybit], %[mybit], %[v1], vcc\n"
+                                : [stop] "=&s"(stop), [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3), [m] "=&s"(m), [corr] "=&s"(corr), [v0] "=&v"(v0), [v1] "=&v"(v1),
+                                  [zc] "+s"(zc), [pos] "+s"(pos), [nzr] "+s"(nzr), [nc] "+s"(nc), [mybit] "+v"(mybit)
+                                : [ent] "s"(ent), [pz] "v"(pz), [Z] "s"(Z), [se1] "s"(se + 1), [rk] "v"(rk), [hist] "s"(hist_mask), [lane] "v"(lane)
+                                : "scc", "vcc");
+                            k = (int)stop + 1;
+                        }
+#else
                         {
                         const int used = (int)((ent >> 4) & 0xFFu), run = (int)((ent >> 12) & 15u);
                         const bool coefficient = (ent >> 16) & 1u;       // a new coefficient at the stop (its sign follows the code); else ZRL
                         // on from k over `run` positions without history to the one that ends the run; what has history on the way is corrected
-                        const int R = zc + run;
+                        const int R = (int)zc + run;
                         const int stop_r = __builtin_amdgcn_readlane(pz, R & 63);
                         const bool inside = R < Z;
                         const int stop = inside ? stop_r : se + 1;
-                        zc = R + 1;
+                        zc = (uint32_t)R + 1u;
                         const uint64_t below = inside ? (1ull << stop) - 1 : ~0ull;          // stop <= 63 here
                         const uint64_t corr = nzr & below;
                         nzr &= ~below;
                         const int c = __popcll(corr);
                         const uint32_t P = pos + (uint32_t)used;                             // the correction bits follow the symbol, in position order
-                        const uint32_t t = (uint32_t)(rk - nc);
+                        const uint32_t t = (uint32_t)rk - nc;
                         if (has_hist && t < (uint32_t)c) mybit = P + t;
                         if (lane == (coefficient ? stop : 64)) mybit = P - 1u;               // stop <= 64: no lane if the walk ran off the block
-                        nc += c;
+                        nc += (uint32_t)c;
                         pos = P + (uint32_t)c;
                         k = stop + 1;
                         }
-                        if (k > se) break;
-                    }
+#endif
+                    } while (k <= se);
+                    if (way_out == 2) { if (lane == 0) atomicOr(st, 1u); finish_pending(); return false; }
                 }
-                if (false) { bad_code: if (lane == 0) atomicOr(st, 1u); finish_pending(); return false; }
                 PROG_T(t_c);
                 eobrun = rfl(eobrun);
                 if (eobrun > 0) {                                // the rest of the block: correction bits only
                     const int c = __popcll(nzr);
-                    const uint32_t t = (uint32_t)(rk - nc);
+                    const uint32_t t = (uint32_t)rk - nc;
                     if (has_hist && t < (uint32_t)c) mybit = pos + t;
                     pos += (uint32_t)c;
                     --eobrun;

@@ -293,17 +293,24 @@ def test_extreme_geometry(hip, launch_mode, img_n, out_n, x, y):
     assert np.array_equal(got, exp)
 
 
-@pytest.fixture(params=["host", "device"])
+@pytest.fixture(params=["host", "device", "device, pitched staging", "device, tight staging"])
 def inflate_mode(request):
-    """the file batch with zlib on host threads, then with the inflate kernel (inflate.hip; batches of >= 32 files choose it
-    themselves, GAMUT_HIP_PNG_INFLATE forces either)"""
-    old = os.environ.get("GAMUT_HIP_PNG_INFLATE")
-    os.environ["GAMUT_HIP_PNG_INFLATE"] = request.param
-    yield request.param
-    if old is None:
-        del os.environ["GAMUT_HIP_PNG_INFLATE"]
-    else:
-        os.environ["GAMUT_HIP_PNG_INFLATE"] = old
+    """where the IDAT streams of the PNG batch call are inflated: zlib on the host threads, or k_inflate on the GPU (inflate.hip: batches of more
+    files than host threads choose it themselves, GAMUT_HIP_PNG_INFLATE forces either) -- and, on the GPU, how the streams' slices go up: every
+    stream `pitch` bytes apart and one hipMemcpy2DAsync per slice round, or a tight image and a copy per (stream, slice) (the call picks by how
+    unequal the streams are; GAMUT_HIP_PNG_PITCHED forces either)"""
+    keys = ("GAMUT_HIP_PNG_INFLATE", "GAMUT_HIP_PNG_PITCHED", "GAMUT_HIP_PNG_SLICE_KB")
+    old = [os.environ.get(k) for k in keys]
+    os.environ["GAMUT_HIP_PNG_INFLATE"] = request.param.split(",")[0]
+    if "staging" in request.param:                               # 64 KiB slices: the larger files of the tests take several rounds
+        os.environ["GAMUT_HIP_PNG_PITCHED"] = "1" if "pitched" in request.param else "0"
+        os.environ["GAMUT_HIP_PNG_SLICE_KB"] = "64"
+    yield request.param.split(",")[0]
+    for k, v in zip(keys, old):
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
 
 
 def test_png_file_batch_feeder(hip, inflate_mode):

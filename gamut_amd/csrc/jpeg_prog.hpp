@@ -414,12 +414,13 @@ __device__ __forceinline__ uint32_t prog_ac_refine(ProgSync sy, AcRefineArgs a, 
         };
         // the block whose bits are on their way
         int16_t* pend_ptr = out; int pend_orig = 0; uint32_t pend_byte = 0, pend_bit = 0xFFFFFFFFu;
-        auto finish_pending = [&]() {
-            if (pend_bit == 0xFFFFFFFFu) return;
+        auto finish_pending = [&]() {                            // (selects, one branch for the store: per block, but on the chain all the same)
+            const bool have = pend_bit != 0xFFFFFFFFu;
             const bool one = (pend_byte >> (7u - (pend_bit & 7u))) & 1u;
-            int coef = pend_orig;
-            if (coef == 0) coef = one ? plus : minus;                                            // a new coefficient: its sign
-            else if (one && (coef & plus) == 0) coef = (int16_t)(coef + (coef >= 0 ? plus : minus));   // history: one more bit of magnitude
+            const int step = pend_orig >= 0 ? plus : minus;
+            const int grown = (one && (pend_orig & plus) == 0) ? (int)(int16_t)(pend_orig + step) : pend_orig;   // history: one more bit of magnitude
+            int coef = pend_orig == 0 ? (one ? plus : minus) : grown;                                            // a new coefficient: its sign
+            coef = have ? coef : pend_orig;
             if (coef != pend_orig) co_store(pend_ptr + nat, coef);
         };
         bool ended = false;

@@ -764,11 +764,16 @@ struct TokCtx {
 // is the previous pass word for word -- the lane stops there and keeps the old exit state and the old totals behind the
 // checkpoint.  Without this every re-decode ran its whole sub-sequence again (3.2 full counting passes per file on average; now
 // one and a fraction).  kSubCk checkpoints per lane live in the write sweep's block staging area (not in use before that sweep).
-constexpr int kSubCk = 6;
-struct SubCk { uint32_t pos; uint16_t cz, nblk, ntok, pad; int dcs[3]; };        // cz = c | z << 4; nblk / ntok modulo 2^16 (only differences are used)
-static_assert(sizeof(SubCk) == 24, "checkpoint size");
+// 16 bytes each: the DC sums modulo 2^16 as well -- only differences between two passes are used, and only the low 16 bits of a DC value reach its
+// coefficient (an int16 product).  A lane's checkpoints share its piece of the staging area with the write sweep's block (dense hand-off: 144
+// bytes, 9 checkpoints) or token buffer (compact hand-off: 64 bytes; the area is 80 bytes then, 5 checkpoints -- 29 KB of LDS per workgroup
+// instead of 45, five workgroups per compute unit instead of three: the kernel is chains of dependent operations, what it lacks is waves).
+constexpr int kSubCkMax = 9;
+struct SubCk { uint32_t pos; uint16_t cz, nblk, ntok; int16_t dcs[3]; };         // cz = c | z << 4; nblk / ntok modulo 2^16 (only differences are used)
+static_assert(sizeof(SubCk) == 16, "checkpoint size");
 struct SubTrace {
-    SubCk* ck;                      // this lane's kSubCk checkpoints (LDS), or nullptr
+    SubCk* ck;                      // this lane's checkpoints (LDS), or nullptr
+    int n_ck;                       // how many
     uint32_t first_bit, step_bits;  // checkpoint j stands at bit first_bit + j * step_bits, j = 1 .. kSubCk
     bool compare;                   // a pass after the first: stop at a checkpoint that matches
     int old_nblk, old_dcs[3];       // the previous pass's totals
@@ -865,28 +870,35 @@ __device__ __forceinline__ bool sub_decode(const SubCtx& x, SubState& s, int& nb
         c = done ? (c + 1 == x.nb ? 0 : c + 1) : c;
         if (MODE == SUB_TOKENS && (++steps & 15u) == 0) tk->flush();             // every lane of the wave at once: at most 16 tokens wait
         if (MODE == SUB_COUNT && br.pos >= ck_next) {                            // (never true without a trace)
-            while (ck_j < kSubCk && br.pos >= ck_next) {                         // one symbol may step over several checkpoints (tiny steps)
+            while (ck_j < tr->n_ck && br.pos >= ck_next) {                         // one symbol may step over several checkpoints (tiny steps)
                 SubCk& k = tr->ck[ck_j];
                 const uint16_t cz = (uint16_t)(c | z << 4);
                 if (tr->compare && k.pos == br.pos && k.cz == cz) {              // in step with the previous pass from here on
                     // what this pass counted up to here instead of the previous one: the later checkpoints and the totals move by it
-                    const int dn = (int16_t)((uint16_t)nblk - k.nblk), dt = (int16_t)((uint16_t)ntok - k.ntok), e0 = dc0 - k.dcs[0], e1 = dc1 - k.dcs[1], e2 = dc2 - k.dcs[2];
-                    for (int jj = ck_j; jj < kSubCk; ++jj) {
+                    const int dn = (int16_t)((uint16_t)nblk - k.nblk), dt = (int16_t)((uint16_t)ntok - k.ntok);
+                    const int e0 = (int16_t)((uint16_t)dc0 - (uint16_t)k.dcs[0]), e1 = (int16_t)((uint16_t)dc1 - (uint16_t)k.dcs[1]), e2 = (int16_t)((uint16_t)dc2 - (uint16_t)k.dcs[2]);
+                    for (int jj = ck_j; jj < tr->n_ck; ++jj) {
                         SubCk& q = tr->ck[jj];
-                        q.nblk = (uint16_t)(q.nblk + dn); q.ntok = (uint16_t)(q.ntok + dt); q.dcs[0] += e0; q.dcs[1] += e1; q.dcs[2] += e2;
+                        q.nblk = (uint16_t)(q.nblk + dn); q.ntok = (uint16_t)(q.ntok + dt);
+                        q.dcs[0] = (int16_t)(q.dcs[0] + e0); q.dcs[1] = (int16_t)(q.dcs[1] + e1); q.dcs[2] = (int16_t)(q.dcs[2] + e2);
                     }
                     nblk = tr->old_nblk + dn; ntok = tr->old_ntok + dt; dc0 = tr->old_dcs[0] + e0; dc1 = tr->old_dcs[1] + e1; dc2 = tr->old_dcs[2] + e2;
                     tr->stopped = true;
                     break;
                 }
-                k.pos = br.pos; k.cz = cz; k.nblk = (uint16_t)nblk; k.ntok = (uint16_t)ntok; k.dcs[0] = dc0; k.dcs[1] = dc1; k.dcs[2] = dc2;
+                k.pos = br.pos; k.cz = cz; k.nblk = (uint16_t)nblk; k.ntok = (uint16_t)ntok; k.dcs[0] = (int16_t)dc0; k.dcs[1] = (int16_t)dc1; k.dcs[2] = (int16_t)dc2;
                 ++ck_j; ck_next += tr->step_bits;
             }
             if (tr->stopped) break;
-            if (ck_j == kSubCk) ck_next = 0xFFFFFFFFu;
+            if (ck_j == tr->n_ck) ck_next = 0xFFFFFFFFu;
         }
     }
     if (MODE == SUB_COUNT && tr) tr->ntok = ntok;
+    // A pass that ran to its end leaves no checkpoint of an EARLIER pass standing: one that lies in the few bits a pass may overshoot its
+    // sub-sequence by is reached by some passes and not by others, and a later pass that matched it would add its difference to the totals
+    // of the pass before it -- which never stood there.  (Found in round 4 with nine checkpoints per lane, i.e. closer ones: the last block of
+    // a restart segment lost; six had passed every test and 1 000 fuzzed files.)
+    if (MODE == SUB_COUNT && tr && !tr->stopped) for (int jj = ck_j; jj < tr->n_ck; ++jj) tr->ck[jj].pos = 0xFFFFFFFFu;
     if (MODE == SUB_COUNT && tr && tr->stopped) { dcs[0] = dc0; dcs[1] = dc1; dcs[2] = dc2; return ok; }      // s: untouched, the caller keeps the previous exit state
     if (MODE == SUB_TOKENS) tk->flush();
     if (MODE == SUB_WRITE && z > 0 && !inherited && b < b_end) {                 // a block of this lane's that the next lanes finish: its line, as far as it goes
@@ -920,7 +932,7 @@ template <int NH, bool TOK = false>
 __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevItem* items, const DevImage* images,
                                                                     const DevHuff* huff_g, int n_huff, const int16_t* quant_g, int n_quant,
                                                                     const uint8_t* blob, int16_t* coeffs, uint8_t* max_zag, uint32_t* status,
-                                                                    uint32_t* tokens = nullptr, uint32_t* strip_tab = nullptr)
+                                                                    uint32_t* tokens = nullptr, uint32_t* strip_tab = nullptr, int n_ck_arg = 0)
 {
     constexpr bool IN_LDS = NH > 0;
     __shared__ DevHuff sh_huff[IN_LDS ? NH : 1];
@@ -928,17 +940,19 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevIte
     __shared__ uint8_t sh_zag[64];
     __shared__ SubState exit_state[kSyncThreads];
     __shared__ int changed, failed, par[9];
-    __shared__ __attribute__((aligned(16))) uint8_t sh_blk[kSyncThreads * 144];             // the write sweep: a block per lane (144-byte pitch)
+    constexpr int kPitch = TOK ? 80 : 144, kSubCkDefault = TOK ? 5 : 6;                     // a lane's piece of the staging area; its checkpoints (up to kPitch / 16:
+    const int kSubCk = n_ck_arg > 0 && n_ck_arg <= kPitch / (int)sizeof(SubCk) ? n_ck_arg : kSubCkDefault;    // GAMUT_HIP_JPEG_CHECKPOINTS, tests)             // a lane's piece of the staging area; its checkpoints
+    __shared__ __attribute__((aligned(16))) uint8_t sh_blk[kSyncThreads * kPitch];          // the write sweep: a block per lane (144-byte pitch) / 16 tokens
     // blocks finished, DC-difference sums of the three components, tokens: prefix-summed between the counting passes and the write sweep,
     // in the staging area (whose checkpoints are done with by then, and which is cleared afterwards)
     int (*scan)[kSyncThreads] = reinterpret_cast<int (*)[kSyncThreads]>(sh_blk);
-    static_assert(5 * kSyncThreads * sizeof(int) <= kSyncThreads * 144, "the scan borrows the staging area");
+    static_assert(5 * kSyncThreads * sizeof(int) <= kSyncThreads * kPitch && kPitch / (int)sizeof(SubCk) <= kSubCkMax && kPitch % 16 == 0 && kPitch >= 64, "the scan, the checkpoints and 16 tokens borrow the staging area");
     load_tables<IN_LDS, kSyncThreads>(sh_huff, sh_quant, sh_zag, huff_g, n_huff, quant_g, n_quant);
     const int t = threadIdx.x;
     {
-        uint4* zb = reinterpret_cast<uint4*>(sh_blk + t * 144);
+        uint4* zb = reinterpret_cast<uint4*>(sh_blk + t * kPitch);
         #pragma unroll
-        for (int i = 0; i < 8; ++i) zb[i] = make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < kPitch / 16; ++i) zb[i] = make_uint4(0, 0, 0, 0);
     }
     SPROF_DECL;
     const DevItem it = items[blockIdx.x];
@@ -963,11 +977,9 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevIte
     SubState entry{ (uint32_t)t * sub * 8u, 0, 0 }, mine = entry;
     int nblk = 0, dcs[3] = { 0, 0, 0 }, ntok = 0;
     SubTrace tr;
-    tr.ck = reinterpret_cast<SubCk*>(sh_blk + t * 144); tr.first_bit = (uint32_t)t * sub * 8u; tr.step_bits = ((sub + kSubCk) / (kSubCk + 1)) * 8u;
+    tr.ck = reinterpret_cast<SubCk*>(sh_blk + t * kPitch); tr.n_ck = kSubCk; tr.first_bit = (uint32_t)t * sub * 8u; tr.step_bits = ((sub + (uint32_t)kSubCk) / (uint32_t)(kSubCk + 1)) * 8u;
     tr.compare = false; tr.old_nblk = 0; tr.old_dcs[0] = tr.old_dcs[1] = tr.old_dcs[2] = 0; tr.old_ntok = 0; tr.ntok = 0; tr.stopped = false;
-    static_assert(kSubCk * sizeof(SubCk) <= 144, "the checkpoints borrow the lane's block staging area");
     if (active) {
-        #pragma unroll
         for (int j = 0; j < kSubCk; ++j) tr.ck[j].pos = 0xFFFFFFFFu;             // (a pass that ends early leaves the later ones unset: never a match)
         sub_decode<SUB_COUNT>(x, mine, nblk, dcs, 0, 0, nullptr, nullptr, nullptr, &tr);
         ntok = tr.ntok;
@@ -1017,9 +1029,9 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevIte
     __syncthreads();                                            // everybody has its prefix sums: the area is the staging area again
     SPROF(2);
     {                                                           // the checkpoints are done with: the staging area starts out zero
-        uint4* zb = reinterpret_cast<uint4*>(sh_blk + t * 144);
+        uint4* zb = reinterpret_cast<uint4*>(sh_blk + t * kPitch);
         #pragma unroll
-        for (int i = 0; i < 9; ++i) zb[i] = make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < kPitch / 16; ++i) zb[i] = make_uint4(0, 0, 0, 0);
     }
     if constexpr (TOK) {
         // the compact hand-off: tokens instead of blocks (sub_decode<SUB_TOKENS>).  A stream that would emit more tokens than the image's
@@ -1031,7 +1043,7 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevIte
             int pred[3] = { pred_in[0], pred_in[1], pred_in[2] };
             SubState s = entry; int n2 = 0;
             TokCtx tk;
-            tk.out = tokens + im.tok_off + tok0; tk.lds = reinterpret_cast<uint32_t*>(sh_blk + t * 144); tk.strip_start = strip_start;
+            tk.out = tokens + im.tok_off + tok0; tk.lds = reinterpret_cast<uint32_t*>(sh_blk + t * kPitch); tk.strip_start = strip_start;
             tk.base = tok0; tk.total = (uint32_t)ntok; tk.emitted = 0; tk.nl = 0;
             tk.SB = im.sb; tk.row_blocks = im.row_blocks; tk.n_strips = (uint32_t)im.n_strips;
             const int64_t gb = (int64_t)it.first_mcu * im.nb + b0;               // the lane's first block, in the image
@@ -1062,7 +1074,7 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevIte
     if (active) {
         int pred[3] = { pred_in[0], pred_in[1], pred_in[2] };
         SubState s = entry; int n2 = 0;
-        if (!sub_decode<SUB_WRITE>(x, s, n2, pred, b0, total_blocks, out, mz, reinterpret_cast<int16_t*>(sh_blk + t * 144))) failed = 1;
+        if (!sub_decode<SUB_WRITE>(x, s, n2, pred, b0, total_blocks, out, mz, reinterpret_cast<int16_t*>(sh_blk + t * kPitch))) failed = 1;
         if (t == nsub - 1 && b0 + n2 != total_blocks) failed = 1;                 // the segment ended before its last block did
     }
     __threadfence();                                            // the lines are on their way before anybody adds single coefficients to them
@@ -1636,15 +1648,17 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
                 if (int rc = launch_status("jpeg_unstuff")) return rc;
             }
             static const int force_nh = [] { const char* e = getenv("GAMUT_HIP_JPEG_TABLES_LDS"); return e && *e ? atoi(e) : -1; }();     // measurements: 0 / 4 / 8
+            const char* const ck_env = getenv("GAMUT_HIP_JPEG_CHECKPOINTS");                       // tests: checkpoints per lane of the counting passes (0 = the kernel's own)
+            const int n_checkpoints = ck_env ? atoi(ck_env) : 0;
             const int nh_sel = force_nh == 0 ? 0 : (n_huff <= 4 && n_quant <= 4 && force_nh != 8) ? 4 : in_lds ? kLdsHuff : 0;
             if (n_tok) {                                       // long segments of the images that hand over tokens
-#define GAMUT_SYNC_TOK(NH) hipLaunchKernelGGL((k_jpeg_entropy_sync<NH, true>), dim3(n_tok), dim3(kSyncThreads), 0, gs, d_items, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st, d_tokens, d_strip_tab)
+#define GAMUT_SYNC_TOK(NH) hipLaunchKernelGGL((k_jpeg_entropy_sync<NH, true>), dim3(n_tok), dim3(kSyncThreads), 0, gs, d_items, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st, d_tokens, d_strip_tab, n_checkpoints)
                 if (nh_sel == 4) GAMUT_SYNC_TOK(4); else if (nh_sel == kLdsHuff) GAMUT_SYNC_TOK(kLdsHuff); else GAMUT_SYNC_TOK(0);
 #undef GAMUT_SYNC_TOK
                 if (int rc = launch_status("jpeg_entropy_sync (tokens)")) return rc;
             }
             if (n_long > n_tok) {
-#define GAMUT_SYNC_DENSE(NH) hipLaunchKernelGGL((k_jpeg_entropy_sync<NH, false>), dim3(n_long - n_tok), dim3(kSyncThreads), 0, gs, d_items + n_tok, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st, (uint32_t*)nullptr, (uint32_t*)nullptr)
+#define GAMUT_SYNC_DENSE(NH) hipLaunchKernelGGL((k_jpeg_entropy_sync<NH, false>), dim3(n_long - n_tok), dim3(kSyncThreads), 0, gs, d_items + n_tok, d_img, d_huff, n_huff, d_quant, n_quant, d_blob, d_coeffs, d_max_zag, st, (uint32_t*)nullptr, (uint32_t*)nullptr, n_checkpoints)
                 if (nh_sel == 4) GAMUT_SYNC_DENSE(4); else if (nh_sel == kLdsHuff) GAMUT_SYNC_DENSE(kLdsHuff); else GAMUT_SYNC_DENSE(0);
 #undef GAMUT_SYNC_DENSE
                 if (int rc = launch_status("jpeg_entropy_sync")) return rc;

@@ -416,10 +416,11 @@ __device__ __forceinline__ uint32_t prog_ac_refine(ProgSync sy, AcRefineArgs a, 
         int16_t* pend_ptr = out; int pend_orig = 0; uint32_t pend_byte = 0, pend_bit = 0xFFFFFFFFu;
         auto finish_pending = [&]() {                            // (selects, one branch for the store: per block, but on the chain all the same)
             const bool have = pend_bit != 0xFFFFFFFFu;
-            const bool one = (pend_byte >> (7u - (pend_bit & 7u))) & 1u;
+            const bool fresh = have && (pend_bit >> 31);         // the lane a symbol's run ended at: it is SET (decode_block_ac_refine :3485-3488 assigns p[k] for any k < 64 --
+            const bool one = (pend_byte >> (7u - (pend_bit & 7u))) & 1u;      // behind the band too, where a damaged stream's run can end on a coefficient of another scan)
             const int step = pend_orig >= 0 ? plus : minus;
             const int grown = (one && (pend_orig & plus) == 0) ? (int)(int16_t)(pend_orig + step) : pend_orig;   // history: one more bit of magnitude
-            int coef = pend_orig == 0 ? (one ? plus : minus) : grown;                                            // a new coefficient: its sign
+            int coef = fresh ? (one ? plus : minus) : grown;                                                     // a new coefficient: its sign
             coef = have ? coef : pend_orig;
             if (coef != pend_orig) co_store(pend_ptr + nat, coef);
         };
@@ -500,6 +501,7 @@ __device__ __forceinline__ uint32_t prog_ac_refine(ProgSync sy, AcRefineArgs a, 
                                 "v_cndmask_b32 %[mybit], %[mybit], %[v0], vcc\n"
                                 "s_cselect_b32 %[t3], %[stop], 64\n"
                                 "s_add_u32 %[t1], %[t1], -1\n"                 // P - 1
+                                "s_bitset1_b32 %[t1], 31\n"                    // ... of a NEW coefficient (whatever stood there: the stop may lie behind the band)
                                 "v_cmp_eq_u32 vcc, %[t3], %[lane]\n"
                                 "v_mov_b32 %[v1], %[t1]\n"
                                 "s_add_u32 %[nc], %[nc], %[t2]\n"
@@ -527,7 +529,7 @@ __device__ __forceinline__ uint32_t prog_ac_refine(ProgSync sy, AcRefineArgs a, 
                         const uint32_t P = pos + (uint32_t)used;                             // the correction bits follow the symbol, in position order
                         const uint32_t t = (uint32_t)rk - nc;
                         if (has_hist && t < (uint32_t)c) mybit = P + t;
-                        if (lane == (coefficient ? stop : 64)) mybit = P - 1u;               // stop <= 64: no lane if the walk ran off the block
+                        if (lane == (coefficient ? stop : 64)) mybit = (P - 1u) | 0x80000000u;  // stop <= 64: no lane if the walk ran off the block; bit 31: a NEW coefficient
                         nc += (uint32_t)c;
                         pos = P + (uint32_t)c;
                         k = stop + 1;
@@ -548,7 +550,7 @@ __device__ __forceinline__ uint32_t prog_ac_refine(ProgSync sy, AcRefineArgs a, 
                 // the block before this one: its correction bits have arrived; this block's are sent for
                 finish_pending();
                 pend_ptr = cur; pend_orig = orig; pend_bit = mybit; pend_byte = 0;
-                if (mybit != 0xFFFFFFFFu) pend_byte = seg[mybit >> 3];
+                if (mybit != 0xFFFFFFFFu) pend_byte = seg[(mybit & 0x7FFFFFFFu) >> 3];
                 if (pos > limit_bit) { if (lane == 0) atomicOr(st, 4u); finish_pending(); return false; }
                 PROG_T(t_d);
                 PROG_ACC(pf_setup, t_a, t_b); PROG_ACC(pf_walk, t_b, t_c); PROG_ACC(pf_tail, t_c, t_d);
@@ -635,6 +637,14 @@ inline void to_dev_huff(const HuffTable& h, DevHuff& d)
     memcpy(d.maxcode, h.maxcode, sizeof(d.maxcode)); memcpy(d.delta, h.delta, sizeof(d.delta)); memcpy(d.vals, h.vals, sizeof(d.vals));
 }
 
+// The highest zig-zag position a scan may WRITE: an AC first scan stores a coefficient wherever its runs take it up to 63 (decode_block_ac_first
+// :3361-3380 checks k against 63, not against Se), an AC refinement scan sets the position its run ends at if that is < 64 (:3485-3488), i.e.
+// up to Se + 1.  Well-formed files stay inside [Ss, Se]; a damaged one that does not must still come out as the reference decodes it -- scan
+// after scan -- so the order of two scans of a component is kept wherever their REACH overlaps, not only their bands.  (Round 4, found by the
+// fuzzer: Y 1-5 and Y 6-63, "independent", ran side by side; a run of the damaged first one ended at position 7, and its value landed on
+// top of the second one's.)  The scans follow each other block by block, so the extra order costs next to nothing.
+inline int prog_scan_reach(int kind, int se) { return kind == PROG_AC_FIRST ? 63 : kind == PROG_AC_REFINE ? (se < 63 ? se + 1 : 63) : se; }
+
 struct ProgScanPrep {
     Scan sc; int kind = 0, level = 0, restart_interval = 0, units = 0, nbx = 0, nby = 0;
     int tab[3] = { 0, 0, 0 };            // file-local table indices (scan order)
@@ -710,7 +720,7 @@ void prog_prepare(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& f,
         for (const ProgScanPrep& e : out.scans) {
             bool shares = false;
             for (int a = 0; a < sc.ncomp; ++a) for (int b = 0; b < e.sc.ncomp; ++b) shares = shares || sc.comp[a] == e.sc.comp[b];
-            if (shares && sc.ss <= e.sc.se && e.sc.ss <= sc.se && e.level + 1 > s.level) s.level = e.level + 1;
+            if (shares && sc.ss <= prog_scan_reach(e.kind, e.sc.se) && e.sc.ss <= prog_scan_reach(s.kind, sc.se) && e.level + 1 > s.level) s.level = e.level + 1;
         }
         s.begin = P.pos; s.end = scan_data_end(base, P.pos, n);
         out.scans.push_back(s);
@@ -933,7 +943,8 @@ int progressive_decode_device(const uint8_t* const* data, const size_t* len, con
                 for (auto& r : last) for (int& v : r) v = -1;
                 for (size_t si = 0; si < n_scans; ++si) {
                     const Scan& sc = pp.scans[si].sc;
-                    for (int a = 0; a < sc.ncomp; ++a) for (int z = sc.ss; z <= sc.se && z < 64; ++z) {
+                    const int hi = prog_scan_reach(pp.scans[si].kind, sc.se);
+                    for (int a = 0; a < sc.ncomp; ++a) for (int z = sc.ss; z <= hi; ++z) {
                         const int e = last[sc.comp[a]][z];
                         if (e >= 0 && std::find(scan_deps[si].begin(), scan_deps[si].end(), e) == scan_deps[si].end()) scan_deps[si].push_back(e);
                         last[sc.comp[a]][z] = (int)si;

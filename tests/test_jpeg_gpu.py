@@ -497,6 +497,19 @@ def test_device_progressive_scan_scripts(hip, progressive_mode):
         assert np.array_equal(zz, d.max_zag), k
 
 
+def test_device_progressive_damaged_scan_that_leaves_its_band(hip, progressive_mode):
+    """tests/golden/jpeg_fuzz/prog_refine_mismatch_r04.jpg (found by tools/fuzz_prog_gpu.py in round 4): a damaged `Y 1-5` first scan whose run ends at
+    zig-zag position 7, inside the band of the `Y 6-63` scan behind it.  Both decoders accept the file; the reference decodes scan after scan, so
+    the later scan's value stands.  On the GPU the two scans used to count as independent (disjoint bands) and ran side by side -- the order of
+    two scans is now kept wherever their REACH overlaps (an AC first scan may write up to position 63, a refinement up to Se + 1)."""
+    data = open(os.path.join(HERE, "golden", "jpeg_fuzz", "prog_refine_mismatch_r04.jpg"), "rb").read()
+    d = O.DecodedJpeg(data)
+    rc, hst, st, res = _entropy_decode_device(hip, [data] * 5)
+    assert rc == 0 and hst == [0] * 5 and not st.any()
+    for co, zz, info in res:
+        assert np.array_equal(co, d.coeffs) and np.array_equal(zz, d.max_zag), np.argwhere(co != d.coeffs)[:4].tolist()
+
+
 def test_device_progressive_corrupt_streams(hip):
     """damaged scans of progressive files on the GPU path: no hang, nothing written outside the file's buffers, the damaged
     files flagged (a scan that decodes to the end without an impossible code is not an error for the reference either);

@@ -44,7 +44,9 @@ def main():
                 sos = data.index(b"\xff\xda")
                 for _ in range(int(rng.integers(1, 5))):
                     kind = int(rng.integers(0, 4))
-                    i = int(rng.integers(sos if kind < 3 else 2, len(data) - 1))
+                    if len(data) < 8:
+                        break                                   # (an earlier truncation left nothing to mutate)
+                    i = int(rng.integers(min(sos, len(data) - 2) if kind < 3 else 2, len(data) - 1))
                     if kind == 0:
                         data[i] = int(rng.integers(0, 256))
                     elif kind == 1:
@@ -81,7 +83,14 @@ def main():
             rc = L.gamut_hip_jpeg_decode_coeffs(ptrs[i], lens[i], C.byref(fr))          # the host feeder on the same bytes
             if rc == 0 and st[i] == 0:
                 ref = np.ctypeslib.as_array(fr.coeffs, (nblk[i] * 64,)); refz = np.ctypeslib.as_array(fr.max_zag, (nblk[i],))
-                assert np.array_equal(co[co_off[i]:co_off[i] + nblk[i] * 64], ref) and np.array_equal(zz[off[i]:off[i] + nblk[i]], refz), (b, i)
+                if not (np.array_equal(co[co_off[i]:co_off[i] + nblk[i] * 64], ref) and np.array_equal(zz[off[i]:off[i] + nblk[i]], refz)):
+                    got = co[co_off[i]:co_off[i] + nblk[i] * 64].reshape(-1, 64); want = ref.reshape(-1, 64)
+                    bad = np.argwhere(got != want)
+                    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                    open(os.path.join(ROOT, "gpurun_out", f"fuzz_prog_mismatch_{b}_{i}.jpg"), "wb").write(blobs[i])
+                    raise AssertionError(f"batch {b} file {i} (seed file {(b + i) % len(seeds)}, {len(blobs[i])} bytes, saved): {len(bad)} coefficients differ, first at "
+                                         f"{bad[:4].tolist()}: device {[int(got[x, y]) for x, y in bad[:4]]} host {[int(want[x, y]) for x, y in bad[:4]]}; "
+                                         f"max_zag differs in {int((zz[off[i]:off[i] + nblk[i]] != refz).sum())} blocks")
                 n_same += 1
             else:
                 assert i % 6 != 0, "an intact file was flagged"

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Mutation fuzzing of gamut_hip_png_decode_batch_device on the GPU box: batches of damaged PNG files decoded twice -- inflate on the
 host threads (zlib) and inflate on the GPU (sliced launches behind the upload) -- must agree file by file: same verdict, same pixels,
-same info; and both must come back.  Usage: python tools/fuzz_png_gpu.py [batches=20] [seed=1]"""
+same info; and both must come back -- and with the oracle's stbi_load (stbdec.d) on the same bytes: same verdict, same pixels.  Usage: python tools/fuzz_png_gpu.py [batches=20] [seed=1]"""
 import ctypes as C
 import io
 import os
@@ -13,6 +13,7 @@ from PIL import Image
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import gen  # noqa: E402
+import oracle_lib as O  # noqa: E402
 from gamut_amd import _capi  # noqa: E402
 
 
@@ -89,8 +90,20 @@ def main():
                 w, h = i_h[k]
                 if not np.array_equal(p_h[k][: w * h * 4], p_d[k][: w * h * 4]):
                     bad += 1; print(f"MISMATCH batch {b} file {k}: pixels differ")
-                else: ok += 1
-            else: rejected += 1
+                else:
+                    ok += 1
+                    r = O.stbi_load(files[k], 4, False)                           # ... and against the oracle's stbi_load (8-bit rgba): verdict and pixels
+                    want = None if r is None else np.ascontiguousarray(r[0]).view(np.uint8).reshape(-1)
+                    if want is None:
+                        bad += 1; print(f"MISMATCH batch {b} file {k}: decoded, the oracle rejects it")
+                    elif want.size != w * h * 4 or not np.array_equal(want, p_d[k][: w * h * 4]):
+                        bad += 1; print(f"MISMATCH batch {b} file {k}: pixels differ from the oracle's")
+                        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True); open(os.path.join(ROOT, "gpurun_out", f"fuzz_png_mismatch_{b}_{k}.png"), "wb").write(files[k])
+            else:
+                rejected += 1
+                if O.stbi_load(files[k], 4, False) is not None:
+                    bad += 1; print(f"MISMATCH batch {b} file {k}: rejected (status {s_d[k]}), the oracle decodes it")
+                    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True); open(os.path.join(ROOT, "gpurun_out", f"fuzz_png_mismatch_{b}_{k}.png"), "wb").write(files[k])
     print(f"fuzz_png_gpu: {batches} batches of 40 files: {ok} decoded alike by both inflaters, {rejected} rejected by both, {bad} mismatches")
     raise SystemExit(1 if bad else 0)
 

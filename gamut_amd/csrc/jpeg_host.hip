@@ -64,7 +64,8 @@ struct HuffTable {
 struct BitReader {
     const uint8_t* p; const uint8_t* end;
     uint64_t acc = 0; int nbits = 0; bool at_marker = false;
-    BitReader(const uint8_t* b, const uint8_t* e) : p(b), end(e) {}
+    const uint8_t* seg; uint64_t used = 0;     // where the reader was (re)started, the bits taken since (resync needs the reference's read position)
+    BitReader(const uint8_t* b, const uint8_t* e) : p(b), end(e), seg(b) {}
     inline void refill()
     {
         while (nbits <= 56) {
@@ -80,7 +81,7 @@ struct BitReader {
         }
     }
     inline uint32_t peek(int n) const { return (uint32_t)(acc >> (nbits - n)) & ((1u << n) - 1); }
-    inline void drop(int n) { nbits -= n; }
+    inline void drop(int n) { nbits -= n; used += (uint64_t)n; }
     inline int receive_extend(int s)          // JPGD_HUFF_EXTEND :816-822
     {
         if (!s) return 0;
@@ -98,7 +99,7 @@ struct BitReader {
         drop(len);
         return h.vals[(code + h.delta[len]) & 0xFF];
     }
-    void restart(const uint8_t* np) { p = np; acc = 0; nbits = 0; at_marker = false; }
+    void restart(const uint8_t* np) { p = np; acc = 0; nbits = 0; at_marker = false; seg = np; used = 0; }
 };
 
 inline int be16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
@@ -239,22 +240,58 @@ int next_scan(Parser& P, gamut_hip_jpeg_frame* f)
     }
 }
 
-// process_restart :2335-2402: the entropy reader stopped at the marker; step over the expected RSTn
+// process_restart :2335-2402, as the oracle restates it (oracle_jpeg.c restart()): raw bytes from where the REFERENCE's input stands -- it
+// buffers 16 .. 32 bits, two octets per refill, four at a (re)start, never past a marker: 4 + 2 * (used / 16) octets behind the (re)start --
+// up to 1536 of them to the next 0xFF, its fill bytes, and then the expected RSTn or JPGD_BAD_RESTART_MARKER.
 bool resync(BitReader& br, int& expect_rst)
 {
-    const uint8_t* q = br.p;
-    while (q + 1 < br.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) ++q;
-    if (q + 1 >= br.end || q[1] != 0xD0 + expect_rst) return false;
-    br.restart(q + 2);
+    const uint8_t* q = br.seg;
+    for (uint64_t n = 4 + 2 * (br.used / 16); n > 0 && q < br.end; --n) {
+        if (*q == 0xFF) { if (q + 1 < br.end && q[1] == 0x00) q += 2; else break; }
+        else ++q;
+    }
+    int tem = 0, i, c = 0;
+    auto get_char = [&]() -> int { return q < br.end ? (int)*q++ : ((tem ^= 1) ? 0xFF : 0xD9); };      // :631-652: FF D9 FF D9 ... past the end
+    for (i = 1536; i > 0; --i) if (get_char() == 0xFF) break;
+    if (i == 0) return false;
+    for (; i > 0; --i) { c = get_char(); if (c != 0xFF) break; }
+    if (i == 0 || c != 0xD0 + expect_rst) return false;
+    br.restart(q);
     expect_rst = (expect_rst + 1) & 7;
     return true;
+}
+
+// calc_mcu_block_order :3068-3088: the blocks of an MCU belong to the components IN THE ORDER THE SOS LISTS THEM (m_comp_list), hs x vs blocks each
+// (one block for a single-component scan).  A conforming file lists them in frame order; the reference does not check, and decodes block b
+// with the tables / the predictor of order[b] while everything behind the entropy decoder goes by the block's position.  -> blocks per MCU.
+inline int scan_block_order(const Parser& P, int* order, int cap)
+{
+    const Scan& sc = P.scan;
+    int nb = 0;
+    if (sc.ncomp == 1) { if (cap > 0) order[0] = sc.comp[0]; return 1; }
+    for (int i = 0; i < sc.ncomp; ++i) for (int k = 0; k < P.hs[sc.comp[i]] * P.vs[sc.comp[i]]; ++k) { if (nb < cap) order[nb] = sc.comp[i]; ++nb; }
+    return nb;
+}
+// A sequential frame whose scan lists a component twice has another number of blocks per MCU than init_frame (:3136-3260) sized
+// m_pMCU_coefficients / the sample buffer for: more overruns them, fewer leaves the rest of every MCU as the allocator left it.  No result to match.
+inline bool baseline_order_ok(const Parser& P, const gamut_hip_jpeg_frame* f, int* order)
+{
+    return scan_block_order(P, order, 6) == f->blocks_per_mcu;
+}
+// decode_scan :3520-3583 steps block_x_mcu / m_block_y_mcu of a component once per time the interleaved scan lists it: listed twice, the walk
+// leaves the component's plane inside the first MCU row (coeff_buf_getp's assert :3293).
+inline bool scan_lists_a_component_twice(const Scan& sc)
+{
+    for (int a = 0; a < sc.ncomp; ++a) for (int b = a + 1; b < sc.ncomp; ++b) if (sc.comp[a] == sc.comp[b]) return true;
+    return false;
 }
 
 // ---- sequential frames: one interleaved scan (decode_next_row :2405-2525) --------------------------------------
 int decode_baseline(Parser& P, gamut_hip_jpeg_frame* f, const int* order, int nb, size_t nmcu)
 {
     if (P.scan.ncomp != f->comps) return fail(f, "only single-scan baseline files are supported");
-    for (int c = 0; c < f->comps; ++c) {                       // check_quant_tables / check_huff_tables :2990-3034
+    for (int i = 0; i < P.scan.ncomp; ++i) {                   // check_quant_tables / check_huff_tables :2990-3034: of the components the scan lists
+        const int c = P.scan.comp[i];
         if (!P.quant_def[P.tq[c]]) return fail(f, "undefined quant table");
         if (!P.huff[P.td[c]].defined || !P.huff[P.ta[c]].defined) return fail(f, "undefined Huffman table");
     }
@@ -444,6 +481,7 @@ struct Progressive {
             if (sc.ss > sc.se || sc.se > 63 || (dc_scan && sc.se != 0)) return fail(f, "bad SOS spectral selection");
             if (!dc_scan && sc.ncomp != 1) return fail(f, "AC scans can only contain one component");
             if (refine && sc.al != sc.ah - 1) return fail(f, "bad SOS successive approximation");
+            if (scan_lists_a_component_twice(sc)) return fail(f, "the scan lists a component twice");
             for (int i = 0; i < sc.ncomp; ++i) {
                 const int c = sc.comp[i];
                 if (!P.quant_def[P.tq[c]]) return fail(f, "undefined quant table");
@@ -505,7 +543,11 @@ int decode_coeffs(const uint8_t* data, size_t len, gamut_hip_jpeg_frame* f)
     f->max_zag = (uint8_t*)malloc(nblk ? nblk : 1);
     if (!f->coeffs || !f->max_zag) { fail(f, "out of memory"); return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: out of memory"); }
 
-    if (!P.progressive) return decode_baseline(P, f, order, nb, nmcu);
+    if (!P.progressive) {
+        int scan_order[6] = { 0, 0, 0, 0, 0, 0 };              // tables and predictors by the scan's list, positions by the frame's (scan_block_order)
+        if (P.scan.ncomp == f->comps && !baseline_order_ok(P, f, scan_order)) return fail(f, "the scan lists a component twice");
+        return decode_baseline(P, f, scan_order, nb, nmcu);
+    }
     Progressive* pg = new (std::nothrow) Progressive(P, f);
     if (!pg) { fail(f, "out of memory"); return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: out of memory"); }
     const int rc = pg->run(order, nb);
@@ -532,14 +574,33 @@ struct DevHuff {                       // one Huffman table (shared by every ima
 };
 struct DevImage {
     int64_t coeff_off, zag_off;        // int16 elements / bytes from the start of the caller's buffers
-    int32_t nb, ny;                    // blocks per MCU, of which luma (component of block b: b < ny ? 0 : b - ny + 1)
+    int32_t nb, org;                   // blocks per MCU; component of block b = (org >> 2 * b) & 3: the order the SOS lists them in (scan_block_order)
     int32_t quant[3], dc[3], ac[3];    // table indices per component
     int32_t tok;                       // 1: the coefficients leave as a token stream (compact hand-off, below) instead of dense 128-byte blocks
     int64_t tok_off, strip_off;        // the image's tokens / strip table: elements from the start of the token buffer / the strip-start buffer
     int32_t sb, row_blocks;            // blocks per strip of the reconstruction kernel (k_jpeg_h2v2: 8 MCUs = 48), blocks per MCU row
     int32_t n_strips, tok_cap;         // strips of the image (its table has n_strips + 1 entries), tokens its slot holds
 };
-struct DevItem { int32_t image, first_mcu, n_mcus, pad; uint64_t begin, end; };    // one restart interval (or whole scan)
+constexpr uint32_t kStatusBadRestart = 8u;
+struct DevItem { int32_t image, first_mcu, n_mcus, pad; uint64_t begin, end; int32_t tail, pad2; };    // one restart interval (or whole scan)
+// tail: -1 = nothing follows the segment but the end of the scan; >= 0 = an RSTn marker follows it, behind `tail` 0xFF fill bytes (restart_leftover_bad)
+
+// process_restart (jpegload.d:2335-2402) does not look for the marker where the interval's data ENDS but from where the decoder's input
+// stands: the bit reader holds 16 .. 32 bits, fetched two octets at a time (four at a (re)start) and never past a marker, so after
+// `used_bits` bits of an interval the input is 4 + 2 * (used_bits / 16) octets behind the interval's start.  From there at most 1536 raw
+// bytes are read up to a 0xFF, then its fill bytes, and what follows has to be the expected RSTn.  For an intact file that position IS the
+// marker (an encoder pads the last byte and nothing more).  A damaged one may leave whole octets between the two: they are skipped if none
+// of them is 0xFF (a stuffed FF 00 is "FF, then not RSTn": JPGD_BAD_RESTART_MARKER) and if they, the marker's 0xFF and its fill bytes are
+// within the 1536 reads.  seg = the UNSTUFFED interval (every 0xFF in it was FF 00), seg_bytes its length, fill = 0xFF bytes between the
+// marker's first 0xFF and its code.  (The markers themselves -- the wrong RSTn, a missing one -- are checked where the scan is unstuffed.)
+__device__ inline bool restart_leftover_bad(const uint8_t* seg, uint32_t seg_bytes, uint32_t used_bits, int fill)
+{
+    const uint64_t oct = 4 + 2 * (uint64_t)(used_bits / 16);
+    const uint32_t left = oct < seg_bytes ? seg_bytes - (uint32_t)oct : 0u;
+    if (left + (uint32_t)fill > 1535u) return true;
+    for (uint32_t i = 0; i < left; ++i) if (seg[oct + i] == 0xFF) return true;
+    return false;
+}
 
 __constant__ uint8_t kZagDev[64] = { 0,1,8,16,9,2,3,10,17,24,32,25,18,11,4,5,12,19,26,33,40,48,41,34,27,20,13,6,7,14,21,28,35,42,49,56,57,50,43,36,29,22,15,23,30,37,44,51,58,59,52,45,38,31,39,46,53,60,61,54,47,55,62,63 };
 
@@ -658,7 +719,7 @@ __global__ __launch_bounds__(kEntropyThreads) void k_jpeg_entropy(const DevItem*
     };
     for (int mcu = 0; mcu < it.n_mcus; ++mcu) {
         for (int b = 0; b < im.nb; ++b, out += 64, ++mz) {
-            const int c = b < im.ny ? 0 : b - im.ny + 1;
+            const int c = (int)((uint32_t)im.org >> (2 * b)) & 3;
             const int16_t* q = quant + (c == 0 ? im.quant[0] : c == 1 ? im.quant[1] : im.quant[2]) * 64;
             const DevHuff* dc = huff + (c == 0 ? im.dc[0] : c == 1 ? im.dc[1] : im.dc[2]);
             const DevHuff* ac = huff + (c == 0 ? im.ac[0] : c == 1 ? im.ac[1] : im.ac[2]);
@@ -690,6 +751,7 @@ __global__ __launch_bounds__(kEntropyThreads) void k_jpeg_entropy(const DevItem*
             for (int k = 0; k < 8; ++k) { dst[k] = src[k]; src[k] = make_uint4(0, 0, 0, 0); }
         }
     }
+    if (it.tail >= 0 && restart_leftover_bad(blob + it.begin, (uint32_t)(it.end - it.begin), br.pos, it.tail)) atomicOr(status + it.image, kStatusBadRestart);
 }
 
 // ---- many lanes per (long) segment: self-synchronising decode --------------------------------------------------------
@@ -708,7 +770,7 @@ struct SubCtx {
     const DevHuff* huff; const int16_t* quant; const uint8_t* zag;
     const uint8_t* seg; uint32_t end_bit;
     const int* par;                     // LDS: [component] -> quant table, DC table, AC table (3 x 3 ints), the segment's image
-    int ny, nb;
+    uint32_t org; int nb;              // org: DevImage.org
 };
 
 // Decode from state `s` while the position is inside this lane's sub-sequence.  WRITE: coefficients / max_zag go out,
@@ -799,7 +861,7 @@ __device__ __forceinline__ bool sub_decode(const SubCtx& x, SubState& s, int& nb
     if (MODE == SUB_COUNT && tr) { ck_next = tr->first_bit + tr->step_bits; tr->stopped = false; }
     while (br.pos < x.end_bit && (!WRITE || b < b_end)) {
         br.refill();                                                             // >= 33 bits: a code (<= 16) and its value (<= 15)
-        const int comp = c < x.ny ? 0 : c - x.ny + 1;
+        const int comp = (int)(x.org >> (2 * c)) & 3;
         const bool is_dc = z == 0;
         const DevHuff* h = x.huff + (is_dc ? (comp == 0 ? d0 : comp == 1 ? d1 : d2) : (comp == 0 ? a0 : comp == 1 ? a1 : a2));
         const uint32_t top16 = br.peek(16);
@@ -968,7 +1030,7 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevIte
     const int nsub = (int)((len + sub - 1) / sub);
     const bool active = t < nsub;
     const SubCtx x{ IN_LDS ? sh_huff : huff_g, IN_LDS ? sh_quant : quant_g, sh_zag, blob + it.begin, min((uint32_t)(t + 1) * sub, len) * 8u,
-                    par, im.ny, im.nb };
+                    par, (uint32_t)im.org, im.nb };
     int16_t* out = TOK ? nullptr : coeffs + im.coeff_off + (int64_t)it.first_mcu * im.nb * 64;
     uint8_t* mz = max_zag + im.zag_off + (int64_t)it.first_mcu * im.nb;
     const int64_t total_blocks = (int64_t)it.n_mcus * im.nb;
@@ -1051,7 +1113,8 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevIte
             const int strips_per_row = (im.row_blocks + im.sb - 1) / im.sb;
             tk.strip = (uint32_t)(row * strips_per_row + local / im.sb); tk.sb = local % im.sb; tk.left_in_row = im.row_blocks - local;
             if (!sub_decode<SUB_TOKENS>(x, s, n2, pred, b0, total_blocks, nullptr, mz, nullptr, nullptr, &tk)) failed = 1;
-            if (t == nsub - 1 && b0 + n2 != total_blocks) failed = 1;             // the segment ended before its last block did
+            if (t == nsub - 1 && b0 + n2 < total_blocks) failed = 1;      // the segment ended before its last block did (behind it: not this interval's)
+            if (it.tail >= 0 && b0 < total_blocks && b0 + n2 == total_blocks && restart_leftover_bad(x.seg, len, s.pos, it.tail)) atomicOr(status + it.image, kStatusBadRestart);   // the lane that ended the last block
         }
         __syncthreads();
         // the strips no block opened (a damaged stream ends early) are empty: their tokens "begin" at the end; blocks nobody reached
@@ -1075,7 +1138,8 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevIte
         int pred[3] = { pred_in[0], pred_in[1], pred_in[2] };
         SubState s = entry; int n2 = 0;
         if (!sub_decode<SUB_WRITE>(x, s, n2, pred, b0, total_blocks, out, mz, reinterpret_cast<int16_t*>(sh_blk + t * kPitch))) failed = 1;
-        if (t == nsub - 1 && b0 + n2 != total_blocks) failed = 1;                 // the segment ended before its last block did
+        if (t == nsub - 1 && b0 + n2 < total_blocks) failed = 1;      // the segment ended before its last block did (behind it: not this interval's)
+        if (it.tail >= 0 && b0 < total_blocks && b0 + n2 == total_blocks && restart_leftover_bad(x.seg, len, s.pos, it.tail)) atomicOr(status + it.image, kStatusBadRestart);       // the lane that ended the last block
     }
     __threadfence();                                            // the lines are on their way before anybody adds single coefficients to them
     __syncthreads();
@@ -1114,7 +1178,6 @@ struct DevRaw {
     int32_t  image, first_item, n_items, restart_interval;
 };
 constexpr int kUnstuffThreads = 256, kUnstuffTile = kUnstuffThreads * 16;
-constexpr uint32_t kStatusBadRestart = 8u;
 __global__ __launch_bounds__(kUnstuffThreads) void k_jpeg_unstuff(const DevRaw* files, DevItem* items, const uint8_t* raw, uint8_t* blob, uint32_t* status)
 {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -1147,8 +1210,8 @@ __global__ __launch_bounds__(kUnstuffThreads) void k_jpeg_unstuff(const DevRaw* 
         __syncthreads();
         return rest;
     };
-    auto close_segment = [&]() {                             // the segment's item, then its 64 bytes of padding
-        if (t == 0 && seg < f.n_items) { items[f.first_item + seg].begin = f.out_begin + seg_begin; items[f.first_item + seg].end = f.out_begin + w; }
+    auto close_segment = [&](int tail) {                     // the segment's item, then its 64 bytes of padding; tail: DevItem.tail
+        if (t == 0 && seg < f.n_items) { items[f.first_item + seg].begin = f.out_begin + seg_begin; items[f.first_item + seg].end = f.out_begin + w; items[f.first_item + seg].tail = tail; }
         if (t < 64) stage[carry + t] = 0xFF;
         const uint32_t m = carry + 64;
         w += 64;
@@ -1217,7 +1280,7 @@ __global__ __launch_bounds__(kUnstuffThreads) void k_jpeg_unstuff(const DevRaw* 
             const uint32_t code = j < f.raw_len ? src[j] : 0xD9u;
             const bool rst = code >= 0xD0u && code <= 0xD7u && f.restart_interval > 0 && seg + 1 < f.n_items;
             if (rst && code != 0xD0u + (uint32_t)expect) { bad = true; ended = true; }
-            else if (rst) { close_segment(); expect = (expect + 1) & 7; cur = j + 1; }
+            else if (rst) { close_segment((int)min(j - (cur + p + 1), (uint64_t)4096)); expect = (expect + 1) & 7; cur = j + 1; }
             else ended = true;                               // EOI or any other marker ends the scan
         } else {
             cur += n;
@@ -1225,7 +1288,7 @@ __global__ __launch_bounds__(kUnstuffThreads) void k_jpeg_unstuff(const DevRaw* 
         }
     }
     if (!bad) {
-        if (seg + 1 == f.n_items) close_segment();
+        if (seg + 1 == f.n_items) close_segment(-1);
         else bad = true;                                     // a restart marker is missing
     }
     if (carry) {                                             // the last, partial chunk (the slot has room for a whole one)
@@ -1252,7 +1315,10 @@ int parse_baseline(Parser& P, const uint8_t* data, size_t len, gamut_hip_jpeg_fr
     if (!want_scan) return GAMUT_HIP_OK;
     if (P.progressive) return set_error(GAMUT_HIP_ERR_UNSUPPORTED, "jpeg: progressive frames are decoded by the host feeder (gamut_hip_jpeg_decode_coeffs)");
     if (P.scan.ncomp != f->comps) return fail(f, "only single-scan baseline files are supported");
-    for (int c = 0; c < f->comps; ++c) {
+    int order[6];
+    if (!baseline_order_ok(P, f, order)) return fail(f, "the scan lists a component twice");
+    for (int i = 0; i < P.scan.ncomp; ++i) {                   // the tables of the components the scan lists (check_quant_tables / check_huff_tables)
+        const int c = P.scan.comp[i];
         if (!P.quant_def[P.tq[c]]) return fail(f, "undefined quant table");
         if (!P.huff[P.td[c]].defined || !P.huff[P.ta[c]].defined) return fail(f, "undefined Huffman table");
     }
@@ -1274,7 +1340,7 @@ struct QuantTab { int16_t q[64]; };
 struct FilePrep {
     int rc = GAMUT_HIP_OK; char msg[200] = { 0 };
     bool progressive = false;                                  // SOF2: left to progressive_decode_device (rc = kDeferred)
-    int comps = 0, nb = 0, ny = 0;
+    int comps = 0, nb = 0, ny = 0; uint32_t org = 0;           // org: DevImage.org
     QuantTab quant[3]; DevHuff huff[3][2];                     // [component][DC, AC]
     size_t scan_pos = 0, cap = 0, used = 0;                    // first scan byte in the file; bound / actual size of the unstuffed segments
     int restart_interval = 0, total_mcus = 0;
@@ -1293,6 +1359,7 @@ void prepare_header(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& 
     out.progressive = out.rc == GAMUT_HIP_ERR_UNSUPPORTED && P.progressive;
     if (out.rc != GAMUT_HIP_OK) { snprintf(out.msg, sizeof(out.msg), "image %d: %s", i, last_error_buf()); return; }
     out.comps = f.comps; out.nb = f.blocks_per_mcu; out.ny = f.comps == 1 ? 1 : P.hs[0] * P.vs[0];
+    { int order[6] = { 0, 0, 0, 0, 0, 0 }; const int blocks = scan_block_order(P, order, 6); out.org = 0; for (int b = 0; b < blocks && b < 6; ++b) out.org |= (uint32_t)order[b] << (2 * b); }
     for (int c = 0; c < f.comps; ++c) {
         memcpy(out.quant[c].q, P.quant[P.tq[c]], sizeof(out.quant[c].q));
         for (int k = 0; k < 2; ++k) {
@@ -1341,9 +1408,10 @@ void unstuff_file(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& f,
             memcpy(dst + w, base + copy_from, k); w += k;
         }
     };
-    auto close_segment = [&](int nm) {
+    int fill = 0;                                          // 0xFF bytes in front of the marker under way, besides its own
+    auto close_segment = [&](int nm, int tail) {
         if (w + 64 > out.cap) { bad = true; return; }
-        DevItem it{}; it.image = i; it.first_mcu = next_mcu; it.n_mcus = nm; it.begin = seg_begin; it.end = w;
+        DevItem it{}; it.image = i; it.first_mcu = next_mcu; it.n_mcus = nm; it.begin = seg_begin; it.end = w; it.tail = tail;
         it.pad = (int32_t)std::min<size_t>(w - seg_begin, 0x7fffffff);
         out.items.push_back(it); next_mcu += nm;
         memset(dst + w, 0xFF, 64); w += 64;
@@ -1356,10 +1424,10 @@ void unstuff_file(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& f,
         q = (size_t)(hit - base);
         if (m == 0x00) { flush(q + 1); copy_from = q + 2; q += 2; continue; }          // stuffed 0xFF: keep the FF, drop the 00
         flush(q); copying = false;                                                        // FF + non-zero: the data ends here (get_octet :683-696)
-        if (m == 0xFF) { q += 1; continue; }                                              // fill bytes before a marker
+        if (m == 0xFF) { q += 1; fill = std::min(fill + 1, 4096); continue; }             // fill bytes before a marker
         if (m >= 0xD0 && m <= 0xD7 && ri && next_mcu + ri < total_mcus) {
             if (m != 0xD0 + expect) { bad = true; break; }
-            close_segment(ri);
+            close_segment(ri, fill); fill = 0;
             expect = (expect + 1) & 7; q += 2; copy_from = q; copying = true;
             continue;
         }
@@ -1367,7 +1435,7 @@ void unstuff_file(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& f,
     }
     if (!bad && next_mcu < total_mcus) {
         if (ri && total_mcus - next_mcu > ri) bad = true;      // a restart marker is missing
-        else close_segment(total_mcus - next_mcu);
+        else close_segment(total_mcus - next_mcu, -1);
     }
     out.used = w;
     if (bad) {
@@ -1455,7 +1523,7 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
         DevImage& im = images[(size_t)i];
         memset(&im, 0, sizeof(im));
         if (fp.rc != GAMUT_HIP_OK) continue;
-        im.coeff_off = coeff_offset[i]; im.zag_off = zag_offset[i]; im.nb = fp.nb; im.ny = fp.ny;
+        im.coeff_off = coeff_offset[i]; im.zag_off = zag_offset[i]; im.nb = fp.nb; im.org = (int32_t)fp.org;
         if (tok[(size_t)i]) {                                  // strips = the reconstruction kernel's: 8 MCUs of 6 blocks along an MCU row
             im.tok = 1; im.tok_off = tok_off[(size_t)i]; im.strip_off = strip_off[(size_t)i]; im.tok_cap = tok_cap[(size_t)i];
             im.sb = 48; im.row_blocks = info[i].mcus_per_row * 6; im.n_strips = info[i].mcus_per_col * ((info[i].mcus_per_row + 7) / 8);
@@ -1489,9 +1557,10 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
         std::vector<size_t> raw_off((size_t)count, 0);
         for (int i = 0; i < count; ++i) {
             const FilePrep& fp = prep[(size_t)i];
-            if (fp.rc != GAMUT_HIP_OK || !fp.dev_unstuff) continue;
+            if (fp.rc != GAMUT_HIP_OK) continue;
+            dev_restarts = dev_restarts || fp.restart_interval > 0;        // (whoever unstuffs: what lies between an interval's last bit and its marker is the kernels' to judge)
+            if (!fp.dev_unstuff) continue;
             raw_off[(size_t)i] = raw_size; raw_size += (fp.raw_len + 32 + 15) & ~(size_t)15; ++n_dev_files;
-            dev_restarts = dev_restarts || fp.restart_interval > 0;
         }
         static thread_local PerDevice<DeviceScratch> raw_scratch_pd;
         static thread_local PerDevice<PinnedScratch> raw_pinned_pd;
@@ -1675,12 +1744,12 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
         GAMUT_HIP_CHECK(hipStreamSynchronize(copy_stream));
         for (int g = 1; g < n_groups; ++g) GAMUT_HIP_CHECK(hipStreamSynchronize(side[g]));
         GAMUT_HIP_CHECK(hipStreamSynchronize(stream));         // the per-thread staging buffers are reused by the next call
-        if (dev_restarts) {                                    // restart markers are checked where the scan is unstuffed: a wrong / missing one is a
-            std::vector<uint32_t> flags((size_t)count);        // header-level failure of the file, as it is when the host finds it (unstuff_file)
+        if (dev_restarts) {                                    // restart markers are checked where the scan is unstuffed, what lies in front of them where it is
+            std::vector<uint32_t> flags((size_t)count);        // decoded (restart_leftover_bad): either way a header-level failure of the file, as when unstuff_file finds it
             GAMUT_HIP_CHECK(hipMemcpy(flags.data(), st, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost));
             for (int i = 0; i < count; ++i) {
                 FilePrep& fp = prep[(size_t)i];
-                if (fp.rc == GAMUT_HIP_OK && fp.dev_unstuff && (flags[(size_t)i] & kStatusBadRestart)) {
+                if (fp.rc == GAMUT_HIP_OK && (flags[(size_t)i] & kStatusBadRestart)) {
                     fail(&info[i], "bad restart marker");
                     fp.rc = GAMUT_HIP_ERR_DECODE; snprintf(fp.msg, sizeof(fp.msg), "image %d: bad restart marker", i);
                 }

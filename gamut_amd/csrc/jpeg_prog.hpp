@@ -45,7 +45,8 @@ struct ProgItem {                      // one restart interval (or whole scan) o
     // (= the items of the file's lower levels) and adds one when it is done.
     int32_t dep[3], dep_pipe, ctr, ctr_need;
     int32_t scan, seg;                 // host only: the scan of the file, the restart segment of the scan
-    int32_t prio, pad_;                // s_setprio of the item's wave: the long chains of a file first (they are its decode time), the short ones in the gaps
+    int32_t prio, tail;                // prio: s_setprio of the item's wave: the long chains of a file first (they are its decode time), the short ones in the gaps;
+                                       // tail: as DevItem.tail (-1: the scan ends behind the segment; >= 0: an RSTn follows, behind that many fill bytes)
 };
 constexpr uint32_t kProgDone = 0x7FFFFFFFu;     // an item's progress word once it has returned (whatever its verdict)
 constexpr int kProgBatch = 64;                  // units between two looks at / reports of progress
@@ -185,7 +186,7 @@ struct AcRefineArgs {
     uint32_t limit_bit;
     int al, n_units, first_unit, mpr, nbm, ss, se, nbx, hs, vs, off;
 };
-__device__ __forceinline__ uint32_t prog_ac_refine(ProgSync sy, AcRefineArgs a, uint4* profile);
+__device__ __forceinline__ uint32_t prog_ac_refine(ProgSync sy, AcRefineArgs a, uint4* profile, uint32_t& end_pos);   // end_pos: set when the interval was decoded to its end
 
 __device__ __forceinline__ void prog_scan_body(const ProgItem& it, const ProgImage& im, DevHuff* sh_huff, const DevHuff* huff_g,
                                                const uint8_t* blob, int16_t* coeffs, uint32_t* status, uint32_t* prog, const uint32_t* counters, int me, uint32_t& waited, uint4* profile)
@@ -209,6 +210,11 @@ __device__ __forceinline__ void prog_scan_body(const ProgItem& it, const ProgIma
     struct Report { ProgSync& s; uint32_t& w; __device__ ~Report() { w = s.waited; } } report{ sy, waited };      // on every way out
     auto wait_units = [&](int upto) { sy.wait_units(upto); };
     auto publish = [&](int units_done) { sy.publish(units_done); };
+    // an interval decoded to its end: may process_restart find the marker from where the reference's input stands?  (restart_leftover_bad)
+    auto interval_done = [&](uint32_t used_bits) {
+        const int tail = rfl(it.tail);
+        if (tail >= 0 && lane == 0 && restart_leftover_bad(seg, seg_bytes, used_bits, tail)) atomicOr(st, kStatusBadRestart);
+    };
     if (rfl(it.ctr) >= 0 && rfl(it.ctr_need) > 0) { uint32_t seen = 0; sy.wait_word(counters + rfl(it.ctr), (uint32_t)rfl(it.ctr_need), seen); }
     const int al = rfl(it.al), n_units = rfl(it.n_units), first_unit = rfl(it.first_unit);
     const int mpr = rfl(im.mcus_per_row), nbm = rfl(im.nb);        // scalars of their own: the structs are indexed by component elsewhere and live in scratch memory
@@ -241,6 +247,7 @@ __device__ __forceinline__ void prog_scan_body(const ProgItem& it, const ProgIma
                 }
             }
         }
+        interval_done((uint32_t)n_units * (uint32_t)bpu);
         return;
     }
 
@@ -286,6 +293,7 @@ __device__ __forceinline__ void prog_scan_body(const ProgItem& it, const ProgIma
                 if (pos > limit_bit) { if (lane == 0) atomicOr(st, 4u); return; }
             }
         }
+        interval_done(pos);
         return;
     }
 
@@ -329,6 +337,7 @@ __device__ __forceinline__ void prog_scan_body(const ProgItem& it, const ProgIma
             }
             if (++bx == nbx) { bx = 0; ++by; }
         }
+        interval_done(pos);
         return;
     }
 
@@ -336,7 +345,9 @@ __device__ __forceinline__ void prog_scan_body(const ProgItem& it, const ProgIma
     // others the kernel spilled seventy of them)
     {
         const AcRefineArgs ra{ seg, out, &sh_huff[0], limit_bit, al, n_units, first_unit, mpr, nbm, ss, se, nbx, hs, vs, off };
-        sy.waited = prog_ac_refine(sy, ra, profile);
+        uint32_t end_pos = 0xFFFFFFFFu;
+        sy.waited = prog_ac_refine(sy, ra, profile, end_pos);
+        if (end_pos != 0xFFFFFFFFu) interval_done(end_pos);
     }
 }
 
@@ -362,7 +373,7 @@ __device__ __forceinline__ void prog_scan_body(const ProgItem& it, const ProgIma
 #define PROG_T(var)
 #define PROG_ACC(dst, a, b)
 #endif
-__device__ __forceinline__ uint32_t prog_ac_refine(ProgSync sy, AcRefineArgs a, uint4* profile)
+__device__ __forceinline__ uint32_t prog_ac_refine(ProgSync sy, AcRefineArgs a, uint4* profile, uint32_t& end_pos)   // end_pos: set when the interval was decoded to its end
 {
     uint32_t pf_setup = 0, pf_walk = 0, pf_tail = 0, pf_syms = 0;     // GAMUT_PROG_PROFILE: shader clocks per phase, symbols
     (void)pf_setup; (void)pf_walk; (void)pf_tail; (void)pf_syms;
@@ -564,7 +575,7 @@ __device__ __forceinline__ uint32_t prog_ac_refine(ProgSync sy, AcRefineArgs a, 
             }
             if (!going) { ended = true; break; }
         }
-        if (!ended) finish_pending();
+        if (!ended) { finish_pending(); end_pos = pos; }
     }
 #ifdef GAMUT_PROG_PROFILE
     if (profile && lane == 0) *profile = make_uint4(pf_setup, pf_walk, pf_tail, pf_syms);
@@ -696,6 +707,7 @@ void prog_prepare(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& f,
         const bool dc_scan = sc.ss == 0, refine = sc.ah != 0;
         if (sc.ss > sc.se || sc.se > 63 || (dc_scan && sc.se != 0)) return bad("bad SOS spectral selection");
         if (!dc_scan && sc.ncomp != 1) return bad("AC scans can only contain one component");
+        if (scan_lists_a_component_twice(sc)) return bad("the scan lists a component twice");   // decode_scan's walk leaves the component's plane (coeff_buf_getp :3293)
         if (refine && sc.al != sc.ah - 1) return bad("bad SOS successive approximation");
         if (sc.al > 13) return bad("bad SOS successive approximation");
         for (int k = 0; k < sc.ncomp; ++k) {
@@ -759,14 +771,15 @@ void prog_unstuff(int i, const uint8_t* base, gamut_hip_jpeg_frame& f, ProgPrep&
                 memcpy(dst + w, base + copy_from, k); w += k;
             }
         };
-        auto close_segment = [&](int nu) {
+        int fill = 0;                                          // 0xFF bytes in front of the marker under way, besides its own
+        auto close_segment = [&](int nu, int tail) {
             if (w + 64 + 16 > out.cap) { bad = true; return; }
             ProgItem it; memset(&it, 0, sizeof(it));
             it.image = i; it.kind = s.kind; it.ncomp = s.sc.ncomp; it.ss = s.sc.ss; it.se = s.sc.se; it.al = s.sc.al;
             for (int k = 0; k < s.sc.ncomp; ++k) { it.comp[k] = s.sc.comp[k]; it.tab[k] = s.tab[k]; }
             it.first_unit = next_unit; it.n_units = nu; it.nbx = s.nbx > 0 ? s.nbx : 1; it.level = s.level;
             it.begin = seg_begin; it.end = w;
-            it.scan = (int32_t)si; it.seg = n_seg++;
+            it.scan = (int32_t)si; it.seg = n_seg++; it.tail = tail;
             it.dep[0] = it.dep[1] = it.dep[2] = -1;
             out.items.push_back(it); next_unit += nu;
             memset(dst + w, 0xFF, 64); w += 64;
@@ -780,10 +793,10 @@ void prog_unstuff(int i, const uint8_t* base, gamut_hip_jpeg_frame& f, ProgPrep&
             q = (size_t)(hit - base);
             if (m == 0x00) { flush(q + 1); copy_from = q + 2; q += 2; continue; }      // stuffed 0xFF: keep the FF, drop the 00
             flush(q); copying = false;
-            if (m == 0xFF) { q += 1; continue; }
+            if (m == 0xFF) { q += 1; fill = std::min(fill + 1, 4096); continue; }
             if (m >= 0xD0 && m <= 0xD7 && ri && next_unit + ri < total) {
                 if (m != 0xD0 + expect) { bad = true; break; }
-                close_segment(ri);
+                close_segment(ri, fill); fill = 0;
                 expect = (expect + 1) & 7; q += 2; copy_from = q; copying = true;
                 continue;
             }
@@ -791,7 +804,7 @@ void prog_unstuff(int i, const uint8_t* base, gamut_hip_jpeg_frame& f, ProgPrep&
         }
         if (!bad && next_unit < total) {
             if (ri && total - next_unit > ri) bad = true;      // a restart marker is missing
-            else close_segment(total - next_unit);
+            else close_segment(total - next_unit, -1);
         }
         if (bad) break;
     }
@@ -1089,6 +1102,25 @@ int progressive_decode_device(const uint8_t* const* data, const size_t* len, con
                                (const ProgImage*)(d + o_img), (int)live.size(), (const int16_t*)(d + o_quant), d_coeffs, d_max_zag);
             if (int rc = launch_status("jpeg_prog_finalize")) return rc;
             GAMUT_HIP_CHECK(hipStreamSynchronize(stream));     // the per-thread staging buffers are reused by the next call
+            // what lay between an interval's last bit and its RSTn was the scan kernel's to judge (restart_leftover_bad): a file-level
+            // failure, as a wrong or missing marker is where the scans are unstuffed
+            bool any_restarts = false;
+            for (int k = 0; k < n && !any_restarts; ++k) if (prep[(size_t)k].rc == GAMUT_HIP_OK) for (const ProgScanPrep& s : prep[(size_t)k].scans) any_restarts = any_restarts || s.restart_interval > 0;
+            if (any_restarts) {
+                int lo = idx[0], hi = idx[0];
+                for (int i : idx) { lo = std::min(lo, i); hi = std::max(hi, i); }
+                std::vector<uint32_t> flags((size_t)(hi - lo + 1));
+                GAMUT_HIP_CHECK(hipMemcpy(flags.data(), st + lo, flags.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                for (int k = 0; k < n; ++k) {
+                    ProgPrep& pp = prep[(size_t)k];
+                    if (pp.rc != GAMUT_HIP_OK) continue;
+                    const int i = idx[(size_t)k];
+                    if (flags[(size_t)(i - lo)] & kStatusBadRestart) {
+                        fail(&info[i], "bad restart marker");
+                        pp.rc = GAMUT_HIP_ERR_DECODE; snprintf(pp.msg, sizeof(pp.msg), "image %d: bad restart marker", i);
+                    }
+                }
+            }
             ms_kernels = ms_since(t_k);
         }
     }

@@ -312,6 +312,8 @@ typedef struct {
     const uint8_t* p; const uint8_t* end;
     u32 bitbuf; int bits;     /* MSB-first, `bits` valid bits in the low end */
     int hit_marker;
+    const uint8_t* seg;       /* where the reader was (re)started, and the bits taken since: process_restart needs the REFERENCE's read position */
+    uint64_t used;
 } bitreader;
 
 static inline void br_fill(bitreader* b)
@@ -330,7 +332,7 @@ static inline void br_fill(bitreader* b)
     }
 }
 static inline u32 br_peek(bitreader* b, int n) { return (b->bitbuf >> (b->bits - n)) & ((1u << n) - 1); }
-static inline void br_skip(bitreader* b, int n) { b->bits -= n; }
+static inline void br_skip(bitreader* b, int n) { b->bits -= n; b->used += (uint64_t)n; }
 static inline u32 br_get(bitreader* b, int n)
 {
     if (!n) return 0;
@@ -456,13 +458,28 @@ static int scan_header(jstate* S, orc_jpeg_frame* f)
     }
 }
 
-/* process_restart :2335-2402: resynchronise on the expected RSTn */
+/* process_restart :2335-2402, statement by statement.  It reads RAW bytes (get_char :631-652) from where the bit reader's input stands: the
+   reference keeps 16 .. 32 bits buffered and fetches two octets per refill (get_bits_no_markers :722-743; four at a (re)start :2390-2397 /
+   init_scan), an octet being a data byte or an FF 00 pair, and never steps over a marker (get_octet :683-696 puts it back) -- so after `used`
+   bits it stands 4 + 2 * (used / 16) octets behind the (re)start, or at the marker that stopped it.  From there: up to 1536 bytes to the next
+   0xFF, the 0xFF fill bytes behind it, and the byte after them must be the expected RSTn -- anything else (a stray marker, stuffed data left
+   over before the marker, more than 1536 bytes of it) is JPGD_BAD_RESTART_MARKER.  Past the end of the file get_char pads with FF D9 FF D9. */
 static int restart(bitreader* br, int* next_restart)
 {
-    const uint8_t* q = br->p;
-    while (q + 1 < br->end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) q++;
-    if (q + 1 >= br->end || q[1] != 0xD0 + *next_restart) return -1;
-    br->p = q + 2; br->bitbuf = 0; br->bits = 0; br->hit_marker = 0;
+    const uint8_t* q = br->seg;
+    for (uint64_t n = 4 + 2 * (br->used / 16); n > 0 && q < br->end; --n) {
+        if (*q == 0xFF) { if (q + 1 < br->end && q[1] == 0x00) q += 2; else break; }
+        else q++;
+    }
+    int tem = 0, i, c = 0;
+#define ORC_GET_CHAR() (q < br->end ? (int)*q++ : ((tem ^= 1) ? 0xFF : 0xD9))
+    for (i = 1536; i > 0; i--) if (ORC_GET_CHAR() == 0xFF) break;
+    if (i == 0) return -1;
+    for (; i > 0; i--) { c = ORC_GET_CHAR(); if (c != 0xFF) break; }
+#undef ORC_GET_CHAR
+    if (i == 0) return -1;
+    if (c != 0xD0 + *next_restart) return -1;
+    br->p = q; br->bitbuf = 0; br->bits = 0; br->hit_marker = 0; br->seg = q; br->used = 0;
     *next_restart = (*next_restart + 1) & 7;
     return 0;
 }
@@ -569,6 +586,10 @@ static int progressive_scan(pstate* P, const orc_jpeg_frame* f, int (*fn)(pstate
     } else {
         mcus_per_row = (((f->width  + 7) / 8) + (max_h - 1)) / max_h;
         mcus_per_col = (((f->height + 7) / 8) + (max_v - 1)) / max_v;
+        /* a component listed twice: decode_scan (:3520-3583) steps its block_x_mcu / m_block_y_mcu twice per MCU, so the walk below leaves the
+           component's plane inside the first MCU row (coeff_buf_getp's assert :3293) whatever the geometry -- and m_mcu_org (10 entries) may not
+           even hold the list.  Rejected here, before the list is laid out. */
+        for (int i = 0; i < S->comps_in_scan; ++i) for (int j = i + 1; j < S->comps_in_scan; ++j) if (S->comp_list[i] == S->comp_list[j]) return -1;
         for (int i = 0; i < S->comps_in_scan; ++i) { const int c = S->comp_list[i]; for (int k = 0; k < S->h_samp[c] * S->v_samp[c]; ++k) mcu_org[nb++] = c; }
     }
     int restarts_left = S->restart_interval, next_restart = 0;
@@ -626,10 +647,21 @@ int orc_jpeg_decode_coeffs(const uint8_t* data, size_t len, orc_jpeg_frame* f)
     if (!S->progressive) {
         /* init_sequential :3666-3677: one interleaved scan carrying every component */
         if (S->comps_in_scan != f->comps) goto done;
-        for (int c = 0; c < f->comps; ++c)                          /* check tables :2990-3034 */
+        for (int i = 0; i < S->comps_in_scan; ++i) {                /* check tables :2990-3034: of the components the scan lists */
+            const int c = S->comp_list[i];
             if (!S->quant_present[S->comp_quant[c]] || !S->huff[S->comp_dc[c]].present || !S->huff[S->comp_ac[c]].present) goto done;
+        }
+        /* calc_mcu_block_order :3068-3088: the MCU's blocks belong to the components in the order the SOS lists them (a conforming file: the
+           frame's order).  Tables, quantisation and predictor of block b go by that list; everything behind the entropy decoder goes by the
+           block's position.  A list with a component twice gives another number of blocks per MCU than init_frame (:3136-3260) sized the
+           decoder's buffers for -- more overruns them, fewer leaves part of every MCU uninitialised: no result to restate, rejected. */
+        if (f->comps > 1) {
+            int n = 0;
+            for (int i = 0; i < S->comps_in_scan; ++i) { const int c = S->comp_list[i]; for (int k = 0; k < S->h_samp[c] * S->v_samp[c]; ++k) { if (n < 6) mcu_org[n] = c; ++n; } }
+            if (n != nb) goto done;
+        }
 
-        bitreader br = { data + S->pos, data + len, 0, 0, 0 };
+        bitreader br = { data + S->pos, data + len, 0, 0, 0, data + S->pos, 0 };
         u32 last_dc[3] = {0,0,0};
         int restarts_left = S->restart_interval, next_restart = 0;
         int16_t* p = f->coeffs; uint8_t* mz = f->max_zag;
@@ -690,7 +722,7 @@ int orc_jpeg_decode_coeffs(const uint8_t* data, size_t len, orc_jpeg_frame* f)
                 if (!S->quant_present[S->comp_quant[c]]) goto done;
                 if (dc_only ? (!refinement && !S->huff[S->comp_dc[c]].present) : !S->huff[S->comp_ac[c]].present) goto done;   /* DC refinement reads raw bits only */
             }
-            P->br.p = data + S->pos; P->br.end = data + len; P->br.bitbuf = 0; P->br.bits = 0; P->br.hit_marker = 0;
+            P->br.p = data + S->pos; P->br.end = data + len; P->br.bitbuf = 0; P->br.bits = 0; P->br.hit_marker = 0; P->br.seg = P->br.p; P->br.used = 0;
             P->last_dc[0] = P->last_dc[1] = P->last_dc[2] = 0; P->eob_run = 0;                 /* init_scan :3108-3110 */
             if (progressive_scan(P, f, dc_only ? (refinement ? dc_refine : dc_first) : (refinement ? ac_refine : ac_first))) goto done;
             S->pos = (size_t)(P->br.p - data);                     /* the reader never steps over a marker */

@@ -241,3 +241,38 @@ def qoi_encode(px, colorspace=0, force_ops=True):
         prev = cur
     out += bytes([0, 0, 0, 0, 0, 0, 0, 1])
     return bytes(out)
+
+
+def sos_component_lists(data, lists=((1, 3, 2), (2, 1, 3), (3, 2, 1), (1, 2, 2), (1, 1, 3), (2, 2, 2), (1, 3, 3))):
+    """A three-component JPEG with the component ids of its interleaved SOS headers rewritten (the table selectors stay where they are): files no
+    encoder writes -- the scan header must list the components in frame order, each once -- but the reference reads them without a check
+    (read_sos_marker jpegload.d:1466-1540, calc_mcu_block_order :3068-3088).  `lists` are positions in the frame (1-based).  -> [bytes]"""
+    i = 2
+    ids = None
+    sos = []
+    while i + 4 <= len(data):
+        assert data[i] == 0xFF
+        m = data[i + 1]
+        seglen = (data[i + 2] << 8) | data[i + 3]
+        if m in (0xC0, 0xC1, 0xC2):
+            ids = [data[i + 10 + 3 * k] for k in range(data[i + 9])]
+        if m == 0xDA:
+            if data[i + 4] == 3:
+                sos.append(i)
+            j = i + 2 + seglen                                   # over the entropy-coded data to the next marker that is not RSTn / a stuffed byte
+            while j + 1 < len(data) and not (data[j] == 0xFF and data[j + 1] not in (0x00, 0xFF) and not 0xD0 <= data[j + 1] <= 0xD7):
+                j += 1
+            i = j
+            continue
+        if m == 0xD9:
+            break
+        i += 2 + seglen
+    assert ids is not None and len(ids) == 3 and sos
+    out = []
+    for lst in lists:
+        for at in sos:
+            b = bytearray(data)
+            for k, c in enumerate(lst):
+                b[at + 5 + 2 * k] = ids[c - 1]
+            out.append(bytes(b))
+    return out

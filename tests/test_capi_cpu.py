@@ -72,6 +72,49 @@ def test_jpeg_feeder_matches_oracle(path):
     L.gamut_hip_jpeg_frame_free(C.byref(fr))           # idempotent
 
 
+def _scan_list_files():
+    import io
+    from PIL import Image
+    import gen
+    img = gen.synth_rgb(97, 61, 5)
+    out = []
+    for kw in (dict(quality=85, subsampling=2), dict(quality=85, subsampling=0), dict(quality=85, subsampling=1, restart_marker_blocks=3),
+               dict(quality=85, subsampling=2, optimize=True), dict(quality=80, subsampling=2, progressive=True), dict(quality=80, subsampling=0, progressive=True)):
+        bio = io.BytesIO(); Image.fromarray(img).save(bio, "JPEG", **kw)
+        out.append(bio.getvalue())
+    return out
+
+
+def test_jpeg_feeder_scan_headers_that_list_components_out_of_order():
+    """calc_mcu_block_order (jpegload.d:3068-3088) lays the MCU out in the order the SOS lists the components, read_sos_marker (:1466-1540) checks
+    neither the order nor repeats: block b is decoded with the tables / predictor of the b-th listed component while the IDCT and the colour
+    conversion go by position.  Sequential: a permuted list decodes (chroma planes swapped or garbled), a repeat with the frame's block count too,
+    any other repeat has no defined result (the decoder's buffers are sized by init_frame :3136-3260) -- rejected.  Progressive: a repeat in an
+    interleaved scan walks out of the component's plane (decode_scan :3520-3583, coeff_buf_getp's assert :3293) -- rejected.  Host feeder == oracle."""
+    import gen
+    L = _capi.lib()
+    n_ok = n_rej = n_changed = 0
+    for f in _scan_list_files():
+        base = O.DecodedJpeg(f)
+        for v in gen.sos_component_lists(f):
+            try:
+                d = O.DecodedJpeg(v)
+            except ValueError:
+                d = None
+            fr = _capi.JpegFrame(); buf = np.frombuffer(v, np.uint8)
+            rc = L.gamut_hip_jpeg_decode_coeffs(buf.ctypes.data, buf.size, C.byref(fr))
+            assert (rc == 0) == (d is not None), (rc, L.gamut_hip_last_error())
+            if d is None:
+                assert rc == _capi.ERR_DECODE
+                n_rej += 1
+                continue
+            n = fr.mcus_per_row * fr.mcus_per_col * fr.blocks_per_mcu
+            assert np.array_equal(np.ctypeslib.as_array(fr.coeffs, (n, 64)), d.coeffs) and np.array_equal(np.ctypeslib.as_array(fr.max_zag, (n,)), d.max_zag)
+            L.gamut_hip_jpeg_frame_free(C.byref(fr))
+            n_ok += 1; n_changed += not np.array_equal(d.coeffs, base.coeffs)
+    assert n_ok >= 20 and n_rej >= 10 and n_changed >= 15, (n_ok, n_rej, n_changed)
+
+
 def test_jpeg_batch_feeder_threads():
     """gamut_hip_jpeg_decode_coeffs_batch: N independent files on a thread pool == one at a time; a bad file fails alone."""
     import time

@@ -645,6 +645,84 @@ def _restart_files():
     return blobs
 
 
+def test_scan_headers_that_list_components_out_of_order(hip, progressive_mode):
+    """the files of tests/test_capi_cpu.py::test_jpeg_feeder_scan_headers_that_list_components_out_of_order through the device decoders: block b of an
+    MCU is decoded with the tables and the predictor of the b-th component the SOS lists (DevImage.org), not of the component its position belongs
+    to; a repeat that changes the MCU's block count, or any repeat in a progressive interleaved scan, is rejected.  Verdict and coefficients == the
+    oracle's; a lane per interval and the multi-lane kernel (a 1080p file)."""
+    import io
+    from PIL import Image
+    import gen
+    import test_capi_cpu as T
+    files = T._scan_list_files()
+    bio = io.BytesIO(); Image.fromarray(gen.synth_rgb(1920, 1080, 31)).save(bio, "JPEG", quality=90, subsampling=2, optimize=True); files.append(bio.getvalue())
+    bio = io.BytesIO(); Image.fromarray(gen.synth_rgb(1920, 1080, 31)).save(bio, "JPEG", quality=90, subsampling=0, restart_marker_rows=16); files.append(bio.getvalue())
+    blobs = [v for f in files for v in gen.sos_component_lists(f)]
+    expect = []
+    for b in blobs:
+        try:
+            expect.append(O.DecodedJpeg(b))
+        except ValueError:
+            expect.append(None)
+    rc, hst, st, res = _entropy_decode_device(hip, blobs)
+    for k, (e, r) in enumerate(zip(expect, res)):
+        assert (hst[k] == 0 and st[k] == 0) == (e is not None), (k, hst[k], int(st[k]), "the oracle " + ("decodes it" if e is not None else "rejects it"))
+        if e is not None:
+            assert np.array_equal(r[0], e.coeffs) and np.array_equal(r[1], e.max_zag), k
+    assert sum(e is None for e in expect) >= 10 and sum(e is not None for e in expect) >= 30
+
+
+def _rst_positions(d):
+    sos = d.index(b"\xff\xda")
+    return [i for i in range(sos, len(d) - 1) if d[i] == 0xFF and 0xD0 <= d[i + 1] <= 0xD7]
+
+
+def _leftover_variants(d, which):
+    """octets between the end of a restart interval's data and its RSTn marker (`which`: the marker's number in the file)"""
+    p = _rst_positions(d)[which]
+    ins = [b"\x55" * 8, b"\x55" * 6 + b"\xff\x00\x55", b"\x11" * 1600, b"\x11" * 1400, b"\xff" * 3, b"\x11" * 1400 + b"\xff" * 200, b"\x00" * 3 + b"\xff" * 1600]
+    ins += [b"\x11" * n for n in range(1526, 1542)]                       # around the 1536 reads process_restart allows itself
+    return [d[:p] + v + d[p:] for v in ins]
+
+
+def test_octets_between_a_restart_interval_and_its_marker(hip, unstuff_site, progressive_mode):
+    """process_restart (jpegload.d:2335-2402) looks for the marker from where the decoder's INPUT stands (4 + 2 * (bits used / 16) octets into the
+    interval, never past the marker): up to 1536 raw bytes to a 0xFF, its fill bytes, then the expected RSTn.  A damaged file may have whole octets
+    between an interval's last bit and the marker: skipped if none is 0xFF and all of it fits in the 1536 reads, JPGD_BAD_RESTART_MARKER otherwise.
+    The device decodes intervals independently of each other and used to ignore what lies behind an interval's data (found by tools/fuzz_mixed_gpu.py
+    against the oracle in round 4); now the kernel that decodes an interval judges its leftover (restart_leftover_bad).  Verdict == the oracle's file
+    by file, coefficients too where it decodes: a lane per interval, the multi-lane kernel (long intervals), progressive scans of every kind."""
+    import io
+    from PIL import Image
+    import gen
+    import jpeg_scripts as JS
+    bio = io.BytesIO(); Image.fromarray(gen.synth_rgb(160, 96, 32)).save(bio, "JPEG", quality=90, subsampling=2, restart_marker_blocks=3); small = bio.getvalue()
+    bio = io.BytesIO(); Image.fromarray(gen.synth_rgb(1920, 1080, 31)).save(bio, "JPEG", quality=92, subsampling=2, restart_marker_rows=8); big = bio.getvalue()
+    prog = JS.progressive_with_script(small, JS.LIBJPEG_DEFAULT, restart=4)
+    n_prog = len(_rst_positions(prog))
+    blobs = _leftover_variants(small, 2) + _leftover_variants(small, len(_rst_positions(small)) - 1) + _leftover_variants(big, 1)
+    for which in range(0, n_prog, max(1, n_prog // 12)):                  # markers of every scan of the script (DC first / refine, AC first / refine)
+        blobs += _leftover_variants(prog, which)
+    # and behind the LAST interval (no marker to find: whatever lies between the last block and the EOI is nobody's)
+    bio = io.BytesIO(); Image.fromarray(gen.synth_rgb(1920, 1080, 31)).save(bio, "JPEG", quality=92, subsampling=2); plain = bio.getvalue()
+    for d in (small, big, plain, prog):
+        blobs += [d[:-2] + b"\x11" * 1400 + d[-2:], d[:-2] + b"\x11" * 7000 + d[-2:], d[:-2] + b"\x11\xff\x00" * 500 + d[-2:]]
+    expect = []
+    for b in blobs:
+        try:
+            expect.append(O.DecodedJpeg(b))
+        except ValueError:
+            expect.append(None)
+    assert sum(e is None for e in expect) > len(blobs) // 4 and sum(e is not None for e in expect) > len(blobs) // 4
+    rc, hst, st, res = _entropy_decode_device(hip, blobs)
+    for k, (e, r) in enumerate(zip(expect, res)):
+        assert (hst[k] == 0) == (e is not None), (k, hst[k], int(st[k]), "the oracle " + ("decodes it" if e is not None else "rejects it"))
+        if e is not None:
+            assert st[k] == 0 and np.array_equal(r[0], e.coeffs) and np.array_equal(r[1], e.max_zag), k
+        else:
+            assert hst[k] == _capi.ERR_DECODE
+
+
 def test_device_unstuff_equals_host_unstuff(hip, unstuff_site):
     """the scan as it is in the file -> unstuffed, padded, cut at its restart markers: on the device (k_jpeg_unstuff: get_bits_no_markers'
     FF00 rule jpegload.d:722-743, process_restart :2335-2402) and on the host threads -- the coefficients must be the oracle's either way:

@@ -565,13 +565,57 @@ int decode_coeffs(const uint8_t* data, size_t len, gamut_hip_jpeg_frame* f)
 // compressed bytes go to the device as they are (230 kB instead of 6.3 MB of coefficients per 1080p image over PCIe) and
 // k_jpeg_entropy writes the same dense de-quantised coefficient form decode_next_row (:2405-2525) produces, straight
 // into HBM, ready for k_jpeg_h2v2 / k_jpeg_generic.  Same arithmetic as decode_baseline() above, which is its oracle.
+#ifndef JPEG_HUFF_SUB_ENTRIES      // (tools/variant.sh knob; the standard tables need 144 / 150 entries)
+#define JPEG_HUFF_SUB_ENTRIES 256
+#endif
 struct DevHuff {                       // one Huffman table (shared by every image that uses the same table)
     uint16_t fast[512];                // 9-bit lookahead -> (length << 8) | symbol, 0 = longer code
     int32_t  maxcode[18];
     int32_t  delta[17];
     uint8_t  vals[256];
     uint8_t  pad[4];
+    // codes of more than 9 bits, second level: fast[p] of a 9-bit prefix p that only longer codes begin with = 0x8000 | x << 12 | offset: the next
+    // x bits (x = the longest such code's length - 9, 1 .. 7) index sub[offset ..] -> (length << 8) | symbol, 0 = no such code.  A table whose
+    // second levels do not fit in sub[] keeps fast[p] = 0 for the prefixes that did not (and the canonical search over maxcode[] finds the code,
+    // as it did for every long code before round 4: up to eight dependent LDS reads, and with 64 lanes per wave SOME lane has a long code in most steps).
+    uint16_t sub[JPEG_HUFF_SUB_ENTRIES];
 };
+constexpr uint32_t kHuffLong = 0x8000u;
+inline void to_dev_huff(const HuffTable& h, DevHuff& d)
+{
+    memset(&d, 0, sizeof(d));
+    for (int w = 0; w < 512; ++w) { const uint16_t e = h.fast[w << 1]; d.fast[w] = (e >> 8) <= 9 ? e : 0; }   // 10-bit table -> 9-bit
+    memcpy(d.maxcode, h.maxcode, sizeof(d.maxcode)); memcpy(d.delta, h.delta, sizeof(d.delta)); memcpy(d.vals, h.vals, sizeof(d.vals));
+    // second level: the longest code under every 9-bit prefix, then the codes themselves (canonical order: bits[] / vals[])
+    uint8_t longest[512] = { 0 };
+    int code = 0, k = 0;
+    for (int len = 1; len <= 16; ++len) {
+        for (int i = 0; i < h.bits[len]; ++i, ++code) if (len > 9) { uint8_t& m = longest[(code >> (len - 9)) & 511]; if (len > m) m = (uint8_t)len; }
+        code <<= 1;
+    }
+    int used = 0;
+    uint16_t off[512];
+    for (int p = 0; p < 512; ++p) {
+        off[p] = 0xFFFF;
+        if (!longest[p] || d.fast[p]) continue;                  // (a prefix shorter codes cover cannot begin a longer one: the table is a prefix code)
+        const int n = 1 << (longest[p] - 9);
+        if (used + n > (int)(sizeof(d.sub) / sizeof(d.sub[0]))) continue;
+        off[p] = (uint16_t)used; used += n;
+        d.fast[p] = (uint16_t)(kHuffLong | (uint32_t)(longest[p] - 9) << 12 | off[p]);
+    }
+    code = 0; k = 0;
+    for (int len = 1; len <= 16; ++len) {
+        for (int i = 0; i < h.bits[len]; ++i, ++code, ++k) {
+            if (len <= 9) continue;
+            const int p = (code >> (len - 9)) & 511;
+            if (off[p] == 0xFFFF) continue;
+            const int x = longest[p] - 9, have = len - 9;         // the code's bits behind the prefix, left-aligned in the x index bits
+            const int first = (code & ((1 << have) - 1)) << (x - have), n = 1 << (x - have);
+            for (int j = 0; j < n; ++j) d.sub[off[p] + first + j] = (uint16_t)((len << 8) | h.vals[k]);
+        }
+        code <<= 1;
+    }
+}
 struct DevImage {
     int64_t coeff_off, zag_off;        // int16 elements / bytes from the start of the caller's buffers
     int32_t nb, org;                   // blocks per MCU; component of block b = (org >> 2 * b) & 3: the order the SOS lists them in (scan_block_order)
@@ -631,7 +675,12 @@ struct DevBits {
     {
         refill();
         const uint32_t e = h->fast[peek(9)];
-        if (e) { drop((int)(e >> 8)); return (int)(e & 0xFF); }
+        if (e && e < kHuffLong) { drop((int)(e >> 8)); return (int)(e & 0xFF); }
+        if (e) {                                                // a longer code: the second level (DevHuff.sub)
+            const int xb = (int)(e >> 12) & 7;
+            const uint32_t e2 = h->sub[(e & 0xFFFu) + (peek(9 + xb) & ((1u << xb) - 1u))];
+            if (e2) { drop((int)(e2 >> 8)); return (int)(e2 & 0xFF); }
+        }
         int32_t code = (int32_t)peek(9); int len = 9;
         while (code > h->maxcode[len]) { if (++len > 16) return -1; code = (int32_t)peek(len); }
         drop(len);
@@ -647,8 +696,16 @@ struct DevBits {
 };
 
 constexpr size_t kBlobSlack = 1024;                          // bytes a lane may read past the last segment: one block + look-ahead in k_jpeg_entropy; in k_prog_scan the 64-byte limit check + a block's worth of a corrupt AC scan (244 bytes) + the 256-byte window
+#ifndef JPEG_HUFF_SUB              // A/B knob (tools/variant.sh jpeg_host:nosub:-DJPEG_HUFF_SUB=0): 0 = no second-level Huffman look-up in sub_decode
+#define JPEG_HUFF_SUB 1
+#endif
+// Lanes per long segment.  A group of 256 files is 256 workgroups -- one per compute unit: with 256 lanes that is ONE wave per SIMD, a chain of
+// dependent instructions at 8 clocks each (tools/microbench/chain_latency.hip) over 880 bytes per lane and pass.  512 lanes: half the bytes per
+// lane, two waves per SIMD to alternate between; the passes to the fixed point grow by less.  Round 4, one box, rocprofv3: the compact kernel
+// 3.49 -> 2.80 ms per group of 256 files (1024 lanes: 2.99), files -> pixels 256 files 5.9-6.7 -> 5.0-5.1 ms, 1024 files 15.6 / 15.6 / 15.0 ->
+// 15.1 / 13.6 / 14.8 (a slow box), 4096 files and the mixed call unchanged (there the GPU is full either way) -- profiles/r04_jpeg_sync_lanes.txt.
 #ifndef JPEG_SYNC_THREADS          // tuning knob (tools/variant.sh)
-#define JPEG_SYNC_THREADS 256
+#define JPEG_SYNC_THREADS 512
 #endif
 constexpr int kEntropyThreads = 64;                          // one wave per workgroup: lanes spread over CUs, each with its own L1
 constexpr int kLdsHuff = JPEG_SYNC_THREADS >= 1024 ? 4 : 8, kLdsQuant = kLdsHuff;                     // tables a workgroup keeps in LDS (15 KB + 1 KB: two encoders' sets; more distinct tables in a batch are read from global memory)
@@ -852,7 +909,12 @@ __device__ __forceinline__ bool sub_decode(const SubCtx& x, SubState& s, int& nb
     nblk = 0;
     bool ok = true;
     bool inherited = z > 0;                                                      // the block under way was started by another lane
-    const int q0 = x.par[0], q1 = x.par[1], q2 = x.par[2], d0 = x.par[3], d1 = x.par[4], d2 = x.par[5], a0 = x.par[6], a1 = x.par[7], a2 = x.par[8];
+    const int q0 = x.par[0], q1 = x.par[1], q2 = x.par[2];
+    // the tables' addresses, not their numbers: no multiply (a quarter-rate instruction) per symbol.  (Through an empty asm: the compiler otherwise
+    // selects among the numbers and multiplies afterwards, as the source used to.)
+    const DevHuff* hd0 = x.huff + x.par[3]; const DevHuff* hd1 = x.huff + x.par[4]; const DevHuff* hd2 = x.huff + x.par[5];
+    const DevHuff* ha0 = x.huff + x.par[6]; const DevHuff* ha1 = x.huff + x.par[7]; const DevHuff* ha2 = x.huff + x.par[8];
+    asm volatile("" : "+v"(hd0), "+v"(hd1), "+v"(hd2), "+v"(ha0), "+v"(ha1), "+v"(ha2));
     int dc0 = dcs[0], dc1 = dcs[1], dc2 = dcs[2];
     int ntok = 0;
     int ck_j = 0;                                                                // checkpoints passed
@@ -863,12 +925,19 @@ __device__ __forceinline__ bool sub_decode(const SubCtx& x, SubState& s, int& nb
         br.refill();                                                             // >= 33 bits: a code (<= 16) and its value (<= 15)
         const int comp = (int)(x.org >> (2 * c)) & 3;
         const bool is_dc = z == 0;
-        const DevHuff* h = x.huff + (is_dc ? (comp == 0 ? d0 : comp == 1 ? d1 : d2) : (comp == 0 ? a0 : comp == 1 ? a1 : a2));
+        const DevHuff* h = is_dc ? (comp == 0 ? hd0 : comp == 1 ? hd1 : hd2) : (comp == 0 ? ha0 : comp == 1 ? ha1 : ha2);
         const uint32_t top16 = br.peek(16);
-        const uint32_t e = h->fast[top16 >> 7];
+        uint32_t e = h->fast[top16 >> 7];
+#if !JPEG_HUFF_SUB
+        if (e >= kHuffLong) e = 0;                                               // (A/B: the canonical search for every long code, as before round 4)
+#endif
+        if (e >= kHuffLong) {                                                    // a code of more than 9 bits: the second level
+            const uint32_t xb = (e >> 12) & 7u;
+            e = h->sub[(e & 0xFFFu) + ((top16 >> (7u - xb)) & ((1u << xb) - 1u))];
+        }
         int len = (int)(e >> 8), sym = (int)(e & 0xFFu);
         bool bad = false;
-        if (!e) {                                                                // a code of more than 9 bits
+        if (!e) {                                                                // no second level for this prefix, or no such code: the canonical search
             int32_t code = (int32_t)(top16 >> 7); len = 9;
             while (code > h->maxcode[len]) { if (++len > 16) break; code = (int32_t)(top16 >> (16 - len)); }
             bad = len > 16;                                                      // no such code: the block ends here, 16 bits are skipped
@@ -1363,10 +1432,7 @@ void prepare_header(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& 
     for (int c = 0; c < f.comps; ++c) {
         memcpy(out.quant[c].q, P.quant[P.tq[c]], sizeof(out.quant[c].q));
         for (int k = 0; k < 2; ++k) {
-            const HuffTable& h = P.huff[k ? P.ta[c] : P.td[c]];
-            DevHuff& d = out.huff[c][k]; memset(&d, 0, sizeof(d));
-            for (int w = 0; w < 512; ++w) { const uint16_t e = h.fast[w << 1]; d.fast[w] = (e >> 8) <= 9 ? e : 0; }   // 10-bit table -> 9-bit
-            memcpy(d.maxcode, h.maxcode, sizeof(d.maxcode)); memcpy(d.delta, h.delta, sizeof(d.delta)); memcpy(d.vals, h.vals, sizeof(d.vals));
+            to_dev_huff(P.huff[k ? P.ta[c] : P.td[c]], out.huff[c][k]);
         }
     }
     out.scan_pos = P.pos; out.restart_interval = P.restart_interval; out.total_mcus = f.mcus_per_row * f.mcus_per_col;

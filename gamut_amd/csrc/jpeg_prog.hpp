@@ -393,6 +393,7 @@ __device__ __forceinline__ uint32_t prog_ac_refine(ProgSync sy, AcRefineArgs a, 
     {
         const int nat = (int)zag_reg;
         const uint64_t band = (se >= 63 ? ~0ull : (1ull << (se + 1)) - 1) & ~((1ull << ss) - 1);
+        const uint64_t m_outside = se >= 63 ? 0ull : ~0ull << (se + 1);      // "positions from the stop on" of a run that leaves the band: none of the band's
         const int plus = 1 << al, minus = (int)(0xFFFFFFFFu << al);
         // Bit reader.  The scalar chain only ever needs the next code and, behind an EOBn code, up to 14 more bits: 30 bits at `pos`.
         // Sign and correction bits are fetched by the lanes they belong to, from memory, when the block is done.  So there is no window
@@ -496,10 +497,10 @@ __device__ __forceinline__ uint32_t prog_ac_refine(ProgSync sy, AcRefineArgs a, 
                                 "s_and_b32 %[t2], %[t0], 63\n"
                                 "v_readlane_b32 %[stop], %[pz], %[t2]\n"
                                 "s_add_u32 %[t1], %[pos], %[t1]\n"             // P = pos + used
-                                "s_cmp_lt_u32 %[t0], %[Z]\n"                   // inside?
-                                "s_cselect_b32 %[stop], %[stop], %[se1]\n"
-                                "s_lshl_b64 %[m], -1, %[stop]\n"               // positions from stop on (stop <= 63 when inside)
-                                "s_cselect_b64 %[m], %[m], 0\n"                // outside: everything that is left is below
+                                "s_lshl_b64 %[m], -1, %[stop]\n"               // positions from stop on (a lane of pz: <= 63).  (Sets SCC: the comparison comes
+                                "s_cmp_lt_u32 %[t0], %[Z]\n"                   // AFTER it -- inside?  Until round 4's fuzz_mixed_gpu.py run the shift stood behind
+                                "s_cselect_b32 %[stop], %[stop], %[se1]\n"     // the comparison and the select below saw the shift's SCC: a run that left a band
+                                "s_cselect_b64 %[m], %[m], %[mo]\n"            // ending at 63 (stop = 64, a shift by 0) corrected nothing of what was left.)
                                 "s_andn2_b64 %[corr], %[nzr], %[m]\n"
                                 "s_and_b64 %[nzr], %[nzr], %[m]\n"
                                 "s_bcnt1_i32_b64 %[t2], %[corr]\n"             // c
@@ -519,7 +520,7 @@ __device__ __forceinline__ uint32_t prog_ac_refine(ProgSync sy, AcRefineArgs a, 
                                 "v_cndmask_b32 %[mybit], %[mybit], %[v1], vcc\n"
                                 : [stop] "=&s"(stop), [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3), [m] "=&s"(m), [corr] "=&s"(corr), [v0] "=&v"(v0), [v1] "=&v"(v1),
                                   [zc] "+s"(zc), [pos] "+s"(pos), [nzr] "+s"(nzr), [nc] "+s"(nc), [mybit] "+v"(mybit)
-                                : [ent] "s"(ent), [pz] "v"(pz), [Z] "s"(Z), [se1] "s"(se + 1), [rk] "v"(rk), [hist] "s"(hist_mask), [lane] "v"(lane)
+                                : [ent] "s"(ent), [pz] "v"(pz), [Z] "s"(Z), [se1] "s"(se + 1), [mo] "s"(m_outside), [rk] "v"(rk), [hist] "s"(hist_mask), [lane] "v"(lane)
                                 : "scc", "vcc");
                             k = (int)stop + 1;
                         }
@@ -641,12 +642,6 @@ __global__ __launch_bounds__(256) void k_prog_finalize(const ProgImage* images, 
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
-inline void to_dev_huff(const HuffTable& h, DevHuff& d)
-{
-    memset(&d, 0, sizeof(d));
-    for (int w = 0; w < 512; ++w) { const uint16_t e = h.fast[w << 1]; d.fast[w] = (e >> 8) <= 9 ? e : 0; }   // 10-bit table -> 9-bit
-    memcpy(d.maxcode, h.maxcode, sizeof(d.maxcode)); memcpy(d.delta, h.delta, sizeof(d.delta)); memcpy(d.vals, h.vals, sizeof(d.vals));
-}
 
 // The highest zig-zag position a scan may WRITE: an AC first scan stores a coefficient wherever its runs take it up to 63 (decode_block_ac_first
 // :3361-3380 checks k against 63, not against Se), an AC refinement scan sets the position its run ends at if that is < 64 (:3485-3488), i.e.
@@ -709,7 +704,8 @@ void prog_prepare(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& f,
         if (!dc_scan && sc.ncomp != 1) return bad("AC scans can only contain one component");
         if (scan_lists_a_component_twice(sc)) return bad("the scan lists a component twice");   // decode_scan's walk leaves the component's plane (coeff_buf_getp :3293)
         if (refine && sc.al != sc.ah - 1) return bad("bad SOS successive approximation");
-        if (sc.al > 13) return bad("bad SOS successive approximation");
+        // (Al is a nibble: the standard stops at 13, read_sos_marker :1466-1540 does not, and every use of it here wraps in 16 bits as the reference's
+        //  jpgd_block_t arithmetic does -- tests/golden/jpeg_fuzz/prog_al14_r04.jpg, found by tools/fuzz_mixed_gpu.py when this line still rejected Al > 13)
         for (int k = 0; k < sc.ncomp; ++k) {
             const int c = sc.comp[k];
             if (!P.quant_def[P.tq[c]]) return bad("undefined quant table");

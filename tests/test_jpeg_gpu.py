@@ -510,6 +510,37 @@ def test_device_progressive_damaged_scan_that_leaves_its_band(hip, progressive_m
         assert np.array_equal(co, d.coeffs) and np.array_equal(zz, d.max_zag), np.argwhere(co != d.coeffs)[:4].tolist()
 
 
+def test_device_progressive_successive_approximation_beyond_the_standard(hip, progressive_mode):
+    """tests/golden/jpeg_fuzz/prog_al14_r04.jpg (tools/fuzz_mixed_gpu.py, round 4): an AC scan whose Ah/Al byte was damaged into Al = 14.  The standard
+    allows 0 .. 13; read_sos_marker (jpegload.d:1466-1540) takes the nibble as it is and the shifts wrap in jpgd_block_t (16 bits).  The device path used
+    to reject the file; now it decodes it like the oracle, as it does hand-made files with Al = 14 / 15 in first and refinement scans of either kind."""
+    data = open(os.path.join(HERE, "golden", "jpeg_fuzz", "prog_al14_r04.jpg"), "rb").read()
+    blobs = [data]
+    files = _progressive_files()
+    for good in (files[4], files[6]):                          # 203 x 117: 4:2:0 with restart intervals, 4:4:4 at quality 100
+        at = [i for i in range(len(good) - 1) if good[i] == 0xFF and good[i + 1] == 0xDA]
+        for sos in at:                                         # every scan of the file in turn: Al = 14 (first scans) / Ah = 15, Al = 14 (refinements); Al = 15
+            ns = good[sos + 4]
+            j = sos + 5 + 2 * ns + 2
+            b = bytearray(good)
+            b[j] = 0xFE if good[j] >> 4 else 0x0E
+            blobs.append(bytes(b))
+            b[j] = 0x0F
+            blobs.append(bytes(b))
+    expect = []
+    for b in blobs:
+        try:
+            expect.append(O.DecodedJpeg(b))
+        except ValueError:
+            expect.append(None)
+    assert expect[0] is not None and sum(e is not None for e in expect) >= len(blobs) // 2
+    rc, hst, st, res = _entropy_decode_device(hip, blobs)
+    for k, (e, r) in enumerate(zip(expect, res)):
+        assert (hst[k] == 0 and st[k] == 0) == (e is not None), (k, hst[k], int(st[k]))
+        if e is not None:
+            assert np.array_equal(r[0], e.coeffs) and np.array_equal(r[1], e.max_zag), (k, np.argwhere(r[0] != e.coeffs)[:4].tolist())
+
+
 def test_device_progressive_corrupt_streams(hip):
     """damaged scans of progressive files on the GPU path: no hang, nothing written outside the file's buffers, the damaged
     files flagged (a scan that decodes to the end without an impossible code is not an error for the reference either);

@@ -3,7 +3,7 @@
 every file against the oracle's decoder for what it claims to be: decompress_jpeg_image_from_memory (baseline and progressive; files -> PIXELS,
 i.e. the GPU entropy decoders AND the reconstruction kernels), stbi_load, qoi_decode -- same verdict, same pixels, and nothing written outside
 a file's slot.  A JPEG whose entropy data is damaged decodes to SOME picture in both decoders (neither checks the stream's end): compared all the same.
-Usage: python tools/fuzz_mixed_gpu.py [batches=30] [seed=5]"""
+Usage: python tools/fuzz_mixed_gpu.py [batches=30] [seed=5]      GAMUT_FUZZ_HEADERS=1: damage the headers too (bit flips / byte changes in front of the data)"""
 import ctypes as C
 import io
 import os
@@ -21,12 +21,17 @@ import torch  # noqa: E402,F401
 from gamut_amd import _capi, synth  # noqa: E402
 
 
+HEADERS = os.environ.get("GAMUT_FUZZ_HEADERS", "") not in ("", "0")     # also damage the bytes in front of `lo` (JPEG: the marker segments before the first scan)
+
+
 def mutate(rng, f, lo):
     s = bytearray(f)
     for _ in range(int(rng.integers(1, 4))):
         if len(s) < lo + 8:
             break
         kind = int(rng.integers(0, 4)); i = int(rng.integers(lo, len(s)))
+        if HEADERS and lo > 16 and rng.integers(0, 3) == 0:
+            kind = 0 if rng.integers(0, 2) else 3; i = int(rng.integers(2, lo))
         if kind == 0: s[i] ^= 1 << int(rng.integers(0, 8))
         elif kind == 1: s = s[:i]
         elif kind == 2: s[i:i] = bytes(rng.integers(0, 256, int(rng.integers(1, 6)), dtype=np.uint8))
@@ -69,6 +74,21 @@ def main():
             else:
                 exp.append(None)
         bufs = [np.frombuffer(f, np.uint8) if len(f) else np.zeros(1, np.uint8) for f in files]
+        if HEADERS:                                                                  # a damaged header may ask for a larger picture than a slot: as a caller would, ask the
+            for i in range(n):                                                       # header readers; such a file is replaced by its seed (the tool's slots are fixed)
+                wh = None
+                if files[i][:2] == b"\xff\xd8":
+                    fr = _capi.JpegFrame()
+                    if L.gamut_hip_jpeg_read_header(bufs[i].ctypes.data, len(files[i]), C.byref(fr)) == 0: wh = (fr.width, fr.height)
+                elif files[i][:4] == b"\x89PNG":
+                    pi = _capi.PngInfo()
+                    if L.gamut_hip_png_read_header(bufs[i].ctypes.data, len(files[i]), C.byref(pi)) == 0: wh = (pi.width, pi.height)
+                elif files[i][:4] == b"qoif":
+                    qd = _capi.QoiDesc()
+                    if L.gamut_hip_qoi_read_header(bufs[i].ctypes.data, len(files[i]), C.byref(qd)) == 0: wh = (qd.width, qd.height)
+                if wh is not None and wh[0] * wh[1] * 4 + 64 > cap:
+                    files[i] = seeds[0][0]; bufs[i] = np.frombuffer(files[i], np.uint8)
+                    r = O.decompress_jpeg(files[i], rc); exp[i] = np.ascontiguousarray(r[0]).reshape(-1)
         ptrs = (C.c_void_p * n)(*[x.ctypes.data for x in bufs]); lens = (C.c_size_t * n)(*[len(f) for f in files])
         offs = np.arange(n, dtype=np.int64) * cap
         out = torch.full((n * cap,), 0xA5, dtype=torch.uint8, device="cuda")
@@ -93,7 +113,8 @@ def main():
             if not np.array_equal(got[i][:exp[i].size], exp[i]):
                 save(); bad = np.argwhere(got[i][:exp[i].size] != exp[i])
                 raise AssertionError(f"batch {b} file {i} ({files[i][:4]!r}, {len(files[i])} bytes, saved): {len(bad)} of {exp[i].size} bytes differ, first at {int(bad[0][0])}")
-            assert (got[i][exp[i].size:] == 0xA5).all(), f"batch {b} file {i}: wrote past its picture"
+            if not (got[i][exp[i].size:] == 0xA5).all():
+                save(); raise AssertionError(f"batch {b} file {i} ({files[i][:4]!r}, saved): wrote past its picture ({info[i].width}x{info[i].height}x{info[i].channels}; the oracle's has {exp[i].size} bytes)")
             n_same += 1
     print(f"fuzz_mixed_gpu: {batches} batches of 48 files: {n_same} decoded like the oracle's decoder of their format, {n_rej} rejected by both")
 

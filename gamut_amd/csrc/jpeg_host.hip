@@ -702,8 +702,8 @@ constexpr size_t kBlobSlack = 1024;                          // bytes a lane may
 // Lanes per long segment.  A group of 256 files is 256 workgroups -- one per compute unit: with 256 lanes that is ONE wave per SIMD, a chain of
 // dependent instructions at 8 clocks each (tools/microbench/chain_latency.hip) over 880 bytes per lane and pass.  512 lanes: half the bytes per
 // lane, two waves per SIMD to alternate between; the passes to the fixed point grow by less.  Round 4, one box, rocprofv3: the compact kernel
-// 3.49 -> 2.80 ms per group of 256 files (1024 lanes: 2.99), files -> pixels 256 files 5.9-6.7 -> 5.0-5.1 ms, 1024 files 15.6 / 15.6 / 15.0 ->
-// 15.1 / 13.6 / 14.8 (a slow box), 4096 files and the mixed call unchanged (there the GPU is full either way) -- profiles/r04_jpeg_sync_lanes.txt.
+// 3.49 -> 2.80 ms per group of 256 files (1024 lanes: 2.99), files -> pixels 256 files 5.9-6.7 -> 5.0-5.1 ms; 1024 files (inside the run-to-run
+// spread), 4096 files and the mixed call unchanged (there the GPU is full either way) -- profiles/r04_jpeg_sync_lanes.txt.
 #ifndef JPEG_SYNC_THREADS          // tuning knob (tools/variant.sh)
 #define JPEG_SYNC_THREADS 512
 #endif

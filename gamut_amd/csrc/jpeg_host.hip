@@ -1652,7 +1652,7 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
         //      first group decodes while the rest is still on its way.
         constexpr int kMaxGroups = 8;
         static const int groups_env = [] { const char* e = getenv("GAMUT_HIP_JPEG_GROUPS"); return e && *e ? atoi(e) : 0; }();        // measurements
-        const int n_groups = groups_env > 0 ? std::min(kMaxGroups, std::min(groups_env, count)) : std::max(1, std::min(kMaxGroups, count / 256));        // (1024 files: 4 groups 14.8 ms, 8 groups 16.1 ms, 2 groups 14.9 ms -- profiles/r04_jpeg_sweep.txt)
+        const int n_groups = groups_env > 0 ? std::min(kMaxGroups, std::min(groups_env, count)) : std::max(1, std::min(kMaxGroups, count / 256));        // (1024 files, a stream per group: 4 groups 14.8 ms, 8 groups 16.1 ms, 2 groups 14.9 ms -- profiles/r04_jpeg_sweep.txt; three streams in turn: 4 groups 12.7 / 13.1, 6 groups 13.1 / 13.4, 8 groups 13.2 / 13.0)
         struct EvN { hipEvent_t e[kMaxGroups]; }; struct StN { hipStream_t s[kMaxGroups]; };
         static thread_local PerDevice<EvN> group_ready_pd;
         hipEvent_t (&group_ready)[kMaxGroups] = group_ready_pd.cur().e;
@@ -1665,9 +1665,18 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
         hipStream_t (&side)[kMaxGroups] = side_pd.cur().s;
         hipEvent_t& fork = fork_pd.cur();
         if (!fork) GAMUT_HIP_CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-        for (int g = 1; g < n_groups; ++g) if (!side[g]) GAMUT_HIP_CHECK(hipStreamCreateWithFlags(&side[g], hipStreamNonBlocking));
+        // ... but not a stream per group: the runtime maps streams onto FOUR hardware queues (GPU_MAX_HW_QUEUES), a fifth stream shares one with
+        // another, and its kernels wait for that stream's.  The timeline of round 4 (profiles/r04_jpeg_timeline.txt; rocprofv3 --kernel-trace
+        // --memory-copy-trace): with `stream`, the copy stream and three side streams the LAST group's kernels started 4 ms after its bytes had
+        // arrived, when the group before it had finished.  Three compute streams, taken in turn (a group's kernels take about as long as three
+        // groups' uploads): 1024 files 14.0 / 13.6 -> 12.7 / 13.1 ms on one box (GAMUT_HIP_JPEG_STREAMS=5 is the old shape).  What is left is the
+        // GPU's own time: side by side the groups' entropy kernels slow each other down (2.1 ms alone, 3.4 - 4.5 ms beside another one and a
+        // reconstruction kernel) -- with four waves per SIMD the decode is bound by instruction issue, no longer by the length of a lane's chain.
+        static const int lanes_env = [] { const char* e = getenv("GAMUT_HIP_JPEG_STREAMS"); return e && *e ? atoi(e) : 0; }();        // measurements
+        const int n_lanes = std::max(1, std::min(n_groups, lanes_env > 0 ? std::min(lanes_env, kMaxGroups) : 3));
+        for (int g = 1; g < n_lanes; ++g) if (!side[g]) GAMUT_HIP_CHECK(hipStreamCreateWithFlags(&side[g], hipStreamNonBlocking));
         GAMUT_HIP_CHECK(hipEventRecord(fork, stream));
-        for (int g = 1; g < n_groups; ++g) GAMUT_HIP_CHECK(hipStreamWaitEvent(side[g], fork, 0));
+        for (int g = 1; g < n_lanes; ++g) GAMUT_HIP_CHECK(hipStreamWaitEvent(side[g], fork, 0));
         auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
         size_t max_items = 0;
         for (int i = 0; i < count; ++i) if (prep[(size_t)i].rc == GAMUT_HIP_OK) max_items += prep[(size_t)i].restart_interval ? (size_t)(prep[(size_t)i].total_mcus / prep[(size_t)i].restart_interval + 1) : 1;
@@ -1774,7 +1783,7 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
                 raws_done += (int)raws.size();
             }
             GAMUT_HIP_CHECK(hipEventRecord(group_ready[g], copy_stream));
-            const hipStream_t gs = g == 0 ? stream : side[g];
+            const hipStream_t gs = g % n_lanes == 0 ? stream : side[g % n_lanes];
             GAMUT_HIP_CHECK(hipStreamWaitEvent(gs, group_ready[g], 0));
             if (trace) { (void)hipStreamSynchronize(gs); ms_upload = ms_since(t_up) - ms_kernels_issue; }
             const auto t_k = std::chrono::steady_clock::now();
@@ -1808,7 +1817,7 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
             if (trace) { (void)hipStreamSynchronize(gs); ms_kernels_issue += ms_since(t_k); }
         }
         GAMUT_HIP_CHECK(hipStreamSynchronize(copy_stream));
-        for (int g = 1; g < n_groups; ++g) GAMUT_HIP_CHECK(hipStreamSynchronize(side[g]));
+        for (int g = 1; g < n_lanes; ++g) GAMUT_HIP_CHECK(hipStreamSynchronize(side[g]));
         GAMUT_HIP_CHECK(hipStreamSynchronize(stream));         // the per-thread staging buffers are reused by the next call
         if (dev_restarts) {                                    // restart markers are checked where the scan is unstuffed, what lies in front of them where it is
             std::vector<uint32_t> flags((size_t)count);        // decoded (restart_leftover_bad): either way a header-level failure of the file, as when unstuff_file finds it

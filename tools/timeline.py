@@ -18,4 +18,4 @@ for i in range(1,len(ev)):
 last=ev[cut:]
 t0=last[0][0]
 for s,e,n,q in last:
-    if (e-s)>30_000: print(f"{(s-t0)/1e6:8.3f} -> {(e-t0)/1e6:8.3f} ms ({(e-s)/1e6:6.3f})  {n} {q}")
+    if (e-s)>int(os.environ.get("TL_MIN_US","30"))*1000: print(f"{(s-t0)/1e6:8.3f} -> {(e-t0)/1e6:8.3f} ms ({(e-s)/1e6:6.3f})  {n} {q}")

@@ -566,7 +566,7 @@ int decode_coeffs(const uint8_t* data, size_t len, gamut_hip_jpeg_frame* f)
 // k_jpeg_entropy writes the same dense de-quantised coefficient form decode_next_row (:2405-2525) produces, straight
 // into HBM, ready for k_jpeg_h2v2 / k_jpeg_generic.  Same arithmetic as decode_baseline() above, which is its oracle.
 #ifndef JPEG_HUFF_SUB_ENTRIES      // (tools/variant.sh knob; the standard tables need 144 / 150 entries)
-#define JPEG_HUFF_SUB_ENTRIES 256
+#define JPEG_HUFF_SUB_ENTRIES 312      // sizeof(DevHuff) = 2048: a table's address is a shift of its number
 #endif
 struct DevHuff {                       // one Huffman table (shared by every image that uses the same table)
     uint16_t fast[512];                // 9-bit lookahead -> (length << 8) | symbol, 0 = longer code
@@ -581,6 +581,7 @@ struct DevHuff {                       // one Huffman table (shared by every ima
     uint16_t sub[JPEG_HUFF_SUB_ENTRIES];
 };
 constexpr uint32_t kHuffLong = 0x8000u;
+static_assert(JPEG_HUFF_SUB_ENTRIES != 312 || sizeof(DevHuff) == 2048, "DevHuff: a power of two");
 inline void to_dev_huff(const HuffTable& h, DevHuff& d)
 {
     memset(&d, 0, sizeof(d));
@@ -910,11 +911,9 @@ __device__ __forceinline__ bool sub_decode(const SubCtx& x, SubState& s, int& nb
     bool ok = true;
     bool inherited = z > 0;                                                      // the block under way was started by another lane
     const int q0 = x.par[0], q1 = x.par[1], q2 = x.par[2];
-    // the tables' addresses, not their numbers: no multiply (a quarter-rate instruction) per symbol.  (Through an empty asm: the compiler otherwise
-    // selects among the numbers and multiplies afterwards, as the source used to.)
-    const DevHuff* hd0 = x.huff + x.par[3]; const DevHuff* hd1 = x.huff + x.par[4]; const DevHuff* hd2 = x.huff + x.par[5];
-    const DevHuff* ha0 = x.huff + x.par[6]; const DevHuff* ha1 = x.huff + x.par[7]; const DevHuff* ha2 = x.huff + x.par[8];
-    asm volatile("" : "+v"(hd0), "+v"(hd1), "+v"(hd2), "+v"(ha0), "+v"(ha1), "+v"(ha2));
+    // (the table is picked by NUMBER and addressed by a shift: sizeof(DevHuff) is 2048.  Picking among six addresses kept apart by an empty asm
+    //  cost the loads their address space -- flat loads with 64-bit addresses instead of ds_read -- and a multiply by 1936 is a quarter-rate instruction.)
+    const int d0 = x.par[3], d1 = x.par[4], d2 = x.par[5], a0 = x.par[6], a1 = x.par[7], a2 = x.par[8];
     int dc0 = dcs[0], dc1 = dcs[1], dc2 = dcs[2];
     int ntok = 0;
     int ck_j = 0;                                                                // checkpoints passed
@@ -925,7 +924,7 @@ __device__ __forceinline__ bool sub_decode(const SubCtx& x, SubState& s, int& nb
         br.refill();                                                             // >= 33 bits: a code (<= 16) and its value (<= 15)
         const int comp = (int)(x.org >> (2 * c)) & 3;
         const bool is_dc = z == 0;
-        const DevHuff* h = is_dc ? (comp == 0 ? hd0 : comp == 1 ? hd1 : hd2) : (comp == 0 ? ha0 : comp == 1 ? ha1 : ha2);
+        const DevHuff* h = x.huff + (is_dc ? (comp == 0 ? d0 : comp == 1 ? d1 : d2) : (comp == 0 ? a0 : comp == 1 ? a1 : a2));
         const uint32_t top16 = br.peek(16);
         uint32_t e = h->fast[top16 >> 7];
 #if !JPEG_HUFF_SUB

@@ -127,55 +127,64 @@ int applyLoadFlags(int type, int f)             // internals/types.d:627-661
     return type;
 }
 
-// ---- allocatePixelStorage (internals/types.d:355-540) ----
+// ---- pixel storage (what internals/types.d:355-540 allocates, and where the first pixel stands in it) ----
+// The layout constraints translate into a geometry -- bytes per row, rows per layer, the byte where pixel (0, 0) of layer 0 stands -- that is
+// worked out first and on its own (PlaneGeometry::plan), the same for host and HBM storage; getting the bytes and orienting the rows come after.
 struct Storage { uint8_t* data = nullptr; uint8_t* alloc = nullptr; int pitch = 0; int layerOffset = 0; };
-// device: the pixels live in HBM (hipMalloc) instead of host malloc memory -- same layout arithmetic on the device address
+struct PlaneGeometry {
+    int row_bytes = 0;            // distance between two rows (before any flip), a multiple of the scanline alignment
+    long long layer_rows = 0;     // rows one layer occupies, its borders included
+    long long total = 0;          // bytes to obtain: all layers + slack to align the first row + the caller's bonus bytes in front
+    size_t lead = 0;              // bytes in front of pixel (0, 0) of layer 0 (bonus bytes, the top border's rows, the left border) before alignment
+    int align = 1;
+    static size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+    bool plan(int type, int layers, int w, int h, int constraints, int bonus)
+    {
+        const int frame = layoutBorderWidth(constraints);                       // pixels around every layer
+        const int tail = layoutTrailingPixels(constraints), step = layoutMultiplicity(constraints);
+        align = layoutScanlineAlignment(constraints);
+        const int px = kPixelSize[type];
+        // behind the last pixel of a row: the frame, widened until (left frame + width) is a whole number of `step` pixels, and never
+        // fewer than the trailing pixels the constraint asks for
+        const int used = frame + w;
+        const int right = std::max(tail, frame + (int)(round_up((size_t)used, (size_t)step) - (size_t)used));
+        row_bytes = (int)round_up((size_t)px * (size_t)(used + right), (size_t)align);
+        layer_rows = (long long)h + 2LL * frame;
+        total = (long long)row_bytes * layer_rows * layers + (align - 1) + bonus;
+        lead = (size_t)bonus + (size_t)row_bytes * (size_t)frame + (size_t)px * (size_t)frame;
+        return total <= MAX_BYTES;
+    }
+};
+// device: the pixels live in HBM (hipMalloc) instead of host malloc memory -- same geometry on the device address
 bool allocatePixelStorage(uint8_t* existing, int type, int layers, int width, int height, int constraints, int bonusBytes,
                           bool clearWithZeroes, Storage& out, bool device = false)
 {
     if (!imageIsValidSize(layers, width, height)) return false;
-    const int border = layoutBorderWidth(constraints), rowAlignment = layoutScanlineAlignment(constraints);
-    const int trailingPixels = layoutTrailingPixels(constraints), xMultiplicity = layoutMultiplicity(constraints);
-    auto nextMultipleOf = [](size_t base, size_t multiple) { return multiple * ((base + multiple - 1) / multiple); };
-    const int rightPadding = (int)nextMultipleOf((size_t)(width + border), (size_t)xMultiplicity) - (width + border);
-    int borderRight = border + rightPadding;
-    if (borderRight < trailingPixels) borderRight = trailingPixels;
-    const int actualWidthInPixels = border + width + borderRight;
-    const long long actualHeightOfOneLayer = (long long)border + height + border;
-    const long long actualHeightInPixels = actualHeightOfOneLayer * layers;
-    const int pixelSize = kPixelSize[type];
-    int bytePitch = pixelSize * actualWidthInPixels;
-    bytePitch = (int)nextMultipleOf((size_t)bytePitch, (size_t)rowAlignment);
-    long long sizeNeeded = (long long)bytePitch * actualHeightInPixels + (rowAlignment - 1) + bonusBytes;
-    if (sizeNeeded > MAX_BYTES) return false;
-    const size_t allocationSize = (size_t)sizeNeeded;
-    uint8_t* allocation;
+    PlaneGeometry g;
+    if (!g.plan(type, layers, width, height, constraints, bonusBytes)) return false;
+    const size_t bytes = (size_t)g.total;
+    uint8_t* base = nullptr;
+    auto give_back = [&] { if (device) (void)hipFree(base); else free(base); };
     if (device) {
         if (existing) (void)hipFree(existing);
         void* p = nullptr;
-        if (hipMalloc(&p, allocationSize ? allocationSize : 1) != hipSuccess) return false;
-        allocation = (uint8_t*)p;
-        if (clearWithZeroes && allocationSize > 0 && hipMemset(allocation, 0, allocationSize) != hipSuccess) { (void)hipFree(allocation); return false; }
+        if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return false;
+        base = (uint8_t*)p;
+        if (clearWithZeroes && bytes && hipMemset(base, 0, bytes) != hipSuccess) { give_back(); return false; }
     } else {
-        allocation = (uint8_t*)realloc(existing, allocationSize);
-        if (allocationSize != 0 && !allocation) return false;
-        if (clearWithZeroes && allocationSize > 0) memset(allocation, 0, allocationSize);
+        base = (uint8_t*)realloc(existing, bytes);
+        if (bytes && !base) return false;
+        if (clearWithZeroes && bytes) memset(base, 0, bytes);
     }
-    const size_t offsetToFirst = (size_t)bonusBytes + (size_t)bytePitch * border + (size_t)pixelSize * border;
-    uint8_t* pixels = (uint8_t*)nextMultipleOf((size_t)(allocation + offsetToFirst), (size_t)rowAlignment);
-    uint8_t* first = pixels; int pitch = bytePitch;
-    const bool forceFlip = (constraints & GAMUT_LAYOUT_VERT_FLIPPED) != 0, forceStraight = (constraints & GAMUT_LAYOUT_VERT_STRAIGHT) != 0;
-    if ((forceFlip && pitch > 0) || (forceStraight && pitch < 0)) {          // flipScanlinePointers :294-306
-        if (height >= 2) first += (ptrdiff_t)pitch * (height - 1);
-        pitch = -pitch;
-    }
-    out.data = first; out.pitch = pitch; out.alloc = allocation;
-    if (layers == 0 || layers == 1) out.layerOffset = 0;
-    else {
-        const long long off = (long long)bytePitch * actualHeightOfOneLayer;
-        if (off > 2147483647LL) { if (device) (void)hipFree(allocation); else free(allocation); return false; }
-        out.layerOffset = (int)off;
-    }
+    const long long between_layers = layers > 1 ? (long long)g.row_bytes * g.layer_rows : 0;
+    if (between_layers > 2147483647LL) { give_back(); return false; }
+    uint8_t* origin = (uint8_t*)PlaneGeometry::round_up((size_t)(base + g.lead), (size_t)g.align);
+    // rows stored bottom-up when the constraint says so (flipScanlinePointers :294-306: the pointer goes to the last row, the pitch turns negative)
+    const bool bottom_up = (constraints & GAMUT_LAYOUT_VERT_FLIPPED) != 0;
+    out.alloc = base;
+    out.data = bottom_up && height >= 2 ? origin + (ptrdiff_t)g.row_bytes * (height - 1) : origin;
+    out.pitch = bottom_up ? -g.row_bytes : g.row_bytes;
+    out.layerOffset = (int)between_layers;
     return true;
 }
 

@@ -115,6 +115,28 @@ def test_jpeg_feeder_scan_headers_that_list_components_out_of_order():
     assert n_ok >= 20 and n_rej >= 10 and n_changed >= 15, (n_ok, n_rej, n_changed)
 
 
+FUZZ_FOUND = sorted(os.path.join(G, "jpeg_fuzz", n) for n in os.listdir(os.path.join(G, "jpeg_fuzz")))
+
+
+@pytest.mark.parametrize("path", FUZZ_FOUND, ids=[os.path.basename(p) for p in FUZZ_FOUND])
+def test_jpeg_feeder_on_the_files_the_fuzzers_found(path):
+    """tests/golden/jpeg_fuzz: the files on which a GPU decoder and the oracle once disagreed (tools/fuzz_prog_gpu.py, tools/fuzz_mixed_gpu.py; what each
+    one showed is told at its GPU test / in DESIGN.md).  Host feeder == oracle: verdict, and coefficients where both decode."""
+    L = _capi.lib()
+    data = open(path, "rb").read()
+    try:
+        d = O.DecodedJpeg(data)
+    except ValueError:
+        d = None
+    fr = _capi.JpegFrame(); buf = np.frombuffer(data, np.uint8)
+    rc = L.gamut_hip_jpeg_decode_coeffs(buf.ctypes.data, buf.size, C.byref(fr))
+    assert (rc == 0) == (d is not None), (rc, L.gamut_hip_last_error())
+    if d is not None:
+        n = fr.mcus_per_row * fr.mcus_per_col * fr.blocks_per_mcu
+        assert np.array_equal(np.ctypeslib.as_array(fr.coeffs, (n, 64)), d.coeffs) and np.array_equal(np.ctypeslib.as_array(fr.max_zag, (n,)), d.max_zag)
+        L.gamut_hip_jpeg_frame_free(C.byref(fr))
+
+
 def test_jpeg_batch_feeder_threads():
     """gamut_hip_jpeg_decode_coeffs_batch: N independent files on a thread pool == one at a time; a bad file fails alone."""
     import time

@@ -541,6 +541,34 @@ def test_device_progressive_successive_approximation_beyond_the_standard(hip, pr
             assert np.array_equal(r[0], e.coeffs) and np.array_equal(r[1], e.max_zag), (k, np.argwhere(r[0] != e.coeffs)[:4].tolist())
 
 
+def test_files_the_fuzzers_found(hip, progressive_mode, unstuff_site):
+    """every file of tests/golden/jpeg_fuzz (a GPU decoder and the oracle once disagreed on each: a run leaving its band, octets between a restart
+    interval and its marker, an SOS listing a component twice, Al = 14) -- alone and in one batch, through the coefficient-level call and the
+    files -> pixels call: verdict, coefficients and pixels == the oracle's"""
+    d = os.path.join(HERE, "golden", "jpeg_fuzz")
+    blobs = [open(os.path.join(d, n), "rb").read() for n in sorted(os.listdir(d))]
+    expect = []
+    for b in blobs:
+        try:
+            expect.append(O.DecodedJpeg(b))
+        except ValueError:
+            expect.append(None)
+    assert any(e is None for e in expect) and any(e is not None for e in expect)
+    for batch in ([[b] for b in blobs] + [blobs]):
+        rc, hst, st, res = _entropy_decode_device(hip, batch)
+        for k, r in enumerate(res):
+            e = expect[blobs.index(batch[k])]
+            assert (hst[k] == 0 and st[k] == 0) == (e is not None), (len(batch), k, hst[k], int(st[k]))
+            if e is not None:
+                assert np.array_equal(r[0], e.coeffs) and np.array_equal(r[1], e.max_zag), (len(batch), k)
+    rc, hst, px = _decode_batch_device(hip, blobs, 4)
+    for k, e in enumerate(expect):
+        assert (hst[k] == 0) == (e is not None), (k, hst[k])
+        if e is not None:
+            want = O.decompress_jpeg(blobs[k], 4)[0]
+            assert np.array_equal(px[k].reshape(-1), np.ascontiguousarray(want).reshape(-1)), k
+
+
 def test_device_progressive_corrupt_streams(hip):
     """damaged scans of progressive files on the GPU path: no hang, nothing written outside the file's buffers, the damaged
     files flagged (a scan that decodes to the end without an impossible code is not an error for the reference either);

@@ -167,8 +167,21 @@ int next_scan(Parser& P, gamut_hip_jpeg_frame* f)
                 if (cnt > 255 || n < cnt) { fail(f, "bad DHT counts"); return -1; }
                 memset(h.vals, 0, sizeof(h.vals)); memcpy(h.vals, s, (size_t)cnt);
                 s += cnt; n -= cnt;
-                if (!h.build()) { h.defined = false; fail(f, "bad DHT counts (not a prefix code)"); return -1; }
-                h.defined = true;
+                // The files of a batch mostly carry the same few tables (an encoder's standard set): a host thread keeps the last tables it
+                // built, found again by their bits[] / vals[] -- a copy instead of the 1024-entry look-up table's construction (a header walk
+                // 16 -> 3 us per file; 1024 files on 16 threads: 1.1 ms of every batch call in front of the first upload)
+                {
+                    struct Built { bool used = false; HuffTable t; };
+                    static thread_local Built cache[8]; static thread_local unsigned victim = 0;
+                    int hit = -1;
+                    for (int k = 0; k < 8 && hit < 0; ++k) if (cache[k].used && !memcmp(cache[k].t.bits, h.bits, sizeof(h.bits)) && !memcmp(cache[k].t.vals, h.vals, sizeof(h.vals))) hit = k;
+                    if (hit >= 0) h = cache[hit].t;
+                    else {
+                        if (!h.build()) { h.defined = false; fail(f, "bad DHT counts (not a prefix code)"); return -1; }
+                        h.defined = true;
+                        Built& b = cache[victim++ & 7]; b.t = h; b.used = true;
+                    }
+                }
             }
             break;
         case 0xC0: case 0xC1: case 0xC2: {                     // SOF0 / SOF1 / SOF2 :1349-1417, :1596-1607
@@ -582,7 +595,17 @@ struct DevHuff {                       // one Huffman table (shared by every ima
 };
 constexpr uint32_t kHuffLong = 0x8000u;
 static_assert(JPEG_HUFF_SUB_ENTRIES != 312 || sizeof(DevHuff) == 2048, "DevHuff: a power of two");
-inline void to_dev_huff(const HuffTable& h, DevHuff& d)
+inline void to_dev_huff_build(const HuffTable& h, DevHuff& d);
+inline void to_dev_huff(const HuffTable& h, DevHuff& d)      // (the same few tables file after file: the last ones a thread converted are kept, as in the DHT walk)
+{
+    struct Made { bool used = false; uint8_t bits[17]; uint8_t vals[256]; DevHuff d; };
+    static thread_local Made cache[8]; static thread_local unsigned victim = 0;
+    for (int k = 0; k < 8; ++k) if (cache[k].used && !memcmp(cache[k].bits, h.bits, sizeof(h.bits)) && !memcmp(cache[k].vals, h.vals, sizeof(h.vals))) { d = cache[k].d; return; }
+    to_dev_huff_build(h, d);
+    Made& m = cache[victim++ & 7];
+    memcpy(m.bits, h.bits, sizeof(m.bits)); memcpy(m.vals, h.vals, sizeof(m.vals)); m.d = d; m.used = true;
+}
+inline void to_dev_huff_build(const HuffTable& h, DevHuff& d)
 {
     memset(&d, 0, sizeof(d));
     for (int w = 0; w < 512; ++w) { const uint16_t e = h.fast[w << 1]; d.fast[w] = (e >> 8) <= 9 ? e : 0; }   // 10-bit table -> 9-bit
@@ -1400,6 +1423,16 @@ template <class T> int intern(std::vector<T>& pool, const T& t)      // index of
     return (int)pool.size() - 1;
 }
 struct QuantTab { int16_t q[64]; };
+// a DevHuff is a function of the code-length counts and the symbols (to_dev_huff): maxcode[] / delta[] hold the former, vals[] the latter -- 396 bytes
+// decide whether two tables are the same one, not 2048 (the serial de-duplication walks six tables of every file of a batch)
+inline int intern(std::vector<DevHuff>& pool, const DevHuff& t)
+{
+    static_assert(offsetof(DevHuff, vals) + sizeof(t.vals) - offsetof(DevHuff, maxcode) == sizeof(t.maxcode) + sizeof(t.delta) + sizeof(t.vals), "DevHuff: maxcode, delta, vals adjacent");
+    const size_t from = offsetof(DevHuff, maxcode), n = sizeof(t.maxcode) + sizeof(t.delta) + sizeof(t.vals);
+    for (size_t i = 0; i < pool.size(); ++i) if (!memcmp((const char*)&pool[i] + from, (const char*)&t + from, n)) return (int)i;
+    pool.push_back(t);
+    return (int)pool.size() - 1;
+}
 
 // What the host prepares for one file, independently of every other file (so files are spread over host threads), in two
 // steps: (A) header walk + tables in device form + an upper bound of the file's share of the upload; (C) the entropy-coded
@@ -1409,7 +1442,10 @@ struct FilePrep {
     int rc = GAMUT_HIP_OK; char msg[200] = { 0 };
     bool progressive = false;                                  // SOF2: left to progressive_decode_device (rc = kDeferred)
     int comps = 0, nb = 0, ny = 0; uint32_t org = 0;           // org: DevImage.org
-    QuantTab quant[3]; DevHuff huff[3][2];                     // [component][DC, AC]
+    QuantTab quant[3];
+    // [component][DC, AC]: six tables of 2 KB -- not inside the record: a vector of 1024 records was 13 MB that the constructor cleared on ONE thread
+    // in front of everything else (most of the "headers" phase).  The batch call points them into one uninitialised block per thread that it keeps.
+    DevHuff (*huff)[2] = nullptr;
     size_t scan_pos = 0, cap = 0, used = 0;                    // first scan byte in the file; bound / actual size of the unstuffed segments
     int restart_interval = 0, total_mcus = 0;
     bool dev_unstuff = false;                                  // the scan goes up as it is and k_jpeg_unstuff makes the segments (items: begin / end filled in there)
@@ -1553,6 +1589,16 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
     workers = workers < 1 ? 1 : workers > 16 ? 16 : workers;
     if (workers > (count + 7) / 8) workers = (count + 7) / 8;
     std::vector<FilePrep> prep((size_t)count);
+    {
+        static thread_local DevHuff* table_store = nullptr; static thread_local size_t table_store_cap = 0;      // (kept: warm pages, no clearing; every table is written before it is read)
+        if ((size_t)count * 6 > table_store_cap) {
+            free(table_store); table_store_cap = 0;
+            table_store = static_cast<DevHuff*>(malloc((size_t)count * 6 * sizeof(DevHuff)));
+            if (!table_store) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: out of memory");
+            table_store_cap = (size_t)count * 6;
+        }
+        for (int i = 0; i < count; ++i) prep[(size_t)i].huff = reinterpret_cast<DevHuff (*)[2]>(table_store + (size_t)i * 6);
+    }
     {
         std::vector<Parser*> parsers((size_t)workers, nullptr);
         for (Parser*& p : parsers) p = new Parser();
@@ -1935,6 +1981,8 @@ int gamut_hip_jpeg_scan_layout(const uint8_t* data, size_t len, gamut_hip_jpeg_f
     try {
         Parser* ps = new Parser();
         FilePrep fp;
+        std::vector<DevHuff> fp_tables(6);
+        fp.huff = reinterpret_cast<DevHuff (*)[2]>(fp_tables.data());
         prepare_header(0, data, len, *info, fp, *ps);
         delete ps;
         if (fp.progressive) {                                  // every scan of the file, cut at its restart markers (jpeg_prog.hpp)

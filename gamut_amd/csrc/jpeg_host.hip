@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <memory>
 #include <new>
 #include <string>
 #include <thread>
@@ -171,15 +172,19 @@ int next_scan(Parser& P, gamut_hip_jpeg_frame* f)
                 // built, found again by their bits[] / vals[] -- a copy instead of the 1024-entry look-up table's construction (a header walk
                 // 16 -> 3 us per file; 1024 files on 16 threads: 1.1 ms of every batch call in front of the first upload)
                 {
+                    // (32 of them: a progressive file defines a table per scan, the same dozen in every file of an encoder's; on the heap, not in
+                    //  the library's thread-local segment, which every thread that touches the library pays for)
                     struct Built { bool used = false; HuffTable t; };
-                    static thread_local Built cache[8]; static thread_local unsigned victim = 0;
+                    constexpr int kKept = 32;
+                    static thread_local std::unique_ptr<Built[]> cache; static thread_local unsigned victim = 0;
+                    if (!cache) cache.reset(new Built[kKept]);
                     int hit = -1;
-                    for (int k = 0; k < 8 && hit < 0; ++k) if (cache[k].used && !memcmp(cache[k].t.bits, h.bits, sizeof(h.bits)) && !memcmp(cache[k].t.vals, h.vals, sizeof(h.vals))) hit = k;
+                    for (int k = 0; k < kKept && hit < 0; ++k) if (cache[k].used && !memcmp(cache[k].t.bits, h.bits, sizeof(h.bits)) && !memcmp(cache[k].t.vals, h.vals, sizeof(h.vals))) hit = k;
                     if (hit >= 0) h = cache[hit].t;
                     else {
                         if (!h.build()) { h.defined = false; fail(f, "bad DHT counts (not a prefix code)"); return -1; }
                         h.defined = true;
-                        Built& b = cache[victim++ & 7]; b.t = h; b.used = true;
+                        Built& b = cache[victim++ % kKept]; b.t = h; b.used = true;
                     }
                 }
             }
@@ -599,10 +604,12 @@ inline void to_dev_huff_build(const HuffTable& h, DevHuff& d);
 inline void to_dev_huff(const HuffTable& h, DevHuff& d)      // (the same few tables file after file: the last ones a thread converted are kept, as in the DHT walk)
 {
     struct Made { bool used = false; uint8_t bits[17]; uint8_t vals[256]; DevHuff d; };
-    static thread_local Made cache[8]; static thread_local unsigned victim = 0;
-    for (int k = 0; k < 8; ++k) if (cache[k].used && !memcmp(cache[k].bits, h.bits, sizeof(h.bits)) && !memcmp(cache[k].vals, h.vals, sizeof(h.vals))) { d = cache[k].d; return; }
+    constexpr int kKept = 32;
+    static thread_local std::unique_ptr<Made[]> cache; static thread_local unsigned victim = 0;
+    if (!cache) cache.reset(new Made[kKept]);
+    for (int k = 0; k < kKept; ++k) if (cache[k].used && !memcmp(cache[k].bits, h.bits, sizeof(h.bits)) && !memcmp(cache[k].vals, h.vals, sizeof(h.vals))) { d = cache[k].d; return; }
     to_dev_huff_build(h, d);
-    Made& m = cache[victim++ & 7];
+    Made& m = cache[victim++ % kKept];
     memcpy(m.bits, h.bits, sizeof(m.bits)); memcpy(m.vals, h.vals, sizeof(m.vals)); m.d = d; m.used = true;
 }
 inline void to_dev_huff_build(const HuffTable& h, DevHuff& d)

@@ -1597,14 +1597,15 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
     if (workers > (count + 7) / 8) workers = (count + 7) / 8;
     std::vector<FilePrep> prep((size_t)count);
     {
-        static thread_local DevHuff* table_store = nullptr; static thread_local size_t table_store_cap = 0;      // (kept: warm pages, no clearing; every table is written before it is read)
-        if ((size_t)count * 6 > table_store_cap) {
-            free(table_store); table_store_cap = 0;
-            table_store = static_cast<DevHuff*>(malloc((size_t)count * 6 * sizeof(DevHuff)));
+        struct FreeIt { void operator()(DevHuff* p) const { free(p); } };
+        static thread_local std::unique_ptr<DevHuff, FreeIt> table_store; static thread_local size_t table_store_cap = 0;      // (kept by the thread, host memory only: warm pages,
+        if ((size_t)count * 6 > table_store_cap) {                                                                              //  no clearing; every table is written before it is read)
+            table_store.reset(); table_store_cap = 0;
+            table_store.reset(static_cast<DevHuff*>(malloc((size_t)count * 6 * sizeof(DevHuff))));
             if (!table_store) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: out of memory");
             table_store_cap = (size_t)count * 6;
         }
-        for (int i = 0; i < count; ++i) prep[(size_t)i].huff = reinterpret_cast<DevHuff (*)[2]>(table_store + (size_t)i * 6);
+        for (int i = 0; i < count; ++i) prep[(size_t)i].huff = reinterpret_cast<DevHuff (*)[2]>(table_store.get() + (size_t)i * 6);
     }
     {
         std::vector<Parser*> parsers((size_t)workers, nullptr);

@@ -1705,7 +1705,7 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
         //      first group decodes while the rest is still on its way.
         constexpr int kMaxGroups = 8;
         static const int groups_env = [] { const char* e = getenv("GAMUT_HIP_JPEG_GROUPS"); return e && *e ? atoi(e) : 0; }();        // measurements
-        const int n_groups = groups_env > 0 ? std::min(kMaxGroups, std::min(groups_env, count)) : std::max(1, std::min(kMaxGroups, count / 256));        // (1024 files, a stream per group: 4 groups 14.8 ms, 8 groups 16.1 ms, 2 groups 14.9 ms -- profiles/r04_jpeg_sweep.txt; three streams in turn: 4 groups 12.7 / 13.1, 6 groups 13.1 / 13.4, 8 groups 13.2 / 13.0)
+        const int n_groups = groups_env > 0 ? std::min(kMaxGroups, std::min(groups_env, count)) : (count < 128 ? 1 : std::max(2, std::min(kMaxGroups, count / 256)));        // (1024 files, a stream per group: 4 groups 14.8 ms, 8 groups 16.1 ms, 2 groups 14.9 ms -- profiles/r04_jpeg_sweep.txt; three streams in turn: 4 groups 12.7 / 13.1, 6 groups 13.1 / 13.4, 8 groups 13.2 / 13.0; 256 files: 1 group 4.5, 2 groups 4.3, 4 groups 5.0 ms)
         struct EvN { hipEvent_t e[kMaxGroups]; }; struct StN { hipStream_t s[kMaxGroups]; };
         static thread_local PerDevice<EvN> group_ready_pd;
         hipEvent_t (&group_ready)[kMaxGroups] = group_ready_pd.cur().e;

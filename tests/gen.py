@@ -276,3 +276,16 @@ def sos_component_lists(data, lists=((1, 3, 2), (2, 1, 3), (3, 2, 1), (1, 2, 2),
                 b[at + 5 + 2 * k] = ids[c - 1]
             out.append(bytes(b))
     return out
+
+
+def rst_positions(d):
+    sos = d.index(b"\xff\xda")
+    return [i for i in range(sos, len(d) - 1) if d[i] == 0xFF and 0xD0 <= d[i + 1] <= 0xD7]
+
+
+def leftover_variants(d, which):
+    """octets between the end of a restart interval's data and its RSTn marker (`which`: the marker's number in the file)"""
+    p = rst_positions(d)[which]
+    ins = [b"\x55" * 8, b"\x55" * 6 + b"\xff\x00\x55", b"\x11" * 1600, b"\x11" * 1400, b"\xff" * 3, b"\x11" * 1400 + b"\xff" * 200, b"\x00" * 3 + b"\xff" * 1600]
+    ins += [b"\x11" * n for n in range(1526, 1542)]                       # around the 1536 reads process_restart allows itself
+    return [d[:p] + v + d[p:] for v in ins]

@@ -137,6 +137,41 @@ def test_jpeg_feeder_on_the_files_the_fuzzers_found(path):
         L.gamut_hip_jpeg_frame_free(C.byref(fr))
 
 
+def test_jpeg_feeder_octets_between_a_restart_interval_and_its_marker():
+    """process_restart (jpegload.d:2335-2402) to the letter, on the CPU: the host feeder's resync() against the oracle's restart() on files with
+    octets between an interval's last bit and its RSTn -- skipped if none is 0xFF and the marker lies within the 1536 bytes the function reads from
+    where the decoder's input stands, JPGD_BAD_RESTART_MARKER otherwise (tests/test_jpeg_gpu.py runs the same files through the device decoders).
+    Baseline (markers early and late in the file) and progressive (a marker of every scan kind)."""
+    import io
+    from PIL import Image
+    import gen
+    import jpeg_scripts as JS
+    L = _capi.lib()
+    bio = io.BytesIO(); Image.fromarray(gen.synth_rgb(160, 96, 32)).save(bio, "JPEG", quality=90, subsampling=2, restart_marker_blocks=3); small = bio.getvalue()
+    prog = JS.progressive_with_script(small, JS.LIBJPEG_DEFAULT, restart=4)
+    n_prog = len(gen.rst_positions(prog))
+    blobs = gen.leftover_variants(small, 2) + gen.leftover_variants(small, len(gen.rst_positions(small)) - 1)
+    for which in range(0, n_prog, max(1, n_prog // 12)):
+        blobs += gen.leftover_variants(prog, which)
+    n_ok = n_rej = 0
+    for k, b in enumerate(blobs):
+        try:
+            d = O.DecodedJpeg(b)
+        except ValueError:
+            d = None
+        fr = _capi.JpegFrame(); buf = np.frombuffer(b, np.uint8)
+        rc = L.gamut_hip_jpeg_decode_coeffs(buf.ctypes.data, buf.size, C.byref(fr))
+        assert (rc == 0) == (d is not None), (k, rc, L.gamut_hip_last_error())
+        if d is None:
+            n_rej += 1
+            continue
+        n = fr.mcus_per_row * fr.mcus_per_col * fr.blocks_per_mcu
+        assert np.array_equal(np.ctypeslib.as_array(fr.coeffs, (n, 64)), d.coeffs) and np.array_equal(np.ctypeslib.as_array(fr.max_zag, (n,)), d.max_zag), k
+        L.gamut_hip_jpeg_frame_free(C.byref(fr))
+        n_ok += 1
+    assert n_ok > len(blobs) // 4 and n_rej > len(blobs) // 4, (n_ok, n_rej)
+
+
 def test_jpeg_batch_feeder_threads():
     """gamut_hip_jpeg_decode_coeffs_batch: N independent files on a thread pool == one at a time; a bad file fails alone."""
     import time

@@ -2,6 +2,7 @@
 through the C ABI vs the CPU oracle.  Bar: bit-exact, every sampling mode, every output format."""
 import ctypes as C
 import fixtures
+import gen as gen_mod
 import hashlib
 import json
 import os
@@ -731,17 +732,8 @@ def test_scan_headers_that_list_components_out_of_order(hip, progressive_mode):
     assert sum(e is None for e in expect) >= 10 and sum(e is not None for e in expect) >= 30
 
 
-def _rst_positions(d):
-    sos = d.index(b"\xff\xda")
-    return [i for i in range(sos, len(d) - 1) if d[i] == 0xFF and 0xD0 <= d[i + 1] <= 0xD7]
-
-
-def _leftover_variants(d, which):
-    """octets between the end of a restart interval's data and its RSTn marker (`which`: the marker's number in the file)"""
-    p = _rst_positions(d)[which]
-    ins = [b"\x55" * 8, b"\x55" * 6 + b"\xff\x00\x55", b"\x11" * 1600, b"\x11" * 1400, b"\xff" * 3, b"\x11" * 1400 + b"\xff" * 200, b"\x00" * 3 + b"\xff" * 1600]
-    ins += [b"\x11" * n for n in range(1526, 1542)]                       # around the 1536 reads process_restart allows itself
-    return [d[:p] + v + d[p:] for v in ins]
+_rst_positions = gen_mod.rst_positions
+_leftover_variants = gen_mod.leftover_variants
 
 
 def test_octets_between_a_restart_interval_and_its_marker(hip, unstuff_site, progressive_mode):

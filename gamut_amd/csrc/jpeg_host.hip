@@ -26,20 +26,42 @@ namespace {
 
 const uint8_t kZag[64] = { 0,1,8,16,9,2,3,10,17,24,32,25,18,11,4,5,12,19,26,33,40,48,41,34,27,20,13,6,7,14,21,28,35,42,49,56,57,50,43,36,29,22,15,23,30,37,44,51,58,59,52,45,38,31,39,46,53,60,61,54,47,55,62,63 };
 
+// One DHT table.  jpgd does not decode with canonical ranges but with make_huff_table's look-up arrays and bit tree (:2851-2987), whose
+// zero entries double as "no such code": a bit pattern no code word begins is NOT an error there, it decodes as symbol 0 (huff_decode
+// :746-813).  The canonical form below reproduces that: the code words, left-aligned in 16 bits, tile [0, span) in table order, so a
+// window w >= span is exactly "unassigned", and how many bits such a step takes follows from where the tree walk meets its first empty slot:
+//   * no code word shares w's first 8 bits (look_up / look_up2 entry 0): the three-argument huff_decode (baseline, :769-813) takes NO bits,
+//     the two-argument one (progressive, :746-766) takes code_size[0] = the length of the last code word whose symbol value is 0 (or 0);
+//   * longer code words do (a subtree): the walk stops at the first prefix of w, 9 bits or more, under which no code word lies; that many bits.
+// The two-argument variant has one more habit: a code word of up to 8 bits takes code_size[symbol] bits -- the length of the LAST code word
+// carrying that symbol value (a table may list a value twice) -- not its own length.
 struct HuffTable {
     bool    defined = false;
+    bool    oversubscribed = false;  // the lengths claim more than the code space: make_huff_table writes behind look_up[] / aliases tree nodes -- no table to match
     uint8_t bits[17] = {};        // number of codes per length
     uint8_t vals[256] = {};
-    // fast path: 10-bit window -> (code length << 8) | symbol, 0 when the code is longer
+    // fast path: 10-bit window -> (code length << 8) | symbol, 0 when the code is longer (or the window begins no code word)
     uint16_t fast[1024];
     // slow path: canonical ranges
     int32_t  maxcode[18];
     int32_t  delta[17];           // valptr - mincode
+    uint32_t span = 0;            // first 16-bit window no code word covers (65536: the code is complete)
+    uint8_t  size_of[256];        // code_size[] of huff_tables (:417): per symbol value, the length of the last code word that carries it
+    uint8_t  dc_limit = 0;        // largest symbol value in the table (a DC category above 15 indexes s_extend_test[] out of bounds, :819-822)
+    bool     twice = false;       // some symbol value is carried by two code words
     bool build()                   // false: the code-length counts over-subscribe the code space (not a prefix code)
     {
         int code = 0, k = 0;
-        for (int len = 1; len <= 16; ++len) { code += bits[len]; if (code > (1 << len)) return false; code <<= 1; }
-        code = 0;
+        span = 0; oversubscribed = false;
+        for (int len = 1; len <= 16; ++len) span += (uint32_t)bits[len] << (16 - len);
+        memset(size_of, 0, sizeof(size_of)); dc_limit = 0; twice = false;
+        for (int len = 1; len <= 16; ++len) for (int i = 0; i < bits[len]; ++i, ++k) {
+            if (size_of[vals[k]]) twice = true;
+            size_of[vals[k]] = (uint8_t)len;
+            if (vals[k] > dc_limit) dc_limit = vals[k];
+        }
+        if (span > 65536u) { oversubscribed = true; return false; }
+        code = 0; k = 0;
         for (int len = 1; len <= 16; ++len) {
             delta[len] = k - code;
             code += bits[len]; k += bits[len];
@@ -58,6 +80,14 @@ struct HuffTable {
         }
         return true;
     }
+    // bits taken by a window no code word covers (w >= span); `two_arg`: the progressive variant of huff_decode
+    inline int unassigned_bits(uint32_t w, bool two_arg) const
+    {
+        if ((w & 0xFF00u) >= span) return two_arg ? size_of[0] : 0;
+        int len = 9;
+        while (((w >> (16 - len)) << (16 - len)) < span) ++len;
+        return len;
+    }
 };
 
 // MSB-first bit reader over the entropy-coded segment; handles FF00 stuffing and stops
@@ -65,8 +95,14 @@ struct HuffTable {
 struct BitReader {
     const uint8_t* p; const uint8_t* end;
     uint64_t acc = 0; int nbits = 0; bool at_marker = false;
-    const uint8_t* seg; uint64_t used = 0;     // where the reader was (re)started, the bits taken since (resync needs the reference's read position)
+    const uint8_t* seg; uint64_t used = 0;     // where the reader was (re)started, the bits taken since (raw_position / resync need the reference's read position)
     BitReader(const uint8_t* b, const uint8_t* e) : p(b), end(e), seg(b) {}
+    // the entropy-coded data of a scan whose header ends at `pos`.  A header that runs past the end of the file took its last bytes out of the
+    // FF D9 FF D9 ... padding; if it stopped between an FF and its D9, the scan's data begins with that 0xD9 (and ends there: FF D9 follows).
+    BitReader(const uint8_t* data, size_t len, size_t pos) : p(data + (pos < len ? pos : len)), end(data + len), seg(p)
+    {
+        if (pos > len && ((pos - len) & 1)) { acc = 0xD9; nbits = 8; }
+    }
     inline void refill()
     {
         while (nbits <= 56) {
@@ -90,13 +126,20 @@ struct BitReader {
         const int v = (int)peek(s); drop(s);
         return v < (1 << (s - 1)) ? v + (int)(0xFFFFFFFFu << s) + 1 : v;
     }
-    inline int decode(const HuffTable& h)
+    // huff_decode: TWO_ARG = the progressive variant (:746-766), otherwise the baseline one (:769-813).  Always a symbol (see HuffTable).
+    template <bool TWO_ARG> inline int decode(const HuffTable& h)
     {
         if (nbits < 16) refill();
         const uint16_t e = h.fast[peek(10)];
-        if (e) { drop(e >> 8); return e & 0xFF; }
+        if (e) {
+            int len = e >> 8;
+            if (TWO_ARG && len <= 8) len = h.size_of[e & 0xFF];
+            drop(len); return e & 0xFF;
+        }
+        const uint32_t w = peek(16);
+        if (w >= h.span) { drop(h.unassigned_bits(w, TWO_ARG)); return 0; }
         int32_t code = (int32_t)peek(10); int len = 10;
-        while (code > h.maxcode[len]) { if (++len > 16) return -1; code = (int32_t)peek(len); }      // no valid code is longer than 16 bits
+        while (code > h.maxcode[len]) { ++len; code = (int32_t)peek(len); }      // w < span: some code word of 11 .. 16 bits covers it
         drop(len);
         return h.vals[(code + h.delta[len]) & 0xFF];
     }
@@ -107,18 +150,37 @@ inline int be16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
 
 // One SOS header (read_sos_marker :1466-1540)
 struct Scan {
-    int ncomp = 0, comp[3] = {};                // frame component indices, in scan order
+    int ncomp = 0, comp[4] = {};                // frame component indices, in scan order (JPGD_MAX_COMPS_IN_SCAN = 4: a scan may list a component twice)
     int ss = 0, se = 63, ah = 0, al = 0;        // spectral selection, successive approximation (progressive only)
+};
+
+// Where the walk over the marker segments stands in the reference's call tree: it decides what SOI / EOI / SOFn / SOS / RSTn mean.
+enum class Walk {
+    kFirstScan,    // locate_sof_marker (:1911-1941), then the first locate_sos_marker (:1944-1967): SOF0-2 once, then SOS
+    kNextScan,     // locate_sos_marker of a later scan of a progressive frame: EOI ends the frame
+    kTrailer       // find_eoi (:2826-2848) behind the last MCU row of a sequential frame: process_markers(allow_restarts) up to ANY of SOFn / SOI / EOI / SOS
 };
 
 struct Parser {
     const uint8_t* data = nullptr; size_t len = 0, pos = 0;
     int16_t   quant[4][64]; bool quant_def[4] = { false, false, false, false };
     HuffTable huff[8];                 // 0-3 DC, 4-7 AC (index mapping of read_dht_marker :1247)
-    int comp_id[3] = {}, hs[3] = {}, vs[3] = {}, tq[3] = {}, td[3] = {}, ta[3] = {};
+    int comp_id[4] = {}, hs[4] = {}, vs[4] = {}, tq[4] = {}, td[4] = {}, ta[4] = {};
     int restart_interval = 0;
     bool have_sof = false, progressive = false;
     Scan scan;
+    std::vector<uint8_t> spill;       // a segment that runs past the end of the file, completed with the reference's padding
+    // The input as jpgd reads it: the file, then FF D9 FF D9 ... without end (get_char :631-652 pads the end of the stream with EOI markers;
+    // stuff_char :677-680 puts read-ahead back in order, so the padding is a property of the position, not of the reader's history)
+    inline uint8_t at(size_t p) const { return p < len ? data[p] : (((p - len) & 1) ? 0xD9 : 0xFF); }
+    // `n` bytes from `from` on, readable `slack` bytes past their end (a table whose counts run over the segment is read before it is refused)
+    const uint8_t* bytes(size_t from, size_t n, size_t slack = 0)
+    {
+        if (from + n + slack <= len) return data + from;
+        spill.resize(n + slack);
+        for (size_t i = 0; i < n + slack; ++i) spill[i] = at(from + i);
+        return spill.data();
+    }
 };
 
 int fail(gamut_hip_jpeg_frame* f, const char* why)
@@ -127,45 +189,165 @@ int fail(gamut_hip_jpeg_frame* f, const char* why)
     return set_error(GAMUT_HIP_ERR_DECODE, "jpeg: %s", why);
 }
 
-// Walks the marker segments from P.pos (process_markers :1578-1848) until an SOS has been read (returns 0xDA, P.pos at
-// the first entropy-coded byte, P.scan filled) or the stream ends (0xD9).  Tables may be (re)defined between scans.
-// On a malformed segment returns -1 after fail().
-int next_scan(Parser& P, gamut_hip_jpeg_frame* f)
+// locate_soi_marker :1854-1908: FF D8 at once, or within the first 4096 bytes and then followed by 0xFF; an FF D9 on the way is the end of the
+// search (reading past the end yields FF D9).  -> position behind the SOI, or 0.
+size_t locate_soi(const Parser& P)
 {
-    const uint8_t* data = P.data; const size_t len = P.len; size_t& pos = P.pos;
+    uint32_t last = P.at(0), cur = P.at(1);
+    size_t pos = 2;
+    if (last == 0xFF && cur == 0xD8) return pos;
+    for (uint32_t left = 4096;;) {
+        if (--left == 0) return 0;
+        last = cur; cur = P.at(pos++);
+        if (last == 0xFF) {
+            if (cur == 0xD8) break;
+            if (cur == 0xD9) return 0;
+        }
+    }
+    return P.at(pos) == 0xFF ? pos : 0;
+}
+
+// `case M_APP0+1` of process_markers, :1704-1816: an "Exif\0\0" segment carries a TIFF file; every IFD of its chain is walked for XResolution
+// (282), YResolution (283) -- RATIONALs behind a value offset -- and ResolutionUnit (296, in the offset field itself), defaults 72 / 72 / inches;
+// inches and centimetres set the density and the aspect ratio, any other unit leaves them alone.  A byte order other than II / MM, a version other
+// than 42, an IFD offset behind the segment: JPGD_DECODE_ERROR.  The reference checks nothing else: a read outside the segment (an entry, a value
+// offset, a chain that loops) is outside its malloc block or never ends -- refused here.  A segment shorter than the identifier is not EXIF.
+// -> false: the file is refused.
+bool exif_density(const uint8_t* s, uint32_t n, gamut_hip_jpeg_frame* f)
+{
+    if (n < 6 || memcmp(s, "Exif\0\0", 6)) return true;
+    const uint8_t* tiff = s + 6; const uint64_t room = n - 6;                      // reads are relative to the TIFF header, bounded by the segment
+    bool ok = true;
+    auto rd = [&](uint64_t at, int k, bool le) -> uint32_t {
+        if (at + (uint64_t)k > room) { ok = false; return 0; }
+        uint32_t v = 0;
+        for (int i = 0; i < k; ++i) v = le ? v | (uint32_t)tiff[at + i] << (8 * i) : (v << 8) | tiff[at + i];
+        return v;
+    };
+    const uint32_t order = rd(0, 2, false);
+    if (!ok || (order != 0x4949 && order != 0x4D4D)) return false;
+    const bool le = order == 0x4949;
+    if (rd(2, 2, le) != 42 || !ok) return false;
+    uint32_t offset = rd(4, 4, le);
+    double rx = 72, ry = 72; int unit = 2;
+    for (uint32_t hops = 0; offset != 0 && ok; ) {
+        if (offset > n || ++hops > n) return false;                                // `offset > exifData.length` (:1769); more IFDs than bytes: a loop
+        uint64_t at = offset;
+        const uint32_t entries = rd(at, 2, le); at += 2;
+        for (uint32_t e = 0; e < entries && ok; ++e, at += 12) {
+            const uint32_t tag = rd(at, 2, le), value = rd(at + 8, 4, le);
+            if (!ok) break;
+            if (tag == 282 || tag == 283) {
+                const double num = rd(value, 4, le), den = rd((uint64_t)value + 4, 4, le);
+                (tag == 282 ? rx : ry) = num / den;
+            }
+            if (tag == 296) unit = (int)value;
+        }
+        offset = rd(at, 4, le);
+    }
+    if (!ok) return false;
+    if (unit == 2)      { f->dpi_y = (float)ry;                                   f->pixel_aspect_ratio = (float)(rx / ry); }
+    else if (unit == 3) { f->dpi_y = (float)(ry * 100) / 39.37007874f;            f->pixel_aspect_ratio = (float)(rx / ry); }   // convertInchesToMeters, types.d:127
+    return true;
+}
+
+// init_frame :3130-3195: the sampling modes jpgd decodes
+bool frame_layout(const Parser& P, gamut_hip_jpeg_frame* f)
+{
+    if (f->comps == 1) {
+        if (P.hs[0] != 1 || P.vs[0] != 1) return false;
+        f->scan_type = GAMUT_JPGD_GRAYSCALE; f->blocks_per_mcu = 1;
+    } else if (f->comps == 3) {
+        if (P.hs[1] != 1 || P.vs[1] != 1 || P.hs[2] != 1 || P.vs[2] != 1) return false;
+        if      (P.hs[0] == 1 && P.vs[0] == 1) { f->scan_type = GAMUT_JPGD_YH1V1; f->blocks_per_mcu = 3; }
+        else if (P.hs[0] == 2 && P.vs[0] == 1) { f->scan_type = GAMUT_JPGD_YH2V1; f->blocks_per_mcu = 4; }
+        else if (P.hs[0] == 1 && P.vs[0] == 2) { f->scan_type = GAMUT_JPGD_YH1V2; f->blocks_per_mcu = 4; }
+        else if (P.hs[0] == 2 && P.vs[0] == 2) { f->scan_type = GAMUT_JPGD_YH2V2; f->blocks_per_mcu = 6; }
+        else return false;
+    } else return false;
+    const int mw = 8 * (f->comps == 3 ? P.hs[0] : 1), mh = 8 * (f->comps == 3 ? P.vs[0] : 1);
+    f->mcus_per_row = (f->width + mw - 1) / mw; f->mcus_per_col = (f->height + mh - 1) / mh;
+    return true;
+}
+
+// Walks the marker segments from P.pos the way process_markers does (:1578-1848) -- tables may be (re)defined anywhere, JFIF / EXIF density is
+// taken wherever it stands, and the verdicts are the reference's: RSTn outside a scan, TEM (FF 01) and JPG (FF C8) are errors, DAC is, a segment
+// shorter than its length field is, and a segment LONGER than the file is read out of the FF D9 padding.  Returns
+//   0xDA  an SOS has been read (P.scan filled, P.pos at the first entropy-coded byte),
+//   0xD9  Walk::kNextScan: EOI -- the frame has no further scan;  Walk::kTrailer: the marker that ends find_eoi's search (whichever it is),
+//   -1    after fail(): the reference returns null for this file.
+int next_scan(Parser& P, gamut_hip_jpeg_frame* f, Walk walk)
+{
+    size_t& pos = P.pos;
     for (;;) {
-        while (pos < len && data[pos] != 0xFF) ++pos;          // next_marker :1544-1572
-        while (pos < len && data[pos] == 0xFF) ++pos;
-        if (pos >= len) return 0xD9;
-        const int m = data[pos++];
-        if (m == 0x00 || m == 0x01 || m == 0xD8 || (m >= 0xD0 && m <= 0xD7)) continue;
-        if (m == 0xD9) return 0xD9;
-        if (pos + 2 > len) { fail(f, "truncated marker"); return -1; }
-        const int seg = be16(data + pos);
-        if (seg < 2 || pos + (size_t)seg > len) { fail(f, "bad marker length"); return -1; }
-        const uint8_t* s = data + pos + 2; int n = seg - 2;
+        int m;
+        do {                                                   // next_marker :1546-1573
+            while (P.at(pos) != 0xFF) ++pos;
+            while (P.at(pos) == 0xFF) ++pos;
+            m = P.at(pos++);
+        } while (m == 0);
+        switch (m) {                                           // the markers process_markers hands back to its caller (:1588-1605)
+        case 0xC0: case 0xC1: case 0xC2:
+            if (walk == Walk::kTrailer) return 0xD9;
+            if (walk != Walk::kFirstScan || P.have_sof) { fail(f, "unexpected marker (a second frame header)"); return -1; }       // locate_sos_marker :1953-1958
+            break;                                             // read_sof_marker below
+        case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB: case 0xCD: case 0xCE: case 0xCF:
+            if (walk == Walk::kTrailer) return 0xD9;
+            fail(f, m == 0xC9 && !P.have_sof ? "arithmetic coding is not supported" : "lossless / hierarchical / arithmetic frames are not supported"); return -1;   // :1932-1938
+        case 0xD8:
+            if (walk == Walk::kTrailer) return 0xD9;
+            fail(f, "unexpected SOI marker"); return -1;
+        case 0xD9:
+            if (walk == Walk::kFirstScan && !P.have_sof) { fail(f, "unsupported marker (EOI in front of the frame header)"); return -1; }
+            return 0xD9;                                       // (a frame without a scan: the caller's business)
+        case 0xDA:
+            if (walk == Walk::kTrailer) return 0xD9;
+            if (!P.have_sof) { fail(f, "unsupported marker (SOS in front of the frame header)"); return -1; }
+            break;
+        case 0xD0: case 0xD1: case 0xD2: case 0xD3: case 0xD4: case 0xD5: case 0xD6: case 0xD7:
+            if (walk == Walk::kTrailer) continue;              // allow_restarts :1826-1827 (Issue #93)
+            // (between two scans of a progressive frame the reference gives up WITHOUT an error code, :3615, and decode() goes on with the
+            //  scans so far in the block order of the last one: parts of every row are memory nobody wrote.  Refused like the rest.)
+            fail(f, "restart marker outside a scan"); return -1;
+        case 0x01: case 0xC8:
+            fail(f, "TEM / JPG marker"); return -1;            // :1833-1838
+        case 0xCC:
+            fail(f, "arithmetic coding is not supported"); return -1;
+        default: break;
+        }
+        // a segment: two bytes of length, which count themselves
+        const uint32_t seg = (uint32_t)P.at(pos) << 8 | P.at(pos + 1);
+        const uint8_t* s = P.bytes(pos + 2, seg >= 2 ? seg - 2 : 0, 288);
+        uint32_t n = seg - 2;                                  // num_left (uint: a length below 2 wraps, and every reader refuses it first)
         switch (m) {
-        case 0xDB:                                             // DQT :1274-1346
-            while (n > 0) {
-                const int prec = s[0] >> 4, id = s[0] & 15; ++s; --n;
-                if (id >= 4 || n < (prec ? 128 : 64)) { fail(f, "bad DQT"); return -1; }
+        case 0xDB:                                             // DQT :1272-1343
+            if (seg < 2) { fail(f, "bad DQT marker"); return -1; }
+            while (n) {
+                const int prec = s[0] >> 4, id = s[0] & 15;
+                if (id >= 4) { fail(f, "bad DQT table"); return -1; }
+                const uint32_t need = prec ? 129 : 65;
+                if (n < need) { fail(f, "bad DQT length"); return -1; }       // (the reference reads the 64 entries first: out of the next segment or the padding)
+                ++s;
                 for (int i = 0; i < 64; ++i) {
                     uint32_t v = *s++; if (prec) v = (v << 8) + *s++;
                     P.quant[id][i] = (int16_t)v;               // stored as `short`, zig-zag order
                 }
-                n -= prec ? 128 : 64; P.quant_def[id] = true;
+                n -= need; P.quant_def[id] = true;
             }
             break;
-        case 0xC4:                                             // DHT :1173-1270
-            while (n > 0) {
-                if (n < 17) { fail(f, "bad DHT"); return -1; }
+        case 0xC4:                                             // DHT :1177-1269
+            if (seg < 2) { fail(f, "bad DHT marker"); return -1; }
+            while (n) {
+                int cnt = 0;
+                for (int i = 1; i <= 16; ++i) cnt += s[i];
+                if (cnt > 255) { fail(f, "bad DHT counts"); return -1; }
+                if (n < (uint32_t)(17 + cnt)) { fail(f, "bad DHT marker"); return -1; }
                 const int idx = (s[0] & 0x0F) + ((s[0] & 0x10) >> 4) * 4;
                 if (idx >= 8) { fail(f, "bad DHT index"); return -1; }
                 HuffTable& h = P.huff[idx];
-                int cnt = 0; h.bits[0] = 0;
-                for (int i = 1; i <= 16; ++i) { h.bits[i] = s[i]; cnt += s[i]; }
+                h.bits[0] = 0;
+                for (int i = 1; i <= 16; ++i) h.bits[i] = s[i];
                 s += 17; n -= 17;
-                if (cnt > 255 || n < cnt) { fail(f, "bad DHT counts"); return -1; }
                 memset(h.vals, 0, sizeof(h.vals)); memcpy(h.vals, s, (size_t)cnt);
                 s += cnt; n -= cnt;
                 // The files of a batch mostly carry the same few tables (an encoder's standard set): a host thread keeps the last tables it
@@ -182,51 +364,35 @@ int next_scan(Parser& P, gamut_hip_jpeg_frame* f)
                     for (int k = 0; k < kKept && hit < 0; ++k) if (cache[k].used && !memcmp(cache[k].t.bits, h.bits, sizeof(h.bits)) && !memcmp(cache[k].t.vals, h.vals, sizeof(h.vals))) hit = k;
                     if (hit >= 0) h = cache[hit].t;
                     else {
-                        if (!h.build()) { h.defined = false; fail(f, "bad DHT counts (not a prefix code)"); return -1; }
+                        // an over-subscribed table is not refused HERE: the reference builds its tables at the start of a scan (check_huff_tables
+                        // :3019-3031, every table defined by then), so one that is replaced before, or arrives behind the last scan, does no harm
+                        h.build();
                         h.defined = true;
                         Built& b = cache[victim++ % kKept]; b.t = h; b.used = true;
                     }
                 }
             }
             break;
-        case 0xC0: case 0xC1: case 0xC2: {                     // SOF0 / SOF1 / SOF2 :1349-1417, :1596-1607
-            if (P.have_sof) { fail(f, "more than one frame header"); return -1; }
-            if (n < 6) { fail(f, "bad SOF"); return -1; }
+        case 0xC0: case 0xC1: case 0xC2: {                     // SOF0 / SOF1 / SOF2: read_sof_marker :1346-1415, then init_frame :3130-3195
             if (s[0] != 8) { fail(f, "only 8-bit precision is supported"); return -1; }
             f->height = be16(s + 1); f->width = be16(s + 3); f->comps = s[5];
             if (f->height < 1 || f->height > 16384) { fail(f, "bad height"); return -1; }
             if (f->width < 1 || f->width > 16384) { fail(f, "bad width"); return -1; }
-            if (f->comps != 1 && f->comps != 3) { fail(f, "unsupported colorspace"); return -1; }       // init_frame :3191-3195
-            if (n != f->comps * 3 + 6) { fail(f, "bad SOF length"); return -1; }
-            for (int i = 0; i < f->comps; ++i) {
-                P.comp_id[i] = s[6 + 3 * i]; P.hs[i] = s[7 + 3 * i] >> 4; P.vs[i] = s[7 + 3 * i] & 15; P.tq[i] = s[8 + 3 * i];
-                if (P.tq[i] >= 4) { fail(f, "bad quant table selector"); return -1; }
-            }
-            // init_frame :3134-3190
-            if (f->comps == 1) {
-                if (P.hs[0] != 1 || P.vs[0] != 1) { fail(f, "unsupported sampling factors"); return -1; }
-                f->scan_type = GAMUT_JPGD_GRAYSCALE; f->blocks_per_mcu = 1;
-            } else {
-                if (P.hs[1] != 1 || P.vs[1] != 1 || P.hs[2] != 1 || P.vs[2] != 1) { fail(f, "unsupported sampling factors"); return -1; }
-                if      (P.hs[0] == 1 && P.vs[0] == 1) { f->scan_type = GAMUT_JPGD_YH1V1; f->blocks_per_mcu = 3; }
-                else if (P.hs[0] == 2 && P.vs[0] == 1) { f->scan_type = GAMUT_JPGD_YH2V1; f->blocks_per_mcu = 4; }
-                else if (P.hs[0] == 1 && P.vs[0] == 2) { f->scan_type = GAMUT_JPGD_YH1V2; f->blocks_per_mcu = 4; }
-                else if (P.hs[0] == 2 && P.vs[0] == 2) { f->scan_type = GAMUT_JPGD_YH2V2; f->blocks_per_mcu = 6; }
-                else { fail(f, "unsupported sampling factors"); return -1; }
-            }
-            const int mw = 8 * (f->comps == 3 ? P.hs[0] : 1), mh = 8 * (f->comps == 3 ? P.vs[0] : 1);
-            f->mcus_per_row = (f->width + mw - 1) / mw; f->mcus_per_col = (f->height + mh - 1) / mh;
+            if (f->comps > 4) { fail(f, "too many components"); return -1; }
+            if (seg != (uint32_t)(f->comps * 3 + 8)) { fail(f, "bad SOF length"); return -1; }
+            for (int i = 0; i < f->comps; ++i) { P.comp_id[i] = s[6 + 3 * i]; P.hs[i] = s[7 + 3 * i] >> 4; P.vs[i] = s[7 + 3 * i] & 15; P.tq[i] = s[8 + 3 * i]; }
+            if (f->comps != 1 && f->comps != 3) { fail(f, "unsupported colorspace"); return -1; }
+            if (!frame_layout(P, f)) { fail(f, "unsupported sampling factors"); return -1; }
+            for (int i = 0; i < f->comps; ++i) if (P.tq[i] >= 4) { fail(f, "bad quant table selector"); return -1; }   // m_quant[4 ..]: outside the array
             P.have_sof = true; P.progressive = (m == 0xC2);
         } break;
-        case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB: case 0xCD: case 0xCE: case 0xCF:
-            fail(f, "lossless / hierarchical / arithmetic frames are not supported"); return -1;       // :1608-1628
-        case 0xCC: fail(f, "arithmetic coding is not supported"); return -1;
         case 0xDD:                                             // DRI :1445-1462
             if (seg != 4) { fail(f, "bad DRI length"); return -1; }
             P.restart_interval = be16(s);
             break;
-        case 0xE0:                                             // APP0 / JFIF density :1632-1690
-            if (n >= 14 && !memcmp(s, "JFIF\0", 5)) {
+        case 0xE0:                                             // APP0 :1634-1702: the density of a JFIF header of 14 bytes or more
+            if (seg < 7) { fail(f, "bad variable marker (APP0)"); return -1; }
+            if (seg >= 14 && !memcmp(s, "JFIF\0", 5)) {
                 const int units = s[7], xd = be16(s + 8), yd = be16(s + 10);
                 f->pixel_aspect_ratio = (float)(xd / (double)yd);
                 if (units == 0) f->dpi_y = -1;
@@ -234,40 +400,73 @@ int next_scan(Parser& P, gamut_hip_jpeg_frame* f)
                 else if (units == 2) f->dpi_y = (yd * 100.0f) / 39.37007874f;
             }
             break;
-        case 0xDA: {                                           // SOS :1466-1540
-            if (!P.have_sof) { fail(f, "SOS before SOF"); return -1; }
+        case 0xE1:                                             // APP1 :1704-1816
+            if (seg < 2) { fail(f, "bad variable marker (APP1)"); return -1; }
+            if (!exif_density(s, n, f)) { fail(f, "bad EXIF segment"); return -1; }
+            break;
+        case 0xDA: {                                           // SOS: read_sos_marker :1466-1543
             Scan& sc = P.scan;
-            if (n < 1 || s[0] < 1 || s[0] > f->comps || n != s[0] * 2 + 4) { fail(f, "bad SOS length"); return -1; }
-            sc.ncomp = s[0];
-            for (int i = 0; i < sc.ncomp; ++i) {
+            const int ns = s[0];
+            if (seg != (uint32_t)(ns * 2 + 6) || ns < 1 || ns > 4) { fail(f, "bad SOS length"); return -1; }
+            sc.ncomp = ns;
+            for (int i = 0; i < ns; ++i) {
                 int ci = 0; while (ci < f->comps && P.comp_id[ci] != s[1 + 2 * i]) ++ci;
                 if (ci >= f->comps) { fail(f, "bad SOS component id"); return -1; }
                 sc.comp[i] = ci;
-                P.td[ci] = (s[2 + 2 * i] >> 4) & 15; P.ta[ci] = (s[2 + 2 * i] & 15) + 4;
-                if (P.td[ci] >= 4 || P.ta[ci] >= 8) { fail(f, "bad Huffman table selector"); return -1; }
+                P.td[ci] = (s[2 + 2 * i] >> 4) & 15; P.ta[ci] = (s[2 + 2 * i] & 15) + 4;     // (a component listed twice keeps its last pair; range: scan_tables_ok)
             }
-            const uint8_t* t = s + 1 + 2 * sc.ncomp;
+            const uint8_t* t = s + 1 + 2 * ns;
             sc.ss = t[0]; sc.se = t[1]; sc.ah = t[2] >> 4; sc.al = t[2] & 15;
             if (!P.progressive) { sc.ss = 0; sc.se = 63; }
             pos += (size_t)seg;
             return 0xDA;
         }
-        default: break;                                        // APPn / COM / unknown: skipped (:1826-1846)
+        default:                                               // DNL / DHP / EXP / APPn / JPGn / COM / RESn: skip_variable_marker :1418-1442
+            if (seg < 2) { fail(f, "bad variable marker"); return -1; }
+            break;
         }
         pos += (size_t)seg;
     }
 }
 
-// process_restart :2335-2402, as the oracle restates it (oracle_jpeg.c restart()): raw bytes from where the REFERENCE's input stands -- it
-// buffers 16 .. 32 bits, two octets per refill, four at a (re)start, never past a marker: 4 + 2 * (used / 16) octets behind the (re)start --
-// up to 1536 of them to the next 0xFF, its fill bytes, and then the expected RSTn or JPGD_BAD_RESTART_MARKER.
-bool resync(BitReader& br, int& expect_rst)
+// What init_scan checks before a scan's first bit (:3101-3106): check_huff_tables wants a DC table for every listed component when the scan
+// starts at coefficient 0 and an AC table when it ends behind it -- whether or not the scan will use them (a DC refinement scan reads raw
+// bits) -- then BUILDS every table defined so far; check_quant_tables wants the listed components' quantisation tables.
+bool scan_tables_ok(const Parser& P, gamut_hip_jpeg_frame* f)
+{
+    const Scan& sc = P.scan;
+    for (int i = 0; i < sc.ncomp; ++i) {
+        const int c = sc.comp[i];
+        // m_huff_num / m_pHuff_tabs have 8 slots, DC in 0-3, AC in 4-7: nothing keeps a DC selector of 4-7 from naming an AC table (the scan is decoded
+        // with it all the same); a selector above that indexes past the arrays -- where the scan looks at it at all (a DC selector in a scan that starts
+        // behind coefficient 0, an AC selector in one that ends at it, is never used)
+        if (sc.ss == 0 && (P.td[c] >= 8 || !P.huff[P.td[c]].defined)) { fail(f, P.td[c] >= 8 ? "bad Huffman table selector" : "undefined Huffman table"); return false; }
+        if (sc.se > 0 && (P.ta[c] >= 8 || !P.huff[P.ta[c]].defined)) { fail(f, P.ta[c] >= 8 ? "bad Huffman table selector" : "undefined Huffman table"); return false; }
+    }
+    for (int t = 0; t < 8; ++t) if (P.huff[t].defined && P.huff[t].oversubscribed) { fail(f, "bad DHT counts (not a prefix code)"); return false; }
+    for (int i = 0; i < sc.ncomp; ++i) if (!P.quant_def[P.tq[sc.comp[i]]]) { fail(f, "undefined quant table"); return false; }
+    return true;
+}
+
+// Where the REFERENCE's input stands while the bit reader is `used` bits into a segment: it buffers 16 .. 32 bits, two octets per refill
+// (get_bits_no_markers :722-743; four at a (re)start :2111-2116 / :2394-2400), an octet being a data byte or an FF 00 pair, and it never steps
+// over a marker (get_octet :683-696 puts it back) -- so it is 4 + 2 * (used / 16) octets behind the (re)start, or at the marker that stopped
+// it.  process_restart, find_eoi and the search for a progressive frame's next scan all continue from THERE, not from the last bit decoded.
+const uint8_t* raw_position(const BitReader& br)
 {
     const uint8_t* q = br.seg;
     for (uint64_t n = 4 + 2 * (br.used / 16); n > 0 && q < br.end; --n) {
         if (*q == 0xFF) { if (q + 1 < br.end && q[1] == 0x00) q += 2; else break; }
         else ++q;
     }
+    return q;
+}
+
+// process_restart :2335-2402: raw bytes from raw_position() on -- up to 1536 of them to the next 0xFF, its fill bytes, and then the expected
+// RSTn or JPGD_BAD_RESTART_MARKER (a stray marker, stuffed data left over in front of the marker, more than 1536 bytes of it).
+bool resync(BitReader& br, int& expect_rst)
+{
+    const uint8_t* q = raw_position(br);
     int tem = 0, i, c = 0;
     auto get_char = [&]() -> int { return q < br.end ? (int)*q++ : ((tem ^= 1) ? 0xFF : 0xD9); };      // :631-652: FF D9 FF D9 ... past the end
     for (i = 1536; i > 0; --i) if (get_char() == 0xFF) break;
@@ -308,12 +507,8 @@ inline bool scan_lists_a_component_twice(const Scan& sc)
 int decode_baseline(Parser& P, gamut_hip_jpeg_frame* f, const int* order, int nb, size_t nmcu)
 {
     if (P.scan.ncomp != f->comps) return fail(f, "only single-scan baseline files are supported");
-    for (int i = 0; i < P.scan.ncomp; ++i) {                   // check_quant_tables / check_huff_tables :2990-3034: of the components the scan lists
-        const int c = P.scan.comp[i];
-        if (!P.quant_def[P.tq[c]]) return fail(f, "undefined quant table");
-        if (!P.huff[P.td[c]].defined || !P.huff[P.ta[c]].defined) return fail(f, "undefined Huffman table");
-    }
-    BitReader br(P.data + P.pos, P.data + P.len);
+    if (!scan_tables_ok(P, f)) return GAMUT_HIP_ERR_DECODE;
+    BitReader br(P.data, P.len, P.pos);
     uint32_t pred[3] = { 0, 0, 0 };
     int until_restart = P.restart_interval, expect_rst = 0;
     int16_t* blk = f->coeffs; uint8_t* mz = f->max_zag;
@@ -327,15 +522,14 @@ int decode_baseline(Parser& P, gamut_hip_jpeg_frame* f, const int* order, int nb
             const int c = order[b];
             const int16_t* q = P.quant[P.tq[c]];
             const HuffTable& dc = P.huff[P.td[c]]; const HuffTable& ac = P.huff[P.ta[c]];
-            int s = br.decode(dc);
-            if (s < 0) return fail(f, "bad Huffman code");
-            int v = br.receive_extend(s & 15);
+            const int s = br.decode<false>(dc);
+            if (s > 15) return fail(f, "a DC category above 15");   // the extra bits are s & 15, the sign test is s_extend_test[s] (:816-822): outside the table
+            int v = br.receive_extend(s);
             pred[c] = (uint32_t)(v += (int)pred[c]);
             blk[0] = (int16_t)((uint32_t)v * (uint32_t)(int32_t)q[0]);
             int kk = 1;
             for (; kk < 64; ++kk) {
-                const int rs = br.decode(ac);
-                if (rs < 0) return fail(f, "bad Huffman code");
+                const int rs = br.decode<false>(ac);
                 const int run = rs >> 4, size = rs & 15;
                 if (size) {
                     if (run) { if (kk + run > 63) return fail(f, "decode error"); kk += run; }
@@ -350,6 +544,11 @@ int decode_baseline(Parser& P, gamut_hip_jpeg_frame* f, const int* order, int nb
         }
         --until_restart;
     }
+    // find_eoi :2826-2848, called with the last MCU row (:564-569): the markers behind the scan are processed like those in front of it --
+    // a table segment that is malformed, a TEM / JPG marker or a bad EXIF segment there makes decode() fail, and a JFIF / EXIF segment there
+    // still sets the density the caller gets
+    P.pos = (size_t)(raw_position(br) - P.data);
+    if (next_scan(P, f, Walk::kTrailer) < 0) return GAMUT_HIP_ERR_DECODE;
     return GAMUT_HIP_OK;
 }
 
@@ -372,9 +571,9 @@ struct Progressive {
 
     bool dc_first(int c, int16_t* b)                     // decode_block_dc_first :3298-3319
     {
-        const int s = br.decode(P.huff[P.td[c]]);
-        if (s < 0) return false;
-        const int v = br.receive_extend(s & 15) + (int)pred[c];
+        const int s = br.decode<true>(P.huff[P.td[c]]);
+        if (s > 15) return false;                        // get_bits_no_markers(s) / s_extend_test[s] with a category above 15
+        const int v = br.receive_extend(s) + (int)pred[c];
         pred[c] = (uint32_t)v;
         b[0] = (int16_t)((uint32_t)v << P.scan.al);
         return true;
@@ -389,8 +588,7 @@ struct Progressive {
         if (eobrun) { --eobrun; return true; }
         const HuffTable& ac = P.huff[P.ta[c]];
         for (int k = P.scan.ss; k <= P.scan.se; ++k) {
-            const int rs = br.decode(ac);
-            if (rs < 0) return false;
+            const int rs = br.decode<true>(ac);
             const int run = rs >> 4, size = rs & 15;
             if (size) {
                 if ((k += run) > 63) return false;
@@ -415,8 +613,7 @@ struct Progressive {
         int k = P.scan.ss;
         if (eobrun == 0) {
             while (k <= P.scan.se) {
-                const int rs = br.decode(ac);
-                if (rs < 0) return false;
+                const int rs = br.decode<true>(ac);
                 int run = rs >> 4; const int size = rs & 15;
                 int fresh = 0;                           // value of the newly non-zero coefficient, if any
                 if (size) {
@@ -486,36 +683,36 @@ struct Progressive {
         return true;
     }
 
-    int run(const int* order, int nb)
+    // `marker`: what the walk behind the frame header found -- 0xDA with P.scan read, or 0xD9: a frame without a scan (init_progressive's loop
+    // ends at once and load_next_row hands out the cleared coefficient buffers: a grey image, not an error)
+    int run(const int* order, int nb, int marker)
     {
         for (int c = 0; c < f->comps; ++c) {
             plane[c].bw = f->mcus_per_row * P.hs[c]; plane[c].bh = f->mcus_per_col * P.vs[c];
             plane[c].blk = (int16_t*)calloc((size_t)plane[c].bw * plane[c].bh * 64, sizeof(int16_t));
             if (!plane[c].blk) { fail(f, "out of memory"); return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: out of memory"); }
         }
-        for (int marker = 0xDA; marker == 0xDA; ) {
+        while (marker == 0xDA) {
             const Scan& sc = P.scan;
             const bool dc_scan = sc.ss == 0, refine = sc.ah != 0;
+            if (scan_lists_a_component_twice(sc)) return fail(f, "the scan lists a component twice");
+            if (!scan_tables_ok(P, f)) return GAMUT_HIP_ERR_DECODE;
             if (sc.ss > sc.se || sc.se > 63 || (dc_scan && sc.se != 0)) return fail(f, "bad SOS spectral selection");
             if (!dc_scan && sc.ncomp != 1) return fail(f, "AC scans can only contain one component");
             if (refine && sc.al != sc.ah - 1) return fail(f, "bad SOS successive approximation");
-            if (scan_lists_a_component_twice(sc)) return fail(f, "the scan lists a component twice");
-            for (int i = 0; i < sc.ncomp; ++i) {
-                const int c = sc.comp[i];
-                if (!P.quant_def[P.tq[c]]) return fail(f, "undefined quant table");
-                if (dc_scan ? (!refine && !P.huff[P.td[c]].defined) : !P.huff[P.ta[c]].defined) return fail(f, "undefined Huffman table");
-            }
-            br = BitReader(P.data + P.pos, P.data + P.len);
+            br = BitReader(P.data, P.len, P.pos);
             pred[0] = pred[1] = pred[2] = 0; eobrun = 0;
             bool ok;
             if (dc_scan) ok = refine ? run_scan([&](int c, int16_t* b) { return dc_refine(c, b); }) : run_scan([&](int c, int16_t* b) { return dc_first(c, b); });
             else         ok = refine ? run_scan([&](int c, int16_t* b) { return ac_refine(c, b); }) : run_scan([&](int c, int16_t* b) { return ac_first(c, b); });
             if (!ok) return fail(f, "decode error in a progressive scan");
-            P.pos = (size_t)(br.p - P.data);                   // the reader never steps over a marker
-            marker = next_scan(P, f);
+            P.pos = (size_t)(raw_position(br) - P.data);       // :3667-3673: the bit buffer is thrown away, the search for the next SOS starts where the input stands
+            marker = next_scan(P, f, Walk::kNextScan);
             if (marker < 0) return GAMUT_HIP_ERR_DECODE;
         }
-        // load_next_row :2259-2333: per block, last non-zero coefficient in zig-zag order + 1, then de-quantise
+        // load_next_row :2259-2333: per block, last non-zero coefficient in zig-zag order + 1, then de-quantise -- with the table of EVERY component
+        // of the frame, which no scan may have asked for (check_quant_tables :2990-3000 looks at the components a scan lists): a null pointer there
+        for (int c = 0; c < f->comps; ++c) if (!P.quant_def[P.tq[c]]) return fail(f, "undefined quant table");
         int16_t* dst = f->coeffs; uint8_t* mz = f->max_zag;
         for (int my = 0; my < f->mcus_per_col; ++my)
             for (int mx = 0; mx < f->mcus_per_row; ++mx)
@@ -536,21 +733,31 @@ struct Progressive {
     }
 };
 
-int decode_coeffs(const uint8_t* data, size_t len, gamut_hip_jpeg_frame* f)
+// decode_init (:3708-3713): the SOI, the markers up to the frame header, the frame header; then what decode_start (:3697-3706) reads up to
+// the first scan.  -> 0xDA / 0xD9 (a progressive frame without a scan) / -1 after fail().
+// pixelAspectRatio / dotsPerInchY start as NaN: they are `float` members of the D struct, which initit (:1971-2078) never assigns -- a file
+// without JFIF / EXIF density hands NaN to its caller, not the -1 the comment at :3719 promises.
+int open_frame(Parser& P, const uint8_t* data, size_t len, gamut_hip_jpeg_frame* f)
 {
     memset(f, 0, sizeof(*f));
-    f->pixel_aspect_ratio = -1; f->dpi_y = -1;
-    if (!data || len < 4 || data[0] != 0xFF || data[1] != 0xD8) return fail(f, "not a JPEG (no SOI)");
+    f->pixel_aspect_ratio = NAN; f->dpi_y = NAN;
+    P.data = data; P.len = data ? len : 0;
+    P.pos = locate_soi(P);
+    if (!P.pos) { fail(f, "not a JPEG (no SOI)"); return -1; }
+    const int first = next_scan(P, f, Walk::kFirstScan);
+    if (first == 0xD9 && !P.progressive) { fail(f, "no SOS marker"); return -1; }
+    return first;
+}
 
+int decode_coeffs(const uint8_t* data, size_t len, gamut_hip_jpeg_frame* f)
+{
     Parser* ps = new (std::nothrow) Parser();
-    if (!ps) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: out of memory");
+    if (!ps) { memset(f, 0, sizeof(*f)); return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: out of memory"); }
     struct Guard { Parser* p; ~Guard() { delete p; } } guard{ ps };
     Parser& P = *ps;
-    P.data = data; P.len = len; P.pos = 2;
 
-    const int first = next_scan(P, f);
+    const int first = open_frame(P, data, len, f);
     if (first < 0) return GAMUT_HIP_ERR_DECODE;
-    if (first != 0xDA) return fail(f, "no SOS marker");
 
     int order[6], nb = 0;                                      // calc_mcu_block_order :3076-3088 (frame-interleaved)
     if (f->comps == 1) order[nb++] = 0;
@@ -568,7 +775,7 @@ int decode_coeffs(const uint8_t* data, size_t len, gamut_hip_jpeg_frame* f)
     }
     Progressive* pg = new (std::nothrow) Progressive(P, f);
     if (!pg) { fail(f, "out of memory"); return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: out of memory"); }
-    const int rc = pg->run(order, nb);
+    const int rc = pg->run(order, nb, first);
     delete pg;
     return rc;
 }
@@ -1403,23 +1610,14 @@ __global__ __launch_bounds__(kUnstuffThreads) void k_jpeg_unstuff(const DevRaw* 
 // geometry + the position of the single baseline scan; shared by read_header and the device decoder
 int parse_baseline(Parser& P, const uint8_t* data, size_t len, gamut_hip_jpeg_frame* f, bool want_scan)
 {
-    memset(f, 0, sizeof(*f));
-    f->pixel_aspect_ratio = -1; f->dpi_y = -1;
-    if (!data || len < 4 || data[0] != 0xFF || data[1] != 0xD8) return fail(f, "not a JPEG (no SOI)");
-    P.data = data; P.len = len; P.pos = 2;
-    const int first = next_scan(P, f);
+    const int first = open_frame(P, data, len, f);
     if (first < 0) return GAMUT_HIP_ERR_DECODE;
-    if (first != 0xDA) return fail(f, "no SOS marker");
     if (!want_scan) return GAMUT_HIP_OK;
     if (P.progressive) return set_error(GAMUT_HIP_ERR_UNSUPPORTED, "jpeg: progressive frames are decoded by the host feeder (gamut_hip_jpeg_decode_coeffs)");
     if (P.scan.ncomp != f->comps) return fail(f, "only single-scan baseline files are supported");
     int order[6];
     if (!baseline_order_ok(P, f, order)) return fail(f, "the scan lists a component twice");
-    for (int i = 0; i < P.scan.ncomp; ++i) {                   // the tables of the components the scan lists (check_quant_tables / check_huff_tables)
-        const int c = P.scan.comp[i];
-        if (!P.quant_def[P.tq[c]]) return fail(f, "undefined quant table");
-        if (!P.huff[P.td[c]].defined || !P.huff[P.ta[c]].defined) return fail(f, "undefined Huffman table");
-    }
+    if (!scan_tables_ok(P, f)) return GAMUT_HIP_ERR_DECODE;    // check_huff_tables / check_quant_tables of init_scan :3101-3106
     return GAMUT_HIP_OK;
 }
 

@@ -686,13 +686,8 @@ void prog_prepare(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& f,
 {
     auto bad = [&](const char* why) { out.rc = GAMUT_HIP_ERR_DECODE; snprintf(out.msg, sizeof(out.msg), "image %d: jpeg: %s", i, why); fail(&f, why); };
     P = Parser();
-    memset(&f, 0, sizeof(f));
-    f.pixel_aspect_ratio = -1; f.dpi_y = -1;
-    if (!base || n < 4 || base[0] != 0xFF || base[1] != 0xD8) return bad("not a JPEG (no SOI)");
-    P.data = base; P.len = n; P.pos = 2;
-    int marker = next_scan(P, &f);
+    int marker = open_frame(P, base, n, &f);
     if (marker < 0) { out.rc = GAMUT_HIP_ERR_DECODE; snprintf(out.msg, sizeof(out.msg), "image %d: %s", i, last_error_buf()); return; }
-    if (marker != 0xDA) return bad("no SOS marker");
     out.comps = f.comps; out.nb = f.blocks_per_mcu; out.ny = f.comps == 1 ? 1 : P.hs[0] * P.vs[0];
     int max_h = 1, max_v = 1;
     for (int c = 0; c < f.comps; ++c) { out.hs[c] = P.hs[c]; out.vs[c] = P.vs[c]; if (P.hs[c] > max_h) max_h = P.hs[c]; if (P.vs[c] > max_v) max_v = P.vs[c]; }
@@ -700,16 +695,15 @@ void prog_prepare(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& f,
         ProgScanPrep s; s.sc = P.scan;
         const Scan& sc = s.sc;
         const bool dc_scan = sc.ss == 0, refine = sc.ah != 0;
+        if (scan_lists_a_component_twice(sc)) return bad("the scan lists a component twice");   // decode_scan's walk leaves the component's plane (coeff_buf_getp :3293)
+        if (!scan_tables_ok(P, &f)) { out.rc = GAMUT_HIP_ERR_DECODE; snprintf(out.msg, sizeof(out.msg), "image %d: %s", i, last_error_buf()); return; }
         if (sc.ss > sc.se || sc.se > 63 || (dc_scan && sc.se != 0)) return bad("bad SOS spectral selection");
         if (!dc_scan && sc.ncomp != 1) return bad("AC scans can only contain one component");
-        if (scan_lists_a_component_twice(sc)) return bad("the scan lists a component twice");   // decode_scan's walk leaves the component's plane (coeff_buf_getp :3293)
         if (refine && sc.al != sc.ah - 1) return bad("bad SOS successive approximation");
         // (Al is a nibble: the standard stops at 13, read_sos_marker :1466-1540 does not, and every use of it here wraps in 16 bits as the reference's
         //  jpgd_block_t arithmetic does -- tests/golden/jpeg_fuzz/prog_al14_r04.jpg, found by tools/fuzz_mixed_gpu.py when this line still rejected Al > 13)
         for (int k = 0; k < sc.ncomp; ++k) {
             const int c = sc.comp[k];
-            if (!P.quant_def[P.tq[c]]) return bad("undefined quant table");
-            if (dc_scan ? (!refine && !P.huff[P.td[c]].defined) : !P.huff[P.ta[c]].defined) return bad("undefined Huffman table");
             if (!(dc_scan && refine)) {
                 DevHuff d; to_dev_huff(P.huff[dc_scan ? P.td[c] : P.ta[c]], d);
                 s.tab[k] = intern(out.tabs, d);
@@ -734,10 +728,11 @@ void prog_prepare(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& f,
         out.scans.push_back(s);
         if (out.scans.size() > 256) return bad("too many scans");
         P.pos = s.end;
-        marker = next_scan(P, &f);
+        marker = next_scan(P, &f, Walk::kNextScan);
         if (marker < 0) { out.rc = GAMUT_HIP_ERR_DECODE; snprintf(out.msg, sizeof(out.msg), "image %d: %s", i, last_error_buf()); return; }
     }
-    // de-quantisation happens after the last scan, with the tables as they stand then (load_next_row :2306-2323)
+    // de-quantisation happens after the last scan, with the tables as they stand then (load_next_row :2306-2323) -- of every component of the frame
+    for (int c = 0; c < f.comps; ++c) if (!P.quant_def[P.tq[c]]) return bad("undefined quant table");
     for (int c = 0; c < f.comps; ++c) for (int k = 0; k < 64; ++k) out.quant[c].q[kZag[k]] = P.quant[P.tq[c]][k];
     out.cap = 0;
     size_t all_segs = 0;

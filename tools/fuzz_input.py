@@ -149,13 +149,27 @@ def sos_offset(d):
     return i if i > 0 else len(d) // 2
 
 
+def i_seg(d, q):
+    """start of the DHT segment that holds offset q"""
+    return d.rfind(b"\xFF\xC4", 0, q)
+
+
 def mutate(data, rng):
+    for _ in range(8):
+        try:
+            return _mutate(data, rng)
+        except (IndexError, ValueError, struct.error):      # an operation that does not fit this (already shortened) file: draw again
+            continue
+    return bytes(data)
+
+
+def _mutate(data, rng):
     d = bytearray(data)
     n = int(rng.integers(1, 4))
     for _ in range(n):
         if not d:
             break
-        op = int(rng.integers(0, 16))
+        op = int(rng.integers(0, 22))
         sos = sos_offset(d)
         head = int(rng.integers(0, max(1, sos)))
         body = int(rng.integers(min(sos, len(d) - 1), len(d)))
@@ -217,6 +231,47 @@ def mutate(data, rng):
             if d[-2:] == b"\xFF\xD9":
                 del d[-2:]
             del d[len(d) - int(rng.integers(0, min(8, len(d)))):]
+        elif 16 <= op <= 19:                                # a Huffman table bent: a count changed, a symbol value repeated / raised / zeroed
+            tabs = []
+            i = d.find(b"\xFF\xC4")
+            while 0 <= i < len(d) - 4:
+                L = struct.unpack(">H", d[i + 2:i + 4])[0]
+                q = i + 4
+                while q + 17 <= min(len(d), i + 2 + L):
+                    cnt = sum(d[q + 1:q + 17])
+                    tabs.append((q, cnt))
+                    q += 17 + cnt
+                i = d.find(b"\xFF\xC4", i + 2 + max(L, 2))
+            if tabs:
+                q, cnt = tabs[int(rng.integers(0, len(tabs)))]
+                if op == 16:                                # one code word fewer / more of some length (the segment length is NOT fixed up: some are refused, some shift)
+                    l = int(rng.integers(1, 17))
+                    if q + 17 + cnt > len(d):
+                        pass
+                    elif rng.integers(0, 2) and d[q + l] > 0 and cnt > 0:
+                        d[q + l] -= 1
+                        del d[q + 17 + cnt - 1]
+                        L = struct.unpack(">H", d[i_seg(d, q) + 2:i_seg(d, q) + 4])[0]
+                        d[i_seg(d, q) + 2:i_seg(d, q) + 4] = struct.pack(">H", max(2, L - 1))
+                    elif d[q + l] < 255:
+                        d[q + l] += 1
+                        d[q + 17 + cnt:q + 17 + cnt] = bytes([int(rng.integers(0, 256))])
+                        L = struct.unpack(">H", d[i_seg(d, q) + 2:i_seg(d, q) + 4])[0]
+                        d[i_seg(d, q) + 2:i_seg(d, q) + 4] = struct.pack(">H", min(65535, L + 1))
+                elif cnt and q + 17 + cnt <= len(d):
+                    v = q + 17 + int(rng.integers(0, cnt))
+                    if op == 17:
+                        d[v] = d[q + 17 + int(rng.integers(0, cnt))]          # a symbol value twice
+                    elif op == 18:
+                        d[v] = int(rng.choice([0, 0x10, 0x1F, 0xF0, 0xFF, 16, 17]))
+                    else:
+                        d[q] = int(rng.choice([0x00, 0x01, 0x04, 0x10, 0x11, 0x13, 0x14, 0x20]))      # the table's class / number
+        elif op == 20:                                      # SOS: selectors, component ids, spectral bytes
+            if sos + 5 < len(d):
+                ns = d[sos + 4]
+                k = sos + 5 + int(rng.integers(0, max(1, 2 * ns + 3)))
+                if k < len(d):
+                    d[k] = int(rng.choice([0x00, 0x01, 0x02, 0x03, 0x10, 0x11, 0x40, 0x44, 0x80, 0x0F, 0x3F, 0xFF]))
         else:                                               # swap two ranges of the header (segment order)
             k = int(rng.integers(2, 30))
             a, b = sorted((int(rng.integers(2, max(3, sos))), int(rng.integers(2, max(3, sos)))))
@@ -345,7 +400,8 @@ def worker(args):
                 fn = os.path.join(outdir, "%s_%s_%s.jpg" % (key.replace(" ", "_").replace("/", "-")[:60], name, h))
                 with open(fn, "wb") as fh:
                     fh.write(m)
-    return stats, found, time.time() - t0
+    import ref_literal_input as R
+    return stats, found, dict(R.EVENTS)
 
 
 def main():
@@ -363,7 +419,10 @@ def main():
         results = pool.map(worker, [(w, per, a.seed, a.product, a.out) for w in range(a.procs)])
     stats = {"image": 0, "null": 0, "undefined": 0}
     found = {}
-    for s, f, _ in results:
+    events = {}
+    for s, f, ev in results:
+        for k, v in ev.items():
+            events[k] = events.get(k, 0) + v
         for k in stats:
             stats[k] += s[k]
         for k, v in f.items():
@@ -371,6 +430,9 @@ def main():
     total = sum(stats.values())
     print("fuzz_input: %d files (seed %d, %d processes, %.0f s): second reading says image %d / null %d / undefined %d; compared with %s"
           % (total, a.seed, a.procs, time.time() - t0, stats["image"], stats["null"], stats["undefined"], "oracle + product host feeder" if a.product else "oracle"))
+    print("exercised (events counted inside the second reading):")
+    for k in sorted(events):
+        print("  %-90s %d" % (k, events[k]))
     if not found:
         print("no disagreement")
     for k in sorted(found):

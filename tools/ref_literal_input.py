@@ -36,6 +36,8 @@ JPGD_GRAYSCALE, JPGD_YH1V1, JPGD_YH2V1, JPGD_YH1V2, JPGD_YH2V2 = 0, 1, 2, 3, 4  
 
 U32 = 0xFFFFFFFF
 NAN = float("nan")
+import collections
+EVENTS = collections.Counter()             # what a run exercised (tools/fuzz_input.py sums them up): not part of the reading
 
 
 class Undefined(Exception):
@@ -119,6 +121,7 @@ class jpeg_decoder:                        # :401-3714
         if not self.m_in_buf_left:
             self.prep_in_buffer()
             if not self.m_in_buf_left:
+                EVENTS["pad byte read"] += 1
                 t = self.m_tem_flag
                 self.m_tem_flag ^= 1
                 return 0xD9 if t else 0xFF
@@ -209,15 +212,25 @@ class jpeg_decoder:                        # :401-3714
         symbol = i32(pH.look_up[self.m_bit_buf >> 24])
         if symbol < 0:
             symbol, ofs = self._tree_walk(pH, symbol)
+            if symbol == 0 and pH.code_size[0] != 8 + (23 - ofs):
+                EVENTS["two-argument huff_decode: empty tree slot"] += 1
             self.get_bits_no_markers(8 + (23 - ofs))
         else:
+            if symbol == 0 and pH.look_up2[self.m_bit_buf >> 24] == 0:
+                EVENTS["two-argument huff_decode: empty look_up entry"] += 1
+            elif pH.look_up2[self.m_bit_buf >> 24] >> 8 & 31 != pH.code_size[symbol] + (symbol & 15 if pH.look_up2[self.m_bit_buf >> 24] & 0x8000 else 0):
+                EVENTS["two-argument huff_decode: code_size[symbol] is another code word's length"] += 1
             self.get_bits_no_markers(pH.code_size[symbol])
         return symbol
 
     def huff_decode2(self, pH):            # :769-813, -> (symbol, extra_bits); extra_bits is None where the D leaves its `ref` untouched... it never does
         symbol = i32(pH.look_up2[self.m_bit_buf >> 24])
+        if symbol == 0:
+            EVENTS["three-argument huff_decode: empty look_up2 entry"] += 1
         if symbol < 0:
             symbol, ofs = self._tree_walk(pH, symbol)
+            if symbol == 0 and pH.code_size[0] != 8 + (23 - ofs):
+                EVENTS["three-argument huff_decode: empty tree slot"] += 1
             self.get_bits_no_markers(8 + (23 - ofs))
             extra_bits = self.get_bits_no_markers(symbol & 0xF)
         else:
@@ -485,6 +498,7 @@ class jpeg_decoder:                        # :401-3714
         exif_id = rd(6)
         if exif_id != [0x45, 0x78, 0x69, 0x66, 0x00, 0x00]:
             return
+        EVENTS["EXIF segment"] += 1
         tiffFile = pos[0]
         byteOrder = u16(False)
         if byteOrder != 0x4949 and byteOrder != 0x4D4D:
@@ -724,6 +738,8 @@ class jpeg_decoder:                        # :401-3714
             if self.get_char() == 0xFF:
                 break
             i -= 1
+        if 0 < i < 1536:
+            EVENTS["process_restart: bytes skipped in front of the marker"] += 1
         if i == 0:
             self.set_error("JPGD_BAD_RESTART_MARKER")
         while i > 0:
@@ -830,9 +846,13 @@ class jpeg_decoder:                        # :401-3714
             self.m_bits_left = 16
             self.get_bits(16)
             self.get_bits(16)
+            before = self.m_total_bytes_read - self.m_in_buf_left
             c, err = self.process_markers(True)
             if err:
+                EVENTS["find_eoi: RSTn-tolerant walk fails on TEM / JPG"] += 1
                 return False
+            if c != M_EOI:
+                EVENTS["find_eoi: ends at a marker other than EOI"] += 1
         self.m_total_bytes_read -= self.m_in_buf_left
         return True
 

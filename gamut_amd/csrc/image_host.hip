@@ -331,6 +331,7 @@ struct gamut_image {
             if (rc == GAMUT_HIP_OK) {
                 rc = gamut_hip_memcpy_h2d(dco, hf.coeffs, nblk * 128, nullptr) | gamut_hip_memcpy_h2d(dzz, hf.max_zag, nblk, nullptr) |
                      gamut_hip_stream_synchronize(nullptr);
+                f.pixel_aspect_ratio = hf.pixel_aspect_ratio; f.dpi_y = hf.dpi_y;      // a JFIF / EXIF segment behind the scan counts too (find_eoi, jpegload.d:2826-2848)
                 gamut_hip_jpeg_frame_free(&hf);
             }
             ok = rc == GAMUT_HIP_OK &&

@@ -1483,7 +1483,8 @@ struct DevRaw {
     int32_t  image, first_item, n_items, restart_interval;
 };
 constexpr int kUnstuffThreads = 256, kUnstuffTile = kUnstuffThreads * 16;
-__global__ __launch_bounds__(kUnstuffThreads) void k_jpeg_unstuff(const DevRaw* files, DevItem* items, const uint8_t* raw, uint8_t* blob, uint32_t* status)
+__global__ __launch_bounds__(kUnstuffThreads) void k_jpeg_unstuff(const DevRaw* files, DevItem* items, const uint8_t* raw, uint8_t* blob, uint32_t* status,
+                                                                   uint32_t* scan_end /* [image]: bytes from the scan's first byte to the marker that ends it (find_eoi starts there) */)
 {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     struct __attribute__((packed, aligned(1))) AnyVec { u32x4 v; };
@@ -1586,10 +1587,10 @@ __global__ __launch_bounds__(kUnstuffThreads) void k_jpeg_unstuff(const DevRaw* 
             const bool rst = code >= 0xD0u && code <= 0xD7u && f.restart_interval > 0 && seg + 1 < f.n_items;
             if (rst && code != 0xD0u + (uint32_t)expect) { bad = true; ended = true; }
             else if (rst) { close_segment((int)min(j - (cur + p + 1), (uint64_t)4096)); expect = (expect + 1) & 7; cur = j + 1; }
-            else ended = true;                               // EOI or any other marker ends the scan
+            else { ended = true; if (t == 0) scan_end[f.image] = (uint32_t)(cur + p); }      // EOI or any other marker ends the scan
         } else {
             cur += n;
-            if (cur >= f.raw_len) ended = true;              // the file ends inside the scan: what is there is the data
+            if (cur >= f.raw_len) { ended = true; if (t == 0) scan_end[f.image] = (uint32_t)f.raw_len; }   // the file ends inside the scan: what is there is the data
         }
     }
     if (!bad) {
@@ -1612,7 +1613,7 @@ int parse_baseline(Parser& P, const uint8_t* data, size_t len, gamut_hip_jpeg_fr
 {
     const int first = open_frame(P, data, len, f);
     if (first < 0) return GAMUT_HIP_ERR_DECODE;
-    if (!want_scan) return GAMUT_HIP_OK;
+    if (!want_scan) return first == 0xDA && !scan_tables_ok(P, f) ? GAMUT_HIP_ERR_DECODE : GAMUT_HIP_OK;      // (what the first scan would be refused for)
     if (P.progressive) return set_error(GAMUT_HIP_ERR_UNSUPPORTED, "jpeg: progressive frames are decoded by the host feeder (gamut_hip_jpeg_decode_coeffs)");
     if (P.scan.ncomp != f->comps) return fail(f, "only single-scan baseline files are supported");
     int order[6];
@@ -1656,8 +1657,13 @@ struct FilePrep {
     bool dev_unstuff = false;                                  // the scan goes up as it is and k_jpeg_unstuff makes the segments (items: begin / end filled in there)
     bool pinned_src = false;                                   // ... straight from the caller's buffer (page-locked host memory): no staging copy
     size_t raw_len = 0;                                        // bytes from scan_pos to the end of the file
+    size_t scan_end = 0;                                       // host-unstuffed files: where the scan's data ended (the marker find_eoi starts at), from the start of the file
     std::vector<DevItem> items;                                // begin / end relative to the file's slot in the blob; pad = (estimated) bytes of the segment
 };
+// FilePrep.rc of a file the host feeder decodes after the device pass: not for the kernels (prepare_header), a restart structure the unstuffing could
+// not follow, or anything a kernel flagged -- a bit pattern no code word begins, a segment that ran out, octets left in front of a marker.  The
+// reference has a result for many of those (jpgd decodes symbol 0 and carries on); the host feeder is the part of the library that knows them all.
+constexpr int kHostRedo = -1001;
 // where the 0x00 stuffing is dropped and the restart markers are found: GAMUT_HIP_JPEG_UNSTUFF=host / device forces either (tests, measurements)
 int unstuff_site() { const char* e = getenv("GAMUT_HIP_JPEG_UNSTUFF"); return !e || !*e ? 0 : !strcmp(e, "host") ? 1 : !strcmp(e, "device") ? 2 : 0; }
 
@@ -1667,6 +1673,10 @@ void prepare_header(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& 
     out.rc = parse_baseline(P, base, n, &f, true);
     out.progressive = out.rc == GAMUT_HIP_ERR_UNSUPPORTED && P.progressive;
     if (out.rc != GAMUT_HIP_OK) { snprintf(out.msg, sizeof(out.msg), "image %d: %s", i, last_error_buf()); return; }
+    // Files the kernels are not given (the host feeder decodes them behind the device pass, host_redo): a scan header that ends in the padding behind
+    // the file (the scan's data is what the padding holds), a DC table with a category above 15 (the kernels mask it, the reference leaves its tables)
+    if (P.pos >= n) { out.rc = kHostRedo; return; }
+    for (int k = 0; k < P.scan.ncomp; ++k) if (P.huff[P.td[P.scan.comp[k]]].dc_limit > 15) { out.rc = kHostRedo; return; }
     out.comps = f.comps; out.nb = f.blocks_per_mcu; out.ny = f.comps == 1 ? 1 : P.hs[0] * P.vs[0];
     { int order[6] = { 0, 0, 0, 0, 0, 0 }; const int blocks = scan_block_order(P, order, 6); out.org = 0; for (int b = 0; b < blocks && b < 6; ++b) out.org |= (uint32_t)order[b] << (2 * b); }
     for (int c = 0; c < f.comps; ++c) {
@@ -1743,12 +1753,50 @@ void unstuff_file(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& f,
         if (ri && total_mcus - next_mcu > ri) bad = true;      // a restart marker is missing
         else close_segment(total_mcus - next_mcu, -1);
     }
-    out.used = w;
-    if (bad) {
-        out.items.clear(); out.used = 0;
-        fail(&f, "bad restart marker");
-        out.rc = GAMUT_HIP_ERR_DECODE; snprintf(out.msg, sizeof(out.msg), "image %d: bad restart marker", i);
+    out.used = w; out.scan_end = q;
+    if (bad) { out.items.clear(); out.used = 0; out.rc = kHostRedo; }      // a wrong or missing RSTn: what the reference makes of it is the host feeder's to say
+}
+
+// The files of a batch the host feeder decodes (decode_coeffs, the whole of it: markers, scans, find_eoi): `deliver` takes the dense coefficients
+// of a file that decoded; rcs[k] / msgs[k] receive the verdicts.  info[] gets the geometry and the density as the host feeder found them.
+int host_redo(const uint8_t* const* data, const size_t* len, const std::vector<int>& idx, gamut_hip_jpeg_frame* info,
+              const std::function<int(int i, const gamut_hip_jpeg_frame& fr)>& deliver, std::vector<int>& rcs, std::vector<std::string>& msgs)
+{
+    const int n = (int)idx.size();
+    rcs.assign((size_t)n, GAMUT_HIP_OK); msgs.assign((size_t)n, std::string());
+    if (!n) return GAMUT_HIP_OK;
+    int workers = host_threads();
+    workers = workers < 1 ? 1 : workers > 16 ? 16 : workers;
+    if (workers > n) workers = n;
+    std::vector<gamut_hip_jpeg_frame> frames((size_t)n);
+    parallel_for(n, workers, [&](int, int k) {
+        const int i = idx[(size_t)k];
+        rcs[(size_t)k] = decode_coeffs(data[i], len[i], &frames[(size_t)k]);
+        if (rcs[(size_t)k] != GAMUT_HIP_OK) msgs[(size_t)k] = last_error_buf();
+    });
+    int hip_rc = GAMUT_HIP_OK;
+    for (int k = 0; k < n; ++k) {
+        const int i = idx[(size_t)k];
+        gamut_hip_jpeg_frame& fr = frames[(size_t)k];
+        if (rcs[(size_t)k] == GAMUT_HIP_OK && hip_rc == GAMUT_HIP_OK) hip_rc = deliver(i, fr);
+        info[i] = fr; info[i].coeffs = nullptr; info[i].max_zag = nullptr;
     }
+    for (gamut_hip_jpeg_frame& fr : frames) { free(fr.coeffs); free(fr.max_zag); fr.coeffs = nullptr; fr.max_zag = nullptr; }
+    return hip_rc;
+}
+// ... into the caller's dense buffers (the coefficient-level entry point; progressive files at either level)
+inline std::function<int(int, const gamut_hip_jpeg_frame&)> deliver_dense(const int64_t* coeff_offset, const int64_t* zag_offset, int16_t* d_coeffs, uint8_t* d_max_zag,
+                                                                           uint32_t* d_status, hipStream_t stream)
+{
+    return [=](int i, const gamut_hip_jpeg_frame& fr) -> int {
+        const size_t nblk = (size_t)fr.mcus_per_row * fr.mcus_per_col * fr.blocks_per_mcu;
+        if (hipMemcpyAsync(d_coeffs + coeff_offset[i], fr.coeffs, nblk * 64 * sizeof(int16_t), hipMemcpyHostToDevice, stream) != hipSuccess ||
+            hipMemcpyAsync(d_max_zag + zag_offset[i], fr.max_zag, nblk, hipMemcpyHostToDevice, stream) != hipSuccess ||
+            (d_status && hipMemsetAsync(d_status + i, 0, sizeof(uint32_t), stream) != hipSuccess) ||
+            hipStreamSynchronize(stream) != hipSuccess)          // (pageable sources, freed when host_redo returns)
+            return set_error(GAMUT_HIP_ERR_HIP, "jpeg: upload of the coefficients of image %d failed", i);
+        return GAMUT_HIP_OK;
+    };
 }
 
 
@@ -1771,6 +1819,7 @@ struct DecodeHooks {
     std::function<int(const gamut_hip_jpeg_frame* info, const int* rc, const char* progressive, int64_t* coeff_offset, int64_t* zag_offset, int16_t** d_coeffs, uint8_t** d_max_zag,
                       const TokenPlan& plan)> layout;
     std::function<int(int lo, int hi, hipStream_t gs)> group_done;
+    std::function<int(int i, const gamut_hip_jpeg_frame& fr, hipStream_t s)> redo;      // a file the host feeder decoded (host_redo): coefficients -> the hook owner's output
 };
 int entropy_decode_device(const uint8_t* const* data, const size_t* len, int count,
                           const int64_t* coeff_offset_in, const int64_t* zag_offset_in,
@@ -1822,7 +1871,7 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
         std::vector<size_t> scan_len((size_t)count, 0);
         for (int i = 0; i < count; ++i) {
             const FilePrep& fp = prep[(size_t)i];
-            rcs[(size_t)i] = fp.rc == kDeferred ? GAMUT_HIP_OK : fp.rc; progs[(size_t)i] = fp.progressive;
+            rcs[(size_t)i] = fp.rc == kDeferred || fp.rc == kHostRedo ? GAMUT_HIP_OK : fp.rc; progs[(size_t)i] = fp.progressive;
             tok_ok[(size_t)i] = fp.rc == GAMUT_HIP_OK && info[i].scan_type == GAMUT_JPGD_YH2V2 && fp.dev_unstuff && fp.items.size() == 1 && (uint32_t)fp.items[0].pad >= kSyncMinBytes;
             scan_len[(size_t)i] = fp.raw_len;
         }
@@ -1856,6 +1905,7 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
     int n_long = 0;
     bool any_ok = false;
     for (int i = 0; i < count; ++i) any_ok = any_ok || prep[(size_t)i].rc == GAMUT_HIP_OK;
+    uint32_t* d_scan_end = nullptr; uint32_t* st_used = nullptr;
 
     if (any_ok) {
         const auto t_up = std::chrono::steady_clock::now();
@@ -1897,6 +1947,11 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
             if (!st) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: status allocation failed");
         }
         GAMUT_HIP_CHECK(hipMemsetAsync(st, 0, (size_t)count * sizeof(uint32_t), stream));
+        static thread_local PerDevice<DeviceScratch> scan_end_pd;                 // per image: where k_jpeg_unstuff saw the scan end
+        d_scan_end = (uint32_t*)scan_end_pd.cur().get((size_t)count * sizeof(uint32_t), stream);
+        if (!d_scan_end) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg: status allocation failed");
+        GAMUT_HIP_CHECK(hipMemsetAsync(d_scan_end, 0xFF, (size_t)count * sizeof(uint32_t), stream));
+        st_used = st;
         // C/D. groups of files.  A group's bytes are copied into pinned memory on the workers (as they are; files with tiny restart
         //      intervals: unstuffed there) and DMA'd at once; its segment list follows and the group's kernels -- unstuff, entropy
         //      decode, and through the hook the reconstruction -- are queued behind an event on a stream of the group's own, so the
@@ -2039,7 +2094,7 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
             if (trace) { (void)hipStreamSynchronize(gs); ms_upload = ms_since(t_up) - ms_kernels_issue; }
             const auto t_k = std::chrono::steady_clock::now();
             if (!raws.empty()) {
-                hipLaunchKernelGGL(k_jpeg_unstuff, dim3((unsigned)raws.size()), dim3(kUnstuffThreads), 0, gs, d_raws, d_items, (const uint8_t*)d_raw, d_blob_w, st);
+                hipLaunchKernelGGL(k_jpeg_unstuff, dim3((unsigned)raws.size()), dim3(kUnstuffThreads), 0, gs, d_raws, d_items, (const uint8_t*)d_raw, d_blob_w, st, d_scan_end);
                 if (int rc = launch_status("jpeg_unstuff")) return rc;
             }
             static const int force_nh = [] { const char* e = getenv("GAMUT_HIP_JPEG_TABLES_LDS"); return e && *e ? atoi(e) : -1; }();     // measurements: 0 / 4 / 8
@@ -2070,19 +2125,42 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
         GAMUT_HIP_CHECK(hipStreamSynchronize(copy_stream));
         for (int g = 1; g < n_lanes; ++g) GAMUT_HIP_CHECK(hipStreamSynchronize(side[g]));
         GAMUT_HIP_CHECK(hipStreamSynchronize(stream));         // the per-thread staging buffers are reused by the next call
-        if (dev_restarts) {                                    // restart markers are checked where the scan is unstuffed, what lies in front of them where it is
-            std::vector<uint32_t> flags((size_t)count);        // decoded (restart_leftover_bad): either way a header-level failure of the file, as when unstuff_file finds it
-            GAMUT_HIP_CHECK(hipMemcpy(flags.data(), st, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost));
-            for (int i = 0; i < count; ++i) {
-                FilePrep& fp = prep[(size_t)i];
-                if (fp.rc == GAMUT_HIP_OK && (flags[(size_t)i] & kStatusBadRestart)) {
-                    fail(&info[i], "bad restart marker");
-                    fp.rc = GAMUT_HIP_ERR_DECODE; snprintf(fp.msg, sizeof(fp.msg), "image %d: bad restart marker", i);
-                }
-            }
+        // What the kernels could not vouch for goes to the host feeder below: any flag (a bit pattern no code word begins, a run past coefficient 63, a
+        // segment that ran out, a wrong / missing RSTn, octets between an interval's last bit and its marker).  For the rest, find_eoi (:2826-2848):
+        // the markers behind the scan are processed like those in front of it -- nearly always FF D9 and nothing to do.
+        (void)dev_restarts;
+        std::vector<uint32_t> flags((size_t)count), ends((size_t)count);
+        GAMUT_HIP_CHECK(hipMemcpy(flags.data(), st, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        GAMUT_HIP_CHECK(hipMemcpy(ends.data(), d_scan_end, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (int i = 0; i < count; ++i) {
+            FilePrep& fp = prep[(size_t)i];
+            if (fp.rc != GAMUT_HIP_OK) continue;
+            if (flags[(size_t)i]) { fp.rc = kHostRedo; continue; }
+            const size_t e = fp.dev_unstuff ? (ends[(size_t)i] == 0xFFFFFFFFu ? len[i] : fp.scan_pos + ends[(size_t)i]) : fp.scan_end;
+            if (e >= len[i] || (e + 1 < len[i] && data[i][e] == 0xFF && data[i][e + 1] == 0xD9)) continue;        // the end of the file, or EOI at once
+            std::unique_ptr<Parser> tp(new Parser());
+            tp->data = data[i]; tp->len = len[i]; tp->pos = e;
+            if (next_scan(*tp, &info[i], Walk::kTrailer) < 0) { fp.rc = GAMUT_HIP_ERR_DECODE; snprintf(fp.msg, sizeof(fp.msg), "image %d: %s", i, last_error_buf()); }
         }
         if (trace) fprintf(stderr, "[gamut_hip] jpeg_entropy_decode_device: %d files in %d group(s), %d long + %d short segments, %d+%d tables, %.1f MB compressed, %d host threads: headers %.1f ms, unstuff + upload %.1f ms, kernels %.1f ms (stages serialised by the trace)\n",
                            count, n_groups, total_long, total_short, n_huff, n_quant, blob_size / 1e6, workers, ms_parse, ms_upload, ms_kernels_issue);
+    }
+    {   // the host feeder's files (see kHostRedo)
+        std::vector<int> redo;
+        for (int i = 0; i < count; ++i) if (prep[(size_t)i].rc == kHostRedo) redo.push_back(i);
+        if (!redo.empty()) {
+            std::vector<int> rcs; std::vector<std::string> msgs;
+            const auto deliver = hooks && hooks->redo ? std::function<int(int, const gamut_hip_jpeg_frame&)>([&](int i, const gamut_hip_jpeg_frame& fr) {
+                                     if (st_used && hipMemsetAsync(st_used + i, 0, sizeof(uint32_t), stream) != hipSuccess) return set_error(GAMUT_HIP_ERR_HIP, "jpeg: status reset failed");
+                                     return hooks->redo(i, fr, stream); })
+                                                      : deliver_dense(coeff_offset, zag_offset, d_coeffs, d_max_zag, st_used ? st_used : d_status, stream);
+            if (int rc = host_redo(data, len, redo, info, deliver, rcs, msgs)) return rc;
+            for (size_t k = 0; k < redo.size(); ++k) {
+                FilePrep& fp = prep[(size_t)redo[k]];
+                fp.rc = rcs[k];
+                if (rcs[k] != GAMUT_HIP_OK) snprintf(fp.msg, sizeof(fp.msg), "image %d: %s", redo[k], msgs[k].c_str());
+            }
+        }
     }
     int first_index = -1;
     for (int i = 0; i < count; ++i) {
@@ -2270,7 +2348,10 @@ int gamut_hip_jpeg_decode_batch_device(const uint8_t* const* data, const size_t*
                 // a token per DC and per non-zero AC coefficient: at most 64 per block, and no more than the scan has bit pairs plus a
                 // DC token per block (a token costs two bits of the scan at least, a DC token of a block that ends at once one)
                 const int64_t cap = std::min<int64_t>(nblk * 64, (int64_t)plan.scan_len[i] * 4 + nblk) + 16;
-                if (want_tokens && plan.tok_ok[i] && cap < 0x7fffffff) {
+                // (the token kernel stores whole rgba8 pixels as dwords: an image whose rows would not be dword-aligned keeps the dense hand-off, whose
+                //  launch falls back to the byte-wise kernel -- jpeg_reconstruct_launch)
+                const bool dword_rows = req_comps != 4 || ((((uintptr_t)out + (uint64_t)out_offset[i]) & 3) == 0);
+                if (want_tokens && plan.tok_ok[i] && cap < 0x7fffffff && dword_rows) {
                     tokm[(size_t)i] = 1; plan.tok[i] = 1;
                     tk_off[(size_t)i] = tokens; plan.tok_off[i] = tokens; plan.tok_cap[i] = (int32_t)cap;
                     sp_off[(size_t)i] = strips; plan.strip_off[i] = strips;
@@ -2317,6 +2398,19 @@ int gamut_hip_jpeg_decode_batch_device(const uint8_t* const* data, const size_t*
             return GAMUT_HIP_OK;
         };
         hooks.group_done = [&](int lo, int hi, hipStream_t gs) -> int { return reconstruct(lo, hi, gs, false); };
+        // a baseline file the host feeder decoded behind the device pass (kHostRedo): its coefficients go up and through the dense reconstruction
+        hooks.redo = [&](int i, const gamut_hip_jpeg_frame& fr, hipStream_t s) -> int {
+            static thread_local PerDevice<DeviceScratch> rco_pd, rzz_pd;
+            const size_t nblk = (size_t)fr.mcus_per_row * fr.mcus_per_col * fr.blocks_per_mcu;
+            int16_t* c = (int16_t*)rco_pd.cur().get(nblk * 128 + 256, s); uint8_t* z = (uint8_t*)rzz_pd.cur().get(nblk + 256, s);
+            if (!c || !z) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "jpeg_decode_batch_device: coefficient scratch of image %d", i);
+            if (hipMemcpyAsync(c, fr.coeffs, nblk * 128, hipMemcpyHostToDevice, s) != hipSuccess || hipMemcpyAsync(z, fr.max_zag, nblk, hipMemcpyHostToDevice, s) != hipSuccess)
+                return set_error(GAMUT_HIP_ERR_HIP, "jpeg_decode_batch_device: upload of the coefficients of image %d failed", i);
+            if (int rc = jpeg_reconstruct_launch(c, (int64_t)nblk * 64, z, (int64_t)nblk, out + out_offset[i], (int64_t)fr.width * req_comps, 0, fr.width, fr.height, fr.scan_type,
+                                                 req_comps, 1, s)) return rc;
+            if (hipStreamSynchronize(s) != hipSuccess) return set_error(GAMUT_HIP_ERR_HIP, "jpeg_decode_batch_device: reconstruction of image %d failed", i);
+            return GAMUT_HIP_OK;
+        };
         // per-file verdicts: the header-level ones (host) and what the kernels flag (device) are folded into ONE status per file, as
         // gamut_hip_png_decode_batch_device does -- a caller that passes no status arrays still gets the failure as the return value
         std::vector<int> own_host; int* hst = status_host;

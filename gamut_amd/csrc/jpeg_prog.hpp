@@ -705,7 +705,11 @@ void prog_prepare(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& f,
         for (int k = 0; k < sc.ncomp; ++k) {
             const int c = sc.comp[k];
             if (!(dc_scan && refine)) {
-                DevHuff d; to_dev_huff(P.huff[dc_scan ? P.td[c] : P.ta[c]], d);
+                // not for the kernels (kHostRedo): a table that carries a symbol value twice (the two-argument huff_decode takes code_size[symbol] bits for a
+                // short code word: the LAST length that value was given), a DC category above 15
+                const HuffTable& ht = P.huff[dc_scan ? P.td[c] : P.ta[c]];
+                if (ht.twice || (dc_scan && ht.dc_limit > 15)) { out.rc = kHostRedo; return; }
+                DevHuff d; to_dev_huff(ht, d);
                 s.tab[k] = intern(out.tabs, d);
             }
         }
@@ -724,6 +728,7 @@ void prog_prepare(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& f,
             for (int a = 0; a < sc.ncomp; ++a) for (int b = 0; b < e.sc.ncomp; ++b) shares = shares || sc.comp[a] == e.sc.comp[b];
             if (shares && sc.ss <= prog_scan_reach(e.kind, e.sc.se) && e.sc.ss <= prog_scan_reach(s.kind, sc.se) && e.level + 1 > s.level) s.level = e.level + 1;
         }
+        if (P.pos >= n) { out.rc = kHostRedo; return; }            // a scan header that ends in the padding behind the file
         s.begin = P.pos; s.end = scan_data_end(base, P.pos, n);
         out.scans.push_back(s);
         if (out.scans.size() > 256) return bad("too many scans");
@@ -793,6 +798,7 @@ void prog_unstuff(int i, const uint8_t* base, gamut_hip_jpeg_frame& f, ProgPrep&
             }
             break;
         }
+        if (!bad && q < n) bad = true;                         // an RSTn the scan has no use for: the reference's input stops THERE, prog_prepare looked for the next scan behind it
         if (!bad && next_unit < total) {
             if (ri && total - next_unit > ri) bad = true;      // a restart marker is missing
             else close_segment(total - next_unit, -1);
@@ -800,11 +806,8 @@ void prog_unstuff(int i, const uint8_t* base, gamut_hip_jpeg_frame& f, ProgPrep&
         if (bad) break;
     }
     out.used = w;
-    if (bad) {
-        out.items.clear(); out.used = 0;
-        fail(&f, "bad restart marker");
-        out.rc = GAMUT_HIP_ERR_DECODE; snprintf(out.msg, sizeof(out.msg), "image %d: bad restart marker", i);
-    }
+    (void)f;
+    if (bad) { out.items.clear(); out.used = 0; out.rc = kHostRedo; }       // what the reference makes of such a restart structure is the host feeder's to say
 }
 
 // Decodes the progressive files data[idx[0..n)] of a batch (indices into the caller's arrays) into the same buffers the
@@ -831,37 +834,21 @@ int progressive_decode_device(const uint8_t* const* data, const size_t* len, con
     // 192 files 185 / 71 ms; 2 threads 16 files 70 / 65 ms).  GAMUT_HIP_JPEG_PROGRESSIVE = host / device forces either (tests, measurements).
     const char* how = getenv("GAMUT_HIP_JPEG_PROGRESSIVE");
     const bool on_host = how && !strcmp(how, "host") ? true : how && !strcmp(how, "device") ? false : n < 5 * workers;
+    // the host feeder's share: every file (on_host), or afterwards the files the kernels flagged / were not given (kHostRedo)
+    auto on_the_host = [&](const std::vector<int>& which, std::vector<int>& rcs, std::vector<std::string>& msgs) -> int {
+        return host_redo(data, len, which, info, deliver_dense(coeff_offset, zag_offset, d_coeffs, d_max_zag, d_status, stream), rcs, msgs);
+    };
     if (on_host) {
-        std::vector<gamut_hip_jpeg_frame> frames((size_t)n);
-        std::vector<int> rcs((size_t)n, GAMUT_HIP_OK);
-        std::vector<std::string> msgs((size_t)n);
-        parallel_for(n, workers, [&](int, int k) {
-            const int i = idx[(size_t)k];
-            rcs[(size_t)k] = decode_coeffs(data[i], len[i], &frames[(size_t)k]);
-            if (rcs[(size_t)k] != GAMUT_HIP_OK) msgs[(size_t)k] = last_error_buf();
-        });
-        int first_rc = GAMUT_HIP_OK, hip_rc = GAMUT_HIP_OK;
+        std::vector<int> rcs; std::vector<std::string> msgs;
+        if (int rc = on_the_host(idx, rcs, msgs)) { *first_index = -1; return rc; }
+        int first_rc = GAMUT_HIP_OK;
         for (int k = 0; k < n; ++k) {
             const int i = idx[(size_t)k];
-            gamut_hip_jpeg_frame& fr = frames[(size_t)k];
-            if (rcs[(size_t)k] == GAMUT_HIP_OK && hip_rc == GAMUT_HIP_OK) {
-                const size_t nblk = (size_t)fr.mcus_per_row * fr.mcus_per_col * fr.blocks_per_mcu;
-                if (hipMemcpyAsync(d_coeffs + coeff_offset[i], fr.coeffs, nblk * 64 * sizeof(int16_t), hipMemcpyHostToDevice, stream) != hipSuccess ||
-                    hipMemcpyAsync(d_max_zag + zag_offset[i], fr.max_zag, nblk, hipMemcpyHostToDevice, stream) != hipSuccess ||
-                    (d_status && hipMemsetAsync(d_status + i, 0, sizeof(uint32_t), stream) != hipSuccess))
-                    hip_rc = set_error(GAMUT_HIP_ERR_HIP, "jpeg: upload of the coefficients of image %d failed", i);
-            }
-            int16_t* co = fr.coeffs; uint8_t* mz = fr.max_zag;
-            info[i] = fr; info[i].coeffs = nullptr; info[i].max_zag = nullptr;
             if (host_status) host_status[i] = rcs[(size_t)k];
             if (rcs[(size_t)k] != GAMUT_HIP_OK && (*first_index < 0 || i < *first_index)) {
                 *first_index = i; first_rc = rcs[(size_t)k]; snprintf(first_msg, msg_cap, "image %d: %s", i, msgs[(size_t)k].c_str());
             }
-            fr.coeffs = co; fr.max_zag = mz;
         }
-        if (hipStreamSynchronize(stream) != hipSuccess && hip_rc == GAMUT_HIP_OK) hip_rc = set_error(GAMUT_HIP_ERR_HIP, "jpeg: upload of the coefficients failed");
-        for (gamut_hip_jpeg_frame& fr : frames) { free(fr.coeffs); free(fr.max_zag); }
-        if (hip_rc != GAMUT_HIP_OK) { *first_index = -1; return hip_rc; }
         return first_rc;
     }
     std::vector<ProgPrep> prep((size_t)n);
@@ -1093,23 +1080,16 @@ int progressive_decode_device(const uint8_t* const* data, const size_t* len, con
                                (const ProgImage*)(d + o_img), (int)live.size(), (const int16_t*)(d + o_quant), d_coeffs, d_max_zag);
             if (int rc = launch_status("jpeg_prog_finalize")) return rc;
             GAMUT_HIP_CHECK(hipStreamSynchronize(stream));     // the per-thread staging buffers are reused by the next call
-            // what lay between an interval's last bit and its RSTn was the scan kernel's to judge (restart_leftover_bad): a file-level
-            // failure, as a wrong or missing marker is where the scans are unstuffed
-            bool any_restarts = false;
-            for (int k = 0; k < n && !any_restarts; ++k) if (prep[(size_t)k].rc == GAMUT_HIP_OK) for (const ProgScanPrep& s : prep[(size_t)k].scans) any_restarts = any_restarts || s.restart_interval > 0;
-            if (any_restarts) {
+            // whatever a kernel flagged -- a bit pattern no code word begins, a run past coefficient 63, a segment that ran out, octets between an
+            // interval's last bit and its RSTn (restart_leftover_bad) -- is the host feeder's to judge (kHostRedo, below)
+            {
                 int lo = idx[0], hi = idx[0];
                 for (int i : idx) { lo = std::min(lo, i); hi = std::max(hi, i); }
                 std::vector<uint32_t> flags((size_t)(hi - lo + 1));
                 GAMUT_HIP_CHECK(hipMemcpy(flags.data(), st + lo, flags.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
                 for (int k = 0; k < n; ++k) {
                     ProgPrep& pp = prep[(size_t)k];
-                    if (pp.rc != GAMUT_HIP_OK) continue;
-                    const int i = idx[(size_t)k];
-                    if (flags[(size_t)(i - lo)] & kStatusBadRestart) {
-                        fail(&info[i], "bad restart marker");
-                        pp.rc = GAMUT_HIP_ERR_DECODE; snprintf(pp.msg, sizeof(pp.msg), "image %d: bad restart marker", i);
-                    }
+                    if (pp.rc == GAMUT_HIP_OK && flags[(size_t)(idx[(size_t)k] - lo)]) pp.rc = kHostRedo;
                 }
             }
             ms_kernels = ms_since(t_k);
@@ -1117,6 +1097,19 @@ int progressive_decode_device(const uint8_t* const* data, const size_t* len, con
     }
     if (trace) fprintf(stderr, "[gamut_hip] progressive_decode_device: %d files, %d levels: headers %.1f ms, unstuff %.1f ms, upload + kernels %.1f ms\n",
                        n, max_level + 1, ms_parse, ms_unstuff, ms_kernels);
+    {
+        std::vector<int> redo, at;
+        for (int k = 0; k < n; ++k) if (prep[(size_t)k].rc == kHostRedo) { redo.push_back(idx[(size_t)k]); at.push_back(k); }
+        if (!redo.empty()) {
+            std::vector<int> rcs; std::vector<std::string> msgs;
+            if (int rc = on_the_host(redo, rcs, msgs)) { *first_index = -1; return rc; }
+            for (size_t j = 0; j < redo.size(); ++j) {
+                ProgPrep& pp = prep[(size_t)at[j]];
+                pp.rc = rcs[j];
+                if (rcs[j] != GAMUT_HIP_OK) snprintf(pp.msg, sizeof(pp.msg), "image %d: %s", redo[j], msgs[j].c_str());
+            }
+        }
+    }
     int first_rc = GAMUT_HIP_OK;
     for (int k = 0; k < n; ++k) {
         const ProgPrep& pp = prep[(size_t)k];

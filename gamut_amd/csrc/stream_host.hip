@@ -48,10 +48,18 @@ struct JpegWalk {
     {
         while (!done) {
             switch (st) {
-            case kSoi:                                       // FF D8; anything else is not a JPEG: let the decoder say so
+            case kSoi: {                                     // locate_soi_marker (:1854-1908): FF D8 at once, or within the first 4097 bytes and before any FF D9
                 if (len - pos < 2) return;
-                if (p[pos] != 0xFF || p[pos + 1] != 0xD8) { done = true; return; }
-                pos += 2; st = kMarker; break;
+                if (p[0] == 0xFF && p[1] == 0xD8) { pos = 2; st = kMarker; break; }
+                size_t q = 2; bool found = false, never = false;
+                for (; q < len && q < 4097 && !found && !never; ++q) {
+                    if (p[q - 1] == 0xFF && p[q] == 0xD8) found = true;
+                    else if (p[q - 1] == 0xFF && p[q] == 0xD9) never = true;
+                }
+                if (found) { pos = q; st = kMarker; break; }
+                if (never || q >= 4097) { done = true; return; }   // not a JPEG: let the decoder say so
+                return;                                      // not decided yet: more bytes
+            }
             case kMarker: {                                  // FF (FF)* code, as next_marker skips fill bytes (:1578-1600)
                 while (pos < len && p[pos] != 0xFF) ++pos;   // garbage before a marker is skipped there too
                 size_t q = pos;

@@ -151,7 +151,9 @@ typedef struct gamut_hip_jpeg_frame {
     int32_t  mcus_per_row, mcus_per_col, blocks_per_mcu;
     int16_t* coeffs;            /* host */
     uint8_t* max_zag;           /* host */
-    float    pixel_aspect_ratio, dpi_y;   /* -1 when unknown */
+    float    pixel_aspect_ratio, dpi_y;   /* what decompress_jpeg_image_from_stream hands out (jpegload.d:3804-3805): from the last JFIF (APP0) / EXIF (APP1) segment the
+                                             decoder met -- in front of the frame, between scans or behind the last MCU row (find_eoi); JFIF without a unit: dpi_y -1;
+                                             a file with neither: NaN (the D struct's float members are never assigned, :510-512), NOT the -1 of :3719's comment */
 } gamut_hip_jpeg_frame;
 int  gamut_hip_jpeg_decode_coeffs(const uint8_t* data, size_t len, gamut_hip_jpeg_frame* out);
 void gamut_hip_jpeg_frame_free(gamut_hip_jpeg_frame* f);
@@ -173,8 +175,13 @@ int  gamut_hip_jpeg_scan_layout(const uint8_t* data, size_t len, gamut_hip_jpeg_
  * scans are decoded level by level on the device -- every scan of a level of every file in one launch; AC refinement
  * blocks a wave each -- then de-quantised in place (gamut_amd/csrc/jpeg_prog.hpp); fewer than twelve such files per host
  * thread are decoded by the host feeder and uploaded instead (GAMUT_HIP_JPEG_PROGRESSIVE=host / device forces either).
- * info[i] receives the geometry (host), status_host[i] (may be NULL) the per-file header status, and status_dev[i]
- * (device, may be NULL) becomes non-zero if file i's entropy stream is corrupt.  Returns when the decode has finished on `stream`;
+ * info[i] receives the geometry and the density (host), status_host[i] (may be NULL) the per-file verdict, and status_dev[i]
+ * (device, may be NULL) is non-zero only for a file the call refuses.  What a kernel cannot vouch for -- a bit pattern no code word
+ * begins, a segment that runs out, a wrong or missing RSTn, octets between an interval's last bit and its marker; the reference has a
+ * result for most of these (jpgd decodes symbol 0 and carries on, huff_decode :746-813) -- is decoded again by the host feeder
+ * (gamut_hip_jpeg_decode_coeffs) behind the device pass and uploaded, so a damaged file costs a host decode, an intact one nothing; the
+ * markers behind the scan (find_eoi :2826-2848) are walked on the host from where the device saw the scan end.
+ * Returns when the decode has finished on `stream`;
  * the status of the lowest-numbered failing file, GAMUT_HIP_OK if none. */
 int  gamut_hip_jpeg_entropy_decode_device(const uint8_t* const* data, const size_t* len, int count,
                                           const int64_t* coeff_offset, const int64_t* zag_offset,

@@ -200,6 +200,12 @@ def decompress_jpeg(data, req_comps=-1):
     return out, ac.value, par.value, dpi.value
 
 
+def same_density(got, want):
+    """pixelAspectRatio / dotsPerInchY pairs, bit for bit as floats except that NaN equals NaN (a file without JFIF / EXIF density: the D struct's
+    float members are never assigned, jpegload.d:510-512)"""
+    return all((np.isnan(np.float32(g)) and np.isnan(np.float32(w))) or np.float32(g) == np.float32(w) for g, w in zip(got, want))
+
+
 # ---------------------------------------------------------------- qoi
 class QoiDesc(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("channels", C.c_uint8), ("colorspace", C.c_uint8)]

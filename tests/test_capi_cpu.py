@@ -115,7 +115,7 @@ def test_jpeg_feeder_scan_headers_that_list_components_out_of_order():
     assert n_ok >= 20 and n_rej >= 10 and n_changed >= 15, (n_ok, n_rej, n_changed)
 
 
-FUZZ_FOUND = sorted(os.path.join(G, "jpeg_fuzz", n) for n in os.listdir(os.path.join(G, "jpeg_fuzz")))
+FUZZ_FOUND = sorted(os.path.join(G, "jpeg_fuzz", n) for n in os.listdir(os.path.join(G, "jpeg_fuzz")) if n.endswith(".jpg"))
 
 
 @pytest.mark.parametrize("path", FUZZ_FOUND, ids=[os.path.basename(p) for p in FUZZ_FOUND])
@@ -283,13 +283,25 @@ def test_jpeg_feeder_rejects_bad_streams():
     L = _capi.lib()
     fr = _capi.JpegFrame()
     good = open(os.path.join(G, "ref_images", "issue35.jpg"), "rb").read()
-    cases = [b"", b"\xff\xd8", b"\x89PNG\r\n\x1a\n" + b"0" * 64, good[:200], good[:4000],
+    cases = [b"", b"\xff\xd8", b"\x89PNG\r\n\x1a\n" + b"0" * 64, good[:200],
              good.replace(b"\xff\xc0", b"\xff\xc2", 1)]                                  # baseline scan under a progressive SOF: bad spectral selection
     for data in cases:
         buf = np.frombuffer(data, np.uint8) if data else np.zeros(1, np.uint8)
         rc = L.gamut_hip_jpeg_decode_coeffs(buf.ctypes.data, len(data), C.byref(fr))
         assert rc == _capi.ERR_DECODE and L.gamut_hip_last_error() != b"", data[:8]
         assert not fr.coeffs and not fr.max_zag
+        with pytest.raises(ValueError):
+            O.DecodedJpeg(data)
+    # a file that ends inside its scan is NOT refused: jpgd pads the stream with FF D9 (get_char, jpegload.d:631-652), the bit reader hands out 1-bits at
+    # the marker (get_octet :683-696) and a bit pattern no code word begins decodes as symbol 0 (huff_decode :746-813) -- the rest of the picture is flat
+    cut = good[:4000]
+    buf = np.frombuffer(cut, np.uint8)
+    assert L.gamut_hip_jpeg_decode_coeffs(buf.ctypes.data, buf.size, C.byref(fr)) == _capi.OK
+    d = O.DecodedJpeg(cut)
+    n = fr.mcus_per_row * fr.mcus_per_col * fr.blocks_per_mcu
+    assert np.array_equal(np.ctypeslib.as_array(fr.coeffs, (n, 64)), d.coeffs) and np.array_equal(np.ctypeslib.as_array(fr.max_zag, (n,)), d.max_zag)
+    assert not d.coeffs[-1].any() or d.max_zag[-1] == 1
+    L.gamut_hip_jpeg_frame_free(C.byref(fr))
     assert L.gamut_hip_jpeg_decode_coeffs(None, 0, None) == _capi.ERR_INVALID_ARG
 
 

@@ -90,6 +90,34 @@ def test_load_jpeg_with_flags(hip, path):
         assert im.loadFromMemory(data) and im.pixelAspectRatio == 1.0 and im.dotsPerInchY == 72.0
 
 
+def test_load_jpeg_density_and_verdicts_of_the_input_layer(hip):
+    """Image.loadFromMemory on the files of tests/golden/jpeg_fuzz (plugins/jpeg.d:61-100): an EXIF segment's resolution reaches pixelAspectRatio /
+    dotsPerInchY (2.0 / 150 for the round-4 review's probe), a malformed one fails the load, a file without any density hands on the NaN the D
+    struct's members start with (`== -1` at :96-97 does not catch it), a file that ends inside its scan loads."""
+    import json
+    import math
+    d = os.path.join(G, "jpeg_fuzz")
+    expected = json.load(open(os.path.join(d, "expected.json")))
+    for name, e in sorted(expected.items()):
+        data = open(os.path.join(d, name), "rb").read()
+        if data[:2] != b"\xff\xd8":
+            continue                                          # detectJPEG (plugins/jpeg.d:103-107) wants the signature at offset 0: not a JPEG for loadFromMemory
+        im = Image()
+        ok = im.loadFromMemory(data, gi.LOAD_RGB | gi.LOAD_8BIT)
+        assert ok == (e["verdict"] == "image"), (name, im.errorMessage)
+        if not ok:
+            assert im.errorMessage == "Image decoding failed", name
+            continue
+        assert (im.width, im.height) == (e["width"], e["height"])
+        for got, want in ((im.pixelAspectRatio, e["pixel_aspect_ratio"]), (im.dotsPerInchY, e["dpi_y"])):
+            assert math.isnan(got) if want == "nan" else np.float32(got) == np.float32(want), (name, got, want)
+        want_px = O.decompress_jpeg(data, 3)[0]
+        assert np.array_equal(im.pixels()[:, :e["width"] * 3], want_px), name
+    im = Image()
+    assert im.loadFromMemory(open(os.path.join(d, "exif_ii_300x150_r05.jpg"), "rb").read()) and (im.pixelAspectRatio, im.dotsPerInchY) == (2.0, 150.0)
+    assert not im.loadFromMemory(open(os.path.join(d, "exif_bad_byte_order_r05.jpg"), "rb").read())
+
+
 def test_load_png_with_flags(hip):
     rng = np.random.default_rng(4)
     w, h = 21, 13

@@ -283,6 +283,31 @@ def test_c_callbacks_with_the_reference_struct_layouts_decode(hip, tmp_path):
 
 
 @pytest.mark.gpu
+def test_jpeg_from_stream_on_the_input_layer_files(hip):
+    """decompress_jpeg_image_from_stream's drop-in on tests/golden/jpeg_fuzz, in pieces of 8192 and of 501 bytes: NULL / pixels / density as
+    expected.json has them (the stream walk must not stop early on bytes in front of SOI, nor at an EOI inside a segment)"""
+    import json
+    d = os.path.join(HERE, "golden", "jpeg_fuzz")
+    expected = json.load(open(os.path.join(d, "expected.json")))
+    libc = C.CDLL(None); libc.free.argtypes = [C.c_void_p]
+    for name, e in sorted(expected.items()):
+        data = open(os.path.join(d, name), "rb").read()
+        for piece in (8192, 501):
+            rd, st = _jpeg_reader(data, piece)
+            w, h, ac = C.c_int(), C.c_int(), C.c_int()
+            par, dpi = C.c_float(), C.c_float()
+            p = hip.gamut_hip_decompress_jpeg_image_from_stream(rd, None, C.byref(w), C.byref(h), C.byref(ac), C.byref(par), C.byref(dpi), 3)
+            assert bool(p) == (e["verdict"] == "image"), (name, piece, hip.gamut_hip_last_error())
+            if not p:
+                continue
+            got = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (h.value, w.value * 3)).copy()
+            libc.free(p)
+            assert np.array_equal(got, O.decompress_jpeg(data, 3)[0]), (name, piece)
+            exp = tuple(float("nan") if v == "nan" else v for v in (e["pixel_aspect_ratio"], e["dpi_y"]))
+            assert O.same_density((par.value, dpi.value), exp), (name, piece)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("path", JPEGS, ids=[os.path.basename(p) for p in JPEGS])
 def test_jpeg_from_stream_equals_oracle(hip, path):
     data = open(path, "rb").read()
@@ -299,7 +324,7 @@ def test_jpeg_from_stream_equals_oracle(hip, path):
             got = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (h.value, w.value * comps)).copy()
             libc.free(p)
             assert np.array_equal(got, exp[0])
-            assert (ac.value, par.value, dpi.value) == exp[1:]
+            assert ac.value == exp[1] and O.same_density((par.value, dpi.value), exp[2:])
             assert st["pos"] == len(data)                      # the fixtures end with EOI: nothing behind the image
     # optional out-pointers may be NULL, as in the reference's callers that do not want the DPI
     rd, _ = _jpeg_reader(data, 1 << 16)

@@ -688,6 +688,7 @@ void prog_prepare(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& f,
     P = Parser();
     int marker = open_frame(P, base, n, &f);
     if (marker < 0) { out.rc = GAMUT_HIP_ERR_DECODE; snprintf(out.msg, sizeof(out.msg), "image %d: %s", i, last_error_buf()); return; }
+    if (marker != 0xDA) { out.rc = kHostRedo; return; }        // a frame without a scan (every coefficient 0): nothing for the kernels, the host feeder writes the zeros
     out.comps = f.comps; out.nb = f.blocks_per_mcu; out.ny = f.comps == 1 ? 1 : P.hs[0] * P.vs[0];
     int max_h = 1, max_v = 1;
     for (int c = 0; c < f.comps; ++c) { out.hs[c] = P.hs[c]; out.vs[c] = P.vs[c]; if (P.hs[c] > max_h) max_h = P.hs[c]; if (P.vs[c] > max_v) max_v = P.vs[c]; }

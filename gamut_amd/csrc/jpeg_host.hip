@@ -1738,7 +1738,10 @@ void unstuff_file(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& f,
         if (!hit || hit + 1 >= base + n) { flush(n); q = n; break; }
         const uint8_t m = hit[1];
         q = (size_t)(hit - base);
-        if (m == 0x00) { flush(q + 1); copy_from = q + 2; q += 2; continue; }          // stuffed 0xFF: keep the FF, drop the 00
+        if (m == 0x00) {
+            if (!copying) { bad = true; break; }                                          // FF .. FF 00: the reference's input stopped at the FIRST of these FFs (not a stuffed byte: get_octet
+            flush(q + 1); copy_from = q + 2; q += 2; continue;                            //  looks one byte ahead), process_restart then reads "FF, fill, 00": for the host feeder (kHostRedo)
+        }                                                                                 // stuffed 0xFF: keep the FF, drop the 00
         flush(q); copying = false;                                                        // FF + non-zero: the data ends here (get_octet :683-696)
         if (m == 0xFF) { q += 1; fill = std::min(fill + 1, 4096); continue; }             // fill bytes before a marker
         if (m >= 0xD0 && m <= 0xD7 && ri && next_mcu + ri < total_mcus) {

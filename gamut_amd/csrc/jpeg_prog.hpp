@@ -788,7 +788,10 @@ void prog_unstuff(int i, const uint8_t* base, gamut_hip_jpeg_frame& f, ProgPrep&
             if (!hit || hit + 1 >= base + n) { flush(n); q = n; break; }
             const uint8_t m = hit[1];
             q = (size_t)(hit - base);
-            if (m == 0x00) { flush(q + 1); copy_from = q + 2; q += 2; continue; }      // stuffed 0xFF: keep the FF, drop the 00
+            if (m == 0x00) {
+                if (!copying) { bad = true; break; }                                    // FF .. FF 00: the input stopped at the first FF (see unstuff_file)
+                flush(q + 1); copy_from = q + 2; q += 2; continue;                      // stuffed 0xFF: keep the FF, drop the 00
+            }
             flush(q); copying = false;
             if (m == 0xFF) { q += 1; fill = std::min(fill + 1, 4096); continue; }
             if (m >= 0xD0 && m <= 0xD7 && ri && next_unit + ri < total) {

@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--total-images", type=int, default=0, help="mixed workload: images over ALL ranks (8192 = BASELINE.json configs[4]); "
                     "each rank takes total / N (strong scaling) instead of --batch")
     ap.add_argument("--no-also", action="store_true", help="default workload only: skip the `also` lines (the other BASELINE.json configs at their stated shapes)")
-    ap.add_argument("--also-seconds", type=float, default=240.0, help="wall-clock budget of the `also` lines; what does not fit is reported as skipped")
+    ap.add_argument("--also-seconds", type=float, default=330.0, help="wall-clock budget of the `also` lines; what does not fit is reported as skipped")
     ap.add_argument("--gather", action="store_true", help="N > 1: also time an all_gather of output slices (after the timed region)")
     return ap.parse_args()
 
@@ -130,6 +130,8 @@ def live_traffic(kernel_substr, pmc_batch):
 ALSO = [  # the other BASELINE.json configs at their stated shapes, each through this same script (its own parity check included)
     ("config 2, what a caller has: coefficients + max_zag from libjpeg-written photographs", "jpeg:photo", []),
     ("config 2's kernel family on 4:4:4 files (k_jpeg_cols)", "jpeg:4:1", []),
+    ("the headline batch -> rgb8, what loadJPEG produces when the caller sets no flags (plugins/jpeg.d:48-86)", "jpeg:3", []),
+    ("the headline batch -> l8 (LOAD_GREYSCALE)", "jpeg:1", []),
     ("config 3: 512 x 3840x2160 RGBA8, random row filters (a fifth Paeth)", "png", []),
     ("config 3: the same with the encoder heuristic's filters (no Paeth rows on this data)", "png:heuristic", []),
     ("config 4: rgba16 -> rgbaf32, 256 layers of 8192x8192 in resident chunks", "convert:rgba16:rgbaf32", ["--batch", "256"]),
@@ -150,7 +152,9 @@ def also_lines(budget_s):
         if left < 20:
             res.append({"what": what, "workload": wl, "skipped": "the --also-seconds budget ran out"})
             continue
-        cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", "20", "--warmup", "5", "--no-cpu", "--no-traffic", "--no-also"] + extra
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", "20", "--warmup", "5", "--no-cpu", "--no-also"] + extra
+        if not wl.startswith("png"):                                     # the PNG lines carry their HBM traffic, measured at their own batch
+            cmd.append("--no-traffic")
         t0 = time.perf_counter()
         try:
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=left, text=True)
@@ -164,6 +168,9 @@ def also_lines(budget_s):
                  "roofline_frac": j["roofline"]["frac"], "achieved_GB/s": j["roofline"]["achieved"], "kernel": j["roofline"]["kernel"],
                  "kernel_ms_avg": j["roofline"]["kernel_ms_avg"], "parity": "ok: " + str(j["config"].get("parity_check", "checked against the oracle before timing")), "steps": j["steps"],
                  "wall_s": round(time.perf_counter() - t0, 1)}
+            if j["roofline"].get("traffic"):
+                e["traffic"] = j["roofline"]["traffic"]; e["traffic_over_algorithmic"] = round(j["roofline"]["traffic"] / j["roofline"]["algorithmic_bytes_per_launch"], 4)
+                e["traffic_source"] = j["roofline"].get("traffic_source")
             for k in ("per_format", "waves_on_sparse_luma_passes", "y_blocks_max_zag_le_10"):
                 if k in j["config"]:
                     e[k] = j["config"][k]
@@ -642,7 +649,10 @@ def main():
         achieved = bytes_per_step / avg_kernel_s / 1e9
         traffic, traffic_src = None, None
         if world == 1 and not args.no_traffic and wl != "mixed":
-            pmc_batch = min(B, 64 if not wl.startswith("convert:") else 2)
+            # the counters are taken on the launch that is TIMED: the same batch (round 4 took them at batch 64, where the PNG kernel's
+            # second touch of a line still hit the L2: 1.05 x the algorithmic bytes there, 1.28 x at the timed 512).  convert: layers are
+            # independent 268 MB streams read once -- two of them.
+            pmc_batch = B if not wl.startswith("convert:") else min(B, 2)
             per_image, traffic_src = live_traffic(kernel_name, pmc_batch)
             traffic = None if per_image is None else round(per_image * B)
         if traffic is None:

@@ -1,8 +1,10 @@
 /**
  * gamut_hip.d -- D binding of include/gamut_hip.h (libgamut_hip.so), the file a Gamut maintainer adds as
  * `source/gamut/hip.d`.  The C header is the source of truth; tests/test_capi_cpu.py::test_d_binding_lists_every_export
- * checks that every function the header declares is declared here with the same number of parameters.
- * (No D compiler exists in the image this was written in: the file is checked textually, not compiled.)
+ * checks that every function the header declares is declared here with the same return and parameter TYPES (a C -> D type map),
+ * ::test_d_binding_struct_layouts that the structs declared here have the header's layout (size and every field offset).
+ * (No D compiler exists in the image this was written in: the file is checked textually, not compiled; the `static assert`s
+ * at the end of the extern(C) block are what a D compiler will check on the first build.)
  *
  * Linkage.  Everything inside the `extern(C)` block has C linkage -- including the function-pointer TYPES it declares.
  * The reference's own callbacks do NOT: `stream_read_jpeg` (plugins/jpeg.d:167), `stb_read`, `stb_skip`, `stb_eof`
@@ -151,6 +153,17 @@ extern(C)
     int  gamut_hip_comm_world(const(gamut_hip_comm)* comm);
     int  gamut_hip_gather_outputs_device(gamut_hip_comm* comm, const(void)* local, long local_stride, long bytes_per_image,
                                          long total_images, void* dst, long dst_stride, int root, void* stream);
+
+    // ---- struct layouts: the numbers gcc prints for include/gamut_hip.h (tests/c/abi_layout.c); a D compiler checks them the first time
+    //      this file is built, tests/test_capi_cpu.py::test_d_binding_struct_layouts checks them against the C compiler every run -------------
+    static assert(gamut_hip_jpeg_desc.sizeof == 48 && gamut_hip_jpeg_desc.coeffs.offsetof == 0 && gamut_hip_jpeg_desc.max_zag.offsetof == 8 && gamut_hip_jpeg_desc.out_.offsetof == 16 && gamut_hip_jpeg_desc.out_pitch.offsetof == 24 && gamut_hip_jpeg_desc.width.offsetof == 32 && gamut_hip_jpeg_desc.height.offsetof == 36 && gamut_hip_jpeg_desc.scan_type.offsetof == 40 && gamut_hip_jpeg_desc.out_comps.offsetof == 44);
+    static assert(gamut_hip_jpeg_frame.sizeof == 56 && gamut_hip_jpeg_frame.width.offsetof == 0 && gamut_hip_jpeg_frame.height.offsetof == 4 && gamut_hip_jpeg_frame.comps.offsetof == 8 && gamut_hip_jpeg_frame.scan_type.offsetof == 12 && gamut_hip_jpeg_frame.mcus_per_row.offsetof == 16 && gamut_hip_jpeg_frame.mcus_per_col.offsetof == 20 && gamut_hip_jpeg_frame.blocks_per_mcu.offsetof == 24 && gamut_hip_jpeg_frame.coeffs.offsetof == 32 && gamut_hip_jpeg_frame.max_zag.offsetof == 40 && gamut_hip_jpeg_frame.pixel_aspect_ratio.offsetof == 48 && gamut_hip_jpeg_frame.dpi_y.offsetof == 52);
+    static assert(gamut_hip_png_desc.sizeof == 48 && gamut_hip_png_desc.raw.offsetof == 0 && gamut_hip_png_desc.out_.offsetof == 8 && gamut_hip_png_desc.raw_len.offsetof == 16 && gamut_hip_png_desc.x.offsetof == 20 && gamut_hip_png_desc.y.offsetof == 24 && gamut_hip_png_desc.img_n.offsetof == 28 && gamut_hip_png_desc.out_n.offsetof == 32 && gamut_hip_png_desc.depth.offsetof == 36 && gamut_hip_png_desc.color.offsetof == 40);
+    static assert(gamut_hip_stbi_io_callbacks.sizeof == 24 && gamut_hip_stbi_io_callbacks.read.offsetof == 0 && gamut_hip_stbi_io_callbacks.skip.offsetof == 8 && gamut_hip_stbi_io_callbacks.eof.offsetof == 16);
+    static assert(gamut_hip_inflate_desc.sizeof == 24 && gamut_hip_inflate_desc.src.offsetof == 0 && gamut_hip_inflate_desc.dst.offsetof == 8 && gamut_hip_inflate_desc.src_len.offsetof == 16 && gamut_hip_inflate_desc.dst_cap.offsetof == 20);
+    static assert(gamut_hip_png_info.sizeof == 32 && gamut_hip_png_info.width.offsetof == 0 && gamut_hip_png_info.height.offsetof == 4 && gamut_hip_png_info.channels_in_file.offsetof == 8 && gamut_hip_png_info.channels.offsetof == 12 && gamut_hip_png_info.bits.offsetof == 16 && gamut_hip_png_info.pixels_per_meter_x.offsetof == 20 && gamut_hip_png_info.pixels_per_meter_y.offsetof == 24 && gamut_hip_png_info.pixel_aspect_ratio.offsetof == 28);
+    static assert(gamut_hip_qoi_desc.sizeof == 12 && gamut_hip_qoi_desc.width.offsetof == 0 && gamut_hip_qoi_desc.height.offsetof == 4 && gamut_hip_qoi_desc.channels.offsetof == 8 && gamut_hip_qoi_desc.colorspace.offsetof == 9);
+    static assert(gamut_hip_image_info.sizeof == 20 && gamut_hip_image_info.format.offsetof == 0 && gamut_hip_image_info.width.offsetof == 4 && gamut_hip_image_info.height.offsetof == 8 && gamut_hip_image_info.channels_in_file.offsetof == 12 && gamut_hip_image_info.channels.offsetof == 16);
 }
 
 // ================================================================================================================

@@ -24,22 +24,40 @@ struct Worker {
     void ensure()
     {
         if (started) return;
-        started = true;
         std::thread([this] {
             for (;;) {
                 std::function<void()> j;
                 { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [this] { return pending; }); j = std::move(job); pending = false; }
-                j();
+                try { j(); } catch (...) { }                 // (a leg reports through its LegResult; nothing may leave a detached thread)
                 { std::lock_guard<std::mutex> lk(m); done = true; }
                 cv.notify_all();
             }
         }).detach();
+        started = true;                                          // (only once the thread exists: a failed start throws and is tried again)
     }
     void submit(std::function<void()> j) { { std::lock_guard<std::mutex> lk(m); job = std::move(j); pending = true; done = false; } cv.notify_all(); }
     void wait() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [this] { return done; }); }
 };
+// A pool per DEVICE: a host that drives its GPUs from a thread each ("one host thread + one HIP stream per GPU") keeps
+// the three-way overlap on every one of them (one process-wide pool let the first caller overlap its legs and made the seven others run
+// theirs one after the other).  Two threads on ONE device: the second finds the pool taken and runs its legs in turn, as before.
 struct Pool { std::mutex busy; Worker w[2]; };
-Pool& pool() { static Pool* p = new Pool(); return *p; }        // never destroyed: the threads outlive main()
+Pool& pool(int dev)                                             // never destroyed: the threads outlive main()
+{
+    static std::mutex m;
+    static Pool* pools[64] = { nullptr };
+    std::lock_guard<std::mutex> lk(m);
+    Pool*& p = pools[dev < 0 || dev >= 64 ? 0 : dev];
+    if (!p) p = new Pool();
+    return *p;
+}
+// What a worker runs refers to the caller's frame (leg[], res[]): the caller must not leave that frame -- by return or by exception --
+// while a worker still runs.  This waits for every job that was handed over, on every way out.
+struct SubmittedJobs {
+    Pool& P; int n = 0;
+    explicit SubmittedJobs(Pool& p) : P(p) {}
+    ~SubmittedJobs() { for (int k = 0; k < n; ++k) P.w[k].wait(); }
+};
 
 struct LegResult { int rc = GAMUT_HIP_OK; char msg[256] = { 0 }; };
 
@@ -133,21 +151,18 @@ extern "C" int gamut_hip_decode_batch_device(const uint8_t* const* data, const s
         // The longest legs first on the workers (PNG: inflate-bound, QOI: PCIe-bound), JPEG on the calling thread.  When another
         // thread's mixed batch holds the workers, the legs run one after the other here: same results.
         static const bool serial = [] { const char* e = getenv("GAMUT_HIP_MIXED_SERIAL"); return e && *e && atoi(e) != 0; }();     // measurements
-        Pool& P = pool();
+        Pool& P = pool(dev);
         const int legs = (int)!idx[0].empty() + (int)!idx[1].empty() + (int)!idx[2].empty();
         if (legs > 1 && !serial && P.busy.try_lock()) {
             std::lock_guard<std::mutex> hold(P.busy, std::adopt_lock);
-            bool on_worker[3] = { false, false, false };
-            int w = 0;
+            SubmittedJobs jobs(P);                                                            // (declared after the lock: waits before it is released)
             for (int f : { (int)GAMUT_HIP_FORMAT_PNG, (int)GAMUT_HIP_FORMAT_QOI }) {
                 if (idx[f].empty()) continue;
-                P.w[w].ensure();
-                P.w[w].submit([&, f] { run_leg(f, true); });
-                on_worker[f] = true; ++w;
+                P.w[jobs.n].ensure();
+                P.w[jobs.n].submit([&, f] { run_leg(f, true); });
+                ++jobs.n;                                                                     // only what was really handed over is waited for
             }
             run_leg(GAMUT_HIP_FORMAT_JPEG, true);
-            w = 0;
-            for (int f : { (int)GAMUT_HIP_FORMAT_PNG, (int)GAMUT_HIP_FORMAT_QOI }) if (on_worker[f]) P.w[w++].wait();
         } else {
             for (int f = 0; f < 3; ++f) run_leg(f, false);
         }

@@ -44,8 +44,14 @@ Rccl& rccl()
     static std::once_flag once;
     std::call_once(once, [] {
         const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
-        for (const char* n : names) if ((r.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;          // reuse a loaded copy (PyTorch's)
-        if (!r.h) for (const char* n : names) if ((r.h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+        // GAMUT_HIP_RCCL_LIB: the library to bind instead (a site's own RCCL build; tests/c/rccl_double.c, which lets the multi-rank
+        // gather run with ranks that are threads on one device).  Set: that file or nothing -- no silent fall-back to another copy.
+        const char* forced = getenv("GAMUT_HIP_RCCL_LIB");
+        if (forced && *forced) r.h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        else {
+            for (const char* n : names) if ((r.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;      // reuse a loaded copy (PyTorch's)
+            if (!r.h) for (const char* n : names) if ((r.h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+        }
         if (!r.h) { const char* e = dlerror(); if (e) snprintf(r.why, sizeof(r.why), "%s", e); return; }
 #define GAMUT_SYM(field, name) *(void**)(&r.field) = dlsym(r.h, name)
         GAMUT_SYM(GetUniqueId, "ncclGetUniqueId"); GAMUT_SYM(CommInitRank, "ncclCommInitRank"); GAMUT_SYM(CommDestroy, "ncclCommDestroy");

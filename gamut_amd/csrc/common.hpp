@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <memory>
 #include <new>
 #include <algorithm>
 #include <thread>
@@ -47,11 +48,11 @@ template <class T> struct PerDevice {
     {
         const int d = current_device();
         for (int i = 0; i < n; ++i) if (slots[i].dev == d) return *slots[i].v;
+        std::unique_ptr<T> v(new T());                       // (allocation failure here throws: the entry points catch and report it)
         Slot* grown = static_cast<Slot*>(realloc(slots, (size_t)(n + 1) * sizeof(Slot)));
-        T* v = new T();                                      // (allocation failure here throws: the entry points catch and report it)
-        if (!grown) { delete v; throw std::bad_alloc(); }
-        slots = grown;
-        slots[n] = Slot{ d, v };
+        if (!grown) throw std::bad_alloc();                  // (`slots` is untouched by a failed realloc)
+        slots = grown;                                       // nothing can throw between the realloc and this line
+        slots[n] = Slot{ d, v.release() };
         return *slots[n++].v;
     }
 };
@@ -152,7 +153,8 @@ int host_threads();
 // staging again.  A helper that arrives after the indices are gone returns at once, so calls from several caller threads (the three
 // legs of gamut_hip_decode_batch_device) share the pool without waiting for one another's helpers to START: a call returns when its
 // own indices are done and its own helpers have left.
-void pool_submit(void (*run)(void*, int), void* ctx, int first_worker, int n_helpers, std::atomic<int>* left);
+void pool_submit(void (*run)(void*, int), void* ctx, int first_worker, int n_helpers, std::atomic<int>* left);     // never throws
+void pool_cancel(std::atomic<int>* left);                  // takes back the caller's tasks that no helper has started
 template <class Fn> void parallel_for(int count, int workers, Fn fn)          // fn(worker, index); the caller runs worker 0
 {
     struct Ctx { std::atomic<int> next{ 0 }; int count; Fn* fn; } c;
@@ -162,6 +164,7 @@ template <class Fn> void parallel_for(int count, int workers, Fn fn)          //
     const int helpers = workers - 1 < count - 1 ? workers - 1 : count - 1;
     if (helpers > 0) pool_submit(run, &c, 1, helpers, &left);
     run(&c, 0);
+    if (left.load(std::memory_order_acquire) > 0) pool_cancel(&left);
     while (left.load(std::memory_order_acquire) > 0) std::this_thread::yield();      // (the helpers still hold references to c and fn)
 }
 

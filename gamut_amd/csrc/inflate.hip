@@ -1079,9 +1079,12 @@ int inflate_scratch(int count, hipStream_t stream, InflateScratch& out)
         // A caller that makes a stream per batch would add an entry per batch: beyond 8 entries the least recently used ones go.  Their
         // stream handles may be dead by now, so nothing stream-specific can be asked of them: the device is drained once instead.
         if (tables.size() >= 8) {
-            (void)hipDeviceSynchronize();
             std::sort(tables.begin(), tables.end(), [](const StreamTable& a, const StreamTable& b) { return a.used > b.used; });
-            while (tables.size() > 4) { if (tables.back().p) (void)hipFree(tables.back().p); tables.pop_back(); }
+            while (tables.size() > 4) {                        // (an entry's memory belongs to ITS device: that is the one to drain)
+                if (tables.back().p) { (void)hipSetDevice(tables.back().device); (void)hipDeviceSynchronize(); (void)hipFree(tables.back().p); }
+                tables.pop_back();
+            }
+            (void)hipSetDevice(device);
         }
         tables.push_back(StreamTable{ device, stream, nullptr, 0, 0, 0 });
         e = &tables.back();
@@ -1141,6 +1144,9 @@ int inflate_launch(const gamut_hip_inflate_desc* descs, int count, uint32_t* out
     if (int rc = inflate_items(descs, count, items)) return rc;
     InflateScratch sc;
     if (int rc = inflate_scratch(count, stream, sc)) return rc;
+    // the lists' busy flags: every workgroup puts its own back, but a launch that died half way (a fault the process survived) would
+    // leave some set for ever -- fewer lists for the launches after it on this stream, or a spin without end.  2 KB, stream-ordered.
+    GAMUT_HIP_CHECK(hipMemsetAsync(sc.busy, 0, (size_t)sc.n_slots * 4, stream));
     GAMUT_HIP_CHECK(hipMemcpyAsync(sc.items, items.data(), items.size() * sizeof(InfItem), hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(k_inflate, dim3((unsigned)count), dim3(kT), sizeof(Shared), stream, (const InfItem*)sc.items, count, sc.toks, sc.busy, sc.n_slots, out_len_dev, status_dev, (InfState*)nullptr, (const uint32_t*)nullptr);
     return launch_status("inflate");
@@ -1154,6 +1160,9 @@ int inflate_sliced_begin(const gamut_hip_inflate_desc* descs, int count, hipStre
     if (int rc = inflate_items(descs, count, items)) return rc;
     InflateScratch sc;
     if (int rc = inflate_scratch(count, stream, sc)) return rc;
+    // the lists' busy flags: every workgroup puts its own back, but a launch that died half way (a fault the process survived) would
+    // leave some set for ever -- fewer lists for the launches after it on this stream, or a spin without end.  2 KB, stream-ordered.
+    GAMUT_HIP_CHECK(hipMemsetAsync(sc.busy, 0, (size_t)sc.n_slots * 4, stream));
     GAMUT_HIP_CHECK(hipMemcpyAsync(sc.items, items.data(), items.size() * sizeof(InfItem), hipMemcpyHostToDevice, stream));
     GAMUT_HIP_CHECK(hipMemsetAsync(sc.states, 0, (size_t)count * sizeof(InfState), stream));
     return GAMUT_HIP_OK;

@@ -1655,7 +1655,6 @@ struct FilePrep {
     size_t scan_pos = 0, cap = 0, used = 0;                    // first scan byte in the file; bound / actual size of the unstuffed segments
     int restart_interval = 0, total_mcus = 0;
     bool dev_unstuff = false;                                  // the scan goes up as it is and k_jpeg_unstuff makes the segments (items: begin / end filled in there)
-    bool pinned_src = false;                                   // ... straight from the caller's buffer (page-locked host memory): no staging copy
     size_t raw_len = 0;                                        // bytes from scan_pos to the end of the file
     size_t scan_end = 0;                                       // host-unstuffed files: where the scan's data ended (the marker find_eoi starts at), from the start of the file
     std::vector<DevItem> items;                                // begin / end relative to the file's slot in the blob; pad = (estimated) bytes of the segment
@@ -1707,7 +1706,6 @@ void prepare_header(int i, const uint8_t* base, size_t n, gamut_hip_jpeg_frame& 
         // (Tried: scans of files that live in page-locked memory uploaded from where they are, a DMA per file -- 1024 x 225 kB: 17.0 ->
         // 20.1 ms, profiles/r04_pinned.txt: a DMA per file costs more than the copy into one pinned image and one DMA per group.  The QOI
         // call, whose files are megabytes, keeps that path: same time, no host copy.)
-        out.pinned_src = false;
     }
 }
 
@@ -2010,9 +2008,6 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
         int total_long = 0, total_short = 0;
         double ms_kernels_issue = 0;
         std::vector<DevRaw> raws;
-        std::atomic<int> dma_failed{ 0 };
-        int dev_now = 0;
-        (void)hipGetDevice(&dev_now);
         for (int g = 0; g < n_groups; ++g) {
             const int g_lo = (int)((int64_t)count * g / n_groups), g_hi = (int)((int64_t)count * (g + 1) / n_groups);
             if (g_hi <= g_lo) continue;
@@ -2020,23 +2015,17 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
                 const int i = g_lo + k;
                 FilePrep& fp = prep[(size_t)i];
                 if (fp.rc != GAMUT_HIP_OK) return;
-                if (fp.dev_unstuff && fp.pinned_src) {           // page-locked already: the DMA reads the caller's buffer
-                    (void)hipSetDevice(dev_now);
-                    if (fp.raw_len && hipMemcpyAsync(d_raw + raw_off[(size_t)i], data[i] + fp.scan_pos, fp.raw_len, hipMemcpyHostToDevice, copy_stream) != hipSuccess) { (void)hipGetLastError(); dma_failed = 1; }
-                }
-                else if (fp.dev_unstuff) memcpy(h_raw + raw_off[(size_t)i], data[i] + fp.scan_pos, fp.raw_len);
+                if (fp.dev_unstuff) memcpy(h_raw + raw_off[(size_t)i], data[i] + fp.scan_pos, fp.raw_len);
                 else unstuff_file(i, data[i], len[i], info[i], fp, h_blob + blob_off[(size_t)i]);
             });
-            if (dma_failed) return set_error(GAMUT_HIP_ERR_HIP, "jpeg: upload from the caller's page-locked buffer failed");
             {   // the group's uploads: one DMA per run of neighbouring slots of the same kind
                 int i = g_lo;
                 while (i < g_hi) {
                     const FilePrep& fp = prep[(size_t)i];
                     if (fp.rc != GAMUT_HIP_OK || fp.used == 0) { ++i; continue; }
-                    if (fp.dev_unstuff && fp.pinned_src) { ++i; continue; }           // went up by itself
                     const bool dev = fp.dev_unstuff;
                     int j = i; size_t b0 = dev ? raw_off[(size_t)i] : blob_off[(size_t)i], b1 = b0;
-                    while (j < g_hi && (prep[(size_t)j].rc != GAMUT_HIP_OK || prep[(size_t)j].used == 0 || (prep[(size_t)j].dev_unstuff == dev && !(prep[(size_t)j].dev_unstuff && prep[(size_t)j].pinned_src)))) {
+                    while (j < g_hi && (prep[(size_t)j].rc != GAMUT_HIP_OK || prep[(size_t)j].used == 0 || prep[(size_t)j].dev_unstuff == dev)) {
                         const FilePrep& fj = prep[(size_t)j];
                         if (fj.rc == GAMUT_HIP_OK && fj.used) b1 = dev ? raw_off[(size_t)j] + fj.raw_len : blob_off[(size_t)j] + fj.used;
                         ++j;

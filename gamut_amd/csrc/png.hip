@@ -112,7 +112,7 @@ __device__ __forceinline__ u32 add_bytes(u32 x, u32 y)
 // bytewise floor((a + b) / 2), the Avg predictor (9-bit sum, stbdec.d:1497)
 __device__ __forceinline__ u32 avg_bytes(u32 a, u32 b)
 {
-    return (a & b) + ((u32)__builtin_amdgcn_bitop3_b32(a, b, 0xfefefefeu, 0x28) >> 1);  // 0x28: (a ^ b) & c in one instruction (the builtin returns int)
+    return __builtin_amdgcn_lerp(a, b, 0u);         // v_lerp_u8: per byte (a + b + (c & 1)) >> 1 with a 9-bit sum -- c = 0: the floor
 }
 // ---- stbi__paeth (stbdec.d:1390-1401) on two channels at once, in packed FP16 ---------------------------------
 // A byte n is carried as the half-precision number 1024 + n, whose bit pattern is simply 0x6400 | n (ulp = 1 in
@@ -136,15 +136,14 @@ __device__ __forceinline__ u32 pkf_abs(u32 t) { u32 r; asm("v_pk_max_f16 %0, %1,
 // Avg / None: (.., ff) -> the third candidate, which is c for Paeth rows, avg(a, b) for Avg rows and 0 for None rows.
 // The two channel pairs (L: bytes 0,1  H: bytes 2,3) are written interleaved so that no packed instruction consumes the
 // result of the one just before it (gfx950 needs a wait state there).
-struct RowFilter { u32 mA, mB, mAvg; u32 sel1, sel2; bool paeth, avg; };     // None/Sub/Up/Avg as one masked form; the Paeth-band form
+struct RowFilter { u32 mA, mB, mAvg, mP; u32 sel1, sel2; };                  // None/Sub/Up/Avg as one masked form; the Paeth-band form
 __device__ __forceinline__ RowFilter row_filter(u32 f)
 {
     const u32 SIGNS = 0x0b0a0908u, ZERO = 0x0c0c0c0cu, ONES = 0x0d0d0d0du, FF = 0xFFFFFFFFu;
     RowFilter r;
-    r.mA = f == 1 ? FF : 0u; r.mB = f == 2 ? FF : 0u; r.mAvg = f == 3 ? FF : 0u;
+    r.mA = f == 1 ? FF : 0u; r.mB = f == 2 ? FF : 0u; r.mAvg = f == 3 ? FF : 0u; r.mP = f == 4 ? FF : 0u;
     r.sel1 = f == 4 ? SIGNS : f == 2 ? ONES : ZERO;
     r.sel2 = f == 4 ? SIGNS : (f == 0 || f == 3) ? ONES : ZERO;
-    r.paeth = f == 4; r.avg = f == 3;
     return r;
 }
 __device__ __forceinline__ u32 bfi(u32 m, u32 x, u32 y) { return (m & x) | (~m & y); }              // m ? x : y, bit by bit
@@ -164,7 +163,9 @@ __device__ __forceinline__ u32 paeth_band_pred(const RowFilter& f, u32 a, u32 b,
     const u32 mL  = pkf_min(paL, pbL),      mH  = pkf_min(paH, pbH);
     const u32 d2L = pkf_sub(pcL, mL),       d2H = pkf_sub(pcH, mH);                     // < 0: c over either  (x - x = +0: ties keep)
     const u32 m1 = __builtin_amdgcn_perm(d1H, d1L, f.sel1), m2 = __builtin_amdgcn_perm(d2H, d2L, f.sel2);
-    const u32 third = f.paeth ? c : f.avg ? avg_bytes(a, b) : 0u;
+    u32 third;                                                                           // (c & mP) | (avg & mAvg): two masks of the lane -- v_and + v_and_or,
+    asm("v_and_b32 %0, %1, %2\n\tv_and_or_b32 %0, %3, %4, %0" : "=&v"(third) : "v"(c), "v"(f.mP), "v"(avg_bytes(a, b)), "v"(f.mAvg));   // which the compiler turns into three selects
+
     return bfi(m2, third, bfi(m1, b, a));
 }
 
@@ -516,8 +517,8 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
     // row crow of the band if the image has it, else the band's first row; + 8k rows per transfer
     const uint8_t* craw = raw + (int64_t)(band * 64 + ((u32)crow < rows_left ? crow : 0)) * (a.wb + 1) + 1;
     uint8_t* cdst = D + (int64_t)(band * 64 + crow) * a.d_pitch;
-    uint8_t* dband = nullptr;                                           // the band's first output row (wave-uniform: the fast write-back adds lane offsets)
-    if constexpr (AL) {
+    uint8_t* dband;                                                     // the band's first output row (wave-uniform: the fast write-back adds lane offsets)
+    {
         const int64_t bo = (int64_t)(band * 64) * a.d_pitch;
         dband = D + (int64_t)(((uint64_t)(u32)__builtin_amdgcn_readfirstlane((int)((uint64_t)bo >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)(uint64_t)bo));
     }
@@ -625,12 +626,30 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
         }
     };
     // the tiles that may take the fast forms (wave-uniform)
-    const bool al_full = AL && rows_left >= 64;
+    const bool full64 = rows_left >= 64, al_full = AL && full64;
     auto fast_prefetch_ok = [&](u32 T0) { return al_full && T0 >= 64 && T0 + 16 <= full_iters; };      // chunks T0 - 62 .. T0 + 15 of every row exist
     auto fast_drop_ok     = [&](u32 T0) { return al_full && T0 >= 72; };                                  // no chunk in front of its row
-    auto fast_wb_ok       = [&](u32 T0) { return al_full && T0 >= 64 && T0 + 8 <= wb_iters; };            // every row writes a whole group
+    auto fast_wb_ok       = [&](u32 T0) { return full64 && T0 >= 64 && T0 + 8 <= wb_iters; };             // every row writes a whole group
+    // the row-aligned grid's own fast form: 64 live rows, every piece of the tile a whole piece inside its row -- the address is a
+    // constant of the lane behind a wave-uniform pointer that moves by 8 rows less 8 pieces per transfer and a piece per trip
+    u32 ploff = 0;
+    const uint8_t* pbase = nullptr;
+    if constexpr (!AL) {
+        const int64_t uo = (int64_t)band * 64 * (a.wb + 1) + 1 - 64 * IB;
+        pbase = raw + (int64_t)(((uint64_t)(u32)__builtin_amdgcn_readfirstlane((int)((uint64_t)uo >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)(uint64_t)uo));
+        ploff = (u32)crow * (a.wb + 1) + (u32)(64 + cslot - crow) * IB;
+    }
     auto prefetch_tile = [&](u32 T0) {
         if constexpr (AL) { if (fast_prefetch_ok(T0)) prefetch_fast(T0); else prefetch_line((int)T0); return; }
+        if (!PNG_NT_LOADS && full64 && T0 >= 64 && T0 + 8 <= full_iters) {
+            const uint8_t* pt = pbase + (size_t)T0 * IB;
+            #pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const PackedU32* q = reinterpret_cast<const PackedU32*>(pt + (int64_t)k * 8 * ((int64_t)a.wb + 1 - IB) + ploff);
+                pre[k] = make_uint4(q[0].v, q[1].v, q[2].v, RGBA ? 0u : q[3].v);
+            }
+            return;
+        }
         #pragma unroll
         for (int k = 0; k < 8; ++k) {
             int it = (int)T0 + cslot - (8 * k + crow);                                     // piece of row 8k+crow used in trip T0 + cslot
@@ -754,11 +773,10 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
                 *reinterpret_cast<uint4*>(co_ring + k * 8 * PITCH + slot * 16) = it < 0 ? make_uint4(0u, 0u, 0u, 0u) : pre[k];
             }
         } else {
+            const u32 s0 = ((T0 + (u32)cslot - (u32)crow) & (RING - 1)) * 16;              // (x - 8 k) mod 16: bit 3 flips with k
+            uint8_t* const wr[2] = { co_ring + s0, co_ring + (s0 ^ 128u) };
             #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const u32 slot = (T0 + (u32)cslot - (u32)(8 * k + crow)) & (RING - 1);
-                *reinterpret_cast<uint4*>(co_ring + k * 8 * PITCH + slot * 16) = pre[k];
-            }
+            for (int k = 0; k < 8; ++k) *reinterpret_cast<uint4*>(wr[k & 1] + k * 8 * PITCH) = pre[k];
         }
         prefetch_tile(T0 + TT);
         // some lane meets the partial last piece of its row (iteration full_iters, trip full_iters + lane) in this tile
@@ -849,7 +867,7 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
 
         // write back the group of 8 pieces each row completed with this tile: one aligned 128-byte run per row
         uint4 wbv[8];                               // all eight LDS reads first: one wait instead of eight round trips in a row
-        if (AL && fast_wb_ok(T0)) {
+        if (fast_wb_ok(T0)) {
             // every row of the band writes a whole group: piece it = T0 - 8 k - 8 [crow > 0] + cslot of row 8 k + crow.  Its ring slot is
             // (cslot | 8 [crow > 0] ^ 8 [k odd] ^ (T0 & 8)): two addresses per tile; its place in the output is a lane constant
             // minus 128 k behind a wave-uniform row pointer -- no predicates, no per-row address arithmetic

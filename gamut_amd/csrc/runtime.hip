@@ -74,14 +74,36 @@ HelperPool& helper_pool() { static HelperPool* p = new HelperPool(); return *p; 
 
 void pool_submit(void (*run)(void*, int), void* ctx, int first_worker, int n_helpers, std::atomic<int>* left)
 {
+    // Nothing may leave this function once a task is visible to a helper: the tasks refer to the caller's frame.  Threads are started
+    // and the queue's room is reserved FIRST (both may fail: then fewer helpers, or none, take part and the caller does the work);
+    // `left` is published with the number of tasks that really go in, and push_back into reserved room cannot throw.
     HelperPool& P = helper_pool();
-    left->store(n_helpers, std::memory_order_relaxed);
+    int queued = 0;
     {
         std::lock_guard<std::mutex> lk(P.m);
-        P.start();
-        for (int k = 0; k < n_helpers; ++k) P.q.push_back(PoolTask{ run, ctx, first_worker + k, left });
+        try { P.start(); } catch (...) { }
+        if (P.threads > 0) {
+            try { P.q.reserve(P.q.size() + (size_t)n_helpers); queued = n_helpers; } catch (...) { queued = 0; }
+        }
+        left->store(queued, std::memory_order_relaxed);
+        for (int k = 0; k < queued; ++k) P.q.push_back(PoolTask{ run, ctx, first_worker + k, left });
     }
-    P.cv.notify_all();
+    if (queued) P.cv.notify_all();
+}
+// The caller has run out of indices: its tasks that no helper has picked up yet have nothing to do -- take them back instead of
+// waiting for busy helpers (another leg's long copy tasks) to dequeue them one by one.
+void pool_cancel(std::atomic<int>* left)
+{
+    HelperPool& P = helper_pool();
+    std::lock_guard<std::mutex> lk(P.m);
+    size_t k = P.head; int removed = 0;
+    for (size_t i = P.head; i < P.q.size(); ++i) {
+        if (P.q[i].left == left) { ++removed; continue; }
+        P.q[k++] = P.q[i];
+    }
+    P.q.resize(k);
+    if (P.head == P.q.size()) { P.q.clear(); P.head = 0; }
+    if (removed) left->fetch_sub(removed, std::memory_order_release);
 }
 
 hipStream_t thread_stream()

@@ -18,7 +18,21 @@ def owner_of(index, world):
     return index % world
 
 
-def gather_outputs(local_outputs, n_items, rank, world, group=None):
+def _collective_device(local_outputs, device, group):
+    """Where the gather's buffers live.  A rank that owns no image (n_items < world) has no tensor to take the device from, and an
+    RCCL all_gather needs GPU buffers on EVERY rank: the caller's `device`, else the outputs' device, else -- backend "nccl" --
+    this process's current GPU (one process per GPU: torch.cuda.set_device was the launcher's first act), else the CPU (gloo)."""
+    import torch.distributed as dist
+    if device is not None:
+        return torch.device(device)
+    if local_outputs:
+        return local_outputs[0].device
+    if dist.is_initialized() and dist.get_backend(group) == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def gather_outputs(local_outputs, n_items, rank, world, group=None, device=None):
     """All-gather per-image outputs.
 
     local_outputs: list of 1-D uint8 tensors, one per index in shard_indices(n_items, rank, world) (same device).
@@ -27,9 +41,9 @@ def gather_outputs(local_outputs, n_items, rank, world, group=None):
     import torch.distributed as dist
     mine = shard_indices(n_items, rank, world)
     assert len(local_outputs) == len(mine)
-    dev = local_outputs[0].device if local_outputs else torch.device("cpu")
     if world == 1:
         return list(local_outputs)
+    dev = _collective_device(local_outputs, device, group)
     per_rank = (n_items + world - 1) // world
     lens = torch.zeros(per_rank, dtype=torch.int64, device=dev)
     for k, t in enumerate(local_outputs):

@@ -376,35 +376,171 @@ def test_argument_validation_needs_no_device():
     assert L.gamut_hip_png_read_header(p, 64, C.byref(hd)) == _capi.ERR_DECODE and L.gamut_hip_png_read_header(p, 64, None) == _capi.ERR_INVALID_ARG
 
 
+def _strip_comments(text):
+    import re
+    return re.sub(r"//[^\n]*", "", re.sub(r"/\*.*?\*/", "", text, flags=re.S))
+
+
+def _split_args(args):
+    out, depth, cur = [], 0, ""
+    for ch in args:
+        depth += ch == "("
+        depth -= ch == ")"
+        if ch == "," and depth == 0:
+            out.append(cur); cur = ""
+        else:
+            cur += ch
+    if cur.strip() not in ("", "void"):
+        out.append(cur)
+    return out
+
+
+_C_SCALARS = {"int": "int", "int32_t": "int", "uint32_t": "uint", "unsigned": "uint", "int64_t": "long", "uint64_t": "ulong", "unsigned long long": "ulong",
+              "int16_t": "short", "uint16_t": "ushort", "uint8_t": "ubyte", "int8_t": "byte", "unsigned char": "ubyte", "char": "char", "float": "float",
+              "double": "double", "size_t": "size_t", "void": "void"}
+
+
+def _c_type_to_d(t):
+    """`const uint8_t* const*` -> `const(ubyte*)*`: the D spelling of a C parameter type (names already stripped)."""
+    import re
+    t = re.sub(r"\s+", " ", t.replace("*", " * ")).strip()
+    toks = t.split(" ")
+    base, i = [], 0
+    lead_const = False
+    while i < len(toks) and toks[i] != "*":
+        if toks[i] == "const":
+            lead_const = True
+        elif toks[i] != "struct":
+            base.append(toks[i])
+        i += 1
+    b = " ".join(base)
+    d = _C_SCALARS.get(b, b)                                  # gamut_hip_* struct and function-pointer typedef names stay
+    cur, const_inner = d, lead_const                           # const_inner: the thing `cur` names is const
+    while i < len(toks):
+        assert toks[i] == "*", t
+        i += 1
+        ptr_const = i < len(toks) and toks[i] == "const"
+        if ptr_const:
+            i += 1
+        cur = (f"const({cur})*" if const_inner else f"{cur}*")
+        const_inner = ptr_const
+    assert not const_inner or cur == d, t                      # a top-level const on a by-value parameter does not occur
+    import re as _re
+    while True:                                                # D's const is transitive: const(const(T)*) is spelled const(T*)
+        nxt = _re.sub(r"const\(const\(([^()]*)\)(\**)\)", r"const(\1\2)", cur)
+        if nxt == cur:
+            return cur
+        cur = nxt
+
+
+def _c_param_type(p):
+    """drops the parameter's name (the last identifier when the declaration has more than a type)"""
+    import re
+    p = re.sub(r"\s+", " ", p).strip()
+    m = re.match(r"^(.*?[\s\*])([A-Za-z_]\w*)$", p)
+    if m and m.group(1).strip() and m.group(1).strip() not in ("const", "unsigned", "struct", "unsigned long"):
+        return m.group(1).strip()
+    return p
+
+
+def _d_param_type(p):
+    import re
+    p = re.sub(r"\s+", " ", p).strip()
+    m = re.match(r"^(.*[\s\*\)])([A-Za-z_]\w*)$", p)
+    return re.sub(r"\s+", "", (m.group(1) if m else p).strip()) if True else p
+
+
 def test_d_binding_lists_every_export():
     """bindings/gamut_hip.d (the file INTEGRATION.md tells a maintainer to add) declares every function of include/gamut_hip.h with the
-    same number of parameters, inside an extern(C) block, and carries the four extern(C) trampolines for the reference's extern(D)
-    callbacks (plugins/jpeg.d:167, stbdec.d:143-165).  No D compiler exists in the image: a textual check."""
+    same RETURN and PARAMETER TYPES -- each C type put through a C -> D type map (`const uint8_t* const*` -> `const(ubyte*)*`,
+    `int64_t` -> `long`, ...) and compared with what the D file says, position by position: a wrong width, a missing `const`, a swapped
+    pair of arguments of different types fail here (round 4 compared parameter COUNTS).  Inside an extern(C) block, with the four
+    extern(C) trampolines for the reference's extern(D) callbacks (plugins/jpeg.d:167, stbdec.d:143-165).  No D compiler exists in
+    the image: a textual check."""
     import re
-    hdr = open(os.path.join(ROOT, "include", "gamut_hip.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    dsrc = open(os.path.join(ROOT, "bindings", "gamut_hip.d")).read()
-    dsrc = re.sub(r"//[^\n]*", "", re.sub(r"/\*.*?\*/", "", dsrc, flags=re.S))
+    hdr = _strip_comments(open(os.path.join(ROOT, "include", "gamut_hip.h")).read())
+    hdr = re.sub(r"^\s*#[^\n]*", "", hdr, flags=re.M)                   # preprocessor lines
+    dsrc = _strip_comments(open(os.path.join(ROOT, "bindings", "gamut_hip.d")).read())
 
-    def protos(text):
+    def protos(text, lang):
         out = {}
-        for m in re.finditer(r"\b(gamut_hip_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
-            args = m.group(2).strip()
-            depth, n = 0, 0 if args in ("", "void") else 1
-            for ch in args:
-                depth += ch == "("
-                depth -= ch == ")"
-                n += ch == "," and depth == 0
-            out[m.group(1)] = n
+        for m in re.finditer(r"([A-Za-z_][\w\s\*\(\)]*?)\b(gamut_hip_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+            ret = re.sub(r"\s+", " ", m.group(1)).strip()
+            if "typedef" in ret or ret.endswith("(") or ret.startswith("alias") or "=" in ret:
+                continue
+            ret = re.sub(r"^(extern \"C\" |GAMUT_HIP_API )", "", ret)
+            args = _split_args(m.group(3).strip())
+            if lang == "c":
+                out[m.group(2)] = (re.sub(r"\s+", "", _c_type_to_d(ret)), [re.sub(r"\s+", "", _c_type_to_d(_c_param_type(a))) for a in args])
+            else:
+                out[m.group(2)] = (re.sub(r"\s+", "", ret), [_d_param_type(a) for a in args])
         return out
-    h, d = protos(hdr), protos(dsrc)
-    h.pop("gamut_hip_jpeg_stream_read_func", None)
+    h, d = protos(hdr, "c"), protos(dsrc, "d")
+    assert len(h) >= 60, len(h)
     missing = sorted(set(h) - set(d))
     assert not missing, missing
-    assert {k: d[k] for k in h} == h
+    for name in sorted(h):
+        assert d[name] == h[name], (name, "header (as D):", h[name], "binding:", d[name])
+    # the one function-pointer typedef: int (*)(void*, int, unsigned char*, void*)  ==  the alias's int function(void*, int, bool*, void*)
+    m = re.search(r"typedef\s+int\s*\(\*gamut_hip_jpeg_stream_read_func\)\s*\(([^)]*)\)", hdr)
+    cb = [re.sub(r"\s+", "", _c_type_to_d(_c_param_type(a))) for a in _split_args(m.group(1))]
+    m = re.search(r"alias\s+gamut_hip_jpeg_stream_read_func\s*=\s*int\s+function\(([^)]*)\)", dsrc)
+    assert [x.replace("bool*", "ubyte*") for x in (_d_param_type(a) for a in _split_args(m.group(1)))] == cb
     assert dsrc.index("extern(C)") < dsrc.index("gamut_hip_version")
     for name in ("gamut_hip_tramp_read_jpeg", "gamut_hip_tramp_stb_read", "gamut_hip_tramp_stb_skip", "gamut_hip_tramp_stb_eof"):
         assert re.search(r"extern\(C\)\s+\w+\s+" + name, dsrc), name
+
+
+def test_d_binding_struct_layouts(tmp_path):
+    """Every struct of include/gamut_hip.h three ways: (1) what the C compiler lays out (tests/c/abi_layout.c: sizeof and every offsetof),
+    (2) the `static assert`s of bindings/gamut_hip.d -- what a D compiler will check on the binding's first build --, (3) the layout the D
+    declarations of that file yield under the C ABI rules extern(C) D structs follow (natural alignment, declaration order), computed
+    here from the D text with D's type sizes.  All three must say the same: a field of the wrong width, a swapped pair, a missing
+    member in the binding moves an offset and fails."""
+    import re
+    import subprocess
+    exe = str(tmp_path / "abi_layout")
+    subprocess.check_call(["gcc", "-std=gnu99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(HERE, "c", "abi_layout.c"), "-o", exe])
+    c_layout = {}
+    for line in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.splitlines():
+        f = line.split()
+        if f:
+            c_layout[f[0]] = (int(f[1]), {kv.split("=")[0]: int(kv.split("=")[1]) for kv in f[2:]})
+    hdr = _strip_comments(open(os.path.join(ROOT, "include", "gamut_hip.h")).read())
+    declared = set(re.findall(r"typedef struct (gamut_hip_\w+)\s*\{", hdr))
+    assert declared == set(c_layout), (declared, set(c_layout))           # abi_layout.c knows every struct with a body
+    dsrc = _strip_comments(open(os.path.join(ROOT, "bindings", "gamut_hip.d")).read())
+    # (2) the static asserts
+    asserted = {}
+    for m in re.finditer(r"static assert\((.*?)\);", dsrc, flags=re.S):
+        for name, field, kind, val in re.findall(r"(gamut_hip_\w+)\.(?:(\w+)\.)?(sizeof|offsetof) == (\d+)", m.group(1)):
+            e = asserted.setdefault(name, [None, {}])
+            if kind == "sizeof":
+                e[0] = int(val)
+            else:
+                e[1]["out" if field == "out_" else field] = int(val)
+    assert {k: (v[0], v[1]) for k, v in asserted.items()} == c_layout
+    # (3) the D declarations themselves
+    size = {"byte": 1, "ubyte": 1, "bool": 1, "char": 1, "short": 2, "ushort": 2, "int": 4, "uint": 4, "float": 4, "long": 8, "ulong": 8, "size_t": 8, "double": 8}
+    for name, (c_size, c_fields) in c_layout.items():
+        m = re.search(r"struct " + name + r"\s*\{(.*?)\}", dsrc, flags=re.S)
+        assert m, name
+        off, align, fields = 0, 1, {}
+        for decl in [x.strip() for x in m.group(1).split(";") if x.strip()]:
+            fm = re.match(r"^(\w+\s+function\([^)]*\))\s+(\w+)$", decl)
+            if fm:
+                typ, names = "ptr", [fm.group(2)]
+            else:
+                tm = re.match(r"^(.*?[\s\*\)])([\w\s,]+)$", decl)
+                typ, names = tm.group(1).strip(), [n.strip() for n in tm.group(2).split(",")]
+            sz = 8 if typ == "ptr" or typ.endswith("*") else size[typ]
+            for n in names:
+                off = (off + sz - 1) // sz * sz
+                fields["out" if n == "out_" else n] = off
+                off += sz
+                align = max(align, sz)
+        total = (off + align - 1) // align * align
+        assert (total, fields) == (c_size, c_fields), (name, "D declaration:", total, fields, "C:", c_size, c_fields)
 
 
 def test_identify_format_and_mixed_batch_arguments():

@@ -78,3 +78,13 @@ def test_two_rank_round_robin_and_gather(n):
     assert [r[1] for r in res] == [True, True]
     assert sum(r[2] for r in res) == n
     assert all(r[3] == 2.0 for r in res)
+
+
+def test_a_rank_without_images_still_has_a_device_for_the_collective():
+    """n_items < world: the empty rank's buffers must live where the other ranks' do (an RCCL all_gather with one CPU tensor fails).
+    gather_outputs takes the device from its argument, the outputs, or -- backend nccl -- the process's GPU; never 'cpu' by accident."""
+    t = torch.zeros(3, dtype=torch.uint8)
+    assert shard._collective_device([t], None, None) == t.device
+    assert shard._collective_device([], "cpu", None) == torch.device("cpu")
+    assert shard._collective_device([], torch.device("meta"), None) == torch.device("meta")
+    assert shard._collective_device([], None, None) == torch.device("cpu")          # no process group: nothing to match

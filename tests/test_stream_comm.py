@@ -455,6 +455,50 @@ def test_pure_c_shard_host(hip, tmp_path):
         assert out.returncode == 0 and f"{world} threads ok" in out.stdout, (out.returncode, out.stdout, out.stderr)
 
 
+def _build_rccl_double(tmp_path):
+    """tests/c/rccl_double.c: the eight nccl* entry points comm.hip binds, for ranks that are threads of one process on one device"""
+    import subprocess
+    so = str(tmp_path / "librccl_double.so")
+    subprocess.check_call(["gcc", "-std=gnu99", "-Wall", "-Wextra", "-Werror", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           os.path.join(HERE, "c", "rccl_double.c"), "-o", so, "-L/opt/rocm/lib", "-lamdhip64", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"])
+    return so
+
+
+def test_rccl_library_override(tmp_path):
+    """GAMUT_HIP_RCCL_LIB names the library comm.hip binds (comm.hip: rccl()): the test double exports every symbol and hands out an id
+    without a device; a path that does not exist is an error that says so -- never a silent fall-back to another copy of RCCL."""
+    import subprocess
+    import sys
+    so = _build_rccl_double(tmp_path)
+    syms = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclSend", "ncclRecv", "ncclGroupStart", "ncclGroupEnd", "ncclGetErrorString"):
+        assert f" T {name}" in syms, name
+    prog = ("import ctypes as C, sys; sys.path.insert(0, %r); from gamut_amd import _capi; L = _capi.lib(); b = (C.c_uint8 * 128)(); "
+            "rc = L.gamut_hip_comm_get_unique_id(b); print(rc, bytes(b[:11]), _capi.last_error())" % os.path.dirname(HERE))
+    out = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=120, env=dict(os.environ, GAMUT_HIP_RCCL_LIB=so))
+    assert out.returncode == 0 and out.stdout.startswith("0 b'rccl-double'"), (out.stdout, out.stderr)
+    out = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=120, env=dict(os.environ, GAMUT_HIP_RCCL_LIB=str(tmp_path / "no_such.so")))
+    assert out.returncode == 0 and not out.stdout.startswith("0 ") and "could not be loaded" in out.stdout and "no_such.so" in out.stdout, (out.stdout, out.stderr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_gather_many_ranks_on_one_device(hip, tmp_path, world):
+    """gamut_hip_gather_outputs_device with world > 1 on a 1-GPU box: tests/c/shard_host.c's threads form -- a host
+    thread per rank, every rank on device 0 -- over tests/c/rccl_double.c instead of librccl (real RCCL refuses two ranks on one
+    device).  Everything above the transport is the product's: which image goes to whom (round-robin owners, root / every rank), the
+    own images' strided device copy, grouped ncclSend / ncclRecv in groups of 256 (600 and 257 images cross the group size), strides
+    larger than an image.  shard_host checks every byte of every image on every rank that receives, that the gaps between images
+    keep their fill, and that a rank that receives nothing is not written at all; roots: every rank, rank 0, the last rank."""
+    import subprocess
+    exe = _build_shard_host(tmp_path)
+    so = _build_rccl_double(tmp_path)
+    env = dict(os.environ, GAMUT_HIP_RCCL_LIB=so, HIP_VISIBLE_DEVICES="0")
+    for total, pad in ((0, 0), (1, 48), (7, 0), (8, 48), (257, 0), (600, 48)):
+        out = subprocess.run([exe, "threads", str(world), str(total), str(pad)], capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0 and f"{world} threads ok ({total} images)" in out.stdout, (world, total, pad, out.returncode, out.stdout, out.stderr[-2000:])
+
+
 def _rccl_rank(rank, world, idfile, ndev, q):
     """One rank of the C-ABI gather: no torch.distributed -- the id travels through a file, as a D host would do it."""
     import time

@@ -237,31 +237,26 @@ struct gamut_image {
         return setStorage(w, h, layers, type, constraints, clear);
     }
 
-    int getAdHocLayoutConstraints() const                                                   // image.d:1809-1905
+    // What the storage AS IT STANDS would satisfy (Image.getAdHocLayoutConstraints, image.d:1809-1905), field by field of the constraint
+    // word.  The two power-of-two fields are logarithms: MULTIPLICITY_n = log2 n in bits 0-1, TRAILING_(n-1) = log2 n in bits 2-3, so both
+    // come from one question -- how many whole pixels fit between the end of a row and the start of the next -- asked once.
+    int getAdHocLayoutConstraints() const
     {
-        const int pitch = _pitch, absPitch = pitch >= 0 ? pitch : -pitch;
-        const int pixelSize = kPixelSize[_type], scanLen = _width * pixelSize;
-        const int excessPixels = (absPitch - scanLen) / pixelSize;
-        int c = 0;
-        int multi = layoutMultiplicity(_layoutConstraints);
-        const int withGap = excessPixels >= 7 ? 8 : excessPixels >= 3 ? 4 : excessPixels >= 1 ? 2 : 1;
-        int withWidth = 1;
-        if (_width % 2 == 0) withWidth = 2;
-        if (_width % 4 == 0) withWidth = 4;
-        if (_width % 8 == 0) withWidth = 8;
-        if (multi < withGap) multi = withGap;
-        if (multi < withWidth) multi = withWidth;
-        c |= multi == 8 ? GAMUT_LAYOUT_MULTIPLICITY_8 : multi == 4 ? GAMUT_LAYOUT_MULTIPLICITY_4 : multi == 2 ? GAMUT_LAYOUT_MULTIPLICITY_2 : 0;
-        c |= excessPixels >= 7 ? GAMUT_LAYOUT_TRAILING_7 : excessPixels >= 3 ? GAMUT_LAYOUT_TRAILING_3 : excessPixels >= 1 ? GAMUT_LAYOUT_TRAILING_1 : 0;
-        const int a1 = pointerAlignment((size_t)_data), a2 = pointerAlignment((size_t)absPitch);
-        c |= a1 < a2 ? a1 : a2;
-        if (pitch >= 0) c |= GAMUT_LAYOUT_VERT_STRAIGHT;
-        if (pitch <= 0) c |= GAMUT_LAYOUT_VERT_FLIPPED;
-        const bool gaplessScanlines = pitch == absPitch;
-        const bool gaplessLayers = (_layerCount == 0 || _layerCount == 1) ? true : _layerOffset == absPitch * _height;
-        if (gaplessScanlines && gaplessLayers) c |= GAMUT_LAYOUT_GAPLESS;
-        c |= (_layoutConstraints & BORDER_MASK);
-        return c;
+        const auto log2_upto8 = [](int n) { return n >= 8 ? 3 : n >= 4 ? 2 : n >= 2 ? 1 : 0; };
+        const int step = _pitch < 0 ? -_pitch : _pitch;                                      // bytes from a row to its neighbour in memory
+        const int px = kPixelSize[_type];
+        const int spare = log2_upto8((step - _width * px) / px + 1);                         // 1 / 3 / 7 pixels to spare behind a row: rows of 2 / 4 / 8
+        const int width_pow = _width % 8 == 0 ? 3 : _width % 4 == 0 ? 2 : _width % 2 == 0 ? 1 : 0;   // the width itself a multiple
+        const int promised = _layoutConstraints & 3;                                         // what the image was allocated under still holds
+        int word = std::max(promised, std::max(spare, width_pow))                            // multiplicity: any of the three witnesses
+                 | spare << 2                                                                // trailing pixels: only what is there
+                 | std::min(pointerAlignment((size_t)_data), pointerAlignment((size_t)step)) // every row as aligned as the first one and the step
+                 | (_layoutConstraints & BORDER_MASK);                                       // a border cannot be seen in the numbers: the promise
+        if (_pitch >= 0) word |= GAMUT_LAYOUT_VERT_STRAIGHT;                                 // (a pitch of 0 -- one row, or none -- is both)
+        if (_pitch <= 0) word |= GAMUT_LAYOUT_VERT_FLIPPED;
+        const bool layers_abut = _layerCount <= 1 || _layerOffset == step * _height;
+        if (_pitch >= 0 && layers_abut) word |= GAMUT_LAYOUT_GAPLESS;                        // the reference asks no more of the rows than pitch == |pitch| (:1886)
+        return word;
     }
 
     bool convertTo(int targetType, int layoutConstraints)                                  // image.d:1180-1332

@@ -5,8 +5,8 @@ feeders included -- not bench.py's contract, whose inputs are resident in HBM). 
   jpeg:progressive   the same pictures as progressive (SOF2) files: ten scans each, all of them decoded on the GPU
   png:noisy   256 x 4K RGB8 files of the synthetic image as it is (12 MB of IDAT each)   } gamut_hip_png_decode_batch_device: chunk walk on the
   png:smooth  the same image behind a Gaussian blur (3.6 MB each)                        } host, inflate + de-filter + expansion on the GPU
-Parity before timing: JPEG == the coefficient path (host entropy decoder -> k_jpeg_h2v2, the path the oracle checks); PNG == Pillow's
-decode of the same file, byte for byte.  Usage: python tools/files_bench.py [jpeg png:noisy png:smooth] [--reps 3]"""
+Parity before timing: JPEG == the oracle's whole-file decoder (oracle/oracle_jpeg.c), every pixel; PNG == Pillow's decode of the same
+file, byte for byte (the PNG oracle's inflate is zlib: tests/test_oracle_pinning.py pins it against Pillow on the same files).  Usage: python tools/files_bench.py [jpeg png:noisy png:smooth] [--reps 3]"""
 import argparse
 import ctypes as C
 import io
@@ -51,27 +51,19 @@ def jpeg_case(L, reps, progressive=False):
         info = (_capi.JpegFrame * B)()
         _capi.check(L.gamut_hip_jpeg_decode_batch_device(ptrs, lens, B, 4, off.ctypes.data_as(C.POINTER(C.c_int64)), out.data_ptr(), info, None, None, stream))
     run(); torch.cuda.synchronize()
-    # parity: the coefficient path for the distinct files
-    nblk = 120 * 68 * 6
-    frames = (_capi.JpegFrame * distinct)()
-    p2 = (C.c_void_p * distinct)(*[f.ctypes.data for f in files]); l2 = (C.c_size_t * distinct)(*[f.size for f in files])
-    _capi.check(L.gamut_hip_jpeg_decode_coeffs_batch(p2, l2, distinct, frames, None, 0))
-    co = torch.empty((distinct, nblk * 64), dtype=torch.int16)
-    zz = torch.empty((distinct, nblk), dtype=torch.uint8)
+    # parity: the ORACLE's whole-file decoder (oracle/oracle_jpeg.c: decompress_jpeg_image_from_stream restated, entropy decode included)
+    # on every distinct file, against the first, a middle and the last image that was decoded from it
+    import oracle_lib as O
+    ok = True
     for i in range(distinct):
-        C.memmove(co[i].data_ptr(), frames[i].coeffs, nblk * 128)
-        C.memmove(zz[i].data_ptr(), frames[i].max_zag, nblk)
-        L.gamut_hip_jpeg_frame_free(C.byref(frames[i]))
-    dco, dzz = co.to(dev), zz.to(dev)
-    ref = torch.empty((distinct, h, w * 4), dtype=torch.uint8, device=dev)
-    _capi.check(L.gamut_hip_jpeg_reconstruct_batch_device(dco.data_ptr(), nblk * 64, dzz.data_ptr(), nblk, ref.data_ptr(), w * 4, h * w * 4, w, h, 4, 4, distinct, stream))
-    torch.cuda.synchronize()
-    ok = all(bool(torch.equal(out[i], ref[i % distinct])) for i in (0, 1, distinct - 1, B - 1, B // 2))
+        exp = O.decompress_jpeg(bytes(files[i]), 4)[0].reshape(h, w * 4)
+        for j in sorted({i, i + distinct * ((B // distinct) // 2), i + B - distinct}):
+            ok = ok and np.array_equal(out[j].cpu().numpy(), exp)
     t = best_of(run, reps)
     kind = "progressive (libjpeg's ten-scan script; every scan decoded on the GPU in one launch)" if progressive else "baseline"
     return {"what": f"files -> pixels: 1024 x 1080p {kind} JPEG 4:2:0 files in host memory -> rgba8 in HBM (gamut_hip_jpeg_decode_batch_device)",
             "value": round(B * w * h / t / 1e6, 1), "unit": "Mpx/s", "ms": round(t * 1e3, 2), "MB_per_file": round(sum(f.size for f in files) / distinct / 1e6, 3),
-            "parity": "ok (== host entropy decoder -> k_jpeg_h2v2)" if ok else "FAILED"}
+            "parity": f"ok (== oracle's decompress_jpeg, {3 * distinct} images of the batch, every pixel)" if ok else "FAILED"}
 
 
 def png_case(L, reps, content):

@@ -32,6 +32,9 @@ namespace {
 
 typedef uint32_t u32;
 
+#ifndef PNG_PAETH_ONE_ASM         // tuning knob (tools/variant.sh): the Paeth predictor's packed operations as one asm statement
+#define PNG_PAETH_ONE_ASM 0           // (measured slower: 7.74 vs 7.58 ms, profiles/r05_png_ab5.txt -- the rigid block keeps the scheduler from interleaving the pixels)
+#endif
 #ifndef PNG_WAVES_N
 #define PNG_WAVES_N 8
 #endif
@@ -153,6 +156,7 @@ __device__ __forceinline__ u32 paeth_band_pred(const RowFilter& f, u32 a, u32 b,
     const u32 aL = __builtin_amdgcn_perm(BIAS, a, LO), aH = __builtin_amdgcn_perm(BIAS, a, HI);
     const u32 bL = __builtin_amdgcn_perm(BIAS, b, LO), bH = __builtin_amdgcn_perm(BIAS, b, HI);
     const u32 cL = __builtin_amdgcn_perm(BIAS, c, LO), cH = __builtin_amdgcn_perm(BIAS, c, HI);   // = the b of the pixel before: no new instruction
+#if !PNG_PAETH_ONE_ASM
     const u32 t1L = pkf_sub(bL, cL),        t1H = pkf_sub(bH, cH);
     const u32 t2L = pkf_sub(aL, cL),        t2H = pkf_sub(aH, cH);
     const u32 paL = pkf_abs(t1L),           paH = pkf_abs(t1H);                         // |p - a|   (p = a + b - c)
@@ -163,6 +167,36 @@ __device__ __forceinline__ u32 paeth_band_pred(const RowFilter& f, u32 a, u32 b,
     const u32 mL  = pkf_min(paL, pbL),      mH  = pkf_min(paH, pbH);
     const u32 d2L = pkf_sub(pcL, mL),       d2H = pkf_sub(pcH, mH);                     // < 0: c over either  (x - x = +0: ties keep)
     const u32 m1 = __builtin_amdgcn_perm(d1H, d1L, f.sel1), m2 = __builtin_amdgcn_perm(d2H, d2L, f.sel2);
+#else
+    // One asm statement for the eighteen packed operations and the two permutes: between asm statements the compiler counts no wait
+    // states (it does not look inside them), so with one statement per operation every consumer of a packed result got an s_nop in
+    // front of it -- nine per 16-byte piece -- although another operation always stood between the two.  In here no operation reads
+    // the result of the one just before it (the one wait state gfx950 asks for behind a packed operation).
+    u32 t1L, t1H, t2L, t2H, paL, paH, d1L, d1H, m1, m2;
+    asm("v_pk_add_f16 %[t1L], %[bL], %[cL] neg_lo:[0,1] neg_hi:[0,1]\n\t"          // t1 = b - c
+        "v_pk_add_f16 %[t1H], %[bH], %[cH] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f16 %[t2L], %[aL], %[cL] neg_lo:[0,1] neg_hi:[0,1]\n\t"          // t2 = a - c
+        "v_pk_add_f16 %[t2H], %[aH], %[cH] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_max_f16 %[paL], %[t1L], %[t1L] neg_lo:[0,1] neg_hi:[0,1]\n\t"        // pa = |p - a| = |t1|   (p = a + b - c)
+        "v_pk_max_f16 %[paH], %[t1H], %[t1H] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f16 %[t1L], %[t1L], %[t2L]\n\t"                                  // t3 = t1 + t2            (in t1)
+        "v_pk_add_f16 %[t1H], %[t1H], %[t2H]\n\t"
+        "v_pk_max_f16 %[t2L], %[t2L], %[t2L] neg_lo:[0,1] neg_hi:[0,1]\n\t"        // pb = |p - b| = |t2|     (in t2)
+        "v_pk_max_f16 %[t2H], %[t2H], %[t2H] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_max_f16 %[t1L], %[t1L], %[t1L] neg_lo:[0,1] neg_hi:[0,1]\n\t"        // pc = |p - c| = |t3|     (in t1)
+        "v_pk_max_f16 %[t1H], %[t1H], %[t1H] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f16 %[d1L], %[t2L], %[paL] neg_lo:[0,1] neg_hi:[0,1]\n\t"        // d1 = pb - pa: < 0: b over a
+        "v_pk_add_f16 %[d1H], %[t2H], %[paH] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_min_f16 %[paL], %[paL], %[t2L]\n\t"                                  // m = min(pa, pb)         (in pa)
+        "v_pk_min_f16 %[paH], %[paH], %[t2H]\n\t"
+        "v_pk_add_f16 %[t1L], %[t1L], %[paL] neg_lo:[0,1] neg_hi:[0,1]\n\t"        // d2 = pc - m: < 0: c over either  (x - x = +0: ties keep)
+        "v_pk_add_f16 %[t1H], %[t1H], %[paH] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_perm_b32 %[m1], %[d1H], %[d1L], %[sel1]\n\t"
+        "v_perm_b32 %[m2], %[t1H], %[t1L], %[sel2]"
+        : [t1L] "=&v"(t1L), [t1H] "=&v"(t1H), [t2L] "=&v"(t2L), [t2H] "=&v"(t2H), [paL] "=&v"(paL), [paH] "=&v"(paH),
+          [d1L] "=&v"(d1L), [d1H] "=&v"(d1H), [m1] "=&v"(m1), [m2] "=&v"(m2)
+        : [aL] "v"(aL), [aH] "v"(aH), [bL] "v"(bL), [bH] "v"(bH), [cL] "v"(cL), [cH] "v"(cH), [sel1] "v"(f.sel1), [sel2] "v"(f.sel2));
+#endif
     u32 third;                                                                           // (c & mP) | (avg & mAvg): two masks of the lane -- v_and + v_and_or,
     asm("v_and_b32 %0, %1, %2\n\tv_and_or_b32 %0, %3, %4, %0" : "=&v"(third) : "v"(c), "v"(f.mP), "v"(avg_bytes(a, b)), "v"(f.mAvg));   // which the compiler turns into three selects
 
@@ -583,7 +617,8 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
     // fast forms: byte offset of the chunk prefetch_line(0) would fetch, from a wave-uniform base (+ 16 T0 per tile); ring offset of the
     // chunk drop_al(0) would write (its low 8 bits: + 16 T0 mod 256 flips bit 7 every other tile); which lanes drop the fresh line
     const uint8_t* ubase = nullptr;
-    u32 pfo[AL ? TT : 1], olow[AL ? TT : 1], freshbits = 0;
+    u32 pfo[AL ? TT : 1], freshbits = 0;          // per row: bits 0-23 the prefetch offset, bits 24-31 the ring offset (one register, not two: the
+                                                  // fast tiles hold three sets of eight pieces as it is)
     if constexpr (AL) {
         // (a wave-uniform byte offset from `raw`, said so to the compiler half by half: the loads then take a scalar base and a
         // 32-bit lane offset; - 2048 keeps the lane offsets positive whatever a row's constants)
@@ -594,10 +629,10 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
             const uint8_t* c0; int Sp, P;
             al_row(k, c0, Sp, P);
             const int cconst = -(8 * k + crow) + 8 - P + cslot;                            // prefetch_line(T0): chunk T0 + cconst
-            pfo[k] = (u32)((int64_t)(c0 - ubase) + (int64_t)cconst * 16);
+            const u32 fetch_off = (u32)((int64_t)(c0 - ubase) + (int64_t)cconst * 16);          // < 2^24: al_full
             const bool fresh = cslot <= P;
             const int dconst = cconst - (fresh ? 0 : 8);                                   // drop_al(T0): chunk T0 + dconst, row byte 16 (T0 + dconst) - S'
-            olow[k] = (u32)(dconst * 16 - Sp) & 255u;
+            pfo[k] = (fetch_off & 0xFFFFFFu) | ((u32)(dconst * 16 - Sp) << 24);
             freshbits |= fresh ? 1u << k : 0u;
             pre_old[k] = make_uint4(0u, 0u, 0u, 0u);
         }
@@ -620,13 +655,13 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
         if constexpr (AL) {
             #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const u32x4 v = *reinterpret_cast<const u32x4*>(ubase + (size_t)(pfo[k] + 16u * T0));
+                const u32x4 v = *reinterpret_cast<const u32x4*>(ubase + (size_t)(__umul24(pfo[k], 1u) + 16u * T0));
                 pre[k] = make_uint4(v.x, v.y, v.z, v.w);
             }
         }
     };
     // the tiles that may take the fast forms (wave-uniform)
-    const bool full64 = rows_left >= 64, al_full = AL && full64;
+    const bool full64 = rows_left >= 64, al_full = AL && full64 && a.wb < 200000u;       // (64 rows of the stream + 4 KB inside 2^24 bytes)
     auto fast_prefetch_ok = [&](u32 T0) { return al_full && T0 >= 64 && T0 + 16 <= full_iters; };      // chunks T0 - 62 .. T0 + 15 of every row exist
     auto fast_drop_ok     = [&](u32 T0) { return al_full && T0 >= 72; };                                  // no chunk in front of its row
     auto fast_wb_ok       = [&](u32 T0) { return full64 && T0 >= 64 && T0 + 8 <= wb_iters; };             // every row writes a whole group
@@ -725,7 +760,7 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
             for (int k = 0; k < 8; ++k) {
                 const bool fresh = (freshbits >> k) & 1u;
                 const uint4 v = fresh ? pre[k] : pre_old[k];
-                const u32 o = olow[k] ^ flip;
+                const u32 o = (pfo[k] >> 24) ^ flip;
                 uint8_t* dst = co_ring + k * 8 * PITCH + o;
                 reinterpret_cast<AnyVec*>(dst)->v = u32x4{ v.x, v.y, v.z, v.w };
                 if (o > 240u) reinterpret_cast<AnyVec*>(dst - 256)->v = u32x4{ v.x, v.y, v.z, v.w };
@@ -745,19 +780,76 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
         for (int u = 0; u < PF; ++u) issue_dprev((u32)u, dset[u]);
     }
 
+    // Write-back of the group of 8 pieces each row completed with tile T0, in two halves: all eight LDS reads first (one wait instead of
+    // eight round trips in a row), then one aligned 128-byte run per row.
+    uint4 wbv[8];
+    u32 wb_T0 = 0;                                  // Q: the last tile, whose groups go out behind the loop
+    // fast form: piece T0 - 8 [crow > 0] + cslot of row crow, as a byte offset from the band's first row: one constant of the lane, + 16 T0
+    const u32 wb_lane = (u32)crow * (u32)a.d_pitch + ((u32)cslot - (crow ? 8u : 0u)) * 16u;
+    const u32 row63_off = 7u * (u32)a.d_pitch + 56u * 16u;     // (lanes of crow == 7, k == 7: the same piece as an offset into row 63)
+    auto wb_read = [&](u32 T0) {
+        if (fast_wb_ok(T0)) {
+            // every row of the band writes a whole group: piece it = T0 - 8 k - 8 [crow > 0] + cslot of row 8 k + crow.  Its ring slot is
+            // (cslot | 8 [crow > 0] ^ 8 [k odd] ^ (T0 & 8)): two addresses per tile
+            const u32 flip = (T0 & 8u) << 4;
+            const u32 base_w = ((crow ? 128u : 0u) | ((u32)cslot << 4)) ^ flip;
+            const uint8_t* rd[2] = { co_ring + base_w, co_ring + (base_w ^ 128u) };
+            #pragma unroll
+            for (int k = 0; k < 8; ++k) wbv[k] = *reinterpret_cast<const uint4*>(rd[k & 1] + k * 8 * PITCH);
+        } else {
+            #pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int it = (((int)T0 - (8 * k + crow)) & ~7) + cslot;
+                wbv[k] = *reinterpret_cast<const uint4*>(co_ring + k * 8 * PITCH + ((u32)it & (RING - 1)) * 16);
+            }
+        }
+    };
+    auto wb_store = [&](u32 T0) {
+        if (fast_wb_ok(T0)) {
+            // a piece's place in the output is a lane constant minus 128 k behind a wave-uniform row pointer -- no predicates, no per-row
+            // address arithmetic
+            const u32 goff0 = wb_lane + T0 * 16u;                                         // (d_pitch * 64 < 2^31: checked by the launcher)
+            #pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint4 v = wbv[k];
+                u32x4* dst = reinterpret_cast<u32x4*>(dband + (int64_t)(8 * k) * a.d_pitch + (size_t)(goff0 - 128u * (u32)k));
+                if (Q && k == 7) {
+                    if (crow == 7) __builtin_amdgcn_raw_buffer_store_b128(u32x4{ v.x, v.y, v.z, v.w }, rs_last, goff0 - row63_off, 0, 16);      // row 63: sc1
+                    else if (PNG_NT_STORES) __builtin_nontemporal_store(u32x4{ v.x, v.y, v.z, v.w }, dst);
+                    else *dst = u32x4{ v.x, v.y, v.z, v.w };
+                }
+                else if (PNG_NT_STORES) __builtin_nontemporal_store(u32x4{ v.x, v.y, v.z, v.w }, dst);
+                else               *dst = u32x4{ v.x, v.y, v.z, v.w };
+            }
+        } else {
+            #pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int it = (((int)T0 - (8 * k + crow)) & ~7) + cslot;                      // piece 8g + cslot, g = floor((T0 - row) / 8)
+                const uint4 v = wbv[k];
+                if ((u32)(8 * k + crow) < rows_left && it >= 0 && it < (int)wb_iters) {
+                    u32x4* dst = reinterpret_cast<u32x4*>(cdst + (int64_t)(8 * k) * a.d_pitch + (int64_t)it * 16);
+                    if (Q && k == 7 && crow == 7) __builtin_amdgcn_raw_buffer_store_b128(u32x4{ v.x, v.y, v.z, v.w }, rs_last, (u32)it * 16u, 0, 16);   // row 63: sc1
+                    else if (PNG_NT_STORES) __builtin_nontemporal_store(u32x4{ v.x, v.y, v.z, v.w }, dst);
+                    else               *dst = u32x4{ v.x, v.y, v.z, v.w };
+                }
+            }
+        }
+    };
+
     // trips must reach iteration niter-1 of lane 63; write-back must reach row 63's last group (tile T0 = 8 g_last + 64)
     const u32 T_end = max(niter + 63, 8 * ((wb_iters - 1) >> 3) + 65);
     u32 my_slot = (u32)(-lane) & (RING - 1);                                               // slot of iteration T - lane, kept incrementally
     u32 polled = 0;                                 // Q: the progress word as loaded one tile ago (a round trip to L2 / the fabric that nobody waits for)
     for (u32 T0 = 0; T0 < T_end; T0 += TT) {
+        // Q: the order of a tile's vector-memory operations is  stores (the groups the tile before completed), progress word, row above,
+        // prefetch -- and nothing else until the next tile's drop.  The counter retires in order: what a drop waits for (its pieces) must be
+        // the YOUNGEST operations in flight, or it waits for whatever was issued behind them -- with the stores at the end of the tile
+        // (where the groups are complete) every drop waited for memory to acknowledge them, a round trip of a microsecond with nothing
+        // between issue and wait.  So the finished groups are read from the ring before the drop overwrites part of them, and stored
+        // behind it; by the next drop they have had a whole tile to complete.
         if constexpr (Q) {
-            if (band > 0) {
-                seen = max(seen, (u32)__builtin_amdgcn_readfirstlane((int)polled));
-                polled = __hip_atomic_load(prod_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                wait_for_band_above(T0 + 2 * TT);                      // the pieces of the next tile, fetched below
-            }
+            if (T0 > 0) wb_read(T0 - TT);
             if (lane < 8) *reinterpret_cast<u32x4*>(dch + lane * 16) = chunk;      // this tile's pieces of the row above
-            issue_chunk(T0 + TT);
         }
         // drop this tile's raw pieces (prefetched) into the rings, then start fetching the next tile.  A lane that has not
         // reached its row yet (iteration < 0: the first 64 trips) finds zeros in its slot: with a zero piece, a zero row above (the
@@ -777,6 +869,24 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
             uint8_t* const wr[2] = { co_ring + s0, co_ring + (s0 ^ 128u) };
             #pragma unroll
             for (int k = 0; k < 8; ++k) *reinterpret_cast<uint4*>(wr[k & 1] + k * 8 * PITCH) = pre[k];
+        }
+        if constexpr (Q) {
+            if (T0 > 0) {
+                // the drop has taken its pieces, the youngest loads: everything this wave ever issued has completed (the wait is free),
+                // so what the tile before this one stored (the groups up to tile T0 - 16) can be published
+                const int done = ((int)T0 - TT - 63) & ~7;
+                if (done > 0) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    publish(min((u32)done, wb_iters));
+                }
+                wb_store(T0 - TT);
+            }
+            if (band > 0) {
+                seen = max(seen, (u32)__builtin_amdgcn_readfirstlane((int)polled));
+                polled = __hip_atomic_load(prod_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                wait_for_band_above(T0 + 2 * TT);                      // the pieces of the next tile, fetched below
+            }
+            issue_chunk(T0 + TT);
         }
         prefetch_tile(T0 + TT);
         // some lane meets the partial last piece of its row (iteration full_iters, trip full_iters + lane) in this tile
@@ -865,60 +975,22 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
             }
         }
 
-        // write back the group of 8 pieces each row completed with this tile: one aligned 128-byte run per row
-        uint4 wbv[8];                               // all eight LDS reads first: one wait instead of eight round trips in a row
-        if (fast_wb_ok(T0)) {
-            // every row of the band writes a whole group: piece it = T0 - 8 k - 8 [crow > 0] + cslot of row 8 k + crow.  Its ring slot is
-            // (cslot | 8 [crow > 0] ^ 8 [k odd] ^ (T0 & 8)): two addresses per tile; its place in the output is a lane constant
-            // minus 128 k behind a wave-uniform row pointer -- no predicates, no per-row address arithmetic
-            const u32 flip = (T0 & 8u) << 4;
-            const u32 base_w = ((crow ? 128u : 0u) | ((u32)cslot << 4)) ^ flip;
-            const uint8_t* rd[2] = { co_ring + base_w, co_ring + (base_w ^ 128u) };
-            #pragma unroll
-            for (int k = 0; k < 8; ++k) wbv[k] = *reinterpret_cast<const uint4*>(rd[k & 1] + k * 8 * PITCH);
-            const u32 itbase = T0 - (crow ? 8u : 0u) + (u32)cslot;
-            const u32 goff0 = (u32)crow * (u32)a.d_pitch + itbase * 16u;                  // (d_pitch * 64 < 2^31: checked by the launcher)
-            #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const uint4 v = wbv[k];
-                u32x4* dst = reinterpret_cast<u32x4*>(dband + (int64_t)(8 * k) * a.d_pitch + (size_t)(goff0 - 128u * (u32)k));
-                if (Q && k == 7) {
-                    if (crow == 7) __builtin_amdgcn_raw_buffer_store_b128(u32x4{ v.x, v.y, v.z, v.w }, rs_last, (itbase - 56u) * 16u, 0, 16);   // row 63: sc1
-                    else if (PNG_NT_STORES) __builtin_nontemporal_store(u32x4{ v.x, v.y, v.z, v.w }, dst);
-                    else *dst = u32x4{ v.x, v.y, v.z, v.w };
-                }
-                else if (PNG_NT_STORES) __builtin_nontemporal_store(u32x4{ v.x, v.y, v.z, v.w }, dst);
-                else               *dst = u32x4{ v.x, v.y, v.z, v.w };
+        // write back the group of 8 pieces each row completed with this tile: one aligned 128-byte run per row.  The LDS reads come
+        // here (the next drop overwrites part of the group); Q: the stores wait until that drop has happened (see there)
+        if constexpr (!Q) {
+            wb_read(T0);
+            wb_store(T0);
+            // publish what lane 63 had written back BEFORE this tile (groups below floor((T0 - 63) / 8)): since then this
+            // tile issued 8 prefetch loads and 8 row-above loads, so "at most 16 vector-memory operations outstanding" implies
+            // those older stores have been acknowledged (the counter retires in order) -- the prefetches in flight are not drained.
+            const int done = ((int)T0 - 63) & ~7;
+            if (done > 0) {
+                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                publish(seq * niter + min((u32)done, wb_iters));
             }
-        } else {
-        #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int it = (((int)T0 - (8 * k + crow)) & ~7) + cslot;
-            wbv[k] = *reinterpret_cast<const uint4*>(co_ring + k * 8 * PITCH + ((u32)it & (RING - 1)) * 16);
-        }
-        #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int it = (((int)T0 - (8 * k + crow)) & ~7) + cslot;                      // piece 8g + cslot, g = floor((T0 - row) / 8)
-            const uint4 v = wbv[k];
-            if ((u32)(8 * k + crow) < rows_left && it >= 0 && it < (int)wb_iters) {
-                u32x4* dst = reinterpret_cast<u32x4*>(cdst + (int64_t)(8 * k) * a.d_pitch + (int64_t)it * 16);
-                if (Q && k == 7 && crow == 7) __builtin_amdgcn_raw_buffer_store_b128(u32x4{ v.x, v.y, v.z, v.w }, rs_last, (u32)it * 16u, 0, 16);   // row 63: sc1
-                else if (PNG_NT_STORES) __builtin_nontemporal_store(u32x4{ v.x, v.y, v.z, v.w }, dst);
-                else               *dst = u32x4{ v.x, v.y, v.z, v.w };
-            }
-        }
-        }
-        // publish what lane 63 had written back BEFORE this tile (groups below floor((T0 - 63) / 8)): since then this
-        // tile issued 8 prefetch loads and 8 row-above loads, so "at most 16 vector-memory operations outstanding" implies
-        // those older stores have been acknowledged (the counter retires in order) -- the prefetches in flight are not drained.
-        const int done = ((int)T0 - 63) & ~7;
-        if (done > 0) {
-            // (Q: this tile issued 9-10 loads and then 8-9 stores after them: "at most 12 outstanding" covers the same stores)
-            if constexpr (Q) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else             asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            publish(seq * niter + min((u32)done, wb_iters));
-        }
+        } else wb_T0 = T0;
     }
+    if constexpr (Q) { wb_read(wb_T0); wb_store(wb_T0); }      // the last tile's groups
     // band finished: everything is on its way; drain and publish the whole band
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     publish(seq * niter + niter);

@@ -1059,6 +1059,277 @@ __global__ __launch_bounds__(W * 64, MINW) void k_png_defilter_queue(DefilterArg
     }
 }
 
+// =====================================================================================================
+// The rolling form of the queue launch: the same bands, the same lane = row trips, the same DPP hand-over -- but a row's ring is
+// EIGHT pieces (128 bytes), not sixteen, and the cooperative transfers are spread over the trips instead of bunched at tile ends.
+// Why: a wave issues a dependent vector instruction every 9 clocks and an independent one every 7 (tools/microbench/valu_latency.hip),
+// a SIMD can take one every 4 -- with the 18 KB rings of defilter_band_ring a compute unit holds 8 waves, two per SIMD, and the Paeth
+// bands (200 instructions per 16-byte piece) ran with the vector ALUs 70 % busy.  9 KB per wave is 16 waves per compute unit.
+//   * piece p of row r lives in slot (p + r) mod 8: in trip T EVERY lane works on slot T mod 8 of its own row (an immediate offset);
+//     rows are 144 bytes apart (nine slots), so eight consecutive lanes reading the same slot number hit eight different bank groups.
+//   * rows r = T + 1 (mod 8) finish a group of eight pieces with trip T and start the next with trip T + 1.  Those are eight rows,
+//     8 q + rho: lane (q, c) = (lane / 8, lane mod 8) takes slot c of row 8 q + rho -- reads the finished piece out of it (to be
+//     stored: 128 aligned bytes per row), puts the raw piece that belongs there next into it (fetched eight trips ago), and fetches
+//     the one after that.  One ds_read, one ds_write, one store and one load per trip, always 8 lanes to a row's 128 bytes.
+//   * the hand-off between bands (progress words, the band's last row written through, the row above in 128 bytes of LDS) is
+//     that of the queue form of defilter_band_ring.
+#ifndef PNG_ROLL_WPS             // waves per SIMD the rolling form is compiled for (tuning knob): 4 -> 128 registers, 3 -> 168
+#define PNG_ROLL_WPS 3
+#endif
+#ifndef PNG_ROLL_ABL             // ablations (wrong pixels; measurements only): 1 = the fast tiles fetch nothing, 2 = store nothing
+#define PNG_ROLL_ABL 0
+#endif
+constexpr int RPITCH = 144;
+template <int FB, bool PAETH>
+__device__ __forceinline__ void defilter_band_roll(const DefilterArgs& a, const uint8_t* raw, uint8_t* D, u32* prog, uint8_t* ring, u32 band,
+                                                   int lane, u32 niter, u32 f, bool row_live, u32* status)
+{
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    typedef u32x4 u32x4_unaligned __attribute__((aligned(1)));
+    constexpr int PW = 4;
+    const RowFilter rf = row_filter(f);
+    const u32 row = band * 64 + lane;
+    const u32 rows_left = a.rows - band * 64;
+    const bool full64 = rows_left >= 64;
+    const u32 full_iters = a.wb / 16;
+    const u32 wb_iters = a.store_tail_masked ? full_iters : niter;
+    const int q = lane >> 3, cslot = lane & 7;
+    uint8_t* drow = D + (int64_t)(row_live ? row : 0) * a.d_pitch;
+    const uint8_t* dprev = band > 0 ? D + (int64_t)(band * 64 - 1) * a.d_pitch : D;
+    u32* const my_flag = prog + band;
+    u32* const prod_flag = prog + (band > 0 ? band - 1 : 0);
+    uint8_t* const my_ring = ring + lane * RPITCH;                       // + 16 (T mod 8)
+    uint8_t* const co_ring = ring + q * 8 * RPITCH + cslot * 16;         // + rho RPITCH
+    uint8_t* const dch = ring + 64 * RPITCH;
+
+    // wave-uniform bases (said so to the compiler half by half, so that loads and stores take a scalar base and a 32-bit lane offset)
+    auto uniform_ptr = [](const uint8_t* base, int64_t off) {
+        return base + (int64_t)(((uint64_t)(u32)__builtin_amdgcn_readfirstlane((int)((uint64_t)off >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)(uint64_t)off));
+    };
+    const uint8_t* const rband = uniform_ptr(raw, (int64_t)band * 64 * ((int64_t)a.wb + 1) + 1);      // first byte of the band's first row
+    uint8_t* const dband = const_cast<uint8_t*>(uniform_ptr(D, (int64_t)band * 64 * a.d_pitch));
+    const u32 lq_raw = (u32)q * (8u * (a.wb + 1u) - 128u);               // fast forms: row 8 q + rho, piece ... - 8 q: the lane's share of the offset
+    const u32 lq_out = (u32)q * (8u * (u32)a.d_pitch - 128u);
+    const u32 cslot16 = (u32)cslot * 16u;
+
+    const auto rs_prev = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(dprev), 0, band > 0 ? (int)(niter * 16) : 0, 0x00020000);
+    const auto rs_last = __builtin_amdgcn_make_buffer_rsrc(D + (int64_t)(band * 64 + 63) * a.d_pitch, 0, (int)(niter * 16), 0x00020000);
+    // generic forms store through a descriptor of the band's live rows with the offsets of lanes that have nothing to store out of its
+    // range (the hardware drops them): one store instruction per trip whatever the data, like the fast forms -- see the vmcnt note below
+    const auto rs_band = __builtin_amdgcn_make_buffer_rsrc(dband, 0, (int)(min(rows_left, 64u) * (u32)a.d_pitch), 0x00020000);
+    u32 seen = 0;
+    auto wait_for_band_above = [&](u32 upto) {
+        const u32 need = min(niter, upto);
+        if (seen >= need) return;
+        const uint64_t t0 = wall_clock64();
+        for (;;) {
+            seen = (u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(prod_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (seen >= need) break;
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > 400000000ull) {                     // 4 s of the 100 MHz clock: give up, say so, never hang
+                if (status && lane == 0) atomicOr(status, STATUS_HANDOFF_TIMEOUT);
+                seen = 0xFFFFFFFFu;
+                break;
+            }
+        }
+    };
+    auto publish = [&](u32 value) { if (lane == 63) __hip_atomic_store(my_flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    u32x4 chunk = { 0u, 0u, 0u, 0u };
+    auto issue_chunk = [&](u32 Tbase) {
+        const u32 piece = min(Tbase + (u32)(lane & 7), niter - 1);
+        if (lane < 8) chunk = __builtin_amdgcn_raw_buffer_load_b128(rs_prev, piece * 16u, 0, 16);        // sc1: past this CU's L1
+    };
+
+    // the raw piece that the boundary of trip Tb (class rho = (Tb + 1) mod 8) will drop: piece Tb + 1 - (8 q + rho) + e of row 8 q + rho
+    // (generic forms: the first and last tiles of a band.  Their per-lane addresses are recomputed where they are used -- `opaque` keeps the
+    // compiler from hoisting sixteen of them per class out of the loop into registers the fast tiles need)
+    auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
+    auto fetch_generic = [&](int Tb, int rho) -> u32x4 {
+        const u32 rc = (u32)(8 * opaque(q) + rho);
+        const int e = (cslot - rho) & 7;
+        int p = Tb + 1 - (int)rc + e;
+        p = p < 0 ? 0 : p;
+        const int64_t off = (u32)p < full_iters ? (int64_t)p * 16 : (int64_t)a.wb - 16;      // the ragged last piece (and anything past it, unused) = the row's last 16 bytes
+        const u32 rl = rc < rows_left ? rc : 0u;                                                // rows past the image re-read a live row of the band (unused)
+        return *reinterpret_cast<const u32x4_unaligned*>(rband + (int64_t)rl * ((int64_t)a.wb + 1) + off);
+    };
+
+    #pragma unroll
+    for (int i = 0; i < RPITCH / 16; ++i) *reinterpret_cast<uint4*>(my_ring + i * 16) = make_uint4(0u, 0u, 0u, 0u);   // a lane that has not reached its row finds zeros
+    u32x4 pre[8];
+    #pragma unroll
+    for (int rho = 0; rho < 8; ++rho) pre[rho] = fetch_generic(rho - 1, rho);       // what the first boundary of every class drops
+    if (band > 0) wait_for_band_above(8);
+    issue_chunk(0);
+    // The first piece of a group never comes out of the ring: slot c = rho of row 8 q + rho is dropped by lane 8 q + rho -- the lane
+    // that computes that row.  It keeps the piece (`keep`) and takes it from there in the next trip, so every lane can ask the ring for
+    // its next piece at the START of a trip (a whole trip before it is needed) although the rows of one class are dropped at its end.
+    u32x4 keep;
+    {   // the boundary "of trip -1": rows 0 (mod 8) start with trip 0 -- only row 0 itself has pieces to drop, the others keep their zeros
+        const int e = cslot;
+        const int p = -(8 * q) + e;
+        keep = p < 0 ? u32x4{ 0u, 0u, 0u, 0u } : pre[0];
+        *reinterpret_cast<u32x4*>(co_ring) = keep;
+        pre[0] = fetch_generic(7, 0);
+    }
+    // (Eight stores that change nothing -- the band's progress word is 0 and stays 0.  The compiler counts, per load, the operations
+    // issued behind it and waits with vmcnt(that many); where paths meet it takes the smaller count.  Entering the loop from here the
+    // fetches above would have 0-8 operations behind them, coming round the loop 1-15: with these the loop's own count stands, and a
+    // drop waits for the piece fetched eight trips ago, not for the loads and stores of the last four trips.)
+    #pragma unroll
+    for (int i = 0; i < 8; ++i) publish(0u);
+
+    u32 outp[PW] = { 0u, 0u, 0u, 0u }, bprev[PW] = { 0u, 0u, 0u, 0u };
+    const u32 g_last = (wb_iters ? wb_iters - 1 : 0u) >> 3;
+    const u32 T_end = max(niter + 63, 63 + 8 * g_last + 8);
+    u32 polled = 0;
+    bool settled = false;                           // the two tiles before this one took the fast forms (one store and one load per trip, whatever the data)
+    bool was_fast = false;
+    uint4 rv_next = *reinterpret_cast<const uint4*>(my_ring);
+    for (u32 T0 = 0; T0 < T_end; T0 += 8) {
+        // head of a tile: what row 63 stored two tiles ago has arrived (at most the 16 operations of the last tile can be outstanding
+        // behind it when both tiles ran the fast forms; otherwise wait for everything) -- publish it; then this tile's pieces of the row above
+        {
+            const int done = (int)T0 - 72;
+            if (done > 0) {
+                if (settled) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                publish(min((u32)done, wb_iters));
+            }
+        }
+        if (band > 0) {
+            seen = max(seen, (u32)__builtin_amdgcn_readfirstlane((int)polled));
+            polled = __hip_atomic_load(prod_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            wait_for_band_above(T0 + 16);                                  // the pieces of the next tile, fetched below
+        }
+        if (lane < 8) *reinterpret_cast<u32x4*>(dch + lane * 16) = chunk;  // this tile's pieces of the row above
+        issue_chunk(T0 + 8);
+        const bool fast = full64 && T0 >= 72 && T0 + 24 <= full_iters;
+        settled = was_fast && fast;
+        was_fast = fast;
+        const bool rag_tile = (a.wb % 16) != 0 && T0 + 8 > full_iters && T0 <= full_iters + 63;
+        u32x4 dch_next = *reinterpret_cast<const u32x4*>(dch);
+
+        auto trip = [&](auto fast_c, auto u_c) {
+            constexpr bool FAST = decltype(fast_c)::value;
+            constexpr int u = decltype(u_c)::value, rho = (u + 1) & 7;
+            const u32 T = T0 + u;
+            const int it = (int)T - lane;
+            const bool ragged = rag_tile && row_live && it == (int)full_iters;
+            const bool first_of_group = (lane & 7) == u;                        // this lane's row starts a group with this trip: its piece is in `keep`
+            const uint4 rv = make_uint4(first_of_group ? keep[0] : rv_next.x, first_of_group ? keep[1] : rv_next.y,
+                                        first_of_group ? keep[2] : rv_next.z, first_of_group ? keep[3] : rv_next.w);
+            const u32x4 dcur = dch_next;
+            rv_next = *reinterpret_cast<const uint4*>(my_ring + ((u + 1) & 7) * 16);       // (for rows dropped at the end of this trip: stale, replaced by `keep`)
+            if (u + 1 < 8) dch_next = *reinterpret_cast<const u32x4*>(dch + (u + 1) * 16);
+            u32 rg[PW] = { rv.x, rv.y, rv.z, rv.w }, bg[PW];
+            if (!FAST && rag_tile) {    // last, partial piece of a row: the staged piece is the row's LAST 16 bytes (see fetch_generic);
+                if (ragged) {           // keep its top nb bytes, moved down by 16 - nb bytes (zeros come in behind).  No memory op here.
+                    const u32 sh = 16 - (a.wb - (u32)it * 16), ds = sh >> 2, bs = sh & 3;
+                    u32 w[5];
+                    #pragma unroll
+                    for (int i = 0; i < 5; ++i) {
+                        const u32 v0 = i < 4 ? rg[i] : 0u, v1 = i + 1 < 4 ? rg[i + 1] : 0u, v2 = i + 2 < 4 ? rg[i + 2] : 0u, v3 = i + 3 < 4 ? rg[i + 3] : 0u;
+                        w[i] = ds == 0 ? v0 : ds == 1 ? v1 : ds == 2 ? v2 : v3;
+                    }
+                    #pragma unroll
+                    for (int i = 0; i < 4; ++i) rg[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], bs);
+                }
+            }
+            #pragma unroll
+            for (int i = 0; i < PW; ++i) bg[i] = from_lane_below(outp[i], dcur[i]);
+            u32 og[PW];
+            filter_piece<FB, PAETH>(rf, rg, bg, outp, bprev, og);
+            #pragma unroll
+            for (int i = 0; i < PW; ++i) { outp[i] = og[i]; bprev[i] = bg[i]; }
+            *reinterpret_cast<uint4*>(my_ring + u * 16) = make_uint4(og[0], og[1], og[2], og[3]);
+            if (!FAST && rag_tile && a.store_tail_masked) {   // partial piece of an exact-size destination row (wb % 4 == 0 there): up to three
+                u32* dst = reinterpret_cast<u32*>(drow + (int64_t)(ragged ? it : 0) * 16);      // dword stores straight to the row, written through
+                const u32 nb = ragged ? a.wb - (u32)it * 16 : 0u;                               // (the band's last row is read by another compute unit)
+                if (nb >= 4) __hip_atomic_store(dst + 0, og[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (nb >= 8) __hip_atomic_store(dst + 1, og[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (nb >= 12) __hip_atomic_store(dst + 2, og[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // the boundary: rows 8 q + rho have just finished the group that ends with piece pn - 1, pn = T + 1 - (8 q + rho)
+            uint8_t* const slot = co_ring + rho * RPITCH;
+            const uint4 wbv = *reinterpret_cast<const uint4*>(slot);
+            const u32 e16 = (cslot16 - 16u * (u32)rho) & 0x70u;               // 16 e, e = (c - rho) mod 8: slot c holds pieces pn - 8 + e, then pn + e
+            if constexpr (FAST) keep = pre[rho];
+            else {
+                const int p_dr = (int)T + 1 - (8 * opaque(q) + rho) + (int)(e16 >> 4);
+                keep = p_dr < 0 ? u32x4{ 0u, 0u, 0u, 0u } : pre[rho];
+            }
+            *reinterpret_cast<u32x4*>(slot) = keep;
+            const u32x4 wv = { wbv.x, wbv.y, wbv.z, wbv.w };
+            if constexpr (FAST) {
+                // piece pn - 8 + e of row 8 q + rho: 16 (T - 7 - rho) + rho d_pitch from the band's first row (uniform), + the lane's q and e
+                uint8_t* const sb = dband + ((int64_t)rho * a.d_pitch + 16 * ((int64_t)T - 7 - rho));
+                const u32 vo = lq_out + e16;
+#if !(PNG_ROLL_ABL & 2)
+                if (rho == 7) {
+                    if (q == 7) __builtin_amdgcn_raw_buffer_store_b128(wv, rs_last, 16u * (T - 7u - 7u - 56u) + e16, 0, 16);      // row 63: sc1
+                    else __builtin_nontemporal_store(wv, reinterpret_cast<u32x4*>(sb + (size_t)vo));
+                } else __builtin_nontemporal_store(wv, reinterpret_cast<u32x4*>(sb + (size_t)vo));
+#else
+                asm volatile("" :: "v"(wv), "v"(vo), "s"(sb));
+#endif
+                const uint8_t* const lb = rband + ((int64_t)rho * ((int64_t)a.wb + 1) + 16 * ((int64_t)T + 9 - rho));
+#if !(PNG_ROLL_ABL & 1)
+                pre[rho] = *reinterpret_cast<const u32x4_unaligned*>(lb + (size_t)(lq_raw + e16));
+#else
+                asm volatile("" :: "v"(lq_raw + e16), "s"(lb));
+#endif
+            } else {
+                const u32 rc = (u32)(8 * opaque(q) + rho);
+                const int p_wb = (int)T + 1 - (int)rc - 8 + (int)(e16 >> 4);
+                const bool in_row = p_wb >= 0 && p_wb < (int)wb_iters;
+                const u32 nowhere = 0x80000000u;                                     // (rows past the image are past the descriptor's range by themselves)
+                __builtin_amdgcn_raw_buffer_store_b128(wv, rs_band, in_row && rc != 63 ? rc * (u32)a.d_pitch + (u32)p_wb * 16u : nowhere, 0, 0);
+                if (rho == 7) __builtin_amdgcn_raw_buffer_store_b128(wv, rs_last, in_row && rc == 63 && rows_left >= 64 ? (u32)p_wb * 16u : nowhere, 0, 16);   // row 63: sc1
+                pre[rho] = fetch_generic((int)T + 8, rho);
+            }
+        };
+        auto tile = [&](auto fast_c) {
+            trip(fast_c, std::integral_constant<int, 0>{}); trip(fast_c, std::integral_constant<int, 1>{});
+            trip(fast_c, std::integral_constant<int, 2>{}); trip(fast_c, std::integral_constant<int, 3>{});
+            trip(fast_c, std::integral_constant<int, 4>{}); trip(fast_c, std::integral_constant<int, 5>{});
+            trip(fast_c, std::integral_constant<int, 6>{}); trip(fast_c, std::integral_constant<int, 7>{});
+        };
+        if (fast) tile(std::true_type{}); else tile(std::false_type{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    publish(niter);
+}
+
+template <int FB, int W, int MINW>
+__global__ __launch_bounds__(W * 64, MINW) void k_png_defilter_rollq(DefilterArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t tiles[W][64 * RPITCH + 128];      // a wave's rings + 128 bytes of the row above its band
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const u32 niter = (a.wb + 15) / 16;
+    const u32 total = a.count * a.nbands, per_group = a.group * a.nbands;
+    for (;;) {
+        u32 u = 0;
+        if (lane == 0) u = __hip_atomic_fetch_add(a.qstate, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u = (u32)__builtin_amdgcn_readfirstlane((int)u);
+        if (u >= total) break;
+        const u32 g = u / per_group, r = u - g * per_group;
+        const u32 gl = min(a.group, a.count - g * a.group);
+        const u32 band = r / gl;
+        const int img = (int)(g * a.group + (r - band * gl));
+        const uint8_t* raw = image_raw(a, img);
+        uint8_t* D = image_rows(a, img);
+        u32* prog = a.qstate + QSTATE_HDR + (size_t)img * a.nbands;
+        const u32 row = band * 64 + lane;
+        const bool row_live = row < a.rows;
+        u32 f = row_live ? raw[(int64_t)row * (a.wb + 1)] : 0;
+        if (f > 4) { if (a.status) atomicOr(a.status + img, 1u); f = 0; }
+        u32* st = a.status ? a.status + img : nullptr;
+        if (__any(f == 4)) defilter_band_roll<FB, true >(a, raw, D, prog, tiles[wave], band, lane, niter, f, row_live, st);
+        else               defilter_band_roll<FB, false>(a, raw, D, prog, tiles[wave], band, lane, niter, f, row_live, st);
+    }
+}
+
 // ---- stage B: expand de-filtered rows into the output image (stbdec.d:1467-1480, 1504-1546, 1552-1632) ----
 struct ExpandArgs {
     const uint8_t* D; int64_t d_stride; int64_t d_pitch;
@@ -1308,6 +1579,25 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
         a.group = ((u32)count + ngroups - 1) / ngroups;              // equal groups
         const unsigned wgs = (unsigned)std::min<uint64_t>((uint64_t)cus, (units + PNG_WAVES - 1) / PNG_WAVES);
         const dim3 qgrid(wgs), qblock(PNG_WAVES * 64);
+        // the rolling form (defilter_band_roll: 9 KB of LDS per wave, ROLL_WPS waves per SIMD) -- only with GAMUT_HIP_PNG_ROLL=1 (every
+        // row of at least one piece).  Bit-exact in every test, and NOT the default: 512 x 4K with random filters 7.95 ms against 7.53,
+        // encoder filters 7.54 against 6.04 on one box (profiles/r05_png_roll2.txt).  Its vector work alone takes 6.17 / 2.97 ms
+        // (profiles/r05_png_roll_abl.txt: the fast tiles without their loads and stores) -- but with 3 072 waves reading rows at odd
+        // addresses a memory line is fetched by two groups of a row eight trips apart and the second fetch no longer finds it in
+        // the L2: loads alone 5.1 ms for 17 GB.  It needs the line-aligned loads of defilter_band_ring<AL> in a form its 8-slot ring
+        // can take (chunks into the ring as they lie in memory, the row's alignment undone per lane in registers) -- DESIGN 4.3.
+        const char* roll_env = getenv("GAMUT_HIP_PNG_ROLL");
+        const bool roll = !rgba_fused && wb >= 16 && roll_env && atoi(roll_env) != 0;
+        if (roll) {
+            constexpr int RW = 4;                                       // waves per workgroup: ROLL_WPS workgroups per compute unit
+            const unsigned rwgs = (unsigned)std::min<uint64_t>((uint64_t)cus * PNG_ROLL_WPS, (units + RW - 1) / RW);
+            switch (FB) {
+#define GAMUT_PNG_CASE(N) case N: hipLaunchKernelGGL((k_png_defilter_rollq<N, RW, PNG_ROLL_WPS>), dim3(rwgs), dim3(RW * 64), 0, stream, a); break;
+            GAMUT_PNG_CASE(1) GAMUT_PNG_CASE(2) GAMUT_PNG_CASE(3) GAMUT_PNG_CASE(4) GAMUT_PNG_CASE(6) GAMUT_PNG_CASE(8)
+#undef GAMUT_PNG_CASE
+            default: return set_error(GAMUT_HIP_ERR_INVALID_ARG, "png_defilter: unsupported filter unit %d", FB);
+            }
+        } else
         if (rgba_fused) hipLaunchKernelGGL((k_png_defilter_queue<3, PNG_WAVES, 2, true>), qgrid, qblock, 0, stream, a);
         else switch (FB) {
 #define GAMUT_PNG_CASE(N) case N: if (aligned) hipLaunchKernelGGL((k_png_defilter_queue<N, PNG_WAVES, 2, false, true>), qgrid, qblock, 0, stream, a); \

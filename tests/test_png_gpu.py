@@ -54,16 +54,18 @@ def gpu_defilter(L, raw, x, y, img_n, out_n, depth, color, count=1, raw_stride=0
     return outs
 
 
-@pytest.fixture(params=["workgroups", "queue", "workgroups+aligned", "queue+aligned"])
+@pytest.fixture(params=["workgroups", "queue", "workgroups+aligned", "queue+aligned", "queue+roll"])
 def launch_mode(request):
     """the two launch shapes of the ring kernels (png.hip): one workgroup per image / row segment, or every (image, band) unit
     of the batch through the device-wide work queue (the launcher's own rule picks the queue for large, badly dividing batches);
     each with the row-aligned loads of round 1-3 and with the line-aligned loads of round 4 (forced on for every row of at least one
-    piece: the launcher's own rule takes them from 256-byte rows on)"""
+    piece: the launcher's own rule takes them from 256-byte rows on); and the queue in its rolling form (round 5: rings of eight pieces,
+    a transfer per trip -- forced on for every row of at least one piece too)"""
     shape, _, al = request.param.partition("+")
-    old = {k: os.environ.get(k) for k in ("GAMUT_HIP_PNG_QUEUE", "GAMUT_HIP_PNG_ALIGNED")}
+    old = {k: os.environ.get(k) for k in ("GAMUT_HIP_PNG_QUEUE", "GAMUT_HIP_PNG_ALIGNED", "GAMUT_HIP_PNG_ROLL")}
     os.environ["GAMUT_HIP_PNG_QUEUE"] = "1" if shape == "queue" else "0"
-    os.environ["GAMUT_HIP_PNG_ALIGNED"] = "1" if al else "0"
+    os.environ["GAMUT_HIP_PNG_ALIGNED"] = "1" if al == "aligned" else "0"
+    os.environ["GAMUT_HIP_PNG_ROLL"] = "1" if al == "roll" else "0"
     yield request.param
     for k, v in old.items():
         if v is None:

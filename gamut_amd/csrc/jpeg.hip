@@ -688,7 +688,7 @@ __global__ __launch_bounds__(MCUS * 8) void k_jpeg_cols4(JpegArgs a)
 {
     static_assert(ST == GAMUT_JPGD_YH2V1 || ST == GAMUT_JPGD_YH1V2, "four blocks per MCU");
     constexpr bool WIDE = ST == GAMUT_JPGD_YH2V1;
-    constexpr int MW = WIDE ? 16 : 8, MH = WIDE ? 8 : 16;
+    constexpr int MH = WIDE ? 8 : 16;
     constexpr int STRIPS = 2;
     __shared__ __attribute__((aligned(16))) i32 T1[MCUS * 2 * BLK_STRIDE];
     const int t = threadIdx.x, m = t >> 3, r = t & 7;

@@ -32,6 +32,9 @@ namespace {
 
 typedef uint32_t u32;
 
+#ifndef PNG_PRED_OPAQUE
+#define PNG_PRED_OPAQUE 1
+#endif
 #ifndef PNG_PAETH_ONE_ASM         // tuning knob (tools/variant.sh): the Paeth predictor's packed operations as one asm statement
 #define PNG_PAETH_ONE_ASM 0           // (measured slower: 7.74 vs 7.58 ms, profiles/r05_png_ab5.txt -- the rigid block keeps the scheduler from interleaving the pixels)
 #endif
@@ -200,7 +203,11 @@ __device__ __forceinline__ u32 paeth_band_pred(const RowFilter& f, u32 a, u32 b,
     u32 third;                                                                           // (c & mP) | (avg & mAvg): two masks of the lane -- v_and + v_and_or,
     asm("v_and_b32 %0, %1, %2\n\tv_and_or_b32 %0, %3, %4, %0" : "=&v"(third) : "v"(c), "v"(f.mP), "v"(avg_bytes(a, b)), "v"(f.mAvg));   // which the compiler turns into three selects
 
-    return bfi(m2, third, bfi(m1, b, a));
+    u32 pred = bfi(m2, third, bfi(m1, b, a));
+#if PNG_PRED_OPAQUE
+    asm("" : "+v"(pred));               // keeps the selection one instruction: left to see through it, the compiler fuses it with the byte-wise add's
+#endif                                  // `& 0x7f7f7f7f` as two three-input operations AND computes it again for the `^` (11 -> 10 instructions per pixel)
+    return pred;
 }
 
 // 4 bytes of the 16-byte piece v[0..3] starting at byte offset O (bytes past the piece read as zero)

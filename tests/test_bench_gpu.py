@@ -112,10 +112,13 @@ def test_config5_1024_mixed_images(hip):
 def test_default_line_carries_the_other_configs(hip):
     """the driver's own `python bench.py` line: the headline + an `also` entry per other config, each with its parity verdict"""
     r = _run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--cpu-seconds", "2", "--no-traffic", "--also-seconds", "400"])
-    assert r["config"]["images_per_gpu_per_step"] == 1024 and len(r["also"]) == 12
+    sys.path.insert(0, ROOT)
+    import bench
+    n = len(bench.ALSO)                                                 # the other BASELINE.json configs (+ 4:4:4, -> rgb8, -> l8), inputs resident in HBM
+    assert r["config"]["images_per_gpu_per_step"] == 1024 and len(r["also"]) == n + 4, [e.get("workload", e.get("what")) for e in r["also"]]
     for e in r["also"]:
         assert "error" not in e and "skipped" not in e and e.get("parity", "").startswith("ok"), e
-    for e in r["also"][:8]:                                             # the other BASELINE.json configs (+ 4:4:4), inputs resident in HBM
+    for e in r["also"][:n]:
         assert e["ms_per_step"] > 0 and 0 < e["roofline_frac"] < 1
-    for e in r["also"][8:]:                                             # files -> pixels (tools/files_bench.py: baseline and progressive JPEG, two kinds of PNG): PCIe-inclusive, labelled so
+    for e in r["also"][n:]:                                             # files -> pixels (tools/files_bench.py: baseline and progressive JPEG, two kinds of PNG): PCIe-inclusive, labelled so
         assert e["what"].startswith("files -> pixels") and e["unit"] == "Mpx/s" and e["value"] > 0 and "host memory" in e["inputs"]

@@ -5,7 +5,7 @@ CTR=$1; shift 2
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/pmc_tmp; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 150 rocprofv3 --output-format csv --pmc $CTR -d $OUT -o t -- python $REPO/bench.py "$@" --no-cpu --no-also > $OUT/log 2>&1
+timeout 150 rocprofv3 --output-format csv --kernel-include-regex gamut --pmc $CTR -d $OUT -o t -- python $REPO/bench.py "$@" --no-cpu --no-also > $OUT/log 2>&1
 python - "$OUT" <<'PY'
 import csv, glob, sys, os
 from collections import defaultdict

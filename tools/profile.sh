@@ -15,8 +15,8 @@ cd /tmp && export TMPDIR=/tmp
 timeout 600 python $REPO/bench.py "$@" --no-also > $OUT/bench.json 2> $OUT/bench.err
 tail -1 $OUT/bench.json
 timeout 400 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o t -- python $REPO/bench.py "$@" --no-cpu --no-also --no-traffic > $OUT/trace.log 2>&1
-timeout 400 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o t -- python $REPO/bench.py "$@" --steps 3 --warmup 1 --no-cpu --no-also --no-traffic --batch $PB > $OUT/pmc_fetch.log 2>&1
-timeout 400 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o t -- python $REPO/bench.py "$@" --steps 3 --warmup 1 --no-cpu --no-also --no-traffic --batch $PB > $OUT/pmc_write.log 2>&1
+timeout 400 rocprofv3 --output-format csv --kernel-include-regex gamut --pmc FETCH_SIZE -d $OUT/pmc_fetch -o t -- python $REPO/bench.py "$@" --steps 3 --warmup 1 --no-cpu --no-also --no-traffic --batch $PB > $OUT/pmc_fetch.log 2>&1
+timeout 400 rocprofv3 --output-format csv --kernel-include-regex gamut --pmc WRITE_SIZE -d $OUT/pmc_write -o t -- python $REPO/bench.py "$@" --steps 3 --warmup 1 --no-cpu --no-also --no-traffic --batch $PB > $OUT/pmc_write.log 2>&1
 grep "^{" $OUT/trace.log | tail -1 > $OUT/bench_profiled.json        # the line of the PROFILED run: its HIP-event average and rocprofv3's come from one process
 python $REPO/tools/summarize_prof.py $OUT $REPO/gpurun_out/summary_$TAG $PB $STEPS $PER_STEP | head -40
 cp $OUT/bench.json $REPO/gpurun_out/summary_$TAG/bench.json

@@ -2008,13 +2008,8 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
         int total_long = 0, total_short = 0;
         double ms_kernels_issue = 0;
         std::vector<DevRaw> raws;
-        // Where the groups begin.  Equal groups leave the GPU idle until a quarter of the batch has been copied and uploaded; with the first
-        // groups smaller (boundary g at count * (g / n)^shape) its first kernels start earlier (GAMUT_HIP_JPEG_GROUP_SHAPE, default below).
-        static const double shape_env = [] { const char* e = getenv("GAMUT_HIP_JPEG_GROUP_SHAPE"); return e && *e ? atof(e) : 0.0; }();
-        const double shape = shape_env > 0 ? shape_env : 1.0;
-        auto group_bound = [&](int g) { return g >= n_groups ? count : (int)((double)count * pow((double)g / n_groups, shape)); };
         for (int g = 0; g < n_groups; ++g) {
-            const int g_lo = group_bound(g), g_hi = group_bound(g + 1);
+            const int g_lo = (int)((int64_t)count * g / n_groups), g_hi = (int)((int64_t)count * (g + 1) / n_groups);
             if (g_hi <= g_lo) continue;
             parallel_for(g_hi - g_lo, workers, [&](int, int k) {
                 const int i = g_lo + k;

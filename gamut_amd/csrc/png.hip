@@ -32,6 +32,9 @@ namespace {
 
 typedef uint32_t u32;
 
+#ifndef PNG_RING_ABL             // ablations of the ring form (wrong pixels; measurements only): 1 = the fast tiles fetch nothing, 2 = store nothing
+#define PNG_RING_ABL 0
+#endif
 #ifndef PNG_PRED_OPAQUE
 #define PNG_PRED_OPAQUE 1
 #endif
@@ -682,8 +685,9 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
         ploff = (u32)crow * (a.wb + 1) + (u32)(64 + cslot - crow) * IB;
     }
     auto prefetch_tile = [&](u32 T0) {
-        if constexpr (AL) { if (fast_prefetch_ok(T0)) prefetch_fast(T0); else prefetch_line((int)T0); return; }
+        if constexpr (AL) { if (fast_prefetch_ok(T0)) { if (!(PNG_RING_ABL & 1)) prefetch_fast(T0); } else prefetch_line((int)T0); return; }
         if (!PNG_NT_LOADS && full64 && T0 >= 64 && T0 + 8 <= full_iters) {
+            if (PNG_RING_ABL & 1) return;
             const uint8_t* pt = pbase + (size_t)T0 * IB;
             #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -813,6 +817,7 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
     };
     auto wb_store = [&](u32 T0) {
         if (fast_wb_ok(T0)) {
+            if (PNG_RING_ABL & 2) { asm volatile("" :: "v"(wbv[0].x ^ wbv[1].x ^ wbv[2].x ^ wbv[3].x ^ wbv[4].x ^ wbv[5].x ^ wbv[6].x ^ wbv[7].x)); return; }
             // a piece's place in the output is a lane constant minus 128 k behind a wave-uniform row pointer -- no predicates, no per-row
             // address arithmetic
             const u32 goff0 = wb_lane + T0 * 16u;                                         // (d_pitch * 64 < 2^31: checked by the launcher)

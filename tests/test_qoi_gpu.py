@@ -63,6 +63,56 @@ def test_qoi_drop_in_and_batch(hip, small_batch_kernel):
             assert np.array_equal(host[offs[i]:offs[i] + nbytes[i]], e[0].reshape(-1)), i
 
 
+@pytest.mark.parametrize("mix", ["all", "some"])
+def test_qoi_files_in_page_locked_memory(hip, mix):
+    """Files that lie in page-locked host memory (gamut_hip_host_malloc_pinned) go up from where they are -- no staging copy -- beside pageable
+    ones that are gathered first (qoi.hip, the upload of gamut_hip_qoi_decode_batch_device): every file pinned, and every other one, must give
+    what the pageable call gives and what the oracle gives, a truncated, a damaged and a header-only file included; each pinned file ends
+    exactly where its allocation's bytes end."""
+    imgs = _qoi_test_images()
+    blobs = [gen.qoi_encode(a) for a in imgs] * 3
+    blobs.append(blobs[2][:200] + blobs[2][-8:])                       # ends early
+    blobs.insert(4, b"qoif" + bytes(30))                               # a bad header in the middle
+    damaged = bytearray(blobs[1]); damaged[40:48] = b"\xff" * 8; blobs.append(bytes(damaged))
+    blobs.append(blobs[0][:14])                                        # the header alone
+    n = len(blobs)
+    hip.gamut_hip_host_malloc_pinned.restype = C.c_void_p; hip.gamut_hip_host_malloc_pinned.argtypes = [C.c_size_t]
+    hip.gamut_hip_host_free_pinned.restype = None; hip.gamut_hip_host_free_pinned.argtypes = [C.c_void_p]
+    exp = [O.qoi_decode(b, 4) for b in blobs]
+    nbytes = [e[0].size if e else 0 for e in exp]
+    offs = np.concatenate([[0], np.cumsum(nbytes)[:-1]]).astype(np.int64)
+
+    def run(pin):
+        keep, pinned, ptr_list = [], [], []
+        for i, b in enumerate(blobs):
+            if pin(i):
+                q = hip.gamut_hip_host_malloc_pinned(len(b))
+                assert q, hip.gamut_hip_last_error()
+                C.memmove(q, b, len(b)); pinned.append(q); ptr_list.append(q)
+            else:
+                a = np.frombuffer(b, np.uint8); keep.append(a); ptr_list.append(a.ctypes.data)
+        ptrs = (C.c_void_p * n)(*ptr_list); sizes = (C.c_int * n)(*[len(b) for b in blobs])
+        dout = hip.gamut_hip_device_malloc(int(sum(nbytes)) + 64)
+        descs = (_capi.QoiDesc * n)(); st = (C.c_int * n)()
+        rc = hip.gamut_hip_qoi_decode_batch_device(ptrs, sizes, n, 4, offs.ctypes.data_as(C.POINTER(C.c_int64)), dout, descs, st, None)
+        host = np.empty(int(sum(nbytes)), np.uint8)
+        _capi.check(hip.gamut_hip_memcpy_d2h(host.ctypes.data, dout, host.nbytes, None))
+        _capi.check(hip.gamut_hip_stream_synchronize(None))
+        hip.gamut_hip_device_free(dout)
+        for q in pinned:
+            hip.gamut_hip_host_free_pinned(q)
+        return rc, list(st), host
+
+    rc0, st0, host0 = run(lambda i: False)
+    rc1, st1, host1 = run((lambda i: True) if mix == "all" else (lambda i: i % 2 == 1))
+    assert (rc1, st1) == (rc0, st0) and rc0 == _capi.ERR_DECODE
+    assert [s != 0 for s in st0] == [e is None for e in exp]
+    for i, e in enumerate(exp):
+        if e:
+            assert np.array_equal(host0[offs[i]:offs[i] + nbytes[i]], e[0].reshape(-1)), i
+            assert np.array_equal(host1[offs[i]:offs[i] + nbytes[i]], e[0].reshape(-1)), i
+
+
 def test_qoi_resident_streams(hip, small_batch_kernel):
     """files already in HBM (gamut_hip_qoi_decode_resident_device): same pixels as the host-pointer batch; bounds are checked"""
     from gamut_amd import synth

@@ -1136,6 +1136,7 @@ struct SubTrace {
     int old_nblk, old_dcs[3];       // the previous pass's totals
     int old_ntok, ntok;             // tokens (every DC, every non-zero AC coefficient): the previous pass's total; this pass's (out)
     bool stopped;                   // out: the pass ended at a matching checkpoint (exit state = the previous one)
+    int stop_ck;                    // out: which one (measurement builds)
 };
 template <int MODE>
 __device__ __forceinline__ bool sub_decode(const SubCtx& x, SubState& s, int& nblk, int (&dcs)[3], int64_t b, int64_t b_end,
@@ -1250,7 +1251,7 @@ __device__ __forceinline__ bool sub_decode(const SubCtx& x, SubState& s, int& nb
                         q.dcs[0] = (int16_t)(q.dcs[0] + e0); q.dcs[1] = (int16_t)(q.dcs[1] + e1); q.dcs[2] = (int16_t)(q.dcs[2] + e2);
                     }
                     nblk = tr->old_nblk + dn; ntok = tr->old_ntok + dt; dc0 = tr->old_dcs[0] + e0; dc1 = tr->old_dcs[1] + e1; dc2 = tr->old_dcs[2] + e2;
-                    tr->stopped = true;
+                    tr->stopped = true; tr->stop_ck = ck_j;
                     break;
                 }
                 k.pos = br.pos; k.cz = cz; k.nblk = (uint16_t)nblk; k.ntok = (uint16_t)ntok; k.dcs[0] = (int16_t)dc0; k.dcs[1] = (int16_t)dc1; k.dcs[2] = (int16_t)dc2;
@@ -1286,14 +1287,18 @@ __device__ __forceinline__ bool sub_decode(const SubCtx& x, SubState& s, int& nb
 #define JPEG_SYNC_PROFILE 0
 #endif
 #if JPEG_SYNC_PROFILE
-__device__ unsigned long long g_sync_prof[8];
+__device__ unsigned long long g_sync_prof[16];      // 0-4 cycles per phase, 6 re-decode sweeps, 7 segments; 8 lanes that decoded again, 9 of them
+                                                     // stopped at a checkpoint, 10 the sum of those checkpoints' numbers, 11 ran to the end of their sub-sequence,
+                                                     // 12 of those: left in another state than before (the lane behind must decode again)
 #define SPROF_DECL unsigned long long sp_t0 = clock64()
 #define SPROF(slot) do { const unsigned long long now_ = clock64(); if (threadIdx.x == 0) atomicAdd(&g_sync_prof[slot], now_ - sp_t0); sp_t0 = now_; } while (0)
 #define SPROF_COUNT(slot, n) do { if (threadIdx.x == 0) atomicAdd(&g_sync_prof[slot], (unsigned long long)(n)); } while (0)
+#define SPROF_LANE(slot, n) atomicAdd(&g_sync_prof[slot], (unsigned long long)(n))
 #else
 #define SPROF_DECL
 #define SPROF(slot)
 #define SPROF_COUNT(slot, n)
+#define SPROF_LANE(slot, n)
 #endif
 template <int NH, bool TOK = false>
 __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevItem* items, const DevImage* images,
@@ -1365,6 +1370,7 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_entropy_sync(const DevIte
             dcs[0] = dcs[1] = dcs[2] = 0;
             sub_decode<SUB_COUNT>(x, mine, nblk, dcs, 0, 0, nullptr, nullptr, nullptr, &tr);
             ntok = tr.ntok;
+            SPROF_LANE(8, 1); if (tr.stopped) { SPROF_LANE(9, 1); SPROF_LANE(10, tr.stop_ck); } else { SPROF_LANE(11, 1); if (!same(mine, exit_state[t])) SPROF_LANE(12, 1); }
             if (!tr.stopped && !same(mine, exit_state[t])) { exit_state[t] = mine; changed = 1; }
         }
         __syncthreads();
@@ -2182,8 +2188,8 @@ using namespace gamut;
 #if JPEG_SYNC_PROFILE
 extern "C" int gamut_hip_jpeg_sync_profile(unsigned long long* out8, int reset)      // measurement builds only
 {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_sync_prof), 64) != hipSuccess) return 1;
-    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_sync_prof), z, 64) != hipSuccess) return 1; }
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_sync_prof), 128) != hipSuccess) return 1;          // (sixteen counters)
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_sync_prof), z, 128) != hipSuccess) return 1; }
     return 0;
 }
 #endif

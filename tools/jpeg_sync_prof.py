@@ -16,8 +16,10 @@ out=torch.empty((B,h,w*4),dtype=torch.uint8,device="cuda"); off=(np.arange(B,dty
 st=torch.cuda.current_stream().cuda_stream
 def run():
     info=(_capi.JpegFrame*B)(); _capi.check(L.gamut_hip_jpeg_decode_batch_device(ptrs,lens,B,4,off.ctypes.data_as(C.POINTER(C.c_int64)),out.data_ptr(),info,None,None,st)); torch.cuda.synchronize()
-run(); buf=(C.c_ulonglong*8)(); prof(buf,1)
+run(); buf=(C.c_ulonglong*16)(); prof(buf,1)
 t0=time.perf_counter(); run(); dt=time.perf_counter()-t0
 prof(buf,0); v=list(buf); n=v[7] or 1
 names=["sweep0","resync","scan","write","first+clear","?","#sweeps","#segments"]
 print(f"{dt*1e3:.2f} ms; per segment (cycles): "+", ".join(f"{names[k]} {v[k]/n:.0f}" for k in range(7)))
+if v[8]:
+    print(f"re-decodes per segment: {v[8]/n:.1f} lanes decoded again; {v[9]/n:.1f} stopped at a checkpoint (mean checkpoint number {v[10]/max(v[9],1):.2f} of 0..4), {v[11]/n:.1f} ran to the end of their sub-sequence, {v[12]/n:.1f} of those left in a new state")

@@ -25,6 +25,10 @@ import time
 import numpy as np
 import torch
 
+# dmabuf IPC: RCCL and device memory shared across processes need it on this pool -- set before the first HIP call on EVERY path (under
+# the driver's own `torch.distributed.run ... bench.py --gpus N` nothing else would)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -48,8 +52,9 @@ def parse():
     ap.add_argument("--total-images", type=int, default=0, help="mixed workload: images over ALL ranks (8192 = BASELINE.json configs[4]); "
                     "each rank takes total / N (strong scaling) instead of --batch")
     ap.add_argument("--no-also", action="store_true", help="default workload only: skip the `also` lines (the other BASELINE.json configs at their stated shapes)")
-    ap.add_argument("--also-seconds", type=float, default=330.0, help="wall-clock budget of the `also` lines; what does not fit is reported as skipped")
-    ap.add_argument("--gather", action="store_true", help="N > 1: also time an all_gather of output slices (after the timed region)")
+    ap.add_argument("--also-seconds", type=float, default=420.0, help="wall-clock budget of the `also` lines; what does not fit is reported as skipped")
+    ap.add_argument("--gather", action="store_true", help="N > 1: also time an all_gather of output slices over RCCL (after the timed region; the only use of RCCL in this script)")
+    ap.add_argument("--also-args", default="", help="N > 1 test aid: extra arguments for every `also` sub-run (e.g. a small geometry); implies the `also` lines at any --batch")
     return ap.parse_args()
 
 
@@ -66,8 +71,8 @@ def host_cores():
 
 
 def traffic_from_profiles(workload, kernel_substr):
-    """HBM bytes per image from the committed rocprofv3 --pmc summary of THIS workload (profiles/<tag>_bench.json names the
-    workload, <tag>_traffic.json holds the counters), or None when the workload has not been profiled."""
+    """(HBM bytes per image, file) from the committed rocprofv3 --pmc summary of THIS workload (profiles/<tag>_bench.json names the
+    workload, <tag>_traffic.json holds the counters), or (None, None) when the workload has not been profiled."""
     import glob
     import re
     norm = lambda w: re.sub(r"^batch \d+ x |, \d+ layers of ", "|", w)
@@ -76,13 +81,14 @@ def traffic_from_profiles(workload, kernel_substr):
             line = [ln for ln in open(p).read().splitlines() if ln.startswith("{")][-1]
             if norm(json.loads(line)["config"]["workload"]) != norm(workload):
                 continue
-            rows = json.load(open(p[:-len("_bench.json")] + "_traffic.json")).get("kernels", [])
+            tf = p[:-len("_bench.json")] + "_traffic.json"
+            rows = json.load(open(tf)).get("kernels", [])
             rows = [r for r in rows if kernel_substr.split(" + ")[0] in r.get("kernel", "") and r.get("hbm_bytes_per_image")]
             if rows:
-                return max(r["hbm_bytes_per_image"] for r in rows)
+                return max(r["hbm_bytes_per_image"] for r in rows), os.path.join("profiles", os.path.basename(tf))
         except Exception:
             pass
-    return None
+    return None, None
 
 
 def live_traffic(kernel_substr, pmc_batch):
@@ -139,6 +145,9 @@ ALSO = [  # the other BASELINE.json configs at their stated shapes, each through
     ("config 4: rgba16 -> rgbaf32, 256 layers of 8192x8192 in resident chunks", "convert:rgba16:rgbaf32", ["--batch", "256"]),
     ("config 4: rgbaf32 -> rgba8, 256 layers", "convert:rgbaf32:rgba8", ["--batch", "256"]),
     ("config 4: rgba8 -> rgba16, 256 layers", "convert:rgba8:rgba16", ["--batch", "256"]),
+    ("config 4, the reverse directions: rgbaf32 -> rgba16 (scanline.d:731-746), 256 layers", "convert:rgbaf32:rgba16", ["--batch", "256"]),
+    ("config 4: rgba8 -> rgbaf32 (scanline.d:428-443), 256 layers", "convert:rgba8:rgbaf32", ["--batch", "256"]),
+    ("config 4: rgba16 -> rgba8 (through the rgbaf32 intermediate, scanline.d:25-31 / image.d:1238-1241), 256 layers", "convert:rgba16:rgba8", ["--batch", "256"]),
     ("config 5 at its stated size on this GPU: 8192 mixed 1080p images", "mixed", ["--total-images", "8192"]),
 ]
 
@@ -155,7 +164,10 @@ def also_lines(budget_s):
             res.append({"what": what, "workload": wl, "skipped": "the --also-seconds budget ran out"})
             continue
         cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", "20", "--warmup", "5", "--no-cpu", "--no-also"] + extra
-        if not wl.startswith("png"):                                     # the PNG lines carry their HBM traffic, measured at their own batch
+        # every line takes its HBM traffic live, at its own timed batch (two rocprofv3 --pmc passes restricted to this library's kernels),
+        # as long as the budget has room for the lines behind it; a line that replays a committed summary names the file.  The mixed
+        # step is three kernels side by side: no single-kernel traffic figure
+        if wl == "mixed" or left < 150:
             cmd.append("--no-traffic")
         t0 = time.perf_counter()
         try:
@@ -200,6 +212,69 @@ def also_lines(budget_s):
     return res
 
 
+ALSO_MULTI = [  # N > 1: what BASELINE.json quotes "at 1 / 8 GPUs" beside the headline -- config 3 and 4 weak (every rank a full batch), config 5 strong (8192 images over all ranks)
+    ("config 3: 512 x 3840x2160 RGBA8 per GPU, random row filters", "png", []),
+    ("config 3: the same with the encoder heuristic's filters", "png:heuristic", []),
+    ("config 4: rgba16 -> rgbaf32, 256 layers of 8192x8192 per GPU", "convert:rgba16:rgbaf32", ["--batch", "256"]),
+    ("config 4: rgbaf32 -> rgba8, 256 layers per GPU", "convert:rgbaf32:rgba8", ["--batch", "256"]),
+    ("config 4: rgba8 -> rgba16, 256 layers per GPU", "convert:rgba8:rgba16", ["--batch", "256"]),
+    ("config 5: 8192 mixed 1080p images over all ranks (strong scaling)", "mixed", ["--total-images", "8192"]),
+]
+
+
+def also_lines_multi(args, rank, world, dist):
+    """Every rank runs each ALSO_MULTI workload as a sub-run of this script with the launcher's RANK / LOCAL_RANK / WORLD_SIZE and a
+    rendezvous port of its own (rank 0 picks it, broadcast over the gloo group); rank 0 condenses its child's JSON line."""
+    import shlex
+    import socket
+    import subprocess
+    t_end = time.perf_counter() + args.also_seconds
+    res = []
+    for k, (what, wl, extra) in enumerate(ALSO_MULTI):
+        left = [t_end - time.perf_counter()]
+        port = [0]
+        if rank == 0:
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                port[0] = sock.getsockname()[1]
+        ctl = [port[0], left[0]]
+        dist.broadcast_object_list(ctl, src=0)                    # (rank 0's clock decides: every rank takes the same branch)
+        if ctl[1] < 30:
+            res.append({"what": what, "workload": wl, "skipped": "the --also-seconds budget ran out"})
+            continue
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(ctl[0]))
+        env.pop("TORCHELASTIC_USE_AGENT_STORE", None)             # the sub-run's rank 0 hosts its own store (the launcher's agent store is on the parent's port)
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--workload", wl, "--steps", "20", "--warmup", "5", "--no-cpu", "--no-also",
+               "--no-traffic"] + extra + shlex.split(args.also_args)
+        t0 = time.perf_counter()
+        e = {"what": what, "workload": wl}
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=ctl[1] + 60, text=True, env=env)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or (rank == 0 and not line):
+                e.update({"parity": "FAILED" if "PARITY" in (r.stderr + r.stdout) else None, "error": ((r.stderr or r.stdout).strip().splitlines() or ["no output"])[-1][:200], "rc": r.returncode})
+            elif rank == 0:
+                j = json.loads(line[-1])
+                e = {"what": what, "workload": j["config"]["workload"], "n_gpus": j["n_gpus"], "scaling": j["scaling"], "value": j["value"], "unit": j["unit"],
+                     "ms_per_step": j["ms_per_step"], "roofline_frac_rank0": j["roofline"]["frac"], "kernel": j["roofline"]["kernel"], "kernel_ms_avg_rank0": j["roofline"]["kernel_ms_avg"],
+                     "images_per_gpu_per_step": j["config"]["images_per_gpu_per_step"],
+                     "parity": "ok on every rank: " + str(j["config"].get("parity_check", "")), "steps": j["steps"], "wall_s": round(time.perf_counter() - t0, 1)}
+                if "per_format" in j["config"]:
+                    e["per_format"] = j["config"]["per_format"]
+        except subprocess.TimeoutExpired:
+            e["skipped"] = "did not finish inside the --also-seconds budget"
+        except Exception as ex:
+            e["error"] = repr(ex)[:200]
+        # a failure on ANY rank is the line's failure
+        bad = [None] * world
+        dist.all_gather_object(bad, e.get("error") or e.get("skipped"))
+        worst = next((f"rank {r_}: {b}" for r_, b in enumerate(bad) if b), None)
+        if worst and "error" not in e and "skipped" not in e:
+            e = {"what": what, "workload": wl, "error": worst}
+        res.append(e)
+    return res
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with no launcher around it: start N ranks of this script under torch.distributed.run (one
     process per GPU, rendezvous on 127.0.0.1) and let rank 0's JSON line through.  The driver's own
@@ -211,8 +286,7 @@ def self_launch(args):
         port = sock.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")              # dmabuf IPC: RCCL across processes needs it on this pool
+    env = dict(os.environ)                                         # (HSA_ENABLE_IPC_MODE_LEGACY=0 is set at import, on every path)
     env.setdefault("OMP_NUM_THREADS", "1")
     raise SystemExit(subprocess.call(cmd, env=env))
 
@@ -228,18 +302,30 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    # GAMUT_BENCH_BACKEND=gloo: run the N > 1 code path on a box with fewer GPUs than ranks (ranks share devices); a test
-    # aid only -- the driver's multi-GPU runs use RCCL ("nccl") with one GPU per rank
-    backend = os.environ.get("GAMUT_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    # One process per GPU; a box with fewer GPUs than ranks (the 1-GPU test boxes) lets ranks share devices.  The data path has NO
+    # collective (images are independent, sharded by index), so the control plane -- rendezvous, the barriers around the
+    # timed region, the max-reduce of the elapsed time -- runs over gloo on the host: an RCCL communicator problem cannot cost the
+    # scaling curve.  RCCL is created only for --gather (the one exchange the path has), and only when every rank has a GPU of its own.
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")        # one node: never resolve the container's hostname
+        sys.stdout.flush()
+        saved = os.dup(1)                                            # gloo announces its connections on stdout ("[Gloo] Rank 0 is connected to ..."):
+        os.dup2(2, 1)                                                # stdout carries ONE JSON line, so they go to stderr
+        try:
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=900))
+            dist.barrier()
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+    gather_backend = "nccl" if (ndev >= int(os.environ.get("LOCAL_WORLD_SIZE", world)) and os.environ.get("GAMUT_BENCH_BACKEND", "nccl") == "nccl") else "gloo"
 
     from gamut_amd import _capi, synth
     L = _capi.lib()
@@ -592,14 +678,13 @@ def main():
     else:
         raise SystemExit(f"unknown workload {wl}")
 
-    if check is not None and rank == 0:
+    if check is not None:                                  # EVERY rank checks its own batch: no rank times unverified output
         if not os.environ.get("GAMUT_BENCH_NOCHECK"):      # experiments with deliberately wrong kernels (tools/variant.sh) only
             check()
 
     # ------------------------------------------------------------------ timing
     def barrier():
         if world > 1:
-            import torch.distributed as dist
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -620,33 +705,43 @@ def main():
 
     gather = None
     if world > 1:
-        import torch.distributed as dist
-        tmax = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         # The only exchange the path has: gathering decoded outputs.  Outside the timed region and reported on
-        # its own -- an all-gather of a slice of every rank's output (<= 256 MiB each) over RCCL / xGMI.
+        # its own -- an all-gather of a slice of every rank's output (<= 256 MiB each) over RCCL / xGMI, on a process group of its
+        # own that exists only for this.
         try:
             if not args.gather:
                 raise StopIteration
+            pg = dist.new_group(backend="nccl", device_id=dev) if gather_backend == "nccl" else None
             piece = out.reshape(-1).view(torch.uint8)[:256 << 20].contiguous()
-            if backend != "nccl":
+            if gather_backend != "nccl":
                 piece = piece.cpu()
             dst = torch.empty(world * piece.numel(), dtype=torch.uint8, device=piece.device)
-            dist.all_gather_into_tensor(dst, piece)                      # warm-up (communicator set-up)
+            dist.all_gather_into_tensor(dst, piece, group=pg)            # warm-up (communicator set-up)
             torch.cuda.synchronize(); dist.barrier()
             t0g = time.perf_counter()
-            dist.all_gather_into_tensor(dst, piece)
+            dist.all_gather_into_tensor(dst, piece, group=pg)
             torch.cuda.synchronize(); dist.barrier()
             dtg = time.perf_counter() - t0g
             ok = bool(torch.equal(dst[rank * piece.numel():(rank + 1) * piece.numel()], piece))
             gather = {"bytes_per_rank": int(piece.numel()), "ms": round(dtg * 1e3, 3), "GB/s_received_per_rank": round((world - 1) * piece.numel() / dtg / 1e9, 1),
-                      "own_slice_intact": ok, "note": "all_gather of output slices, outside the timed region"}
+                      "own_slice_intact": ok, "backend": "rccl" if gather_backend == "nccl" else "gloo (ranks share a device)",
+                      "note": "all_gather of output slices, outside the timed region"}
             del dst, piece
         except StopIteration:
             gather = None
         except Exception as e:                                          # the headline number does not depend on it
             gather = {"error": repr(e)[:200]}
+
+    # N > 1: the other BASELINE.json configs on the same N ranks ("1 vs 8 GPUs", "sharded across 8 MI355X"), each as a sub-run of
+    # this script per rank -- fresh HBM, its own parity check on every rank, its own gloo rendezvous on a port rank 0 picks
+    also_multi = None
+    if world > 1 and wl == "jpeg" and not args.no_also and ((B == 1024 and not (args.width or args.height)) or args.also_args):
+        del coeffs, out, zag
+        torch.cuda.empty_cache()
+        also_multi = also_lines_multi(args, rank, world, dist)
 
     if rank == 0:
         avg_kernel_s = float(np.mean(kern_ms)) * 1e-3
@@ -660,9 +755,9 @@ def main():
             per_image, traffic_src = live_traffic(kernel_name, pmc_batch)
             traffic = None if per_image is None else round(per_image * B)
         if traffic is None:
-            t = traffic_from_profiles(workload, kernel_name)
+            t, tfile = traffic_from_profiles(workload, kernel_name)
             traffic = None if t is None else round(t * B)
-            traffic_src = (f"replayed from profiles/ (live pass unavailable: {traffic_src})" if traffic_src else "replayed from profiles/") if t is not None else traffic_src
+            traffic_src = (f"replayed from {tfile} (live pass unavailable: {traffic_src})" if traffic_src else f"replayed from {tfile}") if t is not None else traffic_src
         res = {
             "metric": "Mpixels/sec decoded (batched 1080p JPEG 4:2:0)" if wl == "jpeg" else f"Mpixels/sec ({wl})",
             "value": round(world * px_per_step * args.steps / elapsed / 1e6, 1),
@@ -709,10 +804,12 @@ def main():
             del coeffs, out, zag                                          # the sub-runs want the HBM
             torch.cuda.empty_cache()
             res["also"] = also_lines(args.also_seconds)
+        if also_multi is not None:
+            res["also"] = also_multi
         print(json.dumps(res), flush=True)
 
     if world > 1:
-        import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
 
 

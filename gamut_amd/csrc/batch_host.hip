@@ -159,7 +159,10 @@ extern "C" int gamut_hip_decode_batch_device(const uint8_t* const* data, const s
             for (int f : { (int)GAMUT_HIP_FORMAT_PNG, (int)GAMUT_HIP_FORMAT_QOI }) {
                 if (idx[f].empty()) continue;
                 P.w[jobs.n].ensure();
-                P.w[jobs.n].submit([&, f] { run_leg(f, true); });
+                P.w[jobs.n].submit([&, f] {                                                   // (anything a leg throws -- bad_alloc from a per-device slot -- is that leg's verdict:
+                    try { run_leg(f, true); }                                                 //  swallowed by the worker it would have left rc == OK over pixels never written)
+                    catch (...) { res[f].rc = GAMUT_HIP_ERR_OUT_OF_MEMORY; snprintf(res[f].msg, sizeof(res[f].msg), "decode_batch_device: out of host memory in the %s leg", f == GAMUT_HIP_FORMAT_PNG ? "PNG" : "QOI"); }
+                });
                 ++jobs.n;                                                                     // only what was really handed over is waited for
             }
             run_leg(GAMUT_HIP_FORMAT_JPEG, true);

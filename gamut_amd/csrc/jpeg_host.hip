@@ -1775,20 +1775,26 @@ int host_redo(const uint8_t* const* data, const size_t* len, const std::vector<i
     int workers = host_threads();
     workers = workers < 1 ? 1 : workers > 16 ? 16 : workers;
     if (workers > n) workers = n;
-    std::vector<gamut_hip_jpeg_frame> frames((size_t)n);
-    parallel_for(n, workers, [&](int, int k) {
-        const int i = idx[(size_t)k];
-        rcs[(size_t)k] = decode_coeffs(data[i], len[i], &frames[(size_t)k]);
-        if (rcs[(size_t)k] != GAMUT_HIP_OK) msgs[(size_t)k] = last_error_buf();
-    });
+    // in chunks of `workers` files -- decode, deliver, free: a batch of a thousand damaged 4K files would otherwise hold their dense
+    // coefficients (25 MB each) in host memory all at once
     int hip_rc = GAMUT_HIP_OK;
-    for (int k = 0; k < n; ++k) {
-        const int i = idx[(size_t)k];
-        gamut_hip_jpeg_frame& fr = frames[(size_t)k];
-        if (rcs[(size_t)k] == GAMUT_HIP_OK && hip_rc == GAMUT_HIP_OK) hip_rc = deliver(i, fr);
-        info[i] = fr; info[i].coeffs = nullptr; info[i].max_zag = nullptr;
+    std::vector<gamut_hip_jpeg_frame> frames((size_t)workers);
+    for (int k0 = 0; k0 < n; k0 += workers) {
+        const int m = std::min(workers, n - k0);
+        for (int j = 0; j < m; ++j) memset(&frames[(size_t)j], 0, sizeof(gamut_hip_jpeg_frame));
+        parallel_for(m, m, [&](int, int j) {
+            const int k = k0 + j, i = idx[(size_t)k];
+            rcs[(size_t)k] = decode_coeffs(data[i], len[i], &frames[(size_t)j]);
+            if (rcs[(size_t)k] != GAMUT_HIP_OK) msgs[(size_t)k] = last_error_buf();
+        });
+        for (int j = 0; j < m; ++j) {
+            const int k = k0 + j, i = idx[(size_t)k];
+            gamut_hip_jpeg_frame& fr = frames[(size_t)j];
+            if (rcs[(size_t)k] == GAMUT_HIP_OK && hip_rc == GAMUT_HIP_OK) hip_rc = deliver(i, fr);
+            info[i] = fr; info[i].coeffs = nullptr; info[i].max_zag = nullptr;
+            free(fr.coeffs); free(fr.max_zag); fr.coeffs = nullptr; fr.max_zag = nullptr;
+        }
     }
-    for (gamut_hip_jpeg_frame& fr : frames) { free(fr.coeffs); free(fr.max_zag); fr.coeffs = nullptr; fr.max_zag = nullptr; }
     return hip_rc;
 }
 // ... into the caller's dense buffers (the coefficient-level entry point; progressive files at either level)
@@ -1913,6 +1919,10 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
     bool any_ok = false;
     for (int i = 0; i < count; ++i) any_ok = any_ok || prep[(size_t)i].rc == GAMUT_HIP_OK;
     uint32_t* d_scan_end = nullptr; uint32_t* st_used = nullptr;
+    // The caller's status words start out clear whatever happens below: a batch in which NO baseline file is the kernels' (every one
+    // of them kHostRedo at prepare_header, or progressive) never reaches the clear inside `any_ok`, and the file-level caller folds
+    // these words into its verdicts -- stale memory there turned a file the host feeder had decoded into ERR_DECODE.
+    if (d_status) GAMUT_HIP_CHECK(hipMemsetAsync(d_status, 0, (size_t)count * sizeof(uint32_t), stream));
 
     if (any_ok) {
         const auto t_up = std::chrono::steady_clock::now();
@@ -2149,7 +2159,8 @@ int entropy_decode_device(const uint8_t* const* data, const size_t* len, int cou
         if (!redo.empty()) {
             std::vector<int> rcs; std::vector<std::string> msgs;
             const auto deliver = hooks && hooks->redo ? std::function<int(int, const gamut_hip_jpeg_frame&)>([&](int i, const gamut_hip_jpeg_frame& fr) {
-                                     if (st_used && hipMemsetAsync(st_used + i, 0, sizeof(uint32_t), stream) != hipSuccess) return set_error(GAMUT_HIP_ERR_HIP, "jpeg: status reset failed");
+                                     uint32_t* const stw = st_used ? st_used : d_status;
+                                     if (stw && hipMemsetAsync(stw + i, 0, sizeof(uint32_t), stream) != hipSuccess) return set_error(GAMUT_HIP_ERR_HIP, "jpeg: status reset failed");
                                      return hooks->redo(i, fr, stream); })
                                                       : deliver_dense(coeff_offset, zag_offset, d_coeffs, d_max_zag, st_used ? st_used : d_status, stream);
             if (int rc = host_redo(data, len, redo, info, deliver, rcs, msgs)) return rc;

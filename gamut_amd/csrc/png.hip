@@ -554,6 +554,12 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
     const u32 out_wb = RGBA ? (a.wb / 3) * 4 : a.wb;
     // pieces written back cooperatively: a partial last piece goes along when the destination rows are padded (scratch)
     const u32 wb_iters = a.store_tail_masked ? full_iters : niter;
+    // Rows that do not start on a 128-byte line (tight rows of a width that is no multiple of 32 pixels: the reference's own layout): a group
+    // of 8 pieces counted from the row's first byte straddles two lines of memory, every line is then written in two partial pieces a tile
+    // apart -- 512 x 3848 x 2160 took 12 ms where 3840 takes 6 (profiles/r06_png_width_probe.txt).  The groups of such rows are the LINES of
+    // memory instead: a row whose first byte is ph pieces into its line writes back pieces 8 g - ph .. 8 g - ph + 7 (wave-uniform switch;
+    // the generic forms only -- the fast forms keep their per-lane constants for line-aligned rows).
+    const bool wb_lines = ((reinterpret_cast<uintptr_t>(D) | (uintptr_t)(uint64_t)a.d_pitch) & 127u) == 0;
 
     // cooperative mapping: in transfer k (0..7) this lane handles row 8k + crow, piece cslot of that row's 8
     const int crow = lane >> 3, cslot = lane & 7;
@@ -566,6 +572,12 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
         const int64_t bo = (int64_t)(band * 64) * a.d_pitch;
         dband = D + (int64_t)(((uint64_t)(u32)__builtin_amdgcn_readfirstlane((int)((uint64_t)bo >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)(uint64_t)bo));
     }
+    auto wb_phase = [&](int k) -> int {                                   // pieces between the line's first byte and the first byte of row 8 k + crow
+        return wb_lines ? 0 : (int)(((reinterpret_cast<uintptr_t>(cdst) + (uintptr_t)((int64_t)(8 * k) * a.d_pitch)) >> 4) & 7u);
+    };
+    const int ph63 = wb_lines ? 0 : (int)(((reinterpret_cast<uintptr_t>(D) + (uintptr_t)((int64_t)(band * 64 + 63) * a.d_pitch)) >> 4) & 7u);
+    // pieces of the band's last row that the write-backs up to tile T0s have stored (what a hand-off may publish once they have arrived)
+    auto stored_through = [&](int T0s) -> int { return (((T0s - 63 + ph63) & ~7) - ph63) + 8; };
     uint8_t* my_ring = ring + lane * PITCH + GUARD;
     uint8_t* co_ring = ring + crow * PITCH + GUARD;                     // + k * 8 * PITCH + slot * 16
 
@@ -674,7 +686,7 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
     const bool full64 = rows_left >= 64, al_full = AL && full64 && a.wb < 200000u;       // (64 rows of the stream + 4 KB inside 2^24 bytes)
     auto fast_prefetch_ok = [&](u32 T0) { return al_full && T0 >= 64 && T0 + 16 <= full_iters; };      // chunks T0 - 62 .. T0 + 15 of every row exist
     auto fast_drop_ok     = [&](u32 T0) { return al_full && T0 >= 72; };                                  // no chunk in front of its row
-    auto fast_wb_ok       = [&](u32 T0) { return full64 && T0 >= 64 && T0 + 8 <= wb_iters; };             // every row writes a whole group
+    auto fast_wb_ok       = [&](u32 T0) { return wb_lines && full64 && T0 >= 64 && T0 + 8 <= wb_iters; }; // every row writes a whole group, a whole line of memory
     // the row-aligned grid's own fast form: 64 live rows, every piece of the tile a whole piece inside its row -- the address is a
     // constant of the lane behind a wave-uniform pointer that moves by 8 rows less 8 pieces per transfer and a piece per trip
     u32 ploff = 0;
@@ -810,7 +822,8 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
         } else {
             #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const int it = (((int)T0 - (8 * k + crow)) & ~7) + cslot;
+                const int ph = wb_phase(k);
+                const int it = ((((int)T0 - (8 * k + crow) + ph) & ~7) - ph) + cslot;
                 wbv[k] = *reinterpret_cast<const uint4*>(co_ring + k * 8 * PITCH + ((u32)it & (RING - 1)) * 16);
             }
         }
@@ -836,7 +849,8 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
         } else {
             #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const int it = (((int)T0 - (8 * k + crow)) & ~7) + cslot;                      // piece 8g + cslot, g = floor((T0 - row) / 8)
+                const int ph = wb_phase(k);
+                const int it = ((((int)T0 - (8 * k + crow) + ph) & ~7) - ph) + cslot;          // piece 8g - ph + cslot, g = floor((T0 - row + ph) / 8)
                 const uint4 v = wbv[k];
                 if ((u32)(8 * k + crow) < rows_left && it >= 0 && it < (int)wb_iters) {
                     u32x4* dst = reinterpret_cast<u32x4*>(cdst + (int64_t)(8 * k) * a.d_pitch + (int64_t)it * 16);
@@ -849,7 +863,7 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
     };
 
     // trips must reach iteration niter-1 of lane 63; write-back must reach row 63's last group (tile T0 = 8 g_last + 64)
-    const u32 T_end = max(niter + 63, 8 * ((wb_iters - 1) >> 3) + 65);
+    const u32 T_end = max(niter + 63, 8 * ((wb_iters - 1) >> 3) + 65) + (wb_lines ? 0u : 8u);       // (line groups end up to 7 pieces later than row groups)
     u32 my_slot = (u32)(-lane) & (RING - 1);                                               // slot of iteration T - lane, kept incrementally
     u32 polled = 0;                                 // Q: the progress word as loaded one tile ago (a round trip to L2 / the fabric that nobody waits for)
     for (u32 T0 = 0; T0 < T_end; T0 += TT) {
@@ -886,7 +900,7 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
             if (T0 > 0) {
                 // the drop has taken its pieces, the youngest loads: everything this wave ever issued has completed (the wait is free),
                 // so what the tile before this one stored (the groups up to tile T0 - 16) can be published
-                const int done = ((int)T0 - TT - 63) & ~7;
+                const int done = stored_through((int)T0 - 2 * TT);                   // (line-aligned rows: ((T0 - TT - 63) & ~7))
                 if (done > 0) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     publish(min((u32)done, wb_iters));
@@ -995,7 +1009,7 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
             // publish what lane 63 had written back BEFORE this tile (groups below floor((T0 - 63) / 8)): since then this
             // tile issued 8 prefetch loads and 8 row-above loads, so "at most 16 vector-memory operations outstanding" implies
             // those older stores have been acknowledged (the counter retires in order) -- the prefetches in flight are not drained.
-            const int done = ((int)T0 - 63) & ~7;
+            const int done = stored_through((int)T0 - TT);                           // (line-aligned rows: ((T0 - 63) & ~7))
             if (done > 0) {
                 asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                 publish(seq * niter + min((u32)done, wb_iters));
@@ -1547,7 +1561,7 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
     else {
         const int64_t group = 4 * FB;
         a.d_pitch = ((int64_t)wb + group - 1) / group * group;
-        a.d_pitch = (a.d_pitch + 15) / 16 * 16;
+        a.d_pitch = (a.d_pitch + 127) / 128 * 128;             // the scratch is ours: every row on a line of its own (the ring kernels' fast write-back)
         a.d_stride = a.d_pitch * y;
         a.D = (uint8_t*)scratch_get((size_t)a.d_stride * count + 512);
         if (!a.D) return set_error(GAMUT_HIP_ERR_OUT_OF_MEMORY, "png_defilter: scratch allocation failed");
@@ -1585,8 +1599,8 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
         // group: images whose bands are dealt out side by side (band-major inside a group).  The whole batch: band b + 1 of an image is
         // then drawn count draws after band b, by when band b has the ~90 trips of head start band b + 1 needs (groups of 128 of
         // 512 4K images: waves queue up behind their producers, -25 %).  GAMUT_HIP_PNG_GROUP overrides (measurements).
-        const char* group_env = getenv("GAMUT_HIP_PNG_GROUP");
-        const u32 group = group_env && atoi(group_env) > 0 ? (u32)atoi(group_env) : (u32)count;
+        static const int group_env = [] { const char* e = getenv("GAMUT_HIP_PNG_GROUP"); return e && *e ? atoi(e) : 0; }();      // (read once: not a getenv per launch)
+        const u32 group = group_env > 0 ? (u32)group_env : (u32)count;
         const u32 ngroups = ((u32)count + group - 1) / group;
         a.group = ((u32)count + ngroups - 1) / ngroups;              // equal groups
         const unsigned wgs = (unsigned)std::min<uint64_t>((uint64_t)cus, (units + PNG_WAVES - 1) / PNG_WAVES);
@@ -1598,7 +1612,10 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
         // addresses a memory line is fetched by two groups of a row eight trips apart and the second fetch no longer finds it in
         // the L2: loads alone 5.1 ms for 17 GB.  It needs the line-aligned loads of defilter_band_ring<AL> in a form its 8-slot ring
         // can take (chunks into the ring as they lie in memory, the row's alignment undone per lane in registers) -- DESIGN 4.3.
-        const char* roll_env = getenv("GAMUT_HIP_PNG_ROLL");
+        // (No co-residency is assumed by either form: a wave only ever waits for the unit drawn just before its own band-major, and whoever
+        // drew that one is running or done -- units are drawn by waves that are resident, in queue order -- so a grid larger than what fits
+        // runs its surplus workgroups when earlier ones retire, at a loss of time, never of progress.)
+        const char* roll_env = getenv("GAMUT_HIP_PNG_ROLL");                // read per call, like GAMUT_HIP_PNG_QUEUE: the tests flip it inside one process
         const bool roll = !rgba_fused && wb >= 16 && roll_env && atoi(roll_env) != 0;
         if (roll) {
             constexpr int RW = 4;                                       // waves per workgroup: ROLL_WPS workgroups per compute unit

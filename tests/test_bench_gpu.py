@@ -52,6 +52,29 @@ def test_self_launch_two_ranks(hip):
     assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["config"]["images_per_gpu_per_step"] == 7
 
 
+def test_eight_ranks_one_device_no_rccl(hip):
+    """The shape of the driver's 8-GPU run on a 1-GPU box: eight ranks (sharing the device here), control plane over gloo -- the
+    default path creates no RCCL communicator at all (the data path has no collective) -- and EVERY rank checks its own batch."""
+    r = _run([sys.executable, "bench.py", "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "16"])
+    assert KEYS <= set(r) and r["n_gpus"] == 8 and r["cpu_baseline"] is None and r["value"] > 0 and r["scaling"] == "weak"
+    assert "all 16 images == oracle" in r["config"]["parity_check"] and "gather" not in r
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.count('init_process_group("gloo"') == 1 and 'init_process_group("nccl"' not in src, "RCCL only behind --gather (dist.new_group)"
+
+
+def test_two_ranks_carry_the_other_configs(hip):
+    """N > 1: one command yields the "1 vs 8 GPUs" figures of configs 3 / 4 / 5 too -- every rank runs each workload as a sub-run with a
+    rendezvous of its own (small geometry here), rank 0 condenses the lines, a failure on any rank fails the line."""
+    r = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16", "--also-args", "--width 320 --height 200"])
+    sys.path.insert(0, ROOT)
+    import bench
+    assert r["n_gpus"] == 2 and len(r["also"]) == len(bench.ALSO_MULTI)
+    for e in r["also"]:
+        assert "error" not in e and "skipped" not in e and e["parity"].startswith("ok on every rank"), e
+        assert e["n_gpus"] == 2 and e["value"] > 0
+    assert r["also"][-1]["scaling"] == "strong" and r["also"][-1]["images_per_gpu_per_step"] == 4096 and r["also"][0]["scaling"] == "weak"
+
+
 def test_live_traffic_counters(hip):
     """roofline.traffic is measured in the run (rocprofv3 --pmc passes on this very workload), not replayed from a file"""
     r = _run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--batch", "32", "--no-cpu"])
@@ -94,11 +117,11 @@ def test_config3_512_images_of_4k(hip, policy):
     assert r["roofline"]["algorithmic_bytes_per_launch"] == 512 * (2160 * (3840 * 4 + 1) + 3840 * 2160 * 4)
 
 
-@pytest.mark.parametrize("pair", ["rgba16:rgbaf32", "rgbaf32:rgba8", "rgba8:rgba16"])
+@pytest.mark.parametrize("pair", ["rgba16:rgbaf32", "rgbaf32:rgba8", "rgba8:rgba16", "rgbaf32:rgba16", "rgba8:rgbaf32", "rgba16:rgba8"])
 def test_config4_256_layers_in_chunks(hip, pair):
     r = _stated("convert:" + pair, "--batch", "256")
     assert "256 layers of 8192x8192" in r["config"]["workload"]
-    if pair == "rgba16:rgbaf32":
+    if pair in ("rgba16:rgbaf32", "rgbaf32:rgba16"):
         assert "launches" in r["config"]["workload"], "24 bytes per pixel x 256 layers exceed one GPU's HBM: converted in chunks"
 
 

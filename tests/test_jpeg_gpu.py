@@ -945,6 +945,45 @@ def test_dropin_decompress_on_the_input_layer_files(hip):
     assert ("2.0", "150.0") in seen and ("nan", "nan") in seen
 
 
+def test_a_batch_of_nothing_but_host_feeder_files_starts_from_clear_status_words(hip):
+    """a batch in which NO baseline file is the kernels' (here count = 1: a file whose scan header ends in the FF D9 padding behind
+    the file -- prepare_header hands it to the host feeder) never reached the clear of the device status words; the file-level call then folded the
+    caller's uninitialised status_dev into its verdict and turned a file the host feeder had decoded into ERR_DECODE.  status_dev arrives as 0xFF."""
+    d = os.path.join(HERE, "golden", "jpeg_fuzz")
+    data = open(os.path.join(d, "file_ends_inside_its_sos_r05.jpg"), "rb").read()
+    want = O.decompress_jpeg(data, 4)
+    assert want is not None
+    for n in (1, 3):
+        bufs = [np.frombuffer(data, np.uint8)] * n
+        ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs]); lens = (C.c_size_t * n)(*[len(data)] * n)
+        size = want[0].size
+        offs = (np.arange(n) * size).astype(np.int64)
+        dout = dev_upload(hip, np.full(n * size + 16, 0xA5, np.uint8))
+        dst = dev_upload(hip, np.full(4 * n, 0xFF, np.uint8))
+        info = (_capi.JpegFrame * n)(); hst = (C.c_int * n)()
+        rc = hip.gamut_hip_jpeg_decode_batch_device(ptrs, lens, n, 4, offs.ctypes.data_as(C.POINTER(C.c_int64)), dout, info, hst, dst, None)
+        assert rc == 0 and list(hst) == [0] * n, (rc, list(hst), hip.gamut_hip_last_error())
+        out = np.empty(n * size + 16, np.uint8); st = np.empty(n, np.uint32)
+        _capi.check(hip.gamut_hip_memcpy_d2h(out.ctypes.data, dout, out.nbytes, None))
+        _capi.check(hip.gamut_hip_memcpy_d2h(st.ctypes.data, dst, st.nbytes, None))
+        _capi.check(hip.gamut_hip_stream_synchronize(None))
+        hip.gamut_hip_device_free(dout); hip.gamut_hip_device_free(dst)
+        assert not st.any()
+        for k in range(n):
+            assert np.array_equal(out[k * size:(k + 1) * size], want[0].reshape(-1)), k
+    # the coefficient-level entry point: the same file, the caller's status words pre-filled
+    co = dev_upload(hip, np.zeros(36 * 64 * 2 + 64, np.uint8)); zz = dev_upload(hip, np.zeros(64, np.uint8)); dst = dev_upload(hip, np.full(4, 0xFF, np.uint8))
+    buf = np.frombuffer(data, np.uint8)
+    ptrs = (C.c_void_p * 1)(buf.ctypes.data); lens = (C.c_size_t * 1)(len(data))
+    z64 = np.zeros(1, np.int64); info = (_capi.JpegFrame * 1)(); hst = (C.c_int * 1)()
+    rc = hip.gamut_hip_jpeg_entropy_decode_device(ptrs, lens, 1, z64.ctypes.data_as(C.POINTER(C.c_int64)), z64.ctypes.data_as(C.POINTER(C.c_int64)), co, zz, dst, info, hst, None)
+    st = np.empty(1, np.uint32)
+    _capi.check(hip.gamut_hip_memcpy_d2h(st.ctypes.data, dst, 4, None)); _capi.check(hip.gamut_hip_stream_synchronize(None))
+    for q in (co, zz, dst):
+        hip.gamut_hip_device_free(q)
+    assert rc == 0 and hst[0] == 0 and st[0] == 0, (rc, hst[0], st[0])
+
+
 def test_files_to_pixels_with_an_odd_output_offset(hip):
     """the token hand-off stores rgba8 pixels as dwords; an image whose output is not dword-aligned must take the dense hand-off (whose launch
     falls back to the byte-wise kernel) instead of failing the whole call."""

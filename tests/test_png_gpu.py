@@ -98,6 +98,27 @@ def test_defilter_formats_filters_sizes(hip, launch_mode, img_n, depth, color):
                 assert np.array_equal(got, exp), f"n={img_n} d={depth} {x}x{y} out_n={out_n} filters={np.unique(filt)}: {np.count_nonzero(got != exp)} bytes differ"
 
 
+@pytest.mark.parametrize("x,y", [(1004, 131), (962, 200), (1001, 70), (3848, 130)])
+def test_rows_off_the_memory_lines(hip, launch_mode, x, y):
+    """tight RGBA8 / RGB8 rows of widths that are no multiple of 32 pixels: the rows start anywhere in a 128-byte line (pitches 4016 / 3848 / 4004 /
+    15392 bytes) and the write-back groups are the lines of memory, not the row's own pieces (png.hip: wb_lines) -- several bands (the hand-off
+    publishes what the LINE groups have stored), several images at a stride that moves every image's first line, every filter mix."""
+    rng = np.random.default_rng(x + y)
+    for img_n, out_n, color in ((4, 4, 6), (3, 4, 2), (3, 3, 2)):
+        n = 3
+        px = [(np.cumsum(rng.integers(-3, 4, (y, x * img_n)), axis=1) + rng.integers(0, 256, (y, 1))) % 256 for _ in range(n)]
+        for filt in (rng.integers(0, 5, y).astype(np.uint8), np.full(y, 4, np.uint8), gen.png_heuristic_filters(px[0], img_n)):
+            stride = (x * img_n + 1) * y + 3
+            raws = np.zeros(n * stride, np.uint8); exps = []
+            for i in range(n):
+                r = gen.png_forward_filter(px[i], img_n, filt)
+                raws[i * stride:i * stride + r.size] = r
+                exps.append(O.png_create_image_raw(r, img_n, out_n, x, y, 8, color))
+            got = gpu_defilter(hip, raws, x, y, img_n, out_n, 8, color, count=n, raw_stride=stride)
+            for i in range(n):
+                assert np.array_equal(got[i], exps[i]), (x, y, img_n, out_n, i, np.unique(filt), int(np.count_nonzero(got[i] != exps[i])))
+
+
 def test_config3_geometry_roundtrip(hip):
     """3840x2160 RGBA8 (BASELINE.json config 3): forward-filter -> GPU de-filter gives the pixels back; both filter policies."""
     w, h = 3840, 2160

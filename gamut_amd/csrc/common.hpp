@@ -214,7 +214,7 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
                         uint8_t* out, int64_t out_stride,
                         uint32_t x, uint32_t y, int img_n, int out_n, int depth, int color,
                         int count, uint32_t* status, hipStream_t stream,
-                        const int64_t* raw_offs = nullptr, const int64_t* out_offs = nullptr, bool offs_dword_aligned = false);
+                        const int64_t* raw_offs = nullptr, const int64_t* out_offs = nullptr, bool offs_dword_aligned = false, bool offs_line_aligned = false);
 
 int png_transparency_launch(void* img, int64_t npx, int out_n, int depth16, const uint16_t tc[3], hipStream_t st);
 int png_palette_launch(const uint8_t* idx, uint8_t* out, int64_t npx, int pal_n, const uint8_t* palette_dev, hipStream_t st);

@@ -528,7 +528,7 @@ constexpr int ROW_PITCH = RING * 16;              // 256 B: lane j's slot (T - j
 // chunks behind the row's phase P) waits in the lanes' registers for the next drop: every line is read exactly once, nothing else
 // changes -- pieces, DPP hand-over, write-back are those of the row-aligned grid.  The ring must start out zero (a row's first
 // pieces are no longer all written by drops).
-template <int FB, int W, bool PAETH, bool RGBA, bool Q = false, bool AL = false>
+template <int FB, int W, bool PAETH, bool RGBA, bool Q = false, bool AL = false, bool LN = true>
 __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const uint8_t* raw, uint8_t* D, u32* prog, uint8_t* ring, u32 band,
                                                int wave, int lane, u32 niter, u32 f, bool row_live, u32* status = nullptr)
 {
@@ -559,7 +559,9 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
     // apart -- 512 x 3848 x 2160 took 12 ms where 3840 takes 6 (profiles/r06_png_width_probe.txt).  The groups of such rows are the LINES of
     // memory instead: a row whose first byte is ph pieces into its line writes back pieces 8 g - ph .. 8 g - ph + 7 (wave-uniform switch;
     // the generic forms only -- the fast forms keep their per-lane constants for line-aligned rows).
-    const bool wb_lines = ((reinterpret_cast<uintptr_t>(D) | (uintptr_t)(uint64_t)a.d_pitch) & 127u) == 0;
+    // LN (the launcher's verdict: every row of every image of the batch starts on a line) makes it a constant: the line-aligned kernels are
+    // compiled exactly as before (with the test at run time in the one kernel the Paeth bands spilled 25 registers instead of 17: 7.51 -> 7.77 ms).
+    const bool wb_lines = LN || ((reinterpret_cast<uintptr_t>(D) | (uintptr_t)(uint64_t)a.d_pitch) & 127u) == 0;
 
     // cooperative mapping: in transfer k (0..7) this lane handles row 8k + crow, piece cslot of that row's 8
     const int crow = lane >> 3, cslot = lane & 7;
@@ -1022,7 +1024,7 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
     publish(seq * niter + niter);
 }
 
-template <int FB, int W, int MINW, bool RGBA = false, bool AL = false>
+template <int FB, int W, int MINW, bool RGBA = false, bool AL = false, bool LN = true>
 __global__ __launch_bounds__(W * 64, MINW) void k_png_defilter_ring(DefilterArgs a)
 {
     __shared__ u32 prog[W];
@@ -1040,8 +1042,8 @@ __global__ __launch_bounds__(W * 64, MINW) void k_png_defilter_ring(DefilterArgs
         const bool row_live = row < a.rows;
         u32 f = row_live ? raw[(int64_t)row * (a.wb + 1)] : 0;
         if (f > 4) { if (a.status) atomicOr(a.status + img, 1u); f = 0; }
-        if (__any(f == 4)) defilter_band_ring<FB, W, true,  RGBA, false, AL && PNG_AL_PAETH>(a, raw, D, prog, tiles[wave], band, wave, lane, niter, f, row_live);
-        else               defilter_band_ring<FB, W, false, RGBA, false, AL>(a, raw, D, prog, tiles[wave], band, wave, lane, niter, f, row_live);
+        if (__any(f == 4)) defilter_band_ring<FB, W, true,  RGBA, false, AL && PNG_AL_PAETH, LN>(a, raw, D, prog, tiles[wave], band, wave, lane, niter, f, row_live);
+        else               defilter_band_ring<FB, W, false, RGBA, false, AL, LN>(a, raw, D, prog, tiles[wave], band, wave, lane, niter, f, row_live);
     }
 }
 
@@ -1055,7 +1057,7 @@ __global__ __launch_bounds__(W * 64, MINW) void k_png_defilter_ring(DefilterArgs
 // oldest unit in flight never waits, so the queue cannot deadlock whatever the number of resident workgroups -- and by the time
 // a wave draws (i, b) the band above it has usually had the ~80 trips of head start it needs (lane 63 of a band runs 63 pieces
 // behind its lane 0), so waves rarely sit waiting.
-template <int FB, int W, int MINW, bool RGBA = false, bool AL = false>
+template <int FB, int W, int MINW, bool RGBA = false, bool AL = false, bool LN = true>
 __global__ __launch_bounds__(W * 64, MINW) void k_png_defilter_queue(DefilterArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tiles[W][64 * (AL ? ROW_PITCH + 32 : ROW_PITCH) + 128];      // a wave's ring + 128 bytes of the row above its band
@@ -1080,8 +1082,8 @@ __global__ __launch_bounds__(W * 64, MINW) void k_png_defilter_queue(DefilterArg
         u32 f = row_live ? raw[(int64_t)row * (a.wb + 1)] : 0;
         if (f > 4) { if (a.status) atomicOr(a.status + img, 1u); f = 0; }
         u32* st = a.status ? a.status + img : nullptr;
-        if (__any(f == 4)) defilter_band_ring<FB, W, true,  RGBA, true, AL && PNG_AL_PAETH>(a, raw, D, prog, tiles[wave], band, wave, lane, niter, f, row_live, st);
-        else               defilter_band_ring<FB, W, false, RGBA, true, AL>(a, raw, D, prog, tiles[wave], band, wave, lane, niter, f, row_live, st);
+        if (__any(f == 4)) defilter_band_ring<FB, W, true,  RGBA, true, AL && PNG_AL_PAETH, LN>(a, raw, D, prog, tiles[wave], band, wave, lane, niter, f, row_live, st);
+        else               defilter_band_ring<FB, W, false, RGBA, true, AL, LN>(a, raw, D, prog, tiles[wave], band, wave, lane, niter, f, row_live, st);
     }
 }
 
@@ -1511,7 +1513,7 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
                          uint8_t* out, int64_t out_stride,
                          uint32_t x, uint32_t y, int img_n, int out_n, int depth, int color,
                          int count, uint32_t* status, hipStream_t stream,
-                         const int64_t* raw_offs, const int64_t* out_offs, bool offs_dword_aligned)
+                         const int64_t* raw_offs, const int64_t* out_offs, bool offs_dword_aligned, bool offs_line_aligned)
 {
     // validation as in stbi__create_png_image_raw (stbdec.d:1419-1430, 1441-1442) and parse_png_file (:1890-1906)
     if (depth != 1 && depth != 2 && depth != 4 && depth != 8 && depth != 16)
@@ -1586,6 +1588,9 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
     // line-aligned loads of the stream (defilter_band_ring<..., AL>): rows of at least two lines; GAMUT_HIP_PNG_ALIGNED=0 / 1 forces either
     const char* al_env = getenv("GAMUT_HIP_PNG_ALIGNED");
     const bool aligned = !rgba_fused && wb >= 16 && (al_env && *al_env ? atoi(al_env) != 0 : wb >= 256);
+    // every row of every image on a 128-byte line of its own?  (the kernels' LN: write-back groups = the rows' own pieces; otherwise the
+    // kernels that look at every image's rows and write back by the lines of memory -- defilter_band_ring, wb_lines)
+    const bool lines = ((uintptr_t)a.D % 128) == 0 && (a.d_pitch % 128) == 0 && (a.d_offs ? offs_line_aligned : (count == 1 || a.d_stride % 128 == 0));
     const char* queue_env = getenv("GAMUT_HIP_PNG_QUEUE");       // read per call: tests flip it
     const uint64_t units = (uint64_t)count * nbands;
     bool queue = wb >= 16 && (int64_t)a.d_pitch * 64 < (1ll << 31) && units < (1ull << 31) &&
@@ -1627,10 +1632,13 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
             default: return set_error(GAMUT_HIP_ERR_INVALID_ARG, "png_defilter: unsupported filter unit %d", FB);
             }
         } else
-        if (rgba_fused) hipLaunchKernelGGL((k_png_defilter_queue<3, PNG_WAVES, 2, true>), qgrid, qblock, 0, stream, a);
+        if (rgba_fused) { if (lines) hipLaunchKernelGGL((k_png_defilter_queue<3, PNG_WAVES, 2, true>), qgrid, qblock, 0, stream, a);
+                          else       hipLaunchKernelGGL((k_png_defilter_queue<3, PNG_WAVES, 2, true, false, false>), qgrid, qblock, 0, stream, a); }
         else switch (FB) {
-#define GAMUT_PNG_CASE(N) case N: if (aligned) hipLaunchKernelGGL((k_png_defilter_queue<N, PNG_WAVES, 2, false, true>), qgrid, qblock, 0, stream, a); \
-                                  else         hipLaunchKernelGGL((k_png_defilter_queue<N, PNG_WAVES, 2>), qgrid, qblock, 0, stream, a); break;
+#define GAMUT_PNG_CASE(N) case N: if (aligned && lines) hipLaunchKernelGGL((k_png_defilter_queue<N, PNG_WAVES, 2, false, true>), qgrid, qblock, 0, stream, a); \
+                                  else if (aligned)     hipLaunchKernelGGL((k_png_defilter_queue<N, PNG_WAVES, 2, false, true, false>), qgrid, qblock, 0, stream, a); \
+                                  else if (lines)       hipLaunchKernelGGL((k_png_defilter_queue<N, PNG_WAVES, 2>), qgrid, qblock, 0, stream, a); \
+                                  else                  hipLaunchKernelGGL((k_png_defilter_queue<N, PNG_WAVES, 2, false, false, false>), qgrid, qblock, 0, stream, a); break;
         GAMUT_PNG_CASE(1) GAMUT_PNG_CASE(2) GAMUT_PNG_CASE(3) GAMUT_PNG_CASE(4) GAMUT_PNG_CASE(6) GAMUT_PNG_CASE(8)
 #undef GAMUT_PNG_CASE
         default: return set_error(GAMUT_HIP_ERR_INVALID_ARG, "png_defilter: unsupported filter unit %d", FB);
@@ -1642,10 +1650,13 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
     // budget left unconstrained (no spills: measured faster than 128-VGPR variants that spill).  Narrower rows: the
     // per-lane kernel.
     const bool ring = wb >= 16;
-    if (rgba_fused) hipLaunchKernelGGL((k_png_defilter_ring<3, PNG_WAVES, 2, true>), grid, block, 0, stream, a);
+    if (rgba_fused) { if (lines) hipLaunchKernelGGL((k_png_defilter_ring<3, PNG_WAVES, 2, true>), grid, block, 0, stream, a);
+                      else       hipLaunchKernelGGL((k_png_defilter_ring<3, PNG_WAVES, 2, true, false, false>), grid, block, 0, stream, a); }
     else switch (FB) {
-#define GAMUT_PNG_CASE(N) case N: if (ring && aligned) hipLaunchKernelGGL((k_png_defilter_ring<N, PNG_WAVES, 2, false, true>), grid, block, 0, stream, a); \
-                                  else if (ring) hipLaunchKernelGGL((k_png_defilter_ring<N, PNG_WAVES, 2>), grid, block, 0, stream, a); \
+#define GAMUT_PNG_CASE(N) case N: if (ring && aligned && lines) hipLaunchKernelGGL((k_png_defilter_ring<N, PNG_WAVES, 2, false, true>), grid, block, 0, stream, a); \
+                                  else if (ring && aligned) hipLaunchKernelGGL((k_png_defilter_ring<N, PNG_WAVES, 2, false, true, false>), grid, block, 0, stream, a); \
+                                  else if (ring && lines) hipLaunchKernelGGL((k_png_defilter_ring<N, PNG_WAVES, 2>), grid, block, 0, stream, a); \
+                                  else if (ring) hipLaunchKernelGGL((k_png_defilter_ring<N, PNG_WAVES, 2, false, false, false>), grid, block, 0, stream, a); \
                                   else      hipLaunchKernelGGL((k_png_defilter<N, PNG_WAVES>), grid, block, 0, stream, a); break;
     GAMUT_PNG_CASE(1) GAMUT_PNG_CASE(2) GAMUT_PNG_CASE(3) GAMUT_PNG_CASE(4) GAMUT_PNG_CASE(6) GAMUT_PNG_CASE(8)
 #undef GAMUT_PNG_CASE

@@ -683,13 +683,14 @@ int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* 
 
         // 2. one de-filter launch per geometry
         std::map<std::tuple<uint32_t, uint32_t, int, int, int, int>, std::vector<int>> groups;
-        bool aligned = ((uintptr_t)out % 4) == 0;
+        bool aligned = ((uintptr_t)out % 4) == 0, lines = ((uintptr_t)out % 128) == 0;       // every image on a dword / on a 128-byte line of memory
         int n_batched = 0;
         for (int i = 0; i < count; ++i) {
             const BatchFile& f = files[(size_t)i];
             if (!f.batched) continue;
             groups[std::make_tuple(f.h.x, f.h.y, f.h.img_n, f.out_n, f.h.depth, f.h.color)].push_back(i);
             aligned = aligned && (out_offset[i] % 4) == 0;
+            lines = lines && (out_offset[i] % 128) == 0;
             ++n_batched;
         }
         std::vector<uint32_t> status((size_t)n_batched, 0);
@@ -711,7 +712,7 @@ int gamut_hip_png_decode_batch_device(const uint8_t* const* data, const size_t* 
                 const int n = (int)g.second.size();
                 const int rc = png_defilter_launch(d_arena, 0, f.need, out, 0, f.h.x, f.h.y, f.h.img_n, f.out_n, f.h.depth, f.h.color, n,
                                                    (uint32_t*)(d_tab + o_status) + base, st,
-                                                   (const int64_t*)d_tab + base, (const int64_t*)d_tab + n_batched + base, aligned);
+                                                   (const int64_t*)d_tab + base, (const int64_t*)d_tab + n_batched + base, aligned, lines);
                 if (rc != GAMUT_HIP_OK && launch_rc == GAMUT_HIP_OK) {
                     launch_rc = rc;
                     for (int i : g.second) { files[(size_t)i].rc = rc; snprintf(files[(size_t)i].msg, sizeof(files[(size_t)i].msg), "image %d: %s", i, last_error_buf()); }

@@ -687,6 +687,15 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # Untimed, in front of the W warm-up steps: the GPU has idled through the parity check (seconds of host work) and its clocks come back
+    # over the first tens of milliseconds of load -- with a 3 ms step the first dozen launches ran up to 40 % slow
+    # (profiles/r06_step_ms.txt).  Steps until 150 ms of load have passed (at most 100), none of them counted or timed.
+    t_pre = time.perf_counter()
+    for _ in range(100):
+        step()
+        torch.cuda.synchronize()
+        if time.perf_counter() - t_pre > 0.15:
+            break
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -702,6 +711,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kern_ms = [a.elapsed_time(b) for a, b in evs]
+    if os.environ.get("GAMUT_BENCH_STEP_MS") and rank == 0:        # every timed step on stderr (looking for slow steps among fast ones)
+        print("[bench] step ms: " + " ".join(f"{x:.3f}" for x in kern_ms), file=sys.stderr)
 
     gather = None
     if world > 1:

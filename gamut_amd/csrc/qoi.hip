@@ -76,6 +76,21 @@ __device__ __forceinline__ uint32_t qoi_map_then(uint32_t a, uint32_t b)        
     return r;
 }
 template <int CTRL, int ROWMASK> __device__ __forceinline__ void qoi_map_scan_step(uint32_t& m) { m = qoi_map_then(qoi_dpp<CTRL, ROWMASK>(m, kQoiMapId), m); }
+// The inclusive scan of `then` over the lanes of a wave (lanes 0 .. this one, composed).  Composing two 15-bit maps is five dependent
+// extract-shift-extract chains, ~25 instructions, six times per window; with a map held as BYTES (entries 0..3 in one register, entry 4 in
+// another) it is a table look-up the hardware has: v_perm_b32 picks, per selector byte 0..7, a byte of its two sources -- `a then b` is
+// perm({b4, b3 b2 b1 b0}, selectors = a's bytes): two permutes per step.  (Bytes 1-3 of the second register carry whatever the look-up puts
+// there -- always some entry of a map, 0..4: valid selectors, never read as an entry.)
+__device__ __forceinline__ void qoi_map_scan64(uint32_t& map)
+{
+    uint32_t lo = (map & 7u) | (map >> 3 & 7u) << 8 | (map >> 6 & 7u) << 16 | (map >> 9 & 7u) << 24, hi = map >> 12 & 7u;
+#define GAMUT_QOI_MAP_STEP(CTRL, ROWMASK) { const uint32_t pl = qoi_dpp<CTRL, ROWMASK>(lo, 0x03020100u), ph = qoi_dpp<CTRL, ROWMASK>(hi, 4u); \
+                                            const uint32_t nl = __builtin_amdgcn_perm(hi, lo, pl), nh = __builtin_amdgcn_perm(hi, lo, ph); lo = nl; hi = nh; }
+    GAMUT_QOI_MAP_STEP(0x111, 0xF) GAMUT_QOI_MAP_STEP(0x112, 0xF) GAMUT_QOI_MAP_STEP(0x114, 0xF) GAMUT_QOI_MAP_STEP(0x118, 0xF)
+    GAMUT_QOI_MAP_STEP(0x142, 0xA) GAMUT_QOI_MAP_STEP(0x143, 0xC)
+#undef GAMUT_QOI_MAP_STEP
+    map = (lo & 7u) | (lo >> 8 & 7u) << 3 | (lo >> 16 & 7u) << 6 | (lo >> 24 & 7u) << 9 | (hi & 7u) << 12;
+}
 // n += the lane CTRL names (nothing for lanes without a source, or in rows outside ROWMASK): one v_add_u32_dpp in place.  Through
 // the builtin the compiler zeroes a temporary, moves into it and adds: three instructions, six times per scan.  (s_nop 1: a DPP
 // read of a register the previous vector instruction wrote needs two wait states, and the compiler does not look into asm.)
@@ -142,6 +157,9 @@ __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* it
     // selects per op; entry 256 = no op (a lane past the window's last op).  (8 bytes, not M and U spelled out in 16: with 14.3 KB
     // of LDS per stream a CU holds 10 streams, 2560 in all, and config 5's 2730 took a second round: 44.5 -> 61 ms.)
     __shared__ uint2 lut[257];
+    // W = 1: 5 * (op length - 1) by the op's first byte (0 / 5 / 15 / 20), for the boundary walk below -- 256 bytes = one row of the 64 banks:
+    // a wave's 64 byte reads never conflict
+    __shared__ __attribute__((aligned(256))) uint8_t sh5tab[kQoiWaves == 1 ? 256 : 4];
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     struct __attribute__((packed, aligned(1))) AnyVec { u32x4 v; };               // 16 bytes at any address
     struct __attribute__((packed, aligned(1))) AnyU32 { uint32_t v; };
@@ -174,6 +192,9 @@ __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* it
               ((!none && (is_rgb || is_rgba)) ? 1u << 9 : 0u) | ((!none && is_rgb) ? 1u << 10 : 0u) | ((!none && (is_rgba || top == 0u)) ? 1u << 11 : 0u);
         lut[b1] = e;
     }
+    if constexpr (kQoiWaves == 1)
+        for (uint32_t b1 = (uint32_t)t; b1 < 256u; b1 += (uint32_t)kQoiT)
+            sh5tab[b1] = (uint8_t)(5u * ((b1 >= 0xFEu ? b1 - 0xFAu : ((b1 >> 6) == 2u ? 2u : 1u)) - 1u));
     uint32_t carry = 0xFF000000u;                             // r = g = b = 0, a = 255 :492-495                (wave 0's state from here ...)
     uint32_t produced = 0, ops_done = 0;                      // pixels decoded, ops decoded
     uint32_t fill = 0; size_t flushed = 0;                    // pixels waiting in obuf, pixels already in the image
@@ -227,6 +248,32 @@ __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* it
         if (t == 0) { win[kQoiWin / 4] = (uint32_t)dtail; win[kQoiWin / 4 + 1] = (uint32_t)(dtail >> 32); }
         // ---- A. op starts among this lane's 8 bytes, for entry offsets 0..4 (bit i of s[e]: an op starts at byte i)
         Starts s[5] = { 1, 2, 4, 8, 16 };
+        uint32_t map = 0;                                     // entry offset e -> offset of the first op start in the next lane's bytes
+        uint32_t rec[6] = { 0, 0, 0, 0, 0, 0 };
+        if constexpr (kQoiLaneBytes == 32) {
+            // One wave per stream, 32 bytes per lane: five 64-bit bit sets walked side by side cost 30 vector instructions per byte (a
+            // variable 64-bit shift and two halves to OR per set) -- 800 per window and lane, a fifth of everything the kernel does (round
+            // 6, from the ISA: a batch's time is its instruction count).  The same walk turned round: ONE register holds, for the next
+            // five byte positions, WHICH of the five entry offsets have an op starting there (5 slots x 5 bits).  Per byte: the set for
+            // this position (`cur`) is recorded (position i -> bits 5 (i mod 6) .. + 4 of rec[i / 6]), the window slides by one slot and
+            // `cur` is added to the slot of position i + length -- five instructions and one byte read from the 256-byte table, whatever
+            // the number of entry offsets.  What is pending after the last byte is the exit map; the true entry's starts are picked out
+            // of the record once the scan over the lanes has said which entry is true (below).
+            uint32_t w = 0x01041041u;                         // slot e = { e }: with entry offset e the first op starts at byte e
+            #pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const uint32_t b = (uint32_t)(dmine.q[i >> 3] >> (8 * (i & 7))) & 255u;
+                const uint32_t sh = sh5tab[b];
+                const uint32_t cur = w & 31u;
+                rec[i / 6] |= cur << (5 * (i % 6));
+                w = (w >> 5) | (cur << sh);
+            }
+            #pragma unroll
+            for (int e = 0; e < 5; ++e) {                     // entry e's chain is pending in exactly one slot k (its first start at or behind byte 32): bit 5 k + e
+                const uint32_t at = (uint32_t)__builtin_ctz(w & (0x00108421u << e)) - (uint32_t)e;      // 5 k
+                map |= ((at * 13u) >> 6) << (3 * e);          // k = at / 5 for at = 0, 5, ... 20
+            }
+        } else {
         #pragma unroll
         for (int i = 0; i < kQoiLaneBytes; ++i) {
             const uint32_t b = (uint32_t)(dmine.q[i >> 3] >> (8 * (i & 7))) & 255u;
@@ -234,12 +281,11 @@ __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* it
             #pragma unroll
             for (int e = 0; e < 5; ++e) s[e] |= (s[e] & ((Starts)1 << i)) << len;
         }
-        uint32_t map = 0;                                     // entry offset e -> offset of the first op start in the next lane's bytes
         #pragma unroll
         for (int e = 0; e < 5; ++e) map |= (uint32_t)__builtin_ctz((uint32_t)(s[e] >> kQoiLaneBytes)) << (3 * e);
+        }
         fetch(pos + kQoiWin, dmine, dtail);
-        qoi_map_scan_step<0x111, 0xF>(map); qoi_map_scan_step<0x112, 0xF>(map); qoi_map_scan_step<0x114, 0xF>(map); qoi_map_scan_step<0x118, 0xF>(map);
-        qoi_map_scan_step<0x142, 0xA>(map); qoi_map_scan_step<0x143, 0xC>(map);                 // lanes 0 .. this one, composed
+        qoi_map_scan64(map);                                  // lanes 0 .. this one, composed
         if (lane == 63) wave_map[wave] = map;
         QPROF(0);
         __syncthreads();
@@ -252,7 +298,19 @@ __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* it
             entry = after;                                    // (after the loop: the next window's entry offset)
         }
         const uint32_t my_entry = qoi_map_apply(qoi_dpp<0x138, 0xF>(map, kQoiMapId), wave_entry);
-        uint32_t starts = (uint32_t)(my_entry == 0 ? s[0] : my_entry == 1 ? s[1] : my_entry == 2 ? s[2] : my_entry == 3 ? s[3] : s[4]);
+        uint32_t starts;
+        if constexpr (kQoiLaneBytes == 32) {
+            // the true entry's bits of the record (5 k + e in every register, k = 0..5), squeezed to one bit per byte: three bits at a time by a
+            // multiplication whose cross terms fall outside the field (x = b0 | b5 | b10: x * 0x111 has b0, b5, b10 at bits 8, 9, 10)
+            starts = 0;
+            #pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const uint32_t x = rec[j] >> my_entry;
+                const uint32_t lo3 = (((x & 0x421u) * 0x111u) >> 8) & 7u, hi3 = ((((x >> 15) & 0x421u) * 0x111u) >> 8) & 7u;
+                starts |= (lo3 | hi3 << 3) << (6 * j);        // (j = 5: positions 30, 31 -- the rest of the register was never written)
+            }
+        } else
+        starts = (uint32_t)(my_entry == 0 ? s[0] : my_entry == 1 ? s[1] : my_entry == 2 ? s[2] : my_entry == 3 ? s[3] : s[4]);
         {
             const int room = chunk_bytes - (pos + t * kQoiLaneBytes);                // op starts only in this lane's bytes and below chunks_len
             const int n = room < kQoiLaneBytes ? room : kQoiLaneBytes;
@@ -582,8 +640,7 @@ __global__ __launch_bounds__(320) void k_qoi_pipe(const QoiItem* items, int n_it
         #pragma unroll
         for (int e = 0; e < 5; ++e) map |= (uint32_t)__builtin_ctz(s[e] >> kLaneBytes) << (3 * e);
         fetch(pos + kQoiWin, dmine, dtail);
-        qoi_map_scan_step<0x111, 0xF>(map); qoi_map_scan_step<0x112, 0xF>(map); qoi_map_scan_step<0x114, 0xF>(map); qoi_map_scan_step<0x118, 0xF>(map);
-        qoi_map_scan_step<0x142, 0xA>(map); qoi_map_scan_step<0x143, 0xC>(map);
+        qoi_map_scan64(map);
         if (lane == 63) wave_map[pwave] = map;
         qoi_producers_meet(&f_meet, meet, lane);
         uint32_t wave_entry = entry;

@@ -149,6 +149,7 @@ ALSO = [  # the other BASELINE.json configs at their stated shapes, each through
     ("config 4: rgba8 -> rgbaf32 (scanline.d:428-443), 256 layers", "convert:rgba8:rgbaf32", ["--batch", "256"]),
     ("config 4: rgba16 -> rgba8 (through the rgbaf32 intermediate, scanline.d:25-31 / image.d:1238-1241), 256 layers", "convert:rgba16:rgba8", ["--batch", "256"]),
     ("config 5 at its stated size on this GPU: 8192 mixed 1080p images", "mixed", ["--total-images", "8192"]),
+    ("config 5, one GPU's share of the 8-GPU run: 1024 mixed images (342 JPEG + 341 PNG + 341 QOI: the four-wave QOI kernel)", "mixed", []),
 ]
 
 

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* it
     __shared__ uint2 lut[257];
     // W = 1: 5 * (op length - 1) by the op's first byte (0 / 5 / 15 / 20), for the boundary walk below -- 256 bytes = one row of the 64 banks:
     // a wave's 64 byte reads never conflict
-    __shared__ __attribute__((aligned(256))) uint8_t sh5tab[kQoiWaves == 1 ? 256 : 4];
+    __shared__ __attribute__((aligned(256))) uint8_t sh5tab[256];
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     struct __attribute__((packed, aligned(1))) AnyVec { u32x4 v; };               // 16 bytes at any address
     struct __attribute__((packed, aligned(1))) AnyU32 { uint32_t v; };
@@ -192,8 +192,7 @@ __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* it
               ((!none && (is_rgb || is_rgba)) ? 1u << 9 : 0u) | ((!none && is_rgb) ? 1u << 10 : 0u) | ((!none && (is_rgba || top == 0u)) ? 1u << 11 : 0u);
         lut[b1] = e;
     }
-    if constexpr (kQoiWaves == 1)
-        for (uint32_t b1 = (uint32_t)t; b1 < 256u; b1 += (uint32_t)kQoiT)
+    for (uint32_t b1 = (uint32_t)t; b1 < 256u; b1 += (uint32_t)kQoiT)
             sh5tab[b1] = (uint8_t)(5u * ((b1 >= 0xFEu ? b1 - 0xFAu : ((b1 >> 6) == 2u ? 2u : 1u)) - 1u));
     uint32_t carry = 0xFF000000u;                             // r = g = b = 0, a = 255 :492-495                (wave 0's state from here ...)
     uint32_t produced = 0, ops_done = 0;                      // pixels decoded, ops decoded
@@ -249,8 +248,9 @@ __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* it
         // ---- A. op starts among this lane's 8 bytes, for entry offsets 0..4 (bit i of s[e]: an op starts at byte i)
         Starts s[5] = { 1, 2, 4, 8, 16 };
         uint32_t map = 0;                                     // entry offset e -> offset of the first op start in the next lane's bytes
-        uint32_t rec[6] = { 0, 0, 0, 0, 0, 0 };
-        if constexpr (kQoiLaneBytes == 32) {
+        constexpr int kRec = (kQoiLaneBytes + 5) / 6;         // six byte positions per record register
+        uint32_t rec[kRec] = {};
+        if constexpr (true) {
             // One wave per stream, 32 bytes per lane: five 64-bit bit sets walked side by side cost 30 vector instructions per byte (a
             // variable 64-bit shift and two halves to OR per set) -- 800 per window and lane, a fifth of everything the kernel does (round
             // 6, from the ISA: a batch's time is its instruction count).  The same walk turned round: ONE register holds, for the next
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* it
             // of the record once the scan over the lanes has said which entry is true (below).
             uint32_t w = 0x01041041u;                         // slot e = { e }: with entry offset e the first op starts at byte e
             #pragma unroll
-            for (int i = 0; i < 32; ++i) {
+            for (int i = 0; i < kQoiLaneBytes; ++i) {
                 const uint32_t b = (uint32_t)(dmine.q[i >> 3] >> (8 * (i & 7))) & 255u;
                 const uint32_t sh = sh5tab[b];
                 const uint32_t cur = w & 31u;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* it
                 w = (w >> 5) | (cur << sh);
             }
             #pragma unroll
-            for (int e = 0; e < 5; ++e) {                     // entry e's chain is pending in exactly one slot k (its first start at or behind byte 32): bit 5 k + e
+            for (int e = 0; e < 5; ++e) {                     // entry e's chain is pending in exactly one slot k (its first start at or behind the lane's last byte): bit 5 k + e
                 const uint32_t at = (uint32_t)__builtin_ctz(w & (0x00108421u << e)) - (uint32_t)e;      // 5 k
                 map |= ((at * 13u) >> 6) << (3 * e);          // k = at / 5 for at = 0, 5, ... 20
             }
@@ -299,15 +299,15 @@ __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* it
         }
         const uint32_t my_entry = qoi_map_apply(qoi_dpp<0x138, 0xF>(map, kQoiMapId), wave_entry);
         uint32_t starts;
-        if constexpr (kQoiLaneBytes == 32) {
+        if constexpr (true) {
             // the true entry's bits of the record (5 k + e in every register, k = 0..5), squeezed to one bit per byte: three bits at a time by a
             // multiplication whose cross terms fall outside the field (x = b0 | b5 | b10: x * 0x111 has b0, b5, b10 at bits 8, 9, 10)
             starts = 0;
             #pragma unroll
-            for (int j = 0; j < 6; ++j) {
+            for (int j = 0; j < kRec; ++j) {
                 const uint32_t x = rec[j] >> my_entry;
                 const uint32_t lo3 = (((x & 0x421u) * 0x111u) >> 8) & 7u, hi3 = ((((x >> 15) & 0x421u) * 0x111u) >> 8) & 7u;
-                starts |= (lo3 | hi3 << 3) << (6 * j);        // (j = 5: positions 30, 31 -- the rest of the register was never written)
+                starts |= (lo3 | hi3 << 3) << (6 * j);        // (the last register holds 2 positions -- the rest of it was never written)
             }
         } else
         starts = (uint32_t)(my_entry == 0 ? s[0] : my_entry == 1 ? s[1] : my_entry == 2 ? s[2] : my_entry == 3 ? s[3] : s[4]);

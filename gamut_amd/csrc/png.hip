@@ -578,12 +578,6 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
         return wb_lines ? 0 : (int)(((reinterpret_cast<uintptr_t>(cdst) + (uintptr_t)((int64_t)(8 * k) * a.d_pitch)) >> 4) & 7u);
     };
     const int ph63 = wb_lines ? 0 : (int)(((reinterpret_cast<uintptr_t>(D) + (uintptr_t)((int64_t)(band * 64 + 63) * a.d_pitch)) >> 4) & 7u);
-    u32 phpack = 0;                                                       // the eight transfers' phases of this lane's rows, 3 bits each: constants of the band
-    if (!wb_lines) {
-        #pragma unroll
-        for (int k = 0; k < 8; ++k) phpack |= (u32)wb_phase(k) << (3 * k);
-    }
-    auto ph_of = [&](int k) -> int { return (int)((phpack >> (3 * k)) & 7u); };
     // pieces of the band's last row that the write-backs up to tile T0s have stored (what a hand-off may publish once they have arrived)
     auto stored_through = [&](int T0s) -> int { return (((T0s - 63 + ph63) & ~7) - ph63) + 8; };
     uint8_t* my_ring = ring + lane * PITCH + GUARD;
@@ -830,7 +824,7 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
         } else {
             #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const int ph = ph_of(k);
+                const int ph = wb_phase(k);
                 const int it = ((((int)T0 - (8 * k + crow) + ph) & ~7) - ph) + cslot;
                 wbv[k] = *reinterpret_cast<const uint4*>(co_ring + k * 8 * PITCH + ((u32)it & (RING - 1)) * 16);
             }
@@ -855,20 +849,11 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
                 else               *dst = u32x4{ v.x, v.y, v.z, v.w };
             }
         } else {
-            // rows off the memory lines, the tiles in between (64 live rows, every row's line group inside its row: pieces T0 - row - 7 .. T0 - row + 7):
-            // no predicates, the address a 32-bit offset behind the band's first row
-            const bool mid = !wb_lines && full64 && T0 >= 72 && T0 + 16 <= wb_iters;       // wave-uniform
             #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const int ph = ph_of(k);
+                const int ph = wb_phase(k);
                 const int it = ((((int)T0 - (8 * k + crow) + ph) & ~7) - ph) + cslot;          // piece 8g - ph + cslot, g = floor((T0 - row + ph) / 8)
                 const uint4 v = wbv[k];
-                if (mid) {
-                    const u32 off = (u32)(8 * k + crow) * (u32)a.d_pitch + (u32)it * 16u;        // (d_pitch * 64 < 2^31: checked by the launcher)
-                    if (Q && k == 7 && crow == 7) __builtin_amdgcn_raw_buffer_store_b128(u32x4{ v.x, v.y, v.z, v.w }, rs_last, (u32)it * 16u, 0, 16);   // row 63: sc1
-                    else if (PNG_NT_STORES) __builtin_nontemporal_store(u32x4{ v.x, v.y, v.z, v.w }, reinterpret_cast<u32x4*>(dband + (size_t)off));
-                    else *reinterpret_cast<u32x4*>(dband + (size_t)off) = u32x4{ v.x, v.y, v.z, v.w };
-                } else
                 if ((u32)(8 * k + crow) < rows_left && it >= 0 && it < (int)wb_iters) {
                     u32x4* dst = reinterpret_cast<u32x4*>(cdst + (int64_t)(8 * k) * a.d_pitch + (int64_t)it * 16);
                     if (Q && k == 7 && crow == 7) __builtin_amdgcn_raw_buffer_store_b128(u32x4{ v.x, v.y, v.z, v.w }, rs_last, (u32)it * 16u, 0, 16);   // row 63: sc1

@@ -108,6 +108,15 @@ __device__ __forceinline__ void store_px_nt(uint8_t* row_base, u32 voff, u32 px)
 {
     asm volatile("global_store_dword %0, %1, %2 nt" :: "v"(voff), "v"(px), "s"(row_base));
 }
+// The same without the hint, for rows that do not start on a 128-byte line (tight rgba8 rows of a width that is no multiple of 32 pixels): a wave's
+// 128-byte run then straddles two lines, each line is written by two workgroups at different times, and with the nontemporal hint every piece goes
+// to memory on its own -- plain stores let the pieces of neighbouring strips meet in the L2 (the XCD-aware order keeps them on one).  Round 6, A/B on
+// one box (profiles/r06_jpeg_nt_ab.txt): 2048 x 1366x768 3.31-3.41 -> 2.70 ms, 1024 x 1080x1920 2.82-2.86 -> 2.71 ms; on lines the hint is 1.5 % better.
+// The other sampling modes' kernels keep the hint everywhere: plain stores measured slower there on and off the lines.
+__device__ __forceinline__ void store_px_plain(uint8_t* row_base, u32 voff, u32 px)
+{
+    asm volatile("global_store_dword %0, %1, %2" :: "v"(voff), "v"(px), "s"(row_base));
+}
 
 #ifndef JPEG_XCD_REMAP
 #define JPEG_XCD_REMAP 1
@@ -139,7 +148,8 @@ constexpr int plain_threads(int scan_type) { return scan_type == GAMUT_JPGD_YH1V
 #ifndef JPEG_MIN_WAVES            // __launch_bounds__'s second argument: minimum waves per SIMD (0 = unconstrained register allocation)
 #define JPEG_MIN_WAVES 0
 #endif
-template <int OC, bool TOK = false>     // output components: 4 = rgba8, 3 = rgb8, 1 = l8 (grey of the RGB result, jpegload.d:3786-3792); TOK: coefficients as tokens
+template <int OC, bool TOK = false, bool NT = true>     // output components: 4 = rgba8, 3 = rgb8, 1 = l8 (grey of the RGB result, jpegload.d:3786-3792); TOK: coefficients as tokens;
+                                                         // NT (rgba8): every row on a 128-byte line -> nontemporal pixel stores (the launcher's verdict; see store_px_plain)
 #if JPEG_MIN_WAVES
 __global__ __launch_bounds__(H2V2_THREADS, JPEG_MIN_WAVES) void k_jpeg_h2v2(JpegArgs a)
 #else
@@ -382,6 +392,7 @@ __global__ __launch_bounds__(H2V2_THREADS) void k_jpeg_h2v2(JpegArgs a)
             if constexpr (OC == 4) {
                 // one pixel per lane per row: a wave store instruction writes two full 128-byte lines.  (16-byte stores after an
                 // in-quad DPP transpose were measured 2 % slower, and on the bare load + store skeleton no faster.)
+                auto store_px = [](uint8_t* row_base, u32 vo, u32 px) { if constexpr (NT) store_px_nt(row_base, vo, px); else store_px_plain(row_base, vo, px); };
                 if (px_live) {
                     if (JPEG_ABLATE == 2) {
                         u32 acc = 0;
@@ -391,11 +402,11 @@ __global__ __launch_bounds__(H2V2_THREADS) void k_jpeg_h2v2(JpegArgs a)
                     } else
                     if (all_rows) {
                         #pragma unroll
-                        for (int i = 0; i < 8; ++i) store_px_nt(otile + (size_t)(a.flip ? 7 - i : i) * pitch, voff, ycc_to_rgba(ys[i], cbs[i], crs[i], cc.kr, cc.kb, cc.kg));
+                        for (int i = 0; i < 8; ++i) store_px(otile + (size_t)(a.flip ? 7 - i : i) * pitch, voff, ycc_to_rgba(ys[i], cbs[i], crs[i], cc.kr, cc.kb, cc.kg));
                     } else {
                         #pragma unroll
                         for (int i = 0; i < 8; ++i)
-                            if (i < rows_here) store_px_nt(otile + (size_t)(a.flip ? 7 - i : i) * pitch, voff, ycc_to_rgba(ys[i], cbs[i], crs[i], cc.kr, cc.kb, cc.kg));
+                            if (i < rows_here) store_px(otile + (size_t)(a.flip ? 7 - i : i) * pitch, voff, ycc_to_rgba(ys[i], cbs[i], crs[i], cc.kr, cc.kb, cc.kg));
                     }
                 }
             } else {
@@ -985,6 +996,7 @@ int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
         const bool tuned = apitch > 0 && apitch < (1 << 27) &&
                            (out_comps != 4 || (((uintptr_t)out & 3) == 0 && (apitch & 3) == 0 && (out_stride & 3) == 0));
         if (tuned && out_pitch < 0 && scan_type == GAMUT_JPGD_YH2V2) { c.flip = 1; c.out_pitch = apitch; c.out += (int64_t)(height - 1) * out_pitch; }
+        const bool on_lines = (((uintptr_t)out | (uintptr_t)apitch | (uintptr_t)(count > 1 ? (out_stride < 0 ? -out_stride : out_stride) : 0)) & 127u) == 0;     // every row of every image on a 128-byte line
         const char* const cols_env = getenv("GAMUT_HIP_JPEG_COLS");                                 // A/B and tests: "plain" = k_jpeg_plain (rounds 1-3) for every mode but 4:2:0
         const bool cols_tuned = !(cols_env && !strcmp(cols_env, "plain"));
         const int ps = plain_strips(scan_type);
@@ -1028,7 +1040,8 @@ int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
         }
         else if (scan_type == GAMUT_JPGD_YH2V1)       GAMUT_JPEG_PLAIN(GAMUT_JPGD_YH2V1, grid_plain);
         else if (scan_type == GAMUT_JPGD_YH1V2)       GAMUT_JPEG_PLAIN(GAMUT_JPGD_YH1V2, grid_plain);
-        else if (out_comps == 4) hipLaunchKernelGGL(k_jpeg_h2v2<4>, grid420, dim3(H2V2_THREADS), 0, stream, c);
+        else if (out_comps == 4 && on_lines) hipLaunchKernelGGL(k_jpeg_h2v2<4>, grid420, dim3(H2V2_THREADS), 0, stream, c);
+        else if (out_comps == 4) hipLaunchKernelGGL((k_jpeg_h2v2<4, false, false>), grid420, dim3(H2V2_THREADS), 0, stream, c);
         else if (out_comps == 3) hipLaunchKernelGGL(k_jpeg_h2v2<3>, grid420, dim3(H2V2_THREADS), 0, stream, c);
         else                     hipLaunchKernelGGL(k_jpeg_h2v2<1>, grid420, dim3(H2V2_THREADS), 0, stream, c);
 #undef GAMUT_JPEG_PLAIN
@@ -1066,7 +1079,9 @@ int jpeg_reconstruct_tokens_launch(const uint32_t* tokens, const uint32_t* strip
 #else
         const dim3 grid420(groups420, a.mcus_per_col, n);
 #endif
-        if (out_comps == 4)      hipLaunchKernelGGL((k_jpeg_h2v2<4, true>), grid420, dim3(H2V2_THREADS), 0, stream, c);
+        const bool on_lines = (((uintptr_t)out | (uintptr_t)apitch | (uintptr_t)(count > 1 ? (out_stride < 0 ? -out_stride : out_stride) : 0)) & 127u) == 0;
+        if (out_comps == 4 && on_lines) hipLaunchKernelGGL((k_jpeg_h2v2<4, true>), grid420, dim3(H2V2_THREADS), 0, stream, c);
+        else if (out_comps == 4) hipLaunchKernelGGL((k_jpeg_h2v2<4, true, false>), grid420, dim3(H2V2_THREADS), 0, stream, c);
         else if (out_comps == 3) hipLaunchKernelGGL((k_jpeg_h2v2<3, true>), grid420, dim3(H2V2_THREADS), 0, stream, c);
         else                     hipLaunchKernelGGL((k_jpeg_h2v2<1, true>), grid420, dim3(H2V2_THREADS), 0, stream, c);
         if (int rc = launch_status("jpeg_reconstruct_tokens")) return rc;

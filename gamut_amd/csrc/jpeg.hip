@@ -47,6 +47,8 @@ struct JpegArgs {
     // the compact hand-off (k_jpeg_h2v2<.., TOK>): instead of `coeffs`, image i's coefficients are the tokens
     // tokens[tok_offs[i] + strip_tab[strip_offs[i] + s] .. strip_tab[strip_offs[i] + s + 1]) of strip s (jpeg_host.hip, SUB_TOKENS)
     const u32* tokens; const u32* strip_tab; const int64_t* tok_offs; const int64_t* strip_offs;
+    int nt;                                          // every row of every image starts on a 128-byte line (the launcher's verdict): the packed outputs' 16-byte chunks leave
+                                                     // with the nontemporal hint (rgb8 2.81 -> 2.78 ms, l8 2.64 -> 2.62; off the lines the hint costs 15 %: profiles/r06_jpeg_packed_nt_ab.txt)
     int flip;                                        // rows stored bottom-up (the caller's pitch was negative): out = the image's LAST row in memory
 };                                                   // order = its first row by address, out_pitch = |pitch|; image row y lives at row height - 1 - y
 
@@ -449,8 +451,13 @@ __global__ __launch_bounds__(H2V2_THREADS) void k_jpeg_h2v2(JpegArgs a)
                     const uint4 v = *reinterpret_cast<const uint4*>(stage + row * BPR + off);
                     uint8_t* o = otile + (u32)(a.flip ? 15 - row : row) * pitch + (u32)off;
                     if (off + 16 <= row_bytes) {
-                        Dwords4u d; d.v[0] = v.x; d.v[1] = v.y; d.v[2] = v.z; d.v[3] = v.w;
-                        *reinterpret_cast<Dwords4u*>(o) = d;
+                        if (a.nt) {                                    // (workgroup-uniform) whole lines leave the strip: nothing of them is touched again
+                            typedef u32 u32x4p __attribute__((ext_vector_type(4), aligned(4)));
+                            __builtin_nontemporal_store(u32x4p{ v.x, v.y, v.z, v.w }, reinterpret_cast<u32x4p*>(o));
+                        } else {
+                            Dwords4u d; d.v[0] = v.x; d.v[1] = v.y; d.v[2] = v.z; d.v[3] = v.w;
+                            *reinterpret_cast<Dwords4u*>(o) = d;
+                        }
                     } else {
                         const u32 w[4] = { v.x, v.y, v.z, v.w };
                         for (int kk = 0; kk < row_bytes - off; ++kk) o[kk] = (uint8_t)(w[kk >> 2] >> ((kk & 3) * 8));
@@ -997,6 +1004,7 @@ int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
                            (out_comps != 4 || (((uintptr_t)out & 3) == 0 && (apitch & 3) == 0 && (out_stride & 3) == 0));
         if (tuned && out_pitch < 0 && scan_type == GAMUT_JPGD_YH2V2) { c.flip = 1; c.out_pitch = apitch; c.out += (int64_t)(height - 1) * out_pitch; }
         const bool on_lines = (((uintptr_t)out | (uintptr_t)apitch | (uintptr_t)(count > 1 ? (out_stride < 0 ? -out_stride : out_stride) : 0)) & 127u) == 0;     // every row of every image on a 128-byte line
+        c.nt = on_lines ? 1 : 0;
         const char* const cols_env = getenv("GAMUT_HIP_JPEG_COLS");                                 // A/B and tests: "plain" = k_jpeg_plain (rounds 1-3) for every mode but 4:2:0
         const bool cols_tuned = !(cols_env && !strcmp(cols_env, "plain"));
         const int ps = plain_strips(scan_type);
@@ -1080,6 +1088,7 @@ int jpeg_reconstruct_tokens_launch(const uint32_t* tokens, const uint32_t* strip
         const dim3 grid420(groups420, a.mcus_per_col, n);
 #endif
         const bool on_lines = (((uintptr_t)out | (uintptr_t)apitch | (uintptr_t)(count > 1 ? (out_stride < 0 ? -out_stride : out_stride) : 0)) & 127u) == 0;
+        c.nt = on_lines ? 1 : 0;
         if (out_comps == 4 && on_lines) hipLaunchKernelGGL((k_jpeg_h2v2<4, true>), grid420, dim3(H2V2_THREADS), 0, stream, c);
         else if (out_comps == 4) hipLaunchKernelGGL((k_jpeg_h2v2<4, true, false>), grid420, dim3(H2V2_THREADS), 0, stream, c);
         else if (out_comps == 3) hipLaunchKernelGGL((k_jpeg_h2v2<3, true>), grid420, dim3(H2V2_THREADS), 0, stream, c);

@@ -612,27 +612,31 @@ __global__ __launch_bounds__(plain_threads(ST)) void k_jpeg_plain(JpegArgs a)
 // :2715-2728 one Y block).  One LDS block slot per MCU, the components take turns in it: registers, not LDS, decide how many waves a SIMD holds.
 // one pixel per lane of a row, lanes along x: rgba8 a dword each; rgb8 / l8: the four lanes of a quad (j = place in it) pass their pixels
 // along so that whole dwords leave -- `whole`: the quad lies inside the image, else every lane writes its own bytes.  All lanes must call.
-template <int OC>
+// NT: the nontemporal hint on the pixel stores -- for rows on 128-byte lines (a wave's run is whole lines); rows off the lines store plain, so that the
+// partial lines of neighbouring strips meet in the L2 their XCD shares (the workgroup order below keeps an image's strips on one XCD).  Round 6, one box
+// (profiles/r06_jpeg_cols_xr_ab.txt): 4:4:4 -> rgba8 2048 x 1366x768 5.0-5.4 -> 4.38 ms, 1024 x 1080x1920 4.65-4.72 -> 4.31-4.34; 1920x1080 (on lines) 3.59 either way.
+#define GAMUT_EMIT_STORE(v, p) do { if constexpr (NT) __builtin_nontemporal_store((v), (p)); else *(p) = (v); } while (0)
+template <int OC, bool NT>
 __device__ __forceinline__ void emit_px(uint8_t* orow, int x, u32 px, u32 grey, int j, u32 sel3, bool mine, bool whole)
 {
     typedef u32 u32x1a __attribute__((aligned(1)));
     if constexpr (OC == 4) {
-        if (mine) __builtin_nontemporal_store(px, reinterpret_cast<u32*>(orow + (int64_t)x * 4));
+        if (mine) GAMUT_EMIT_STORE(px, reinterpret_cast<u32*>(orow + (int64_t)x * 4));
     } else if constexpr (OC == 3) {
         const u32 nxt = (u32)__builtin_amdgcn_update_dpp(0, (int)px, 0x101, 0xF, 0xF, false);                 // row_shl:1 -- the pixel to the right
         const u32 d = __builtin_amdgcn_perm(nxt, px, sel3);
-        if (whole) { if (mine && j < 3) __builtin_nontemporal_store((u32x1a)d, reinterpret_cast<u32x1a*>(orow + (int64_t)(x - j) * 3 + j * 4)); }
+        if (whole) { if (mine && j < 3) GAMUT_EMIT_STORE((u32x1a)d, reinterpret_cast<u32x1a*>(orow + (int64_t)(x - j) * 3 + j * 4)); }
         else if (mine) { uint8_t* q = orow + (int64_t)x * 3; q[0] = (uint8_t)px; q[1] = (uint8_t)(px >> 8); q[2] = (uint8_t)(px >> 16); }
     } else {
         u32 g = grey;
         g |= (u32)__builtin_amdgcn_update_dpp(0, (int)g, 0x101, 0xF, 0xF, false) << 8;                      // + the pixel to the right
         g |= (u32)__builtin_amdgcn_update_dpp(0, (int)g, 0x102, 0xF, 0xF, false) << 16;                     // + the pair two to the right
-        if (whole) { if (mine && j == 0) __builtin_nontemporal_store((u32x1a)g, reinterpret_cast<u32x1a*>(orow + x)); }
+        if (whole) { if (mine && j == 0) GAMUT_EMIT_STORE((u32x1a)g, reinterpret_cast<u32x1a*>(orow + x)); }
         else if (mine) orow[x] = (uint8_t)g;
     }
 }
 
-template <int ST, int OC, int MCUS>     // MCUs per strip = threads / 8
+template <int ST, int OC, int MCUS, bool NT = true>     // MCUs per strip = threads / 8
 __global__ __launch_bounds__(MCUS * 8) void k_jpeg_cols(JpegArgs a)
 {
     static_assert(ST == GAMUT_JPGD_GRAYSCALE || ST == GAMUT_JPGD_YH1V1, "one block per component and MCU");
@@ -640,13 +644,15 @@ __global__ __launch_bounds__(MCUS * 8) void k_jpeg_cols(JpegArgs a)
     constexpr int STRIPS = 2;
     __shared__ __attribute__((aligned(16))) i32 T1[MCUS * BLK_STRIDE];
     const int t = threadIdx.x, m = t >> 3, r = t & 7;
-    const int img = blockIdx.z, mcu_y = blockIdx.y;
+    // XCD-aware order, as k_jpeg_h2v2: gridDim.x is a multiple of 8, the XCD is blockIdx.x & 7 and takes whole images (image = 8 z + xcd)
+    const int img = blockIdx.z * 8 + (blockIdx.x & 7), mcu_y = blockIdx.y, bx = blockIdx.x >> 3;
+    if (img >= a.count) return;
     const ColourConsts cc = colour_consts();
     const int rows_here = min(8, a.height - mcu_y * 8);
     const int j = t & 3;                                          // place in the group of four pixels that shares its output dwords (rgb8, l8)
     const u32 sel3 = j == 0 ? 0x04020100u : j == 1 ? 0x05040201u : 0x06050402u;
     for (int strip = 0; strip < STRIPS; ++strip) {
-        const int mcu_x0 = (blockIdx.x * STRIPS + strip) * MCUS;
+        const int mcu_x0 = (bx * STRIPS + strip) * MCUS;
         if (mcu_x0 >= a.mcus_per_row) break;                      // workgroup-uniform
         const int64_t blk0 = ((int64_t)mcu_y * a.mcus_per_row + mcu_x0) * NC;
         const int16_t* cbase = a.coeffs + (int64_t)img * a.coeff_stride + blk0 * 64;
@@ -692,7 +698,7 @@ __global__ __launch_bounds__(MCUS * 8) void k_jpeg_cols(JpegArgs a)
             else                   px = ycc_to_rgba(smp[0][y], smp[1][y], smp[NC - 1][y], cc.kr, cc.kb, cc.kg);
             u32 g = 0;
             if constexpr (OC == 1) { if constexpr (NC == 1) g = (u32)smp[0][y]; else g = rgb_to_luma(px); }
-            emit_px<OC>(orow, x, px, g, j, sel3, mine, whole);
+            emit_px<OC, NT>(orow, x, px, g, j, sel3, mine, whole);
         }
     }
 }
@@ -701,7 +707,7 @@ __global__ __launch_bounds__(MCUS * 8) void k_jpeg_cols(JpegArgs a)
 // :2603-2647: two Y blocks stacked, 8 x 16 pixels, one chroma sample per pair of rows) the same way: eight threads per MCU, each runs pass 1 on
 // row r of the four blocks, then four column passes -- 4:4:0: column r of Y-top, Y-bottom, Cb, Cr = its 16 pixels; 4:2:2: the Y columns 2r and
 // 2r + 1 (both in block r >> 2) and chroma column r = its 8 x 2 pixels.  Two LDS block slots per MCU: the Y pair, then the chroma pair.
-template <int ST, int OC, int MCUS>
+template <int ST, int OC, int MCUS, bool NT = true>
 __global__ __launch_bounds__(MCUS * 8) void k_jpeg_cols4(JpegArgs a)
 {
     static_assert(ST == GAMUT_JPGD_YH2V1 || ST == GAMUT_JPGD_YH1V2, "four blocks per MCU");
@@ -710,11 +716,12 @@ __global__ __launch_bounds__(MCUS * 8) void k_jpeg_cols4(JpegArgs a)
     constexpr int STRIPS = 2;
     __shared__ __attribute__((aligned(16))) i32 T1[MCUS * 2 * BLK_STRIDE];
     const int t = threadIdx.x, m = t >> 3, r = t & 7;
-    const int img = blockIdx.z, mcu_y = blockIdx.y;
+    const int img = blockIdx.z * 8 + (blockIdx.x & 7), mcu_y = blockIdx.y, bx = blockIdx.x >> 3;      // XCD-aware order, as k_jpeg_cols
+    if (img >= a.count) return;
     const ColourConsts cc = colour_consts();
     const int rows_here = min(MH, a.height - mcu_y * MH);
     for (int strip = 0; strip < STRIPS; ++strip) {
-        const int mcu_x0 = (blockIdx.x * STRIPS + strip) * MCUS;
+        const int mcu_x0 = (bx * STRIPS + strip) * MCUS;
         if (mcu_x0 >= a.mcus_per_row) break;                      // workgroup-uniform
         const int64_t blk0 = ((int64_t)mcu_y * a.mcus_per_row + mcu_x0) * 4;
         const int16_t* cbase = a.coeffs + (int64_t)img * a.coeff_stride + blk0 * 64;
@@ -772,7 +779,7 @@ __global__ __launch_bounds__(MCUS * 8) void k_jpeg_cols4(JpegArgs a)
                     const u32 px = ycc_to_rgba(smp[y >> 3][y & 7], smp[2][y >> 1], smp[3][y >> 1], cc.kr, cc.kb, cc.kg);
                     u32 g = 0;
                     if constexpr (OC == 1) g = rgb_to_luma(px);
-                    emit_px<OC>(o0 + (int64_t)y * a.out_pitch, x, px, g, j, sel3, mine, whole);
+                    emit_px<OC, NT>(o0 + (int64_t)y * a.out_pitch, x, px, g, j, sel3, mine, whole);
                 }
         } else {
             const int x0 = (mcu_x0 + m) * 16 + 2 * r;             // this thread's two pixels: x0, x0 + 1; a lane PAIR shares the dwords of four pixels
@@ -788,15 +795,15 @@ __global__ __launch_bounds__(MCUS * 8) void k_jpeg_cols4(JpegArgs a)
                 const u32 p0 = ycc_to_rgba(smp[0][y], smp[2][y], smp[3][y], cc.kr, cc.kb, cc.kg), p1 = ycc_to_rgba(smp[1][y], smp[2][y], smp[3][y], cc.kr, cc.kb, cc.kg);
                 if constexpr (OC == 4) {
                     typedef u32 u32x2n __attribute__((ext_vector_type(2), aligned(4)));
-                    if (mine) { if (both) __builtin_nontemporal_store(u32x2n{ p0, p1 }, reinterpret_cast<u32x2n*>(orow + (int64_t)x0 * 4));
-                                else      __builtin_nontemporal_store(p0, reinterpret_cast<u32*>(orow + (int64_t)x0 * 4)); }
+                    if (mine) { if (both) GAMUT_EMIT_STORE((u32x2n{ p0, p1 }), reinterpret_cast<u32x2n*>(orow + (int64_t)x0 * 4));
+                                else      GAMUT_EMIT_STORE(p0, reinterpret_cast<u32*>(orow + (int64_t)x0 * 4)); }
                 } else if constexpr (OC == 3) {
                     const u32 left1 = (u32)__builtin_amdgcn_update_dpp(0, (int)p1, 0x111, 0xF, 0xF, false);           // row_shr:1 -- the left lane's second pixel
                     if (whole) {
                         if (mine) {
-                            if (!odd) __builtin_nontemporal_store((u32x1a)__builtin_amdgcn_perm(p1, p0, 0x04020100u), reinterpret_cast<u32x1a*>(orow + (int64_t)gx * 3));
-                            else      __builtin_nontemporal_store(u32x2a{ __builtin_amdgcn_perm(p0, left1, 0x05040201u), __builtin_amdgcn_perm(p1, p0, 0x06050402u) },
-                                                                  reinterpret_cast<u32x2a*>(orow + (int64_t)gx * 3 + 4));
+                            if (!odd) GAMUT_EMIT_STORE((u32x1a)__builtin_amdgcn_perm(p1, p0, 0x04020100u), reinterpret_cast<u32x1a*>(orow + (int64_t)gx * 3));
+                            else      GAMUT_EMIT_STORE((u32x2a{ __builtin_amdgcn_perm(p0, left1, 0x05040201u), __builtin_amdgcn_perm(p1, p0, 0x06050402u) }),
+                                                       reinterpret_cast<u32x2a*>(orow + (int64_t)gx * 3 + 4));
                         }
                     } else if (mine) {
                         uint8_t* q = orow + (int64_t)x0 * 3; q[0] = (uint8_t)p0; q[1] = (uint8_t)(p0 >> 8); q[2] = (uint8_t)(p0 >> 16);
@@ -805,7 +812,7 @@ __global__ __launch_bounds__(MCUS * 8) void k_jpeg_cols4(JpegArgs a)
                 } else {
                     u32 g = rgb_to_luma(p0) | (rgb_to_luma(p1) << 8);
                     g |= (u32)__builtin_amdgcn_update_dpp(0, (int)g, 0x101, 0xF, 0xF, false) << 16;                 // + the right lane's two
-                    if (whole) { if (mine && !odd) __builtin_nontemporal_store((u32x1a)g, reinterpret_cast<u32x1a*>(orow + gx)); }
+                    if (whole) { if (mine && !odd) GAMUT_EMIT_STORE((u32x1a)g, reinterpret_cast<u32x1a*>(orow + gx)); }
                     else if (mine) { orow[x0] = (uint8_t)g; if (both) orow[x0 + 1] = (uint8_t)(g >> 8); }
                 }
             }
@@ -1028,9 +1035,9 @@ int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
             // strips of 32 or 24 MCUs, whichever leaves fewer idle threads at the end of a row (1080p: 240 MCUs = 10 x 24)
             const int waste32 = (32 - a.mcus_per_row % 32) % 32, waste24 = (24 - a.mcus_per_row % 24) % 24;
             const bool m24 = waste24 * 32 < waste32 * 24;
-            const dim3 g(((a.mcus_per_row + (m24 ? 23 : 31)) / (m24 ? 24 : 32) + 1) / 2, a.mcus_per_col, n);
-#define GAMUT_JPEG_COLS(ST, OC) do { if (m24) hipLaunchKernelGGL((k_jpeg_cols<ST, OC, 24>), g, dim3(192), 0, stream, c); \
-                                     else     hipLaunchKernelGGL((k_jpeg_cols<ST, OC, 32>), g, dim3(256), 0, stream, c); } while (0)
+            const dim3 g(8u * (unsigned)(((a.mcus_per_row + (m24 ? 23 : 31)) / (m24 ? 24 : 32) + 1) / 2), a.mcus_per_col, (n + 7) / 8);      // (x & 7 = the XCD = the image's place among eight)
+#define GAMUT_JPEG_COLS(ST, OC) do { if (m24) { if (on_lines) hipLaunchKernelGGL((k_jpeg_cols<ST, OC, 24>), g, dim3(192), 0, stream, c); else hipLaunchKernelGGL((k_jpeg_cols<ST, OC, 24, false>), g, dim3(192), 0, stream, c); } \
+                                     else     { if (on_lines) hipLaunchKernelGGL((k_jpeg_cols<ST, OC, 32>), g, dim3(256), 0, stream, c); else hipLaunchKernelGGL((k_jpeg_cols<ST, OC, 32, false>), g, dim3(256), 0, stream, c); } } while (0)
             if (scan_type == GAMUT_JPGD_YH1V1) { if (out_comps == 4) GAMUT_JPEG_COLS(GAMUT_JPGD_YH1V1, 4); else if (out_comps == 3) GAMUT_JPEG_COLS(GAMUT_JPGD_YH1V1, 3); else GAMUT_JPEG_COLS(GAMUT_JPGD_YH1V1, 1); }
             else                               { if (out_comps == 4) GAMUT_JPEG_COLS(GAMUT_JPGD_GRAYSCALE, 4); else if (out_comps == 3) GAMUT_JPEG_COLS(GAMUT_JPGD_GRAYSCALE, 3); else GAMUT_JPEG_COLS(GAMUT_JPGD_GRAYSCALE, 1); }
 #undef GAMUT_JPEG_COLS
@@ -1039,9 +1046,9 @@ int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
         else if ((scan_type == GAMUT_JPGD_YH2V1 || scan_type == GAMUT_JPGD_YH1V2) && cols_tuned) {
             const int waste32 = (32 - a.mcus_per_row % 32) % 32, waste24 = (24 - a.mcus_per_row % 24) % 24;
             const bool m24 = waste24 * 32 < waste32 * 24;
-            const dim3 g(((a.mcus_per_row + (m24 ? 23 : 31)) / (m24 ? 24 : 32) + 1) / 2, a.mcus_per_col, n);
-#define GAMUT_JPEG_COLS4(ST, OC) do { if (m24) hipLaunchKernelGGL((k_jpeg_cols4<ST, OC, 24>), g, dim3(192), 0, stream, c); \
-                                      else     hipLaunchKernelGGL((k_jpeg_cols4<ST, OC, 32>), g, dim3(256), 0, stream, c); } while (0)
+            const dim3 g(8u * (unsigned)(((a.mcus_per_row + (m24 ? 23 : 31)) / (m24 ? 24 : 32) + 1) / 2), a.mcus_per_col, (n + 7) / 8);
+#define GAMUT_JPEG_COLS4(ST, OC) do { if (m24) { if (on_lines) hipLaunchKernelGGL((k_jpeg_cols4<ST, OC, 24>), g, dim3(192), 0, stream, c); else hipLaunchKernelGGL((k_jpeg_cols4<ST, OC, 24, false>), g, dim3(192), 0, stream, c); } \
+                                      else     { if (on_lines) hipLaunchKernelGGL((k_jpeg_cols4<ST, OC, 32>), g, dim3(256), 0, stream, c); else hipLaunchKernelGGL((k_jpeg_cols4<ST, OC, 32, false>), g, dim3(256), 0, stream, c); } } while (0)
             if (scan_type == GAMUT_JPGD_YH2V1) { if (out_comps == 4) GAMUT_JPEG_COLS4(GAMUT_JPGD_YH2V1, 4); else if (out_comps == 3) GAMUT_JPEG_COLS4(GAMUT_JPGD_YH2V1, 3); else GAMUT_JPEG_COLS4(GAMUT_JPGD_YH2V1, 1); }
             else                               { if (out_comps == 4) GAMUT_JPEG_COLS4(GAMUT_JPGD_YH1V2, 4); else if (out_comps == 3) GAMUT_JPEG_COLS4(GAMUT_JPGD_YH1V2, 3); else GAMUT_JPEG_COLS4(GAMUT_JPGD_YH1V2, 1); }
 #undef GAMUT_JPEG_COLS4

@@ -483,7 +483,7 @@ struct __attribute__((packed, aligned(4))) Dwords4 { u32 v[4]; };
 struct __attribute__((packed, aligned(1))) Dwords3 { u32 v[3]; };
 struct __attribute__((packed, aligned(1))) Dword1 { u32 v; };
 
-template <int ST, int OC>
+template <int ST, int OC, bool NT = true>     // NT: rows on 128-byte lines -> nontemporal stores (see emit_px below)
 __global__ __launch_bounds__(plain_threads(ST)) void k_jpeg_plain(JpegArgs a)
 {
     constexpr int NTHR = plain_threads(ST);
@@ -499,13 +499,14 @@ __global__ __launch_bounds__(plain_threads(ST)) void k_jpeg_plain(JpegArgs a)
     __shared__ __attribute__((aligned(16))) uint8_t S[NBLK * 64];
 
     const int t = threadIdx.x;
-    const int img = blockIdx.z, mcu_y = blockIdx.y;
+    const int img = blockIdx.z * 8 + (blockIdx.x & 7), mcu_y = blockIdx.y, bx = blockIdx.x >> 3;      // XCD-aware order: an image's strips on one XCD (gridDim.x is a multiple of 8)
+    if (img >= a.count) return;
     // A strip is 3-4 KB of coefficients in and 2-4 KB of pixels out: a workgroup per strip made the launch millions of workgroups
     // (1024 x 1080p 4:4:4: 4.1 M) that the dispatcher hands out slower than the kernel could run them.  A workgroup takes
     // PLAIN_STRIPS consecutive strips of its MCU row where that pays (plain_strips).
     constexpr int PLAIN_STRIPS = plain_strips(ST);
     for (int strip = 0; strip < PLAIN_STRIPS; ++strip) {
-    const int mcu_x0 = (blockIdx.x * PLAIN_STRIPS + strip) * MCUS;
+    const int mcu_x0 = (bx * PLAIN_STRIPS + strip) * MCUS;
     if (mcu_x0 >= a.mcus_per_row) break;                          // workgroup-uniform
     const int64_t blk0 = ((int64_t)mcu_y * a.mcus_per_row + mcu_x0) * BPM;
     const int16_t* cbase = a.coeffs + (int64_t)img * a.coeff_stride + blk0 * 64;
@@ -588,9 +589,15 @@ __global__ __launch_bounds__(plain_threads(ST)) void k_jpeg_plain(JpegArgs a)
             typedef u32 u32x4a __attribute__((ext_vector_type(4), aligned(4)));
             typedef u32 u32x3a __attribute__((ext_vector_type(3), aligned(1)));
             typedef u32 u32x1a __attribute__((aligned(1)));
-            if constexpr (OC == 4)      __builtin_nontemporal_store(u32x4a{ w[0], w[1], w[2], w[3] }, reinterpret_cast<u32x4a*>(o));
-            else if constexpr (OC == 3) __builtin_nontemporal_store(u32x3a{ w[0], w[1], w[2] }, reinterpret_cast<u32x3a*>(o));
-            else                        __builtin_nontemporal_store((u32x1a)w[0], reinterpret_cast<u32x1a*>(o));
+            if constexpr (NT) {
+                if constexpr (OC == 4)      __builtin_nontemporal_store(u32x4a{ w[0], w[1], w[2], w[3] }, reinterpret_cast<u32x4a*>(o));
+                else if constexpr (OC == 3) __builtin_nontemporal_store(u32x3a{ w[0], w[1], w[2] }, reinterpret_cast<u32x3a*>(o));
+                else                        __builtin_nontemporal_store((u32x1a)w[0], reinterpret_cast<u32x1a*>(o));
+            } else {
+                if constexpr (OC == 4)      *reinterpret_cast<u32x4a*>(o) = u32x4a{ w[0], w[1], w[2], w[3] };
+                else if constexpr (OC == 3) *reinterpret_cast<u32x3a*>(o) = u32x3a{ w[0], w[1], w[2] };
+                else                        *reinterpret_cast<u32x1a*>(o) = (u32x1a)w[0];
+            }
         } else {
             for (int k = 0; k < npx * OC; ++k) o[k] = (uint8_t)(w[k >> 2] >> ((k & 3) * 8));
         }
@@ -1016,8 +1023,8 @@ int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
         const bool cols_tuned = !(cols_env && !strcmp(cols_env, "plain"));
         const int ps = plain_strips(scan_type);
         const int pm = plain_mcus(scan_type, out_comps);
-        const dim3 grid32(((a.mcus_per_row + 31) / 32 + ps - 1) / ps, a.mcus_per_col, n);           // grey: 32 MCUs per strip
-        const dim3 grid_plain(((a.mcus_per_row + pm - 1) / pm + ps - 1) / ps, a.mcus_per_col, n);
+        const dim3 grid32(8u * (unsigned)(((a.mcus_per_row + 31) / 32 + ps - 1) / ps), a.mcus_per_col, (n + 7) / 8);           // grey: 32 MCUs per strip; x & 7 = the image's place among eight
+        const dim3 grid_plain(8u * (unsigned)(((a.mcus_per_row + pm - 1) / pm + ps - 1) / ps), a.mcus_per_col, (n + 7) / 8);
         const int strips420 = out_comps == 4 ? JPEG_STRIPS : JPEG_STRIPS_PACKED;
         const unsigned groups420 = (unsigned)(((a.mcus_per_row + H2V2_MCUS - 1) / H2V2_MCUS + strips420 - 1) / strips420);
 #if JPEG_XCD_REMAP
@@ -1026,9 +1033,9 @@ int jpeg_reconstruct_launch(const int16_t* coeffs, int64_t coeff_stride,
         const dim3 grid420(groups420, a.mcus_per_col, n);
 #endif
 #define GAMUT_JPEG_PLAIN(ST, G) do { \
-            if (out_comps == 4)      hipLaunchKernelGGL((k_jpeg_plain<ST, 4>), G, dim3(plain_threads(ST)), 0, stream, c); \
-            else if (out_comps == 3) hipLaunchKernelGGL((k_jpeg_plain<ST, 3>), G, dim3(plain_threads(ST)), 0, stream, c); \
-            else                     hipLaunchKernelGGL((k_jpeg_plain<ST, 1>), G, dim3(plain_threads(ST)), 0, stream, c); } while (0)
+            if (out_comps == 4)      hipLaunchKernelGGL((k_jpeg_plain<ST, 4>), G, dim3(plain_threads(ST)), 0, stream, c);      /* (rgba8 off the lines: plain stores 3 % slower here) */ \
+            else if (out_comps == 3) { if (on_lines) hipLaunchKernelGGL((k_jpeg_plain<ST, 3>), G, dim3(plain_threads(ST)), 0, stream, c); else hipLaunchKernelGGL((k_jpeg_plain<ST, 3, false>), G, dim3(plain_threads(ST)), 0, stream, c); } \
+            else                     { if (on_lines) hipLaunchKernelGGL((k_jpeg_plain<ST, 1>), G, dim3(plain_threads(ST)), 0, stream, c); else hipLaunchKernelGGL((k_jpeg_plain<ST, 1, false>), G, dim3(plain_threads(ST)), 0, stream, c); } } while (0)
         if (!tuned)                                   hipLaunchKernelGGL(k_jpeg_generic, grid, dim3(256), 0, stream, c);
         else if (scan_type == GAMUT_JPGD_GRAYSCALE)   GAMUT_JPEG_PLAIN(GAMUT_JPGD_GRAYSCALE, grid32);
         else if ((scan_type == GAMUT_JPGD_YH1V1 || scan_type == GAMUT_JPGD_GRAYSCALE) && cols_tuned) {

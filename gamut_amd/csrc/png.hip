@@ -536,7 +536,7 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
     static_assert(!(AL && RGBA), "the alpha-inserting walk has 12-byte pieces: its ring is not a byte line of the row");
     constexpr int IB = RGBA ? 12 : 16;            // stream bytes per piece
     constexpr int PW = 4;                         // dwords per piece
-    constexpr int PITCH = AL ? ROW_PITCH + 32 : ROW_PITCH;      // AL: guards; 288 keeps the per-lane ds_read_b128 pattern conflict-free ((T + lane) mod 16)
+    constexpr int PITCH = (AL || !LN) ? ROW_PITCH + 32 : ROW_PITCH;      // AL: guards; 288 keeps the per-lane ds_read_b128 pattern conflict-free ((T + lane) mod 16); !LN: room behind slot 15 (dwp below)
     constexpr int GUARD = AL ? 16 : 0;
     typedef u32 u32x4 __attribute__((ext_vector_type(4)));
     struct __attribute__((packed, aligned(1))) AnyVec { u32x4 v; };
@@ -578,8 +578,16 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
         return wb_lines ? 0 : (int)(((reinterpret_cast<uintptr_t>(cdst) + (uintptr_t)((int64_t)(8 * k) * a.d_pitch)) >> 4) & 7u);
     };
     const int ph63 = wb_lines ? 0 : (int)(((reinterpret_cast<uintptr_t>(D) + (uintptr_t)((int64_t)(band * 64 + 63) * a.d_pitch)) >> 4) & 7u);
+    // Rows that are not even 16-byte aligned (a width that is no multiple of 4 pixels: 1366 x 4 = 5464 bytes): every 16-byte piece of the row straddles two
+    // 16-byte units of memory, and a store of it is two partial ones -- 2048 x 1366x768 took 6.5 ms where 1024x1024 takes 3.5 (profiles/r06_geometry_sweep_after.txt).
+    // The write-back's units are then the 16-byte CHUNKS OF MEMORY: chunk m of a row whose first byte lies d dwords into its unit holds the row's dwords
+    // 4 m - d .. 4 m - d + 3 -- the last d dwords of piece m - 1 and the first 4 - d of piece m, one LDS read at a dword offset (slot 15's chunk ends in a copy of
+    // slot 0 behind it) -- and leaves as one aligned store; a row's first and last chunk go out dword by dword.  dwp: wave-uniform, only in the !LN kernels.
+    const bool dwp = !LN && !wb_lines && ((reinterpret_cast<uintptr_t>(D) | (uintptr_t)(uint64_t)a.d_pitch) & 15u) != 0;
+    auto dw_of = [&](int k) -> int { return dwp ? (int)(((reinterpret_cast<uintptr_t>(cdst) + (uintptr_t)((int64_t)(8 * k) * a.d_pitch)) >> 2) & 3u) : 0; };
+    const int d63 = dwp ? (int)(((reinterpret_cast<uintptr_t>(D) + (uintptr_t)((int64_t)(band * 64 + 63) * a.d_pitch)) >> 2) & 3u) : 0;
     // pieces of the band's last row that the write-backs up to tile T0s have stored (what a hand-off may publish once they have arrived)
-    auto stored_through = [&](int T0s) -> int { return (((T0s - 63 + ph63) & ~7) - ph63) + 8; };
+    auto stored_through = [&](int T0s) -> int { return (((T0s - 63 + ph63) & ~7) - ph63) + 8 - (d63 ? 1 : 0); };
     uint8_t* my_ring = ring + lane * PITCH + GUARD;
     uint8_t* co_ring = ring + crow * PITCH + GUARD;                     // + k * 8 * PITCH + slot * 16
 
@@ -822,10 +830,23 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
             #pragma unroll
             for (int k = 0; k < 8; ++k) wbv[k] = *reinterpret_cast<const uint4*>(rd[k & 1] + k * 8 * PITCH);
         } else {
+            if constexpr (!LN) {
+                if (dwp) {                                            // slot 0 once more behind slot 15 (the write-back's own copy: the trips know nothing of it)
+                    #pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (cslot == 0) *reinterpret_cast<uint4*>(co_ring + k * 8 * PITCH + RING * 16) = *reinterpret_cast<const uint4*>(co_ring + k * 8 * PITCH);
+                }
+            }
             #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int ph = wb_phase(k);
                 const int it = ((((int)T0 - (8 * k + crow) + ph) & ~7) - ph) + cslot;
+                if constexpr (!LN) {
+                    const int d = dw_of(k);                            // chunk `it`: from dword 4 - d of piece it - 1 (d > 0), else piece it
+                    const u32 off = ((u32)(it - (d ? 1 : 0)) & (RING - 1)) * 16u + (d ? 16u - 4u * (u32)d : 0u);
+                    const AnyVec q = *reinterpret_cast<const AnyVec*>(co_ring + k * 8 * PITCH + off);
+                    wbv[k] = make_uint4(q.v.x, q.v.y, q.v.z, q.v.w);
+                } else
                 wbv[k] = *reinterpret_cast<const uint4*>(co_ring + k * 8 * PITCH + ((u32)it & (RING - 1)) * 16);
             }
         }
@@ -854,6 +875,31 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
                 const int ph = wb_phase(k);
                 const int it = ((((int)T0 - (8 * k + crow) + ph) & ~7) - ph) + cslot;          // piece 8g - ph + cslot, g = floor((T0 - row + ph) / 8)
                 const uint4 v = wbv[k];
+                if constexpr (!LN) {
+                    if (dwp) {
+                        const int d = dw_of(k), q0 = 4 * it - d;                             // the chunk's first dword of the row (in front of the row for it = 0)
+                        const int lo = q0 < 0 ? -q0 : 0, hi = min(4, 4 * (int)wb_iters - q0);  // its dwords [lo, hi) belong to the row's written-back part
+                        if ((u32)(8 * k + crow) < rows_left && hi > lo) {
+                            uint8_t* const rowp = cdst + (int64_t)(8 * k) * a.d_pitch;
+                            const bool last_row = Q && k == 7 && crow == 7;
+                            if (lo == 0 && hi == 4) {
+                                u32x4* dst = reinterpret_cast<u32x4*>(rowp + (int64_t)q0 * 4);
+                                if (last_row) __builtin_amdgcn_raw_buffer_store_b128(u32x4{ v.x, v.y, v.z, v.w }, rs_last, (u32)q0 * 4u, 0, 16);   // row 63: sc1
+                                else if (PNG_NT_STORES) __builtin_nontemporal_store(u32x4{ v.x, v.y, v.z, v.w }, dst);
+                                else *dst = u32x4{ v.x, v.y, v.z, v.w };
+                            } else {
+                                const u32 w4[4] = { v.x, v.y, v.z, v.w };
+                                #pragma unroll
+                                for (int i = 0; i < 4; ++i)
+                                    if (i >= lo && i < hi) {
+                                        if (last_row) __builtin_amdgcn_raw_buffer_store_b32(w4[i], rs_last, (u32)(q0 + i) * 4u, 0, 16);
+                                        else *reinterpret_cast<u32*>(rowp + (int64_t)(q0 + i) * 4) = w4[i];
+                                    }
+                            }
+                        }
+                        continue;
+                    }
+                }
                 if ((u32)(8 * k + crow) < rows_left && it >= 0 && it < (int)wb_iters) {
                     u32x4* dst = reinterpret_cast<u32x4*>(cdst + (int64_t)(8 * k) * a.d_pitch + (int64_t)it * 16);
                     if (Q && k == 7 && crow == 7) __builtin_amdgcn_raw_buffer_store_b128(u32x4{ v.x, v.y, v.z, v.w }, rs_last, (u32)it * 16u, 0, 16);   // row 63: sc1
@@ -865,7 +911,7 @@ __device__ __forceinline__ void defilter_band_ring(const DefilterArgs& a, const 
     };
 
     // trips must reach iteration niter-1 of lane 63; write-back must reach row 63's last group (tile T0 = 8 g_last + 64)
-    const u32 T_end = max(niter + 63, 8 * ((wb_iters - 1) >> 3) + 65) + (wb_lines ? 0u : 8u);       // (line groups end up to 7 pieces later than row groups)
+    const u32 T_end = max(niter + 63, 8 * ((wb_iters - 1) >> 3) + 65) + (wb_lines ? 0u : dwp ? 16u : 8u);       // (line groups end up to 7 pieces later than row groups; chunks of memory one more)
     u32 my_slot = (u32)(-lane) & (RING - 1);                                               // slot of iteration T - lane, kept incrementally
     u32 polled = 0;                                 // Q: the progress word as loaded one tile ago (a round trip to L2 / the fabric that nobody waits for)
     for (u32 T0 = 0; T0 < T_end; T0 += TT) {
@@ -1028,7 +1074,7 @@ template <int FB, int W, int MINW, bool RGBA = false, bool AL = false, bool LN =
 __global__ __launch_bounds__(W * 64, MINW) void k_png_defilter_ring(DefilterArgs a)
 {
     __shared__ u32 prog[W];
-    __shared__ __attribute__((aligned(16))) uint8_t tiles[W][64 * (AL ? ROW_PITCH + 32 : ROW_PITCH)];
+    __shared__ __attribute__((aligned(16))) uint8_t tiles[W][64 * ((AL || !LN) ? ROW_PITCH + 32 : ROW_PITCH)];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int img; const uint8_t* raw; uint8_t* D;
     if (!take_segment(a, img, raw, D)) return;
@@ -1060,7 +1106,7 @@ __global__ __launch_bounds__(W * 64, MINW) void k_png_defilter_ring(DefilterArgs
 template <int FB, int W, int MINW, bool RGBA = false, bool AL = false, bool LN = true>
 __global__ __launch_bounds__(W * 64, MINW) void k_png_defilter_queue(DefilterArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t tiles[W][64 * (AL ? ROW_PITCH + 32 : ROW_PITCH) + 128];      // a wave's ring + 128 bytes of the row above its band
+    __shared__ __attribute__((aligned(16))) uint8_t tiles[W][64 * ((AL || !LN) ? ROW_PITCH + 32 : ROW_PITCH) + 128];      // a wave's ring + 128 bytes of the row above its band
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     constexpr u32 IB = RGBA ? 12 : 16;
     const u32 niter = (a.wb + IB - 1) / IB;
@@ -1587,10 +1633,15 @@ int png_defilter_launch(const uint8_t* raw, int64_t raw_stride, uint32_t raw_len
     // 384 x 4K 365 k / 595 k, 512 x 4K 616 k / 643 k (random filters 512 k / 529 k): the queue from 1024 units on.
     // line-aligned loads of the stream (defilter_band_ring<..., AL>): rows of at least two lines; GAMUT_HIP_PNG_ALIGNED=0 / 1 forces either
     const char* al_env = getenv("GAMUT_HIP_PNG_ALIGNED");
-    const bool aligned = !rgba_fused && wb >= 16 && (al_env && *al_env ? atoi(al_env) != 0 : wb >= 256);
+    const bool aligned_asked = !rgba_fused && wb >= 16 && (al_env && *al_env ? atoi(al_env) != 0 : wb >= 256);
     // every row of every image on a 128-byte line of its own?  (the kernels' LN: write-back groups = the rows' own pieces; otherwise the
     // kernels that look at every image's rows and write back by the lines of memory -- defilter_band_ring, wb_lines)
     const bool lines = ((uintptr_t)a.D % 128) == 0 && (a.d_pitch % 128) == 0 && (a.d_offs ? offs_line_aligned : (count == 1 || a.d_stride % 128 == 0));
+    // rows on 16-byte units at least?  If not, the write-back reads its chunks across two pieces of the ring (dwp) -- the oldest of them 16 pieces behind the
+    // newest the ring holds, and the line-aligned drop has by then put the head of the next raw piece into the slot that piece ends in (a chunk of the stream
+    // straddles the tile's last piece).  Such rows take the row-aligned loads, whose drops write whole slots only.
+    const bool rows16 = ((uintptr_t)a.D % 16) == 0 && (a.d_pitch % 16) == 0 && (a.d_offs ? offs_line_aligned : (count == 1 || a.d_stride % 16 == 0));
+    const bool aligned = aligned_asked && (lines || rows16);
     const char* queue_env = getenv("GAMUT_HIP_PNG_QUEUE");       // read per call: tests flip it
     const uint64_t units = (uint64_t)count * nbands;
     bool queue = wb >= 16 && (int64_t)a.d_pitch * 64 < (1ll << 31) && units < (1ull << 31) &&

@@ -126,6 +126,73 @@ template <int CTRL, int ROWMASK> __device__ __forceinline__ void qoi_scan_step(Q
     qoi_add_scan_step<CTRL, ROWMASK>(n);
 }
 
+// ---- the same functions WITHOUT composing them (round 6) ----------------------------------------------------------------------
+// qoi_scan_step composes (M, V, U) triples: per step three DPP moves, a bytewise add (five instructions: the part has no packed
+// byte add) and the mask logic, 14 vector instructions x 6 steps -- 83 of the ~175 a group of 64 ops costs, and a batch's time
+// is its instruction count.  But a group's functions have a simple shape: the colour bytes of op i are EITHER the deltas of ops
+// 0..i added to the pixel before the group (no RGB / RGBA / INDEX op up to i), OR the value the most recent such op j set (from
+// the stream, or from the index) plus the deltas of ops j+1..i.  Deltas add; so
+//   * P = inclusive prefix sums of the deltas, as PLAIN integer sums: R and B in the 16-bit halves of one register, G in another
+//     (64 values below 271 never carry out of a half; masked to bytes once, at the end) -- one v_add_u32_dpp per step and register;
+//   * jm = 1 + the lane of the most recent absolute op (0: none) -- a v_max_u32_dpp per step;
+//   * op i's value = A[jm] - P[jm] + P[i], A = the bytes an RGB / RGBA op carries (0 for INDEX: the index value is added when it
+//     is known): the lane's own P, and Q = A - P fetched from lane jm - 1 by ds_bpermute_b32 (the crossbar, no memory).
+// Four chains (with the run lengths') interleaved: a DPP read of a register written four instructions earlier needs no wait states.
+// 24 + ~20 vector instructions instead of 83 + 12.  Alpha only changes at RGBA and INDEX ops: groups without either (six in ten of
+// a photograph's) skip it, groups with INDEX ops only mark the lanes from the first one on, RGBA ops take a scan of their own.
+// The result is the same (M, V, U) the composition gives, bit for bit (U a subset of M, V's alpha 0 unless an RGBA op set it).
+#define GAMUT_QOI_SCAN4(CTRL) asm volatile("v_add_u32_dpp %0, %0, %0 " CTRL "\n\tv_add_u32_dpp %1, %1, %1 " CTRL "\n\tv_add_u32_dpp %2, %2, %2 " CTRL "\n\tv_max_u32_dpp %3, %3, %3 " CTRL \
+                                           : "+v"(pe), "+v"(po), "+v"(n), "+v"(jm))
+template <int CTRL, int ROWMASK> __device__ __forceinline__ void qoi_max_scan_step(uint32_t& v) { const uint32_t p = qoi_dpp<CTRL, ROWMASK>(v, 0u); v = p > v ? p : v; }
+// lane: 0..63; dE = R | B << 16 and dO = G: the deltas of a DIFF / LUMA op (0 for every other op); m_stream = all ones for an RGB / RGBA
+// op (bytes 1..4 of the op are v_abs); n: in = the op's run length, out = the inclusive prefix sum
+__device__ __forceinline__ QoiFn qoi_group_scan(int lane, uint32_t dE, uint32_t dO, uint32_t m_stream, bool is_index, bool is_rgba, uint32_t v_abs, uint32_t& n)
+{
+    uint32_t pe = dE, po = dO, jm = (m_stream != 0u || is_index) ? (uint32_t)lane + 1u : 0u;
+    asm volatile("s_nop 1");
+    GAMUT_QOI_SCAN4("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    GAMUT_QOI_SCAN4("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    GAMUT_QOI_SCAN4("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    GAMUT_QOI_SCAN4("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+    GAMUT_QOI_SCAN4("row_bcast:15 row_mask:0xa bank_mask:0xf");
+    GAMUT_QOI_SCAN4("row_bcast:31 row_mask:0xc bank_mask:0xf");
+    const uint32_t qE = (v_abs & m_stream & 0x00FF00FFu) - pe, qO = ((v_abs >> 8) & m_stream & 0xFFu) - po;
+    const int addr = (int)(jm << 2) - 4;
+    const bool none = jm == 0u;
+    uint32_t fE = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)qE), fO = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)qO);
+    fE = none ? 0u : fE; fO = none ? 0u : fO;
+    QoiFn f;
+    f.V = ((fE + pe) & 0x00FF00FFu) | ((fO + po) & 0xFFu) << 8;
+    f.M = none ? 0u : 0x00FFFFFFu;
+    f.U = 0u;
+    const uint64_t bal_idx = __ballot(is_index), bal_rgba = __ballot(is_rgba);
+    if (bal_idx | bal_rgba) {                                  // (wave-uniform)
+        const uint32_t src_is_index = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, is_index ? 0x00FFFFFF : 0);
+        f.U = none ? 0u : src_is_index;
+        if (bal_rgba == 0ull) {                                // INDEX ops only: from the first one on, alpha is an index value's
+            const bool behind = lane >= __builtin_ctzll(bal_idx);
+            f.M |= behind ? 0xFF000000u : 0u;
+            f.U |= behind ? 0xFF000000u : 0u;
+        } else {                                               // the most recent op that sets alpha: an RGBA op's own byte, or an index value's
+            uint32_t ja = (is_index || is_rgba) ? (uint32_t)lane + 1u : 0u;
+            qoi_max_scan_step<0x111, 0xF>(ja); qoi_max_scan_step<0x112, 0xF>(ja); qoi_max_scan_step<0x114, 0xF>(ja); qoi_max_scan_step<0x118, 0xF>(ja);
+            qoi_max_scan_step<0x142, 0xA>(ja); qoi_max_scan_step<0x143, 0xC>(ja);
+            const uint32_t wa = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ja << 2) - 4, is_index ? 1 : (int)(v_abs & 0xFF000000u));
+            if (ja != 0u) {
+                f.M |= 0xFF000000u;
+                if (wa & 1u) f.U |= 0xFF000000u; else f.V |= wa & 0xFF000000u;
+            }
+        }
+    }
+    return f;
+}
+
+#ifndef QOI_GROUP_SCAN            // 1: qoi_group_scan, 0: the composition scan (qoi_scan_step) -- the A/B knob (tools/variant.sh)
+#define QOI_GROUP_SCAN 1
+#endif
+#ifndef QOI_PREFETCH              // 1: the one-wave kernel fetches a group's op offsets / bytes / table entries a group ahead.  Measured and left off:
+#define QOI_PREFETCH 0            // 2730 streams 32.9 -> 33.6 ms (profiles/r06_qoi_prefetch_ab.txt) -- the waits it removes were covered by the SIMD's other waves
+#endif
 #ifndef QOI_DIRECT_RGBA           // tuning knob (tools/variant.sh): 0 = RGBA outputs through the LDS pixel buffer like RGB ones
 #define QOI_DIRECT_RGBA 1
 #endif
@@ -188,7 +255,13 @@ __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* it
         const uint32_t v_luma = ((vg - 8u) & 255u) | (vg & 255u) << 8 | ((vg - 8u) & 255u) << 16;
         uint2 e;
         e.x = none ? 0u : top == 1u ? v_diff : top == 2u ? v_luma : 0u;
-        e.y = (none ? 0u : (top == 3u && !is_rgb && !is_rgba) ? 1u + (b1 & 63u) : 1u) | ((!none && top == 0u) ? 1u << 8 : 0u) | ((!none && top == 2u) ? 0x000F0000u : 0u) |
+#if QOI_GROUP_SCAN
+        const uint32_t g_delta = (e.x >> 8) & 255u;           // the deltas as qoi_group_scan sums them: R | B << 16 in x, G in bits 20-27 of y
+        e.x &= 0x00FF00FFu;
+#else
+        const uint32_t g_delta = 0u;
+#endif
+        e.y = g_delta << 20 | (none ? 0u : (top == 3u && !is_rgb && !is_rgba) ? 1u + (b1 & 63u) : 1u) | ((!none && top == 0u) ? 1u << 8 : 0u) | ((!none && top == 2u) ? 0x000F0000u : 0u) |
               ((!none && (is_rgb || is_rgba)) ? 1u << 9 : 0u) | ((!none && is_rgb) ? 1u << 10 : 0u) | ((!none && (is_rgba || top == 0u)) ? 1u << 11 : 0u);
         lut[b1] = e;
     }
@@ -332,31 +405,45 @@ __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* it
         QPROF(1);
         // ---- B. the ops as functions of the previous pixel, 64 at a time (W = 4: groups dealt to the waves, results in LDS)
         struct Group { QoiFn f; uint32_t run_incl, npx, b1; bool is_index; };
-        auto parse_group = [&](uint32_t g) -> Group {
-            const bool active = g + lane < nops;
-            uint32_t lo = 0, hi = 0;
-            if (active) {
-                const uint32_t o = ops[g + lane];
-                const uint32_t w0 = win[o >> 2], w1 = win[(o >> 2) + 1], w2 = win[(o >> 2) + 2];
-                const uint32_t sh = 8 * (o & 3);
-                lo = __builtin_amdgcn_alignbit(w1, w0, sh); hi = __builtin_amdgcn_alignbit(w2, w1, sh);
-            }
+        // The three look-ups a group starts with depend on each other (op offset -> its bytes in the window -> the table entry of its first
+        // byte): three LDS round trips before the first useful instruction; rocprofv3 has the waves of the one-wave kernel waiting on a counter
+        // a third of their time (SQ_WAIT_ANY 14.5 G of SQ_WAVE_CYCLES 42 G, profiles/r06_qoi_group_scan_pmc.txt).  They are stages so that the
+        // one-wave loop CAN fetch each a group ahead of its use (QOI_PREFETCH) -- which turned out slower: with three waves on the SIMDs that
+        // decide the launch's time, one wave's wait is another's issue slot, and the staging costs eight instructions per group.
+        struct Raw { uint32_t lo, hi; uint2 e; };
+        auto fetch_op = [&](uint32_t g) -> uint32_t { return g + lane < nops ? ops[g + lane] : 0u; };         // (lanes past the last op: offset 0, entry 256)
+        struct Win3 { uint32_t w0, w1, w2, sh; };
+        auto fetch_win = [&](uint32_t o) -> Win3 { return Win3{ win[o >> 2], win[(o >> 2) + 1], win[(o >> 2) + 2], 8 * (o & 3) }; };
+        auto fetch_lut = [&](uint32_t g, const Win3& w) -> Raw {
+            Raw r;
+            r.lo = __builtin_amdgcn_alignbit(w.w1, w.w0, w.sh); r.hi = __builtin_amdgcn_alignbit(w.w2, w.w1, w.sh);
+            r.e = lut[g + lane < nops ? (r.lo & 255u) : 256u];
+            return r;
+        };
+        auto scan_group = [&](const Raw& r) -> Group {
+            const uint32_t lo = r.lo, hi = r.hi;
             const uint32_t b1 = lo & 255u, b2 = (lo >> 8) & 255u;
-            const uint2 e = lut[active ? b1 : 256u];
+            const uint2 e = r.e;
             const uint32_t v_abs = __builtin_amdgcn_alignbit(hi, lo, 8);                          // stream bytes 1..4
             const uint32_t nib = ((b2 >> 4) | (b2 & 15u) << 16) & (e.y >> 16 | (e.y & 0x000F0000u));  // LUMA: dr - dg + 8, db - dg + 8 (:528-530); else 0
             Group G;
             G.is_index = (e.y >> 8 & 1u) != 0;
             G.b1 = b1;
+            G.npx = e.y & 0xFFu;
+            G.run_incl = G.npx;
+#if QOI_GROUP_SCAN
+            // (the nibbles go on top of the halves of x: at most 255 + 15, the halves do not meet)
+            G.f = qoi_group_scan(lane, e.x + nib, (e.y >> 20) & 255u, (uint32_t)((int32_t)(e.y << 22) >> 31), G.is_index, (e.y & 0xA00u) == 0xA00u, v_abs, G.run_incl);
+#else
             G.f.M = (uint32_t)((int32_t)(e.y << 20) >> 31) | ((uint32_t)((int32_t)(e.y << 21) >> 31) & 0x00FFFFFFu);      // bit 11: all, bit 10: colour
             G.f.U = (uint32_t)((int32_t)(e.y << 23) >> 31);                                                             // bit 8: an INDEX op
             G.f.V = (e.y >> 9 & 1u) ? (v_abs & G.f.M) : qoi_add_bytes(e.x, nib);                  // RGB / RGBA: the bytes the op sets
-            G.npx = e.y & 0xFFu;
-            G.run_incl = G.npx;
             qoi_scan_step<0x111, 0xF>(G.f, G.run_incl); qoi_scan_step<0x112, 0xF>(G.f, G.run_incl); qoi_scan_step<0x114, 0xF>(G.f, G.run_incl);
             qoi_scan_step<0x118, 0xF>(G.f, G.run_incl); qoi_scan_step<0x142, 0xA>(G.f, G.run_incl); qoi_scan_step<0x143, 0xC>(G.f, G.run_incl);
+#endif
             return G;
         };
+        auto parse_group = [&](uint32_t g) -> Group { return scan_group(fetch_lut(g, fetch_win(fetch_op(g)))); };
         // ---- C. pixels and table of one group (in stream order: wave 0) -> the group's pixels, its first pixel's index
         auto resolve_group = [&](uint32_t g, const Group& G, uint32_t& first_px) -> uint32_t {
             const uint32_t cnt = nops - g < 64u ? nops - g : 64u;
@@ -418,6 +505,22 @@ __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* it
             if (fill >= 256u) flush_rows();
         };
         if constexpr (kQoiWaves == 1) {
+#if QOI_PREFETCH
+            Raw cur = fetch_lut(0, fetch_win(fetch_op(0)));
+            uint32_t o_next = fetch_op(64);
+            for (uint32_t g = 0; g < nops && produced < npx_total; g += 64) {
+                const Win3 w_next = fetch_win(o_next);                 // (its offsets were asked for a group ago)
+                const Group G = scan_group(cur);
+                QPROF(3);
+                cur = fetch_lut(g + 64, w_next);
+                uint32_t first_px;
+                const uint32_t x = resolve_group(g, G, first_px);
+                QPROF(5);
+                o_next = fetch_op(g + 128);
+                emit_buffered(G, x, first_px);
+                QPROF(6);
+            }
+#else
             for (uint32_t g = 0; g < nops && produced < npx_total; g += 64) {
                 const Group G = parse_group(g);
                 QPROF(3);
@@ -427,6 +530,7 @@ __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* it
                 emit_buffered(G, x, first_px);
                 QPROF(6);
             }
+#endif
         } else {
             // (a full group's run lengths can sum to 64 * 62 = 3968 < 4096: the 12-bit prefix never wraps)
             for (uint32_t g = (uint32_t)wave * 64u; g < nops; g += kQoiT) {
@@ -692,8 +796,15 @@ __global__ __launch_bounds__(320) void k_qoi_pipe(const QoiItem* items, int n_it
             f.V = !active ? 0u : is_rgb ? (v_abs & 0x00FFFFFFu) : is_rgba ? v_abs : top == 1u ? v_diff : top == 2u ? v_luma : 0u;
             const uint32_t npx = !active ? 0u : is_run ? 1u + (b1 & 63u) : 1u;
             uint32_t run_incl = npx;
+#if QOI_GROUP_SCAN
+            {
+                const uint32_t dv = !active ? 0u : top == 1u ? v_diff : top == 2u ? v_luma : 0u;
+                f = qoi_group_scan(lane, dv & 0x00FF00FFu, (dv >> 8) & 255u, (active && (is_rgb || is_rgba)) ? 0xFFFFFFFFu : 0u, is_index, active && is_rgba, v_abs, run_incl);
+            }
+#else
             qoi_scan_step<0x111, 0xF>(f, run_incl); qoi_scan_step<0x112, 0xF>(f, run_incl); qoi_scan_step<0x114, 0xF>(f, run_incl);
             qoi_scan_step<0x118, 0xF>(f, run_incl); qoi_scan_step<0x142, 0xA>(f, run_incl); qoi_scan_step<0x143, 0xC>(f, run_incl);
+#endif
             const uint32_t mc = f.M == 0u ? 0u : f.M == 0x00FFFFFFu ? 1u : 2u, uc = f.U == 0u ? 0u : f.U == 0xFF000000u ? 1u : 2u;
             B.prep[g + lane] = make_uint2(f.V, run_incl | npx << 12 | b1 << 18 | (is_index ? 1u << 26 : 0u) | mc << 27 | uc << 29);
         }

@@ -164,12 +164,26 @@ def _arbitrary_streams():
         if k % 4 == 1:
             body[rng.random(nbytes) < 0.6] &= 0x3F                                    # many INDEX ops
         out.append(b"qoif" + w.to_bytes(4, "big") + h.to_bytes(4, "big") + bytes([ch, 0]) + body.tobytes() + bytes(7) + b"\x01")
+    # RGB, RGBA and INDEX ops close together among DIFF / LUMA ops: every combination of "the most recent op that set the colour" and "the most
+    # recent op that set alpha" inside one group of 64 ops (qoi_group_scan's three alpha cases), in densities from a few per group to most ops
+    for k in range(16):
+        w, h, ch = int(rng.integers(40, 500)), int(rng.integers(8, 50)), 3 + (k & 1)
+        nbytes = int(rng.integers(w * h, 3 * w * h))
+        body = rng.integers(0x40, 0xC0, nbytes, dtype=np.uint8)                         # DIFF and LUMA ops (a LUMA op's second byte: any of these)
+        p_rgb, p_rgba, p_idx = [(0.02, 0.0, 0.01), (0.0, 0.02, 0.02), (0.05, 0.05, 0.05), (0.3, 0.2, 0.2)][k // 4]
+        r = rng.random(nbytes)
+        body[r < p_rgb] = 0xFE
+        body[(r >= p_rgb) & (r < p_rgb + p_rgba)] = 0xFF
+        body[(r >= p_rgb + p_rgba) & (r < p_rgb + p_rgba + p_idx)] &= 0x3F
+        if k % 4 == 3:
+            body[rng.random(nbytes) < 0.03] = 0xC0 | int(rng.integers(0, 62))
+        out.append(b"qoif" + w.to_bytes(4, "big") + h.to_bytes(4, "big") + bytes([ch, 0]) + body.tobytes() + bytes(7) + b"\x01")
     return out
 
 
 def test_qoi_arbitrary_streams(hip, small_batch_kernel):
     files = _arbitrary_streams()
-    for reps in (1, 40):                                       # 24 streams: the small-batch kernels; 960: one wave per stream
+    for reps in (1, 24):                                       # 40 streams: the small-batch kernels; 960: one wave per stream
         blobs = files * reps
         n = len(blobs)
         if reps > 1 and small_batch_kernel == "phases":

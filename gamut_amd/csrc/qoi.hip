@@ -339,7 +339,9 @@ __global__ __launch_bounds__(kQoiWaves * 64) void k_qoi_decode(const QoiItem* it
                 const uint32_t sh = sh5tab[b];
                 const uint32_t cur = w & 31u;
                 rec[i / 6] |= cur << (5 * (i % 6));
-                w = (w >> 5) | (cur << sh);
+                // (one v_lshl_or_b32; left to itself the compiler computes the next `cur` from the two halves in parallel -- a shorter chain, a
+                //  fourth instruction per byte)
+                { const uint32_t ws = w >> 5; asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(w) : "v"(cur), "v"(sh), "v"(ws)); }
             }
             #pragma unroll
             for (int e = 0; e < 5; ++e) {                     // entry e's chain is pending in exactly one slot k (its first start at or behind the lane's last byte): bit 5 k + e

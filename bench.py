@@ -446,7 +446,7 @@ def main():
         sdt = O.PT_DTYPE[st]
         # BASELINE.json configs[3] is a batch of 256 layers: 412 GB for rgba16 -> rgbaf32, more than one GPU holds.  The layers
         # are converted in chunks: R resident layers (<= 128 GB of source + destination), a step = ceil(B / R) launches over them.
-        R = max(1, min(B, int(128e9 // (npx * (O.PT_SIZE[st] + O.PT_SIZE[dt_])))))
+        R = max(1, min(B, int(float(os.environ.get("GAMUT_BENCH_CONVERT_GB", "128")) * 1e9 // (npx * (O.PT_SIZE[st] + O.PT_SIZE[dt_])))))
         if sdt == np.float32:
             src = torch.rand((R, npx * O.PT_CHANNELS[st]), device=dev, generator=g, dtype=torch.float32)
         elif sdt == np.uint16:
@@ -467,14 +467,14 @@ def main():
                                                                   w, h, min(R, B - c), stream))
 
         def check():
-            """whole layers against the oracle: the first, the middle and the last resident layer (the last one the step's final launch
-            converted), every row of each, in bands of 128 rows on the host threads"""
+            """whole layers against the oracle: the first, the middle and the last resident layer and the last one the step's final launch
+            converted, every row of each, in bands of 128 rows on the host threads"""
             from concurrent.futures import ThreadPoolExecutor
             step()
             torch.cuda.synchronize()
             rows = 128
             last = (B - 1) % R if B % R else R - 1                     # a layer the step's last launch converted
-            layers = sorted({0, R // 2, last})
+            layers = sorted({0, R // 2, last, R - 1})                  # (R - 1: the library splits more layers than 32 bits index into several launches -- the last of them)
 
             def one(job):
                 layer, r0 = job

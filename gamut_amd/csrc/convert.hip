@@ -449,6 +449,21 @@ int launch_pair(ConvArgs a, int width, int height, int layers, hipStream_t strea
     int64_t w = width; int rows = height * layers; int h = height;
     const bool gapless = a.srcPitch == (int64_t)width * PT<S>::size && a.dstPitch == (int64_t)width * PT<D>::size &&
                          (layers == 1 || (a.srcLayer == a.srcPitch * height && a.dstLayer == a.dstPitch * height));
+    // More gapless layers than one launch can index with 32 bits (158 layers of 8192 x 8192 rgba8 -> rgba16 are 5.3 G units): as one launch they take the
+    // rows-and-layers form, whose unit index needs a 64-bit division per unit -- measured 5-7 % on an HBM-bound kernel (256 layers in chunks of 158: 0.71-0.74 of
+    // peak, in chunks of 79: 0.77-0.78; profiles/r06_convert_chunk_size.txt).  So such a batch goes as several launches of as many whole layers as fit.
+    if (gapless && layers > 1 && (int64_t)width * rows / G >= 0xFFFFFFF0LL) {
+        const int64_t per_layer = (int64_t)width * height / G + 1;
+        const int per = (int)std::max<int64_t>(1, 0xFFFFFFF0LL / per_layer - 1);
+        if (per < layers) {
+            for (int l0 = 0; l0 < layers; l0 += per) {
+                ConvArgs b = a;
+                b.src = a.src + (int64_t)l0 * a.srcLayer; b.dst = a.dst + (int64_t)l0 * a.dstLayer;
+                if (const int rc = launch_pair<S, D>(b, width, height, std::min(per, layers - l0), stream)) return rc;
+            }
+            return GAMUT_HIP_OK;
+        }
+    }
     if (gapless && (int64_t)width * rows / G < 0xFFFFFFF0LL) { w = (int64_t)width * rows; rows = 1; h = 1; }
     a.rows = (u32)rows; a.height = (u32)h;
     const bool vec_ok = aligned(a.src, a.srcPitch, a.srcLayer, rows, rows > h ? 2 : 1, vec_bytes(SB)) &&

@@ -211,3 +211,43 @@ def test_full_size_round_trip_properties(hip):
     assert np.array_equal(e.get(), ramp)
     for buf in (a, b, c, d, e):
         buf.free()
+
+
+def test_more_gapless_layers_than_one_launch_indexes(hip):
+    """257 gapless layers of 4096 x 4096 l8 <-> rgbaf32 are 4.31 G units -- more than a launch indexes with 32 bits, so the library converts them as
+    several launches of whole layers (launch_pair, convert.hip).  Rows of the first layer, of the layers either side of the cut and of the last layer
+    against the oracle, both directions; 77 GB of HBM."""
+    from gamut_amd import _capi
+    L = hip
+    w = h = 4096
+    layers = 257
+    npx = w * h
+    assert npx * layers >= 0xFFFFFFF0
+    rng = np.random.default_rng(77)
+    base = rng.integers(0, 256, npx, dtype=np.uint8)
+    src = L.gamut_hip_device_malloc(npx * layers); mid = L.gamut_hip_device_malloc(npx * layers * 16); back = L.gamut_hip_device_malloc(npx * layers)
+    assert src and mid and back
+    try:
+        for k in range(layers):
+            layer = base ^ np.uint8(k & 255)
+            _capi.check(L.gamut_hip_memcpy_h2d(src + k * npx, layer.ctypes.data, npx, None))
+            _capi.check(L.gamut_hip_stream_synchronize(None))          # (the host array is reused)
+        _capi.check(L.gamut_hip_scanlines_convert_device(PT["l8"], src, w, w * h, PT["rgbaf32"], mid, w * 16, w * h * 16, w, h, layers, None))
+        _capi.check(L.gamut_hip_scanlines_convert_device(PT["rgbaf32"], mid, w * 16, w * h * 16, PT["l8"], back, w, w * h, w, h, layers, None))
+        _capi.check(L.gamut_hip_stream_synchronize(None))
+        per = 0xFFFFFFF0 // (npx + 1) - 1                                # layers per launch (G = 1 for this pair)
+        assert 1 <= per < layers
+        rows = 8
+        for k in sorted({0, per - 1, per, layers - 1}):
+            for r0 in (0, h // 2 + 5, h - rows):
+                a = (base ^ np.uint8(k & 255))[r0 * w:(r0 + rows) * w]
+                f = np.empty(rows * w * 16, np.uint8); b = np.empty(rows * w, np.uint8)
+                _capi.check(L.gamut_hip_memcpy_d2h(f.ctypes.data, mid + (k * npx + r0 * w) * 16, f.size, None))
+                _capi.check(L.gamut_hip_memcpy_d2h(b.ctypes.data, back + k * npx + r0 * w, b.size, None))
+                _capi.check(L.gamut_hip_stream_synchronize(None))
+                exp_f = O.scanlines_convert(PT["l8"], a, PT["rgbaf32"], w, rows)
+                assert np.array_equal(f, exp_f), (k, r0)
+                assert np.array_equal(b, O.scanlines_convert(PT["rgbaf32"], exp_f, PT["l8"], w, rows)), (k, r0)
+    finally:
+        for p in (src, mid, back):
+            L.gamut_hip_device_free(p)

@@ -213,13 +213,14 @@ def test_full_size_round_trip_properties(hip):
         buf.free()
 
 
-def test_more_gapless_layers_than_one_launch_indexes(hip):
+@pytest.mark.parametrize("w,h", [(4096, 4096), (4099, 4093)])
+def test_more_gapless_layers_than_one_launch_indexes(hip, w, h):
     """257 gapless layers of 4096 x 4096 l8 <-> rgbaf32 are 4.31 G units -- more than a launch indexes with 32 bits, so the library converts them as
     several launches of whole layers (launch_pair, convert.hip).  Rows of the first layer, of the layers either side of the cut and of the last layer
-    against the oracle, both directions; 77 GB of HBM."""
+    against the oracle, both directions; 77 GB of HBM.  4099 x 4093: layers of an odd number of bytes -- the later launches start at addresses that are
+    no multiple of 16 (the byte-wise kernel) and every launch has a tail of its own."""
     from gamut_amd import _capi
     L = hip
-    w = h = 4096
     layers = 257
     npx = w * h
     assert npx * layers >= 0xFFFFFFF0

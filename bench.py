@@ -14,6 +14,9 @@ Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on t
 stream; `cpu_baseline` is the CPU oracle (a scalar C restatement of the reference's loops,
 oracle/) timed on this box's host cores over a bounded sample of the same coefficients.
 Other kernels of the path: --workload convert:<src>:<dst> | png | mixed (configs[4]: JPEG / PNG / QOI)  (same JSON shape).
+Measurement knobs (environment): GAMUT_BENCH_CONVERT_GB (resident chunk of the convert workloads, default 128), GAMUT_BENCH_STEP_MS (every
+timed step on stderr), GAMUT_BENCH_BACKEND=gloo (the optional gather without RCCL), GAMUT_BENCH_NOCHECK (experiments with deliberately
+wrong kernels only: the line says so in config.parity_check).
 """
 import argparse
 import ctypes as C
